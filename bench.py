@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the TT-LSTM / TT-GRU hot path on MI355X (contract: see the task brief).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward pass (`no_grad`) of the workload's module over one synthetic batch
+[B, T, in] that is already resident in HBM.  Workload at every N: BASELINE.json configs[1]
+("cfg2": TT-LSTM in=1 H=256 ncores=3 ttrank=8, seq_len=784, batch=64 PER GPU, fp32) — batch-sharded,
+no data-path collective in the forward (weak scaling).  `value` = whole-job timesteps/s =
+N * T / t_step, t_step = max over ranks of the mean step time.
+
+Extra objects on the JSON line:
+  roofline      compute roofline of the dominant kernel (ttrnn_rnn_forward): algorithmic FLOP per
+                launch (691 712 FLOP per sample-timestep for cfg2) / the kernel's
+                mean duration measured with events on its launch stream; peak = 157.3 TFLOP/s fp32.
+  cpu_baseline  the oracle's op-for-op torch-CPU restatement of the reference path ("port") timed
+                on this host's cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tensorized-rnn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: kind, in, H, layers, ncores, rank, B (per GPU), T, dtype, FLOP per sample-timestep
+    "cfg2": dict(kind="ttlstm", inp=1, H=256, L=1, d=3, r=8, B=64, T=784, dtype="f32", flop=691712,
+                 desc="TT-LSTM in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=64/GPU fp32 (BASELINE.json configs[1])"),
+    "cfg3": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=256, T=784, dtype="bf16", flop=519360,
+                 desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=256/GPU bf16 storage (configs[2])"),
+    "cfg4": dict(kind="ttlstm", inp=40, H=256, L=3, d=3, r=16, B=512, T=160, dtype="f32", flop=12416768,
+                 desc="3-layer TT-LSTM in=40 H=256 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (configs[3] per-GPU batch)"),
+    "cfg1": dict(kind="ttlstm", inp=1, H=128, L=1, d=2, r=4, B=32, T=784, dtype="f32", flop=71552,
+                 desc="TT-LSTM in=1 H=128 ncores=2 ttrank=4 seq_len=784 batch=32 fp32 (configs[0] shapes)"),
+}
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0
+
+
+class EventTimer(object):
+    """Records (start, end) event pairs on the current stream around named kernel launches."""
+
+    def __init__(self):
+        self.pairs = {}
+        self._open = {}
+        self.enabled = False
+
+    def start(self, name):
+        if self.enabled:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._open[name] = ev
+
+    def stop(self, name):
+        if self.enabled:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.pairs.setdefault(name, []).append((self._open.pop(name), ev))
+
+    def mean_ms(self, name):
+        p = self.pairs.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else None
+
+    def count(self, name):
+        return len(self.pairs.get(name, []))
+
+
+def build_model(w, device):
+    from tensorized_rnn.gru import TTGRU
+    from tensorized_rnn.tt_lstm import TTLSTM
+    torch.manual_seed(1111)
+    cls = TTLSTM if w["kind"] == "ttlstm" else TTGRU
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = cls(w["inp"], w["H"], w["L"], device, n_cores=w["d"], tt_rank=w["r"])
+    if w["dtype"] == "bf16":
+        m = m.to(torch.bfloat16)
+    return m.eval()
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """Times the oracle (op-for-op torch-CPU restatement of the reference path) on the host."""
+    from oracle import ttrnn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1111)
+    from tensorized_rnn.rnn_utils import tt_shape
+    G = 4 if w["kind"] == "ttlstm" else 3
+    layers = []
+    for l in range(w["L"]):
+        i = w["inp"] if l == 0 else w["H"]
+        s_in = tt_shape(i, w["H"], w["d"], G)
+        s_hid = tt_shape(w["H"], w["H"], w["d"], G)
+        layers.append((O.random_tt(s_in[0], s_in[1], w["r"], g), O.random_tt(s_hid[0], s_hid[1], w["r"], g)))
+    # bounded sample: the full batch, a T-slice sized so one run is ~2-4 s on a typical host
+    T = min(w["T"], 784 if w["L"] == 1 else 16)
+    x = torch.rand(w["B"], T, w["inp"], generator=g)
+    fwd = O.lstm_forward if w["kind"] == "ttlstm" else O.gru_forward
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        fwd(layers, x[:, :min(T, 8)])       # warm-up
+        while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 9):
+            t0 = time.perf_counter()
+            fwd(layers, x)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > 3 * budget_s:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": T / med, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ttrnn_oracle.py (torch-CPU, op-for-op restatement of the reference loop), "
+                      "batch {} x {} of {} timesteps, fp32, no_grad, median of {} runs, {} threads".format(
+                          w["B"], T, w["T"], len(times), cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node {} for --gpus {}".format(
+                args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libttrnn has no CPU path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    w = WORKLOADS[args.workload]
+    from ttrnn_hip import functional as F
+    model = build_model(w, device)
+    torch.manual_seed(1111 + rank)
+    x = torch.rand(w["B"], w["T"], w["inp"], device=device)
+    if w["dtype"] == "bf16":
+        x = x.to(torch.bfloat16)
+
+    timer = EventTimer()
+    F.KERNEL_TIMER = timer
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    kern_ms = timer.mean_ms("ttrnn_rnn_forward")
+    launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    t_step = elapsed / args.steps
+
+    if rank == 0:
+        flop_per_launch = float(w["flop"]) * w["B"] * w["T"] / launches_per_step
+        peak = PEAK_FP32_TFLOPS if w["dtype"] == "f32" else PEAK_BF16_TFLOPS
+        achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
+        line = {
+            "metric": "timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}".format(
+                w["B"], "TT-LSTM" if w["kind"] == "ttlstm" else "TT-GRU", w["H"], w["d"], w["r"]),
+            "value": world * w["T"] / t_step,
+            "unit": "timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": w["dtype"], "data": "synthetic",
+            "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
+                       "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
+                       "mode": "forward (no_grad), inputs resident in HBM"},
+            "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "ttrnn_rnn_forward", "kernel_ms": kern_ms,
+                         "flop_per_launch": flop_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * ttrnn.h — C ABI of libttrnn.so: tensor-train LSTM / GRU hot path for AMD MI355X (gfx950).
+ *
+ * The reference (onucharles/tensorized-rnn) has no FFI / operator registry: its boundary for this
+ * path is the Python nn.Module API of `tensorized_rnn` + `t3nsor`.  Every entry point below names
+ * the reference code (file:line under the reference repo) whose arithmetic it replaces; the host
+ * side in `tensorized-rnn_amd/` re-creates that module API on top of these calls (INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C types only; all tensor arguments are raw DEVICE pointers owned by the caller;
+ *   - every launch goes to the caller's stream (`void* stream` is a hipStream_t, NULL = default);
+ *   - no allocation, no synchronisation, no host<->device copy inside any call except the
+ *     documented ttrnn_*_workspace queries (pure host arithmetic) — graph-capture safe;
+ *   - return value: TTRNN_OK (0) or a negative ttrnn_status; nothing is launched on error;
+ *   - batch-first contiguous layouts: x[B][T][in], out[B][T][H], h/c[B][H]  (lstm.py:117, gru.py:118);
+ *   - storage dtype `dtype` applies to x / out / h0 / c0 / hT / cT / bias / cores; packed cores,
+ *     recurrent state, gate arithmetic and accumulation are always fp32.
+ *
+ * TT-matrix convention (t3nsor/ops.py:54-93, t3nsor/layers.py:121-127):
+ *   y[n][o] = sum G_0[0,i_0,j_0,a_1] * G_1[a_1,i_1,j_1,a_2] ... G_{d-1}[a_{d-1},i_{d-1},j_{d-1},0] * x[n][i] + bias[o]
+ *   o = ((i_0*I_1+i_1)*I_2+i_2)...,  i = ((j_0*J_1+j_1)*J_2+j_2)...   (index 0 most significant)
+ *   core k is the reference's Parameter `weight_t.tt_cores[k]`: logical shape (R_k, I_k, J_k, R_{k+1}),
+ *   arbitrary element strides (the reference stores it as a transposed view, tensor_train.py:104-114).
+ */
+#ifndef TTRNN_H_
+#define TTRNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTRNN_ABI_VERSION 1
+#define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
+
+typedef enum ttrnn_status {
+  TTRNN_OK = 0,
+  TTRNN_ERR_BAD_DESC = -1,     /* inconsistent modes / ranks / sizes                          */
+  TTRNN_ERR_NULL = -2,         /* a required pointer is NULL                                  */
+  TTRNN_ERR_UNSUPPORTED = -3,  /* legal but not implemented (dtype / d / size combination)    */
+  TTRNN_ERR_WORKSPACE = -4,    /* workspace smaller than ttrnn_*_workspace() reported          */
+  TTRNN_ERR_LAUNCH = -5        /* HIP refused the launch (hipGetLastError != hipSuccess)      */
+} ttrnn_status;
+
+typedef enum ttrnn_dtype { TTRNN_F32 = 0, TTRNN_BF16 = 1 } ttrnn_dtype;
+typedef enum ttrnn_cell { TTRNN_LSTM = 0, TTRNN_GRU = 1 } ttrnn_cell;
+
+/* One TT-matrix = the weight of one TTLinear (t3nsor/layers.py:83-127). */
+typedef struct ttrnn_ttm {
+  int32_t d;                          /* number of cores                                      */
+  int32_t in_modes[TTRNN_MAX_D];      /* J_k, prod = in features                              */
+  int32_t out_modes[TTRNN_MAX_D];     /* I_k, prod = out features                             */
+  int32_t ranks[TTRNN_MAX_D + 1];     /* R_0 .. R_d, R_0 = R_d = 1                            */
+} ttrnn_ttm;
+
+/* One recurrent layer (one TTLSTMCell / TTGRUCell unrolled over the sequence):
+ * tensorized_rnn/lstm.py:23-41,101-135; gru.py:25-50,104-136; tt_lstm.py:16-40; gru.py:148-172. */
+typedef struct ttrnn_rnn_desc {
+  int32_t cell;          /* ttrnn_cell: LSTM gate order i,f,g,o (lstm.py:26-29); GRU r,z,n (gru.py:38-44) */
+  int32_t dtype;         /* ttrnn_dtype of x/out/state tensors                                 */
+  int32_t batch;         /* B                                                                  */
+  int32_t seq_len;       /* T (1 = single cell step, LSTMCell.forward / GRUCell.forward)       */
+  int32_t input_size;    /* in  = prod(in_w.in_modes)                                          */
+  int32_t hidden_size;   /* H   ; prod(out_modes) = n_gates*H (4 LSTM, 3 GRU)                  */
+  int32_t has_bias_in;   /* TTLSTMCell/TTGRUCell put a bias on BOTH TTLinears (tt_lstm.py:26,39) */
+  int32_t has_bias_hid;
+  ttrnn_ttm in_w;        /* cell.input_weights                                                 */
+  ttrnn_ttm hid_w;       /* cell.hidden_weights                                                */
+} ttrnn_rnn_desc;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int ttrnn_abi_version(void);
+const char* ttrnn_status_string(int status);
+/* 1 when a usable HIP device is visible to this process, else 0 (never launches). */
+int ttrnn_device_available(void);
+
+/* ---- weights: strided reference Parameters <-> packed fp32 cores ----------------------------
+ * Packed layout (fp32): for k = 0..d-1   W_k [K_k = J_k*R_{k+1}][M_k = I_k*R_k],
+ *   W_k[(j*R_{k+1}+b)*M_k + (i*R_k+a)] = G_k[a,i,j,b]          (the stage-k GEMM operand),
+ * followed by the same matrices transposed, Wt_k[M_k][K_k] (operand of the backward chain).
+ * ttrnn_packed_elems() = 2 * sum_k K_k*M_k floats. */
+int64_t ttrnn_packed_elems(const ttrnn_ttm* w);
+/* replaces: t3nsor/ops.py:47-51 `transpose` + tensor_train.py:104-114 (parameter views) as seen by
+ * tt_dense_matmul.  cores[k]: device pointer of core k; strides[4*k..4*k+3]: its element strides
+ * for the logical (R_k, I_k, J_k, R_{k+1}) axes. */
+int ttrnn_pack_cores(const ttrnn_ttm* w, const void* const* cores, const int64_t* strides,
+                     int dtype, float* packed, void* stream);
+/* inverse for gradients: scatters the first half (W_k grads) of `packed_grad` into strided
+ * per-core gradient tensors of the given dtype (overwrite, not accumulate). */
+int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* const* core_grads,
+                            const int64_t* strides, int dtype, void* stream);
+
+/* ---- TTLinear ------------------------------------------------------------------------------
+ * replaces: TTLinear.forward t3nsor/layers.py:121-127 -> tt_dense_matmul t3nsor/ops.py:54-93
+ * y[n_rows][out] = TT(packed) x[n_rows][in] (+ bias).  bias may be NULL. */
+size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows);
+int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const float* packed,
+                           const void* bias, const void* x, void* y,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* autograd of the above (reference: torch autograd through ops.py:81-90).  Any of dx /
+ * d_packed / d_bias may be NULL to skip it.  d_packed (fp32, ttrnn_packed_elems floats, first
+ * half used) and d_bias (fp32[out]) are ACCUMULATED into: zero them first.
+ * `dtype` is the storage type of x and dx; `dy_dtype` that of dy (the recurrent backward hands
+ * fp32 gate gradients to bf16 layers). */
+int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                            const void* x, const void* dy, void* dx, float* d_packed,
+                            float* d_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- recurrent layer -----------------------------------------------------------------------
+ * replaces: the Python time loop LSTM.forward lstm.py:123-133 / GRU.forward gru.py:124-134 for ONE
+ * layer (layer l+1 consumes layer l's `out`; same result as the reference's step-major loop),
+ * LSTMCell.forward lstm.py:23-32 / GRUCell.forward gru.py:25-44 and both TTLinear chains.
+ *   x[B][T][in], h0/c0[B][H] (NULL = zeros, lstm.py:88-91) -> out[B][T][H], hT/cT[B][H] (may be NULL).
+ *   c0 / cT are ignored for GRU.
+ *   reserve: NULL for inference; else fp32 [B][T][5H] (LSTM: i,f,g,o,c_t) or [B][T][4H]
+ *            (GRU: r,z,n, hidden_part_n) saved for ttrnn_rnn_backward. */
+size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc);
+size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc);
+int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,
+                      const float* packed_in, const void* bias_in,
+                      const float* packed_hid, const void* bias_hid,
+                      void* out, void* hT, void* cT, float* reserve,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Reverse-time part of BPTT (reference: torch autograd through lstm.py:123-133 / gru.py:124-134).
+ *   d_out[B][T][H], d_hT/d_cT[B][H] (any may be NULL = zeros)
+ *   -> d_gates_in[B][T][G*H], d_gates_hid[B][T][G*H] (fp32: gradients w.r.t. the outputs of the
+ *      input / hidden TTLinear; for LSTM both are identical and d_gates_hid may alias d_gates_in
+ *      or be NULL), d_h0/d_c0[B][H] (may be NULL).
+ * The weight / input gradients then follow from ttrnn_ttlinear_backward over the B*T rows
+ * (x rows for in_w; h_{t-1} rows for hid_w). */
+size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc);
+int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
+                       const float* packed_hid, const float* reserve,
+                       const void* d_out, const void* d_hT, const void* d_cT,
+                       float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTRNN_H_ */

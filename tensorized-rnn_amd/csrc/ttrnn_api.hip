@@ -1,0 +1,158 @@
+// ttrnn_api.hip — the extern "C" surface of libttrnn.so (see include/ttrnn.h for the contract).
+// Validates descriptors, picks a kernel (shape-specialised MFMA kernel when one exists for the
+// descriptor, else the any-shape kernel), and launches on the caller's stream.
+#include <hip/hip_runtime.h>
+#include "ttrnn.h"
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+
+using namespace ttrnn;
+
+extern "C" {
+
+int ttrnn_abi_version(void) { return TTRNN_ABI_VERSION; }
+
+const char* ttrnn_status_string(int status) {
+  switch (status) {
+    case TTRNN_OK: return "ok";
+    case TTRNN_ERR_BAD_DESC: return "bad descriptor (modes / ranks / sizes inconsistent)";
+    case TTRNN_ERR_NULL: return "required pointer is NULL";
+    case TTRNN_ERR_UNSUPPORTED: return "unsupported configuration";
+    case TTRNN_ERR_WORKSPACE: return "workspace too small";
+    case TTRNN_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown status";
+  }
+}
+
+int ttrnn_device_available(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n > 0 ? 1 : 0;
+}
+
+int64_t ttrnn_packed_elems(const ttrnn_ttm* w) {
+  TtShape s;
+  if (tt_shape_init(&s, w) != TTRNN_OK) return -1;
+  return 2 * (int64_t)s.wtotal;
+}
+
+int ttrnn_pack_cores(const ttrnn_ttm* w, const void* const* cores, const int64_t* strides, int dtype, float* packed,
+                     void* stream) {
+  TtShape s;
+  int st = tt_shape_init(&s, w);
+  if (st != TTRNN_OK) return st;
+  if (!cores || !strides || !packed) return TTRNN_ERR_NULL;
+  for (int k = 0; k < s.d; ++k) if (!cores[k]) return TTRNN_ERR_NULL;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  return launch_pack(s, cores, strides, dtype, packed, (hipStream_t)stream);
+}
+
+int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* const* core_grads,
+                            const int64_t* strides, int dtype, void* stream) {
+  TtShape s;
+  int st = tt_shape_init(&s, w);
+  if (st != TTRNN_OK) return st;
+  if (!packed_grad || !core_grads || !strides) return TTRNN_ERR_NULL;
+  for (int k = 0; k < s.d; ++k) if (!core_grads[k]) return TTRNN_ERR_NULL;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  return launch_unpack(s, packed_grad, core_grads, strides, dtype, (hipStream_t)stream);
+}
+
+// ---- TTLinear ---------------------------------------------------------------------------------
+size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
+  TtShape s;
+  if (tt_shape_init(&s, w) != TTRNN_OK || n_rows < 0) return 0;
+  const LinPlan f = plan_ttlinear_fwd(s, n_rows);
+  const LinPlan b = plan_ttlinear_bwd(s, n_rows);
+  return f.ws_bytes > b.ws_bytes ? f.ws_bytes : b.ws_bytes;
+}
+
+int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const float* packed, const void* bias,
+                           const void* x, void* y, void* workspace, size_t workspace_bytes, void* stream) {
+  TtShape s;
+  int st = tt_shape_init(&s, w);
+  if (st != TTRNN_OK) return st;
+  if (n_rows < 0) return TTRNN_ERR_BAD_DESC;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  if (n_rows == 0) return TTRNN_OK;
+  if (!packed || !x || !y) return TTRNN_ERR_NULL;
+  const LinPlan p = plan_ttlinear_fwd(s, n_rows);
+  if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+  return launch_ttlinear_fwd(s, p, dtype, n_rows, packed, bias, x, y, workspace, (hipStream_t)stream);
+}
+
+int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed, const void* x,
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  TtShape s;
+  int st = tt_shape_init(&s, w);
+  if (st != TTRNN_OK) return st;
+  if (n_rows < 0) return TTRNN_ERR_BAD_DESC;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  if (dy_dtype != TTRNN_F32 && dy_dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  if (n_rows == 0) return TTRNN_OK;
+  if (!packed || !dy) return TTRNN_ERR_NULL;
+  if (d_packed && !x) return TTRNN_ERR_NULL;
+  if (!dx && !d_packed && !d_bias) return TTRNN_OK;
+  const LinPlan p = plan_ttlinear_bwd(s, n_rows);
+  if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+  return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
+                             (hipStream_t)stream);
+}
+
+// ---- recurrent layer ----------------------------------------------------------------------------
+size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return plan_rnn_generic(rs, false).ws_bytes;
+}
+
+size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return plan_rnn_generic(rs, true).ws_bytes;
+}
+
+size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  const size_t per = rs.cell == TTRNN_LSTM ? (size_t)5 * rs.H : (size_t)4 * rs.H;
+  return (size_t)rs.B * rs.T * per * sizeof(float);
+}
+
+int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,
+                      const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
+                      void* out, void* hT, void* cT, float* reserve, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  RnnShape rs;
+  int st = rnn_shape_init(&rs, desc);
+  if (st != TTRNN_OK) return st;
+  if (rs.B == 0) return TTRNN_OK;
+  if (!packed_in || !packed_hid) return TTRNN_ERR_NULL;
+  if (rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
+  if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
+  if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
+  const RnnPlan p = plan_rnn_generic(rs, false);
+  if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+  return launch_rnn_fwd_generic(rs, p, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,
+                                reserve, workspace, (hipStream_t)stream);
+}
+
+int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
+                       const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                       const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  RnnShape rs;
+  int st = rnn_shape_init(&rs, desc);
+  if (st != TTRNN_OK) return st;
+  if (rs.B == 0) return TTRNN_OK;
+  if (!packed_hid) return TTRNN_ERR_NULL;
+  if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
+  if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
+  const RnnPlan p = plan_rnn_generic(rs, true);
+  if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+  return launch_rnn_bwd_generic(rs, p, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
+                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

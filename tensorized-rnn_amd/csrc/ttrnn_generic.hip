@@ -1,0 +1,414 @@
+// ttrnn_generic.hip — any-shape kernels of libttrnn (gfx950) and their launchers.
+//
+// These kernels accept every descriptor include/ttrnn.h allows (any d <= 6, any modes / ranks,
+// LSTM / GRU, f32 / bf16 storage): one workgroup per batch tile, sequence loop on device, state and
+// chain intermediates in LDS (spilling to a global workspace only when a sample's intermediates do
+// not fit 160 KB), fp32 VALU FMAs with 4-row register tiles.  The shape-specialised MFMA kernels in
+// ttrnn_fast.hip take over for the configurations they are built for (see ttrnn_api.hip).
+#include <hip/hip_runtime.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+
+namespace ttrnn {
+
+struct DevExec {
+  template <class F>
+  __device__ __forceinline__ void par(F f) {
+    f((int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
+  }
+};
+
+struct AddPlain {
+  __device__ __forceinline__ void operator()(float* p, float v) const { *p += v; }
+};
+struct AddAtomic {
+  __device__ __forceinline__ void operator()(float* p, float v) const { atomicAdd(p, v); }
+};
+
+static constexpr int NT_RNN = 512;
+static constexpr int NT_LIN = 256;
+
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int n) {
+  for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = src[e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack / unpack
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+  const void* core[TTRNN_MAX_D];
+  void* grad[TTRNN_MAX_D];
+  int64_t st[TTRNN_MAX_D * 4];
+};
+
+template <typename T>
+__global__ void k_pack_cores(TtShape s, PackArgs a, float* packed) {
+  const int k = blockIdx.y;
+  pack_core_elems<T>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, s, k,
+                     (const T*)a.core[k], &a.st[4 * k], packed);
+}
+
+template <typename T>
+__global__ void k_unpack_core_grads(TtShape s, PackArgs a, const float* packed_grad) {
+  const int k = blockIdx.y;
+  unpack_core_grad_elems<T>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, s, k,
+                            packed_grad, (T*)a.grad[k], &a.st[4 * k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TTLinear forward / backward over n_rows rows (grid-stride over tiles of nb rows)
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool W_LDS, bool BUF_GLOBAL>
+__global__ void __launch_bounds__(NT_LIN) k_ttlinear_fwd(TtShape s, int64_t n_rows, int nb, int bs,
+                                                         const float* packed, const T* bias, const T* x, T* y,
+                                                         float* ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  DevExec ex;
+  float* p = smem;
+  float *bufA, *bufB;
+  if (BUF_GLOBAL) {
+    bufA = ws + (size_t)blockIdx.x * 2 * nb * bs; bufB = bufA + (size_t)nb * bs;
+  } else {
+    bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs;
+  }
+  const float* W = packed;
+  if (W_LDS) { copy_to_lds(p, packed, s.wtotal); W = p; __syncthreads(); }
+  const int64_t ntiles = (n_rows + nb - 1) / nb;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * nb;
+    const int n = (int)tmin<int64_t>(nb, n_rows - n0);
+    ttlinear_fwd_tile<DevExec, T>(ex, s, W, bias, x, y, n0, n, bufA, bufB, bs);
+  }
+}
+
+template <typename T, typename TDY, bool BUF_GLOBAL, bool ACC_LDS>
+__global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_rows, int nb, int bs, int ss,
+                                                         const float* packed, const T* x, const TDY* dy, T* dx,
+                                                         float* d_packed, float* d_bias, float* ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  DevExec ex;
+  float* p = smem;
+  float *bufA, *bufB, *stash;
+  if (BUF_GLOBAL) {
+    float* base = ws + (size_t)blockIdx.x * ((size_t)2 * nb * bs + (size_t)nb * ss);
+    bufA = base; bufB = bufA + (size_t)nb * bs; stash = bufB + (size_t)nb * bs;
+  } else {
+    bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs; stash = p; p += (size_t)nb * ss;
+  }
+  float* dWacc = d_packed;
+  float* dbacc = d_bias;
+  if (ACC_LDS) {
+    if (d_packed) { dWacc = p; p += s.wtotal; for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) dWacc[e] = 0.f; }
+    if (d_bias) { dbacc = p; p += s.out_size; for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) dbacc[e] = 0.f; }
+    __syncthreads();
+  }
+  const float* W = packed;
+  const float* Wt = packed + s.wtotal;
+  const int64_t ntiles = (n_rows + nb - 1) / nb;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * nb;
+    const int n = (int)tmin<int64_t>(nb, n_rows - n0);
+    if (ACC_LDS)
+      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddPlain());
+    else
+      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddAtomic());
+  }
+  if (ACC_LDS) {
+    __syncthreads();
+    if (d_packed) for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) { const float v = dWacc[e]; if (v != 0.f) atomicAdd(d_packed + e, v); }
+    if (d_bias) for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) { const float v = dbacc[e]; if (v != 0.f) atomicAdd(d_bias + e, v); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// recurrent layer: persistent over the sequence, one workgroup per tile of nb samples
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool W_LDS, bool BUF_GLOBAL>
+__global__ void __launch_bounds__(NT_RNN) k_rnn_fwd(RnnShape rs, int nb, const T* x, const T* h0, const T* c0,
+                                                    const float* packed_in, const T* bias_in,
+                                                    const float* packed_hid, const T* bias_hid,
+                                                    T* out, T* hT, T* cT, float* reserve, float* ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  DevExec ex;
+  const int b0 = blockIdx.x * nb;
+  const int n = tmin(nb, rs.B - b0);
+  const int H = rs.H, GH = rs.G * rs.H, bs = rs.bs;
+  float* p = smem;
+  float* hbuf = p; p += (size_t)nb * H;
+  float* cbuf = p; p += (size_t)nb * H;
+  float* gin = p; p += (size_t)nb * GH;
+  float *bufA, *bufB;
+  if (BUF_GLOBAL) {
+    bufA = ws + (size_t)blockIdx.x * 2 * nb * bs; bufB = bufA + (size_t)nb * bs;
+  } else {
+    bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs;
+  }
+  const float* Win = packed_in;
+  const float* Whid = packed_hid;
+  if (W_LDS) {
+    copy_to_lds(p, packed_in, rs.in_s.wtotal); Win = p; p += rs.in_s.wtotal;
+    copy_to_lds(p, packed_hid, rs.hid_s.wtotal); Whid = p; p += rs.hid_s.wtotal;
+    __syncthreads();
+  }
+  rnn_fwd_body<DevExec, T>(ex, rs, b0, n, x, h0, c0, Win, rs.has_bias_in ? bias_in : nullptr, Whid,
+                           rs.has_bias_hid ? bias_hid : nullptr, out, hT, cT, reserve, bufA, bufB, hbuf, cbuf, gin);
+}
+
+template <typename T, bool W_LDS, bool BUF_GLOBAL>
+__global__ void __launch_bounds__(NT_RNN) k_rnn_bwd(RnnShape rs, int nb, const T* out, const T* h0, const T* c0,
+                                                    const float* packed_hid, const float* reserve,
+                                                    const T* d_out, const T* d_hT, const T* d_cT,
+                                                    float* dg_in, float* dg_hid, T* d_h0, T* d_c0, float* ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  DevExec ex;
+  const int b0 = blockIdx.x * nb;
+  const int n = tmin(nb, rs.B - b0);
+  const int H = rs.H, bs = rs.bs;
+  float* p = smem;
+  float* dh = p; p += (size_t)nb * H;
+  float* dc = p; p += (size_t)nb * H;
+  float* dhd = p; p += (size_t)nb * H;
+  float *bufA, *bufB;
+  if (BUF_GLOBAL) {
+    bufA = ws + (size_t)blockIdx.x * 2 * nb * bs; bufB = bufA + (size_t)nb * bs;
+  } else {
+    bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs;
+  }
+  const float* Wt = packed_hid + rs.hid_s.wtotal;
+  if (W_LDS) { copy_to_lds(p, Wt, rs.hid_s.wtotal); Wt = p; __syncthreads(); }
+  rnn_bwd_body<DevExec, T>(ex, rs, b0, n, out, h0, c0, Wt, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0,
+                           bufA, bufB, dh, dc, dhd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <class K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_LIMIT) != hipSuccess)
+      return TTRNN_ERR_LAUNCH;
+  }
+  return TTRNN_OK;
+}
+
+static int check_launch() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }
+
+int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
+                hipStream_t stream) {
+  PackArgs a;
+  int maxn = 1;
+  for (int k = 0; k < s.d; ++k) {
+    a.core[k] = cores[k];
+    for (int q = 0; q < 4; ++q) a.st[4 * k + q] = strides[4 * k + q];
+    if (s.K[k] * s.M[k] > maxn) maxn = s.K[k] * s.M[k];
+  }
+  dim3 grid((maxn + 255) / 256, s.d);
+  if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_pack_cores<float>, grid, dim3(256), 0, stream, s, a, packed);
+  else hipLaunchKernelGGL(k_pack_cores<bf16_t>, grid, dim3(256), 0, stream, s, a, packed);
+  return check_launch();
+}
+
+int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
+                  hipStream_t stream) {
+  PackArgs a;
+  int maxn = 1;
+  for (int k = 0; k < s.d; ++k) {
+    a.grad[k] = grads[k];
+    for (int q = 0; q < 4; ++q) a.st[4 * k + q] = strides[4 * k + q];
+    if (s.K[k] * s.M[k] > maxn) maxn = s.K[k] * s.M[k];
+  }
+  dim3 grid((maxn + 255) / 256, s.d);
+  if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_unpack_core_grads<float>, grid, dim3(256), 0, stream, s, a, packed_grad);
+  else hipLaunchKernelGGL(k_unpack_core_grads<bf16_t>, grid, dim3(256), 0, stream, s, a, packed_grad);
+  return check_launch();
+}
+
+// ---- TTLinear plans ---------------------------------------------------------------------------
+LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows) {
+  LinPlan p{};
+  p.bs = (s.maxbuf + 3) & ~3;
+  int nb = (4096 + p.bs - 1) / p.bs;
+  if (nb < 1) nb = 1;
+  if (nb > 16) nb = 16;
+  if (n_rows < nb) nb = n_rows > 0 ? (int)n_rows : 1;
+  const size_t wbytes = (size_t)s.wtotal * 4;
+  // shrink the tile until the ping-pong buffers fit LDS; else spill them to global
+  while (nb > 1 && (size_t)2 * nb * p.bs * 4 > LDS_LIMIT) nb >>= 1;
+  p.nb = nb;
+  const size_t bufbytes = (size_t)2 * nb * p.bs * 4;
+  p.buf_global = bufbytes > LDS_LIMIT;
+  size_t lds = p.buf_global ? 0 : bufbytes;
+  p.w_lds = lds + wbytes <= LDS_LIMIT;
+  if (p.w_lds) lds += wbytes;
+  p.lds_bytes = lds;
+  const int64_t ntiles = (n_rows + nb - 1) / nb;
+  p.grid = (int)(ntiles < 1 ? 1 : (ntiles > 2048 ? 2048 : ntiles));
+  p.ws_bytes = p.buf_global ? (size_t)p.grid * bufbytes : 0;
+  return p;
+}
+
+LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
+  LinPlan p{};
+  p.bs = (s.maxbuf + 3) & ~3;
+  p.ss = stash_floats(s);
+  p.nb = 1;
+  const size_t per = ((size_t)2 * p.bs + p.ss) * 4;
+  const size_t acc = ((size_t)s.wtotal + s.out_size) * 4;
+  p.buf_global = per > LDS_LIMIT;
+  size_t lds = p.buf_global ? 0 : per;
+  if (!p.buf_global) {
+    // more rows per tile amortise the per-stage barriers when a sample is small
+    while (p.nb < 8 && (size_t)(p.nb * 2) * per + acc <= LDS_LIMIT / 2 && (int64_t)(p.nb * 2) <= n_rows &&
+           (size_t)(p.nb * 2) * p.bs < 8192)
+      p.nb *= 2;
+    lds = (size_t)p.nb * per;
+  }
+  p.acc_lds = lds + acc <= LDS_LIMIT;
+  if (p.acc_lds) lds += acc;
+  p.w_lds = false;
+  p.lds_bytes = lds;
+  const int64_t ntiles = (n_rows + p.nb - 1) / p.nb;
+  p.grid = (int)(ntiles < 1 ? 1 : (ntiles > 1024 ? 1024 : ntiles));
+  p.ws_bytes = p.buf_global ? (size_t)p.grid * p.nb * per : 0;
+  return p;
+}
+
+template <typename T>
+static int launch_lin_fwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, const float* packed, const void* bias,
+                            const void* x, void* y, void* ws, hipStream_t stream) {
+#define TT_LAUNCH(WL, BG)                                                                                          \
+  do {                                                                                                             \
+    auto kern = k_ttlinear_fwd<T, WL, BG>;                                                                         \
+    if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_LIN), p.lds_bytes, stream, s, n_rows, p.nb, p.bs, packed,       \
+                       (const T*)bias, (const T*)x, (T*)y, (float*)ws);                                            \
+  } while (0)
+  if (p.w_lds && !p.buf_global) TT_LAUNCH(true, false);
+  else if (!p.w_lds && !p.buf_global) TT_LAUNCH(false, false);
+  else if (p.w_lds && p.buf_global) TT_LAUNCH(true, true);
+  else TT_LAUNCH(false, true);
+#undef TT_LAUNCH
+  return check_launch();
+}
+
+int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n_rows, const float* packed,
+                        const void* bias, const void* x, void* y, void* ws, hipStream_t stream) {
+  if (n_rows == 0) return TTRNN_OK;
+  return dtype == TTRNN_F32 ? launch_lin_fwd_t<float>(s, p, n_rows, packed, bias, x, y, ws, stream)
+                            : launch_lin_fwd_t<bf16_t>(s, p, n_rows, packed, bias, x, y, ws, stream);
+}
+
+template <typename T, typename TDY>
+static int launch_lin_bwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, const float* packed, const void* x,
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+#define TT_LAUNCH(BG, AL)                                                                                          \
+  do {                                                                                                             \
+    auto kern = k_ttlinear_bwd<T, TDY, BG, AL>;                                                                         \
+    if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_LIN), p.lds_bytes, stream, s, n_rows, p.nb, p.bs, p.ss, packed, \
+                       (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws);                         \
+  } while (0)
+  if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, true);
+  else if (!p.buf_global && !p.acc_lds) TT_LAUNCH(false, false);
+  else if (p.buf_global && p.acc_lds) TT_LAUNCH(true, true);
+  else TT_LAUNCH(true, false);
+#undef TT_LAUNCH
+  return check_launch();
+}
+
+int launch_ttlinear_bwd(const TtShape& s, const LinPlan& p, int dtype, int dy_dtype, int64_t n_rows,
+                        const float* packed, const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
+                        void* ws, hipStream_t stream) {
+  if (n_rows == 0) return TTRNN_OK;
+  if (dtype == TTRNN_F32)
+    return dy_dtype == TTRNN_F32
+               ? launch_lin_bwd_t<float, float>(s, p, n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream)
+               : launch_lin_bwd_t<float, bf16_t>(s, p, n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  return dy_dtype == TTRNN_F32
+             ? launch_lin_bwd_t<bf16_t, float>(s, p, n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream)
+             : launch_lin_bwd_t<bf16_t, bf16_t>(s, p, n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+}
+
+// ---- recurrent plans --------------------------------------------------------------------------
+RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward) {
+  RnnPlan p{};
+  p.nb = 1;
+  const size_t state = backward ? (size_t)3 * rs.H * 4 : ((size_t)2 * rs.H + (size_t)rs.G * rs.H) * 4;
+  const size_t bufs = (size_t)2 * rs.bs * 4;
+  const size_t wbytes = backward ? (size_t)rs.hid_s.wtotal * 4 : ((size_t)rs.in_s.wtotal + rs.hid_s.wtotal) * 4;
+  p.buf_global = state + bufs > LDS_LIMIT;
+  size_t lds = state + (p.buf_global ? 0 : bufs);
+  p.w_lds = lds + wbytes <= LDS_LIMIT;
+  if (p.w_lds) lds += wbytes;
+  p.lds_bytes = lds;
+  p.grid = (rs.B + p.nb - 1) / p.nb;
+  if (p.grid < 1) p.grid = 1;
+  p.ws_bytes = p.buf_global ? (size_t)p.grid * p.nb * bufs : 0;
+  return p;
+}
+
+template <typename T>
+static int launch_rnn_fwd_t(const RnnShape& rs, const RnnPlan& p, const void* x, const void* h0, const void* c0,
+                            const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
+                            void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
+#define TT_LAUNCH(WL, BG)                                                                                          \
+  do {                                                                                                             \
+    auto kern = k_rnn_fwd<T, WL, BG>;                                                                              \
+    if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_RNN), p.lds_bytes, stream, rs, p.nb, (const T*)x, (const T*)h0, \
+                       (const T*)c0, packed_in, (const T*)bias_in, packed_hid, (const T*)bias_hid, (T*)out,        \
+                       (T*)hT, (T*)cT, reserve, (float*)ws);                                                       \
+  } while (0)
+  if (p.w_lds && !p.buf_global) TT_LAUNCH(true, false);
+  else if (!p.w_lds && !p.buf_global) TT_LAUNCH(false, false);
+  else if (p.w_lds && p.buf_global) TT_LAUNCH(true, true);
+  else TT_LAUNCH(false, true);
+#undef TT_LAUNCH
+  return check_launch();
+}
+
+int launch_rnn_fwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* x, const void* h0,
+                           const void* c0, const float* packed_in, const void* bias_in, const float* packed_hid,
+                           const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                           hipStream_t stream) {
+  return dtype == TTRNN_F32
+             ? launch_rnn_fwd_t<float>(rs, p, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream)
+             : launch_rnn_fwd_t<bf16_t>(rs, p, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+}
+
+template <typename T>
+static int launch_rnn_bwd_t(const RnnShape& rs, const RnnPlan& p, const void* out, const void* h0, const void* c0,
+                            const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                            const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                            hipStream_t stream) {
+#define TT_LAUNCH(WL, BG)                                                                                          \
+  do {                                                                                                             \
+    auto kern = k_rnn_bwd<T, WL, BG>;                                                                              \
+    if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_RNN), p.lds_bytes, stream, rs, p.nb, (const T*)out,             \
+                       (const T*)h0, (const T*)c0, packed_hid, reserve, (const T*)d_out, (const T*)d_hT,           \
+                       (const T*)d_cT, dg_in, dg_hid, (T*)d_h0, (T*)d_c0, (float*)ws);                             \
+  } while (0)
+  if (p.w_lds && !p.buf_global) TT_LAUNCH(true, false);
+  else if (!p.w_lds && !p.buf_global) TT_LAUNCH(false, false);
+  else if (p.w_lds && p.buf_global) TT_LAUNCH(true, true);
+  else TT_LAUNCH(false, true);
+#undef TT_LAUNCH
+  return check_launch();
+}
+
+int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* out, const void* h0,
+                           const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                           const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0,
+                           void* ws, hipStream_t stream) {
+  return dtype == TTRNN_F32
+             ? launch_rnn_bwd_t<float>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream)
+             : launch_rnn_bwd_t<bf16_t>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream);
+}
+
+}  // namespace ttrnn

@@ -1,0 +1,47 @@
+// ttrnn_launch.h — launch plans shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ttrnn_core.h"
+
+namespace ttrnn {
+
+struct LinPlan {
+  int nb;            // rows per tile
+  int bs;            // per-row stride of the ping-pong buffers (floats)
+  int ss;            // per-row stride of the stage-input stash (backward only)
+  int grid;
+  bool w_lds;        // packed cores staged in LDS
+  bool buf_global;   // chain intermediates in the global workspace (sample too large for LDS)
+  bool acc_lds;      // backward: weight/bias gradient accumulators in LDS
+  size_t lds_bytes, ws_bytes;
+};
+
+struct RnnPlan {
+  int nb, grid;
+  bool w_lds, buf_global;
+  size_t lds_bytes, ws_bytes;
+};
+
+LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows);
+LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
+RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
+
+int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
+                hipStream_t stream);
+int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
+                  hipStream_t stream);
+int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n_rows, const float* packed,
+                        const void* bias, const void* x, void* y, void* ws, hipStream_t stream);
+int launch_ttlinear_bwd(const TtShape& s, const LinPlan& p, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                        const void* x, const void* dy, void* dx, float* d_packed, float* d_bias, void* ws,
+                        hipStream_t stream);
+int launch_rnn_fwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* x, const void* h0,
+                           const void* c0, const float* packed_in, const void* bias_in, const float* packed_hid,
+                           const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                           hipStream_t stream);
+int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* out, const void* h0,
+                           const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                           const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0,
+                           void* ws, hipStream_t stream);
+
+}  // namespace ttrnn

@@ -1,0 +1,123 @@
+"""Shared machinery of the drop-in LSTM / GRU modules.
+
+The reference runs ``for step in range(seq_len): for layer in layers: cell(...)`` in Python
+(``tensorized_rnn/lstm.py:123-133``, ``gru.py:124-134``).  Here every layer is ONE call into
+libttrnn.so that keeps the sequence loop on the GPU (``ttrnn_rnn_forward``); layer l+1 consumes the
+full output sequence of layer l, which is the same computation re-ordered (layer l at step t only
+depends on layer l-1 at step t and on itself at step t-1).
+
+Dense (``nn.Linear``) cells ride the same kernels: a dense matrix is a TT-matrix with a single
+core ``(1, out, in, 1)``.
+
+Two situations fall back from the fused sequence call to stepping the cells one timestep at a
+time — still on the GPU through the same library, never on the CPU:
+  * ``log_grads=True``: the hooks of ``ActivGradLogger`` need per-step ``hy`` / ``cy`` tensors;
+  * ``is_naive=True`` cells (``TTLinearSet``: one TT-matrix per gate), whose per-gate TTLinear
+    kernels are combined with device-side pointwise ops.
+"""
+import torch
+from torch import nn
+
+
+def _lin_as_tt(linear):
+    """nn.Linear weight [out, in] viewed as the single core (1, out, in, 1) of a d=1 TT-matrix."""
+    w = linear.weight
+    return [w.view(1, w.shape[0], w.shape[1], 1)], linear.bias
+
+
+class FusedCellMixin(object):
+    """Adds `_operands()` / `_layer_spec()` to a cell that owns input_weights / hidden_weights."""
+    kind = None      # 'lstm' | 'gru'
+
+    def _operands(self):
+        """(cores_in, bias_in, cores_hid, bias_hid) or None when the cell cannot be expressed as two
+        TT matrices (naive per-gate variant)."""
+        ops = []
+        for w in (self.input_weights, self.hidden_weights):
+            if isinstance(w, nn.Linear):
+                ops.append(_lin_as_tt(w))
+            elif hasattr(w, 'weight_t'):
+                ops.append((list(w.weight_t.tt_cores), w.bias))
+            else:
+                return None
+        return ops[0][0], ops[0][1], ops[1][0], ops[1][1]
+
+    def _layer_spec(self):
+        spec = getattr(self, '_spec_cache', None)
+        if spec is None:
+            from ttrnn_hip.functional import RnnLayerSpec, TTSpec
+            cin, bin_, chid, bhid = self._operands()
+            spec = RnnLayerSpec(self.kind, self.input_size, self.hidden_size, TTSpec.from_cores(cin),
+                                TTSpec.from_cores(chid), bin_ is not None, bhid is not None)
+            # plain attribute (bypasses nn.Module bookkeeping); rebuilt lazily after unpickling
+            object.__setattr__(self, '_spec_cache', spec)
+        return spec
+
+    def _fused_step(self, x, hx, cx=None):
+        """One timestep through the fused kernel (T = 1)."""
+        from ttrnn_hip import functional as F
+        cin, bin_, chid, bhid = self._operands()
+        res = F.tt_rnn_layer(self._layer_spec(), x.unsqueeze(1), hx, cx, cin, bin_, chid, bhid)
+        return res[1:]          # (hy, cy) or (hy,)
+
+    def _run_sequence(self, seq, h0, c0=None):
+        from ttrnn_hip import functional as F
+        cin, bin_, chid, bhid = self._operands()
+        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid)
+
+
+class FusedRnnBase(nn.Module):
+    """Layer stack + state handling shared by LSTM and GRU."""
+    kind = None
+
+    def _build_layers(self, log_grads):
+        from .rnn_utils import ActivGradLogger
+        self._all_layers = []
+        for i in range(self.num_layers):
+            cell = self._create_first_layer_cell() if i == 0 else self._create_other_layer_cell()
+            setattr(self, 'cell{}'.format(i), cell)
+            self._all_layers.append(cell)
+        if log_grads:
+            for i, cell in enumerate(self._all_layers):
+                h_fwd, h_bwd = ActivGradLogger("hidden_{}".format(i)).create_hooks(0)
+                cell.register_forward_hook(h_fwd)
+                cell._h_backward_hook = h_bwd
+                if self.kind == 'lstm':
+                    c_fwd, c_bwd = ActivGradLogger("cell_{}".format(i)).create_hooks(1)
+                    cell.register_forward_hook(c_fwd)
+                    cell._c_backward_hook = c_bwd
+
+    def param_count(self):
+        from .rnn_utils import param_count as pc
+        return sum(pc(getattr(cell, attr)) for cell in self._all_layers
+                   for attr in ('input_weights', 'hidden_weights'))
+
+    def _needs_stepping(self):
+        return self.log_grads or any(cell._operands() is None for cell in self._all_layers)
+
+    def _forward_fused(self, input, h0, c0):
+        seq = input
+        last = None
+        for cell in self._all_layers:
+            last = cell._run_sequence(seq, h0, c0)
+            seq = last[0]
+        return last
+
+    def _forward_stepwise(self, input, h0, c0):
+        """Step-major loop with per-step cell calls (hooks fire per step, as in the reference)."""
+        lstm = self.kind == 'lstm'
+        state = [(h0, c0)] * self.num_layers
+        steps = []
+        x = None
+        for t in range(input.shape[1]):
+            x = input[:, t, :]
+            for i, cell in enumerate(self._all_layers):
+                h, c = state[i]
+                if lstm:
+                    x, c = cell(x, h, c)
+                else:
+                    x = cell(x, h)
+                state[i] = (x, c)
+            steps.append(x)
+        outputs = torch.stack(steps, dim=1)
+        return outputs, state[-1][0], state[-1][1]

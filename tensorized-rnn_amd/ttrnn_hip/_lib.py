@@ -1,0 +1,104 @@
+"""ctypes binding of libttrnn.so (the C ABI declared in include/ttrnn.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C tensorized-rnn_amd/csrc``.
+There is no CPU fallback: every compute entry point raises if the library is missing.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: libttrnn resolves libamdhip64.so.7 to torch's copy)
+
+TTRNN_MAX_D = 6
+TTRNN_F32, TTRNN_BF16 = 0, 1
+TTRNN_LSTM, TTRNN_GRU = 0, 1
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttrnn.so")
+
+
+class TtmDesc(ctypes.Structure):
+    """struct ttrnn_ttm"""
+    _fields_ = [("d", ctypes.c_int32),
+                ("in_modes", ctypes.c_int32 * TTRNN_MAX_D),
+                ("out_modes", ctypes.c_int32 * TTRNN_MAX_D),
+                ("ranks", ctypes.c_int32 * (TTRNN_MAX_D + 1))]
+
+
+class RnnDesc(ctypes.Structure):
+    """struct ttrnn_rnn_desc"""
+    _fields_ = [("cell", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("seq_len", ctypes.c_int32),
+                ("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
+                ("has_bias_in", ctypes.c_int32), ("has_bias_hid", ctypes.c_int32),
+                ("in_w", TtmDesc), ("hid_w", TtmDesc)]
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "ttrnn_abi_version": (ctypes.c_int, []),
+    "ttrnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "ttrnn_device_available": (ctypes.c_int, []),
+    "ttrnn_packed_elems": (ctypes.c_int64, [ctypes.POINTER(TtmDesc)]),
+    "ttrnn_pack_cores": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.c_int, _P, _P]),
+    "ttrnn_unpack_core_grads": (ctypes.c_int, [ctypes.POINTER(TtmDesc), _P, ctypes.POINTER(_P),
+                                               ctypes.POINTER(ctypes.c_int64), ctypes.c_int, _P]),
+    "ttrnn_ttlinear_workspace": (ctypes.c_size_t, [ctypes.POINTER(TtmDesc), ctypes.c_int64]),
+    "ttrnn_ttlinear_forward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P,
+                                              _P, ctypes.c_size_t, _P]),
+    "ttrnn_ttlinear_backward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P,
+                                               _P, _P, _P, ctypes.c_size_t, _P]),
+    "ttrnn_rnn_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 11 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 13 + [ctypes.c_size_t, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class TtrnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libttrnn.so, check the ABI version, bind signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TtrnnError(
+            "libttrnn.so not found at {} - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C tensorized-rnn_amd/csrc`). There is no CPU fallback for the TT-RNN hot path.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ttrnn_abi_version() != ABI_VERSION:
+        raise TtrnnError("libttrnn.so ABI {} != binding ABI {}".format(lib.ttrnn_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ttrnn_status_string(status).decode()
+        raise TtrnnError("{} failed: {} ({})".format(what, msg, status))
+
+
+def make_ttm(in_modes, out_modes, ranks):
+    d = len(in_modes)
+    if d > TTRNN_MAX_D or len(out_modes) != d or len(ranks) != d + 1:
+        raise ValueError("TT-matrix with d={} cores is not supported (max {})".format(d, TTRNN_MAX_D))
+    t = TtmDesc()
+    t.d = d
+    for k in range(d):
+        t.in_modes[k] = int(in_modes[k])
+        t.out_modes[k] = int(out_modes[k])
+    for k in range(d + 1):
+        t.ranks[k] = int(ranks[k])
+    return t

@@ -1,0 +1,324 @@
+"""Autograd-aware entry points that route t3nsor.TTLinear and the tensorized_rnn layers through
+libttrnn.so.  Every function here needs device tensors on an MI355X; there is no CPU path.
+
+Reference arithmetic replaced (file:line under the reference repo):
+  tt_linear      -> t3nsor/layers.py:121-127 + t3nsor/ops.py:54-93
+  tt_rnn_layer   -> tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 for one layer
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import TTRNN_BF16, TTRNN_F32, TTRNN_GRU, TTRNN_LSTM, RnnDesc, check, make_ttm
+
+_DT = {torch.float32: TTRNN_F32, torch.bfloat16: TTRNN_BF16}
+
+# Optional measurement hook (bench.py): an object with start(name) / stop(name) that records
+# events on the current stream around the dominant kernel launches.  None in normal use.
+KERNEL_TIMER = None
+
+
+class _timed(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_TIMER is not None:
+            KERNEL_TIMER.start(self.name)
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMER is not None:
+            KERNEL_TIMER.stop(self.name)
+        return False
+
+
+def _dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise _lib.TtrnnError("libttrnn supports float32 and bfloat16 storage, got {}".format(t.dtype))
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.TtrnnError(
+                "the TT-RNN hot path runs on the GPU (libttrnn.so, gfx950) only; got a {} tensor. "
+                "There is deliberately no CPU fallback.".format(t.device))
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+class TTSpec(object):
+    """Static description of one TT-matrix (modes, ranks) + helpers to pack its cores."""
+
+    def __init__(self, in_modes, out_modes, ranks):
+        self.in_modes = [int(v) for v in in_modes]
+        self.out_modes = [int(v) for v in out_modes]
+        self.ranks = [int(v) for v in ranks]
+        self.d = len(self.in_modes)
+        self.in_features = 1
+        self.out_features = 1
+        for j, i in zip(self.in_modes, self.out_modes):
+            self.in_features *= j
+            self.out_features *= i
+        self.desc = make_ttm(self.in_modes, self.out_modes, self.ranks)
+        self._packed_elems = None
+
+    @classmethod
+    def from_cores(cls, cores):
+        # core k has logical shape (R_k, I_k, J_k, R_{k+1})  (t3nsor/ops.py:47-51 after transpose)
+        return cls([c.shape[2] for c in cores], [c.shape[1] for c in cores],
+                   [c.shape[0] for c in cores] + [cores[-1].shape[3]])
+
+    @property
+    def packed_elems(self):
+        if self._packed_elems is None:
+            n = _lib.load().ttrnn_packed_elems(ctypes.byref(self.desc))
+            if n < 0:
+                raise _lib.TtrnnError("invalid TT-matrix description {}x{} ranks {}".format(
+                    self.in_modes, self.out_modes, self.ranks))
+            self._packed_elems = int(n)
+        return self._packed_elems
+
+    def _core_args(self, tensors):
+        d = self.d
+        ptrs = (ctypes.c_void_p * d)(*[t.data_ptr() for t in tensors])
+        strides = (ctypes.c_int64 * (4 * d))()
+        for k, t in enumerate(tensors):
+            exp = (self.ranks[k], self.out_modes[k], self.in_modes[k], self.ranks[k + 1])
+            if tuple(t.shape) != exp:
+                raise ValueError("core {} has shape {}, expected {}".format(k, tuple(t.shape), exp))
+            for q in range(4):
+                strides[4 * k + q] = t.stride(q)
+        return ptrs, strides
+
+    def pack(self, cores):
+        """strided parameter views -> packed fp32 [W_0..W_{d-1} | Wt_0..Wt_{d-1}] on the device."""
+        _require_device(*cores)
+        lib = _lib.load()
+        dt = _dtype_code(cores[0])
+        packed = torch.empty(self.packed_elems, dtype=torch.float32, device=cores[0].device)
+        ptrs, strides = self._core_args(cores)
+        check(lib.ttrnn_pack_cores(ctypes.byref(self.desc), ptrs, strides, dt, _ptr(packed), _stream(packed)),
+              "ttrnn_pack_cores")
+        return packed
+
+    def unpack_grads(self, packed_grad, like):
+        """packed fp32 gradient -> list of gradient tensors with the layout of `like` (the cores)."""
+        lib = _lib.load()
+        grads = [torch.empty_strided(c.shape, c.stride(), dtype=c.dtype, device=c.device) for c in like]
+        ptrs, strides = self._core_args(grads)
+        check(lib.ttrnn_unpack_core_grads(ctypes.byref(self.desc), _ptr(packed_grad), ptrs, strides,
+                                          _dtype_code(like[0]), _stream(packed_grad)), "ttrnn_unpack_core_grads")
+        return grads
+
+
+def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db):
+    lib = _lib.load()
+    n = dy2d.shape[0]
+    dev = dy2d.device
+    dx = torch.empty(n, spec.in_features, dtype=x2d.dtype, device=dev) if need_dx else None
+    dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
+    wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
+    ws = _workspace(wsb, dev)
+    check(lib.ttrnn_ttlinear_backward(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
+                                      _ptr(x2d), _ptr(dy2d), _ptr(dx), _ptr(dpk), _ptr(db), _ptr(ws), wsb,
+                                      _stream(dy2d)), "ttrnn_ttlinear_backward")
+    return dx, dpk, db
+
+
+class _TTLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, bias, spec, *cores):
+        lib = _lib.load()
+        packed = spec.pack(cores)
+        n = x2d.shape[0]
+        y = torch.empty(n, spec.out_features, dtype=x2d.dtype, device=x2d.device)
+        wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
+        ws = _workspace(wsb, x2d.device)
+        check(lib.ttrnn_ttlinear_forward(ctypes.byref(spec.desc), _dtype_code(x2d), n, _ptr(packed), _ptr(bias),
+                                         _ptr(x2d), _ptr(y), _ptr(ws), wsb, _stream(x2d)), "ttrnn_ttlinear_forward")
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2d, packed, *cores)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, packed = ctx.saved_tensors[:2]
+        cores = ctx.saved_tensors[2:]
+        spec = ctx.spec
+        need_dx = ctx.needs_input_grad[0]
+        need_db = ctx.has_bias and ctx.needs_input_grad[1]
+        need_dw = any(ctx.needs_input_grad[3:])
+        dy = dy.contiguous()
+        dx, dpk, db = _ttlinear_backward(spec, packed, x2d, dy, need_dx, need_dw, need_db)
+        dcores = spec.unpack_grads(dpk, cores) if need_dw else [None] * len(cores)
+        if db is not None:
+            db = db.to(dy.dtype)
+        return (dx, db, None) + tuple(dcores)
+
+
+def tt_linear(x, cores, bias=None, spec=None):
+    """y[..., out] = TT(cores) x[..., in] + bias — the reference's TTLinear.forward."""
+    cores = list(cores)
+    _require_device(x, bias, *cores)
+    if spec is None:
+        spec = TTSpec.from_cores(cores)
+    if x.shape[-1] != spec.in_features:
+        raise ValueError('Arguments shapes should align got {} and {} instead.'.format(
+            [spec.out_features, spec.in_features], list(x.shape)))
+    lead = x.shape[:-1]
+    x2d = x.reshape(-1, spec.in_features).contiguous()
+    y = _TTLinearFn.apply(x2d, bias, spec, *cores)
+    return y.reshape(*lead, spec.out_features)
+
+
+class RnnLayerSpec(object):
+    """Static description of one recurrent layer (cell kind + its two TT matrices)."""
+
+    def __init__(self, cell, input_size, hidden_size, in_spec, hid_spec, has_bias_in, has_bias_hid):
+        assert cell in ("lstm", "gru")
+        self.cell = cell
+        self.n_gates = 4 if cell == "lstm" else 3
+        self.input_size = int(input_size)
+        self.hidden_size = int(hidden_size)
+        self.in_spec = in_spec
+        self.hid_spec = hid_spec
+        self.has_bias_in = bool(has_bias_in)
+        self.has_bias_hid = bool(has_bias_hid)
+        gh = self.n_gates * self.hidden_size
+        if in_spec.in_features != self.input_size or hid_spec.in_features != self.hidden_size or \
+                in_spec.out_features != gh or hid_spec.out_features != gh:
+            raise ValueError("TT shapes {}x{} / {}x{} do not match a {} layer in={} H={}".format(
+                in_spec.in_modes, in_spec.out_modes, hid_spec.in_modes, hid_spec.out_modes, cell,
+                input_size, hidden_size))
+
+    def desc(self, batch, seq_len, dtype_code):
+        d = RnnDesc()
+        d.cell = TTRNN_LSTM if self.cell == "lstm" else TTRNN_GRU
+        d.dtype = dtype_code
+        d.batch, d.seq_len = int(batch), int(seq_len)
+        d.input_size, d.hidden_size = self.input_size, self.hidden_size
+        d.has_bias_in, d.has_bias_hid = int(self.has_bias_in), int(self.has_bias_hid)
+        d.in_w = self.in_spec.desc
+        d.hid_w = self.hid_spec.desc
+        return d
+
+
+class _TTRnnLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, c0, bias_in, bias_hid, spec, n_in, *cores):
+        lib = _lib.load()
+        cores_in, cores_hid = cores[:n_in], cores[n_in:]
+        B, T, _ = x.shape
+        H = spec.hidden_size
+        dev = x.device
+        desc = spec.desc(B, T, _dtype_code(x))
+        packed_in = spec.in_spec.pack(cores_in)
+        packed_hid = spec.hid_spec.pack(cores_hid)
+        out = torch.empty(B, T, H, dtype=x.dtype, device=dev)
+        hT = torch.empty(B, H, dtype=x.dtype, device=dev)
+        cT = torch.empty(B, H, dtype=x.dtype, device=dev) if spec.cell == "lstm" else None
+        need_grad = any(ctx.needs_input_grad)
+        reserve = None
+        if need_grad:
+            reserve = torch.empty(lib.ttrnn_rnn_reserve_bytes(ctypes.byref(desc)) // 4, dtype=torch.float32, device=dev)
+        wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
+        ws = _workspace(wsb, dev)
+        with _timed("ttrnn_rnn_forward"):
+            check(lib.ttrnn_rnn_forward(ctypes.byref(desc), _ptr(x), _ptr(h0), _ptr(c0), _ptr(packed_in),
+                                        _ptr(bias_in), _ptr(packed_hid), _ptr(bias_hid), _ptr(out), _ptr(hT),
+                                        _ptr(cT), _ptr(reserve), _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward")
+        ctx.spec = spec
+        ctx.n_in = n_in
+        ctx.flags = (h0 is not None, c0 is not None, bias_in is not None, bias_hid is not None)
+        saved = [x, out, reserve, packed_in, packed_hid]
+        saved += [t for t in (h0, c0) if t is not None]
+        ctx.save_for_backward(*(saved + list(cores)))
+        if spec.cell == "lstm":
+            return out, hT, cT
+        return out, hT
+
+    @staticmethod
+    def backward(ctx, d_out, d_hT, d_cT=None):
+        lib = _lib.load()
+        spec = ctx.spec
+        has_h0, has_c0, has_bin, has_bhid = ctx.flags
+        saved = list(ctx.saved_tensors)
+        x, out, reserve, packed_in, packed_hid = saved[:5]
+        pos = 5
+        h0 = c0 = None
+        if has_h0:
+            h0 = saved[pos]; pos += 1
+        if has_c0:
+            c0 = saved[pos]; pos += 1
+        cores = saved[pos:]
+        cores_in, cores_hid = cores[:ctx.n_in], cores[ctx.n_in:]
+        B, T, _ = x.shape
+        H, G = spec.hidden_size, spec.n_gates
+        dev = x.device
+        desc = spec.desc(B, T, _dtype_code(x))
+        d_out = d_out.contiguous() if d_out is not None else None
+        d_hT = d_hT.contiguous() if d_hT is not None else None
+        d_cT = d_cT.contiguous() if d_cT is not None else None
+        dg_in = torch.empty(B, T, G * H, dtype=torch.float32, device=dev)
+        dg_hid = torch.empty(B, T, G * H, dtype=torch.float32, device=dev) if spec.cell == "gru" else dg_in
+        need = ctx.needs_input_grad
+        d_h0 = torch.empty(B, H, dtype=x.dtype, device=dev) if (has_h0 and need[1]) else None
+        d_c0 = torch.empty(B, H, dtype=x.dtype, device=dev) if (has_c0 and need[2]) else None
+        wsb = lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc))
+        ws = _workspace(wsb, dev)
+        with _timed("ttrnn_rnn_backward"):
+            check(lib.ttrnn_rnn_backward(ctypes.byref(desc), _ptr(out), _ptr(h0), _ptr(c0), _ptr(packed_hid),
+                                         _ptr(reserve), _ptr(d_out), _ptr(d_hT), _ptr(d_cT), _ptr(dg_in),
+                                         _ptr(dg_hid), _ptr(d_h0), _ptr(d_c0), _ptr(ws), wsb, _stream(x)),
+                  "ttrnn_rnn_backward")
+        # weight / input gradients: two TTLinear backward passes over the B*T rows
+        n_in = ctx.n_in
+        need_dw_in = any(need[7:7 + n_in])
+        need_dw_hid = any(need[7 + n_in:])
+        dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
+                                               dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3])
+        # h_{t-1} rows: [h0, out[:, :-1]]
+        first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
+        hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
+        _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
+                                                False, need_dw_hid, has_bhid and need[4])
+        dcin = spec.in_spec.unpack_grads(dpk_in, cores_in) if need_dw_in else [None] * n_in
+        dchid = spec.hid_spec.unpack_grads(dpk_hid, cores_hid) if need_dw_hid else [None] * len(cores_hid)
+        if dx is not None:
+            dx = dx.reshape(x.shape)
+        if db_in is not None:
+            db_in = db_in.to(x.dtype)
+        if db_hid is not None:
+            db_hid = db_hid.to(x.dtype)
+        return (dx, d_h0, d_c0, db_in, db_hid, None, None) + tuple(dcin) + tuple(dchid)
+
+
+def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid):
+    """One recurrent layer over the whole sequence on the device.
+    Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU."""
+    cores_in, cores_hid = list(cores_in), list(cores_hid)
+    _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
+    if x.dim() != 3 or x.shape[2] != spec.input_size:
+        raise ValueError("expected input of shape (batch, seq_len, {}), got {}".format(spec.input_size, tuple(x.shape)))
+    x = x.contiguous()
+    h0 = h0.contiguous().to(x.dtype) if h0 is not None else None
+    c0 = c0.contiguous().to(x.dtype) if (c0 is not None and spec.cell == "lstm") else None
+    return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), *(cores_in + cores_hid))

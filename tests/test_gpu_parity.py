@@ -1,0 +1,267 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the product modules — drop-in
+`tensorized_rnn` / `t3nsor` API over libttrnn.so — against
+  (1) the golden fixtures generated from the reference itself (tests/golden/*.npz),
+  (2) the CPU oracle on seeded random inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances: fp32 forward 1e-5 abs (2e-5 for the 784-step cases); gradients 1e-4 of
+the tensor's max magnitude; bf16 storage vs the fp32 oracle 2e-2 abs.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import Case, build_module, case_names
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _maxabs(a, b):
+    return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+def _loaded_module(case):
+    m = build_module(case.meta, dev())
+    missing = m.load_state_dict(case.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def _run(case, m, requires_grad=False):
+    lstm = case.meta["kind"] in ("ttlstm", "lstm")
+    x = case.tensor("x").to(dev())
+    h0 = case.tensor("h0")
+    c0 = case.tensor("c0")
+    h0 = h0.to(dev()) if h0 is not None else None
+    c0 = c0.to(dev()) if c0 is not None else None
+    if requires_grad:
+        x.requires_grad_(True)
+        if h0 is not None:
+            h0.requires_grad_(True)
+        if c0 is not None:
+            c0.requires_grad_(True)
+    if lstm:
+        out, (hT, cT) = m(x, None if h0 is None else (h0, c0))
+    else:
+        out, hT = m(x, h0)
+        cT = None
+    return dict(out=out, hT=hT, cT=cT, x=x, h0=h0, c0=c0)
+
+
+def _check_forward(case, res, tol):
+    out = res["out"].detach().cpu()
+    if "out_t_index" in case.arr:
+        out = out[:, torch.from_numpy(case.arr["out_t_index"]), :]
+    assert _maxabs(out, case.arr["out"]) <= tol
+    assert _maxabs(res["hT"].detach(), case.arr["hT"]) <= tol
+    if res["cT"] is not None:
+        assert _maxabs(res["cT"].detach(), case.arr["cT"]) <= tol
+
+
+def test_library_loaded_and_device_visible():
+    from ttrnn_hip import _lib
+    lib = _lib.load()
+    assert lib.ttrnn_device_available() == 1
+
+
+@pytest.mark.parametrize("name", case_names("g3_ttlinear_"))
+def test_ttlinear_golden(name):
+    from t3nsor.layers import TTLinear
+    case = Case(name)
+    meta = case.meta
+    with contextlib.redirect_stdout(io.StringIO()):
+        lin = TTLinear(out_features=int(np.prod(meta["shape"][1])), shape=meta["shape"], bias=meta["bias"],
+                       auto_shapes=False, d=len(meta["shape"][0]), tt_rank=meta["tt_rank"]).to(dev())
+    lin.load_state_dict(case.state_dict(), strict=True)
+    x = case.tensor("x").to(dev()).requires_grad_(True)
+    y = lin(x)
+    assert _maxabs(y.detach(), case.arr["y"]) <= 1e-5
+    (y * case.tensor("w").to(dev())).sum().backward()
+
+    def close(got, exp, what):
+        assert _maxabs(got, exp) <= 1e-4 * max(float(np.abs(exp).max()), 1e-6) + 1e-7, what
+
+    close(x.grad, case.arr["grad_x"], "grad_x")
+    for n, p in lin.named_parameters():
+        close(p.grad, case.arr["grad/" + n], n)
+        assert p.grad.stride() == p.stride()
+
+
+@pytest.mark.parametrize("name", case_names("g4_cell_"))
+def test_cell_step_golden(name):
+    case = Case(name)
+    m = _loaded_module(case)
+    x, h = case.tensor("x").to(dev()), case.tensor("h").to(dev())
+    with torch.no_grad():
+        if case.meta["kind"] == "ttlstm":
+            hy, cy = m.cell0(x, h, case.tensor("c").to(dev()))
+            assert _maxabs(cy, case.arr["cy"]) <= 1e-5
+        else:
+            hy = m.cell0(x, h)
+    assert _maxabs(hy, case.arr["hy"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", case_names("g5_seq_") + case_names("g8_var_"))
+def test_sequence_golden(name):
+    case = Case(name)
+    m = _loaded_module(case)
+    with torch.no_grad():
+        res = _run(case, m)
+    _check_forward(case, res, 2e-5 if case.meta["T"] > 100 else 1e-5)
+
+
+@pytest.mark.parametrize("name", case_names("g6_bwd_") + [n for n in case_names("g8_var_") if "b1t1" not in n])
+def test_gradients_golden(name):
+    case = Case(name)
+    m = _loaded_module(case)
+    res = _run(case, m, requires_grad=True)
+    _check_forward(case, res, 1e-5)
+    loss = (res["out"] * case.tensor("w_out").to(dev())).sum() + (res["hT"] * case.tensor("w_h").to(dev())).sum()
+    if res["cT"] is not None:
+        loss = loss + (res["cT"] * case.tensor("w_c").to(dev())).sum()
+    loss.backward()
+
+    def close(got, exp, what):
+        assert got is not None, what
+        assert _maxabs(got, exp) <= 1e-4 * max(float(np.abs(exp).max()), 1e-6) + 1e-7, what
+
+    params = dict(m.named_parameters())
+    for key, g in case.grads().items():
+        close(params[key].grad, g.numpy(), key)
+    close(res["x"].grad, case.arr["grad_x"], "grad_x")
+    if "grad_h0" in case.arr:
+        close(res["h0"].grad, case.arr["grad_h0"], "grad_h0")
+    if "grad_c0" in case.arr:
+        close(res["c0"].grad, case.arr["grad_c0"], "grad_c0")
+
+
+# ---- (2) seeded random inputs against the oracle -----------------------------------------------------
+ORACLE_CFGS = [
+    ("ttlstm", 1, 256, 1, 3, 8, 6, 40),      # cfg2 shapes
+    ("ttgru", 1, 256, 1, 3, 8, 5, 40),       # cfg3 shapes (fp32)
+    ("ttlstm", 40, 256, 3, 3, 16, 5, 12),    # cfg4 shapes
+    ("ttlstm", 1, 128, 1, 2, 4, 7, 50),      # cfg1 shapes
+    ("ttgru", 28, 64, 2, 2, 3, 9, 11),       # ragged batch, tiny
+    ("ttlstm", 10, 100, 1, 2, 5, 3, 7),      # non power-of-two modes
+]
+
+
+def _oracle_forward(kind, sd, L, x, init=None):
+    from oracle import ttrnn_oracle as O
+    layers, _ = O.layers_from_state_dict(sd, L)
+    with torch.no_grad():
+        if kind == "ttlstm":
+            out, (h, c) = O.lstm_forward(layers, x, init)
+            return out, h, c
+        out, h = O.gru_forward(layers, x, init)
+        return out, h, None
+
+
+@pytest.mark.parametrize("kind,inp,H,L,d,r,B,T", ORACLE_CFGS)
+def test_sequence_vs_oracle(kind, inp, H, L, d, r, B, T):
+    torch.manual_seed(1234 + H + T)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r)
+    m = build_module(meta, dev())
+    x = torch.randn(B, T, inp)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ro, rh, rc = _oracle_forward(kind, sd, L, x)
+    with torch.no_grad():
+        res = m(x.to(dev()))
+    out = res[0]
+    hT = res[1][0] if kind == "ttlstm" else res[1]
+    assert _maxabs(out, ro) <= 1e-5
+    assert _maxabs(hT, rh) <= 1e-5
+    if kind == "ttlstm":
+        assert _maxabs(res[1][1], rc) <= 1e-5
+
+
+def test_bf16_storage_vs_fp32_oracle():
+    """cfg3-shaped TT-GRU with bf16 storage (x / out / weights), fp32 state and accumulation; the
+    reference has no bf16 path, so the check is against the fp32 oracle on bf16-rounded weights."""
+    torch.manual_seed(7)
+    meta = dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev()).to(torch.bfloat16)
+    x = torch.rand(8, 64, 1).to(torch.bfloat16)
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    ro, rh, _ = _oracle_forward("ttgru", sd, 1, x.float())
+    with torch.no_grad():
+        out, hT = m(x.to(dev()))
+    assert out.dtype == torch.bfloat16
+    assert _maxabs(out.float(), ro) <= 2e-2
+    assert _maxabs(hT.float(), rh) <= 2e-2
+
+
+# ---- (3) properties at full size -------------------------------------------------------------------
+def _cfg2_module():
+    torch.manual_seed(1111)
+    return build_module(dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), dev())
+
+
+def test_full_size_batch_independence_and_prefix():
+    """cfg2 at full size (B=64, T=784): samples never interact, and the first steps of a long
+    sequence equal a short run (causality); hT equals the last output row; cT is finite."""
+    m = _cfg2_module()
+    torch.manual_seed(1111)
+    x = torch.rand(64, 784, 1, device=dev())
+    with torch.no_grad():
+        out, (hT, cT) = m(x)
+        out_a, _ = m(x[:17])
+        out_b, _ = m(x[17:])
+        out_p, (hp, cp) = m(x[:, :100].contiguous())
+    assert torch.equal(out[:17], out_a) and torch.equal(out[17:], out_b)
+    assert torch.equal(out[:, :100], out_p)
+    assert torch.equal(out[:, -1], hT)
+    assert torch.isfinite(out).all() and torch.isfinite(cT).all()
+    # restart from the state at step 100 reproduces the tail
+    with torch.no_grad():
+        out_t, (ht, ct) = m(x[:, 100:].contiguous(), (hp, cp))
+    assert _maxabs(out_t, out[:, 100:]) <= 1e-6
+    assert _maxabs(ct, cT) <= 1e-6
+
+
+def test_full_size_cfg2_subsample_vs_oracle():
+    """Two samples of the full cfg2 problem against the oracle over all 784 steps."""
+    m = _cfg2_module()
+    torch.manual_seed(5)
+    x = torch.rand(64, 784, 1)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ro, rh, rc = _oracle_forward("ttlstm", sd, 1, x[[3, 60]])
+    with torch.no_grad():
+        out, (hT, cT) = m(x.to(dev()))
+    assert _maxabs(out[[3, 60]], ro) <= 2e-5
+    assert _maxabs(cT[[3, 60]], rc) <= 2e-5
+
+
+def test_ttlinear_linearity_full_rows():
+    """TTLinear over 64*784 rows: f(a x1 + b x2) - bias = a (f(x1) - bias) + b (f(x2) - bias)."""
+    from t3nsor.layers import TTLinear
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        lin = TTLinear(out_features=1024, shape=[[4, 8, 8], [8, 8, 16]], bias=True, auto_shapes=False, d=3,
+                       tt_rank=8).to(dev())
+    x1 = torch.randn(64 * 784, 256, device=dev())
+    x2 = torch.randn(64 * 784, 256, device=dev())
+    with torch.no_grad():
+        b = lin.bias
+        lhs = lin(0.5 * x1 - 2.0 * x2) - b
+        rhs = 0.5 * (lin(x1) - b) - 2.0 * (lin(x2) - b)
+    assert _maxabs(lhs, rhs) <= 1e-5
+
+
+def test_empty_and_degenerate_inputs():
+    m = _cfg2_module()
+    with torch.no_grad():
+        out, (hT, cT) = m(torch.zeros(0, 5, 1, device=dev()))
+        assert out.shape == (0, 5, 256) and hT.shape == (0, 256)
+        out, (hT, cT) = m(torch.rand(1, 1, 1, device=dev()))
+        assert out.shape == (1, 1, 256) and torch.equal(out[:, -1], hT)
+    with pytest.raises(Exception):
+        m(torch.zeros(2, 3, 5, device=dev()))          # wrong input size
+    with pytest.raises(Exception):
+        m(torch.zeros(2, 3, 1))                          # CPU tensor: no CPU fallback
