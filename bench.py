@@ -102,26 +102,39 @@ def cpu_baseline(w, budget_s=12.0):
         s_in = tt_shape(i, w["H"], w["d"], G)
         s_hid = tt_shape(w["H"], w["H"], w["d"], G)
         layers.append((O.random_tt(s_in[0], s_in[1], w["r"], g), O.random_tt(s_hid[0], s_hid[1], w["r"], g)))
-    # bounded sample: the full batch, a T-slice sized so one run is ~2-4 s on a typical host
-    T = min(w["T"], 784 if w["L"] == 1 else 16)
-    x = torch.rand(w["B"], T, w["inp"], generator=g)
     fwd = O.lstm_forward if w["kind"] == "ttlstm" else O.gru_forward
-    times = []
+    x = torch.rand(w["B"], w["T"], w["inp"], generator=g)
+
+    def run(T):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            fwd(layers, x[:, :T])
+        return time.perf_counter() - t0
+
+    # the reference path is ~40 tiny ATen ops per timestep: more threads is not always faster, so
+    # probe a few thread counts on a short slice and keep the fastest (stated in `sample`)
+    probe_T = min(w["T"], 6)
+    best_n, best_t = 1, None
+    for n in sorted({1, min(8, cores), min(32, cores), cores}):
+        torch.set_num_threads(n)
+        run(2)
+        t = min(run(probe_T), run(probe_T)) / probe_T
+        if best_t is None or t < best_t:
+            best_n, best_t = n, t
+    torch.set_num_threads(best_n)
+    # bounded sample: the full batch over a T-slice sized for ~budget_s/3 of CPU work per run
+    T = int(max(probe_T, min(w["T"], budget_s / 3.0 / best_t)))
+    times = [run(T)]
     t_all = time.perf_counter()
-    with torch.no_grad():
-        fwd(layers, x[:, :min(T, 8)])       # warm-up
-        while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 9):
-            t0 = time.perf_counter()
-            fwd(layers, x)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_all > 3 * budget_s:
-                break
+    while len(times) < 3 and time.perf_counter() - t_all + times[0] < budget_s:
+        times.append(run(T))
     times.sort()
     med = times[len(times) // 2]
-    return {"value": T / med, "unit": "timesteps/s", "cores": cores, "kind": "port",
+    return {"value": T / med, "unit": "timesteps/s", "cores": best_n, "kind": "port",
             "sample": "oracle/ttrnn_oracle.py (torch-CPU, op-for-op restatement of the reference loop), "
-                      "batch {} x {} of {} timesteps, fp32, no_grad, median of {} runs, {} threads".format(
-                          w["B"], T, w["T"], len(times), cores)}
+                      "batch {} x first {} of {} timesteps, fp32, no_grad, median of {} runs, {} threads "
+                      "(fastest of a 1/8/32/all-thread probe; host has {} logical cores)".format(
+                          w["B"], T, w["T"], len(times), best_n, cores)}
 
 
 def main():

@@ -51,7 +51,7 @@ _SIGNATURES = {
                                                _P, _P, _P, ctypes.c_size_t, _P]),
     "ttrnn_rnn_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
-    "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 11 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 13 + [ctypes.c_size_t, _P]),
 }

@@ -164,4 +164,4 @@ def test_descriptor_validation_without_gpu():
         RnnLayerSpec("gru", 1, 256, TTSpec([1, 1, 1], [8, 8, 16], [1, 8, 8, 1]),
                      TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
     # NULL pointers are rejected before anything is launched
-    assert lib.ttrnn_rnn_forward(ctypes.byref(d), *([None] * 11), 0, None) == -2
+    assert lib.ttrnn_rnn_forward(ctypes.byref(d), *([None] * 12), 0, None) == -2
