@@ -2,6 +2,7 @@
 // Validates descriptors, picks a kernel (shape-specialised MFMA kernel when one exists for the
 // descriptor, else the any-shape kernel), and launches on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
@@ -101,9 +102,35 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 }
 
 // ---- recurrent layer ----------------------------------------------------------------------------
+// The shape-specialised path hoists the input projection: its workspace holds gin = W_in x + b_in
+// for every (b, t) as fp32 [B][T][G*H], followed by whatever the batched TTLinear launch needs.
+struct FastFwdPlan {
+  bool use;
+  size_t gin_bytes, lin_ws_bytes;
+  LinPlan lin;
+};
+
+static bool force_generic() {
+  const char* e = getenv("TTRNN_FORCE_GENERIC");
+  return e && e[0] == '1';
+}
+
+static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
+  FastFwdPlan f{};
+  f.use = !force_generic() && fast_rnn_fwd_available(rs, dtype);
+  if (!f.use) return f;
+  const int64_t n_rows = (int64_t)rs.B * rs.T;
+  f.gin_bytes = ((size_t)n_rows * rs.G * rs.H * sizeof(float) + 255) & ~(size_t)255;
+  f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
+  f.lin_ws_bytes = f.lin.ws_bytes;
+  return f;
+}
+
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+  if (f.use) return f.gin_bytes + f.lin_ws_bytes;
   return plan_rnn_generic(rs, false).ws_bytes;
 }
 
@@ -132,6 +159,17 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
+  const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+  if (f.use) {
+    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes) return TTRNN_ERR_WORKSPACE;
+    float* gin = (float*)workspace;
+    void* lin_ws = (char*)workspace + f.gin_bytes;
+    // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
+    st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
+                             rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream);
+    if (st != TTRNN_OK) return st;
+    return launch_rnn_fwd_fast(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
+  }
   const RnnPlan p = plan_rnn_generic(rs, false);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_rnn_fwd_generic(rs, p, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,

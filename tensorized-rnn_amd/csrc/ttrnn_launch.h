@@ -44,4 +44,10 @@ int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, cons
                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0,
                            void* ws, hipStream_t stream);
 
+// shape-specialised MFMA recurrent kernel (ttrnn_fast.hip); gin = hoisted input projection, fp32 [B][T][G*H]
+bool fast_rnn_fwd_available(const RnnShape& rs, int dtype);
+int launch_rnn_fwd_fast(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+                        const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                        hipStream_t stream);
+
 }  // namespace ttrnn
