@@ -1,0 +1,81 @@
+"""Batch-data-parallel helpers for the TT-RNN path: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+The reference is single-device (no torch.distributed anywhere).  The path shards over batch — samples
+never interact inside the RNN (t3nsor/ops.py:78-93 keeps the batch as a row index; gates are
+pointwise) — so:
+  * forward / inference: contiguous batch shards, NO collective;
+  * training: one all-reduce of the gradients per step.  TT models are tiny (cfg2 38 KB, cfg4 514 KB
+    of gradients), so the collective is latency-bound: every gradient is packed into ONE flat fp32
+    bucket and reduced with a single call instead of one small ring per tensor; the mean over ranks
+    keeps single-GPU semantics for mean-reduced losses.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous [lo, hi) slice of n items for `rank` (first n % world ranks get one extra)."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(x, rank=None, world=None, dim=0):
+    """This rank's contiguous shard of a batch-first tensor."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    lo, hi = shard_bounds(x.shape[dim], rank, world)
+    return x.narrow(dim, lo, hi - lo)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters (strided TT cores keep their layout)."""
+    for p in module.parameters():
+        buf = p.detach().contiguous()
+        dist.broadcast(buf, src=src, group=group)
+        with torch.no_grad():
+            p.copy_(buf)
+
+
+class FlatGradAllReduce(object):
+    """All-reduce (mean) of every gradient of `module` through one persistent flat fp32 bucket."""
+
+    def __init__(self, module, group=None):
+        self.group = group
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        # nn.Module.parameters() de-duplicates shared tensors (e.g. TTLinearSet's gate{i} / gates.{i})
+        self.sizes = [p.numel() for p in self.params]
+        total = sum(self.sizes)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @property
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+    def sync(self):
+        """Call after backward(): grads become the mean over ranks.  Missing grads count as zero."""
+        if self.world == 1:
+            return
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            seg = self.flat[off:off + n]
+            if p.grad is None:
+                seg.zero_()
+            else:
+                seg.copy_(p.grad.reshape(-1) if p.grad.is_contiguous() else p.grad.contiguous().view(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / self.world)
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            seg = self.flat[off:off + n]
+            if p.grad is None:
+                p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+            if p.grad.is_contiguous():
+                p.grad.view(-1).copy_(seg)
+            else:
+                p.grad.copy_(seg.view(p.shape))
+            off += n

@@ -1,0 +1,98 @@
+"""world_size-2 `gloo` tests (CPU) of the batch-data-parallel helpers: shard arithmetic, parameter
+broadcast and the flat-bucket gradient all-reduce on real TT modules (strided core Parameters)."""
+import contextlib
+import io
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tmpdir):
+    for p in (ROOT, os.path.join(ROOT, "tensorized-rnn_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tensorized_rnn.tt_lstm import TTLSTM
+        from ttrnn_hip.dist import FlatGradAllReduce, broadcast_parameters, shard_batch
+        torch.manual_seed(100 + rank)            # different init per rank on purpose
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = TTLSTM(28, 64, 2, torch.device("cpu"), n_cores=2, tt_rank=3)
+        broadcast_parameters(m, src=0)
+        # every rank now holds rank 0's parameters, strides untouched
+        flat = torch.cat([p.detach().contiguous().view(-1) for p in m.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        assert any(not p.is_contiguous() for p in m.parameters())
+
+        # fabricate rank-dependent gradients with the parameters' own (transposed) layout
+        g = torch.Generator().manual_seed(7)
+        base = [torch.randn(p.shape, generator=g) for p in m.parameters()]
+        params = list(m.parameters())
+        for i, (p, b) in enumerate(zip(params, base)):
+            if i == 1 and rank == 1:
+                p.grad = None                     # a rank may have no grad for a tensor: counts as zero
+                continue
+            gr = torch.empty_strided(p.shape, p.stride())
+            gr.copy_(b * (rank + 1))
+            p.grad = gr
+        red = FlatGradAllReduce(m)
+        assert red.nbytes == 4 * sum(p.numel() for p in params)
+        red.sync()
+        for i, (p, b) in enumerate(zip(params, base)):
+            expect = b * (1.0 if i == 1 else 1.5)        # mean of 1x and 2x (or 1x and 0)
+            if i == 1:
+                expect = b * 0.5
+            assert torch.allclose(p.grad, expect, atol=1e-6), i
+            assert p.grad.stride() == p.stride()
+
+        # batch sharding: contiguous, covers everything, no overlap
+        x = torch.arange(7 * 3).view(7, 3)
+        mine = shard_batch(x)
+        parts = [torch.zeros(4, 3, dtype=x.dtype) for _ in range(world)]
+        pad = torch.zeros(4, 3, dtype=x.dtype)
+        pad[:mine.shape[0]] = mine
+        dist.all_gather(parts, pad)
+        sizes = [4, 3]
+        assert torch.equal(torch.cat([parts[r][:sizes[r]] for r in range(world)]), x)
+        with open(os.path.join(tmpdir, "ok%d" % rank), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_grad_allreduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def test_shard_bounds():
+    sys.path.insert(0, os.path.join(ROOT, "tensorized-rnn_amd"))
+    from ttrnn_hip.dist import shard_bounds
+    for n in (0, 1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
