@@ -102,8 +102,9 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 }
 
 // ---- recurrent layer ----------------------------------------------------------------------------
-// The shape-specialised path hoists the input projection: its workspace holds gin = W_in x + b_in
-// for every (b, t) as fp32 [B][T][G*H], followed by whatever the batched TTLinear launch needs.
+// The shape-specialised path hoists the input projection: its workspace holds gin = W_in x + b_in for every
+// (b, t), gate-interleaved per hidden unit as fp32 [B][T][H][4] (LSTM slots i,g,f,o; GRU r,z,n,-), followed by
+// whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
   bool use;
   size_t gin_bytes, lin_ws_bytes;
@@ -120,7 +121,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   f.use = !force_generic() && fast_rnn_fwd_available(rs, dtype);
   if (!f.use) return f;
   const int64_t n_rows = (int64_t)rs.B * rs.T;
-  f.gin_bytes = ((size_t)n_rows * rs.G * rs.H * sizeof(float) + 255) & ~(size_t)255;
+  f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [B][T][H][4]
   f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
   f.lin_ws_bytes = f.lin.ws_bytes;
   return f;
@@ -166,7 +167,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     void* lin_ws = (char*)workspace + f.gin_bytes;
     // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
     st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
-                             rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream);
+                             rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
+                             rs.cell == TTRNN_LSTM ? 2 : 1);
     if (st != TTRNN_OK) return st;
     return launch_rnn_fwd_fast(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
   }

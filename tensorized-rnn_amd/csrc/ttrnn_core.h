@@ -274,9 +274,19 @@ TT_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // ------------------------------------------------------------------------------------------------
 // TTLinear forward over a tile of nb rows:  y = chain(x) + bias     (layers.py:121-127)
 // ------------------------------------------------------------------------------------------------
+// ilv_h > 0 selects the gate-interleaved output used by the hoisted input projection of the recurrent
+// kernels: y[n][o], o = g*ilv_h + hid, is stored at ((n*ilv_h + hid)*4 + slot(g)); ilv_mode 1: slot = g,
+// ilv_mode 2 (LSTM): slots ordered i,g,f,o so that each half-wave of the fused kernel loads one 8-byte pair.
+TT_HD size_t ilv_index(int64_t n, int o, int out, int ilv_h, int ilv_mode) {
+  if (ilv_h <= 0) return (size_t)n * out + o;
+  const int g = o / ilv_h, hid = o - g * ilv_h;
+  const int slot = (ilv_mode == 2) ? (g == 1 ? 2 : (g == 2 ? 1 : g)) : g;
+  return ((size_t)n * ilv_h + hid) * 4 + slot;
+}
+
 template <class Ex, typename T>
 TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* bias, const T* x, T* y,
-                             int64_t n0, int nb, float* bufA, float* bufB, int bs) {
+                             int64_t n0, int nb, float* bufA, float* bufB, int bs, int ilv_h = 0, int ilv_mode = 0) {
   const int in = s.in_size, out = s.out_size;
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * in; e += nthr) {
@@ -290,7 +300,7 @@ TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* 
       const int sidx = e / out, o = e - sidx * out;
       float v = r[(size_t)sidx * bs + o];
       if (bias) v += ld(bias, o);
-      st(y, (size_t)(n0 + sidx) * out + o, v);
+      st(y, ilv_index(n0 + sidx, o, out, ilv_h, ilv_mode), v);
     }
   });
 }
@@ -392,7 +402,7 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* hbuf, float* cbuf, float* gin) {
   const int H = rs.H, G = rs.G, GH = G * H, in = rs.in, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RS = lstm ? 5 * H : 4 * H;   // reserve floats per (b, t)
+  const int RU = lstm ? 5 : 4;           // reserve floats per (b, t, hidden unit): LSTM i,g,f,o,c  GRU r,z,n,hn
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;
@@ -442,8 +452,8 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           hy = og * tanhf(cy);
           cbuf[e] = cy;
           if (reserve) {
-            float* rv = reserve + bt * RS;
-            rv[j] = ig; rv[H + j] = fg; rv[2 * H + j] = gg; rv[3 * H + j] = og; rv[4 * H + j] = cy;
+            float* rv = reserve + (bt * H + j) * RU;
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
         } else {
           float hr = gh[j], hz = gh[H + j], hn = gh[2 * H + j];
@@ -453,8 +463,8 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           const float ng = tanhf(gi[2 * H + j] + rg * hn);
           hy = (1.0f - zg) * ng + zg * hbuf[e];
           if (reserve) {
-            float* rv = reserve + bt * RS;
-            rv[j] = rg; rv[H + j] = zg; rv[2 * H + j] = ng; rv[3 * H + j] = hn;
+            float* rv = reserve + (bt * H + j) * RU;
+            rv[0] = rg; rv[1] = zg; rv[2] = ng; rv[3] = hn;
           }
         }
         // the stored output is what the next step (and the next layer) sees: round once
@@ -485,7 +495,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* dh, float* dc, float* dhd) {
   const int H = rs.H, G = rs.G, GH = G * H, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RS = lstm ? 5 * H : 4 * H;
+  const int RU = lstm ? 5 : 4;
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;
@@ -499,13 +509,13 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
         const int s = e / H, j = e - s * H;
         const size_t b = (size_t)(b0 + s);
         const size_t bt = b * Tn + t;
-        const float* rv = reserve + bt * RS;
+        const float* rv = reserve + (bt * H + j) * RU;
         float dht = dh[e];
         if (d_out) dht += ld(d_out, bt * H + j);
         float* ga = bufA + (size_t)s * bs;
         if (lstm) {
-          const float ig = rv[j], fg = rv[H + j], gg = rv[2 * H + j], og = rv[3 * H + j], cy = rv[4 * H + j];
-          const float cprev = t > 0 ? reserve[(bt - 1) * RS + 4 * H + j] : (c0 ? ld(c0, b * H + j) : 0.f);
+          const float ig = rv[0], gg = rv[1], fg = rv[2], og = rv[3], cy = rv[4];
+          const float cprev = t > 0 ? reserve[((bt - 1) * H + j) * RU + 4] : (c0 ? ld(c0, b * H + j) : 0.f);
           const float tc = tanhf(cy);
           const float dct = dc[e] + dht * og * (1.0f - tc * tc);
           const float p0 = dct * gg * ig * (1.0f - ig);
@@ -521,7 +531,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
             gq[j] = p0; gq[H + j] = p1; gq[2 * H + j] = p2; gq[3 * H + j] = p3;
           }
         } else {
-          const float rg = rv[j], zg = rv[H + j], ng = rv[2 * H + j], hn = rv[3 * H + j];
+          const float rg = rv[0], zg = rv[1], ng = rv[2], hn = rv[3];
           const float hprev = t > 0 ? ld(out, (bt - 1) * H + j) : (h0 ? ld(h0, b * H + j) : 0.f);
           const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
           const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);

@@ -20,6 +20,7 @@
 // Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 and gru.py:33-44,124-134 with the
 // hidden-weights chain of t3nsor/ops.py:78-93 (reference file:line).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
 
@@ -124,6 +125,21 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Diagnostic builds only (TTRNN_DIAG=1): per-phase cycle stamps, MI355X guide section 7 "In-kernel stamps".
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define TT_STAMP(idx)                                   \
+  if constexpr (DIAG) {                                 \
+    const unsigned long long now_ = stamp();            \
+    seg[idx] += now_ - last_;                           \
+    last_ = now_;                                       \
+  }
+
 // ---- one chain stage ---------------------------------------------------------------------------------
 template <class S, int k, int NW_>
 __device__ __forceinline__ void load_wfrag(float (&w)[NW_], const float* packed,
@@ -146,12 +162,13 @@ __device__ __forceinline__ void load_wfrag(float (&w)[NW_], const float* packed,
   }
 }
 
-// Ain: LDS image [ROWS][K] (a_off<K>);  Cout: LDS image of the next stage input (k > 0) or the flat
-// gate pre-activation vector (k == 0).
-template <class S, int k, int NW_>
-__device__ __forceinline__ void run_stage(const float (&w)[NW_],
-                                          const float* Ain, float* Cout, int wave, int lane) {
+// Fragment reads + MFMAs of stage k for the tiles this wave owns.  Ain: LDS image [ROWS][K] (a_off<K>).
+// D[p = 4q + j][c]: p <-> output feature of m-tile mt, c <-> chain row 16*rt + c.
+template <class S, int k, int NW_, int XM_, int YR_>
+__device__ __forceinline__ void stage_mma(const float (&w)[NW_], const float* Ain, f32x4 (&acc)[XM_][YR_], int wave,
+                                          int lane) {
   using T = St<S, k>;
+  static_assert(NW_ == T::NWREG && XM_ == T::XM && YR_ == T::YR, "stage tile bookkeeping");
   const int c = lane & 15, q = lane >> 4;
   float af[T::YR][T::NSTEP];
 #pragma unroll
@@ -173,7 +190,6 @@ __device__ __forceinline__ void run_stage(const float (&w)[NW_],
       }
     }
   }
-  f32x4 acc[T::XM][T::YR];
 #pragma unroll
   for (int x = 0; x < T::XM; ++x)
 #pragma unroll
@@ -185,7 +201,15 @@ __device__ __forceinline__ void run_stage(const float (&w)[NW_],
 #pragma unroll
       for (int y = 0; y < T::YR; ++y)
         acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[y][s], acc[x][y], 0, 0, 0);
-  // D[p = 4q + j][c]: p <-> output feature m = 16*mt + p, c <-> chain row 16*rt + c
+}
+
+// Cout: LDS image of the next stage input (k > 0) or the flat gate pre-activation vector (k == 0).
+template <class S, int k, int NW_>
+__device__ __forceinline__ void run_stage(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane) {
+  using T = St<S, k>;
+  const int c = lane & 15, q = lane >> 4;
+  f32x4 acc[T::XM][T::YR];
+  stage_mma<S, k>(w, Ain, acc, wave, lane);
 #pragma unroll
   for (int x = 0; x < T::XM; ++x) {
     const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
@@ -261,7 +285,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
   if constexpr (D > 3) load_wfrag<S, 3>(w3, packed_hid, wave, lane);
 
   // per-thread recurrent state and constants for its hidden units
-  float cst[HPT], hst[HPT], bh[HPT][G], gi[HPT][G];
+  // gin is gate-interleaved: [B][T][H][4], slot order i,g,f,o (LSTM) / r,z,n,- (GRU): one 16-byte load
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+  float cst[HPT], hst[HPT], bh[HPT][G];
+  f32x4 gi[HPT];
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -269,12 +296,11 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
     hst[u] = (ok && h0) ? h0[b * H + hid] : 0.f;
     cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? c0[b * H + hid] : 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      bh[u][g] = (ok && bias_hid) ? bias_hid[g * H + hid] : 0.f;
-      gi[u][g] = (ok && T > 0) ? gin[(b * T) * GH + g * H + hid] : 0.f;
-    }
+    for (int g = 0; g < G; ++g) bh[u][g] = (ok && bias_hid) ? bias_hid[g * H + hid] : 0.f;
+    gi[u] = (ok && T > 0) ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};
     if (ok) hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hst[u];
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see k_lstm_fwd_fused
   lds_barrier();
 
   for (int t = 0; t < T; ++t) {
@@ -310,15 +336,15 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
         float hy;
         if constexpr (CELL == TTRNN_LSTM) {
           const float ig = fsigmoid(gi[u][0] + gbuf[hid] + bh[u][0]);
-          const float fg = fsigmoid(gi[u][1] + gbuf[H + hid] + bh[u][1]);
-          const float gg = ftanh(gi[u][2] + gbuf[2 * H + hid] + bh[u][2]);
+          const float fg = fsigmoid(gi[u][2] + gbuf[H + hid] + bh[u][1]);
+          const float gg = ftanh(gi[u][1] + gbuf[2 * H + hid] + bh[u][2]);
           const float og = fsigmoid(gi[u][3] + gbuf[3 * H + hid] + bh[u][3]);
           const float cy = fg * cst[u] + ig * gg;
           hy = og * ftanh(cy);
           cst[u] = cy;
           if (reserve) {
-            float* rv = reserve + bt * (5 * H);
-            rv[hid] = ig; rv[H + hid] = fg; rv[2 * H + hid] = gg; rv[3 * H + hid] = og; rv[4 * H + hid] = cy;
+            float* rv = reserve + (bt * H + hid) * 5;
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
         } else {
           const float hn = gbuf[2 * H + hid] + bh[u][2];
@@ -326,19 +352,13 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
           const float zg = fsigmoid(gi[u][1] + gbuf[H + hid] + bh[u][1]);
           const float ng = ftanh(gi[u][2] + rg * hn);
           hy = (1.0f - zg) * ng + zg * hst[u];
-          if (reserve) {
-            float* rv = reserve + bt * (4 * H);
-            rv[hid] = rg; rv[H + hid] = zg; rv[2 * H + hid] = ng; rv[3 * H + hid] = hn;
-          }
+          if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
         }
         hst[u] = hy;
         out[bt * H + hid] = hy;
         hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hy;
         // prefetch the hoisted input projection of the next step; consumed one iteration later
-        if (t + 1 < T) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) gi[u][g] = gin[(bt + 1) * GH + g * H + hid];
-        }
+        if (t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
       }
     }
     lds_barrier();
@@ -349,6 +369,231 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
     if (hid < H) {
       if (hT) hT[b * H + hid] = hst[u];
       if (CELL == TTRNN_LSTM && cT) cT[b * H + hid] = cst[u];
+    }
+  }
+}
+
+// ---- LSTM: last chain stage fused with the gate arithmetic --------------------------------------------
+// o = gate*H + hid and o = i_0*ROWS_0 + row give i_0 = gate*P + par, hid = par*ROWS_0 + row (P = I_0/4).
+// Loading the stage-0 core with its rows permuted — MFMA row p = 4*qq + j of m-tile mt <-> i_0 = j*P + (4*mt+qq) —
+// puts the four gate pre-activations of ONE hidden unit into the four accumulator registers of ONE lane
+// (lane (c, q): hid = (4*mt+q)*ROWS_0 + 16*rt + c).  The gate math then runs straight on the accumulators:
+// no gate buffer in LDS and one barrier fewer per timestep; c and the hoisted gate inputs live in that lane.
+template <class S>
+constexpr bool lstm_fusable() { return S::D >= 2 && S::R[0] == 1 && S::I[0] % 4 == 0; }
+
+// PAIR variant (P <= 2, one m-tile): MFMA row p = 4*qq + j holds, for pair = qq >> 1 and par = qq & 1, gate
+// (pair ? f : i) in j = 0 and (pair ? o : g) in j = 1; rows j = 2, 3 are zero.  Lanes 0-31 then own (i, g) and
+// lanes 32-63 own (f, o) of the same hidden unit: every lane evaluates two non-linearities instead of five and
+// one v_permlane32_swap hands i*g to the lane that keeps c.
+template <class S>
+constexpr bool lstm_pair_mode() { return S::I[0] / 4 <= 2; }
+
+template <class S, int NW_>
+__device__ __forceinline__ void load_wfrag0_lstm(float (&w)[NW_], const float* packed, int wave, int lane) {
+  using T = St<S, 0>;
+  static_assert(NW_ == T::NWREG, "weight fragment array size");
+  constexpr int P = S::I[0] / 4;
+  const int r = lane & 15, q = lane >> 4;
+  const int j = r & 3, qq = r >> 2;
+#pragma unroll
+  for (int x = 0; x < T::XM; ++x) {
+    const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
+    int par = 4 * mt + qq;
+    int i0 = j * P + par;
+    if constexpr (lstm_pair_mode<S>()) {
+      const int pair = qq >> 1;
+      par = (j < 2) ? (qq & 1) : P;                                      // rows j = 2,3 -> zero
+      const int gate = (j == 0) ? (pair ? 1 : 0) : (pair ? 3 : 2);
+      i0 = gate * P + (qq & 1);
+    }
+#pragma unroll
+    for (int u = 0; u < T::NU; ++u)
+#pragma unroll
+      for (int e = 0; e < T::WV; ++e) {
+        const int kk = (4 * u + q) * T::WV + e;
+        w[x * T::NSTEP + u * T::WV + e] = (mt < T::MT && par < P) ? packed[kk * T::M + i0] : 0.f;   // M = I_0
+      }
+  }
+}
+
+template <class S, bool DIAG>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const float* __restrict__ gin,
+                                                            const float* __restrict__ h0, const float* __restrict__ c0,
+                                                            const float* __restrict__ packed_hid,
+                                                            const float* __restrict__ bias_hid, float* __restrict__ out,
+                                                            float* __restrict__ hT, float* __restrict__ cT,
+                                                            float* __restrict__ reserve) {
+  constexpr int D = S::D;
+  constexpr int H = in_size_of<S>();
+  constexpr int GH = 4 * H;
+  static_assert(out_size_of<S>() == GH, "TT output size must be 4 * hidden");
+  constexpr int MID = maxmid_of<S>();
+  using SL = St<S, D - 1>;
+  using T0 = St<S, 0>;
+  constexpr int P = S::I[0] / 4;
+  static_assert(P * T0::ROWS == H, "hidden index decomposition");
+
+  __shared__ __attribute__((aligned(16))) float hbuf[H];
+  __shared__ __attribute__((aligned(16))) float bufA[MID];
+  __shared__ __attribute__((aligned(16))) float bufB[D > 2 ? MID : 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  float w0[nwreg<S, 0>()];
+  float w1[nwreg<S, (D > 1 ? 1 : 0)>()];
+  float w2[nwreg<S, (D > 2 ? 2 : 0)>()];
+  float w3[nwreg<S, (D > 3 ? 3 : 0)>()];
+  load_wfrag0_lstm<S>(w0, packed_hid, wave, lane);
+  if constexpr (D > 1) load_wfrag<S, 1>(w1, packed_hid, wave, lane);
+  if constexpr (D > 2) load_wfrag<S, 2>(w2, packed_hid, wave, lane);
+  if constexpr (D > 3) load_wfrag<S, 3>(w3, packed_hid, wave, lane);
+
+  // hidden units owned by this lane (one per stage-0 tile of the wave).  gin is gate-interleaved
+  // [B][T][H][4] with slot order i,g,f,o.  PAIR: lanes 0-31 take slots (i,g), lanes 32-63 (f,o) and own c.
+  constexpr bool PAIR = lstm_pair_mode<S>();
+  constexpr int NG = PAIR ? 2 : 4;                  // gates evaluated per lane
+  const int pair = PAIR ? (q >> 1) : 1;             // 1 = this lane owns c / h of its hidden unit
+  const float sgn = (PAIR && pair == 0) ? 2.0f : 1.0f;   // second gate: tanh (= 2*sigmoid(2x) - 1) or sigmoid
+  int hid[T0::XM][T0::YR];
+  bool ok[T0::XM][T0::YR];
+  float cst[T0::XM][T0::YR], hst[T0::XM][T0::YR], bh[T0::XM][T0::YR][NG], gi[T0::XM][T0::YR][NG];
+#pragma unroll
+  for (int x = 0; x < T0::XM; ++x) {
+    const int mt = T0::SPLIT ? (wave % T0::MT) : (wave + FAST_NW * x);
+#pragma unroll
+    for (int y = 0; y < T0::YR; ++y) {
+      const int rt = T0::SPLIT ? (wave / T0::MT + T0::G * y) : y;
+      const int row = 16 * rt + c, par = PAIR ? (q & 1) : (4 * mt + q);
+      ok[x][y] = mt < T0::MT && rt < T0::RT && row < T0::ROWS && par < P;
+      hid[x][y] = ok[x][y] ? par * T0::ROWS + row : 0;
+      const int hd = hid[x][y];
+      hst[x][y] = (ok[x][y] && h0) ? h0[b * H + hd] : 0.f;
+      cst[x][y] = (ok[x][y] && c0) ? c0[b * H + hd] : 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        // slot s of the interleaved layout <-> reference gate index: i,g,f,o -> 0,2,1,3
+        const int slot = PAIR ? 2 * pair + g : g;
+        const int gate = slot == 1 ? 2 : (slot == 2 ? 1 : slot);
+        bh[x][y][g] = (ok[x][y] && bias_hid) ? bias_hid[gate * H + hd] : 0.f;
+        gi[x][y][g] = (ok[x][y] && T > 0) ? gin[((b * T) * H + hd) * 4 + slot] : 0.f;
+      }
+      if (ok[x][y] && pair) hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hst[x][y];
+    }
+  }
+  // All pre-loop global loads (core fragments, biases, first gate inputs) must be provably complete here:
+  // otherwise hipcc guards the first use of a weight register inside the loop with s_waitcnt vmcnt(0), which in
+  // steady state drains the gate-input prefetch issued a few hundred cycles earlier (one exposed HBM latency
+  // per timestep).  0x0F70 = vmcnt(0) only.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  for (int t = 0; t < T; ++t) {
+    const float* last;   // input image of stage 0
+    if constexpr (D == 2) {
+      run_stage<S, 1>(w1, hbuf, bufA, wave, lane);
+      TT_STAMP(2)
+      last = bufA;
+    } else if constexpr (D == 3) {
+      run_stage<S, 2>(w2, hbuf, bufA, wave, lane);
+      TT_STAMP(0)
+      lds_barrier();
+      TT_STAMP(1)
+      run_stage<S, 1>(w1, bufA, bufB, wave, lane);
+      TT_STAMP(2)
+      last = bufB;
+    } else {
+      run_stage<S, 3>(w3, hbuf, bufA, wave, lane);
+      lds_barrier();
+      run_stage<S, 2>(w2, bufA, bufB, wave, lane);
+      lds_barrier();
+      run_stage<S, 1>(w1, bufB, bufA, wave, lane);
+      last = bufA;
+    }
+    lds_barrier();
+    TT_STAMP(3)
+    f32x4 acc[T0::XM][T0::YR];
+    stage_mma<S, 0>(w0, last, acc, wave, lane);
+    if constexpr (DIAG) {
+      asm volatile("" : "+v"(acc[0][0]));
+    }
+    TT_STAMP(4)
+    const size_t bt = b * T + t;
+#pragma unroll
+    for (int x = 0; x < T0::XM; ++x)
+#pragma unroll
+      for (int y = 0; y < T0::YR; ++y) {
+        const int hd = hid[x][y];
+        if constexpr (PAIR) {
+          // lanes 0-31: (i, g); lanes 32-63: (f, o).  u = sigmoid(first), v = tanh|sigmoid(second)
+          const float u = fsigmoid(acc[x][y][0] + gi[x][y][0] + bh[x][y][0]);                 // lstm.py:26-27
+          const float a1 = acc[x][y][1] + gi[x][y][1] + bh[x][y][1];
+          const float v = sgn * fsigmoid(sgn * a1) + (1.0f - sgn);                           // lstm.py:28-29
+          const float prod = u * v;                                                          // i*g on lanes 0-31
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(prod), __float_as_uint(prod), false, false);
+          const float ig_g = __uint_as_float(sw[0]);                                         // lanes 32-63 <- lanes 0-31
+          const float cy = u * cst[x][y] + ig_g;                                             // lstm.py:31
+          const float hy = v * ftanh(cy);                                                    // lstm.py:32
+          if (reserve && ok[x][y]) {
+            float* rv = reserve + (bt * H + hd) * 5 + 2 * pair;                              // i,g | f,o,c
+            rv[0] = u; rv[1] = v;
+            if (pair) rv[2] = cy;
+          }
+          if (ok[x][y] && pair) {
+            cst[x][y] = cy;
+            hst[x][y] = hy;
+            out[bt * H + hd] = hy;                                                           // lstm.py:133
+            hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
+          }
+          if (ok[x][y] && t + 1 < T) {
+            const f32x2 nx = *reinterpret_cast<const f32x2*>(gin + ((bt + 1) * H + hd) * 4 + 2 * pair);
+            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1];
+          }
+        } else if (ok[x][y]) {
+          const float ig = fsigmoid(acc[x][y][0] + gi[x][y][0] + bh[x][y][0]);     // lstm.py:26
+          const float gg = ftanh(acc[x][y][2] + gi[x][y][1] + bh[x][y][1]);        // lstm.py:28
+          const float fg = fsigmoid(acc[x][y][1] + gi[x][y][2] + bh[x][y][2]);     // lstm.py:27
+          const float og = fsigmoid(acc[x][y][3] + gi[x][y][3] + bh[x][y][3]);     // lstm.py:29
+          const float cy = fg * cst[x][y] + ig * gg;                               // lstm.py:31
+          const float hy = og * ftanh(cy);                                         // lstm.py:32
+          cst[x][y] = cy;
+          hst[x][y] = hy;
+          out[bt * H + hd] = hy;                                                   // lstm.py:133
+          hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
+          if (reserve) {
+            float* rv = reserve + (bt * H + hd) * 5;
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+          }
+          if (t + 1 < T) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1]; gi[x][y][2] = nx[2]; gi[x][y][3] = nx[3];
+          }
+        }
+      }
+    TT_STAMP(5)
+    lds_barrier();
+    TT_STAMP(6)
+  }
+#pragma unroll
+  for (int x = 0; x < T0::XM; ++x)
+#pragma unroll
+    for (int y = 0; y < T0::YR; ++y)
+      if (ok[x][y] && pair) {
+        if (hT) hT[b * H + hid[x][y]] = hst[x][y];
+        if (cT) cT[b * H + hid[x][y]] = cst[x][y];
+      }
+  if constexpr (DIAG) {
+    // stamps leave through a buffer nothing else reads: the caller passes a scratch `reserve`
+    if (lane == 0 && reserve && b < 8) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * FAST_NW + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = seg[i];
     }
   }
 }
@@ -366,6 +611,20 @@ template <class S, int CELL>
 static int launch_one(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
   static_assert(shape_ok<S>(), "shape not supported by the MFMA path");
+  if constexpr (CELL == TTRNN_LSTM && lstm_fusable<S>()) {
+    const char* diag = getenv("TTRNN_DIAG");
+    if (diag && diag[0] == '1' && reserve)   // diagnostic build: phase stamps overwrite the reserve buffer
+      hipLaunchKernelGGL((k_lstm_fwd_fused<S, true>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                         (const float*)h0, (const float*)c0, packed_hid,
+                         rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,
+                         (float*)cT, reserve);
+    else
+      hipLaunchKernelGGL((k_lstm_fwd_fused<S, false>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                         (const float*)h0, (const float*)c0, packed_hid,
+                         rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,
+                         (float*)cT, reserve);
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL((k_rnn_fwd_fast<S, CELL>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
                      (const float*)h0, (const float*)c0, packed_hid,
                      rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,

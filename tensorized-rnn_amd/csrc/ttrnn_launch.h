@@ -30,8 +30,10 @@ int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strid
                 hipStream_t stream);
 int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
                   hipStream_t stream);
+// ilv_h / ilv_mode: optional gate-interleaved output layout, see ttrnn_core.h:ilv_index
 int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n_rows, const float* packed,
-                        const void* bias, const void* x, void* y, void* ws, hipStream_t stream);
+                        const void* bias, const void* x, void* y, void* ws, hipStream_t stream, int ilv_h = 0,
+                        int ilv_mode = 0);
 int launch_ttlinear_bwd(const TtShape& s, const LinPlan& p, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
                         const void* x, const void* dy, void* dx, float* d_packed, float* d_bias, void* ws,
                         hipStream_t stream);

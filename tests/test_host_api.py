@@ -159,7 +159,11 @@ def test_descriptor_validation_without_gpu():
                         TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
     d = spec.desc(64, 784, 0)
     assert lib.ttrnn_rnn_reserve_bytes(ctypes.byref(d)) == 64 * 784 * 5 * 256 * 4
-    assert lib.ttrnn_rnn_workspace(ctypes.byref(d)) == 0           # cfg2 lives entirely in LDS
+    # cfg2 runs on the shape-specialised kernel: workspace = hoisted gate inputs, fp32 [B][T][H][4]
+    assert lib.ttrnn_rnn_workspace(ctypes.byref(d)) == 64 * 784 * 256 * 4 * 4
+    tiny = RnnLayerSpec("gru", 28, 64, TTSpec([4, 7], [12, 16], [1, 3, 1]), TTSpec([8, 8], [12, 16], [1, 3, 1]),
+                        True, True).desc(3, 6, 0)
+    assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) == 0        # generic kernel, everything in LDS
     with pytest.raises(ValueError):
         RnnLayerSpec("gru", 1, 256, TTSpec([1, 1, 1], [8, 8, 16], [1, 8, 8, 1]),
                      TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)

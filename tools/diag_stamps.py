@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Developer diagnostic: per-phase cycle shares of the fused LSTM kernel (TTRNN_DIAG=1 build variant with
+s_memtime stamps).  Shares only — never quote the diagnostic build's run time."""
+import contextlib, io, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tensorized-rnn_amd"))
+os.environ["TTRNN_DIAG"] = "1"
+import numpy as np, torch
+from tensorized_rnn.tt_lstm import TTLSTM
+from ttrnn_hip import functional as F
+
+dev = torch.device("cuda:0")
+torch.manual_seed(1111)
+with contextlib.redirect_stdout(io.StringIO()):
+    m = TTLSTM(1, 256, 1, dev, n_cores=3, tt_rank=8)
+B, T = 64, 784
+x = torch.rand(B, T, 1, device=dev, requires_grad=True)     # requires_grad -> reserve buffer exists
+captured = {}
+orig = F._TTRnnLayerFn.forward
+def fwd(ctx, *a):
+    osave = ctx.save_for_backward
+    def save(*ts):
+        captured["reserve"] = ts[2]
+        return osave(*ts)
+    ctx.save_for_backward = save
+    return orig(ctx, *a)
+F._TTRnnLayerFn.forward = staticmethod(fwd)
+for _ in range(2):
+    out, _ = m(x)
+torch.cuda.synchronize()
+raw = captured["reserve"][:8 * 8 * 8 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
+names = ["S2 mma+store", "barrier1", "S1 mma+store", "barrier2", "S0 mma", "gates", "barrier3", "-"]
+per_step = raw.astype(np.float64) / T
+print("cycles per step (mean over 8 blocks), per wave:")
+for w in range(8):
+    print("wave", w, " ".join("%7.0f" % v for v in per_step[:, w, :7].mean(0)), " total %.0f" % per_step[:, w, :7].mean(0).sum())
+print("segments:", names[:7])
