@@ -9,6 +9,11 @@
 
 using namespace ttrnn;
 
+static bool force_generic() {
+  const char* e = getenv("TTRNN_FORCE_GENERIC");
+  return e && e[0] == '1';
+}
+
 extern "C" {
 
 int ttrnn_abi_version(void) { return TTRNN_ABI_VERSION; }
@@ -77,6 +82,8 @@ int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const 
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
   if (n_rows == 0) return TTRNN_OK;
   if (!packed || !x || !y) return TTRNN_ERR_NULL;
+  if (!force_generic() && fast_ttlinear_fwd_available(s, dtype, 0))
+    return launch_ttlinear_fwd_fast(s, n_rows, packed, bias, x, y, 0, 0, (hipStream_t)stream);
   const LinPlan p = plan_ttlinear_fwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_ttlinear_fwd(s, p, dtype, n_rows, packed, bias, x, y, workspace, (hipStream_t)stream);
@@ -106,15 +113,11 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 // (b, t), gate-interleaved per hidden unit as fp32 [B][T][H][4] (LSTM slots i,g,f,o; GRU r,z,n,-), followed by
 // whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
-  bool use;
+  bool use, lin_fast;
   size_t gin_bytes, lin_ws_bytes;
   LinPlan lin;
 };
 
-static bool force_generic() {
-  const char* e = getenv("TTRNN_FORCE_GENERIC");
-  return e && e[0] == '1';
-}
 
 static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   FastFwdPlan f{};
@@ -122,8 +125,11 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   if (!f.use) return f;
   const int64_t n_rows = (int64_t)rs.B * rs.T;
   f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [B][T][H][4]
-  f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
-  f.lin_ws_bytes = f.lin.ws_bytes;
+  f.lin_fast = fast_ttlinear_fwd_available(rs.in_s, dtype, rs.H);
+  if (!f.lin_fast) {
+    f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
+    f.lin_ws_bytes = f.lin.ws_bytes;
+  }
   return f;
 }
 
@@ -166,9 +172,14 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     float* gin = (float*)workspace;
     void* lin_ws = (char*)workspace + f.gin_bytes;
     // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
-    st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
-                             rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
-                             rs.cell == TTRNN_LSTM ? 2 : 1);
+    const int ilv_mode = rs.cell == TTRNN_LSTM ? 2 : 1;
+    if (f.lin_fast)
+      st = launch_ttlinear_fwd_fast(rs.in_s, (int64_t)rs.B * rs.T, packed_in, rs.has_bias_in ? bias_in : nullptr, x,
+                                    gin, rs.H, ilv_mode, (hipStream_t)stream);
+    else
+      st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
+                               rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
+                               ilv_mode);
     if (st != TTRNN_OK) return st;
     return launch_rnn_fwd_fast(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
   }

@@ -23,229 +23,9 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
 
 namespace ttrnn {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-static constexpr int FAST_NW = 8;            // waves per workgroup
-static constexpr int FAST_NT = FAST_NW * 64;
-
-// ---- compile-time shapes ---------------------------------------------------------------------------
-template <int D_, int J0, int J1, int J2, int J3, int I0, int I1, int I2, int I3, int R1, int R2, int R3>
-struct Shp {
-  static constexpr int D = D_;
-  static constexpr int J[4] = {J0, J1, J2, J3};
-  static constexpr int I[4] = {I0, I1, I2, I3};
-  static constexpr int R[5] = {1, D_ > 1 ? R1 : 1, D_ > 2 ? R2 : 1, D_ > 3 ? R3 : 1, 1};
-};
-
-constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
-template <class S>
-constexpr int rows_of(int k) {   // chain rows of stage k: prod_{m>k} I_m * prod_{m<k} J_m
-  int r = 1;
-  for (int m = k + 1; m < S::D; ++m) r *= S::I[m];
-  for (int m = 0; m < k; ++m) r *= S::J[m];
-  return r;
-}
-
-template <class S, int k>
-struct St {
-  static constexpr int R = S::R[k], I = S::I[k], J = S::J[k], R1 = S::R[k + 1];
-  static constexpr int K = J * R1, M = I * R;
-  static constexpr int ROWS = rows_of<S>(k);
-  static constexpr int MT = (M + 15) / 16, RT = (ROWS + 15) / 16;
-  static constexpr int WV = (K % 16 == 0) ? 4 : ((K % 8 == 0) ? 2 : 1);   // floats per fragment read
-  static constexpr int NU = K / (4 * WV);                                 // fragment reads per row tile
-  static constexpr int NSTEP = K / 4;                                     // MFMA k-steps
-  // tile ownership: whole m-tiles per wave, or (few m-tiles) the row tiles of one m-tile split over waves
-  static constexpr bool SPLIT = (MT < FAST_NW) && (FAST_NW % MT == 0);
-  static constexpr int G = SPLIT ? FAST_NW / MT : 1;
-  static constexpr int XM = SPLIT ? 1 : (MT + FAST_NW - 1) / FAST_NW;
-  static constexpr int YR = SPLIT ? (RT + G - 1) / G : RT;
-  static constexpr int NWREG = XM * NSTEP;
-  static constexpr int IN_ELEMS = ROWS * K, OUT_ELEMS = ROWS * M;
-};
-
-template <class S, int k>
-constexpr int nwreg() { return St<S, k>::NWREG; }
-
-template <class S>
-constexpr int in_size_of() { int n = 1; for (int k = 0; k < S::D; ++k) n *= S::J[k]; return n; }
-template <class S>
-constexpr int out_size_of() { int n = 1; for (int k = 0; k < S::D; ++k) n *= S::I[k]; return n; }
-template <class S>
-constexpr int woff_of(int k) {   // float offset of W_k in the canonical packed buffer
-  int off = 0;
-  for (int m = 0; m < k; ++m) off += S::J[m] * S::R[m + 1] * S::I[m] * S::R[m];
-  return off;
-}
-template <class S>
-constexpr int maxmid_of() {      // largest intermediate (floats) that has to live in a ping-pong buffer
-  int best = 4;
-  for (int k = 1; k < S::D; ++k) {
-    int rows = 1;
-    for (int m = k + 1; m < S::D; ++m) rows *= S::I[m];
-    for (int m = 0; m < k; ++m) rows *= S::J[m];
-    int e = rows * S::I[k] * S::R[k];
-    if (e > best) best = e;
-  }
-  return best;
-}
-template <class S>
-constexpr bool shape_ok() {      // what the MFMA path needs: ranks multiple of 4, K multiple of 4
-  for (int k = 0; k < S::D; ++k) {
-    if (k > 0 && S::R[k] % 4 != 0) return false;
-    if ((S::J[k] * S::R[k + 1]) % 4 != 0) return false;
-  }
-  return true;
-}
-
-// float offset of element (row, kk) in the LDS image of a [rows][K] stage input.  For K a multiple of
-// 32 with K/4 a power of two the 16-byte slot index is XOR-swizzled with the row so that the
-// ds_read_b128 fragment reads (lane (c,q) reads slot 4u+q of row 16*rt+c) hit 16 distinct slots per
-// 16-lane group.
-template <int K>
-__device__ __forceinline__ int a_off(int row, int kk) {
-  if constexpr (K % 32 == 0 && is_pow2(K / 4)) {
-    constexpr int ns = K / 4;
-    const int slot = kk >> 2;
-    const int g = (ns >= 16) ? (row & 15) : ((row >> 1) & 7);
-    return ((row * ns + (slot ^ g)) << 2) + (kk & 3);
-  } else {
-    return row * K + kk;
-  }
-}
-
-__device__ __forceinline__ void lds_barrier() {
-  // LDS-only hand-off between the waves of the workgroup: drain this wave's LDS ops, then barrier.
-  // Deliberately no vmcnt wait: the gate-input prefetch and the output stores stay in flight.
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Diagnostic builds only (TTRNN_DIAG=1): per-phase cycle stamps, MI355X guide section 7 "In-kernel stamps".
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define TT_STAMP(idx)                                   \
-  if constexpr (DIAG) {                                 \
-    const unsigned long long now_ = stamp();            \
-    seg[idx] += now_ - last_;                           \
-    last_ = now_;                                       \
-  }
-
-// ---- one chain stage ---------------------------------------------------------------------------------
-template <class S, int k, int NW_>
-__device__ __forceinline__ void load_wfrag(float (&w)[NW_], const float* packed,
-                                           int wave, int lane) {
-  using T = St<S, k>;
-  static_assert(NW_ == T::NWREG, "weight fragment array size");
-  const int r = lane & 15, q = lane >> 4;
-  const float* W = packed + woff_of<S>(k);
-#pragma unroll
-  for (int x = 0; x < T::XM; ++x) {
-    const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
-    const int m = 16 * mt + r;
-#pragma unroll
-    for (int u = 0; u < T::NU; ++u)
-#pragma unroll
-      for (int e = 0; e < T::WV; ++e) {
-        const int kk = (4 * u + q) * T::WV + e;
-        w[x * T::NSTEP + u * T::WV + e] = (mt < T::MT && m < T::M) ? W[kk * T::M + m] : 0.f;
-      }
-  }
-}
-
-// Fragment reads + MFMAs of stage k for the tiles this wave owns.  Ain: LDS image [ROWS][K] (a_off<K>).
-// D[p = 4q + j][c]: p <-> output feature of m-tile mt, c <-> chain row 16*rt + c.
-template <class S, int k, int NW_, int XM_, int YR_>
-__device__ __forceinline__ void stage_mma(const float (&w)[NW_], const float* Ain, f32x4 (&acc)[XM_][YR_], int wave,
-                                          int lane) {
-  using T = St<S, k>;
-  static_assert(NW_ == T::NWREG && XM_ == T::XM && YR_ == T::YR, "stage tile bookkeeping");
-  const int c = lane & 15, q = lane >> 4;
-  float af[T::YR][T::NSTEP];
-#pragma unroll
-  for (int y = 0; y < T::YR; ++y) {
-    const int rt = T::SPLIT ? (wave / T::MT + T::G * y) : y;
-    int row = 16 * rt + c;
-    row = row < T::ROWS ? row : T::ROWS - 1;
-#pragma unroll
-    for (int u = 0; u < T::NU; ++u) {
-      const float* p = Ain + a_off<T::K>(row, (4 * u + q) * T::WV);
-      if constexpr (T::WV == 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
-      } else if constexpr (T::WV == 2) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(p);
-        af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
-      } else {
-        af[y][u] = *p;
-      }
-    }
-  }
-#pragma unroll
-  for (int x = 0; x < T::XM; ++x)
-#pragma unroll
-    for (int y = 0; y < T::YR; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < T::NSTEP; ++s)
-#pragma unroll
-    for (int x = 0; x < T::XM; ++x)
-#pragma unroll
-      for (int y = 0; y < T::YR; ++y)
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[y][s], acc[x][y], 0, 0, 0);
-}
-
-// Cout: LDS image of the next stage input (k > 0) or the flat gate pre-activation vector (k == 0).
-template <class S, int k, int NW_>
-__device__ __forceinline__ void run_stage(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane) {
-  using T = St<S, k>;
-  const int c = lane & 15, q = lane >> 4;
-  f32x4 acc[T::XM][T::YR];
-  stage_mma<S, k>(w, Ain, acc, wave, lane);
-#pragma unroll
-  for (int x = 0; x < T::XM; ++x) {
-    const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
-#pragma unroll
-    for (int y = 0; y < T::YR; ++y) {
-      const int rt = T::SPLIT ? (wave / T::MT + T::G * y) : y;
-      const int row = 16 * rt + c;
-      const int m0 = 16 * mt + 4 * q;
-      if (mt < T::MT && rt < T::RT && row < T::ROWS && m0 < T::M) {
-        if constexpr (k > 0) {
-          // C_k flat index f = i*ROWS*R + row*R + a  ==  A_{k-1} flat index (ops.py:89-90)
-          using N = St<S, k - 1>;
-          const int i = m0 / T::R, a0 = m0 % T::R;
-          const int f = i * (T::ROWS * T::R) + row * T::R + a0;
-          float* p = Cout + a_off<N::K>(f / N::K, f % N::K);
-          *reinterpret_cast<f32x4*>(p) = acc[x][y];
-        } else {
-          // R_0 = 1: m is i_0 and the result is y[o], o = i_0*ROWS + row
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (m0 + j < T::M) Cout[(m0 + j) * T::ROWS + row] = acc[x][y][j];
-        }
-      }
-    }
-  }
-}
-
-// Gate non-linearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp each):
-// absolute error ~1e-7, far inside the 1e-5 parity tolerance, and ~10 instructions instead of the
-// ~80-instruction branchy libm expansions (the gate phase is on the per-step critical path).
-__device__ __forceinline__ float fsigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float ftanh(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-}
 
 // ---- the persistent kernel ---------------------------------------------------------------------------
 // gin: fp32 [B][T][G*H] = W_in x_t + b_in (hoisted).  One workgroup per sample.
@@ -599,18 +379,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
-template <class S>
-static bool shape_matches(const TtShape& s) {
-  if (s.d != S::D) return false;
-  for (int k = 0; k < S::D; ++k)
-    if (s.J[k] != S::J[k] || s.I[k] != S::I[k] || s.R[k] != S::R[k]) return false;
-  return true;
-}
-
 template <class S, int CELL>
 static int launch_one(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
-  static_assert(shape_ok<S>(), "shape not supported by the MFMA path");
+  static_assert(shape_ok_recurrent<S>(), "shape not supported by the MFMA path");
   if constexpr (CELL == TTRNN_LSTM && lstm_fusable<S>()) {
     const char* diag = getenv("TTRNN_DIAG");
     if (diag && diag[0] == '1' && reserve)   // diagnostic build: phase stamps overwrite the reserve buffer
@@ -631,13 +403,6 @@ static int launch_one(const RnnShape& rs, const float* gin, const void* h0, cons
                      (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
-
-// hidden-weight shapes with a specialised kernel
-using ShpH256R8L = Shp<3, 4, 8, 8, 1, 8, 8, 16, 1, 8, 8, 1>;     // cfg2: TT-LSTM H=256 d=3 r=8
-using ShpH256R8G = Shp<3, 4, 8, 8, 1, 8, 8, 12, 1, 8, 8, 1>;     // cfg3: TT-GRU  H=256 d=3 r=8
-using ShpH256R16L = Shp<3, 4, 8, 8, 1, 8, 8, 16, 1, 16, 16, 1>;  // cfg4: TT-LSTM H=256 d=3 r=16
-using ShpH256R16G = Shp<3, 4, 8, 8, 1, 8, 8, 12, 1, 16, 16, 1>;  //       TT-GRU  H=256 d=3 r=16
-using ShpH128R4L = Shp<2, 8, 16, 1, 1, 16, 32, 1, 1, 4, 1, 1>;   // cfg1: TT-LSTM H=128 d=2 r=4
 
 bool fast_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (dtype != TTRNN_F32 || rs.B < 1 || rs.T < 1) return false;

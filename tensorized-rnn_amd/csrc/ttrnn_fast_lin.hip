@@ -1,0 +1,265 @@
+// ttrnn_fast_lin.hip — shape-specialised batched TTLinear forward on fp32 MFMA (gfx950).
+//
+// y[n][out] = TT(cores) x[n][in] + bias for n_rows rows; used for
+//   * the hoisted input projection of the recurrent kernels (all B*T rows in one launch on all CUs, output
+//     gate-interleaved per hidden unit, see ttrnn_core.h:ilv_index), and
+//   * TTLinear.forward itself (t3nsor/layers.py:121-127 -> ops.py:54-93) for the shapes in the table.
+// A workgroup (8 waves) takes NB rows at a time: the chain rows of all NB samples are stacked in one LDS image
+// per stage ([NB*ROWS_k][K_k], same XOR-swizzled layout and MFMA tile code as the recurrent kernel, core
+// fragments resident in VGPRs), the last stage lands in an LDS tile that already has the final memory layout
+// and leaves with coalesced 16-byte stores (+ bias).
+#include <hip/hip_runtime.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+
+namespace ttrnn {
+
+// index of output feature o of stacked sample smp inside the LDS output tile
+template <int G, int OUT>
+__device__ __forceinline__ int ytile_index(int smp, int o, int ilv_mode) {
+  if constexpr (G == 0) {
+    return smp * OUT + o;
+  } else {
+    constexpr int H = OUT / G;
+    const int g = o / H, hid = o - g * H;
+    const int slot = (ilv_mode == 2) ? (g == 1 ? 2 : (g == 2 ? 1 : g)) : g;
+    return (smp * H + hid) * 4 + slot;
+  }
+}
+
+// one chain stage over NB stacked samples; runtime loop over row tiles, two tiles in flight per iteration
+template <class S, int k, int NB, int G, int NW_>
+__device__ __forceinline__ void lin_stage(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane,
+                                          int ilv_mode) {
+  using T = St<S, k>;
+  static_assert(NW_ == T::NWREG, "weight fragment array size");
+  constexpr int TOT = NB * T::ROWS;                 // stacked chain rows
+  constexpr int RT_ALL = (TOT + 15) / 16;
+  constexpr int OUT = out_size_of<S>();
+  constexpr int RSTEP = T::SPLIT ? T::G : 1;
+  const int c = lane & 15, q = lane >> 4;
+  const int rt0 = T::SPLIT ? (wave / T::MT) : 0;
+  for (int rtb = rt0; rtb < RT_ALL; rtb += 2 * RSTEP) {
+    float af[2][T::NSTEP];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      int R = 16 * (rtb + y * RSTEP) + c;
+      R = R < TOT ? R : TOT - 1;
+#pragma unroll
+      for (int u = 0; u < T::NU; ++u) {
+        const float* p = Ain + a_off<T::KP>(R, (4 * u + q) * T::WV);
+        if constexpr (T::WV == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+          af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
+        } else if constexpr (T::WV == 2) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+          af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
+        } else {
+          af[y][u] = *p;
+        }
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < T::XM; ++x) {
+      const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < T::NSTEP; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[1][s], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const f32x4 acc = y == 0 ? acc0 : acc1;
+        const int rt = rtb + y * RSTEP;
+        const int R = 16 * rt + c;
+        const int m0 = 16 * mt + 4 * q;
+        if (mt < T::MT && rt < RT_ALL && R < TOT && m0 < T::M) {
+          const int smp = R / T::ROWS, row = R - smp * T::ROWS;
+          if constexpr (k > 0) {
+            // C_k flat index within the sample == A_{k-1} flat index (ops.py:89-90)
+            using N = St<S, k - 1>;
+            const int i = m0 / T::R, a0 = m0 % T::R;
+            const int f = i * (T::ROWS * T::R) + row * T::R + a0;
+            float* p = Cout + a_off<N::KP>(smp * N::ROWS + f / N::K, f % N::K);
+            *reinterpret_cast<f32x4*>(p) = acc;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (m0 + j < T::M) Cout[ytile_index<G, OUT>(smp, (m0 + j) * T::ROWS + row, ilv_mode)] = acc[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class S, int k, int NB>
+constexpr int mid_elems() {      // floats of the stage-k output image (input of stage k-1), k in 1..D-1
+  return (k >= 1 && k < S::D) ? NB * St<S, (k >= 1 && k < S::D) ? k : 0>::ROWS * St<S, (k >= 1 && k < S::D) ? k : 0>::M : 4;
+}
+
+// G = 0: plain y[n][out];  G = 3/4: gate-interleaved y[n][H][4]
+template <class S, int NB, int G>
+__global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, const float* __restrict__ packed,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ x, float* __restrict__ y,
+                                                               int ilv_mode) {
+  constexpr int D = S::D;
+  constexpr int IN = in_size_of<S>(), OUT = out_size_of<S>();
+  using SL = St<S, D - 1>;
+  constexpr int YT = G == 0 ? OUT : (OUT / (G > 0 ? G : 1)) * 4;     // floats per sample in the output tile
+  constexpr int IMG0 = NB * SL::ROWS * SL::KP;
+
+  __shared__ __attribute__((aligned(16))) float img0[IMG0 > 4 ? IMG0 : 4];
+  __shared__ __attribute__((aligned(16))) float mid1[mid_elems<S, 1, NB>()];
+  __shared__ __attribute__((aligned(16))) float mid2[mid_elems<S, 2, NB>()];
+  __shared__ __attribute__((aligned(16))) float mid3[mid_elems<S, 3, NB>()];
+  __shared__ __attribute__((aligned(16))) float ytile[NB * YT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  float w0[nwreg<S, 0>()];
+  float w1[nwreg<S, (D > 1 ? 1 : 0)>()];
+  float w2[nwreg<S, (D > 2 ? 2 : 0)>()];
+  float w3[nwreg<S, (D > 3 ? 3 : 0)>()];
+  load_wfrag<S, 0>(w0, packed, wave, lane);
+  if constexpr (D > 1) load_wfrag<S, 1>(w1, packed, wave, lane);
+  if constexpr (D > 2) load_wfrag<S, 2>(w2, packed, wave, lane);
+  if constexpr (D > 3) load_wfrag<S, 3>(w3, packed, wave, lane);
+
+  // zero once: the K padding of the first image is never overwritten; a 3-gate tile keeps slot 3 = 0
+  for (int e = tid; e < IMG0; e += FAST_NT) img0[e] = 0.f;
+  if constexpr (G == 3)
+    for (int e = tid; e < NB * YT; e += FAST_NT) ytile[e] = 0.f;
+  __syncthreads();
+
+  const int64_t ntiles = (n_rows + NB - 1) / NB;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * NB;
+    // x rows -> first image: sample smp, feature j -> chain row j / K, column j % K
+    for (int e = tid; e < NB * IN; e += FAST_NT) {
+      const int smp = e / IN, j = e - smp * IN;
+      const float v = (n0 + smp < n_rows) ? x[(n0 + smp) * IN + j] : 0.f;
+      img0[a_off<SL::KP>(smp * SL::ROWS + j / SL::K, j % SL::K)] = v;
+    }
+    __syncthreads();
+    if constexpr (D == 1) {
+      lin_stage<S, 0, NB, G>(w0, img0, ytile, wave, lane, ilv_mode);
+    } else if constexpr (D == 2) {
+      lin_stage<S, 1, NB, G>(w1, img0, mid1, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 0, NB, G>(w0, mid1, ytile, wave, lane, ilv_mode);
+    } else if constexpr (D == 3) {
+      lin_stage<S, 2, NB, G>(w2, img0, mid2, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 1, NB, G>(w1, mid2, mid1, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 0, NB, G>(w0, mid1, ytile, wave, lane, ilv_mode);
+    } else {
+      lin_stage<S, 3, NB, G>(w3, img0, mid3, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 2, NB, G>(w2, mid3, mid2, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 1, NB, G>(w1, mid2, mid1, wave, lane, ilv_mode);
+      __syncthreads();
+      lin_stage<S, 0, NB, G>(w0, mid1, ytile, wave, lane, ilv_mode);
+    }
+    __syncthreads();
+    // coalesced copy-out (+ bias)
+    if constexpr (G > 0) {
+      constexpr int H = OUT / G;
+      const f32x4* yt4 = reinterpret_cast<const f32x4*>(ytile);
+      f32x4* y4 = reinterpret_cast<f32x4*>(y);
+      for (int e = tid; e < NB * H; e += FAST_NT) {
+        const int smp = e / H, hid = e - smp * H;
+        if (n0 + smp < n_rows) {
+          f32x4 v = yt4[e];
+          if (bias) {
+#pragma unroll
+            for (int sl = 0; sl < G; ++sl) {
+              const int g = (ilv_mode == 2) ? (sl == 1 ? 2 : (sl == 2 ? 1 : sl)) : sl;
+              v[sl] += bias[g * H + hid];
+            }
+          }
+          y4[(n0 + smp) * H + hid] = v;
+        }
+      }
+    } else if constexpr (OUT % 4 == 0) {
+      const f32x4* yt4 = reinterpret_cast<const f32x4*>(ytile);
+      f32x4* y4 = reinterpret_cast<f32x4*>(y);
+      constexpr int O4 = OUT / 4;
+      for (int e = tid; e < NB * O4; e += FAST_NT) {
+        const int smp = e / O4, o4 = e - smp * O4;
+        if (n0 + smp < n_rows) {
+          f32x4 v = yt4[e];
+          if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
+          y4[(n0 + smp) * O4 + o4] = v;
+        }
+      }
+    } else {
+      for (int e = tid; e < NB * OUT; e += FAST_NT) {
+        const int smp = e / OUT, o = e - smp * OUT;
+        if (n0 + smp < n_rows) y[(n0 + smp) * OUT + o] = ytile[e] + (bias ? bias[o] : 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- dispatch --------------------------------------------------------------------------------------------
+template <class S, int NB, int G>
+static int launch_lin(int64_t n_rows, const float* packed, const void* bias, const void* x, void* y, int ilv_mode,
+                      hipStream_t stream) {
+  static_assert(shape_ok<S>(), "shape not supported by the MFMA path");
+  const int64_t ntiles = (n_rows + NB - 1) / NB;
+  const int grid = (int)(ntiles < 1 ? 1 : (ntiles > 1024 ? 1024 : ntiles));
+  hipLaunchKernelGGL((k_ttlinear_fwd_fast<S, NB, G>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed,
+                     (const float*)bias, (const float*)x, (float*)y, ilv_mode);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// NB per shape: as many rows as fit 160 KB of LDS with the exact per-stage images
+#define TT_LIN_SHAPES(X)      \
+  X(ShpI1R8L, 16)             \
+  X(ShpI1R8G, 16)             \
+  X(ShpI40R16L, 4)            \
+  X(ShpI1R4L, 32)             \
+  X(ShpH256R8L, 4)            \
+  X(ShpH256R8G, 4)            \
+  X(ShpH256R16L, 2)           \
+  X(ShpH256R16G, 2)           \
+  X(ShpH128R4L, 16)
+
+bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h) {
+  if (dtype != TTRNN_F32) return false;
+#define TT_X(SHAPE, NBV) \
+  if (shape_matches<SHAPE>(s))                                                      \
+    return ilv_h == 0 || (s.out_size % ilv_h == 0 && s.out_size / ilv_h == (out_size_of<SHAPE>() % 3 == 0 ? 3 : 4));
+  TT_LIN_SHAPES(TT_X)
+#undef TT_X
+  return false;
+}
+
+int launch_ttlinear_fwd_fast(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
+                             void* y, int ilv_h, int ilv_mode, hipStream_t stream) {
+  if (n_rows == 0) return TTRNN_OK;
+  const int G = ilv_h > 0 ? s.out_size / ilv_h : 0;
+#define TT_X(SHAPE, NBV)                                                                                        \
+  if (shape_matches<SHAPE>(s)) {                                                                                \
+    if (G == 0) return launch_lin<SHAPE, NBV, 0>(n_rows, packed, bias, x, y, ilv_mode, stream);                 \
+    if constexpr (out_size_of<SHAPE>() % 3 == 0) {                                                              \
+      if (G == 3) return launch_lin<SHAPE, NBV, 3>(n_rows, packed, bias, x, y, ilv_mode, stream);               \
+    } else {                                                                                                    \
+      if (G == 4) return launch_lin<SHAPE, NBV, 4>(n_rows, packed, bias, x, y, ilv_mode, stream);               \
+    }                                                                                                           \
+    return TTRNN_ERR_UNSUPPORTED;                                                                               \
+  }
+  TT_LIN_SHAPES(TT_X)
+#undef TT_X
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn

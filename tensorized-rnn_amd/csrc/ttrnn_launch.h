@@ -52,4 +52,9 @@ int launch_rnn_fwd_fast(const RnnShape& rs, const float* gin, const void* h0, co
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
+// shape-specialised batched TTLinear forward (ttrnn_fast_lin.hip), fp32 only; ilv as launch_ttlinear_fwd
+bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h);
+int launch_ttlinear_fwd_fast(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
+                             void* y, int ilv_h, int ilv_mode, hipStream_t stream);
+
 }  // namespace ttrnn
