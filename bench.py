@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward: the headline metric (no_grad forward). train: forward + BPTT + flat-bucket "
+                         "gradient all-reduce (RCCL) + SGD update, reported in the same unit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,9 +177,26 @@ def main():
     timer = EventTimer()
     F.KERNEL_TIMER = timer
 
+    reducer = None
+    if args.mode == "train":
+        from ttrnn_hip.dist import FlatGradAllReduce
+        model.train()
+        reducer = FlatGradAllReduce(model) if dist is not None else None
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+
     def step():
-        with torch.no_grad():
-            return model(x)
+        if args.mode == "forward":
+            with torch.no_grad():
+                return model(x)
+        opt.zero_grad(set_to_none=True)
+        res = model(x)
+        out = res[0]
+        loss = (out.float() * out.float()).mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.sync()
+        opt.step()
+        return loss
 
     for _ in range(args.warmup):
         step()
@@ -204,7 +224,7 @@ def main():
     t_step = elapsed / args.steps
 
     if rank == 0:
-        flop_per_launch = float(w["flop"]) * w["B"] * w["T"] / launches_per_step
+        flop_per_launch = float(w["flop"]) * w["B"] * w["T"] / max(launches_per_step, 1e-9)
         peak = PEAK_FP32_TFLOPS if w["dtype"] == "f32" else PEAK_BF16_TFLOPS
         achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
         line = {
@@ -218,7 +238,8 @@ def main():
             "dtype": w["dtype"], "data": "synthetic",
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
                        "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
-                       "mode": "forward (no_grad), inputs resident in HBM"},
+                       "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
+                                "train step: forward + BPTT + gradient all-reduce + SGD, inputs resident in HBM")},
             "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,

@@ -83,7 +83,7 @@ int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const 
   if (n_rows == 0) return TTRNN_OK;
   if (!packed || !x || !y) return TTRNN_ERR_NULL;
   if (!force_generic() && fast_ttlinear_fwd_available(s, dtype, 0))
-    return launch_ttlinear_fwd_fast(s, n_rows, packed, bias, x, y, 0, 0, (hipStream_t)stream);
+    return launch_ttlinear_fwd_fast(s, dtype, false, n_rows, packed, bias, x, y, 0, 0, (hipStream_t)stream);
   const LinPlan p = plan_ttlinear_fwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_ttlinear_fwd(s, p, dtype, n_rows, packed, bias, x, y, workspace, (hipStream_t)stream);
@@ -126,6 +126,10 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   const int64_t n_rows = (int64_t)rs.B * rs.T;
   f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [B][T][H][4]
   f.lin_fast = fast_ttlinear_fwd_available(rs.in_s, dtype, rs.H);
+  if (!f.lin_fast && dtype != TTRNN_F32) {   // the generic K-in writes storage-typed output; gin must be fp32
+    f.use = false;
+    return f;
+  }
   if (!f.lin_fast) {
     f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
     f.lin_ws_bytes = f.lin.ws_bytes;
@@ -174,14 +178,15 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
     const int ilv_mode = rs.cell == TTRNN_LSTM ? 2 : 1;
     if (f.lin_fast)
-      st = launch_ttlinear_fwd_fast(rs.in_s, (int64_t)rs.B * rs.T, packed_in, rs.has_bias_in ? bias_in : nullptr, x,
-                                    gin, rs.H, ilv_mode, (hipStream_t)stream);
+      st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, (int64_t)rs.B * rs.T, packed_in,
+                                    rs.has_bias_in ? bias_in : nullptr, x, gin, rs.H, ilv_mode, (hipStream_t)stream);
     else
       st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
                                rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
                                ilv_mode);
     if (st != TTRNN_OK) return st;
-    return launch_rnn_fwd_fast(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
+    return launch_rnn_fwd_fast(rs, desc->dtype, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
+                               (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, false);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

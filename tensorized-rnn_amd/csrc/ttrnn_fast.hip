@@ -27,14 +27,21 @@
 
 namespace ttrnn {
 
+// what a value becomes after a round trip through the storage type (h is fed back as stored)
+template <typename TS>
+__device__ __forceinline__ float round_storage(float v) {
+  if constexpr (sizeof(TS) == 2) return bf16_to_f32(f32_to_bf16(v));
+  else return v;
+}
+
 // ---- the persistent kernel ---------------------------------------------------------------------------
 // gin: fp32 [B][T][G*H] = W_in x_t + b_in (hoisted).  One workgroup per sample.
-template <class S, int CELL>
+template <class S, int CELL, typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const float* __restrict__ gin,
-                                                          const float* __restrict__ h0, const float* __restrict__ c0,
+                                                          const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
-                                                          const float* __restrict__ bias_hid, float* __restrict__ out,
-                                                          float* __restrict__ hT, float* __restrict__ cT,
+                                                          const TS* __restrict__ bias_hid, TS* __restrict__ out,
+                                                          TS* __restrict__ hT, TS* __restrict__ cT,
                                                           float* __restrict__ reserve) {
   constexpr int D = S::D;
   constexpr int H = in_size_of<S>();
@@ -73,10 +80,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
     const bool ok = hid < H;
-    hst[u] = (ok && h0) ? h0[b * H + hid] : 0.f;
-    cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? c0[b * H + hid] : 0.f;
+    hst[u] = (ok && h0) ? ld(h0, b * H + hid) : 0.f;
+    cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? ld(c0, b * H + hid) : 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) bh[u][g] = (ok && bias_hid) ? bias_hid[g * H + hid] : 0.f;
+    for (int g = 0; g < G; ++g) bh[u][g] = (ok && bias_hid) ? ld(bias_hid, g * H + hid) : 0.f;
     gi[u] = (ok && T > 0) ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};
     if (ok) hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hst[u];
   }
@@ -134,8 +141,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
           hy = (1.0f - zg) * ng + zg * hst[u];
           if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
         }
+        // the stored output is what the next step (and the next layer) sees: round once to the storage type
+        st(out, bt * H + hid, hy);
+        hy = ld(out, bt * H + hid);
         hst[u] = hy;
-        out[bt * H + hid] = hy;
         hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hy;
         // prefetch the hoisted input projection of the next step; consumed one iteration later
         if (t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
@@ -147,8 +156,8 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
     if (hid < H) {
-      if (hT) hT[b * H + hid] = hst[u];
-      if (CELL == TTRNN_LSTM && cT) cT[b * H + hid] = cst[u];
+      if (hT) st(hT, b * H + hid, hst[u]);
+      if (CELL == TTRNN_LSTM && cT) st(cT, b * H + hid, cst[u]);
     }
   }
 }
@@ -197,12 +206,12 @@ __device__ __forceinline__ void load_wfrag0_lstm(float (&w)[NW_], const float* p
   }
 }
 
-template <class S, bool DIAG>
+template <class S, bool DIAG, typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const float* __restrict__ gin,
-                                                            const float* __restrict__ h0, const float* __restrict__ c0,
+                                                            const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                             const float* __restrict__ packed_hid,
-                                                            const float* __restrict__ bias_hid, float* __restrict__ out,
-                                                            float* __restrict__ hT, float* __restrict__ cT,
+                                                            const TS* __restrict__ bias_hid, TS* __restrict__ out,
+                                                            TS* __restrict__ hT, TS* __restrict__ cT,
                                                             float* __restrict__ reserve) {
   constexpr int D = S::D;
   constexpr int H = in_size_of<S>();
@@ -251,14 +260,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
       ok[x][y] = mt < T0::MT && rt < T0::RT && row < T0::ROWS && par < P;
       hid[x][y] = ok[x][y] ? par * T0::ROWS + row : 0;
       const int hd = hid[x][y];
-      hst[x][y] = (ok[x][y] && h0) ? h0[b * H + hd] : 0.f;
-      cst[x][y] = (ok[x][y] && c0) ? c0[b * H + hd] : 0.f;
+      hst[x][y] = (ok[x][y] && h0) ? ld(h0, b * H + hd) : 0.f;
+      cst[x][y] = (ok[x][y] && c0) ? ld(c0, b * H + hd) : 0.f;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         // slot s of the interleaved layout <-> reference gate index: i,g,f,o -> 0,2,1,3
         const int slot = PAIR ? 2 * pair + g : g;
         const int gate = slot == 1 ? 2 : (slot == 2 ? 1 : slot);
-        bh[x][y][g] = (ok[x][y] && bias_hid) ? bias_hid[gate * H + hd] : 0.f;
+        bh[x][y][g] = (ok[x][y] && bias_hid) ? ld(bias_hid, gate * H + hd) : 0.f;
         gi[x][y][g] = (ok[x][y] && T > 0) ? gin[((b * T) * H + hd) * 4 + slot] : 0.f;
       }
       if (ok[x][y] && pair) hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hst[x][y];
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(prod), __float_as_uint(prod), false, false);
           const float ig_g = __uint_as_float(sw[0]);                                         // lanes 32-63 <- lanes 0-31
           const float cy = u * cst[x][y] + ig_g;                                             // lstm.py:31
-          const float hy = v * ftanh(cy);                                                    // lstm.py:32
+          const float hy = round_storage<TS>(v * ftanh(cy));                                 // lstm.py:32
           if (reserve && ok[x][y]) {
             float* rv = reserve + (bt * H + hd) * 5 + 2 * pair;                              // i,g | f,o,c
             rv[0] = u; rv[1] = v;
@@ -328,7 +337,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           if (ok[x][y] && pair) {
             cst[x][y] = cy;
             hst[x][y] = hy;
-            out[bt * H + hd] = hy;                                                           // lstm.py:133
+            st(out, bt * H + hd, hy);                                                        // lstm.py:133
             hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           }
           if (ok[x][y] && t + 1 < T) {
@@ -341,10 +350,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           const float fg = fsigmoid(acc[x][y][1] + gi[x][y][2] + bh[x][y][2]);     // lstm.py:27
           const float og = fsigmoid(acc[x][y][3] + gi[x][y][3] + bh[x][y][3]);     // lstm.py:29
           const float cy = fg * cst[x][y] + ig * gg;                               // lstm.py:31
-          const float hy = og * ftanh(cy);                                         // lstm.py:32
+          const float hy = round_storage<TS>(og * ftanh(cy));                      // lstm.py:32
           cst[x][y] = cy;
           hst[x][y] = hy;
-          out[bt * H + hd] = hy;                                                   // lstm.py:133
+          st(out, bt * H + hd, hy);                                                // lstm.py:133
           hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           if (reserve) {
             float* rv = reserve + (bt * H + hd) * 5;
@@ -365,8 +374,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
 #pragma unroll
     for (int y = 0; y < T0::YR; ++y)
       if (ok[x][y] && pair) {
-        if (hT) hT[b * H + hid[x][y]] = hst[x][y];
-        if (cT) cT[b * H + hid[x][y]] = cst[x][y];
+        if (hT) st(hT, b * H + hid[x][y], hst[x][y]);
+        if (cT) st(cT, b * H + hid[x][y], cst[x][y]);
       }
   if constexpr (DIAG) {
     // stamps leave through a buffer nothing else reads: the caller passes a scratch `reserve`
@@ -379,45 +388,49 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
-template <class S, int CELL>
-static int launch_one(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
-                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
+template <class S, int CELL, typename TS>
+static int launch_one_t(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
   static_assert(shape_ok_recurrent<S>(), "shape not supported by the MFMA path");
+  const TS* bh = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
   if constexpr (CELL == TTRNN_LSTM && lstm_fusable<S>()) {
     const char* diag = getenv("TTRNN_DIAG");
     if (diag && diag[0] == '1' && reserve)   // diagnostic build: phase stamps overwrite the reserve buffer
-      hipLaunchKernelGGL((k_lstm_fwd_fused<S, true>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                         (const float*)h0, (const float*)c0, packed_hid,
-                         rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,
-                         (float*)cT, reserve);
+      hipLaunchKernelGGL((k_lstm_fwd_fused<S, true, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                         (const TS*)h0, (const TS*)c0, packed_hid, bh, (TS*)out, (TS*)hT, (TS*)cT, reserve);
     else
-      hipLaunchKernelGGL((k_lstm_fwd_fused<S, false>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                         (const float*)h0, (const float*)c0, packed_hid,
-                         rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,
-                         (float*)cT, reserve);
+      hipLaunchKernelGGL((k_lstm_fwd_fused<S, false, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                         (const TS*)h0, (const TS*)c0, packed_hid, bh, (TS*)out, (TS*)hT, (TS*)cT, reserve);
     return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((k_rnn_fwd_fast<S, CELL>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                     (const float*)h0, (const float*)c0, packed_hid,
-                     rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr, (float*)out, (float*)hT,
-                     (float*)cT, reserve);
+  hipLaunchKernelGGL((k_rnn_fwd_fast<S, CELL, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                     (const TS*)h0, (const TS*)c0, packed_hid, bh, (TS*)out, (TS*)hT, (TS*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+template <class S, int CELL>
+static int launch_one(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                      hipStream_t stream) {
+  return dtype == TTRNN_F32
+             ? launch_one_t<S, CELL, float>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream)
+             : launch_one_t<S, CELL, bf16_t>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream);
+}
+
 bool fast_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  if (dtype != TTRNN_F32 || rs.B < 1 || rs.T < 1) return false;
+  if ((dtype != TTRNN_F32 && dtype != TTRNN_BF16) || rs.B < 1 || rs.T < 1) return false;
   if (rs.cell == TTRNN_LSTM)
     return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s) ||
            shape_matches<ShpH128R4L>(rs.hid_s);
   return shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s);
 }
 
-int launch_rnn_fwd_fast(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream) {
 #define TT_TRY(SHAPE, CELL)                                                                         \
   if (rs.cell == CELL && shape_matches<SHAPE>(rs.hid_s))                                            \
-    return launch_one<SHAPE, CELL>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream)
+    return launch_one<SHAPE, CELL>(rs, dtype, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream)
   TT_TRY(ShpH256R8L, TTRNN_LSTM);
   TT_TRY(ShpH256R16L, TTRNN_LSTM);
   TT_TRY(ShpH128R4L, TTRNN_LSTM);

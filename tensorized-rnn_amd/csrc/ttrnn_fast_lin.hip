@@ -15,6 +15,15 @@
 
 namespace ttrnn {
 
+__device__ __forceinline__ void store4(float* y, size_t idx, f32x4 v) { *reinterpret_cast<f32x4*>(y + idx) = v; }
+__device__ __forceinline__ void store4(bf16_t* y, size_t idx, f32x4 v) {
+  typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+  u16x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = f32_to_bf16(v[j]).v;
+  *reinterpret_cast<u16x4*>(y + idx) = r;
+}
+
 // index of output feature o of stacked sample smp inside the LDS output tile
 template <int G, int OUT>
 __device__ __forceinline__ int ytile_index(int smp, int o, int ilv_mode) {
@@ -101,10 +110,10 @@ constexpr int mid_elems() {      // floats of the stage-k output image (input of
 }
 
 // G = 0: plain y[n][out];  G = 3/4: gate-interleaved y[n][H][4]
-template <class S, int NB, int G>
+template <class S, int NB, int G, typename TI, typename TO>
 __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, const float* __restrict__ packed,
-                                                               const float* __restrict__ bias,
-                                                               const float* __restrict__ x, float* __restrict__ y,
+                                                               const TI* __restrict__ bias,
+                                                               const TI* __restrict__ x, TO* __restrict__ y,
                                                                int ilv_mode) {
   constexpr int D = S::D;
   constexpr int IN = in_size_of<S>(), OUT = out_size_of<S>();
@@ -142,7 +151,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, c
     // x rows -> first image: sample smp, feature j -> chain row j / K, column j % K
     for (int e = tid; e < NB * IN; e += FAST_NT) {
       const int smp = e / IN, j = e - smp * IN;
-      const float v = (n0 + smp < n_rows) ? x[(n0 + smp) * IN + j] : 0.f;
+      const float v = (n0 + smp < n_rows) ? ld(x, (n0 + smp) * IN + j) : 0.f;
       img0[a_off<SL::KP>(smp * SL::ROWS + j / SL::K, j % SL::K)] = v;
     }
     __syncthreads();
@@ -172,7 +181,6 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, c
     if constexpr (G > 0) {
       constexpr int H = OUT / G;
       const f32x4* yt4 = reinterpret_cast<const f32x4*>(ytile);
-      f32x4* y4 = reinterpret_cast<f32x4*>(y);
       for (int e = tid; e < NB * H; e += FAST_NT) {
         const int smp = e / H, hid = e - smp * H;
         if (n0 + smp < n_rows) {
@@ -181,28 +189,30 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, c
 #pragma unroll
             for (int sl = 0; sl < G; ++sl) {
               const int g = (ilv_mode == 2) ? (sl == 1 ? 2 : (sl == 2 ? 1 : sl)) : sl;
-              v[sl] += bias[g * H + hid];
+              v[sl] += ld(bias, g * H + hid);
             }
           }
-          y4[(n0 + smp) * H + hid] = v;
+          store4(y, ((n0 + smp) * H + hid) * 4, v);
         }
       }
     } else if constexpr (OUT % 4 == 0) {
       const f32x4* yt4 = reinterpret_cast<const f32x4*>(ytile);
-      f32x4* y4 = reinterpret_cast<f32x4*>(y);
       constexpr int O4 = OUT / 4;
       for (int e = tid; e < NB * O4; e += FAST_NT) {
         const int smp = e / O4, o4 = e - smp * O4;
         if (n0 + smp < n_rows) {
           f32x4 v = yt4[e];
-          if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
-          y4[(n0 + smp) * O4 + o4] = v;
+          if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += ld(bias, 4 * o4 + j);
+          }
+          store4(y, ((n0 + smp) * O4 + o4) * 4, v);
         }
       }
     } else {
       for (int e = tid; e < NB * OUT; e += FAST_NT) {
         const int smp = e / OUT, o = e - smp * OUT;
-        if (n0 + smp < n_rows) y[(n0 + smp) * OUT + o] = ytile[e] + (bias ? bias[o] : 0.f);
+        if (n0 + smp < n_rows) st(y, (n0 + smp) * OUT + o, ytile[e] + (bias ? ld(bias, o) : 0.f));
       }
     }
     __syncthreads();
@@ -210,15 +220,23 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_fast(int64_t n_rows, c
 }
 
 // ---- dispatch --------------------------------------------------------------------------------------------
-template <class S, int NB, int G>
-static int launch_lin(int64_t n_rows, const float* packed, const void* bias, const void* x, void* y, int ilv_mode,
-                      hipStream_t stream) {
+template <class S, int NB, int G, typename TI, typename TO>
+static int launch_lin_t(int64_t n_rows, const float* packed, const void* bias, const void* x, void* y, int ilv_mode,
+                        hipStream_t stream) {
   static_assert(shape_ok<S>(), "shape not supported by the MFMA path");
   const int64_t ntiles = (n_rows + NB - 1) / NB;
   const int grid = (int)(ntiles < 1 ? 1 : (ntiles > 1024 ? 1024 : ntiles));
-  hipLaunchKernelGGL((k_ttlinear_fwd_fast<S, NB, G>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed,
-                     (const float*)bias, (const float*)x, (float*)y, ilv_mode);
+  hipLaunchKernelGGL((k_ttlinear_fwd_fast<S, NB, G, TI, TO>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed,
+                     (const TI*)bias, (const TI*)x, (TO*)y, ilv_mode);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+template <class S, int NB, int G>
+static int launch_lin(int dtype, bool y_f32, int64_t n_rows, const float* packed, const void* bias, const void* x,
+                      void* y, int ilv_mode, hipStream_t stream) {
+  if (dtype == TTRNN_F32) return launch_lin_t<S, NB, G, float, float>(n_rows, packed, bias, x, y, ilv_mode, stream);
+  if (y_f32) return launch_lin_t<S, NB, G, bf16_t, float>(n_rows, packed, bias, x, y, ilv_mode, stream);
+  return launch_lin_t<S, NB, G, bf16_t, bf16_t>(n_rows, packed, bias, x, y, ilv_mode, stream);
 }
 
 // NB per shape: as many rows as fit 160 KB of LDS with the exact per-stage images
@@ -234,8 +252,8 @@ static int launch_lin(int64_t n_rows, const float* packed, const void* bias, con
   X(ShpH128R4L, 16)
 
 bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h) {
-  if (dtype != TTRNN_F32) return false;
-#define TT_X(SHAPE, NBV) \
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
+#define TT_X(SHAPE, NBV)                                                            \
   if (shape_matches<SHAPE>(s))                                                      \
     return ilv_h == 0 || (s.out_size % ilv_h == 0 && s.out_size / ilv_h == (out_size_of<SHAPE>() % 3 == 0 ? 3 : 4));
   TT_LIN_SHAPES(TT_X)
@@ -243,17 +261,17 @@ bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h) {
   return false;
 }
 
-int launch_ttlinear_fwd_fast(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
-                             void* y, int ilv_h, int ilv_mode, hipStream_t stream) {
+int launch_ttlinear_fwd_fast(const TtShape& s, int dtype, bool y_f32, int64_t n_rows, const float* packed,
+                             const void* bias, const void* x, void* y, int ilv_h, int ilv_mode, hipStream_t stream) {
   if (n_rows == 0) return TTRNN_OK;
   const int G = ilv_h > 0 ? s.out_size / ilv_h : 0;
 #define TT_X(SHAPE, NBV)                                                                                        \
   if (shape_matches<SHAPE>(s)) {                                                                                \
-    if (G == 0) return launch_lin<SHAPE, NBV, 0>(n_rows, packed, bias, x, y, ilv_mode, stream);                 \
+    if (G == 0) return launch_lin<SHAPE, NBV, 0>(dtype, y_f32, n_rows, packed, bias, x, y, ilv_mode, stream);   \
     if constexpr (out_size_of<SHAPE>() % 3 == 0) {                                                              \
-      if (G == 3) return launch_lin<SHAPE, NBV, 3>(n_rows, packed, bias, x, y, ilv_mode, stream);               \
+      if (G == 3) return launch_lin<SHAPE, NBV, 3>(dtype, true, n_rows, packed, bias, x, y, ilv_mode, stream);  \
     } else {                                                                                                    \
-      if (G == 4) return launch_lin<SHAPE, NBV, 4>(n_rows, packed, bias, x, y, ilv_mode, stream);               \
+      if (G == 4) return launch_lin<SHAPE, NBV, 4>(dtype, true, n_rows, packed, bias, x, y, ilv_mode, stream);  \
     }                                                                                                           \
     return TTRNN_ERR_UNSUPPORTED;                                                                               \
   }

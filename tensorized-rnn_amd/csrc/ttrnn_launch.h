@@ -48,13 +48,14 @@ int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, cons
 
 // shape-specialised MFMA recurrent kernel (ttrnn_fast.hip); gin = hoisted input projection, fp32 [B][T][G*H]
 bool fast_rnn_fwd_available(const RnnShape& rs, int dtype);
-int launch_rnn_fwd_fast(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
-// shape-specialised batched TTLinear forward (ttrnn_fast_lin.hip), fp32 only; ilv as launch_ttlinear_fwd
+// shape-specialised batched TTLinear forward (ttrnn_fast_lin.hip); ilv as launch_ttlinear_fwd.  x / bias have
+// storage type `dtype`; y has `dtype` too unless y_f32 (hoisted gate inputs are always fp32).
 bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h);
-int launch_ttlinear_fwd_fast(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
-                             void* y, int ilv_h, int ilv_mode, hipStream_t stream);
+int launch_ttlinear_fwd_fast(const TtShape& s, int dtype, bool y_f32, int64_t n_rows, const float* packed,
+                             const void* bias, const void* x, void* y, int ilv_h, int ilv_mode, hipStream_t stream);
 
 }  // namespace ttrnn
