@@ -115,7 +115,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
  * LSTMCell.forward lstm.py:23-32 / GRUCell.forward gru.py:25-44 and both TTLinear chains.
  *   x[B][T][in], h0/c0[B][H] (NULL = zeros, lstm.py:88-91) -> out[B][T][H], hT/cT[B][H] (may be NULL).
  *   c0 / cT are ignored for GRU.
- *   reserve: NULL for inference; else fp32 [B][T][H][5] (LSTM, per hidden unit: i,g,f,o,c_t) or
+ *   reserve: NULL for inference; else fp32 [B][T][H][8] (LSTM, per hidden unit: i,g,f,o,c_t,-,-,-) or
  *            [B][T][H][4] (GRU: r,z,n, hidden_part_n) saved for ttrnn_rnn_backward. */
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc);
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc);

@@ -102,6 +102,9 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
   if (!packed || !dy) return TTRNN_ERR_NULL;
   if (d_packed && !x) return TTRNN_ERR_NULL;
   if (!dx && !d_packed && !d_bias) return TTRNN_OK;
+  if (!force_generic() && fast_ttlinear_bwd_available(s, dtype, dy_dtype))
+    return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
+                                    (hipStream_t)stream);
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
@@ -148,13 +151,14 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) return 0;
   return plan_rnn_generic(rs, true).ws_bytes;
 }
 
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
-  const size_t per = rs.cell == TTRNN_LSTM ? (size_t)5 * rs.H : (size_t)4 * rs.H;
+  const size_t per = rs.cell == TTRNN_LSTM ? (size_t)8 * rs.H : (size_t)4 * rs.H;
   return (size_t)rs.B * rs.T * per * sizeof(float);
 }
 
@@ -205,6 +209,9 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (!packed_hid) return TTRNN_ERR_NULL;
   if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
+  if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
+    return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
+                               d_gates_hid, d_h0, d_c0, (hipStream_t)stream);
   const RnnPlan p = plan_rnn_generic(rs, true);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_rnn_bwd_generic(rs, p, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,

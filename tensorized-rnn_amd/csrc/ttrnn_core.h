@@ -402,7 +402,7 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* hbuf, float* cbuf, float* gin) {
   const int H = rs.H, G = rs.G, GH = G * H, in = rs.in, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RU = lstm ? 5 : 4;           // reserve floats per (b, t, hidden unit): LSTM i,g,f,o,c  GRU r,z,n,hn
+  const int RU = lstm ? 8 : 4;           // reserve floats per (b, t, hidden unit): LSTM i,g,f,o,c,-,-,-  GRU r,z,n,hn
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;
@@ -495,7 +495,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* dh, float* dc, float* dhd) {
   const int H = rs.H, G = rs.G, GH = G * H, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RU = lstm ? 5 : 4;
+  const int RU = lstm ? 8 : 4;
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
           hy = og * ftanh(cy);
           cst[u] = cy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hid) * 5;
+            float* rv = reserve + (bt * H + hid) * 8;
             rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
         } else {
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           const float cy = u * cst[x][y] + ig_g;                                             // lstm.py:31
           const float hy = round_storage<TS>(v * ftanh(cy));                                 // lstm.py:32
           if (reserve && ok[x][y]) {
-            float* rv = reserve + (bt * H + hd) * 5 + 2 * pair;                              // i,g | f,o,c
+            float* rv = reserve + (bt * H + hd) * 8 + 2 * pair;                              // i,g | f,o,c
             rv[0] = u; rv[1] = v;
             if (pair) rv[2] = cy;
           }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           st(out, bt * H + hd, hy);                                                // lstm.py:133
           hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hd) * 5;
+            float* rv = reserve + (bt * H + hd) * 8;
             rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
           if (t + 1 < T) {

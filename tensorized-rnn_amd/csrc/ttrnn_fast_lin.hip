@@ -24,86 +24,6 @@ __device__ __forceinline__ void store4(bf16_t* y, size_t idx, f32x4 v) {
   *reinterpret_cast<u16x4*>(y + idx) = r;
 }
 
-// index of output feature o of stacked sample smp inside the LDS output tile
-template <int G, int OUT>
-__device__ __forceinline__ int ytile_index(int smp, int o, int ilv_mode) {
-  if constexpr (G == 0) {
-    return smp * OUT + o;
-  } else {
-    constexpr int H = OUT / G;
-    const int g = o / H, hid = o - g * H;
-    const int slot = (ilv_mode == 2) ? (g == 1 ? 2 : (g == 2 ? 1 : g)) : g;
-    return (smp * H + hid) * 4 + slot;
-  }
-}
-
-// one chain stage over NB stacked samples; runtime loop over row tiles, two tiles in flight per iteration
-template <class S, int k, int NB, int G, int NW_>
-__device__ __forceinline__ void lin_stage(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane,
-                                          int ilv_mode) {
-  using T = St<S, k>;
-  static_assert(NW_ == T::NWREG, "weight fragment array size");
-  constexpr int TOT = NB * T::ROWS;                 // stacked chain rows
-  constexpr int RT_ALL = (TOT + 15) / 16;
-  constexpr int OUT = out_size_of<S>();
-  constexpr int RSTEP = T::SPLIT ? T::G : 1;
-  const int c = lane & 15, q = lane >> 4;
-  const int rt0 = T::SPLIT ? (wave / T::MT) : 0;
-  for (int rtb = rt0; rtb < RT_ALL; rtb += 2 * RSTEP) {
-    float af[2][T::NSTEP];
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      int R = 16 * (rtb + y * RSTEP) + c;
-      R = R < TOT ? R : TOT - 1;
-#pragma unroll
-      for (int u = 0; u < T::NU; ++u) {
-        const float* p = Ain + a_off<T::KP>(R, (4 * u + q) * T::WV);
-        if constexpr (T::WV == 4) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-          af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
-        } else if constexpr (T::WV == 2) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(p);
-          af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
-        } else {
-          af[y][u] = *p;
-        }
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < T::XM; ++x) {
-      const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < T::NSTEP; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[1][s], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        const f32x4 acc = y == 0 ? acc0 : acc1;
-        const int rt = rtb + y * RSTEP;
-        const int R = 16 * rt + c;
-        const int m0 = 16 * mt + 4 * q;
-        if (mt < T::MT && rt < RT_ALL && R < TOT && m0 < T::M) {
-          const int smp = R / T::ROWS, row = R - smp * T::ROWS;
-          if constexpr (k > 0) {
-            // C_k flat index within the sample == A_{k-1} flat index (ops.py:89-90)
-            using N = St<S, k - 1>;
-            const int i = m0 / T::R, a0 = m0 % T::R;
-            const int f = i * (T::ROWS * T::R) + row * T::R + a0;
-            float* p = Cout + a_off<N::KP>(smp * N::ROWS + f / N::K, f % N::K);
-            *reinterpret_cast<f32x4*>(p) = acc;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (m0 + j < T::M) Cout[ytile_index<G, OUT>(smp, (m0 + j) * T::ROWS + row, ilv_mode)] = acc[j];
-          }
-        }
-      }
-    }
-  }
-}
-
 template <class S, int k, int NB>
 constexpr int mid_elems() {      // floats of the stage-k output image (input of stage k-1), k in 1..D-1
   return (k >= 1 && k < S::D) ? NB * St<S, (k >= 1 && k < S::D) ? k : 0>::ROWS * St<S, (k >= 1 && k < S::D) ? k : 0>::M : 4;

@@ -58,4 +58,16 @@ bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h);
 int launch_ttlinear_fwd_fast(const TtShape& s, int dtype, bool y_f32, int64_t n_rows, const float* packed,
                              const void* bias, const void* x, void* y, int ilv_h, int ilv_mode, hipStream_t stream);
 
+// shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
+bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);
+int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
+                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                        const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, hipStream_t stream);
+
+// shape-specialised batched TTLinear backward (ttrnn_fast_bwd.hip); accumulates into d_packed / d_bias
+bool fast_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
+int launch_ttlinear_bwd_fast(const TtShape& s, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                             const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
+                             hipStream_t stream);
+
 }  // namespace ttrnn
