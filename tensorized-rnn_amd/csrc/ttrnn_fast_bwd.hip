@@ -145,6 +145,91 @@ __device__ __forceinline__ void run_bstage(const float (&w)[NW_], const float* C
   }
 }
 
+// ---- last transposed stage (k = D-1): few output tiles, long contraction -> split the contraction over waves ----
+// Stage D-1 produces dh[ROWS][K = J_{D-1}]: KT*RT tiles only (cfg2: 2) but M/4 k-steps (cfg2: 32).  Run as is it
+// is a 32-deep dependent MFMA chain on two waves while six idle.  Instead wave w takes tile (w % tiles) and
+// contraction slice (w / tiles); the CS partial results go to dhpart[slice][H] and the gate phase adds them up.
+template <class S>
+constexpr int last_tiles() { return Tb<S, S::D - 1>::KT * Tb<S, S::D - 1>::RT; }
+template <class S>
+constexpr int last_split() {
+  constexpr int tiles = last_tiles<S>();
+  if (tiles >= FAST_NW || FAST_NW % tiles != 0) return 1;
+  int cs = FAST_NW / tiles;
+  while (cs > 1 && Tb<S, S::D - 1>::NU % cs != 0) cs >>= 1;
+  return cs;
+}
+template <class S>
+constexpr int nwreg_last() { return Tb<S, S::D - 1>::NSTEP / last_split<S>(); }
+
+template <class S, int NW_>
+__device__ __forceinline__ void load_wfrag_b_last(float (&w)[NW_], const float* packed, int wave, int lane) {
+  constexpr int k = S::D - 1;
+  using T = Tb<S, k>;
+  constexpr int tiles = last_tiles<S>(), CS = last_split<S>(), UPS = T::NU / CS;
+  static_assert(NW_ == UPS * T::WV, "weight fragment array size");
+  const int r = lane & 15, q = lane >> 4;
+  const float* W = packed + woff_of<S>(k);
+  const int tl = wave % tiles, sl = wave / tiles;
+  const int kk = 16 * (tl % T::KT) + r;
+#pragma unroll
+  for (int u = 0; u < UPS; ++u)
+#pragma unroll
+    for (int e = 0; e < T::WV; ++e) {
+      const int m = (4 * (sl * UPS + u) + q) * T::WV + e;
+      w[u * T::WV + e] = (sl < CS && kk < T::K) ? W[kk * T::M + m] : 0.f;
+    }
+}
+
+template <class S, int NW_>
+__device__ __forceinline__ void run_bstage_last(const float (&w)[NW_], const float* Cin, float* dhpart, int wave,
+                                                int lane) {
+  constexpr int k = S::D - 1;
+  using T = Tb<S, k>;
+  constexpr int tiles = last_tiles<S>(), CS = last_split<S>(), UPS = T::NU / CS;
+  constexpr int H = T::ROWS * T::K;
+  const int c = lane & 15, q = lane >> 4;
+  const int tl = wave % tiles, sl = wave / tiles;
+  const int kt = tl % T::KT, rt = tl / T::KT;
+  if (sl >= CS) return;
+  int row = 16 * rt + c;
+  const bool rok = row < T::ROWS;
+  row = rok ? row : T::ROWS - 1;
+  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < UPS; ++u) {
+    const float* p = Cin + b_off<S, k>(row, (4 * (sl * UPS + u) + q) * T::WV);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (T::WV == 4) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(p);
+      v[0] = t4[0]; v[1] = t4[1]; v[2] = t4[2]; v[3] = t4[3];
+    } else if constexpr (T::WV == 2) {
+      const f32x2 t2 = *reinterpret_cast<const f32x2*>(p);
+      v[0] = t2[0]; v[1] = t2[1];
+    } else {
+      v[0] = *p;
+    }
+#pragma unroll
+    for (int e = 0; e < T::WV; ++e) {
+      // two interleaved accumulators hide the 40-cycle dependent-MFMA latency
+      if ((u * T::WV + e) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u * T::WV + e], v[e], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u * T::WV + e], v[e], acc0, 0, 0, 0);
+    }
+  }
+  const f32x4 acc = acc0 + acc1;
+  const int kk0 = 16 * kt + 4 * q;
+  if (rok && kk0 < T::K) {
+    float* dst = dhpart + sl * H + row * T::K + kk0;
+    if constexpr (T::K % 4 == 0) {
+      *reinterpret_cast<f32x4*>(dst) = acc;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (kk0 + j < T::K) dst[j] = acc[j];
+    }
+  }
+}
+
 // dg_in / dg_hid: fp32 [B][T][G*H] (plain layout expected by ttrnn_ttlinear_backward's dy)
 template <class S, int CELL, typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS* __restrict__ out,
@@ -163,7 +248,8 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
   constexpr int HPT = (H + FAST_NT - 1) / FAST_NT;
   constexpr int MAXC = maxc_of<S>();
 
-  __shared__ __attribute__((aligned(16))) float dhbuf[H];
+  constexpr int CS = last_split<S>();
+  __shared__ __attribute__((aligned(16))) float dhbuf[CS * H];
   __shared__ __attribute__((aligned(16))) float bufA[MAXC];
   __shared__ __attribute__((aligned(16))) float bufB[MAXC];
 
@@ -171,14 +257,15 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t b = blockIdx.x;
 
+  // stages 0 .. D-2 own whole tiles; stage D-1 is contraction-split (wl)
   float w0[nwreg_b<S, 0>()];
-  float w1[nwreg_b<S, (D > 1 ? 1 : 0)>()];
-  float w2[nwreg_b<S, (D > 2 ? 2 : 0)>()];
-  float w3[nwreg_b<S, (D > 3 ? 3 : 0)>()];
-  load_wfrag_b<S, 0>(w0, packed_hid, wave, lane);
-  if constexpr (D > 1) load_wfrag_b<S, 1>(w1, packed_hid, wave, lane);
-  if constexpr (D > 2) load_wfrag_b<S, 2>(w2, packed_hid, wave, lane);
-  if constexpr (D > 3) load_wfrag_b<S, 3>(w3, packed_hid, wave, lane);
+  float w1[nwreg_b<S, (D > 2 ? 1 : 0)>()];
+  float w2[nwreg_b<S, (D > 3 ? 2 : 0)>()];
+  float wl[nwreg_last<S>()];
+  if constexpr (D > 1) load_wfrag_b<S, 0>(w0, packed_hid, wave, lane);
+  if constexpr (D > 2) load_wfrag_b<S, 1>(w1, packed_hid, wave, lane);
+  if constexpr (D > 3) load_wfrag_b<S, 2>(w2, packed_hid, wave, lane);
+  load_wfrag_b_last<S>(wl, packed_hid, wave, lane);
 
   // per-thread state for its hidden units: dc (LSTM), the direct dh path (GRU), and the saved record of the
   // step being processed (prefetched one step ahead)
@@ -190,7 +277,11 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
     const bool ok = hid < H;
     dcs[u] = (ok && CELL == TTRNN_LSTM && d_cT) ? ld(d_cT, b * H + hid) : 0.f;
     dhd[u] = 0.f;
-    if (ok) dhbuf[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
+    if (ok) {
+      dhbuf[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
+#pragma unroll
+      for (int sl = 1; sl < CS; ++sl) dhbuf[sl * H + hid] = 0.f;
+    }
     ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     dout_n[u] = 0.f;
@@ -213,7 +304,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
       const int hid = tid + u * FAST_NT;
       if (hid < H) {
         const f32x4 qa = ra[u], qb = rb[u];
-        const float dht = dhbuf[hid] + dhd[u] + dout_n[u];
+        float dht = dhd[u] + dout_n[u];
+#pragma unroll
+        for (int sl = 0; sl < CS; ++sl) dht += dhbuf[sl * H + hid];
         // prefetch record(t-1) / c_{t-1} / h_{t-1} / d_out(t-1) for the next iteration
         f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = f32x4{0.f, 0.f, 0.f, 0.f};
         float dn = 0.f;
@@ -255,17 +348,17 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
     lds_barrier();
     // ---- transposed chain: stage 0 .. D-1, last stage writes dh_{t-1} (flat hidden index) -------------------
     if constexpr (D == 1) {
-      run_bstage<S, 0>(w0, bufA, dhbuf, wave, lane);
+      run_bstage_last<S>(wl, bufA, dhbuf, wave, lane);
     } else if constexpr (D == 2) {
       run_bstage<S, 0>(w0, bufA, bufB, wave, lane);
       lds_barrier();
-      run_bstage<S, 1>(w1, bufB, dhbuf, wave, lane);
+      run_bstage_last<S>(wl, bufB, dhbuf, wave, lane);
     } else if constexpr (D == 3) {
       run_bstage<S, 0>(w0, bufA, bufB, wave, lane);
       lds_barrier();
       run_bstage<S, 1>(w1, bufB, bufA, wave, lane);
       lds_barrier();
-      run_bstage<S, 2>(w2, bufA, dhbuf, wave, lane);
+      run_bstage_last<S>(wl, bufA, dhbuf, wave, lane);
     } else {
       run_bstage<S, 0>(w0, bufA, bufB, wave, lane);
       lds_barrier();
@@ -273,7 +366,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
       lds_barrier();
       run_bstage<S, 2>(w2, bufA, bufB, wave, lane);
       lds_barrier();
-      run_bstage<S, 3>(w3, bufB, dhbuf, wave, lane);
+      run_bstage_last<S>(wl, bufB, dhbuf, wave, lane);
     }
     lds_barrier();
   }
@@ -281,7 +374,12 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
     if (hid < H) {
-      if (d_h0) st(d_h0, b * H + hid, dhbuf[hid] + dhd[u]);
+      if (d_h0) {
+        float v = dhd[u];
+#pragma unroll
+        for (int sl = 0; sl < CS; ++sl) v += dhbuf[sl * H + hid];
+        st(d_h0, b * H + hid, v);
+      }
       if (CELL == TTRNN_LSTM && d_c0) st(d_c0, b * H + hid, dcs[u]);
     }
   }
@@ -311,49 +409,61 @@ __device__ __forceinline__ void lin_bstage(const float (&w)[NW_], const float* C
   constexpr int RSTEP = T::SPLIT ? T::G : 1;
   const int c = lane & 15, q = lane >> 4;
   const int rt0 = T::SPLIT ? (wave / T::KT) : 0;
+  constexpr int UC = chunk_of(T::NU);                // fragment reads per chunk (bounds live registers)
   for (int rtb = rt0; rtb < RT_ALL; rtb += 2 * RSTEP) {
-    float bf[2][T::NSTEP];
+    int Rr[2], smp[2], row[2];
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       int R = 16 * (rtb + y * RSTEP) + c;
       R = R < TOT ? R : TOT - 1;
-      const int smp = R / T::ROWS, row = R - smp * T::ROWS;
+      Rr[y] = R; smp[y] = R / T::ROWS; row[y] = R - smp[y] * T::ROWS;
+    }
+    f32x4 acc[T::XK][2];
 #pragma unroll
-      for (int u = 0; u < T::NU; ++u) {
-        const float* p = Cin + smp * CSZ + b_off<S, k>(row, (4 * u + q) * T::WV);
-        if constexpr (T::WV == 4) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-          bf[y][4 * u + 0] = v[0]; bf[y][4 * u + 1] = v[1]; bf[y][4 * u + 2] = v[2]; bf[y][4 * u + 3] = v[3];
-        } else if constexpr (T::WV == 2) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(p);
-          bf[y][2 * u + 0] = v[0]; bf[y][2 * u + 1] = v[1];
-        } else {
-          bf[y][u] = *p;
+    for (int x = 0; x < T::XK; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u0 = 0; u0 < T::NU; u0 += UC) {
+      float bf[2][UC * T::WV];
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          const float* p = Cin + smp[y] * CSZ + b_off<S, k>(row[y], (4 * (u0 + u) + q) * T::WV);
+          if constexpr (T::WV == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            bf[y][4 * u + 0] = v[0]; bf[y][4 * u + 1] = v[1]; bf[y][4 * u + 2] = v[2]; bf[y][4 * u + 3] = v[3];
+          } else if constexpr (T::WV == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+            bf[y][2 * u + 0] = v[0]; bf[y][2 * u + 1] = v[1];
+          } else {
+            bf[y][u] = *p;
+          }
         }
-      }
+#pragma unroll
+      for (int x = 0; x < T::XK; ++x)
+#pragma unroll
+        for (int s2 = 0; s2 < UC * T::WV; ++s2) {
+          const float wv = w[x * T::NSTEP + u0 * T::WV + s2];
+          acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, bf[0][s2], acc[x][0], 0, 0, 0);
+          acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, bf[1][s2], acc[x][1], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int x = 0; x < T::XK; ++x) {
       const int kt = T::SPLIT ? (wave % T::KT) : (wave + FAST_NW * x);
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < T::NSTEP; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], bf[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], bf[1][s], acc1, 0, 0, 0);
-      }
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const int rt = rtb + y * RSTEP;
         const int R = 16 * rt + c;
         const int kk0 = 16 * kt + 4 * q;
         if (kt < T::KT && rt < RT_ALL && R < TOT && kk0 < T::K) {
-          const f32x4 acc = (y == 0 ? acc0 : acc1);
+          const f32x4 a = acc[x][y];
           if constexpr (T::K % 4 == 0) {
-            *reinterpret_cast<f32x4*>(Aout + R * T::K + kk0) = acc;      // R*K = smp*ROWS*K + row*K
+            *reinterpret_cast<f32x4*>(Aout + R * T::K + kk0) = a;      // R*K = smp*ROWS*K + row*K
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (kk0 + j < T::K) Aout[R * T::K + kk0 + j] = acc[j];
+              if (kk0 + j < T::K) Aout[R * T::K + kk0 + j] = a[j];
           }
         }
       }
@@ -450,7 +560,45 @@ constexpr int cmax_elems() {
   return best > in ? best : in;
 }
 
-template <class S, int NB, typename TI, typename TDY>
+// Register budget: keeping the forward AND transposed fragments of every stage resident costs (cfg4, r = 16)
+// ~180 VGPRs before any working set -> scratch spills inside the MFMA loops.  Above the budget the fragments of a
+// stage are (re)loaded from L2 right before the stage runs, once per tile of NB rows, and die with it.
+template <class S>
+constexpr int resident_regs() {
+  int n = 0;
+  if (S::D > 1) n += nwreg<S, (S::D > 1 ? 1 : 0)>();
+  if (S::D > 2) n += nwreg<S, (S::D > 2 ? 2 : 0)>();
+  if (S::D > 3) n += nwreg<S, (S::D > 3 ? 3 : 0)>();
+  n += nwreg_b<S, 0>();
+  if (S::D > 1) n += nwreg_b<S, (S::D > 1 ? 1 : 0)>();
+  if (S::D > 2) n += nwreg_b<S, (S::D > 2 ? 2 : 0)>();
+  if (S::D > 3) n += nwreg_b<S, (S::D > 3 ? 3 : 0)>();
+  return n;
+}
+template <class S>
+constexpr bool resident_ok() { return resident_regs<S>() <= 96; }
+
+template <class S, int k, int NB>
+__device__ __forceinline__ void fwd_stage_reload(const float* packed, const float* in, float* out, int wave, int lane) {
+  // opaque zero offset: without it LICM hoists these loop-invariant loads out of the tile loop, which makes
+  // the fragments resident again (-> spilled to scratch and re-read before every MFMA)
+  int z = 0;
+  asm volatile("" : "+v"(z));        // per-lane opaque zero: keeps the per-lane address arithmetic in the loop too
+  float w[nwreg<S, k>()];
+  load_wfrag<S, k>(w, packed, wave, lane + z);
+  lin_stage<S, k, NB, 0>(w, in, out, wave, lane, 0);
+}
+template <class S, int k, int NB>
+__device__ __forceinline__ void bwd_stage_reload(const float* packed, const float* in, float* out, int wave, int lane) {
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  float w[nwreg_b<S, k>()];
+  load_wfrag_b<S, k>(w, packed, wave, lane + z);
+  lin_bstage<S, k, NB>(w, in, out, wave, lane);
+}
+
+// NEED_DX = false drops the last transposed stage and its resident core fragments (registers!)
+template <class S, int NB, typename TI, typename TDY, bool NEED_DX>
 __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, const float* __restrict__ packed,
                                                                const TI* __restrict__ x, const TDY* __restrict__ dy,
                                                                TI* __restrict__ dx, float* __restrict__ d_packed,
@@ -477,17 +625,19 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, c
   float wf1[nwreg<S, (D > 1 ? 1 : 0)>()];
   float wf2[nwreg<S, (D > 2 ? 2 : 0)>()];
   float wf3[nwreg<S, (D > 3 ? 3 : 0)>()];
-  if constexpr (D > 1) load_wfrag<S, 1>(wf1, packed, wave, lane);
-  if constexpr (D > 2) load_wfrag<S, 2>(wf2, packed, wave, lane);
-  if constexpr (D > 3) load_wfrag<S, 3>(wf3, packed, wave, lane);
+  constexpr bool RES = resident_ok<S>();
+  if constexpr (RES && D > 1) load_wfrag<S, 1>(wf1, packed, wave, lane);
+  if constexpr (RES && D > 2) load_wfrag<S, 2>(wf2, packed, wave, lane);
+  if constexpr (RES && D > 3) load_wfrag<S, 3>(wf3, packed, wave, lane);
+  constexpr int LASTB = NEED_DX ? D - 1 : D - 2;     // last transposed stage that has to run
   float wb0[nwreg_b<S, 0>()];
-  float wb1[nwreg_b<S, (D > 1 ? 1 : 0)>()];
-  float wb2[nwreg_b<S, (D > 2 ? 2 : 0)>()];
-  float wb3[nwreg_b<S, (D > 3 ? 3 : 0)>()];
-  load_wfrag_b<S, 0>(wb0, packed, wave, lane);
-  if constexpr (D > 1) load_wfrag_b<S, 1>(wb1, packed, wave, lane);
-  if constexpr (D > 2) load_wfrag_b<S, 2>(wb2, packed, wave, lane);
-  if constexpr (D > 3) load_wfrag_b<S, 3>(wb3, packed, wave, lane);
+  float wb1[nwreg_b<S, (LASTB >= 1 ? 1 : 0)>()];
+  float wb2[nwreg_b<S, (LASTB >= 2 ? 2 : 0)>()];
+  float wb3[nwreg_b<S, (LASTB >= 3 ? 3 : 0)>()];
+  if constexpr (RES && LASTB >= 0) load_wfrag_b<S, 0>(wb0, packed, wave, lane);
+  if constexpr (RES && LASTB >= 1) load_wfrag_b<S, 1>(wb1, packed, wave, lane);
+  if constexpr (RES && LASTB >= 2) load_wfrag_b<S, 2>(wb2, packed, wave, lane);
+  if constexpr (RES && LASTB >= 3) load_wfrag_b<S, 3>(wb3, packed, wave, lane);
 
   f32x4 g0[wg_tpw<S, 0>()];
   f32x4 g1[wg_tpw<S, (D > 1 ? 1 : 0)>()];
@@ -537,47 +687,65 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, c
     // ---- forward recompute: A_{D-1} -> ... -> A_0 ---------------------------------------------------------------
     if (want_w) {
       if constexpr (D == 2) {
-        lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
         __syncthreads();
       } else if constexpr (D == 3) {
-        lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
+        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave, lane);
         __syncthreads();
-        lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
         __syncthreads();
       } else if constexpr (D == 4) {
-        lin_stage<S, 3, NB, 0>(wf3, a3, a2, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 3, NB, 0>(wf3, a3, a2, wave, lane, 0);
+        else fwd_stage_reload<S, 3, NB>(packed, a3, a2, wave, lane);
         __syncthreads();
-        lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
+        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave, lane);
         __syncthreads();
-        lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
         __syncthreads();
       }
     }
     // ---- backward: per stage weight gradient (reads A_k, dC_k) and data gradient (dC_k -> dC_{k+1}) --------------
     // the two read the same dC_k and write disjoint places: no barrier between them
     if (want_w) wgrad_stage<S, 0, NB>(g0, a0, cA, wave, lane);
-    if (D > 1 || dx) lin_bstage<S, 0, NB>(wb0, cA, cB, wave, lane);
+    if constexpr (LASTB >= 0) {
+      if constexpr (RES) lin_bstage<S, 0, NB>(wb0, cA, cB, wave, lane);
+      else bwd_stage_reload<S, 0, NB>(packed, cA, cB, wave, lane);
+    }
     __syncthreads();
     float* last = cB;
     if constexpr (D > 1) {
       if (want_w) wgrad_stage<S, 1, NB>(g1, a1, cB, wave, lane);
-      if (D > 2 || dx) lin_bstage<S, 1, NB>(wb1, cB, cA, wave, lane);
+      if constexpr (LASTB >= 1) {
+        if constexpr (RES) lin_bstage<S, 1, NB>(wb1, cB, cA, wave, lane);
+        else bwd_stage_reload<S, 1, NB>(packed, cB, cA, wave, lane);
+      }
       __syncthreads();
       last = cA;
     }
     if constexpr (D > 2) {
       if (want_w) wgrad_stage<S, 2, NB>(g2, a2, cA, wave, lane);
-      if (D > 3 || dx) lin_bstage<S, 2, NB>(wb2, cA, cB, wave, lane);
+      if constexpr (LASTB >= 2) {
+        if constexpr (RES) lin_bstage<S, 2, NB>(wb2, cA, cB, wave, lane);
+        else bwd_stage_reload<S, 2, NB>(packed, cA, cB, wave, lane);
+      }
       __syncthreads();
       last = cB;
     }
     if constexpr (D > 3) {
       if (want_w) wgrad_stage<S, 3, NB>(g3, a3, cB, wave, lane);
-      if (dx) lin_bstage<S, 3, NB>(wb3, cB, cA, wave, lane);
+      if constexpr (LASTB >= 3) {
+        if constexpr (RES) lin_bstage<S, 3, NB>(wb3, cB, cA, wave, lane);
+        else bwd_stage_reload<S, 3, NB>(packed, cB, cA, wave, lane);
+      }
       __syncthreads();
       last = cA;
     }
-    if (dx) {
+    if constexpr (NEED_DX) {
       for (int e = tid; e < NB * IN; e += FAST_NT) {
         const int smp = e / IN;
         if (n0 + smp < n_rows) st(dx, n0 * IN + e, last[e]);
@@ -607,8 +775,12 @@ static int launch_lin_bwd_tt(int64_t n_rows, const float* packed, const void* x,
   static_assert(bwd_shape_ok<S>() && shape_ok<S>(), "shape not supported by the MFMA backward path");
   const int64_t ntiles = (n_rows + NB - 1) / NB;
   const int grid = (int)(ntiles < 1 ? 1 : (ntiles > 256 ? 256 : ntiles));
-  hipLaunchKernelGGL((k_ttlinear_bwd_fast<S, NB, TI, TDY>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed,
-                     (const TI*)x, (const TDY*)dy, (TI*)dx, d_packed, d_bias);
+  if (dx)
+    hipLaunchKernelGGL((k_ttlinear_bwd_fast<S, NB, TI, TDY, true>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows,
+                       packed, (const TI*)x, (const TDY*)dy, (TI*)dx, d_packed, d_bias);
+  else
+    hipLaunchKernelGGL((k_ttlinear_bwd_fast<S, NB, TI, TDY, false>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows,
+                       packed, (const TI*)x, (const TDY*)dy, (TI*)dx, d_packed, d_bias);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

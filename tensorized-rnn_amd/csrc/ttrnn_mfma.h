@@ -23,6 +23,7 @@ struct Shp {
 };
 
 constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+constexpr int chunk_of(int nu) { return nu % 4 == 0 ? 4 : (nu % 3 == 0 ? 3 : (nu % 2 == 0 ? 2 : 1)); }
 
 template <class S>
 constexpr int rows_of(int k) {   // chain rows of stage k: prod_{m>k} I_m * prod_{m<k} J_m
@@ -257,38 +258,50 @@ __device__ __forceinline__ void lin_stage(const float (&w)[NW_], const float* Ai
   constexpr int RSTEP = T::SPLIT ? T::G : 1;
   const int c = lane & 15, q = lane >> 4;
   const int rt0 = T::SPLIT ? (wave / T::MT) : 0;
+  constexpr int UC = chunk_of(T::NU);                // fragment reads per chunk (bounds live registers)
   for (int rtb = rt0; rtb < RT_ALL; rtb += 2 * RSTEP) {
-    float af[2][T::NSTEP];
+    int Rr[2];
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
-      int R = 16 * (rtb + y * RSTEP) + c;
-      R = R < TOT ? R : TOT - 1;
+      const int R = 16 * (rtb + y * RSTEP) + c;
+      Rr[y] = R < TOT ? R : TOT - 1;
+    }
+    f32x4 acc[T::XM][2];
 #pragma unroll
-      for (int u = 0; u < T::NU; ++u) {
-        const float* p = Ain + a_off<T::KP>(R, (4 * u + q) * T::WV);
-        if constexpr (T::WV == 4) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-          af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
-        } else if constexpr (T::WV == 2) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(p);
-          af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
-        } else {
-          af[y][u] = *p;
+    for (int x = 0; x < T::XM; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u0 = 0; u0 < T::NU; u0 += UC) {
+      float af[2][UC * T::WV];
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          const float* p = Ain + a_off<T::KP>(Rr[y], (4 * (u0 + u) + q) * T::WV);
+          if constexpr (T::WV == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
+          } else if constexpr (T::WV == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+            af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
+          } else {
+            af[y][u] = *p;
+          }
         }
-      }
+#pragma unroll
+      for (int x = 0; x < T::XM; ++x)
+#pragma unroll
+        for (int s2 = 0; s2 < UC * T::WV; ++s2) {
+          const float wv = w[x * T::NSTEP + u0 * T::WV + s2];
+          acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, af[0][s2], acc[x][0], 0, 0, 0);
+          acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, af[1][s2], acc[x][1], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int x = 0; x < T::XM; ++x) {
       const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < T::NSTEP; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[x * T::NSTEP + s], af[1][s], acc1, 0, 0, 0);
-      }
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
-        const f32x4 acc = y == 0 ? acc0 : acc1;
+        const f32x4 a = acc[x][y];
         const int rt = rtb + y * RSTEP;
         const int R = 16 * rt + c;
         const int m0 = 16 * mt + 4 * q;
@@ -300,11 +313,11 @@ __device__ __forceinline__ void lin_stage(const float (&w)[NW_], const float* Ai
             const int i = m0 / T::R, a0 = m0 % T::R;
             const int f = i * (T::ROWS * T::R) + row * T::R + a0;
             float* p = Cout + a_off<N::KP>(smp * N::ROWS + f / N::K, f % N::K);
-            *reinterpret_cast<f32x4*>(p) = acc;
+            *reinterpret_cast<f32x4*>(p) = a;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (m0 + j < T::M) Cout[ytile_index<G, OUT>(smp, (m0 + j) * T::ROWS + row, ilv_mode)] = acc[j];
+              if (m0 + j < T::M) Cout[ytile_index<G, OUT>(smp, (m0 + j) * T::ROWS + row, ilv_mode)] = a[j];
           }
         }
       }
