@@ -27,6 +27,15 @@
 
 namespace ttrnn {
 
+__device__ __forceinline__ void store4(float* y, size_t idx, f32x4 v) { *reinterpret_cast<f32x4*>(y + idx) = v; }
+__device__ __forceinline__ void store4(bf16_t* y, size_t idx, f32x4 v) {
+  typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+  u16x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = f32_to_bf16(v[j]).v;
+  *reinterpret_cast<u16x4*>(y + idx) = r;
+}
+
 // what a value becomes after a round trip through the storage type (h is fed back as stored)
 template <typename TS>
 __device__ __forceinline__ float round_storage(float v) {
@@ -337,7 +346,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           if (ok[x][y] && pair) {
             cst[x][y] = cy;
             hst[x][y] = hy;
-            st(out, bt * H + hd, hy);                                                        // lstm.py:133
             hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           }
           if (ok[x][y] && t + 1 < T) {
@@ -353,7 +361,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
           const float hy = round_storage<TS>(og * ftanh(cy));                      // lstm.py:32
           cst[x][y] = cy;
           hst[x][y] = hy;
-          st(out, bt * H + hd, hy);                                                // lstm.py:133
           hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           if (reserve) {
             float* rv = reserve + (bt * H + hd) * 8;
@@ -368,6 +375,17 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
     TT_STAMP(5)
     lds_barrier();
     TT_STAMP(6)
+    // outputs[:, t, :] = h_t (lstm.py:133): h_t now sits complete in the LDS image the next step reads; the last
+    // wave streams it out as whole 16-byte pieces per lane (one coalesced store per timestep instead of eight
+    // half-empty ones).  The image is not overwritten before the next gate phase, three barriers away.
+    if (wave == FAST_NW - 1) {
+#pragma unroll
+      for (int h4 = lane; h4 < H / 4; h4 += 64) {
+        const int hd0 = 4 * h4;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + a_off<SL::K>(hd0 / SL::K, hd0 % SL::K));
+        store4(out, bt * H + hd0, hv);
+      }
+    }
   }
 #pragma unroll
   for (int x = 0; x < T0::XM; ++x)
