@@ -37,7 +37,7 @@ WORKLOADS = {
     # name: kind, in, H, layers, ncores, rank, B (per GPU), T, dtype, FLOP per sample-timestep
     "cfg2": dict(kind="ttlstm", inp=1, H=256, L=1, d=3, r=8, B=64, T=784, dtype="f32", flop=691712,
                  desc="TT-LSTM in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=64/GPU fp32 (BASELINE.json configs[1])"),
-    "cfg3": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=256, T=784, dtype="bf16", flop=519360,
+    "cfg3": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=256, T=784, dtype="bf16", arith="f32", flop=519360,
                  desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=256/GPU bf16 storage (configs[2])"),
     "cfg4": dict(kind="ttlstm", inp=40, H=256, L=3, d=3, r=16, B=512, T=160, dtype="f32", flop=12416768,
                  desc="3-layer TT-LSTM in=40 H=256 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (configs[3] per-GPU batch)"),
@@ -225,7 +225,18 @@ def main():
 
     if rank == 0:
         flop_per_launch = float(w["flop"]) * w["B"] * w["T"] / max(launches_per_step, 1e-9)
-        peak = PEAK_FP32_TFLOPS if w["dtype"] == "f32" else PEAK_BF16_TFLOPS
+        # `dtype` on the JSON line is the ARITHMETIC type: the bf16-storage workload still runs its chain on the
+        # exact-fp32 MFMA (bf16 only in HBM), so it is priced against the fp32 peak
+        arith = w.get("arith", w["dtype"])
+        peak = PEAK_FP32_TFLOPS if arith == "f32" else PEAK_BF16_TFLOPS
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                tr = json.load(fh).get(args.workload)
+            if tr and args.mode == "forward":
+                traffic = tr["hbm_bytes_per_launch"]       # rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
+        except (OSError, ValueError, KeyError):
+            traffic = None
         achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
         line = {
             "metric": "timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}".format(
@@ -235,15 +246,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": w["dtype"], "data": "synthetic",
+            "dtype": arith if arith == w["dtype"] else "{} ({} storage)".format(arith, w["dtype"]), "data": "synthetic",
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
                        "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
                                 "train step: forward + BPTT + gradient all-reduce + SGD, inputs resident in HBM")},
             "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "kernel": "ttrnn_rnn_forward", "kernel_ms": kern_ms,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "ttrnn_rnn_forward (K-in batched input projection + K-rec persistent recurrent kernel)",
+                         "kernel_ms": kern_ms,
                          "flop_per_launch": flop_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
