@@ -158,13 +158,20 @@ def main():
                 args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libttrnn has no CPU path)")
+    # TTRNN_BENCH_SINGLE_DEVICE=1 (with TTRNN_BENCH_BACKEND=gloo) lets a 1-GPU box exercise the N>1 code path
+    if os.environ.get("TTRNN_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("TTRNN_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": device} if backend == "nccl" else {}))
 
     w = WORKLOADS[args.workload]
     from ttrnn_hip import functional as F
@@ -217,7 +224,7 @@ def main():
     kern_ms = timer.mean_ms("ttrnn_rnn_forward")
     launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -265,3 +265,59 @@ def test_empty_and_degenerate_inputs():
         m(torch.zeros(2, 3, 5, device=dev()))          # wrong input size
     with pytest.raises(Exception):
         m(torch.zeros(2, 3, 1))                          # CPU tensor: no CPU fallback
+
+
+def test_bf16_storage_gradients_vs_fp32_oracle():
+    """bf16 storage through the MFMA forward + reverse-time + batched backward kernels (fp32 gate
+    gradients against bf16 activations); checked against the fp32 oracle on the bf16-rounded weights."""
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(11)
+    for kind in ("ttgru", "ttlstm"):
+        meta = dict(kind=kind, input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8)
+        m = build_module(meta, dev()).to(torch.bfloat16)
+        x = torch.rand(6, 12, 1).to(torch.bfloat16)
+        sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+        layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+        xr = x.float().requires_grad_(True)
+        if kind == "ttlstm":
+            ro, (rh, rc) = O.lstm_forward(layers, xr)
+        else:
+            ro, rh = O.gru_forward(layers, xr)
+        w = torch.randn(ro.shape)
+        (ro * w).sum().backward()
+        xg = x.to(dev()).requires_grad_(True)
+        res = m(xg)
+        (res[0].float() * w.to(dev())).sum().backward()
+        assert _maxabs(res[0].float(), ro.detach()) <= 2e-2
+        for name, p in m.named_parameters():
+            ref = leaves[name].grad
+            scale = max(float(ref.abs().max()), 1e-3)
+            assert p.grad is not None and p.grad.dtype == torch.bfloat16
+            assert _maxabs(p.grad.float(), ref) <= 6e-2 * scale, (kind, name)
+        assert _maxabs(xg.grad.float(), xr.grad) <= 6e-2 * max(float(xr.grad.abs().max()), 1e-3)
+
+
+def test_fast_and_generic_paths_agree():
+    """The shape-specialised MFMA kernels against the any-shape kernels (TTRNN_FORCE_GENERIC=1) on the
+    same module: forward and every gradient."""
+    import os
+    torch.manual_seed(5)
+    meta = dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev())
+    x = torch.rand(5, 20, 1, device=dev())
+    w = torch.randn(5, 20, 256, device=dev())
+    outs = []
+    for force in ("0", "1"):
+        os.environ["TTRNN_FORCE_GENERIC"] = force
+        try:
+            m.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            out, (h, c) = m(xg)
+            ((out * w).sum() + c.sum()).backward()
+            outs.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ["TTRNN_FORCE_GENERIC"] = "0"
+    assert _maxabs(outs[0][0], outs[1][0]) <= 2e-6
+    assert _maxabs(outs[0][1], outs[1][1]) <= 1e-5 * max(1.0, float(outs[1][1].abs().max()))
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
