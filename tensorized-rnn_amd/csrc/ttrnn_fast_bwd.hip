@@ -663,6 +663,13 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, c
   const int64_t ntiles = (n_rows + NB - 1) / NB;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * NB;
+    // opaque per-iteration copies: stop LICM from hoisting the (hundreds of) unrolled LDS address computations of
+    // all stages out of the tile loop, where they would all be live at once and spill to scratch
+    int lane_i = lane, wave_i = wave;
+    if constexpr (!RES) {      // small shapes have registers to spare: let the compiler hoist
+      asm volatile("" : "+v"(lane_i));
+      asm volatile("" : "+s"(wave_i));
+    }
     // ---- loads: x -> first forward image; dy -> dC_0 (C-layout of stage 0 == flat o) ---------------------------
     if (want_w) {
       for (int e = tid; e < NB * IN; e += FAST_NT) {
@@ -687,60 +694,60 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, c
     // ---- forward recompute: A_{D-1} -> ... -> A_0 ---------------------------------------------------------------
     if (want_w) {
       if constexpr (D == 2) {
-        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
-        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave_i, lane_i);
         __syncthreads();
       } else if constexpr (D == 3) {
-        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
-        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave, lane);
+        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave_i, lane_i);
         __syncthreads();
-        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
-        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave_i, lane_i);
         __syncthreads();
       } else if constexpr (D == 4) {
-        if constexpr (RES) lin_stage<S, 3, NB, 0>(wf3, a3, a2, wave, lane, 0);
-        else fwd_stage_reload<S, 3, NB>(packed, a3, a2, wave, lane);
+        if constexpr (RES) lin_stage<S, 3, NB, 0>(wf3, a3, a2, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 3, NB>(packed, a3, a2, wave_i, lane_i);
         __syncthreads();
-        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave, lane, 0);
-        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave, lane);
+        if constexpr (RES) lin_stage<S, 2, NB, 0>(wf2, a2, a1, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 2, NB>(packed, a2, a1, wave_i, lane_i);
         __syncthreads();
-        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave, lane, 0);
-        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave, lane);
+        if constexpr (RES) lin_stage<S, 1, NB, 0>(wf1, a1, a0, wave_i, lane_i, 0);
+        else fwd_stage_reload<S, 1, NB>(packed, a1, a0, wave_i, lane_i);
         __syncthreads();
       }
     }
     // ---- backward: per stage weight gradient (reads A_k, dC_k) and data gradient (dC_k -> dC_{k+1}) --------------
     // the two read the same dC_k and write disjoint places: no barrier between them
-    if (want_w) wgrad_stage<S, 0, NB>(g0, a0, cA, wave, lane);
+    if (want_w) wgrad_stage<S, 0, NB>(g0, a0, cA, wave_i, lane_i);
     if constexpr (LASTB >= 0) {
-      if constexpr (RES) lin_bstage<S, 0, NB>(wb0, cA, cB, wave, lane);
-      else bwd_stage_reload<S, 0, NB>(packed, cA, cB, wave, lane);
+      if constexpr (RES) lin_bstage<S, 0, NB>(wb0, cA, cB, wave_i, lane_i);
+      else bwd_stage_reload<S, 0, NB>(packed, cA, cB, wave_i, lane_i);
     }
     __syncthreads();
     float* last = cB;
     if constexpr (D > 1) {
-      if (want_w) wgrad_stage<S, 1, NB>(g1, a1, cB, wave, lane);
+      if (want_w) wgrad_stage<S, 1, NB>(g1, a1, cB, wave_i, lane_i);
       if constexpr (LASTB >= 1) {
-        if constexpr (RES) lin_bstage<S, 1, NB>(wb1, cB, cA, wave, lane);
-        else bwd_stage_reload<S, 1, NB>(packed, cB, cA, wave, lane);
+        if constexpr (RES) lin_bstage<S, 1, NB>(wb1, cB, cA, wave_i, lane_i);
+        else bwd_stage_reload<S, 1, NB>(packed, cB, cA, wave_i, lane_i);
       }
       __syncthreads();
       last = cA;
     }
     if constexpr (D > 2) {
-      if (want_w) wgrad_stage<S, 2, NB>(g2, a2, cA, wave, lane);
+      if (want_w) wgrad_stage<S, 2, NB>(g2, a2, cA, wave_i, lane_i);
       if constexpr (LASTB >= 2) {
-        if constexpr (RES) lin_bstage<S, 2, NB>(wb2, cA, cB, wave, lane);
-        else bwd_stage_reload<S, 2, NB>(packed, cA, cB, wave, lane);
+        if constexpr (RES) lin_bstage<S, 2, NB>(wb2, cA, cB, wave_i, lane_i);
+        else bwd_stage_reload<S, 2, NB>(packed, cA, cB, wave_i, lane_i);
       }
       __syncthreads();
       last = cB;
     }
     if constexpr (D > 3) {
-      if (want_w) wgrad_stage<S, 3, NB>(g3, a3, cB, wave, lane);
+      if (want_w) wgrad_stage<S, 3, NB>(g3, a3, cB, wave_i, lane_i);
       if constexpr (LASTB >= 3) {
-        if constexpr (RES) lin_bstage<S, 3, NB>(wb3, cB, cA, wave, lane);
-        else bwd_stage_reload<S, 3, NB>(packed, cB, cA, wave, lane);
+        if constexpr (RES) lin_bstage<S, 3, NB>(wb3, cB, cA, wave_i, lane_i);
+        else bwd_stage_reload<S, 3, NB>(packed, cB, cA, wave_i, lane_i);
       }
       __syncthreads();
       last = cA;
