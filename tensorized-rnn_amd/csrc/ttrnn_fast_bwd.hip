@@ -82,7 +82,9 @@ __device__ __forceinline__ void load_wfrag_b(float (&w)[NW_], const float* packe
 #pragma unroll
       for (int e = 0; e < T::WV; ++e) {
         const int m = (4 * u + q) * T::WV + e;
-        w[x * T::NSTEP + u * T::WV + e] = (kt < T::KT && kk < T::K) ? W[kk * T::M + m] : 0.f;
+        const bool okw = kt < T::KT && kk < T::K;
+        const float wv = W[okw ? kk * T::M + m : 0];      // branch-free: in-bounds load, then mask
+        w[x * T::NSTEP + u * T::WV + e] = okw ? wv : 0.f;
       }
   }
 }
@@ -488,6 +490,9 @@ __device__ __forceinline__ void wgrad_stage(f32x4 (&acc)[TP_], const float* Aimg
   constexpr int CSZ = csz<S, k, NB>();
   static_assert(TOT % 4 == 0, "chain rows must come in quads");
   const int r = lane & 15, q = lane >> 4;
+  // tile x of this wave: tix = wave*TP_ + x -> (kt, mt).  When a wave's tiles share one kt (TP_ divides MT) the
+  // A-side fragment is read once per row quad and reused for all of them.
+  constexpr bool SAME_KT = (MT % TP_ == 0);
   int aoff[TP_], boff[TP_];
   bool aok[TP_], bok[TP_];
 #pragma unroll
@@ -507,11 +512,21 @@ __device__ __forceinline__ void wgrad_stage(f32x4 (&acc)[TP_], const float* Aimg
       const bool rok = R < TOT;
       R = rok ? R : TOT - 1;
       const int smp = R / F::ROWS, row = R - smp * F::ROWS;
+      float a0 = 0.f;
+      if constexpr (SAME_KT) {
+        a0 = Aimg[a_off<F::KP>(R, aoff[0])];
+        a0 = (aok[0] && rok) ? a0 : 0.f;
+      }
 #pragma unroll
       for (int x = 0; x < TP_; ++x) {
-        float a = Aimg[a_off<F::KP>(R, aoff[x])];
+        float a;
+        if constexpr (SAME_KT) {
+          a = a0;
+        } else {
+          a = Aimg[a_off<F::KP>(R, aoff[x])];
+          a = (aok[x] && rok) ? a : 0.f;
+        }
         float b = Cimg[smp * CSZ + b_off<S, k>(row, boff[x])];
-        a = (aok[x] && rok) ? a : 0.f;
         b = bok[x] ? b : 0.f;
         acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[x], 0, 0, 0);
       }
@@ -576,7 +591,9 @@ constexpr int resident_regs() {
   return n;
 }
 template <class S>
-constexpr bool resident_ok() { return resident_regs<S>() <= 96; }
+constexpr bool resident_ok() { return resident_regs<S>() <= 160; }
+template <class S>
+constexpr bool big_shape() { return resident_regs<S>() > 96; }   // register-hungry: keep address math in the tile loop
 
 template <class S, int k, int NB>
 __device__ __forceinline__ void fwd_stage_reload(const float* packed, const float* in, float* out, int wave, int lane) {
@@ -666,7 +683,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_bwd_fast(int64_t n_rows, c
     // opaque per-iteration copies: stop LICM from hoisting the (hundreds of) unrolled LDS address computations of
     // all stages out of the tile loop, where they would all be live at once and spill to scratch
     int lane_i = lane, wave_i = wave;
-    if constexpr (!RES) {      // small shapes have registers to spare: let the compiler hoist
+    if constexpr (big_shape<S>()) {      // small shapes have registers to spare: let the compiler hoist
       asm volatile("" : "+v"(lane_i));
       asm volatile("" : "+s"(wave_i));
     }

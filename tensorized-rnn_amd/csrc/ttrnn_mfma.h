@@ -142,7 +142,10 @@ __device__ __forceinline__ void load_wfrag(float (&w)[NW_], const float* packed,
 #pragma unroll
       for (int e = 0; e < T::WV; ++e) {
         const int kk = (4 * u + q) * T::WV + e;
-        w[x * T::NSTEP + u * T::WV + e] = (mt < T::MT && m < T::M && kk < T::K) ? W[kk * T::M + m] : 0.f;
+        // branch-free: always load an in-bounds element, then mask (a conditional load costs a branch each)
+        const bool okw = mt < T::MT && m < T::M && kk < T::K;
+        const float wv = W[okw ? kk * T::M + m : 0];
+        w[x * T::NSTEP + u * T::WV + e] = okw ? wv : 0.f;
       }
   }
 }
