@@ -189,6 +189,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                                rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
                                ilv_mode);
     if (st != TTRNN_OK) return st;
+    if (fast_rnn_fwd_bf16_available(rs, desc->dtype))
+      return launch_rnn_fwd_bf16(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     return launch_rnn_fwd_fast(rs, desc->dtype, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                (hipStream_t)stream);
   }

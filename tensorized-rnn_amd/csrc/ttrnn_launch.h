@@ -58,6 +58,12 @@ bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h);
 int launch_ttlinear_fwd_fast(const TtShape& s, int dtype, bool y_f32, int64_t n_rows, const float* packed,
                              const void* bias, const void* x, void* y, int ilv_h, int ilv_mode, hipStream_t stream);
 
+// bf16-storage recurrent kernel on the bf16 MFMA (ttrnn_fast_bf16.hip)
+bool fast_rnn_fwd_bf16_available(const RnnShape& rs, int dtype);
+int launch_rnn_fwd_bf16(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+                        const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                        hipStream_t stream);
+
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);
 int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
