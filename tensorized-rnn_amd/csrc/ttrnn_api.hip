@@ -116,7 +116,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 // (b, t), gate-interleaved per hidden unit as fp32 [B][T][H][4] (LSTM slots i,g,f,o; GRU r,z,n,-), followed by
 // whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
-  bool use, lin_fast;
+  bool use, lin_fast, in1;
   size_t gin_bytes, lin_ws_bytes;
   LinPlan lin;
 };
@@ -126,9 +126,14 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   FastFwdPlan f{};
   f.use = !force_generic() && fast_rnn_fwd_available(rs, dtype);
   if (!f.use) return f;
-  const int64_t n_rows = (int64_t)rs.B * rs.T;
-  f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [B][T][H][4]
+  int64_t n_rows = (int64_t)rs.B * rs.T;
   f.lin_fast = fast_ttlinear_fwd_available(rs.in_s, dtype, rs.H);
+  // input_size == 1: the projection is linear in a scalar -> only the two rows chain(1)+b, chain(0)+b are needed
+  const char* no_in1 = getenv("TTRNN_NO_IN1");
+  f.in1 = rs.in == 1 && f.lin_fast && !(no_in1 && no_in1[0] == '1');
+  if (f.in1) n_rows = 2;
+  f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [rows][H][4]
+  if (f.in1) f.gin_bytes += 256;                                                    // + the two unit input rows
   if (!f.lin_fast && dtype != TTRNN_F32) {   // the generic K-in writes storage-typed output; gin must be fp32
     f.use = false;
     return f;
@@ -179,19 +184,28 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes) return TTRNN_ERR_WORKSPACE;
     float* gin = (float*)workspace;
     void* lin_ws = (char*)workspace + f.gin_bytes;
-    // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
     const int ilv_mode = rs.cell == TTRNN_LSTM ? 2 : 1;
-    if (f.lin_fast)
-      st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, (int64_t)rs.B * rs.T, packed_in,
-                                    rs.has_bias_in ? bias_in : nullptr, x, gin, rs.H, ilv_mode, (hipStream_t)stream);
-    else
-      st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in,
-                               rs.has_bias_in ? bias_in : nullptr, x, gin, lin_ws, (hipStream_t)stream, rs.H,
-                               ilv_mode);
+    const void* bin = rs.has_bias_in ? bias_in : nullptr;
+    GinSrc src{gin, x, f.in1 ? 1 : 0};
+    if (f.in1) {
+      // K-in on the two unit rows x = [1, 0] (same chain kernel, microseconds); K-rec scales by the real x
+      void* unit = (char*)workspace + f.gin_bytes - 256;
+      st = launch_fill_unit_rows(unit, desc->dtype, (hipStream_t)stream);
+      if (st != TTRNN_OK) return st;
+      st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
+                                    (hipStream_t)stream);
+    } else if (f.lin_fast) {
+      // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
+      st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, (int64_t)rs.B * rs.T, packed_in, bin, x, gin, rs.H,
+                                    ilv_mode, (hipStream_t)stream);
+    } else {
+      st = launch_ttlinear_fwd(rs.in_s, f.lin, desc->dtype, (int64_t)rs.B * rs.T, packed_in, bin, x, gin, lin_ws,
+                               (hipStream_t)stream, rs.H, ilv_mode);
+    }
     if (st != TTRNN_OK) return st;
     if (fast_rnn_fwd_bf16_available(rs, desc->dtype))
-      return launch_rnn_fwd_bf16(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
-    return launch_rnn_fwd_fast(rs, desc->dtype, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
+      return launch_rnn_fwd_bf16(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
+    return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, false);

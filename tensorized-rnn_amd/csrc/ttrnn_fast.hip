@@ -46,7 +46,7 @@ __device__ __forceinline__ float round_storage(float v) {
 // ---- the persistent kernel ---------------------------------------------------------------------------
 // gin: fp32 [B][T][G*H] = W_in x_t + b_in (hoisted).  One workgroup per sample.
 template <class S, int CELL, typename TS>
-__global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const float* __restrict__ gin,
+__global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc gs,
                                                           const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
                                                           const TS* __restrict__ bias_hid, TS* __restrict__ out,
@@ -82,9 +82,12 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
 
   // per-thread recurrent state and constants for its hidden units
   // gin is gate-interleaved: [B][T][H][4], slot order i,g,f,o (LSTM) / r,z,n,- (GRU): one 16-byte load
+  const float* __restrict__ gin = gs.gin;
+  const TS* __restrict__ xs = reinterpret_cast<const TS*>(gs.x);
+  const bool in1 = gs.in1 != 0;
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
   float cst[HPT], hst[HPT], bh[HPT][G];
-  f32x4 gi[HPT];
+  f32x4 gi[HPT], vv[HPT], bb[HPT];
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -93,7 +96,18 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
     cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? ld(c0, b * H + hid) : 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) bh[u][g] = (ok && bias_hid) ? ld(bias_hid, g * H + hid) : 0.f;
-    gi[u] = (ok && T > 0) ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};
+    vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok && T > 0) {
+      if (in1) {
+        bb[u] = gin4[H + hid];
+        vv[u] = gin4[hid] - bb[u];
+        gi[u] = bb[u] + ld(xs, b * T) * vv[u];
+      } else {
+        gi[u] = gin4[(b * T) * H + hid];
+      }
+    }
     if (ok) hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hst[u];
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see k_lstm_fwd_fused
@@ -156,7 +170,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, const fl
         hst[u] = hy;
         hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hy;
         // prefetch the hoisted input projection of the next step; consumed one iteration later
-        if (t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
+        if (t + 1 < T) gi[u] = in1 ? bb[u] + ld(xs, bt + 1) * vv[u] : gin4[(bt + 1) * H + hid];
       }
     }
     lds_barrier();
@@ -216,7 +230,7 @@ __device__ __forceinline__ void load_wfrag0_lstm(float (&w)[NW_], const float* p
 }
 
 template <class S, bool DIAG, typename TS>
-__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const float* __restrict__ gin,
+__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc gs,
                                                             const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                             const float* __restrict__ packed_hid,
                                                             const TS* __restrict__ bias_hid, TS* __restrict__ out,
@@ -258,7 +272,11 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
   const float sgn = (PAIR && pair == 0) ? 2.0f : 1.0f;   // second gate: tanh (= 2*sigmoid(2x) - 1) or sigmoid
   int hid[T0::XM][T0::YR];
   bool ok[T0::XM][T0::YR];
+  const float* __restrict__ gin = gs.gin;
+  const TS* __restrict__ xs = reinterpret_cast<const TS*>(gs.x);
+  const bool in1 = gs.in1 != 0;
   float cst[T0::XM][T0::YR], hst[T0::XM][T0::YR], bh[T0::XM][T0::YR][NG], gi[T0::XM][T0::YR][NG];
+  float vv[T0::XM][T0::YR][NG], bb[T0::XM][T0::YR][NG];
 #pragma unroll
   for (int x = 0; x < T0::XM; ++x) {
     const int mt = T0::SPLIT ? (wave % T0::MT) : (wave + FAST_NW * x);
@@ -277,7 +295,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
         const int slot = PAIR ? 2 * pair + g : g;
         const int gate = slot == 1 ? 2 : (slot == 2 ? 1 : slot);
         bh[x][y][g] = (ok[x][y] && bias_hid) ? ld(bias_hid, gate * H + hd) : 0.f;
-        gi[x][y][g] = (ok[x][y] && T > 0) ? gin[((b * T) * H + hd) * 4 + slot] : 0.f;
+        vv[x][y][g] = 0.f; bb[x][y][g] = 0.f; gi[x][y][g] = 0.f;
+        if (ok[x][y] && T > 0) {
+          if (in1) {
+            bb[x][y][g] = gin[(H + hd) * 4 + slot];
+            vv[x][y][g] = gin[hd * 4 + slot] - bb[x][y][g];
+            gi[x][y][g] = bb[x][y][g] + ld(xs, b * T) * vv[x][y][g];
+          } else {
+            gi[x][y][g] = gin[((b * T) * H + hd) * 4 + slot];
+          }
+        }
       }
       if (ok[x][y] && pair) hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hst[x][y];
     }
@@ -349,8 +376,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
             hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           }
           if (ok[x][y] && t + 1 < T) {
-            const f32x2 nx = *reinterpret_cast<const f32x2*>(gin + ((bt + 1) * H + hd) * 4 + 2 * pair);
-            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1];
+            if (in1) {
+              const float xn = ld(xs, bt + 1);
+              gi[x][y][0] = bb[x][y][0] + xn * vv[x][y][0];
+              gi[x][y][1] = bb[x][y][1] + xn * vv[x][y][1];
+            } else {
+              const f32x2 nx = *reinterpret_cast<const f32x2*>(gin + ((bt + 1) * H + hd) * 4 + 2 * pair);
+              gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1];
+            }
           }
         } else if (ok[x][y]) {
           const float ig = fsigmoid(acc[x][y][0] + gi[x][y][0] + bh[x][y][0]);     // lstm.py:26
@@ -367,8 +400,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
             rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
           if (t + 1 < T) {
-            const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
-            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1]; gi[x][y][2] = nx[2]; gi[x][y][3] = nx[3];
+            if (in1) {
+              const float xn = ld(xs, bt + 1);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) gi[x][y][g] = bb[x][y][g] + xn * vv[x][y][g];
+            } else {
+              const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+              gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1]; gi[x][y][2] = nx[2]; gi[x][y][3] = nx[3];
+            }
           }
         }
       }
@@ -407,7 +446,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, const 
 
 // ---- dispatch ------------------------------------------------------------------------------------------
 template <class S, int CELL, typename TS>
-static int launch_one_t(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+static int launch_one_t(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                         const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
   static_assert(shape_ok_recurrent<S>(), "shape not supported by the MFMA path");
   const TS* bh = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
@@ -427,7 +466,7 @@ static int launch_one_t(const RnnShape& rs, const float* gin, const void* h0, co
 }
 
 template <class S, int CELL>
-static int launch_one(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+static int launch_one(const RnnShape& rs, int dtype, GinSrc gin, const void* h0, const void* c0,
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                       hipStream_t stream) {
   return dtype == TTRNN_F32
@@ -443,7 +482,7 @@ bool fast_rnn_fwd_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s);
 }
 
-int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, GinSrc gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream) {
 #define TT_TRY(SHAPE, CELL)                                                                         \

@@ -158,7 +158,7 @@ __device__ __forceinline__ float htanh(float x) {
 
 // gin: fp32 [B][T][H][4] gate-interleaved (LSTM i,g,f,o / GRU r,z,n,-).  One workgroup per sample.
 template <class S, int CELL>
-__global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, const float* __restrict__ gin,
+__global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc gs,
                                                           const bf16_t* __restrict__ h0, const bf16_t* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
                                                           const bf16_t* __restrict__ bias_hid, bf16_t* __restrict__ out,
@@ -196,9 +196,12 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, const fl
   for (int e = tid; e < HIMG; e += FAST_NT) hbuf[e] = (__bf16)0.f;
   __syncthreads();
 
+  const float* __restrict__ gin = gs.gin;
+  const bf16_t* __restrict__ xs = reinterpret_cast<const bf16_t*>(gs.x);
+  const bool in1 = gs.in1 != 0;
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
   float cst[HPT], hst[HPT], bh[HPT][G];
-  f32x4 gi[HPT];
+  f32x4 gi[HPT], vv[HPT], bb[HPT];
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -207,7 +210,18 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, const fl
     cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? ld(c0, b * H + hid) : 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) bh[u][g] = (ok && bias_hid) ? ld(bias_hid, g * H + hid) : 0.f;
-    gi[u] = (ok && T > 0) ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};
+    vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok && T > 0) {
+      if (in1) {
+        bb[u] = gin4[H + hid];
+        vv[u] = gin4[hid] - bb[u];
+        gi[u] = bb[u] + ld(xs, b * T) * vv[u];
+      } else {
+        gi[u] = gin4[(b * T) * H + hid];
+      }
+    }
     if (ok) hbuf[h_off<SL::KI>(hid / SL::K, hid % SL::K)] = (__bf16)hst[u];
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
@@ -267,7 +281,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, const fl
         hy = bf16_to_f32(hb);
         hst[u] = hy;
         hbuf[h_off<SL::KI>(hid / SL::K, hid % SL::K)] = (__bf16)hy;
-        if (t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
+        if (t + 1 < T) gi[u] = in1 ? bb[u] + ld(xs, bt + 1) * vv[u] : gin4[(bt + 1) * H + hid];
       }
     }
     lds_barrier();
@@ -283,7 +297,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, const fl
 }
 
 template <class S, int CELL>
-static int launch_bf16(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+static int launch_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
   static_assert(shape_ok_recurrent<S>(), "shape not supported by the MFMA path");
   hipLaunchKernelGGL((k_rnn_fwd_bf16<S, CELL>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
@@ -301,7 +315,7 @@ bool fast_rnn_fwd_bf16_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s);
 }
 
-int launch_rnn_fwd_bf16(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream) {
 #define TT_TRY(SHAPE, CELL)                               \

@@ -33,6 +33,17 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int n)
   for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = src[e];
 }
 
+template <typename T>
+__global__ void k_fill_unit_rows(T* dst) {
+  if (threadIdx.x == 0) { st(dst, 0, 1.0f); st(dst, 1, 0.0f); }
+}
+
+int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream) {
+  if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_fill_unit_rows<float>, dim3(1), dim3(64), 0, stream, (float*)dst);
+  else hipLaunchKernelGGL(k_fill_unit_rows<bf16_t>, dim3(1), dim3(64), 0, stream, (bf16_t*)dst);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pack / unpack
 // ---------------------------------------------------------------------------------------------

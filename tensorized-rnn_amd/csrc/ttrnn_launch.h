@@ -5,6 +5,17 @@
 
 namespace ttrnn {
 
+// Where the recurrent kernels get the hoisted input projection from.
+//   in1 == 0: gin = fp32 [B][T][H][4], one gate-interleaved row per (b, t)
+//   in1 == 1: input_size == 1.  W_in x + b is linear in the scalar x: gin holds just TWO rows, chain(1)+b and
+//             chain(0)+b (= b), produced by the same chain kernel, and the recurrent kernel forms
+//             b + x[b][t] * (row0 - row1) itself from the raw input x (storage dtype) — no [B][T] buffer at all.
+struct GinSrc {
+  const float* gin;
+  const void* x;
+  int in1;
+};
+
 struct LinPlan {
   int nb;            // rows per tile
   int bs;            // per-row stride of the ping-pong buffers (floats)
@@ -26,6 +37,7 @@ LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows);
 LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
 RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
 
+int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream);   // dst[0] = 1, dst[1] = 0 (storage dtype)
 int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
                 hipStream_t stream);
 int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
@@ -48,7 +60,7 @@ int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, cons
 
 // shape-specialised MFMA recurrent kernel (ttrnn_fast.hip); gin = hoisted input projection, fp32 [B][T][G*H]
 bool fast_rnn_fwd_available(const RnnShape& rs, int dtype);
-int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_fast(const RnnShape& rs, int dtype, GinSrc gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
@@ -60,7 +72,7 @@ int launch_ttlinear_fwd_fast(const TtShape& s, int dtype, bool y_f32, int64_t n_
 
 // bf16-storage recurrent kernel on the bf16 MFMA (ttrnn_fast_bf16.hip)
 bool fast_rnn_fwd_bf16_available(const RnnShape& rs, int dtype);
-int launch_rnn_fwd_bf16(const RnnShape& rs, const float* gin, const void* h0, const void* c0,
+int launch_rnn_fwd_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0,
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
