@@ -65,12 +65,17 @@ int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* 
 }
 
 // ---- TTLinear ---------------------------------------------------------------------------------
+// input_size == 1 backward: dv (fp32[out]) + the unit input row live in the workspace
+static size_t in1_bwd_bytes(const TtShape& s) { return ((size_t)s.out_size * sizeof(float) + 255 + 256) & ~(size_t)255; }
+
 size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   TtShape s;
   if (tt_shape_init(&s, w) != TTRNN_OK || n_rows < 0) return 0;
   const LinPlan f = plan_ttlinear_fwd(s, n_rows);
   const LinPlan b = plan_ttlinear_bwd(s, n_rows);
-  return f.ws_bytes > b.ws_bytes ? f.ws_bytes : b.ws_bytes;
+  size_t ws = f.ws_bytes > b.ws_bytes ? f.ws_bytes : b.ws_bytes;
+  if (s.in_size == 1 && in1_bwd_bytes(s) > ws) ws = in1_bwd_bytes(s);
+  return ws;
 }
 
 int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const float* packed, const void* bias,
@@ -102,9 +107,26 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
   if (!packed || !dy) return TTRNN_ERR_NULL;
   if (d_packed && !x) return TTRNN_ERR_NULL;
   if (!dx && !d_packed && !d_bias) return TTRNN_OK;
-  if (!force_generic() && fast_ttlinear_bwd_available(s, dtype, dy_dtype))
+  if (!force_generic() && fast_ttlinear_bwd_available(s, dtype, dy_dtype)) {
+    const char* no_in1 = getenv("TTRNN_NO_IN1");
+    if (s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= in1_bwd_bytes(s) &&
+        !(no_in1 && no_in1[0] == '1')) {
+      // y_n = b + x_n * chain(1): reduce dy over the rows once (dv = sum x_n dy_n, d_bias = sum dy_n), then
+      // back-propagate dv through the chain on the single unit row
+      float* dv = (float*)workspace;
+      void* unit = (char*)workspace + in1_bwd_bytes(s) - 256;
+      if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      st = launch_fill_unit_rows(unit, dtype, (hipStream_t)stream);
+      if (st != TTRNN_OK) return st;
+      st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (hipStream_t)stream);
+      if (st != TTRNN_OK) return st;
+      return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
+                                      (hipStream_t)stream);
+    }
     return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
                                     (hipStream_t)stream);
+  }
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,

@@ -44,6 +44,43 @@ int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+// input_size == 1: y_n = b + x_n * v  =>  dL/dv[o] = sum_n x_n dy[n][o],  dL/db[o] = sum_n dy[n][o].
+// One pass over dy (memory-bound); each workgroup owns a slab of rows, each thread a few columns.
+template <typename TX, typename TDY>
+__global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, const TX* __restrict__ x,
+                                                    const TDY* __restrict__ dy, float* __restrict__ dv,
+                                                    float* __restrict__ db) {
+  const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < n_rows ? r0 + per : n_rows;
+  for (int o = threadIdx.x; o < out; o += blockDim.x) {
+    float av = 0.f, ab = 0.f;
+    for (int64_t n = r0; n < r1; ++n) {
+      const float g = ld(dy, (size_t)n * out + o);
+      av = fmaf(ld(x, (size_t)n), g, av);
+      ab += g;
+    }
+    if (r1 > r0) {
+      atomicAdd(dv + o, av);
+      if (db) atomicAdd(db + o, ab);
+    }
+  }
+}
+
+int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
+                      float* db, hipStream_t stream) {
+  int grid = (int)((n_rows + 127) / 128);
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+#define TT_L(TX, TDY) hipLaunchKernelGGL((k_in1_reduce<TX, TDY>), dim3(grid), dim3(256), 0, stream, n_rows, out, (const TX*)x, (const TDY*)dy, dv, db)
+  if (dtype == TTRNN_F32 && dy_dtype == TTRNN_F32) TT_L(float, float);
+  else if (dtype == TTRNN_F32) TT_L(float, bf16_t);
+  else if (dy_dtype == TTRNN_F32) TT_L(bf16_t, float);
+  else TT_L(bf16_t, bf16_t);
+#undef TT_L
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pack / unpack
 // ---------------------------------------------------------------------------------------------

@@ -38,6 +38,8 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
 RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
 
 int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream);   // dst[0] = 1, dst[1] = 0 (storage dtype)
+int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
+                      float* db, hipStream_t stream);
 int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
                 hipStream_t stream);
 int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
