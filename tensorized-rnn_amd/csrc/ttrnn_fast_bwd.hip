@@ -329,8 +329,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           const float p3 = dht * tc * og * (1.0f - og);
           dcs[u] = dct * fg;
           bufA[hid] = p0; bufA[H + hid] = p1; bufA[2 * H + hid] = p2; bufA[3 * H + hid] = p3;
-          float* gp = dg_in + bt * GH;
-          gp[hid] = p0; gp[H + hid] = p1; gp[2 * H + hid] = p2; gp[3 * H + hid] = p3;
         } else {
           const float rg = qa[0], zg = qa[1], ng = qa[2], hn = qa[3];
           const float hprev = t > 0 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
@@ -339,15 +337,28 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
           dhd[u] = dht * zg;
           bufA[hid] = dr_pre; bufA[H + hid] = dz_pre; bufA[2 * H + hid] = dn_pre * rg;
-          float* gp = dg_in + bt * GH;
-          gp[hid] = dr_pre; gp[H + hid] = dz_pre; gp[2 * H + hid] = dn_pre;
-          float* gq = dg_hid + bt * GH;
-          gq[hid] = dr_pre; gq[H + hid] = dz_pre; gq[2 * H + hid] = dn_pre * rg;
+          dg_in[bt * GH + 2 * H + hid] = dn_pre;      // the only block where d_gates_in != d_gates_hid
         }
         ra[u] = na; rb[u] = nb; dout_n[u] = dn;
       }
     }
     lds_barrier();
+    // The gate-gradient row now sits complete in bufA in exactly the [G*H] order of the HBM row: stream it out
+    // as whole 16-byte pieces (coalesced) instead of four scattered dword stores per thread.  bufA is not
+    // rewritten before the second chain stage, two barriers away.
+    {
+      const f32x4* src4 = reinterpret_cast<const f32x4*>(bufA);
+      for (int e = tid; e < GH / 4; e += FAST_NT) {
+        const f32x4 v = src4[e];
+        if constexpr (CELL == TTRNN_LSTM) {
+          reinterpret_cast<f32x4*>(dg_in + bt * GH)[e] = v;
+          if (dg_hid && dg_hid != dg_in) reinterpret_cast<f32x4*>(dg_hid + bt * GH)[e] = v;
+        } else {
+          reinterpret_cast<f32x4*>(dg_hid + bt * GH)[e] = v;
+          if (e < 2 * H / 4) reinterpret_cast<f32x4*>(dg_in + bt * GH)[e] = v;
+        }
+      }
+    }
     // ---- transposed chain: stage 0 .. D-1, last stage writes dh_{t-1} (flat hidden index) -------------------
     if constexpr (D == 1) {
       run_bstage_last<S>(wl, bufA, dhbuf, wave, lane);
