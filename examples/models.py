@@ -1,0 +1,59 @@
+"""Callers of the hot path, restated for the drop-in packages (harness rows H1-H3).
+
+`MNISTClassifier` has the shape contract of the reference's experiments/digit_classification/
+mnist_classifier.py:13-57 (TT-RNN -> TTLinear head on the last timestep -> log_softmax);
+`SpeakerEncoder.forward` that of experiments/speaker_verification/encoder/speaker_encoder.py:69-91
+(TT-RNN -> TTLinear on the last hidden state -> ReLU -> L2 normalisation).  Both are ordinary nn.Modules over
+`tensorized_rnn` / `t3nsor` from tensorized-rnn_amd/, so every matmul-shaped op runs in libttrnn.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tensorized-rnn_amd"))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from torch import nn  # noqa: E402
+
+from t3nsor.layers import TTLinear  # noqa: E402
+from tensorized_rnn.gru import TTGRU  # noqa: E402
+from tensorized_rnn.tt_lstm import TTLSTM  # noqa: E402
+
+
+class MNISTClassifier(nn.Module):
+    def __init__(self, input_size, output_size, hidden_size, num_layers, device, gru=False, n_cores=3, tt_rank=8,
+                 naive_tt=False, extra_core=None, log_grads=False):
+        super().__init__()
+        self.gru = gru
+        cls = TTGRU if gru else TTLSTM
+        self.rnn = cls(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, device=device,
+                       n_cores=n_cores, tt_rank=tt_rank, log_grads=log_grads, is_naive=naive_tt, new_core=extra_core)
+        self.linear = TTLinear(in_features=hidden_size, out_features=output_size, bias=True, auto_shapes=True,
+                               d=n_cores, tt_rank=tt_rank)
+
+    def param_count(self):
+        return self.rnn.param_count() + sum(p.numel() for p in self.linear.parameters())
+
+    def forward(self, inputs):
+        out = self.rnn(inputs)[0]
+        return F.log_softmax(self.linear(out[:, -1, :]), dim=1)
+
+
+class SpeakerEncoder(nn.Module):
+    def __init__(self, mel_n_channels, hidden_size, num_layers, embedding_size, device, n_cores=3, rank=16,
+                 use_gru=False):
+        super().__init__()
+        cls = TTGRU if use_gru else TTLSTM
+        self.use_gru = use_gru
+        self.rnn = cls(mel_n_channels, hidden_size, num_layers, device, n_cores=n_cores, tt_rank=rank)
+        self.linear = TTLinear(in_features=hidden_size, out_features=embedding_size, bias=True, auto_shapes=True,
+                               d=n_cores, tt_rank=rank).to(device)
+        self.similarity_weight = nn.Parameter(torch.tensor([10.]))
+        self.similarity_bias = nn.Parameter(torch.tensor([-5.]))
+
+    def forward(self, utterances):
+        res = self.rnn(utterances)
+        last_hidden = res[1] if self.use_gru else res[1][0]
+        embeds_raw = torch.relu(self.linear(last_hidden))
+        return embeds_raw / torch.norm(embeds_raw, dim=1, keepdim=True)

@@ -321,3 +321,49 @@ def test_fast_and_generic_paths_agree():
     assert _maxabs(outs[0][1], outs[1][1]) <= 1e-5 * max(1.0, float(outs[1][1].abs().max()))
     for a, b in zip(outs[0][2], outs[1][2]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+
+
+def test_classifier_and_encoder_heads_vs_oracle():
+    """The callers of the path: TT-RNN -> TTLinear head -> log_softmax, and
+    TT-RNN -> TTLinear -> ReLU -> L2-normalise; forward and one backward against the CPU oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from models import MNISTClassifier, SpeakerEncoder
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(21)
+    with contextlib.redirect_stdout(io.StringIO()):
+        clf = MNISTClassifier(1, 10, 256, 1, dev(), gru=False, n_cores=3, tt_rank=8).to(dev())
+        enc = SpeakerEncoder(40, 256, 2, 256, dev(), n_cores=3, rank=16).to(dev())
+    x = torch.rand(4, 30, 1)
+    target = torch.tensor([1, 3, 5, 7])
+    logp = clf(x.to(dev()))
+    loss = torch.nn.functional.nll_loss(logp, target.to(dev()))
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in clf.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("rnn.")}, 1, True)
+    head = [sd["linear.parameters.%d" % k].clone().requires_grad_(True) for k in range(3)]
+    hb = sd["linear.bias"].clone().requires_grad_(True)
+    ro, _ = O.lstm_forward(layers, x)
+    rlogp = torch.log_softmax(O.ttlinear(head, hb, ro[:, -1, :]), dim=1)
+    rloss = torch.nn.functional.nll_loss(rlogp, target)
+    rloss.backward()
+    assert _maxabs(logp.detach(), rlogp.detach()) <= 1e-5
+    assert abs(loss.item() - rloss.item()) <= 1e-5
+    for k in range(3):
+        g = clf.linear.weight_t.tt_cores[k].grad
+        assert _maxabs(g, head[k].grad) <= 1e-4 * max(float(head[k].grad.abs().max()), 1e-6)
+    for name, p in clf.rnn.named_parameters():
+        ref = leaves[name].grad
+        assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    # speaker encoder forward
+    u = torch.rand(6, 12, 40)
+    emb = enc(u.to(dev()))
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    layers, _ = O.layers_from_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("rnn.")}, 2)
+    with torch.no_grad():
+        _, (rh, _) = O.lstm_forward(layers, u)
+        raw = torch.relu(O.ttlinear([sd["linear.parameters.%d" % k] for k in range(3)], sd["linear.bias"], rh))
+        remb = raw / torch.norm(raw, dim=1, keepdim=True)
+    assert emb.shape == (6, 256)
+    assert _maxabs(emb.detach(), remb) <= 1e-4
