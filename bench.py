@@ -41,6 +41,8 @@ WORKLOADS = {
                  desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=256/GPU bf16 storage (configs[2])"),
     "cfg4": dict(kind="ttlstm", inp=40, H=256, L=3, d=3, r=16, B=512, T=160, dtype="f32", flop=12416768,
                  desc="3-layer TT-LSTM in=40 H=256 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (configs[3] per-GPU batch)"),
+    "cfg5": dict(kind="ttlstm", inp=1024, H=1024, L=1, d=4, r=32, B=128, T=1024, dtype="f32", flop=70267904,
+                 desc="TT-LSTM in=1024 (assumed) H=1024 ncores=4 ttrank=32 seq_len=1024 batch=128/GPU fp32 (configs[4] global batch on one GPU)"),
     "cfg1": dict(kind="ttlstm", inp=1, H=128, L=1, d=2, r=4, B=32, T=784, dtype="f32", flop=71552, flop_in=4352,
                  desc="TT-LSTM in=1 H=128 ncores=2 ttrank=4 seq_len=784 batch=32 fp32 (configs[0] shapes)"),
 }

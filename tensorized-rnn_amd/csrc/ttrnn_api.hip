@@ -172,6 +172,7 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) return f.gin_bytes + f.lin_ws_bytes;
+  if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
 
@@ -229,6 +230,11 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
       return launch_rnn_fwd_bf16(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                (hipStream_t)stream);
+  }
+  if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) {
+    if (!workspace || workspace_bytes < big_rnn_fwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_fwd_big(rs, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,
+                              reserve, workspace, (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, false);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

@@ -1,0 +1,239 @@
+// ttrnn_fast_big.hip — MFMA kernels for TT shapes that do not fit on chip (BASELINE cfg5: H = 1024, d = 4, r = 32).
+//
+// One sample's chain intermediates are 256 KB (> 160 KB LDS) and one TT-matrix is 405 KB of cores (> the register
+// file), so the "everything resident" layout of ttrnn_fast.hip cannot hold.  These variants keep the same MFMA stage
+// code (ttrnn_mfma.h:lin_stage — runtime loop over row tiles, two tiles in flight, chunked fragment reads) and the
+// same persistent one-workgroup-per-sample structure, but
+//   * the stage images ping-pong through a per-workgroup slab of the global workspace (2 x 256 KB, L2 / Infinity
+//     Cache resident: 128 workgroups x 512 KB = 64 MB), a plain workgroup barrier orders the hand-off;
+//   * core fragments are re-streamed from L2 at the start of every stage (405 KB per step per workgroup) instead
+//     of living in VGPRs; the opaque per-stage lane id keeps hipcc from hoisting (and spilling) them;
+//   * h, c and the gate vector stay on chip (LDS / registers) exactly as in the small-shape kernels.
+// At 70 MFLOP per sample-step this regime is MFMA-bound (57 us of MFMA per step and CU), not latency-bound, so the
+// L2 round trips are affordable.  Replaces the same reference code as ttrnn_fast.hip.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+
+namespace ttrnn {
+
+using ShpH1024R32L = Shp<4, 4, 4, 8, 8, 8, 8, 8, 8, 32, 32, 32>;   // cfg5: TT-LSTM H = in = 1024, d = 4, r = 32
+
+template <class S, int k, int G>
+__device__ __forceinline__ void big_stage(const float* packed, const float* in, float* out, int wave, int lane,
+                                          int ilv_mode) {
+  int z = 0;
+  asm volatile("" : "+v"(z));          // keep the fragment loads and their address arithmetic inside this stage
+  float w[nwreg<S, k>()];
+  load_wfrag<S, k>(w, packed, wave, lane + z);
+  lin_stage<S, k, 1, G>(w, in, out, wave, lane + z, ilv_mode);
+}
+
+template <class S>
+constexpr int big_mid() {      // floats of the largest stage image
+  int best = in_size_of<S>();
+  for (int k = 1; k < S::D; ++k) {
+    const int e = rows_of<S>(k) * S::I[k] * S::R[k];
+    if (e > best) best = e;
+  }
+  return best;
+}
+
+__device__ __forceinline__ float bsigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float btanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// chain y = TT(packed) v for ONE sample whose input image already sits in img0 (a_off<KP> layout);
+// the result (flat o, or gate-interleaved when G > 0) is written to `res`.
+template <class S, int G>
+__device__ __forceinline__ void big_chain(const float* packed, float* img0, float* imgA, float* imgB, float* res,
+                                          int wave, int lane, int ilv_mode) {
+  constexpr int D = S::D;
+  if constexpr (D == 1) {
+    big_stage<S, 0, G>(packed, img0, res, wave, lane, ilv_mode);
+  } else if constexpr (D == 2) {
+    big_stage<S, 1, G>(packed, img0, imgA, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 0, G>(packed, imgA, res, wave, lane, ilv_mode);
+  } else if constexpr (D == 3) {
+    big_stage<S, 2, G>(packed, img0, imgA, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 1, G>(packed, imgA, imgB, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 0, G>(packed, imgB, res, wave, lane, ilv_mode);
+  } else {
+    big_stage<S, 3, G>(packed, img0, imgA, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 2, G>(packed, imgA, imgB, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 1, G>(packed, imgB, imgA, wave, lane, ilv_mode);
+    __syncthreads();
+    big_stage<S, 0, G>(packed, imgA, res, wave, lane, ilv_mode);
+  }
+}
+
+// ---- batched input projection: gin[n][H][4] = TT(packed_in) x[n] (bias is added by the recurrent kernel) ----------
+template <class S, int G, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_big(int64_t n_rows, const float* __restrict__ packed,
+                                                              const TS* __restrict__ x, float* __restrict__ y,
+                                                              float* __restrict__ ws, int ilv_mode) {
+  constexpr int IN = in_size_of<S>(), OUT = out_size_of<S>();
+  constexpr int MID = big_mid<S>();
+  using SL = St<S, S::D - 1>;
+  static_assert(SL::K % 4 == 0, "big-shape kernels need an unpadded first image");
+  constexpr int YT = G == 0 ? OUT : (OUT / (G > 0 ? G : 1)) * 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* img0 = ws + (size_t)blockIdx.x * 3 * MID;
+  float* imgA = img0 + MID;
+  float* imgB = imgA + MID;
+  for (int64_t n = blockIdx.x; n < n_rows; n += gridDim.x) {
+    for (int e = tid; e < IN; e += FAST_NT) img0[a_off<SL::KP>(e / SL::K, e % SL::K)] = ld(x, (size_t)n * IN + e);
+    __syncthreads();
+    big_chain<S, G>(packed, img0, imgA, imgB, y + (size_t)n * YT, wave, lane, ilv_mode);
+    __syncthreads();
+  }
+}
+
+// ---- persistent recurrent kernel --------------------------------------------------------------------------------
+template <class S, int CELL, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const float* __restrict__ gin,
+                                                         const TS* __restrict__ h0, const TS* __restrict__ c0,
+                                                         const float* __restrict__ packed_hid,
+                                                         const TS* __restrict__ bias_in, const TS* __restrict__ bias_hid,
+                                                         TS* __restrict__ out, TS* __restrict__ hT, TS* __restrict__ cT,
+                                                         float* __restrict__ reserve, float* __restrict__ ws) {
+  constexpr int H = in_size_of<S>();
+  constexpr int G = CELL == TTRNN_LSTM ? 4 : 3;
+  constexpr int GH = G * H;
+  static_assert(out_size_of<S>() == GH, "TT output size must be n_gates * hidden");
+  constexpr int HPT = (H + FAST_NT - 1) / FAST_NT;
+  constexpr int MID = big_mid<S>();
+  using SL = St<S, S::D - 1>;
+  static_assert(SL::K % 4 == 0, "big-shape kernels need an unpadded first image");
+
+  __shared__ __attribute__((aligned(16))) float hbuf[H];
+  __shared__ __attribute__((aligned(16))) float gbuf[GH];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t b = blockIdx.x;
+  float* imgA = ws + (size_t)blockIdx.x * 2 * MID;
+  float* imgB = imgA + MID;
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+
+  float cst[HPT], hst[HPT], bh[HPT][G];
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) {
+    const int hid = tid + u * FAST_NT;
+    const bool ok = hid < H;
+    hst[u] = (ok && h0) ? ld(h0, b * H + hid) : 0.f;
+    cst[u] = (ok && c0 && CELL == TTRNN_LSTM) ? ld(c0, b * H + hid) : 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      bh[u][g] = (ok && bias_hid ? ld(bias_hid, g * H + hid) : 0.f) + (ok && bias_in ? ld(bias_in, g * H + hid) : 0.f);
+    if (ok) hbuf[a_off<SL::KP>(hid / SL::K, hid % SL::K)] = hst[u];
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    big_chain<S, 0>(packed_hid, hbuf, imgA, imgB, gbuf, wave, lane, 0);
+    __syncthreads();
+    const size_t bt = b * T + t;
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+      const int hid = tid + u * FAST_NT;
+      if (hid < H) {
+        const f32x4 gi = gin4[bt * H + hid];          // slots i,g,f,o (LSTM) / r,z,n,- (GRU)
+        float hy;
+        if constexpr (CELL == TTRNN_LSTM) {
+          const float ig = bsigmoid(gi[0] + gbuf[hid] + bh[u][0]);                 // lstm.py:26
+          const float fg = bsigmoid(gi[2] + gbuf[H + hid] + bh[u][1]);             // lstm.py:27
+          const float gg = btanh(gi[1] + gbuf[2 * H + hid] + bh[u][2]);            // lstm.py:28
+          const float og = bsigmoid(gi[3] + gbuf[3 * H + hid] + bh[u][3]);         // lstm.py:29
+          const float cy = fg * cst[u] + ig * gg;                                  // lstm.py:31
+          hy = og * btanh(cy);                                                     // lstm.py:32
+          cst[u] = cy;
+          if (reserve) {
+            float* rv = reserve + (bt * H + hid) * 8;
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+          }
+        } else {
+          // bias_in must not be scaled by r: split the fused bias again for the n gate (gru.py:42-43)
+          const float bn_in = bias_in ? ld(bias_in, 2 * H + hid) : 0.f;
+          const float hn = gbuf[2 * H + hid] + bh[u][2] - bn_in;
+          const float rg = bsigmoid(gi[0] + gbuf[hid] + bh[u][0]);
+          const float zg = bsigmoid(gi[1] + gbuf[H + hid] + bh[u][1]);
+          const float ng = btanh(gi[2] + bn_in + rg * hn);
+          hy = (1.0f - zg) * ng + zg * hst[u];
+          if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+        }
+        st(out, bt * H + hid, hy);
+        hy = ld(out, bt * H + hid);
+        hst[u] = hy;
+        hbuf[a_off<SL::KP>(hid / SL::K, hid % SL::K)] = hy;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) {
+    const int hid = tid + u * FAST_NT;
+    if (hid < H) {
+      if (hT) st(hT, b * H + hid, hst[u]);
+      if (CELL == TTRNN_LSTM && cT) st(cT, b * H + hid, cst[u]);
+    }
+  }
+}
+
+// ---- dispatch -------------------------------------------------------------------------------------------------------
+static constexpr int BIG_LIN_GRID = 512;     // workgroups of the batched projection (2 per CU)
+
+bool big_rnn_fwd_available(const RnnShape& rs, int dtype) {
+  if ((dtype != TTRNN_F32 && dtype != TTRNN_BF16) || rs.B < 1 || rs.T < 1 || rs.cell != TTRNN_LSTM) return false;
+  return shape_matches<ShpH1024R32L>(rs.hid_s) && shape_matches<ShpH1024R32L>(rs.in_s);
+}
+
+size_t big_rnn_fwd_workspace(const RnnShape& rs) {
+  constexpr size_t MID = big_mid<ShpH1024R32L>();
+  const size_t gin = (size_t)rs.B * rs.T * rs.H * 4 * sizeof(float);
+  const size_t lin = (size_t)BIG_LIN_GRID * 3 * MID * sizeof(float);
+  const size_t rec = (size_t)rs.B * 2 * MID * sizeof(float);
+  return gin + (lin > rec ? lin : rec);
+}
+
+template <typename TS>
+static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in,
+                        const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT,
+                        void* cT, float* reserve, void* workspace, hipStream_t stream) {
+  using S = ShpH1024R32L;
+  float* gin = (float*)workspace;
+  float* slab = gin + (size_t)rs.B * rs.T * rs.H * 4;
+  const int64_t n_rows = (int64_t)rs.B * rs.T;
+  const int grid = (int)(n_rows < BIG_LIN_GRID ? n_rows : BIG_LIN_GRID);
+  hipLaunchKernelGGL((k_ttlinear_fwd_big<S, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed_in,
+                     (const TS*)x, gin, slab, 2);
+  if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL((k_rnn_fwd_big<S, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                     (const TS*)h0, (const TS*)c0, packed_hid,
+                     rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr,
+                     rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr, (TS*)out, (TS*)hT, (TS*)cT, reserve,
+                     slab);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_rnn_fwd_big(const RnnShape& rs, int dtype, const void* x, const void* h0, const void* c0,
+                       const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
+                       void* out, void* hT, void* cT, float* reserve, void* workspace, hipStream_t stream) {
+  return dtype == TTRNN_F32 ? launch_big_t<float>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,
+                                                  reserve, workspace, stream)
+                            : launch_big_t<bf16_t>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT,
+                                                   cT, reserve, workspace, stream);
+}
+
+}  // namespace ttrnn

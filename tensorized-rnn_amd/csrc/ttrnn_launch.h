@@ -78,6 +78,13 @@ int launch_rnn_fwd_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const vo
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
+// shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
+bool big_rnn_fwd_available(const RnnShape& rs, int dtype);
+size_t big_rnn_fwd_workspace(const RnnShape& rs);
+int launch_rnn_fwd_big(const RnnShape& rs, int dtype, const void* x, const void* h0, const void* c0,
+                       const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
+                       void* out, void* hT, void* cT, float* reserve, void* workspace, hipStream_t stream);
+
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);
 int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
