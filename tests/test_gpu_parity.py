@@ -367,3 +367,30 @@ def test_classifier_and_encoder_heads_vs_oracle():
         remb = raw / torch.norm(raw, dim=1, keepdim=True)
     assert emb.shape == (6, 256)
     assert _maxabs(emb.detach(), remb) <= 1e-4
+
+
+@pytest.mark.parametrize("kind,inp,H,L,r,B,T,dtype", [
+    ("ttlstm", 1, 256, 1, 8, 64, 200, torch.float32),      # fused LSTM kernel, in=1 path
+    ("ttgru", 1, 256, 1, 8, 96, 120, torch.float32),       # unfused kernel
+    ("ttlstm", 40, 256, 2, 16, 80, 40, torch.float32),     # r=16, hoisted batched projection, 2 layers
+    ("ttgru", 1, 256, 1, 8, 128, 150, torch.bfloat16),     # bf16 MFMA kernel
+])
+def test_repeat_runs_are_bitwise_identical(kind, inp, H, L, r, B, T, dtype):
+    """Race screen for the LDS hand-offs behind raw s_barrier: forward results must not change between
+    launches (no atomics on the forward path), and gradients must agree to rounding (atomic flushes)."""
+    torch.manual_seed(3)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=3, tt_rank=r), dev())
+    m = m.to(dtype)
+    x = torch.rand(B, T, inp, device=dev()).to(dtype)
+    with torch.no_grad():
+        ref = m(x)[0].clone()
+        for _ in range(4):
+            assert torch.equal(m(x)[0], ref)
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        out = m(x)[0]
+        out.float().square().mean().backward()
+        grads.append([p.grad.float().clone() for p in m.parameters()])
+    for a, b in zip(*grads):
+        assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6)

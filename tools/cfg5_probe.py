@@ -1,5 +1,5 @@
 import sys, time, contextlib, io
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tensorized-rnn_amd')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tensorized-rnn_amd"))
 import torch
 from tensorized_rnn.tt_lstm import TTLSTM
 dev = torch.device('cuda:0')
