@@ -66,6 +66,64 @@ class FusedCellMixin(object):
         return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid)
 
 
+class TTWeightsMixin(object):
+    """TT weight factories shared by ``TTLSTMCell`` and ``TTGRUCell``.
+
+    Reference behaviour being mirrored (``tt_lstm.py:13-40``, ``gru.py:139-163``): both weight sets are a
+    gates-concatenated ``TTLinear`` (``n_gate * hidden`` outputs, mode shapes from ``tt_shape``) or, for
+    ``is_naive``, a ``TTLinearSet`` of ``n_gate`` independent TTLinears.  ``naive_bias`` is what the
+    naive set receives for ``bias``: the LSTM passes a literal False (tt_lstm.py:21,34), the GRU passes
+    the cell's flag (gru.py:150,163)."""
+    n_gate = None
+    naive_bias = None       # None -> follow self.bias
+
+    def _tt_options(self, n_cores, tt_rank, is_naive, new_core):
+        # must run BEFORE the dense base __init__, which calls the factories below
+        self.n_cores, self.tt_rank = n_cores, tt_rank
+        self.is_naive, self.new_core = is_naive, new_core
+
+    def _tt_weights(self, fan_in):
+        from t3nsor.layers import TTLinear
+        from .rnn_utils import tt_shape
+        from .tt_linearset import TTLinearSet
+        G, H = self.n_gate, self.hidden_size
+        if self.is_naive:
+            b = self.bias if self.naive_bias is None else self.naive_bias
+            w = TTLinearSet(in_features=fan_in, out_features=H, n_gates=G, bias=b, auto_shapes=True,
+                            d=self.n_cores, tt_rank=self.tt_rank)
+        else:
+            modes = tt_shape(fan_in, H, self.n_cores, G, new_core=self.new_core)
+            w = TTLinear(out_features=G * H, shape=modes, bias=self.bias, auto_shapes=False,
+                         d=self.n_cores, tt_rank=self.tt_rank)
+        return w.to(self.device)
+
+    def _create_input_hidden_weights(self):
+        return self._tt_weights(self.input_size)
+
+    def _create_hidden_hidden_weights(self):
+        return self._tt_weights(self.hidden_size)
+
+
+class TTStackMixin(object):
+    """Layer factories of the multi-layer TT models: every layer gets a cell of ``tt_cell_cls``."""
+    tt_cell_cls = None
+
+    def _tt_options(self, n_cores, tt_rank, is_naive, new_core):
+        assert new_core in [None, 'first', 'last']
+        self.n_cores, self.tt_rank = n_cores, tt_rank
+        self.is_naive, self.new_core = is_naive, new_core
+
+    def _tt_cell(self, fan_in):
+        return self.tt_cell_cls(fan_in, self.hidden_size, self.bias, self.device, n_cores=self.n_cores,
+                                tt_rank=self.tt_rank, is_naive=self.is_naive, new_core=self.new_core)
+
+    def _create_first_layer_cell(self):
+        return self._tt_cell(self.input_size)
+
+    def _create_other_layer_cell(self):
+        return self._tt_cell(self.hidden_size)
+
+
 class FusedRnnBase(nn.Module):
     """Layer stack + state handling shared by LSTM and GRU."""
     kind = None

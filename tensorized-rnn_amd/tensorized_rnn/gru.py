@@ -12,11 +12,7 @@ kernel (see ``_fused.py``).
 import torch
 from torch import nn
 
-from t3nsor.layers import TTLinear
-
-from ._fused import FusedCellMixin, FusedRnnBase
-from .rnn_utils import tt_shape
-from .tt_linearset import TTLinearSet
+from ._fused import FusedCellMixin, FusedRnnBase, TTStackMixin, TTWeightsMixin
 
 
 class GRUCell(FusedCellMixin, nn.Module):
@@ -90,48 +86,19 @@ class GRU(FusedRnnBase):
         return outputs, hT
 
 
-class TTGRUCell(GRUCell):
+class TTGRUCell(TTWeightsMixin, GRUCell):
+    n_gate = 3
+
     def __init__(self, input_size, hidden_size, bias, device, n_cores, tt_rank,
                  is_naive=False, new_core=None):
-        self.n_cores = n_cores
-        self.tt_rank = tt_rank
-        self.is_naive = is_naive
-        self.new_core = new_core
-        super().__init__(input_size, hidden_size, bias, device)
-
-    def _tt_weights(self, in_features):
-        if self.is_naive:
-            layer = TTLinearSet(in_features=in_features, out_features=self.hidden_size, n_gates=3,
-                                bias=self.bias, auto_shapes=True, d=self.n_cores, tt_rank=self.tt_rank)
-        else:
-            shape = tt_shape(in_features, self.hidden_size, self.n_cores, 3, new_core=self.new_core)
-            layer = TTLinear(out_features=3 * self.hidden_size, shape=shape, bias=self.bias,
-                             auto_shapes=False, d=self.n_cores, tt_rank=self.tt_rank)
-        return layer.to(self.device)
-
-    def _create_input_hidden_weights(self):
-        return self._tt_weights(self.input_size)
-
-    def _create_hidden_hidden_weights(self):
-        return self._tt_weights(self.hidden_size)
+        self._tt_options(n_cores, tt_rank, is_naive, new_core)
+        GRUCell.__init__(self, input_size, hidden_size, bias, device)
 
 
-class TTGRU(GRU):
+class TTGRU(TTStackMixin, GRU):
+    tt_cell_cls = TTGRUCell
+
     def __init__(self, input_size, hidden_size, num_layers, device, n_cores, tt_rank,
                  bias=True, is_naive=False, log_grads=False, new_core=None):
-        assert new_core in [None, 'first', 'last']
-        self.n_cores = n_cores
-        self.tt_rank = tt_rank
-        self.is_naive = is_naive
-        self.new_core = new_core
-        super().__init__(input_size, hidden_size, num_layers, device, bias, log_grads=log_grads)
-
-    def _make_cell(self, in_features):
-        return TTGRUCell(in_features, self.hidden_size, self.bias, self.device, n_cores=self.n_cores,
-                         tt_rank=self.tt_rank, is_naive=self.is_naive, new_core=self.new_core)
-
-    def _create_first_layer_cell(self):
-        return self._make_cell(self.input_size)
-
-    def _create_other_layer_cell(self):
-        return self._make_cell(self.hidden_size)
+        self._tt_options(n_cores, tt_rank, is_naive, new_core)
+        GRU.__init__(self, input_size, hidden_size, num_layers, device, bias, log_grads=log_grads)
