@@ -77,6 +77,21 @@ const char* ttrnn_status_string(int status);
 /* 1 when a usable HIP device is visible to this process, else 0 (never launches). */
 int ttrnn_device_available(void);
 
+/* How fp32 tensors are multiplied inside the shape-specialised recurrent kernels (process-wide; the analogue of
+ * torch.backends.*.matmul precision switches — the reference itself has none, its fp32 GEMMs are whatever the
+ * BLAS under torch.einsum does, t3nsor/ops.py:85-91):
+ *   TTRNN_MATH_EXACT  v_mfma_f32_16x16x4_f32 on the fp32 operands;
+ *   TTRNN_MATH_SPLIT  every fp32 operand is split into three bf16 pieces (x = x0+x1+x2) and the product is rebuilt
+ *                     from the six bf16 MFMA terms of weight >= 2^-18 with fp32 accumulation: per-product error
+ *                     < 2^-24 relative, i.e. fp32-class results at 2.67x less matrix-pipe time.  Only the order and
+ *                     grouping of fp32 additions differ from TTRNN_MATH_EXACT.
+ * Default: environment variable TTRNN_FP32_MATH = "exact" | "split" read at first use, else see DESIGN.md.
+ * Storage dtype, accumulators, gate math and state are unaffected; TTRNN_BF16 descriptors ignore the switch. */
+#define TTRNN_MATH_EXACT 0
+#define TTRNN_MATH_SPLIT 1
+int ttrnn_set_fp32_math(int mode);      /* TTRNN_OK or TTRNN_ERR_UNSUPPORTED */
+int ttrnn_get_fp32_math(void);
+
 /* ---- weights: strided reference Parameters <-> packed fp32 cores ----------------------------
  * Packed layout (fp32): for k = 0..d-1   W_k [K_k = J_k*R_{k+1}][M_k = I_k*R_k],
  *   W_k[(j*R_{k+1}+b)*M_k + (i*R_k+a)] = G_k[a,i,j,b]          (the stage-k GEMM operand),

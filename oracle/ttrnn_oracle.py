@@ -90,9 +90,9 @@ def lstm_forward(layers, x, init_states=None):
     layers: list of (w_in, w_hid)."""
     B, T, _ = x.shape
     H = _hidden_size(layers[0][1])
-    outputs = torch.zeros(B, T, H)
+    outputs = torch.zeros(B, T, H, dtype=x.dtype)
     if init_states is None:
-        h, c = torch.zeros(B, H), torch.zeros(B, H)
+        h, c = torch.zeros(B, H, dtype=x.dtype), torch.zeros(B, H, dtype=x.dtype)
     else:
         h, c = init_states
     state = [(h, c)] * len(layers)
@@ -111,8 +111,8 @@ def gru_forward(layers, x, init_states=None):
     """GRU.forward.                                               tensorized_rnn/gru.py:104-136"""
     B, T, _ = x.shape
     H = _hidden_size(layers[0][1])
-    outputs = torch.zeros(B, T, H)
-    h = torch.zeros(B, H) if init_states is None else init_states
+    outputs = torch.zeros(B, T, H, dtype=x.dtype)
+    h = torch.zeros(B, H, dtype=x.dtype) if init_states is None else init_states
     state = [h] * len(layers)
     inp = None
     for t in range(T):
@@ -141,13 +141,14 @@ def _hidden_size(w_hid):
 # --------------------------------------------------------------------------------------------------
 # helpers to rebuild the oracle's operands from a golden case / from shapes
 # --------------------------------------------------------------------------------------------------
-def layers_from_state_dict(sd, num_layers, requires_grad=False):
+def layers_from_state_dict(sd, num_layers, requires_grad=False, dtype=torch.float32):
     """sd: {key: tensor} with the reference's state_dict keys.  Returns the
-    `layers` list for lstm_forward / gru_forward plus a {key: tensor} dict of the leaf tensors."""
+    `layers` list for lstm_forward / gru_forward plus a {key: tensor} dict of the leaf tensors.
+    dtype=torch.float64 evaluates the same op sequence in double (the "exact" result for error measurements)."""
     leaves = {}
 
     def leaf(key):
-        t = sd[key].clone().float()
+        t = sd[key].clone().to(dtype)
         if requires_grad:
             t.requires_grad_(True)
         leaves[key] = t

@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
   float cst[HPT], hst[HPT], bh[HPT][G];
   f32x4 gi[HPT], vv[HPT], bb[HPT];
+  XChunk<TS> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -103,7 +106,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
       if (in1) {
         bb[u] = gin4[H + hid];
         vv[u] = gin4[hid] - bb[u];
-        gi[u] = bb[u] + ld(xs, b * T) * vv[u];
       } else {
         gi[u] = gin4[(b * T) * H + hid];
       }
@@ -139,11 +141,13 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
     lds_barrier();
     // ---- gates + state update (lstm.py:26-32 / gru.py:38-44) ----------------------------------------
     const size_t bt = b * T + t;
+    const float xt = in1 ? xq.at(t) : 0.f;
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
       const int hid = tid + u * FAST_NT;
       if (hid < H) {
         float hy;
+        if (in1) gi[u] = bb[u] + xt * vv[u];      // W_in x_t + b_in from the two unit rows (GinSrc)
         if constexpr (CELL == TTRNN_LSTM) {
           const float ig = fsigmoid(gi[u][0] + gbuf[hid] + bh[u][0]);
           const float fg = fsigmoid(gi[u][2] + gbuf[H + hid] + bh[u][1]);
@@ -170,9 +174,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
         hst[u] = hy;
         hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hy;
         // prefetch the hoisted input projection of the next step; consumed one iteration later
-        if (t + 1 < T) gi[u] = in1 ? bb[u] + ld(xs, bt + 1) * vv[u] : gin4[(bt + 1) * H + hid];
+        if (!in1 && t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
       }
     }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
     lds_barrier();
   }
 #pragma unroll
@@ -277,6 +282,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
   const bool in1 = gs.in1 != 0;
   float cst[T0::XM][T0::YR], hst[T0::XM][T0::YR], bh[T0::XM][T0::YR][NG], gi[T0::XM][T0::YR][NG];
   float vv[T0::XM][T0::YR][NG], bb[T0::XM][T0::YR][NG];
+  XChunk<TS> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
 #pragma unroll
   for (int x = 0; x < T0::XM; ++x) {
     const int mt = T0::SPLIT ? (wave % T0::MT) : (wave + FAST_NW * x);
@@ -300,7 +308,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
           if (in1) {
             bb[x][y][g] = gin[(H + hd) * 4 + slot];
             vv[x][y][g] = gin[hd * 4 + slot] - bb[x][y][g];
-            gi[x][y][g] = bb[x][y][g] + ld(xs, b * T) * vv[x][y][g];
           } else {
             gi[x][y][g] = gin[((b * T) * H + hd) * 4 + slot];
           }
@@ -350,11 +357,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
     }
     TT_STAMP(4)
     const size_t bt = b * T + t;
+    const float xt = in1 ? xq.at(t) : 0.f;
 #pragma unroll
     for (int x = 0; x < T0::XM; ++x)
 #pragma unroll
       for (int y = 0; y < T0::YR; ++y) {
         const int hd = hid[x][y];
+        if (in1) {      // W_in x_t + b_in from the two unit rows (GinSrc)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) gi[x][y][g] = bb[x][y][g] + xt * vv[x][y][g];
+        }
         if constexpr (PAIR) {
           // lanes 0-31: (i, g); lanes 32-63: (f, o).  u = sigmoid(first), v = tanh|sigmoid(second)
           const float u = fsigmoid(acc[x][y][0] + gi[x][y][0] + bh[x][y][0]);                 // lstm.py:26-27
@@ -375,15 +387,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
             hst[x][y] = hy;
             hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           }
-          if (ok[x][y] && t + 1 < T) {
-            if (in1) {
-              const float xn = ld(xs, bt + 1);
-              gi[x][y][0] = bb[x][y][0] + xn * vv[x][y][0];
-              gi[x][y][1] = bb[x][y][1] + xn * vv[x][y][1];
-            } else {
-              const f32x2 nx = *reinterpret_cast<const f32x2*>(gin + ((bt + 1) * H + hd) * 4 + 2 * pair);
-              gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1];
-            }
+          if (!in1 && ok[x][y] && t + 1 < T) {
+            const f32x2 nx = *reinterpret_cast<const f32x2*>(gin + ((bt + 1) * H + hd) * 4 + 2 * pair);
+            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1];
           }
         } else if (ok[x][y]) {
           const float ig = fsigmoid(acc[x][y][0] + gi[x][y][0] + bh[x][y][0]);     // lstm.py:26
@@ -399,18 +405,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
             float* rv = reserve + (bt * H + hd) * 8;
             rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
           }
-          if (t + 1 < T) {
-            if (in1) {
-              const float xn = ld(xs, bt + 1);
-#pragma unroll
-              for (int g = 0; g < 4; ++g) gi[x][y][g] = bb[x][y][g] + xn * vv[x][y][g];
-            } else {
-              const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
-              gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1]; gi[x][y][2] = nx[2]; gi[x][y][3] = nx[3];
-            }
+          if (!in1 && t + 1 < T) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+            gi[x][y][0] = nx[0]; gi[x][y][1] = nx[1]; gi[x][y][2] = nx[2]; gi[x][y][3] = nx[3];
           }
         }
       }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
     TT_STAMP(5)
     lds_barrier();
     TT_STAMP(6)

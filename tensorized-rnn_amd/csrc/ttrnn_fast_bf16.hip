@@ -202,6 +202,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
   float cst[HPT], hst[HPT], bh[HPT][G];
   f32x4 gi[HPT], vv[HPT], bb[HPT];
+  XChunk<bf16_t> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -217,7 +220,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
       if (in1) {
         bb[u] = gin4[H + hid];
         vv[u] = gin4[hid] - bb[u];
-        gi[u] = bb[u] + ld(xs, b * T) * vv[u];
       } else {
         gi[u] = gin4[(b * T) * H + hid];
       }
@@ -251,11 +253,13 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
     }
     lds_barrier();
     const size_t bt = b * T + t;
+    const float xt = in1 ? xq.at(t) : 0.f;
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
       const int hid = tid + u * FAST_NT;
       if (hid < H) {
         float hy;
+        if (in1) gi[u] = bb[u] + xt * vv[u];      // W_in x_t + b_in from the two unit rows (GinSrc)
         if constexpr (CELL == TTRNN_LSTM) {
           const float ig = hsigmoid(gi[u][0] + gbuf[hid] + bh[u][0]);              // lstm.py:26
           const float fg = hsigmoid(gi[u][2] + gbuf[H + hid] + bh[u][1]);          // lstm.py:27
@@ -281,9 +285,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
         hy = bf16_to_f32(hb);
         hst[u] = hy;
         hbuf[h_off<SL::KI>(hid / SL::K, hid % SL::K)] = (__bf16)hy;
-        if (t + 1 < T) gi[u] = in1 ? bb[u] + ld(xs, bt + 1) * vv[u] : gin4[(bt + 1) * H + hid];
+        if (!in1 && t + 1 < T) gi[u] = gin4[(bt + 1) * H + hid];
       }
     }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
     lds_barrier();
   }
 #pragma unroll

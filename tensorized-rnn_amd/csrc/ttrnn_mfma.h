@@ -235,6 +235,29 @@ __device__ __forceinline__ float ftanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// input_size == 1 (GinSrc::in1): the scalar inputs x[b][t] of 64 consecutive timesteps sit in ONE VGPR of every wave
+// (lane l <-> step t0 + l) and are refilled a whole chunk ahead.  The time loop reads x_t with v_readlane and never
+// waits on a load it has just issued (a per-step `global_load ; s_waitcnt vmcnt(0)` exposes one L2/HBM round trip
+// per timestep on the critical path).
+template <typename TS>
+struct XChunk {
+  float cur, nxt;
+  __device__ __forceinline__ void init(const TS* xs, size_t base, int T, int lane) {
+    cur = lane < T ? ld(xs, base + lane) : 0.f;
+    nxt = 64 + lane < T ? ld(xs, base + 64 + lane) : 0.f;
+  }
+  __device__ __forceinline__ float at(int t) const {      // t must lie in the current chunk
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), t & 63));
+  }
+  __device__ __forceinline__ void advance(const TS* xs, size_t base, int T, int t, int lane) {   // after step t's use
+    if ((t & 63) == 63) {
+      cur = nxt;
+      const int i = t + 65 + lane;
+      nxt = i < T ? ld(xs, base + i) : 0.f;
+    }
+  }
+};
+
 // ---- batched (NB stacked samples) forward stage, shared by ttrnn_fast_lin.hip and ttrnn_fast_bwd.hip ------------
 // index of output feature o of stacked sample smp inside the LDS output tile
 template <int G, int OUT>

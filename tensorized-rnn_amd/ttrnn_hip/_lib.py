@@ -3,6 +3,7 @@
 The library is built in-tree by ``__graft_entry__.build()`` / ``make -C tensorized-rnn_amd/csrc``.
 There is no CPU fallback: every compute entry point raises if the library is missing.
 """
+import contextlib
 import ctypes
 import os
 
@@ -14,7 +15,8 @@ TTRNN_LSTM, TTRNN_GRU = 0, 1
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttrnn.so")
+# TTRNN_LIB_PATH: developer override (A/B-ing two builds of the library in one session); default = the in-tree build
+LIB_PATH = os.environ.get("TTRNN_LIB_PATH") or os.path.join(_HERE, "libttrnn.so")
 
 
 class TtmDesc(ctypes.Structure):
@@ -39,6 +41,8 @@ _SIGNATURES = {
     "ttrnn_abi_version": (ctypes.c_int, []),
     "ttrnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "ttrnn_device_available": (ctypes.c_int, []),
+    "ttrnn_set_fp32_math": (ctypes.c_int, [ctypes.c_int]),
+    "ttrnn_get_fp32_math": (ctypes.c_int, []),
     "ttrnn_packed_elems": (ctypes.c_int64, [ctypes.POINTER(TtmDesc)]),
     "ttrnn_pack_cores": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
                                         ctypes.c_int, _P, _P]),
@@ -88,6 +92,33 @@ def check(status, what):
     if status != 0:
         msg = load().ttrnn_status_string(status).decode()
         raise TtrnnError("{} failed: {} ({})".format(what, msg, status))
+
+
+MATH_MODES = {"exact": 0, "split": 1}     # TTRNN_MATH_EXACT / TTRNN_MATH_SPLIT (include/ttrnn.h)
+
+
+def set_fp32_math(mode):
+    """Select how the shape-specialised kernels multiply fp32 operands: "exact" (fp32 MFMA) or "split"
+    (three-way bf16 split, six bf16 MFMA terms, fp32 accumulation).  Process-wide; returns the previous mode."""
+    if mode not in MATH_MODES:
+        raise ValueError("fp32 math mode must be one of {}".format(sorted(MATH_MODES)))
+    prev = get_fp32_math()
+    check(load().ttrnn_set_fp32_math(MATH_MODES[mode]), "ttrnn_set_fp32_math")
+    return prev
+
+
+def get_fp32_math():
+    code = load().ttrnn_get_fp32_math()
+    return next(name for name, c in MATH_MODES.items() if c == code)
+
+
+@contextlib.contextmanager
+def fp32_math(mode):
+    prev = set_fp32_math(mode)
+    try:
+        yield
+    finally:
+        set_fp32_math(prev)
 
 
 def make_ttm(in_modes, out_modes, ranks):

@@ -116,8 +116,7 @@ def test_sequence_golden(name):
     _check_forward(case, res, 2e-5 if case.meta["T"] > 100 else 1e-5)
 
 
-@pytest.mark.parametrize("name", case_names("g6_bwd_") + [n for n in case_names("g8_var_") if "b1t1" not in n])
-def test_gradients_golden(name):
+def _check_gradients_golden(name):
     case = Case(name)
     m = _loaded_module(case)
     res = _run(case, m, requires_grad=True)
@@ -141,6 +140,11 @@ def test_gradients_golden(name):
         close(res["c0"].grad, case.arr["grad_c0"], "grad_c0")
 
 
+@pytest.mark.parametrize("name", case_names("g6_bwd_") + [n for n in case_names("g8_var_") if "b1t1" not in n])
+def test_gradients_golden(name):
+    _check_gradients_golden(name)
+
+
 # ---- (2) seeded random inputs against the oracle -----------------------------------------------------
 ORACLE_CFGS = [
     ("ttlstm", 1, 256, 1, 3, 8, 6, 40),      # cfg2 shapes
@@ -154,7 +158,7 @@ ORACLE_CFGS = [
 
 def _oracle_forward(kind, sd, L, x, init=None):
     from oracle import ttrnn_oracle as O
-    layers, _ = O.layers_from_state_dict(sd, L)
+    layers, _ = O.layers_from_state_dict(sd, L, dtype=x.dtype)
     with torch.no_grad():
         if kind == "ttlstm":
             out, (h, c) = O.lstm_forward(layers, x, init)
@@ -394,3 +398,68 @@ def test_repeat_runs_are_bitwise_identical(kind, inp, H, L, r, B, T, dtype):
         grads.append([p.grad.float().clone() for p in m.parameters()])
     for a, b in zip(*grads):
         assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6)
+
+
+# ---- (4) fp32 math modes: fp32 MFMA ("exact") vs three-way bf16 split ("split") ------------------------
+@pytest.fixture
+def split_math():
+    import ttrnn_hip
+    with ttrnn_hip.fp32_math("split"):
+        yield
+
+
+@pytest.mark.parametrize("name", ["g5_seq_cfg2", "g5_seq_cfg2_scaled"])
+def test_split_math_forward_golden(split_math, name):
+    """The reference's own outputs, same tolerances as the fp32-MFMA path (1e-5 / 2e-5 abs)."""
+    case = Case(name)
+    m = _loaded_module(case)
+    with torch.no_grad():
+        res = _run(case, m)
+    _check_forward(case, res, 2e-5 if case.meta["T"] > 100 else 1e-5)
+
+
+def test_split_math_cell_step_golden(split_math):
+    test_cell_step_golden("g4_cell_cfg2")
+
+
+def test_split_math_training_forward_feeds_backward(split_math):
+    """Training mode (reserve written by the split kernel, consumed by the reverse-time kernel): forward and
+    gradients against the reference's, same tolerances as the fp32-MFMA path."""
+    _check_gradients_golden("g6_bwd_cfg2")
+
+
+def test_split_math_error_vs_fp64_is_fp32_class():
+    """cfg2 shapes over the full 784 steps against the oracle evaluated in float64: the split mode must be as
+    close to the exact result as ordinary fp32 arithmetic is (the fp32-MFMA mode and the torch-CPU fp32 oracle)."""
+    import ttrnn_hip
+    m = _cfg2_module()
+    torch.manual_seed(99)
+    x = torch.rand(4, 784, 1)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, _, c64 = _oracle_forward("ttlstm", sd, 1, x.double())
+    r32, _, c32 = _oracle_forward("ttlstm", sd, 1, x)
+    errs = {"cpu_fp32": max(_maxabs(r32, r64), _maxabs(c32, c64))}
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            out, (hT, cT) = m(x.to(dev()))
+        errs[mode] = max(_maxabs(out, r64), _maxabs(cT, c64))
+    print("max abs error vs float64 oracle:", errs)
+    assert errs["split"] <= 2e-5
+    assert errs["split"] <= 2.0 * max(errs["exact"], errs["cpu_fp32"]) + 1e-7
+
+
+def test_split_math_full_size_properties(split_math):
+    """cfg2 at full size under the split mode: batch independence, causality, bitwise repeatability."""
+    m = _cfg2_module()
+    torch.manual_seed(1111)
+    x = torch.rand(64, 784, 1, device=dev())
+    with torch.no_grad():
+        out, (hT, cT) = m(x)
+        out2, _ = m(x)
+        out_a, _ = m(x[:17])
+        out_p, _ = m(x[:, :100].contiguous())
+    assert torch.equal(out, out2)
+    assert torch.equal(out[:17], out_a)
+    assert torch.equal(out[:, :100], out_p)
+    assert torch.equal(out[:, -1], hT)
+    assert torch.isfinite(out).all() and torch.isfinite(cT).all()
