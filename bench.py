@@ -33,6 +33,14 @@ for _p in (ROOT, os.path.join(ROOT, "tensorized-rnn_amd")):
 
 import torch  # noqa: E402
 
+FP32_MATH_DESC = {
+    None: None,
+    "split": "split (default where a split kernel exists): fp32 operands as 3 bf16 pieces, 6 bf16-MFMA terms, fp32 "
+             "accumulate; error vs float64 equal to the fp32-MFMA mode (tests/test_gpu_parity.py::"
+             "test_split_math_error_vs_fp64_is_fp32_class); TTRNN_FP32_MATH=exact selects the fp32 MFMA",
+    "exact": "exact: v_mfma_f32_16x16x4_f32 on fp32 operands",
+}
+
 WORKLOADS = {
     # name: kind, in, H, layers, ncores, rank, B (per GPU), T, dtype, FLOP per sample-timestep
     "cfg2": dict(kind="ttlstm", inp=1, H=256, L=1, d=3, r=8, B=64, T=784, dtype="f32", flop=691712, flop_in=33024,
@@ -226,6 +234,24 @@ def main():
     kern_ms = timer.mean_ms("ttrnn_rnn_forward")
     launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
 
+    # fp32 workloads: which matrix arithmetic ran (include/ttrnn.h TTRNN_MATH_*) and, at N=1, the same steps again
+    # in the OTHER mode, so that both figures come from one process on one device (outside the timed region above)
+    import ttrnn_hip
+    math_mode = ttrnn_hip.get_fp32_math() if w["dtype"] == "f32" else None
+    other = None
+    if math_mode is not None and args.mode == "forward" and world == 1:
+        alt = "exact" if math_mode == "split" else "split"
+        with ttrnn_hip.fp32_math(alt):
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            alt_ms = (time.perf_counter() - ta) * 1e3 / max(args.steps, 1)
+        other = {"fp32_math": alt, "ms_per_step": alt_ms, "value": w["T"] / (alt_ms * 1e-3), "unit": "timesteps/s"}
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -259,7 +285,8 @@ def main():
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
                        "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
-                                "train step: forward + BPTT + gradient all-reduce + SGD, inputs resident in HBM")},
+                                "train step: forward + BPTT + gradient all-reduce + SGD, inputs resident in HBM"),
+                       "fp32_math": FP32_MATH_DESC.get(math_mode)},
             "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
@@ -271,6 +298,8 @@ def main():
                          "achieved_hidden_chain_only": achieved * (1.0 - w.get("flop_in", 0) / float(w["flop"])),
                          "flop_per_launch": flop_per_launch},
         }
+        if other is not None:
+            line["other_fp32_math"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -85,7 +85,9 @@ int ttrnn_device_available(void);
  *                     from the six bf16 MFMA terms of weight >= 2^-18 with fp32 accumulation: per-product error
  *                     < 2^-24 relative, i.e. fp32-class results at 2.67x less matrix-pipe time.  Only the order and
  *                     grouping of fp32 additions differ from TTRNN_MATH_EXACT.
- * Default: environment variable TTRNN_FP32_MATH = "exact" | "split" read at first use, else see DESIGN.md.
+ * Default: TTRNN_MATH_SPLIT where a split kernel exists for the descriptor (DESIGN.md section 5 lists them and gives
+ * the measured error of both modes against a float64 evaluation); the environment variable TTRNN_FP32_MATH =
+ * "exact" | "split", read at first use, overrides the default; ttrnn_set_fp32_math overrides both.
  * Storage dtype, accumulators, gate math and state are unaffected; TTRNN_BF16 descriptors ignore the switch. */
 #define TTRNN_MATH_EXACT 0
 #define TTRNN_MATH_SPLIT 1

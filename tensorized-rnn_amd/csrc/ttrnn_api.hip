@@ -19,7 +19,7 @@ static int g_fp32_math = -1;
 static int fp32_math() {
   if (g_fp32_math < 0) {
     const char* e = getenv("TTRNN_FP32_MATH");
-    g_fp32_math = (e && (e[0] == 's' || e[0] == '1')) ? TTRNN_MATH_SPLIT : TTRNN_MATH_EXACT;
+    g_fp32_math = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
   }
   return g_fp32_math;
 }
@@ -244,8 +244,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                                (hipStream_t)stream, rs.H, ilv_mode);
     }
     if (st != TTRNN_OK) return st;
-    if (fp32_math() == TTRNN_MATH_SPLIT && x3_rnn_fwd_available(rs, desc->dtype))
-      return launch_rnn_fwd_x3(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
+    if (fp32_math() == TTRNN_MATH_SPLIT && f10_rnn_fwd_available(rs, desc->dtype))
+      return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     if (fast_rnn_fwd_bf16_available(rs, desc->dtype))
       return launch_rnn_fwd_bf16(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,

@@ -1,0 +1,353 @@
+// ttrnn_fast_f10.hip — TT-LSTM recurrent kernel with cores 1 and 0 contracted ahead of the time loop (gfx950).
+//
+// For a d = 3 TT-matrix the per-timestep chain of t3nsor/ops.py:78-93 is three GEMM stages
+//     S2: [J0*J1][J2]       x core2 -> [I2][J0*J1][R2]
+//     S1: [I2*J0][J1*R2]    x core1 -> [I1][I2*J0][R1]
+//     S0: [I2*I1][J0*R1]    x core0 -> [I0][I2*I1]            (gate pre-activations, o = (i0*I1 + i1)*I2 + i2)
+// The cores never change inside a launch, so the contraction over the inner rank R1 can be done ONCE per launch:
+//     W10[(j0,j1,r2)][(i0,i1)] = sum_r1 G0[i0,j0,r1] * G1[r1,i1,j1,r2]                 (K10 = J0*J1*R2, M10 = I0*I1)
+//     S10: [I2][K10] x W10 -> [M10][I2]
+// and the S2 output, viewed flat, IS the [I2][K10] operand.  For cfg2 (H=256, r=8) S10 costs 0.52 MFLOP per step
+// instead of 0.52 + 0.07 for S1 + S0, for cfg4 (r=16) 1.05 instead of 2.23 — and, more important once the matrix
+// pipe is no longer the bound, one whole LDS round trip, one barrier and one operand-splitting pass per timestep
+// disappear.  W10 (M10 x K10 fp32-equivalent values) lives in VGPRs of four waves, one 16-feature tile each.
+//
+// Tile layout of S10: MFMA rows = output features, permuted so that row 4q+j of tile t is feature
+// m = MPG*j + 4t + q (MPG = M10/4 features per gate); MFMA columns = i2.  Then the four accumulator registers of lane
+// (c, q) are the four gate pre-activations (i, f, g, o) of ONE hidden unit, hid = (4t+q)*I2 + c: the gate math runs on
+// the accumulators, c stays in that lane's register, h goes straight back to the image S2 reads.
+//
+// Per timestep:
+//     phase A  all 8 waves   S2: two tiles (16 features x 16 chain rows) per wave, results split into three bf16 planes
+//     barrier
+//     phase B  waves 0-3     S10 on split-bf16 MFMAs (ttrnn_split.h), gates, h_t -> LDS;  wave 7 streams h_{t-1} to `out`
+//     barrier
+// (Overlapping the second half of phase A with the first half of phase B on the partner waves of each SIMD was
+// measured 5 % SLOWER: the MFMA stream of the gate wave takes half of the SIMD's issue slots from the splitting
+// VALU work, and the extra barrier costs more than the overlap returns.)
+// S2 has a contraction length of only J2 = 8, so its six split terms are PACKED along the 32-wide k of one bf16 MFMA:
+//     MFMA 1:  core groups [w0|w1|w0|w1] x activation groups [x0|x0|x1|x1]  =  x0w0 + x0w1 + x1w0 + x1w1
+//     MFMA 2:  core groups [w2|w0| 0| 0] x activation groups [x0|x2| -| -]  =  x0w2 + x2w0
+// (two bf16 MFMAs = 32 matrix-pipe cycles per tile instead of two fp32 MFMAs = 64).
+// Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 with the hidden chain of t3nsor/ops.py:78-93.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+
+namespace ttrnn {
+
+template <class S>
+struct F10 {
+  static constexpr int H = in_size_of<S>();
+  static constexpr int J0 = S::J[0], J1 = S::J[1], I0 = S::I[0], I1 = S::I[1], I2 = S::I[2];
+  static constexpr int R1 = S::R[1], R2 = S::R[2];
+  static constexpr int K = J0 * J1 * R2;          // contraction length of the fused stage
+  static constexpr int M = I0 * I1;               // output features of the fused stage (x I2 columns)
+  static constexpr int MPG = M / 4;               // features per gate
+  static constexpr int MT = M / 16;               // 16-feature tiles = active waves of phase B
+  static constexpr int NM = K / 32;               // 32-wide k blocks
+  static constexpr int PLANE = I2 * K;            // bf16 elements per plane of the [I2][K] image
+  static constexpr int J2 = S::J[2];
+  static constexpr int ROWS2 = J0 * J1;           // chain rows of S2
+  static constexpr int M2 = I2 * R2;              // output features of S2
+  static constexpr int MT2 = M2 / 16;             // S2 m-tiles
+  static constexpr int XA = MT2 / 8;              // S2 m-tiles per wave (each over both chain-row tiles)
+};
+
+template <class S>
+constexpr bool f10_ok() {
+  using F = F10<S>;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::K % 32 == 0 && F::M % 16 == 0 &&
+         F::I2 <= 16 && F::MPG % 4 == 0 && F::MPG * F::I2 == F::H && F::MT <= FAST_NW && F::MPG == 4 * F::MT &&
+         out_size_of<S>() == 4 * F::H && S::R[2] % 4 == 0 && F::J2 == 8 && F::ROWS2 == 32 && F::M2 % 128 == 0 &&
+         FAST_NW == 8;
+}
+
+template <class S>
+constexpr size_t f10_lds_bytes() {
+  // fp32 h (two parities, for the output store) + bf16 h planes (two parities) + the three planes of the S10 operand
+  return 2 * sizeof(float) * F10<S>::H + 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE;
+}
+
+// term-packed fragments of core 2 for m-tile mt: lane (r, q) holds feature 16mt + r, k-group q (8 values of j2)
+template <class S>
+__device__ __forceinline__ void f10_load_w2(xbf8& a1, xbf8& a2, const float* packed, int mt, int lane) {
+  using F = F10<S>;
+  const int r = lane & 15, q = lane >> 4;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 p0, p1, p2;
+    split3(W2[e * F::M2 + 16 * mt + r], p0, p1, p2);
+    a1[e] = (q & 1) ? p1 : p0;                            // groups w0 | w1 | w0 | w1
+    a2[e] = q == 0 ? p2 : (q == 1 ? p0 : (__bf16)0.f);    // groups w2 | w0 | 0 | 0
+  }
+}
+
+// one S2 tile (m-tile mt, chain-row tile rt): hp = the three bf16 planes [3][H] of h_{t-1}; result split into img
+template <class S>
+__device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, const __bf16* hp, __bf16* img, int mt, int rt,
+                                            int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = 16 * rt + c;
+  const int pl1 = q >> 1;                                 // groups x0 | x0 | x1 | x1
+  const int pl2 = q == 1 ? 2 : 0;                         // groups x0 | x2 | (x0 against zero core groups)
+  const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::H + row * 8);
+  const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::H + row * 8);
+  f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
+  const int m0 = 16 * mt + 4 * q;
+  const int i = m0 / F::R2, a0 = m0 % F::R2;
+  const int f = i * (F::ROWS2 * F::R2) + row * F::R2 + a0;   // C2 flat == the [I2][K10] image (ops.py:89-90)
+  store_split4(img, F::PLANE, x_off<F::K>(f / F::K, f % F::K), acc);
+}
+
+// S10 k-blocks [U0, U0 + NU): reads run PD blocks ahead of the MFMAs (one wave per SIMD does this: nothing else hides
+// the LDS latency; sched_barrier keeps the compiler from sinking the reads back next to their use)
+template <class S, int U0, int NU>
+__device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][F10<S>::NM], const __bf16* img, int row, int q,
+                                             f32x4& acc_lo, f32x4& acc_hi) {
+  using F = F10<S>;
+  constexpr int PD = NU < 3 ? NU : 3;
+  xbf8 af[NU][3];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+    const int off = x_off<F::K>(row, 32 * (U0 + u) + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[u][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (u + PD < NU) {
+      const int off = x_off<F::K>(row, 32 * (U0 + u + PD) + 8 * q);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[u + PD][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 5; ++s)      // the five low-order terms, then the leading one into its own accumulator
+      acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[SPLIT_TW[s]][U0 + u], af[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[0][U0 + u], af[u][0], acc_hi, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// resident split fragments of the fused core for tile t (waves 0 .. MT-1): w[plane][u], lane (r, q) holds MFMA row r,
+// k = 32u + 8q .. +7
+template <class S>
+__device__ __forceinline__ void f10_load_w(xbf8 (&w)[3][F10<S>::NM], const float* packed, int t, int lane) {
+  using F = F10<S>;
+  const int r = lane & 15, q = lane >> 4;
+  const int m = F::MPG * (r & 3) + 4 * t + (r >> 2);     // gate r&3, feature-within-gate 4t + (r>>2)
+  const int i0 = m / F::I1, i1 = m % F::I1;
+  const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+  const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+  float g0[F::J0][F::R1];                                 // G0[i0, j0, r1]
+#pragma unroll
+  for (int j0 = 0; j0 < F::J0; ++j0)
+#pragma unroll
+    for (int r1 = 0; r1 < F::R1; ++r1) g0[j0][r1] = W0[(j0 * F::R1 + r1) * F::I0 + i0];
+#pragma unroll
+  for (int u = 0; u < F::NM; ++u) {
+    xbf8 f0, f1, f2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = 32 * u + 8 * q + e;                  // = (j0*J1 + j1)*R2 + r2
+      const int r2 = kk % F::R2, row2 = kk / F::R2;
+      const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+      const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+      float v = 0.f;
+#pragma unroll
+      for (int r1 = 0; r1 < F::R1; ++r1) {
+        float gsel = g0[0][r1];
+#pragma unroll
+        for (int jj = 1; jj < F::J0; ++jj) gsel = (j0 == jj) ? g0[jj][r1] : gsel;
+        v = fmaf(gsel, w1p[r1], v);
+      }
+      __bf16 p0, p1, p2;
+      split3(v, p0, p1, p2);
+      f0[e] = p0; f1[e] = p1; f2[e] = p2;
+    }
+    w[0][u] = f0; w[1][u] = f1; w[2][u] = f2;
+  }
+}
+
+template <class S, bool DIAG>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
+                                                          const float* __restrict__ c0,
+                                                          const float* __restrict__ packed_hid,
+                                                          const float* __restrict__ bias_hid, float* __restrict__ out,
+                                                          float* __restrict__ hT, float* __restrict__ cT,
+                                                          float* __restrict__ reserve) {
+  static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
+  using F = F10<S>;
+  constexpr int H = F::H;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* hbuf = reinterpret_cast<float*>(smem);                             // fp32 h, two parities (output store)
+  __bf16* hpl = reinterpret_cast<__bf16*>(smem + 2 * sizeof(float) * H);    // bf16 planes of h: [parity][3][H]
+  __bf16* img = hpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+  const bool gate_wave = wave < F::MT;
+
+  // S2 fragments of the m-tiles {wave + 8x}
+  xbf8 s1[F::XA], s2[F::XA];
+#pragma unroll
+  for (int x = 0; x < F::XA; ++x) f10_load_w2<S>(s1[x], s2[x], packed_hid, wave + FAST_NW * x, lane);
+  xbf8 w10[3][F::NM];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int u = 0; u < F::NM; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w10[p][u][e] = (__bf16)0.f;
+  if (gate_wave) f10_load_w<S>(w10, packed_hid, wave, lane);
+
+  // the hidden unit of this lane in phase B (waves 0 .. MT-1): hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o.
+  // gin is gate-interleaved [B][T][H][4] with slots i,g,f,o.
+  const float* __restrict__ gin = gs.gin;
+  const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
+  const bool in1 = gs.in1 != 0;
+  const bool ok = gate_wave && c < F::I2;
+  const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
+  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
+  float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
+  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
+  XChunk<float> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
+  if (ok) {
+    if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
+    if (T > 0) {
+      if (in1) {
+        bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
+        vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
+      } else {
+        gi = *reinterpret_cast<const f32x4*>(gin + ((b * T) * H + hd) * 4);
+      }
+    }
+    __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
+    split3(hst, p0, p1, p2);
+    hpl[hd] = p0; hpl[H + hd] = p1; hpl[2 * H + hd] = p2;
+    hbuf[hd] = hst;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  const int row10 = c < F::I2 ? c : F::I2 - 1;
+  for (int t = 0; t < T; ++t) {
+    const __bf16* hp = hpl + (t & 1) * 3 * H;             // planes of h_{t-1}
+    __bf16* hn = hpl + ((t + 1) & 1) * 3 * H;             // planes of h_t
+    // ---- phase A: S2, all waves ---------------------------------------------------------------------------
+#pragma unroll
+    for (int x = 0; x < F::XA; ++x) {
+      f10_s2_tile<S>(s1[x], s2[x], hp, img, wave + FAST_NW * x, 0, lane);
+      f10_s2_tile<S>(s1[x], s2[x], hp, img, wave + FAST_NW * x, 1, lane);
+    }
+    TT_STAMP(0)
+    lds_barrier();
+    TT_STAMP(1)
+    const size_t bt = b * T + t;
+    if (gate_wave) {
+      // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+      f10_s10_part<S, 0, F::NM>(w10, img, row10, q, acc_lo, acc_hi);
+      f32x4 acc = acc_hi + acc_lo;
+      if constexpr (DIAG) {
+        asm volatile("" : "+v"(acc));
+      }
+      TT_STAMP(2)
+      if (in1) gi = bb + xq.at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
+      const float ig = fsigmoid(acc[0] + gi[0] + bh[0]);      // lstm.py:26
+      const float fg = fsigmoid(acc[1] + gi[2] + bh[2]);      // lstm.py:27
+      const float gg = ftanh(acc[2] + gi[1] + bh[1]);         // lstm.py:28
+      const float og = fsigmoid(acc[3] + gi[3] + bh[3]);      // lstm.py:29
+      const float cy = fg * cst + ig * gg;                    // lstm.py:31
+      const float hy = og * ftanh(cy);                        // lstm.py:32
+      if (ok) {
+        cst = cy;
+        hst = hy;
+        __bf16 p0, p1, p2;
+        split3(hy, p0, p1, p2);
+        hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
+        hbuf[((t + 1) & 1) * H + hd] = hy;
+        if (reserve) {
+          float* rv = reserve + (bt * H + hd) * 8;
+          *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
+          rv[4] = cy;
+        }
+        if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+      }
+      if (in1) xq.advance(xs, b * T, T, t, lane);
+      TT_STAMP(3)
+    } else if (wave == FAST_NW - 1 && t > 0) {
+      // outputs[:, t-1, :] = h_{t-1} (lstm.py:133): an idle wave streams the complete vector out, 16 bytes per lane
+      const float* hprev = hbuf + (t & 1) * H;
+#pragma unroll
+      for (int h4 = lane; h4 < H / 4; h4 += 64)
+        *reinterpret_cast<f32x4*>(out + (bt - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
+    }
+    lds_barrier();
+    TT_STAMP(4)
+  }
+  if (T > 0 && wave == FAST_NW - 1) {
+    const float* hlast = hbuf + (T & 1) * H;
+#pragma unroll
+    for (int h4 = lane; h4 < H / 4; h4 += 64)
+      *reinterpret_cast<f32x4*>(out + (b * T + T - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hlast + 4 * h4);
+  }
+  if (ok) {
+    if (hT) hT[b * H + hd] = hst;
+    if (cT) cT[b * H + hd] = cst;
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && reserve && b < 8) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * FAST_NW + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = seg[i];
+    }
+  }
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+template <class S>
+static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
+  constexpr size_t lds = f10_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
+  const char* diag = getenv("TTRNN_DIAG");
+  const bool dg = diag && diag[0] == '1' && reserve;
+  auto kern = dg ? k_lstm_fwd_f10<S, true> : k_lstm_fwd_f10<S, false>;
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
+                     (const float*)c0, packed_hid, bh, (float*)out, (float*)hT, (float*)cT, reserve);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
+  const char* e = getenv("TTRNN_NO_F10");
+  if (e && e[0] == '1') return false;
+  return shape_matches<ShpH256R8L>(rs.hid_s);
+}
+
+int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
+    return launch_f10<ShpH256R8L>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn

@@ -78,10 +78,11 @@ int launch_rnn_fwd_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const vo
                         const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                         hipStream_t stream);
 
-// fp32 storage, chain on split-bf16 MFMAs (ttrnn_fast_x3.hip); selected by ttrnn_set_fp32_math(TTRNN_MATH_SPLIT)
-bool x3_rnn_fwd_available(const RnnShape& rs, int dtype);
-int launch_rnn_fwd_x3(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
-                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream);
+// fp32 storage, cores 1 and 0 contracted once per launch, fused stage on split-bf16 MFMAs (ttrnn_fast_f10.hip);
+// selected by ttrnn_set_fp32_math(TTRNN_MATH_SPLIT), the default
+bool f10_rnn_fwd_available(const RnnShape& rs, int dtype);
+int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);

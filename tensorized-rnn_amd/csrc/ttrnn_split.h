@@ -1,0 +1,71 @@
+// ttrnn_split.h — three-way bf16 splitting of fp32 operands for the bf16 MFMA (TTRNN_MATH_SPLIT), shared by the
+// split-precision kernels.  Device-only (gfx950).
+//
+//     x = x0 + x1 + x2   with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)   (|x_i| <= 2^-9 |x_{i-1}|, RNE)
+//     x*w = x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0) + O(2^-26 |xw|)
+// Every bf16*bf16 product is exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32: the six-term sum has a
+// per-product relative error below fp32's rounding unit (2^-24) at 6*16 = 96 instead of 8*32 = 256 matrix-pipe cycles
+// per 16x16x32 block of the fp32 MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ttrnn_mfma.h"
+
+namespace ttrnn {
+
+typedef __bf16 xbf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf4 __attribute__((ext_vector_type(4)));
+
+// element offset of (row, kk) inside one bf16 plane [ROWS][K]; 16-byte slots XOR-swizzled so that the ds_read_b128
+// fragment reads (lane (c, q) -> slot 4u+q of row 16rt+c) are conflict-free for the b128 lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X guide, LDS table).
+template <int K>
+__device__ __forceinline__ int x_off(int row, int kk) {
+  constexpr int ns = K / 8;
+  const int slot = kk >> 3;
+  int g = 0;
+  if constexpr (ns == 4) g = (-(row >> 2)) & 3;
+  else if constexpr (ns == 8) g = (row >> 1) & 7;
+  else if constexpr (ns >= 16 && is_pow2(ns)) g = row & 15;
+  return ((row * ns + (slot ^ g)) << 3) + (kk & 7);
+}
+
+__device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& p2) {
+  p0 = (__bf16)v;
+  float r = v - (float)p0;      // exact
+  p1 = (__bf16)r;
+  r -= (float)p1;               // exact
+  p2 = (__bf16)r;
+}
+
+// two elements at a time: v_cvt_pk_bf16_f32 rounds both (RNE), a shift / a mask turn the packed pair back into
+// floats, the subtractions are exact.  9 VALU instructions per pair and three packed dwords out.
+typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const xbf2 p = __builtin_convertvector(f32x2{a, b}, xbf2);
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pk_bf16(a, b);
+  float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(ra, rb);
+  ra -= __uint_as_float(p1 << 16);
+  rb -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(ra, rb);
+}
+
+// four consecutive elements -> three 8-byte stores
+__device__ __forceinline__ void store_split4(__bf16* img, int plane_elems, int off, f32x4 v) {
+  unsigned a0, b0, c0, a1, b1, c1;
+  split_pair(v[0], v[1], a0, b0, c0);
+  split_pair(v[2], v[3], a1, b1, c1);
+  *reinterpret_cast<u32x2*>(img + off) = u32x2{a0, a1};
+  *reinterpret_cast<u32x2*>(img + plane_elems + off) = u32x2{b0, b1};
+  *reinterpret_cast<u32x2*>(img + 2 * plane_elems + off) = u32x2{c0, c1};
+}
+
+// MFMA term order of the six-term product, smallest terms first: (w2,x0) (w0,x2) (w1,x1) | (w1,x0) (w0,x1) | (w0,x0)
+static constexpr int SPLIT_TW[6] = {2, 0, 1, 1, 0, 0};
+static constexpr int SPLIT_TX[6] = {0, 2, 1, 0, 1, 0};
+
+}  // namespace ttrnn

@@ -29,7 +29,11 @@ for _ in range(2):
     out, _ = m(x)
 torch.cuda.synchronize()
 raw = captured["reserve"][:8 * 8 * 8 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
-names = ["S2 mma+store", "barrier1", "S1 mma+store", "barrier2", "S0 mma", "gates", "barrier3", "-"]
+import ttrnn_hip
+if ttrnn_hip.get_fp32_math() == "split":     # k_lstm_fwd_f10 (ttrnn_fast_f10.hip)
+    names = ["S2+split", "barrier1", "S10 mma", "gates", "barrier2", "-", "-", "-"]
+else:                                        # k_lstm_fwd_fused (ttrnn_fast.hip)
+    names = ["S2 mma+store", "barrier1", "S1 mma+store", "barrier2", "S0 mma", "gates", "barrier3", "-"]
 per_step = raw.astype(np.float64) / T
 print("cycles per step (mean over 8 blocks), per wave:")
 for w in range(8):
