@@ -55,6 +55,16 @@ struct F10 {
   static constexpr int M2 = I2 * R2;              // output features of S2
   static constexpr int MT2 = M2 / 16;             // S2 m-tiles
   static constexpr int XA = MT2 / 8;              // S2 m-tiles per wave (each over both chain-row tiles)
+  // Order of the contraction index inside an image row.  The natural order (row2, r2) makes the 16 lanes of a
+  // ds_write_b64 group (same q, 16 chain rows) hit only the first or only the second half of 16 slots: a 2-way bank
+  // conflict on every store of phase A.  With two chain rows per 16-byte slot and the slots of one r2-quad contiguous —
+  //     slot = (r2 >> 2) * ROWS2/2 + (row2 >> 1),   kk = 8*slot + (row2 & 1) * 4 + (r2 & 3)
+  // — those 16 lanes fill 8 consecutive slots (128 contiguous bytes; the XOR swizzle of x_off keeps an aligned block
+  // of 8 slots together).  The fused core is built in the same order (f10_load_w).
+  static constexpr int HR = ROWS2 / 2;            // slots per r2-quad
+  __device__ static constexpr int kperm(int row2, int r2) {
+    return ((r2 >> 2) * HR + (row2 >> 1)) * 8 + (row2 & 1) * 4 + (r2 & 3);
+  }
 };
 
 template <class S>
@@ -102,8 +112,8 @@ __device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, cons
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
   const int m0 = 16 * mt + 4 * q;
   const int i = m0 / F::R2, a0 = m0 % F::R2;
-  const int f = i * (F::ROWS2 * F::R2) + row * F::R2 + a0;   // C2 flat == the [I2][K10] image (ops.py:89-90)
-  store_split4(img, F::PLANE, x_off<F::K>(f / F::K, f % F::K), acc);
+  // C2[i][row][a0..a0+3] (ops.py:89-90: C2 flat == the [I2][K10] operand of the next stage), k order: F10::kperm
+  store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);
 }
 
 // S10 k-blocks [U0, U0 + NU): reads run PD blocks ahead of the MFMAs (one wave per SIMD does this: nothing else hides
@@ -157,8 +167,8 @@ __device__ __forceinline__ void f10_load_w(xbf8 (&w)[3][F10<S>::NM], const float
     xbf8 f0, f1, f2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int kk = 32 * u + 8 * q + e;                  // = (j0*J1 + j1)*R2 + r2
-      const int r2 = kk % F::R2, row2 = kk / F::R2;
+      const int slot = 4 * u + q;                          // k = 8*slot + e in F10::kperm order
+      const int r2 = (slot / F::HR) * 4 + (e & 3), row2 = 2 * (slot % F::HR) + (e >> 2);
       const int j1 = row2 % F::J1, j0 = row2 / F::J1;
       const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
       float v = 0.f;
