@@ -157,7 +157,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 // whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
   bool use, lin_fast, in1;
-  size_t gin_bytes, lin_ws_bytes;
+  size_t gin_bytes, lin_ws_bytes, f10_bytes;
   LinPlan lin;
 };
 
@@ -180,8 +180,9 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   }
   if (!f.lin_fast) {
     f.lin = plan_ttlinear_fwd(rs.in_s, n_rows);
-    f.lin_ws_bytes = f.lin.ws_bytes;
+    f.lin_ws_bytes = (f.lin.ws_bytes + 255) & ~(size_t)255;
   }
+  f.f10_bytes = f10_workspace_bytes(rs, dtype);   // reserved whatever the math mode is at query time
   return f;
 }
 
@@ -189,7 +190,7 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
-  if (f.use) return f.gin_bytes + f.lin_ws_bytes;
+  if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes;
   if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
@@ -222,7 +223,7 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
-    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes) return TTRNN_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes) return TTRNN_ERR_WORKSPACE;
     float* gin = (float*)workspace;
     void* lin_ws = (char*)workspace + f.gin_bytes;
     const int ilv_mode = rs.cell == TTRNN_LSTM ? 2 : 1;
@@ -244,8 +245,10 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                                (hipStream_t)stream, rs.H, ilv_mode);
     }
     if (st != TTRNN_OK) return st;
-    if (fp32_math() == TTRNN_MATH_SPLIT && f10_rnn_fwd_available(rs, desc->dtype))
-      return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
+    // fused-core kernels: fp32 LSTM shapes under the split math mode; the bf16 GRU shape always (bf16 MFMA either way)
+    if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
+      return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
+                                (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);
     if (fast_rnn_fwd_bf16_available(rs, desc->dtype))
       return launch_rnn_fwd_bf16(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,

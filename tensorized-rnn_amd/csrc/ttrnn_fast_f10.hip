@@ -76,10 +76,12 @@ constexpr bool f10_ok() {
          FAST_NW == 8;
 }
 
-template <class S>
+template <class S, int KS>
 constexpr size_t f10_lds_bytes() {
   // fp32 h (two parities, for the output store) + bf16 h planes (two parities) + the three planes of the S10 operand
-  return 2 * sizeof(float) * F10<S>::H + 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE;
+  // + (KS == 2) the partial accumulators handed from the second k-half's waves to the gate waves
+  return 2 * sizeof(float) * F10<S>::H + 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE +
+         (KS == 2 ? F10<S>::MT * 64 * sizeof(f32x4) : 0);
 }
 
 // term-packed fragments of core 2 for m-tile mt: lane (r, q) holds feature 16mt + r, k-group q (8 values of j2)
@@ -116,17 +118,18 @@ __device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, cons
   store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);
 }
 
-// S10 k-blocks [U0, U0 + NU): reads run PD blocks ahead of the MFMAs (one wave per SIMD does this: nothing else hides
-// the LDS latency; sched_barrier keeps the compiler from sinking the reads back next to their use)
-template <class S, int U0, int NU>
-__device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][F10<S>::NM], const __bf16* img, int row, int q,
+// S10 k-blocks [u0, u0 + NU) (w10 holds exactly those): reads run PD blocks ahead of the MFMAs (at most two waves per
+// SIMD do this: little else hides the LDS latency; sched_barrier keeps the compiler from sinking the reads back next
+// to their use)
+template <class S, int NU>
+__device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __bf16* img, int row, int q, int u0,
                                              f32x4& acc_lo, f32x4& acc_hi) {
   using F = F10<S>;
   constexpr int PD = NU < 3 ? NU : 3;
   xbf8 af[NU][3];
 #pragma unroll
   for (int u = 0; u < PD; ++u) {
-    const int off = x_off<F::K>(row, 32 * (U0 + u) + 8 * q);
+    const int off = x_off<F::K>(row, 32 * (u0 + u) + 8 * q);
 #pragma unroll
     for (int p = 0; p < 3; ++p) af[u][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
   }
@@ -134,63 +137,62 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][F10<S>::NM], c
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     if (u + PD < NU) {
-      const int off = x_off<F::K>(row, 32 * (U0 + u + PD) + 8 * q);
+      const int off = x_off<F::K>(row, 32 * (u0 + u + PD) + 8 * q);
 #pragma unroll
       for (int p = 0; p < 3; ++p) af[u + PD][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 5; ++s)      // the five low-order terms, then the leading one into its own accumulator
-      acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[SPLIT_TW[s]][U0 + u], af[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
-    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[0][U0 + u], af[u][0], acc_hi, 0, 0, 0);
+      acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[SPLIT_TW[s]][u], af[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[0][u], af[u][0], acc_hi, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// resident split fragments of the fused core for tile t (waves 0 .. MT-1): w[plane][u], lane (r, q) holds MFMA row r,
-// k = 32u + 8q .. +7
+// The fused core, contracted and split ONCE per launch by a small kernel of its own and stored in fragment order:
+//   wfrag[((t*NM + u)*3 + plane)*64 + lane] = the 8 bf16 (16 bytes) lane (r, q) feeds the MFMA for feature tile t,
+//   k-block u:  MFMA row r <-> feature m = MPG*(r&3) + 4t + (r>>2),  k = 32u + 8q + e in F10::kperm order.
+// The recurrent workgroups then fetch their resident fragments with coalesced 16-byte loads (1 KB per instruction).
+// (Computing W10 inside every workgroup's prologue instead cost ~1 000 scattered 4-byte loads per lane: ~50 us of the
+// 860 us cfg2 launch, and half of a 160-step cfg4 launch.)
 template <class S>
-__device__ __forceinline__ void f10_load_w(xbf8 (&w)[3][F10<S>::NM], const float* packed, int t, int lane) {
+__global__ void __launch_bounds__(64) k_f10_prep(const float* __restrict__ packed, xbf8* __restrict__ wfrag) {
   using F = F10<S>;
+  const int lane = threadIdx.x, u = blockIdx.x % F::NM, t = blockIdx.x / F::NM;
   const int r = lane & 15, q = lane >> 4;
   const int m = F::MPG * (r & 3) + 4 * t + (r >> 2);     // gate r&3, feature-within-gate 4t + (r>>2)
   const int i0 = m / F::I1, i1 = m % F::I1;
   const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
   const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
-  float g0[F::J0][F::R1];                                 // G0[i0, j0, r1]
+  xbf8 f0, f1, f2;
 #pragma unroll
-  for (int j0 = 0; j0 < F::J0; ++j0)
-#pragma unroll
-    for (int r1 = 0; r1 < F::R1; ++r1) g0[j0][r1] = W0[(j0 * F::R1 + r1) * F::I0 + i0];
-#pragma unroll
-  for (int u = 0; u < F::NM; ++u) {
-    xbf8 f0, f1, f2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int slot = 4 * u + q;                          // k = 8*slot + e in F10::kperm order
-      const int r2 = (slot / F::HR) * 4 + (e & 3), row2 = 2 * (slot % F::HR) + (e >> 2);
-      const int j1 = row2 % F::J1, j0 = row2 / F::J1;
-      const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
-      float v = 0.f;
-#pragma unroll
-      for (int r1 = 0; r1 < F::R1; ++r1) {
-        float gsel = g0[0][r1];
-#pragma unroll
-        for (int jj = 1; jj < F::J0; ++jj) gsel = (j0 == jj) ? g0[jj][r1] : gsel;
-        v = fmaf(gsel, w1p[r1], v);
-      }
-      __bf16 p0, p1, p2;
-      split3(v, p0, p1, p2);
-      f0[e] = p0; f1[e] = p1; f2[e] = p2;
-    }
-    w[0][u] = f0; w[1][u] = f1; w[2][u] = f2;
+  for (int e = 0; e < 8; ++e) {
+    const int slot = 4 * u + q;                           // k = 8*slot + e in F10::kperm order
+    const int r2 = (slot / F::HR) * 4 + (e & 3), row2 = 2 * (slot % F::HR) + (e >> 2);
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+    __bf16 p0, p1, p2;
+    split3(v, p0, p1, p2);
+    f0[e] = p0; f1[e] = p1; f2[e] = p2;
   }
+  xbf8* dst = wfrag + (size_t)((t * F::NM + u) * 3) * 64 + lane;
+  dst[0] = f0; dst[64] = f1; dst[128] = f2;
 }
 
-template <class S, bool DIAG>
+template <class S>
+constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
+
+// KS = 1: waves 0..MT-1 run the whole contraction of their tile.  KS = 2 (long contractions: the resident fragments
+// of a whole tile row would not fit the register file): waves t and t+4 — the two waves of one SIMD — take one half of
+// the k-blocks each, the second hands its partial accumulators to the first through LDS.
+template <class S, int KS, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
+                                                          const xbf8* __restrict__ wfrag,
                                                           const float* __restrict__ bias_hid, float* __restrict__ out,
                                                           float* __restrict__ hT, float* __restrict__ cT,
                                                           float* __restrict__ reserve) {
@@ -202,25 +204,36 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   float* hbuf = reinterpret_cast<float*>(smem);                             // fp32 h, two parities (output store)
   __bf16* hpl = reinterpret_cast<__bf16*>(smem + 2 * sizeof(float) * H);    // bf16 planes of h: [parity][3][H]
   __bf16* img = hpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
+  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // KS == 2: partial accumulators
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
+  static_assert(KS == 1 || (KS == 2 && F::MT == 4 && F::NM % 2 == 0), "k-split layout");
+  constexpr int NU = F::NM / KS;                         // k-blocks per MFMA wave
   const bool gate_wave = wave < F::MT;
+  const bool mma_wave = KS == 2 || gate_wave;
+  const int tile = KS == 2 ? (wave & 3) : wave;          // S10 feature tile of this wave
+  const int u0 = KS == 2 ? (wave >> 2) * NU : 0;         // its first k-block
 
   // S2 fragments of the m-tiles {wave + 8x}
   xbf8 s1[F::XA], s2[F::XA];
 #pragma unroll
   for (int x = 0; x < F::XA; ++x) f10_load_w2<S>(s1[x], s2[x], packed_hid, wave + FAST_NW * x, lane);
-  xbf8 w10[3][F::NM];
+  xbf8 w10[3][NU];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int u = 0; u < F::NM; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int e = 0; e < 8; ++e) w10[p][u][e] = (__bf16)0.f;
-  if (gate_wave) f10_load_w<S>(w10, packed_hid, wave, lane);
+  if (mma_wave) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 3 + p) * 64 + lane];
+  }
 
   // the hidden unit of this lane in phase B (waves 0 .. MT-1): hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o.
   // gin is gate-interleaved [B][T][H][4] with slots i,g,f,o.
@@ -270,15 +283,23 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
     lds_barrier();
     TT_STAMP(1)
     const size_t bt = b * T + t;
-    if (gate_wave) {
-      // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
+    // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (mma_wave) {
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-      f10_s10_part<S, 0, F::NM>(w10, img, row10, q, acc_lo, acc_hi);
-      f32x4 acc = acc_hi + acc_lo;
+      f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
+      acc = acc_hi + acc_lo;
       if constexpr (DIAG) {
         asm volatile("" : "+v"(acc));
       }
-      TT_STAMP(2)
+    }
+    TT_STAMP(2)
+    if constexpr (KS == 2) {
+      if (!gate_wave) xbuf[tile * 64 + lane] = acc;
+      lds_barrier();
+      if (gate_wave) acc += xbuf[tile * 64 + lane];
+    }
+    if (gate_wave) {
       if (in1) gi = bb + xq.at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
       const float ig = fsigmoid(acc[0] + gi[0] + bh[0]);      // lstm.py:26
       const float fg = fsigmoid(acc[1] + gi[2] + bh[2]);      // lstm.py:27
@@ -331,32 +352,242 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   }
 }
 
-// ---- dispatch ------------------------------------------------------------------------------------------
+// ---- bf16-storage GRU on the same fused core ---------------------------------------------------------------------
+// cfg3 (TT-GRU, bf16 storage, fp32 state / gates / accumulation): the chain runs directly on the bf16 MFMA (no
+// splitting: storage precision is bf16), with W10 rounded to bf16 once.  A GRU's r, z, n pre-activations of one
+// hidden unit do NOT land in one lane (o = m*I2 + i2 with I2 = 12 does not align with the gate boundaries), so the
+// fused stage leaves them in an fp32 LDS vector and a third phase does the gate math, one hidden unit per thread:
+//     A  S2: (16 features x 16 chain rows) tiles over the 8 waves, K = J2 = 8 zero-padded to one bf16 MFMA
+//     B  S10 (waves 0-3): 8 MFMAs per wave -> gate pre-activations into gbuf
+//     C  gates (gru.py:38-44), h_t -> bf16 image for S2, `out`
+// three barriers per step instead of the four phases of the stage-wise kernel (ttrnn_fast_bf16.hip).
 template <class S>
+constexpr bool f10g_ok() {
+  using F = F10<S>;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::K % 32 == 0 && F::M == 64 &&
+         F::I2 <= 16 && out_size_of<S>() == 3 * F::H && F::J2 == 8 && F::ROWS2 == 32 && F::M2 % 16 == 0 &&
+         F::MT2 <= 2 * FAST_NW && F::R2 % 4 == 0 && F::H <= FAST_NT;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) k_f10g_prep(const float* __restrict__ packed, xbf8* __restrict__ wfrag) {
+  using F = F10<S>;
+  const int lane = threadIdx.x, u = blockIdx.x % F::NM, t = blockIdx.x / F::NM;
+  const int r = lane & 15, q = lane >> 4;
+  const int m = 16 * t + r;                                // natural feature order
+  const int i0 = m / F::I1, i1 = m % F::I1;
+  const float* W0 = packed + woff_of<S>(0);
+  const float* W1 = packed + woff_of<S>(1);
+  xbf8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int slot = 4 * u + q;
+    const int r2 = (slot / F::HR) * 4 + (e & 3), row2 = 2 * (slot % F::HR) + (e >> 2);
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+    f[e] = (__bf16)v;
+  }
+  wfrag[(size_t)(t * F::NM + u) * 64 + lane] = f;
+}
+
+template <class S>
+__global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs, const bf16_t* __restrict__ h0,
+                                                         const float* __restrict__ packed_hid,
+                                                         const xbf8* __restrict__ wfrag,
+                                                         const bf16_t* __restrict__ bias_hid, bf16_t* __restrict__ out,
+                                                         bf16_t* __restrict__ hT, float* __restrict__ reserve) {
+  static_assert(f10g_ok<S>(), "shape not supported by the fused-core GRU kernel");
+  using F = F10<S>;
+  constexpr int H = F::H;
+  constexpr int NT2 = F::MT2 * 2;                          // S2 tiles (m-tile, chain-row tile)
+  constexpr int XT = (NT2 + FAST_NW - 1) / FAST_NW;        // per wave
+
+  __shared__ __attribute__((aligned(16))) __bf16 hq[H];                  // h_{t-1}, bf16, [ROWS2][J2]
+  __shared__ __attribute__((aligned(16))) __bf16 img[F::PLANE];          // S10 operand [I2][K10]
+  __shared__ __attribute__((aligned(16))) float gbuf[3 * H];             // gate pre-activations of the hidden chain
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  // S2 fragments: tile id = wave + 8x -> (mt = id % MT2, rt = id / MT2); K = 8 real k values live in k-group 0
+  xbf8 a2[XT];
+#pragma unroll
+  for (int x = 0; x < XT; ++x) {
+    const int id = wave + FAST_NW * x, mt = id % F::MT2;
+    const float* W2 = packed_hid + woff_of<S>(2);          // [J2][M2]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = W2[e * F::M2 + 16 * mt + c];          // lane (r = c, q): feature 16mt + r
+      a2[x][e] = (__bf16)((q == 0 && id < NT2) ? v : 0.f);
+    }
+  }
+  xbf8 w10[F::NM];
+#pragma unroll
+  for (int u = 0; u < F::NM; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w10[u][e] = (__bf16)0.f;
+  if (wave < 4) {
+#pragma unroll
+    for (int u = 0; u < F::NM; ++u) w10[u] = wfrag[(size_t)(wave * F::NM + u) * 64 + lane];
+  }
+
+  // gate phase: thread tid < H owns hidden unit tid.  gin: fp32 [B][T][H][4], slots r,z,n,-
+  const float* __restrict__ gin = gs.gin;
+  const bf16_t* __restrict__ xs = reinterpret_cast<const bf16_t*>(gs.x);
+  const bool in1 = gs.in1 != 0;
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float hst = (own && h0) ? ld(h0, b * H + hid) : 0.f;
+  float bh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bh[g] = (own && bias_hid) ? ld(bias_hid, g * H + hid) : 0.f;
+  f32x4 gi = f32x4{0.f, 0.f, 0.f, 0.f}, vv = gi, bb = gi;
+  XChunk<bf16_t> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
+  if (own && T > 0) {
+    if (in1) {
+      bb = gin4[H + hid];
+      vv = gin4[hid] - bb;
+    } else {
+      gi = gin4[(b * T) * H + hid];
+    }
+  }
+  if (own) hq[hid] = (__bf16)hst;
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
+  lds_barrier();
+
+  const int row10 = c < F::I2 ? c : F::I2 - 1;
+  for (int t = 0; t < T; ++t) {
+    // ---- A: S2 ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int x = 0; x < XT; ++x) {
+      const int id = wave + FAST_NW * x;
+      if (id < NT2) {
+        const int mt = id % F::MT2, rt = id / F::MT2;
+        const int row = 16 * rt + c;
+        const xbf8 bfrag = *reinterpret_cast<const xbf8*>(hq + row * 8);     // every k-group reads the same 16 bytes
+        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[x], bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int m0 = 16 * mt + 4 * q;
+        const int i = m0 / F::R2, a0 = m0 % F::R2;
+        xbf4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[j];
+        *reinterpret_cast<xbf4*>(img + x_off<F::K>(i, F::kperm(row, a0))) = o;
+      }
+    }
+    lds_barrier();
+    // ---- B: fused S1*S0 stage, waves 0-3 -------------------------------------------------------------------------
+    if (wave < 4) {
+      xbf8 af[F::NM];
+#pragma unroll
+      for (int u = 0; u < F::NM; ++u) af[u] = *reinterpret_cast<const xbf8*>(img + x_off<F::K>(row10, 32 * u + 8 * q));
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int u = 0; u < F::NM; u += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[u], af[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[u + 1], af[u + 1], acc1, 0, 0, 0);
+      }
+      const f32x4 acc = acc0 + acc1;
+      if (c < F::I2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gbuf[(16 * wave + 4 * q + j) * F::I2 + c] = acc[j];   // o = m*I2 + i2
+      }
+    }
+    lds_barrier();
+    // ---- C: gates + state (gru.py:38-44) ---------------------------------------------------------------------------
+    const size_t bt = b * T + t;
+    if (own) {
+      if (in1) gi = bb + xq.at(t) * vv;
+      const float hn = gbuf[2 * H + hid] + bh[2];
+      const float rg = fsigmoid(gi[0] + gbuf[hid] + bh[0]);              // gru.py:38-39
+      const float zg = fsigmoid(gi[1] + gbuf[H + hid] + bh[1]);          // gru.py:40-41
+      const float ng = ftanh(gi[2] + rg * hn);                           // gru.py:42-43
+      float hy = (1.0f - zg) * ng + zg * hst;                            // gru.py:44
+      if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+      const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
+      out[bt * H + hid] = hb;
+      hy = bf16_to_f32(hb);
+      hst = hy;
+      hq[hid] = (__bf16)hy;
+      if (!in1 && t + 1 < T) gi = gin4[(bt + 1) * H + hid];
+    }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
+    lds_barrier();
+  }
+  if (own && hT) st(hT, b * H + hid, hst);
+}
+
+template <class S>
+static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
+                       void* out, void* hT, float* reserve, void* ws, hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
+  hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
+  hipLaunchKernelGGL((k_gru_fwd_f10<S>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0,
+                     packed_hid, wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr,
+                     (bf16_t*)out, (bf16_t*)hT, reserve);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+template <class S, int KS>
 static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
-                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
-  constexpr size_t lds = f10_lds_bytes<S>();
+                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                      hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
+  hipLaunchKernelGGL((k_f10_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
+  constexpr size_t lds = f10_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
   const char* diag = getenv("TTRNN_DIAG");
   const bool dg = diag && diag[0] == '1' && reserve;
-  auto kern = dg ? k_lstm_fwd_f10<S, true> : k_lstm_fwd_f10<S, false>;
+  auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
-                     (const float*)c0, packed_hid, bh, (float*)out, (float*)hT, (float*)cT, reserve);
+                     (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+// bytes of workspace launch_rnn_fwd_f10 needs for the fused core's fragments (0 when the shape has no f10 kernel)
+size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
+  if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
+    return (size_t)4 * F10<ShpH256R8G>::NM * 64 * sizeof(xbf8);
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
+  if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R8L>();
+  if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R16L>();
+  return 0;
+}
+
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
   const char* e = getenv("TTRNN_NO_F10");
-  if (e && e[0] == '1') return false;
-  return shape_matches<ShpH256R8L>(rs.hid_s);
+  if ((e && e[0] == '1') || rs.B < 1 || rs.T < 1) return false;
+  if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
+  return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
-                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
-  if (shape_matches<ShpH256R8L>(rs.hid_s))
-    return launch_f10<ShpH256R8L>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, stream);
+                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                       hipStream_t stream) {
+  if (rs.cell == TTRNN_GRU) {
+    if (shape_matches<ShpH256R8G>(rs.hid_s))
+      return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream);
+    return TTRNN_ERR_UNSUPPORTED;
+  }
+  if (shape_matches<ShpH256R8L>(rs.hid_s)) {
+    const char* e = getenv("TTRNN_F10_KSPLIT");        // A/B switch
+    if (e && e[0] == '1')
+      return launch_f10<ShpH256R8L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+    return launch_f10<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+  }
+  if (shape_matches<ShpH256R16L>(rs.hid_s))
+    return launch_f10<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

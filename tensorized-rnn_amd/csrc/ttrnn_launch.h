@@ -81,8 +81,10 @@ int launch_rnn_fwd_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const vo
 // fp32 storage, cores 1 and 0 contracted once per launch, fused stage on split-bf16 MFMAs (ttrnn_fast_f10.hip);
 // selected by ttrnn_set_fp32_math(TTRNN_MATH_SPLIT), the default
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype);
+size_t f10_workspace_bytes(const RnnShape& rs, int dtype);   // fused-core fragments, independent of the math mode
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
-                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream);
+                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                       hipStream_t stream);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);

@@ -12,9 +12,10 @@ from ttrnn_hip import functional as F
 dev = torch.device("cuda:0")
 torch.manual_seed(1111)
 with contextlib.redirect_stdout(io.StringIO()):
-    m = TTLSTM(1, 256, 1, dev, n_cores=3, tt_rank=8)
-B, T = 64, 784
-x = torch.rand(B, T, 1, device=dev, requires_grad=True)     # requires_grad -> reserve buffer exists
+    RANK, INP = int(os.environ.get("DIAG_RANK", "8")), int(os.environ.get("DIAG_IN", "1"))
+    m = TTLSTM(INP, 256, 1, dev, n_cores=3, tt_rank=RANK)
+B, T = int(os.environ.get("DIAG_B", "64")), int(os.environ.get("DIAG_T", "784"))
+x = torch.rand(B, T, INP, device=dev, requires_grad=True)     # requires_grad -> reserve buffer exists
 captured = {}
 orig = F._TTRnnLayerFn.forward
 def fwd(ctx, *a):
