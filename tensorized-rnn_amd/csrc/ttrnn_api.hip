@@ -157,7 +157,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 // whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
   bool use, lin_fast, in1;
-  size_t gin_bytes, lin_ws_bytes, f10_bytes;
+  size_t gin_bytes, lin_ws_bytes, f10_bytes, f10_lin_bytes;
   LinPlan lin;
 };
 
@@ -183,6 +183,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
     f.lin_ws_bytes = (f.lin.ws_bytes + 255) & ~(size_t)255;
   }
   f.f10_bytes = f10_workspace_bytes(rs, dtype);   // reserved whatever the math mode is at query time
+  f.f10_lin_bytes = f.in1 ? 0 : f10_ttlinear_workspace_bytes(rs.in_s, dtype, rs.H, rs.cell == TTRNN_LSTM ? 2 : 1);
   return f;
 }
 
@@ -190,7 +191,7 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
-  if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes;
+  if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes;
   if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
@@ -223,7 +224,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
-    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes) return TTRNN_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes)
+      return TTRNN_ERR_WORKSPACE;
     float* gin = (float*)workspace;
     void* lin_ws = (char*)workspace + f.gin_bytes;
     const int ilv_mode = rs.cell == TTRNN_LSTM ? 2 : 1;
@@ -236,6 +238,11 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
       if (st != TTRNN_OK) return st;
       st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
                                     (hipStream_t)stream);
+    } else if (fp32_math() == TTRNN_MATH_SPLIT && f.f10_lin_bytes > 0 &&
+               f10_ttlinear_fwd_available(rs.in_s, desc->dtype, rs.H, ilv_mode)) {
+      // K-in of a layer fed by another layer (in = H): fused-core kernel, split fp32 math
+      st = launch_ttlinear_fwd_f10(rs.in_s, (int64_t)rs.B * rs.T, packed_in, bin, x, gin,
+                                   (char*)workspace + f.gin_bytes + f.lin_ws_bytes + f.f10_bytes, (hipStream_t)stream);
     } else if (f.lin_fast) {
       // K-in: every timestep's input projection in one batched launch (all CUs), then K-rec
       st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, (int64_t)rs.B * rs.T, packed_in, bin, x, gin, rs.H,

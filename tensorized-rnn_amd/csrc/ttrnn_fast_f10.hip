@@ -352,6 +352,132 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   }
 }
 
+// ---- batched input projection (K-in) of the layers above the first one, on the same fused core ----------------------
+// gin[n][hid][slot] = W_in x[n] + b for n = B*T rows of the previous layer's output (in = H): the matrix has the
+// hidden-to-hidden shape, so the two-stage form S2 -> S10 applies unchanged; rows are independent, so a workgroup
+// simply walks over rows n = blockIdx.x, blockIdx.x + gridDim.x, ...  Per row: x[n] (1 KB) is split into three bf16
+// planes by wave 0 one row ahead (during the MFMA phase of the previous row), phase A = S2 tiles on all waves,
+// phase B = S10 k-halves on all waves (KS = 2 layout), the gate waves add the partner's partial sums and the bias and
+// store one 16-byte gate quadruple (slots i,g,f,o) per lane.  Two barriers per row.
+template <class S>
+__global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const float* __restrict__ x,
+                                                              const float* __restrict__ packed,
+                                                              const xbf8* __restrict__ wfrag,
+                                                              const float* __restrict__ bias, float* __restrict__ y) {
+  static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
+  using F = F10<S>;
+  constexpr int H = F::H;
+  static_assert(F::MT == 4 && F::NM % 2 == 0 && H == 256, "k-split layout");
+  constexpr int NU = F::NM / 2;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* xpl = reinterpret_cast<__bf16*>(smem);                            // bf16 planes of x: [parity][3][H]
+  __bf16* img = xpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
+  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // partial accumulators
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const bool gate_wave = wave < F::MT;
+  const int tile = wave & 3, u0 = (wave >> 2) * NU;
+
+  xbf8 s1[F::XA], s2[F::XA];
+#pragma unroll
+  for (int xx = 0; xx < F::XA; ++xx) f10_load_w2<S>(s1[xx], s2[xx], packed, wave + FAST_NW * xx, lane);
+  xbf8 w10[3][NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 3 + p) * 64 + lane];
+
+  const bool ok = gate_wave && c < F::I2;
+  const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
+  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f};                                     // slot order i,g,f,o
+  if (ok && bias) bh = f32x4{bias[hd], bias[2 * H + hd], bias[H + hd], bias[3 * H + hd]};
+
+  // wave 0: row n+G of x, four floats per lane, prefetched into registers a whole row ahead
+  const long G = gridDim.x;
+  long n = blockIdx.x;
+  f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave == 0 && n < n_rows) xv = *reinterpret_cast<const f32x4*>(x + n * H + 4 * lane);
+  if (wave == 0) {
+    store_split4(xpl, H, 4 * lane, xv);
+    if (n + G < n_rows) xv = *reinterpret_cast<const f32x4*>(x + (n + G) * H + 4 * lane);
+  }
+  lds_barrier();
+  const int row10 = c < F::I2 ? c : F::I2 - 1;
+  int par = 0;
+  for (; n < n_rows; n += G, par ^= 1) {
+    const __bf16* xp = xpl + par * 3 * H;
+    // ---- phase A: S2 ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int xx = 0; xx < F::XA; ++xx) {
+      f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, 0, lane);
+      f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, 1, lane);
+    }
+    lds_barrier();
+    // ---- phase B: S10 k-halves; wave 0 first puts the next row's planes in place -----------------------------------
+    if (wave == 0 && n + G < n_rows) {
+      store_split4(xpl + (par ^ 1) * 3 * H, H, 4 * lane, xv);
+      if (n + 2 * G < n_rows) xv = *reinterpret_cast<const f32x4*>(x + (n + 2 * G) * H + 4 * lane);
+    }
+    f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+    f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
+    f32x4 acc = acc_hi + acc_lo;
+    if (!gate_wave) xbuf[tile * 64 + lane] = acc;
+    lds_barrier();
+    if (ok) {
+      acc += xbuf[tile * 64 + lane];
+      // accumulator registers are i,f,g,o (reference gate order); the interleaved row wants slots i,g,f,o
+      *reinterpret_cast<f32x4*>(y + ((size_t)n * H + hd) * 4) =
+          f32x4{acc[0] + bh[0], acc[2] + bh[1], acc[1] + bh[2], acc[3] + bh[3]};
+    }
+  }
+}
+
+template <class S>
+constexpr size_t f10_lin_lds_bytes() {
+  return 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE + 4 * 64 * sizeof(f32x4);
+}
+
+template <class S>
+static int launch_lin_f10(long n_rows, const float* packed, const void* bias, const void* x, void* y, void* ws,
+                          hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
+  hipLaunchKernelGGL((k_f10_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed, wfrag);
+  constexpr size_t lds = f10_lin_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long grid = n_rows < (long)cus ? n_rows : (long)cus;       // one resident workgroup per CU walks the rows
+  hipLaunchKernelGGL((k_ttlinear_fwd_f10<S>), dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows,
+                     (const float*)x, packed, wfrag, (const float*)bias, (float*)y);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// gate-interleaved LSTM input projection (ilv_mode 2) of fp32 rows through a hidden-shaped TT-matrix
+bool f10_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h, int ilv_mode) {
+  const char* e = getenv("TTRNN_NO_F10");
+  if ((e && e[0] == '1') || dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return false;
+  return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s);
+}
+
+size_t f10_ttlinear_workspace_bytes(const TtShape& s, int dtype, int ilv_h, int ilv_mode) {
+  if (dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return 0;
+  if (shape_matches<ShpH256R8L>(s)) return f10_wfrag_bytes<ShpH256R8L>();
+  if (shape_matches<ShpH256R16L>(s)) return f10_wfrag_bytes<ShpH256R16L>();
+  return 0;
+}
+
+int launch_ttlinear_fwd_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
+                            void* y, void* ws, hipStream_t stream) {
+  if (n_rows <= 0) return TTRNN_OK;
+  if (shape_matches<ShpH256R8L>(s)) return launch_lin_f10<ShpH256R8L>((long)n_rows, packed, bias, x, y, ws, stream);
+  if (shape_matches<ShpH256R16L>(s)) return launch_lin_f10<ShpH256R16L>((long)n_rows, packed, bias, x, y, ws, stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
 // ---- bf16-storage GRU on the same fused core ---------------------------------------------------------------------
 // cfg3 (TT-GRU, bf16 storage, fp32 state / gates / accumulation): the chain runs directly on the bf16 MFMA (no
 // splitting: storage precision is bf16), with W10 rounded to bf16 once.  A GRU's r, z, n pre-activations of one

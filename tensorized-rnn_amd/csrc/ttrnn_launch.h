@@ -86,6 +86,13 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream);
 
+// batched gate-interleaved LSTM input projection through a hidden-shaped TT-matrix on the fused core (K-in of the
+// layers above the first); ws: f10_ttlinear_workspace_bytes
+bool f10_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h, int ilv_mode);
+size_t f10_ttlinear_workspace_bytes(const TtShape& s, int dtype, int ilv_h, int ilv_mode);
+int launch_ttlinear_fwd_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
+                            void* y, void* ws, hipStream_t stream);
+
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);
 size_t big_rnn_fwd_workspace(const RnnShape& rs);
