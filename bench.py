@@ -292,6 +292,9 @@ def main():
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": "ttrnn_rnn_forward (K-in batched input projection + K-rec persistent recurrent kernel)",
                          "kernel_ms": kern_ms,
+                         "basis": "algorithmic FLOPs of the reference's stage-by-stage chain (SURVEY.md 8(d)) over the "
+                                  "MFMA peak of the arithmetic dtype; the fused-core / split-math kernels execute "
+                                  "fewer FLOPs, on the bf16 MFMA (DESIGN.md 4a, 8)",
                          # input_size == 1 workloads evaluate the input chain on two unit rows and scale by x_t
                          # (W_in x is linear in a scalar): `achieved` prices the reference's ALGORITHMIC FLOPs
                          # (SURVEY.md 8(d)); this is the same figure with the input chain's share left out
