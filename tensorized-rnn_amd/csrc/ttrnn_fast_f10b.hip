@@ -1,0 +1,311 @@
+// ttrnn_fast_f10b.hip — reverse-time TT-LSTM kernel on the fused core (gfx950, fp32 storage, split-bf16 MFMAs).
+//
+// BPTT of one layer: for t = T-1 .. 0, from the saved gates (i,g,f,o,c) of step t and dh_t = d_out[t] + W_hid^T dg_{t+1}:
+//     dg_t  (the four gate pre-activation gradients, lstm.py:26-32 differentiated)      -> d_gates_in/hid[b][t][4H]
+//     dh_{t-1} = W_hid^T dg_t
+// W_hid^T dg is the transposed TT chain.  With cores 1 and 0 contracted once per launch (ttrnn_f10.h) it is two stages:
+//     T01: dC2[(row2,r2)][i2] = sum_m  W10[(row2,r2)][m] * dg[m][i2]              (256 features x 16 columns, K = 64)
+//     T2 : dh[row2][j2]       = sum_(i2,r2) G2[j2; i2,r2] * dC2[(row2,r2)][i2]    (8 features x 32 columns,  K = 128)
+// both on v_mfma_f32_16x16x32_bf16 with three-way split operands (ttrnn_split.h), like the forward kernel
+// (ttrnn_fast_f10.hip).  The stage-wise kernel (ttrnn_fast_bwd.hip: three fp32-MFMA stages, four barriers) stays as the
+// TTRNN_MATH_EXACT path.
+//
+// Per timestep (one 8-wave workgroup per sample):
+//     G    waves 0-3   one hidden unit per thread: gate gradients -> fp32 row (for the HBM store) and, split into three
+//                      bf16 planes, the [i2][m] operand of T01; the k order inside a row is chosen so that the four
+//                      gates of a thread are 4 consecutive k (one 8-byte store per plane)
+//     barrier
+//     T01  all waves   2 feature tiles per wave (24 MFMAs), result split into the [row2][(i2,r2)] operand of T2; the
+//                      fp32 gate-gradient row streams out to HBM in 16-byte pieces meanwhile
+//     barrier
+//     T2   all waves   wave = (column tile, k-block): 6 MFMAs each, partial dh sums (one slice per k-block) -> LDS
+//     barrier          (the next G phase adds the four slices)
+//
+// Replaces, for one layer: torch autograd through tensorized_rnn/lstm.py:23-32,123-133 and t3nsor/ops.py:78-93.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10.h"
+
+namespace ttrnn {
+
+template <class S>
+struct F10B {
+  using F = F10<S>;
+  static constexpr int H = F::H;
+  static constexpr int K1 = F::M;                 // T01 contraction: m = (i0,i1)                 (64)
+  static constexpr int NM1 = K1 / 32;             // k-blocks of T01                               (2)
+  static constexpr int FT = F::K / 16;            // T01 feature tiles (features = (row2,r2))      (16)
+  static constexpr int XF = FT / FAST_NW;         // per wave                                      (2)
+  static constexpr int K2 = F::I2 * F::R2;        // T2 contraction: (i2,r2)                       (128)
+  static constexpr int NM2 = K2 / 32;             // k-blocks of T2 = partial-sum slices           (4)
+  static constexpr int CT2 = F::ROWS2 / 16;       // T2 column tiles (columns = row2)              (2)
+  static constexpr int PL1 = F::I2 * K1;          // bf16 elements per plane of the T01 operand [I2][K1]
+  static constexpr int PL2 = F::ROWS2 * K2;       // bf16 elements per plane of the T2 operand [ROWS2][K2]
+  // k order of the T01 operand: thread hid holds gates g = 0..3 of m = MPG*g + hid/I2 -> 4 consecutive k
+  __device__ static constexpr int k1_of_m(int m) { return (m % F::MPG) * 4 + m / F::MPG; }
+  __device__ static constexpr int m_of_k1(int k) { return (k & 3) * F::MPG + (k >> 2); }
+  // k order of the T2 operand: two i2 per 16-byte slot, slots of one r2-quad contiguous (conflict-free stores from
+  // the T01 accumulators, same idea as F10::kperm)
+  static constexpr int HI = F::I2 / 2;
+  __device__ static constexpr int k2_of(int i2, int r2) { return ((r2 >> 2) * HI + (i2 >> 1)) * 8 + (i2 & 1) * 4 + (r2 & 3); }
+};
+
+template <class S>
+constexpr bool f10b_ok() {
+  using F = F10<S>;
+  using B = F10B<S>;
+  return f10_ok<S>() && F::I2 == 16 && B::K1 % 32 == 0 && B::FT % FAST_NW == 0 && B::K2 % 32 == 0 &&
+         B::NM2 * B::CT2 == FAST_NW && F::J2 == 8 && F::H == 256;
+}
+
+template <class S>
+constexpr size_t f10b_wfrag_elems() {      // xbf8 fragments: T01 [FT][NM1][3][64] then T2 [NM2][3][64]
+  return (size_t)(F10B<S>::FT * F10B<S>::NM1 + F10B<S>::NM2) * 3 * 64;
+}
+
+// fragment order: T01: wf[((ft*NM1 + u)*3 + p)*64 + lane], lane (r, q): feature 16ft + r = row2*R2 + r2, k = 32u + 8q + e
+//                 T2 : wf[T01 part + (u*3 + p)*64 + lane],  lane (r, q): feature j2 = r (< J2, else 0)
+template <class S>
+__global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ packed, xbf8* __restrict__ wfrag) {
+  using F = F10<S>;
+  using B = F10B<S>;
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  xbf8 f0, f1, f2;
+  if (blockIdx.x < B::FT * B::NM1) {
+    const int u = blockIdx.x % B::NM1, ft = blockIdx.x / B::NM1;
+    const int f = 16 * ft + r;
+    const int row2 = f / F::R2, r2 = f % F::R2;
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+    const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = B::m_of_k1(32 * u + 8 * q + e);
+      const int i0 = m / F::I1, i1 = m % F::I1;
+      const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+      float v = 0.f;
+      for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+      __bf16 p0, p1, p2;
+      split3(v, p0, p1, p2);
+      f0[e] = p0; f1[e] = p1; f2[e] = p2;
+    }
+    xbf8* dst = wfrag + (size_t)(blockIdx.x * 3) * 64 + lane;
+    dst[0] = f0; dst[64] = f1; dst[128] = f2;
+  } else {
+    const int u = blockIdx.x - B::FT * B::NM1;
+    const float* W2 = packed + woff_of<S>(2);               // [J2][M2 = I2*R2]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int slot = 4 * u + q;
+      const int i2 = 2 * (slot % B::HI) + (e >> 2), r2 = (slot / B::HI) * 4 + (e & 3);
+      const float v = r < F::J2 ? W2[r * F::M2 + i2 * F::R2 + r2] : 0.f;
+      __bf16 p0, p1, p2;
+      split3(v, p0, p1, p2);
+      f0[e] = p0; f1[e] = p1; f2[e] = p2;
+    }
+    xbf8* dst = wfrag + (size_t)(B::FT * B::NM1 * 3 + u * 3) * 64 + lane;
+    dst[0] = f0; dst[64] = f1; dst[128] = f2;
+  }
+}
+
+template <class S>
+constexpr size_t f10b_lds_bytes() {
+  using B = F10B<S>;
+  return sizeof(float) * 4 * B::H                     // dgf: fp32 gate-gradient row
+         + sizeof(float) * B::NM2 * B::H              // dhs: partial dh slices
+         + 2 * 3 * (size_t)(B::PL1 + B::PL2);         // the two split operands
+}
+
+template <class S>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const float* __restrict__ c0,
+                                                          const xbf8* __restrict__ wfrag,
+                                                          const float* __restrict__ reserve,
+                                                          const float* __restrict__ d_out,
+                                                          const float* __restrict__ d_hT,
+                                                          const float* __restrict__ d_cT, float* __restrict__ dg_in,
+                                                          float* __restrict__ dg_hid, float* __restrict__ d_h0,
+                                                          float* __restrict__ d_c0) {
+  static_assert(f10b_ok<S>(), "shape not supported by the fused-core reverse-time kernel");
+  using F = F10<S>;
+  using B = F10B<S>;
+  constexpr int H = F::H, GH = 4 * H;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* dgf = reinterpret_cast<float*>(smem);                               // [4H] in HBM row order
+  float* dhs = dgf + GH;                                                     // [NM2][H]
+  __bf16* img1 = reinterpret_cast<__bf16*>(dhs + B::NM2 * H);                 // 3 planes [I2][K1]
+  __bf16* img2 = img1 + 3 * B::PL1;                                          // 3 planes [ROWS2][K2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  // resident fragments: T01 for the feature tiles {wave + 8x}, T2 for k-block wave >> 1 (column tile wave & 1)
+  xbf8 w01[B::XF][B::NM1][3], w2t[3];
+#pragma unroll
+  for (int x = 0; x < B::XF; ++x)
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 3 + p) * 64 + lane];
+  const int ct = wave & 1, ub = wave >> 1;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) w2t[p] = wfrag[(size_t)(B::FT * B::NM1 * 3 + ub * 3 + p) * 64 + lane];
+
+  // gate phase: thread tid < H owns hidden unit tid; record(t) = (i,g,f,o),(c,-,-,-) prefetched one step ahead
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float dcs = (own && d_cT) ? d_cT[b * H + hid] : 0.f;
+  f32x4 ra = f32x4{0.f, 0.f, 0.f, 0.f}, rb = ra;
+  float dout_n = 0.f;
+  if (own) {
+    dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
+    if (T > 0) {
+      const size_t bt = b * T + (T - 1);
+      const float* rv = reserve + (bt * H + hid) * 8;
+      ra = *reinterpret_cast<const f32x4*>(rv);
+      rb = *reinterpret_cast<const f32x4*>(rv + 4);
+      dout_n = d_out ? d_out[bt * H + hid] : 0.f;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
+  lds_barrier();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t bt = b * T + t;
+    // ---- G: gate gradients (lstm.py:26-32 differentiated) ---------------------------------------------------------
+    if (own) {
+      const f32x4 qa = ra, qb = rb;
+      float dht = dout_n;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
+      f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
+      float dn = 0.f;
+      if (t > 0) {                       // record(t-1) / d_out(t-1) for the next iteration
+        const float* rv = reserve + ((bt - 1) * H + hid) * 8;
+        na = *reinterpret_cast<const f32x4*>(rv);
+        nb = *reinterpret_cast<const f32x4*>(rv + 4);
+        dn = d_out ? d_out[(bt - 1) * H + hid] : 0.f;
+      }
+      const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = qb[0];
+      const float cprev = t > 0 ? nb[0] : (c0 ? c0[b * H + hid] : 0.f);
+      const float tc = ftanh(cy);
+      const float dct = dcs + dht * og * (1.0f - tc * tc);
+      const float p0 = dct * gg * ig * (1.0f - ig);             // d pre-activation of i
+      const float p1 = dct * cprev * fg * (1.0f - fg);          //                     f
+      const float p2 = dct * ig * (1.0f - gg * gg);             //                     g
+      const float p3 = dht * tc * og * (1.0f - og);             //                     o
+      dcs = dct * fg;
+      dgf[hid] = p0; dgf[H + hid] = p1; dgf[2 * H + hid] = p2; dgf[3 * H + hid] = p3;
+      // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
+      store_split4(img1, B::PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), f32x4{p0, p1, p2, p3});
+      ra = na; rb = nb; dout_n = dn;
+    }
+    lds_barrier();
+    // ---- T01: dC2 = W10 dg, two feature tiles per wave; meanwhile the fp32 row goes out to HBM -------------------
+    {
+      if (tid < GH / 4) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[tid];
+        reinterpret_cast<f32x4*>(dg_in + bt * GH)[tid] = v;
+        if (dg_hid && dg_hid != dg_in) reinterpret_cast<f32x4*>(dg_hid + bt * GH)[tid] = v;
+      }
+      xbf8 bf[B::NM1][3];
+#pragma unroll
+      for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[u][p] = *reinterpret_cast<const xbf8*>(img1 + p * B::PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+      for (int x = 0; x < B::XF; ++x) {
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s)
+            acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[x][u][SPLIT_TW[s]], bf[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+          acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[x][u][0], bf[u][0], acc_hi, 0, 0, 0);
+        }
+        const f32x4 acc = acc_hi + acc_lo;
+        // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = 4*(q&1) + j)
+        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+        store_split4(img2, B::PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc);
+      }
+    }
+    lds_barrier();
+    // ---- T2: dh_{t-1}[row2][j2], wave = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
+    {
+      const int row = 16 * ct + c;
+      xbf8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        bf[p] = *reinterpret_cast<const xbf8*>(img2 + p * B::PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+        acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
+      acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[0], bf[0], acc_hi, 0, 0, 0);
+      const f32x4 acc = acc_hi + acc_lo;
+      // lane (c = row2 in the column tile, q), registers j: j2 = 4q + j (valid for q < 2): hidden = row2*J2 + j2
+      if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc;
+    }
+    lds_barrier();
+  }
+  if (own) {
+    if (d_h0) {
+      float v = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) v += dhs[sl * H + hid];
+      d_h0[b * H + hid] = v;
+    }
+    if (d_c0) d_c0[b * H + hid] = dcs;
+  }
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+template <class S>
+static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                          const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                          void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  using B = F10B<S>;
+  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
+  hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed_hid, wfrag);
+  constexpr size_t lds = f10b_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  hipLaunchKernelGGL((k_lstm_bwd_f10<S>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, wfrag,
+                     reserve, (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                     (float*)d_c0);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
+  const char* e = getenv("TTRNN_NO_F10");
+  if ((e && e[0] == '1') || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
+  return shape_matches<ShpH256R8L>(rs.hid_s);
+}
+
+size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
+  if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
+  return 0;
+}
+
+int launch_rnn_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                       const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
+                       void* d_c0, void* ws, hipStream_t stream) {
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
+    return launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
+                                      stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn

@@ -106,6 +106,13 @@ int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const vo
                         const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                         const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, hipStream_t stream);
 
+// reverse-time TT-LSTM kernel on the fused core, split fp32 math (ttrnn_fast_f10b.hip); ws: fragments built per launch
+bool f10_rnn_bwd_available(const RnnShape& rs, int dtype);
+size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype);
+int launch_rnn_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                       const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
+                       void* d_c0, void* ws, hipStream_t stream);
+
 // shape-specialised batched TTLinear backward (ttrnn_fast_bwd.hip); accumulates into d_packed / d_bias
 bool fast_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
 int launch_ttlinear_bwd_fast(const TtShape& s, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
