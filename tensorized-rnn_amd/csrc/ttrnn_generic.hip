@@ -45,34 +45,69 @@ int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream) {
 }
 
 // input_size == 1: y_n = b + x_n * v  =>  dL/dv[o] = sum_n x_n dy[n][o],  dL/db[o] = sum_n dy[n][o].
-// One pass over dy (memory-bound); each workgroup owns a slab of rows, each thread a few columns.
+typedef float4 f32x4_t;
+
+// One pass over dy (HBM-bound: reads n_rows * out values once).  A workgroup owns a slab of rows; a thread owns FOUR
+// consecutive columns (one 16-byte load per row when dy is fp32) and walks the slab eight rows at a time so that eight
+// independent loads are in flight per lane; partial sums leave through one atomic per column and workgroup.
 template <typename TX, typename TDY>
-__global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, const TX* __restrict__ x,
+__global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, int rows_per_wg, const TX* __restrict__ x,
                                                     const TDY* __restrict__ dy, float* __restrict__ dv,
                                                     float* __restrict__ db) {
-  const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * per;
-  const int64_t r1 = r0 + per < n_rows ? r0 + per : n_rows;
-  for (int o = threadIdx.x; o < out; o += blockDim.x) {
-    float av = 0.f, ab = 0.f;
-    for (int64_t n = r0; n < r1; ++n) {
-      const float g = ld(dy, (size_t)n * out + o);
-      av = fmaf(ld(x, (size_t)n), g, av);
-      ab += g;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < n_rows ? r0 + rows_per_wg : n_rows;
+  if (r0 >= r1) return;
+  for (int o = 4 * threadIdx.x; o < out; o += 4 * blockDim.x) {
+    float av[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nc = out - o < 4 ? out - o : 4;
+    int64_t n = r0;
+    if (nc == 4 && out % 4 == 0) {      // 16-byte aligned rows
+      for (; n + 8 <= r1; n += 8) {
+        float g[8][4], xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if constexpr (sizeof(TDY) == 4) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(dy) + (size_t)(n + k) * out + o);
+            g[k][0] = v.x; g[k][1] = v.y; g[k][2] = v.z; g[k][3] = v.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[k][j] = ld(dy, (size_t)(n + k) * out + o + j);
+          }
+          xv[k] = ld(x, (size_t)(n + k));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            av[j] = fmaf(xv[k], g[k][j], av[j]);
+            ab[j] += g[k][j];
+          }
+      }
     }
-    if (r1 > r0) {
-      atomicAdd(dv + o, av);
-      if (db) atomicAdd(db + o, ab);
+    for (; n < r1; ++n) {
+      const float xn = ld(x, (size_t)n);
+      for (int j = 0; j < nc; ++j) {
+        const float g = ld(dy, (size_t)n * out + o + j);
+        av[j] = fmaf(xn, g, av[j]);
+        ab[j] += g;
+      }
+    }
+    for (int j = 0; j < nc; ++j) {
+      atomicAdd(dv + o + j, av[j]);
+      if (db) atomicAdd(db + o + j, ab[j]);
     }
   }
 }
 
 int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
                       float* db, hipStream_t stream) {
-  int grid = (int)((n_rows + 127) / 128);
-  if (grid < 1) grid = 1;
-  if (grid > 1024) grid = 1024;
-#define TT_L(TX, TDY) hipLaunchKernelGGL((k_in1_reduce<TX, TDY>), dim3(grid), dim3(256), 0, stream, n_rows, out, (const TX*)x, (const TDY*)dy, dv, db)
+  // ~512 workgroups (two per CU): every workgroup ends with one atomic per column, and more workgroups than that made
+  // the atomics (1 568 per address for cfg2), not the HBM stream, the limit
+  int rows_per_wg = (int)((n_rows + 511) / 512);
+  rows_per_wg = (rows_per_wg + 7) & ~7;
+  if (rows_per_wg < 8) rows_per_wg = 8;
+  const int grid = (int)((n_rows + rows_per_wg - 1) / rows_per_wg) > 0 ? (int)((n_rows + rows_per_wg - 1) / rows_per_wg) : 1;
+#define TT_L(TX, TDY) hipLaunchKernelGGL((k_in1_reduce<TX, TDY>), dim3(grid), dim3(256), 0, stream, n_rows, out, rows_per_wg, (const TX*)x, (const TDY*)dy, dv, db)
   if (dtype == TTRNN_F32 && dy_dtype == TTRNN_F32) TT_L(float, float);
   else if (dtype == TTRNN_F32) TT_L(float, bf16_t);
   else if (dy_dtype == TTRNN_F32) TT_L(bf16_t, float);

@@ -14,8 +14,22 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else name[:60]
+    """kernel base name + the template arguments that tell instantiations apart (shape digits, flags)"""
+    m = re.search(r"(k_[a-z0-9_]+)(<.*>)?", name)
+    if not m:
+        return name[:60]
+    args = m.group(2) or ""
+    shp = re.search(r"Shp<([0-9, ]+)>", args)
+    tag = ""
+    if shp:
+        d = [int(v) for v in shp.group(1).split(",")]
+        tag = "[J=%s I=%s R=%s]" % ("x".join(map(str, d[1:1 + d[0]])), "x".join(map(str, d[5:5 + d[0]])),
+                                    "x".join(map(str, d[9:9 + d[0] - 1])))
+        rest = re.sub(r"ttrnn::Shp<[0-9, ]+>,?\s*", "", args)
+        rest = rest.strip("<> ")
+        if rest:
+            tag += "<" + rest + ">"
+    return m.group(1) + tag
 
 
 def main(out):
