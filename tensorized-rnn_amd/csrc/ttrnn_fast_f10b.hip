@@ -287,6 +287,22 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+// the fragment set alone (shared with the weight-gradient kernel, ttrnn_fast_f10w.hip)
+size_t f10b_fragment_bytes(const TtShape& s) {
+  if (shape_matches<ShpH256R8L>(s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
+  return 0;
+}
+
+int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream) {
+  if (shape_matches<ShpH256R8L>(s)) {
+    using B = F10B<ShpH256R8L>;
+    hipLaunchKernelGGL((k_f10b_prep<ShpH256R8L>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed,
+                       reinterpret_cast<xbf8*>(wfrag));
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   const char* e = getenv("TTRNN_NO_F10");
   if ((e && e[0] == '1') || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;

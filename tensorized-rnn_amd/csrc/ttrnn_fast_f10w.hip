@@ -1,0 +1,277 @@
+// ttrnn_fast_f10w.hip — batched weight gradients of a hidden-shaped TT-matrix through the fused core (gfx950, fp32).
+//
+// dL/dG_k of y_n = TT(G) x_n over n = B*T rows (autograd of t3nsor/ops.py:78-93 for `hidden_weights`: x_n = h_{t-1},
+// dy_n = the gate gradients of the reverse-time kernel; dx is NOT produced here — dh travels inside that kernel).
+// The stage-wise kernel (ttrnn_fast_bwd.hip) recomputes the three forward stages, runs two transposed stages and three
+// weight-gradient GEMMs per row: 1.83 MFLOP per row on the fp32 MFMA.  With cores 1 and 0 contracted (ttrnn_f10.h)
+//     y[m][i2] = sum_k W10[k][m] * C2[i2][k],      C2 = S2(x)        (k = (row2, r2), m = (i0, i1))
+// the gradients factor as
+//     dW10[k][m]        += sum_i2   C2[i2][k] * dy[m][i2]                       (256 x 64, contraction 16 per row)
+//     dW2[j2][(i2,r2)]  += sum_row2 x[row2][j2] * dC2[row2][(i2,r2)],   dC2 = W10 dy   (8 x 128, contraction 32 per row)
+// accumulated over all rows in MFMA accumulators that stay in registers for the whole launch (32 + 4 VGPRs per lane),
+// and ONE small kernel at the end turns dW10 into dG0 and dG1 by the product rule (W10 = sum_r1 G0 * G1).
+// Per row: S2 (fp32 MFMA, 4 per wave), dC2 = T01 on split-bf16 MFMAs with the fragments of the reverse-time kernel
+// (24 per wave), dW10 (32 fp32 MFMAs per wave), dW2 (8 per wave): 0.66 MFLOP on the fp32 pipe + 0.52 on the bf16 pipe.
+// The weight-gradient GEMMs contract over the index that is the MFMA *column* of their producers, which the fp32
+// MFMA's one-value-per-lane operands read straight from (padded, conflict-free) fp32 LDS images; their operands are
+// therefore not split.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10.h"
+
+namespace ttrnn {
+
+template <class S>
+struct F10W {
+  using F = F10<S>;
+  static constexpr int H = F::H, OUT = 4 * F::H;
+  static constexpr int K1 = F::M, NM1 = K1 / 32;          // T01 contraction (m) and its k-blocks
+  static constexpr int FT = F::K / 16, XF = FT / FAST_NW;  // T01 / dW10 feature tiles (k = (row2, r2)), per wave
+  static constexpr int MT = F::M / 16;                     // dW10 column tiles (m)
+  static constexpr int K2 = F::I2 * F::R2;                 // (i2, r2): columns of dC2 / dW2
+  static constexpr int CT2 = K2 / 16;                      // dW2 column tiles: one per wave
+  static constexpr int PL1 = F::I2 * K1;                   // bf16 elements per plane of the T01 operand
+  static constexpr int DGS = K1 + 16;                      // row stride of dgT  [I2][m]       (fp32, +16: bank shift)
+  static constexpr int C2S = F::K + 16;                    // row stride of C2   [I2][k]
+  static constexpr int DCS = K2 + 16;                      // row stride of dC2  [ROWS2][(i2,r2)]
+};
+
+template <class S>
+constexpr bool f10w_ok() {
+  using F = F10<S>;
+  using W = F10W<S>;
+  return f10_ok<S>() && F::I2 == 16 && F::H == 256 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 && W::CT2 == FAST_NW &&
+         W::MT == 4 && F::J2 == 8 && St<S, 2>::MT == FAST_NW && St<S, 2>::RT == 2 && !St<S, 2>::SPLIT;
+}
+
+template <class S>
+constexpr size_t f10w_lds_bytes() {
+  using F = F10<S>;
+  using W = F10W<S>;
+  return sizeof(float) * (F::H + F::I2 * W::DGS + F::I2 * W::C2S + F::ROWS2 * W::DCS) + 2 * 3 * (size_t)W::PL1;
+}
+
+// wfrag: the T01 fragments of k_f10b_prep (ttrnn_fast_f10b.hip);  dW10: fp32 [K][M] accumulation buffer (zeroed)
+template <class S>
+__global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, const float* __restrict__ packed,
+                                                                const xbf8* __restrict__ wfrag,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ dy, float* __restrict__ dW10,
+                                                                float* __restrict__ d_packed,
+                                                                float* __restrict__ d_bias) {
+  static_assert(f10w_ok<S>(), "shape not supported by the fused-core weight-gradient kernel");
+  using F = F10<S>;
+  using W = F10W<S>;
+  constexpr int H = F::H, OUT = W::OUT;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* ximg = reinterpret_cast<float*>(smem);               // x row, [ROWS2][J2] = flat hidden index
+  float* dgT = ximg + H;                                      // dy transposed: [i2][m]
+  float* c2i = dgT + F::I2 * W::DGS;                          // C2 = S2(x): [i2][k]
+  float* dci = c2i + F::I2 * W::C2S;                          // dC2 = W10 dy: [row2][(i2,r2)]
+  __bf16* img1 = reinterpret_cast<__bf16*>(dci + F::ROWS2 * W::DCS);   // split dy, T01 operand: 3 planes [i2][k1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+
+  float w2[nwreg<S, 2>()];
+  load_wfrag<S, 2>(w2, packed, wave, lane);
+  xbf8 w01[W::XF][W::NM1][3];
+#pragma unroll
+  for (int xx = 0; xx < W::XF; ++xx)
+#pragma unroll
+    for (int u = 0; u < W::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        w01[xx][u][p] = wfrag[(size_t)(((wave + FAST_NW * xx) * W::NM1 + u) * 3 + p) * 64 + lane];
+
+  // accumulators: dW10 tiles (k-tile wave + 8*xx, m-tile mt) and the dW2 tile of column tile `wave`
+  f32x4 g10[W::XF][W::MT], g2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int xx = 0; xx < W::XF; ++xx)
+#pragma unroll
+    for (int mt = 0; mt < W::MT; ++mt) g10[xx][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbias[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // loads: thread tid < H owns hidden unit tid (4 gate gradients); threads tid < H/4 also carry 4 values of x
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  const long G = gridDim.x;
+  long n = blockIdx.x;
+  f32x4 dyv = f32x4{0.f, 0.f, 0.f, 0.f}, xv = dyv;
+  if (n < n_rows) {
+    if (own) dyv = f32x4{dy[n * OUT + hid], dy[n * OUT + H + hid], dy[n * OUT + 2 * H + hid], dy[n * OUT + 3 * H + hid]};
+    if (tid < H / 4) xv = *reinterpret_cast<const f32x4*>(x + n * H + 4 * tid);
+  }
+  for (; n < n_rows; n += G) {
+    // ---- phase 1: this row into LDS; the next row's loads take off ---------------------------------------------
+    if (own) {
+      // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid % I2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        dgT[(hid % F::I2) * W::DGS + F::MPG * g + hid / F::I2] = dyv[g];
+        dbias[g] += dyv[g];
+      }
+      store_split4(img1, W::PL1, x_off<W::K1>(hid % F::I2, 4 * (hid / F::I2)), dyv);     // k1 = 4*(hid/I2) + gate
+    }
+    if (tid < H / 4) *reinterpret_cast<f32x4*>(ximg + 4 * tid) = xv;
+    if (n + G < n_rows) {
+      const long nn = n + G;
+      if (own) dyv = f32x4{dy[nn * OUT + hid], dy[nn * OUT + H + hid], dy[nn * OUT + 2 * H + hid], dy[nn * OUT + 3 * H + hid]};
+      if (tid < H / 4) xv = *reinterpret_cast<const f32x4*>(x + nn * H + 4 * tid);
+    }
+    lds_barrier();
+    // ---- phase 2: C2 = S2(x) (fp32 MFMA) and dC2 = W10 dy (split-bf16 MFMAs), both into fp32 images ----------------
+    {
+      using T2 = St<S, 2>;
+      f32x4 acc[T2::XM][T2::YR];
+      stage_mma<S, 2>(w2, ximg, acc, wave, lane);
+#pragma unroll
+      for (int y = 0; y < T2::YR; ++y) {
+        const int row2 = 16 * y + c, m0 = 16 * wave + 4 * q;                 // feature m0 = (i2, r2 .. r2+3)
+        *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[0][y];
+      }
+      xbf8 bf[W::NM1][3];
+#pragma unroll
+      for (int u = 0; u < W::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[u][p] = *reinterpret_cast<const xbf8*>(img1 + p * W::PL1 + x_off<W::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+      for (int xx = 0; xx < W::XF; ++xx) {
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+        for (int u = 0; u < W::NM1; ++u) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s)
+            acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[xx][u][SPLIT_TW[s]], bf[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+          acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[xx][u][0], bf[u][0], acc_hi, 0, 0, 0);
+        }
+        // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = 4*(q&1) + j)
+        const int f0 = 16 * (wave + FAST_NW * xx) + 4 * q;
+        *reinterpret_cast<f32x4*>(dci + (f0 / F::R2) * W::DCS + c * F::R2 + f0 % F::R2) = acc_hi + acc_lo;
+      }
+    }
+    lds_barrier();
+    // ---- phase 3: weight-gradient MFMAs (fp32, contraction on the k slots) -----------------------------------------
+#pragma unroll
+    for (int s = 0; s < F::I2 / 4; ++s) {                    // dW10[k][m] += C2[i2][k] * dy[m][i2], i2 = 4s + q
+      float a[W::XF], bm[W::MT];
+#pragma unroll
+      for (int xx = 0; xx < W::XF; ++xx) a[xx] = c2i[(4 * s + q) * W::C2S + 16 * (wave + FAST_NW * xx) + c];
+#pragma unroll
+      for (int mt = 0; mt < W::MT; ++mt) bm[mt] = dgT[(4 * s + q) * W::DGS + 16 * mt + c];
+#pragma unroll
+      for (int xx = 0; xx < W::XF; ++xx)
+#pragma unroll
+        for (int mt = 0; mt < W::MT; ++mt)
+          g10[xx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xx], bm[mt], g10[xx][mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < F::ROWS2 / 4; ++s) {                 // dW2[j2][col] += x[row2][j2] * dC2[row2][col], row2 = 4s + q
+      const float a = c < F::J2 ? ximg[(4 * s + q) * F::J2 + c] : 0.f;
+      const float bcol = dci[(4 * s + q) * W::DCS + 16 * wave + c];
+      g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcol, g2, 0, 0, 0);
+    }
+    lds_barrier();
+  }
+  // ---- flush: one atomic per accumulator element and workgroup ---------------------------------------------------------
+#pragma unroll
+  for (int xx = 0; xx < W::XF; ++xx)
+#pragma unroll
+    for (int mt = 0; mt < W::MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)      // D row 4q + j = feature k, column c = m
+        atomicAdd(dW10 + (size_t)(16 * (wave + FAST_NW * xx) + 4 * q + j) * F::M + 16 * mt + c, g10[xx][mt][j]);
+  if (q < 2) {
+    float* dW2 = d_packed + woff_of<S>(2);                    // [J2][M2 = (i2, r2)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * wave + c, g2[j]);
+  }
+  if (d_bias && own) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(d_bias + g * H + hid, dbias[g]);
+  }
+}
+
+// dG0, dG1 from dW10 by the product rule; one thread per core element, accumulating into d_packed
+template <class S>
+__global__ void __launch_bounds__(256) k_f10w_finish(const float* __restrict__ packed, const float* __restrict__ dW10,
+                                                     float* __restrict__ d_packed) {
+  using F = F10<S>;
+  constexpr int N0 = F::J0 * F::R1 * F::I0;                  // elements of W_0 [J0*R1][I0]
+  constexpr int N1 = F::J1 * F::R2 * F::I1 * F::R1;          // elements of W_1 [J1*R2][I1*R1]
+  const float* W0 = packed + woff_of<S>(0);
+  const float* W1 = packed + woff_of<S>(1);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < N0) {
+    const int i0 = e % F::I0, r1 = (e / F::I0) % F::R1, j0 = e / (F::I0 * F::R1);
+    float v = 0.f;
+    for (int j1 = 0; j1 < F::J1; ++j1)
+      for (int r2 = 0; r2 < F::R2; ++r2)
+        for (int i1 = 0; i1 < F::I1; ++i1)
+          v = fmaf(W1[(j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1 + r1],
+                   dW10[(size_t)((j0 * F::J1 + j1) * F::R2 + r2) * F::M + i0 * F::I1 + i1], v);
+    d_packed[woff_of<S>(0) + e] += v;
+  } else if (e < N0 + N1) {
+    const int f = e - N0;
+    const int r1 = f % F::R1, i1 = (f / F::R1) % F::I1, r2 = (f / (F::R1 * F::I1)) % F::R2, j1 = f / (F::R1 * F::I1 * F::R2);
+    float v = 0.f;
+    for (int j0 = 0; j0 < F::J0; ++j0)
+      for (int i0 = 0; i0 < F::I0; ++i0)
+        v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0],
+                 dW10[(size_t)((j0 * F::J1 + j1) * F::R2 + r2) * F::M + i0 * F::I1 + i1], v);
+    d_packed[woff_of<S>(1) + f] += v;
+  }
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+template <class S>
+static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed, const void* x, const void* dy,
+                            float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+  using F = F10<S>;
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  float* dW10 = reinterpret_cast<float*>(ws);
+  const size_t dw_bytes = (size_t)F::K * F::M * sizeof(float);
+  void* wfrag = (char*)ws + dw_bytes;
+  if (hipMemsetAsync(dW10, 0, dw_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  int st = launch_f10b_prep(ts, packed, wfrag, stream);
+  if (st != TTRNN_OK) return st;
+  constexpr size_t lds = f10w_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long grid = n_rows < (long)cus ? n_rows : (long)cus;
+  hipLaunchKernelGGL((k_ttlinear_wgrad_f10<S>), dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows, packed,
+                     (const xbf8*)wfrag, (const float*)x, (const float*)dy, dW10, d_packed, d_bias);
+  constexpr int NE = F::J0 * F::R1 * F::I0 + F::J1 * F::R2 * F::I1 * F::R1;
+  hipLaunchKernelGGL((k_f10w_finish<S>), dim3((NE + 255) / 256), dim3(256), 0, stream, packed, dW10, d_packed);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
+  const char* e = getenv("TTRNN_NO_F10");
+  if ((e && e[0] == '1') || dtype != TTRNN_F32 || dy_dtype != TTRNN_F32) return false;
+  return shape_matches<ShpH256R8L>(s);
+}
+
+size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
+  if (shape_matches<ShpH256R8L>(s))
+    return (size_t)F10<ShpH256R8L>::K * F10<ShpH256R8L>::M * sizeof(float) + f10b_fragment_bytes(s);
+  return 0;
+}
+
+int launch_ttlinear_wgrad_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* x, const void* dy,
+                              float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+  if (n_rows <= 0) return TTRNN_OK;
+  if (shape_matches<ShpH256R8L>(s))
+    return launch_wgrad_f10<ShpH256R8L>(s, (long)n_rows, packed, x, dy, d_packed, d_bias, ws, stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn
