@@ -496,3 +496,53 @@ def test_math_modes_full_size_properties(math_mode):
     assert torch.equal(out[:, :100], out_p)
     assert torch.equal(out[:, -1], hT)
     assert torch.isfinite(out).all() and torch.isfinite(cT).all()
+
+
+# ---- (5) fused-core kernels: persistent row loops, stacked layers, switches ---------------------------------------
+@pytest.mark.parametrize("rank,B,T", [(8, 41, 23), (16, 37, 19)])
+def test_stacked_layers_many_rows_vs_generic(rank, B, T):
+    """Two stacked TT-LSTM layers (the second one's input projection and both weight-gradient passes run on the
+    fused-core kernels, whose workgroups WALK over B*T > 256 rows) against the any-shape kernels on the same module:
+    forward, input gradient and every parameter gradient."""
+    import os
+    torch.manual_seed(77 + rank)
+    meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=rank)
+    m = build_module(meta, dev())
+    x = torch.rand(B, T, 40, device=dev())
+    w = torch.randn(B, T, 256, device=dev())
+    outs = []
+    for force in ("0", "1"):
+        os.environ["TTRNN_FORCE_GENERIC"] = force
+        try:
+            m.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            out, (h, c) = m(xg)
+            ((out * w).sum() + c.sum() + h.sum()).backward()
+            outs.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ["TTRNN_FORCE_GENERIC"] = "0"
+    assert _maxabs(outs[0][0], outs[1][0]) <= 5e-6
+    assert _maxabs(outs[0][1], outs[1][1]) <= 1e-4 * max(1e-3, float(outs[1][1].abs().max()))
+    for (name, _), a, b in zip(m.named_parameters(), outs[0][2], outs[1][2]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6), name
+
+
+def test_fused_core_switch_off_matches():
+    """TTRNN_NO_F10=1 (stage-wise kernels instead of the fused-core ones) gives the same results within fp32 tolerance."""
+    import os
+    m = _cfg2_module()
+    torch.manual_seed(8)
+    x = torch.rand(6, 50, 1, device=dev())
+    res = []
+    for flag in ("0", "1"):
+        os.environ["TTRNN_NO_F10"] = flag
+        try:
+            m.zero_grad()
+            out, (h, c) = m(x)
+            (out.square().sum() + c.sum()).backward()
+            res.append((out.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ["TTRNN_NO_F10"] = "0"
+    assert _maxabs(res[0][0], res[1][0]) <= 2e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
