@@ -546,3 +546,21 @@ def test_fused_core_switch_off_matches():
     assert _maxabs(res[0][0], res[1][0]) <= 2e-6
     for a, b in zip(res[0][1], res[1][1]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("rank", [8, 16])
+def test_fused_core_edge_cases_vs_oracle(rank):
+    """Fused-core kernels at the corners: no biases, B = 1, T = 1 and T = 2, explicit and absent initial state."""
+    torch.manual_seed(300 + rank)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from tensorized_rnn.tt_lstm import TTLSTM
+        m = TTLSTM(1, 256, 1, dev(), n_cores=3, tt_rank=rank, bias=False)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert not any(k.endswith("bias") for k in sd)
+    for B, T, with_init in [(1, 1, False), (1, 2, True), (3, 1, True), (2, 5, False)]:
+        x = torch.randn(B, T, 1)
+        init = (torch.randn(B, 256) * 0.3, torch.randn(B, 256) * 0.3) if with_init else None
+        ro, rh, rc = _oracle_forward("ttlstm", sd, 1, x, init)
+        with torch.no_grad():
+            out, (hT, cT) = m(x.to(dev()), None if init is None else (init[0].to(dev()), init[1].to(dev())))
+        assert _maxabs(out, ro) <= 1e-5 and _maxabs(hT, rh) <= 1e-5 and _maxabs(cT, rc) <= 1e-5, (B, T, with_init)
