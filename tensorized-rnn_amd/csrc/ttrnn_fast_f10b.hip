@@ -290,16 +290,21 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
 // the fragment set alone (shared with the weight-gradient kernel, ttrnn_fast_f10w.hip)
 size_t f10b_fragment_bytes(const TtShape& s) {
   if (shape_matches<ShpH256R8L>(s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
+  if (shape_matches<ShpH256R16L>(s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8);
   return 0;
 }
 
+template <class S>
+static int launch_prep_b(const float* packed, void* wfrag, hipStream_t stream) {
+  using B = F10B<S>;
+  hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed,
+                     reinterpret_cast<xbf8*>(wfrag));
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream) {
-  if (shape_matches<ShpH256R8L>(s)) {
-    using B = F10B<ShpH256R8L>;
-    hipLaunchKernelGGL((k_f10b_prep<ShpH256R8L>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed,
-                       reinterpret_cast<xbf8*>(wfrag));
-    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
-  }
+  if (shape_matches<ShpH256R8L>(s)) return launch_prep_b<ShpH256R8L>(packed, wfrag, stream);
+  if (shape_matches<ShpH256R16L>(s)) return launch_prep_b<ShpH256R16L>(packed, wfrag, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

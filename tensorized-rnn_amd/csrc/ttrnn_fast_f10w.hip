@@ -33,34 +33,42 @@ struct F10W {
   static constexpr int FT = F::K / 16, XF = FT / FAST_NW;  // T01 / dW10 feature tiles (k = (row2, r2)), per wave
   static constexpr int MT = F::M / 16;                     // dW10 column tiles (m)
   static constexpr int K2 = F::I2 * F::R2;                 // (i2, r2): columns of dC2 / dW2
-  static constexpr int CT2 = K2 / 16;                      // dW2 column tiles: one per wave
+  static constexpr int CT2 = K2 / 16, XC = CT2 / FAST_NW;  // dW2 column tiles, per wave
   static constexpr int PL1 = F::I2 * K1;                   // bf16 elements per plane of the T01 operand
   static constexpr int DGS = K1 + 16;                      // row stride of dgT  [I2][m]       (fp32, +16: bank shift)
   static constexpr int C2S = F::K + 16;                    // row stride of C2   [I2][k]
-  static constexpr int DCS = K2 + 16;                      // row stride of dC2  [ROWS2][(i2,r2)]
+  // row stride of dC2 [ROWS2][(i2,r2)]: read with lanes along the columns (dW2) AND with lanes along the rows (dx);
+  // +4 keeps 16-byte alignment and leaves both patterns at most 2-way conflicted
+  static constexpr int DCS = K2 + 4;
+  // dx = G2^T dC2 (only for matrices whose input is another layer's output): wave = (column tile, quarter of the
+  // (i2,r2) contraction), partial sums through LDS
+  static constexpr int KQ = K2 / 4 / 4;                    // k-steps per quarter
 };
 
 template <class S>
 constexpr bool f10w_ok() {
   using F = F10<S>;
   using W = F10W<S>;
-  return f10_ok<S>() && F::I2 == 16 && F::H == 256 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 && W::CT2 == FAST_NW &&
-         W::MT == 4 && F::J2 == 8 && St<S, 2>::MT == FAST_NW && St<S, 2>::RT == 2 && !St<S, 2>::SPLIT;
+  return f10_ok<S>() && F::I2 == 16 && F::H == 256 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 &&
+         W::CT2 % FAST_NW == 0 && W::MT == 4 && F::J2 == 8 && St<S, 2>::MT % FAST_NW == 0 && St<S, 2>::RT == 2 &&
+         !St<S, 2>::SPLIT && F::ROWS2 == 32 && W::K2 % 16 == 0;
 }
 
 template <class S>
 constexpr size_t f10w_lds_bytes() {
   using F = F10<S>;
   using W = F10W<S>;
-  return sizeof(float) * (F::H + F::I2 * W::DGS + F::I2 * W::C2S + F::ROWS2 * W::DCS) + 2 * 3 * (size_t)W::PL1;
+  return sizeof(float) * (F::H + F::I2 * W::DGS + F::I2 * W::C2S + F::ROWS2 * W::DCS + 4 * F::H) + 2 * 3 * (size_t)W::PL1;
 }
 
-// wfrag: the T01 fragments of k_f10b_prep (ttrnn_fast_f10b.hip);  dW10: fp32 [K][M] accumulation buffer (zeroed)
-template <class S>
+// wfrag: the T01 fragments of k_f10b_prep (ttrnn_fast_f10b.hip);  dW10: fp32 [K][M] accumulation buffer (zeroed);
+// NEED_DX: also dx[n] = W^T dy[n] (fp32 rows)
+template <class S, bool NEED_DX>
 __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, const float* __restrict__ packed,
                                                                 const xbf8* __restrict__ wfrag,
                                                                 const float* __restrict__ x,
-                                                                const float* __restrict__ dy, float* __restrict__ dW10,
+                                                                const float* __restrict__ dy, float* __restrict__ dx,
+                                                                float* __restrict__ dW10,
                                                                 float* __restrict__ d_packed,
                                                                 float* __restrict__ d_bias) {
   static_assert(f10w_ok<S>(), "shape not supported by the fused-core weight-gradient kernel");
@@ -73,7 +81,8 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
   float* dgT = ximg + H;                                      // dy transposed: [i2][m]
   float* c2i = dgT + F::I2 * W::DGS;                          // C2 = S2(x): [i2][k]
   float* dci = c2i + F::I2 * W::C2S;                          // dC2 = W10 dy: [row2][(i2,r2)]
-  __bf16* img1 = reinterpret_cast<__bf16*>(dci + F::ROWS2 * W::DCS);   // split dy, T01 operand: 3 planes [i2][k1]
+  float* dxs = dci + F::ROWS2 * W::DCS;                       // NEED_DX: four partial-sum slices of dx [4][H]
+  __bf16* img1 = reinterpret_cast<__bf16*>(dxs + 4 * H);      // split dy, T01 operand: 3 planes [i2][k1]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,12 +99,22 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       for (int p = 0; p < 3; ++p)
         w01[xx][u][p] = wfrag[(size_t)(((wave + FAST_NW * xx) * W::NM1 + u) * 3 + p) * 64 + lane];
 
-  // accumulators: dW10 tiles (k-tile wave + 8*xx, m-tile mt) and the dW2 tile of column tile `wave`
-  f32x4 g10[W::XF][W::MT], g2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // accumulators: dW10 tiles (k-tile wave + 8*xx, m-tile mt) and the dW2 tiles of the column tiles wave + 8*xc
+  f32x4 g10[W::XF][W::MT], g2[W::XC];
 #pragma unroll
   for (int xx = 0; xx < W::XF; ++xx)
 #pragma unroll
     for (int mt = 0; mt < W::MT; ++mt) g10[xx][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int xc = 0; xc < W::XC; ++xc) g2[xc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // NEED_DX: G2 fragments of this wave's quarter of the (i2,r2) contraction: row j2 = c, one value per k-step
+  float wdx[NEED_DX ? W::KQ : 1];
+  const int dct = wave & 1, dkq = wave >> 1;                 // dx: column tile (row2 half), contraction quarter
+  if constexpr (NEED_DX) {
+    const float* W2 = packed + woff_of<S>(2);                 // [J2][M2 = (i2,r2)]
+#pragma unroll
+    for (int s = 0; s < W::KQ; ++s) wdx[s] = c < F::J2 ? W2[c * F::M2 + 4 * (dkq * W::KQ + s) + q] : 0.f;
+  }
   float dbias[4] = {0.f, 0.f, 0.f, 0.f};
 
   // loads: thread tid < H owns hidden unit tid (4 gate gradients); threads tid < H/4 also carry 4 values of x
@@ -132,10 +151,12 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       f32x4 acc[T2::XM][T2::YR];
       stage_mma<S, 2>(w2, ximg, acc, wave, lane);
 #pragma unroll
-      for (int y = 0; y < T2::YR; ++y) {
-        const int row2 = 16 * y + c, m0 = 16 * wave + 4 * q;                 // feature m0 = (i2, r2 .. r2+3)
-        *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[0][y];
-      }
+      for (int xm = 0; xm < T2::XM; ++xm)
+#pragma unroll
+        for (int y = 0; y < T2::YR; ++y) {
+          const int row2 = 16 * y + c, m0 = 16 * (wave + FAST_NW * xm) + 4 * q;   // feature m0 = (i2, r2 .. r2+3)
+          *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[xm][y];
+        }
       xbf8 bf[W::NM1][3];
 #pragma unroll
       for (int u = 0; u < W::NM1; ++u)
@@ -175,10 +196,29 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
 #pragma unroll
     for (int s = 0; s < F::ROWS2 / 4; ++s) {                 // dW2[j2][col] += x[row2][j2] * dC2[row2][col], row2 = 4s + q
       const float a = c < F::J2 ? ximg[(4 * s + q) * F::J2 + c] : 0.f;
-      const float bcol = dci[(4 * s + q) * W::DCS + 16 * wave + c];
-      g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcol, g2, 0, 0, 0);
+#pragma unroll
+      for (int xc = 0; xc < W::XC; ++xc) {
+        const float bcol = dci[(4 * s + q) * W::DCS + 16 * (wave + FAST_NW * xc) + c];
+        g2[xc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcol, g2[xc], 0, 0, 0);
+      }
+    }
+    if constexpr (NEED_DX) {
+      // dx[row2][j2] = sum_(i2,r2) G2[j2; i2,r2] * dC2[row2][(i2,r2)]: this wave's quarter of the contraction for the
+      // 16 chain rows of column tile dct
+      f32x4 ax = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < W::KQ; ++s)
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(wdx[s], dci[(16 * dct + c) * W::DCS + 4 * (dkq * W::KQ + s) + q], ax, 0, 0, 0);
+      // lane (c = row2 in the tile, q), registers j: j2 = 4q + j (q < 2)
+      if (q < 2) *reinterpret_cast<f32x4*>(dxs + dkq * H + (16 * dct + c) * F::J2 + 4 * q) = ax;
     }
     lds_barrier();
+    if constexpr (NEED_DX) {
+      if (tid < H / 4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(dxs) + tid;
+        *reinterpret_cast<f32x4*>(dx + n * H + 4 * tid) = p[0] + p[H / 4] + p[2 * (H / 4)] + p[3 * (H / 4)];
+      }
+    }
   }
   // ---- flush: one atomic per accumulator element and workgroup ---------------------------------------------------------
 #pragma unroll
@@ -191,7 +231,10 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
   if (q < 2) {
     float* dW2 = d_packed + woff_of<S>(2);                    // [J2][M2 = (i2, r2)]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * wave + c, g2[j]);
+    for (int xc = 0; xc < W::XC; ++xc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * (wave + FAST_NW * xc) + c, g2[xc][j]);
   }
   if (d_bias && own) {
 #pragma unroll
@@ -233,7 +276,7 @@ __global__ void __launch_bounds__(256) k_f10w_finish(const float* __restrict__ p
 // ---- dispatch ------------------------------------------------------------------------------------------
 template <class S>
 static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed, const void* x, const void* dy,
-                            float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+                            void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
   using F = F10<S>;
   if (!ws) return TTRNN_ERR_WORKSPACE;
   float* dW10 = reinterpret_cast<float*>(ws);
@@ -243,12 +286,22 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
   int st = launch_f10b_prep(ts, packed, wfrag, stream);
   if (st != TTRNN_OK) return st;
   constexpr size_t lds = f10w_lds_bytes<S>();
-  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  static_assert(lds <= 160 * 1024, "LDS image set too large");
+  auto kern = dx ? k_ttlinear_wgrad_f10<S, true> : k_ttlinear_wgrad_f10<S, false>;
+  if (lds > 64 * 1024) {
+    static bool raised[2] = {false, false};
+    if (!raised[dx ? 1 : 0]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised[dx ? 1 : 0] = true;
+    }
+  }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const long grid = n_rows < (long)cus ? n_rows : (long)cus;
-  hipLaunchKernelGGL((k_ttlinear_wgrad_f10<S>), dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows, packed,
-                     (const xbf8*)wfrag, (const float*)x, (const float*)dy, dW10, d_packed, d_bias);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows, packed, (const xbf8*)wfrag,
+                     (const float*)x, (const float*)dy, (float*)dx, dW10, d_packed, d_bias);
   constexpr int NE = F::J0 * F::R1 * F::I0 + F::J1 * F::R2 * F::I1 * F::R1;
   hipLaunchKernelGGL((k_f10w_finish<S>), dim3((NE + 255) / 256), dim3(256), 0, stream, packed, dW10, d_packed);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
@@ -257,20 +310,25 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
   const char* e = getenv("TTRNN_NO_F10");
   if ((e && e[0] == '1') || dtype != TTRNN_F32 || dy_dtype != TTRNN_F32) return false;
-  return shape_matches<ShpH256R8L>(s);
+  return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s);
 }
 
 size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
   if (shape_matches<ShpH256R8L>(s))
     return (size_t)F10<ShpH256R8L>::K * F10<ShpH256R8L>::M * sizeof(float) + f10b_fragment_bytes(s);
+  if (shape_matches<ShpH256R16L>(s))
+    return (size_t)F10<ShpH256R16L>::K * F10<ShpH256R16L>::M * sizeof(float) + f10b_fragment_bytes(s);
   return 0;
 }
 
+// dx may be NULL (hidden-to-hidden matrices: dh travels inside the reverse-time kernel)
 int launch_ttlinear_wgrad_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* x, const void* dy,
-                              float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+                              void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
   if (n_rows <= 0) return TTRNN_OK;
   if (shape_matches<ShpH256R8L>(s))
-    return launch_wgrad_f10<ShpH256R8L>(s, (long)n_rows, packed, x, dy, d_packed, d_bias, ws, stream);
+    return launch_wgrad_f10<ShpH256R8L>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  if (shape_matches<ShpH256R16L>(s))
+    return launch_wgrad_f10<ShpH256R16L>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 
