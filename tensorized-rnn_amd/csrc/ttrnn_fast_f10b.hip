@@ -43,6 +43,7 @@ struct F10B {
   static constexpr int K2 = F::I2 * F::R2;        // T2 contraction: (i2,r2)                       (128)
   static constexpr int NM2 = K2 / 32;             // k-blocks of T2 = partial-sum slices           (4)
   static constexpr int CT2 = F::ROWS2 / 16;       // T2 column tiles (columns = row2)              (2)
+  static constexpr int XT2 = NM2 * CT2 / FAST_NW; // T2 (column tile, k-block) pairs per wave     (1; r = 16: 2)
   static constexpr int PL1 = F::I2 * K1;          // bf16 elements per plane of the T01 operand [I2][K1]
   static constexpr int PL2 = F::ROWS2 * K2;       // bf16 elements per plane of the T2 operand [ROWS2][K2]
   // k order of the T01 operand: thread hid holds gates g = 0..3 of m = MPG*g + hid/I2 -> 4 consecutive k
@@ -59,7 +60,7 @@ constexpr bool f10b_ok() {
   using F = F10<S>;
   using B = F10B<S>;
   return f10_ok<S>() && F::I2 == 16 && B::K1 % 32 == 0 && B::FT % FAST_NW == 0 && B::K2 % 32 == 0 &&
-         B::NM2 * B::CT2 == FAST_NW && F::J2 == 8 && F::H == 256;
+         (B::NM2 * B::CT2) % FAST_NW == 0 && B::CT2 == 2 && F::J2 == 8 && F::H == 256;
 }
 
 template <class S>
@@ -145,8 +146,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
 
-  // resident fragments: T01 for the feature tiles {wave + 8x}, T2 for k-block wave >> 1 (column tile wave & 1)
-  xbf8 w01[B::XF][B::NM1][3], w2t[3];
+  // resident fragments: T01 for the feature tiles {wave + 8x}; T2 for the pairs id = wave + 8x: column tile id & 1,
+  // k-block id >> 1
+  xbf8 w01[B::XF][B::NM1][3], w2t[B::XT2][3];
 #pragma unroll
   for (int x = 0; x < B::XF; ++x)
 #pragma unroll
@@ -154,9 +156,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 3 + p) * 64 + lane];
-  const int ct = wave & 1, ub = wave >> 1;
+  const int ct = wave & 1;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) w2t[p] = wfrag[(size_t)(B::FT * B::NM1 * 3 + ub * 3 + p) * 64 + lane];
+  for (int x = 0; x < B::XT2; ++x)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 3 + ((wave + FAST_NW * x) >> 1) * 3 + p) * 64 + lane];
 
   // gate phase: thread tid < H owns hidden unit tid; record(t) = (i,g,f,o),(c,-,-,-) prefetched one step ahead
   const bool own = tid < H;
@@ -241,8 +246,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       }
     }
     lds_barrier();
-    // ---- T2: dh_{t-1}[row2][j2], wave = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
-    {
+    // ---- T2: dh_{t-1}[row2][j2], pair = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
+#pragma unroll
+    for (int x = 0; x < B::XT2; ++x) {
+      const int ub = (wave + FAST_NW * x) >> 1;
       const int row = 16 * ct + c;
       xbf8 bf[3];
 #pragma unroll
@@ -251,8 +258,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
 #pragma unroll
       for (int s = 0; s < 5; ++s)
-        acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
-      acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[0], bf[0], acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[x][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
+      acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[x][0], bf[0], acc_hi, 0, 0, 0);
       const f32x4 acc = acc_hi + acc_lo;
       // lane (c = row2 in the column tile, q), registers j: j2 = 4q + j (valid for q < 2): hidden = row2*J2 + j2
       if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc;
@@ -280,7 +287,16 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
   xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
   hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed_hid, wfrag);
   constexpr size_t lds = f10b_lds_bytes<S>();
-  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  static_assert(lds <= 160 * 1024, "LDS image set too large");
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL((k_lstm_bwd_f10<S>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, wfrag,
                      reserve, (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
                      (float*)d_c0);
@@ -311,12 +327,13 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   const char* e = getenv("TTRNN_NO_F10");
   if ((e && e[0] == '1') || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
-  return shape_matches<ShpH256R8L>(rs.hid_s);
+  return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
 size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
+  if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8);
   return 0;
 }
 
@@ -326,6 +343,9 @@ int launch_rnn_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_h
   if (shape_matches<ShpH256R8L>(rs.hid_s))
     return launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
                                       stream);
+  if (shape_matches<ShpH256R16L>(rs.hid_s))
+    return launch_bwd_f10<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
+                                       stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 
