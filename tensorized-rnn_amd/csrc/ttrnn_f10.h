@@ -27,7 +27,7 @@ struct F10 {
   // conflict on every store of phase A.  With two chain rows per 16-byte slot and the slots of one r2-quad contiguous —
   //     slot = (r2 >> 2) * ROWS2/2 + (row2 >> 1),   kk = 8*slot + (row2 & 1) * 4 + (r2 & 3)
   // — those 16 lanes fill 8 consecutive slots (128 contiguous bytes; the XOR swizzle of x_off keeps an aligned block
-  // of 8 slots together).  The fused core is built in the same order (f10_load_w).
+  // of 8 slots together).  The fused core's fragments are built in the same order (k_f10_prep).
   static constexpr int HR = ROWS2 / 2;            // slots per r2-quad
   __device__ static constexpr int kperm(int row2, int r2) {
     return ((r2 >> 2) * HR + (row2 >> 1)) * 8 + (row2 & 1) * 4 + (r2 & 3);

@@ -1,4 +1,8 @@
-// ttrnn_fast_f10.hip — TT-LSTM recurrent kernel with cores 1 and 0 contracted ahead of the time loop (gfx950).
+// ttrnn_fast_f10.hip — forward kernels with cores 1 and 0 contracted ahead of the time loop (gfx950):
+//   k_lstm_fwd_f10      fp32 TT-LSTM recurrent kernel (described below; KS = 2: k-split variant for r = 16)
+//   k_ttlinear_fwd_f10  the batched input projection of stacked layers on the same two stages
+//   k_gru_fwd_f10       bf16-storage TT-GRU recurrent kernel on the same fused core
+//   k_f10_prep / k_f10g_prep  build the fused core's MFMA fragments once per launch
 //
 // For a d = 3 TT-matrix the per-timestep chain of t3nsor/ops.py:78-93 is three GEMM stages
 //     S2: [J0*J1][J2]       x core2 -> [I2][J0*J1][R2]
@@ -670,12 +674,9 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
       return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream);
     return TTRNN_ERR_UNSUPPORTED;
   }
-  if (shape_matches<ShpH256R8L>(rs.hid_s)) {
-    const char* e = getenv("TTRNN_F10_KSPLIT");        // A/B switch
-    if (e && e[0] == '1')
-      return launch_f10<ShpH256R8L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+  // r = 8: one wave per tile row (measured 7 % faster than the k-split layout); r = 16: k-split (register budget)
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
     return launch_f10<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
-  }
   if (shape_matches<ShpH256R16L>(rs.hid_s))
     return launch_f10<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
   return TTRNN_ERR_UNSUPPORTED;
