@@ -271,8 +271,11 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
 
   // per-thread state for its hidden units: dc (LSTM), the direct dh path (GRU), and the saved record of the
   // step being processed (prefetched one step ahead)
-  float dcs[HPT], dhd[HPT], dout_n[HPT];
-  f32x4 ra[HPT], rb[HPT];          // record(t): LSTM (i,g,f,o),(c,-,-,-)   GRU (r,z,n,hn),-
+  // record(t): LSTM (i,g,f,o),(c,-,-,-)   GRU (r,z,n,hn),-.  Step t also needs c_{t-1} = record(t-1).c (LSTM) / h_{t-1}
+  // (GRU): both are fetched early enough to have landed — record two steps ahead (qa2/qb2 = record(t-1)), h_{t-1} one
+  // step ahead — instead of being consumed in the phase that issues their load (one exposed HBM round trip per step).
+  float dcs[HPT], dhd[HPT], dout_n[HPT], hprev_n[HPT];
+  f32x4 ra[HPT], rb[HPT], qa2[HPT], qb2[HPT];
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
@@ -286,13 +289,22 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
     }
     ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    qa2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    qb2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     dout_n[u] = 0.f;
+    hprev_n[u] = 0.f;
     if (ok && T > 0) {
       const size_t bt = b * T + (T - 1);
       const float* rv = reserve + (bt * H + hid) * RU;
       ra[u] = *reinterpret_cast<const f32x4*>(rv);
       if constexpr (CELL == TTRNN_LSTM) rb[u] = *reinterpret_cast<const f32x4*>(rv + 4);
       dout_n[u] = d_out ? ld(d_out, bt * H + hid) : 0.f;
+      if (T > 1) {
+        qa2[u] = *reinterpret_cast<const f32x4*>(rv - H * RU);
+        if constexpr (CELL == TTRNN_LSTM) qb2[u] = *reinterpret_cast<const f32x4*>(rv - H * RU + 4);
+      }
+      if constexpr (CELL == TTRNN_GRU)
+        hprev_n[u] = T > 1 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see k_lstm_fwd_fused
@@ -309,14 +321,19 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
         float dht = dhd[u] + dout_n[u];
 #pragma unroll
         for (int sl = 0; sl < CS; ++sl) dht += dhbuf[sl * H + hid];
-        // prefetch record(t-1) / c_{t-1} / h_{t-1} / d_out(t-1) for the next iteration
-        f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = f32x4{0.f, 0.f, 0.f, 0.f};
-        float dn = 0.f;
-        if (t > 0) {
-          const float* rv = reserve + ((bt - 1) * H + hid) * RU;
-          na = *reinterpret_cast<const f32x4*>(rv);
-          if constexpr (CELL == TTRNN_LSTM) nb = *reinterpret_cast<const f32x4*>(rv + 4);
-          dn = d_out ? ld(d_out, (bt - 1) * H + hid) : 0.f;
+        // record(t-1) landed an iteration ago; fetch record(t-2), d_out(t-1) and (GRU) h_{t-2} for later iterations
+        const f32x4 na = qa2[u], nb = qb2[u];
+        f32x4 fa = f32x4{0.f, 0.f, 0.f, 0.f}, fb = f32x4{0.f, 0.f, 0.f, 0.f};
+        float dn = 0.f, hn2 = 0.f;
+        if (t > 1) {
+          const float* rv = reserve + ((bt - 2) * H + hid) * RU;
+          fa = *reinterpret_cast<const f32x4*>(rv);
+          if constexpr (CELL == TTRNN_LSTM) fb = *reinterpret_cast<const f32x4*>(rv + 4);
+        }
+        if (t > 0) dn = d_out ? ld(d_out, (bt - 1) * H + hid) : 0.f;
+        if constexpr (CELL == TTRNN_GRU) {
+          if (t > 1) hn2 = ld(out, (bt - 2) * H + hid);
+          else if (t == 1) hn2 = h0 ? ld(h0, b * H + hid) : 0.f;
         }
         if constexpr (CELL == TTRNN_LSTM) {
           const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = qb[0];
@@ -331,7 +348,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           bufA[hid] = p0; bufA[H + hid] = p1; bufA[2 * H + hid] = p2; bufA[3 * H + hid] = p3;
         } else {
           const float rg = qa[0], zg = qa[1], ng = qa[2], hn = qa[3];
-          const float hprev = t > 0 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
+          const float hprev = hprev_n[u];
           const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
           const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
           const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
@@ -339,7 +356,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           bufA[hid] = dr_pre; bufA[H + hid] = dz_pre; bufA[2 * H + hid] = dn_pre * rg;
           dg_in[bt * GH + 2 * H + hid] = dn_pre;      // the only block where d_gates_in != d_gates_hid
         }
-        ra[u] = na; rb[u] = nb; dout_n[u] = dn;
+        ra[u] = na; rb[u] = nb; qa2[u] = fa; qb2[u] = fb; dout_n[u] = dn; hprev_n[u] = hn2;
       }
     }
     lds_barrier();

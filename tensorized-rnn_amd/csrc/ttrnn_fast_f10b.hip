@@ -121,7 +121,7 @@ constexpr size_t f10b_lds_bytes() {
          + 2 * 3 * (size_t)(B::PL1 + B::PL2);         // the two split operands
 }
 
-template <class S>
+template <class S, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const float* __restrict__ c0,
                                                           const xbf8* __restrict__ wfrag,
                                                           const float* __restrict__ reserve,
@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
                                                           const float* __restrict__ d_hT,
                                                           const float* __restrict__ d_cT, float* __restrict__ dg_in,
                                                           float* __restrict__ dg_hid, float* __restrict__ d_h0,
-                                                          float* __restrict__ d_c0) {
+                                                          float* __restrict__ d_c0,
+                                                          unsigned long long* __restrict__ diag) {
   static_assert(f10b_ok<S>(), "shape not supported by the fused-core reverse-time kernel");
   using F = F10<S>;
   using B = F10B<S>;
@@ -163,45 +164,66 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
     for (int p = 0; p < 3; ++p)
       w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 3 + ((wave + FAST_NW * x) >> 1) * 3 + p) * 64 + lane];
 
-  // gate phase: thread tid < H owns hidden unit tid; record(t) = (i,g,f,o),(c,-,-,-) prefetched one step ahead
+  // gate phase: thread tid < H owns hidden unit tid.  record(t) = (i,g,f,o),(c,-,-,-); step t also needs c_{t-1} =
+  // record(t-1).c.  Three register sets rotate their ROLES (current / next / in flight) from step to step — the time
+  // loop is unrolled by three so that no register copy is needed: iteration t issues the loads of record(t-2) and
+  // d_out(t-2) into the set that held record(t+1) and nobody touches them before iteration t-1.  (Consuming a value, or
+  // merely copying it to another register, in the phase that issued its load put one HBM round trip per timestep on
+  // the critical path: 1 800 of 4 000 cycles.  So did a conditional load of c0 inside the loop.)
   const bool own = tid < H;
   const int hid = own ? tid : 0;
   float dcs = (own && d_cT) ? d_cT[b * H + hid] : 0.f;
-  f32x4 ra = f32x4{0.f, 0.f, 0.f, 0.f}, rb = ra;
-  float dout_n = 0.f;
+  const float c0v = (own && c0) ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;      // (i,g,f,o) of the three sets
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;                               // c of the three sets (a dwordx4 load with dead
+                                                                       // lanes gets its registers reused -> WAW wait)
+  float do0 = 0.f, do1 = 0.f, do2 = 0.f;
   if (own) {
     dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
 #pragma unroll
     for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
-    if (T > 0) {
+    if (T > 0) {                         // set 0 = record(T-1), set 1 = record(T-2)
       const size_t bt = b * T + (T - 1);
       const float* rv = reserve + (bt * H + hid) * 8;
-      ra = *reinterpret_cast<const f32x4*>(rv);
-      rb = *reinterpret_cast<const f32x4*>(rv + 4);
-      dout_n = d_out ? d_out[bt * H + hid] : 0.f;
+      ra0 = *reinterpret_cast<const f32x4*>(rv);
+      rb0 = rv[4];
+      do0 = dptr[bt * H + hid];
+      if (T > 1) {
+        ra1 = *reinterpret_cast<const f32x4*>(rv - H * 8);
+        rb1 = rv[4 - H * 8];
+        do1 = dptr[(bt - 1) * H + hid];
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
   lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
 
-  for (int t = T - 1; t >= 0; --t) {
+  // one timestep; (ra, rb, dout_c) = record / d_out of step t, nb = record(t-1) (its c), (fa, fb, dout_f): in-flight set
+  auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dout_c, const float& nb, f32x4& fa,
+                  float& fb, float& dout_f) {
     const size_t bt = b * T + t;
     // ---- G: gate gradients (lstm.py:26-32 differentiated) ---------------------------------------------------------
     if (own) {
-      const f32x4 qa = ra, qb = rb;
-      float dht = dout_n;
+      {                                  // record(t-2), d_out(t-2): not touched before the next iteration.  Always
+        // three loads, no branch (index clamped, a null d_out reads the reserve and is scaled by zero): a conditional
+        // VMEM operation makes the compiler's vmcnt bookkeeping fall back to vmcnt(0)
+        const size_t b2 = t > 1 ? bt - 2 : b * T;
+        const float* rv = reserve + (b2 * H + hid) * 8;
+        fa = *reinterpret_cast<const f32x4*>(rv);
+        fb = rv[4];
+        dout_f = dptr[b2 * H + hid];                 // scaled where it is consumed
+      }
+      const f32x4 qa = ra;
+      float dht = dout_c * dscale;
 #pragma unroll
       for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
-      f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
-      float dn = 0.f;
-      if (t > 0) {                       // record(t-1) / d_out(t-1) for the next iteration
-        const float* rv = reserve + ((bt - 1) * H + hid) * 8;
-        na = *reinterpret_cast<const f32x4*>(rv);
-        nb = *reinterpret_cast<const f32x4*>(rv + 4);
-        dn = d_out ? d_out[(bt - 1) * H + hid] : 0.f;
-      }
-      const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = qb[0];
-      const float cprev = t > 0 ? nb[0] : (c0 ? c0[b * H + hid] : 0.f);
+      const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = rb;
+      const float cprev = t > 0 ? nb : c0v;
       const float tc = ftanh(cy);
       const float dct = dcs + dht * og * (1.0f - tc * tc);
       const float p0 = dct * gg * ig * (1.0f - ig);             // d pre-activation of i
@@ -212,9 +234,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       dgf[hid] = p0; dgf[H + hid] = p1; dgf[2 * H + hid] = p2; dgf[3 * H + hid] = p3;
       // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
       store_split4(img1, B::PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), f32x4{p0, p1, p2, p3});
-      ra = na; rb = nb; dout_n = dn;
     }
+    TT_STAMP(0)
     lds_barrier();
+    TT_STAMP(1)
     // ---- T01: dC2 = W10 dg, two feature tiles per wave; meanwhile the fp32 row goes out to HBM -------------------
     {
       if (tid < GH / 4) {
@@ -245,7 +268,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
         store_split4(img2, B::PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc);
       }
     }
+    TT_STAMP(2)
     lds_barrier();
+    TT_STAMP(3)
     // ---- T2: dh_{t-1}[row2][j2], pair = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
 #pragma unroll
     for (int x = 0; x < B::XT2; ++x) {
@@ -264,7 +289,20 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       // lane (c = row2 in the column tile, q), registers j: j2 = 4q + j (valid for q < 2): hidden = row2*J2 + j2
       if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc;
     }
+    TT_STAMP(4)
     lds_barrier();
+    TT_STAMP(5)
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1);
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && diag && b < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) diag[(b * FAST_NW + wave) * 8 + i] = seg[i];
+    }
   }
   if (own) {
     if (d_h0) {
@@ -291,15 +329,23 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return TTRNN_ERR_LAUNCH;
       raised = true;
     }
   }
-  hipLaunchKernelGGL((k_lstm_bwd_f10<S>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, wfrag,
-                     reserve, (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
-                     (float*)d_c0);
+  // TTRNN_DIAG=1: per-phase s_memtime stamps of the first 8 workgroups land in the 4 KB behind the fragments
+  const char* de = getenv("TTRNN_DIAG");
+  const bool dg = de && de[0] == '1';
+  auto kern = dg ? k_lstm_bwd_f10<S, true> : k_lstm_bwd_f10<S, false>;
+  unsigned long long* diag =
+      dg ? reinterpret_cast<unsigned long long*>((char*)ws + f10b_wfrag_elems<S>() * sizeof(xbf8)) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, wfrag, reserve,
+                     (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                     (float*)d_c0, diag);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -330,10 +376,10 @@ bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
-size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
+size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // fragments + 4 KB for diagnostic stamps
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
-  if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
-  if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8);
+  if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8) + 4096;
+  if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8) + 4096;
   return 0;
 }
 
