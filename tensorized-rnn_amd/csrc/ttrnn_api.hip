@@ -144,9 +144,11 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
                                       (hipStream_t)stream);
     }
-    if (fp32_math() == TTRNN_MATH_SPLIT && d_packed && f10_ttlinear_wgrad_available(s, dtype, dy_dtype) &&
+    if ((fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && d_packed &&
+        f10_ttlinear_wgrad_available(s, dtype, dy_dtype) &&
         workspace && workspace_bytes >= f10_ttlinear_wgrad_workspace_bytes(s))
-      return launch_ttlinear_wgrad_f10(s, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream);
+      return launch_ttlinear_wgrad_f10(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
+                                       (hipStream_t)stream);
     return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
                                     (hipStream_t)stream);
   }

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ pack
     const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int m = B::m_of_k1(32 * u + 8 * q + e);
+      // LSTM shapes: gate-interleaved k order (m_of_k1); other cells: natural order (ttrnn_fast_f10w.hip, NATK)
+      const int m = f10_ok<S>() ? B::m_of_k1(32 * u + 8 * q + e) : 32 * u + 8 * q + e;
       const int i0 = m / F::I1, i1 = m % F::I1;
       const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
       float v = 0.f;
@@ -353,6 +354,7 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
 size_t f10b_fragment_bytes(const TtShape& s) {
   if (shape_matches<ShpH256R8L>(s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
   if (shape_matches<ShpH256R16L>(s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8);
+  if (shape_matches<ShpH256R8G>(s)) return f10b_wfrag_elems<ShpH256R8G>() * sizeof(xbf8);
   return 0;
 }
 
@@ -367,6 +369,7 @@ static int launch_prep_b(const float* packed, void* wfrag, hipStream_t stream) {
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream) {
   if (shape_matches<ShpH256R8L>(s)) return launch_prep_b<ShpH256R8L>(packed, wfrag, stream);
   if (shape_matches<ShpH256R16L>(s)) return launch_prep_b<ShpH256R16L>(packed, wfrag, stream);
+  if (shape_matches<ShpH256R8G>(s)) return launch_prep_b<ShpH256R8G>(packed, wfrag, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

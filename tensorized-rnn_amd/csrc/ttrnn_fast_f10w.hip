@@ -28,12 +28,12 @@ namespace ttrnn {
 template <class S>
 struct F10W {
   using F = F10<S>;
-  static constexpr int H = F::H, OUT = 4 * F::H;
+  static constexpr int H = F::H, OUT = out_size_of<S>(), NG = OUT / H;   // gates: 4 (LSTM) or 3 (GRU)
   static constexpr int K1 = F::M, NM1 = K1 / 32;          // T01 contraction (m) and its k-blocks
   static constexpr int FT = F::K / 16, XF = FT / FAST_NW;  // T01 / dW10 feature tiles (k = (row2, r2)), per wave
   static constexpr int MT = F::M / 16;                     // dW10 column tiles (m)
   static constexpr int K2 = F::I2 * F::R2;                 // (i2, r2): columns of dC2 / dW2
-  static constexpr int CT2 = K2 / 16, XC = CT2 / FAST_NW;  // dW2 column tiles, per wave
+  static constexpr int CT2 = K2 / 16, XC = (CT2 + FAST_NW - 1) / FAST_NW;  // dW2 column tiles, per wave
   static constexpr int PL1 = F::I2 * K1;                   // bf16 elements per plane of the T01 operand
   static constexpr int DGS = K1 + 16;                      // row stride of dgT  [I2][m]       (fp32, +16: bank shift)
   static constexpr int C2S = F::K + 16;                    // row stride of C2   [I2][k]
@@ -45,13 +45,19 @@ struct F10W {
   static constexpr int KQ = K2 / 4 / 4;                    // k-steps per quarter
 };
 
+// LSTM shapes (f10_ok: gates aligned with the m index) load a thread's four gate gradients as 4 consecutive k of the
+// T01 operand; any other cell (GRU: I2 = 12) goes element by element with the natural k order (NATK)
+template <class S>
+constexpr bool f10w_natk() { return !f10_ok<S>(); }
+
 template <class S>
 constexpr bool f10w_ok() {
   using F = F10<S>;
   using W = F10W<S>;
-  return f10_ok<S>() && F::I2 == 16 && F::H == 256 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 &&
-         W::CT2 % FAST_NW == 0 && W::MT == 4 && F::J2 == 8 && St<S, 2>::MT % FAST_NW == 0 && St<S, 2>::RT == 2 &&
-         !St<S, 2>::SPLIT && F::ROWS2 == 32 && W::K2 % 16 == 0;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::I2 % 4 == 0 && F::I2 <= 16 &&
+         F::H == 256 && F::K % 32 == 0 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 && W::MT == 4 && F::J2 == 8 &&
+         St<S, 2>::RT == 2 && !St<S, 2>::SPLIT && F::ROWS2 == 32 && W::K2 % 16 == 0 && W::OUT % F::H == 0 &&
+         (f10_ok<S>() || W::OUT <= 2 * FAST_NT) && S::R[2] % 4 == 0;
 }
 
 template <class S>
@@ -63,11 +69,11 @@ constexpr size_t f10w_lds_bytes() {
 
 // wfrag: the T01 fragments of k_f10b_prep (ttrnn_fast_f10b.hip);  dW10: fp32 [K][M] accumulation buffer (zeroed);
 // NEED_DX: also dx[n] = W^T dy[n] (fp32 rows)
-template <class S, bool NEED_DX>
+template <class S, typename TI, bool NEED_DX>
 __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, const float* __restrict__ packed,
                                                                 const xbf8* __restrict__ wfrag,
-                                                                const float* __restrict__ x,
-                                                                const float* __restrict__ dy, float* __restrict__ dx,
+                                                                const TI* __restrict__ x,
+                                                                const float* __restrict__ dy, TI* __restrict__ dx,
                                                                 float* __restrict__ dW10,
                                                                 float* __restrict__ d_packed,
                                                                 float* __restrict__ d_bias) {
@@ -115,21 +121,51 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
 #pragma unroll
     for (int s = 0; s < W::KQ; ++s) wdx[s] = c < F::J2 ? W2[c * F::M2 + 4 * (dkq * W::KQ + s) + q] : 0.f;
   }
+  constexpr bool NATK = f10w_natk<S>();
   float dbias[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // loads: thread tid < H owns hidden unit tid (4 gate gradients); threads tid < H/4 also carry 4 values of x
+  // loads.  LSTM: thread tid < H owns hidden unit tid (its 4 gate gradients, one strided dword each).  NATK: thread
+  // tid owns the flat outputs tid and tid + 512.  Threads tid < H/4 also carry 4 values of x.
   const bool own = tid < H;
   const int hid = own ? tid : 0;
   const long G = gridDim.x;
   long n = blockIdx.x;
   f32x4 dyv = f32x4{0.f, 0.f, 0.f, 0.f}, xv = dyv;
-  if (n < n_rows) {
-    if (own) dyv = f32x4{dy[n * OUT + hid], dy[n * OUT + H + hid], dy[n * OUT + 2 * H + hid], dy[n * OUT + 3 * H + hid]};
-    if (tid < H / 4) xv = *reinterpret_cast<const f32x4*>(x + n * H + 4 * tid);
-  }
+  auto load_row = [&](long r) {
+    if constexpr (NATK) {
+      dyv[0] = tid < OUT ? dy[r * OUT + tid] : 0.f;
+      dyv[1] = tid + FAST_NT < OUT ? dy[r * OUT + tid + FAST_NT] : 0.f;
+    } else {
+      if (own) dyv = f32x4{dy[r * OUT + hid], dy[r * OUT + H + hid], dy[r * OUT + 2 * H + hid], dy[r * OUT + 3 * H + hid]};
+    }
+    if (tid < H / 4) {
+      if constexpr (sizeof(TI) == 4) {
+        xv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * H + 4 * tid);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = ld(x, (size_t)(r * H + 4 * tid + j));
+      }
+    }
+  };
+  if (n < n_rows) load_row(n);
   for (; n < n_rows; n += G) {
     // ---- phase 1: this row into LDS; the next row's loads take off ---------------------------------------------
-    if (own) {
+    if constexpr (NATK) {
+      // flat output o = m*I2 + i2: dgT[i2][m], T01 operand plane[i2][k1 = m], one element at a time
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int o = tid + e * FAST_NT;
+        if (o < OUT) {
+          const int m = o / F::I2, i2 = o % F::I2;
+          dgT[i2 * W::DGS + m] = dyv[e];
+          dbias[e] += dyv[e];
+          __bf16 p0, p1, p2;
+          split3(dyv[e], p0, p1, p2);
+          const int off = x_off<W::K1>(i2, m);
+          img1[off] = p0; img1[W::PL1 + off] = p1; img1[2 * W::PL1 + off] = p2;
+        }
+      }
+    } else if (own) {
       // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid % I2
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -139,11 +175,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       store_split4(img1, W::PL1, x_off<W::K1>(hid % F::I2, 4 * (hid / F::I2)), dyv);     // k1 = 4*(hid/I2) + gate
     }
     if (tid < H / 4) *reinterpret_cast<f32x4*>(ximg + 4 * tid) = xv;
-    if (n + G < n_rows) {
-      const long nn = n + G;
-      if (own) dyv = f32x4{dy[nn * OUT + hid], dy[nn * OUT + H + hid], dy[nn * OUT + 2 * H + hid], dy[nn * OUT + 3 * H + hid]};
-      if (tid < H / 4) xv = *reinterpret_cast<const f32x4*>(x + nn * H + 4 * tid);
-    }
+    if (n + G < n_rows) load_row(n + G);
     lds_barrier();
     // ---- phase 2: C2 = S2(x) (fp32 MFMA) and dC2 = W10 dy (split-bf16 MFMAs), both into fp32 images ----------------
     {
@@ -155,14 +187,16 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
 #pragma unroll
         for (int y = 0; y < T2::YR; ++y) {
           const int row2 = 16 * y + c, m0 = 16 * (wave + FAST_NW * xm) + 4 * q;   // feature m0 = (i2, r2 .. r2+3)
-          *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[xm][y];
+          if (m0 < F::M2)
+            *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[xm][y];
         }
       xbf8 bf[W::NM1][3];
 #pragma unroll
       for (int u = 0; u < W::NM1; ++u)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          bf[u][p] = *reinterpret_cast<const xbf8*>(img1 + p * W::PL1 + x_off<W::K1>(c, 32 * u + 8 * q));
+          bf[u][p] = *reinterpret_cast<const xbf8*>(img1 + p * W::PL1 +
+                                                    x_off<W::K1>(c < F::I2 ? c : F::I2 - 1, 32 * u + 8 * q));
 #pragma unroll
       for (int xx = 0; xx < W::XF; ++xx) {
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
@@ -175,7 +209,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
         }
         // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = 4*(q&1) + j)
         const int f0 = 16 * (wave + FAST_NW * xx) + 4 * q;
-        *reinterpret_cast<f32x4*>(dci + (f0 / F::R2) * W::DCS + c * F::R2 + f0 % F::R2) = acc_hi + acc_lo;
+        if (c < F::I2) *reinterpret_cast<f32x4*>(dci + (f0 / F::R2) * W::DCS + c * F::R2 + f0 % F::R2) = acc_hi + acc_lo;
       }
     }
     lds_barrier();
@@ -198,7 +232,8 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       const float a = c < F::J2 ? ximg[(4 * s + q) * F::J2 + c] : 0.f;
 #pragma unroll
       for (int xc = 0; xc < W::XC; ++xc) {
-        const float bcol = dci[(4 * s + q) * W::DCS + 16 * (wave + FAST_NW * xc) + c];
+        const int ctile = wave + FAST_NW * xc;                  // wave-uniform; tiles beyond CT2 do not exist
+        const float bcol = dci[(4 * s + q) * W::DCS + 16 * (ctile < W::CT2 ? ctile : 0) + c];
         g2[xc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcol, g2[xc], 0, 0, 0);
       }
     }
@@ -216,7 +251,9 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
     if constexpr (NEED_DX) {
       if (tid < H / 4) {
         const f32x4* p = reinterpret_cast<const f32x4*>(dxs) + tid;
-        *reinterpret_cast<f32x4*>(dx + n * H + 4 * tid) = p[0] + p[H / 4] + p[2 * (H / 4)] + p[3 * (H / 4)];
+        const f32x4 v = p[0] + p[H / 4] + p[2 * (H / 4)] + p[3 * (H / 4)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st(dx, (size_t)(n * H + 4 * tid + j), v[j]);
       }
     }
   }
@@ -232,13 +269,21 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
     float* dW2 = d_packed + woff_of<S>(2);                    // [J2][M2 = (i2, r2)]
 #pragma unroll
     for (int xc = 0; xc < W::XC; ++xc)
+      if (wave + FAST_NW * xc < W::CT2) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * (wave + FAST_NW * xc) + c, g2[xc][j]);
+        for (int j = 0; j < 4; ++j)
+          atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * (wave + FAST_NW * xc) + c, g2[xc][j]);
+      }
   }
-  if (d_bias && own) {
+  if (d_bias) {
+    if constexpr (NATK) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) atomicAdd(d_bias + g * H + hid, dbias[g]);
+      for (int e = 0; e < 2; ++e)
+        if (tid + e * FAST_NT < OUT) atomicAdd(d_bias + tid + e * FAST_NT, dbias[e]);
+    } else if (own) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) atomicAdd(d_bias + g * H + hid, dbias[g]);
+    }
   }
 }
 
@@ -274,7 +319,7 @@ __global__ void __launch_bounds__(256) k_f10w_finish(const float* __restrict__ p
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
-template <class S>
+template <class S, typename TI>
 static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed, const void* x, const void* dy,
                             void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
   using F = F10<S>;
@@ -287,7 +332,7 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
   if (st != TTRNN_OK) return st;
   constexpr size_t lds = f10w_lds_bytes<S>();
   static_assert(lds <= 160 * 1024, "LDS image set too large");
-  auto kern = dx ? k_ttlinear_wgrad_f10<S, true> : k_ttlinear_wgrad_f10<S, false>;
+  auto kern = dx ? k_ttlinear_wgrad_f10<S, TI, true> : k_ttlinear_wgrad_f10<S, TI, false>;
   if (lds > 64 * 1024) {
     static bool raised[2] = {false, false};
     if (!raised[dx ? 1 : 0]) {
@@ -301,7 +346,7 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const long grid = n_rows < (long)cus ? n_rows : (long)cus;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows, packed, (const xbf8*)wfrag,
-                     (const float*)x, (const float*)dy, (float*)dx, dW10, d_packed, d_bias);
+                     (const TI*)x, (const float*)dy, (TI*)dx, dW10, d_packed, d_bias);
   constexpr int NE = F::J0 * F::R1 * F::I0 + F::J1 * F::R2 * F::I1 * F::R1;
   hipLaunchKernelGGL((k_f10w_finish<S>), dim3((NE + 255) / 256), dim3(256), 0, stream, packed, dW10, d_packed);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
@@ -309,8 +354,9 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
 
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
   const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || dtype != TTRNN_F32 || dy_dtype != TTRNN_F32) return false;
-  return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s);
+  if ((e && e[0] == '1') || dy_dtype != TTRNN_F32) return false;
+  if (dtype == TTRNN_F32) return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpH256R8G>(s);
+  return dtype == TTRNN_BF16 && shape_matches<ShpH256R8G>(s);
 }
 
 size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
@@ -318,17 +364,26 @@ size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
     return (size_t)F10<ShpH256R8L>::K * F10<ShpH256R8L>::M * sizeof(float) + f10b_fragment_bytes(s);
   if (shape_matches<ShpH256R16L>(s))
     return (size_t)F10<ShpH256R16L>::K * F10<ShpH256R16L>::M * sizeof(float) + f10b_fragment_bytes(s);
+  if (shape_matches<ShpH256R8G>(s))
+    return (size_t)F10<ShpH256R8G>::K * F10<ShpH256R8G>::M * sizeof(float) + f10b_fragment_bytes(s);
   return 0;
 }
 
 // dx may be NULL (hidden-to-hidden matrices: dh travels inside the reverse-time kernel)
-int launch_ttlinear_wgrad_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* x, const void* dy,
-                              void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+// dtype: storage type of x / dx (fp32; bf16 for the GRU shape); dy is fp32
+int launch_ttlinear_wgrad_f10(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
+                              const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
   if (n_rows <= 0) return TTRNN_OK;
-  if (shape_matches<ShpH256R8L>(s))
-    return launch_wgrad_f10<ShpH256R8L>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
-  if (shape_matches<ShpH256R16L>(s))
-    return launch_wgrad_f10<ShpH256R16L>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  if (dtype == TTRNN_F32) {
+    if (shape_matches<ShpH256R8L>(s))
+      return launch_wgrad_f10<ShpH256R8L, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+    if (shape_matches<ShpH256R16L>(s))
+      return launch_wgrad_f10<ShpH256R16L, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+    if (shape_matches<ShpH256R8G>(s))
+      return launch_wgrad_f10<ShpH256R8G, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  } else if (dtype == TTRNN_BF16 && shape_matches<ShpH256R8G>(s)) {
+    return launch_wgrad_f10<ShpH256R8G, bf16_t>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  }
   return TTRNN_ERR_UNSUPPORTED;
 }
 

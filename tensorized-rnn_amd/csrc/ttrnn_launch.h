@@ -119,8 +119,8 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 // batched weight (+ bias) gradients of a hidden-shaped TT-matrix through the fused core, dx optional (ttrnn_fast_f10w.hip)
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype);
 size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s);
-int launch_ttlinear_wgrad_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* x, const void* dy,
-                              void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
+int launch_ttlinear_wgrad_f10(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
+                              const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
 
 // shape-specialised batched TTLinear backward (ttrnn_fast_bwd.hip); accumulates into d_packed / d_bias
 bool fast_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
