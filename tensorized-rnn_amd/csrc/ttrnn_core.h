@@ -42,6 +42,8 @@ TT_HD bf16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN stays NaN
   r.v = (uint16_t)(c.u >> 16);
   return r;
 }
+TT_HD float to_f32(float v) { return v; }
+TT_HD float to_f32(bf16_t v) { return bf16_to_f32(v); }
 TT_HD float ld(const float* p, size_t i) { return p[i]; }
 TT_HD float ld(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
 TT_HD void st(float* p, size_t i, float v) { p[i] = v; }

@@ -269,75 +269,77 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
   if constexpr (D > 3) load_wfrag_b<S, 2>(w2, packed_hid, wave, lane);
   load_wfrag_b_last<S>(wl, packed_hid, wave, lane);
 
-  // per-thread state for its hidden units: dc (LSTM), the direct dh path (GRU), and the saved record of the
-  // step being processed (prefetched one step ahead)
-  // record(t): LSTM (i,g,f,o),(c,-,-,-)   GRU (r,z,n,hn),-.  Step t also needs c_{t-1} = record(t-1).c (LSTM) / h_{t-1}
-  // (GRU): both are fetched early enough to have landed — record two steps ahead (qa2/qb2 = record(t-1)), h_{t-1} one
-  // step ahead — instead of being consumed in the phase that issues their load (one exposed HBM round trip per step).
-  float dcs[HPT], dhd[HPT], dout_n[HPT], hprev_n[HPT];
-  f32x4 ra[HPT], rb[HPT], qa2[HPT], qb2[HPT];
+  // per-thread state for its hidden units: dc (LSTM), the direct dh path (GRU), and three sets of saved-step data whose
+  // ROLES rotate (the time loop is unrolled by three, no register copies): set(t) = record(t) [LSTM (i,g,f,o) + c,
+  // GRU (r,z,n,hn)], d_out(t) and (GRU) h_{t-1}.  Iteration t consumes set(t) and the c of set(t-1), and ISSUES the loads
+  // of set(t-2) into the registers that held set(t+1); nobody touches them before iteration t-1.  All loads are
+  // unconditional (clamped indices, null pointers redirected and scaled away at the point of use) and exactly as wide
+  // as what is used; raw storage bits are converted where they are consumed — see ttrnn_fast_f10b.hip for why.
+  struct RecSet {
+    f32x4 a[HPT];
+    float c[HPT];
+    TS dout[HPT], hprev[HPT];
+  };
+  RecSet s0, s1, s2;
+  float dcs[HPT], dhd[HPT], c0v[HPT];
+  const TS* dptr = d_out ? d_out : out;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  auto issue = [&](RecSet& f, int t) {      // loads of set(t); t may be negative (clamped, never consumed)
+    const size_t bt = b * T + (t > 0 ? t : 0);
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+      const int hid = tid + u * FAST_NT;
+      if (hid < H) {
+        const float* rv = reserve + (bt * H + hid) * RU;
+        f.a[u] = *reinterpret_cast<const f32x4*>(rv);
+        if constexpr (CELL == TTRNN_LSTM) f.c[u] = rv[4];
+        f.dout[u] = dptr[bt * H + hid];
+        if constexpr (CELL == TTRNN_GRU) {
+          const TS* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);
+          f.hprev[u] = hp[hid];
+        }
+      }
+    }
+  };
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
     const int hid = tid + u * FAST_NT;
     const bool ok = hid < H;
     dcs[u] = (ok && CELL == TTRNN_LSTM && d_cT) ? ld(d_cT, b * H + hid) : 0.f;
+    c0v[u] = (ok && CELL == TTRNN_LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
     dhd[u] = 0.f;
     if (ok) {
       dhbuf[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
 #pragma unroll
       for (int sl = 1; sl < CS; ++sl) dhbuf[sl * H + hid] = 0.f;
     }
-    ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    qa2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    qb2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dout_n[u] = 0.f;
-    hprev_n[u] = 0.f;
-    if (ok && T > 0) {
-      const size_t bt = b * T + (T - 1);
-      const float* rv = reserve + (bt * H + hid) * RU;
-      ra[u] = *reinterpret_cast<const f32x4*>(rv);
-      if constexpr (CELL == TTRNN_LSTM) rb[u] = *reinterpret_cast<const f32x4*>(rv + 4);
-      dout_n[u] = d_out ? ld(d_out, bt * H + hid) : 0.f;
-      if (T > 1) {
-        qa2[u] = *reinterpret_cast<const f32x4*>(rv - H * RU);
-        if constexpr (CELL == TTRNN_LSTM) qb2[u] = *reinterpret_cast<const f32x4*>(rv - H * RU + 4);
-      }
-      if constexpr (CELL == TTRNN_GRU)
-        hprev_n[u] = T > 1 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
-    }
+    s0.a[u] = s1.a[u] = s2.a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s0.c[u] = s1.c[u] = s2.c[u] = 0.f;
+    s0.dout[u] = s1.dout[u] = s2.dout[u] = TS{};
+    s0.hprev[u] = s1.hprev[u] = s2.hprev[u] = TS{};
+  }
+  if (T > 0) {
+    issue(s0, T - 1);
+    issue(s1, T - 2);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see k_lstm_fwd_fused
   lds_barrier();
 
-  for (int t = T - 1; t >= 0; --t) {
+  auto step = [&](const int t, const RecSet& cur, const RecSet& nxt, RecSet& fut) {
     const size_t bt = b * T + t;
     // ---- gate phase ------------------------------------------------------------------------------------
+    issue(fut, t - 2);
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
       const int hid = tid + u * FAST_NT;
       if (hid < H) {
-        const f32x4 qa = ra[u], qb = rb[u];
-        float dht = dhd[u] + dout_n[u];
+        const f32x4 qa = cur.a[u];
+        float dht = dhd[u] + to_f32(cur.dout[u]) * dscale;
 #pragma unroll
         for (int sl = 0; sl < CS; ++sl) dht += dhbuf[sl * H + hid];
-        // record(t-1) landed an iteration ago; fetch record(t-2), d_out(t-1) and (GRU) h_{t-2} for later iterations
-        const f32x4 na = qa2[u], nb = qb2[u];
-        f32x4 fa = f32x4{0.f, 0.f, 0.f, 0.f}, fb = f32x4{0.f, 0.f, 0.f, 0.f};
-        float dn = 0.f, hn2 = 0.f;
-        if (t > 1) {
-          const float* rv = reserve + ((bt - 2) * H + hid) * RU;
-          fa = *reinterpret_cast<const f32x4*>(rv);
-          if constexpr (CELL == TTRNN_LSTM) fb = *reinterpret_cast<const f32x4*>(rv + 4);
-        }
-        if (t > 0) dn = d_out ? ld(d_out, (bt - 1) * H + hid) : 0.f;
-        if constexpr (CELL == TTRNN_GRU) {
-          if (t > 1) hn2 = ld(out, (bt - 2) * H + hid);
-          else if (t == 1) hn2 = h0 ? ld(h0, b * H + hid) : 0.f;
-        }
         if constexpr (CELL == TTRNN_LSTM) {
-          const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = qb[0];
-          const float cprev = t > 0 ? nb[0] : (c0 ? ld(c0, b * H + hid) : 0.f);
+          const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = cur.c[u];
+          const float cprev = t > 0 ? nxt.c[u] : c0v[u];
           const float tc = ftanh(cy);
           const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
           const float p0 = dct * gg * ig * (1.0f - ig);
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           bufA[hid] = p0; bufA[H + hid] = p1; bufA[2 * H + hid] = p2; bufA[3 * H + hid] = p3;
         } else {
           const float rg = qa[0], zg = qa[1], ng = qa[2], hn = qa[3];
-          const float hprev = hprev_n[u];
+          const float hprev = (t > 0 || h0) ? to_f32(cur.hprev[u]) : 0.f;
           const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
           const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
           const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
@@ -356,7 +358,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
           bufA[hid] = dr_pre; bufA[H + hid] = dz_pre; bufA[2 * H + hid] = dn_pre * rg;
           dg_in[bt * GH + 2 * H + hid] = dn_pre;      // the only block where d_gates_in != d_gates_hid
         }
-        ra[u] = na; rb[u] = nb; qa2[u] = fa; qb2[u] = fb; dout_n[u] = dn; hprev_n[u] = hn2;
       }
     }
     lds_barrier();
@@ -399,6 +400,11 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
       run_bstage_last<S>(wl, bufB, dhbuf, wave, lane);
     }
     lds_barrier();
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, s0, s1, s2);
+    if (t >= 1) step(t - 1, s1, s2, s0);
+    if (t >= 2) step(t - 2, s2, s0, s1);
   }
 #pragma unroll
   for (int u = 0; u < HPT; ++u) {
