@@ -145,7 +145,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
                                       (hipStream_t)stream);
     }
     if ((fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && d_packed &&
-        f10_ttlinear_wgrad_available(s, dtype, dy_dtype) &&
+        f10_ttlinear_wgrad_available(s, dtype, dy_dtype) && (!dx || f10_ttlinear_wgrad_has_dx(s)) &&
         workspace && workspace_bytes >= f10_ttlinear_wgrad_workspace_bytes(s))
       return launch_ttlinear_wgrad_f10(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                                        (hipStream_t)stream);

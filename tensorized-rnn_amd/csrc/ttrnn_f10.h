@@ -8,7 +8,8 @@ namespace ttrnn {
 
 template <class S>
 struct F10 {
-  static constexpr int H = in_size_of<S>();
+  static constexpr int H = in_size_of<S>();       // input features (= hidden size for hidden-to-hidden matrices)
+  static constexpr int HID = out_size_of<S>() / 4; // hidden units of the LSTM this matrix feeds (4 gates)
   static constexpr int J0 = S::J[0], J1 = S::J[1], I0 = S::I[0], I1 = S::I[1], I2 = S::I[2];
   static constexpr int R1 = S::R[1], R2 = S::R[2];
   static constexpr int K = J0 * J1 * R2;          // contraction length of the fused stage
@@ -21,7 +22,10 @@ struct F10 {
   static constexpr int ROWS2 = J0 * J1;           // chain rows of S2
   static constexpr int M2 = I2 * R2;              // output features of S2
   static constexpr int MT2 = M2 / 16;             // S2 m-tiles
-  static constexpr int XA = MT2 / 8;              // S2 m-tiles per wave (each over both chain-row tiles)
+  static constexpr int XA = MT2 / 8;              // S2 m-tiles per wave (each over all chain-row tiles)
+  static constexpr int RT2 = (ROWS2 + 15) / 16;   // chain-row tiles of S2
+  static constexpr int XPL = RT2 * 16 * 8;        // bf16 elements per plane of the S2 operand [RT2*16 rows][8]: j2 and
+                                                  // the rows zero-padded (hidden shapes: exactly the H values of h)
   // Order of the contraction index inside an image row.  The natural order (row2, r2) makes the 16 lanes of a
   // ds_write_b64 group (same q, 16 chain rows) hit only the first or only the second half of 16 slots: a 2-way bank
   // conflict on every store of phase A.  With two chain rows per 16-byte slot and the slots of one r2-quad contiguous —
@@ -34,6 +38,17 @@ struct F10 {
   }
 };
 
+// input-to-hidden matrices of an LSTM layer (any in_size whose last mode is <= 8): the batched kernels only
+template <class S>
+constexpr bool f10_in_ok() {
+  using F = F10<S>;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok<S>() && F::K % 32 == 0 && F::M % 16 == 0 &&
+         F::I2 <= 16 && F::MPG % 4 == 0 && F::MPG * F::I2 == F::HID && F::MT == 4 && F::MPG == 4 * F::MT &&
+         out_size_of<S>() == 4 * F::HID && F::HID == 256 && S::R[2] % 4 == 0 && F::J2 <= 8 && F::ROWS2 <= 32 &&
+         F::ROWS2 % 4 == 0 && F::M2 % 128 == 0 && F::NM % 2 == 0 && FAST_NW == 8;
+}
+
+// hidden-to-hidden matrices (recurrent kernels): in = hidden, last mode exactly 8
 template <class S>
 constexpr bool f10_ok() {
   using F = F10<S>;

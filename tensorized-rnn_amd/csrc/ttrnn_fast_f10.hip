@@ -61,7 +61,7 @@ __device__ __forceinline__ void f10_load_w2(xbf8& a1, xbf8& a2, const float* pac
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     __bf16 p0, p1, p2;
-    split3(W2[e * F::M2 + 16 * mt + r], p0, p1, p2);
+    split3(e < F::J2 ? W2[e * F::M2 + 16 * mt + r] : 0.f, p0, p1, p2);
     a1[e] = (q & 1) ? p1 : p0;                            // groups w0 | w1 | w0 | w1
     a2[e] = q == 0 ? p2 : (q == 1 ? p0 : (__bf16)0.f);    // groups w2 | w0 | 0 | 0
   }
@@ -76,14 +76,14 @@ __device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, cons
   const int row = 16 * rt + c;
   const int pl1 = q >> 1;                                 // groups x0 | x0 | x1 | x1
   const int pl2 = q == 1 ? 2 : 0;                         // groups x0 | x2 | (x0 against zero core groups)
-  const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::H + row * 8);
-  const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::H + row * 8);
+  const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::XPL + row * 8);
+  const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::XPL + row * 8);
   f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
   const int m0 = 16 * mt + 4 * q;
   const int i = m0 / F::R2, a0 = m0 % F::R2;
   // C2[i][row][a0..a0+3] (ops.py:89-90: C2 flat == the [I2][K10] operand of the next stage), k order: F10::kperm
-  store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);
+  if (row < F::ROWS2) store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);   // padding rows: no store
 }
 
 // S10 k-blocks [u0, u0 + NU) (w10 holds exactly those): reads run PD blocks ahead of the MFMAs (at most two waves per
@@ -332,15 +332,16 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const
                                                               const float* __restrict__ packed,
                                                               const xbf8* __restrict__ wfrag,
                                                               const float* __restrict__ bias, float* __restrict__ y) {
-  static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
+  static_assert(f10_in_ok<S>(), "shape not supported by the fused-core input projection");
   using F = F10<S>;
-  constexpr int H = F::H;
-  static_assert(F::MT == 4 && F::NM % 2 == 0 && H == 256, "k-split layout");
+  constexpr int IN = F::H, HID = F::HID, XPL = F::XPL;
   constexpr int NU = F::NM / 2;
+  constexpr bool DENSE = F::J2 == 8 && XPL == IN;        // x row == the S2 operand, no padding (hidden-shaped matrices)
+  constexpr int XE = XPL / 64;                            // padded elements per lane of wave 0 (generic path)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* xpl = reinterpret_cast<__bf16*>(smem);                            // bf16 planes of x: [parity][3][H]
-  __bf16* img = xpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
+  __bf16* xpl = reinterpret_cast<__bf16*>(smem);                            // bf16 planes of x: [parity][3][XPL]
+  __bf16* img = xpl + 2 * 3 * XPL;                                          // three bf16 planes [I2][K10]
   f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // partial accumulators
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -361,33 +362,59 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f};                                     // slot order i,g,f,o
-  if (ok && bias) bh = f32x4{bias[hd], bias[2 * H + hd], bias[H + hd], bias[3 * H + hd]};
+  if (ok && bias) bh = f32x4{bias[hd], bias[2 * HID + hd], bias[HID + hd], bias[3 * HID + hd]};
 
-  // wave 0: row n+G of x, four floats per lane, prefetched into registers a whole row ahead
+  // wave 0 carries the x row one row ahead in registers: DENSE four floats per lane; otherwise the XE padded
+  // positions p = lane + 64e of the [rows][8] operand (position (row2, j2) <- x[row2*J2 + j2], zero outside)
   const long G = gridDim.x;
   long n = blockIdx.x;
   f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (wave == 0 && n < n_rows) xv = *reinterpret_cast<const f32x4*>(x + n * H + 4 * lane);
+  auto fetch = [&](long r) {
+    if constexpr (DENSE) {
+      xv = *reinterpret_cast<const f32x4*>(x + r * IN + 4 * lane);
+    } else {
+#pragma unroll
+      for (int e = 0; e < XE; ++e) {
+        const int p = lane + 64 * e, row2 = p >> 3, j2 = p & 7;
+        const bool in = row2 < F::ROWS2 && j2 < F::J2;
+        const float v = x[r * IN + (in ? row2 * F::J2 + j2 : 0)];
+        xv[e] = in ? v : 0.f;
+      }
+    }
+  };
+  auto put = [&](__bf16* dst) {
+    if constexpr (DENSE) {
+      store_split4(dst, XPL, 4 * lane, xv);
+    } else {
+#pragma unroll
+      for (int e = 0; e < XE; ++e) {
+        __bf16 p0, p1, p2;
+        split3(xv[e], p0, p1, p2);
+        dst[lane + 64 * e] = p0; dst[XPL + lane + 64 * e] = p1; dst[2 * XPL + lane + 64 * e] = p2;
+      }
+    }
+  };
+  static_assert(DENSE || XE <= 4, "x row too long for the register prefetch");
   if (wave == 0) {
-    store_split4(xpl, H, 4 * lane, xv);
-    if (n + G < n_rows) xv = *reinterpret_cast<const f32x4*>(x + (n + G) * H + 4 * lane);
+    if (n < n_rows) fetch(n);
+    put(xpl);
+    if (n + G < n_rows) fetch(n + G);
   }
   lds_barrier();
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   int par = 0;
   for (; n < n_rows; n += G, par ^= 1) {
-    const __bf16* xp = xpl + par * 3 * H;
+    const __bf16* xp = xpl + par * 3 * XPL;
     // ---- phase A: S2 ------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int xx = 0; xx < F::XA; ++xx) {
-      f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, 0, lane);
-      f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, 1, lane);
-    }
+    for (int xx = 0; xx < F::XA; ++xx)
+#pragma unroll
+      for (int rt = 0; rt < F::RT2; ++rt) f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, rt, lane);
     lds_barrier();
     // ---- phase B: S10 k-halves; wave 0 first puts the next row's planes in place -----------------------------------
     if (wave == 0 && n + G < n_rows) {
-      store_split4(xpl + (par ^ 1) * 3 * H, H, 4 * lane, xv);
-      if (n + 2 * G < n_rows) xv = *reinterpret_cast<const f32x4*>(x + (n + 2 * G) * H + 4 * lane);
+      put(xpl + (par ^ 1) * 3 * XPL);
+      if (n + 2 * G < n_rows) fetch(n + 2 * G);
     }
     f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
     f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
@@ -397,7 +424,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const
     if (ok) {
       acc += xbuf[tile * 64 + lane];
       // accumulator registers are i,f,g,o (reference gate order); the interleaved row wants slots i,g,f,o
-      *reinterpret_cast<f32x4*>(y + ((size_t)n * H + hd) * 4) =
+      *reinterpret_cast<f32x4*>(y + ((size_t)n * HID + hd) * 4) =
           f32x4{acc[0] + bh[0], acc[2] + bh[1], acc[1] + bh[2], acc[3] + bh[3]};
     }
   }
@@ -405,7 +432,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const
 
 template <class S>
 constexpr size_t f10_lin_lds_bytes() {
-  return 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE + 4 * 64 * sizeof(f32x4);
+  return 2 * 3 * 2 * (size_t)F10<S>::XPL + 2 * 3 * (size_t)F10<S>::PLANE + 4 * 64 * sizeof(f32x4);
 }
 
 template <class S>
@@ -428,13 +455,14 @@ static int launch_lin_f10(long n_rows, const float* packed, const void* bias, co
 bool f10_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h, int ilv_mode) {
   const char* e = getenv("TTRNN_NO_F10");
   if ((e && e[0] == '1') || dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return false;
-  return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s);
+  return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpI40R16L>(s);
 }
 
 size_t f10_ttlinear_workspace_bytes(const TtShape& s, int dtype, int ilv_h, int ilv_mode) {
   if (dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return 0;
   if (shape_matches<ShpH256R8L>(s)) return f10_wfrag_bytes<ShpH256R8L>();
   if (shape_matches<ShpH256R16L>(s)) return f10_wfrag_bytes<ShpH256R16L>();
+  if (shape_matches<ShpI40R16L>(s)) return f10_wfrag_bytes<ShpI40R16L>();
   return 0;
 }
 
@@ -443,6 +471,7 @@ int launch_ttlinear_fwd_f10(const TtShape& s, int64_t n_rows, const float* packe
   if (n_rows <= 0) return TTRNN_OK;
   if (shape_matches<ShpH256R8L>(s)) return launch_lin_f10<ShpH256R8L>((long)n_rows, packed, bias, x, y, ws, stream);
   if (shape_matches<ShpH256R16L>(s)) return launch_lin_f10<ShpH256R16L>((long)n_rows, packed, bias, x, y, ws, stream);
+  if (shape_matches<ShpI40R16L>(s)) return launch_lin_f10<ShpI40R16L>((long)n_rows, packed, bias, x, y, ws, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

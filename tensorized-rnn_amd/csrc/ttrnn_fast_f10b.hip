@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ pack
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       // LSTM shapes: gate-interleaved k order (m_of_k1); other cells: natural order (ttrnn_fast_f10w.hip, NATK)
-      const int m = f10_ok<S>() ? B::m_of_k1(32 * u + 8 * q + e) : 32 * u + 8 * q + e;
+      const int m = (f10_ok<S>() || f10_in_ok<S>()) ? B::m_of_k1(32 * u + 8 * q + e) : 32 * u + 8 * q + e;
       const int i0 = m / F::I1, i1 = m % F::I1;
       const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
       float v = 0.f;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ pack
     for (int e = 0; e < 8; ++e) {
       const int slot = 4 * u + q;
       const int i2 = 2 * (slot % B::HI) + (e >> 2), r2 = (slot / B::HI) * 4 + (e & 3);
-      const float v = r < F::J2 ? W2[r * F::M2 + i2 * F::R2 + r2] : 0.f;
+      const float v = (r < F::J2 && i2 < F::I2) ? W2[r * F::M2 + i2 * F::R2 + r2] : 0.f;
       __bf16 p0, p1, p2;
       split3(v, p0, p1, p2);
       f0[e] = p0; f1[e] = p1; f2[e] = p2;
@@ -355,6 +355,7 @@ size_t f10b_fragment_bytes(const TtShape& s) {
   if (shape_matches<ShpH256R8L>(s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8);
   if (shape_matches<ShpH256R16L>(s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8);
   if (shape_matches<ShpH256R8G>(s)) return f10b_wfrag_elems<ShpH256R8G>() * sizeof(xbf8);
+  if (shape_matches<ShpI40R16L>(s)) return f10b_wfrag_elems<ShpI40R16L>() * sizeof(xbf8);
   return 0;
 }
 
@@ -370,6 +371,7 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
   if (shape_matches<ShpH256R8L>(s)) return launch_prep_b<ShpH256R8L>(packed, wfrag, stream);
   if (shape_matches<ShpH256R16L>(s)) return launch_prep_b<ShpH256R16L>(packed, wfrag, stream);
   if (shape_matches<ShpH256R8G>(s)) return launch_prep_b<ShpH256R8G>(packed, wfrag, stream);
+  if (shape_matches<ShpI40R16L>(s)) return launch_prep_b<ShpI40R16L>(packed, wfrag, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

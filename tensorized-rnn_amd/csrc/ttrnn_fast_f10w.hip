@@ -28,7 +28,10 @@ namespace ttrnn {
 template <class S>
 struct F10W {
   using F = F10<S>;
-  static constexpr int H = F::H, OUT = out_size_of<S>(), NG = OUT / H;   // gates: 4 (LSTM) or 3 (GRU)
+  static constexpr int IN = F::H, OUT = out_size_of<S>();
+  static constexpr int H = 256;                            // hidden units of the cell the matrix feeds
+  static constexpr int NG = OUT / H;                       // gates: 4 (LSTM) or 3 (GRU)
+  static constexpr int XI = F::ROWS2 * 8;                  // x image [ROWS2][8] (j2 zero-padded to the fp32 MFMA's k)
   static constexpr int K1 = F::M, NM1 = K1 / 32;          // T01 contraction (m) and its k-blocks
   static constexpr int FT = F::K / 16, XF = FT / FAST_NW;  // T01 / dW10 feature tiles (k = (row2, r2)), per wave
   static constexpr int MT = F::M / 16;                     // dW10 column tiles (m)
@@ -45,26 +48,30 @@ struct F10W {
   static constexpr int KQ = K2 / 4 / 4;                    // k-steps per quarter
 };
 
-// LSTM shapes (f10_ok: gates aligned with the m index) load a thread's four gate gradients as 4 consecutive k of the
-// T01 operand; any other cell (GRU: I2 = 12) goes element by element with the natural k order (NATK)
+// LSTM shapes (gates aligned with the m index) load a thread's four gate gradients as 4 consecutive k of the T01
+// operand; any other cell (GRU: I2 = 12) goes element by element with the natural k order (NATK)
 template <class S>
-constexpr bool f10w_natk() { return !f10_ok<S>(); }
+constexpr bool f10w_natk() { return !(f10_ok<S>() || f10_in_ok<S>()); }
+template <class S>
+constexpr bool NEEDS_HIDDEN_DX() { return F10<S>::J2 == 8 && F10<S>::ROWS2 == 32; }   // dx only for hidden-shaped inputs
 
 template <class S>
 constexpr bool f10w_ok() {
   using F = F10<S>;
   using W = F10W<S>;
-  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::I2 % 4 == 0 && F::I2 <= 16 &&
-         F::H == 256 && F::K % 32 == 0 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 && W::MT == 4 && F::J2 == 8 &&
-         St<S, 2>::RT == 2 && !St<S, 2>::SPLIT && F::ROWS2 == 32 && W::K2 % 16 == 0 && W::OUT % F::H == 0 &&
-         (f10_ok<S>() || W::OUT <= 2 * FAST_NT) && S::R[2] % 4 == 0;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok<S>() && F::I2 % 4 == 0 && F::I2 <= 16 &&
+         F::K % 32 == 0 && W::K1 % 32 == 0 && W::FT % FAST_NW == 0 && W::MT == 4 && F::J2 <= 8 &&
+         St<S, 2>::KP == 8 && !St<S, 2>::SPLIT && F::ROWS2 % 4 == 0 && F::ROWS2 <= 32 && W::K2 % 16 == 0 &&
+         W::OUT % W::H == 0 && (f10_ok<S>() || f10_in_ok<S>() || W::OUT <= 2 * FAST_NT) && S::R[2] % 4 == 0 &&
+         W::XI <= 4 * FAST_NT;
 }
 
 template <class S>
 constexpr size_t f10w_lds_bytes() {
   using F = F10<S>;
   using W = F10W<S>;
-  return sizeof(float) * (F::H + F::I2 * W::DGS + F::I2 * W::C2S + F::ROWS2 * W::DCS + 4 * F::H) + 2 * 3 * (size_t)W::PL1;
+  return sizeof(float) * (W::XI + F::I2 * W::DGS + F::I2 * W::C2S + F::ROWS2 * W::DCS + 4 * W::H) +
+         2 * 3 * (size_t)W::PL1;
 }
 
 // wfrag: the T01 fragments of k_f10b_prep (ttrnn_fast_f10b.hip);  dW10: fp32 [K][M] accumulation buffer (zeroed);
@@ -80,11 +87,13 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
   static_assert(f10w_ok<S>(), "shape not supported by the fused-core weight-gradient kernel");
   using F = F10<S>;
   using W = F10W<S>;
-  constexpr int H = F::H, OUT = W::OUT;
+  constexpr int H = W::H, IN = W::IN, OUT = W::OUT, XI = W::XI;
+  constexpr bool DENSE = F::J2 == 8;                          // x row == the [ROWS2][8] image (hidden-shaped input)
+  static_assert(!NEED_DX || NEEDS_HIDDEN_DX<S>(), "dx is only produced for hidden-shaped inputs");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* ximg = reinterpret_cast<float*>(smem);               // x row, [ROWS2][J2] = flat hidden index
-  float* dgT = ximg + H;                                      // dy transposed: [i2][m]
+  float* ximg = reinterpret_cast<float*>(smem);               // x row as [ROWS2][8] (j2 zero-padded)
+  float* dgT = ximg + XI;                                     // dy transposed: [i2][m]
   float* c2i = dgT + F::I2 * W::DGS;                          // C2 = S2(x): [i2][k]
   float* dci = c2i + F::I2 * W::C2S;                          // dC2 = W10 dy: [row2][(i2,r2)]
   float* dxs = dci + F::ROWS2 * W::DCS;                       // NEED_DX: four partial-sum slices of dx [4][H]
@@ -138,12 +147,16 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
     } else {
       if (own) dyv = f32x4{dy[r * OUT + hid], dy[r * OUT + H + hid], dy[r * OUT + 2 * H + hid], dy[r * OUT + 3 * H + hid]};
     }
-    if (tid < H / 4) {
-      if constexpr (sizeof(TI) == 4) {
-        xv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * H + 4 * tid);
+    if (tid < XI / 4) {       // four consecutive positions p = 4*tid + j of the [ROWS2][8] image: (row2, j2) <- x[row2*J2 + j2]
+      if constexpr (DENSE && sizeof(TI) == 4) {
+        xv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * IN + 4 * tid);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = ld(x, (size_t)(r * H + 4 * tid + j));
+        for (int j = 0; j < 4; ++j) {
+          const int p = 4 * tid + j, row2 = p >> 3, j2 = p & 7;
+          const float v = ld(x, (size_t)(r * IN + (j2 < F::J2 ? row2 * F::J2 + j2 : 0)));
+          xv[j] = j2 < F::J2 ? v : 0.f;
+        }
       }
     }
   };
@@ -174,7 +187,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       }
       store_split4(img1, W::PL1, x_off<W::K1>(hid % F::I2, 4 * (hid / F::I2)), dyv);     // k1 = 4*(hid/I2) + gate
     }
-    if (tid < H / 4) *reinterpret_cast<f32x4*>(ximg + 4 * tid) = xv;
+    if (tid < XI / 4) *reinterpret_cast<f32x4*>(ximg + 4 * tid) = xv;
     if (n + G < n_rows) load_row(n + G);
     lds_barrier();
     // ---- phase 2: C2 = S2(x) (fp32 MFMA) and dC2 = W10 dy (split-bf16 MFMAs), both into fp32 images ----------------
@@ -187,7 +200,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
 #pragma unroll
         for (int y = 0; y < T2::YR; ++y) {
           const int row2 = 16 * y + c, m0 = 16 * (wave + FAST_NW * xm) + 4 * q;   // feature m0 = (i2, r2 .. r2+3)
-          if (m0 < F::M2)
+          if (m0 < F::M2 && row2 < F::ROWS2)
             *reinterpret_cast<f32x4*>(c2i + (m0 / F::R2) * W::C2S + row2 * F::R2 + m0 % F::R2) = acc[xm][y];
         }
       xbf8 bf[W::NM1][3];
@@ -229,7 +242,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
     }
 #pragma unroll
     for (int s = 0; s < F::ROWS2 / 4; ++s) {                 // dW2[j2][col] += x[row2][j2] * dC2[row2][col], row2 = 4s + q
-      const float a = c < F::J2 ? ximg[(4 * s + q) * F::J2 + c] : 0.f;
+      const float a = c < F::J2 ? ximg[(4 * s + q) * 8 + c] : 0.f;
 #pragma unroll
       for (int xc = 0; xc < W::XC; ++xc) {
         const int ctile = wave + FAST_NW * xc;                  // wave-uniform; tiles beyond CT2 do not exist
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_f10(long n_rows, con
       if (wave + FAST_NW * xc < W::CT2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * (wave + FAST_NW * xc) + c, g2[xc][j]);
+          if (4 * q + j < F::J2) atomicAdd(dW2 + (size_t)(4 * q + j) * F::M2 + 16 * (wave + FAST_NW * xc) + c, g2[xc][j]);
       }
   }
   if (d_bias) {
@@ -332,7 +345,10 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
   if (st != TTRNN_OK) return st;
   constexpr size_t lds = f10w_lds_bytes<S>();
   static_assert(lds <= 160 * 1024, "LDS image set too large");
-  auto kern = dx ? k_ttlinear_wgrad_f10<S, TI, true> : k_ttlinear_wgrad_f10<S, TI, false>;
+  auto kern = k_ttlinear_wgrad_f10<S, TI, false>;
+  if constexpr (NEEDS_HIDDEN_DX<S>()) {
+    if (dx) kern = k_ttlinear_wgrad_f10<S, TI, true>;
+  }
   if (lds > 64 * 1024) {
     static bool raised[2] = {false, false};
     if (!raised[dx ? 1 : 0]) {
@@ -355,7 +371,9 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
   const char* e = getenv("TTRNN_NO_F10");
   if ((e && e[0] == '1') || dy_dtype != TTRNN_F32) return false;
-  if (dtype == TTRNN_F32) return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpH256R8G>(s);
+  if (dtype == TTRNN_F32)
+    return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpH256R8G>(s) ||
+           shape_matches<ShpI40R16L>(s);
   return dtype == TTRNN_BF16 && shape_matches<ShpH256R8G>(s);
 }
 
@@ -366,8 +384,13 @@ size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
     return (size_t)F10<ShpH256R16L>::K * F10<ShpH256R16L>::M * sizeof(float) + f10b_fragment_bytes(s);
   if (shape_matches<ShpH256R8G>(s))
     return (size_t)F10<ShpH256R8G>::K * F10<ShpH256R8G>::M * sizeof(float) + f10b_fragment_bytes(s);
+  if (shape_matches<ShpI40R16L>(s))
+    return (size_t)F10<ShpI40R16L>::K * F10<ShpI40R16L>::M * sizeof(float) + f10b_fragment_bytes(s);
   return 0;
 }
+
+// whether the kernel can also produce dx for this shape (hidden-shaped inputs only)
+bool f10_ttlinear_wgrad_has_dx(const TtShape& s) { return !shape_matches<ShpI40R16L>(s); }
 
 // dx may be NULL (hidden-to-hidden matrices: dh travels inside the reverse-time kernel)
 // dtype: storage type of x / dx (fp32; bf16 for the GRU shape); dy is fp32
@@ -381,6 +404,8 @@ int launch_ttlinear_wgrad_f10(const TtShape& s, int dtype, int64_t n_rows, const
       return launch_wgrad_f10<ShpH256R16L, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
     if (shape_matches<ShpH256R8G>(s))
       return launch_wgrad_f10<ShpH256R8G, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+    if (shape_matches<ShpI40R16L>(s) && !dx)
+      return launch_wgrad_f10<ShpI40R16L, float>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
   } else if (dtype == TTRNN_BF16 && shape_matches<ShpH256R8G>(s)) {
     return launch_wgrad_f10<ShpH256R8G, bf16_t>(s, (long)n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
   }

@@ -119,6 +119,7 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 // batched weight (+ bias) gradients of a hidden-shaped TT-matrix through the fused core, dx optional (ttrnn_fast_f10w.hip)
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype);
 size_t f10_ttlinear_wgrad_workspace_bytes(const TtShape& s);
+bool f10_ttlinear_wgrad_has_dx(const TtShape& s);
 int launch_ttlinear_wgrad_f10(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
                               const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
 

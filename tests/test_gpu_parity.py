@@ -499,11 +499,12 @@ def test_math_modes_full_size_properties(math_mode):
 
 
 # ---- (5) fused-core kernels: persistent row loops, stacked layers, switches ---------------------------------------
-@pytest.mark.parametrize("rank,B,T", [(8, 41, 23), (16, 37, 19)])
-def test_stacked_layers_many_rows_vs_generic(rank, B, T):
-    """Two stacked TT-LSTM layers (the second one's input projection and both weight-gradient passes run on the
-    fused-core kernels, whose workgroups WALK over B*T > 256 rows) against the any-shape kernels on the same module:
-    forward, input gradient and every parameter gradient."""
+@pytest.mark.parametrize("rank,B,T,x_grad", [(8, 41, 23, True), (16, 37, 19, True), (16, 37, 19, False)])
+def test_stacked_layers_many_rows_vs_generic(rank, B, T, x_grad):
+    """Two stacked TT-LSTM layers (input projections and weight-gradient passes run on the fused-core kernels, whose
+    workgroups WALK over B*T > 256 rows) against the any-shape kernels on the same module: forward, input gradient
+    and every parameter gradient.  Without an input gradient the first layer's in=40 matrix takes the fused-core
+    weight-gradient kernel too (it produces dx only for hidden-shaped inputs)."""
     import os
     torch.manual_seed(77 + rank)
     meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=rank)
@@ -515,10 +516,11 @@ def test_stacked_layers_many_rows_vs_generic(rank, B, T):
         os.environ["TTRNN_FORCE_GENERIC"] = force
         try:
             m.zero_grad()
-            xg = x.clone().requires_grad_(True)
+            xg = x.clone().requires_grad_(x_grad)
             out, (h, c) = m(xg)
             ((out * w).sum() + c.sum() + h.sum()).backward()
-            outs.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+            outs.append((out.detach().clone(), xg.grad.clone() if x_grad else torch.zeros(1),
+                         [p.grad.clone() for p in m.parameters()]))
         finally:
             os.environ["TTRNN_FORCE_GENERIC"] = "0"
     assert _maxabs(outs[0][0], outs[1][0]) <= 5e-6
