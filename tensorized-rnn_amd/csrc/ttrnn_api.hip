@@ -264,6 +264,9 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
       return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                 (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);
+    if (fp32_math() == TTRNN_MATH_EXACT && f.f10_bytes > 0 && f10x_rnn_fwd_available(rs, desc->dtype))
+      return launch_rnn_fwd_f10x(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
+                                 (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);
     if (fast_rnn_fwd_bf16_available(rs, desc->dtype))
       return launch_rnn_fwd_bf16(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, (hipStream_t)stream);
     return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,

@@ -86,6 +86,12 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream);
 
+// the same fused-core recurrent kernel on the fp32 MFMA (TTRNN_MATH_EXACT; ttrnn_fast_f10x.hip); ws as above
+bool f10x_rnn_fwd_available(const RnnShape& rs, int dtype);
+int launch_rnn_fwd_f10x(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                        hipStream_t stream);
+
 // batched gate-interleaved LSTM input projection through a hidden-shaped TT-matrix on the fused core (K-in of the
 // layers above the first); ws: f10_ttlinear_workspace_bytes
 bool f10_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h, int ilv_mode);
