@@ -12,8 +12,11 @@
 //                phase B  waves 0-3     S10: 16-byte fragment reads three k-groups ahead, K10/4 MFMAs per wave, gates,
 //                                       h_t -> LDS; wave 7 streams h_{t-1} to `out`
 //                barrier
-// k order of the fused stage: MFMA step (u, j) contracts k = 16u + 4q + j on lane group q, so that one ds_read_b128
-// per lane feeds four consecutive MFMAs; the core fragments are laid out the same way by k_f10x_prep.
+// k order of the fused stage: MFMA step (u, j) contracts image position 16u + 4q + j on lane group q, so that one
+// ds_read_b128 per lane feeds four consecutive MFMAs; image position p holds (row2, r2) = ((p/4) % ROWS2,
+// 4*(p / (4*ROWS2)) + p%4) — the 16-byte slots of one r2-quad are contiguous over row2, so the 8 lanes of a
+// ds_write_b128 group (8 consecutive chain rows) fill 128 contiguous bytes (the natural order (row2, r2) left every
+// other slot out: 2-way bank conflicts on every S2 store).  k_f10x_prep lays the core fragments out the same way.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "ttrnn_core.h"
@@ -30,8 +33,8 @@ __global__ void __launch_bounds__(64) k_f10x_prep(const float* __restrict__ pack
   const int lane = threadIdx.x, st = blockIdx.x % (F::K / 4), t = blockIdx.x / (F::K / 4);
   const int r = lane & 15, q = lane >> 4;
   const int u = st >> 2, j = st & 3;
-  const int kk = 16 * u + 4 * q + j;                       // natural order: kk = row2*R2 + r2
-  const int row2 = kk / F::R2, r2 = kk % F::R2;
+  const int p = 16 * u + 4 * q + j;                        // image position (see the header)
+  const int row2 = (p >> 2) % F::ROWS2, r2 = 4 * (p / (4 * F::ROWS2)) + (p & 3);
   const int j1 = row2 % F::J1, j0 = row2 / F::J1;
   const int m = F::MPG * (r & 3) + 4 * t + (r >> 2);
   const int i0 = m / F::I1, i1 = m % F::I1;
@@ -112,7 +115,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10x(int B, int T, GinSrc 
 #pragma unroll
         for (int y = 0; y < T2::YR; ++y) {
           const int row2 = 16 * y + c, m0 = 16 * (wave + FAST_NW * xm) + 4 * q;     // feature m0 = (i2, r2 .. r2+3)
-          *reinterpret_cast<f32x4*>(img + a_off<K>(m0 / F::R2, row2 * F::R2 + m0 % F::R2)) = acc[xm][y];
+          const int r20 = m0 % F::R2;                        // 4 consecutive r2 = one slot: quad r20/4 of chain row row2
+          *reinterpret_cast<f32x4*>(img + a_off<K>(m0 / F::R2, ((r20 >> 2) * F::ROWS2 + row2) * 4)) = acc[xm][y];
         }
     }
     lds_barrier();
