@@ -67,10 +67,9 @@ __device__ __forceinline__ void f10_load_w2(xbf8& a1, xbf8& a2, const float* pac
   }
 }
 
-// one S2 tile (m-tile mt, chain-row tile rt): hp = the three bf16 planes [3][H] of h_{t-1}; result split into img
+// one S2 tile (m-tile mt, chain-row tile rt): hp = the three bf16 planes [3][XPL] of the input; the MFMA part ...
 template <class S>
-__device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, const __bf16* hp, __bf16* img, int mt, int rt,
-                                            int lane) {
+__device__ __forceinline__ f32x4 f10_s2_mma(const xbf8& a1, const xbf8& a2, const __bf16* hp, int rt, int lane) {
   using F = F10<S>;
   const int c = lane & 15, q = lane >> 4;
   const int row = 16 * rt + c;
@@ -79,13 +78,19 @@ __device__ __forceinline__ void f10_s2_tile(const xbf8& a1, const xbf8& a2, cons
   const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::XPL + row * 8);
   const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::XPL + row * 8);
   f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
+}
+// ... and the split of its result into the S10 operand
+template <class S>
+__device__ __forceinline__ void f10_s2_store(f32x4 acc, __bf16* img, int mt, int rt, int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = 16 * rt + c;
   const int m0 = 16 * mt + 4 * q;
   const int i = m0 / F::R2, a0 = m0 % F::R2;
   // C2[i][row][a0..a0+3] (ops.py:89-90: C2 flat == the [I2][K10] operand of the next stage), k order: F10::kperm
   if (row < F::ROWS2) store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);   // padding rows: no store
 }
-
 // S10 k-blocks [u0, u0 + NU) (w10 holds exactly those): reads run PD blocks ahead of the MFMAs (at most two waves per
 // SIMD do this: little else hides the LDS latency; sched_barrier keeps the compiler from sinking the reads back next
 // to their use)
@@ -242,10 +247,21 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
     const __bf16* hp = hpl + (t & 1) * 3 * H;             // planes of h_{t-1}
     __bf16* hn = hpl + ((t + 1) & 1) * 3 * H;             // planes of h_t
     // ---- phase A: S2, all waves ---------------------------------------------------------------------------
+    // all MFMAs first, then the splitting: the VALU work of one tile runs in the shadow of the others' MFMA latency
+    // instead of behind an s_nop after every pair
+    {
+      f32x4 t2[F::XA][2];
 #pragma unroll
-    for (int x = 0; x < F::XA; ++x) {
-      f10_s2_tile<S>(s1[x], s2[x], hp, img, wave + FAST_NW * x, 0, lane);
-      f10_s2_tile<S>(s1[x], s2[x], hp, img, wave + FAST_NW * x, 1, lane);
+      for (int x = 0; x < F::XA; ++x) {
+        t2[x][0] = f10_s2_mma<S>(s1[x], s2[x], hp, 0, lane);
+        t2[x][1] = f10_s2_mma<S>(s1[x], s2[x], hp, 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < F::XA; ++x) {
+        f10_s2_store<S>(t2[x][0], img, wave + FAST_NW * x, 0, lane);
+        f10_s2_store<S>(t2[x][1], img, wave + FAST_NW * x, 1, lane);
+      }
     }
     TT_STAMP(0)
     lds_barrier();
@@ -406,10 +422,18 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_f10(long n_rows, const
   for (; n < n_rows; n += G, par ^= 1) {
     const __bf16* xp = xpl + par * 3 * XPL;
     // ---- phase A: S2 ------------------------------------------------------------------------------------------
+    {
+      f32x4 t2[F::XA][F::RT2];      // all MFMAs first, then the splitting (see k_lstm_fwd_f10)
 #pragma unroll
-    for (int xx = 0; xx < F::XA; ++xx)
+      for (int xx = 0; xx < F::XA; ++xx)
 #pragma unroll
-      for (int rt = 0; rt < F::RT2; ++rt) f10_s2_tile<S>(s1[xx], s2[xx], xp, img, wave + FAST_NW * xx, rt, lane);
+        for (int rt = 0; rt < F::RT2; ++rt) t2[xx][rt] = f10_s2_mma<S>(s1[xx], s2[xx], xp, rt, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int xx = 0; xx < F::XA; ++xx)
+#pragma unroll
+        for (int rt = 0; rt < F::RT2; ++rt) f10_s2_store<S>(t2[xx][rt], img, wave + FAST_NW * xx, rt, lane);
+    }
     lds_barrier();
     // ---- phase B: S10 k-halves; wave 0 first puts the next row's planes in place -----------------------------------
     if (wave == 0 && n + G < n_rows) {
