@@ -295,10 +295,11 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
   if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
-    if (fp32_math() == TTRNN_MATH_SPLIT && rs.T > 0 && f10_rnn_bwd_available(rs, desc->dtype)) {
+    if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&
+        f10_rnn_bwd_available(rs, desc->dtype)) {
       if (!workspace || workspace_bytes < f10_rnn_bwd_workspace_bytes(rs, desc->dtype)) return TTRNN_ERR_WORKSPACE;
-      return launch_rnn_bwd_f10(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
-                                workspace, (hipStream_t)stream);
+      return launch_rnn_bwd_f10(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
+                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream);
     }
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);

@@ -316,6 +316,200 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
   }
 }
 
+// ---- GRU ---------------------------------------------------------------------------------------------------------
+// Same two transposed stages for the TT-GRU (fp32 or bf16 storage; reserve, gate gradients and all arithmetic fp32):
+// the gate gradients of gru.py:38-44 are dr, dz, dn*r for the hidden chain (dn for the input chain), and the flat
+// gate index o = gate*H + hid = m*I2 + i2 does not align with the MFMA tiles (I2 = 12), so the T01 operand is filled
+// element by element in the natural k order (the fragments of k_f10b_prep follow, see f10_ok there).  The direct
+// path dh_{t-1} += dh_t * z stays in the thread's register.
+template <class S>
+constexpr bool f10b_gru_ok() {
+  using F = F10<S>;
+  using B = F10B<S>;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::H == 256 &&
+         out_size_of<S>() == 3 * F::H && F::I2 % 2 == 0 && F::I2 <= 16 && F::M == 64 && B::K1 % 32 == 0 &&
+         B::FT % FAST_NW == 0 && B::K2 % 32 == 0 && B::CT2 == 2 && F::J2 == 8 && S::R[2] % 4 == 0;
+}
+
+template <class S>
+constexpr size_t f10b_gru_lds_bytes() {
+  using B = F10B<S>;
+  return sizeof(float) * 3 * B::H + sizeof(float) * B::NM2 * B::H + 2 * 3 * (size_t)(B::PL1 + B::PL2);
+}
+
+template <class S, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS* __restrict__ out,
+                                                         const TS* __restrict__ h0, const xbf8* __restrict__ wfrag,
+                                                         const float* __restrict__ reserve,
+                                                         const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
+                                                         float* __restrict__ dg_in, float* __restrict__ dg_hid,
+                                                         TS* __restrict__ d_h0) {
+  static_assert(f10b_gru_ok<S>(), "shape not supported by the fused-core GRU reverse-time kernel");
+  using F = F10<S>;
+  using B = F10B<S>;
+  constexpr int H = F::H, GH = 3 * H;
+  constexpr int NP = B::NM2 * B::CT2, XT = (NP + FAST_NW - 1) / FAST_NW;      // T2 (column tile, k-block) pairs
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* dgf = reinterpret_cast<float*>(smem);                               // [3H]: dr, dz, dn*r (hidden chain)
+  float* dhs = dgf + GH;                                                     // [NM2][H]
+  __bf16* img1 = reinterpret_cast<__bf16*>(dhs + B::NM2 * H);                 // 3 planes [I2][K1], natural k
+  __bf16* img2 = img1 + 3 * B::PL1;                                          // 3 planes [ROWS2][K2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  xbf8 w01[B::XF][B::NM1][3], w2t[XT][3];
+#pragma unroll
+  for (int x = 0; x < B::XF; ++x)
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 3 + p) * 64 + lane];
+#pragma unroll
+  for (int x = 0; x < XT; ++x) {
+    const int id = wave + FAST_NW * x, ub = (id < NP ? id : 0) >> 1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 3 + ub * 3 + p) * 64 + lane];
+  }
+
+  // three rotating sets of (record(t) = (r,z,n,hn), d_out(t), h_{t-1}) — see k_lstm_bwd_f10
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float dhd = 0.f;
+  const TS* dptr = d_out ? d_out : out;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  TS do0 = TS{}, do1 = TS{}, do2 = TS{}, hp0 = TS{}, hp1 = TS{}, hp2 = TS{};
+  auto issue = [&](int t, f32x4& ra, TS& dq, TS& hq) {       // loads of set(t); clamped, unconditional
+    const size_t bt = b * T + (t > 0 ? t : 0);
+    ra = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
+    dq = dptr[bt * H + hid];
+    const TS* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);
+    hq = hp[hid];
+  };
+  if (own) {
+    dhs[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
+    if (T > 0) {
+      issue(T - 1, ra0, do0, hp0);
+      issue(T - 2, ra1, do1, hp1);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  lds_barrier();
+
+  auto step = [&](const int t, const f32x4& ra, const TS& dq, const TS& hq, f32x4& fa, TS& fd, TS& fh) {
+    const size_t bt = b * T + t;
+    // ---- G: gate gradients (gru.py:38-44 differentiated) -----------------------------------------------------------
+    if (own) {
+      issue(t - 2, fa, fd, fh);
+      float dht = dhd + to_f32(dq) * dscale;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
+      const float rg = ra[0], zg = ra[1], ng = ra[2], hn = ra[3];
+      const float hprev = (t > 0 || h0) ? to_f32(hq) : 0.f;
+      const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
+      const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
+      const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+      dhd = dht * zg;
+      const float pv[3] = {dr_pre, dz_pre, dn_pre * rg};
+      dg_in[bt * GH + 2 * H + hid] = dn_pre;                // the only block where d_gates_in != d_gates_hid
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        dgf[g * H + hid] = pv[g];
+        const int o = g * H + hid, m = o / F::I2, i2 = o % F::I2;     // flat gate index -> (m, i2), natural k = m
+        __bf16 p0, p1, p2;
+        split3(pv[g], p0, p1, p2);
+        const int off = x_off<B::K1>(i2, m);
+        img1[off] = p0; img1[B::PL1 + off] = p1; img1[2 * B::PL1 + off] = p2;
+      }
+    }
+    lds_barrier();
+    // ---- T01: dC2 = W10 dg; the fp32 rows go out to HBM meanwhile ----------------------------------------------------
+    {
+      if (tid < GH / 4) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[tid];
+        reinterpret_cast<f32x4*>(dg_hid + bt * GH)[tid] = v;
+        if (tid < 2 * H / 4) reinterpret_cast<f32x4*>(dg_in + bt * GH)[tid] = v;
+      }
+      const int rowc = c < F::I2 ? c : F::I2 - 1;
+      xbf8 bf[B::NM1][3];
+#pragma unroll
+      for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[u][p] = *reinterpret_cast<const xbf8*>(img1 + p * B::PL1 + x_off<B::K1>(rowc, 32 * u + 8 * q));
+#pragma unroll
+      for (int x = 0; x < B::XF; ++x) {
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s)
+            acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[x][u][SPLIT_TW[s]], bf[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+          acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w01[x][u][0], bf[u][0], acc_hi, 0, 0, 0);
+        }
+        const f32x4 acc = acc_hi + acc_lo;
+        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+        if (c < F::I2) store_split4(img2, B::PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc);
+      }
+    }
+    lds_barrier();
+    // ---- T2: dh_{t-1}[row2][j2]: pair id = (column tile id & 1, k-block id >> 1), one slice per k-block ---------------
+#pragma unroll
+    for (int x = 0; x < XT; ++x) {
+      const int id = wave + FAST_NW * x;
+      if (id < NP) {
+        const int ub = id >> 1, row = 16 * (id & 1) + c;
+        xbf8 bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[p] = *reinterpret_cast<const xbf8*>(img2 + p * B::PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+          acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[x][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
+        acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2t[x][0], bf[0], acc_hi, 0, 0, 0);
+        const f32x4 acc = acc_hi + acc_lo;
+        if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc;
+      }
+    }
+    lds_barrier();
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, do0, hp0, ra2, do2, hp2);
+    if (t >= 1) step(t - 1, ra1, do1, hp1, ra0, do0, hp0);
+    if (t >= 2) step(t - 2, ra2, do2, hp2, ra1, do1, hp1);
+  }
+  if (own && d_h0) {
+    float v = dhd;
+#pragma unroll
+    for (int sl = 0; sl < B::NM2; ++sl) v += dhs[sl * H + hid];
+    st(d_h0, b * H + hid, v);
+  }
+}
+
+template <class S, typename TS>
+static int launch_gru_bwd_f10(const RnnShape& rs, const void* out, const void* h0, const float* packed_hid,
+                              const float* reserve, const void* d_out, const void* d_hT, float* dg_in, float* dg_hid,
+                              void* d_h0, void* ws, hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  using B = F10B<S>;
+  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
+  hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed_hid, wfrag);
+  constexpr size_t lds = f10b_gru_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  hipLaunchKernelGGL((k_gru_bwd_f10<S, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)out,
+                     (const TS*)h0, wfrag, reserve, (const TS*)d_out, (const TS*)d_hT, dg_in, dg_hid, (TS*)d_h0);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 // ---- dispatch ------------------------------------------------------------------------------------------
 template <class S>
 static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
@@ -377,20 +571,33 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
+  if ((e && e[0] == '1') || rs.B < 1 || rs.T < 1) return false;
+  if (rs.cell == TTRNN_GRU) return (dtype == TTRNN_F32 || dtype == TTRNN_BF16) && shape_matches<ShpH256R8G>(rs.hid_s);
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
 size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // fragments + 4 KB for diagnostic stamps
+  if (rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
+    return f10b_wfrag_elems<ShpH256R8G>() * sizeof(xbf8) + 4096;
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8) + 4096;
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8) + 4096;
   return 0;
 }
 
-int launch_rnn_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
-                       const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
-                       void* d_c0, void* ws, hipStream_t stream) {
+int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
+                       const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                       const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                       hipStream_t stream) {
+  if (rs.cell == TTRNN_GRU) {
+    if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
+    if (dtype == TTRNN_F32)
+      return launch_gru_bwd_f10<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0,
+                                                   ws, stream);
+    return launch_gru_bwd_f10<ShpH256R8G, bf16_t>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0,
+                                                  ws, stream);
+  }
   if (shape_matches<ShpH256R8L>(rs.hid_s))
     return launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
                                       stream);

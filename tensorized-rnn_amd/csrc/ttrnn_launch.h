@@ -115,9 +115,10 @@ int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const vo
 // reverse-time TT-LSTM kernel on the fused core, split fp32 math (ttrnn_fast_f10b.hip); ws: fragments built per launch
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype);
-int launch_rnn_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
-                       const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
-                       void* d_c0, void* ws, hipStream_t stream);
+int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
+                       const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                       const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                       hipStream_t stream);
 
 size_t f10b_fragment_bytes(const TtShape& s);     // the transposed fused-core fragments alone
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream);
