@@ -21,6 +21,43 @@ namespace ttrnn {
 
 using ShpH1024R32L = Shp<4, 4, 4, 8, 8, 8, 8, 8, 8, 32, 32, 32>;   // cfg5: TT-LSTM H = in = 1024, d = 4, r = 32
 
+// Contracting cores 0 and 1 once per launch turns a d-core TT-matrix into a (d-1)-core one with first modes
+// (J0*J1, I0*I1) and the same input / output index order:  G01[(i0,i1), (j0,j1), r2] = sum_r1 G0[i0,j0,r1] G1[r1,i1,j1,r2].
+// For cfg5 the chain then costs 21.5 instead of 35.1 MFLOP per sample-step (the two stages with contraction lengths 128
+// over 256 / 512 rows become one with 512 over 64 rows) and runs on the very same stage code.
+using ShpH1024R32L_M = Shp<3, 16, 8, 8, 1, 64, 8, 8, 1, 32, 32, 1>;
+
+// packed4: [W_0 | W_1 | W_2 | W_3 ...] of S4;  packed3: [W'_0 = merged | W'_1 = W_2 | W'_2 = W_3] of S3
+template <class S4, class S3>
+__global__ void __launch_bounds__(256) k_merge_cores01(const float* __restrict__ packed4, float* __restrict__ packed3) {
+  constexpr int J1 = S4::J[1], I0 = S4::I[0], I1 = S4::I[1], R1 = S4::R[1], R2 = S4::R[2];
+  constexpr int M0 = S3::I[0], K0 = S3::J[0] * S3::R[1];
+  constexpr int N0 = K0 * M0;
+  constexpr int N1 = S3::J[1] * S3::R[2] * S3::I[1] * S3::R[1], N2 = S3::J[2] * S3::R[3] * S3::I[2] * S3::R[2];
+  static_assert(S3::J[0] == S4::J[0] * J1 && M0 == I0 * I1 && S3::R[1] == R2 && S3::D == 3 && S4::D == 4, "merged shape");
+  const float* W0 = packed4 + woff_of<S4>(0);
+  const float* W1 = packed4 + woff_of<S4>(1);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < N0) {
+    const int kk = e / M0, m = e % M0;
+    const int jj = kk / R2, r2 = kk % R2, j0 = jj / J1, j1 = jj % J1, i0 = m / I1, i1 = m % I1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < R1; ++r1)
+      v = fmaf(W0[(j0 * R1 + r1) * I0 + i0], W1[(j1 * R2 + r2) * (I1 * R1) + i1 * R1 + r1], v);
+    packed3[woff_of<S3>(0) + e] = v;
+  } else if (e < N0 + N1) {
+    packed3[woff_of<S3>(1) + e - N0] = packed4[woff_of<S4>(2) + e - N0];
+  } else if (e < N0 + N1 + N2) {
+    packed3[woff_of<S3>(2) + e - N0 - N1] = packed4[woff_of<S4>(3) + e - N0 - N1];
+  }
+}
+
+template <class S3>
+constexpr int merged_elems() {
+  return S3::J[0] * S3::R[1] * S3::I[0] + S3::J[1] * S3::R[2] * S3::I[1] * S3::R[1] +
+         S3::J[2] * S3::R[3] * S3::I[2] * S3::R[2];
+}
+
 template <class S, int k, int G>
 __device__ __forceinline__ void big_stage(const float* packed, const float* in, float* out, int wave, int lane,
                                           int ilv_mode) {
@@ -199,31 +236,54 @@ bool big_rnn_fwd_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH1024R32L>(rs.hid_s) && shape_matches<ShpH1024R32L>(rs.in_s);
 }
 
+static bool big_merge_enabled() {
+  const char* e = getenv("TTRNN_BIG_NO_MERGE");      // A/B switch: run the four-core chain as is
+  return !(e && e[0] == '1');
+}
+
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {
-  constexpr size_t MID = big_mid<ShpH1024R32L>();
+  constexpr size_t MID = big_mid<ShpH1024R32L>();      // >= big_mid of the merged shape
   const size_t gin = (size_t)rs.B * rs.T * rs.H * 4 * sizeof(float);
   const size_t lin = (size_t)BIG_LIN_GRID * 3 * MID * sizeof(float);
   const size_t rec = (size_t)rs.B * 2 * MID * sizeof(float);
-  return gin + (lin > rec ? lin : rec);
+  const size_t merged = 2 * (((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255);
+  return gin + (lin > rec ? lin : rec) + merged;
 }
 
 template <typename TS>
 static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in,
                         const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT,
                         void* cT, float* reserve, void* workspace, hipStream_t stream) {
-  using S = ShpH1024R32L;
+  using S4 = ShpH1024R32L;
+  using S3 = ShpH1024R32L_M;
+  static_assert(big_mid<S3>() <= big_mid<S4>(), "slab size");
   float* gin = (float*)workspace;
   float* slab = gin + (size_t)rs.B * rs.T * rs.H * 4;
   const int64_t n_rows = (int64_t)rs.B * rs.T;
   const int grid = (int)(n_rows < BIG_LIN_GRID ? n_rows : BIG_LIN_GRID);
-  hipLaunchKernelGGL((k_ttlinear_fwd_big<S, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed_in,
+  const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
+  const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
+  if (big_merge_enabled()) {
+    // the merged cores live behind the slab region (the tail of the workspace)
+    const size_t mbytes = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
+    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * mbytes;
+    float* m_in = (float*)tail;
+    float* m_hid = (float*)(tail + mbytes);
+    const int mg = (merged_elems<S3>() + 255) / 256;
+    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(mg), dim3(256), 0, stream, packed_in, m_in);
+    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(mg), dim3(256), 0, stream, packed_hid, m_hid);
+    hipLaunchKernelGGL((k_ttlinear_fwd_big<S3, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, m_in,
+                       (const TS*)x, gin, slab, 2);
+    if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((k_rnn_fwd_big<S3, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                       (const TS*)h0, (const TS*)c0, m_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((k_ttlinear_fwd_big<S4, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed_in,
                      (const TS*)x, gin, slab, 2);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL((k_rnn_fwd_big<S, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                     (const TS*)h0, (const TS*)c0, packed_hid,
-                     rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr,
-                     rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr, (TS*)out, (TS*)hT, (TS*)cT, reserve,
-                     slab);
+  hipLaunchKernelGGL((k_rnn_fwd_big<S4, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                     (const TS*)h0, (const TS*)c0, packed_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
