@@ -52,20 +52,163 @@ __global__ void __launch_bounds__(256) k_merge_cores01(const float* __restrict__
   }
 }
 
+// ... and the same for the LAST two cores: G23[r2, (i2,i3), (j2,j3)] = sum_r3 G2[r2,i2,j2,r3] G3[r3,i3,j3,0]; the chain is
+// then two stages of 4.2 MFLOP each (16 x 64 x 2048 and 64 x 512 x 64), the cost of the dense 4096 x 1024 product
+using ShpH1024R32L_M2 = Shp<2, 16, 64, 1, 1, 64, 64, 1, 1, 32, 1, 1>;
+
+// packed3: [W'_0 | W'_1 | W'_2] of S3;  packed2: [W''_0 = W'_0 | W''_1 = merged W'_1,W'_2] of S2
+template <class S3, class S2>
+__global__ void __launch_bounds__(256) k_merge_cores_last(const float* __restrict__ packed3,
+                                                          float* __restrict__ packed2) {
+  constexpr int J1 = S3::J[1], J2 = S3::J[2], I1 = S3::I[1], I2 = S3::I[2], R1 = S3::R[1], R2 = S3::R[2];
+  constexpr int N0 = S3::J[0] * R1 * S3::I[0];
+  constexpr int K1 = S2::J[1], M1 = S2::I[1] * S2::R[1];       // W''_1 [J1*J2][I1*I2*R1]
+  static_assert(S2::J[1] == J1 * J2 && S2::I[1] == I1 * I2 && S2::R[1] == R1 && S2::J[0] == S3::J[0] &&
+                    S2::I[0] == S3::I[0] && S3::R[3] == 1, "merged shape");
+  const float* W1 = packed3 + woff_of<S3>(1);                  // [J1*R2][I1*R1]
+  const float* W2 = packed3 + woff_of<S3>(2);                  // [J2*1][I2*R2]
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < N0) {
+    packed2[woff_of<S2>(0) + e] = packed3[woff_of<S3>(0) + e];
+  } else if (e < N0 + K1 * M1) {
+    const int f = e - N0, kk = f / M1, mm = f % M1;            // kk = j1*J2 + j2;  mm = (i1*I2 + i2)*R1 + a
+    const int j1 = kk / J2, j2 = kk % J2, a = mm % R1, ii = mm / R1, i1 = ii / I2, i2 = ii % I2;
+    float v = 0.f;
+    for (int r2 = 0; r2 < R2; ++r2)
+      v = fmaf(W1[(j1 * R2 + r2) * (I1 * R1) + i1 * R1 + a], W2[j2 * (I2 * R2) + i2 * R2 + r2], v);
+    packed2[woff_of<S2>(1) + f] = v;
+  }
+}
+
+template <class S2>
+constexpr int merged2_elems() { return S2::J[0] * S2::R[1] * S2::I[0] + S2::J[1] * S2::I[1] * S2::R[1]; }
+
 template <class S3>
 constexpr int merged_elems() {
   return S3::J[0] * S3::R[1] * S3::I[0] + S3::J[1] * S3::R[2] * S3::I[1] * S3::R[1] +
          S3::J[2] * S3::R[3] * S3::I[2] * S3::R[2];
 }
 
+// fragments of the m-tiles {wave + 8(x0 + x) : x < XC} of stage k (chunk of a wave's tile list)
+template <class S, int k, int XC, int NW_>
+__device__ __forceinline__ void load_wfrag_x(float (&w)[NW_], const float* packed, int wave, int lane, int x0) {
+  using T = St<S, k>;
+  static_assert(!T::SPLIT && NW_ == XC * T::NSTEP, "chunked stages own whole m-tiles");
+  const int r = lane & 15, q = lane >> 4;
+  const float* W = packed + woff_of<S>(k);
+#pragma unroll
+  for (int x = 0; x < XC; ++x) {
+    const int mt = wave + FAST_NW * (x0 + x);
+    const int m = 16 * mt + r;
+#pragma unroll
+    for (int u = 0; u < T::NU; ++u)
+#pragma unroll
+      for (int e = 0; e < T::WV; ++e) {
+        const int kk = (4 * u + q) * T::WV + e;
+        const bool okw = mt < T::MT && m < T::M && kk < T::K;
+        const float wv = W[okw ? kk * T::M + m : 0];
+        w[x * T::NSTEP + u * T::WV + e] = okw ? wv : 0.f;
+      }
+  }
+}
+
+// lin_stage (ttrnn_mfma.h) restricted to that chunk of m-tiles, one sample (NB = 1)
+template <class S, int k, int G, int XC, int NW_>
+__device__ __forceinline__ void lin_stage_x(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane,
+                                            int ilv_mode, int x0) {
+  using T = St<S, k>;
+  static_assert(NW_ == XC * T::NSTEP, "fragment array size");
+  constexpr int TOT = T::ROWS;
+  constexpr int RT_ALL = (TOT + 15) / 16;
+  constexpr int OUT = out_size_of<S>();
+  const int c = lane & 15, q = lane >> 4;
+  constexpr int UC = chunk_of(T::NU);
+  for (int rtb = 0; rtb < RT_ALL; rtb += 2) {
+    int Rr[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int R = 16 * (rtb + y) + c;
+      Rr[y] = R < TOT ? R : TOT - 1;
+    }
+    f32x4 acc[XC][2];
+#pragma unroll
+    for (int x = 0; x < XC; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u0 = 0; u0 < T::NU; u0 += UC) {
+      float af[2][UC * T::WV];
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          const float* p = Ain + a_off<T::KP>(Rr[y], (4 * (u0 + u) + q) * T::WV);
+          if constexpr (T::WV == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            af[y][4 * u + 0] = v[0]; af[y][4 * u + 1] = v[1]; af[y][4 * u + 2] = v[2]; af[y][4 * u + 3] = v[3];
+          } else if constexpr (T::WV == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+            af[y][2 * u + 0] = v[0]; af[y][2 * u + 1] = v[1];
+          } else {
+            af[y][u] = *p;
+          }
+        }
+#pragma unroll
+      for (int x = 0; x < XC; ++x)
+#pragma unroll
+        for (int s2 = 0; s2 < UC * T::WV; ++s2) {
+          const float wv = w[x * T::NSTEP + u0 * T::WV + s2];
+          acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, af[0][s2], acc[x][0], 0, 0, 0);
+          if (RT_ALL > 1) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, af[1][s2], acc[x][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < XC; ++x) {
+      const int mt = wave + FAST_NW * (x0 + x);
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const f32x4 a = acc[x][y];
+        const int rt = rtb + y;
+        const int R = 16 * rt + c;
+        const int m0 = 16 * mt + 4 * q;
+        if (mt < T::MT && rt < RT_ALL && R < TOT && m0 < T::M) {
+          if constexpr (k > 0) {
+            using N = St<S, k - 1>;
+            const int i = m0 / T::R, a0 = m0 % T::R;
+            const int f = i * (T::ROWS * T::R) + R * T::R + a0;
+            *reinterpret_cast<f32x4*>(Cout + a_off<N::KP>(f / N::K, f % N::K)) = a;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (m0 + j < T::M) Cout[ytile_index<G, OUT>(0, (m0 + j) * T::ROWS + R, ilv_mode)] = a[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+// One chain stage.  Stages whose fragment set (XM m-tiles x NSTEP k-steps per wave) would not fit the register file
+// go through it in chunks of XC m-tiles.
 template <class S, int k, int G>
 __device__ __forceinline__ void big_stage(const float* packed, const float* in, float* out, int wave, int lane,
                                           int ilv_mode) {
-  int z = 0;
-  asm volatile("" : "+v"(z));          // keep the fragment loads and their address arithmetic inside this stage
-  float w[nwreg<S, k>()];
-  load_wfrag<S, k>(w, packed, wave, lane + z);
-  lin_stage<S, k, 1, G>(w, in, out, wave, lane + z, ilv_mode);
+  using T = St<S, k>;
+  if constexpr (T::NWREG <= 128) {
+    int z = 0;
+    asm volatile("" : "+v"(z));          // keep the fragment loads and their address arithmetic inside this stage
+    float w[nwreg<S, k>()];
+    load_wfrag<S, k>(w, packed, wave, lane + z);
+    lin_stage<S, k, 1, G>(w, in, out, wave, lane + z, ilv_mode);
+  } else {
+    constexpr int XC = 64 / T::NSTEP > 0 ? 64 / T::NSTEP : 1;       // <= 64 fragment registers per chunk
+    static_assert(T::XM % XC == 0, "chunking of the m-tile list");
+    for (int x0 = 0; x0 < T::XM; x0 += XC) {
+      int z = 0;
+      asm volatile("" : "+v"(z));        // per-chunk opaque lane id: no hoisting of the next chunk's loads
+      float w[XC * T::NSTEP];
+      load_wfrag_x<S, k, XC>(w, packed, wave, lane + z, x0);
+      lin_stage_x<S, k, G, XC>(w, in, out, wave, lane + z, ilv_mode, x0);
+    }
+  }
 }
 
 template <class S>
@@ -236,9 +379,12 @@ bool big_rnn_fwd_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH1024R32L>(rs.hid_s) && shape_matches<ShpH1024R32L>(rs.in_s);
 }
 
-static bool big_merge_enabled() {
-  const char* e = getenv("TTRNN_BIG_NO_MERGE");      // A/B switch: run the four-core chain as is
-  return !(e && e[0] == '1');
+// how many pairs of cores are contracted per launch: 2 (default: first two and last two -> a 2-core matrix),
+// 1 (first two only), 0 (the four-core chain as is).  TTRNN_BIG_MERGE is an A/B switch.
+static int big_merge_level() {
+  const char* e = getenv("TTRNN_BIG_MERGE");
+  if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
+  return 2;
 }
 
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {
@@ -246,8 +392,10 @@ size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   const size_t gin = (size_t)rs.B * rs.T * rs.H * 4 * sizeof(float);
   const size_t lin = (size_t)BIG_LIN_GRID * 3 * MID * sizeof(float);
   const size_t rec = (size_t)rs.B * 2 * MID * sizeof(float);
-  const size_t merged = 2 * (((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255);
-  return gin + (lin > rec ? lin : rec) + merged;
+  // per TT-matrix: the 3-core and the 2-core merged packed buffers
+  const size_t m3 = ((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255;
+  const size_t m2 = ((size_t)merged2_elems<ShpH1024R32L_M2>() * sizeof(float) + 255) & ~(size_t)255;
+  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2);
 }
 
 template <typename TS>
@@ -263,20 +411,37 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
   const int grid = (int)(n_rows < BIG_LIN_GRID ? n_rows : BIG_LIN_GRID);
   const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
   const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
-  if (big_merge_enabled()) {
-    // the merged cores live behind the slab region (the tail of the workspace)
-    const size_t mbytes = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
-    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * mbytes;
-    float* m_in = (float*)tail;
-    float* m_hid = (float*)(tail + mbytes);
-    const int mg = (merged_elems<S3>() + 255) / 256;
-    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(mg), dim3(256), 0, stream, packed_in, m_in);
-    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(mg), dim3(256), 0, stream, packed_hid, m_hid);
-    hipLaunchKernelGGL((k_ttlinear_fwd_big<S3, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, m_in,
+  const int level = big_merge_level();
+  if (level > 0) {
+    // the merged cores live behind the slab region (the tail of the workspace): [m3_in | m3_hid | m2_in | m2_hid]
+    using S2 = ShpH1024R32L_M2;
+    static_assert(big_mid<S2>() <= big_mid<S4>(), "slab size");
+    const size_t b3 = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
+    const size_t b2 = ((size_t)merged2_elems<S2>() * sizeof(float) + 255) & ~(size_t)255;
+    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2);
+    float* m3_in = (float*)tail;
+    float* m3_hid = (float*)(tail + b3);
+    float* m2_in = (float*)(tail + 2 * b3);
+    float* m2_hid = (float*)(tail + 2 * b3 + b2);
+    const int g3 = (merged_elems<S3>() + 255) / 256;
+    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(g3), dim3(256), 0, stream, packed_in, m3_in);
+    hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3(g3), dim3(256), 0, stream, packed_hid, m3_hid);
+    if (level == 1) {
+      hipLaunchKernelGGL((k_ttlinear_fwd_big<S3, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, m3_in,
+                         (const TS*)x, gin, slab, 2);
+      if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+      hipLaunchKernelGGL((k_rnn_fwd_big<S3, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                         (const TS*)h0, (const TS*)c0, m3_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
+      return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    }
+    const int g2 = (merged2_elems<S2>() + 255) / 256;
+    hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3(g2), dim3(256), 0, stream, m3_in, m2_in);
+    hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3(g2), dim3(256), 0, stream, m3_hid, m2_hid);
+    hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, m2_in,
                        (const TS*)x, gin, slab, 2);
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL((k_rnn_fwd_big<S3, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                       (const TS*)h0, (const TS*)c0, m_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
+    hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
+                       (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
     return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((k_ttlinear_fwd_big<S4, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed_in,
