@@ -174,3 +174,24 @@ def test_descriptor_validation_without_gpu():
                      TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
     # NULL pointers are rejected before anything is launched
     assert lib.ttrnn_rnn_forward(ctypes.byref(d), *([None] * 12), 0, None) == -2
+
+
+def test_fp32_math_mode_switch_without_gpu():
+    """ttrnn_set_fp32_math / ttrnn_get_fp32_math (include/ttrnn.h): pure host state, no device needed."""
+    import ttrnn_hip
+    from ttrnn_hip import _lib
+    lib = _lib.load()
+    start = ttrnn_hip.get_fp32_math()
+    assert start in ("split", "exact")
+    try:
+        assert ttrnn_hip.set_fp32_math("exact") == start
+        assert ttrnn_hip.get_fp32_math() == "exact" and lib.ttrnn_get_fp32_math() == 0
+        with ttrnn_hip.fp32_math("split"):
+            assert lib.ttrnn_get_fp32_math() == 1
+        assert ttrnn_hip.get_fp32_math() == "exact"            # restored by the context manager
+        assert lib.ttrnn_set_fp32_math(7) == -3                # TTRNN_ERR_UNSUPPORTED, mode unchanged
+        assert ttrnn_hip.get_fp32_math() == "exact"
+        with pytest.raises(ValueError):
+            ttrnn_hip.set_fp32_math("tf32")
+    finally:
+        ttrnn_hip.set_fp32_math(start)
