@@ -57,26 +57,43 @@ __global__ void __launch_bounds__(256) k_merge_cores01(const float* __restrict__
 using ShpH1024R32L_M2 = Shp<2, 16, 64, 1, 1, 64, 64, 1, 1, 32, 1, 1>;
 
 // packed3: [W'_0 | W'_1 | W'_2] of S3;  packed2: [W''_0 = W'_0 | W''_1 = merged W'_1,W'_2] of S2
+// The two-core buffer is stored in MFMA-FRAGMENT order (what load_wfrag would gather with one 4-byte load per k-step
+// becomes one coalesced 16-byte load per four k-steps):  for stage k, m-tile mt, fragment group u, lane (r, q):
+//     frag_k[((mt*NU_k + u)*64 + lane)*4 + e] = W_k[kk = (4u + q)*4 + e][m = 16 mt + r]
+template <class S, int k>
+__device__ __forceinline__ void frag_decode(int idx, int& kk, int& m) {
+  using T = St<S, k>;
+  static_assert(T::WV == 4 && T::K % 16 == 0 && T::M % 16 == 0, "fragment order needs 16-byte fragment reads");
+  const int e = idx & 3, lane = (idx >> 2) & 63, g = idx >> 8;
+  const int u = g % T::NU, mt = g / T::NU;
+  kk = (4 * u + (lane >> 4)) * 4 + e;
+  m = 16 * mt + (lane & 15);
+}
+
 template <class S3, class S2>
 __global__ void __launch_bounds__(256) k_merge_cores_last(const float* __restrict__ packed3,
                                                           float* __restrict__ packed2) {
-  constexpr int J1 = S3::J[1], J2 = S3::J[2], I1 = S3::I[1], I2 = S3::I[2], R1 = S3::R[1], R2 = S3::R[2];
-  constexpr int N0 = S3::J[0] * R1 * S3::I[0];
+  constexpr int J2 = S3::J[2], I1 = S3::I[1], I2 = S3::I[2], R1 = S3::R[1], R2 = S3::R[2];
+  constexpr int M0 = S3::I[0], N0 = S3::J[0] * R1 * M0;
   constexpr int K1 = S2::J[1], M1 = S2::I[1] * S2::R[1];       // W''_1 [J1*J2][I1*I2*R1]
-  static_assert(S2::J[1] == J1 * J2 && S2::I[1] == I1 * I2 && S2::R[1] == R1 && S2::J[0] == S3::J[0] &&
+  static_assert(S2::J[1] == S3::J[1] * J2 && S2::I[1] == I1 * I2 && S2::R[1] == R1 && S2::J[0] == S3::J[0] &&
                     S2::I[0] == S3::I[0] && S3::R[3] == 1, "merged shape");
+  const float* W0 = packed3 + woff_of<S3>(0);
   const float* W1 = packed3 + woff_of<S3>(1);                  // [J1*R2][I1*R1]
   const float* W2 = packed3 + woff_of<S3>(2);                  // [J2*1][I2*R2]
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < N0) {
-    packed2[woff_of<S2>(0) + e] = packed3[woff_of<S3>(0) + e];
+    int kk, m;
+    frag_decode<S2, 0>(e, kk, m);
+    packed2[woff_of<S2>(0) + e] = W0[kk * M0 + m];
   } else if (e < N0 + K1 * M1) {
-    const int f = e - N0, kk = f / M1, mm = f % M1;            // kk = j1*J2 + j2;  mm = (i1*I2 + i2)*R1 + a
+    int kk, mm;                                                // kk = j1*J2 + j2;  mm = (i1*I2 + i2)*R1 + a
+    frag_decode<S2, 1>(e - N0, kk, mm);
     const int j1 = kk / J2, j2 = kk % J2, a = mm % R1, ii = mm / R1, i1 = ii / I2, i2 = ii % I2;
     float v = 0.f;
     for (int r2 = 0; r2 < R2; ++r2)
       v = fmaf(W1[(j1 * R2 + r2) * (I1 * R1) + i1 * R1 + a], W2[j2 * (I2 * R2) + i2 * R2 + r2], v);
-    packed2[woff_of<S2>(1) + f] = v;
+    packed2[woff_of<S2>(1) + e - N0] = v;
   }
 }
 
@@ -186,6 +203,44 @@ __device__ __forceinline__ void lin_stage_x(const float (&w)[NW_], const float* 
   }
 }
 
+// fragment-ordered buffers (two-core matrices, see k_merge_cores_last): 16-byte loads
+template <class S>
+constexpr bool big_frag_order() { return S::D == 2; }
+
+template <class S, int k, int NW_>
+__device__ __forceinline__ void load_wfrag_f(float (&w)[NW_], const float* packed, int wave, int lane) {
+  using T = St<S, k>;
+  static_assert(NW_ == T::NWREG && T::WV == 4, "fragment array size");
+  const f32x4* F = reinterpret_cast<const f32x4*>(packed + woff_of<S>(k));
+#pragma unroll
+  for (int x = 0; x < T::XM; ++x) {
+    const int mt = T::SPLIT ? (wave % T::MT) : (wave + FAST_NW * x);
+#pragma unroll
+    for (int u = 0; u < T::NU; ++u) {
+      const f32x4 v = F[(size_t)((mt < T::MT ? mt : 0) * T::NU + u) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[x * T::NSTEP + 4 * u + e] = mt < T::MT ? v[e] : 0.f;
+    }
+  }
+}
+
+template <class S, int k, int XC, int NW_>
+__device__ __forceinline__ void load_wfrag_xf(float (&w)[NW_], const float* packed, int wave, int lane, int x0) {
+  using T = St<S, k>;
+  static_assert(!T::SPLIT && NW_ == XC * T::NSTEP && T::WV == 4, "chunked stages own whole m-tiles");
+  const f32x4* F = reinterpret_cast<const f32x4*>(packed + woff_of<S>(k));
+#pragma unroll
+  for (int x = 0; x < XC; ++x) {
+    const int mt = wave + FAST_NW * (x0 + x);
+#pragma unroll
+    for (int u = 0; u < T::NU; ++u) {
+      const f32x4 v = F[(size_t)((mt < T::MT ? mt : 0) * T::NU + u) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[x * T::NSTEP + 4 * u + e] = mt < T::MT ? v[e] : 0.f;
+    }
+  }
+}
+
 // One chain stage.  Stages whose fragment set (XM m-tiles x NSTEP k-steps per wave) would not fit the register file
 // go through it in chunks of XC m-tiles.
 template <class S, int k, int G>
@@ -196,7 +251,8 @@ __device__ __forceinline__ void big_stage(const float* packed, const float* in, 
     int z = 0;
     asm volatile("" : "+v"(z));          // keep the fragment loads and their address arithmetic inside this stage
     float w[nwreg<S, k>()];
-    load_wfrag<S, k>(w, packed, wave, lane + z);
+    if constexpr (big_frag_order<S>()) load_wfrag_f<S, k>(w, packed, wave, lane + z);
+    else load_wfrag<S, k>(w, packed, wave, lane + z);
     lin_stage<S, k, 1, G>(w, in, out, wave, lane + z, ilv_mode);
   } else {
     constexpr int XC = 64 / T::NSTEP > 0 ? 64 / T::NSTEP : 1;       // <= 64 fragment registers per chunk
@@ -205,7 +261,8 @@ __device__ __forceinline__ void big_stage(const float* packed, const float* in, 
       int z = 0;
       asm volatile("" : "+v"(z));        // per-chunk opaque lane id: no hoisting of the next chunk's loads
       float w[XC * T::NSTEP];
-      load_wfrag_x<S, k, XC>(w, packed, wave, lane + z, x0);
+      if constexpr (big_frag_order<S>()) load_wfrag_xf<S, k, XC>(w, packed, wave, lane + z, x0);
+      else load_wfrag_x<S, k, XC>(w, packed, wave, lane + z, x0);
       lin_stage_x<S, k, G, XC>(w, in, out, wave, lane + z, ilv_mode, x0);
     }
   }
@@ -219,6 +276,13 @@ constexpr int big_mid() {      // floats of the largest stage image
     if (e > best) best = e;
   }
   return best;
+}
+
+// a two-core matrix whose single intermediate image (+ input image, h and gate vectors) fits the 160 KB of LDS
+template <class S>
+constexpr bool big_lds_images() {
+  return S::D == 2 && (size_t)(big_mid<S>() + in_size_of<S>() + in_size_of<S>() + out_size_of<S>()) * sizeof(float) <=
+                          156 * 1024;
 }
 
 __device__ __forceinline__ float bsigmoid(float x) {
@@ -269,8 +333,12 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_fwd_big(int64_t n_rows, co
   constexpr int YT = G == 0 ? OUT : (OUT / (G > 0 ? G : 1)) * 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* img0 = ws + (size_t)blockIdx.x * 3 * MID;
-  float* imgA = img0 + MID;
+  // two-core matrices need ONE intermediate image (plus the input image): both stay in LDS when they fit; deeper
+  // chains ping-pong through the L2-resident slab
+  extern __shared__ __attribute__((aligned(16))) float big_lds[];
+  constexpr bool LDSIMG = big_lds_images<S>();
+  float* img0 = LDSIMG ? big_lds : ws + (size_t)blockIdx.x * 3 * MID;
+  float* imgA = LDSIMG ? big_lds + IN : img0 + MID;
   float* imgB = imgA + MID;
   for (int64_t n = blockIdx.x; n < n_rows; n += gridDim.x) {
     for (int e = tid; e < IN; e += FAST_NT) img0[a_off<SL::KP>(e / SL::K, e % SL::K)] = ld(x, (size_t)n * IN + e);
@@ -303,7 +371,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t b = blockIdx.x;
-  float* imgA = ws + (size_t)blockIdx.x * 2 * MID;
+  extern __shared__ __attribute__((aligned(16))) float big_lds[];
+  constexpr bool LDSIMG = big_lds_images<S>();              // see k_ttlinear_fwd_big
+  float* imgA = LDSIMG ? big_lds : ws + (size_t)blockIdx.x * 2 * MID;
   float* imgB = imgA + MID;
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
 
@@ -437,11 +507,28 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     const int g2 = (merged2_elems<S2>() + 255) / 256;
     hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3(g2), dim3(256), 0, stream, m3_in, m2_in);
     hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3(g2), dim3(256), 0, stream, m3_hid, m2_hid);
-    hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, m2_in,
+    // the two-core chain keeps its images in LDS (dynamic, > 64 KB: raise the limit once per kernel)
+    static_assert(big_lds_images<S2>(), "two-core images must fit LDS");
+    constexpr size_t lds_lin = (size_t)(big_mid<S2>() + in_size_of<S2>()) * sizeof(float);
+    constexpr size_t lds_rec = (size_t)big_mid<S2>() * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttlinear_fwd_big<S2, 4, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lin) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(k_rnn_fwd_big<S2, TTRNN_LSTM, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid2 = (int)(n_rows < cus ? n_rows : cus);          // one workgroup per CU (LDS)
+    hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid2), dim3(FAST_NT), lds_lin, stream, n_rows, m2_in,
                        (const TS*)x, gin, slab, 2);
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
-                       (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, slab);
+    hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), lds_rec, stream, rs.B, rs.T,
+                       gin, (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve,
+                       slab);
     return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((k_ttlinear_fwd_big<S4, 4, TS>), dim3(grid), dim3(FAST_NT), 0, stream, n_rows, packed_in,
