@@ -568,3 +568,31 @@ def test_fused_core_edge_cases_vs_oracle(rank):
         with torch.no_grad():
             out, (hT, cT) = m(x.to(dev()), None if init is None else (init[0].to(dev()), init[1].to(dev())))
         assert _maxabs(out, ro) <= 1e-5 and _maxabs(hT, rh) <= 1e-5 and _maxabs(cT, rc) <= 1e-5, (B, T, with_init)
+
+
+def test_big_shape_merge_levels_and_bf16_storage():
+    """cfg5-class matrix (H = in = 1024, d = 4, r = 32): the three contraction groupings (TTRNN_BIG_MERGE = 2, 1, 0) agree
+    with the oracle, and bf16 storage runs through the same kernels (2e-2 vs the fp32 oracle on bf16-rounded weights)."""
+    import os
+    torch.manual_seed(55)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    x = torch.randn(3, 4, 1024)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ro, rh, rc = _oracle_forward("ttlstm", sd, 1, x)
+    try:
+        for level in ("2", "1", "0"):
+            os.environ["TTRNN_BIG_MERGE"] = level
+            with torch.no_grad():
+                out, (hT, cT) = m(x.to(dev()))
+            assert _maxabs(out, ro) <= 1e-5 and _maxabs(cT, rc) <= 1e-5, level
+    finally:
+        os.environ.pop("TTRNN_BIG_MERGE", None)
+    mb = build_module(meta, dev()).to(torch.bfloat16)
+    sdb = {k: v.detach().cpu().float() for k, v in mb.state_dict().items()}
+    xb = x.to(torch.bfloat16)
+    rob, _, rcb = _oracle_forward("ttlstm", sdb, 1, xb.float())
+    with torch.no_grad():
+        outb, (hb, cb) = mb(xb.to(dev()))
+    assert outb.dtype == torch.bfloat16
+    assert _maxabs(outb.float(), rob) <= 2e-2 and _maxabs(cb.float(), rcb) <= 2e-2
