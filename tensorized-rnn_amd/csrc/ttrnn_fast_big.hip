@@ -130,9 +130,10 @@ __device__ __forceinline__ void load_wfrag_x(float (&w)[NW_], const float* packe
 }
 
 // lin_stage (ttrnn_mfma.h) restricted to that chunk of m-tiles, one sample (NB = 1)
+// out_row0: first row of the next stage's image that lives at Cout (a workgroup that owns only a slice of the rows)
 template <class S, int k, int G, int XC, int NW_>
 __device__ __forceinline__ void lin_stage_x(const float (&w)[NW_], const float* Ain, float* Cout, int wave, int lane,
-                                            int ilv_mode, int x0) {
+                                            int ilv_mode, int x0, int out_row0 = 0) {
   using T = St<S, k>;
   static_assert(NW_ == XC * T::NSTEP, "fragment array size");
   constexpr int TOT = T::ROWS;
@@ -191,7 +192,7 @@ __device__ __forceinline__ void lin_stage_x(const float (&w)[NW_], const float* 
             using N = St<S, k - 1>;
             const int i = m0 / T::R, a0 = m0 % T::R;
             const int f = i * (T::ROWS * T::R) + R * T::R + a0;
-            *reinterpret_cast<f32x4*>(Cout + a_off<N::KP>(f / N::K, f % N::K)) = a;
+            *reinterpret_cast<f32x4*>(Cout + a_off<N::KP>(f / N::K - out_row0, f % N::K)) = a;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -441,6 +442,150 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
   }
 }
 
+// ---- two workgroups per sample (two-core matrices, LSTM) ------------------------------------------------------------
+// With B = 128 samples the one-workgroup-per-sample kernel leaves half of the 256 CUs idle.  Both stages of the
+// two-core chain split cleanly over the rows of the SECOND stage: stage 1's output features are (i1, r1) and become,
+// viewed flat, the rows i1 of stage 0, whose rows are independent and end up as the low part of the hidden index
+// (hid = (m0 % 16) * I1 + i1).  Workgroup `half` of a pair therefore computes the m-tiles of stage 1 with
+// i1 in [half*I1/2, (half+1)*I1/2) (half of W_1 streamed), stage 0 on those rows, and the gates of those H/2 hidden
+// units — no exchange inside a step.  Once per step the halves of h_t are swapped through a double-buffered global
+// row and a release/acquire counter at agent scope (both workgroups are resident: 2B <= #CUs, one workgroup per CU).
+template <class S, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const float* __restrict__ gin,
+                                                           const TS* __restrict__ h0, const TS* __restrict__ c0,
+                                                           const float* __restrict__ packed,
+                                                           const TS* __restrict__ bias_in,
+                                                           const TS* __restrict__ bias_hid, TS* __restrict__ out,
+                                                           TS* __restrict__ hT, TS* __restrict__ cT,
+                                                           float* __restrict__ reserve, float* __restrict__ hx,
+                                                           unsigned int* __restrict__ sync) {
+  static_assert(S::D == 2 && big_frag_order<S>(), "two-core matrices in fragment order");
+  using T1 = St<S, 1>;
+  using T0 = St<S, 0>;
+  constexpr int H = in_size_of<S>(), I1 = S::I[1], HR = T0::ROWS / 2;      // HR: stage-0 rows per workgroup
+  static_assert(out_size_of<S>() == 4 * H && T0::ROWS == I1 && HR % 16 == 0 && H / 2 == FAST_NT && T0::M == 64 &&
+                    T0::MT * (HR / 16) == FAST_NW && !T1::SPLIT && T1::XM % 2 == 0 && T1::K % 4 == 0,
+                "pair layout");
+  constexpr int XC = 64 / T1::NSTEP > 0 ? 64 / T1::NSTEP : 1;
+  static_assert((T1::XM / 2) % XC == 0, "chunking of the half m-tile list");
+
+  __shared__ __attribute__((aligned(16))) float hbuf[H];                 // h_{t-1}, image of stage 1
+  __shared__ __attribute__((aligned(16))) float gb[T0::M * HR];          // pre-activations [m0][local row]
+  extern __shared__ __attribute__((aligned(16))) float big_lds[];        // image of stage 0: [HR rows][K0]
+  float* img = big_lds;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x >> 1;
+  const int half = blockIdx.x & 1;
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+
+  // gate phase: thread tid owns hid = (tid / HR) * I1 + half*HR + tid % HR  (m0 % 16 = tid / HR, local row tid % HR)
+  const int rl = tid % HR, mq = tid / HR;
+  const int hid = mq * I1 + half * HR + rl;
+  const int hidp = mq * I1 + (1 - half) * HR + rl;                       // the partner's unit at the same position
+  float hst = h0 ? ld(h0, b * H + hid) : 0.f;
+  float cst = c0 ? ld(c0, b * H + hid) : 0.f;
+  float bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    bh[g] = (bias_hid ? ld(bias_hid, g * H + hid) : 0.f) + (bias_in ? ld(bias_in, g * H + hid) : 0.f);
+  hbuf[a_off<T1::KP>(hid / T1::K, hid % T1::K)] = hst;
+  hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = h0 ? ld(h0, b * H + hidp) : 0.f;
+  f32x4 gi = T > 0 ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};     // slots i,g,f,o; prefetched a step ahead
+  unsigned int* flag = sync + b;
+  bool dead = false;                                       // thread 0 only
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    // ---- stage 1: this workgroup's half of the m-tiles, result = its HR rows of the stage-0 image -------------------
+    for (int x0 = half * (T1::XM / 2); x0 < (half + 1) * (T1::XM / 2); x0 += XC) {
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      float w[XC * T1::NSTEP];
+      load_wfrag_xf<S, 1, XC>(w, packed, wave, lane + z, x0);
+      lin_stage_x<S, 1, 0, XC>(w, hbuf, img, wave, lane + z, 0, x0, half * HR);
+    }
+    __syncthreads();
+    // ---- stage 0 on the local rows: wave = (m-tile wave % MT, local row tile wave / MT) ---------------------------
+    {
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      const int mt = wave % T0::MT, rtl = wave / T0::MT;
+      const f32x4* F = reinterpret_cast<const f32x4*>(packed + woff_of<S>(0));
+      const int row = 16 * rtl + c;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      constexpr int UC = 8;                                   // fragment groups per chunk (32 k-steps)
+#pragma unroll 1
+      for (int u0 = 0; u0 < T0::NU; u0 += UC) {
+        f32x4 wf[UC], af[UC];
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          wf[u] = F[(size_t)(mt * T0::NU + u0 + u) * 64 + lane + z];
+          af[u] = *reinterpret_cast<const f32x4*>(img + a_off<T0::KP>(row, (4 * (u0 + u) + q) * 4));
+        }
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], af[u][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], af[u][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], af[u][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], af[u][3], acc1, 0, 0, 0);
+        }
+      }
+      const f32x4 acc = acc0 + acc1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gb[(16 * mt + 4 * q + j) * HR + row] = acc[j];      // [m0][local row]
+    }
+    __syncthreads();
+    // ---- gates (lstm.py:26-32): o = m0*I1 + i1, gate = m0 / 16 ---------------------------------------------------------
+    const size_t bt = b * T + t;
+    {
+      const float ig = bsigmoid(gi[0] + gb[(0 * 16 + mq) * HR + rl] + bh[0]);
+      const float fg = bsigmoid(gi[2] + gb[(1 * 16 + mq) * HR + rl] + bh[1]);
+      const float gg = btanh(gi[1] + gb[(2 * 16 + mq) * HR + rl] + bh[2]);
+      const float og = bsigmoid(gi[3] + gb[(3 * 16 + mq) * HR + rl] + bh[3]);
+      const float cy = fg * cst + ig * gg;
+      float hy = og * btanh(cy);
+      cst = cy;
+      if (reserve) {
+        float* rv = reserve + (bt * H + hid) * 8;
+        rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+      }
+      st(out, bt * H + hid, hy);
+      hy = ld(out, bt * H + hid);                  // what the next step sees: rounded once to the storage type
+      hst = hy;
+      hbuf[a_off<T1::KP>(hid / T1::K, hid % T1::K)] = hy;
+      __hip_atomic_store(hx + (b * 2 + (t & 1)) * H + hid, hy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
+    }
+    // ---- swap halves of h_t with the partner workgroup -------------------------------------------------------------
+    __syncthreads();
+    if (tid == 0) {
+      // relaxed agent-scope atomics only: they are performed at the memory side, coherent across XCDs, WITHOUT the
+      // L2 write-back / invalidate a release / acquire pair costs (that flush evicted the streamed cores every step and
+      // ate the whole gain); ordering comes from the barrier before (all h stores acknowledged) and after
+      __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = 2u * (unsigned int)(t + 1);
+      // bounded: a partner that is not resident must not hang the GPU — after one time-out (~0.1 s) stop waiting for
+      // the rest of the launch (the results are then wrong, which the parity tests would show, but the kernel ends)
+      long spin = 0;
+      while (!dead && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spin > (1L << 21)) dead = true;
+      }
+    }
+    __syncthreads();
+    {
+      const float hp = __hip_atomic_load(hx + (b * 2 + (t & 1)) * H + hidp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = hp;
+    }
+    __syncthreads();
+  }
+  if (hT) st(hT, b * H + hid, hst);
+  if (cT) st(cT, b * H + hid, cst);
+}
+
 // ---- dispatch -------------------------------------------------------------------------------------------------------
 static constexpr int BIG_LIN_GRID = 512;     // workgroups of the batched projection (2 per CU)
 
@@ -465,7 +610,8 @@ size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   // per TT-matrix: the 3-core and the 2-core merged packed buffers
   const size_t m3 = ((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255;
   const size_t m2 = ((size_t)merged2_elems<ShpH1024R32L_M2>() * sizeof(float) + 255) & ~(size_t)255;
-  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2);
+  const size_t pair = (size_t)rs.B * 2 * rs.H * sizeof(float) + (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
+  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair;      // + h exchange rows and counters of the pair kernel
 }
 
 template <typename TS>
@@ -488,7 +634,9 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     static_assert(big_mid<S2>() <= big_mid<S4>(), "slab size");
     const size_t b3 = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
     const size_t b2 = ((size_t)merged2_elems<S2>() * sizeof(float) + 255) & ~(size_t)255;
-    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2);
+    const size_t pair_bytes = (size_t)rs.B * 2 * rs.H * sizeof(float) +
+                              (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
+    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes;
     float* m3_in = (float*)tail;
     float* m3_hid = (float*)(tail + b3);
     float* m2_in = (float*)(tail + 2 * b3);
@@ -526,6 +674,27 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid2), dim3(FAST_NT), lds_lin, stream, n_rows, m2_in,
                        (const TS*)x, gin, slab, 2);
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+    const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
+    if (2 * rs.B <= cus && !(np && np[0] == '1')) {
+      // two workgroups per sample: h exchange rows [B][2][H] + counters behind the merged cores
+      float* hxb = (float*)(tail + 2 * (b3 + b2));
+      unsigned int* cnt = (unsigned int*)((char*)hxb + (size_t)rs.B * 2 * rs.H * sizeof(float));
+      if (hipMemsetAsync(cnt, 0, (size_t)rs.B * sizeof(unsigned int), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+      // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (76 KB each would fit twice, and
+      // the dispatcher then packs the pairs onto half of the CUs: measured no faster than one workgroup per sample)
+      constexpr size_t lds_img = (size_t)(St<S2, 0>::ROWS / 2) * St<S2, 0>::KP * sizeof(float);
+      constexpr size_t lds_pair = lds_img > 100 * 1024 ? lds_img : 100 * 1024;
+      static bool raised2 = false;
+      if (!raised2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair) != hipSuccess)
+          return TTRNN_ERR_LAUNCH;
+        raised2 = true;
+      }
+      hipLaunchKernelGGL((k_lstm_fwd_big2<S2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
+                         (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb, cnt);
+      return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), lds_rec, stream, rs.B, rs.T,
                        gin, (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve,
                        slab);

@@ -596,3 +596,25 @@ def test_big_shape_merge_levels_and_bf16_storage():
         outb, (hb, cb) = mb(xb.to(dev()))
     assert outb.dtype == torch.bfloat16
     assert _maxabs(outb.float(), rob) <= 2e-2 and _maxabs(cb.float(), rcb) <= 2e-2
+
+
+def test_big_shape_two_workgroups_per_sample_matches_one():
+    """cfg5-class K-rec with two cooperating workgroups per sample (halves of h swapped through global memory once per
+    step) against the one-workgroup kernel: many steps, many samples, bitwise-equal arithmetic order per hidden unit."""
+    import os
+    torch.manual_seed(56)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    x = torch.randn(24, 96, 1024, device=dev())
+    h0, c0 = torch.randn(24, 1024, device=dev()) * 0.3, torch.randn(24, 1024, device=dev()) * 0.3
+    res = []
+    try:
+        for flag in ("0", "1"):
+            os.environ["TTRNN_BIG_NO_PAIR"] = flag
+            with torch.no_grad():
+                out, (hT, cT) = m(x, (h0, c0))
+            res.append((out.clone(), cT.clone()))
+    finally:
+        os.environ.pop("TTRNN_BIG_NO_PAIR", None)
+    assert torch.isfinite(res[0][0]).all()
+    assert _maxabs(res[0][0], res[1][0]) <= 2e-6 and _maxabs(res[0][1], res[1][1]) <= 2e-6
