@@ -95,6 +95,8 @@ size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   if (s.in_size == 1 && in1_bwd_bytes(s) > ws) ws = in1_bwd_bytes(s);
   const size_t f10w = f10_ttlinear_wgrad_workspace_bytes(s);      // fused-core weight gradients (any math mode)
   if (f10w > ws) ws = f10w;
+  const size_t bigw = big_ttlinear_wgrad_workspace_bytes(s);      // merged-core weight gradients of the big shape
+  if (bigw > 0) ws = ((ws + 255) & ~(size_t)255) + bigw;          // behind what the any-shape dx pass needs
   return ws;
 }
 
@@ -154,6 +156,16 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
   }
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+  if (!force_generic() && d_packed && big_ttlinear_wgrad_available(s, dtype, dy_dtype)) {
+    // big shape: weight / bias gradients through the merged two-core matrix; dx (if asked for) by the any-shape kernel
+    const size_t off = (p.ws_bytes + 255) & ~(size_t)255;
+    if (!workspace || workspace_bytes < off + big_ttlinear_wgrad_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
+    st = launch_ttlinear_wgrad_big(s, dtype, n_rows, packed, x, dy, d_packed, d_bias, (char*)workspace + off,
+                                   (hipStream_t)stream);
+    if (st != TTRNN_OK || !dx) return st;
+    return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, nullptr, nullptr, workspace,
+                               (hipStream_t)stream);
+  }
   return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                              (hipStream_t)stream);
 }
@@ -208,6 +220,7 @@ size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
   if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
     return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
+  if (!force_generic() && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
 }
 
@@ -303,6 +316,11 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
     }
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);
+  }
+  if (!force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
+    if (!workspace || workspace_bytes < big_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_bwd_big(rs, desc->dtype, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
+                              d_h0, d_c0, workspace, (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, true);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

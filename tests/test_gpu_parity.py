@@ -623,3 +623,63 @@ def test_big_shape_two_workgroups_per_sample_matches_one():
         os.environ.pop("TTRNN_BIG_NO_PAIR", None)
     assert torch.isfinite(res[0][0]).all()
     assert _maxabs(res[0][0], res[1][0]) <= 2e-6 and _maxabs(res[0][1], res[1][1]) <= 2e-6
+
+
+def test_big_shape_gradients_vs_oracle():
+    """cfg5-class BPTT through the merged two-core matrix (reverse-time kernel with two workgroups per sample, weight
+    gradients accumulated in MFMA registers, product rule back to the four cores) against the oracle's autograd: every
+    core and bias gradient, the input gradient (any-shape dx pass) and the initial-state gradients."""
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(57)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 3, 5
+    x = torch.randn(B, T, 1024)
+    h0, c0 = torch.randn(B, 1024) * 0.3, torch.randn(B, 1024) * 0.3
+    w = torch.randn(B, T, 1024)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+    xr, h0r, c0r = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    ((ro * w).sum() + rc.sum() + 0.5 * rh.sum()).backward()
+    xg, h0g, c0g = (t.to(dev()).requires_grad_(True) for t in (x, h0, c0))
+    out, (hT, cT) = m(xg, (h0g, c0g))
+    ((out * w.to(dev())).sum() + cT.sum() + 0.5 * hT.sum()).backward()
+    assert _maxabs(out.detach(), ro.detach()) <= 1e-5
+    for name, p in m.named_parameters():
+        ref = leaves[name].grad
+        assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    for got, ref in ((xg.grad, xr.grad), (h0g.grad, h0r.grad), (c0g.grad, c0r.grad)):
+        assert _maxabs(got, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_big_shape_backward_kernels_agree(dtype):
+    """The three cfg5-class backward paths on the same module and inputs: pair kernel + merged-core weight gradients
+    (default), one workgroup per sample (TTRNN_BIG_NO_PAIR=1), any-shape kernels (TTRNN_NO_BIGB=1).  Many rows per
+    weight-gradient workgroup (B*T = 260 > 64 row chunks), no input gradient, zero initial state."""
+    import os
+    torch.manual_seed(58)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev()).to(dtype)
+    B, T = 20, 13
+    x = torch.randn(B, T, 1024, device=dev()).to(dtype)
+    w = torch.randn(B, T, 1024, device=dev())
+    res = []
+    try:
+        for env in ({}, {"TTRNN_BIG_NO_PAIR": "1"}, {"TTRNN_NO_BIGB": "1"}):
+            os.environ.update(env)
+            m.zero_grad()
+            out, (hT, cT) = m(x)
+            ((out.float() * w).sum() + cT.float().sum()).backward()
+            res.append([p.grad.float().clone() for p in m.parameters()])
+            for k in env:
+                os.environ.pop(k)
+    finally:
+        os.environ.pop("TTRNN_BIG_NO_PAIR", None)
+        os.environ.pop("TTRNN_NO_BIGB", None)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for (name, _), a, b, c in zip(m.named_parameters(), *res):
+        scale = max(float(c.abs().max()), 1e-6)
+        assert _maxabs(a, c) <= tol * scale, ("pair", name)
+        assert _maxabs(b, c) <= tol * scale, ("single", name)
