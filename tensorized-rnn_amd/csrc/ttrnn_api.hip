@@ -95,8 +95,8 @@ size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   if (s.in_size == 1 && in1_bwd_bytes(s) > ws) ws = in1_bwd_bytes(s);
   const size_t f10w = f10_ttlinear_wgrad_workspace_bytes(s);      // fused-core weight gradients (any math mode)
   if (f10w > ws) ws = f10w;
-  const size_t bigw = big_ttlinear_wgrad_workspace_bytes(s);      // merged-core weight gradients of the big shape
-  if (bigw > 0) ws = ((ws + 255) & ~(size_t)255) + bigw;          // behind what the any-shape dx pass needs
+  const size_t bigw = big_ttlinear_bwd_workspace_bytes(s);        // merged-core backward of the big shape
+  if (bigw > ws) ws = bigw;
   return ws;
 }
 
@@ -154,18 +154,13 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
     return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
                                     (hipStream_t)stream);
   }
+  if (!force_generic() && (d_packed || (dx && !d_bias)) && big_ttlinear_bwd_available(s, dtype, dy_dtype)) {
+    // big shape: dx, weight and bias gradients through the merged two-core matrix
+    if (!workspace || workspace_bytes < big_ttlinear_bwd_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
+    return launch_ttlinear_bwd_big(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream);
+  }
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
-  if (!force_generic() && d_packed && big_ttlinear_wgrad_available(s, dtype, dy_dtype)) {
-    // big shape: weight / bias gradients through the merged two-core matrix; dx (if asked for) by the any-shape kernel
-    const size_t off = (p.ws_bytes + 255) & ~(size_t)255;
-    if (!workspace || workspace_bytes < off + big_ttlinear_wgrad_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
-    st = launch_ttlinear_wgrad_big(s, dtype, n_rows, packed, x, dy, d_packed, d_bias, (char*)workspace + off,
-                                   (hipStream_t)stream);
-    if (st != TTRNN_OK || !dx) return st;
-    return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, nullptr, nullptr, workspace,
-                               (hipStream_t)stream);
-  }
   return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                              (hipStream_t)stream);
 }

@@ -55,6 +55,90 @@ __global__ void __launch_bounds__(256) k_bigb_prep(const float* __restrict__ pac
   }
 }
 
+// T0 of the transposed chain on the RL = 64 / NH local rows (i23) of the gate-gradient image dyimg[i23 local][i01]:
+//   img0[j01][(i23 local, r)] = sum_i01 A[(j01,r)][i01] dy[i01][i23];  m-tiles {wave + 8x}, two row tiles at a time
+template <class ST, int NH>
+__device__ __forceinline__ void bigT_stage1(const float* __restrict__ fragT, const float* dyimg, float* img0, int wave,
+                                            int lane) {
+  using T1 = St<ST, 1>;
+  using T0 = St<ST, 0>;
+  constexpr int RTL = T1::ROWS / NH / 16, K0L = T0::K / NH;
+  const int c = lane & 15, q = lane >> 4;
+  int z = 0;
+  asm volatile("" : "+v"(z));          // keep the fragment loads inside this phase
+  const f32x4* F1 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(1));
+  f32x4 wf[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wf[x][u] = F1[(size_t)((wave + FAST_NW * x) * T1::NU + u) * 64 + lane + z];
+#pragma unroll 1
+  for (int rtb = 0; rtb < RTL; rtb += 2) {
+    f32x4 af[2][4];
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        af[y][u] = *reinterpret_cast<const f32x4*>(dyimg + a_off<T1::K>(16 * (rtb + y) + c, (4 * u + q) * 4));
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = acc[x][0]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][u][e], af[0][u][e], acc[x][0], 0, 0, 0);
+          acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][u][e], af[1][u][e], acc[x][1], 0, 0, 0);
+        }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int m0 = 16 * (wave + FAST_NW * x) + 4 * q;       // (j01, r0 .. r0+3)
+      const int j01 = m0 / T1::R, r0 = m0 % T1::R;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+        *reinterpret_cast<f32x4*>(img0 + a_off<K0L>(j01, (16 * (rtb + y) + c) * T1::R + r0)) = acc[x][y];
+    }
+  }
+}
+
+// T1 over this workgroup's K slice: dhp[k half][j23][j01] = partial sum_(i23,r) img0[j01][(i23,r)] Bm[j23][(i23,r)];
+// wave = (m-tile wave % 4, k half wave / 4)
+template <class ST, int NH>
+__device__ __forceinline__ void bigT_stage0(const float* __restrict__ fragT, const float* img0, float* dhp, int half,
+                                            int wave, int lane) {
+  using T0 = St<ST, 0>;
+  constexpr int K0L = T0::K / NH, NUL = K0L / 16, NUW = NUL / 2;
+  const int c = lane & 15, q = lane >> 4;
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  const int mt = wave & 3, kh = wave >> 2;
+  const f32x4* F0 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(0));
+  const int ug0 = half * NUL + kh * NUW, ul0 = kh * NUW;
+  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  constexpr int UC = 8;
+#pragma unroll 1
+  for (int u0 = 0; u0 < NUW; u0 += UC) {
+    f32x4 wf[UC], af[UC];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      wf[u] = F0[(size_t)(mt * T0::NU + ug0 + u0 + u) * 64 + lane + z];
+      af[u] = *reinterpret_cast<const f32x4*>(img0 + a_off<K0L>(c, (4 * (ul0 + u0 + u) + q) * 4));
+    }
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], af[u][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], af[u][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], af[u][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], af[u][3], acc1, 0, 0, 0);
+    }
+  }
+  const f32x4 acc = acc0 + acc1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dhp[(kh * T0::M + 16 * mt + 4 * q + j) * 16 + c] = acc[j];
+}
+
 // ---- reverse-time kernel ------------------------------------------------------------------------------------------------
 template <class ST, int NH>
 constexpr size_t bigb_lds_bytes() { return (size_t)St<ST, 0>::ROWS * (St<ST, 0>::K / NH) * sizeof(float); }
@@ -74,8 +158,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
   constexpr int RL = I23 / NH;                // i23 values (rows of T0) of this workgroup
   constexpr int NUT = 2 / NH;                 // hidden units per thread
   constexpr int K0L = T0::K / NH;             // this workgroup's slice of T1's contraction
-  constexpr int RTL = RL / 16;
-  constexpr int NUL = K0L / 16, NUW = NUL / 2;      // 16-byte fragment groups: per workgroup / per wave
+  constexpr int RTL = RL / 16, NUW = K0L / 32;      // row tiles of T0; 16-byte fragment groups of T1 per wave
   static_assert((NH == 1 || NH == 2) && GH == 4 * H && T1::K == 64 && T1::NU == 4 && T1::MT == 4 * FAST_NW &&
                     T0::M == 64 && T0::ROWS == 16 && I23 == 64 && H == 2 * FAST_NT && T1::R == 32 && RTL % 2 == 0 &&
                     NUW % 8 == 0,
@@ -88,7 +171,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
   const size_t b = NH == 2 ? blockIdx.x >> 1 : blockIdx.x;
   const int half = NH == 2 ? (blockIdx.x & 1) : 0;
 
@@ -151,76 +233,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       fd[u] = d_out ? ld(d_out, b2 * H + hid[u]) : 0.f;
     }
     __syncthreads();
-    // ---- T0: dimg[i23][(j01,r)] = A dg on this workgroup's rows; m-tiles {wave + 8x} ---------------------------------
-    {
-      int z = 0;
-      asm volatile("" : "+v"(z));          // keep the fragment loads inside this phase
-      const f32x4* F1 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(1));
-      f32x4 wf[4][4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wf[x][u] = F1[(size_t)((wave + FAST_NW * x) * T1::NU + u) * 64 + lane + z];
-#pragma unroll 1
-      for (int rtb = 0; rtb < RTL; rtb += 2) {
-        f32x4 af[2][4];
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            af[y][u] = *reinterpret_cast<const f32x4*>(dyimg + a_off<T1::K>(16 * (rtb + y) + c, (4 * u + q) * 4));
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = acc[x][0]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][u][e], af[0][u][e], acc[x][0], 0, 0, 0);
-              acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][u][e], af[1][u][e], acc[x][1], 0, 0, 0);
-            }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int m0 = 16 * (wave + FAST_NW * x) + 4 * q;       // (j01, r0 .. r0+3)
-          const int j01 = m0 / T1::R, r0 = m0 % T1::R;
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-            *reinterpret_cast<f32x4*>(img0 + a_off<K0L>(j01, (16 * (rtb + y) + c) * T1::R + r0)) = acc[x][y];
-        }
-      }
-    }
+    bigT_stage1<ST, NH>(fragT, dyimg, img0, wave, lane);
     __syncthreads();
-    // ---- T1: partial dh[j01][j23] over this workgroup's K slice; wave = (m-tile wave % 4, k half wave / 4) ---------------
-    {
-      int z = 0;
-      asm volatile("" : "+v"(z));
-      const int mt = wave & 3, kh = wave >> 2;
-      const f32x4* F0 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(0));
-      const int ug0 = half * NUL + kh * NUW, ul0 = kh * NUW;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      constexpr int UC = 8;
-#pragma unroll 1
-      for (int u0 = 0; u0 < NUW; u0 += UC) {
-        f32x4 wf[UC], af[UC];
-#pragma unroll
-        for (int u = 0; u < UC; ++u) {
-          wf[u] = F0[(size_t)(mt * T0::NU + ug0 + u0 + u) * 64 + lane + z];
-          af[u] = *reinterpret_cast<const f32x4*>(img0 + a_off<K0L>(c, (4 * (ul0 + u0 + u) + q) * 4));
-        }
-#pragma unroll
-        for (int u = 0; u < UC; ++u) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], af[u][0], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], af[u][1], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], af[u][2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], af[u][3], acc1, 0, 0, 0);
-        }
-      }
-      const f32x4 acc = acc0 + acc1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dhp[(kh * T0::M + 16 * mt + 4 * q + j) * 16 + c] = acc[j];
-    }
+    bigT_stage0<ST, NH>(fragT, img0, dhp, half, wave, lane);
     __syncthreads();
     // ---- dh_{t-1} of the own units (+ the partner's share) ----------------------------------------------------------------
     if constexpr (NH == 1) {
@@ -259,6 +274,33 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
   for (int u = 0; u < NUT; ++u) {
     if (d_h0) st(d_h0, b * H + hid[u], dhrec[u]);
     if (d_c0) st(d_c0, b * H + hid[u], dcs[u]);
+  }
+}
+
+// ---- batched input gradient: dx[n] = W dy[n] through the same two transposed stages (one row per iteration) -------------
+template <class ST, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_ttlinear_dx_big(int64_t n_rows, const float* __restrict__ fragT,
+                                                             const float* __restrict__ dy, TS* __restrict__ dx) {
+  using T1 = St<ST, 1>;
+  using T0 = St<ST, 0>;
+  constexpr int IN = out_size_of<ST>(), OUT = in_size_of<ST>(), I23 = T1::ROWS;
+  __shared__ __attribute__((aligned(16))) float dyimg[I23 * T1::K];
+  __shared__ __attribute__((aligned(16))) float dhp[2 * T0::M * 16];
+  extern __shared__ __attribute__((aligned(16))) float big_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int64_t n = blockIdx.x; n < n_rows; n += gridDim.x) {
+    for (int e = tid; e < OUT; e += FAST_NT) dyimg[a_off<T1::K>(e % I23, e / I23)] = dy[(size_t)n * OUT + e];   // o = i01*64 + i23
+    __syncthreads();
+    bigT_stage1<ST, 1>(fragT, dyimg, big_lds, wave, lane);
+    __syncthreads();
+    bigT_stage0<ST, 1>(fragT, big_lds, dhp, 0, wave, lane);
+    __syncthreads();
+    for (int j = tid; j < IN; j += FAST_NT) {                 // j = j01*64 + j23
+      const int j01 = j / T0::M, j23 = j % T0::M;
+      st(dx, (size_t)n * IN + j, dhp[j23 * 16 + j01] + dhp[(T0::M + j23) * 16 + j01]);
+    }
+    // the next row's stores to dyimg / image / dhp each sit behind a barrier that follows the last reads of this row
   }
 }
 
@@ -604,17 +646,17 @@ int launch_rnn_bwd_big(const RnnShape& rs, int dtype, const void* c0, const floa
   return TTRNN_OK;
 }
 
-bool big_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
+bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype) {
   if ((dtype != TTRNN_F32 && dtype != TTRNN_BF16) || dy_dtype != TTRNN_F32 || no_bigb()) return false;
   return shape_matches<S4>(s);
 }
 
-size_t big_ttlinear_wgrad_workspace_bytes(const TtShape& s) {
+size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
   return shape_matches<S4>(s) ? B3 + B2 + BT + BDA + BDB : 0;
 }
 
 template <typename TS>
-static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, const void* dy, float* d_packed,
+static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, const void* dy, void* dx, float* d_packed,
                          float* d_bias, void* ws, hipStream_t stream) {
   float* m3 = (float*)ws;
   float* m2 = (float*)((char*)ws + B3);
@@ -622,8 +664,24 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
   float* dA = (float*)((char*)ws + B3 + B2 + BT);
   float* dB = (float*)((char*)dA + BDA);
   hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3((merged_elems<S3>() + 255) / 256), dim3(256), 0, stream, packed, m3);
-  hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, m2);
   hipLaunchKernelGGL((k_bigb_prep<S3, ST>), dim3((int)(BT / sizeof(float) + 255) / 256), dim3(256), 0, stream, m3, mT);
+  if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  const int cus = device_cus();
+  if (dx) {
+    constexpr size_t lds = bigb_lds_bytes<ST, 1>();
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttlinear_dx_big<ST, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised = true;
+    }
+    hipLaunchKernelGGL((k_ttlinear_dx_big<ST, TS>), dim3((int)(n_rows < cus ? n_rows : cus)), dim3(FAST_NT), lds, stream,
+                       n_rows, mT, (const float*)dy, (TS*)dx);
+    if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  }
+  if (!d_packed) return TTRNN_OK;
+  hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, m2);
   if (hipMemsetAsync(dA, 0, BDA + BDB, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
   constexpr size_t lds = (size_t)BigW::TOTAL * sizeof(float);
   static bool raised = false;
@@ -633,7 +691,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
       return TTRNN_ERR_LAUNCH;
     raised = true;
   }
-  int chunks = device_cus() / 4;
+  int chunks = cus / 4;
   if (chunks < 1) chunks = 1;
   if (n_rows < chunks) chunks = (int)n_rows;
   const int rows_per_wg = (int)((n_rows + chunks - 1) / chunks);
@@ -647,11 +705,12 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_ttlinear_wgrad_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
-                              const void* dy, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+// dx and / or (d_packed [+ d_bias]); a bias gradient alone is not offered
+int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
   (void)s;
-  return dtype == TTRNN_F32 ? launch_bigw_t<float>(n_rows, packed, x, dy, d_packed, d_bias, ws, stream)
-                            : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, d_packed, d_bias, ws, stream);
+  return dtype == TTRNN_F32 ? launch_bigw_t<float>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream)
+                            : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
 }
 
 }  // namespace ttrnn

@@ -107,16 +107,17 @@ int launch_rnn_fwd_big(const RnnShape& rs, int dtype, const void* x, const void*
                        void* out, void* hT, void* cT, float* reserve, void* workspace, hipStream_t stream);
 
 // BPTT of the big shape through the merged two-core matrix (ttrnn_fast_bigb.hip): reverse-time kernel (one or two
-// workgroups per sample) and batched weight / bias gradients (dx is left to the any-shape kernel)
+// workgroups per sample) and the batched TTLinear backward (dx through the transposed merged chain; weight + bias
+// gradients accumulated in MFMA registers)
 bool big_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t big_rnn_bwd_workspace(const RnnShape& rs);
 int launch_rnn_bwd_big(const RnnShape& rs, int dtype, const void* c0, const float* packed_hid, const float* reserve,
                        const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
                        void* d_c0, void* ws, hipStream_t stream);
-bool big_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype);
-size_t big_ttlinear_wgrad_workspace_bytes(const TtShape& s);
-int launch_ttlinear_wgrad_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
-                              const void* dy, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
+bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
+size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s);
+int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
 
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);

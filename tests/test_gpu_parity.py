@@ -628,7 +628,7 @@ def test_big_shape_two_workgroups_per_sample_matches_one():
 def test_big_shape_gradients_vs_oracle():
     """cfg5-class BPTT through the merged two-core matrix (reverse-time kernel with two workgroups per sample, weight
     gradients accumulated in MFMA registers, product rule back to the four cores) against the oracle's autograd: every
-    core and bias gradient, the input gradient (any-shape dx pass) and the initial-state gradients."""
+    core and bias gradient, the input gradient (batched transposed chain) and the initial-state gradients."""
     from oracle import ttrnn_oracle as O
     torch.manual_seed(57)
     meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
@@ -683,3 +683,31 @@ def test_big_shape_backward_kernels_agree(dtype):
         scale = max(float(c.abs().max()), 1e-6)
         assert _maxabs(a, c) <= tol * scale, ("pair", name)
         assert _maxabs(b, c) <= tol * scale, ("single", name)
+
+
+def test_big_shape_ttlinear_backward_vs_oracle():
+    """Standalone TTLinear of the cfg5 matrix (1024 -> 4096, d = 4, r = 32): dx, core and bias gradients of the merged-core
+    kernels against the oracle's autograd over 70 rows, then dx alone with frozen weights."""
+    from oracle import ttrnn_oracle as O
+    from t3nsor.layers import TTLinear
+    torch.manual_seed(59)
+    lin = TTLinear(out_features=4096, shape=[[4, 4, 8, 8], [8, 8, 8, 8]], bias=True, auto_shapes=False, d=4,
+                   tt_rank=32).to(dev())
+    x = torch.randn(70, 1024)
+    w = torch.randn(70, 4096)
+    cores = [c.detach().cpu().clone().requires_grad_(True) for c in lin.weight_t.tt_cores]
+    bias = lin.bias.detach().cpu().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    (O.ttlinear(cores, bias, xr) * w).sum().backward()
+    xg = x.to(dev()).requires_grad_(True)
+    y = lin(xg)
+    (y * w.to(dev())).sum().backward()
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * float(xr.grad.abs().max())
+    for k in range(4):
+        assert _maxabs(lin.weight_t.tt_cores[k].grad, cores[k].grad) <= 1e-4 * float(cores[k].grad.abs().max()), k
+    assert _maxabs(lin.bias.grad, bias.grad) <= 1e-4 * float(bias.grad.abs().max())
+    for p in lin.parameters():
+        p.requires_grad_(False)
+    xg2 = x.to(dev()).requires_grad_(True)
+    (lin(xg2) * w.to(dev())).sum().backward()
+    assert _maxabs(xg2.grad, xr.grad) <= 1e-4 * float(xr.grad.abs().max())
