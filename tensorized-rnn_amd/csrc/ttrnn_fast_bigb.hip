@@ -497,6 +497,174 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_big(int64_t n_rows, 
   }
 }
 
+// ---- weight gradients through the DENSE gradient -------------------------------------------------------------------------
+// dW[j][o] = sum_n x[n][j] dy[n][o] is one plain GEMM (8.4 MFLOP per row — half of what recomputing both merged-chain
+// images per row costs, and no weight streaming), and the TT cores' gradients are linear in it:
+//   dA[(j01,r)][i01] = sum_(j23,i23) dW[(j01,j23)][(i01,i23)] Bm[j23][(i23,r)],   dBm[j23][(i23,r)] = sum_(j01,i01) dW[..] A[(j01,r)][i01]
+// (two projections of 134 M MACs, once per launch), then the product rule of k_bigw_finish.
+// GEMM: 128 x 128 tile per workgroup = 8 x 32 tiles = 256 workgroups, every one over ALL rows (no atomics); rows are
+// staged 32 at a time through LDS (row stride 144 floats: the four k rows of an MFMA operand fall on four different
+// 16-bank groups), double-buffered.  The tile map is XCD-aware: the 32 workgroups of one XCD (blockIdx % 8) form a
+// 4 x 8 block of tiles, so that XCD's L2 serves each x / dy line to its 8 / 4 users from one HBM read.
+struct BigD {
+  static constexpr int TM = 128, TN = 128, KB = 32, LS = 144;
+  static constexpr size_t LDS_BYTES = (size_t)2 * 2 * KB * LS * sizeof(float);
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p, size_t i) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p + i);
+  return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+               __uint_as_float(v.y & 0xFFFF0000u)};
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_bigw_dense(int64_t n_rows, const TS* __restrict__ x,
+                                                        const float* __restrict__ dy, float* __restrict__ dW,
+                                                        float* __restrict__ d_bias) {
+  constexpr int IN = 1024, OUT = 4096, KB = BigD::KB, LS = BigD::LS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                       // [2][KB][LS]
+  float* ds = lds + 2 * KB * LS;         // [2][KB][LS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int tj = (xcd >> 2) * 4 + (local >> 3), to = (xcd & 3) * 8 + (local & 7);
+  const int j0 = tj * BigD::TM, o0 = to * BigD::TN;
+  const int wm = wave & 1, wn = wave >> 1;               // wave tile: 64 (j) x 32 (o)
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+  f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = d_bias != nullptr && tj == 0;
+
+  // staging: thread -> rows (tid / 32) and (tid / 32) + 16 of the chunk, four consecutive columns
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  f32x4 sx[2], sd[2];
+  auto stage_load = [&](int64_t nb) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t n = nb + srow + 16 * e;
+      const int64_t nc = n < n_rows ? n : n_rows - 1;       // unconditional loads; rows past the end are zeroed below
+      const f32x4 vx = ld4(x, (size_t)nc * IN + j0 + scol);
+      const f32x4 vd = ld4(dy, (size_t)nc * OUT + o0 + scol);
+      const float keep = n < n_rows ? 1.0f : 0.0f;
+      sx[e] = vx * keep;
+      sd[e] = vd * keep;
+    }
+  };
+  stage_load(0);
+  const int64_t chunks = (n_rows + KB - 1) / KB;
+  for (int64_t ch = 0; ch < chunks; ++ch) {
+    const int buf = (int)(ch & 1);
+    float* xb = xs + buf * KB * LS;
+    float* db = ds + buf * KB * LS;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e];
+      *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = sd[e];
+      dbs += sd[e];
+    }
+    if (ch + 1 < chunks) stage_load((ch + 1) * KB);
+    __syncthreads();
+#pragma unroll
+    for (int sp = 0; sp < KB / 4; ++sp) {
+      float a[4], bv[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = xb[(4 * sp + q) * LS + wm * 64 + 16 * mi + c];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bv[ni] = db[(4 * sp + q) * LS + wn * 32 + 16 * ni + c];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+    // the next chunk goes to the other buffer; its barrier orders these reads before the stores of the chunk after it
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dW[(size_t)(j0 + wm * 64 + 16 * mi + 4 * q + j) * OUT + o0 + wn * 32 + 16 * ni + c] = acc[mi][ni][j];
+  if (want_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(d_bias + o0 + scol + e, dbs[e]);
+  }
+}
+
+// natural-order merged cores for the projections:  BmN[j23][(i23, a)]  and  AT[(j01, i01)][r] = A[(j01, r)][i01]
+template <class S3>
+__global__ void __launch_bounds__(256) k_bigw_natural(const float* __restrict__ packed3, float* __restrict__ BmN,
+                                                      float* __restrict__ AT) {
+  constexpr int J2 = S3::J[2], I1 = S3::I[1], I2 = S3::I[2], R1 = S3::R[1], R2 = S3::R[2], M0 = S3::I[0];
+  constexpr int NB = S3::J[1] * J2 * I1 * I2 * R1, NA = S3::J[0] * R1 * M0;
+  const float* W0 = packed3 + woff_of<S3>(0);
+  const float* W1 = packed3 + woff_of<S3>(1);
+  const float* W2 = packed3 + woff_of<S3>(2);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < NB) {
+    const int a = e % R1, i23 = (e / R1) % (I1 * I2), j23 = e / (R1 * I1 * I2);
+    const int i1 = i23 / I2, i2 = i23 % I2, j1 = j23 / J2, j2 = j23 % J2;
+    float v = 0.f;
+    for (int r2 = 0; r2 < R2; ++r2)
+      v = fmaf(W1[(j1 * R2 + r2) * (I1 * R1) + i1 * R1 + a], W2[j2 * (I2 * R2) + i2 * R2 + r2], v);
+    BmN[e] = v;
+  } else if (e < NB + NA) {
+    const int f = e - NB;
+    const int r = f % R1, i01 = (f / R1) % M0, j01 = f / (R1 * M0);
+    AT[f] = W0[(j01 * R1 + r) * M0 + i01];
+  }
+}
+
+// dA[(j01, r)][i01]: one workgroup per (j01, i01), the 64 x 64 block dW[(j01, :)][(i01, :)] staged in LDS
+__global__ void __launch_bounds__(256) k_bigw_proj_a(const float* __restrict__ dW, const float* __restrict__ BmN,
+                                                     float* __restrict__ dA) {
+  __shared__ float sub[64 * 64];
+  __shared__ float part[8 * 32];
+  const int tid = threadIdx.x, j01 = blockIdx.x >> 6, i01 = blockIdx.x & 63;
+  for (int e = tid; e < 4096; e += 256) sub[e] = dW[(size_t)(j01 * 64 + (e >> 6)) * 4096 + i01 * 64 + (e & 63)];
+  __syncthreads();
+  const int r = tid & 31, p = tid >> 5;
+  float v = 0.f;
+  for (int j23 = 8 * p; j23 < 8 * p + 8; ++j23)
+#pragma unroll 8
+    for (int i23 = 0; i23 < 64; ++i23) v = fmaf(sub[j23 * 64 + i23], BmN[(size_t)j23 * 2048 + i23 * 32 + r], v);
+  part[p * 32 + r] = v;
+  __syncthreads();
+  if (tid < 32) {
+    float t = 0.f;
+    for (int pp = 0; pp < 8; ++pp) t += part[pp * 32 + tid];
+    dA[(j01 * 32 + tid) * 64 + i01] = t;
+  }
+}
+
+// dBm[j23][(i23, r)]: one workgroup per (j23, i23), the 16 x 64 gathered block dW[(:, j23)][(:, i23)] staged in LDS
+__global__ void __launch_bounds__(256) k_bigw_proj_b(const float* __restrict__ dW, const float* __restrict__ AT,
+                                                     float* __restrict__ dB) {
+  __shared__ float sub[16 * 64];
+  __shared__ float part[8 * 32];
+  const int tid = threadIdx.x, j23 = blockIdx.x >> 6, i23 = blockIdx.x & 63;
+  for (int e = tid; e < 1024; e += 256) sub[e] = dW[(size_t)((e >> 6) * 64 + j23) * 4096 + (e & 63) * 64 + i23];
+  __syncthreads();
+  const int r = tid & 31, p = tid >> 5;
+  float v = 0.f;
+  for (int j01 = 2 * p; j01 < 2 * p + 2; ++j01)
+#pragma unroll 8
+    for (int i01 = 0; i01 < 64; ++i01) v = fmaf(sub[j01 * 64 + i01], AT[(size_t)(j01 * 64 + i01) * 32 + r], v);
+  part[p * 32 + r] = v;
+  __syncthreads();
+  if (tid < 32) {
+    float t = 0.f;
+    for (int pp = 0; pp < 8; ++pp) t += part[pp * 32 + tid];
+    dB[(size_t)j23 * 2048 + i23 * 32 + tid] = t;
+  }
+}
+
 // product rule from the merged-core gradients back to the four TT cores (packed layout of S4), accumulated into d_packed:
 //   A[(j0,j1,r2)][(i0,i1)] = sum_r1 W0[(j0,r1)][i0] W1[(j1,r2)][(i1,r1)];  Bm[(j2,j3)][(i2,i3,a)] = sum_r3 W2[(j2,r3)][(i2,a)] W3[j3][(i3,r3)]
 template <class S4>
@@ -564,6 +732,7 @@ constexpr size_t B2 = al256((size_t)merged2_elems<S2>() * sizeof(float));
 constexpr size_t BT = al256((size_t)(St<ST, 0>::K * St<ST, 0>::M + St<ST, 1>::K * St<ST, 1>::M) * sizeof(float));
 constexpr size_t BDA = (size_t)St<S2, 0>::K * St<S2, 0>::M * sizeof(float);      // 512 x 64
 constexpr size_t BDB = (size_t)St<S2, 1>::K * St<S2, 1>::M * sizeof(float);      // 64 x 2048
+constexpr size_t BDW = (size_t)1024 * 4096 * sizeof(float);                      // dense gradient
 
 int device_cus() {
   int dev = 0, cus = 256;
@@ -652,7 +821,7 @@ bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype) {
 }
 
 size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
-  return shape_matches<S4>(s) ? B3 + B2 + BT + BDA + BDB : 0;
+  return shape_matches<S4>(s) ? B3 + B2 + BT + BDA + BDB + BDW : 0;
 }
 
 template <typename TS>
@@ -681,6 +850,25 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   }
   if (!d_packed) return TTRNN_OK;
+  const char* sl = getenv("TTRNN_BIGW_SLICES");             // A/B switch: per-row merged-chain kernel instead of the dense GEMM
+  if (!(sl && sl[0] == '1')) {
+    float* BmN = m2;                                        // the natural-order cores reuse the m2 / dA / dB regions
+    float* AT = m2 + St<S2, 1>::K * St<S2, 1>::M;
+    float* dWf = (float*)((char*)dB + BDB);
+    hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
+    static bool raised_d = false;
+    if (!raised_d) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bigw_dense<TS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)BigD::LDS_BYTES) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised_d = true;
+    }
+    hipLaunchKernelGGL((k_bigw_dense<TS>), dim3(256), dim3(FAST_NT), BigD::LDS_BYTES, stream, n_rows, (const TS*)x,
+                       (const float*)dy, dWf, d_bias);
+    hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
+    hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);
+    if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  } else {
   hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, m2);
   if (hipMemsetAsync(dA, 0, BDA + BDB, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
   constexpr size_t lds = (size_t)BigW::TOTAL * sizeof(float);
@@ -699,6 +887,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
   hipLaunchKernelGGL((k_ttlinear_wgrad_big<S2, ST, TS>), dim3(4 * chunks), dim3(FAST_NT), lds, stream, n_rows,
                      rows_per_wg, m2, mT, (const TS*)x, (const float*)dy, dA, dB, d_bias);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  }
   constexpr int NW = St<S4, 0>::K * St<S4, 0>::M + St<S4, 1>::K * St<S4, 1>::M + St<S4, 2>::K * St<S4, 2>::M +
                      St<S4, 3>::K * St<S4, 3>::M;
   hipLaunchKernelGGL((k_bigw_finish<S4>), dim3((NW + 255) / 256), dim3(256), 0, stream, packed, dA, dB, d_packed);

@@ -655,9 +655,10 @@ def test_big_shape_gradients_vs_oracle():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_big_shape_backward_kernels_agree(dtype):
-    """The three cfg5-class backward paths on the same module and inputs: pair kernel + merged-core weight gradients
-    (default), one workgroup per sample (TTRNN_BIG_NO_PAIR=1), any-shape kernels (TTRNN_NO_BIGB=1).  Many rows per
-    weight-gradient workgroup (B*T = 260 > 64 row chunks), no input gradient, zero initial state."""
+    """The cfg5-class backward paths on the same module and inputs: pair reverse-time kernel + weight gradients through the
+    dense-gradient GEMM and its projections (default); one workgroup per sample + the per-row merged-chain weight-gradient
+    kernel (TTRNN_BIG_NO_PAIR=1, TTRNN_BIGW_SLICES=1; B*T = 260 > 64 row chunks); any-shape kernels (TTRNN_NO_BIGB=1).
+    No input gradient, zero initial state."""
     import os
     torch.manual_seed(58)
     meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
@@ -667,7 +668,7 @@ def test_big_shape_backward_kernels_agree(dtype):
     w = torch.randn(B, T, 1024, device=dev())
     res = []
     try:
-        for env in ({}, {"TTRNN_BIG_NO_PAIR": "1"}, {"TTRNN_NO_BIGB": "1"}):
+        for env in ({}, {"TTRNN_BIG_NO_PAIR": "1", "TTRNN_BIGW_SLICES": "1"}, {"TTRNN_NO_BIGB": "1"}):
             os.environ.update(env)
             m.zero_grad()
             out, (hT, cT) = m(x)
@@ -676,8 +677,8 @@ def test_big_shape_backward_kernels_agree(dtype):
             for k in env:
                 os.environ.pop(k)
     finally:
-        os.environ.pop("TTRNN_BIG_NO_PAIR", None)
-        os.environ.pop("TTRNN_NO_BIGB", None)
+        for k in ("TTRNN_BIG_NO_PAIR", "TTRNN_BIGW_SLICES", "TTRNN_NO_BIGB"):
+            os.environ.pop(k, None)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     for (name, _), a, b, c in zip(m.named_parameters(), *res):
         scale = max(float(c.abs().max()), 1e-6)
