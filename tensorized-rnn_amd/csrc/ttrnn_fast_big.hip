@@ -13,6 +13,7 @@
 // L2 round trips are affordable.  Replaces the same reference code as ttrnn_fast.hip.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
 #include "ttrnn_mfma.h"
@@ -511,6 +512,10 @@ static int big_merge_level() {
   return 2;
 }
 
+static size_t big_gemm_bytes(const RnnShape& rs) {
+  return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H);
+}
+
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   constexpr size_t MID = big_mid<ShpH1024R32L>();      // >= big_mid of the merged shape
   const size_t gin = (size_t)rs.B * rs.T * rs.H * 4 * sizeof(float);
@@ -520,7 +525,8 @@ size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   const size_t m3 = ((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255;
   const size_t m2 = ((size_t)merged2_elems<ShpH1024R32L_M2>() * sizeof(float) + 255) & ~(size_t)255;
   const size_t pair = (size_t)rs.B * 2 * rs.H * sizeof(float) + (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
-  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair;      // + h exchange rows and counters of the pair kernel
+  // + h exchange rows and counters of the pair kernel + identity rows, dense W_in and its bf16 planes of the GEMM K-in
+  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair + big_gemm_bytes(rs);
 }
 
 template <typename TS>
@@ -545,7 +551,7 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     const size_t b2 = ((size_t)merged2_elems<S2>() * sizeof(float) + 255) & ~(size_t)255;
     const size_t pair_bytes = (size_t)rs.B * 2 * rs.H * sizeof(float) +
                               (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
-    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes;
+    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes - big_gemm_bytes(rs);
     float* m3_in = (float*)tail;
     float* m3_hid = (float*)(tail + b3);
     float* m2_in = (float*)(tail + 2 * b3);
@@ -580,9 +586,28 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid2 = (int)(n_rows < cus ? n_rows : cus);          // one workgroup per CU (LDS)
-    hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid2), dim3(FAST_NT), lds_lin, stream, n_rows, m2_in,
-                       (const TS*)x, gin, slab, 2);
-    if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+    const char* ng = getenv("TTRNN_BIG_NO_GEMM");            // A/B switch: K-in through the merged chain, row by row
+    if (ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT && !(ng && ng[0] == '1') && gemm_split_ok(rs.in, 4 * rs.H)) {
+      // K-in as one dense split-bf16 GEMM: W_in (gate-interleaved columns) = the chain kernel on the unit rows
+      char* gt = tail + 2 * (b3 + b2) + pair_bytes;
+      void* ident = gt;
+      float* wdense = (float*)(gt + gemm_split_identity_bytes(rs.in));
+      void* planes = (char*)wdense + gemm_split_dense_bytes(rs.in, 4 * rs.H);
+      int st = launch_fill_identity(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, rs.in, ident, stream);
+      if (st != TTRNN_OK) return st;
+      hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(rs.in < cus ? rs.in : cus), dim3(FAST_NT), lds_lin, stream,
+                         (int64_t)rs.in, m2_in, (const TS*)ident, wdense, slab, 2);
+      if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+      st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, stream);
+      if (st != TTRNN_OK) return st;
+      st = launch_gemm_split(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, rs.in, 4 * rs.H, x, planes, nullptr, rs.H,
+                             gin, stream);
+      if (st != TTRNN_OK) return st;
+    } else {
+      hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid2), dim3(FAST_NT), lds_lin, stream, n_rows, m2_in,
+                         (const TS*)x, gin, slab, 2);
+      if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+    }
     const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
     if (2 * rs.B <= cus && !(np && np[0] == '1')) {
       // two workgroups per sample: h exchange rows [B][2][H] + counters behind the merged cores

@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_big(int64_t n_rows, 
 // 16-bank groups), double-buffered.  The tile map is XCD-aware: the 32 workgroups of one XCD (blockIdx % 8) form a
 // 4 x 8 block of tiles, so that XCD's L2 serves each x / dy line to its 8 / 4 users from one HBM read.
 struct BigD {
-  static constexpr int TM = 128, TN = 128, KB = 32, LS = 144;
+  static constexpr int TM = 128, TN = 128, KB = 64, LS = 144;
   static constexpr size_t LDS_BYTES = (size_t)2 * 2 * KB * LS * sizeof(float);
 };
 
@@ -540,19 +540,18 @@ __global__ void __launch_bounds__(FAST_NT) k_bigw_dense(int64_t n_rows, const TS
   f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool want_bias = d_bias != nullptr && tj == 0;
 
-  // staging: thread -> rows (tid / 32) and (tid / 32) + 16 of the chunk, four consecutive columns
+  // staging: thread -> rows (tid / 32) + 16e of the chunk, four consecutive columns.  The loads of chunk ch+1 are issued
+  // right after chunk ch went to LDS and are not touched (not even scaled) before the next iteration
+  constexpr int SR = KB / 16;
   const int srow = tid >> 5, scol = (tid & 31) * 4;
-  f32x4 sx[2], sd[2];
+  f32x4 sx[SR], sd[SR];
   auto stage_load = [&](int64_t nb) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < SR; ++e) {
       const int64_t n = nb + srow + 16 * e;
-      const int64_t nc = n < n_rows ? n : n_rows - 1;       // unconditional loads; rows past the end are zeroed below
-      const f32x4 vx = ld4(x, (size_t)nc * IN + j0 + scol);
-      const f32x4 vd = ld4(dy, (size_t)nc * OUT + o0 + scol);
-      const float keep = n < n_rows ? 1.0f : 0.0f;
-      sx[e] = vx * keep;
-      sd[e] = vd * keep;
+      const int64_t nc = n < n_rows ? n : n_rows - 1;       // unconditional loads; rows past the end are zeroed at the store
+      sx[e] = ld4(x, (size_t)nc * IN + j0 + scol);
+      sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
     }
   };
   stage_load(0);
@@ -562,10 +561,12 @@ __global__ void __launch_bounds__(FAST_NT) k_bigw_dense(int64_t n_rows, const TS
     float* xb = xs + buf * KB * LS;
     float* db = ds + buf * KB * LS;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e];
-      *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = sd[e];
-      dbs += sd[e];
+    for (int e = 0; e < SR; ++e) {
+      const float keep = ch * KB + srow + 16 * e < n_rows ? 1.0f : 0.0f;
+      const f32x4 vd = sd[e] * keep;
+      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * keep;
+      *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = vd;
+      dbs += vd;
     }
     if (ch + 1 < chunks) stage_load((ch + 1) * KB);
     __syncthreads();

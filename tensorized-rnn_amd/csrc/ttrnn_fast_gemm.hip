@@ -1,0 +1,248 @@
+// ttrnn_fast_gemm.hip — the batched input projection as ONE dense GEMM in split-bf16 fp32 arithmetic (gfx950).
+//
+// K-in computes gin[n] = W_in x[n] for all B*T rows at once: nothing is sequential, so the TT chain buys nothing but
+// FLOPs there (cfg4: 2.4 MFLOP per row through the chain against 0.5 dense-equivalent; cfg5 with merged cores: equal).
+// Per launch the dense matrix is produced by the chain kernel itself, applied to the `in` unit rows (WG[j][m'] in the
+// gate-interleaved output order m' = 4*hid + slot that the recurrent kernels read), split into three bf16 planes
+// (ttrnn_split.h) and then
+//     gin[n][m'] = sum_j x[n][j] WG[j][m']       — six bf16-MFMA terms per product, fp32 accumulate
+// runs as a 128 x 128-tile GEMM: x rows are split while they are staged into LDS (18 VALU per four elements, once per
+// workgroup tile), both operands sit in LDS as [plane][row][32 k] (64-byte rows: every ds_read_b128 fragment read of a
+// wave covers one contiguous KB), chunks of 32 k double-buffered, one barrier per chunk.  MFMA rows are the output
+// features, so a lane's four accumulators are the four gate slots of ONE hidden unit: one 16-byte store per lane.
+// Tile order is XCD-aware: the 32 workgroups an XCD runs side by side form an 8 (feature tiles) x 4 (row tiles) block.
+// Replaces t3nsor/layers.py:121-127 -> ops.py:54-93 for the input_weights of a whole sequence (lstm.py:25).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+
+namespace ttrnn {
+
+namespace {
+constexpr int GT = 128;                       // tile edge (features and rows)
+constexpr int GK = 32;                        // k per chunk = one bf16 MFMA
+constexpr int GPL = GT * GK;                  // bf16 elements per plane tile
+constexpr size_t G_LDS = (size_t)2 * 6 * GPL * sizeof(__bf16);
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+}  // namespace
+
+template <typename TS>
+__global__ void __launch_bounds__(256) k_fill_identity(TS* __restrict__ id, int K) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (size_t)K * K) st(id, e, (e / K == e % K) ? 1.0f : 0.0f);
+}
+
+// planes[p][kc][m][32] (bf16) <- WG[k][m] (fp32), k zero-padded up to 32*KCn
+__global__ void __launch_bounds__(256) k_gemm_prep(const float* __restrict__ WG, int K, int KCn, int M,
+                                                   __bf16* __restrict__ planes) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (k quad, m)
+  const int m = (int)(e % M);
+  const int k4 = (int)(e / M) * 4;
+  if (k4 >= 32 * KCn) return;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = k4 + i < K ? WG[(size_t)(k4 + i) * M + m] : 0.f;
+  unsigned a0, b0, c0, a1, b1, c1;
+  split_pair(v[0], v[1], a0, b0, c0);
+  split_pair(v[2], v[3], a1, b1, c1);
+  const size_t pl = (size_t)KCn * M * 32;
+  const size_t off = ((size_t)(k4 >> 5) * M + m) * 32 + (k4 & 31);
+  *reinterpret_cast<u32x2*>(planes + off) = u32x2{a0, a1};
+  *reinterpret_cast<u32x2*>(planes + pl + off) = u32x2{b0, b1};
+  *reinterpret_cast<u32x2*>(planes + 2 * pl + off) = u32x2{c0, c1};
+}
+
+__device__ __forceinline__ void ld8(const float* p, size_t i, f32x4& a, f32x4& b) {
+  a = *reinterpret_cast<const f32x4*>(p + i);
+  b = *reinterpret_cast<const f32x4*>(p + i + 4);
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, size_t i, f32x4& a, f32x4& b) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p + i);
+  a = f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xFFFF0000u), __uint_as_float(v[1] << 16),
+            __uint_as_float(v[1] & 0xFFFF0000u)};
+  b = f32x4{__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xFFFF0000u), __uint_as_float(v[3] << 16),
+            __uint_as_float(v[3] & 0xFFFF0000u)};
+}
+
+// y[n][m'] (fp32, row stride M) = sum_k x[n][k] W[k][m'] (+ bias of hidden unit m'/4, slots i,g,f,o when bias != NULL)
+template <typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, int KCn, int M,
+                                                        const TS* __restrict__ x, const __bf16* __restrict__ planes,
+                                                        const TS* __restrict__ bias, int Hb, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* lds = reinterpret_cast<__bf16*>(smem);           // [buf][A planes 3][128][32], [B planes 3][128][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  // ---- tile of this workgroup (XCD-aware when the feature tiles come in groups of 8) ----------------------------------
+  const int MT = M / GT;
+  const int64_t RT = (n_rows + GT - 1) / GT;
+  int mt_tile;
+  int64_t rt_tile;
+  if (MT % 8 == 0) {
+    const int xcd = blockIdx.x & 7;
+    const int64_t i = blockIdx.x >> 3;
+    const int64_t g = (i >> 5) * 8 + xcd;                 // super-tile: 8 feature tiles x 4 row tiles
+    const int within = (int)(i & 31);
+    const int smc = MT / 8;
+    mt_tile = (int)(g % smc) * 8 + (within & 7);
+    rt_tile = (g / smc) * 4 + (within >> 3);
+  } else {
+    mt_tile = (int)(blockIdx.x % MT);
+    rt_tile = blockIdx.x / MT;
+  }
+  if (rt_tile >= RT) return;
+  const int m0 = mt_tile * GT;
+  const int64_t n0 = rt_tile * GT;
+  const int wm = wave & 3, wr = wave >> 2;                 // wave tile: features [32 wm, +32) x rows [64 wr, +64)
+
+  // ---- staging: thread -> (row / feature tid >> 2, k group tid & 3) ------------------------------------------------------
+  const int srow = tid >> 2, skq = tid & 3;
+  const int64_t an = n0 + srow < n_rows ? n0 + srow : n_rows - 1;
+  const TS* xrow = x + (size_t)an * K;
+  const size_t plane_elems = (size_t)KCn * M * 32;
+  const __bf16* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
+  f32x4 xa, xb;
+  xbf8 wb[3];
+  auto stage_load = [&](int kc) {
+    const int k = kc * GK + 8 * skq;
+    const int kcl = k + 8 <= K ? k : (K >= 8 ? K - 8 : 0);      // unconditional loads; out-of-range groups are zeroed below
+    ld8(xrow, (size_t)kcl, xa, xb);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      wb[p] = *reinterpret_cast<const xbf8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
+  };
+  auto stage_store = [&](int buf, int kc) {
+    __bf16* As = lds + buf * 6 * GPL;
+    __bf16* Bs = As + 3 * GPL;
+    const int k = kc * GK + 8 * skq;
+    const float keep = k + 8 <= K ? 1.0f : 0.0f;
+    const f32x4 va = xa * keep, vb = xb * keep;
+    unsigned p0[4], p1[4], p2[4];
+    split_pair(va[0], va[1], p0[0], p1[0], p2[0]);
+    split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
+    split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
+    split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
+    const int off = srow * GK + 8 * skq;
+    *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
+    *reinterpret_cast<u32x4*>(As + GPL + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(As + 2 * GPL + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<xbf8*>(Bs + p * GPL + off) = wb[p];
+  };
+
+  f32x4 acc_lo[2][4], acc_hi[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) { acc_lo[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi[mi][ri] = acc_lo[mi][ri]; }
+
+  stage_load(0);
+  for (int kc = 0; kc < KCn; ++kc) {
+    const int buf = kc & 1;
+    stage_store(buf, kc);
+    stage_load(kc + 1 < KCn ? kc + 1 : kc);                // (the last iteration re-reads its own chunk: no branch)
+    __syncthreads();
+    const __bf16* As = lds + buf * 6 * GPL;
+    const __bf16* Bs = As + 3 * GPL;
+    xbf8 wf[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPL + (wm * 32 + 16 * mi + c) * GK + 8 * q);
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      xbf8 af[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        af[p] = *reinterpret_cast<const xbf8*>(As + p * GPL + (wr * 64 + 16 * ri + c) * GK + 8 * q);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+          acc_lo[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc_lo[mi][ri],
+                                                                  0, 0, 0);
+        acc_hi[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][0], af[0], acc_hi[mi][ri], 0, 0, 0);
+      }
+    }
+    // the next chunk goes to the other buffer; its barrier orders these reads before the stores of the chunk after it
+  }
+  // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 32wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int mf = m0 + wm * 32 + 16 * mi + 4 * q;
+    f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const int hd = mf >> 2;
+      bh = f32x4{ld(bias, hd), ld(bias, 2 * Hb + hd), ld(bias, Hb + hd), ld(bias, 3 * Hb + hd)};     // slots i,g,f,o
+    }
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const int64_t n = n0 + wr * 64 + 16 * ri + c;
+      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc_hi[mi][ri] + acc_lo[mi][ri] + bh;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+static size_t al256g(size_t v) { return (v + 255) & ~(size_t)255; }
+
+bool gemm_split_ok(int K, int M) { return K >= 8 && K % 8 == 0 && M % GT == 0; }
+
+size_t gemm_split_identity_bytes(int K) { return al256g((size_t)K * K * sizeof(float)); }
+size_t gemm_split_dense_bytes(int K, int M) { return al256g((size_t)K * M * sizeof(float)); }
+size_t gemm_split_plane_bytes(int K, int M) { return al256g((size_t)3 * ((K + GK - 1) / GK) * GK * M * sizeof(__bf16)); }
+
+int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream) {
+  const int grid = (int)(((size_t)K * K + 255) / 256);
+  if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_fill_identity<float>, dim3(grid), dim3(256), 0, stream, (float*)id, K);
+  else hipLaunchKernelGGL(k_fill_identity<bf16_t>, dim3(grid), dim3(256), 0, stream, (bf16_t*)id, K);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream) {
+  const int KCn = (K + GK - 1) / GK;
+  const size_t threads = (size_t)KCn * 8 * M;
+  hipLaunchKernelGGL(k_gemm_prep, dim3((int)((threads + 255) / 256)), dim3(256), 0, stream, WG, K, KCn, M,
+                     (__bf16*)planes);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+template <typename TS>
+static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias, int Hb,
+                         float* y, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_split<TS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G_LDS) != hipSuccess)
+      return TTRNN_ERR_LAUNCH;
+    raised = true;
+  }
+  const int KCn = (K + GK - 1) / GK;
+  const int MT = M / GT;
+  const int64_t RT = (n_rows + GT - 1) / GT;
+  int64_t grid;
+  if (MT % 8 == 0) {
+    const int64_t supers = (int64_t)(MT / 8) * ((RT + 3) / 4);
+    grid = ((supers + 7) / 8) * 8 * 32;
+  } else {
+    grid = (int64_t)MT * RT;
+  }
+  hipLaunchKernelGGL(k_gemm_split<TS>, dim3((unsigned)grid), dim3(FAST_NT), G_LDS, stream, n_rows, K, KCn, M,
+                     (const TS*)x, (const __bf16*)planes, (const TS*)bias, Hb, y);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
+                      int Hb, float* y, hipStream_t stream) {
+  if (n_rows <= 0) return TTRNN_OK;
+  return dtype == TTRNN_F32 ? launch_gemm_t<float>(n_rows, K, M, x, planes, bias, Hb, y, stream)
+                            : launch_gemm_t<bf16_t>(n_rows, K, M, x, planes, bias, Hb, y, stream);
+}
+
+}  // namespace ttrnn

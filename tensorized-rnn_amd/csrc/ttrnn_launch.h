@@ -99,6 +99,17 @@ size_t f10_ttlinear_workspace_bytes(const TtShape& s, int dtype, int ilv_h, int 
 int launch_ttlinear_fwd_f10(const TtShape& s, int64_t n_rows, const float* packed, const void* bias, const void* x,
                             void* y, void* ws, hipStream_t stream);
 
+// dense split-bf16 GEMM for the batched input projection (ttrnn_fast_gemm.hip): y[n][M] = x[n][K] W[K][M] (+ gate bias);
+// `planes` come from launch_gemm_split_prep(W dense fp32 [K][M], produced by a chain kernel on the K unit rows)
+bool gemm_split_ok(int K, int M);
+size_t gemm_split_identity_bytes(int K);
+size_t gemm_split_dense_bytes(int K, int M);
+size_t gemm_split_plane_bytes(int K, int M);
+int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream);
+int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream);
+int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
+                      int Hb, float* y, hipStream_t stream);
+
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);
 size_t big_rnn_fwd_workspace(const RnnShape& rs);
