@@ -14,6 +14,11 @@ static bool force_generic() {
   return e && e[0] == '1';
 }
 
+static bool no_gemm() {
+  const char* e = getenv("TTRNN_NO_GEMM");      // A/B switch: batched input projections through the TT chain kernels
+  return e && e[0] == '1';
+}
+
 // fp32 matrix arithmetic of the shape-specialised kernels (include/ttrnn.h: TTRNN_MATH_*); process-wide.
 static int g_fp32_math = -1;
 static int fp32_math() {
@@ -171,7 +176,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
 // whatever the batched TTLinear launch needs.
 struct FastFwdPlan {
   bool use, lin_fast, in1;
-  size_t gin_bytes, lin_ws_bytes, f10_bytes, f10_lin_bytes;
+  size_t gin_bytes, lin_ws_bytes, f10_bytes, f10_lin_bytes, gemm_bytes;
   LinPlan lin;
 };
 
@@ -198,6 +203,10 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   }
   f.f10_bytes = f10_workspace_bytes(rs, dtype);   // reserved whatever the math mode is at query time
   f.f10_lin_bytes = f.in1 ? 0 : f10_ttlinear_workspace_bytes(rs.in_s, dtype, rs.H, rs.cell == TTRNN_LSTM ? 2 : 1);
+  // K-in as a dense split-bf16 GEMM (ttrnn_fast_gemm.hip): identity rows, dense W_in, its bf16 planes
+  if (f.f10_lin_bytes > 0 && rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 && gemm_split_ok(rs.in, 4 * rs.H))
+    f.gemm_bytes = gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) +
+                   gemm_split_plane_bytes(rs.in, 4 * rs.H);
   return f;
 }
 
@@ -205,7 +214,7 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
-  if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes;
+  if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes;
   if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
@@ -240,7 +249,7 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
-    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes)
+    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes)
       return TTRNN_ERR_WORKSPACE;
     float* gin = (float*)workspace;
     void* lin_ws = (char*)workspace + f.gin_bytes;
@@ -254,6 +263,21 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
       if (st != TTRNN_OK) return st;
       st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
                                     (hipStream_t)stream);
+    } else if (fp32_math() == TTRNN_MATH_SPLIT && f.gemm_bytes > 0 && (int64_t)rs.B * rs.T >= 2 * (int64_t)rs.in &&
+               !no_gemm() && f10_ttlinear_fwd_available(rs.in_s, desc->dtype, rs.H, ilv_mode)) {
+      // K-in as ONE dense GEMM: W_in (gate-interleaved columns) = the fused-core kernel on the `in` unit rows, then
+      // gin = x W_in + b in split-bf16 arithmetic — the chain's extra FLOPs buy nothing where no step is sequential
+      char* lin10 = (char*)workspace + f.gin_bytes + f.lin_ws_bytes + f.f10_bytes;
+      char* gw = lin10 + f.f10_lin_bytes;
+      float* wdense = (float*)(gw + gemm_split_identity_bytes(rs.in));
+      void* planes = (char*)wdense + gemm_split_dense_bytes(rs.in, 4 * rs.H);
+      st = launch_fill_identity(TTRNN_F32, rs.in, gw, (hipStream_t)stream);
+      if (st == TTRNN_OK)
+        st = launch_ttlinear_fwd_f10(rs.in_s, rs.in, packed_in, nullptr, gw, wdense, lin10, (hipStream_t)stream);
+      if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, (hipStream_t)stream);
+      if (st == TTRNN_OK)
+        st = launch_gemm_split(TTRNN_F32, (int64_t)rs.B * rs.T, rs.in, 4 * rs.H, x, planes, bin, rs.H, gin,
+                               (hipStream_t)stream);
     } else if (fp32_math() == TTRNN_MATH_SPLIT && f.f10_lin_bytes > 0 &&
                f10_ttlinear_fwd_available(rs.in_s, desc->dtype, rs.H, ilv_mode)) {
       // K-in of a layer fed by another layer (in = H): fused-core kernel, split fp32 math

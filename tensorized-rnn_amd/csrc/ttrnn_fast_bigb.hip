@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(FAST_NT) k_bigw_dense(int64_t n_rows, const TS
       dbs += vd;
     }
     if (ch + 1 < chunks) stage_load((ch + 1) * KB);
-    __syncthreads();
+    lds_barrier();                                         // LDS hand-off only: the next chunk's global loads stay in flight
 #pragma unroll
     for (int sp = 0; sp < KB / 4; ++sp) {
       float a[4], bv[2];

@@ -7,8 +7,8 @@
 // (ttrnn_split.h) and then
 //     gin[n][m'] = sum_j x[n][j] WG[j][m']       — six bf16-MFMA terms per product, fp32 accumulate
 // runs as a 128 x 128-tile GEMM: x rows are split while they are staged into LDS (18 VALU per four elements, once per
-// workgroup tile), both operands sit in LDS as [plane][row][32 k] (64-byte rows: every ds_read_b128 fragment read of a
-// wave covers one contiguous KB), chunks of 32 k double-buffered, one barrier per chunk.  MFMA rows are the output
+// workgroup tile), both operands sit in LDS as [plane][row][32 k] with the 16-byte slots XOR-swizzled per row group
+// (x_off: conflict-free ds_read_b128 fragment reads), chunks of 32 k double-buffered, one barrier per chunk.  MFMA rows are the output
 // features, so a lane's four accumulators are the four gate slots of ONE hidden unit: one 16-byte store per lane.
 // Tile order is XCD-aware: the 32 workgroups an XCD runs side by side form an 8 (feature tiles) x 4 (row tiles) block.
 // Replaces t3nsor/layers.py:121-127 -> ops.py:54-93 for the input_weights of a whole sequence (lstm.py:25).
@@ -106,9 +106,11 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   const TS* xrow = x + (size_t)an * K;
   const size_t plane_elems = (size_t)KCn * M * 32;
   const __bf16* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
-  f32x4 xa, xb;
-  xbf8 wb[3];
-  auto stage_load = [&](int kc) {
+  // two register sets: the loads of chunk kc+2 are issued while chunk kc is being multiplied and are not touched
+  // before the iteration after next (a global round trip is longer than one chunk's 768 matrix-pipe cycles)
+  f32x4 xa0, xb0, xa1, xb1;
+  xbf8 wb0[3], wb1[3];
+  auto stage_load = [&](int kc, f32x4& xa, f32x4& xb, xbf8 (&wb)[3]) {
     const int k = kc * GK + 8 * skq;
     const int kcl = k + 8 <= K ? k : (K >= 8 ? K - 8 : 0);      // unconditional loads; out-of-range groups are zeroed below
     ld8(xrow, (size_t)kcl, xa, xb);
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     for (int p = 0; p < 3; ++p)
       wb[p] = *reinterpret_cast<const xbf8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
   };
-  auto stage_store = [&](int buf, int kc) {
+  auto stage_store = [&](int buf, int kc, const f32x4& xa, const f32x4& xb, const xbf8 (&wb)[3]) {
     __bf16* As = lds + buf * 6 * GPL;
     __bf16* Bs = As + 3 * GPL;
     const int k = kc * GK + 8 * skq;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
     split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
     split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
-    const int off = srow * GK + 8 * skq;
+    const int off = x_off<GK>(srow, 8 * skq);           // 16-byte slots XOR-swizzled per row group (ttrnn_split.h)
     *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
     *reinterpret_cast<u32x4*>(As + GPL + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
     *reinterpret_cast<u32x4*>(As + 2 * GPL + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
@@ -141,36 +143,49 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) { acc_lo[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi[mi][ri] = acc_lo[mi][ri]; }
 
-  stage_load(0);
-  for (int kc = 0; kc < KCn; ++kc) {
-    const int buf = kc & 1;
-    stage_store(buf, kc);
-    stage_load(kc + 1 < KCn ? kc + 1 : kc);                // (the last iteration re-reads its own chunk: no branch)
-    __syncthreads();
+  // one chunk: fragment reads of `buf`, then the MFMAs with the split + LDS stores of the NEXT chunk (other buffer, data
+  // prefetched into registers two chunks ago) issued between the two halves of the MFMA stream, so that the 13-cycle
+  // ds_write_b128 transfers and the splitting VALU work overlap the matrix pipe instead of preceding it
+  auto chunk = [&](int buf, int kc_next, bool has_next, const f32x4& xa, const f32x4& xb, const xbf8 (&wb)[3]) {
     const __bf16* As = lds + buf * 6 * GPL;
     const __bf16* Bs = As + 3 * GPL;
-    xbf8 wf[2][3];
+    xbf8 wf[2][3], af[4][3];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPL + (wm * 32 + 16 * mi + c) * GK + 8 * q);
+        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPL + x_off<GK>(wm * 32 + 16 * mi + c, 8 * q));
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      xbf8 af[3];
+    for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        af[p] = *reinterpret_cast<const xbf8*>(As + p * GPL + (wr * 64 + 16 * ri + c) * GK + 8 * q);
+        af[ri][p] = *reinterpret_cast<const xbf8*>(As + p * GPL + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      if (ri == 2 && has_next) stage_store(buf ^ 1, kc_next, xa, xb, wb);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int s = 0; s < 5; ++s)
-          acc_lo[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc_lo[mi][ri],
-                                                                  0, 0, 0);
-        acc_hi[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][0], af[0], acc_hi[mi][ri], 0, 0, 0);
+          acc_lo[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[ri][SPLIT_TX[s]],
+                                                                  acc_lo[mi][ri], 0, 0, 0);
+        acc_hi[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][0], af[ri][0], acc_hi[mi][ri], 0, 0, 0);
       }
     }
-    // the next chunk goes to the other buffer; its barrier orders these reads before the stores of the chunk after it
+  };
+
+  // KCn is even (the planes are zero-padded to an even number of chunks); past-the-end prefetches re-read the last chunk
+  stage_load(0, xa0, xb0, wb0);
+  stage_load(1, xa1, xb1, wb1);
+  stage_store(0, 0, xa0, xb0, wb0);
+  stage_load(2 < KCn ? 2 : KCn - 2, xa0, xb0, wb0);
+  for (int kc = 0; kc < KCn; kc += 2) {
+    lds_barrier();                                         // chunk kc is in buffer 0; nobody reads buffer 1 any more
+    chunk(0, kc + 1, true, xa1, xb1, wb1);
+    stage_load(kc + 3 < KCn ? kc + 3 : KCn - 1, xa1, xb1, wb1);
+    lds_barrier();
+    chunk(1, kc + 2, kc + 2 < KCn, xa0, xb0, wb0);
+    stage_load(kc + 4 < KCn ? kc + 4 : KCn - 2, xa0, xb0, wb0);
   }
   // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 32wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
 #pragma unroll
@@ -196,7 +211,8 @@ bool gemm_split_ok(int K, int M) { return K >= 8 && K % 8 == 0 && M % GT == 0; }
 
 size_t gemm_split_identity_bytes(int K) { return al256g((size_t)K * K * sizeof(float)); }
 size_t gemm_split_dense_bytes(int K, int M) { return al256g((size_t)K * M * sizeof(float)); }
-size_t gemm_split_plane_bytes(int K, int M) { return al256g((size_t)3 * ((K + GK - 1) / GK) * GK * M * sizeof(__bf16)); }
+static int gemm_chunks(int K) { return ((K + 2 * GK - 1) / (2 * GK)) * 2; }      // even: the k loop is unrolled by two
+size_t gemm_split_plane_bytes(int K, int M) { return al256g((size_t)3 * gemm_chunks(K) * GK * M * sizeof(__bf16)); }
 
 int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream) {
   const int grid = (int)(((size_t)K * K + 255) / 256);
@@ -206,7 +222,7 @@ int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream) {
 }
 
 int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream) {
-  const int KCn = (K + GK - 1) / GK;
+  const int KCn = gemm_chunks(K);
   const size_t threads = (size_t)KCn * 8 * M;
   hipLaunchKernelGGL(k_gemm_prep, dim3((int)((threads + 255) / 256)), dim3(256), 0, stream, WG, K, KCn, M,
                      (__bf16*)planes);
@@ -223,7 +239,7 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
       return TTRNN_ERR_LAUNCH;
     raised = true;
   }
-  const int KCn = (K + GK - 1) / GK;
+  const int KCn = gemm_chunks(K);
   const int MT = M / GT;
   const int64_t RT = (n_rows + GT - 1) / GT;
   int64_t grid;

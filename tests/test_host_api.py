@@ -165,7 +165,9 @@ def test_descriptor_validation_without_gpu():
     wide = RnnLayerSpec("lstm", 256, 256, TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]),
                         TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True).desc(64, 784, 0)
     # gate inputs fp32 [B][T][H][4] + the fused-core fragments of the hidden AND of the (hidden-shaped) input matrix
-    assert lib.ttrnn_rnn_workspace(ctypes.byref(wide)) == 64 * 784 * 256 * 4 * 4 + 2 * 4 * 8 * 3 * 1024
+    # + the dense-GEMM K-in: identity rows [in][in], dense W_in [in][4H] (fp32) and its three bf16 planes
+    assert lib.ttrnn_rnn_workspace(ctypes.byref(wide)) == (64 * 784 * 256 * 4 * 4 + 2 * 4 * 8 * 3 * 1024 +
+                                                           256 * 256 * 4 + 256 * 1024 * 4 + 3 * 256 * 1024 * 2)
     tiny = RnnLayerSpec("gru", 28, 64, TTSpec([4, 7], [12, 16], [1, 3, 1]), TTSpec([8, 8], [12, 16], [1, 3, 1]),
                         True, True).desc(3, 6, 0)
     assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) == 0        # generic kernel, everything in LDS
