@@ -91,6 +91,15 @@ int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* 
 // input_size == 1 backward: dv (fp32[out]) + the unit input row live in the workspace
 static size_t in1_bwd_bytes(const TtShape& s) { return ((size_t)s.out_size * sizeof(float) + 255 + 256) & ~(size_t)255; }
 
+// Dense-gradient backward (ttrnn_fast_gemm.hip) of a shape with a fused-core weight-gradient kernel: workspace =
+// [that kernel's own | identity rows in x in | dW in x out | dense W in x out | bf16 planes of W^T (K = out, M = in)]
+static size_t dense_bwd_f10w(const TtShape& s) { return (f10_ttlinear_wgrad_workspace_bytes(s) + 255) & ~(size_t)255; }
+static size_t dense_bwd_bytes(const TtShape& s) {
+  if (f10_ttlinear_wgrad_workspace_bytes(s) == 0 || !dense_wgrad_ok(s.in_size, s.out_size)) return 0;
+  return dense_bwd_f10w(s) + gemm_split_identity_bytes(s.in_size) + 2 * gemm_split_dense_bytes(s.in_size, s.out_size) +
+         gemm_split_plane_bytes(s.out_size, s.in_size);
+}
+
 size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   TtShape s;
   if (tt_shape_init(&s, w) != TTRNN_OK || n_rows < 0) return 0;
@@ -100,6 +109,8 @@ size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   if (s.in_size == 1 && in1_bwd_bytes(s) > ws) ws = in1_bwd_bytes(s);
   const size_t f10w = f10_ttlinear_wgrad_workspace_bytes(s);      // fused-core weight gradients (any math mode)
   if (f10w > ws) ws = f10w;
+  const size_t dnb = dense_bwd_bytes(s);                          // dense-gradient backward of the fused-core shapes
+  if (dnb > ws) ws = dnb;
   const size_t bigw = big_ttlinear_bwd_workspace_bytes(s);        // merged-core backward of the big shape
   if (bigw > ws) ws = bigw;
   return ws;
@@ -150,6 +161,31 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       if (st != TTRNN_OK) return st;
       return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
                                       (hipStream_t)stream);
+    }
+    if ((fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && d_packed && !no_gemm() &&
+        f10_ttlinear_wgrad_available(s, dtype, dy_dtype) && dense_bwd_bytes(s) > 0 && n_rows >= 4 * (int64_t)s.in_size &&
+        (!dx || (dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && gemm_split_ok(s.out_size, s.in_size) &&
+                 fast_ttlinear_fwd_available(s, dtype, 0))) &&
+        workspace && workspace_bytes >= dense_bwd_bytes(s)) {
+      // Every row is independent, so the TT structure buys nothing here: one dense GEMM dW = x^T dy (fp32 MFMA), whose
+      // image under the adjoint of "cores -> dense matrix" is what the fused-core weight-gradient kernel computes when it
+      // is fed the `in` unit rows as x and dW's rows as dy; dx = dy W^T is a second dense GEMM (split-bf16).
+      hipStream_t sm = (hipStream_t)stream;
+      char* wsb = (char*)workspace;
+      void* ident = wsb + dense_bwd_f10w(s);
+      float* dWd = (float*)((char*)ident + gemm_split_identity_bytes(s.in_size));
+      float* Wd = (float*)((char*)dWd + gemm_split_dense_bytes(s.in_size, s.out_size));
+      void* planes = (char*)Wd + gemm_split_dense_bytes(s.in_size, s.out_size);
+      st = launch_fill_identity(dtype, s.in_size, ident, sm);
+      if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm);
+      if (st == TTRNN_OK)
+        st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
+      if (st != TTRNN_OK || !dx) return st;
+      st = launch_ttlinear_fwd_fast(s, dtype, true, s.in_size, packed, nullptr, ident, Wd, 0, 0, sm);     // W[j][o]
+      if (st == TTRNN_OK) st = launch_gemm_split_prep(Wd, s.out_size, s.in_size, planes, sm, true);
+      if (st == TTRNN_OK)
+        st = launch_gemm_split(TTRNN_F32, n_rows, s.out_size, s.in_size, dy, planes, nullptr, 0, (float*)dx, sm);
+      return st;
     }
     if ((fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && d_packed &&
         f10_ttlinear_wgrad_available(s, dtype, dy_dtype) && (!dx || f10_ttlinear_wgrad_has_dx(s)) &&

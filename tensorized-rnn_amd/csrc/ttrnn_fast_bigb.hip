@@ -502,102 +502,7 @@ __global__ void __launch_bounds__(FAST_NT) k_ttlinear_wgrad_big(int64_t n_rows, 
 // images per row costs, and no weight streaming), and the TT cores' gradients are linear in it:
 //   dA[(j01,r)][i01] = sum_(j23,i23) dW[(j01,j23)][(i01,i23)] Bm[j23][(i23,r)],   dBm[j23][(i23,r)] = sum_(j01,i01) dW[..] A[(j01,r)][i01]
 // (two projections of 134 M MACs, once per launch), then the product rule of k_bigw_finish.
-// GEMM: 128 x 128 tile per workgroup = 8 x 32 tiles = 256 workgroups, every one over ALL rows (no atomics); rows are
-// staged 32 at a time through LDS (row stride 144 floats: the four k rows of an MFMA operand fall on four different
-// 16-bank groups), double-buffered.  The tile map is XCD-aware: the 32 workgroups of one XCD (blockIdx % 8) form a
-// 4 x 8 block of tiles, so that XCD's L2 serves each x / dy line to its 8 / 4 users from one HBM read.
-struct BigD {
-  static constexpr int TM = 128, TN = 128, KB = 64, LS = 144;
-  static constexpr size_t LDS_BYTES = (size_t)2 * 2 * KB * LS * sizeof(float);
-};
-
-__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); }
-__device__ __forceinline__ f32x4 ld4(const bf16_t* p, size_t i) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p + i);
-  return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
-               __uint_as_float(v.y & 0xFFFF0000u)};
-}
-
-template <typename TS>
-__global__ void __launch_bounds__(FAST_NT) k_bigw_dense(int64_t n_rows, const TS* __restrict__ x,
-                                                        const float* __restrict__ dy, float* __restrict__ dW,
-                                                        float* __restrict__ d_bias) {
-  constexpr int IN = 1024, OUT = 4096, KB = BigD::KB, LS = BigD::LS;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;                       // [2][KB][LS]
-  float* ds = lds + 2 * KB * LS;         // [2][KB][LS]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int tj = (xcd >> 2) * 4 + (local >> 3), to = (xcd & 3) * 8 + (local & 7);
-  const int j0 = tj * BigD::TM, o0 = to * BigD::TN;
-  const int wm = wave & 1, wn = wave >> 1;               // wave tile: 64 (j) x 32 (o)
-
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
-  f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool want_bias = d_bias != nullptr && tj == 0;
-
-  // staging: thread -> rows (tid / 32) + 16e of the chunk, four consecutive columns.  The loads of chunk ch+1 are issued
-  // right after chunk ch went to LDS and are not touched (not even scaled) before the next iteration
-  constexpr int SR = KB / 16;
-  const int srow = tid >> 5, scol = (tid & 31) * 4;
-  f32x4 sx[SR], sd[SR];
-  auto stage_load = [&](int64_t nb) {
-#pragma unroll
-    for (int e = 0; e < SR; ++e) {
-      const int64_t n = nb + srow + 16 * e;
-      const int64_t nc = n < n_rows ? n : n_rows - 1;       // unconditional loads; rows past the end are zeroed at the store
-      sx[e] = ld4(x, (size_t)nc * IN + j0 + scol);
-      sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
-    }
-  };
-  stage_load(0);
-  const int64_t chunks = (n_rows + KB - 1) / KB;
-  for (int64_t ch = 0; ch < chunks; ++ch) {
-    const int buf = (int)(ch & 1);
-    float* xb = xs + buf * KB * LS;
-    float* db = ds + buf * KB * LS;
-#pragma unroll
-    for (int e = 0; e < SR; ++e) {
-      const float keep = ch * KB + srow + 16 * e < n_rows ? 1.0f : 0.0f;
-      const f32x4 vd = sd[e] * keep;
-      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * keep;
-      *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = vd;
-      dbs += vd;
-    }
-    if (ch + 1 < chunks) stage_load((ch + 1) * KB);
-    lds_barrier();                                         // LDS hand-off only: the next chunk's global loads stay in flight
-#pragma unroll
-    for (int sp = 0; sp < KB / 4; ++sp) {
-      float a[4], bv[2];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[mi] = xb[(4 * sp + q) * LS + wm * 64 + 16 * mi + c];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bv[ni] = db[(4 * sp + q) * LS + wn * 32 + 16 * ni + c];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-    }
-    // the next chunk goes to the other buffer; its barrier orders these reads before the stores of the chunk after it
-  }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        dW[(size_t)(j0 + wm * 64 + 16 * mi + 4 * q + j) * OUT + o0 + wn * 32 + 16 * ni + c] = acc[mi][ni][j];
-  if (want_bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(d_bias + o0 + scol + e, dbs[e]);
-  }
-}
-
+// The GEMM is launch_dense_wgrad (ttrnn_fast_gemm.hip): 8 x 32 tiles of 128 x 128 = 256 workgroups, every one over ALL rows.
 // natural-order merged cores for the projections:  BmN[j23][(i23, a)]  and  AT[(j01, i01)][r] = A[(j01, r)][i01]
 template <class S3>
 __global__ void __launch_bounds__(256) k_bigw_natural(const float* __restrict__ packed3, float* __restrict__ BmN,
@@ -857,15 +762,9 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     float* AT = m2 + St<S2, 1>::K * St<S2, 1>::M;
     float* dWf = (float*)((char*)dB + BDB);
     hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
-    static bool raised_d = false;
-    if (!raised_d) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bigw_dense<TS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)BigD::LDS_BYTES) != hipSuccess)
-        return TTRNN_ERR_LAUNCH;
-      raised_d = true;
-    }
-    hipLaunchKernelGGL((k_bigw_dense<TS>), dim3(256), dim3(FAST_NT), BigD::LDS_BYTES, stream, n_rows, (const TS*)x,
-                       (const float*)dy, dWf, d_bias);
+    const int sd = launch_dense_wgrad(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, 1024, 4096, x, (const float*)dy, dWf,
+                                      d_bias, stream);
+    if (sd != TTRNN_OK) return sd;
     hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
     hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;

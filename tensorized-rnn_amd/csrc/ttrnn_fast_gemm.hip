@@ -35,16 +35,16 @@ __global__ void __launch_bounds__(256) k_fill_identity(TS* __restrict__ id, int 
   if (e < (size_t)K * K) st(id, e, (e / K == e % K) ? 1.0f : 0.0f);
 }
 
-// planes[p][kc][m][32] (bf16) <- WG[k][m] (fp32), k zero-padded up to 32*KCn
-__global__ void __launch_bounds__(256) k_gemm_prep(const float* __restrict__ WG, int K, int KCn, int M,
-                                                   __bf16* __restrict__ planes) {
+// planes[p][kc][m][32] (bf16) <- W(k, m) = WG[k*sk + m*sm] (fp32), k zero-padded up to 32*KCn
+__global__ void __launch_bounds__(256) k_gemm_prep(const float* __restrict__ WG, int K, int KCn, int M, int64_t sk,
+                                                   int64_t sm, __bf16* __restrict__ planes) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (k quad, m)
   const int m = (int)(e % M);
   const int k4 = (int)(e / M) * 4;
   if (k4 >= 32 * KCn) return;
   float v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = k4 + i < K ? WG[(size_t)(k4 + i) * M + m] : 0.f;
+  for (int i = 0; i < 4; ++i) v[i] = k4 + i < K ? WG[(size_t)(k4 + i) * sk + (size_t)m * sm] : 0.f;
   unsigned a0, b0, c0, a1, b1, c1;
   split_pair(v[0], v[1], a0, b0, c0);
   split_pair(v[2], v[3], a1, b1, c1);
@@ -204,6 +204,128 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   }
 }
 
+// ---- dense weight gradient dW[j][o] (+)= sum_n x[n][j] dy[n][o] on the fp32 MFMA ----------------------------------------------
+// Both operands have the contraction index n as their SLOW index, which the k-packed bf16 MFMA operands cannot take
+// without a transpose; the fp32 16x16x4 MFMA takes one value per lane and reads them straight out of row-major LDS tiles
+// (row stride 144 floats: the four k rows of an operand fall on four different 16-bank groups).  128 x 128 tile per
+// workgroup, rows staged 64 at a time, double-buffered, LDS-only barrier.  KS > 1 splits the rows over KS workgroups per
+// tile (atomic flush into a zeroed dW) when there are fewer tiles than CUs; all tiles of one row range run on one XCD
+// (blockIdx % 8), so its L2 serves every x / dy line to all of its users from one HBM read.
+struct DenseG {
+  static constexpr int TM = 128, TN = 128, KB = 64, LS = 144;
+  static constexpr size_t LDS_BYTES = (size_t)2 * 2 * KB * LS * sizeof(float);
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p, size_t i) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p + i);
+  return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+               __uint_as_float(v.y & 0xFFFF0000u)};
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
+                                                         const TS* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dW, float* __restrict__ d_bias) {
+  constexpr int KB = DenseG::KB, LS = DenseG::LS;
+  extern __shared__ __attribute__((aligned(16))) float ldsf[];
+  float* xs = ldsf;                      // [2][KB][LS]
+  float* ds = ldsf + 2 * KB * LS;        // [2][KB][LS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int TJ = IN / DenseG::TM, TO = OUT / DenseG::TN;
+  int tj, to, ks;
+  if (KS == 1 && TJ == 8 && TO == 32) {
+    // one workgroup per tile: the 32 workgroups of an XCD form a 4 x 8 block of tiles
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    tj = (xcd >> 2) * 4 + (local >> 3);
+    to = (xcd & 3) * 8 + (local & 7);
+    ks = 0;
+  } else if (KS % 8 == 0) {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, tile = i % (TJ * TO);
+    ks = (i / (TJ * TO)) * 8 + xcd;
+    tj = tile / TO;
+    to = tile % TO;
+  } else {
+    const int tile = blockIdx.x % (TJ * TO);
+    ks = blockIdx.x / (TJ * TO);
+    tj = tile / TO;
+    to = tile % TO;
+  }
+  const int j0 = tj * DenseG::TM, o0 = to * DenseG::TN;
+  const int64_t r0 = (int64_t)ks * rows_per;
+  const int64_t r1 = r0 + rows_per < n_rows ? r0 + rows_per : n_rows;
+  if (r0 >= r1) return;
+  const int wm = wave & 1, wn = wave >> 1;               // wave tile: 64 (j) x 32 (o)
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+  f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = d_bias != nullptr && tj == 0;
+
+  // staging: thread -> rows (tid / 32) + 16e of the chunk, four consecutive columns.  The loads of chunk ch+1 are issued
+  // right after chunk ch went to LDS and are not touched (not even scaled) before the next iteration
+  constexpr int SR = KB / 16;
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  f32x4 sx[SR], sd[SR];
+  auto stage_load = [&](int64_t nb) {
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      const int64_t n = nb + srow + 16 * e;
+      const int64_t nc = n < r1 ? n : r1 - 1;               // unconditional loads; rows past the end are zeroed at the store
+      sx[e] = ld4(x, (size_t)nc * IN + j0 + scol);
+      sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
+    }
+  };
+  stage_load(r0);
+  const int64_t chunks = (r1 - r0 + KB - 1) / KB;
+  for (int64_t ch = 0; ch < chunks; ++ch) {
+    const int buf = (int)(ch & 1);
+    float* xb = xs + buf * KB * LS;
+    float* db = ds + buf * KB * LS;
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      const float keep = r0 + ch * KB + srow + 16 * e < r1 ? 1.0f : 0.0f;
+      const f32x4 vd = sd[e] * keep;
+      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * keep;
+      *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = vd;
+      dbs += vd;
+    }
+    stage_load(r0 + (ch + 1 < chunks ? ch + 1 : ch) * KB);
+    lds_barrier();                                         // LDS hand-off only: the next chunk's global loads stay in flight
+#pragma unroll
+    for (int sp = 0; sp < KB / 4; ++sp) {
+      float a[4], bv[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = xb[(4 * sp + q) * LS + wm * 64 + 16 * mi + c];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bv[ni] = db[(4 * sp + q) * LS + wn * 32 + 16 * ni + c];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+    // the next chunk goes to the other buffer; its barrier orders these reads before the stores of the chunk after it
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* p = dW + (size_t)(j0 + wm * 64 + 16 * mi + 4 * q + j) * OUT + o0 + wn * 32 + 16 * ni + c;
+        if (KS == 1) *p = acc[mi][ni][j];
+        else atomicAdd(p, acc[mi][ni][j]);
+      }
+  if (want_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(d_bias + o0 + scol + e, dbs[e]);
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 static size_t al256g(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -221,11 +343,12 @@ int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream) {
+// transposed: W(k, m) = WG[m][k] (WG is [M][K] row-major) instead of WG[k][m]
+int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream, bool transposed) {
   const int KCn = gemm_chunks(K);
   const size_t threads = (size_t)KCn * 8 * M;
   hipLaunchKernelGGL(k_gemm_prep, dim3((int)((threads + 255) / 256)), dim3(256), 0, stream, WG, K, KCn, M,
-                     (__bf16*)planes);
+                     (int64_t)(transposed ? 1 : M), (int64_t)(transposed ? K : 1), (__bf16*)planes);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -259,6 +382,43 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
   if (n_rows <= 0) return TTRNN_OK;
   return dtype == TTRNN_F32 ? launch_gemm_t<float>(n_rows, K, M, x, planes, bias, Hb, y, stream)
                             : launch_gemm_t<bf16_t>(n_rows, K, M, x, planes, bias, Hb, y, stream);
+}
+
+
+bool dense_wgrad_ok(int in, int out) { return in % DenseG::TM == 0 && out % DenseG::TN == 0; }
+
+// dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into
+int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
+                       float* d_bias, hipStream_t stream) {
+  const int tiles = (in / DenseG::TM) * (out / DenseG::TN);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int KS = 1;
+  if (tiles < cus) {
+    KS = ((cus / tiles + 7) / 8) * 8;                               // multiple of 8: one row range per XCD at a time
+    const int64_t max_ks = (n_rows + DenseG::KB - 1) / DenseG::KB;    // at least one chunk per split
+    if (KS > max_ks) KS = max_ks < 1 ? 1 : (int)max_ks;
+  }
+  int64_t rows_per = (n_rows + KS - 1) / KS;
+  rows_per = (rows_per + DenseG::KB - 1) / DenseG::KB * DenseG::KB;
+  if (KS > 1 && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  static bool raised[2] = {false, false};
+  const int di = dtype == TTRNN_F32 ? 0 : 1;
+  const void* fn = di == 0 ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
+                           : reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>);
+  if (!raised[di]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseG::LDS_BYTES) != hipSuccess)
+      return TTRNN_ERR_LAUNCH;
+    raised[di] = true;
+  }
+  const unsigned grid = (unsigned)(tiles * KS);
+  if (di == 0)
+    hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), DenseG::LDS_BYTES, stream, n_rows, in, out, KS,
+                       rows_per, (const float*)x, dy, dW, d_bias);
+  else
+    hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), DenseG::LDS_BYTES, stream, n_rows, in, out, KS,
+                       rows_per, (const bf16_t*)x, dy, dW, d_bias);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
 }  // namespace ttrnn

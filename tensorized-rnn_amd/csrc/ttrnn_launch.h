@@ -106,9 +106,14 @@ size_t gemm_split_identity_bytes(int K);
 size_t gemm_split_dense_bytes(int K, int M);
 size_t gemm_split_plane_bytes(int K, int M);
 int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream);
-int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream);
+int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream, bool transposed = false);
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
                       int Hb, float* y, hipStream_t stream);
+
+// dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
+bool dense_wgrad_ok(int in, int out);
+int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
+                       float* d_bias, hipStream_t stream);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);

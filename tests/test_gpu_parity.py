@@ -506,12 +506,15 @@ def test_math_modes_full_size_properties(math_mode):
 
 
 # ---- (5) fused-core kernels: persistent row loops, stacked layers, switches ---------------------------------------
-@pytest.mark.parametrize("rank,B,T,x_grad", [(8, 41, 23, True), (16, 37, 19, True), (16, 37, 19, False)])
+@pytest.mark.parametrize("rank,B,T,x_grad", [(8, 41, 23, True), (16, 37, 19, True), (16, 37, 19, False),
+                                             (16, 48, 27, True), (8, 53, 25, False)])
 def test_stacked_layers_many_rows_vs_generic(rank, B, T, x_grad):
     """Two stacked TT-LSTM layers (input projections and weight-gradient passes run on the fused-core kernels, whose
     workgroups WALK over B*T > 256 rows) against the any-shape kernels on the same module: forward, input gradient
     and every parameter gradient.  Without an input gradient the first layer's in=40 matrix takes the fused-core
-    weight-gradient kernel too (it produces dx only for hidden-shaped inputs)."""
+    weight-gradient kernel too (it produces dx only for hidden-shaped inputs).  From B*T >= 512 rows on the input
+    projections run as dense split-bf16 GEMMs, from B*T >= 1024 the weight gradients go through the dense gradient
+    x^T dy and dx through a second GEMM (ttrnn_fast_gemm.hip): the last two cases."""
     import os
     torch.manual_seed(77 + rank)
     meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=rank)
@@ -712,3 +715,51 @@ def test_big_shape_ttlinear_backward_vs_oracle():
     xg2 = x.to(dev()).requires_grad_(True)
     (lin(xg2) * w.to(dev())).sum().backward()
     assert _maxabs(xg2.grad, xr.grad) <= 1e-4 * float(xr.grad.abs().max())
+
+
+def test_dense_gemm_paths_switch_off_matches():
+    """TTRNN_NO_GEMM=1 (input projections, weight gradients and dx row by row through the TT chain kernels) against the
+    dense-GEMM paths on the same 3-layer cfg4-shaped module over 1 300 rows: forward, dx and every parameter gradient."""
+    import os
+    torch.manual_seed(91)
+    meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16)
+    m = build_module(meta, dev())
+    x = torch.rand(50, 26, 40, device=dev())
+    w = torch.randn(50, 26, 256, device=dev())
+    res = []
+    for flag in ("0", "1"):
+        os.environ["TTRNN_NO_GEMM"] = flag
+        try:
+            m.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            out, (h, c) = m(xg)
+            ((out * w).sum() + c.sum()).backward()
+            res.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ.pop("TTRNN_NO_GEMM", None)
+    assert _maxabs(res[0][0], res[1][0]) <= 5e-6
+    assert _maxabs(res[0][1], res[1][1]) <= 1e-4 * max(1e-3, float(res[1][1].abs().max()))
+    for (name, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6), name
+
+
+def test_dense_gradient_path_bf16_gru_vs_chain():
+    """bf16-storage TT-GRU (cfg3 shape) over 1 280 rows: weight gradients through the dense gradient (bf16 x rows, fp32
+    gate gradients) against the row-by-row fused-core kernel."""
+    import os
+    torch.manual_seed(92)
+    meta = dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev()).to(torch.bfloat16)
+    x = torch.rand(40, 32, 1, device=dev()).to(torch.bfloat16)
+    res = []
+    for flag in ("0", "1"):
+        os.environ["TTRNN_NO_GEMM"] = flag
+        try:
+            m.zero_grad()
+            out, h = m(x)
+            out.float().square().sum().backward()
+            res.append([p.grad.float().clone() for p in m.parameters()])
+        finally:
+            os.environ.pop("TTRNN_NO_GEMM", None)
+    for (name, _), a, b in zip(m.named_parameters(), *res):
+        assert _maxabs(a, b) <= 2e-2 * max(float(b.abs().max()), 1e-6), name
