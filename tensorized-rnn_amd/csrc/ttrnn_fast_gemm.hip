@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const int TJ = IN / DenseG::TM, TO = OUT / DenseG::TN;
+  const int TJ = (IN + DenseG::TM - 1) / DenseG::TM, TO = OUT / DenseG::TN;      // a last, partly filled j tile is masked
   int tj, to, ks;
   if (KS == 1 && TJ == 8 && TO == 32) {
     // one workgroup per tile: the 32 workgroups of an XCD form a 4 x 8 block of tiles
@@ -269,13 +269,15 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
   // right after chunk ch went to LDS and are not touched (not even scaled) before the next iteration
   constexpr int SR = KB / 16;
   const int srow = tid >> 5, scol = (tid & 31) * 4;
+  const bool jin = j0 + scol + 4 <= IN;                   // IN % 4 == 0: a column quad is in or out as a whole
+  const int jc = jin ? j0 + scol : 0;
   f32x4 sx[SR], sd[SR];
   auto stage_load = [&](int64_t nb) {
 #pragma unroll
     for (int e = 0; e < SR; ++e) {
       const int64_t n = nb + srow + 16 * e;
       const int64_t nc = n < r1 ? n : r1 - 1;               // unconditional loads; rows past the end are zeroed at the store
-      sx[e] = ld4(x, (size_t)nc * IN + j0 + scol);
+      sx[e] = ld4(x, (size_t)nc * IN + jc);
       sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
     }
   };
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
     for (int e = 0; e < SR; ++e) {
       const float keep = r0 + ch * KB + srow + 16 * e < r1 ? 1.0f : 0.0f;
       const f32x4 vd = sd[e] * keep;
-      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * keep;
+      *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * (jin ? keep : 0.0f);
       *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = vd;
       dbs += vd;
     }
@@ -316,9 +318,12 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float* p = dW + (size_t)(j0 + wm * 64 + 16 * mi + 4 * q + j) * OUT + o0 + wn * 32 + 16 * ni + c;
-        if (KS == 1) *p = acc[mi][ni][j];
-        else atomicAdd(p, acc[mi][ni][j]);
+        const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
+        if (jj < IN) {
+          float* p = dW + (size_t)jj * OUT + o0 + wn * 32 + 16 * ni + c;
+          if (KS == 1) *p = acc[mi][ni][j];
+          else atomicAdd(p, acc[mi][ni][j]);
+        }
       }
   if (want_bias) {
 #pragma unroll
@@ -385,12 +390,12 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 }
 
 
-bool dense_wgrad_ok(int in, int out) { return in % DenseG::TM == 0 && out % DenseG::TN == 0; }
+bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % DenseG::TN == 0; }
 
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
                        float* d_bias, hipStream_t stream) {
-  const int tiles = (in / DenseG::TM) * (out / DenseG::TN);
+  const int tiles = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int KS = 1;
