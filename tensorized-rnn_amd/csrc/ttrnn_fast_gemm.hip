@@ -6,7 +6,7 @@
 // gate-interleaved output order m' = 4*hid + slot that the recurrent kernels read), split into three bf16 planes
 // (ttrnn_split.h) and then
 //     gin[n][m'] = sum_j x[n][j] WG[j][m']       — six bf16-MFMA terms per product, fp32 accumulate
-// runs as a 128 x 128-tile GEMM: x rows are split while they are staged into LDS (18 VALU per four elements, once per
+// runs as a 128 x 256-tile GEMM: x rows are split while they are staged into LDS (18 VALU per four elements, once per
 // workgroup tile), both operands sit in LDS as [plane][row][32 k] with the 16-byte slots XOR-swizzled per row group
 // (x_off: conflict-free ds_read_b128 fragment reads), chunks of 32 k double-buffered, one barrier per chunk.  MFMA rows are the output
 // features, so a lane's four accumulators are the four gate slots of ONE hidden unit: one 16-byte store per lane.
@@ -19,13 +19,20 @@
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 
+#ifndef GEMM_EXP
+#define GEMM_EXP 0
+#endif
+
 namespace ttrnn {
 
 namespace {
-constexpr int GT = 128;                       // tile edge (features and rows)
+constexpr int GF = 128;                       // features per workgroup tile
+constexpr int GR = 256;                       // rows per workgroup tile
+constexpr int GT = GF;
 constexpr int GK = 32;                        // k per chunk = one bf16 MFMA
-constexpr int GPL = GT * GK;                  // bf16 elements per plane tile
-constexpr size_t G_LDS = (size_t)2 * 6 * GPL * sizeof(__bf16);
+constexpr int GPA = GR * GK, GPB = GF * GK;   // bf16 elements per plane tile (rows / features)
+constexpr int G_BUF = 3 * GPA + 3 * GPB;      // one buffer: three planes of each operand
+constexpr size_t G_LDS = (size_t)2 * G_BUF * sizeof(__bf16);
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
@@ -68,19 +75,21 @@ __device__ __forceinline__ void ld8(const bf16_t* p, size_t i, f32x4& a, f32x4& 
 }
 
 // y[n][m'] (fp32, row stride M) = sum_k x[n][k] W[k][m'] (+ bias of hidden unit m'/4, slots i,g,f,o when bias != NULL)
+// Workgroup tile: 128 features x 256 rows, wave tile 64 x 64 (4 x 4 MFMA tiles: 24 fragment reads feed 96 MFMAs per
+// chunk — the 128 x 128 tile with 32 x 64 wave tiles spent as long in LDS traffic, splitting and barriers as in MFMAs).
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, int KCn, int M,
                                                         const TS* __restrict__ x, const __bf16* __restrict__ planes,
                                                         const TS* __restrict__ bias, int Hb, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* lds = reinterpret_cast<__bf16*>(smem);           // [buf][A planes 3][128][32], [B planes 3][128][32]
+  __bf16* lds = reinterpret_cast<__bf16*>(smem);           // [buf][A planes 3][256][32], [B planes 3][128][32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   // ---- tile of this workgroup (XCD-aware when the feature tiles come in groups of 8) ----------------------------------
-  const int MT = M / GT;
-  const int64_t RT = (n_rows + GT - 1) / GT;
+  const int MT = M / GF;
+  const int64_t RT = (n_rows + GR - 1) / GR;
   int mt_tile;
   int64_t rt_tile;
   if (MT % 8 == 0) {
@@ -96,101 +105,100 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     rt_tile = blockIdx.x / MT;
   }
   if (rt_tile >= RT) return;
-  const int m0 = mt_tile * GT;
-  const int64_t n0 = rt_tile * GT;
-  const int wm = wave & 3, wr = wave >> 2;                 // wave tile: features [32 wm, +32) x rows [64 wr, +64)
+  const int m0 = mt_tile * GF;
+  const int64_t n0 = rt_tile * GR;
+  const int wm = wave & 1, wr = wave >> 1;                 // wave tile: features [64 wm, +64) x rows [64 wr, +64)
 
-  // ---- staging: thread -> (row / feature tid >> 2, k group tid & 3) ------------------------------------------------------
+  // ---- staging: thread -> (rows tid >> 2 and 128 + (tid >> 2) / feature tid >> 2, k group tid & 3) ------------------------
   const int srow = tid >> 2, skq = tid & 3;
-  const int64_t an = n0 + srow < n_rows ? n0 + srow : n_rows - 1;
-  const TS* xrow = x + (size_t)an * K;
+  const TS* xrow[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int64_t an = n0 + srow + 128 * e < n_rows ? n0 + srow + 128 * e : n_rows - 1;
+    xrow[e] = x + (size_t)an * K;
+  }
   const size_t plane_elems = (size_t)KCn * M * 32;
   const __bf16* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
-  // two register sets: the loads of chunk kc+2 are issued while chunk kc is being multiplied and are not touched
-  // before the iteration after next (a global round trip is longer than one chunk's 768 matrix-pipe cycles)
-  f32x4 xa0, xb0, xa1, xb1;
-  xbf8 wb0[3], wb1[3];
-  auto stage_load = [&](int kc, f32x4& xa, f32x4& xb, xbf8 (&wb)[3]) {
+  f32x4 xa[2], xb[2];
+  xbf8 wb[3];
+  auto stage_load = [&](int kc) {
     const int k = kc * GK + 8 * skq;
     const int kcl = k + 8 <= K ? k : (K >= 8 ? K - 8 : 0);      // unconditional loads; out-of-range groups are zeroed below
-    ld8(xrow, (size_t)kcl, xa, xb);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) ld8(xrow[e], (size_t)kcl, xa[e], xb[e]);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       wb[p] = *reinterpret_cast<const xbf8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
   };
-  auto stage_store = [&](int buf, int kc, const f32x4& xa, const f32x4& xb, const xbf8 (&wb)[3]) {
-    __bf16* As = lds + buf * 6 * GPL;
-    __bf16* Bs = As + 3 * GPL;
+  auto stage_store = [&](int buf, int kc) {
+    __bf16* As = lds + buf * G_BUF;
+    __bf16* Bs = As + 3 * GPA;
     const int k = kc * GK + 8 * skq;
     const float keep = k + 8 <= K ? 1.0f : 0.0f;
-    const f32x4 va = xa * keep, vb = xb * keep;
-    unsigned p0[4], p1[4], p2[4];
-    split_pair(va[0], va[1], p0[0], p1[0], p2[0]);
-    split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
-    split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
-    split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
-    const int off = x_off<GK>(srow, 8 * skq);           // 16-byte slots XOR-swizzled per row group (ttrnn_split.h)
-    *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
-    *reinterpret_cast<u32x4*>(As + GPL + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
-    *reinterpret_cast<u32x4*>(As + 2 * GPL + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<xbf8*>(Bs + p * GPL + off) = wb[p];
+    for (int e = 0; e < 2; ++e) {
+      const f32x4 va = xa[e] * keep, vb = xb[e] * keep;
+      unsigned p0[4], p1[4], p2[4];
+      split_pair(va[0], va[1], p0[0], p1[0], p2[0]);
+      split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
+      split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
+      split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
+      const int off = x_off<GK>(srow + 128 * e, 8 * skq);   // 16-byte slots XOR-swizzled per row group (ttrnn_split.h)
+      *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
+      *reinterpret_cast<u32x4*>(As + GPA + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      *reinterpret_cast<u32x4*>(As + 2 * GPA + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    }
+    const int offb = x_off<GK>(srow, 8 * skq);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<xbf8*>(Bs + p * GPB + offb) = wb[p];
   };
 
-  f32x4 acc_lo[2][4], acc_hi[2][4];
+  // one fp32 accumulator per tile: the six terms of a chunk are added smallest first (SPLIT_TW / SPLIT_TX order)
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) { acc_lo[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi[mi][ri] = acc_lo[mi][ri]; }
+    for (int ri = 0; ri < 4; ++ri) acc[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // one chunk: fragment reads of `buf`, then the MFMAs with the split + LDS stores of the NEXT chunk (other buffer, data
-  // prefetched into registers two chunks ago) issued between the two halves of the MFMA stream, so that the 13-cycle
-  // ds_write_b128 transfers and the splitting VALU work overlap the matrix pipe instead of preceding it
-  auto chunk = [&](int buf, int kc_next, bool has_next, const f32x4& xa, const f32x4& xb, const xbf8 (&wb)[3]) {
-    const __bf16* As = lds + buf * 6 * GPL;
-    const __bf16* Bs = As + 3 * GPL;
-    xbf8 wf[2][3], af[4][3];
+  stage_load(0);
+  stage_store(0, 0);
+  stage_load(1 < KCn ? 1 : 0);
+  for (int kc = 0; kc < KCn; ++kc) {
+    const int buf = kc & 1;
+    lds_barrier();                                         // chunk kc is in `buf`; nobody reads the other buffer any more
+    const __bf16* As = lds + buf * G_BUF;
+    const __bf16* Bs = As + 3 * GPA;
+    xbf8 wf[4][3];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPL + x_off<GK>(wm * 32 + 16 * mi + c, 8 * q));
-#pragma unroll
-    for (int ri = 0; ri < 4; ++ri)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        af[ri][p] = *reinterpret_cast<const xbf8*>(As + p * GPL + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
+        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPB + x_off<GK>(wm * 64 + 16 * mi + c, 8 * q));
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
-      if (ri == 2 && has_next) stage_store(buf ^ 1, kc_next, xa, xb, wb);
+      xbf8 af[3];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int s = 0; s < 5; ++s)
-          acc_lo[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[ri][SPLIT_TX[s]],
-                                                                  acc_lo[mi][ri], 0, 0, 0);
-        acc_hi[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][0], af[ri][0], acc_hi[mi][ri], 0, 0, 0);
+      for (int p = 0; p < 3; ++p)
+        af[p] = *reinterpret_cast<const xbf8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
+      // the next chunk's split + LDS stores (other buffer; its data was requested a chunk ago) ride inside the MFMA stream
+      if (ri == 1 && kc + 1 < KCn) {
+        stage_store(buf ^ 1, kc + 1);
+        stage_load(kc + 2 < KCn ? kc + 2 : kc + 1);
       }
-    }
-  };
-
-  // KCn is even (the planes are zero-padded to an even number of chunks); past-the-end prefetches re-read the last chunk
-  stage_load(0, xa0, xb0, wb0);
-  stage_load(1, xa1, xb1, wb1);
-  stage_store(0, 0, xa0, xb0, wb0);
-  stage_load(2 < KCn ? 2 : KCn - 2, xa0, xb0, wb0);
-  for (int kc = 0; kc < KCn; kc += 2) {
-    lds_barrier();                                         // chunk kc is in buffer 0; nobody reads buffer 1 any more
-    chunk(0, kc + 1, true, xa1, xb1, wb1);
-    stage_load(kc + 3 < KCn ? kc + 3 : KCn - 1, xa1, xb1, wb1);
-    lds_barrier();
-    chunk(1, kc + 2, kc + 2 < KCn, xa0, xb0, wb0);
-    stage_load(kc + 4 < KCn ? kc + 4 : KCn - 2, xa0, xb0, wb0);
-  }
-  // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 32wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
+#if GEMM_EXP == 1
+      if (K > 0) continue;                                  // experiment: no MFMAs
+#endif
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int mf = m0 + wm * 32 + 16 * mi + 4 * q;
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc[mi][ri], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 64wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int mf = m0 + wm * 64 + 16 * mi + 4 * q;
     f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias) {
       const int hd = mf >> 2;
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc_hi[mi][ri] + acc_lo[mi][ri] + bh;
+      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] + bh;
     }
   }
 }
@@ -369,7 +377,7 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
   }
   const int KCn = gemm_chunks(K);
   const int MT = M / GT;
-  const int64_t RT = (n_rows + GT - 1) / GT;
+  const int64_t RT = (n_rows + GR - 1) / GR;
   int64_t grid;
   if (MT % 8 == 0) {
     const int64_t supers = (int64_t)(MT / 8) * ((RT + 3) / 4);
