@@ -19,10 +19,6 @@
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 
-#ifndef GEMM_EXP
-#define GEMM_EXP 0
-#endif
-
 namespace ttrnn {
 
 namespace {
@@ -181,13 +177,10 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
       for (int p = 0; p < 3; ++p)
         af[p] = *reinterpret_cast<const xbf8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
       // the next chunk's split + LDS stores (other buffer; its data was requested a chunk ago) ride inside the MFMA stream
-      if (ri == 1 && kc + 1 < KCn) {
-        stage_store(buf ^ 1, kc + 1);
-        stage_load(kc + 2 < KCn ? kc + 2 : kc + 1);
+      if (ri == 1) {                                        // unconditional: no branch inside the chunk
+        stage_store(buf ^ 1, kc + 1);                       // past the end it fills the idle buffer with a masked chunk
+        stage_load(kc + 2 < KCn ? kc + 2 : KCn - 1);
       }
-#if GEMM_EXP == 1
-      if (K > 0) continue;                                  // experiment: no MFMAs
-#endif
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
