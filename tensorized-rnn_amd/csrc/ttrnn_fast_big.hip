@@ -408,44 +408,64 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
   bool dead = false;                                       // thread 0 only
   __syncthreads();
 
-  for (int t = 0; t < T; ++t) {
-    // ---- stage 1: this workgroup's half of the m-tiles, result = its HR rows of the stage-0 image -------------------
-    for (int x0 = half * (T1::XM / 2); x0 < (half + 1) * (T1::XM / 2); x0 += XC) {
-      int z = 0;
-      asm volatile("" : "+v"(z));
-      float w[XC * T1::NSTEP];
-      load_wfrag_xf<S, 1, XC>(w, packed, wave, lane + z, x0);
-      lin_stage_x<S, 1, 0, XC>(w, hbuf, img, wave, lane + z, 0, x0, half * HR);
+  // Core fragments travel AHEAD of their use (streaming 384 KB per step from L2 at ~70 GB/s per CU takes about as long as
+  // the MFMAs; loaded right before use, as in the one-workgroup kernel, the two did not overlap).  Stage 1 goes through
+  // its 8 m-tiles in four chunks of two with two register slots (the next chunk is requested before the current one is
+  // multiplied; chunk 0 of step t+1 during stage 0 of step t); stage 0's 32 fragment groups go through three slots of
+  // eight, the first three requested during stage 1.
+  constexpr int XC2 = 2;
+  static_assert(T1::XM / 2 == 4 * XC2 && T0::NU == 32, "four chunks of stage 1, four quarters of stage 0");
+  const f32x4* F0 = reinterpret_cast<const f32x4*>(packed + woff_of<S>(0));
+  const int mt0 = wave % T0::MT, rtl = wave / T0::MT;
+  const int xb = half * (T1::XM / 2);
+  const int row0 = 16 * rtl + c;
+  float s1a[XC2 * T1::NSTEP], s1b[XC2 * T1::NSTEP];
+  f32x4 q0[8], q1[8], q2[8];
+  f32x4 acc0, acc1;
+  auto loadq = [&](f32x4 (&qq)[8], int i, int zz) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) qq[u] = F0[(size_t)(mt0 * T0::NU + 8 * i + u) * 64 + lane + zz];
+  };
+  auto mm = [&](const f32x4 (&qq)[8], int i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(img + a_off<T0::KP>(row0, (4 * (8 * i + u) + q) * 4));
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[u][0], af[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[u][1], af[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[u][2], af[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[u][3], af[3], acc1, 0, 0, 0);
     }
+  };
+  load_wfrag_xf<S, 1, XC2>(s1a, packed, wave, lane, xb);
+
+  for (int t = 0; t < T; ++t) {
+    int z = 0;
+    asm volatile("" : "+v"(z));            // per-step opaque lane id: the fragment loads stay where they are written
+    // ---- stage 1: this workgroup's half of the m-tiles, result = its HR rows of the stage-0 image -------------------
+    load_wfrag_xf<S, 1, XC2>(s1b, packed, wave, lane + z, xb + 2);
+    lin_stage_x<S, 1, 0, XC2>(s1a, hbuf, img, wave, lane, 0, xb, half * HR);
+    load_wfrag_xf<S, 1, XC2>(s1a, packed, wave, lane + z, xb + 4);
+    loadq(q0, 0, z);
+    lin_stage_x<S, 1, 0, XC2>(s1b, hbuf, img, wave, lane, 0, xb + 2, half * HR);
+    load_wfrag_xf<S, 1, XC2>(s1b, packed, wave, lane + z, xb + 6);
+    loadq(q1, 1, z);
+    lin_stage_x<S, 1, 0, XC2>(s1a, hbuf, img, wave, lane, 0, xb + 4, half * HR);
+    loadq(q2, 2, z);
+    lin_stage_x<S, 1, 0, XC2>(s1b, hbuf, img, wave, lane, 0, xb + 6, half * HR);
     __syncthreads();
     // ---- stage 0 on the local rows: wave = (m-tile wave % MT, local row tile wave / MT) ---------------------------
     {
-      int z = 0;
-      asm volatile("" : "+v"(z));
-      const int mt = wave % T0::MT, rtl = wave / T0::MT;
-      const f32x4* F = reinterpret_cast<const f32x4*>(packed + woff_of<S>(0));
-      const int row = 16 * rtl + c;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      constexpr int UC = 8;                                   // fragment groups per chunk (32 k-steps)
-#pragma unroll 1
-      for (int u0 = 0; u0 < T0::NU; u0 += UC) {
-        f32x4 wf[UC], af[UC];
-#pragma unroll
-        for (int u = 0; u < UC; ++u) {
-          wf[u] = F[(size_t)(mt * T0::NU + u0 + u) * 64 + lane + z];
-          af[u] = *reinterpret_cast<const f32x4*>(img + a_off<T0::KP>(row, (4 * (u0 + u) + q) * 4));
-        }
-#pragma unroll
-        for (int u = 0; u < UC; ++u) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], af[u][0], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], af[u][1], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], af[u][2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], af[u][3], acc1, 0, 0, 0);
-        }
-      }
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
+      load_wfrag_xf<S, 1, XC2>(s1a, packed, wave, lane + z, xb);         // chunk 0 of step t+1
+      mm(q0, 0);
+      loadq(q0, 3, z);
+      mm(q1, 1);
+      mm(q2, 2);
+      mm(q0, 3);
       const f32x4 acc = acc0 + acc1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) gb[(16 * mt + 4 * q + j) * HR + row] = acc[j];      // [m0][local row]
+      for (int j = 0; j < 4; ++j) gb[(16 * mt0 + 4 * q + j) * HR + row0] = acc[j];      // [m0][local row]
     }
     __syncthreads();
     // ---- gates (lstm.py:26-32): o = m0*I1 + i1, gate = m0 / 16 ---------------------------------------------------------
