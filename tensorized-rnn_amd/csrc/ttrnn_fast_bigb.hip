@@ -57,21 +57,23 @@ __global__ void __launch_bounds__(256) k_bigb_prep(const float* __restrict__ pac
 
 // T0 of the transposed chain on the RL = 64 / NH local rows (i23) of the gate-gradient image dyimg[i23 local][i01]:
 //   img0[j01][(i23 local, r)] = sum_i01 A[(j01,r)][i01] dy[i01][i23];  m-tiles {wave + 8x}, two row tiles at a time
+template <class ST>
+__device__ __forceinline__ void bigT_load1(f32x4 (&wf)[4][4], const float* __restrict__ fragT, int wave, int lane) {
+  using T1 = St<ST, 1>;
+  const f32x4* F1 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(1));
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wf[x][u] = F1[(size_t)((wave + FAST_NW * x) * T1::NU + u) * 64 + lane];
+}
+
 template <class ST, int NH>
-__device__ __forceinline__ void bigT_stage1(const float* __restrict__ fragT, const float* dyimg, float* img0, int wave,
-                                            int lane) {
+__device__ __forceinline__ void bigT_stage1w(const f32x4 (&wf)[4][4], const float* dyimg, float* img0, int wave,
+                                             int lane) {
   using T1 = St<ST, 1>;
   using T0 = St<ST, 0>;
   constexpr int RTL = T1::ROWS / NH / 16, K0L = T0::K / NH;
   const int c = lane & 15, q = lane >> 4;
-  int z = 0;
-  asm volatile("" : "+v"(z));          // keep the fragment loads inside this phase
-  const f32x4* F1 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(1));
-  f32x4 wf[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wf[x][u] = F1[(size_t)((wave + FAST_NW * x) * T1::NU + u) * 64 + lane + z];
 #pragma unroll 1
   for (int rtb = 0; rtb < RTL; rtb += 2) {
     f32x4 af[2][4];
@@ -103,6 +105,16 @@ __device__ __forceinline__ void bigT_stage1(const float* __restrict__ fragT, con
   }
 }
 
+template <class ST, int NH>
+__device__ __forceinline__ void bigT_stage1(const float* __restrict__ fragT, const float* dyimg, float* img0, int wave,
+                                            int lane) {
+  int z = 0;
+  asm volatile("" : "+v"(z));          // keep the fragment loads inside this phase
+  f32x4 wf[4][4];
+  bigT_load1<ST>(wf, fragT, wave, lane + z);
+  bigT_stage1w<ST, NH>(wf, dyimg, img0, wave, lane);
+}
+
 // T1 over this workgroup's K slice: dhp[k half][j23][j01] = partial sum_(i23,r) img0[j01][(i23,r)] Bm[j23][(i23,r)];
 // wave = (m-tile wave % 4, k half wave / 4)
 template <class ST, int NH>
@@ -132,6 +144,59 @@ __device__ __forceinline__ void bigT_stage0(const float* __restrict__ fragT, con
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], af[u][1], acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], af[u][2], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], af[u][3], acc1, 0, 0, 0);
+    }
+  }
+  const f32x4 acc = acc0 + acc1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dhp[(kh * T0::M + 16 * mt + 4 * q + j) * 16 + c] = acc[j];
+}
+
+// The same stage for the time loop: chunk 0 of this wave's fragment groups stays in registers for the whole launch
+// (r0), the others stream through two slots of eight groups, each requested two chunks before it is multiplied.
+template <class ST, int NH>
+__device__ __forceinline__ void bigT_load0(f32x4 (&w)[8], const float* __restrict__ fragT, int half, int wave, int lane,
+                                           int chunk) {
+  using T0 = St<ST, 0>;
+  constexpr int NUL = T0::K / NH / 16, NUW = NUL / 2;
+  const int mt = wave & 3, kh = wave >> 2;
+  const f32x4* F0 = reinterpret_cast<const f32x4*>(fragT + woff_of<ST>(0));
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = F0[(size_t)(mt * T0::NU + half * NUL + kh * NUW + 8 * chunk + u) * 64 + lane];
+}
+
+template <class ST, int NH>
+__device__ __forceinline__ void bigT_stage0p(const f32x4 (&r0)[8], const float* __restrict__ fragT, const float* img0,
+                                             float* dhp, int half, int wave, int lane) {
+  using T0 = St<ST, 0>;
+  constexpr int K0L = T0::K / NH, NUW = K0L / 32, NCH = NUW / 8;
+  static_assert(NCH >= 3, "three or more chunks per wave");
+  const int c = lane & 15, q = lane >> 4;
+  const int mt = wave & 3, kh = wave >> 2;
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  f32x4 sa[8], sb[8];
+  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  auto mmc = [&](const f32x4 (&w)[8], int chunk) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(img0 + a_off<K0L>(c, (4 * (kh * NUW + 8 * chunk + u) + q) * 4));
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][0], af[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][1], af[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][2], af[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][3], af[3], acc1, 0, 0, 0);
+    }
+  };
+  bigT_load0<ST, NH>(sa, fragT, half, wave, lane + z, 1);
+  bigT_load0<ST, NH>(sb, fragT, half, wave, lane + z, 2);
+  mmc(r0, 0);
+#pragma unroll
+  for (int i = 1; i < NCH; ++i) {
+    if (i & 1) {
+      mmc(sa, i);
+      if (i + 2 < NCH) bigT_load0<ST, NH>(sa, fragT, half, wave, lane + z, i + 2);
+    } else {
+      mmc(sb, i);
+      if (i + 2 < NCH) bigT_load0<ST, NH>(sb, fragT, half, wave, lane + z, i + 2);
     }
   }
   const f32x4 acc = acc0 + acc1;
@@ -199,6 +264,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
   }
   unsigned int* flag = sync + b;
   bool dead = false;                                       // thread 0 only
+  // resident for the whole launch: T0's fragments (A^T, 64 registers) and the first chunk of T1's
+  f32x4 wf1[4][4], r0[8];
+  bigT_load1<ST>(wf1, fragT, wave, lane);
+  bigT_load0<ST, NH>(r0, fragT, half, wave, lane, 0);
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -233,9 +302,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       fd[u] = d_out ? ld(d_out, b2 * H + hid[u]) : 0.f;
     }
     __syncthreads();
-    bigT_stage1<ST, NH>(fragT, dyimg, img0, wave, lane);
+    bigT_stage1w<ST, NH>(wf1, dyimg, img0, wave, lane);
     __syncthreads();
-    bigT_stage0<ST, NH>(fragT, img0, dhp, half, wave, lane);
+    bigT_stage0p<ST, NH>(r0, fragT, img0, dhp, half, wave, lane);
     __syncthreads();
     // ---- dh_{t-1} of the own units (+ the partner's share) ----------------------------------------------------------------
     if constexpr (NH == 1) {
