@@ -177,7 +177,8 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       float* Wd = (float*)((char*)dWd + gemm_split_dense_bytes(s.in_size, s.out_size));
       void* planes = (char*)Wd + gemm_split_dense_bytes(s.in_size, s.out_size);
       st = launch_fill_identity(dtype, s.in_size, ident, sm);
-      if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm);
+      if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm,
+                                                 fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16);
       if (st == TTRNN_OK)
         st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       if (st != TTRNN_OK || !dx) return st;

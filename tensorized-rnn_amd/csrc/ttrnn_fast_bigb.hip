@@ -15,6 +15,7 @@
 //     atomics at the end; k_bigw_finish applies the product rule back to the four TT cores.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
 #include "ttrnn_mfma.h"
@@ -802,6 +803,7 @@ size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
 template <typename TS>
 static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, const void* dy, void* dx, float* d_packed,
                          float* d_bias, void* ws, hipStream_t stream) {
+  const bool split_math = ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT;
   float* m3 = (float*)ws;
   float* m2 = (float*)((char*)ws + B3);
   float* mT = (float*)((char*)ws + B3 + B2);
@@ -832,7 +834,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     float* dWf = (float*)((char*)dB + BDB);
     hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
     const int sd = launch_dense_wgrad(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, 1024, 4096, x, (const float*)dy, dWf,
-                                      d_bias, stream);
+                                      d_bias, stream, split_math);
     if (sd != TTRNN_OK) return sd;
     hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
     hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);

@@ -332,6 +332,184 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
   }
 }
 
+// ---- the same dense gradient on the bf16 MFMA (split arithmetic) ---------------------------------------------------------------
+// The contraction index (row n) is the slow index of both operands, so the k-packed MFMA operands are columns of the
+// staged tiles: gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block of 16-bit elements,
+// delivered column-major) fetches them from ROW-major bf16 planes, so staging stays a plain coalesced copy + split
+// (three 8-byte stores per four elements).  Plane layout: [32 rows][128 columns] with the 16-byte chunks XOR-swizzled by
+// the row (conflict-free for the row stores and the transposed reads); 128 (j) x 256 (o) tile per workgroup, 64 x 64 per
+// wave, 32 rows per chunk = one MFMA k-step, both operands split on the fly.
+struct DenseS {
+  static constexpr int TJ = 128, TO = 256, KB = 32;
+  static constexpr int PLANE = KB * 128;                   // bf16 elements of one [32][128] plane
+  static constexpr int BUF = 3 * PLANE * 3;                // x: 3 planes; dy: 3 planes x 2 column halves
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(__bf16);
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// byte offset of 16-byte chunk ch (0..15) of row `row` in a [rows][128 x 16-bit] plane
+__device__ __forceinline__ int tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// the 8 consecutive rows 8g .. 8g+7 (g = lane >> 4) of column 16*cb + (lane & 15): the k-packed MFMA operand of a lane
+__device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
+  const int g = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+  const char* base = reinterpret_cast<const char*>(plane);
+  const int o0 = tr_off(8 * g + qq, 2 * cb + (p >> 1)) + 8 * (p & 1);
+  const int o1 = tr_off(8 * g + 4 + qq, 2 * cb + (p >> 1)) + 8 * (p & 1);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(xbf8, v);
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
+                                                               const TS* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dW, float* __restrict__ d_bias) {
+  constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  __bf16* ldsb = reinterpret_cast<__bf16*>(smem2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int TJn = (IN + DenseS::TJ - 1) / DenseS::TJ, TOn = OUT / DenseS::TO;
+  int tj, to, ks;
+  if (KS % 8 == 0) {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, tile = i % (TJn * TOn);
+    ks = (i / (TJn * TOn)) * 8 + xcd;                      // all tiles of one row range on one XCD
+    tj = tile / TOn;
+    to = tile % TOn;
+  } else {
+    const int tile = blockIdx.x % (TJn * TOn);
+    ks = blockIdx.x / (TJn * TOn);
+    tj = tile / TOn;
+    to = tile % TOn;
+  }
+  const int j0 = tj * DenseS::TJ, o0 = to * DenseS::TO;
+  const int64_t r0 = (int64_t)ks * rows_per;
+  const int64_t r1 = r0 + rows_per < n_rows ? r0 + rows_per : n_rows;
+  if (r0 >= r1) return;
+  const int wm = wave & 1, wn = wave >> 1;                 // wave tile: j [64 wm, +64) x o [64 wn, +64)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dbs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dbs[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = d_bias != nullptr && tj == 0;
+
+  // staging: x quads tid + 512e (row = id >> 5, columns 4 (id & 31)); dy quads tid + 512e (row = id >> 6, columns 4 (id & 63))
+  f32x4 sx[2], sd[4];
+  int xr[2], xc[2], dr[4], dc[4];
+  bool xin[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int id = tid + FAST_NT * e;
+    xr[e] = id >> 5;
+    xc[e] = 4 * (id & 31);
+    xin[e] = j0 + xc[e] + 4 <= IN;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int id = tid + FAST_NT * e;
+    dr[e] = id >> 6;
+    dc[e] = 4 * (id & 63);
+  }
+  auto stage_load = [&](int64_t nb) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t n = nb + xr[e] < r1 ? nb + xr[e] : r1 - 1;          // unconditional loads; masked at the store
+      sx[e] = ld4(x, (size_t)n * IN + (xin[e] ? j0 + xc[e] : 0));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t n = nb + dr[e] < r1 ? nb + dr[e] : r1 - 1;
+      sd[e] = ld4(dy, (size_t)n * OUT + o0 + dc[e]);
+    }
+  };
+  auto store4 = [&](__bf16* plane0, int row, int col, const f32x4& v) {   // col: 0..127, multiple of 4
+    unsigned a0, b0, c0, a1, b1, c1;
+    split_pair(v[0], v[1], a0, b0, c0);
+    split_pair(v[2], v[3], a1, b1, c1);
+    char* base = reinterpret_cast<char*>(plane0) + tr_off(row, col >> 3) + 8 * ((col >> 2) & 1);
+    *reinterpret_cast<u32x2*>(base) = u32x2{a0, a1};
+    *reinterpret_cast<u32x2*>(base + PL * 2) = u32x2{b0, b1};
+    *reinterpret_cast<u32x2*>(base + 2 * PL * 2) = u32x2{c0, c1};
+  };
+  auto stage_store = [&](int buf, int64_t nb) {
+    __bf16* xs = ldsb + buf * DenseS::BUF;                 // [3][32][128]
+    __bf16* ds0 = xs + 3 * PL;                             // columns 0..127:   [3][32][128]
+    __bf16* ds1 = ds0 + 3 * PL;                            // columns 128..255: [3][32][128]
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float keep = (nb + xr[e] < r1 && xin[e]) ? 1.0f : 0.0f;
+      store4(xs, xr[e], xc[e], sx[e] * keep);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float keep = nb + dr[e] < r1 ? 1.0f : 0.0f;
+      const f32x4 vd = sd[e] * keep;
+      store4(dc[e] < 128 ? ds0 : ds1, dr[e], dc[e] & 127, vd);
+      dbs[e] += vd;
+    }
+  };
+
+  const int64_t chunks = (r1 - r0 + KB - 1) / KB;
+  stage_load(r0);
+  stage_store(0, r0);
+  stage_load(r0 + (1 < chunks ? 1 : 0) * KB);
+  for (int64_t ch = 0; ch < chunks; ++ch) {
+    const int buf = (int)(ch & 1);
+    lds_barrier();                                         // chunk ch is in `buf`; nobody reads the other buffer any more
+    const __bf16* xs = ldsb + buf * DenseS::BUF;
+    const __bf16* dsw = xs + 3 * PL + (wn >> 1) * 3 * PL;  // this wave's column half of dy
+    xbf8 af[4][3];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[mi][p] = tr_frag(xs + p * PL, wm * 4 + mi, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      xbf8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = tr_frag(dsw + p * PL, (wn & 1) * 4 + ni, lane);
+      if (ni == 1) {                                        // the next chunk's split + stores ride inside the MFMA stream
+        stage_store(buf ^ 1, r0 + (ch + 1) * KB);           // (past the end: a fully masked chunk into the idle buffer)
+        stage_load(r0 + (ch + 2 < chunks ? ch + 2 : ch + 1 < chunks ? ch + 1 : ch) * KB);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc[mi][ni], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
+        if (jj < IN) {
+          float* p = dW + (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
+          if (KS == 1) *p = acc[mi][ni][j];
+          else atomicAdd(p, acc[mi][ni][j]);
+        }
+      }
+  if (want_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(d_bias + o0 + dc[e] + i, dbs[e][i]);
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 static size_t al256g(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -393,37 +571,56 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 
 bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % DenseG::TN == 0; }
 
-// dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into
+// dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
+// split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream) {
-  const int tiles = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
+                       float* d_bias, hipStream_t stream, bool split) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const char* nsw = getenv("TTRNN_DENSE_FP32");            // A/B switch: dense gradient on the fp32 MFMA
+  split = split && out % DenseS::TO == 0 && !(nsw && nsw[0] == '1');
+  const int KBc = split ? DenseS::KB : DenseG::KB;
+  const int tiles = split ? ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO)
+                          : ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   int KS = 1;
   if (tiles < cus) {
     KS = ((cus / tiles + 7) / 8) * 8;                               // multiple of 8: one row range per XCD at a time
-    const int64_t max_ks = (n_rows + DenseG::KB - 1) / DenseG::KB;    // at least one chunk per split
+    const int64_t max_ks = (n_rows + KBc - 1) / KBc;                // at least one chunk per split
     if (KS > max_ks) KS = max_ks < 1 ? 1 : (int)max_ks;
   }
   int64_t rows_per = (n_rows + KS - 1) / KS;
-  rows_per = (rows_per + DenseG::KB - 1) / DenseG::KB * DenseG::KB;
+  rows_per = (rows_per + KBc - 1) / KBc * KBc;
   if (KS > 1 && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  static bool raised[2] = {false, false};
-  const int di = dtype == TTRNN_F32 ? 0 : 1;
-  const void* fn = di == 0 ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
-                           : reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>);
+  static bool raised[4] = {false, false, false, false};
+  const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0);
+  const void* fn = di == 0   ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
+                   : di == 1 ? reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>)
+                   : di == 2 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float>)
+                             : reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t>);
+  const size_t lds = split ? DenseS::LDS_BYTES : DenseG::LDS_BYTES;
   if (!raised[di]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseG::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TTRNN_ERR_LAUNCH;
     raised[di] = true;
   }
   const unsigned grid = (unsigned)(tiles * KS);
-  if (di == 0)
-    hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), DenseG::LDS_BYTES, stream, n_rows, in, out, KS,
-                       rows_per, (const float*)x, dy, dW, d_bias);
-  else
-    hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), DenseG::LDS_BYTES, stream, n_rows, in, out, KS,
-                       rows_per, (const bf16_t*)x, dy, dW, d_bias);
+  switch (di) {
+    case 0:
+      hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
+                         (const float*)x, dy, dW, d_bias);
+      break;
+    case 1:
+      hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
+                         (const bf16_t*)x, dy, dW, d_bias);
+      break;
+    case 2:
+      hipLaunchKernelGGL(k_dense_wgrad_split<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const float*)x, dy, dW, d_bias);
+      break;
+    default:
+      hipLaunchKernelGGL(k_dense_wgrad_split<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias);
+  }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
