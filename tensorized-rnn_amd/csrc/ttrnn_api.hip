@@ -92,12 +92,13 @@ int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* 
 static size_t in1_bwd_bytes(const TtShape& s) { return ((size_t)s.out_size * sizeof(float) + 255 + 256) & ~(size_t)255; }
 
 // Dense-gradient backward (ttrnn_fast_gemm.hip) of a shape with a fused-core weight-gradient kernel: workspace =
-// [that kernel's own | identity rows in x in | dW in x out | dense W in x out | bf16 planes of W^T (K = out, M = in)]
+// [that kernel's own | identity rows in x in | dW in x out | dense W in x out | bf16 planes of W^T (K = out, M = in) |
+//  partial dW tiles of the row ranges]
 static size_t dense_bwd_f10w(const TtShape& s) { return (f10_ttlinear_wgrad_workspace_bytes(s) + 255) & ~(size_t)255; }
 static size_t dense_bwd_bytes(const TtShape& s) {
   if (f10_ttlinear_wgrad_workspace_bytes(s) == 0 || !dense_wgrad_ok(s.in_size, s.out_size)) return 0;
   return dense_bwd_f10w(s) + gemm_split_identity_bytes(s.in_size) + 2 * gemm_split_dense_bytes(s.in_size, s.out_size) +
-         gemm_split_plane_bytes(s.out_size, s.in_size);
+         gemm_split_plane_bytes(s.out_size, s.in_size) + dense_wgrad_scratch_bytes(s.in_size, s.out_size);
 }
 
 size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
@@ -178,7 +179,8 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       void* planes = (char*)Wd + gemm_split_dense_bytes(s.in_size, s.out_size);
       st = launch_fill_identity(dtype, s.in_size, ident, sm);
       if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm,
-                                                 fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16);
+                                                 fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16,
+                                                 (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)));
       if (st == TTRNN_OK)
         st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       if (st != TTRNN_OK || !dx) return st;

@@ -797,7 +797,7 @@ bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype) {
 }
 
 size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
-  return shape_matches<S4>(s) ? B3 + B2 + BT + BDA + BDB + BDW : 0;
+  return shape_matches<S4>(s) ? B3 + B2 + BT + BDA + BDB + BDW + dense_wgrad_scratch_bytes(1024, 4096) : 0;
 }
 
 template <typename TS>
@@ -834,7 +834,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     float* dWf = (float*)((char*)dB + BDB);
     hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
     const int sd = launch_dense_wgrad(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, 1024, 4096, x, (const float*)dy, dWf,
-                                      d_bias, stream, split_math);
+                                      d_bias, stream, split_math, (float*)((char*)dWf + BDW));
     if (sd != TTRNN_OK) return sd;
     hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
     hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);

@@ -227,7 +227,7 @@ __device__ __forceinline__ f32x4 ld4(const bf16_t* p, size_t i) {
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                          const TS* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ dW, float* __restrict__ d_bias) {
+                                                         float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part) {
   constexpr int KB = DenseG::KB, LS = DenseG::LS;
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
   float* xs = ldsf;                      // [2][KB][LS]
@@ -321,9 +321,10 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
       for (int j = 0; j < 4; ++j) {
         const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
         if (jj < IN) {
-          float* p = dW + (size_t)jj * OUT + o0 + wn * 32 + 16 * ni + c;
-          if (KS == 1) *p = acc[mi][ni][j];
-          else atomicAdd(p, acc[mi][ni][j]);
+          const size_t e = (size_t)jj * OUT + o0 + wn * 32 + 16 * ni + c;
+          if (KS == 1) dW[e] = acc[mi][ni][j];
+          else if (part) part[(size_t)ks * IN * OUT + e] = acc[mi][ni][j];      // summed by k_dense_reduce
+          else atomicAdd(dW + e, acc[mi][ni][j]);
         }
       }
   if (want_bias) {
@@ -367,7 +368,7 @@ __device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dW, float* __restrict__ d_bias) {
+                                                               float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   __bf16* ldsb = reinterpret_cast<__bf16*>(smem2);
@@ -378,9 +379,15 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
   int tj, to, ks;
   if (KS % 8 == 0) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, tile = i % (TJn * TOn);
-    ks = (i / (TJn * TOn)) * 8 + xcd;                      // all tiles of one row range on one XCD
-    tj = tile / TOn;
-    to = tile % TOn;
+    ks = (i / (TJn * TOn)) * 8 + xcd;                      // all tiles of one row range on one XCD ...
+    if (TJn % 4 == 0 && TOn % 8 == 0) {                    // ... in blocks of 4 x 8 tiles (the 32 that run side by side)
+      const int blk = tile >> 5, within = tile & 31, nbo = TOn / 8;
+      tj = (blk / nbo) * 4 + (within >> 3);
+      to = (blk % nbo) * 8 + (within & 7);
+    } else {
+      tj = tile / TOn;
+      to = tile % TOn;
+    }
   } else {
     const int tile = blockIdx.x % (TJn * TOn);
     ks = blockIdx.x / (TJn * TOn);
@@ -497,9 +504,10 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
       for (int j = 0; j < 4; ++j) {
         const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
         if (jj < IN) {
-          float* p = dW + (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
-          if (KS == 1) *p = acc[mi][ni][j];
-          else atomicAdd(p, acc[mi][ni][j]);
+          const size_t e = (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
+          if (KS == 1) dW[e] = acc[mi][ni][j];
+          else if (part) part[(size_t)ks * IN * OUT + e] = acc[mi][ni][j];      // summed by k_dense_reduce
+          else atomicAdd(dW + e, acc[mi][ni][j]);
         }
       }
   if (want_bias) {
@@ -508,6 +516,17 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
 #pragma unroll
       for (int i = 0; i < 4; ++i) atomicAdd(d_bias + o0 + dc[e] + i, dbs[e][i]);
   }
+}
+
+// dW[e] = sum over the KS row ranges of part[ks][e] (row ranges past the end of the rows are not summed)
+__global__ void __launch_bounds__(256) k_dense_reduce(const float* __restrict__ part, int KS, size_t n4,
+                                                      float* __restrict__ dW) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(part);
+  f32x4 v = p[e];
+  for (int k = 1; k < KS; ++k) v += p[(size_t)k * n4 + e];
+  reinterpret_cast<f32x4*>(dW)[e] = v;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -574,7 +593,7 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % De
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream, bool split) {
+                       float* d_bias, hipStream_t stream, bool split, float* scratch) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const char* nsw = getenv("TTRNN_DENSE_FP32");            // A/B switch: dense gradient on the fp32 MFMA
@@ -590,7 +609,11 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   }
   int64_t rows_per = (n_rows + KS - 1) / KS;
   rows_per = (rows_per + KBc - 1) / KBc * KBc;
-  if (KS > 1 && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  KS = (int)((n_rows + rows_per - 1) / rows_per);                   // no empty row range
+  // KS > 1: every row range writes its own partial tile into `scratch` (summed afterwards); atomics without scratch
+  float* part = KS > 1 ? scratch : nullptr;
+  if (KS > 1 && !part && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess)
+    return TTRNN_ERR_LAUNCH;
   static bool raised[4] = {false, false, false, false};
   const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0);
   const void* fn = di == 0   ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
@@ -607,21 +630,38 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   switch (di) {
     case 0:
       hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const float*)x, dy, dW, d_bias);
+                         (const float*)x, dy, dW, d_bias, part);
       break;
     case 1:
       hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const bf16_t*)x, dy, dW, d_bias);
+                         (const bf16_t*)x, dy, dW, d_bias, part);
       break;
     case 2:
       hipLaunchKernelGGL(k_dense_wgrad_split<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias);
+                         rows_per, (const float*)x, dy, dW, d_bias, part);
       break;
     default:
       hipLaunchKernelGGL(k_dense_wgrad_split<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias);
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part);
+  }
+  if (part) {
+    const size_t n4 = (size_t)in * out / 4;
+    hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, KS, n4, dW);
   }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// bytes of the partial-tile scratch launch_dense_wgrad wants for this shape (0: one workgroup per tile covers all rows)
+size_t dense_wgrad_scratch_bytes(int in, int out) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  else (void)hipGetLastError();
+  const int tiles_s = ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO > 0 ? out / DenseS::TO : 1);
+  const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
+  const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;
+  if (tiles >= cus) return 0;
+  const int KS = ((cus / tiles + 7) / 8) * 8;
+  return (size_t)KS * in * out * sizeof(float);
 }
 
 }  // namespace ttrnn

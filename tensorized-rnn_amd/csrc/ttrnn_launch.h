@@ -113,7 +113,8 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream, bool split);
+                       float* d_bias, hipStream_t stream, bool split, float* scratch);
+size_t dense_wgrad_scratch_bytes(int in, int out);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
 bool big_rnn_fwd_available(const RnnShape& rs, int dtype);
