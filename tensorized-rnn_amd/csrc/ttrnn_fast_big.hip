@@ -352,14 +352,18 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
   }
 }
 
+__device__ __forceinline__ float round_like(const float*, float v) { return v; }
+__device__ __forceinline__ float round_like(const bf16_t*, float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 // ---- two workgroups per sample (two-core matrices, LSTM) ------------------------------------------------------------
 // With B = 128 samples the one-workgroup-per-sample kernel leaves half of the 256 CUs idle.  Both stages of the
 // two-core chain split cleanly over the rows of the SECOND stage: stage 1's output features are (i1, r1) and become,
 // viewed flat, the rows i1 of stage 0, whose rows are independent and end up as the low part of the hidden index
 // (hid = (m0 % 16) * I1 + i1).  Workgroup `half` of a pair therefore computes the m-tiles of stage 1 with
 // i1 in [half*I1/2, (half+1)*I1/2) (half of W_1 streamed), stage 0 on those rows, and the gates of those H/2 hidden
-// units — no exchange inside a step.  Once per step the halves of h_t are swapped through a double-buffered global
-// row and a release/acquire counter at agent scope (both workgroups are resident: 2B <= #CUs, one workgroup per CU).
+// units — no exchange inside a step.  Once per step the halves of h_t are swapped through double-buffered global rows of
+// self-validating 64-bit words (value, step tag) written and polled with relaxed agent-scope atomics (both workgroups
+// are resident: 2B <= #CUs, one workgroup per CU).
 template <class S, typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const float* __restrict__ gin,
                                                            const TS* __restrict__ h0, const TS* __restrict__ c0,
@@ -367,8 +371,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
                                                            const TS* __restrict__ bias_in,
                                                            const TS* __restrict__ bias_hid, TS* __restrict__ out,
                                                            TS* __restrict__ hT, TS* __restrict__ cT,
-                                                           float* __restrict__ reserve, float* __restrict__ hx,
-                                                           unsigned int* __restrict__ sync) {
+                                                           float* __restrict__ reserve,
+                                                           unsigned long long* __restrict__ hx) {
   static_assert(S::D == 2 && big_frag_order<S>(), "two-core matrices in fragment order");
   using T1 = St<S, 1>;
   using T0 = St<S, 0>;
@@ -404,8 +408,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
   hbuf[a_off<T1::KP>(hid / T1::K, hid % T1::K)] = hst;
   hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = h0 ? ld(h0, b * H + hidp) : 0.f;
   f32x4 gi = T > 0 ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};     // slots i,g,f,o; prefetched a step ahead
-  unsigned int* flag = sync + b;
-  bool dead = false;                                       // thread 0 only
+  bool dead = false;
   __syncthreads();
 
   // Core fragments travel AHEAD of their use (streaming 384 KB per step from L2 at ~70 GB/s per CU takes about as long as
@@ -483,32 +486,32 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
         rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
       }
       st(out, bt * H + hid, hy);
-      hy = ld(out, bt * H + hid);                  // what the next step sees: rounded once to the storage type
+      hy = round_like(out, hy);                    // what the next step sees: rounded once to the storage type
       hst = hy;
       hbuf[a_off<T1::KP>(hid / T1::K, hid % T1::K)] = hy;
-      __hip_atomic_store(hx + (b * 2 + (t & 1)) * H + hid, hy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- swap halves of h_t with the partner workgroup: every unit travels as one 64-bit word (value, step tag) -------
+      // Relaxed agent-scope atomics only: they are performed at the memory side, coherent across XCDs, WITHOUT the L2
+      // write-back / invalidate a release / acquire pair costs (that flush evicted the streamed cores every step).  The
+      // tag makes the word self-validating, so no flag, no counter and no barrier stand between the store and the
+      // partner's load: one memory round trip per step instead of three.  Double-buffered by step parity: a slot is
+      // rewritten two steps later, which needs the partner's h of the step in between — written after it read this one.
+      __hip_atomic_store(hx + (b * 2 + (t & 1)) * H + hid,
+                         ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(hy),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
     }
-    // ---- swap halves of h_t with the partner workgroup -------------------------------------------------------------
-    __syncthreads();
-    if (tid == 0) {
-      // relaxed agent-scope atomics only: they are performed at the memory side, coherent across XCDs, WITHOUT the
-      // L2 write-back / invalidate a release / acquire pair costs (that flush evicted the streamed cores every step and
-      // ate the whole gain); ordering comes from the barrier before (all h stores acknowledged) and after
-      __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int target = 2u * (unsigned int)(t + 1);
+    {
+      const unsigned long long* src = hx + (b * 2 + (t & 1)) * H + hidp;
+      unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // bounded: a partner that is not resident must not hang the GPU — after one time-out (~0.1 s) stop waiting for
       // the rest of the launch (the results are then wrong, which the parity tests would show, but the kernel ends)
       long spin = 0;
-      while (!dead && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      while (!dead && (unsigned)(v >> 32) != (unsigned)(t + 1)) {
         __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (++spin > (1L << 21)) dead = true;
       }
-    }
-    __syncthreads();
-    {
-      const float hp = __hip_atomic_load(hx + (b * 2 + (t & 1)) * H + hidp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = hp;
+      hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = __uint_as_float((unsigned)v);
     }
     __syncthreads();
   }
@@ -544,7 +547,7 @@ size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   // per TT-matrix: the 3-core and the 2-core merged packed buffers
   const size_t m3 = ((size_t)merged_elems<ShpH1024R32L_M>() * sizeof(float) + 255) & ~(size_t)255;
   const size_t m2 = ((size_t)merged2_elems<ShpH1024R32L_M2>() * sizeof(float) + 255) & ~(size_t)255;
-  const size_t pair = (size_t)rs.B * 2 * rs.H * sizeof(float) + (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
+  const size_t pair = (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);      // tagged h exchange words of the pair kernel
   // + h exchange rows and counters of the pair kernel + identity rows, dense W_in and its bf16 planes of the GEMM K-in
   return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair + big_gemm_bytes(rs);
 }
@@ -569,8 +572,7 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     static_assert(big_mid<S2>() <= big_mid<S4>(), "slab size");
     const size_t b3 = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
     const size_t b2 = ((size_t)merged2_elems<S2>() * sizeof(float) + 255) & ~(size_t)255;
-    const size_t pair_bytes = (size_t)rs.B * 2 * rs.H * sizeof(float) +
-                              (((size_t)rs.B * sizeof(unsigned int) + 255) & ~(size_t)255);
+    const size_t pair_bytes = (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);
     char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes - big_gemm_bytes(rs);
     float* m3_in = (float*)tail;
     float* m3_hid = (float*)(tail + b3);
@@ -630,10 +632,9 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     }
     const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
     if (2 * rs.B <= cus && !(np && np[0] == '1')) {
-      // two workgroups per sample: h exchange rows [B][2][H] + counters behind the merged cores
-      float* hxb = (float*)(tail + 2 * (b3 + b2));
-      unsigned int* cnt = (unsigned int*)((char*)hxb + (size_t)rs.B * 2 * rs.H * sizeof(float));
-      if (hipMemsetAsync(cnt, 0, (size_t)rs.B * sizeof(unsigned int), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+      // two workgroups per sample: tagged h exchange words [B][2][H] behind the merged cores (tag 0 = never written)
+      unsigned long long* hxb = (unsigned long long*)(tail + 2 * (b3 + b2));
+      if (hipMemsetAsync(hxb, 0, pair_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
       // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (76 KB each would fit twice, and
       // the dispatcher then packs the pairs onto half of the CUs: measured no faster than one workgroup per sample)
       constexpr size_t lds_img = (size_t)(St<S2, 0>::ROWS / 2) * St<S2, 0>::KP * sizeof(float);
@@ -646,7 +647,7 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
         raised2 = true;
       }
       hipLaunchKernelGGL((k_lstm_fwd_big2<S2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
-                         (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb, cnt);
+                         (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb);
       return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), lds_rec, stream, rs.B, rs.T,
