@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
                                                           const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                           const TS* __restrict__ d_cT, float* __restrict__ dg_in,
                                                           TS* __restrict__ d_h0, TS* __restrict__ d_c0,
-                                                          float* __restrict__ hx, unsigned int* __restrict__ sync) {
+                                                          unsigned long long* __restrict__ hx) {
   using T1 = St<ST, 1>;
   using T0 = St<ST, 0>;
   constexpr int H = out_size_of<ST>(), GH = in_size_of<ST>();
@@ -263,8 +263,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
     dcur[u] = d_out ? ld(d_out, bt * H + hid[u]) : 0.f;
     dnxt[u] = d_out ? ld(d_out, bt1 * H + hid[u]) : 0.f;
   }
-  unsigned int* flag = sync + b;
-  bool dead = false;                                       // thread 0 only
+  bool dead = false;
   // resident for the whole launch: T0's fragments (A^T, 64 registers) and the first chunk of T1's
   f32x4 wf1[4][4], r0[8];
   bigT_load1<ST>(wf1, fragT, wave, lane);
@@ -319,20 +318,20 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       const int j23o = half * RL + rl, j23p = (1 - half) * RL + rl;
       const float own = dhp[j23o * 16 + mq] + dhp[(T0::M + j23o) * 16 + mq];
       const float snd = dhp[j23p * 16 + mq] + dhp[(T0::M + j23p) * 16 + mq];
-      __hip_atomic_store(hx + (b * 2 + (n & 1)) * H + mq * I23 + j23p, snd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (tid == 0) {
-        // relaxed agent-scope atomics only (no L2 write-back / invalidate); ordering comes from the barriers around
-        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int target = 2u * (unsigned int)(n + 1);
-        long spin = 0;                                      // bounded: a partner that is not resident must not hang the GPU
-        while (!dead && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spin > (1L << 21)) dead = true;
-        }
+      // self-validating (value, step tag) words, relaxed agent-scope atomics, double-buffered by step parity: see the
+      // forward pair kernel (ttrnn_fast_big.hip)
+      __hip_atomic_store(hx + (b * 2 + (n & 1)) * H + mq * I23 + j23p,
+                         ((unsigned long long)(unsigned)(n + 1) << 32) | (unsigned long long)__float_as_uint(snd),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long* src = hx + (b * 2 + (n & 1)) * H + hid[0];
+      unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long spin = 0;                                        // bounded: a partner that is not resident must not hang the GPU
+      while (!dead && (unsigned)(v >> 32) != (unsigned)(n + 1)) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spin > (1L << 21)) dead = true;
       }
-      __syncthreads();
-      dhrec[0] = own + __hip_atomic_load(hx + (b * 2 + (n & 1)) * H + hid[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dhrec[0] = own + __uint_as_float((unsigned)v);
     }
 #pragma unroll
     for (int u = 0; u < NUT; ++u) {
@@ -729,7 +728,7 @@ bool big_rnn_bwd_available(const RnnShape& rs, int dtype) {
 }
 
 size_t big_rnn_bwd_workspace(const RnnShape& rs) {
-  return B3 + BT + (size_t)rs.B * 2 * rs.H * sizeof(float) + al256((size_t)rs.B * sizeof(unsigned int));
+  return B3 + BT + (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);      // + tagged exchange words of the pair kernel
 }
 
 template <typename TS>
@@ -738,8 +737,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
                          void* ws, hipStream_t stream) {
   float* m3 = (float*)ws;
   float* mT = (float*)((char*)ws + B3);
-  float* hxb = (float*)((char*)ws + B3 + BT);
-  unsigned int* cnt = (unsigned int*)((char*)hxb + (size_t)rs.B * 2 * rs.H * sizeof(float));
+  unsigned long long* hxb = (unsigned long long*)((char*)ws + B3 + BT);
   hipLaunchKernelGGL((k_merge_cores01<S4, S3>), dim3((merged_elems<S3>() + 255) / 256), dim3(256), 0, stream,
                      packed_hid, m3);
   hipLaunchKernelGGL((k_bigb_prep<S3, ST>), dim3((int)(BT / sizeof(float) + 255) / 256), dim3(256), 0, stream, m3, mT);
@@ -747,7 +745,8 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
   const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
   const bool pair = 2 * rs.B <= device_cus() && !(np && np[0] == '1');
   if (pair) {
-    if (hipMemsetAsync(cnt, 0, (size_t)rs.B * sizeof(unsigned int), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    if (hipMemsetAsync(hxb, 0, (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long), stream) != hipSuccess)
+      return TTRNN_ERR_LAUNCH;
     // 64 KB image; 100 KB requested so that a second workgroup cannot share the CU (see the forward pair kernel)
     constexpr size_t lds = bigb_lds_bytes<ST, 2>() > 100 * 1024 ? bigb_lds_bytes<ST, 2>() : 100 * 1024;
     static bool raised = false;
@@ -759,7 +758,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T,
                        (const TS*)c0, mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in,
-                       (TS*)d_h0, (TS*)d_c0, hxb, cnt);
+                       (TS*)d_h0, (TS*)d_c0, hxb);
   } else {
     constexpr size_t lds = bigb_lds_bytes<ST, 1>();
     static bool raised = false;
@@ -771,7 +770,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 1, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0,
                        mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0,
-                       hxb, cnt);
+                       hxb);
   }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
