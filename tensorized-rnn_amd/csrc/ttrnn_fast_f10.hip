@@ -161,7 +161,11 @@ constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 
 // KS = 1: waves 0..MT-1 run the whole contraction of their tile.  KS = 2 (long contractions: the resident fragments
 // of a whole tile row would not fit the register file): waves t and t+4 — the two waves of one SIMD — take one half of
 // the k-blocks each, the second hands its partial accumulators to the first through LDS.
-template <class S, int KS, bool DIAG>
+// NB = 2: the workgroup carries TWO samples through every phase (own LDS images and states, the SAME resident core
+// fragments).  The kernel needs more than half of the register file, so one workgroup owns a CU; with more samples than
+// CUs the workgroups of one CU ran one after the other, each paying the per-step barriers, LDS round trips and
+// transcendental chains alone — two samples per step share them.
+template <class S, int KS, int NB, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
@@ -170,19 +174,15 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
                                                           float* __restrict__ hT, float* __restrict__ cT,
                                                           float* __restrict__ reserve) {
   static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
+  static_assert(NB == 1 || NB == 2, "one or two samples per workgroup");
   using F = F10<S>;
   constexpr int H = F::H;
+  constexpr size_t SMP = f10_lds_bytes<S, KS>();                            // LDS bytes of one sample
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* hbuf = reinterpret_cast<float*>(smem);                             // fp32 h, two parities (output store)
-  __bf16* hpl = reinterpret_cast<__bf16*>(smem + 2 * sizeof(float) * H);    // bf16 planes of h: [parity][3][H]
-  __bf16* img = hpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
-  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // KS == 2: partial accumulators
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const size_t b = blockIdx.x;
   static_assert(KS == 1 || (KS == 2 && F::MT == 4 && F::NM % 2 == 0), "k-split layout");
   constexpr int NU = F::NM / KS;                         // k-blocks per MFMA wave
   const bool gate_wave = wave < F::MT;
@@ -215,26 +215,45 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const bool in1 = gs.in1 != 0;
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
-  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
-  float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
-  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
-  XChunk<float> xq;
-  xq.cur = 0.f; xq.nxt = 0.f;
-  if (in1) xq.init(xs, b * T, T, lane);
+  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, vv = bh, bb = bh;       // slot order i,g,f,o
   if (ok) {
     if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
-    if (T > 0) {
-      if (in1) {
-        bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
-        vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
-      } else {
-        gi = *reinterpret_cast<const f32x4*>(gin + ((b * T) * H + hd) * 4);
-      }
+    if (T > 0 && in1) {
+      bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
+      vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
     }
-    __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
-    split3(hst, p0, p1, p2);
-    hpl[hd] = p0; hpl[H + hd] = p1; hpl[2 * H + hd] = p2;
-    hbuf[hd] = hst;
+  }
+  // per-sample state; a workgroup whose second sample lies past the batch carries a copy of the last one (never stored)
+  size_t bs[NB];
+  bool live[NB];
+  float hst[NB], cst[NB];
+  f32x4 gi[NB];
+  XChunk<float> xq[NB];
+  float* hbuf[NB];
+  __bf16 *hpl[NB], *img[NB];
+  f32x4* xbuf[NB];
+#pragma unroll
+  for (int sm = 0; sm < NB; ++sm) {
+    const size_t bb0 = (size_t)blockIdx.x * NB + sm;
+    live[sm] = bb0 < (size_t)B;
+    bs[sm] = live[sm] ? bb0 : (size_t)B - 1;
+    unsigned char* base = smem + sm * SMP;
+    hbuf[sm] = reinterpret_cast<float*>(base);                                 // fp32 h, two parities (output store)
+    hpl[sm] = reinterpret_cast<__bf16*>(base + 2 * sizeof(float) * H);         // bf16 planes of h: [parity][3][H]
+    img[sm] = hpl[sm] + 2 * 3 * H;                                             // three bf16 planes [I2][K10]
+    xbuf[sm] = reinterpret_cast<f32x4*>(img[sm] + 3 * F::PLANE);                // KS == 2: partial accumulators
+    hst[sm] = (ok && h0) ? h0[bs[sm] * H + hd] : 0.f;
+    cst[sm] = (ok && c0) ? c0[bs[sm] * H + hd] : 0.f;
+    gi[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xq[sm].cur = 0.f; xq[sm].nxt = 0.f;
+    if (in1) xq[sm].init(xs, bs[sm] * T, T, lane);
+    if (ok) {
+      if (T > 0 && !in1) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bs[sm] * T) * H + hd) * 4);
+      __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
+      split3(hst[sm], p0, p1, p2);
+      hpl[sm][hd] = p0; hpl[sm][H + hd] = p1; hpl[sm][2 * H + hd] = p2;
+      hbuf[sm][hd] = hst[sm];
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
   lds_barrier();
@@ -244,12 +263,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   for (int t = 0; t < T; ++t) {
-    const __bf16* hp = hpl + (t & 1) * 3 * H;             // planes of h_{t-1}
-    __bf16* hn = hpl + ((t + 1) & 1) * 3 * H;             // planes of h_t
     // ---- phase A: S2, all waves ---------------------------------------------------------------------------
     // all MFMAs first, then the splitting: the VALU work of one tile runs in the shadow of the others' MFMA latency
     // instead of behind an s_nop after every pair
-    {
+#pragma unroll
+    for (int sm = 0; sm < NB; ++sm) {
+      const __bf16* hp = hpl[sm] + (t & 1) * 3 * H;       // planes of h_{t-1}
       f32x4 t2[F::XA][2];
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
@@ -259,75 +278,99 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        f10_s2_store<S>(t2[x][0], img, wave + FAST_NW * x, 0, lane);
-        f10_s2_store<S>(t2[x][1], img, wave + FAST_NW * x, 1, lane);
+        f10_s2_store<S>(t2[x][0], img[sm], wave + FAST_NW * x, 0, lane);
+        f10_s2_store<S>(t2[x][1], img[sm], wave + FAST_NW * x, 1, lane);
       }
     }
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
-    const size_t bt = b * T + t;
     // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (mma_wave) {
-      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-      f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
-      acc = acc_hi + acc_lo;
-      if constexpr (DIAG) {
-        asm volatile("" : "+v"(acc));
+    f32x4 acc[NB];
+#pragma unroll
+    for (int sm = 0; sm < NB; ++sm) {
+      acc[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mma_wave) {
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        f10_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
+        acc[sm] = acc_hi + acc_lo;
+        if constexpr (DIAG) {
+          asm volatile("" : "+v"(acc[sm]));
+        }
       }
     }
     TT_STAMP(2)
     if constexpr (KS == 2) {
-      if (!gate_wave) xbuf[tile * 64 + lane] = acc;
+      if (!gate_wave) {
+#pragma unroll
+        for (int sm = 0; sm < NB; ++sm) xbuf[sm][tile * 64 + lane] = acc[sm];
+      }
       lds_barrier();
-      if (gate_wave) acc += xbuf[tile * 64 + lane];
+      if (gate_wave) {
+#pragma unroll
+        for (int sm = 0; sm < NB; ++sm) acc[sm] += xbuf[sm][tile * 64 + lane];
+      }
     }
     if (gate_wave) {
-      if (in1) gi = bb + xq.at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
-      const float ig = fsigmoid(acc[0] + gi[0] + bh[0]);      // lstm.py:26
-      const float fg = fsigmoid(acc[1] + gi[2] + bh[2]);      // lstm.py:27
-      const float gg = ftanh(acc[2] + gi[1] + bh[1]);         // lstm.py:28
-      const float og = fsigmoid(acc[3] + gi[3] + bh[3]);      // lstm.py:29
-      const float cy = fg * cst + ig * gg;                    // lstm.py:31
-      const float hy = og * ftanh(cy);                        // lstm.py:32
-      if (ok) {
-        cst = cy;
-        hst = hy;
-        __bf16 p0, p1, p2;
-        split3(hy, p0, p1, p2);
-        hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
-        hbuf[((t + 1) & 1) * H + hd] = hy;
-        if (reserve) {
-          float* rv = reserve + (bt * H + hd) * 8;
-          *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
-          rv[4] = cy;
+#pragma unroll
+      for (int sm = 0; sm < NB; ++sm) {
+        const size_t bt = bs[sm] * T + t;
+        __bf16* hn = hpl[sm] + ((t + 1) & 1) * 3 * H;       // planes of h_t
+        if (in1) gi[sm] = bb + xq[sm].at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
+        const float ig = fsigmoid(acc[sm][0] + gi[sm][0] + bh[0]);      // lstm.py:26
+        const float fg = fsigmoid(acc[sm][1] + gi[sm][2] + bh[2]);      // lstm.py:27
+        const float gg = ftanh(acc[sm][2] + gi[sm][1] + bh[1]);         // lstm.py:28
+        const float og = fsigmoid(acc[sm][3] + gi[sm][3] + bh[3]);      // lstm.py:29
+        const float cy = fg * cst[sm] + ig * gg;                        // lstm.py:31
+        const float hy = og * ftanh(cy);                                // lstm.py:32
+        if (ok) {
+          cst[sm] = cy;
+          hst[sm] = hy;
+          __bf16 p0, p1, p2;
+          split3(hy, p0, p1, p2);
+          hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
+          hbuf[sm][((t + 1) & 1) * H + hd] = hy;
+          if (reserve && live[sm]) {
+            float* rv = reserve + (bt * H + hd) * 8;
+            *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
+            rv[4] = cy;
+          }
+          if (!in1 && t + 1 < T) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
         }
-        if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+        if (in1) xq[sm].advance(xs, bs[sm] * T, T, t, lane);
       }
-      if (in1) xq.advance(xs, b * T, T, t, lane);
       TT_STAMP(3)
     } else if (wave == FAST_NW - 1 && t > 0) {
       // outputs[:, t-1, :] = h_{t-1} (lstm.py:133): an idle wave streams the complete vector out, 16 bytes per lane
-      const float* hprev = hbuf + (t & 1) * H;
 #pragma unroll
-      for (int h4 = lane; h4 < H / 4; h4 += 64)
-        *reinterpret_cast<f32x4*>(out + (bt - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
+      for (int sm = 0; sm < NB; ++sm) {
+        if (!live[sm]) continue;
+        const float* hprev = hbuf[sm] + (t & 1) * H;
+#pragma unroll
+        for (int h4 = lane; h4 < H / 4; h4 += 64)
+          *reinterpret_cast<f32x4*>(out + (bs[sm] * T + t - 1) * H + 4 * h4) =
+              *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
+      }
     }
     lds_barrier();
     TT_STAMP(4)
   }
-  if (T > 0 && wave == FAST_NW - 1) {
-    const float* hlast = hbuf + (T & 1) * H;
 #pragma unroll
-    for (int h4 = lane; h4 < H / 4; h4 += 64)
-      *reinterpret_cast<f32x4*>(out + (b * T + T - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hlast + 4 * h4);
-  }
-  if (ok) {
-    if (hT) hT[b * H + hd] = hst;
-    if (cT) cT[b * H + hd] = cst;
+  for (int sm = 0; sm < NB; ++sm) {
+    if (!live[sm]) continue;
+    if (T > 0 && wave == FAST_NW - 1) {
+      const float* hlast = hbuf[sm] + (T & 1) * H;
+#pragma unroll
+      for (int h4 = lane; h4 < H / 4; h4 += 64)
+        *reinterpret_cast<f32x4*>(out + (bs[sm] * T + T - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hlast + 4 * h4);
+    }
+    if (ok) {
+      if (hT) hT[bs[sm] * H + hd] = hst[sm];
+      if (cT) cT[bs[sm] * H + hd] = cst[sm];
+    }
   }
   if constexpr (DIAG) {
+    const size_t b = blockIdx.x;
     if (lane == 0 && reserve && b < 8) {
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * FAST_NW + wave) * 8;
 #pragma unroll
@@ -695,7 +738,24 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
   const char* diag = getenv("TTRNN_DIAG");
   const bool dg = diag && diag[0] == '1' && reserve;
-  auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
+  // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const char* nb1 = getenv("TTRNN_F10_NB1");               // A/B switch: one sample per workgroup
+  if (rs.B > cus && !dg && !(nb1 && nb1[0] == '1')) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_fwd_f10<S, KS, 2, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)) != hipSuccess)
+        return TTRNN_ERR_LAUNCH;
+      raised = true;
+    }
+    hipLaunchKernelGGL((k_lstm_fwd_f10<S, KS, 2, false>), dim3((rs.B + 1) / 2), dim3(FAST_NT), 2 * lds, stream, rs.B,
+                       rs.T, gin, (const float*)h0, (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT,
+                       (float*)cT, reserve);
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
+  auto kern = dg ? k_lstm_fwd_f10<S, KS, 1, true> : k_lstm_fwd_f10<S, KS, 1, false>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;

@@ -763,3 +763,31 @@ def test_dense_gradient_path_bf16_gru_vs_chain():
             os.environ.pop("TTRNN_NO_GEMM", None)
     for (name, _), a, b in zip(m.named_parameters(), *res):
         assert _maxabs(a, b) <= 2e-2 * max(float(b.abs().max()), 1e-6), name
+
+
+@pytest.mark.parametrize("rank,inp", [(16, 40), (8, 1)])
+def test_two_samples_per_workgroup_matches_one(rank, inp):
+    """More samples than CUs: the fused-core forward kernel carries two samples per workgroup (B = 301: the last workgroup
+    has a single live sample).  Against one sample per workgroup (TTRNN_F10_NB1=1) on the same module: outputs and final
+    states bit for bit (same arithmetic per sample), and the gradients computed from the reserve it wrote."""
+    import os
+    torch.manual_seed(93)
+    meta = dict(kind="ttlstm", input_size=inp, hidden_size=256, num_layers=2, n_cores=3, tt_rank=rank)
+    m = build_module(meta, dev())
+    B, T = 301, 9
+    x = torch.rand(B, T, inp, device=dev())
+    h0, c0 = torch.randn(B, 256, device=dev()) * 0.3, torch.randn(B, 256, device=dev()) * 0.3
+    w = torch.randn(B, T, 256, device=dev())
+    res = []
+    for flag in ("0", "1"):
+        os.environ["TTRNN_F10_NB1"] = flag
+        try:
+            m.zero_grad()
+            out, (h, c) = m(x, (h0, c0))
+            ((out * w).sum() + c.sum()).backward()
+            res.append((out.detach().clone(), h.detach().clone(), c.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ.pop("TTRNN_F10_NB1", None)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
