@@ -1,0 +1,91 @@
+// ttrnn_f10_dev.h — device pieces of the fused-core forward step shared by ttrnn_fast_f10.hip (one sample per workgroup)
+// and ttrnn_fast_f10nb.hip (two samples per workgroup).  Device-only (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ttrnn_core.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10.h"
+
+namespace ttrnn {
+
+template <class S, int KS>
+constexpr size_t f10_lds_bytes() {
+  // fp32 h (two parities, for the output store) + bf16 h planes (two parities) + the three planes of the S10 operand
+  // + (KS == 2) the partial accumulators handed from the second k-half's waves to the gate waves
+  return 2 * sizeof(float) * F10<S>::H + 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE +
+         (KS == 2 ? F10<S>::MT * 64 * sizeof(f32x4) : 0);
+}
+
+// term-packed fragments of core 2 for m-tile mt: lane (r, q) holds feature 16mt + r, k-group q (8 values of j2)
+template <class S>
+__device__ __forceinline__ void f10_load_w2(xbf8& a1, xbf8& a2, const float* packed, int mt, int lane) {
+  using F = F10<S>;
+  const int r = lane & 15, q = lane >> 4;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 p0, p1, p2;
+    split3(e < F::J2 ? W2[e * F::M2 + 16 * mt + r] : 0.f, p0, p1, p2);
+    a1[e] = (q & 1) ? p1 : p0;                            // groups w0 | w1 | w0 | w1
+    a2[e] = q == 0 ? p2 : (q == 1 ? p0 : (__bf16)0.f);    // groups w2 | w0 | 0 | 0
+  }
+}
+
+// one S2 tile (m-tile mt, chain-row tile rt): hp = the three bf16 planes [3][XPL] of the input; the MFMA part ...
+template <class S>
+__device__ __forceinline__ f32x4 f10_s2_mma(const xbf8& a1, const xbf8& a2, const __bf16* hp, int rt, int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = 16 * rt + c;
+  const int pl1 = q >> 1;                                 // groups x0 | x0 | x1 | x1
+  const int pl2 = q == 1 ? 2 : 0;                         // groups x0 | x2 | (x0 against zero core groups)
+  const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::XPL + row * 8);
+  const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::XPL + row * 8);
+  f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
+}
+// ... and the split of its result into the S10 operand
+template <class S>
+__device__ __forceinline__ void f10_s2_store(f32x4 acc, __bf16* img, int mt, int rt, int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = 16 * rt + c;
+  const int m0 = 16 * mt + 4 * q;
+  const int i = m0 / F::R2, a0 = m0 % F::R2;
+  // C2[i][row][a0..a0+3] (ops.py:89-90: C2 flat == the [I2][K10] operand of the next stage), k order: F10::kperm
+  if (row < F::ROWS2) store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);   // padding rows: no store
+}
+// S10 k-blocks [u0, u0 + NU) (w10 holds exactly those): reads run PD blocks ahead of the MFMAs (at most two waves per
+// SIMD do this: little else hides the LDS latency; sched_barrier keeps the compiler from sinking the reads back next
+// to their use)
+template <class S, int NU>
+__device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __bf16* img, int row, int q, int u0,
+                                             f32x4& acc_lo, f32x4& acc_hi) {
+  using F = F10<S>;
+  constexpr int PD = NU < 3 ? NU : 3;
+  xbf8 af[NU][3];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+    const int off = x_off<F::K>(row, 32 * (u0 + u) + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[u][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (u + PD < NU) {
+      const int off = x_off<F::K>(row, 32 * (u0 + u + PD) + 8 * q);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[u + PD][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 5; ++s)      // the five low-order terms, then the leading one into its own accumulator
+      acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[SPLIT_TW[s]][u], af[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
+    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[0][u], af[u][0], acc_hi, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace ttrnn

@@ -605,8 +605,7 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
         return TTRNN_ERR_LAUNCH;
       raised = true;
     }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cu_count();
     const int grid2 = (int)(n_rows < cus ? n_rows : cus);          // one workgroup per CU (LDS)
     const char* ng = getenv("TTRNN_BIG_NO_GEMM");            // A/B switch: K-in through the merged chain, row by row
     if (ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT && !(ng && ng[0] == '1') && gemm_split_ok(rs.in, 4 * rs.H)) {

@@ -710,8 +710,7 @@ constexpr size_t BDB = (size_t)St<S2, 1>::K * St<S2, 1>::M * sizeof(float);     
 constexpr size_t BDW = (size_t)1024 * 4096 * sizeof(float);                      // dense gradient
 
 int device_cus() {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = device_cu_count();
   return cus;
 }
 

@@ -41,87 +41,9 @@
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 #include "ttrnn_f10.h"
+#include "ttrnn_f10_dev.h"
 
 namespace ttrnn {
-
-template <class S, int KS>
-constexpr size_t f10_lds_bytes() {
-  // fp32 h (two parities, for the output store) + bf16 h planes (two parities) + the three planes of the S10 operand
-  // + (KS == 2) the partial accumulators handed from the second k-half's waves to the gate waves
-  return 2 * sizeof(float) * F10<S>::H + 2 * 3 * 2 * (size_t)F10<S>::H + 2 * 3 * (size_t)F10<S>::PLANE +
-         (KS == 2 ? F10<S>::MT * 64 * sizeof(f32x4) : 0);
-}
-
-// term-packed fragments of core 2 for m-tile mt: lane (r, q) holds feature 16mt + r, k-group q (8 values of j2)
-template <class S>
-__device__ __forceinline__ void f10_load_w2(xbf8& a1, xbf8& a2, const float* packed, int mt, int lane) {
-  using F = F10<S>;
-  const int r = lane & 15, q = lane >> 4;
-  const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 p0, p1, p2;
-    split3(e < F::J2 ? W2[e * F::M2 + 16 * mt + r] : 0.f, p0, p1, p2);
-    a1[e] = (q & 1) ? p1 : p0;                            // groups w0 | w1 | w0 | w1
-    a2[e] = q == 0 ? p2 : (q == 1 ? p0 : (__bf16)0.f);    // groups w2 | w0 | 0 | 0
-  }
-}
-
-// one S2 tile (m-tile mt, chain-row tile rt): hp = the three bf16 planes [3][XPL] of the input; the MFMA part ...
-template <class S>
-__device__ __forceinline__ f32x4 f10_s2_mma(const xbf8& a1, const xbf8& a2, const __bf16* hp, int rt, int lane) {
-  using F = F10<S>;
-  const int c = lane & 15, q = lane >> 4;
-  const int row = 16 * rt + c;
-  const int pl1 = q >> 1;                                 // groups x0 | x0 | x1 | x1
-  const int pl2 = q == 1 ? 2 : 0;                         // groups x0 | x2 | (x0 against zero core groups)
-  const xbf8 b1 = *reinterpret_cast<const xbf8*>(hp + pl1 * F::XPL + row * 8);
-  const xbf8 b2 = *reinterpret_cast<const xbf8*>(hp + pl2 * F::XPL + row * 8);
-  f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
-}
-// ... and the split of its result into the S10 operand
-template <class S>
-__device__ __forceinline__ void f10_s2_store(f32x4 acc, __bf16* img, int mt, int rt, int lane) {
-  using F = F10<S>;
-  const int c = lane & 15, q = lane >> 4;
-  const int row = 16 * rt + c;
-  const int m0 = 16 * mt + 4 * q;
-  const int i = m0 / F::R2, a0 = m0 % F::R2;
-  // C2[i][row][a0..a0+3] (ops.py:89-90: C2 flat == the [I2][K10] operand of the next stage), k order: F10::kperm
-  if (row < F::ROWS2) store_split4(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);   // padding rows: no store
-}
-// S10 k-blocks [u0, u0 + NU) (w10 holds exactly those): reads run PD blocks ahead of the MFMAs (at most two waves per
-// SIMD do this: little else hides the LDS latency; sched_barrier keeps the compiler from sinking the reads back next
-// to their use)
-template <class S, int NU>
-__device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __bf16* img, int row, int q, int u0,
-                                             f32x4& acc_lo, f32x4& acc_hi) {
-  using F = F10<S>;
-  constexpr int PD = NU < 3 ? NU : 3;
-  xbf8 af[NU][3];
-#pragma unroll
-  for (int u = 0; u < PD; ++u) {
-    const int off = x_off<F::K>(row, 32 * (u0 + u) + 8 * q);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) af[u][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    if (u + PD < NU) {
-      const int off = x_off<F::K>(row, 32 * (u0 + u + PD) + 8 * q);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) af[u + PD][p] = *reinterpret_cast<const xbf8*>(img + p * F::PLANE + off);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 5; ++s)      // the five low-order terms, then the leading one into its own accumulator
-      acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[SPLIT_TW[s]][u], af[u][SPLIT_TX[s]], acc_lo, 0, 0, 0);
-    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[0][u], af[u][0], acc_hi, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 
 // The fused core, contracted and split ONCE per launch by a small kernel of its own and stored in fragment order:
 //   wfrag[((t*NM + u)*3 + plane)*64 + lane] = the 8 bf16 (16 bytes) lane (r, q) feeds the MFMA for feature tile t,
@@ -161,11 +83,7 @@ constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 
 // KS = 1: waves 0..MT-1 run the whole contraction of their tile.  KS = 2 (long contractions: the resident fragments
 // of a whole tile row would not fit the register file): waves t and t+4 — the two waves of one SIMD — take one half of
 // the k-blocks each, the second hands its partial accumulators to the first through LDS.
-// NB = 2: the workgroup carries TWO samples through every phase (own LDS images and states, the SAME resident core
-// fragments).  The kernel needs more than half of the register file, so one workgroup owns a CU; with more samples than
-// CUs the workgroups of one CU ran one after the other, each paying the per-step barriers, LDS round trips and
-// transcendental chains alone — two samples per step share them.
-template <class S, int KS, int NB, bool DIAG>
+template <class S, int KS, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
@@ -174,15 +92,19 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
                                                           float* __restrict__ hT, float* __restrict__ cT,
                                                           float* __restrict__ reserve) {
   static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
-  static_assert(NB == 1 || NB == 2, "one or two samples per workgroup");
   using F = F10<S>;
   constexpr int H = F::H;
-  constexpr size_t SMP = f10_lds_bytes<S, KS>();                            // LDS bytes of one sample
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* hbuf = reinterpret_cast<float*>(smem);                             // fp32 h, two parities (output store)
+  __bf16* hpl = reinterpret_cast<__bf16*>(smem + 2 * sizeof(float) * H);    // bf16 planes of h: [parity][3][H]
+  __bf16* img = hpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
+  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // KS == 2: partial accumulators
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
   static_assert(KS == 1 || (KS == 2 && F::MT == 4 && F::NM % 2 == 0), "k-split layout");
   constexpr int NU = F::NM / KS;                         // k-blocks per MFMA wave
   const bool gate_wave = wave < F::MT;
@@ -215,45 +137,26 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const bool in1 = gs.in1 != 0;
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
-  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, vv = bh, bb = bh;       // slot order i,g,f,o
+  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
+  float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
+  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
+  XChunk<float> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
   if (ok) {
     if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
-    if (T > 0 && in1) {
-      bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
-      vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
+    if (T > 0) {
+      if (in1) {
+        bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
+        vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
+      } else {
+        gi = *reinterpret_cast<const f32x4*>(gin + ((b * T) * H + hd) * 4);
+      }
     }
-  }
-  // per-sample state; a workgroup whose second sample lies past the batch carries a copy of the last one (never stored)
-  size_t bs[NB];
-  bool live[NB];
-  float hst[NB], cst[NB];
-  f32x4 gi[NB];
-  XChunk<float> xq[NB];
-  float* hbuf[NB];
-  __bf16 *hpl[NB], *img[NB];
-  f32x4* xbuf[NB];
-#pragma unroll
-  for (int sm = 0; sm < NB; ++sm) {
-    const size_t bb0 = (size_t)blockIdx.x * NB + sm;
-    live[sm] = bb0 < (size_t)B;
-    bs[sm] = live[sm] ? bb0 : (size_t)B - 1;
-    unsigned char* base = smem + sm * SMP;
-    hbuf[sm] = reinterpret_cast<float*>(base);                                 // fp32 h, two parities (output store)
-    hpl[sm] = reinterpret_cast<__bf16*>(base + 2 * sizeof(float) * H);         // bf16 planes of h: [parity][3][H]
-    img[sm] = hpl[sm] + 2 * 3 * H;                                             // three bf16 planes [I2][K10]
-    xbuf[sm] = reinterpret_cast<f32x4*>(img[sm] + 3 * F::PLANE);                // KS == 2: partial accumulators
-    hst[sm] = (ok && h0) ? h0[bs[sm] * H + hd] : 0.f;
-    cst[sm] = (ok && c0) ? c0[bs[sm] * H + hd] : 0.f;
-    gi[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
-    xq[sm].cur = 0.f; xq[sm].nxt = 0.f;
-    if (in1) xq[sm].init(xs, bs[sm] * T, T, lane);
-    if (ok) {
-      if (T > 0 && !in1) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bs[sm] * T) * H + hd) * 4);
-      __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
-      split3(hst[sm], p0, p1, p2);
-      hpl[sm][hd] = p0; hpl[sm][H + hd] = p1; hpl[sm][2 * H + hd] = p2;
-      hbuf[sm][hd] = hst[sm];
-    }
+    __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
+    split3(hst, p0, p1, p2);
+    hpl[hd] = p0; hpl[H + hd] = p1; hpl[2 * H + hd] = p2;
+    hbuf[hd] = hst;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
   lds_barrier();
@@ -263,12 +166,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   for (int t = 0; t < T; ++t) {
+    const __bf16* hp = hpl + (t & 1) * 3 * H;             // planes of h_{t-1}
+    __bf16* hn = hpl + ((t + 1) & 1) * 3 * H;             // planes of h_t
     // ---- phase A: S2, all waves ---------------------------------------------------------------------------
     // all MFMAs first, then the splitting: the VALU work of one tile runs in the shadow of the others' MFMA latency
     // instead of behind an s_nop after every pair
-#pragma unroll
-    for (int sm = 0; sm < NB; ++sm) {
-      const __bf16* hp = hpl[sm] + (t & 1) * 3 * H;       // planes of h_{t-1}
+    {
       f32x4 t2[F::XA][2];
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
@@ -278,99 +181,75 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        f10_s2_store<S>(t2[x][0], img[sm], wave + FAST_NW * x, 0, lane);
-        f10_s2_store<S>(t2[x][1], img[sm], wave + FAST_NW * x, 1, lane);
+        f10_s2_store<S>(t2[x][0], img, wave + FAST_NW * x, 0, lane);
+        f10_s2_store<S>(t2[x][1], img, wave + FAST_NW * x, 1, lane);
       }
     }
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
+    const size_t bt = b * T + t;
     // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
-    f32x4 acc[NB];
-#pragma unroll
-    for (int sm = 0; sm < NB; ++sm) {
-      acc[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (mma_wave) {
-        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-        f10_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
-        acc[sm] = acc_hi + acc_lo;
-        if constexpr (DIAG) {
-          asm volatile("" : "+v"(acc[sm]));
-        }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (mma_wave) {
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+      f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
+      acc = acc_hi + acc_lo;
+      if constexpr (DIAG) {
+        asm volatile("" : "+v"(acc));
       }
     }
     TT_STAMP(2)
     if constexpr (KS == 2) {
-      if (!gate_wave) {
-#pragma unroll
-        for (int sm = 0; sm < NB; ++sm) xbuf[sm][tile * 64 + lane] = acc[sm];
-      }
+      if (!gate_wave) xbuf[tile * 64 + lane] = acc;
       lds_barrier();
-      if (gate_wave) {
-#pragma unroll
-        for (int sm = 0; sm < NB; ++sm) acc[sm] += xbuf[sm][tile * 64 + lane];
-      }
+      if (gate_wave) acc += xbuf[tile * 64 + lane];
     }
     if (gate_wave) {
-#pragma unroll
-      for (int sm = 0; sm < NB; ++sm) {
-        const size_t bt = bs[sm] * T + t;
-        __bf16* hn = hpl[sm] + ((t + 1) & 1) * 3 * H;       // planes of h_t
-        if (in1) gi[sm] = bb + xq[sm].at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
-        const float ig = fsigmoid(acc[sm][0] + gi[sm][0] + bh[0]);      // lstm.py:26
-        const float fg = fsigmoid(acc[sm][1] + gi[sm][2] + bh[2]);      // lstm.py:27
-        const float gg = ftanh(acc[sm][2] + gi[sm][1] + bh[1]);         // lstm.py:28
-        const float og = fsigmoid(acc[sm][3] + gi[sm][3] + bh[3]);      // lstm.py:29
-        const float cy = fg * cst[sm] + ig * gg;                        // lstm.py:31
-        const float hy = og * ftanh(cy);                                // lstm.py:32
-        if (ok) {
-          cst[sm] = cy;
-          hst[sm] = hy;
-          __bf16 p0, p1, p2;
-          split3(hy, p0, p1, p2);
-          hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
-          hbuf[sm][((t + 1) & 1) * H + hd] = hy;
-          if (reserve && live[sm]) {
-            float* rv = reserve + (bt * H + hd) * 8;
-            *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
-            rv[4] = cy;
-          }
-          if (!in1 && t + 1 < T) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+      if (in1) gi = bb + xq.at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
+      const float ig = fsigmoid(acc[0] + gi[0] + bh[0]);      // lstm.py:26
+      const float fg = fsigmoid(acc[1] + gi[2] + bh[2]);      // lstm.py:27
+      const float gg = ftanh(acc[2] + gi[1] + bh[1]);         // lstm.py:28
+      const float og = fsigmoid(acc[3] + gi[3] + bh[3]);      // lstm.py:29
+      const float cy = fg * cst + ig * gg;                    // lstm.py:31
+      const float hy = og * ftanh(cy);                        // lstm.py:32
+      if (ok) {
+        cst = cy;
+        hst = hy;
+        __bf16 p0, p1, p2;
+        split3(hy, p0, p1, p2);
+        hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
+        hbuf[((t + 1) & 1) * H + hd] = hy;
+        if (reserve) {
+          float* rv = reserve + (bt * H + hd) * 8;
+          *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
+          rv[4] = cy;
         }
-        if (in1) xq[sm].advance(xs, bs[sm] * T, T, t, lane);
+        if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
       }
+      if (in1) xq.advance(xs, b * T, T, t, lane);
       TT_STAMP(3)
     } else if (wave == FAST_NW - 1 && t > 0) {
       // outputs[:, t-1, :] = h_{t-1} (lstm.py:133): an idle wave streams the complete vector out, 16 bytes per lane
+      const float* hprev = hbuf + (t & 1) * H;
 #pragma unroll
-      for (int sm = 0; sm < NB; ++sm) {
-        if (!live[sm]) continue;
-        const float* hprev = hbuf[sm] + (t & 1) * H;
-#pragma unroll
-        for (int h4 = lane; h4 < H / 4; h4 += 64)
-          *reinterpret_cast<f32x4*>(out + (bs[sm] * T + t - 1) * H + 4 * h4) =
-              *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
-      }
+      for (int h4 = lane; h4 < H / 4; h4 += 64)
+        *reinterpret_cast<f32x4*>(out + (bt - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
     }
     lds_barrier();
     TT_STAMP(4)
   }
+  if (T > 0 && wave == FAST_NW - 1) {
+    const float* hlast = hbuf + (T & 1) * H;
 #pragma unroll
-  for (int sm = 0; sm < NB; ++sm) {
-    if (!live[sm]) continue;
-    if (T > 0 && wave == FAST_NW - 1) {
-      const float* hlast = hbuf[sm] + (T & 1) * H;
-#pragma unroll
-      for (int h4 = lane; h4 < H / 4; h4 += 64)
-        *reinterpret_cast<f32x4*>(out + (bs[sm] * T + T - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hlast + 4 * h4);
-    }
-    if (ok) {
-      if (hT) hT[bs[sm] * H + hd] = hst[sm];
-      if (cT) cT[bs[sm] * H + hd] = cst[sm];
-    }
+    for (int h4 = lane; h4 < H / 4; h4 += 64)
+      *reinterpret_cast<f32x4*>(out + (b * T + T - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hlast + 4 * h4);
+  }
+  if (ok) {
+    if (hT) hT[b * H + hd] = hst;
+    if (cT) cT[b * H + hd] = cst;
   }
   if constexpr (DIAG) {
-    const size_t b = blockIdx.x;
     if (lane == 0 && reserve && b < 8) {
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * FAST_NW + wave) * 8;
 #pragma unroll
@@ -510,8 +389,7 @@ static int launch_lin_f10(long n_rows, const float* packed, const void* bias, co
   hipLaunchKernelGGL((k_f10_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed, wfrag);
   constexpr size_t lds = f10_lin_lds_bytes<S>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = device_cu_count();
   const long grid = n_rows < (long)cus ? n_rows : (long)cus;       // one resident workgroup per CU walks the rows
   hipLaunchKernelGGL((k_ttlinear_fwd_f10<S>), dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows,
                      (const float*)x, packed, wfrag, (const float*)bias, (float*)y);
@@ -739,23 +617,12 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   const char* diag = getenv("TTRNN_DIAG");
   const bool dg = diag && diag[0] == '1' && reserve;
   // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const char* nb1 = getenv("TTRNN_F10_NB1");               // A/B switch: one sample per workgroup
+  const int cus = device_cu_count();
+  const char* nb1 = rs.B > cus ? getenv("TTRNN_F10_NB1") : nullptr;      // A/B switch: one sample per workgroup
   if (rs.B > cus && !dg && !(nb1 && nb1[0] == '1')) {
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_fwd_f10<S, KS, 2, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)) != hipSuccess)
-        return TTRNN_ERR_LAUNCH;
-      raised = true;
-    }
-    hipLaunchKernelGGL((k_lstm_fwd_f10<S, KS, 2, false>), dim3((rs.B + 1) / 2), dim3(FAST_NT), 2 * lds, stream, rs.B,
-                       rs.T, gin, (const float*)h0, (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT,
-                       (float*)cT, reserve);
-    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, wfrag, bh, out, hT, cT, reserve, stream);
   }
-  auto kern = dg ? k_lstm_fwd_f10<S, KS, 1, true> : k_lstm_fwd_f10<S, KS, 1, false>;
+  auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;

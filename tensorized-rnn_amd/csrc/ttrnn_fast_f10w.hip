@@ -358,8 +358,7 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
       raised[dx ? 1 : 0] = true;
     }
   }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = device_cu_count();
   const long grid = n_rows < (long)cus ? n_rows : (long)cus;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows, packed, (const xbf8*)wfrag,
                      (const TI*)x, (const float*)dy, (TI*)dx, dW10, d_packed, d_bias);

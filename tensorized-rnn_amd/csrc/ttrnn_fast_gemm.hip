@@ -594,8 +594,7 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % De
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
                        float* d_bias, hipStream_t stream, bool split, float* scratch) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = device_cu_count();
   const char* nsw = getenv("TTRNN_DENSE_FP32");            // A/B switch: dense gradient on the fp32 MFMA
   split = split && out % DenseS::TO == 0 && !(nsw && nsw[0] == '1');
   const int KBc = split ? DenseS::KB : DenseG::KB;
@@ -653,9 +652,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
 
 // bytes of the partial-tile scratch launch_dense_wgrad wants for this shape (0: one workgroup per tile covers all rows)
 size_t dense_wgrad_scratch_bytes(int in, int out) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  else (void)hipGetLastError();
+  const int cus = device_cu_count();
   const int tiles_s = ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO > 0 ? out / DenseS::TO : 1);
   const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;

@@ -5,6 +5,24 @@
 
 namespace ttrnn {
 
+// number of CUs of the current device, queried once per device and process (a hipDeviceGetAttribute per launch showed up
+// in the 0.83 ms cfg2 step)
+inline int device_cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int v = 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) (void)hipGetLastError();
+    cached[dev] = v > 0 ? v : 256;
+  }
+  return cached[dev];
+}
+
 // Where the recurrent kernels get the hoisted input projection from.
 //   in1 == 0: gin = fp32 [B][T][H][4], one gate-interleaved row per (b, t)
 //   in1 == 1: input_size == 1.  W_in x + b is linear in the scalar x: gin holds just TWO rows, chain(1)+b and
@@ -85,6 +103,11 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype);   // fused-core fragm
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream);
+
+// two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
+int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                           const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                           hipStream_t stream);
 
 // the same fused-core recurrent kernel on the fp32 MFMA (TTRNN_MATH_EXACT; ttrnn_fast_f10x.hip); ws as above
 bool f10x_rnn_fwd_available(const RnnShape& rs, int dtype);
