@@ -791,3 +791,30 @@ def test_two_samples_per_workgroup_matches_one(rank, inp):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][3], res[1][3]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+
+
+def test_dense_gemm_paths_gru_two_layers():
+    """Two stacked fp32 TT-GRU layers over 1 150 rows: the second layer's hidden-shaped input matrix takes the dense-gradient
+    GEMM (out = 768: three 256-column tiles) and the dx GEMM with K = 768, M = 256 (two feature tiles: the plain, not the
+    XCD-blocked, tile order) — against the row-by-row chain kernels (TTRNN_NO_GEMM=1)."""
+    import os
+    torch.manual_seed(94)
+    meta = dict(kind="ttgru", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev())
+    x = torch.rand(46, 25, 40, device=dev())
+    w = torch.randn(46, 25, 256, device=dev())
+    res = []
+    for flag in ("0", "1"):
+        os.environ["TTRNN_NO_GEMM"] = flag
+        try:
+            m.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            out, h = m(xg)
+            ((out * w).sum() + h.sum()).backward()
+            res.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+        finally:
+            os.environ.pop("TTRNN_NO_GEMM", None)
+    assert _maxabs(res[0][0], res[1][0]) <= 5e-6
+    assert _maxabs(res[0][1], res[1][1]) <= 1e-4 * max(1e-3, float(res[1][1].abs().max()))
+    for (name, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
+        assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6), name
