@@ -818,3 +818,24 @@ def test_dense_gemm_paths_gru_two_layers():
     assert _maxabs(res[0][1], res[1][1]) <= 1e-4 * max(1e-3, float(res[1][1].abs().max()))
     for (name, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6), name
+
+
+def test_dense_gemm_error_vs_fp64_is_fp32_class():
+    """3-layer cfg4-shaped model over 2 560 rows (input projections as dense split-bf16 GEMMs, one accumulator per tile)
+    against the oracle evaluated in float64: as close as the fp32-MFMA chain kernels and the torch-CPU fp32 oracle."""
+    import ttrnn_hip
+    torch.manual_seed(95)
+    meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16)
+    m = build_module(meta, dev())
+    x = torch.rand(64, 40, 40)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, _, c64 = _oracle_forward("ttlstm", sd, 3, x.double())
+    r32, _, c32 = _oracle_forward("ttlstm", sd, 3, x)
+    errs = {"cpu_fp32": max(_maxabs(r32, r64), _maxabs(c32, c64))}
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            out, (hT, cT) = m(x.to(dev()))
+        errs[mode] = max(_maxabs(out, r64), _maxabs(cT, c64))
+    print("max abs error vs float64 oracle:", errs)
+    assert errs["split"] <= 2e-6 and errs["exact"] <= 2e-6
+    assert errs["split"] <= 2.0 * max(errs["exact"], errs["cpu_fp32"]) + 1e-7
