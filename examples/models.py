@@ -3,12 +3,14 @@
 `MNISTClassifier` has the shape contract of the reference's experiments/digit_classification/
 mnist_classifier.py:13-57 (TT-RNN -> TTLinear head on the last timestep -> log_softmax);
 `SpeakerEncoder.forward` that of experiments/speaker_verification/encoder/speaker_encoder.py:69-91
-(TT-RNN -> TTLinear on the last hidden state -> ReLU -> L2 normalisation).  Both are ordinary nn.Modules over
+(TT-RNN -> TTLinear on the last hidden state -> ReLU -> L2 normalisation); its GE2E similarity matrix / loss
+(:93-170) are the vectorised device-side versions of examples/ge2e.py.  Both are ordinary nn.Modules over
 `tensorized_rnn` / `t3nsor` from tensorized-rnn_amd/, so every matmul-shaped op runs in libttrnn.
 """
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tensorized-rnn_amd"))
 
@@ -57,3 +59,26 @@ class SpeakerEncoder(nn.Module):
         last_hidden = res[1] if self.use_gru else res[1][0]
         embeds_raw = torch.relu(self.linear(last_hidden))
         return embeds_raw / torch.norm(embeds_raw, dim=1, keepdim=True)
+
+    def similarity_matrix(self, verification_embeds, enrollment_embeds=None):
+        """speaker_encoder.py:93-140, vectorised and on the embeddings' device (examples/ge2e.py)."""
+        import ge2e
+        return ge2e.similarity_matrix(verification_embeds, self.similarity_weight.to(verification_embeds.device),
+                                      self.similarity_bias.to(verification_embeds.device), enrollment_embeds)
+
+    def loss(self, verification_embeds, enrollment_embeds=None):
+        """(loss, eer) as speaker_encoder.py:142-170; under torch.distributed every rank passes the [S_local, U, D]
+        embeddings of its own speakers (ge2e.ge2e_loss_data_parallel: one all-gather)."""
+        import ge2e
+        w = self.similarity_weight.to(verification_embeds.device)
+        b = self.similarity_bias.to(verification_embeds.device)
+        if enrollment_embeds is None and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            return ge2e.ge2e_loss_data_parallel(verification_embeds, w, b)
+        return ge2e.ge2e_loss(verification_embeds, w, b, enrollment_embeds)
+
+    def do_gradient_ops(self, clip=3.0):
+        """speaker_encoder.py:60-66: scale the similarity parameters' gradients by 0.01, clip the global norm."""
+        self.similarity_weight.grad *= 0.01
+        self.similarity_bias.grad *= 0.01
+        torch.nn.utils.clip_grad_norm_(self.parameters(), clip, norm_type=2)

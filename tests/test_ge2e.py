@@ -1,0 +1,103 @@
+"""GE2E similarity / loss: the loop oracle against fixtures produced by the reference itself, the
+vectorised implementation against both, and the data-parallel gather over two gloo ranks."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "g9_ge2e_*.npz")))
+
+
+def _load(name):
+    d = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    enr = torch.from_numpy(d["enroll"]) if d["enroll"].size else None
+    return d, torch.from_numpy(d["embeds"]), enr
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_fixture(name):
+    from oracle import ge2e_oracle as G
+    d, emb, enr = _load(name)
+    emb = emb.clone().requires_grad_(True)
+    w, b = torch.tensor(float(d["weight"])), torch.tensor(float(d["bias"]))
+    sim = G.similarity_matrix(emb, w, b, enr)
+    assert float((sim.detach() - torch.from_numpy(d["sim"])).abs().max()) <= 1e-5
+    loss, eer = G.loss(emb, w, b, enr)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 1e-5 and abs(eer - float(d["eer"])) <= 1e-6
+    assert float((emb.grad - torch.from_numpy(d["d_embeds"])).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_vectorised_matches_fixture_and_oracle(name):
+    import ge2e
+    d, emb, enr = _load(name)
+    emb = emb.clone().requires_grad_(True)
+    w, b = torch.tensor(float(d["weight"])), torch.tensor(float(d["bias"]))
+    sim = ge2e.similarity_matrix(emb, w, b, enr)
+    assert float((sim.detach() - torch.from_numpy(d["sim"])).abs().max()) <= 1e-5
+    loss, eer = ge2e.ge2e_loss(emb, w, b, enr)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 1e-5 and abs(eer - float(d["eer"])) <= 1e-6
+    assert float((emb.grad - torch.from_numpy(d["d_embeds"])).abs().max()) <= 1e-6
+
+
+def _dp_worker(rank, world, port, name, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import ge2e
+        d, emb, _ = _load(name)
+        S = emb.shape[0] // world
+        local = emb[rank * S:(rank + 1) * S].clone().requires_grad_(True)
+        w, b = torch.tensor(float(d["weight"])), torch.tensor(float(d["bias"]))
+        loss, _ = ge2e.ge2e_loss_data_parallel(local, w, b)
+        loss.backward()
+        g = local.grad / world                     # the loss carries the factor `world` for the mean all-reduce of the step
+        q.put((rank, float(loss.item()) / world, g.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gather_two_ranks():
+    import torch.multiprocessing as mp
+    name = "g9_ge2e_train_s16u8"
+    d, emb, _ = _load(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = torch.from_numpy(d["d_embeds"])
+    S = emb.shape[0] // 2
+    for rank, loss, g in res:
+        assert abs(loss - float(d["loss"])) <= 1e-5
+        assert float((torch.from_numpy(g) - ref[rank * S:(rank + 1) * S]).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_vectorised_on_device():
+    import ge2e
+    name = "g9_ge2e_train_s16u8"
+    d, emb, _ = _load(name)
+    dev = torch.device("cuda:0")
+    e = emb.to(dev).requires_grad_(True)
+    w, b = torch.tensor(float(d["weight"]), device=dev), torch.tensor(float(d["bias"]), device=dev)
+    loss, eer = ge2e.ge2e_loss(e, w, b)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 2e-5 and abs(eer - float(d["eer"])) <= 1e-4
+    assert float((e.grad.cpu() - torch.from_numpy(d["d_embeds"])).abs().max()) <= 2e-6
