@@ -105,6 +105,11 @@ int64_t ttrnn_packed_elems(const ttrnn_ttm* w);
  * for the logical (R_k, I_k, J_k, R_{k+1}) axes. */
 int ttrnn_pack_cores(const ttrnn_ttm* w, const void* const* cores, const int64_t* strides,
                      int dtype, float* packed, void* stream);
+/* the same for TWO TT-matrices (one recurrent layer's input_weights and hidden_weights, tt_lstm.py:16-40) in one launch:
+ * the per-call launch count matters at sub-millisecond sequences */
+int ttrnn_pack_cores2(const ttrnn_ttm* wa, const void* const* cores_a, const int64_t* strides_a, float* packed_a,
+                      const ttrnn_ttm* wb, const void* const* cores_b, const int64_t* strides_b, float* packed_b,
+                      int dtype, void* stream);
 /* inverse for gradients: scatters the first half (W_k grads) of `packed_grad` into strided
  * per-core gradient tensors of the given dtype (overwrite, not accumulate). */
 int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* const* core_grads,

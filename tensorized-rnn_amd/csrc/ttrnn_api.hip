@@ -76,6 +76,21 @@ int ttrnn_pack_cores(const ttrnn_ttm* w, const void* const* cores, const int64_t
   return launch_pack(s, cores, strides, dtype, packed, (hipStream_t)stream);
 }
 
+int ttrnn_pack_cores2(const ttrnn_ttm* wa, const void* const* cores_a, const int64_t* strides_a, float* packed_a,
+                      const ttrnn_ttm* wb, const void* const* cores_b, const int64_t* strides_b, float* packed_b,
+                      int dtype, void* stream) {
+  TtShape sa, sb;
+  int st = tt_shape_init(&sa, wa);
+  if (st != TTRNN_OK) return st;
+  st = tt_shape_init(&sb, wb);
+  if (st != TTRNN_OK) return st;
+  if (!cores_a || !strides_a || !packed_a || !cores_b || !strides_b || !packed_b) return TTRNN_ERR_NULL;
+  for (int k = 0; k < sa.d; ++k) if (!cores_a[k]) return TTRNN_ERR_NULL;
+  for (int k = 0; k < sb.d; ++k) if (!cores_b[k]) return TTRNN_ERR_NULL;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
+  return launch_pack2(sa, cores_a, strides_a, packed_a, sb, cores_b, strides_b, packed_b, dtype, (hipStream_t)stream);
+}
+
 int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* const* core_grads,
                             const int64_t* strides, int dtype, void* stream) {
   TtShape s;
@@ -153,11 +168,10 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       // y_n = b + x_n * chain(1): reduce dy over the rows once (dv = sum x_n dy_n, d_bias = sum dy_n), then
       // back-propagate dv through the chain on the single unit row
       float* dv = (float*)workspace;
-      void* unit = (char*)workspace + in1_bwd_bytes(s) - 256;
+      const void* unit = unit_rows_ptr(dtype);
+      if (!unit) return TTRNN_ERR_LAUNCH;
       if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return TTRNN_ERR_LAUNCH;
-      st = launch_fill_unit_rows(unit, dtype, (hipStream_t)stream);
-      if (st != TTRNN_OK) return st;
       st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (hipStream_t)stream);
       if (st != TTRNN_OK) return st;
       return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
@@ -297,9 +311,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     GinSrc src{gin, x, f.in1 ? 1 : 0};
     if (f.in1) {
       // K-in on the two unit rows x = [1, 0] (same chain kernel, microseconds); K-rec scales by the real x
-      void* unit = (char*)workspace + f.gin_bytes - 256;
-      st = launch_fill_unit_rows(unit, desc->dtype, (hipStream_t)stream);
-      if (st != TTRNN_OK) return st;
+      const void* unit = unit_rows_ptr(desc->dtype);
+      if (!unit) return TTRNN_ERR_LAUNCH;
       st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
                                     (hipStream_t)stream);
     } else if (fp32_math() == TTRNN_MATH_SPLIT && f.gemm_bytes > 0 && (int64_t)rs.B * rs.T >= 2 * (int64_t)rs.in &&

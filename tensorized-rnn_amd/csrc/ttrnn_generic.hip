@@ -33,15 +33,30 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int n)
   for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = src[e];
 }
 
-template <typename T>
-__global__ void k_fill_unit_rows(T* dst) {
-  if (threadIdx.x == 0) { st(dst, 0, 1.0f); st(dst, 1, 0.0f); }
-}
+// The two unit input rows x = [1, 0] of the input_size == 1 paths live in device constants (one launch less per
+// forward than filling them into the workspace: the cfg2 step has only six launches, ~8 us each)
+__device__ __attribute__((used)) float g_unit_rows_f32[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+__device__ __attribute__((used)) uint16_t g_unit_rows_bf16[4] = {0x3F80, 0, 0, 0};        // bf16(1.0), bf16(0.0)
 
-int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream) {
-  if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_fill_unit_rows<float>, dim3(1), dim3(64), 0, stream, (float*)dst);
-  else hipLaunchKernelGGL(k_fill_unit_rows<bf16_t>, dim3(1), dim3(64), 0, stream, (bf16_t*)dst);
-  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+const void* unit_rows_ptr(int dtype) {
+  static const void* cached[16][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    (void)hipGetLastError();
+    dev = 0;
+  }
+  const int di = dtype == TTRNN_F32 ? 0 : 1;
+  if (!cached[dev][di]) {
+    void* p = nullptr;
+    const hipError_t e = di == 0 ? hipGetSymbolAddress(&p, HIP_SYMBOL(g_unit_rows_f32))
+                                 : hipGetSymbolAddress(&p, HIP_SYMBOL(g_unit_rows_bf16));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    cached[dev][di] = p;
+  }
+  return cached[dev][di];
 }
 
 // input_size == 1: y_n = b + x_n * v  =>  dL/dv[o] = sum_n x_n dy[n][o],  dL/db[o] = sum_n dy[n][o].
@@ -130,6 +145,18 @@ __global__ void k_pack_cores(TtShape s, PackArgs a, float* packed) {
   const int k = blockIdx.y;
   pack_core_elems<T>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, s, k,
                      (const T*)a.core[k], &a.st[4 * k], packed);
+}
+
+// two TT-matrices (a layer's input and hidden weights) in ONE launch: blockIdx.y < sa.d packs matrix a, the rest matrix b
+template <typename T>
+__global__ void k_pack_cores2(TtShape sa, PackArgs aa, float* packed_a, TtShape sb, PackArgs ab, float* packed_b) {
+  const int k = blockIdx.y;
+  if (k < sa.d)
+    pack_core_elems<T>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, sa, k,
+                       (const T*)aa.core[k], &aa.st[4 * k], packed_a);
+  else
+    pack_core_elems<T>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, sb, k - sa.d,
+                       (const T*)ab.core[k - sa.d], &ab.st[4 * (k - sa.d)], packed_b);
 }
 
 template <typename T>
@@ -293,6 +320,29 @@ int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strid
   dim3 grid((maxn + 255) / 256, s.d);
   if (dtype == TTRNN_F32) hipLaunchKernelGGL(k_pack_cores<float>, grid, dim3(256), 0, stream, s, a, packed);
   else hipLaunchKernelGGL(k_pack_cores<bf16_t>, grid, dim3(256), 0, stream, s, a, packed);
+  return check_launch();
+}
+
+int launch_pack2(const TtShape& sa, const void* const* cores_a, const int64_t* strides_a, float* packed_a,
+                 const TtShape& sb, const void* const* cores_b, const int64_t* strides_b, float* packed_b, int dtype,
+                 hipStream_t stream) {
+  PackArgs aa, ab;
+  int maxn = 1;
+  for (int k = 0; k < sa.d; ++k) {
+    aa.core[k] = cores_a[k];
+    for (int q = 0; q < 4; ++q) aa.st[4 * k + q] = strides_a[4 * k + q];
+    if (sa.K[k] * sa.M[k] > maxn) maxn = sa.K[k] * sa.M[k];
+  }
+  for (int k = 0; k < sb.d; ++k) {
+    ab.core[k] = cores_b[k];
+    for (int q = 0; q < 4; ++q) ab.st[4 * k + q] = strides_b[4 * k + q];
+    if (sb.K[k] * sb.M[k] > maxn) maxn = sb.K[k] * sb.M[k];
+  }
+  dim3 grid((maxn + 255) / 256, sa.d + sb.d);
+  if (dtype == TTRNN_F32)
+    hipLaunchKernelGGL(k_pack_cores2<float>, grid, dim3(256), 0, stream, sa, aa, packed_a, sb, ab, packed_b);
+  else
+    hipLaunchKernelGGL(k_pack_cores2<bf16_t>, grid, dim3(256), 0, stream, sa, aa, packed_a, sb, ab, packed_b);
   return check_launch();
 }
 

@@ -55,11 +55,14 @@ LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows);
 LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
 RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
 
-int launch_fill_unit_rows(void* dst, int dtype, hipStream_t stream);   // dst[0] = 1, dst[1] = 0 (storage dtype)
+const void* unit_rows_ptr(int dtype);   // device constant {1, 0} in the storage dtype (NULL: symbol lookup failed)
 int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
                       float* db, hipStream_t stream);
 int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
                 hipStream_t stream);
+int launch_pack2(const TtShape& sa, const void* const* cores_a, const int64_t* strides_a, float* packed_a,
+                 const TtShape& sb, const void* const* cores_b, const int64_t* strides_b, float* packed_b, int dtype,
+                 hipStream_t stream);
 int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads, const int64_t* strides, int dtype,
                   hipStream_t stream);
 // ilv_h / ilv_mode: optional gate-interleaved output layout, see ttrnn_core.h:ilv_index

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "ttrnn_packed_elems": (ctypes.c_int64, [ctypes.POINTER(TtmDesc)]),
     "ttrnn_pack_cores": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
                                         ctypes.c_int, _P, _P]),
+    "ttrnn_pack_cores2": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), _P,
+                                         ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), _P,
+                                         ctypes.c_int, _P]),
     "ttrnn_unpack_core_grads": (ctypes.c_int, [ctypes.POINTER(TtmDesc), _P, ctypes.POINTER(_P),
                                                ctypes.POINTER(ctypes.c_int64), ctypes.c_int, _P]),
     "ttrnn_ttlinear_workspace": (ctypes.c_size_t, [ctypes.POINTER(TtmDesc), ctypes.c_int64]),

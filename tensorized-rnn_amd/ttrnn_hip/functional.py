@@ -117,6 +117,21 @@ class TTSpec(object):
               "ttrnn_pack_cores")
         return packed
 
+    @staticmethod
+    def pack_pair(spec_a, cores_a, spec_b, cores_b):
+        """pack() of two TT-matrices (a layer's input and hidden weights) in one launch."""
+        _require_device(*(list(cores_a) + list(cores_b)))
+        lib = _lib.load()
+        dt = _dtype_code(cores_a[0])
+        dev = cores_a[0].device
+        pa = torch.empty(spec_a.packed_elems, dtype=torch.float32, device=dev)
+        pb = torch.empty(spec_b.packed_elems, dtype=torch.float32, device=dev)
+        ptrs_a, strides_a = spec_a._core_args(cores_a)
+        ptrs_b, strides_b = spec_b._core_args(cores_b)
+        check(lib.ttrnn_pack_cores2(ctypes.byref(spec_a.desc), ptrs_a, strides_a, _ptr(pa), ctypes.byref(spec_b.desc),
+                                    ptrs_b, strides_b, _ptr(pb), dt, _stream(pa)), "ttrnn_pack_cores2")
+        return pa, pb
+
     def unpack_grads(self, packed_grad, like):
         """packed fp32 gradient -> list of gradient tensors with the layout of `like` (the cores)."""
         lib = _lib.load()
@@ -231,8 +246,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
         H = spec.hidden_size
         dev = x.device
         desc = spec.desc(B, T, _dtype_code(x))
-        packed_in = spec.in_spec.pack(cores_in)
-        packed_hid = spec.hid_spec.pack(cores_hid)
+        packed_in, packed_hid = TTSpec.pack_pair(spec.in_spec, cores_in, spec.hid_spec, cores_hid)
         out = torch.empty(B, T, H, dtype=x.dtype, device=dev)
         hT = torch.empty(B, H, dtype=x.dtype, device=dev)
         cT = torch.empty(B, H, dtype=x.dtype, device=dev) if spec.cell == "lstm" else None
