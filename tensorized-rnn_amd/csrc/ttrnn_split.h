@@ -37,20 +37,29 @@ __device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& 
   p2 = (__bf16)r;
 }
 
-// two elements at a time: v_cvt_pk_bf16_f32 rounds both (RNE), a shift / a mask turn the packed pair back into
-// floats, the subtractions are exact.  9 VALU instructions per pair and three packed dwords out.
+// two elements at a time: v_cvt_pk_bf16_f32 rounds both (RNE); three packed dwords out.
 typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   const xbf2 p = __builtin_convertvector(f32x2{a, b}, xbf2);
   return __builtin_bit_cast(unsigned, p);
 }
+// residual of a packed pair: v - (its bf16 piece) in ONE instruction, v_dot2c_f32_bf16 with the packed constants
+// (lo -1, hi 0) / (lo 0, hi -1): pieces.lo * -1 + pieces.hi * 0 + v.  Bit-identical to shift / mask + subtract (checked
+// on 2^20 pairs over 60 binades incl. zeros and denormals) at 7 instead of 11 VALU instructions per pair.  The constants
+// are built from bits behind an opaque asm: hipcc folds a bf16x2 literal {-1, 0} into the INLINE constant -1.0, whose
+// bits are (lo 0, hi -1) — the other piece.
+__device__ __forceinline__ float bf16_residual(unsigned pieces, unsigned sel, float v) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(xbf2, pieces), __builtin_bit_cast(xbf2, sel), v, false);
+}
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  unsigned sel_lo = 0x0000BF80u, sel_hi = 0xBF800000u;
+  asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
   p0 = pk_bf16(a, b);
-  float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  float ra = bf16_residual(p0, sel_lo, a), rb = bf16_residual(p0, sel_hi, b);
   p1 = pk_bf16(ra, rb);
-  ra -= __uint_as_float(p1 << 16);
-  rb -= __uint_as_float(p1 & 0xffff0000u);
+  ra = bf16_residual(p1, sel_lo, ra);
+  rb = bf16_residual(p1, sel_hi, rb);
   p2 = pk_bf16(ra, rb);
 }
 
