@@ -4,7 +4,7 @@
 mnist_classifier.py:13-57 (TT-RNN -> TTLinear head on the last timestep -> log_softmax);
 `SpeakerEncoder.forward` that of experiments/speaker_verification/encoder/speaker_encoder.py:69-91
 (TT-RNN -> TTLinear on the last hidden state -> ReLU -> L2 normalisation); its GE2E similarity matrix / loss
-(:93-170) are the vectorised device-side versions of examples/ge2e.py.  Both are ordinary nn.Modules over
+(:93-170) are the vectorised device-side versions of ttrnn_hip/ge2e.py.  Both are ordinary nn.Modules over
 `tensorized_rnn` / `t3nsor` from tensorized-rnn_amd/, so every matmul-shaped op runs in libttrnn.
 """
 import os
@@ -61,15 +61,15 @@ class SpeakerEncoder(nn.Module):
         return embeds_raw / torch.norm(embeds_raw, dim=1, keepdim=True)
 
     def similarity_matrix(self, verification_embeds, enrollment_embeds=None):
-        """speaker_encoder.py:93-140, vectorised and on the embeddings' device (examples/ge2e.py)."""
-        import ge2e
+        """speaker_encoder.py:93-140, vectorised and on the embeddings' device (ttrnn_hip/ge2e.py)."""
+        from ttrnn_hip import ge2e
         return ge2e.similarity_matrix(verification_embeds, self.similarity_weight.to(verification_embeds.device),
                                       self.similarity_bias.to(verification_embeds.device), enrollment_embeds)
 
     def loss(self, verification_embeds, enrollment_embeds=None):
         """(loss, eer) as speaker_encoder.py:142-170; under torch.distributed every rank passes the [S_local, U, D]
         embeddings of its own speakers (ge2e.ge2e_loss_data_parallel: one all-gather)."""
-        import ge2e
+        from ttrnn_hip import ge2e
         w = self.similarity_weight.to(verification_embeds.device)
         b = self.similarity_bias.to(verification_embeds.device)
         if enrollment_embeds is None and torch.distributed.is_available() and torch.distributed.is_initialized() \

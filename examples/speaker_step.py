@@ -40,7 +40,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         embeds = model(x).view(S, U, -1)
-        import ge2e
+        from ttrnn_hip import ge2e
         loss, _ = ge2e.ge2e_loss(embeds, model.similarity_weight, model.similarity_bias, None, with_eer=False)
         loss.backward()
         model.do_gradient_ops()

@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "examples"))
+sys.path.insert(0, os.path.join(ROOT, "tensorized-rnn_amd"))
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "g9_ge2e_*.npz")))
 
@@ -37,7 +38,7 @@ def test_oracle_matches_reference_fixture(name):
 
 @pytest.mark.parametrize("name", CASES)
 def test_vectorised_matches_fixture_and_oracle(name):
-    import ge2e
+    from ttrnn_hip import ge2e
     d, emb, enr = _load(name)
     emb = emb.clone().requires_grad_(True)
     w, b = torch.tensor(float(d["weight"])), torch.tensor(float(d["bias"]))
@@ -54,24 +55,40 @@ def _dp_worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sys.path.insert(0, os.path.join(ROOT, "examples"))
-        import ge2e
+        from ttrnn_hip import ge2e
+        from ttrnn_hip.dist import FlatGradAllReduce
         d, emb, _ = _load(name)
         S = emb.shape[0] // world
+        # a stand-in "encoder": embeds = normalise(local * scale) with a REPLICATED parameter `scale`, so that the
+        # data-parallel mean is exercised on a parameter upstream of the gather as well as on w, b downstream of it
+        holder = torch.nn.Module()
+        holder.scale = torch.nn.Parameter(torch.ones(emb.shape[2]))
+        holder.w = torch.nn.Parameter(torch.tensor(float(d["weight"])))
+        holder.b = torch.nn.Parameter(torch.tensor(float(d["bias"])))
         local = emb[rank * S:(rank + 1) * S].clone().requires_grad_(True)
-        w, b = torch.tensor(float(d["weight"])), torch.tensor(float(d["bias"]))
-        loss, _ = ge2e.ge2e_loss_data_parallel(local, w, b)
+        loss, _ = ge2e.ge2e_loss_data_parallel(local * holder.scale, holder.w, holder.b)
         loss.backward()
-        g = local.grad / world                     # the loss carries the factor `world` for the mean all-reduce of the step
-        q.put((rank, float(loss.item()) / world, g.numpy()))
+        FlatGradAllReduce(holder).sync()            # the step's gradient all-reduce (mean)
+        q.put((rank, float(loss.item()), (local.grad / world).numpy(), holder.scale.grad.numpy(),
+               float(holder.w.grad), float(holder.b.grad)))
     finally:
         dist.destroy_process_group()
 
 
 def test_data_parallel_gather_two_ranks():
+    """Two gloo ranks against ONE process on the same fixture: loss value, the slice gradients, and — after the mean
+    all-reduce of the data-parallel step — the gradients of replicated parameters both upstream of the gather (the
+    encoder's) and downstream of it (similarity weight / bias; ADVICE r1: these came out `world` times too large)."""
     import torch.multiprocessing as mp
+    from ttrnn_hip import ge2e
     name = "g9_ge2e_train_s16u8"
     d, emb, _ = _load(name)
+    scale = torch.ones(emb.shape[2], requires_grad=True)
+    w = torch.tensor(float(d["weight"]), requires_grad=True)
+    b = torch.tensor(float(d["bias"]), requires_grad=True)
+    single, _ = ge2e.ge2e_loss(emb * scale, w, b, None, with_eer=False)
+    single.backward()
+    assert abs(single.item() - float(d["loss"])) <= 1e-5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + os.getpid() % 300
@@ -84,14 +101,17 @@ def test_data_parallel_gather_two_ranks():
         assert p.exitcode == 0
     ref = torch.from_numpy(d["d_embeds"])
     S = emb.shape[0] // 2
-    for rank, loss, g in res:
-        assert abs(loss - float(d["loss"])) <= 1e-5
+    for rank, loss, g, gscale, gw, gb in res:
+        assert abs(loss - float(d["loss"])) <= 1e-5                       # unscaled
         assert float((torch.from_numpy(g) - ref[rank * S:(rank + 1) * S]).abs().max()) <= 1e-6
+        assert float((torch.from_numpy(gscale) - scale.grad).abs().max()) <= 1e-6 * max(1.0, float(scale.grad.abs().max()))
+        assert abs(gw - float(w.grad)) <= 1e-6 * max(1.0, abs(float(w.grad)))
+        assert abs(gb - float(b.grad)) <= 1e-6 * max(1.0, abs(float(b.grad)))
 
 
 @pytest.mark.gpu
 def test_vectorised_on_device():
-    import ge2e
+    from ttrnn_hip import ge2e
     name = "g9_ge2e_train_s16u8"
     d, emb, _ = _load(name)
     dev = torch.device("cuda:0")
