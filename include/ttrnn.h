@@ -94,6 +94,18 @@ int ttrnn_device_available(void);
 int ttrnn_set_fp32_math(int mode);      /* TTRNN_OK or TTRNN_ERR_UNSUPPORTED */
 int ttrnn_get_fp32_math(void);
 
+/* Library options: the kernel-route switches used for A/B measurements and by the parity tests that compare two routes
+ * on one input (the reference has no counterpart; its only "route" is ATen's dispatcher).  All options live in ONE
+ * table that is filled once, at first use, from the environment variables TTRNN_<NAME> (upper case) and is afterwards
+ * changed only through ttrnn_set_option — no getenv on any launch path; the fields are atomics, so a host thread may
+ * flip a switch while others launch (a launch reads each switch once).  Names (value 0 / 1 unless noted):
+ *   "fp32_math" (TTRNN_MATH_*), "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "diag", "bf16_fp32_mfma",
+ *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32".
+ * Workspace sizes must be queried under the same options the launch will run with.
+ * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
+int ttrnn_set_option(const char* name, int value);
+int ttrnn_get_option(const char* name, int* value);
+
 /* ---- weights: strided reference Parameters <-> packed fp32 cores ----------------------------
  * Packed layout (fp32): for k = 0..d-1   W_k [K_k = J_k*R_{k+1}][M_k = I_k*R_k],
  *   W_k[(j*R_{k+1}+b)*M_k + (i*R_k+a)] = G_k[a,i,j,b]          (the stage-k GEMM operand),

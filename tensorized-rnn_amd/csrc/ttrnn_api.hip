@@ -3,39 +3,77 @@
 // descriptor, else the any-shape kernel), and launches on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 
 using namespace ttrnn;
 
-static bool force_generic() {
-  const char* e = getenv("TTRNN_FORCE_GENERIC");
-  return e && e[0] == '1';
-}
-
-static bool no_gemm() {
-  const char* e = getenv("TTRNN_NO_GEMM");      // A/B switch: batched input projections through the TT chain kernels
-  return e && e[0] == '1';
-}
-
-// fp32 matrix arithmetic of the shape-specialised kernels (include/ttrnn.h: TTRNN_MATH_*); process-wide.
-static int g_fp32_math = -1;
-static int fp32_math() {
-  if (g_fp32_math < 0) {
-    const char* e = getenv("TTRNN_FP32_MATH");
-    g_fp32_math = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
+// ---- options: one table, filled once from TTRNN_* environment variables, atomics afterwards (ttrnn_opts.h) ---------
+namespace ttrnn {
+namespace {
+struct OptTable {
+  std::atomic<int> v[OPT_COUNT];
+  OptTable() {
+    static const char* const env[OPT_COUNT] = {
+        "TTRNN_FP32_MATH", "TTRNN_FORCE_GENERIC", "TTRNN_NO_GEMM", "TTRNN_NO_IN1", "TTRNN_NO_F10", "TTRNN_NO_G2",
+        "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
+        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32"};
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      const char* e = getenv(env[i]);
+      int val = 0;
+      if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
+      else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+      else val = (e && e[0] == '1') ? 1 : 0;
+      v[i].store(val, std::memory_order_relaxed);
+    }
   }
-  return g_fp32_math;
+};
+OptTable& table() {
+  static OptTable t;      // thread-safe initialisation (C++11 magic static)
+  return t;
 }
+const char* const kOptNames[OPT_COUNT] = {
+    "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "diag", "bf16_fp32_mfma", "big_merge",
+    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32"};
+}  // namespace
+int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
+const char* opt_name(OptId id) { return kOptNames[id]; }
+static int opt_find(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptNames[i]) == 0) return i;
+  return -1;
+}
+int opt_set(const char* name, int value) {
+  const int i = opt_find(name);
+  if (i < 0) return -1;
+  if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
+  if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
+  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && value != 0 && value != 1) return -1;
+  table().v[i].store(value, std::memory_order_relaxed);
+  return 0;
+}
+int opt_get(const char* name, int* value) {
+  const int i = opt_find(name);
+  if (i < 0 || !value) return -1;
+  *value = table().v[i].load(std::memory_order_relaxed);
+  return 0;
+}
+}  // namespace ttrnn
+
+static bool force_generic() { return opt(OPT_FORCE_GENERIC) != 0; }
+static bool no_gemm() { return opt(OPT_NO_GEMM) != 0; }
+static int fp32_math() { return opt(OPT_FP32_MATH); }
 
 extern "C" {
 
-int ttrnn_set_fp32_math(int mode) {
-  if (mode != TTRNN_MATH_EXACT && mode != TTRNN_MATH_SPLIT) return TTRNN_ERR_UNSUPPORTED;
-  g_fp32_math = mode;
-  return TTRNN_OK;
-}
+int ttrnn_set_fp32_math(int mode) { return opt_set("fp32_math", mode) == 0 ? TTRNN_OK : TTRNN_ERR_UNSUPPORTED; }
+
+int ttrnn_set_option(const char* name, int value) { return opt_set(name, value) == 0 ? TTRNN_OK : TTRNN_ERR_UNSUPPORTED; }
+int ttrnn_get_option(const char* name, int* value) { return opt_get(name, value) == 0 ? TTRNN_OK : TTRNN_ERR_UNSUPPORTED; }
 
 int ttrnn_get_fp32_math(void) { return fp32_math(); }
 
@@ -162,9 +200,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
   if (d_packed && !x) return TTRNN_ERR_NULL;
   if (!dx && !d_packed && !d_bias) return TTRNN_OK;
   if (!force_generic() && fast_ttlinear_bwd_available(s, dtype, dy_dtype)) {
-    const char* no_in1 = getenv("TTRNN_NO_IN1");
-    if (s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= in1_bwd_bytes(s) &&
-        !(no_in1 && no_in1[0] == '1')) {
+    if (s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= in1_bwd_bytes(s) && !opt(OPT_NO_IN1)) {
       // y_n = b + x_n * chain(1): reduce dy over the rows once (dv = sum x_n dy_n, d_bias = sum dy_n), then
       // back-propagate dv through the chain on the single unit row
       float* dv = (float*)workspace;
@@ -241,8 +277,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   int64_t n_rows = (int64_t)rs.B * rs.T;
   f.lin_fast = fast_ttlinear_fwd_available(rs.in_s, dtype, rs.H);
   // input_size == 1: the projection is linear in a scalar -> only the two rows chain(1)+b, chain(0)+b are needed
-  const char* no_in1 = getenv("TTRNN_NO_IN1");
-  f.in1 = rs.in == 1 && f.lin_fast && !(no_in1 && no_in1[0] == '1');
+  f.in1 = rs.in == 1 && f.lin_fast && !opt(OPT_NO_IN1);
   if (f.in1) n_rows = 2;
   f.gin_bytes = ((size_t)n_rows * 4 * rs.H * sizeof(float) + 255) & ~(size_t)255;   // [rows][H][4]
   if (f.in1) f.gin_bytes += 256;                                                    // + the two unit input rows

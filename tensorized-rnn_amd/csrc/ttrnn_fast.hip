@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 
 namespace ttrnn {
@@ -452,8 +453,8 @@ static int launch_one_t(const RnnShape& rs, GinSrc gin, const void* h0, const vo
   static_assert(shape_ok_recurrent<S>(), "shape not supported by the MFMA path");
   const TS* bh = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
   if constexpr (CELL == TTRNN_LSTM && lstm_fusable<S>()) {
-    const char* diag = getenv("TTRNN_DIAG");
-    if (diag && diag[0] == '1' && reserve)   // diagnostic build: phase stamps overwrite the reserve buffer
+    const bool diag_on = opt(OPT_DIAG) != 0;
+    if (diag_on && reserve)   // diagnostic build: phase stamps overwrite the reserve buffer
       hipLaunchKernelGGL((k_lstm_fwd_fused<S, true, TS>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin,
                          (const TS*)h0, (const TS*)c0, packed_hid, bh, (TS*)out, (TS*)hT, (TS*)cT, reserve);
     else

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 
 namespace ttrnn {
@@ -314,8 +315,8 @@ static int launch_bf16(const RnnShape& rs, GinSrc gin, const void* h0, const voi
 
 bool fast_rnn_fwd_bf16_available(const RnnShape& rs, int dtype) {
   if (dtype != TTRNN_BF16 || rs.B < 1 || rs.T < 1) return false;
-  const char* e = getenv("TTRNN_BF16_FP32_MFMA");      // A/B switch: keep bf16 storage on the fp32 MFMA kernels
-  if (e && e[0] == '1') return false;
+  const bool keep_fp32 = opt(OPT_BF16_FP32_MFMA) != 0;      // A/B switch: keep bf16 storage on the fp32 MFMA kernels
+  if (keep_fp32) return false;
   if (rs.cell == TTRNN_LSTM) return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
   return shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s);
 }

@@ -16,6 +16,7 @@
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_big.h"
 
@@ -503,18 +504,22 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
     {
       const unsigned long long* src = hx + (b * 2 + (t & 1)) * H + hidp;
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // bounded: a partner that is not resident must not hang the GPU — after one time-out (~0.1 s) stop waiting for
-      // the rest of the launch (the results are then wrong, which the parity tests would show, but the kernel ends)
+      // bounded: a partner that is not resident (CUs held by another stream / process) must not hang the GPU — after
+      // one time-out (~0.1 s) stop waiting for the rest of the launch.  The launch cannot report that through its status
+      // (no synchronisation inside the API), so the time-out POISONS the state instead: the missing half of h becomes
+      // NaN, which reaches every gate of this sample at the next step and from there `out`, hT and cT — a timed-out
+      // launch can never look like a result.
       long spin = 0;
       while (!dead && (unsigned)(v >> 32) != (unsigned)(t + 1)) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (++spin > (1L << 21)) dead = true;
       }
-      hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = __uint_as_float((unsigned)v);
+      hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = dead ? __uint_as_float(0x7FC00000u) : __uint_as_float((unsigned)v);
     }
     __syncthreads();
   }
+  if (dead) hst = cst = __uint_as_float(0x7FC00000u);       // T == time-out step: nothing downstream has seen the NaN yet
   if (hT) st(hT, b * H + hid, hst);
   if (cT) st(cT, b * H + hid, cst);
 }
@@ -529,11 +534,7 @@ bool big_rnn_fwd_available(const RnnShape& rs, int dtype) {
 
 // how many pairs of cores are contracted per launch: 2 (default: first two and last two -> a 2-core matrix),
 // 1 (first two only), 0 (the four-core chain as is).  TTRNN_BIG_MERGE is an A/B switch.
-static int big_merge_level() {
-  const char* e = getenv("TTRNN_BIG_MERGE");
-  if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
-  return 2;
-}
+static int big_merge_level() { return opt(OPT_BIG_MERGE); }
 
 static size_t big_gemm_bytes(const RnnShape& rs) {
   return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H);
@@ -607,8 +608,8 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     }
     const int cus = device_cu_count();
     const int grid2 = (int)(n_rows < cus ? n_rows : cus);          // one workgroup per CU (LDS)
-    const char* ng = getenv("TTRNN_BIG_NO_GEMM");            // A/B switch: K-in through the merged chain, row by row
-    if (ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT && !(ng && ng[0] == '1') && gemm_split_ok(rs.in, 4 * rs.H)) {
+    // OPT_BIG_NO_GEMM: A/B switch, K-in through the merged chain, row by row
+    if (opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_NO_GEMM) && gemm_split_ok(rs.in, 4 * rs.H)) {
       // K-in as one dense split-bf16 GEMM: W_in (gate-interleaved columns) = the chain kernel on the unit rows
       char* gt = tail + 2 * (b3 + b2) + pair_bytes;
       void* ident = gt;
@@ -629,8 +630,7 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
                          (const TS*)x, gin, slab, 2);
       if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
     }
-    const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
-    if (2 * rs.B <= cus && !(np && np[0] == '1')) {
+    if (2 * rs.B <= cus && !opt(OPT_BIG_NO_PAIR)) {      // OPT_BIG_NO_PAIR: A/B switch, one workgroup per sample
       // two workgroups per sample: tagged h exchange words [B][2][H] behind the merged cores (tag 0 = never written)
       unsigned long long* hxb = (unsigned long long*)(tail + 2 * (b3 + b2));
       if (hipMemsetAsync(hxb, 0, pair_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;

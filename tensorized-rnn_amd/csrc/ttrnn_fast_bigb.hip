@@ -18,6 +18,7 @@
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_big.h"
 
@@ -325,13 +326,15 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long* src = hx + (b * 2 + (n & 1)) * H + hid[0];
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      long spin = 0;                                        // bounded: a partner that is not resident must not hang the GPU
+      // bounded: a partner that is not resident must not hang the GPU; a time-out poisons dh with NaN (it then reaches every
+      // gate gradient of the sample and d_h0 / d_c0), see the forward pair kernel
+      long spin = 0;
       while (!dead && (unsigned)(v >> 32) != (unsigned)(n + 1)) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (++spin > (1L << 21)) dead = true;
       }
-      dhrec[0] = own + __uint_as_float((unsigned)v);
+      dhrec[0] = dead ? __uint_as_float(0x7FC00000u) : own + __uint_as_float((unsigned)v);
     }
 #pragma unroll
     for (int u = 0; u < NUT; ++u) {
@@ -714,10 +717,7 @@ int device_cus() {
   return cus;
 }
 
-bool no_bigb() {
-  const char* e = getenv("TTRNN_NO_BIGB");      // A/B switch: any-shape backward for the big shape
-  return e && e[0] == '1';
-}
+bool no_bigb() { return opt(OPT_NO_BIGB) != 0; }      // A/B switch: any-shape backward for the big shape
 }  // namespace
 
 bool big_rnn_bwd_available(const RnnShape& rs, int dtype) {
@@ -741,8 +741,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
                      packed_hid, m3);
   hipLaunchKernelGGL((k_bigb_prep<S3, ST>), dim3((int)(BT / sizeof(float) + 255) / 256), dim3(256), 0, stream, m3, mT);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-  const char* np = getenv("TTRNN_BIG_NO_PAIR");            // A/B switch: one workgroup per sample
-  const bool pair = 2 * rs.B <= device_cus() && !(np && np[0] == '1');
+  const bool pair = 2 * rs.B <= device_cus() && !opt(OPT_BIG_NO_PAIR);      // A/B switch: one workgroup per sample
   if (pair) {
     if (hipMemsetAsync(hxb, 0, (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long), stream) != hipSuccess)
       return TTRNN_ERR_LAUNCH;
@@ -825,8 +824,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   }
   if (!d_packed) return TTRNN_OK;
-  const char* sl = getenv("TTRNN_BIGW_SLICES");             // A/B switch: per-row merged-chain kernel instead of the dense GEMM
-  if (!(sl && sl[0] == '1')) {
+  if (!opt(OPT_BIGW_SLICES)) {      // A/B switch: per-row merged-chain kernel instead of the dense GEMM
     float* BmN = m2;                                        // the natural-order cores reuse the m2 / dA / dB regions
     float* AT = m2 + St<S2, 1>::K * St<S2, 1>::M;
     float* dWf = (float*)((char*)dB + BDB);

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 #include "ttrnn_f10.h"
@@ -398,8 +399,7 @@ static int launch_lin_f10(long n_rows, const float* packed, const void* bias, co
 
 // gate-interleaved LSTM input projection (ilv_mode 2) of fp32 rows through a hidden-shaped TT-matrix
 bool f10_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h, int ilv_mode) {
-  const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return false;
+  if (opt(OPT_NO_F10) || dtype != TTRNN_F32 || ilv_h != 256 || ilv_mode != 2) return false;
   return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpI40R16L>(s);
 }
 
@@ -614,12 +614,10 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   constexpr size_t lds = f10_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
-  const char* diag = getenv("TTRNN_DIAG");
-  const bool dg = diag && diag[0] == '1' && reserve;
+  const bool dg = opt(OPT_DIAG) && reserve;
   // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
   const int cus = device_cu_count();
-  const char* nb1 = rs.B > cus ? getenv("TTRNN_F10_NB1") : nullptr;      // A/B switch: one sample per workgroup
-  if (rs.B > cus && !dg && !(nb1 && nb1[0] == '1')) {
+  if (rs.B > cus && !dg && !opt(OPT_F10_NB1)) {      // OPT_F10_NB1: A/B switch, one sample per workgroup
     return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, wfrag, bh, out, hT, cT, reserve, stream);
   }
   auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
@@ -639,8 +637,7 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
 }
 
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || rs.B < 1 || rs.T < 1) return false;
+  if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 #include "ttrnn_f10.h"
@@ -533,8 +534,7 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
     }
   }
   // TTRNN_DIAG=1: per-phase s_memtime stamps of the first 8 workgroups land in the 4 KB behind the fragments
-  const char* de = getenv("TTRNN_DIAG");
-  const bool dg = de && de[0] == '1';
+  const bool dg = opt(OPT_DIAG) != 0;
   auto kern = dg ? k_lstm_bwd_f10<S, true> : k_lstm_bwd_f10<S, false>;
   unsigned long long* diag =
       dg ? reinterpret_cast<unsigned long long*>((char*)ws + f10b_wfrag_elems<S>() * sizeof(xbf8)) : nullptr;
@@ -570,8 +570,7 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 }
 
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
-  const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || rs.B < 1 || rs.T < 1) return false;
+  if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (rs.cell == TTRNN_GRU) return (dtype == TTRNN_F32 || dtype == TTRNN_BF16) && shape_matches<ShpH256R8G>(rs.hid_s);
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 #include "ttrnn_f10.h"
@@ -368,8 +369,7 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
 }
 
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype) {
-  const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || dy_dtype != TTRNN_F32) return false;
+  if (opt(OPT_NO_F10) || dy_dtype != TTRNN_F32) return false;
   if (dtype == TTRNN_F32)
     return shape_matches<ShpH256R8L>(s) || shape_matches<ShpH256R16L>(s) || shape_matches<ShpH256R8G>(s) ||
            shape_matches<ShpI40R16L>(s);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_f10.h"
 
@@ -198,8 +199,7 @@ static int launch_f10x(const RnnShape& rs, GinSrc gin, const void* h0, const voi
 
 // fragments: MT * K/4 * 64 floats; never larger than the split-mode fragment set the workspace query reserves
 bool f10x_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  const char* e = getenv("TTRNN_NO_F10");
-  if ((e && e[0] == '1') || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
+  if (opt(OPT_NO_F10) || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.B < 1 || rs.T < 1) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s);
 }
 

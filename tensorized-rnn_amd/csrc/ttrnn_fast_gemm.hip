@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 
@@ -595,8 +596,7 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % De
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
                        float* d_bias, hipStream_t stream, bool split, float* scratch) {
   const int cus = device_cu_count();
-  const char* nsw = getenv("TTRNN_DENSE_FP32");            // A/B switch: dense gradient on the fp32 MFMA
-  split = split && out % DenseS::TO == 0 && !(nsw && nsw[0] == '1');
+  split = split && out % DenseS::TO == 0 && !opt(OPT_DENSE_FP32);      // A/B switch: dense gradient on the fp32 MFMA
   const int KBc = split ? DenseS::KB : DenseG::KB;
   const int tiles = split ? ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO)
                           : ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);

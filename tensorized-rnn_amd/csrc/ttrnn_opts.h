@@ -1,0 +1,34 @@
+// ttrnn_opts.h — process-wide library options (kernel-route A/B switches and the fp32 math mode).
+// Read ONCE from the TTRNN_* environment variables at first use, afterwards only through ttrnn_set_option /
+// ttrnn_get_option (include/ttrnn.h): no getenv on any launch path, and every field is an atomic, so concurrent
+// host threads may launch while another thread flips a switch.
+#pragma once
+#include <atomic>
+
+namespace ttrnn {
+
+enum OptId {
+  OPT_FP32_MATH = 0,     // TTRNN_FP32_MATH = exact | split   (TTRNN_MATH_EXACT / TTRNN_MATH_SPLIT)
+  OPT_FORCE_GENERIC,     // TTRNN_FORCE_GENERIC=1   any-shape VALU kernels for everything
+  OPT_NO_GEMM,           // TTRNN_NO_GEMM=1         batched projections / gradients through the TT chain kernels
+  OPT_NO_IN1,            // TTRNN_NO_IN1=1          no input_size == 1 shortcut
+  OPT_NO_F10,            // TTRNN_NO_F10=1          no fused-core kernels (stage-wise MFMA kernels instead)
+  OPT_NO_G2,             // TTRNN_NO_G2=1           no runtime-shape two-stage MFMA kernels (any-shape VALU kernels instead)
+  OPT_DIAG,              // TTRNN_DIAG=1            diagnostic builds with s_memtime stamps
+  OPT_BF16_FP32_MFMA,    // TTRNN_BF16_FP32_MFMA=1  bf16 storage on the fp32 MFMA kernels
+  OPT_BIG_MERGE,         // TTRNN_BIG_MERGE=0|1|2   pairs of cores contracted per launch (big shape)
+  OPT_BIG_NO_GEMM,       // TTRNN_BIG_NO_GEMM=1
+  OPT_BIG_NO_PAIR,       // TTRNN_BIG_NO_PAIR=1     one workgroup per sample (big shape)
+  OPT_NO_BIGB,           // TTRNN_NO_BIGB=1         any-shape backward for the big shape
+  OPT_BIGW_SLICES,       // TTRNN_BIGW_SLICES=1
+  OPT_F10_NB1,           // TTRNN_F10_NB1=1         one sample per workgroup even when B > #CUs
+  OPT_DENSE_FP32,        // TTRNN_DENSE_FP32=1      dense weight gradient on the fp32 MFMA
+  OPT_COUNT
+};
+
+int opt(OptId id);                       // current value
+const char* opt_name(OptId id);          // "fp32_math", "force_generic", ...
+int opt_set(const char* name, int value);   // 0 or -1 (unknown name / bad value)
+int opt_get(const char* name, int* value);
+
+}  // namespace ttrnn

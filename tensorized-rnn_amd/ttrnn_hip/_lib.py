@@ -43,6 +43,8 @@ _SIGNATURES = {
     "ttrnn_device_available": (ctypes.c_int, []),
     "ttrnn_set_fp32_math": (ctypes.c_int, [ctypes.c_int]),
     "ttrnn_get_fp32_math": (ctypes.c_int, []),
+    "ttrnn_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "ttrnn_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "ttrnn_packed_elems": (ctypes.c_int64, [ctypes.POINTER(TtmDesc)]),
     "ttrnn_pack_cores": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
                                         ctypes.c_int, _P, _P]),
@@ -122,6 +124,30 @@ def fp32_math(mode):
         yield
     finally:
         set_fp32_math(prev)
+
+
+def get_option(name):
+    """Current value of a library option (include/ttrnn.h: ttrnn_get_option)."""
+    v = ctypes.c_int(0)
+    check(load().ttrnn_get_option(name.encode(), ctypes.byref(v)), "ttrnn_get_option({!r})".format(name))
+    return v.value
+
+
+def set_option(name, value):
+    """Set a library option; returns the previous value."""
+    prev = get_option(name)
+    check(load().ttrnn_set_option(name.encode(), int(value)), "ttrnn_set_option({!r}, {})".format(name, value))
+    return prev
+
+
+@contextlib.contextmanager
+def option(name, value):
+    """`with option("no_gemm", 1): ...` — route switches for A/B runs and route-vs-route parity tests."""
+    prev = set_option(name, value)
+    try:
+        yield
+    finally:
+        set_option(name, prev)
 
 
 def make_ttm(in_modes, out_modes, ranks):

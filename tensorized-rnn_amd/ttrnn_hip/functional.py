@@ -56,10 +56,25 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+# Debug switch (tests / tools/stress_determinism.py): fill every buffer this module allocates WITHOUT initialising it —
+# outputs, workspaces, packed cores, reserves, gradient buffers — with random bytes (about one fp32 pattern in 256 is a
+# NaN or Inf).  A kernel that reads memory nobody wrote, or leaves part of an output unwritten, then changes its results
+# from launch to launch instead of depending on what the allocator happened to hand out.
+POISON_ALLOCATIONS = False
+
+
+def _alloc(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if POISON_ALLOCATIONS and t.numel() > 0:
+        t.view(-1).view(torch.uint8).copy_(
+            torch.randint(0, 256, (t.numel() * t.element_size(),), dtype=torch.uint8, device=device))
+    return t
+
+
 def _workspace(nbytes, device):
     if nbytes == 0:
         return None
-    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return _alloc(int(nbytes), torch.uint8, device)
 
 
 class TTSpec(object):
@@ -111,7 +126,7 @@ class TTSpec(object):
         _require_device(*cores)
         lib = _lib.load()
         dt = _dtype_code(cores[0])
-        packed = torch.empty(self.packed_elems, dtype=torch.float32, device=cores[0].device)
+        packed = _alloc((self.packed_elems,), torch.float32, cores[0].device)
         ptrs, strides = self._core_args(cores)
         check(lib.ttrnn_pack_cores(ctypes.byref(self.desc), ptrs, strides, dt, _ptr(packed), _stream(packed)),
               "ttrnn_pack_cores")
@@ -124,8 +139,8 @@ class TTSpec(object):
         lib = _lib.load()
         dt = _dtype_code(cores_a[0])
         dev = cores_a[0].device
-        pa = torch.empty(spec_a.packed_elems, dtype=torch.float32, device=dev)
-        pb = torch.empty(spec_b.packed_elems, dtype=torch.float32, device=dev)
+        pa = _alloc((spec_a.packed_elems,), torch.float32, dev)
+        pb = _alloc((spec_b.packed_elems,), torch.float32, dev)
         ptrs_a, strides_a = spec_a._core_args(cores_a)
         ptrs_b, strides_b = spec_b._core_args(cores_b)
         check(lib.ttrnn_pack_cores2(ctypes.byref(spec_a.desc), ptrs_a, strides_a, _ptr(pa), ctypes.byref(spec_b.desc),
@@ -136,6 +151,9 @@ class TTSpec(object):
         """packed fp32 gradient -> list of gradient tensors with the layout of `like` (the cores)."""
         lib = _lib.load()
         grads = [torch.empty_strided(c.shape, c.stride(), dtype=c.dtype, device=c.device) for c in like]
+        if POISON_ALLOCATIONS:
+            for g in grads:
+                g.copy_(torch.full_like(g, float("nan")))
         ptrs, strides = self._core_args(grads)
         check(lib.ttrnn_unpack_core_grads(ctypes.byref(self.desc), _ptr(packed_grad), ptrs, strides,
                                           _dtype_code(like[0]), _stream(packed_grad)), "ttrnn_unpack_core_grads")
@@ -146,7 +164,7 @@ def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db):
     lib = _lib.load()
     n = dy2d.shape[0]
     dev = dy2d.device
-    dx = torch.empty(n, spec.in_features, dtype=x2d.dtype, device=dev) if need_dx else None
+    dx = _alloc((n, spec.in_features), x2d.dtype, dev) if need_dx else None
     dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
     db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
     wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
@@ -163,7 +181,7 @@ class _TTLinearFn(torch.autograd.Function):
         lib = _lib.load()
         packed = spec.pack(cores)
         n = x2d.shape[0]
-        y = torch.empty(n, spec.out_features, dtype=x2d.dtype, device=x2d.device)
+        y = _alloc((n, spec.out_features), x2d.dtype, x2d.device)
         wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
         ws = _workspace(wsb, x2d.device)
         check(lib.ttrnn_ttlinear_forward(ctypes.byref(spec.desc), _dtype_code(x2d), n, _ptr(packed), _ptr(bias),
@@ -247,16 +265,16 @@ class _TTRnnLayerFn(torch.autograd.Function):
         dev = x.device
         desc = spec.desc(B, T, _dtype_code(x))
         packed_in, packed_hid = TTSpec.pack_pair(spec.in_spec, cores_in, spec.hid_spec, cores_hid)
-        out = torch.empty(B, T, H, dtype=x.dtype, device=dev)
-        hT = torch.empty(B, H, dtype=x.dtype, device=dev)
-        cT = torch.empty(B, H, dtype=x.dtype, device=dev) if spec.cell == "lstm" else None
+        out = _alloc((B, T, H), x.dtype, dev)
+        hT = _alloc((B, H), x.dtype, dev)
+        cT = _alloc((B, H), x.dtype, dev) if spec.cell == "lstm" else None
         # needs_input_grad is True for Parameters even under torch.no_grad() (and grad mode is always
         # off inside forward): tt_rnn_layer decides outside whether a graph is being recorded, so that
         # inference does not pay for the training reserve (cfg2: 411 MB of writes per forward)
         need_grad = spec.recording and any(ctx.needs_input_grad)
         reserve = None
         if need_grad:
-            reserve = torch.empty(lib.ttrnn_rnn_reserve_bytes(ctypes.byref(desc)) // 4, dtype=torch.float32, device=dev)
+            reserve = _alloc((lib.ttrnn_rnn_reserve_bytes(ctypes.byref(desc)) // 4,), torch.float32, dev)
         wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
         with _timed("ttrnn_rnn_forward"):
@@ -295,11 +313,11 @@ class _TTRnnLayerFn(torch.autograd.Function):
         d_out = d_out.contiguous() if d_out is not None else None
         d_hT = d_hT.contiguous() if d_hT is not None else None
         d_cT = d_cT.contiguous() if d_cT is not None else None
-        dg_in = torch.empty(B, T, G * H, dtype=torch.float32, device=dev)
-        dg_hid = torch.empty(B, T, G * H, dtype=torch.float32, device=dev) if spec.cell == "gru" else dg_in
+        dg_in = _alloc((B, T, G * H), torch.float32, dev)
+        dg_hid = _alloc((B, T, G * H), torch.float32, dev) if spec.cell == "gru" else dg_in
         need = ctx.needs_input_grad
-        d_h0 = torch.empty(B, H, dtype=x.dtype, device=dev) if (has_h0 and need[1]) else None
-        d_c0 = torch.empty(B, H, dtype=x.dtype, device=dev) if (has_c0 and need[2]) else None
+        d_h0 = _alloc((B, H), x.dtype, dev) if (has_h0 and need[1]) else None
+        d_c0 = _alloc((B, H), x.dtype, dev) if (has_c0 and need[2]) else None
         wsb = lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
         with _timed("ttrnn_rnn_backward"):

@@ -18,6 +18,34 @@ from golden_io import Case, build_module, case_names
 pytestmark = pytest.mark.gpu
 
 
+
+class _RouteSwitches(object):
+    """The library's kernel-route switches (include/ttrnn.h: ttrnn_set_option) behind the names of the environment
+    variables that initialise them: OPT["TTRNN_NO_GEMM"] = "1"; OPT.pop("TTRNN_NO_GEMM") restores the default."""
+    DEFAULTS = {"big_merge": 2}
+
+    @staticmethod
+    def _name(key):
+        assert key.startswith("TTRNN_")
+        return key[len("TTRNN_"):].lower()
+
+    def __setitem__(self, key, value):
+        import ttrnn_hip
+        ttrnn_hip.set_option(self._name(key), int(value))
+
+    def pop(self, key, default=None):
+        import ttrnn_hip
+        name = self._name(key)
+        ttrnn_hip.set_option(name, self.DEFAULTS.get(name, 0))
+
+    def update(self, mapping):
+        for k, v in mapping.items():
+            self[k] = v
+
+
+OPT = _RouteSwitches()
+
+
 def dev():
     return torch.device("cuda:0")
 
@@ -312,7 +340,7 @@ def test_fast_and_generic_paths_agree():
     w = torch.randn(5, 20, 256, device=dev())
     outs = []
     for force in ("0", "1"):
-        os.environ["TTRNN_FORCE_GENERIC"] = force
+        OPT["TTRNN_FORCE_GENERIC"] = force
         try:
             m.zero_grad()
             xg = x.clone().requires_grad_(True)
@@ -320,7 +348,7 @@ def test_fast_and_generic_paths_agree():
             ((out * w).sum() + c.sum()).backward()
             outs.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ["TTRNN_FORCE_GENERIC"] = "0"
+            OPT["TTRNN_FORCE_GENERIC"] = "0"
     assert _maxabs(outs[0][0], outs[1][0]) <= 2e-6
     assert _maxabs(outs[0][1], outs[1][1]) <= 1e-5 * max(1.0, float(outs[1][1].abs().max()))
     for a, b in zip(outs[0][2], outs[1][2]):
@@ -403,6 +431,60 @@ def test_repeat_runs_are_bitwise_identical(kind, inp, H, L, r, B, T, dtype):
         grads.append([p.grad.float().clone() for p in m.parameters()])
     for a, b in zip(*grads):
         assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("kind,inp,H,L,d,r,B,T,dtype,route", [
+    ("ttlstm", 1, 256, 1, 3, 8, 9, 70, torch.float32, {}),                       # cfg2 kernels, in=1 path
+    ("ttgru", 1, 256, 1, 3, 8, 7, 33, torch.bfloat16, {}),                       # cfg3 kernels
+    ("ttgru", 1, 256, 1, 3, 8, 7, 33, torch.float32, {}),
+    ("ttlstm", 40, 256, 2, 3, 16, 80, 40, torch.float32, {}),                    # dense-GEMM K-in, KS=2 K-rec
+    ("ttlstm", 40, 256, 2, 3, 16, 80, 40, torch.float32, {"TTRNN_NO_GEMM": "1"}),   # fused-core K-in (round-1 suspect route)
+    ("ttlstm", 40, 256, 2, 3, 16, 5, 6, torch.float32, {}),                      # B*T < 2*in
+    ("ttlstm", 40, 256, 3, 3, 16, 300, 12, torch.float32, {}),                   # two samples per workgroup (B > #CUs)
+    ("ttlstm", 1, 128, 1, 2, 4, 6, 50, torch.float32, {}),                       # cfg1 kernels
+    ("ttlstm", 1024, 1024, 1, 4, 32, 3, 5, torch.float32, {}),                   # cfg5 kernels (pair)
+    ("ttlstm", 28, 96, 2, 2, 3, 5, 9, torch.float32, {}),                        # shape without a specialised kernel
+    ("ttgru", 28, 96, 2, 3, 5, 5, 9, torch.float32, {}),
+])
+def test_poisoned_allocations_do_not_change_results(kind, inp, H, L, d, r, B, T, dtype, route):
+    """Every buffer the host side allocates without initialising (outputs, workspaces, packed cores, reserves, gradient
+    buffers) is filled with random bytes — NaN / Inf patterns included — before each launch
+    (ttrnn_hip.functional.POISON_ALLOCATIONS).  A kernel that reads memory nobody wrote, or leaves part of an output
+    unwritten, shows up as a changed or non-finite result here on EVERY box, instead of only on boxes whose fresh
+    allocations are not zero.  Forward: bitwise equal to the clean launch (no atomics); gradients: equal to rounding."""
+    from ttrnn_hip import functional as F
+    torch.manual_seed(17)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r), dev()).to(dtype)
+    x = torch.rand(B, T, inp, device=dev()).to(dtype)
+    w = torch.randn(B, T, H, device=dev())
+
+    def run():
+        m.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        res = m(xg)
+        out = res[0]
+        hT = res[1][0] if kind == "ttlstm" else res[1]
+        ((out.float() * w).sum() + hT.float().sum()).backward()
+        with torch.no_grad():
+            inf = m(x)[0]
+        return out.detach().clone(), inf.clone(), xg.grad.float().clone(), [p.grad.float().clone() for p in m.parameters()]
+
+    try:
+        OPT.update(route)
+        clean = run()
+        F.POISON_ALLOCATIONS = True
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got[0], clean[0]) and torch.equal(got[1], clean[1]), "forward changed under poisoned buffers"
+            assert torch.isfinite(got[2]).all()
+            assert _maxabs(got[2], clean[2]) <= 1e-4 * max(float(clean[2].abs().max()), 1e-6)
+            for (name, _), a, b in zip(m.named_parameters(), got[3], clean[3]):
+                assert torch.isfinite(a).all(), name
+                assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6), name
+    finally:
+        F.POISON_ALLOCATIONS = False
+        for k in route:
+            OPT.pop(k)
 
 
 # ---- (4) fp32 math modes: three-way bf16 split (default) vs fp32 MFMA ("exact") -------------------------
@@ -523,7 +605,7 @@ def test_stacked_layers_many_rows_vs_generic(rank, B, T, x_grad):
     w = torch.randn(B, T, 256, device=dev())
     outs = []
     for force in ("0", "1"):
-        os.environ["TTRNN_FORCE_GENERIC"] = force
+        OPT["TTRNN_FORCE_GENERIC"] = force
         try:
             m.zero_grad()
             xg = x.clone().requires_grad_(x_grad)
@@ -532,7 +614,7 @@ def test_stacked_layers_many_rows_vs_generic(rank, B, T, x_grad):
             outs.append((out.detach().clone(), xg.grad.clone() if x_grad else torch.zeros(1),
                          [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ["TTRNN_FORCE_GENERIC"] = "0"
+            OPT["TTRNN_FORCE_GENERIC"] = "0"
     assert _maxabs(outs[0][0], outs[1][0]) <= 5e-6
     assert _maxabs(outs[0][1], outs[1][1]) <= 1e-4 * max(1e-3, float(outs[1][1].abs().max()))
     for (name, _), a, b in zip(m.named_parameters(), outs[0][2], outs[1][2]):
@@ -547,14 +629,14 @@ def test_fused_core_switch_off_matches():
     x = torch.rand(6, 50, 1, device=dev())
     res = []
     for flag in ("0", "1"):
-        os.environ["TTRNN_NO_F10"] = flag
+        OPT["TTRNN_NO_F10"] = flag
         try:
             m.zero_grad()
             out, (h, c) = m(x)
             (out.square().sum() + c.sum()).backward()
             res.append((out.detach().clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ["TTRNN_NO_F10"] = "0"
+            OPT["TTRNN_NO_F10"] = "0"
     assert _maxabs(res[0][0], res[1][0]) <= 2e-6
     for a, b in zip(res[0][1], res[1][1]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
@@ -590,12 +672,12 @@ def test_big_shape_merge_levels_and_bf16_storage():
     ro, rh, rc = _oracle_forward("ttlstm", sd, 1, x)
     try:
         for level in ("2", "1", "0"):
-            os.environ["TTRNN_BIG_MERGE"] = level
+            OPT["TTRNN_BIG_MERGE"] = level
             with torch.no_grad():
                 out, (hT, cT) = m(x.to(dev()))
             assert _maxabs(out, ro) <= 1e-5 and _maxabs(cT, rc) <= 1e-5, level
     finally:
-        os.environ.pop("TTRNN_BIG_MERGE", None)
+        OPT.pop("TTRNN_BIG_MERGE", None)
     mb = build_module(meta, dev()).to(torch.bfloat16)
     sdb = {k: v.detach().cpu().float() for k, v in mb.state_dict().items()}
     xb = x.to(torch.bfloat16)
@@ -618,12 +700,12 @@ def test_big_shape_two_workgroups_per_sample_matches_one():
     res = []
     try:
         for flag in ("0", "1"):
-            os.environ["TTRNN_BIG_NO_PAIR"] = flag
+            OPT["TTRNN_BIG_NO_PAIR"] = flag
             with torch.no_grad():
                 out, (hT, cT) = m(x, (h0, c0))
             res.append((out.clone(), cT.clone()))
     finally:
-        os.environ.pop("TTRNN_BIG_NO_PAIR", None)
+        OPT.pop("TTRNN_BIG_NO_PAIR", None)
     assert torch.isfinite(res[0][0]).all()
     assert _maxabs(res[0][0], res[1][0]) <= 2e-6 and _maxabs(res[0][1], res[1][1]) <= 2e-6
 
@@ -672,16 +754,16 @@ def test_big_shape_backward_kernels_agree(dtype):
     res = []
     try:
         for env in ({}, {"TTRNN_BIG_NO_PAIR": "1", "TTRNN_BIGW_SLICES": "1"}, {"TTRNN_NO_BIGB": "1"}):
-            os.environ.update(env)
+            OPT.update(env)
             m.zero_grad()
             out, (hT, cT) = m(x)
             ((out.float() * w).sum() + cT.float().sum()).backward()
             res.append([p.grad.float().clone() for p in m.parameters()])
             for k in env:
-                os.environ.pop(k)
+                OPT.pop(k)
     finally:
         for k in ("TTRNN_BIG_NO_PAIR", "TTRNN_BIGW_SLICES", "TTRNN_NO_BIGB"):
-            os.environ.pop(k, None)
+            OPT.pop(k, None)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     for (name, _), a, b, c in zip(m.named_parameters(), *res):
         scale = max(float(c.abs().max()), 1e-6)
@@ -728,7 +810,7 @@ def test_dense_gemm_paths_switch_off_matches():
     w = torch.randn(50, 26, 256, device=dev())
     res = []
     for flag in ("0", "1"):
-        os.environ["TTRNN_NO_GEMM"] = flag
+        OPT["TTRNN_NO_GEMM"] = flag
         try:
             m.zero_grad()
             xg = x.clone().requires_grad_(True)
@@ -736,7 +818,7 @@ def test_dense_gemm_paths_switch_off_matches():
             ((out * w).sum() + c.sum()).backward()
             res.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ.pop("TTRNN_NO_GEMM", None)
+            OPT.pop("TTRNN_NO_GEMM", None)
     assert _maxabs(res[0][0], res[1][0]) <= 5e-6
     assert _maxabs(res[0][1], res[1][1]) <= 1e-4 * max(1e-3, float(res[1][1].abs().max()))
     for (name, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
@@ -753,14 +835,14 @@ def test_dense_gradient_path_bf16_gru_vs_chain():
     x = torch.rand(40, 32, 1, device=dev()).to(torch.bfloat16)
     res = []
     for flag in ("0", "1"):
-        os.environ["TTRNN_NO_GEMM"] = flag
+        OPT["TTRNN_NO_GEMM"] = flag
         try:
             m.zero_grad()
             out, h = m(x)
             out.float().square().sum().backward()
             res.append([p.grad.float().clone() for p in m.parameters()])
         finally:
-            os.environ.pop("TTRNN_NO_GEMM", None)
+            OPT.pop("TTRNN_NO_GEMM", None)
     for (name, _), a, b in zip(m.named_parameters(), *res):
         assert _maxabs(a, b) <= 2e-2 * max(float(b.abs().max()), 1e-6), name
 
@@ -780,14 +862,14 @@ def test_two_samples_per_workgroup_matches_one(rank, inp):
     w = torch.randn(B, T, 256, device=dev())
     res = []
     for flag in ("0", "1"):
-        os.environ["TTRNN_F10_NB1"] = flag
+        OPT["TTRNN_F10_NB1"] = flag
         try:
             m.zero_grad()
             out, (h, c) = m(x, (h0, c0))
             ((out * w).sum() + c.sum()).backward()
             res.append((out.detach().clone(), h.detach().clone(), c.detach().clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ.pop("TTRNN_F10_NB1", None)
+            OPT.pop("TTRNN_F10_NB1", None)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][3], res[1][3]):
         assert _maxabs(a, b) <= 1e-4 * max(float(b.abs().max()), 1e-6)
@@ -805,7 +887,7 @@ def test_dense_gemm_paths_gru_two_layers():
     w = torch.randn(46, 25, 256, device=dev())
     res = []
     for flag in ("0", "1"):
-        os.environ["TTRNN_NO_GEMM"] = flag
+        OPT["TTRNN_NO_GEMM"] = flag
         try:
             m.zero_grad()
             xg = x.clone().requires_grad_(True)
@@ -813,7 +895,7 @@ def test_dense_gemm_paths_gru_two_layers():
             ((out * w).sum() + h.sum()).backward()
             res.append((out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in m.parameters()]))
         finally:
-            os.environ.pop("TTRNN_NO_GEMM", None)
+            OPT.pop("TTRNN_NO_GEMM", None)
     assert _maxabs(res[0][0], res[1][0]) <= 5e-6
     assert _maxabs(res[0][1], res[1][1]) <= 1e-4 * max(1e-3, float(res[1][1].abs().max()))
     for (name, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
