@@ -54,7 +54,17 @@ def sd_arrays(module):
     return out
 
 
+# `python tests/golden/gen_golden.py g6_bwd_cfg4_l3 g6_bwd_cfg5` regenerates only the named cases (prefix match)
+ONLY = [a for a in sys.argv[1:] if not a.startswith('-')]
+
+
+def wanted(name):
+    return not ONLY or any(name.startswith(o) for o in ONLY)
+
+
 def save(name, meta, **arrays):
+    if not wanted(name):
+        return
     arrays = {k: v for k, v in arrays.items() if v is not None}
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
@@ -84,6 +94,8 @@ def scale_weights(model, factor):
 
 def seq_case(name, meta, B, T, init=False, t_index=None, input_dist='normal', grads=False, weight_scale=1.0):
     """Forward (and optionally backward) of a full module on a [B,T,in] input."""
+    if not wanted(name):
+        return
     meta = dict(meta, B=B, T=T, init_states=init, input_dist=input_dist, weight_scale=weight_scale)
     model = build_rnn(meta)
     scale_weights(model, weight_scale)
@@ -265,6 +277,8 @@ def main():
     seq_case('g6_bwd_cfg3', cfg3, B=3, T=24, grads=True, init=True)
     seq_case('g6_bwd_cfg1_init', cfg1, B=3, T=7, grads=True, init=True, weight_scale=1.5)
     seq_case('g6_bwd_cfg4', dict(cfg4, num_layers=2), B=2, T=6, grads=True, input_dist='uniform')
+    seq_case('g6_bwd_cfg4_l3', cfg4, B=2, T=6, grads=True, input_dist='uniform')        # the real cfg4: three layers
+    seq_case('g6_bwd_cfg5', cfg5, B=2, T=3, grads=True)
 
     # ---- G7: init parity ---------------------------------------------------------------------------
     init_case('g7_init_cfg1', cfg1)

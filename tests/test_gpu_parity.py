@@ -270,6 +270,66 @@ def test_full_size_cfg2_subsample_vs_oracle():
     assert _maxabs(cT[[3, 60]], rc) <= 2e-5
 
 
+FULL_SIZE = {
+    # BASELINE.json configs[2..4] at their full per-GPU size: (kind, in, H, L, d, r, B, T, storage dtype, sub-sampled
+    # batch rows checked against the oracle over ALL steps, abs tol, tol relative to max |oracle|)
+    "cfg3": ("ttgru", 1, 256, 1, 3, 8, 256, 784, torch.bfloat16, [0, 101, 255], 2e-2, None),
+    "cfg3_fp32": ("ttgru", 1, 256, 1, 3, 8, 256, 784, torch.float32, [0, 101, 255], 2e-5, 2e-4),
+    "cfg4": ("ttlstm", 40, 256, 3, 3, 16, 512, 160, torch.float32, [0, 1, 300, 511], 2e-5, 2e-4),
+    "cfg5": ("ttlstm", 1024, 1024, 1, 4, 32, 128, 1024, torch.float32, [5, 127], 2e-5, 2e-4),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_full_size_configs_vs_oracle_and_properties(name):
+    """cfg3 / cfg4 / cfg5 at the sizes bench.py times them — the kernels that only run there (cfg3: 256 workgroups of the
+    bf16 fused-core GRU; cfg4: two samples per workgroup + dense-GEMM K-in over 81 920 rows; cfg5: pair kernels with the
+    1 024-step tagged exchange) against the oracle on sub-sampled batch rows over ALL steps, plus the size-independent
+    properties of tensorized_rnn/lstm.py:101-135: samples never interact (a different batch split reproduces the rows
+    bit for bit), causality (a prefix run equals the head of the long run), hT == outputs[:, -1], restart from a
+    mid-sequence state reproduces the tail."""
+    kind, inp, H, L, d, r, B, T, dtype, rows, atol, rtol = FULL_SIZE[name]
+    lstm = kind == "ttlstm"
+    torch.manual_seed(1111)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r), dev()).to(dtype)
+    torch.manual_seed(23)
+    x = torch.rand(B, T, inp).to(dtype)
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    ro, rh, rc = _oracle_forward(kind, sd, L, x[rows].float())
+    xd = x.to(dev())
+    with torch.no_grad():
+        res = m(xd)
+        out, hT = res[0], (res[1][0] if lstm else res[1])
+        cT = res[1][1] if lstm else None
+        assert out.dtype == dtype and out.shape == (B, T, H)
+        err = _maxabs(out[rows].float(), ro)
+        scale = float(ro.abs().max())
+        print("%s: max |out - oracle| = %.3g over %d x %d steps (max |oracle| %.3g, relative %.3g)" % (
+            name, err, len(rows), T, scale, err / scale))
+        assert err <= atol
+        if rtol is not None:
+            assert err <= rtol * scale
+        assert _maxabs(hT[rows].float(), rh) <= atol
+        if lstm:
+            assert _maxabs(cT[rows].float(), rc) <= atol
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(out[:, -1], hT)                                        # lstm.py:133,135
+        # batch independence: another split of the batch (different workgroup <-> sample assignment; for cfg4 the second
+        # part has an odd number of samples: one workgroup of the two-samples kernel runs half empty)
+        cut = B // 2 - 3
+        oa = m(xd[:cut])[0]
+        ob = m(xd[cut:])[0]
+        assert torch.equal(out[:cut], oa) and torch.equal(out[cut:], ob)
+        # causality + restart (only layer-0-state semantics for L == 1: init_states is shared by all layers, lstm.py:120)
+        tp = T // 3
+        resp = m(xd[:, :tp].contiguous())
+        assert torch.equal(out[:, :tp], resp[0])
+        if L == 1:
+            rest = m(xd[:, tp:].contiguous(), resp[1])
+            tail_tol = 2e-2 if dtype == torch.bfloat16 else 1e-6
+            assert _maxabs(rest[0].float(), out[:, tp:].float()) <= tail_tol
+
+
 def test_ttlinear_linearity_full_rows():
     """TTLinear over 64*784 rows: f(a x1 + b x2) - bias = a (f(x1) - bias) + b (f(x2) - bias)."""
     from t3nsor.layers import TTLinear
@@ -480,7 +540,9 @@ def test_poisoned_allocations_do_not_change_results(kind, inp, H, L, d, r, B, T,
             assert _maxabs(got[2], clean[2]) <= 1e-4 * max(float(clean[2].abs().max()), 1e-6)
             for (name, _), a, b in zip(m.named_parameters(), got[3], clean[3]):
                 assert torch.isfinite(a).all(), name
-                assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6), name
+                # atomic flush order differs from launch to launch; bf16 gradients round to 2^-8 relative on top
+                gtol = 2e-3 if dtype == torch.float32 else 1.2e-2
+                assert _maxabs(a, b) <= gtol * max(float(b.abs().max()), 1e-6), name
     finally:
         F.POISON_ALLOCATIONS = False
         for k in route:
