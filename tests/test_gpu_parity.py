@@ -493,6 +493,25 @@ def test_repeat_runs_are_bitwise_identical(kind, inp, H, L, r, B, T, dtype):
         assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("case,route", [("small", "default"), ("small", "nogemm"), ("mid", "nogemm"), ("mid", "default"),
+                                        ("cfg4", "default"), ("cfg2", "default"), ("cfg3", "default")])
+def test_forward_200_launches_bitwise_per_kernel(case, route):
+    """200 launches of the r = 16 two-layer model on the route that runs k_ttlinear_fwd_f10 +
+    k_lstm_fwd_f10<KS=2> (B*T < 2*in, or any size with the dense-GEMM switch off), of the full-size cfg4 (two samples per
+    workgroup) and of the cfg2 / cfg3 kernels, layer by layer through the C ABI (tools/stress_determinism.py): the hoisted
+    input projection and the outputs of every layer must reproduce the first launch bit for bit; a difference is
+    reported with the kernel (K-in: the workspace differs; K-rec: only `out` does) and the first (b, t, unit)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "stress_determinism", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                           "stress_determinism.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    recs = tool.run([case], [route], 200)
+    assert recs[0]["bad_launches"] == 0, recs[0]
+
+
 @pytest.mark.parametrize("kind,inp,H,L,d,r,B,T,dtype,route", [
     ("ttlstm", 1, 256, 1, 3, 8, 9, 70, torch.float32, {}),                       # cfg2 kernels, in=1 path
     ("ttgru", 1, 256, 1, 3, 8, 7, 33, torch.bfloat16, {}),                       # cfg3 kernels

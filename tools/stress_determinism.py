@@ -77,17 +77,10 @@ def first_diff(a, b):
     return [int(v) for v in d[0].tolist()], int(len(d))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=300)
-    ap.add_argument("--cases", default="small,mid,cfg4")
-    ap.add_argument("--routes", default="default,nogemm")
-    ap.add_argument("--dtype", default="float32")
-    ap.add_argument("--poison", action="store_true", help="random bytes in every output / workspace buffer before each launch")
-    args = ap.parse_args()
+def run(cases, routes, reps, poison=False, log=None):
+    """Returns one record per (case, route); record["bad_launches"] == 0 means every launch reproduced the first."""
     global POISON
-    POISON = args.poison
-
+    POISON = poison
     from tensorized_rnn.gru import TTGRU
     from tensorized_rnn.tt_lstm import TTLSTM
     from ttrnn_hip import _lib as L
@@ -95,63 +88,83 @@ def main():
 
     lib = L.load()
     dev = torch.device("cuda:0")
+    records = []
+    prev_route = L.get_option("no_gemm")
+    try:
+        for cname in cases:
+            kind, inp, H, nl, d, r, B, T = CASES[cname]
+            for route in routes:
+                L.set_option("no_gemm", 1 if route == "nogemm" else 0)
+                torch.manual_seed(3)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    cls = TTLSTM if kind == "ttlstm" else TTGRU
+                    m = cls(inp, H, nl, dev, n_cores=d, tt_rank=r)
+                dt = torch.bfloat16 if cname == "cfg3" else torch.float32
+                m = m.to(dt)
+                x = torch.rand(B, T, inp, device=dev).to(dt)
+                ref = None
+                nbad = 0
+                first = None
+                t0 = time.time()
+                names = ("out" if POISON else "ws", "out", "hT", "packed_in", "packed_hid")
+                with torch.no_grad():
+                    for rep in range(reps):
+                        seq = x
+                        cur = []
+                        for cell in m._all_layers:
+                            out, hT, cT, ws, packed = layer_forward_capture(cell, seq, lib, F, L)
+                            # poisoned workspaces legitimately differ outside the regions a launch writes: compare results only
+                            cur.append((out if POISON else ws, out, hT, packed[0], packed[1]))
+                            seq = out
+                        torch.cuda.synchronize()
+                        if ref is None:
+                            ref = cur
+                            continue
+                        hit = None
+                        for li, (a, b) in enumerate(zip(ref, cur)):
+                            for bname, ta, tb in zip(names, a, b):
+                                if not torch.equal(ta, tb):
+                                    hit = (li, bname, ta, tb)
+                                    break
+                            if hit:
+                                break
+                        if hit:
+                            nbad += 1
+                            if first is None:
+                                li, bname, ta, tb = hit
+                                idx, cnt = first_diff(ta, tb)
+                                if bname == "ws":
+                                    # gin = the first B*T*4H floats of the workspace (two rows for input_size == 1)
+                                    first = {"launch": rep, "layer": li, "buffer": "ws", "byte": idx[0], "n_bytes": cnt,
+                                             "gin_bytes": int(B * T * 4 * H * 4), "kernel": "K-in (or fragment prep)"}
+                                else:
+                                    first = {"launch": rep, "layer": li, "buffer": bname, "index_b_t_unit": idx, "n_elems": cnt,
+                                             "max_abs": float((ta.float() - tb.float()).abs().nan_to_num(1e30).max()),
+                                             "rows_b": sorted(set((ta != tb).nonzero()[:, 0].tolist()))[:8],
+                                             "kernel": "K-rec" if bname in ("out", "hT") else "pack"}
+                rec = {"case": cname, "route": route, "poison": POISON, "reps": reps, "bad_launches": nbad, "first": first,
+                       "seconds": round(time.time() - t0, 1)}
+                records.append(rec)
+                if log:
+                    log(rec)
+    finally:
+        L.set_option("no_gemm", prev_route)
+    return records
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=300)
+    ap.add_argument("--cases", default="small,mid,cfg4")
+    ap.add_argument("--routes", default="default,nogemm")
+    ap.add_argument("--poison", action="store_true", help="random bytes in every output / workspace buffer before each launch")
+    args = ap.parse_args()
     props = torch.cuda.get_device_properties(0)
     print(json.dumps({"device": props.name, "cus": props.multi_processor_count,
                       "mem_gb": round(props.total_memory / 2 ** 30, 1)}), flush=True)
-    bad_total = 0
-    for cname in args.cases.split(","):
-        kind, inp, H, nl, d, r, B, T = CASES[cname]
-        for route in args.routes.split(","):
-            L.set_option("no_gemm", 1 if route == "nogemm" else 0)
-            torch.manual_seed(3)
-            with contextlib.redirect_stdout(io.StringIO()):
-                cls = TTLSTM if kind == "ttlstm" else TTGRU
-                m = cls(inp, H, nl, dev, n_cores=d, tt_rank=r)
-            dt = torch.bfloat16 if cname == "cfg3" else torch.float32
-            m = m.to(dt)
-            x = torch.rand(B, T, inp, device=dev).to(dt)
-            ref = None
-            nbad = 0
-            first = None
-            t0 = time.time()
-            with torch.no_grad():
-                for rep in range(args.reps):
-                    seq = x
-                    cur = []
-                    for cell in m._all_layers:
-                        out, hT, cT, ws, packed = layer_forward_capture(cell, seq, lib, F, L)
-                        # poisoned workspaces legitimately differ outside the regions a launch writes: compare results only
-                        cur.append((out if POISON else ws, out, hT, packed[0], packed[1]))
-                        seq = out
-                    torch.cuda.synchronize()
-                    if ref is None:
-                        ref = cur
-                        continue
-                    for li, (a, b) in enumerate(zip(ref, cur)):
-                        for bname, ta, tb in zip(("out" if POISON else "ws", "out", "hT", "packed_in", "packed_hid"), a, b):
-                            if not torch.equal(ta, tb):
-                                nbad += 1
-                                if first is None:
-                                    if bname == "ws":
-                                        # which region of the workspace: gin = the first B*T*4H floats (0 for in=1 paths)
-                                        idx, cnt = first_diff(ta, tb)
-                                        first = {"launch": rep, "layer": li, "buffer": "ws", "byte": idx[0], "n_bytes": cnt,
-                                                 "gin_bytes": int(B * T * 4 * H * 4)}
-                                    else:
-                                        idx, cnt = first_diff(ta, tb)
-                                        fa, fb = ta.float(), tb.float()
-                                        first = {"launch": rep, "layer": li, "buffer": bname, "index": idx, "n_elems": cnt,
-                                                 "max_abs": float((fa - fb).abs().max()),
-                                                 "rows_b": sorted(set((ta != tb).nonzero()[:, 0].tolist()))[:8]}
-                                break
-                        else:
-                            continue
-                        break
-            rec = {"case": cname, "route": route, "poison": POISON, "reps": args.reps, "bad_launches": nbad, "first": first,
-                   "seconds": round(time.time() - t0, 1)}
-            print(json.dumps(rec), flush=True)
-            bad_total += nbad
-    L.set_option("no_gemm", 0)
+    recs = run(args.cases.split(","), args.routes.split(","), args.reps, args.poison,
+               log=lambda r: print(json.dumps(r), flush=True))
+    bad_total = sum(r["bad_launches"] for r in recs)
     print(json.dumps({"summary": "deterministic" if bad_total == 0 else "DIFFERENCES", "bad": bad_total}), flush=True)
     sys.exit(0 if bad_total == 0 else 1)
 
