@@ -19,6 +19,7 @@ struct OptTable {
   OptTable() {
     static const char* const env[OPT_COUNT] = {
         "TTRNN_FP32_MATH", "TTRNN_FORCE_GENERIC", "TTRNN_NO_GEMM", "TTRNN_NO_IN1", "TTRNN_NO_F10", "TTRNN_NO_G2",
+        "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
         "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32"};
     for (int i = 0; i < OPT_COUNT; ++i) {
@@ -36,7 +37,7 @@ OptTable& table() {
   return t;
 }
 const char* const kOptNames[OPT_COUNT] = {
-    "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "diag", "bf16_fp32_mfma", "big_merge",
+    "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
     "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
@@ -301,18 +302,22 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes;
   if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
+  if (!force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
 
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
     return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
   if (!force_generic() && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
+  if (!force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
 }
 
@@ -335,7 +340,8 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
-  const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+  const bool g2_first = opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype);
+  const FastFwdPlan f = g2_first ? FastFwdPlan{} : plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
     if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes)
       return TTRNN_ERR_WORKSPACE;
@@ -391,10 +397,16 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     return launch_rnn_fwd_fast(rs, desc->dtype, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                (hipStream_t)stream);
   }
-  if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) {
+  if (!g2_first && !force_generic() && big_rnn_fwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < big_rnn_fwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_fwd_big(rs, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,
                               reserve, workspace, (hipStream_t)stream);
+  }
+  if (!force_generic() && g2_rnn_available(rs, desc->dtype)) {
+    // runtime-shape two-stage MFMA kernels: every other TT shape with d >= 2 cores
+    if (!workspace || workspace_bytes < g2_rnn_fwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_fwd_g2(rs, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve,
+                             workspace, (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, false);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
@@ -413,7 +425,8 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (!packed_hid) return TTRNN_ERR_NULL;
   if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
-  if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
+  const bool g2_first = opt(OPT_FORCE_G2) && !force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype);
+  if (!g2_first && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&
         f10_rnn_bwd_available(rs, desc->dtype)) {
       if (!workspace || workspace_bytes < f10_rnn_bwd_workspace_bytes(rs, desc->dtype)) return TTRNN_ERR_WORKSPACE;
@@ -423,10 +436,15 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);
   }
-  if (!force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
+  if (!g2_first && !force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < big_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_big(rs, desc->dtype, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                               d_h0, d_c0, workspace, (hipStream_t)stream);
+  }
+  if (!force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype)) {
+    if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
+                             d_h0, d_c0, workspace, (hipStream_t)stream);
   }
   const RnnPlan p = plan_rnn_generic(rs, true);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

@@ -77,7 +77,8 @@ __device__ __forceinline__ void ld8(const bf16_t* p, size_t i, f32x4& a, f32x4& 
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, int KCn, int M,
                                                         const TS* __restrict__ x, const __bf16* __restrict__ planes,
-                                                        const TS* __restrict__ bias, int Hb, float* __restrict__ y) {
+                                                        const TS* __restrict__ bias, int Hb, float* __restrict__ y,
+                                                        const float* __restrict__ bias_ilv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* lds = reinterpret_cast<__bf16*>(smem);           // [buf][A planes 3][256][32], [B planes 3][128][32]
 
@@ -197,6 +198,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     if (bias) {
       const int hd = mf >> 2;
       bh = f32x4{ld(bias, hd), ld(bias, 2 * Hb + hd), ld(bias, Hb + hd), ld(bias, 3 * Hb + hd)};     // slots i,g,f,o
+    } else if (bias_ilv) {
+      bh = *reinterpret_cast<const f32x4*>(bias_ilv + mf);          // fp32 row already in column order (ttrnn_g2.hip)
     }
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
@@ -558,7 +561,7 @@ int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStrea
 
 template <typename TS>
 static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias, int Hb,
-                         float* y, hipStream_t stream) {
+                         float* y, hipStream_t stream, const float* bias_ilv) {
   static bool raised = false;
   if (!raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_split<TS>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -577,15 +580,15 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
     grid = (int64_t)MT * RT;
   }
   hipLaunchKernelGGL(k_gemm_split<TS>, dim3((unsigned)grid), dim3(FAST_NT), G_LDS, stream, n_rows, K, KCn, M,
-                     (const TS*)x, (const __bf16*)planes, (const TS*)bias, Hb, y);
+                     (const TS*)x, (const __bf16*)planes, (const TS*)bias, Hb, y, bias_ilv);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
-                      int Hb, float* y, hipStream_t stream) {
+                      int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
   if (n_rows <= 0) return TTRNN_OK;
-  return dtype == TTRNN_F32 ? launch_gemm_t<float>(n_rows, K, M, x, planes, bias, Hb, y, stream)
-                            : launch_gemm_t<bf16_t>(n_rows, K, M, x, planes, bias, Hb, y, stream);
+  return dtype == TTRNN_F32 ? launch_gemm_t<float>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv)
+                            : launch_gemm_t<bf16_t>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv);
 }
 
 

@@ -1,0 +1,167 @@
+// ttrnn_g2.h — plan of the runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): ANY TT-matrix with d >= 2 cores is
+// evaluated as a two-core matrix, its cores contracted ONCE per launch into
+//     tail  Gt[(i_t, a)][j_t]     = cores s .. d-1   (I_t = prod I_k, J_t = prod J_k over k >= s;  a = rank index R_s)
+//     head  Gh[i_h][(j_h, a)]     = cores 0 .. s-1   (I_h, J_h over k < s)
+// so that the per-timestep chain of t3nsor/ops.py:78-93 becomes two GEMM stages whatever d, the modes and the ranks are:
+//     stage 1  C1[i_t][(j_h, a)] = sum_{j_t}     Gt[(i_t, a)][j_t] * h[j_h][j_t]        M = I_t*R, N = J_h, K = J_t   (small K)
+//     stage 2  y[i_h*I_t + i_t]  = sum_{(j_h,a)} Gh[i_h][(j_h, a)] * C1[i_t][(j_h, a)]   M = I_h,   N = I_t, K = J_h*R  (the FLOPs)
+// and the reverse-time chain (BPTT) the transposed pair
+//     T2  dC1[i_t][(j_h, a)] = sum_{i_h}     Gh[i_h][(j_h, a)] * dy[i_h*I_t + i_t]      M = J_h*R, N = I_t, K = I_h
+//     T1  dh[j_h][j_t]       = sum_{(i_t,a)} Gt[(i_t, a)][j_t] * dC1[i_t][(j_h, a)]      M = J_t,   N = J_h, K = I_t*R.
+// All shape-dependent index arithmetic lives in the prep kernels (which write the merged cores as MFMA fragments in the
+// order the waves consume them) and in per-thread constants computed before the time loop; the time loops see padded tile
+// counts only.  Host + device POD, no HIP types.
+#pragma once
+#include "ttrnn_core.h"
+
+namespace ttrnn {
+
+constexpr int G2_NW = 4;            // waves per workgroup (one per SIMD; small workgroups so that several samples share a CU)
+constexpr int G2_NT = G2_NW * 64;
+constexpr int G2_PF = 8;            // head fragments in flight per wave (k-blocks of 32): ~770 matrix-pipe cycles of cover
+constexpr int G2_UPT = 4;           // hidden units per thread in the gate phase: H <= 1024
+constexpr int G2_MAX_R = 64;        // rank at the split point
+constexpr int G2_LDS_LIMIT = 160 * 1024;
+
+struct G2Mat {
+  int ok;
+  int d, s;                         // cores, split point
+  int It, Jt, Ih, Jh, R, Rp;        // Rp = R rounded up to 4 (four accumulator registers = four consecutive a)
+  int in, out;
+  // forward stage 1 (fp32 MFMA 16x16x4): tiles (m1 tile, n1 tile), k steps of 4
+  int M1T, N1T, KS1, T1;
+  // forward stage 2 (bf16 MFMA 16x16x32, three-way split): tiles (m2, n2), k blocks of 32; a tile's k range is split
+  // over KSPLIT waves when there are fewer tiles than waves; unit u = tile*KSPLIT + part, wave w takes u = w, w+NW, ..
+  int M2T, N2T, NKB, T2, KSPLIT, KPER, KBP, U, UW;  // KPER = k-blocks per part, KBP = KPER padded to G2_PF, UW = units per wave (max)
+  int JtS;                          // fp32 h image [16*N1T][JtS]
+  int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
+  // reverse T2 (bf16 MFMA, split): M = Jh*Rp, N = It, K = Ih
+  int bM2T, bNKB, bT2, bKBP, bU, bUW;              // no k split: T1 reads the complete dC1
+  int IhS;                          // bf16 dy planes [16*N2T][IhS]
+  // reverse T1 (fp32 MFMA): M = Jt (one or more m tiles), N = Jh, K = It*Rp in steps of 4, split over bKS1P parts
+  int bM1T, bKS1, bT1, bK1SPLIT, bKS1P, bU1;        // bKS1P = k-steps per part
+  int K1S;                          // fp32 dC1 image [16*N1T][K1S]
+  // element counts of the per-launch buffers (workspace)
+  long head_elems, tail_elems;      // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
+  long fs2_bytes, ft1_bytes;        // forward: head fragment stream (bf16 x 3 planes), tail fragments (fp32)
+  long bs2_bytes, bt1_bytes;        // reverse: the same for T2 / T1
+};
+
+inline int g2_ceil(int a, int b) { return (a + b - 1) / b; }
+
+// how the k range of `tiles` tiles with `nkb` blocks each is spread over the waves
+inline void g2_split(int tiles, int nkb, int* ksplit, int* kper, int* kbp, int* units, int* uw) {
+  int ks = 1;
+  if (tiles < G2_NW) {
+    ks = G2_NW / tiles;
+    if (ks > nkb) ks = nkb;
+    if (ks < 1) ks = 1;
+  }
+  int per = g2_ceil(nkb, ks);
+  ks = g2_ceil(nkb, per);                       // no empty part
+  *ksplit = ks;
+  *kper = per;
+  *kbp = g2_ceil(per, G2_PF) * G2_PF;
+  *units = tiles * ks;
+  *uw = g2_ceil(*units, G2_NW);
+}
+
+inline void g2_plan_mat(G2Mat* m, const TtShape& s) {
+  *m = G2Mat{};
+  if (s.d < 2) return;
+  long best = -1;
+  int bs = 1;
+  for (int sp = 1; sp < s.d; ++sp) {
+    long It = 1, Jh = 1;
+    for (int k = sp; k < s.d; ++k) It *= s.I[k];
+    for (int k = 0; k < sp; ++k) Jh *= s.J[k];
+    const long rp = (s.R[sp] + 3) & ~3;
+    // MFMA work with the tile padding: stage 1 (fp32, 4x the cycles per FLOP of a split bf16 block) + stage 2
+    const long c1 = (long)g2_ceil((int)(It * rp), 16) * g2_ceil((int)Jh, 16) * g2_ceil(s.in_size / (int)Jh, 4) * 32;
+    const long c2 = (long)g2_ceil(s.out_size / (int)It, 16) * g2_ceil((int)It, 16) * g2_ceil((int)(Jh * rp), 32) * 96;
+    const long cost = c1 + c2;
+    if (best < 0 || cost < best) { best = cost; bs = sp; }
+  }
+  m->d = s.d; m->s = bs;
+  m->It = m->Jt = m->Ih = m->Jh = 1;
+  for (int k = bs; k < s.d; ++k) { m->It *= s.I[k]; m->Jt *= s.J[k]; }
+  for (int k = 0; k < bs; ++k) { m->Ih *= s.I[k]; m->Jh *= s.J[k]; }
+  m->R = s.R[bs]; m->Rp = (m->R + 3) & ~3;
+  m->in = s.in_size; m->out = s.out_size;
+  if (m->R > G2_MAX_R) return;
+  for (int k = 0; k <= s.d; ++k) if (s.R[k] > G2_MAX_R) return;
+  m->M1T = g2_ceil(m->It * m->Rp, 16); m->N1T = g2_ceil(m->Jh, 16); m->KS1 = g2_ceil(m->Jt, 4);
+  m->T1 = m->M1T * m->N1T;
+  m->M2T = g2_ceil(m->Ih, 16); m->N2T = g2_ceil(m->It, 16); m->NKB = g2_ceil(m->Jh * m->Rp, 32);
+  m->T2 = m->M2T * m->N2T;
+  g2_split(m->T2, m->NKB, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
+  m->JtS = 4 * m->KS1 + 1;
+  m->K2S = 32 * m->NKB + 8;
+  m->bM2T = g2_ceil(m->Jh * m->Rp, 16); m->bNKB = g2_ceil(m->Ih, 32);
+  m->bT2 = m->bM2T * m->N2T;
+  m->bKBP = g2_ceil(m->bNKB, G2_PF) * G2_PF;
+  m->bU = m->bT2;
+  m->bUW = g2_ceil(m->bU, G2_NW);
+  m->IhS = 32 * m->bNKB + 8;
+  m->bM1T = g2_ceil(m->Jt, 16); m->bKS1 = (m->It * m->Rp) / 4;
+  m->bT1 = m->bM1T * m->N1T;
+  {
+    int ks = 1;
+    if (m->bT1 < G2_NW) { ks = G2_NW / m->bT1; if (ks > m->bKS1) ks = m->bKS1; if (ks < 1) ks = 1; }
+    m->bKS1P = g2_ceil(m->bKS1, ks);
+    m->bK1SPLIT = g2_ceil(m->bKS1, m->bKS1P);
+    m->bU1 = m->bT1 * m->bK1SPLIT;
+  }
+  m->K1S = m->It * m->Rp + 4;
+  m->head_elems = (long)m->Ih * m->Jh * m->R;
+  m->tail_elems = (long)m->It * m->Jt * m->R;
+  m->fs2_bytes = (long)G2_NW * m->UW * m->KBP * 3 * 64 * 16;
+  m->ft1_bytes = (long)m->M1T * m->KS1 * 64 * 4;
+  m->bs2_bytes = (long)G2_NW * m->bUW * m->bKBP * 3 * 64 * 16;
+  m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
+  m->ok = 1;
+}
+
+struct G2Plan {
+  int ok;
+  int cell, G, H, B, T;
+  G2Mat hid;
+  int upt;                          // hidden units per thread
+  // LDS carve-up (bytes) of the forward and the reverse-time kernel
+  int f_hb, f_img, f_ybuf, f_tab, f_lds;       // f_tab: stage-1 store offsets [T1][64] ints
+  int b_dy, b_dc1, b_dh, b_tab, b_lds;         // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
+};
+
+inline size_t g2_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline void g2_plan(G2Plan* p, const RnnShape& rs) {
+  *p = G2Plan{};
+  p->cell = rs.cell; p->G = rs.G; p->H = rs.H; p->B = rs.B; p->T = rs.T;
+  g2_plan_mat(&p->hid, rs.hid_s);
+  if (!p->hid.ok) return;
+  if (rs.H > G2_UPT * G2_NT) return;
+  p->upt = g2_ceil(rs.H, G2_NT);
+  const G2Mat& m = p->hid;
+  p->f_hb = (int)g2_al((size_t)16 * m.N1T * m.JtS * 4);
+  p->f_img = (int)g2_al((size_t)3 * 16 * m.N2T * m.K2S * 2);
+  p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
+  p->f_tab = (int)g2_al((size_t)m.T1 * 64 * 4);
+  p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab;
+  p->b_dy = (int)g2_al((size_t)3 * 16 * m.N2T * m.IhS * 2);
+  p->b_dc1 = (int)g2_al(((size_t)16 * m.N1T * m.K1S) * 4);
+  p->b_dh = (int)g2_al((size_t)m.bK1SPLIT * rs.H * 4);
+  p->b_tab = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4) * 4);
+  p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
+  if (p->f_lds > G2_LDS_LIMIT || p->b_lds > G2_LDS_LIMIT) return;
+  p->ok = 1;
+}
+
+// workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
+inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
+  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes);
+}
+inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
+  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);
+}
+
+}  // namespace ttrnn

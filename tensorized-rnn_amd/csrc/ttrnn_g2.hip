@@ -1,0 +1,736 @@
+// ttrnn_g2.hip — runtime-shape two-stage MFMA kernels (gfx950): the recurrent forward and the reverse-time kernel of
+// BPTT for ANY TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores (ttrnn_g2.h: plan and algebra).  This is the
+// tier between the shape-specialised kernels (register-resident fragments: cfg1..cfg5) and the any-shape VALU kernels
+// (ttrnn_generic.hip): every (hidden_size, ncores, ttrank, new_core) the reference's experiment flags can produce
+// (pmnist_test.py:47-56, params_model.py) runs its time loop on the matrix cores.
+//
+// Arithmetic: fp32-class whatever the storage type.  The big stage (stage 2 / T2) takes its fp32 operands as three bf16
+// pieces on v_mfma_f32_16x16x32_bf16 (ttrnn_split.h: six terms, fp32 accumulation); the small stage (stage 1 / T1,
+// contraction over the last mode(s) only) runs on v_mfma_f32_16x16x4_f32 straight from fp32 LDS images, so the forward
+// splits only the stage-1 result and the reverse only the gate gradients.
+//
+// Data movement: one workgroup of 4 waves per sample for all T steps, h / c in registers, all intermediates in LDS.
+// The merged head core does not fit registers for runtime shapes, so each wave STREAMS its fragments from L2 every step —
+// written by the prep kernel in exactly the order the wave consumes them (coalesced 16-byte loads), G2_PF k-blocks in
+// flight through rolling register slots; the loads of step t+1 are issued while step t still multiplies, so the stream
+// never waits on the recurrence.  LDS per workgroup stays small (cfg2-like shapes: ~40 KB), several samples share a CU
+// when B > #CUs and hide each other's barriers.
+//
+// Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 with the hidden chain of
+// t3nsor/ops.py:78-93, and torch autograd through them.
+#include <hip/hip_runtime.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_g2.h"
+
+namespace ttrnn {
+
+namespace {
+
+// ---- prep 1: contract the cores on either side of the split point ------------------------------------------------------
+// packed: W_k[(j*R_{k+1} + b)*M_k + (i*R_k + a)] = G_k[a, i, j, b]  (include/ttrnn.h)
+__global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const float* __restrict__ packed,
+                                                  float* __restrict__ Gh, float* __restrict__ Gt) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nh = (long)m.Ih * m.Jh, nt = (long)m.It * m.Jt;
+  float v[G2_MAX_R], w[G2_MAX_R];
+  if (e < nh) {
+    int ih = (int)(e / m.Jh), jh = (int)(e % m.Jh);
+    int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
+    for (int k = m.s - 1; k >= 0; --k) { ii[k] = ih % s.I[k]; ih /= s.I[k]; jj[k] = jh % s.J[k]; jh /= s.J[k]; }
+    const float* W0 = packed + s.woff[0];
+    for (int b = 0; b < s.R[1]; ++b) v[b] = W0[(size_t)(jj[0] * s.R[1] + b) * s.M[0] + ii[0]];
+    for (int k = 1; k < m.s; ++k) {
+      const float* Wk = packed + s.woff[k];
+      for (int b = 0; b < s.R[k + 1]; ++b) {
+        float acc = 0.f;
+        for (int a = 0; a < s.R[k]; ++a) acc = fmaf(v[a], Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], acc);
+        w[b] = acc;
+      }
+      for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
+    }
+    for (int a = 0; a < m.R; ++a) Gh[(size_t)e * m.R + a] = v[a];
+  } else if (e < nh + nt) {
+    const long f = e - nh;
+    int it = (int)(f / m.Jt), jt = (int)(f % m.Jt);
+    int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
+    for (int k = s.d - 1; k >= m.s; --k) { ii[k] = it % s.I[k]; it /= s.I[k]; jj[k] = jt % s.J[k]; jt /= s.J[k]; }
+    const int kl = s.d - 1;
+    const float* Wl = packed + s.woff[kl];
+    for (int a = 0; a < s.R[kl]; ++a) v[a] = Wl[(size_t)jj[kl] * s.M[kl] + ii[kl] * s.R[kl] + a];       // R_d = 1
+    for (int k = kl - 1; k >= m.s; --k) {
+      const float* Wk = packed + s.woff[k];
+      for (int a = 0; a < s.R[k]; ++a) {
+        float acc = 0.f;
+        for (int b = 0; b < s.R[k + 1]; ++b) acc = fmaf(Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], v[b], acc);
+        w[a] = acc;
+      }
+      for (int a = 0; a < s.R[k]; ++a) v[a] = w[a];
+    }
+    for (int a = 0; a < m.R; ++a) Gt[(size_t)f * m.R + a] = v[a];
+  }
+}
+
+// ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
+// head stream (bf16 x 3 planes): block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl)*3 planes * 64 lanes
+//   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
+//   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
+template <bool REV>
+__global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs) {
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
+  const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKB : m.KPER, NKB = REV ? m.bNKB : m.NKB;
+  const int blk = blockIdx.x;                    // (w*UW + ui)*KBP + kbl
+  const int kbl = blk % KBP, ui = (blk / KBP) % UW, w = blk / (KBP * UW);
+  const int u = w + ui * G2_NW;
+  xbf8 f0, f1, f2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f; }
+  if (u < U && kbl < KPER) {
+    const int tile = u / KSPLIT, part = u % KSPLIT;
+    const int mt = tile / m.N2T;
+    const int kb = part * KPER + kbl;
+    if (kb < NKB) {
+      const int row = 16 * mt + r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * kb + 8 * q + e;
+        int ih, jh, a;
+        if (REV) { jh = row / m.Rp; a = row % m.Rp; ih = k; }
+        else { ih = row; jh = k / m.Rp; a = k % m.Rp; }
+        float v = 0.f;
+        if (ih < m.Ih && jh < m.Jh && a < m.R) v = Gh[((size_t)ih * m.Jh + jh) * m.R + a];
+        __bf16 p0, p1, p2;
+        split3(v, p0, p1, p2);
+        f0[e] = p0; f1[e] = p1; f2[e] = p2;
+      }
+    }
+  }
+  xbf8* dst = fs + (size_t)blk * 3 * 64 + lane;
+  dst[0] = f0; dst[64] = f1; dst[128] = f2;
+}
+
+// tail fragments (fp32, one value per lane and k-step):  lane (m = lane & 15, kq = lane >> 4)
+//   forward: A[m][k] = Gt[(i_t, a) = divmod(16 mt + m, Rp)][j_t = 4 ks + kq]         at (mt*KS1 + ks)*64 + lane
+//   reverse: A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]         at (mt*bKS1 + ks)*64 + lane
+template <bool REV>
+__global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft) {
+  const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
+  const int KS = REV ? m.bKS1 : m.KS1;
+  const int ks = blockIdx.x % KS, mt = blockIdx.x / KS;
+  int it, a, jt;
+  if (REV) { const int k = 4 * ks + kq; it = k / m.Rp; a = k % m.Rp; jt = 16 * mt + mm; }
+  else { const int row = 16 * mt + mm; it = row / m.Rp; a = row % m.Rp; jt = 4 * ks + kq; }
+  float v = 0.f;
+  if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
+  ft[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
+// biases of both TTLinears -> one gate-interleaved fp32 row [H][4] that the input projection adds to gin:
+//   LSTM slots i,g,f,o: b_in + b_hid;   GRU slots r,z: b_in + b_hid, n: b_in only, slot 3: b_hid of the n gate (it sits
+//   inside the r * (...) product, gru.py:42-43, so it travels to the gate phase as the fourth gin slot)
+template <typename TS>
+__global__ void __launch_bounds__(256) k_g2_bias(int cell, int H, const TS* __restrict__ bin, const TS* __restrict__ bhid,
+                                                 float* __restrict__ bilv) {
+  const int hid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hid >= H) return;
+  auto b = [&](const TS* p, int g) { return p ? ld(p, (size_t)g * H + hid) : 0.f; };
+  f32x4 v;
+  if (cell == TTRNN_LSTM) v = f32x4{b(bin, 0) + b(bhid, 0), b(bin, 2) + b(bhid, 2), b(bin, 1) + b(bhid, 1), b(bin, 3) + b(bhid, 3)};
+  else v = f32x4{b(bin, 0) + b(bhid, 0), b(bin, 1) + b(bhid, 1), b(bin, 2), b(bhid, 2)};
+  reinterpret_cast<f32x4*>(bilv)[hid] = v;
+}
+
+// x[n][in] -> xpad[n][inp] (zero-filled columns): the dense GEMM stages 8 contraction values per load
+template <typename TS>
+__global__ void __launch_bounds__(256) k_g2_pad_rows(long n_rows, int in, int inp, const TS* __restrict__ x, TS* __restrict__ xp) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_rows * inp) return;
+  const long n = e / inp;
+  const int j = (int)(e - n * inp);
+  st(xp, (size_t)e, j < in ? ld(x, (size_t)n * in + j) : 0.f);
+}
+
+__device__ __forceinline__ float round_to(float v, const float*) { return v; }
+__device__ __forceinline__ float round_to(float v, const bf16_t*) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// one wave's walk over its share of the head stream: G2_PF blocks in rolling register slots
+struct HeadStream {
+  const xbf8* base;      // this wave's blocks, + lane
+  int total;             // blocks per timestep
+  int seq;               // next block to CONSUME (0 .. total-1)
+};
+
+// ---- forward ----------------------------------------------------------------------------------------------------------------
+template <int CELL, typename TS>
+__global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
+                                                  const TS* __restrict__ c0, const xbf8* __restrict__ fs2,
+                                                  const float* __restrict__ ft1, TS* __restrict__ out, TS* __restrict__ hT,
+                                                  TS* __restrict__ cT, float* __restrict__ reserve) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const G2Mat& m = P.hid;
+  float* hb = reinterpret_cast<float*>(smem);
+  __bf16* img = reinterpret_cast<__bf16*>(smem + P.f_hb);
+  float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
+  int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
+  const int plane = 16 * m.N2T * m.K2S;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+  const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
+  constexpr bool LSTM = CELL == TTRNN_LSTM;
+
+  // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
+  for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += G2_NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  for (int e = tid; e < m.T1 * 64; e += G2_NT) {
+    const int t1 = e >> 6, l = e & 63;
+    const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
+    const int m1 = 16 * mt1 + 4 * (l >> 4), jh = 16 * nt1 + (l & 15);
+    const int it = m1 / m.Rp, a = m1 - it * m.Rp;
+    s1off[e] = (it < m.It && jh < m.Jh) ? it * m.K2S + jh * m.Rp + a : -1;
+  }
+  float hst[G2_UPT], cst[G2_UPT];
+  int hoff[G2_UPT];
+  f32x4 gi[G2_UPT], bb[G2_UPT];      // input_size == 1: gi holds the unit row's projection, bb the bias row
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gs.gin);
+  const f32x4* bil4 = reinterpret_cast<const f32x4*>(bilv);
+  const TS* xs = reinterpret_cast<const TS*>(gs.x);
+  const bool in1 = gs.in1 != 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < G2_UPT; ++u) {
+    hst[u] = 0.f; cst[u] = 0.f; hoff[u] = 0;
+    gi[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bb[u] = gi[u];
+    if (u < upt) {
+      const int hid = tid + u * G2_NT;
+      if (hid < H) {
+        hoff[u] = (hid / m.Jt) * m.JtS + hid % m.Jt;
+        hst[u] = h0 ? ld(h0, b * H + hid) : 0.f;
+        cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
+        hb[hoff[u]] = hst[u];
+        if (in1) { gi[u] = gin4[hid]; bb[u] = bil4[hid]; }
+      }
+    }
+  }
+  // head stream of this wave
+  const int nu_w = wave < m.U ? (m.U - wave + G2_NW - 1) / G2_NW : 0;
+  const int total = nu_w * m.KBP;
+  const xbf8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 3 * 64 + lane;
+  xbf8 wbuf[G2_PF][3];
+#pragma unroll
+  for (int j = 0; j < G2_PF; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
+      if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+    }
+  float xcur = (in1 && T > 0) ? ld(xs, b * T) : 0.f;
+  lds_barrier();
+
+  for (int t = 0; t < T; ++t) {
+    const size_t bt = b * T + t;
+    // gate inputs of this step: requested now, used after both stages
+    float xnext = 0.f;
+    if (in1) {
+      xnext = t + 1 < T ? ld(xs, bt + 1) : 0.f;
+    } else {
+#pragma unroll
+      for (int u = 0; u < G2_UPT; ++u)
+        if (u < upt) { const int hid = tid + u * G2_NT; gi[u] = gin4[bt * H + (hid < H ? hid : 0)]; }
+    }
+    // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
+    for (int t1 = wave; t1 < m.T1; t1 += G2_NW) {
+      const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
+      const float* ap = ft1 + (size_t)mt1 * m.KS1 * 64 + lane;
+      const float* bp = hb + (16 * nt1 + c) * m.JtS + q;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < m.KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 64], bp[4 * ks], acc, 0, 0, 0);
+      const int off = s1off[t1 * 64 + lane];
+      if (off >= 0) store_split4(img, plane, off, acc);
+    }
+    lds_barrier();
+    // ---- stage 2 (split bf16 MFMA, streamed head fragments) ----------------------------------------------------------------------
+    {
+      int seq = 0;
+      for (int ui = 0; ui < nu_w; ++ui) {
+        const int u = wave + ui * G2_NW;
+        const int tile = u / m.KSPLIT, part = u - tile * m.KSPLIT;
+        const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
+        const int kb0 = part * m.KPER;
+        const __bf16* brow = img + (16 * nt + c) * m.K2S + 8 * q;
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
+#pragma unroll
+          for (int j = 0; j < G2_PF; ++j) {
+            const int kb = kb0 + kbl + j;
+            if (kbl + j < m.KPER && kb < m.NKB) {
+              xbf8 bf[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
+#pragma unroll
+              for (int s = 0; s < 5; ++s)
+                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
+              acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][0], bf[0], acc_hi, 0, 0, 0);
+            }
+            int nxt = seq + G2_PF;                       // refill the slot with the block G2_PF ahead (wraps into step t+1)
+            nxt -= nxt >= total ? total : 0;             // total >= G2_PF
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+            ++seq;
+          }
+        }
+        const f32x4 acc = acc_hi + acc_lo;
+        const int itc = 16 * nt + c;
+        if (itc < m.It) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ih = 16 * mt + 4 * q + j;
+            if (ih < m.Ih) ybuf[part * GH + ih * m.It + itc] = acc[j];
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- gates + state (lstm.py:26-32 / gru.py:38-44) --------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < G2_UPT; ++u) {
+      if (u < upt) {
+        const int hid = tid + u * G2_NT;
+        if (hid < H) {
+          float y[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int pt = 0; pt < m.KSPLIT; ++pt)
+#pragma unroll
+            for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ybuf[pt * GH + g * H + hid];
+          f32x4 g4 = gi[u];
+          if (in1) g4 = bb[u] + xcur * gi[u];
+          float hy;
+          if (LSTM) {                                    // gin slots i,g,f,o
+            const float ig = fsigmoid(y[0] + g4[0]);
+            const float fg = fsigmoid(y[1] + g4[2]);
+            const float gg = ftanh(y[2] + g4[1]);
+            const float og = fsigmoid(y[3] + g4[3]);
+            const float cy = fg * cst[u] + ig * gg;
+            hy = og * ftanh(cy);
+            cst[u] = cy;
+            if (reserve) {
+              float* rv = reserve + (bt * H + hid) * 8;
+              *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
+              rv[4] = cy;
+            }
+          } else {                                       // gin slots r,z,n, b_hid of n
+            const float hn = y[2] + g4[3];                 // slot 3: b_hid of the n gate (k_g2_bias)
+            const float rg = fsigmoid(y[0] + g4[0]);
+            const float zg = fsigmoid(y[1] + g4[1]);
+            const float ng = ftanh(g4[2] + rg * hn);
+            hy = (1.0f - zg) * ng + zg * hst[u];
+            if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+          }
+          hy = round_to(hy, out);                        // the stored value is what the next step and the next layer see
+          st(out, bt * H + hid, hy);
+          hst[u] = hy;
+          hb[hoff[u]] = hy;
+        }
+      }
+    }
+    xcur = xnext;
+    lds_barrier();
+  }
+#pragma unroll
+  for (int u = 0; u < G2_UPT; ++u)
+    if (u < upt) {
+      const int hid = tid + u * G2_NT;
+      if (hid < H) {
+        if (hT) st(hT, b * H + hid, hst[u]);
+        if (LSTM && cT) st(cT, b * H + hid, cst[u]);
+      }
+    }
+}
+
+// ---- reverse time -----------------------------------------------------------------------------------------------------------
+// per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients) and
+// the split bf16 image of dy;  T2 (streamed head^T, split MFMA) -> fp32 dC1 image;  T1 (fp32 MFMA, k split over the
+// waves when there are few tiles) -> partial dh vectors summed by the next gate phase.
+template <int CELL, typename TS>
+__global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
+                                                  const TS* __restrict__ c0, const float* __restrict__ reserve,
+                                                  const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
+                                                  const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
+                                                  const float* __restrict__ bt1, float* __restrict__ dg_in,
+                                                  float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const G2Mat& m = P.hid;
+  __bf16* dyimg = reinterpret_cast<__bf16*>(smem);
+  float* dc1 = reinterpret_cast<float*>(smem + P.b_dy);
+  float* dhb = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1);
+  int* dyoff = reinterpret_cast<int*>(smem + P.b_dy + P.b_dc1 + P.b_dh);
+  int* t2off = dyoff + P.G * P.H;
+  const int plane = 16 * m.N2T * m.IhS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+  const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
+  constexpr bool LSTM = CELL == TTRNN_LSTM;
+  constexpr int NG = LSTM ? 4 : 3;
+
+  for (int e = tid; e < (P.b_dy + P.b_dc1 + P.b_dh) / 4; e += G2_NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  for (int o = tid; o < GH; o += G2_NT) {
+    const int ih = o / m.It, it = o - ih * m.It;
+    dyoff[o] = it * m.IhS + ih;
+  }
+  for (int e = tid; e < m.bM2T * 4; e += G2_NT) {
+    const int m2 = 16 * (e >> 2) + 4 * (e & 3);
+    const int jh = m2 / m.Rp, a = m2 - jh * m.Rp;
+    t2off[e] = jh < m.Jh ? jh * m.K1S + a : -1;
+  }
+  float dhd[G2_UPT], dcs[G2_UPT];
+#pragma unroll
+  for (int u = 0; u < G2_UPT; ++u) {
+    dhd[u] = 0.f; dcs[u] = 0.f;
+    if (u < upt) {
+      const int hid = tid + u * G2_NT;
+      if (hid < H) {
+        dhd[u] = d_hT ? ld(d_hT, b * H + hid) : 0.f;      // carried dh that does not come through the chain
+        dcs[u] = (LSTM && d_cT) ? ld(d_cT, b * H + hid) : 0.f;
+      }
+    }
+  }
+  const int nu_w = wave < m.bU ? (m.bU - wave + G2_NW - 1) / G2_NW : 0;
+  const int total = nu_w * m.bKBP;
+  const xbf8* sp = bs2 + (size_t)wave * m.bUW * m.bKBP * 3 * 64 + lane;
+  xbf8 wbuf[G2_PF][3];
+#pragma unroll
+  for (int j = 0; j < G2_PF; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
+      if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+    }
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t bt = b * T + t;
+    // ---- gate gradients ------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < G2_UPT; ++u) {
+      if (u < upt) {
+        const int hid = tid + u * G2_NT;
+        if (hid < H) {
+          float dht = dhd[u];
+          for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
+          if (d_out) dht += ld(d_out, bt * H + hid);
+          float p[4] = {0.f, 0.f, 0.f, 0.f}, ph2 = 0.f;
+          if (LSTM) {
+            const float* rv = reserve + (bt * H + hid) * 8;
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(rv);
+            const float ig = gq[0], gg = gq[1], fg = gq[2], og = gq[3], cy = rv[4];
+            const float cprev = t > 0 ? reserve[((bt - 1) * H + hid) * 8 + 4] : (c0 ? ld(c0, b * H + hid) : 0.f);
+            const float tc = ftanh(cy);
+            const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
+            p[0] = dct * gg * ig * (1.0f - ig);
+            p[1] = dct * cprev * fg * (1.0f - fg);
+            p[2] = dct * ig * (1.0f - gg * gg);
+            p[3] = dht * tc * og * (1.0f - og);
+            dcs[u] = dct * fg;
+            dhd[u] = 0.f;
+          } else {
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
+            const float rg = gq[0], zg = gq[1], ng = gq[2], hn = gq[3];
+            const float hprev = t > 0 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
+            const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
+            p[1] = dht * (hprev - ng) * zg * (1.0f - zg);
+            p[0] = dn_pre * hn * rg * (1.0f - rg);
+            p[2] = dn_pre;                                  // w.r.t. the input part of n
+            ph2 = dn_pre * rg;                              // w.r.t. the hidden part of n (inside the r * (...) product)
+            dhd[u] = dht * zg;
+          }
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            dg_in[bt * GH + g * H + hid] = p[g];
+            const float ph = (!LSTM && g == 2) ? ph2 : p[g];
+            if (!LSTM) dg_hid[bt * GH + g * H + hid] = ph;
+            __bf16 s0, s1, s2;
+            split3(ph, s0, s1, s2);
+            const int off = dyoff[g * H + hid];
+            dyimg[off] = s0; dyimg[plane + off] = s1; dyimg[2 * plane + off] = s2;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- T2: dC1 = head^T dy (split bf16 MFMA, streamed) ---------------------------------------------------------------------------
+    {
+      int seq = 0;
+      for (int ui = 0; ui < nu_w; ++ui) {
+        const int tile = wave + ui * G2_NW;
+        const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
+        const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q;
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        for (int kbl = 0; kbl < m.bKBP; kbl += G2_PF) {
+#pragma unroll
+          for (int j = 0; j < G2_PF; ++j) {
+            const int kb = kbl + j;
+            if (kb < m.bNKB) {
+              xbf8 bf[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
+#pragma unroll
+              for (int s = 0; s < 5; ++s)
+                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
+              acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][0], bf[0], acc_hi, 0, 0, 0);
+            }
+            int nxt = seq + G2_PF;
+            nxt -= nxt >= total ? total : 0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+            ++seq;
+          }
+        }
+        const int off = t2off[mt * 4 + q];
+        const int it = 16 * nt + c;
+        if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + it * m.Rp) = acc_hi + acc_lo;
+      }
+    }
+    lds_barrier();
+    // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
+    for (int u1 = wave; u1 < m.bU1; u1 += G2_NW) {
+      const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
+      const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
+      const int k0 = part * m.bKS1P;
+      const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
+      const float* ap = bt1 + (size_t)mt * m.bKS1 * 64 + lane;
+      const float* bp = dc1 + (16 * nt + c) * m.K1S + q;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = k0; ks < k1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 64], bp[4 * ks], acc, 0, 0, 0);
+      const int jh = 16 * nt + c;
+      if (jh < m.Jh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int jt = 16 * mt + 4 * q + j;
+          if (jt < m.Jt) dhb[part * H + jh * m.Jt + jt] = acc[j];
+        }
+      }
+    }
+    lds_barrier();
+  }
+#pragma unroll
+  for (int u = 0; u < G2_UPT; ++u)
+    if (u < upt) {
+      const int hid = tid + u * G2_NT;
+      if (hid < H) {
+        float dht = dhd[u];
+        for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
+        if (d_h0) st(d_h0, b * H + hid, dht);
+        if (LSTM && d_c0) st(d_c0, b * H + hid, dcs[u]);
+      }
+    }
+}
+
+int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }
+
+template <class K>
+int raise_lds(K kern, bool* raised, size_t bytes) {
+  if (bytes > 64 * 1024 && !*raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_LIMIT) !=
+        hipSuccess)
+      return TTRNN_ERR_LAUNCH;
+    *raised = true;
+  }
+  return TTRNN_OK;
+}
+
+// merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
+int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
+         hipStream_t stream) {
+  char* p = (char*)ws;
+  float* Gh = (float*)p; p += g2_al((size_t)m.head_elems * 4);
+  float* Gt = (float*)p; p += g2_al((size_t)m.tail_elems * 4);
+  xbf8* hs = (xbf8*)p; p += g2_al((size_t)(rev ? m.bs2_bytes : m.fs2_bytes));
+  float* tf = (float*)p;
+  const long nm = (long)m.Ih * m.Jh + (long)m.It * m.Jt;
+  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, s, m, packed, Gh, Gt);
+  if (rev) {
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(G2_NW * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs);
+    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf);
+  } else {
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(G2_NW * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs);
+    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf);
+  }
+  *fs = hs;
+  *ft = tf;
+  return check();
+}
+
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------
+// K-in of the G2 route: input_size == 1 -> the unit row through the any-shape chain kernel (the recurrent kernel scales
+// it by x_t); otherwise ONE dense split-bf16 GEMM (ttrnn_fast_gemm.hip) whose matrix is the chain kernel applied to the
+// `in` identity rows — the input contraction padded to a multiple of 8, the gate-interleaved fp32 bias row added in the
+// GEMM's epilogue.
+static int in_pad(int in) { return (in + 7) & ~7; }
+
+bool g2_rnn_available(const RnnShape& rs, int dtype) {
+  if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
+  if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
+  G2Plan p;
+  g2_plan(&p, rs);
+  if (!p.ok) return false;
+  if (rs.in == 1) return true;
+  return gemm_split_ok(in_pad(rs.in), 4 * rs.H);
+}
+
+struct G2FwdWs {
+  size_t gin, bilv, rec, ident, wdense, planes, xpad, lin, total;
+};
+
+static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
+  G2FwdWs w{};
+  G2Plan p;
+  g2_plan(&p, rs);
+  const bool in1 = rs.in == 1;
+  const int inp = in_pad(rs.in);
+  const int64_t rows = in1 ? 1 : (int64_t)rs.B * rs.T;
+  w.gin = g2_al((size_t)rows * 4 * rs.H * sizeof(float));
+  w.bilv = g2_al((size_t)4 * rs.H * sizeof(float));
+  w.rec = g2_fwd_ws_bytes(p.hid);
+  if (!in1) {
+    w.ident = gemm_split_identity_bytes(rs.in);
+    w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
+    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H);
+    w.xpad = inp != rs.in ? g2_al((size_t)rs.B * rs.T * inp * 4) : 0;
+  }
+  w.lin = g2_al(plan_ttlinear_fwd(rs.in_s, in1 ? 1 : rs.in).ws_bytes);
+  w.total = w.gin + w.bilv + w.rec + w.ident + w.wdense + w.planes + w.xpad + w.lin;
+  return w;
+}
+
+size_t g2_rnn_fwd_workspace(const RnnShape& rs) { return g2_fwd_layout(rs).total; }
+
+size_t g2_rnn_bwd_workspace(const RnnShape& rs) {
+  G2Plan p;
+  g2_plan(&p, rs);
+  return g2_bwd_ws_bytes(p.hid);
+}
+
+template <typename TS>
+static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, const void* h0, const void* c0,
+                 const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid, void* out,
+                 void* hT, void* cT, float* reserve, void* workspace, hipStream_t stream) {
+  const G2FwdWs L = g2_fwd_layout(rs);
+  char* p = (char*)workspace;
+  float* gin = (float*)p; p += L.gin;
+  float* bilv = (float*)p; p += L.bilv;
+  void* rec = p; p += L.rec;
+  void* ident = p; p += L.ident;
+  float* wdense = (float*)p; p += L.wdense;
+  void* planes = p; p += L.planes;
+  TS* xpad = (TS*)p; p += L.xpad;
+  void* linws = p;
+  const bool in1 = rs.in == 1;
+  const int H = rs.H, ilv = rs.cell == TTRNN_LSTM ? 2 : 1;
+  hipLaunchKernelGGL(k_g2_bias<TS>, dim3((H + 255) / 256), dim3(256), 0, stream, rs.cell, H,
+                     rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr,
+                     rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr, bilv);
+  int st = check();
+  if (st != TTRNN_OK) return st;
+  if (in1) {
+    const void* unit = unit_rows_ptr(TTRNN_F32);
+    if (!unit) return TTRNN_ERR_LAUNCH;
+    if (hipMemsetAsync(gin, 0, (size_t)4 * H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    const LinPlan lp = plan_ttlinear_fwd(rs.in_s, 1);
+    st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, 1, packed_in, nullptr, unit, gin, linws, stream, H, ilv);
+  } else {
+    const int inp = in_pad(rs.in);
+    const int64_t rows = (int64_t)rs.B * rs.T;
+    if (hipMemsetAsync(wdense, 0, (size_t)inp * 4 * H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    st = launch_fill_identity(TTRNN_F32, rs.in, ident, stream);
+    const LinPlan lp = plan_ttlinear_fwd(rs.in_s, rs.in);
+    if (st == TTRNN_OK)
+      st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, rs.in, packed_in, nullptr, ident, wdense, linws, stream, H, ilv);
+    if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, inp, 4 * H, planes, stream);
+    const void* xg = x;
+    if (st == TTRNN_OK && inp != rs.in) {
+      const long n = (long)rows * inp;
+      hipLaunchKernelGGL(k_g2_pad_rows<TS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long)rows, rs.in, inp,
+                         (const TS*)x, xpad);
+      st = check();
+      xg = xpad;
+    }
+    if (st == TTRNN_OK) st = launch_gemm_split(dtype, rows, inp, 4 * H, xg, planes, nullptr, 0, gin, stream, bilv);
+  }
+  if (st != TTRNN_OK) return st;
+  const xbf8* fs2;
+  const float* ft1;
+  st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream);
+  if (st != TTRNN_OK) return st;
+  GinSrc src{gin, x, in1 ? 1 : 0};
+  static bool raised[2] = {false, false};
+  if (rs.cell == TTRNN_LSTM) {
+    auto kern = k_g2_fwd<TTRNN_LSTM, TS>;
+    if (raise_lds(kern, &raised[0], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2, ft1,
+                       (TS*)out, (TS*)hT, (TS*)cT, reserve);
+  } else {
+    auto kern = k_g2_fwd<TTRNN_GRU, TS>;
+    if (raise_lds(kern, &raised[1], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2, ft1,
+                       (TS*)out, (TS*)hT, (TS*)cT, reserve);
+  }
+  return check();
+}
+
+int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* h0, const void* c0, const float* packed_in,
+                      const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT,
+                      float* reserve, void* workspace, hipStream_t stream) {
+  G2Plan P;
+  g2_plan(&P, rs);
+  if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
+  return dtype == TTRNN_F32
+             ? fwd_t<float>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream)
+             : fwd_t<bf16_t>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream);
+}
+
+template <typename TS>
+static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                 const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                 void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+  const xbf8* bs2;
+  const float* bt1;
+  int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
+  if (st != TTRNN_OK) return st;
+  static bool raised[2] = {false, false};
+  if (rs.cell == TTRNN_LSTM) {
+    auto kern = k_g2_bwd<TTRNN_LSTM, TS>;
+    if (raise_lds(kern, &raised[0], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0, reserve,
+                       (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0, (TS*)d_c0);
+  } else {
+    auto kern = k_g2_bwd<TTRNN_GRU, TS>;
+    if (raise_lds(kern, &raised[1], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0, reserve,
+                       (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0, (TS*)d_c0);
+  }
+  return check();
+}
+
+int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                      const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+  G2Plan P;
+  g2_plan(&P, rs);
+  if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
+  return dtype == TTRNN_F32
+             ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream)
+             : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream);
+}
+
+}  // namespace ttrnn

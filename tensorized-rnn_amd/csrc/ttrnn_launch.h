@@ -134,7 +134,7 @@ size_t gemm_split_plane_bytes(int K, int M);
 int launch_fill_identity(int dtype, int K, void* id, hipStream_t stream);
 int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStream_t stream, bool transposed = false);
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
-                      int Hb, float* y, hipStream_t stream);
+                      int Hb, float* y, hipStream_t stream, const float* bias_ilv = nullptr);
 
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
@@ -161,6 +161,17 @@ bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
 size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s);
 int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
+
+// runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): any TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores
+bool g2_rnn_available(const RnnShape& rs, int dtype);
+size_t g2_rnn_fwd_workspace(const RnnShape& rs);
+size_t g2_rnn_bwd_workspace(const RnnShape& rs);
+int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* h0, const void* c0, const float* packed_in,
+                      const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT,
+                      float* reserve, void* workspace, hipStream_t stream);
+int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                      const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream);
 
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);

@@ -14,6 +14,7 @@ enum OptId {
   OPT_NO_IN1,            // TTRNN_NO_IN1=1          no input_size == 1 shortcut
   OPT_NO_F10,            // TTRNN_NO_F10=1          no fused-core kernels (stage-wise MFMA kernels instead)
   OPT_NO_G2,             // TTRNN_NO_G2=1           no runtime-shape two-stage MFMA kernels (any-shape VALU kernels instead)
+  OPT_FORCE_G2,          // TTRNN_FORCE_G2=1        runtime-shape kernels even where a shape-specialised kernel exists (A/B)
   OPT_DIAG,              // TTRNN_DIAG=1            diagnostic builds with s_memtime stamps
   OPT_BF16_FP32_MFMA,    // TTRNN_BF16_FP32_MFMA=1  bf16 storage on the fp32 MFMA kernels
   OPT_BIG_MERGE,         // TTRNN_BIG_MERGE=0|1|2   pairs of cores contracted per launch (big shape)
