@@ -16,8 +16,8 @@
 
 namespace ttrnn {
 
-constexpr int G2_NW = 4;            // waves per workgroup (one per SIMD; small workgroups so that several samples share a CU)
-constexpr int G2_NT = G2_NW * 64;
+constexpr int G2_NW_MAX = 8;        // waves per workgroup: 8 when every sample can own a CU (B <= #CUs: two waves per SIMD hide
+constexpr int G2_NT_MAX = G2_NW_MAX * 64;   // each other's LDS / MFMA latency on the per-step critical path), else 4 (several samples share a CU)
 constexpr int G2_PF = 8;            // head fragments in flight per wave (k-blocks of 32): ~770 matrix-pipe cycles of cover
 constexpr int G2_UPT = 4;           // hidden units per thread in the gate phase: H <= 1024
 constexpr int G2_MAX_R = 64;        // rank at the split point
@@ -25,6 +25,7 @@ constexpr int G2_LDS_LIMIT = 160 * 1024;
 
 struct G2Mat {
   int ok;
+  int nw;                           // waves per workgroup the plan (tile -> wave assignment, fragment streams) is made for
   int d, s;                         // cores, split point
   int It, Jt, Ih, Jh, R, Rp;        // Rp = R rounded up to 4 (four accumulator registers = four consecutive a)
   int in, out;
@@ -50,10 +51,10 @@ struct G2Mat {
 inline int g2_ceil(int a, int b) { return (a + b - 1) / b; }
 
 // how the k range of `tiles` tiles with `nkb` blocks each is spread over the waves
-inline void g2_split(int tiles, int nkb, int* ksplit, int* kper, int* kbp, int* units, int* uw) {
+inline void g2_split(int nw, int tiles, int nkb, int* ksplit, int* kper, int* kbp, int* units, int* uw) {
   int ks = 1;
-  if (tiles < G2_NW) {
-    ks = G2_NW / tiles;
+  if (tiles < nw) {
+    ks = nw / tiles;
     if (ks > nkb) ks = nkb;
     if (ks < 1) ks = 1;
   }
@@ -63,11 +64,12 @@ inline void g2_split(int tiles, int nkb, int* ksplit, int* kper, int* kbp, int* 
   *kper = per;
   *kbp = g2_ceil(per, G2_PF) * G2_PF;
   *units = tiles * ks;
-  *uw = g2_ceil(*units, G2_NW);
+  *uw = g2_ceil(*units, nw);
 }
 
-inline void g2_plan_mat(G2Mat* m, const TtShape& s) {
+inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw) {
   *m = G2Mat{};
+  m->nw = nw;
   if (s.d < 2) return;
   long best = -1;
   int bs = 1;
@@ -94,20 +96,20 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s) {
   m->T1 = m->M1T * m->N1T;
   m->M2T = g2_ceil(m->Ih, 16); m->N2T = g2_ceil(m->It, 16); m->NKB = g2_ceil(m->Jh * m->Rp, 32);
   m->T2 = m->M2T * m->N2T;
-  g2_split(m->T2, m->NKB, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
+  g2_split(nw, m->T2, m->NKB, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
   m->JtS = 4 * m->KS1 + 1;
   m->K2S = 32 * m->NKB + 8;
   m->bM2T = g2_ceil(m->Jh * m->Rp, 16); m->bNKB = g2_ceil(m->Ih, 32);
   m->bT2 = m->bM2T * m->N2T;
   m->bKBP = g2_ceil(m->bNKB, G2_PF) * G2_PF;
   m->bU = m->bT2;
-  m->bUW = g2_ceil(m->bU, G2_NW);
+  m->bUW = g2_ceil(m->bU, nw);
   m->IhS = 32 * m->bNKB + 8;
   m->bM1T = g2_ceil(m->Jt, 16); m->bKS1 = (m->It * m->Rp) / 4;
   m->bT1 = m->bM1T * m->N1T;
   {
     int ks = 1;
-    if (m->bT1 < G2_NW) { ks = G2_NW / m->bT1; if (ks > m->bKS1) ks = m->bKS1; if (ks < 1) ks = 1; }
+    if (m->bT1 < nw) { ks = nw / m->bT1; if (ks > m->bKS1) ks = m->bKS1; if (ks < 1) ks = 1; }
     m->bKS1P = g2_ceil(m->bKS1, ks);
     m->bK1SPLIT = g2_ceil(m->bKS1, m->bKS1P);
     m->bU1 = m->bT1 * m->bK1SPLIT;
@@ -115,9 +117,9 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s) {
   m->K1S = m->It * m->Rp + 4;
   m->head_elems = (long)m->Ih * m->Jh * m->R;
   m->tail_elems = (long)m->It * m->Jt * m->R;
-  m->fs2_bytes = (long)G2_NW * m->UW * m->KBP * 3 * 64 * 16;
+  m->fs2_bytes = (long)nw * m->UW * m->KBP * 3 * 64 * 16;
   m->ft1_bytes = (long)m->M1T * m->KS1 * 64 * 4;
-  m->bs2_bytes = (long)G2_NW * m->bUW * m->bKBP * 3 * 64 * 16;
+  m->bs2_bytes = (long)nw * m->bUW * m->bKBP * 3 * 64 * 16;
   m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
   m->ok = 1;
 }
@@ -128,30 +130,38 @@ struct G2Plan {
   G2Mat hid;
   int upt;                          // hidden units per thread
   // LDS carve-up (bytes) of the forward and the reverse-time kernel
-  int f_hb, f_img, f_ybuf, f_tab, f_lds;       // f_tab: stage-1 store offsets [T1][64] ints
-  int b_dy, b_dc1, b_dh, b_tab, b_lds;         // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
+  int f_hb, f_img, f_ybuf, f_tab, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][64] ints; f_t1: tail fragments (0: from L2)
+  int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
 };
 
 inline size_t g2_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-inline void g2_plan(G2Plan* p, const RnnShape& rs) {
+// wide: 8 waves per workgroup (the caller passes B <= #CUs)
+inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   *p = G2Plan{};
   p->cell = rs.cell; p->G = rs.G; p->H = rs.H; p->B = rs.B; p->T = rs.T;
-  g2_plan_mat(&p->hid, rs.hid_s);
+  const int nw = wide ? G2_NW_MAX : 4;
+  g2_plan_mat(&p->hid, rs.hid_s, nw);
   if (!p->hid.ok) return;
-  if (rs.H > G2_UPT * G2_NT) return;
-  p->upt = g2_ceil(rs.H, G2_NT);
+  // the gate phase runs on the first 256 threads (1, 2 or 4 hidden units per thread)
+  if (rs.H > G2_UPT * 256) return;
+  p->upt = g2_ceil(rs.H, 256);
+  if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
   const G2Mat& m = p->hid;
   p->f_hb = (int)g2_al((size_t)16 * m.N1T * m.JtS * 4);
   p->f_img = (int)g2_al((size_t)3 * 16 * m.N2T * m.K2S * 2);
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
   p->f_tab = (int)g2_al((size_t)m.T1 * 64 * 4);
   p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab;
+  p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
+  p->f_lds += p->f_t1;
   p->b_dy = (int)g2_al((size_t)3 * 16 * m.N2T * m.IhS * 2);
   p->b_dc1 = (int)g2_al(((size_t)16 * m.N1T * m.K1S) * 4);
   p->b_dh = (int)g2_al((size_t)m.bK1SPLIT * rs.H * 4);
   p->b_tab = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4) * 4);
   p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
+  p->b_t1 = (m.bt1_bytes <= 32 * 1024 && p->b_lds + (int)g2_al((size_t)m.bt1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.bt1_bytes) : 0;
+  p->b_lds += p->b_t1;
   if (p->f_lds > G2_LDS_LIMIT || p->b_lds > G2_LDS_LIMIT) return;
   p->ok = 1;
 }

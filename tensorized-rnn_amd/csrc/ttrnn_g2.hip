@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKB : m.KPER, NKB = REV ? m.bNKB : m.NKB;
   const int blk = blockIdx.x;                    // (w*UW + ui)*KBP + kbl
   const int kbl = blk % KBP, ui = (blk / KBP) % UW, w = blk / (KBP * UW);
-  const int u = w + ui * G2_NW;
+  const int u = w + ui * m.nw;
   xbf8 f0, f1, f2;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f; }
@@ -164,9 +164,21 @@ struct HeadStream {
   int seq;               // next block to CONSUME (0 .. total-1)
 };
 
+
+// one 16x16x32 block of the six-term split product on THREE accumulator chains (a: w2x0 w0x2 w1x1, b: w1x0 w0x1, hi: w0x0),
+// issued round-robin so that no MFMA waits for the one before it (a dependent 8-pass MFMA stalls ~2x its issue time)
+__device__ __forceinline__ void split_block(const xbf8 (&w)[3], const xbf8 (&x)[3], f32x4& acc_a, f32x4& acc_b, f32x4& acc_hi) {
+  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], acc_a, 0, 0, 0);
+  acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], acc_b, 0, 0, 0);
+  acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc_hi, 0, 0, 0);
+  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], acc_a, 0, 0, 0);
+  acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], acc_b, 0, 0, 0);
+  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc_a, 0, 0, 0);
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------------------
-template <int CELL, typename TS>
-__global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
+template <int CELL, typename TS, int UPT, bool DIAG>
+__global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xbf8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, TS* __restrict__ out, TS* __restrict__ hT,
                                                   TS* __restrict__ cT, float* __restrict__ reserve) {
@@ -176,39 +188,45 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
   __bf16* img = reinterpret_cast<__bf16*>(smem + P.f_hb);
   float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
+  float* lt1 = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // tail fragments (P.f_t1 > 0)
   const int plane = 16 * m.N2T * m.K2S;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
+  const int NW = m.nw, NT = NW * 64;
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
-  for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += G2_NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
-  for (int e = tid; e < m.T1 * 64; e += G2_NT) {
+  for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  for (int e = tid; e < m.T1 * 64; e += NT) {
     const int t1 = e >> 6, l = e & 63;
     const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
     const int m1 = 16 * mt1 + 4 * (l >> 4), jh = 16 * nt1 + (l & 15);
     const int it = m1 / m.Rp, a = m1 - it * m.Rp;
     s1off[e] = (it < m.It && jh < m.Jh) ? it * m.K2S + jh * m.Rp + a : -1;
   }
-  float hst[G2_UPT], cst[G2_UPT];
-  int hoff[G2_UPT];
-  f32x4 gi[G2_UPT], bb[G2_UPT];      // input_size == 1: gi holds the unit row's projection, bb the bias row
+  // the tail fragments are read by every wave every step: resident in LDS when they fit (else L1 / L2)
+  const bool t1_lds = P.f_t1 > 0;
+  if (t1_lds)
+    for (int e = tid; e < m.M1T * m.KS1 * 64; e += NT) lt1[e] = ft1[e];
+  float hst[UPT], cst[UPT];
+  int hoff[UPT];
+  f32x4 gi[UPT], bb[UPT];      // input_size == 1: gi holds the unit row's projection, bb the bias row
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gs.gin);
   const f32x4* bil4 = reinterpret_cast<const f32x4*>(bilv);
   const TS* xs = reinterpret_cast<const TS*>(gs.x);
   const bool in1 = gs.in1 != 0;
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < G2_UPT; ++u) {
+  for (int u = 0; u < UPT; ++u) {
     hst[u] = 0.f; cst[u] = 0.f; hoff[u] = 0;
     gi[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bb[u] = gi[u];
     if (u < upt) {
-      const int hid = tid + u * G2_NT;
-      if (hid < H) {
+      const int hid = tid + u * 256;
+      if (hid < H && tid < 256) {
         hoff[u] = (hid / m.Jt) * m.JtS + hid % m.Jt;
         hst[u] = h0 ? ld(h0, b * H + hid) : 0.f;
         cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
@@ -218,8 +236,9 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
     }
   }
   // head stream of this wave
-  const int nu_w = wave < m.U ? (m.U - wave + G2_NW - 1) / G2_NW : 0;
+  const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
   const int total = nu_w * m.KBP;
+  const bool resident = total <= G2_PF;          // the wave's whole share of the head core lives in its register slots
   const xbf8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 3 * 64 + lane;
   xbf8 wbuf[G2_PF][3];
 #pragma unroll
@@ -230,61 +249,89 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
       if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
     }
-  float xcur = (in1 && T > 0) ? ld(xs, b * T) : 0.f;
+  XChunk<TS> xq;                    // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) here: no wait for the set-up loads inside the time loop
   lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
 
   for (int t = 0; t < T; ++t) {
     const size_t bt = b * T + t;
     // gate inputs of this step: requested now, used after both stages
-    float xnext = 0.f;
-    if (in1) {
-      xnext = t + 1 < T ? ld(xs, bt + 1) : 0.f;
-    } else {
+    if (!in1) {
 #pragma unroll
-      for (int u = 0; u < G2_UPT; ++u)
-        if (u < upt) { const int hid = tid + u * G2_NT; gi[u] = gin4[bt * H + (hid < H ? hid : 0)]; }
+      for (int u = 0; u < UPT; ++u)
+        if (u < upt) { const int hid = tid + u * 256; gi[u] = gin4[bt * H + (hid < H ? hid : 0)]; }
     }
     // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
-    for (int t1 = wave; t1 < m.T1; t1 += G2_NW) {
-      const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
-      const float* ap = ft1 + (size_t)mt1 * m.KS1 * 64 + lane;
-      const float* bp = hb + (16 * nt1 + c) * m.JtS + q;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < m.KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 64], bp[4 * ks], acc, 0, 0, 0);
-      const int off = s1off[t1 * 64 + lane];
-      if (off >= 0) store_split4(img, plane, off, acc);
-    }
+    // (tail fragments: LDS-resident or from L1 / L2 — two explicit loops: ONE pointer that may be either makes every read a
+    // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
+    auto stage1 = [&](auto frag) {
+      for (int t1 = wave; t1 < m.T1; t1 += 2 * NW) {         // two tiles per iteration: independent MFMA / split chains
+        const int t1b = t1 + NW < m.T1 ? t1 + NW : t1;        // (the second one repeats the first when there is none)
+        const int mta = t1 / m.N1T, nta = t1 - mta * m.N1T;
+        const int mtb = t1b / m.N1T, ntb = t1b - mtb * m.N1T;
+        const float* bpa = hb + (16 * nta + c) * m.JtS + q;
+        const float* bpb = hb + (16 * ntb + c) * m.JtS + q;
+        const int offa = s1off[t1 * 64 + lane], offb = s1off[t1b * 64 + lane];
+        f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;
+        for (int ks = 0; ks < m.KS1; ++ks) {
+          acca = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mta * m.KS1 + ks) * 64 + lane), bpa[4 * ks], acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mtb * m.KS1 + ks) * 64 + lane), bpb[4 * ks], accb, 0, 0, 0);
+        }
+        if (offa >= 0) store_split4(img, plane, offa, acca);
+        if (offb >= 0 && t1b != t1) store_split4(img, plane, offb, accb);
+      }
+    };
+    if (t1_lds) stage1([&](int i) { return lt1[i]; });
+    else stage1([&](int i) { return ft1[i]; });
+    TT_STAMP(0)
     lds_barrier();
+    TT_STAMP(1)
     // ---- stage 2 (split bf16 MFMA, streamed head fragments) ----------------------------------------------------------------------
     {
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
-        const int u = wave + ui * G2_NW;
+        const int u = wave + ui * NW;
         const int tile = u / m.KSPLIT, part = u - tile * m.KSPLIT;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
         const int kb0 = part * m.KPER;
         const __bf16* brow = img + (16 * nt + c) * m.K2S + 8 * q;
-        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+        // operand fragments of the NEXT block are requested before the current block's MFMAs are issued
+        xbf8 bf[2][3];
+        {
+          const int kbc = kb0 < m.NKB ? kb0 : m.NKB - 1;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbc);
+        }
         for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
             const int kb = kb0 + kbl + j;
-            if (kbl + j < m.KPER && kb < m.NKB) {
-              xbf8 bf[3];
+            {
+              const int kbn = kb + 1 < m.NKB ? kb + 1 : m.NKB - 1;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
-#pragma unroll
-              for (int s = 0; s < 5; ++s)
-                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
-              acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][0], bf[0], acc_hi, 0, 0, 0);
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbn);
             }
-            int nxt = seq + G2_PF;                       // refill the slot with the block G2_PF ahead (wraps into step t+1)
-            nxt -= nxt >= total ? total : 0;             // total >= G2_PF
+            if (kbl + j < m.KPER && kb < m.NKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            // refill the slot with the block G2_PF ahead (wraps into step t+1) — unless the wave's whole share of the
+            // head core already sits in its slots (resident), or that block is zero padding
+            int nl = kbl + j + G2_PF;
+            nl -= nl >= m.KBP ? m.KBP : 0;
+            if (!resident && nl < m.KPER) {
+              int nxt = seq + G2_PF;
+              nxt -= nxt >= total ? total : 0;           // total >= G2_PF
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+            }
             ++seq;
           }
         }
+        const f32x4 acc_lo = acc_a + acc_b;
         const f32x4 acc = acc_hi + acc_lo;
         const int itc = 16 * nt + c;
         if (itc < m.It) {
@@ -296,19 +343,21 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
         }
       }
     }
+    TT_STAMP(2)
     lds_barrier();
+    TT_STAMP(3)
     // ---- gates + state (lstm.py:26-32 / gru.py:38-44) --------------------------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < G2_UPT; ++u) {
+    for (int u = 0; u < UPT; ++u) {
       if (u < upt) {
-        const int hid = tid + u * G2_NT;
-        if (hid < H) {
+        const int hid = tid + u * 256;
+        if (hid < H && tid < 256) {
           float y[4] = {0.f, 0.f, 0.f, 0.f};
           for (int pt = 0; pt < m.KSPLIT; ++pt)
 #pragma unroll
             for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ybuf[pt * GH + g * H + hid];
           f32x4 g4 = gi[u];
-          if (in1) g4 = bb[u] + xcur * gi[u];
+          if (in1) g4 = bb[u] + xq.at(t) * gi[u];
           float hy;
           if (LSTM) {                                    // gin slots i,g,f,o
             const float ig = fsigmoid(y[0] + g4[0]);
@@ -338,14 +387,23 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
         }
       }
     }
-    xcur = xnext;
+    if (in1) xq.advance(xs, b * T, T, t, lane);
+    TT_STAMP(4)
     lds_barrier();
+    TT_STAMP(5)
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && reserve && b < 4) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * G2_NW_MAX + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = seg[i];
+    }
   }
 #pragma unroll
-  for (int u = 0; u < G2_UPT; ++u)
+  for (int u = 0; u < UPT; ++u)
     if (u < upt) {
-      const int hid = tid + u * G2_NT;
-      if (hid < H) {
+      const int hid = tid + u * 256;
+      if (hid < H && tid < 256) {
         if (hT) st(hT, b * H + hid, hst[u]);
         if (LSTM && cT) st(cT, b * H + hid, cst[u]);
       }
@@ -356,8 +414,8 @@ __global__ void __launch_bounds__(G2_NT) k_g2_fwd(G2Plan P, GinSrc gs, const flo
 // per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients) and
 // the split bf16 image of dy;  T2 (streamed head^T, split MFMA) -> fp32 dC1 image;  T1 (fp32 MFMA, k split over the
 // waves when there are few tiles) -> partial dh vectors summed by the next gate phase.
-template <int CELL, typename TS>
-__global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
+template <int CELL, typename TS, int UPT>
+__global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const float* __restrict__ reserve,
                                                   const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                   const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
@@ -370,40 +428,46 @@ __global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict
   float* dhb = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1);
   int* dyoff = reinterpret_cast<int*>(smem + P.b_dy + P.b_dc1 + P.b_dh);
   int* t2off = dyoff + P.G * P.H;
+  float* lt1 = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1 + P.b_dh + P.b_tab);       // tail^T fragments (P.b_t1 > 0)
   const int plane = 16 * m.N2T * m.IhS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
+  const int NW = m.nw, NT = NW * 64;
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
   constexpr int NG = LSTM ? 4 : 3;
 
-  for (int e = tid; e < (P.b_dy + P.b_dc1 + P.b_dh) / 4; e += G2_NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
-  for (int o = tid; o < GH; o += G2_NT) {
+  for (int e = tid; e < (P.b_dy + P.b_dc1 + P.b_dh) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  for (int o = tid; o < GH; o += NT) {
     const int ih = o / m.It, it = o - ih * m.It;
     dyoff[o] = it * m.IhS + ih;
   }
-  for (int e = tid; e < m.bM2T * 4; e += G2_NT) {
+  for (int e = tid; e < m.bM2T * 4; e += NT) {
     const int m2 = 16 * (e >> 2) + 4 * (e & 3);
     const int jh = m2 / m.Rp, a = m2 - jh * m.Rp;
     t2off[e] = jh < m.Jh ? jh * m.K1S + a : -1;
   }
-  float dhd[G2_UPT], dcs[G2_UPT];
+  const bool t1_lds = P.b_t1 > 0;
+  if (t1_lds)
+    for (int e = tid; e < m.bM1T * m.bKS1 * 64; e += NT) lt1[e] = bt1[e];
+  float dhd[UPT], dcs[UPT];
 #pragma unroll
-  for (int u = 0; u < G2_UPT; ++u) {
+  for (int u = 0; u < UPT; ++u) {
     dhd[u] = 0.f; dcs[u] = 0.f;
     if (u < upt) {
-      const int hid = tid + u * G2_NT;
-      if (hid < H) {
+      const int hid = tid + u * 256;
+      if (hid < H && tid < 256) {
         dhd[u] = d_hT ? ld(d_hT, b * H + hid) : 0.f;      // carried dh that does not come through the chain
         dcs[u] = (LSTM && d_cT) ? ld(d_cT, b * H + hid) : 0.f;
       }
     }
   }
-  const int nu_w = wave < m.bU ? (m.bU - wave + G2_NW - 1) / G2_NW : 0;
+  const int nu_w = wave < m.bU ? (m.bU - wave + NW - 1) / NW : 0;
   const int total = nu_w * m.bKBP;
+  const bool resident = total <= G2_PF;
   const xbf8* sp = bs2 + (size_t)wave * m.bUW * m.bKBP * 3 * 64 + lane;
   xbf8 wbuf[G2_PF][3];
 #pragma unroll
@@ -420,10 +484,10 @@ __global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict
     const size_t bt = b * T + t;
     // ---- gate gradients ------------------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < G2_UPT; ++u) {
+    for (int u = 0; u < UPT; ++u) {
       if (u < upt) {
-        const int hid = tid + u * G2_NT;
-        if (hid < H) {
+        const int hid = tid + u * 256;
+        if (hid < H && tid < 256) {
           float dht = dhd[u];
           for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
           if (d_out) dht += ld(d_out, bt * H + hid);
@@ -470,30 +534,35 @@ __global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict
     {
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
-        const int tile = wave + ui * G2_NW;
+        const int tile = wave + ui * NW;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
         const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q;
-        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+        xbf8 bf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane);
         for (int kbl = 0; kbl < m.bKBP; kbl += G2_PF) {
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
             const int kb = kbl + j;
-            if (kb < m.bNKB) {
-              xbf8 bf[3];
+            {
+              const int kbn = kb + 1 < m.bNKB ? kb + 1 : m.bNKB - 1;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
-#pragma unroll
-              for (int s = 0; s < 5; ++s)
-                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc_lo, 0, 0, 0);
-              acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[j][0], bf[0], acc_hi, 0, 0, 0);
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbn);
             }
-            int nxt = seq + G2_PF;
-            nxt -= nxt >= total ? total : 0;
+            if (kb < m.bNKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            int nl = kbl + j + G2_PF;
+            nl -= nl >= m.bKBP ? m.bKBP : 0;
+            if (!resident && nl < m.bNKB) {
+              int nxt = seq + G2_PF;
+              nxt -= nxt >= total ? total : 0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+            }
             ++seq;
           }
         }
+        const f32x4 acc_lo = acc_a + acc_b;
         const int off = t2off[mt * 4 + q];
         const int it = 16 * nt + c;
         if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + it * m.Rp) = acc_hi + acc_lo;
@@ -501,31 +570,40 @@ __global__ void __launch_bounds__(G2_NT) k_g2_bwd(G2Plan P, const TS* __restrict
     }
     lds_barrier();
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
-    for (int u1 = wave; u1 < m.bU1; u1 += G2_NW) {
-      const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
-      const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
-      const int k0 = part * m.bKS1P;
-      const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
-      const float* ap = bt1 + (size_t)mt * m.bKS1 * 64 + lane;
-      const float* bp = dc1 + (16 * nt + c) * m.K1S + q;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ks = k0; ks < k1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 64], bp[4 * ks], acc, 0, 0, 0);
-      const int jh = 16 * nt + c;
-      if (jh < m.Jh) {
+    auto stageT1 = [&](auto frag) {
+      for (int u1 = wave; u1 < m.bU1; u1 += NW) {
+        const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
+        const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
+        const int k0 = part * m.bKS1P;
+        const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
+        const float* bp = dc1 + (16 * nt + c) * m.K1S + q;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        int ks = k0;
+        for (; ks + 1 < k1; ks += 2) {                        // two accumulator chains
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks) * 64 + lane), bp[4 * ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks + 1) * 64 + lane), bp[4 * ks + 4], acc1, 0, 0, 0);
+        }
+        if (ks < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks) * 64 + lane), bp[4 * ks], acc0, 0, 0, 0);
+        const f32x4 acc = acc0 + acc1;
+        const int jh = 16 * nt + c;
+        if (jh < m.Jh) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int jt = 16 * mt + 4 * q + j;
-          if (jt < m.Jt) dhb[part * H + jh * m.Jt + jt] = acc[j];
+          for (int j = 0; j < 4; ++j) {
+            const int jt = 16 * mt + 4 * q + j;
+            if (jt < m.Jt) dhb[part * H + jh * m.Jt + jt] = acc[j];
+          }
         }
       }
-    }
+    };
+    if (t1_lds) stageT1([&](int i) { return lt1[i]; });
+    else stageT1([&](int i) { return bt1[i]; });
     lds_barrier();
   }
 #pragma unroll
-  for (int u = 0; u < G2_UPT; ++u)
+  for (int u = 0; u < UPT; ++u)
     if (u < upt) {
-      const int hid = tid + u * G2_NT;
-      if (hid < H) {
+      const int hid = tid + u * 256;
+      if (hid < H && tid < 256) {
         float dht = dhd[u];
         for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
         if (d_h0) st(d_h0, b * H + hid, dht);
@@ -558,10 +636,10 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
   const long nm = (long)m.Ih * m.Jh + (long)m.It * m.Jt;
   hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, s, m, packed, Gh, Gt);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(G2_NW * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs);
     hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf);
   } else {
-    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(G2_NW * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs);
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs);
     hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf);
   }
   *fs = hs;
@@ -582,7 +660,7 @@ bool g2_rnn_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
   G2Plan p;
-  g2_plan(&p, rs);
+  g2_plan(&p, rs, rs.B <= device_cu_count());
   if (!p.ok) return false;
   if (rs.in == 1) return true;
   return gemm_split_ok(in_pad(rs.in), 4 * rs.H);
@@ -595,7 +673,7 @@ struct G2FwdWs {
 static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   G2FwdWs w{};
   G2Plan p;
-  g2_plan(&p, rs);
+  g2_plan(&p, rs, rs.B <= device_cu_count());
   const bool in1 = rs.in == 1;
   const int inp = in_pad(rs.in);
   const int64_t rows = in1 ? 1 : (int64_t)rs.B * rs.T;
@@ -617,7 +695,7 @@ size_t g2_rnn_fwd_workspace(const RnnShape& rs) { return g2_fwd_layout(rs).total
 
 size_t g2_rnn_bwd_workspace(const RnnShape& rs) {
   G2Plan p;
-  g2_plan(&p, rs);
+  g2_plan(&p, rs, rs.B <= device_cu_count());
   return g2_bwd_ws_bytes(p.hid);
 }
 
@@ -673,18 +751,24 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
-  static bool raised[2] = {false, false};
+  static bool raised[2][3] = {{false, false, false}, {false, false, false}};
+#define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \
+  do {                                                                                                                   \
+    auto kern = (opt(OPT_DIAG) && reserve && UPTV == 1) ? k_g2_fwd<CELLV, TS, UPTV, true> : k_g2_fwd<CELLV, TS, UPTV, false>; \
+    if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2,   \
+                       ft1, (TS*)out, (TS*)hT, (TS*)cT, reserve);                                                         \
+  } while (0)
   if (rs.cell == TTRNN_LSTM) {
-    auto kern = k_g2_fwd<TTRNN_LSTM, TS>;
-    if (raise_lds(kern, &raised[0], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2, ft1,
-                       (TS*)out, (TS*)hT, (TS*)cT, reserve);
+    if (P.upt == 1) TT_G2_FWD(TTRNN_LSTM, 1, 0);
+    else if (P.upt == 2) TT_G2_FWD(TTRNN_LSTM, 2, 1);
+    else TT_G2_FWD(TTRNN_LSTM, 4, 2);
   } else {
-    auto kern = k_g2_fwd<TTRNN_GRU, TS>;
-    if (raise_lds(kern, &raised[1], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2, ft1,
-                       (TS*)out, (TS*)hT, (TS*)cT, reserve);
+    if (P.upt == 1) TT_G2_FWD(TTRNN_GRU, 1, 0);
+    else if (P.upt == 2) TT_G2_FWD(TTRNN_GRU, 2, 1);
+    else TT_G2_FWD(TTRNN_GRU, 4, 2);
   }
+#undef TT_G2_FWD
   return check();
 }
 
@@ -692,7 +776,7 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
                       const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT,
                       float* reserve, void* workspace, hipStream_t stream) {
   G2Plan P;
-  g2_plan(&P, rs);
+  g2_plan(&P, rs, rs.B <= device_cu_count());
   if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
              ? fwd_t<float>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream)
@@ -707,18 +791,25 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
-  static bool raised[2] = {false, false};
+  static bool raised[2][3] = {{false, false, false}, {false, false, false}};
+#define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
+  do {                                                                                                                   \
+    auto kern = k_g2_bwd<CELLV, TS, UPTV>;                                                                               \
+    if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,   \
+                       reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
+                       (TS*)d_c0);                                                                                        \
+  } while (0)
   if (rs.cell == TTRNN_LSTM) {
-    auto kern = k_g2_bwd<TTRNN_LSTM, TS>;
-    if (raise_lds(kern, &raised[0], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0, reserve,
-                       (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0, (TS*)d_c0);
+    if (P.upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
+    else if (P.upt == 2) TT_G2_BWD(TTRNN_LSTM, 2, 1);
+    else TT_G2_BWD(TTRNN_LSTM, 4, 2);
   } else {
-    auto kern = k_g2_bwd<TTRNN_GRU, TS>;
-    if (raise_lds(kern, &raised[1], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(G2_NT), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0, reserve,
-                       (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0, (TS*)d_c0);
+    if (P.upt == 1) TT_G2_BWD(TTRNN_GRU, 1, 0);
+    else if (P.upt == 2) TT_G2_BWD(TTRNN_GRU, 2, 1);
+    else TT_G2_BWD(TTRNN_GRU, 4, 2);
   }
+#undef TT_G2_BWD
   return check();
 }
 
@@ -726,7 +817,7 @@ int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
                       float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
   G2Plan P;
-  g2_plan(&P, rs);
+  g2_plan(&P, rs, rs.B <= device_cu_count());
   if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
              ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream)
