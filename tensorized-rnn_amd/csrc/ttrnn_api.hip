@@ -155,6 +155,35 @@ static size_t dense_bwd_bytes(const TtShape& s) {
          gemm_split_plane_bytes(s.out_size, s.in_size) + dense_wgrad_scratch_bytes(s.in_size, s.out_size);
 }
 
+// The same dense-gradient backward for shapes WITHOUT a specialised kernel (the callers' side of ttrnn_g2.hip): dW = x^T dy
+// as one dense GEMM, pulled back to the cores by the any-shape backward kernel on the `in` identity rows (the adjoint of
+// "cores -> dense matrix" is linear in dW); dx = dy W^T as a split-bf16 GEMM with W = the any-shape chain on the identity
+// rows.  Workspace = [any-shape backward (in rows) | identity | dW | W | planes of W^T | row-range partials | any-shape forward]
+struct GenDense {
+  bool ok, dx_ok;
+  size_t lin_bwd, ident, dwd, wd, planes, scratch, lin_fwd, total;
+};
+static GenDense gen_dense(const TtShape& s) {
+  GenDense g{};
+  g.ok = s.in_size >= 4 && dense_wgrad_ok(s.in_size, s.out_size);
+  if (!g.ok) return g;
+  g.dx_ok = gemm_split_ok(s.out_size, s.in_size);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  g.lin_bwd = al(plan_ttlinear_bwd(s, s.in_size).ws_bytes);
+  g.ident = gemm_split_identity_bytes(s.in_size);
+  g.dwd = gemm_split_dense_bytes(s.in_size, s.out_size);
+  g.wd = g.dx_ok ? gemm_split_dense_bytes(s.in_size, s.out_size) : 0;
+  g.planes = g.dx_ok ? gemm_split_plane_bytes(s.out_size, s.in_size) : 0;
+  g.scratch = dense_wgrad_scratch_bytes(s.in_size, s.out_size);
+  g.lin_fwd = g.dx_ok ? al(plan_ttlinear_fwd(s, s.in_size).ws_bytes) : 0;
+  g.total = g.lin_bwd + g.ident + g.dwd + g.wd + g.planes + g.scratch + g.lin_fwd;
+  return g;
+}
+// input_size == 1 without a specialised kernel: dv + the any-shape backward's own workspace for ONE row
+static size_t gen_in1_bytes(const TtShape& s) {
+  return in1_bwd_bytes(s) + ((plan_ttlinear_bwd(s, 1).ws_bytes + 255) & ~(size_t)255);
+}
+
 size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   TtShape s;
   if (tt_shape_init(&s, w) != TTRNN_OK || n_rows < 0) return 0;
@@ -168,6 +197,9 @@ size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   if (dnb > ws) ws = dnb;
   const size_t bigw = big_ttlinear_bwd_workspace_bytes(s);        // merged-core backward of the big shape
   if (bigw > ws) ws = bigw;
+  const GenDense gd = gen_dense(s);                               // dense-gradient backward of every other shape
+  if (gd.ok && gd.total > ws) ws = gd.total;
+  if (s.in_size == 1 && gen_in1_bytes(s) > ws) ws = gen_in1_bytes(s);
   return ws;
 }
 
@@ -253,6 +285,46 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
     // big shape: dx, weight and bias gradients through the merged two-core matrix
     if (!workspace || workspace_bytes < big_ttlinear_bwd_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
     return launch_ttlinear_bwd_big(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream);
+  }
+  if (!force_generic() && !no_gemm() && s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= gen_in1_bytes(s) &&
+      !opt(OPT_NO_IN1)) {
+    // y_n = b + x_n * chain(1): one reduction over the rows, then the any-shape backward on the single unit row
+    hipStream_t sm = (hipStream_t)stream;
+    float* dv = (float*)workspace;
+    const void* unit = unit_rows_ptr(TTRNN_F32);
+    if (!unit) return TTRNN_ERR_LAUNCH;
+    if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), sm) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, sm);
+    if (st != TTRNN_OK) return st;
+    const LinPlan p1 = plan_ttlinear_bwd(s, 1);
+    return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
+                               (char*)workspace + in1_bwd_bytes(s), sm);
+  }
+  const GenDense gd = gen_dense(s);
+  if (!force_generic() && !no_gemm() && gd.ok && d_packed && dy_dtype == TTRNN_F32 && n_rows >= 4 * (int64_t)s.in_size &&
+      (!dx || (gd.dx_ok && dtype == TTRNN_F32)) && workspace && workspace_bytes >= gd.total) {
+    hipStream_t sm = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    void* lin_bwd = p; p += gd.lin_bwd;
+    void* ident = p; p += gd.ident;
+    float* dWd = (float*)p; p += gd.dwd;
+    float* Wd = (float*)p; p += gd.wd;
+    void* planes = p; p += gd.planes;
+    float* scratch = (float*)p; p += gd.scratch;
+    void* lin_fwd = p;
+    st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
+    if (st == TTRNN_OK)
+      st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, true, scratch);
+    if (st == TTRNN_OK) {
+      const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
+      st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
+    }
+    if (st != TTRNN_OK || !dx) return st;
+    const LinPlan pf = plan_ttlinear_fwd(s, s.in_size);
+    st = launch_ttlinear_fwd(s, pf, TTRNN_F32, s.in_size, packed, nullptr, ident, Wd, lin_fwd, sm);            // W[j][o]
+    if (st == TTRNN_OK) st = launch_gemm_split_prep(Wd, s.out_size, s.in_size, planes, sm, true);
+    if (st == TTRNN_OK) st = launch_gemm_split(TTRNN_F32, n_rows, s.out_size, s.in_size, dy, planes, nullptr, 0, (float*)dx, sm);
+    return st;
   }
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

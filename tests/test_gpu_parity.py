@@ -522,8 +522,11 @@ def test_forward_200_launches_bitwise_per_kernel(case, route):
     ("ttlstm", 40, 256, 3, 3, 16, 300, 12, torch.float32, {}),                   # two samples per workgroup (B > #CUs)
     ("ttlstm", 1, 128, 1, 2, 4, 6, 50, torch.float32, {}),                       # cfg1 kernels
     ("ttlstm", 1024, 1024, 1, 4, 32, 3, 5, torch.float32, {}),                   # cfg5 kernels (pair)
-    ("ttlstm", 28, 96, 2, 2, 3, 5, 9, torch.float32, {}),                        # shape without a specialised kernel
-    ("ttgru", 28, 96, 2, 3, 5, 5, 9, torch.float32, {}),
+    ("ttlstm", 28, 96, 2, 2, 3, 5, 9, torch.float32, {}),                        # shapes without a specialised kernel:
+    ("ttgru", 28, 96, 2, 3, 5, 5, 9, torch.float32, {}),                         # runtime-shape MFMA kernels (ttrnn_g2.hip)
+    ("ttlstm", 40, 512, 2, 3, 4, 32, 70, torch.float32, {}),                     # ... with the dense-gradient backward
+    ("ttgru", 1, 384, 1, 3, 5, 40, 40, torch.float32, {}),
+    ("ttlstm", 28, 96, 2, 2, 3, 5, 9, torch.float32, {"TTRNN_NO_G2": "1"}),      # any-shape VALU kernels
 ])
 def test_poisoned_allocations_do_not_change_results(kind, inp, H, L, d, r, B, T, dtype, route):
     """Every buffer the host side allocates without initialising (outputs, workspaces, packed cores, reserves, gradient
@@ -566,6 +569,101 @@ def test_poisoned_allocations_do_not_change_results(kind, inp, H, L, d, r, B, T,
         F.POISON_ALLOCATIONS = False
         for k in route:
             OPT.pop(k)
+
+
+# ---- (3b) runtime-shape two-stage MFMA kernels (csrc/ttrnn_g2.hip) ------------------------------------------------------------
+G2_GRID = [
+    # kind, in, H, L, d, r, B, T, new_core — the (hidden_size, ncores, ttrank, extra core) combinations the reference's
+    # experiment flags produce (pmnist_test.py:47-56, params_model.py), none of which has a shape-specialised kernel ...
+    ("ttlstm", 28, 128, 1, 2, 3, 4, 11, None),
+    ("ttgru", 28, 64, 2, 2, 3, 9, 11, None),
+    ("ttlstm", 40, 512, 1, 3, 4, 3, 8, None),
+    ("ttlstm", 40, 768, 1, 4, 6, 3, 6, None),
+    ("ttgru", 40, 768, 1, 3, 2, 3, 6, None),
+    ("ttlstm", 1, 1024, 1, 3, 8, 3, 5, None),
+    ("ttlstm", 1, 256, 1, 2, 8, 4, 12, None),
+    ("ttlstm", 28, 64, 1, 2, 3, 5, 7, "first"),
+    ("ttgru", 28, 64, 1, 2, 3, 5, 7, "last"),
+    ("ttlstm", 40, 256, 1, 4, 5, 5, 7, None),
+    ("ttlstm", 1, 256, 1, 4, 2, 70, 33, None),
+    # ... with enough rows for the dense-gradient backward of every matrix (B*T >= 4*in)
+    ("ttlstm", 28, 128, 1, 2, 3, 32, 20, None),
+    ("ttgru", 28, 128, 2, 2, 3, 32, 20, None),
+    ("ttlstm", 40, 512, 2, 3, 4, 32, 70, None),
+    ("ttlstm", 1, 512, 1, 3, 8, 40, 60, None),
+    ("ttgru", 1, 384, 1, 3, 5, 40, 40, None),
+    ("ttlstm", 10, 96, 1, 2, 5, 30, 20, None),
+    # ... and the benchmark shapes with the specialised kernels switched off (force_g2)
+    ("ttlstm", 1, 256, 1, 3, 8, 5, 20, None),
+    ("ttgru", 1, 256, 1, 3, 8, 5, 20, None),
+    ("ttlstm", 40, 256, 2, 3, 16, 6, 9, None),
+    ("ttlstm", 1, 128, 1, 2, 4, 7, 30, None),
+    ("ttlstm", 40, 256, 3, 3, 16, 300, 8, None),        # B > #CUs: four waves per workgroup, several samples per CU
+]
+
+
+@pytest.mark.parametrize("kind,inp,H,L,d,r,B,T,new_core", G2_GRID)
+def test_runtime_shape_kernels_vs_oracle(kind, inp, H, L, d, r, B, T, new_core):
+    """Forward and every gradient of the runtime-shape MFMA route against the oracle (1e-5 abs / 1e-4 of the tensor max),
+    and the route check itself: with `no_g2` the same module takes the any-shape VALU kernels and must agree."""
+    import ttrnn_hip
+    torch.manual_seed(7)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r, new_core=new_core)
+    m = build_module(meta, dev())
+    lstm = kind == "ttlstm"
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, H)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, L, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    if lstm:
+        ro, (rh, rc) = O.lstm_forward(layers, xr)
+        ((ro * w).sum() + rc.sum() + rh.sum()).backward()
+    else:
+        ro, rh = O.gru_forward(layers, xr)
+        ((ro * w).sum() + rh.sum()).backward()
+    with ttrnn_hip.option("force_g2", 1):
+        xg = x.to(dev()).requires_grad_(True)
+        res = m(xg)
+        out = res[0]
+        if lstm:
+            ((out * w.to(dev())).sum() + res[1][1].sum() + res[1][0].sum()).backward()
+        else:
+            ((out * w.to(dev())).sum() + res[1].sum()).backward()
+    assert _maxabs(out.detach(), ro.detach()) <= 1e-5
+    assert _maxabs(res[1][0] if lstm else res[1], rh.detach()) <= 1e-5
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6)
+    for name, p in m.named_parameters():
+        ref = leaves[name].grad
+        assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    with ttrnn_hip.option("no_g2", 1), ttrnn_hip.option("force_generic", 1), torch.no_grad():
+        other = m(x.to(dev()))[0]
+    assert _maxabs(other, out.detach()) <= 5e-6
+    assert not torch.equal(other, out.detach()) or B * T * H < 64      # two different routes really ran
+
+
+def test_runtime_shape_kernels_bf16_storage_and_states():
+    """bf16 storage (fp32 state / accumulation) and non-zero initial states through the runtime-shape route."""
+    import ttrnn_hip
+    torch.manual_seed(12)
+    meta = dict(kind="ttlstm", input_size=40, hidden_size=512, num_layers=2, n_cores=3, tt_rank=4)
+    m = build_module(meta, dev())
+    x = torch.randn(6, 14, 40)
+    h0, c0 = torch.randn(6, 512) * 0.5, torch.randn(6, 512) * 0.5
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ro, rh, rc = _oracle_forward("ttlstm", sd, 2, x, (h0, c0))
+    with torch.no_grad():
+        out, (hT, cT) = m(x.to(dev()), (h0.to(dev()), c0.to(dev())))
+    assert _maxabs(out, ro) <= 1e-5 and _maxabs(cT, rc) <= 1e-5 and _maxabs(hT, rh) <= 1e-5
+    mb = build_module(dict(meta, kind="ttgru", num_layers=1), dev()).to(torch.bfloat16)
+    sdb = {k: v.detach().cpu().float() for k, v in mb.state_dict().items()}
+    xb = torch.rand(5, 30, 40).to(torch.bfloat16)
+    rob, rhb, _ = _oracle_forward("ttgru", sdb, 1, xb.float())
+    with torch.no_grad():
+        ob, hb = mb(xb.to(dev()))
+    assert ob.dtype == torch.bfloat16
+    assert _maxabs(ob.float(), rob) <= 2e-2 and _maxabs(hb.float(), rhb) <= 2e-2
 
 
 # ---- (4) fp32 math modes: three-way bf16 split (default) vs fp32 MFMA ("exact") -------------------------
