@@ -185,12 +185,67 @@ def cpu_baseline(w, budget_s=20.0):
                       "two".format(w["B"], sample_T[1], sample_T[phys], phys, w["T"])}
 
 
+def run_grid(args, device):
+    """H x ncores x ttrank x {LSTM, GRU} (in = 40, B = 64, T = 64): which kernel family each shape runs on and its forward
+    time against the any-shape VALU kernels (force_generic) — VERDICT r1 item 4: no experiment flag combination of the
+    reference (pmnist_test.py:47-56, params_model.py) should land on ttrnn_generic.hip."""
+    import ttrnn_hip
+    from tensorized_rnn.gru import TTGRU
+    from tensorized_rnn.tt_lstm import TTLSTM
+    from ttrnn_hip import functional as F
+    B, T, inp = 64, 64, 40
+    rows = []
+
+    def timed(m, x, n):
+        with torch.no_grad():
+            m(x)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                m(x)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e3
+
+    for cell, cls in (("lstm", TTLSTM), ("gru", TTGRU)):
+        for H in (64, 128, 256, 512, 768, 1024):
+            for d in (2, 3, 4):
+                for r in (2, 4, 8, 16):
+                    torch.manual_seed(1111)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        m = cls(inp, H, 1, device, n_cores=d, tt_rank=r).eval()
+                    x = torch.rand(B, T, inp, device=device)
+                    route = F.rnn_route(m._all_layers[0]._layer_spec(), B, T)
+                    ms = timed(m, x, max(3, args.steps // 4))
+                    with ttrnn_hip.option("force_generic", 1):
+                        valu_ms = timed(m, x, 3)
+                    rows.append({"cell": cell, "H": H, "ncores": d, "ttrank": r, "route": route, "ms": round(ms, 4),
+                                 "valu_ms": round(valu_ms, 4), "speedup": round(valu_ms / ms, 2)})
+    on_valu = [r for r in rows if r["route"] == "valu"]
+    geo = 1.0
+    for r in rows:
+        geo *= r["speedup"] ** (1.0 / len(rows))
+    line = {"metric": "forward time per shape, MFMA route vs any-shape VALU kernels (geometric-mean speed-up)", "value": geo,
+            "unit": "x", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "grid: TT-LSTM / TT-GRU in=40, H in {64..1024}, ncores in {2,3,4}, ttrank in {2,4,8,16}, "
+                                   "batch 64, seq_len 64, forward (no_grad)"},
+            "shapes": len(rows), "shapes_on_valu_route": len(on_valu),
+            "routes": {k: sum(1 for r in rows if r["route"] == k) for k in sorted({r["route"] for r in rows})},
+            "grid": rows}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["grid"],
+                    help="cfgN: one BASELINE.json configuration (cfg2 = the headline metric).  grid: sweep over the "
+                         "(hidden_size, ncores, ttrank, cell) combinations of the reference's experiment flags, route and "
+                         "time per shape against the any-shape VALU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward: the headline metric (no_grad forward). train: forward + BPTT + flat-bucket "
@@ -221,6 +276,10 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if backend == "nccl" else {}))
 
+    if args.workload == "grid":
+        if world != 1:
+            raise SystemExit("--workload grid is a single-GPU sweep")
+        return run_grid(args, device)
     w = WORKLOADS[args.workload]
     from ttrnn_hip import functional as F
     model = build_model(w, device)

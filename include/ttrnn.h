@@ -160,6 +160,15 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                       void* out, void* hT, void* cT, float* reserve,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Which family of kernels ttrnn_rnn_forward would run for this descriptor under the current options (pure host logic, no
+ * launch): the benchmark sweep and the tests report / assert it, so that "an MFMA kernel ran" is a checked statement. */
+#define TTRNN_ROUTE_VALU 0            /* any-shape VALU kernels (ttrnn_generic.hip)                                   */
+#define TTRNN_ROUTE_STAGEWISE_MFMA 1  /* shape-specialised stage-wise chain on the MFMA (ttrnn_fast*.hip)              */
+#define TTRNN_ROUTE_FUSED_CORE 2      /* shape-specialised fused-core kernels (ttrnn_fast_f10*.hip)                    */
+#define TTRNN_ROUTE_MERGED_BIG 3      /* merged two-core kernels of the H = 1024, d = 4, r = 32 shape (ttrnn_fast_big) */
+#define TTRNN_ROUTE_RUNTIME_MFMA 4    /* runtime-shape two-stage MFMA kernels, any d >= 2 (ttrnn_g2.hip)               */
+int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc);   /* TTRNN_ROUTE_* or a negative ttrnn_status */
+
 /* Reverse-time part of BPTT (reference: torch autograd through lstm.py:123-133 / gru.py:124-134).
  *   d_out[B][T][H], d_hT/d_cT[B][H] (any may be NULL = zeros)
  *   -> d_gates_in[B][T][G*H], d_gates_hid[B][T][G*H] (fp32: gradients w.r.t. the outputs of the

@@ -486,6 +486,24 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                                 reserve, workspace, (hipStream_t)stream);
 }
 
+int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
+  if (force_generic()) return TTRNN_ROUTE_VALU;
+  if (opt(OPT_FORCE_G2) && g2_rnn_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+  if (f.use) {
+    if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
+      return TTRNN_ROUTE_FUSED_CORE;
+    if (fp32_math() == TTRNN_MATH_EXACT && f.f10_bytes > 0 && f10x_rnn_fwd_available(rs, desc->dtype))
+      return TTRNN_ROUTE_FUSED_CORE;
+    return TTRNN_ROUTE_STAGEWISE_MFMA;
+  }
+  if (big_rnn_fwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
+  if (g2_rnn_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  return TTRNN_ROUTE_VALU;
+}
+
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,

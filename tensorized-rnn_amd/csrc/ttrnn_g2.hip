@@ -19,6 +19,7 @@
 // Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 with the hidden chain of
 // t3nsor/ops.py:78-93, and torch autograd through them.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
 #include "ttrnn_opts.h"
@@ -232,6 +233,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
         hb[hoff[u]] = hst[u];
         if (in1) { gi[u] = gin4[hid]; bb[u] = bil4[hid]; }
+        else if (T > 0) gi[u] = gin4[(b * T) * H + hid];
       }
     }
   }
@@ -261,11 +263,6 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   for (int t = 0; t < T; ++t) {
     const size_t bt = b * T + t;
     // gate inputs of this step: requested now, used after both stages
-    if (!in1) {
-#pragma unroll
-      for (int u = 0; u < UPT; ++u)
-        if (u < upt) { const int hid = tid + u * 256; gi[u] = gin4[bt * H + (hid < H ? hid : 0)]; }
-    }
     // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
     // (tail fragments: LDS-resident or from L1 / L2 — two explicit loops: ONE pointer that may be either makes every read a
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
@@ -291,8 +288,13 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
-    // ---- stage 2 (split bf16 MFMA, streamed head fragments) ----------------------------------------------------------------------
-    {
+    // ---- stage 2 (split bf16 MFMA) -------------------------------------------------------------------------------------------------
+    // Two instantiations of the same body: RESIDENT (the wave's whole share of the head core sits in its register slots:
+    // NO vector-memory instruction in the loop) and streaming (every slot is refilled unconditionally right after its use,
+    // padding blocks included).  A CONDITIONAL refill makes hipcc guard every block with s_waitcnt vmcnt(0), which also
+    // waits for the `out` store of the previous step: measured 3 300 instead of ~700 cycles for four blocks.
+    auto stage2 = [&](auto res_tag) {
+      constexpr bool RES = decltype(res_tag)::value;
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
         const int u = wave + ui * NW;
@@ -312,23 +314,18 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
             const int kb = kb0 + kbl + j;
-            {
-              const int kbn = kb + 1 < m.NKB ? kb + 1 : m.NKB - 1;
+            if (kbl + j + 1 < m.KPER && kb + 1 < m.NKB) {      // the next block is live (padding blocks are never read)
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbn);
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
             if (kbl + j < m.KPER && kb < m.NKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
-            // refill the slot with the block G2_PF ahead (wraps into step t+1) — unless the wave's whole share of the
-            // head core already sits in its slots (resident), or that block is zero padding
-            int nl = kbl + j + G2_PF;
-            nl -= nl >= m.KBP ? m.KBP : 0;
-            if (!resident && nl < m.KPER) {
-              int nxt = seq + G2_PF;
-              nxt -= nxt >= total ? total : 0;           // total >= G2_PF
+            if constexpr (!RES) {
+              int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
+              nxt -= nxt >= total ? total : 0;
 #pragma unroll
               for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              ++seq;
             }
-            ++seq;
           }
         }
         const f32x4 acc_lo = acc_a + acc_b;
@@ -342,7 +339,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
           }
         }
       }
-    }
+    };
+    if (resident) stage2(std::true_type{});
+    else stage2(std::false_type{});
     TT_STAMP(2)
     lds_barrier();
     TT_STAMP(3)
@@ -384,6 +383,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
           st(out, bt * H + hid, hy);
           hst[u] = hy;
           hb[hoff[u]] = hy;
+          // gate inputs of the NEXT step: requested after this step's last use of the registers and after its stores, used a
+          // whole step later (no wait ever lands on a request just issued; the address is clamped, the load unconditional)
+          if (!in1) gi[u] = gin4[(t + 1 < T ? bt + 1 : bt) * H + hid];
         }
       }
     }
@@ -530,8 +532,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       }
     }
     lds_barrier();
-    // ---- T2: dC1 = head^T dy (split bf16 MFMA, streamed) ---------------------------------------------------------------------------
-    {
+    // ---- T2: dC1 = head^T dy (split bf16 MFMA; resident / streaming instantiations as in the forward kernel) -----------------------------
+    auto stageT2 = [&](auto res_tag) {
+      constexpr bool RES = decltype(res_tag)::value;
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
         const int tile = wave + ui * NW;
@@ -545,21 +548,18 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
             const int kb = kbl + j;
-            {
-              const int kbn = kb + 1 < m.bNKB ? kb + 1 : m.bNKB - 1;
+            if (kb + 1 < m.bNKB) {
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbn);
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
             if (kb < m.bNKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
-            int nl = kbl + j + G2_PF;
-            nl -= nl >= m.bKBP ? m.bKBP : 0;
-            if (!resident && nl < m.bNKB) {
+            if constexpr (!RES) {
               int nxt = seq + G2_PF;
               nxt -= nxt >= total ? total : 0;
 #pragma unroll
               for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              ++seq;
             }
-            ++seq;
           }
         }
         const f32x4 acc_lo = acc_a + acc_b;
@@ -567,7 +567,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const int it = 16 * nt + c;
         if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + it * m.Rp) = acc_hi + acc_lo;
       }
-    }
+    };
+    if (resident) stageT2(std::true_type{});
+    else stageT2(std::false_type{});
     lds_barrier();
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
     auto stageT1 = [&](auto frag) {

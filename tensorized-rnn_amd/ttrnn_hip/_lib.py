@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ttrnn_rnn_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_forward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 13 + [ctypes.c_size_t, _P]),
 }
@@ -148,6 +149,9 @@ def option(name, value):
         yield
     finally:
         set_option(name, prev)
+
+
+ROUTES = {0: "valu", 1: "stagewise_mfma", 2: "fused_core", 3: "merged_big", 4: "runtime_mfma"}
 
 
 def make_ttm(in_modes, out_modes, ranks):

@@ -347,6 +347,15 @@ class _TTRnnLayerFn(torch.autograd.Function):
         return (dx, d_h0, d_c0, db_in, db_hid, None, None) + tuple(dcin) + tuple(dchid)
 
 
+def rnn_route(spec, batch, seq_len, dtype=torch.float32):
+    """Name of the kernel family ttrnn_rnn_forward runs for this layer at this size ("fused_core", "runtime_mfma", "valu", ...)."""
+    desc = spec.desc(batch, seq_len, _DT[dtype])
+    code = _lib.load().ttrnn_rnn_forward_route(ctypes.byref(desc))
+    if code < 0:
+        check(code, "ttrnn_rnn_forward_route")
+    return _lib.ROUTES[code]
+
+
 def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid):
     """One recurrent layer over the whole sequence on the device.
     Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU."""

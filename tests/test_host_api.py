@@ -170,7 +170,14 @@ def test_descriptor_validation_without_gpu():
                                                            256 * 256 * 4 + 256 * 1024 * 4 + 3 * 256 * 1024 * 2)
     tiny = RnnLayerSpec("gru", 28, 64, TTSpec([4, 7], [12, 16], [1, 3, 1]), TTSpec([8, 8], [12, 16], [1, 3, 1]),
                         True, True).desc(3, 6, 0)
-    assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) == 0        # generic kernel, everything in LDS
+    # no shape-specialised kernel: the runtime-shape MFMA route (ttrnn_g2.hip), whose workspace holds the hoisted input
+    # projection, the merged cores and their fragment streams; the any-shape VALU kernels keep everything in LDS
+    assert lib.ttrnn_rnn_forward_route(ctypes.byref(tiny)) == 4 and lib.ttrnn_rnn_forward_route(ctypes.byref(d)) == 2
+    assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) >= 3 * 6 * 64 * 4 * 4
+    import ttrnn_hip
+    with ttrnn_hip.option("no_g2", 1):
+        assert lib.ttrnn_rnn_forward_route(ctypes.byref(tiny)) == 0
+        assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) == 0
     with pytest.raises(ValueError):
         RnnLayerSpec("gru", 1, 256, TTSpec([1, 1, 1], [8, 8, 16], [1, 8, 8, 1]),
                      TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
