@@ -39,7 +39,7 @@ class MNISTClassifier(nn.Module):
 
     def forward(self, inputs):
         out = self.rnn(inputs)[0]
-        return F.log_softmax(self.linear(out[:, -1, :]), dim=1)
+        return self.linear.forward_head(out[:, -1, :], "log_softmax")       # TTLinear + log_softmax: one library call
 
 
 class SpeakerEncoder(nn.Module):
@@ -57,8 +57,7 @@ class SpeakerEncoder(nn.Module):
     def forward(self, utterances):
         res = self.rnn(utterances)
         last_hidden = res[1] if self.use_gru else res[1][0]
-        embeds_raw = torch.relu(self.linear(last_hidden))
-        return embeds_raw / torch.norm(embeds_raw, dim=1, keepdim=True)
+        return self.linear.forward_head(last_hidden, "relu_l2norm")              # TTLinear + ReLU + L2 norm: one library call
 
     def similarity_matrix(self, verification_embeds, enrollment_embeds=None):
         """speaker_encoder.py:93-140, vectorised and on the embeddings' device (ttrnn_hip/ge2e.py)."""

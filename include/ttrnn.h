@@ -144,6 +144,23 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
                             const void* x, const void* dy, void* dx, float* d_packed,
                             float* d_bias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- TTLinear heads with fused row-wise epilogues ---------------------------------------------------------------
+ * The step right after the path in both callers:
+ *   TTRNN_EPI_LOG_SOFTMAX   y = log_softmax(TT(x) + b, dim=1)      experiments/digit_classification/mnist_classifier.py:55-57
+ *   TTRNN_EPI_RELU_L2NORM   u = relu(TT(x) + b);  y = u / ||u||_2  experiments/speaker_verification/encoder/speaker_encoder.py:86-89
+ * y has the storage dtype; aux (fp32[n_rows], may be NULL for inference with LOG_SOFTMAX) receives the row's log-sum-exp /
+ * L2 norm.  ttrnn_head_backward takes the SAVED outputs y (+ aux), turns dy into the pre-activation gradient and runs
+ * ttrnn_ttlinear_backward on it (same accumulate / NULL conventions).  Workspace: ttrnn_head_workspace(w, n_rows). */
+#define TTRNN_EPI_NONE 0
+#define TTRNN_EPI_LOG_SOFTMAX 1
+#define TTRNN_EPI_RELU_L2NORM 2
+size_t ttrnn_head_workspace(const ttrnn_ttm* w, int64_t n_rows);
+int ttrnn_head_forward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_rows, const float* packed, const void* bias,
+                       const void* x, void* y, float* aux, void* workspace, size_t workspace_bytes, void* stream);
+int ttrnn_head_backward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_rows, const float* packed, const void* x,
+                        const void* y, const float* aux, const void* dy, void* dx, float* d_packed, float* d_bias,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- recurrent layer -----------------------------------------------------------------------
  * replaces: the Python time loop LSTM.forward lstm.py:123-133 / GRU.forward gru.py:124-134 for ONE
  * layer (layer l+1 consumes layer l's `out`; same result as the reference's step-major loop),

@@ -57,3 +57,10 @@ class TTLinear(nn.Module):
     def forward(self, x):
         from ttrnn_hip import functional as F
         return F.tt_linear(x, self.weight_t.tt_cores, self.bias, spec=self.tt_spec())
+
+    def forward_head(self, x, epilogue):
+        """Not in the reference: forward + the caller's row-wise epilogue in ONE library call — `epilogue` is
+        "log_softmax" (experiments/digit_classification/mnist_classifier.py:55-57) or "relu_l2norm"
+        (experiments/speaker_verification/encoder/speaker_encoder.py:86-89)."""
+        from ttrnn_hip import functional as F
+        return F.tt_linear_head(x, self.weight_t.tt_cores, self.bias, spec=self.tt_spec(), epilogue=epilogue)

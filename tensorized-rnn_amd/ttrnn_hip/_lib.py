@@ -58,6 +58,11 @@ _SIGNATURES = {
                                               _P, ctypes.c_size_t, _P]),
     "ttrnn_ttlinear_backward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P,
                                                _P, _P, _P, ctypes.c_size_t, _P]),
+    "ttrnn_head_workspace": (ctypes.c_size_t, [ctypes.POINTER(TtmDesc), ctypes.c_int64]),
+    "ttrnn_head_forward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P, _P,
+                                          _P, ctypes.c_size_t, _P]),
+    "ttrnn_head_backward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P,
+                                           _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "ttrnn_rnn_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
@@ -151,6 +156,7 @@ def option(name, value):
         set_option(name, prev)
 
 
+EPILOGUES = {None: 0, "log_softmax": 1, "relu_l2norm": 2}     # TTRNN_EPI_*
 ROUTES = {0: "valu", 1: "stagewise_mfma", 2: "fused_core", 3: "merged_big", 4: "runtime_mfma"}
 
 

@@ -207,6 +207,68 @@ class _TTLinearFn(torch.autograd.Function):
         return (dx, db, None) + tuple(dcores)
 
 
+class _TTHeadFn(torch.autograd.Function):
+    """TTLinear + row-wise epilogue in one library call (ttrnn_head_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x2d, bias, spec, epi, *cores):
+        lib = _lib.load()
+        packed = spec.pack(cores)
+        n = x2d.shape[0]
+        y = _alloc((n, spec.out_features), x2d.dtype, x2d.device)
+        aux = _alloc((n,), torch.float32, x2d.device)
+        wsb = lib.ttrnn_head_workspace(ctypes.byref(spec.desc), n)
+        ws = _workspace(wsb, x2d.device)
+        check(lib.ttrnn_head_forward(ctypes.byref(spec.desc), _dtype_code(x2d), epi, n, _ptr(packed), _ptr(bias), _ptr(x2d),
+                                     _ptr(y), _ptr(aux), _ptr(ws), wsb, _stream(x2d)), "ttrnn_head_forward")
+        ctx.spec, ctx.epi, ctx.has_bias = spec, epi, bias is not None
+        ctx.save_for_backward(x2d, packed, y, aux, *cores)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2d, packed, y, aux = ctx.saved_tensors[:4]
+        cores = ctx.saved_tensors[4:]
+        spec = ctx.spec
+        need_dx = ctx.needs_input_grad[0]
+        need_db = ctx.has_bias and ctx.needs_input_grad[1]
+        need_dw = any(ctx.needs_input_grad[4:])
+        n = x2d.shape[0]
+        dev = x2d.device
+        dy = dy.contiguous().to(x2d.dtype)
+        dx = _alloc((n, spec.in_features), x2d.dtype, dev) if need_dx else None
+        dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
+        db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
+        wsb = lib.ttrnn_head_workspace(ctypes.byref(spec.desc), n)
+        ws = _workspace(wsb, dev)
+        check(lib.ttrnn_head_backward(ctypes.byref(spec.desc), _dtype_code(x2d), ctx.epi, n, _ptr(packed), _ptr(x2d), _ptr(y),
+                                      _ptr(aux), _ptr(dy), _ptr(dx), _ptr(dpk), _ptr(db), _ptr(ws), wsb, _stream(dy)),
+              "ttrnn_head_backward")
+        dcores = spec.unpack_grads(dpk, cores) if need_dw else [None] * len(cores)
+        if db is not None:
+            db = db.to(dy.dtype)
+        return (dx, db, None, None) + tuple(dcores)
+
+
+def tt_linear_head(x, cores, bias=None, spec=None, epilogue="log_softmax"):
+    """TTLinear followed by the row-wise epilogue of one of the reference's two callers, fused into one library call:
+    "log_softmax" (mnist_classifier.py:55-57) or "relu_l2norm" (speaker_encoder.py:86-89: ReLU, then L2 normalisation)."""
+    if epilogue not in _lib.EPILOGUES or epilogue is None:
+        raise ValueError("epilogue must be 'log_softmax' or 'relu_l2norm', got {!r}".format(epilogue))
+    cores = list(cores)
+    _require_device(x, bias, *cores)
+    if spec is None:
+        spec = TTSpec.from_cores(cores)
+    if x.shape[-1] != spec.in_features:
+        raise ValueError('Arguments shapes should align got {} and {} instead.'.format(
+            [spec.out_features, spec.in_features], list(x.shape)))
+    lead = x.shape[:-1]
+    x2d = x.reshape(-1, spec.in_features).contiguous()
+    y = _TTHeadFn.apply(x2d, bias, spec, _lib.EPILOGUES[epilogue], *cores)
+    return y.reshape(*lead, spec.out_features)
+
+
 def tt_linear(x, cores, bias=None, spec=None):
     """y[..., out] = TT(cores) x[..., in] + bias — the reference's TTLinear.forward."""
     cores = list(cores)
