@@ -248,8 +248,9 @@ def main():
                          "time per shape against the any-shape VALU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
-                    help="forward: the headline metric (no_grad forward). train: forward + BPTT + flat-bucket "
-                         "gradient all-reduce (RCCL) + SGD update, reported in the same unit")
+                    help="forward: the headline metric (no_grad forward). train: the reference's training benchmark step "
+                         "(benchmarking.py:41-70: classifier forward + nll_loss + BPTT + Adam) + flat-bucket gradient "
+                         "all-reduce (RCCL) for N > 1, reported in the same unit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,19 +294,32 @@ def main():
 
     reducer = None
     if args.mode == "train":
+        # the reference's own training benchmark step (experiments/digit_classification/benchmarking.py:41-70):
+        # MNIST_Classifier (TT-RNN -> TTLinear head on the last timestep -> log_softmax), random integer targets,
+        # zero_grad + forward + nll_loss + backward + Adam(lr 1e-3); plus, for N > 1, the flat-bucket gradient all-reduce
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        from models import MNISTClassifier
         from ttrnn_hip.dist import FlatGradAllReduce
+        n_cls = 10 if w["inp"] == 1 else 256           # pMNIST classes / benchmarking.py's default emb_size
+        torch.manual_seed(1111)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = MNISTClassifier(w["inp"], n_cls, w["H"], w["L"], device, gru=(w["kind"] == "ttgru"), n_cores=w["d"],
+                                    tt_rank=w["r"]).to(device)
+        if w["dtype"] == "bf16":
+            model = model.to(torch.bfloat16)
         model.train()
+        torch.manual_seed(2222 + rank)
+        target = torch.randint(0, n_cls, (w["B"],), device=device)
         reducer = FlatGradAllReduce(model) if dist is not None else None
-        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     def step():
         if args.mode == "forward":
             with torch.no_grad():
                 return model(x)
-        opt.zero_grad(set_to_none=True)
-        res = model(x)
-        out = res[0]
-        loss = (out.float() * out.float()).mean()
+        opt.zero_grad()
+        out = model(x)
+        loss = torch.nn.functional.nll_loss(out.float(), target)
         loss.backward()
         if reducer is not None:
             reducer.sync()
@@ -407,7 +421,8 @@ def main():
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
                        "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
-                                "train step: forward + BPTT + gradient all-reduce + SGD, inputs resident in HBM"),
+                                "train step of the reference's benchmarking.py:41-70 (zero_grad + classifier forward + nll_loss "
+                                "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM"),
                        "fp32_math": FP32_MATH_DESC.get(math_mode)},
             "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

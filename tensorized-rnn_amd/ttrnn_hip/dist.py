@@ -55,27 +55,29 @@ class FlatGradAllReduce(object):
     def nbytes(self):
         return self.flat.numel() * 4
 
+    def _views(self):
+        """One view of the flat bucket per parameter, laid out like that parameter's gradient (TT cores are dense but
+        permuted: t3nsor/tensor_train.py:104-114), so that bucket <-> gradient copies are plain element-wise copies."""
+        views, grads, off = [], [], 0
+        for p, n in zip(self.params, self.sizes):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)      # missing gradients count as zero
+            g = p.grad
+            dense = g.is_contiguous() or g.permute(*sorted(range(g.dim()), key=lambda d: -g.stride(d))).is_contiguous()
+            if not dense:
+                p.grad = g = g.contiguous()
+            views.append(torch.as_strided(self.flat, g.shape, g.stride(), off))
+            grads.append(g)
+            off += n
+        return views, grads
+
     def sync(self):
-        """Call after backward(): grads become the mean over ranks.  Missing grads count as zero."""
+        """Call after backward(): grads become the mean over ranks.  Missing grads count as zero.  Two multi-tensor
+        copies (torch._foreach_copy_: one launch each, whatever the number of parameters) around ONE all-reduce."""
         if self.world == 1:
             return
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            seg = self.flat[off:off + n]
-            if p.grad is None:
-                seg.zero_()
-            else:
-                seg.copy_(p.grad.reshape(-1) if p.grad.is_contiguous() else p.grad.contiguous().view(-1))
-            off += n
+        views, grads = self._views()
+        torch._foreach_copy_(views, grads)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            seg = self.flat[off:off + n]
-            if p.grad is None:
-                p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
-            if p.grad.is_contiguous():
-                p.grad.view(-1).copy_(seg)
-            else:
-                p.grad.copy_(seg.view(p.shape))
-            off += n
+        torch._foreach_copy_(grads, views)

@@ -96,3 +96,31 @@ def test_shard_bounds():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["forward", "train"])
+def test_bench_two_ranks_on_one_device(mode):
+    """The N > 1 path of bench.py exactly as the driver launches it (torch.distributed.run, one rank per process, barrier +
+    max-over-ranks timing, rank 0 prints ONE JSON line) on a one-GPU box: both ranks share cuda:0
+    (TTRNN_BENCH_SINGLE_DEVICE=1) and rendezvous over gloo, because RCCL refuses two ranks on one device.  Checks the JSON
+    contract of both modes; says nothing about scaling."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TTRNN_BENCH_SINGLE_DEVICE="1", TTRNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200 + (7 if mode == "train" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--mode", mode]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["unit"] == "timesteps/s"
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert abs(rec["value"] - 2 * 784 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]      # whole-job aggregate
+    assert rec["config"]["global_batch"] == 128 and "cpu_baseline" not in rec
+    assert rec["roofline"]["frac"] > 0
