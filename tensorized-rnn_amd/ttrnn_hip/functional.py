@@ -48,6 +48,20 @@ def _require_device(*tensors):
                 "There is deliberately no CPU fallback.".format(t.device))
 
 
+def _check_operands(x, named):
+    """The kernels read every operand in x's storage dtype on x's device: refuse a mismatch instead of reinterpreting bytes
+    (the reference raises torch's own dtype / device errors at this point)."""
+    for name, t in named:
+        if t is None:
+            continue
+        if t.device != x.device:
+            raise _lib.TtrnnError("{} is on {} but the input is on {}: all operands of a libttrnn call must share one "
+                                  "device".format(name, t.device, x.device))
+        if t.dtype != x.dtype:
+            raise _lib.TtrnnError("{} has dtype {} but the input has dtype {}: libttrnn computes in the input's storage "
+                                  "dtype (cast the module or the input)".format(name, t.dtype, x.dtype))
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -263,9 +277,11 @@ def tt_linear_head(x, cores, bias=None, spec=None, epilogue="log_softmax"):
     if x.shape[-1] != spec.in_features:
         raise ValueError('Arguments shapes should align got {} and {} instead.'.format(
             [spec.out_features, spec.in_features], list(x.shape)))
+    _check_operands(x, [("bias", bias)] + [("core {}".format(k), c) for k, c in enumerate(cores)])
     lead = x.shape[:-1]
     x2d = x.reshape(-1, spec.in_features).contiguous()
-    y = _TTHeadFn.apply(x2d, bias, spec, _lib.EPILOGUES[epilogue], *cores)
+    with torch.cuda.device(x.device):
+        y = _TTHeadFn.apply(x2d, bias, spec, _lib.EPILOGUES[epilogue], *cores)
     return y.reshape(*lead, spec.out_features)
 
 
@@ -278,9 +294,11 @@ def tt_linear(x, cores, bias=None, spec=None):
     if x.shape[-1] != spec.in_features:
         raise ValueError('Arguments shapes should align got {} and {} instead.'.format(
             [spec.out_features, spec.in_features], list(x.shape)))
+    _check_operands(x, [("bias", bias)] + [("core {}".format(k), c) for k, c in enumerate(cores)])
     lead = x.shape[:-1]
     x2d = x.reshape(-1, spec.in_features).contiguous()
-    y = _TTLinearFn.apply(x2d, bias, spec, *cores)
+    with torch.cuda.device(x.device):
+        y = _TTLinearFn.apply(x2d, bias, spec, *cores)
     return y.reshape(*lead, spec.out_features)
 
 
@@ -425,8 +443,13 @@ def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid):
     _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
     if x.dim() != 3 or x.shape[2] != spec.input_size:
         raise ValueError("expected input of shape (batch, seq_len, {}), got {}".format(spec.input_size, tuple(x.shape)))
+    _check_operands(x, [("bias_in", bias_in), ("bias_hid", bias_hid)] + [("core", c) for c in cores_in + cores_hid])
+    for name, t in (("h0", h0), ("c0", c0)):
+        if t is not None and t.device != x.device:
+            raise _lib.TtrnnError("{} is on {} but the input is on {}".format(name, t.device, x.device))
     x = x.contiguous()
     h0 = h0.contiguous().to(x.dtype) if h0 is not None else None
     c0 = c0.contiguous().to(x.dtype) if (c0 is not None and spec.cell == "lstm") else None
     spec.recording = torch.is_grad_enabled()
-    return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), *(cores_in + cores_hid))
+    with torch.cuda.device(x.device):       # the library launches on the CURRENT device's context
+        return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), *(cores_in + cores_hid))

@@ -666,6 +666,21 @@ def test_runtime_shape_kernels_bf16_storage_and_states():
     assert _maxabs(ob.float(), rob) <= 2e-2 and _maxabs(hb.float(), rhb) <= 2e-2
 
 
+def test_dtype_and_device_mismatches_are_refused():
+    """a bf16 input into an fp32 module used to reinterpret the fp32 bias as bf16; now it raises."""
+    import ttrnn_hip
+    m = build_module(dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), dev())
+    with pytest.raises(ttrnn_hip.TtrnnError):
+        m(torch.rand(2, 3, 1, device=dev()).to(torch.bfloat16))
+    with pytest.raises(ttrnn_hip.TtrnnError):
+        m(torch.rand(2, 3, 1))                                    # CPU tensor: no CPU path
+    from t3nsor.layers import TTLinear
+    with contextlib.redirect_stdout(io.StringIO()):
+        lin = TTLinear(in_features=256, out_features=10, d=3, tt_rank=8).to(dev())
+    with pytest.raises(ttrnn_hip.TtrnnError):
+        lin(torch.rand(4, 256, device=dev()).to(torch.bfloat16))
+
+
 # ---- (4) fp32 math modes: three-way bf16 split (default) vs fp32 MFMA ("exact") -------------------------
 # Every test above runs in the library's default mode (split where a split kernel exists: the cfg2 hidden shape);
 # the ones below pin BOTH modes explicitly on that shape.
