@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 1
+#define TTRNN_ABI_VERSION 2
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {
@@ -192,12 +192,15 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc);   /* TTRNN_ROUTE_* or a
  *      input / hidden TTLinear; for LSTM both are identical and d_gates_hid may alias d_gates_in
  *      or be NULL), d_h0/d_c0[B][H] (may be NULL).
  * The weight / input gradients then follow from ttrnn_ttlinear_backward over the B*T rows
- * (x rows for in_w; h_{t-1} rows for hid_w). */
+ * (x rows for in_w; h_{t-1} rows for hid_w).
+ *   d_state (may be NULL): fp32 [B][T][H][2] = the TOTAL gradients w.r.t. h_t and c_t of every step (slot 1 is 0 for GRU) —
+ *      what the tensor hooks of ActivGradLogger see (rnn_utils.py:127-171, lstm.py:35-39).  Requesting it selects the
+ *      runtime-shape / any-shape reverse kernels, which write it from the registers that already hold the values. */
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc);
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve,
                        const void* d_out, const void* d_hT, const void* d_cT,
-                       float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
+                       float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0, float* d_state,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -385,12 +385,21 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  // a d_state request (ttrnn_rnn_backward) takes the runtime-shape / any-shape route whatever the shape: cover both
+  size_t alt = 0;
+  if (!force_generic()) {
+    alt = plan_rnn_generic(rs, true).ws_bytes;
+    if (g2_rnn_available(rs, desc->dtype) && g2_rnn_bwd_workspace(rs) > alt) alt = g2_rnn_bwd_workspace(rs);
+  }
+  const size_t own = [&]() -> size_t {
   if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
     return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
   if (!force_generic() && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
   if (!force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
+  }();
+  return own > alt ? own : alt;
 }
 
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
@@ -507,7 +516,7 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       float* d_state, void* workspace, size_t workspace_bytes, void* stream) {
   RnnShape rs;
   int st = rnn_shape_init(&rs, desc);
   if (st != TTRNN_OK) return st;
@@ -515,8 +524,11 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (!packed_hid) return TTRNN_ERR_NULL;
   if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
-  const bool g2_first = opt(OPT_FORCE_G2) && !force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype);
-  if (!g2_first && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
+  // d_state (the per-step state gradients ActivGradLogger records) is written by the runtime-shape and the any-shape
+  // reverse kernels; a request for it takes those routes (the shape-specialised kernels stay untouched)
+  const bool g2_first = (opt(OPT_FORCE_G2) || d_state) && !force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype);
+  const bool want_state = d_state != nullptr;
+  if (!g2_first && !want_state && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&
         f10_rnn_bwd_available(rs, desc->dtype)) {
       if (!workspace || workspace_bytes < f10_rnn_bwd_workspace_bytes(rs, desc->dtype)) return TTRNN_ERR_WORKSPACE;
@@ -526,7 +538,7 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);
   }
-  if (!g2_first && !force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
+  if (!g2_first && !want_state && !force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < big_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_big(rs, desc->dtype, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                               d_h0, d_c0, workspace, (hipStream_t)stream);
@@ -534,12 +546,12 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (!force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
-                             d_h0, d_c0, workspace, (hipStream_t)stream);
+                             d_h0, d_c0, workspace, (hipStream_t)stream, d_state);
   }
   const RnnPlan p = plan_rnn_generic(rs, true);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_rnn_bwd_generic(rs, p, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
-                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream);
+                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream, d_state);
 }
 
 }  // extern "C"

@@ -494,7 +494,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         const T* out, const T* h0, const T* c0, const float* Wt_hid, const float* reserve,
                         const T* d_out, const T* d_hT, const T* d_cT,
                         float* dg_in, float* dg_hid, T* d_h0, T* d_c0,
-                        float* bufA, float* bufB, float* dh, float* dc, float* dhd) {
+                        float* bufA, float* bufB, float* dh, float* dc, float* dhd, float* dstate = nullptr) {
   const int H = rs.H, G = rs.G, GH = G * H, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
   const int RU = lstm ? 8 : 4;
@@ -520,6 +520,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           const float cprev = t > 0 ? reserve[((bt - 1) * H + j) * RU + 4] : (c0 ? ld(c0, b * H + j) : 0.f);
           const float tc = tanhf(cy);
           const float dct = dc[e] + dht * og * (1.0f - tc * tc);
+          if (dstate) { dstate[(bt * H + j) * 2] = dht; dstate[(bt * H + j) * 2 + 1] = dct; }
           const float p0 = dct * gg * ig * (1.0f - ig);
           const float p1 = dct * cprev * fg * (1.0f - fg);
           const float p2 = dct * ig * (1.0f - gg * gg);
@@ -535,6 +536,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
         } else {
           const float rg = rv[0], zg = rv[1], ng = rv[2], hn = rv[3];
           const float hprev = t > 0 ? ld(out, (bt - 1) * H + j) : (h0 ? ld(h0, b * H + j) : 0.f);
+          if (dstate) { dstate[(bt * H + j) * 2] = dht; dstate[(bt * H + j) * 2 + 1] = 0.f; }
           const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
           const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
           const float dr_pre = dn_pre * hn * rg * (1.0f - rg);

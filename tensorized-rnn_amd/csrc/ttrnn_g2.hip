@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
                                                   const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                   const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
                                                   const float* __restrict__ bt1, float* __restrict__ dg_in,
-                                                  float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0) {
+                                                  float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0,
+                                                  float* __restrict__ dstate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
   __bf16* dyimg = reinterpret_cast<__bf16*>(smem);
@@ -501,6 +502,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             const float cprev = t > 0 ? reserve[((bt - 1) * H + hid) * 8 + 4] : (c0 ? ld(c0, b * H + hid) : 0.f);
             const float tc = ftanh(cy);
             const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
+            if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = dct; }
             p[0] = dct * gg * ig * (1.0f - ig);
             p[1] = dct * cprev * fg * (1.0f - fg);
             p[2] = dct * ig * (1.0f - gg * gg);
@@ -511,6 +513,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             const f32x4 gq = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
             const float rg = gq[0], zg = gq[1], ng = gq[2], hn = gq[3];
             const float hprev = t > 0 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
+            if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = 0.f; }
             const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
             p[1] = dht * (hprev - ng) * zg * (1.0f - zg);
             p[0] = dn_pre * hn * rg * (1.0f - rg);
@@ -788,7 +791,7 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
 template <typename TS>
 static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const void* h0, const void* c0, const float* packed_hid,
                  const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
-                 void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+                 void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate) {
   const xbf8* bs2;
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
@@ -800,7 +803,7 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
     if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,   \
                        reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
-                       (TS*)d_c0);                                                                                        \
+                       (TS*)d_c0, dstate);                                                                                \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
     if (P.upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
@@ -817,13 +820,13 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
 
 int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
-                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate) {
   G2Plan P;
   g2_plan(&P, rs, rs.B <= device_cu_count());
   if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
-             ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream)
-             : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream);
+             ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate)
+             : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate);
 }
 
 }  // namespace ttrnn

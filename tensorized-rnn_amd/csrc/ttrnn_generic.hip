@@ -269,7 +269,8 @@ template <typename T, bool W_LDS, bool BUF_GLOBAL>
 __global__ void __launch_bounds__(NT_RNN) k_rnn_bwd(RnnShape rs, int nb, const T* out, const T* h0, const T* c0,
                                                     const float* packed_hid, const float* reserve,
                                                     const T* d_out, const T* d_hT, const T* d_cT,
-                                                    float* dg_in, float* dg_hid, T* d_h0, T* d_c0, float* ws) {
+                                                    float* dg_in, float* dg_hid, T* d_h0, T* d_c0, float* ws,
+                                                    float* dstate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DevExec ex;
   const int b0 = blockIdx.x * nb;
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(NT_RNN) k_rnn_bwd(RnnShape rs, int nb, const T
   const float* Wt = packed_hid + rs.hid_s.wtotal;
   if (W_LDS) { copy_to_lds(p, Wt, rs.hid_s.wtotal); Wt = p; __syncthreads(); }
   rnn_bwd_body<DevExec, T>(ex, rs, b0, n, out, h0, c0, Wt, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0,
-                           bufA, bufB, dh, dc, dhd);
+                           bufA, bufB, dh, dc, dhd, dstate);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,14 +520,14 @@ template <typename T>
 static int launch_rnn_bwd_t(const RnnShape& rs, const RnnPlan& p, const void* out, const void* h0, const void* c0,
                             const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                             const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
-                            hipStream_t stream) {
+                            hipStream_t stream, float* dstate) {
 #define TT_LAUNCH(WL, BG)                                                                                          \
   do {                                                                                                             \
     auto kern = k_rnn_bwd<T, WL, BG>;                                                                              \
     if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_RNN), p.lds_bytes, stream, rs, p.nb, (const T*)out,             \
                        (const T*)h0, (const T*)c0, packed_hid, reserve, (const T*)d_out, (const T*)d_hT,           \
-                       (const T*)d_cT, dg_in, dg_hid, (T*)d_h0, (T*)d_c0, (float*)ws);                             \
+                       (const T*)d_cT, dg_in, dg_hid, (T*)d_h0, (T*)d_c0, (float*)ws, dstate);                     \
   } while (0)
   if (p.w_lds && !p.buf_global) TT_LAUNCH(true, false);
   else if (!p.w_lds && !p.buf_global) TT_LAUNCH(false, false);
@@ -539,10 +540,10 @@ static int launch_rnn_bwd_t(const RnnShape& rs, const RnnPlan& p, const void* ou
 int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* out, const void* h0,
                            const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0,
-                           void* ws, hipStream_t stream) {
+                           void* ws, hipStream_t stream, float* dstate) {
   return dtype == TTRNN_F32
-             ? launch_rnn_bwd_t<float>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream)
-             : launch_rnn_bwd_t<bf16_t>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream);
+             ? launch_rnn_bwd_t<float>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate)
+             : launch_rnn_bwd_t<bf16_t>(rs, p, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate);
 }
 
 }  // namespace ttrnn

@@ -79,7 +79,7 @@ int launch_rnn_fwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, cons
 int launch_rnn_bwd_generic(const RnnShape& rs, const RnnPlan& p, int dtype, const void* out, const void* h0,
                            const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0,
-                           void* ws, hipStream_t stream);
+                           void* ws, hipStream_t stream, float* dstate = nullptr);
 
 // shape-specialised MFMA recurrent kernel (ttrnn_fast.hip); gin = hoisted input projection, fp32 [B][T][G*H]
 bool fast_rnn_fwd_available(const RnnShape& rs, int dtype);
@@ -171,7 +171,7 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
                       float* reserve, void* workspace, hipStream_t stream);
 int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
-                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream);
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate = nullptr);
 
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);

@@ -9,11 +9,14 @@ depends on layer l-1 at step t and on itself at step t-1).
 Dense (``nn.Linear``) cells ride the same kernels: a dense matrix is a TT-matrix with a single
 core ``(1, out, in, 1)``.
 
-Two situations fall back from the fused sequence call to stepping the cells one timestep at a
-time — still on the GPU through the same library, never on the CPU:
-  * ``log_grads=True``: the hooks of ``ActivGradLogger`` need per-step ``hy`` / ``cy`` tensors;
-  * ``is_naive=True`` cells (``TTLinearSet``: one TT-matrix per gate), whose per-gate TTLinear
-    kernels are combined with device-side pointwise ops.
+``log_grads=True`` stays on the fused path: the per-step statistics ``ActivGradLogger`` records through
+forward / tensor hooks in the reference come out of the sequence call itself (``ttrnn_hip.functional.StepStats``:
+activations from ``out`` and the saved ``c_t``, gradients from the ``d_state`` output of the reverse-time kernel).
+
+One situation falls back from the fused sequence call to stepping the cells one timestep at a
+time — still on the GPU through the same library, never on the CPU: ``is_naive=True`` cells
+(``TTLinearSet``: one TT-matrix per gate), whose per-gate TTLinear kernels are combined with
+device-side pointwise ops; with ``log_grads=True`` their hooks fire per step as in the reference.
 """
 import torch
 from torch import nn
@@ -63,7 +66,10 @@ class FusedCellMixin(object):
     def _run_sequence(self, seq, h0, c0=None):
         from ttrnn_hip import functional as F
         cin, bin_, chid, bhid = self._operands()
-        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid)
+        stats = None
+        if getattr(self, '_h_logger', None) is not None:       # log_grads=True: per-step statistics from the fused call
+            stats = F.StepStats(self._h_logger, getattr(self, '_c_logger', None))
+        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats)
 
 
 class TTWeightsMixin(object):
@@ -137,13 +143,17 @@ class FusedRnnBase(nn.Module):
             self._all_layers.append(cell)
         if log_grads:
             for i, cell in enumerate(self._all_layers):
-                h_fwd, h_bwd = ActivGradLogger("hidden_{}".format(i)).create_hooks(0)
+                h_logger = ActivGradLogger("hidden_{}".format(i))
+                h_fwd, h_bwd = h_logger.create_hooks(0)
                 cell.register_forward_hook(h_fwd)
                 cell._h_backward_hook = h_bwd
+                object.__setattr__(cell, '_h_logger', h_logger)       # fused path: fed by ttrnn_hip.functional.StepStats
                 if self.kind == 'lstm':
-                    c_fwd, c_bwd = ActivGradLogger("cell_{}".format(i)).create_hooks(1)
+                    c_logger = ActivGradLogger("cell_{}".format(i))
+                    c_fwd, c_bwd = c_logger.create_hooks(1)
                     cell.register_forward_hook(c_fwd)
                     cell._c_backward_hook = c_bwd
+                    object.__setattr__(cell, '_c_logger', c_logger)
 
     def param_count(self):
         from .rnn_utils import param_count as pc
@@ -151,7 +161,9 @@ class FusedRnnBase(nn.Module):
                    for attr in ('input_weights', 'hidden_weights'))
 
     def _needs_stepping(self):
-        return self.log_grads or any(cell._operands() is None for cell in self._all_layers)
+        # log_grads=True stays on the fused path (per-step statistics come out of the sequence kernels); only the naive
+        # per-gate cells (TTLinearSet) are stepped
+        return any(cell._operands() is None for cell in self._all_layers)
 
     def _forward_fused(self, input, h0, c0):
         seq = input

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: libttrnn resolves libamdhip
 TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TTRNN_LIB_PATH: developer override (A/B-ing two builds of the library in one session); default = the in-tree build
@@ -68,7 +68,7 @@ _SIGNATURES = {
     "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_forward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
-    "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 13 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

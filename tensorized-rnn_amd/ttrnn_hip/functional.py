@@ -337,7 +337,7 @@ class RnnLayerSpec(object):
 
 class _TTRnnLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, bias_in, bias_hid, spec, n_in, *cores):
+    def forward(ctx, x, h0, c0, bias_in, bias_hid, spec, n_in, stats, *cores):
         lib = _lib.load()
         cores_in, cores_hid = cores[:n_in], cores[n_in:]
         B, T, _ = x.shape
@@ -353,7 +353,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
         # inference does not pay for the training reserve (cfg2: 411 MB of writes per forward)
         need_grad = spec.recording and any(ctx.needs_input_grad)
         reserve = None
-        if need_grad:
+        if need_grad or (stats is not None and spec.cell == "lstm"):      # the per-step c_t live in the reserve records
             reserve = _alloc((lib.ttrnn_rnn_reserve_bytes(ctypes.byref(desc)) // 4,), torch.float32, dev)
         wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
@@ -361,6 +361,9 @@ class _TTRnnLayerFn(torch.autograd.Function):
             check(lib.ttrnn_rnn_forward(ctypes.byref(desc), _ptr(x), _ptr(h0), _ptr(c0), _ptr(packed_in),
                                         _ptr(bias_in), _ptr(packed_hid), _ptr(bias_hid), _ptr(out), _ptr(hT),
                                         _ptr(cT), _ptr(reserve), _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward")
+        if stats is not None:
+            stats.forward(out, reserve.view(B, T, H, 8)[..., 4] if spec.cell == "lstm" else None)
+        ctx.stats = stats
         ctx.spec = spec
         ctx.n_in = n_in
         ctx.flags = (h0 is not None, c0 is not None, bias_in is not None, bias_hid is not None)
@@ -400,15 +403,18 @@ class _TTRnnLayerFn(torch.autograd.Function):
         d_c0 = _alloc((B, H), x.dtype, dev) if (has_c0 and need[2]) else None
         wsb = lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
+        d_state = _alloc((B, T, H, 2), torch.float32, dev) if ctx.stats is not None else None
         with _timed("ttrnn_rnn_backward"):
             check(lib.ttrnn_rnn_backward(ctypes.byref(desc), _ptr(out), _ptr(h0), _ptr(c0), _ptr(packed_hid),
                                          _ptr(reserve), _ptr(d_out), _ptr(d_hT), _ptr(d_cT), _ptr(dg_in),
-                                         _ptr(dg_hid), _ptr(d_h0), _ptr(d_c0), _ptr(ws), wsb, _stream(x)),
+                                         _ptr(dg_hid), _ptr(d_h0), _ptr(d_c0), _ptr(d_state), _ptr(ws), wsb, _stream(x)),
                   "ttrnn_rnn_backward")
+        if d_state is not None:
+            ctx.stats.backward(d_state[..., 0], d_state[..., 1] if spec.cell == "lstm" else None)
         # weight / input gradients: two TTLinear backward passes over the B*T rows
         n_in = ctx.n_in
-        need_dw_in = any(need[7:7 + n_in])
-        need_dw_hid = any(need[7 + n_in:])
+        need_dw_in = any(need[8:8 + n_in])
+        need_dw_hid = any(need[8 + n_in:])
         dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
                                                dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3])
         # h_{t-1} rows: [h0, out[:, :-1]]
@@ -424,7 +430,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
             db_in = db_in.to(x.dtype)
         if db_hid is not None:
             db_hid = db_hid.to(x.dtype)
-        return (dx, d_h0, d_c0, db_in, db_hid, None, None) + tuple(dcin) + tuple(dchid)
+        return (dx, d_h0, d_c0, db_in, db_hid, None, None, None) + tuple(dcin) + tuple(dchid)
 
 
 def rnn_route(spec, batch, seq_len, dtype=torch.float32):
@@ -436,9 +442,44 @@ def rnn_route(spec, batch, seq_len, dtype=torch.float32):
     return _lib.ROUTES[code]
 
 
-def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid):
+class StepStats(object):
+    """Feeds the per-timestep statistics of ActivGradLogger (reference: tensorized_rnn/rnn_utils.py:127-171,217-226 —
+    mean over the batch of ||v_t||^2 and of log ||v_t||^2, for v = h, c and their gradients) from ONE fused sequence call
+    instead of T per-step cell calls: activations from `out` and the reserve's c_t, gradients from the d_state output of
+    the reverse-time kernel.  h_logger / c_logger are ActivGradLogger instances (c_logger None for GRU)."""
+
+    def __init__(self, h_logger, c_logger=None):
+        self.h_logger, self.c_logger = h_logger, c_logger
+
+    @staticmethod
+    def _av(v):                          # [B, T, H] -> (mean_b ||.||^2 [T], mean_b log ||.||^2 [T])
+        n = v.float().square().sum(2)
+        return n.mean(0), n.log().mean(0)
+
+    @torch.no_grad()
+    def forward(self, out, c_steps):
+        for lg, v in ((self.h_logger, out), (self.c_logger, c_steps)):
+            if lg is None or v is None:
+                continue
+            av, avl = self._av(v)
+            lg.act.extend(av.unbind(0))
+            lg.log_act.extend(avl.unbind(0))
+
+    @torch.no_grad()
+    def backward(self, dh, dc):
+        for lg, v in ((self.h_logger, dh), (self.c_logger, dc)):
+            if lg is None or v is None:
+                continue
+            av, avl = self._av(v)
+            for a, b in zip(reversed(av.unbind(0)), reversed(avl.unbind(0))):      # the hooks fire last timestep first
+                lg.grad.appendleft(a)
+                lg.log_grad.appendleft(b)
+
+
+def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None):
     """One recurrent layer over the whole sequence on the device.
-    Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU."""
+    Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU.
+    stats: optional StepStats — ActivGradLogger's per-step statistics without leaving the fused path."""
     cores_in, cores_hid = list(cores_in), list(cores_hid)
     _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
     if x.dim() != 3 or x.shape[2] != spec.input_size:
@@ -452,4 +493,4 @@ def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid):
     c0 = c0.contiguous().to(x.dtype) if (c0 is not None and spec.cell == "lstm") else None
     spec.recording = torch.is_grad_enabled()
     with torch.cuda.device(x.device):       # the library launches on the CURRENT device's context
-        return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), *(cores_in + cores_hid))
+        return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), stats, *(cores_in + cores_hid))
