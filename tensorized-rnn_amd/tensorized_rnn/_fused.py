@@ -13,10 +13,10 @@ core ``(1, out, in, 1)``.
 forward / tensor hooks in the reference come out of the sequence call itself (``ttrnn_hip.functional.StepStats``:
 activations from ``out`` and the saved ``c_t``, gradients from the ``d_state`` output of the reverse-time kernel).
 
-One situation falls back from the fused sequence call to stepping the cells one timestep at a
-time — still on the GPU through the same library, never on the CPU: ``is_naive=True`` cells
-(``TTLinearSet``: one TT-matrix per gate), whose per-gate TTLinear kernels are combined with
-device-side pointwise ops; with ``log_grads=True`` their hooks fire per step as in the reference.
+``is_naive=True`` cells (``TTLinearSet``: one TT-matrix per gate) take the same fused path: the set is handed to
+the library as one TT-matrix with a leading gate-selector core (``TTLinearSet.joint_cores``).  Stepping the cells one
+timestep at a time (``_forward_stepwise``) remains only for cells whose weights are neither ``nn.Linear``, ``TTLinear``
+nor ``TTLinearSet``.
 """
 import torch
 from torch import nn
@@ -41,6 +41,8 @@ class FusedCellMixin(object):
                 ops.append(_lin_as_tt(w))
             elif hasattr(w, 'weight_t'):
                 ops.append((list(w.weight_t.tt_cores), w.bias))
+            elif hasattr(w, 'joint_cores'):
+                ops.append(w.joint_cores())          # naive per-gate set as ONE TT-matrix (tt_linearset.py)
             else:
                 return None
         return ops[0][0], ops[0][1], ops[1][0], ops[1][1]

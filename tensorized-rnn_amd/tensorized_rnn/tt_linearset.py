@@ -3,6 +3,13 @@ concatenated column-wise (reference: ``tensorized_rnn/tt_linearset.py:5-38``).
 
 state_dict keeps the reference's duplicate registration (``gate{i}.*`` attributes AND the
 ``gates`` ModuleList, tt_linearset.py:23,25).  Each gate runs the fused HIP chain kernel.
+
+For the persistent sequence kernels the set is presented as ONE TT-matrix (``joint_cores``): the direct sum of the
+per-gate matrices IS a tensor train with one more core — a leading (1 -> n_gates) "gate selector" mode and block-diagonal
+cores of rank n_gates * r — whose output index is ``gate * H + i``, exactly the column order of the concatenation
+(tt_linearset.py:33-38).  The assembly is a handful of differentiable tensor ops on KB-sized cores, so autograd scatters
+the joint cores' gradients back onto the per-gate Parameters and ``is_naive=True`` models run the same fused time loop
+(libttrnn's runtime-shape MFMA kernels) as every other TT shape instead of T x L Python cell calls.
 """
 import torch
 from torch import nn
@@ -26,6 +33,29 @@ class TTLinearSet(nn.Module):
             built.append(TTLinear(**per_gate))
             self.add_module('gate%d' % index, built[-1])
         self.gates = nn.ModuleList(built)
+
+    def joint_cores(self):
+        """(cores, bias) of the single TT-matrix  x -> cat_g TT_g(x):  d + 1 cores with logical shapes
+        (1, G, 1, G), (G, I_0, J_0, G r_1), (G r_1, I_1, J_1, G r_2), ..., (G r_{d-1}, I_{d-1}, J_{d-1}, 1)."""
+        G = self.n_gates
+        per_gate = [list(member.weight_t.tt_cores) for member in self.gates]
+        d = len(per_gate[0])
+        ref = per_gate[0][0]
+        cores = [torch.eye(G, dtype=ref.dtype, device=ref.device).view(1, G, 1, G)]
+        for k in range(d):
+            blocks = []
+            for g in range(G):
+                c = per_gate[g][k]                                  # (r_k, I_k, J_k, r_{k+1})
+                if k == d - 1:
+                    blocks.append(c)                                # last core: ranks (G r_{d-1}) -> 1, stacked along dim 0
+                    continue
+                left = c.new_zeros(c.shape[0], c.shape[1], c.shape[2], g * c.shape[3])
+                right = c.new_zeros(c.shape[0], c.shape[1], c.shape[2], (G - 1 - g) * c.shape[3])
+                blocks.append(torch.cat([left, c, right], dim=3))
+            cores.append(torch.cat(blocks, dim=0))
+        biases = [member.bias for member in self.gates]
+        bias = None if biases[0] is None else torch.cat(biases, dim=0)
+        return cores, bias
 
     def forward(self, x):
         if x.size(1) != self.in_features:

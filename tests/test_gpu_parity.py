@@ -643,6 +643,43 @@ def test_runtime_shape_kernels_vs_oracle(kind, inp, H, L, d, r, B, T, new_core):
     assert not torch.equal(other, out.detach()) or B * T * H < 64      # two different routes really ran
 
 
+@pytest.mark.parametrize("kind,inp,H,L,d,r,B,T", [("ttlstm", 40, 256, 2, 3, 4, 6, 9), ("ttgru", 28, 128, 1, 2, 5, 7, 11),
+                                                   ("ttlstm", 1, 256, 1, 3, 8, 5, 12)])
+def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
+    """is_naive=True (TTLinearSet, tt_linearset.py:5-38; LSTM without any bias, GRU with biases: tt_lstm.py:17-21,
+    gru.py:150-153) is presented to the library as ONE TT-matrix with a gate-selector core: no per-step Python loop, the
+    persistent MFMA kernels run, outputs and every per-gate gradient match the oracle's per-gate evaluation."""
+    from ttrnn_hip import functional as F
+    torch.manual_seed(21)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r, is_naive=True)
+    m = build_module(meta, dev())
+    assert not m._needs_stepping()
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
+    lstm = kind == "ttlstm"
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, H)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, L, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    ro = (O.lstm_forward(layers, xr) if lstm else O.gru_forward(layers, xr))[0]
+    (ro * w).sum().backward()
+    xg = x.to(dev()).requires_grad_(True)
+    out = m(xg)[0]
+    (out * w.to(dev())).sum().backward()
+    assert _maxabs(out.detach(), ro.detach()) <= 1e-5
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6)
+    seen = 0
+    for name, p in m.named_parameters():
+        key = name.replace(".gate", ".gates.")        # gate{i} (attribute) and gates.{i} (ModuleList) are the same Parameters
+        if key not in leaves:
+            continue
+        seen += 1
+        ref = leaves[key].grad
+        assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    assert seen >= 2 * L * d * (4 if lstm else 3)
+
+
 def test_runtime_shape_kernels_bf16_storage_and_states():
     """bf16 storage (fp32 state / accumulation) and non-zero initial states through the runtime-shape route."""
     import ttrnn_hip
