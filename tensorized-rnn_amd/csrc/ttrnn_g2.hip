@@ -178,7 +178,7 @@ __device__ __forceinline__ void split_block(const xbf8 (&w)[3], const xbf8 (&x)[
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------------
-template <int CELL, typename TS, int UPT, bool DIAG>
+template <int CELL, typename TS, int UPT, bool RES, bool DIAG>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xbf8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, TS* __restrict__ out, TS* __restrict__ hT,
@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   // head stream of this wave
   const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
   const int total = nu_w * m.KBP;
-  const bool resident = total <= G2_PF;          // the wave's whole share of the head core lives in its register slots
+  // RES (chosen by the host for the whole launch: UW * KBP <= G2_PF): every wave's share of the head core lives in its
+  // register slots for all T steps; otherwise the slots roll over a stream of fragments
   const xbf8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 3 * 64 + lane;
   xbf8 wbuf[G2_PF][3];
 #pragma unroll
@@ -251,6 +252,28 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
       if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
     }
+  // ---- per-wave constants of the time loop, computed ONCE (the tier is instruction-issue bound: DESIGN.md 4c) -----------------
+  // first stage-1 tile pair of this wave (small and medium shapes have no other)
+  const bool s1_has = wave < m.T1;
+  const int s1_ta = s1_has ? wave : 0, s1_tb = (s1_has && wave + NW < m.T1) ? wave + NW : s1_ta;
+  const int s1_mta = s1_ta / m.N1T, s1_nta = s1_ta - s1_mta * m.N1T;
+  const int s1_mtb = s1_tb / m.N1T, s1_ntb = s1_tb - s1_mtb * m.N1T;
+  const int s1_fa = s1_mta * m.KS1 * 64 + lane, s1_fb = s1_mtb * m.KS1 * 64 + lane;
+  const float* s1_bpa = hb + (16 * s1_nta + c) * m.JtS + q;
+  const float* s1_bpb = hb + (16 * s1_ntb + c) * m.JtS + q;
+  const int s1_oa = s1_has ? s1off[s1_ta * 64 + lane] : -1;
+  const int s1_ob = (s1_has && s1_tb != s1_ta) ? s1off[s1_tb * 64 + lane] : -1;
+  // the single stage-2 unit of this wave when its head fragments are register-resident
+  const int r_tile = wave / m.KSPLIT, r_part = wave - r_tile * m.KSPLIT;
+  const int r_mt = r_tile / m.N2T, r_nt = r_tile - r_mt * m.N2T;
+  const int r_kb0 = r_part * m.KPER;
+  int r_nlive = m.NKB - r_kb0 < m.KPER ? m.NKB - r_kb0 : m.KPER;
+  r_nlive = (nu_w > 0 && r_nlive > 0) ? r_nlive : 0;
+  const __bf16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
+  const int r_ybase = r_part * GH + (16 * r_mt + 4 * q) * m.It + 16 * r_nt + c;
+  int r_ymask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r_ymask |= (16 * r_nt + c < m.It && 16 * r_mt + 4 * q + j < m.Ih) ? (1 << j) : 0;
   XChunk<TS> xq;                    // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -266,21 +289,23 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
     // (tail fragments: LDS-resident or from L1 / L2 — two explicit loops: ONE pointer that may be either makes every read a
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
+    auto pair = [&](auto frag, int fa, int fb, const float* bpa, const float* bpb, int offa, int offb) {
+      f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;   // two tiles: independent MFMA / split chains
+      for (int ks = 0; ks < m.KS1; ++ks) {
+        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(frag(fa + ks * 64), bpa[4 * ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(frag(fb + ks * 64), bpb[4 * ks], accb, 0, 0, 0);
+      }
+      if (offa >= 0) store_split4(img, plane, offa, acca);
+      if (offb >= 0) store_split4(img, plane, offb, accb);
+    };
     auto stage1 = [&](auto frag) {
-      for (int t1 = wave; t1 < m.T1; t1 += 2 * NW) {         // two tiles per iteration: independent MFMA / split chains
-        const int t1b = t1 + NW < m.T1 ? t1 + NW : t1;        // (the second one repeats the first when there is none)
+      if (s1_has) pair(frag, s1_fa, s1_fb, s1_bpa, s1_bpb, s1_oa, s1_ob);
+      for (int t1 = wave + 2 * NW; t1 < m.T1; t1 += 2 * NW) {  // larger shapes: further pairs, decoded on the fly
+        const int t1b = t1 + NW < m.T1 ? t1 + NW : t1;          // (the second tile repeats the first when there is none)
         const int mta = t1 / m.N1T, nta = t1 - mta * m.N1T;
         const int mtb = t1b / m.N1T, ntb = t1b - mtb * m.N1T;
-        const float* bpa = hb + (16 * nta + c) * m.JtS + q;
-        const float* bpb = hb + (16 * ntb + c) * m.JtS + q;
-        const int offa = s1off[t1 * 64 + lane], offb = s1off[t1b * 64 + lane];
-        f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;
-        for (int ks = 0; ks < m.KS1; ++ks) {
-          acca = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mta * m.KS1 + ks) * 64 + lane), bpa[4 * ks], acca, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mtb * m.KS1 + ks) * 64 + lane), bpb[4 * ks], accb, 0, 0, 0);
-        }
-        if (offa >= 0) store_split4(img, plane, offa, acca);
-        if (offb >= 0 && t1b != t1) store_split4(img, plane, offb, accb);
+        pair(frag, mta * m.KS1 * 64 + lane, mtb * m.KS1 * 64 + lane, hb + (16 * nta + c) * m.JtS + q,
+             hb + (16 * ntb + c) * m.JtS + q, s1off[t1 * 64 + lane], t1b != t1 ? s1off[t1b * 64 + lane] : -1);
       }
     };
     if (t1_lds) stage1([&](int i) { return lt1[i]; });
@@ -293,8 +318,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     // NO vector-memory instruction in the loop) and streaming (every slot is refilled unconditionally right after its use,
     // padding blocks included).  A CONDITIONAL refill makes hipcc guard every block with s_waitcnt vmcnt(0), which also
     // waits for the `out` store of the previous step: measured 3 300 instead of ~700 cycles for four blocks.
-    auto stage2 = [&](auto res_tag) {
-      constexpr bool RES = decltype(res_tag)::value;
+    auto stage2 = [&]() {
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
         const int u = wave + ui * NW;
@@ -319,7 +343,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
               for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
             if (kbl + j < m.KPER && kb < m.NKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
-            if constexpr (!RES) {
+            {
               int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
               nxt -= nxt >= total ? total : 0;
 #pragma unroll
@@ -340,8 +364,31 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         }
       }
     };
-    if (resident) stage2(std::true_type{});
-    else stage2(std::false_type{});
+    if constexpr (RES) {
+      // one unit, at most G2_PF blocks, every constant hoisted: fragment reads at immediate offsets, MFMAs, four stores
+      if (r_nlive > 0) {
+        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+        xbf8 bf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(r_brow + p * plane);
+#pragma unroll
+        for (int j = 0; j < G2_PF; ++j) {
+          if (j < r_nlive) {
+            if (j + 1 < r_nlive) {
+#pragma unroll
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(r_brow + p * plane + 32 * (j + 1));
+            }
+            split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+          }
+        }
+        const f32x4 acc = acc_hi + (acc_a + acc_b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r_ymask & (1 << j)) ybuf[r_ybase + j * m.It] = acc[j];
+      }
+    } else {
+      stage2();
+    }
     TT_STAMP(2)
     lds_barrier();
     TT_STAMP(3)
@@ -416,7 +463,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 // per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients) and
 // the split bf16 image of dy;  T2 (streamed head^T, split MFMA) -> fp32 dC1 image;  T1 (fp32 MFMA, k split over the
 // waves when there are few tiles) -> partial dh vectors summed by the next gate phase.
-template <int CELL, typename TS, int UPT>
+template <int CELL, typename TS, int UPT, bool RES>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const float* __restrict__ reserve,
                                                   const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
@@ -470,8 +517,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   }
   const int nu_w = wave < m.bU ? (m.bU - wave + NW - 1) / NW : 0;
   const int total = nu_w * m.bKBP;
-  const bool resident = total <= G2_PF;
   const xbf8* sp = bs2 + (size_t)wave * m.bUW * m.bKBP * 3 * 64 + lane;
+  // RES (host: one column tile, bNKB <= 4 and bUW * bNKB <= G2_PF): slot s holds live block (unit s / bNKB, k-block s % bNKB)
+  // of this wave for the whole launch; otherwise the slots roll over the wave's stream
+  const int r_nlive = RES ? nu_w * m.bNKB : 0;
   xbf8 wbuf[G2_PF][3];
 #pragma unroll
   for (int j = 0; j < G2_PF; ++j)
@@ -479,7 +528,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
-      if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+      if constexpr (RES) {
+        const int ui = j / m.bNKB, kb = j - ui * m.bNKB;
+        if (j < r_nlive) wbuf[j][p] = sp[(size_t)(ui * m.bKBP + kb) * 3 * 64 + p * 64];
+      } else {
+        if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+      }
     }
   __syncthreads();
 
@@ -536,8 +590,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     }
     lds_barrier();
     // ---- T2: dC1 = head^T dy (split bf16 MFMA; resident / streaming instantiations as in the forward kernel) -----------------------------
-    auto stageT2 = [&](auto res_tag) {
-      constexpr bool RES = decltype(res_tag)::value;
+    auto stageT2 = [&]() {
       int seq = 0;
       for (int ui = 0; ui < nu_w; ++ui) {
         const int tile = wave + ui * NW;
@@ -556,13 +609,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
               for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
             if (kb < m.bNKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
-            if constexpr (!RES) {
-              int nxt = seq + G2_PF;
-              nxt -= nxt >= total ? total : 0;
+            int nxt = seq + G2_PF;
+            nxt -= nxt >= total ? total : 0;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
-              ++seq;
-            }
+            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+            ++seq;
           }
         }
         const f32x4 acc_lo = acc_a + acc_b;
@@ -571,8 +622,41 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + it * m.Rp) = acc_hi + acc_lo;
       }
     };
-    if (resident) stageT2(std::true_type{});
-    else stageT2(std::false_type{});
+    // resident: the dy fragments are the SAME for every row tile (one column tile): read once per step, then every live
+    // slot is one split block; a unit's accumulators are flushed after its last k-block.  NKB is a compile-time constant
+    // inside each instantiation of the body (slot -> k-block must index registers statically).
+    auto stageT2res = [&](auto nkb_tag) {
+      constexpr int NKB = decltype(nkb_tag)::value;
+      const __bf16* brow = dyimg + c * m.IhS + 8 * q;
+      xbf8 bfr[NKB][3];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bfr[kb][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
+      f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+#pragma unroll
+      for (int sl = 0; sl < G2_PF; ++sl) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ui = sl / NKB, kb = sl % NKB;
+        if (sl < r_nlive) {
+          if (kb == 0) { acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a; }
+          split_block(wbuf[sl], bfr[kb], acc_a, acc_b, acc_hi);
+          if (kb == NKB - 1) {
+            const int off = t2off[(wave + ui * NW) * 4 + q];
+            if (off >= 0 && c < m.It) *reinterpret_cast<f32x4*>(dc1 + off + c * m.Rp) = acc_hi + (acc_a + acc_b);
+          }
+        }
+      }
+    };
+    if constexpr (RES) {
+      if (m.bNKB == 1) stageT2res(std::integral_constant<int, 1>{});
+      else if (m.bNKB == 2) stageT2res(std::integral_constant<int, 2>{});
+      else if (m.bNKB == 3) stageT2res(std::integral_constant<int, 3>{});
+      else stageT2res(std::integral_constant<int, 4>{});
+    } else {
+      stageT2();
+    }
     lds_barrier();
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
     auto stageT1 = [&](auto frag) {
@@ -757,9 +841,12 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
   static bool raised[2][3] = {{false, false, false}, {false, false, false}};
+  const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
 #define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
-    auto kern = (opt(OPT_DIAG) && reserve && UPTV == 1) ? k_g2_fwd<CELLV, TS, UPTV, true> : k_g2_fwd<CELLV, TS, UPTV, false>; \
+    auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? k_g2_fwd<CELLV, TS, UPTV, true, true>                   \
+                                                               : k_g2_fwd<CELLV, TS, UPTV, true, false>)                 \
+                    : k_g2_fwd<CELLV, TS, UPTV, false, false>;                                                            \
     if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2,   \
                        ft1, (TS*)out, (TS*)hT, (TS*)cT, reserve);                                                         \
@@ -797,9 +884,10 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
   static bool raised[2][3] = {{false, false, false}, {false, false, false}};
+  const bool res = P.hid.N2T == 1 && P.hid.bNKB <= 4 && P.hid.bUW * P.hid.bNKB <= G2_PF;
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
-    auto kern = k_g2_bwd<CELLV, TS, UPTV>;                                                                               \
+    auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \
     if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,   \
                        reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
