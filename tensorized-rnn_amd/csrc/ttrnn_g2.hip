@@ -291,9 +291,20 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
     auto pair = [&](auto frag, int fa, int fb, const float* bpa, const float* bpb, int offa, int offb) {
       f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;   // two tiles: independent MFMA / split chains
-      for (int ks = 0; ks < m.KS1; ++ks) {
-        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(frag(fa + ks * 64), bpa[4 * ks], acca, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(frag(fb + ks * 64), bpb[4 * ks], accb, 0, 0, 0);
+      for (int ks0 = 0; ks0 < m.KS1; ks0 += 4) {              // operands of four k-steps are requested before the first MFMA
+        float wa[4], wb[4], xa[4], xb[4];                       // (one read -> wait -> MFMA per step exposed the LDS latency 2 KS1 times)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ks = ks0 + e < m.KS1 ? ks0 + e : m.KS1 - 1;
+          wa[e] = frag(fa + ks * 64); wb[e] = frag(fb + ks * 64);
+          xa[e] = bpa[4 * ks]; xb[e] = bpb[4 * ks];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ks0 + e < m.KS1) {
+            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xa[e], acca, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[e], xb[e], accb, 0, 0, 0);
+          }
       }
       if (offa >= 0) store_split4(img, plane, offa, acca);
       if (offb >= 0) store_split4(img, plane, offb, accb);
@@ -399,9 +410,15 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int hid = tid + u * 256;
         if (hid < H && tid < 256) {
           float y[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int pt = 0; pt < m.KSPLIT; ++pt)
+          for (int pt = 0; pt < m.KSPLIT; pt += 2) {           // two partial sums per trip: all reads issued before the adds
+            const int p1 = pt + 1 < m.KSPLIT ? pt + 1 : pt;
+            const float k1 = pt + 1 < m.KSPLIT ? 1.0f : 0.0f;
+            float ya[4], yb[4];
 #pragma unroll
-            for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ybuf[pt * GH + g * H + hid];
+            for (int g = 0; g < (LSTM ? 4 : 3); ++g) { ya[g] = ybuf[pt * GH + g * H + hid]; yb[g] = ybuf[p1 * GH + g * H + hid]; }
+#pragma unroll
+            for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ya[g] + k1 * yb[g];
+          }
           f32x4 g4 = gi[u];
           if (in1) g4 = bb[u] + xq.at(t) * gi[u];
           float hy;
@@ -546,7 +563,13 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const int hid = tid + u * 256;
         if (hid < H && tid < 256) {
           float dht = dhd[u];
-          for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
+          for (int pt = 0; pt < m.bK1SPLIT; pt += 4) {        // up to four partial sums per trip, reads issued together
+            float pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = dhb[(pt + e < m.bK1SPLIT ? pt + e : pt) * H + hid];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dht += pt + e < m.bK1SPLIT ? pv[e] : 0.f;
+          }
           if (d_out) dht += ld(d_out, bt * H + hid);
           float p[4] = {0.f, 0.f, 0.f, 0.f}, ph2 = 0.f;
           if (LSTM) {
@@ -667,12 +690,20 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
         const float* bp = dc1 + (16 * nt + c) * m.K1S + q;
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        int ks = k0;
-        for (; ks + 1 < k1; ks += 2) {                        // two accumulator chains
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks) * 64 + lane), bp[4 * ks], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks + 1) * 64 + lane), bp[4 * ks + 4], acc1, 0, 0, 0);
+        const int fbase = mt * m.bKS1 * 64 + lane;
+        for (int ks0 = k0; ks0 < k1; ks0 += 8) {               // eight k-steps' operands in flight, two accumulator chains
+          float wv[8], xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ks = ks0 + e < k1 ? ks0 + e : k1 - 1;
+            wv[e] = frag(fbase + ks * 64); xv[e] = bp[4 * ks];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            if (ks0 + e < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[e], acc0, 0, 0, 0);
+            if (ks0 + e + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e + 1], xv[e + 1], acc1, 0, 0, 0);
+          }
         }
-        if (ks < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag((mt * m.bKS1 + ks) * 64 + lane), bp[4 * ks], acc0, 0, 0, 0);
         const f32x4 acc = acc0 + acc1;
         const int jh = 16 * nt + c;
         if (jh < m.Jh) {
