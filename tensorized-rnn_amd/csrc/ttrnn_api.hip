@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
@@ -62,6 +65,25 @@ int opt_get(const char* name, int* value) {
   if (i < 0 || !value) return -1;
   *value = table().v[i].load(std::memory_order_relaxed);
   return 0;
+}
+}  // namespace ttrnn
+
+namespace ttrnn {
+int ensure_dynamic_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return TTRNN_OK;
+  static std::mutex mu;
+  static std::vector<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TTRNN_ERR_LAUNCH; }
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& e : done)
+    if (e.first == dev && e.second == fn) return TTRNN_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    (void)hipGetLastError();
+    return TTRNN_ERR_LAUNCH;
+  }
+  done.emplace_back(dev, fn);
+  return TTRNN_OK;
 }
 }  // namespace ttrnn
 

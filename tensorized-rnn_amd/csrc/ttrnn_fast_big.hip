@@ -597,14 +597,10 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     static_assert(big_lds_images<S2>(), "two-core images must fit LDS");
     constexpr size_t lds_lin = (size_t)(big_mid<S2>() + in_size_of<S2>()) * sizeof(float);
     constexpr size_t lds_rec = (size_t)big_mid<S2>() * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttlinear_fwd_big<S2, 4, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lin) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(k_rnn_fwd_big<S2, TTRNN_LSTM, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_ttlinear_fwd_big<S2, 4, TS>), lds_lin) != TTRNN_OK ||
+          ensure_dynamic_lds(reinterpret_cast<const void*>(k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), lds_rec) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised = true;
     }
     const int cus = device_cu_count();
     const int grid2 = (int)(n_rows < cus ? n_rows : cus);          // one workgroup per CU (LDS)
@@ -638,12 +634,9 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
       // the dispatcher then packs the pairs onto half of the CUs: measured no faster than one workgroup per sample)
       constexpr size_t lds_img = (size_t)(St<S2, 0>::ROWS / 2) * St<S2, 0>::KP * sizeof(float);
       constexpr size_t lds_pair = lds_img > 100 * 1024 ? lds_img : 100 * 1024;
-      static bool raised2 = false;
-      if (!raised2) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair) != hipSuccess)
+      {
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>), lds_pair) != TTRNN_OK)
           return TTRNN_ERR_LAUNCH;
-        raised2 = true;
       }
       hipLaunchKernelGGL((k_lstm_fwd_big2<S2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
                          (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb);

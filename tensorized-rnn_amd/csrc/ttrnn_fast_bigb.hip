@@ -747,24 +747,18 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
       return TTRNN_ERR_LAUNCH;
     // 64 KB image; 100 KB requested so that a second workgroup cannot share the CU (see the forward pair kernel)
     constexpr size_t lds = bigb_lds_bytes<ST, 2>() > 100 * 1024 ? bigb_lds_bytes<ST, 2>() : 100 * 1024;
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 2, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 2, TS>), lds) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised = true;
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T,
                        (const TS*)c0, mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in,
                        (TS*)d_h0, (TS*)d_c0, hxb);
   } else {
     constexpr size_t lds = bigb_lds_bytes<ST, 1>();
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 1, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 1, TS>), lds) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised = true;
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 1, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0,
                        mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0,
@@ -812,12 +806,9 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
   const int cus = device_cus();
   if (dx) {
     constexpr size_t lds = bigb_lds_bytes<ST, 1>();
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttlinear_dx_big<ST, TS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_ttlinear_dx_big<ST, TS>), lds) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised = true;
     }
     hipLaunchKernelGGL((k_ttlinear_dx_big<ST, TS>), dim3((int)(n_rows < cus ? n_rows : cus)), dim3(FAST_NT), lds, stream,
                        n_rows, mT, (const float*)dy, (TS*)dx);
@@ -839,12 +830,9 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
   hipLaunchKernelGGL((k_merge_cores_last<S3, S2>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, m2);
   if (hipMemsetAsync(dA, 0, BDA + BDB, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
   constexpr size_t lds = (size_t)BigW::TOTAL * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttlinear_wgrad_big<S2, ST, TS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  {
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_ttlinear_wgrad_big<S2, ST, TS>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
-    raised = true;
   }
   int chunks = cus / 4;
   if (chunks < 1) chunks = 1;

@@ -523,14 +523,10 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
   constexpr size_t lds = f10b_lds_bytes<S>();
   static_assert(lds <= 160 * 1024, "LDS image set too large");
   if (lds > 64 * 1024) {
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, false>), lds) != TTRNN_OK ||
+          ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_f10<S, true>), lds) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised = true;
     }
   }
   // TTRNN_DIAG=1: per-phase s_memtime stamps of the first 8 workgroups land in the 4 KB behind the fragments

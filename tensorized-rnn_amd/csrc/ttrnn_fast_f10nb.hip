@@ -237,12 +237,9 @@ static int launch_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void
                       hipStream_t stream) {
   constexpr size_t lds = 2 * f10_lds_bytes<S, KS>();
   static_assert(lds <= 160 * 1024, "two samples must fit the LDS");
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_fwd_f10_nb<S, KS, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  {
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_f10_nb<S, KS, 2>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
-    raised = true;
   }
   hipLaunchKernelGGL((k_lstm_fwd_f10_nb<S, KS, 2>), dim3((rs.B + 1) / 2), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin,
                      (const float*)h0, (const float*)c0, packed_hid, (const xbf8*)wfrag, bh, (float*)out, (float*)hT,

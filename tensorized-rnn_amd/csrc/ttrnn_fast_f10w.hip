@@ -351,12 +351,9 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
     if (dx) kern = k_ttlinear_wgrad_f10<S, TI, true>;
   }
   if (lds > 64 * 1024) {
-    static bool raised[2] = {false, false};
-    if (!raised[dx ? 1 : 0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
+    {
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK)
         return TTRNN_ERR_LAUNCH;
-      raised[dx ? 1 : 0] = true;
     }
   }
   const int cus = device_cu_count();

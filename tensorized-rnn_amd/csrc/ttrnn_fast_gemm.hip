@@ -562,12 +562,9 @@ int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStrea
 template <typename TS>
 static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias, int Hb,
                          float* y, hipStream_t stream, const float* bias_ilv) {
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_split<TS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G_LDS) != hipSuccess)
+  {
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_split<TS>), G_LDS) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
-    raised = true;
   }
   const int KCn = gemm_chunks(K);
   const int MT = M / GT;
@@ -616,17 +613,15 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   float* part = KS > 1 ? scratch : nullptr;
   if (KS > 1 && !part && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess)
     return TTRNN_ERR_LAUNCH;
-  static bool raised[4] = {false, false, false, false};
   const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0);
   const void* fn = di == 0   ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
                    : di == 1 ? reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>)
                    : di == 2 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float>)
                              : reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t>);
   const size_t lds = split ? DenseS::LDS_BYTES : DenseG::LDS_BYTES;
-  if (!raised[di]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  {
+    if (ensure_dynamic_lds(fn, lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
-    raised[di] = true;
   }
   const unsigned grid = (unsigned)(tiles * KS);
   switch (di) {

@@ -734,17 +734,6 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 
 int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }
 
-template <class K>
-int raise_lds(K kern, bool* raised, size_t bytes) {
-  if (bytes > 64 * 1024 && !*raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_LIMIT) !=
-        hipSuccess)
-      return TTRNN_ERR_LAUNCH;
-    *raised = true;
-  }
-  return TTRNN_OK;
-}
-
 // merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
 int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
          hipStream_t stream) {
@@ -871,14 +860,13 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
-  static bool raised[2][3] = {{false, false, false}, {false, false, false}};
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
 #define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? k_g2_fwd<CELLV, TS, UPTV, true, true>                   \
                                                                : k_g2_fwd<CELLV, TS, UPTV, true, false>)                 \
                     : k_g2_fwd<CELLV, TS, UPTV, false, false>;                                                            \
-    if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2,   \
                        ft1, (TS*)out, (TS*)hT, (TS*)cT, reserve);                                                         \
   } while (0)
@@ -914,12 +902,11 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
-  static bool raised[2][3] = {{false, false, false}, {false, false, false}};
   const bool res = P.hid.N2T == 1 && P.hid.bNKB <= 4 && P.hid.bUW * P.hid.bNKB <= G2_PF;
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \
-    if (raise_lds(kern, &raised[CELLV == TTRNN_LSTM ? 0 : 1][SLOT], P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,   \
                        reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
                        (TS*)d_c0, dstate);                                                                                \

@@ -299,12 +299,7 @@ static constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <class K>
 static int set_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_LIMIT) != hipSuccess)
-      return TTRNN_ERR_LAUNCH;
-  }
-  return TTRNN_OK;
+  return ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 static int check_launch() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }

@@ -23,6 +23,11 @@ inline int device_cu_count() {
   return cached[dev];
 }
 
+// Raises a kernel's dynamic-LDS limit (needed above 64 KB) once per (device, kernel): hipFuncSetAttribute acts on the
+// CURRENT device's copy of the function, so the memo is keyed by the device id as well — a process that drives several GPUs
+// (or switches device between calls) gets the limit raised on each of them.  Thread-safe.
+int ensure_dynamic_lds(const void* fn, size_t bytes);
+
 // Where the recurrent kernels get the hoisted input projection from.
 //   in1 == 0: gin = fp32 [B][T][H][4], one gate-interleaved row per (b, t)
 //   in1 == 1: input_size == 1.  W_in x + b is linear in the scalar x: gin holds just TWO rows, chain(1)+b and
