@@ -70,19 +70,25 @@ int opt_get(const char* name, int* value) {
 
 namespace ttrnn {
 int ensure_dynamic_lds(const void* fn, size_t bytes) {
-  if (bytes <= 64 * 1024) return TTRNN_OK;
+  // (small threshold only: a kernel's static __shared__ arrays count against the default 64 KB as well; the limit is set
+  // to exactly what the launch asks for — a blanket 160 KB is refused for kernels that also have static LDS)
+  if (bytes <= 32 * 1024) return TTRNN_OK;
+  struct Entry { int dev; const void* fn; size_t bytes; };
   static std::mutex mu;
-  static std::vector<std::pair<int, const void*>> done;
+  static std::vector<Entry> done;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TTRNN_ERR_LAUNCH; }
   std::lock_guard<std::mutex> lock(mu);
-  for (const auto& e : done)
-    if (e.first == dev && e.second == fn) return TTRNN_OK;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+  Entry* hit = nullptr;
+  for (auto& e : done)
+    if (e.dev == dev && e.fn == fn) { hit = &e; break; }
+  if (hit && hit->bytes >= bytes) return TTRNN_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
     (void)hipGetLastError();
     return TTRNN_ERR_LAUNCH;
   }
-  done.emplace_back(dev, fn);
+  if (hit) hit->bytes = bytes;
+  else done.push_back(Entry{dev, fn, bytes});
   return TTRNN_OK;
 }
 }  // namespace ttrnn
