@@ -69,6 +69,11 @@ typedef struct ttrnn_rnn_desc {
   int32_t has_bias_hid;
   ttrnn_ttm in_w;        /* cell.input_weights                                                 */
   ttrnn_ttm hid_w;       /* cell.hidden_weights                                                */
+  int32_t hid_blocks;    /* 0 / 1: nothing known about hid_w's cores.  G > 1: a PROMISE that hid_w is the direct sum of G
+                          * TT-matrices written as one train — a leading (1 -> G) selector core followed by cores that are
+                          * block-diagonal in their rank indices (rank = G * r, block g couples only to block g): the
+                          * naive per-gate TTLinearSet (tt_linearset.py:5-38) presented as one matrix.  The kernels may
+                          * then skip the zero blocks; results equal those of hid_blocks = 0 on such cores. */
 } ttrnn_rnn_desc;
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -103,6 +103,7 @@ inline int tt_shape_init(TtShape* s, const ttrnn_ttm* w) {
 struct RnnShape {
   int cell, B, T, in, H, G;      // G = 4 (LSTM) / 3 (GRU)
   int has_bias_in, has_bias_hid;
+  int hid_blocks;                // ttrnn_rnn_desc::hid_blocks (1 = general)
   TtShape in_s, hid_s;
   int bs;                        // per-sample stride (floats) of the ping-pong buffers
 };
@@ -119,6 +120,8 @@ inline int rnn_shape_init(RnnShape* r, const ttrnn_rnn_desc* d) {
   r->cell = d->cell; r->B = d->batch; r->T = d->seq_len; r->in = d->input_size; r->H = d->hidden_size;
   r->G = d->cell == TTRNN_LSTM ? 4 : 3;
   r->has_bias_in = d->has_bias_in; r->has_bias_hid = d->has_bias_hid;
+  if (d->hid_blocks < 0 || d->hid_blocks > 8) return TTRNN_ERR_BAD_DESC;
+  r->hid_blocks = d->hid_blocks > 1 ? d->hid_blocks : 1;
   if (r->in_s.in_size != r->in || r->hid_s.in_size != r->H) return TTRNN_ERR_BAD_DESC;
   if (r->in_s.out_size != r->G * r->H || r->hid_s.out_size != r->G * r->H) return TTRNN_ERR_BAD_DESC;
   int mb = r->in_s.maxbuf > r->hid_s.maxbuf ? r->in_s.maxbuf : r->hid_s.maxbuf;

@@ -28,6 +28,11 @@ struct G2Mat {
   int nw;                           // waves per workgroup the plan (tile -> wave assignment, fragment streams) is made for
   int d, s;                         // cores, split point
   int It, Jt, Ih, Jh, R, Rp;        // Rp = R rounded up to 4 (four accumulator registers = four consecutive a)
+  // block-diagonal heads (ttrnn_rnn_desc::hid_blocks = ng > 1): rank index a = (g, a'), a' < Rb; the head couples output
+  // rows of gate g (IhG = Ih / ng rows each) only to ranks of block g.  The contraction index of stage 2 / row index of T2 is
+  // then gate-major, k2 = g*Kg + j_h*Rb + a' (Kg = J_h*Rb, a multiple of 32), and a tile only visits its own gate's
+  // k-blocks: NKBt = Kg / 32 of the NKB = ng * NKBt (forward), bNKBt = IhG / 32 of bNKB (reverse).  ng = 1: Kg = J_h*Rp.
+  int ng, Rb, Kg, IhG, NKBt, bNKBt;
   int in, out;
   // forward stage 1 (fp32 MFMA 16x16x4): tiles (m1 tile, n1 tile), k steps of 4
   int M1T, N1T, KS1, T1;
@@ -67,7 +72,7 @@ inline void g2_split(int nw, int tiles, int nkb, int* ksplit, int* kper, int* kb
   *uw = g2_ceil(*units, nw);
 }
 
-inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw) {
+inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   *m = G2Mat{};
   m->nw = nw;
   if (s.d < 2) return;
@@ -81,7 +86,10 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw) {
     // MFMA work with the tile padding: stage 1 (fp32, 4x the cycles per FLOP of a split bf16 block) + stage 2
     const long c1 = (long)g2_ceil((int)(It * rp), 16) * g2_ceil((int)Jh, 16) * g2_ceil(s.in_size / (int)Jh, 4) * 32;
     const long c2 = (long)g2_ceil(s.out_size / (int)It, 16) * g2_ceil((int)It, 16) * g2_ceil((int)(Jh * rp), 32) * 96;
-    const long cost = c1 + c2;
+    long cost = c1 + c2;
+    // a block-diagonal head (checked below) only visits 1/blocks of the stage-2 k range
+    if (blocks > 1 && sp >= 2 && s.I[0] == blocks && s.J[0] == 1 && s.R[sp] % (4 * blocks) == 0 &&
+        (s.out_size / It / blocks) % 32 == 0 && (Jh * (s.R[sp] / blocks)) % 32 == 0) cost = c1 + c2 / blocks;
     if (best < 0 || cost < best) { best = cost; bs = sp; }
   }
   m->d = s.d; m->s = bs;
@@ -92,18 +100,30 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw) {
   m->in = s.in_size; m->out = s.out_size;
   if (m->R > G2_MAX_R) return;
   for (int k = 0; k <= s.d; ++k) if (s.R[k] > G2_MAX_R) return;
+  // block-diagonal head: usable when the selector core lies in the head (s >= 2) and every block boundary falls on a tile /
+  // k-block boundary; otherwise the joint matrix is treated as dense (correct, 1/ng of the stage-2 work is non-zero)
+  m->ng = 1; m->Rb = m->Rp; m->Kg = m->Jh * m->Rp; m->IhG = m->Ih;
+  if (blocks > 1 && bs >= 2 && s.J[0] == 1 && s.I[0] == blocks && m->R % blocks == 0) {
+    const int rb = m->R / blocks, ihg = m->Ih / blocks;
+    if (rb % 4 == 0 && m->Ih % blocks == 0 && ihg % 32 == 0 && (m->Jh * rb) % 32 == 0) {
+      m->ng = blocks; m->Rb = rb; m->Kg = m->Jh * rb; m->IhG = ihg;
+    }
+  }
   m->M1T = g2_ceil(m->It * m->Rp, 16); m->N1T = g2_ceil(m->Jh, 16); m->KS1 = g2_ceil(m->Jt, 4);
   m->T1 = m->M1T * m->N1T;
-  m->M2T = g2_ceil(m->Ih, 16); m->N2T = g2_ceil(m->It, 16); m->NKB = g2_ceil(m->Jh * m->Rp, 32);
+  m->M2T = g2_ceil(m->Ih, 16); m->N2T = g2_ceil(m->It, 16);
+  m->NKBt = m->ng > 1 ? m->Kg / 32 : g2_ceil(m->Jh * m->Rp, 32);
+  m->NKB = m->ng * m->NKBt;
   m->T2 = m->M2T * m->N2T;
-  g2_split(nw, m->T2, m->NKB, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
+  g2_split(nw, m->T2, m->NKBt, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
   m->JtS = 4 * m->KS1 + 1;
   // row stride = 32 (mod 64) bytes-of-slots: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
   // (MI355X guide, LDS table); with rows 16 bf16 past a multiple of 32 every group covers all 64 banks once (enumerated)
   m->K2S = 32 * m->NKB + 16;
-  m->bM2T = g2_ceil(m->Jh * m->Rp, 16); m->bNKB = g2_ceil(m->Ih, 32);
+  m->bM2T = g2_ceil(m->ng > 1 ? m->ng * m->Kg : m->Jh * m->Rp, 16); m->bNKB = g2_ceil(m->Ih, 32);
+  m->bNKBt = m->ng > 1 ? m->IhG / 32 : m->bNKB;
   m->bT2 = m->bM2T * m->N2T;
-  m->bKBP = g2_ceil(m->bNKB, G2_PF) * G2_PF;
+  m->bKBP = g2_ceil(m->bNKBt, G2_PF) * G2_PF;
   m->bU = m->bT2;
   m->bUW = g2_ceil(m->bU, nw);
   m->IhS = 32 * m->bNKB + 16;
@@ -143,7 +163,7 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   *p = G2Plan{};
   p->cell = rs.cell; p->G = rs.G; p->H = rs.H; p->B = rs.B; p->T = rs.T;
   const int nw = wide ? G2_NW_MAX : 4;
-  g2_plan_mat(&p->hid, rs.hid_s, nw);
+  g2_plan_mat(&p->hid, rs.hid_s, nw, rs.hid_blocks);
   if (!p->hid.ok) return;
   // the gate phase runs on the first 256 threads (1, 2 or 4 hidden units per thread)
   if (rs.H > G2_UPT * 256) return;

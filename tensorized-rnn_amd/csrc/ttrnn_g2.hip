@@ -83,7 +83,7 @@ template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs) {
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
-  const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKB : m.KPER, NKB = REV ? m.bNKB : m.NKB;
+  const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
   const int blk = blockIdx.x;                    // (w*UW + ui)*KBP + kbl
   const int kbl = blk % KBP, ui = (blk / KBP) % UW, w = blk / (KBP * UW);
   const int u = w + ui * m.nw;
@@ -93,15 +93,24 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   if (u < U && kbl < KPER) {
     const int tile = u / KSPLIT, part = u % KSPLIT;
     const int mt = tile / m.N2T;
-    const int kb = part * KPER + kbl;
-    if (kb < NKB) {
+    // block-diagonal heads: a tile walks its own gate's k-blocks only (gate of a forward tile: its output rows; of a reverse
+    // tile: its (g, j_h, a') rows)
+    const int gate = m.ng > 1 ? (16 * mt) / (REV ? m.Kg : m.IhG) : 0;
+    const int kloc = part * KPER + kbl;
+    if (kloc < NKBt) {
+      const int kb = gate * NKBt + kloc;
       const int row = 16 * mt + r;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 32 * kb + 8 * q + e;
         int ih, jh, a;
-        if (REV) { jh = row / m.Rp; a = row % m.Rp; ih = k; }
-        else { ih = row; jh = k / m.Rp; a = k % m.Rp; }
+        // (j_h, a) <-> position: ng = 1: j_h * Rp + a;  ng > 1: g * Kg + j_h * Rb + a'  with a = g * Rb + a'
+        auto unpos = [&](int pos, int& jh_, int& a_) {
+          if (m.ng > 1) { const int g = pos / m.Kg, rem = pos - g * m.Kg; jh_ = rem / m.Rb; a_ = g * m.Rb + rem % m.Rb; }
+          else { jh_ = pos / m.Rp; a_ = pos % m.Rp; }
+        };
+        if (REV) { unpos(row, jh, a); ih = k; }
+        else { ih = row; unpos(k, jh, a); }
         float v = 0.f;
         if (ih < m.Ih && jh < m.Jh && a < m.R) v = Gh[((size_t)ih * m.Jh + jh) * m.R + a];
         __bf16 p0, p1, p2;
@@ -207,7 +216,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
     const int m1 = 16 * mt1 + 4 * (l >> 4), jh = 16 * nt1 + (l & 15);
     const int it = m1 / m.Rp, a = m1 - it * m.Rp;
-    s1off[e] = (it < m.It && jh < m.Jh) ? it * m.K2S + jh * m.Rp + a : -1;
+    const int pos = m.ng > 1 ? (a / m.Rb) * m.Kg + jh * m.Rb + a % m.Rb : jh * m.Rp + a;     // gate-major for block-diagonal heads
+    s1off[e] = (it < m.It && jh < m.Jh) ? it * m.K2S + pos : -1;
   }
   // the tail fragments are read by every wave every step: resident in LDS when they fit (else L1 / L2)
   const bool t1_lds = P.f_t1 > 0;
@@ -266,9 +276,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   // the single stage-2 unit of this wave when its head fragments are register-resident
   const int r_tile = wave / m.KSPLIT, r_part = wave - r_tile * m.KSPLIT;
   const int r_mt = r_tile / m.N2T, r_nt = r_tile - r_mt * m.N2T;
-  const int r_kb0 = r_part * m.KPER;
-  int r_nlive = m.NKB - r_kb0 < m.KPER ? m.NKB - r_kb0 : m.KPER;
+  const int r_kloc = r_part * m.KPER;                                   // first k-block inside the tile's own range
+  int r_nlive = m.NKBt - r_kloc < m.KPER ? m.NKBt - r_kloc : m.KPER;
   r_nlive = (nu_w > 0 && r_nlive > 0) ? r_nlive : 0;
+  const int r_kb0 = (m.ng > 1 ? (16 * r_mt) / m.IhG : 0) * m.NKBt + r_kloc;
   const __bf16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
   const int r_ybase = r_part * GH + (16 * r_mt + 4 * q) * m.It + 16 * r_nt + c;
   int r_ymask = 0;
@@ -335,25 +346,26 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int u = wave + ui * NW;
         const int tile = u / m.KSPLIT, part = u - tile * m.KSPLIT;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
-        const int kb0 = part * m.KPER;
-        const __bf16* brow = img + (16 * nt + c) * m.K2S + 8 * q;
+        const int kloc0 = part * m.KPER;                                              // inside the tile's own k range
+        const int kbase = (m.ng > 1 ? (16 * mt) / m.IhG : 0) * m.NKBt;                // block-diagonal heads: the gate's range
+        const __bf16* brow = img + (16 * nt + c) * m.K2S + 8 * q + 32 * kbase;
         f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
         // operand fragments of the NEXT block are requested before the current block's MFMAs are issued
         xbf8 bf[2][3];
         {
-          const int kbc = kb0 < m.NKB ? kb0 : m.NKB - 1;
+          const int kbc = kloc0 < m.NKBt ? kloc0 : m.NKBt - 1;
 #pragma unroll
           for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbc);
         }
         for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
-            const int kb = kb0 + kbl + j;
-            if (kbl + j + 1 < m.KPER && kb + 1 < m.NKB) {      // the next block is live (padding blocks are never read)
+            const int kb = kloc0 + kbl + j;
+            if (kbl + j + 1 < m.KPER && kb + 1 < m.NKBt) {     // the next block is live (padding blocks are never read)
 #pragma unroll
               for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
-            if (kbl + j < m.KPER && kb < m.NKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            if (kbl + j < m.KPER && kb < m.NKBt) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
             {
               int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
               nxt -= nxt >= total ? total : 0;
@@ -514,8 +526,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   }
   for (int e = tid; e < m.bM2T * 4; e += NT) {
     const int m2 = 16 * (e >> 2) + 4 * (e & 3);
-    const int jh = m2 / m.Rp, a = m2 - jh * m.Rp;
-    t2off[e] = jh < m.Jh ? jh * m.K1S + a : -1;
+    int jh, a;
+    if (m.ng > 1) { const int g = m2 / m.Kg, rem = m2 - g * m.Kg; jh = rem / m.Rb; a = g * m.Rb + rem % m.Rb; }
+    else { jh = m2 / m.Rp; a = m2 - jh * m.Rp; }
+    t2off[e] = (jh < m.Jh && a < m.Rp) ? jh * m.K1S + a : -1;
   }
   const bool t1_lds = P.b_t1 > 0;
   if (t1_lds)
@@ -618,7 +632,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       for (int ui = 0; ui < nu_w; ++ui) {
         const int tile = wave + ui * NW;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
-        const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q;
+        const int kbase = (m.ng > 1 ? (16 * mt) / m.Kg : 0) * m.bNKBt;                 // block-diagonal heads: the gate's i_h range
+        const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q + 32 * kbase;
         f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
         xbf8 bf[2][3];
 #pragma unroll
@@ -627,11 +642,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
             const int kb = kbl + j;
-            if (kb + 1 < m.bNKB) {
+            if (kb + 1 < m.bNKBt) {
 #pragma unroll
               for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
             }
-            if (kb < m.bNKB) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            if (kb < m.bNKBt) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
             int nxt = seq + G2_PF;
             nxt -= nxt >= total ? total : 0;
 #pragma unroll
@@ -902,7 +917,7 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
-  const bool res = P.hid.N2T == 1 && P.hid.bNKB <= 4 && P.hid.bUW * P.hid.bNKB <= G2_PF;
+  const bool res = P.hid.ng == 1 && P.hid.N2T == 1 && P.hid.bNKB <= 4 && P.hid.bUW * P.hid.bNKB <= G2_PF;
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \

@@ -52,8 +52,9 @@ class FusedCellMixin(object):
         if spec is None:
             from ttrnn_hip.functional import RnnLayerSpec, TTSpec
             cin, bin_, chid, bhid = self._operands()
+            blocks = self.hidden_weights.n_gates if hasattr(self.hidden_weights, 'joint_cores') else 1
             spec = RnnLayerSpec(self.kind, self.input_size, self.hidden_size, TTSpec.from_cores(cin),
-                                TTSpec.from_cores(chid), bin_ is not None, bhid is not None)
+                                TTSpec.from_cores(chid), bin_ is not None, bhid is not None, hid_blocks=blocks)
             # plain attribute (bypasses nn.Module bookkeeping); rebuilt lazily after unpickling
             object.__setattr__(self, '_spec_cache', spec)
         return spec

@@ -33,7 +33,7 @@ class RnnDesc(ctypes.Structure):
                 ("batch", ctypes.c_int32), ("seq_len", ctypes.c_int32),
                 ("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
                 ("has_bias_in", ctypes.c_int32), ("has_bias_hid", ctypes.c_int32),
-                ("in_w", TtmDesc), ("hid_w", TtmDesc)]
+                ("in_w", TtmDesc), ("hid_w", TtmDesc), ("hid_blocks", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p

@@ -305,8 +305,10 @@ def tt_linear(x, cores, bias=None, spec=None):
 class RnnLayerSpec(object):
     """Static description of one recurrent layer (cell kind + its two TT matrices)."""
 
-    def __init__(self, cell, input_size, hidden_size, in_spec, hid_spec, has_bias_in, has_bias_hid):
+    def __init__(self, cell, input_size, hidden_size, in_spec, hid_spec, has_bias_in, has_bias_hid, hid_blocks=1):
         assert cell in ("lstm", "gru")
+        # hid_blocks = n_gates: the hidden matrix is TTLinearSet.joint_cores (block-diagonal cores behind a gate-selector core)
+        self.hid_blocks = int(hid_blocks)
         self.cell = cell
         self.n_gates = 4 if cell == "lstm" else 3
         self.input_size = int(input_size)
@@ -332,6 +334,7 @@ class RnnLayerSpec(object):
         d.has_bias_in, d.has_bias_hid = int(self.has_bias_in), int(self.has_bias_hid)
         d.in_w = self.in_spec.desc
         d.hid_w = self.hid_spec.desc
+        d.hid_blocks = self.hid_blocks
         return d
 
 

@@ -644,7 +644,8 @@ def test_runtime_shape_kernels_vs_oracle(kind, inp, H, L, d, r, B, T, new_core):
 
 
 @pytest.mark.parametrize("kind,inp,H,L,d,r,B,T", [("ttlstm", 40, 256, 2, 3, 4, 6, 9), ("ttgru", 28, 128, 1, 2, 5, 7, 11),
-                                                   ("ttlstm", 1, 256, 1, 3, 8, 5, 12)])
+                                                   ("ttlstm", 1, 256, 1, 3, 8, 5, 12), ("ttgru", 1, 256, 1, 3, 8, 4, 10),
+                                                   ("ttlstm", 40, 512, 1, 3, 4, 3, 7)])
 def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     """is_naive=True (TTLinearSet, tt_linearset.py:5-38; LSTM without any bias, GRU with biases: tt_lstm.py:17-21,
     gru.py:150-153) is presented to the library as ONE TT-matrix with a gate-selector core: no per-step Python loop, the
@@ -678,6 +679,14 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
         ref = leaves[key].grad
         assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
     assert seen >= 2 * L * d * (4 if lstm else 3)
+    # the block-diagonal promise (ttrnn_rnn_desc::hid_blocks) only skips exact zeros: same outputs as the dense evaluation
+    spec = m._all_layers[0]._layer_spec()
+    assert spec.hid_blocks == (4 if lstm else 3)
+    for c in m._all_layers:
+        c._layer_spec().hid_blocks = 1          # the cached spec object: the next launches describe a dense joint matrix
+    with torch.no_grad():
+        dense = m(x.to(dev()))[0]
+    assert _maxabs(dense, out.detach()) <= 2e-6
 
 
 def test_runtime_shape_kernels_bf16_storage_and_states():
