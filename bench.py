@@ -35,9 +35,11 @@ import torch  # noqa: E402
 
 FP32_MATH_DESC = {
     None: None,
-    "split": "split (default where a split kernel exists): fp32 operands as 3 bf16 pieces, 6 bf16-MFMA terms, fp32 "
-             "accumulate; error vs float64 equal to the fp32-MFMA mode (tests/test_gpu_parity.py::"
-             "test_split_math_error_vs_fp64_is_fp32_class); TTRNN_FP32_MATH=exact selects the fp32 MFMA",
+    "split": "split (default where a split kernel exists): fp32 operands as error-compensated 16-bit pieces with fp32 "
+             "accumulate - two fp16 pieces / 3 MFMA terms under per-launch power-of-two scales in the fused-core LSTM "
+             "forward kernels (cfg2, cfg4), three bf16 pieces / 6 terms elsewhere; error vs float64 equal to the fp32-MFMA "
+             "mode (tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges); "
+             "TTRNN_FP32_MATH=exact selects the fp32 MFMA",
     "exact": "exact: v_mfma_f32_16x16x4_f32 on fp32 operands",
 }
 
@@ -59,23 +61,26 @@ PEAK_BF16_TFLOPS = 2500.0
 GPU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock; MFMA busy cycles are priced against it
 
 # What the default kernels EXECUTE per sample-timestep on the matrix pipes (MFMA instructions issued, padding and the
-# six split terms included; DESIGN.md section 4 derives each count):
-#   bf16 = v_mfma_f32_16x16x32_bf16 (16 384 FLOP, 16 pipe cycles on one SIMD), fp32 = v_mfma_f32_16x16x4_f32 (2 048 FLOP,
+# split terms included; DESIGN.md section 4 derives each count):
+#   bf16_mfma = 16-bit MFMAs, v_mfma_f32_16x16x32_{bf16,f16} (16 384 FLOP, 16 pipe cycles on one SIMD; `pipe16` names the
+#   operand type), fp32 = v_mfma_f32_16x16x4_f32 (2 048 FLOP,
 #   32 pipe cycles).  `rec_simds` = SIMDs the recurrent kernel's MFMAs of ONE sample are spread over (a workgroup owns a CU).
 EXECUTED = {
-    # cfg2: S2 16 tiles x 2 term-packed MFMAs + S10 4 tiles x 8 k-blocks x 6 terms (k_lstm_fwd_f10)
-    "cfg2": dict(bf16_mfma=32 + 192, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
-                 note="fused core: S2 (K=8, six terms packed into two MFMAs per tile) + S10 (64 x 16 x 256, six split terms)"),
+    # cfg2: S2 16 tiles x 1 term-packed fp16 MFMA + S10 4 tiles x 8 k-blocks x 3 terms (k_lstm_fwd_f10)
+    "cfg2": dict(bf16_mfma=16 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
+                 note="fused core on two-piece fp16 operands: S2 (K=8, four terms packed into one MFMA per tile) + S10 "
+                      "(64 x 16 x 256, three terms x0w0 + x0w1 + x1w0)"),
     # cfg1: stage-wise fp32 kernel: stage 1 8 m-tiles x 4 k-steps, stage 0 2 row tiles x 8 k-steps
     "cfg1": dict(bf16_mfma=0, fp32_mfma=32 + 16, kin_bf16_flop=0, rec_simds=4,
                  note="stage-wise fp32 MFMA kernel (k_lstm_fwd_fused)"),
     # cfg3: bf16 storage, plain bf16 MFMAs: S2 12 tiles + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10)
     "cfg3": dict(bf16_mfma=12 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
                  note="bf16 fused core, no splitting (storage precision is bf16)"),
-    # cfg4, per layer: S2 32 tiles x 2 + S10 4 tiles x 16 k-blocks x 6 terms; K-in: dense split-bf16 GEMM, 6 terms,
-    # contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
-    "cfg4": dict(bf16_mfma=3 * (64 + 384), fp32_mfma=0, kin_bf16_flop=6 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
-                 note="per layer: fused core (r = 16) + K-in as one dense split-bf16 GEMM over B*T rows"),
+    # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense split-bf16 GEMM,
+    # 6 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
+    "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=6 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
+                 pipe16="f16_mfma + bf16_mfma", terms=3,
+                 note="per layer: fused core (r = 16) on two-piece fp16 operands + K-in as one dense split-bf16 GEMM over B*T rows"),
     # cfg5: merged two-core matrix on the fp32 MFMA (8.4 MFLOP per sample-step) + K-in as a dense split-bf16 GEMM
     "cfg5": dict(bf16_mfma=0, fp32_mfma=(2 * 16 * 64 * 2048 + 2 * 64 * 512 * 64) // 2048,
                  kin_bf16_flop=6 * 2 * 1024 * 4096, rec_simds=8,
@@ -395,12 +400,13 @@ def main():
             floor_s = bf16_flop / (PEAK_BF16_TFLOPS * 1e12) + fp32_flop / (PEAK_FP32_TFLOPS * 1e12)
             # matrix-pipe busy share of the RECURRENT kernel on the CUs it occupies: MFMA pipe cycles per SIMD and step
             rec_cycles = (ex["bf16_mfma"] * 16.0 + ex["fp32_mfma"] * 32.0) / ex["rec_simds"]
-            pipes = [n for n, f in (("bf16_mfma", bf16_flop), ("fp32_mfma", fp32_flop)) if f]
+            pipes = [n for n, f in ((ex.get("pipe16", "bf16_mfma"), bf16_flop), ("fp32_mfma", fp32_flop)) if f]
             per_cu = max(1, -(-w["B"] // 256))                 # samples one CU works through per launch
             executed = {"flop": bf16_flop + fp32_flop, "pipe": " + ".join(pipes),
                         "bf16_mfma_flop": bf16_flop, "fp32_mfma_flop": fp32_flop,
-                        "split_terms": 6 if (w["dtype"] == "f32" and bf16_flop) else 1,
-                        "peak": {"bf16_mfma": PEAK_BF16_TFLOPS, "fp32_mfma": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"},
+                        "split_terms": ex.get("terms", 6) if (w["dtype"] == "f32" and bf16_flop) else 1,
+                        "peak": {"bf16_mfma": PEAK_BF16_TFLOPS, "f16_mfma": PEAK_BF16_TFLOPS, "fp32_mfma": PEAK_FP32_TFLOPS,
+                                 "unit": "TFLOP/s"},
                         "pipe_time_at_peak_ms": floor_s * 1e3,
                         "frac": floor_s / step_kernel_s,
                         "mfma_busy_frac": rec_cycles * w["T"] * per_cu / (step_kernel_s * GPU_CLOCK_HZ),

@@ -86,10 +86,17 @@ int ttrnn_device_available(void);
  * torch.backends.*.matmul precision switches — the reference itself has none, its fp32 GEMMs are whatever the
  * BLAS under torch.einsum does, t3nsor/ops.py:85-91):
  *   TTRNN_MATH_EXACT  v_mfma_f32_16x16x4_f32 on the fp32 operands;
- *   TTRNN_MATH_SPLIT  every fp32 operand is split into three bf16 pieces (x = x0+x1+x2) and the product is rebuilt
- *                     from the six bf16 MFMA terms of weight >= 2^-18 with fp32 accumulation: per-product error
- *                     < 2^-24 relative, i.e. fp32-class results at 2.67x less matrix-pipe time.  Only the order and
- *                     grouping of fp32 additions differ from TTRNN_MATH_EXACT.
+ *   TTRNN_MATH_SPLIT  every fp32 operand is split into 16-bit pieces and the product is rebuilt from 16-bit MFMA terms
+ *                     with fp32 accumulation (error-compensated products).  Two flavours, chosen by the kernel:
+ *                     (a) three bf16 pieces (x = x0+x1+x2 exactly), the six terms of weight >= 2^-18: per-product
+ *                         error < 2^-24 relative, 2.67x less matrix-pipe time than TTRNN_MATH_EXACT;
+ *                     (b) the fused-core LSTM forward kernels: two fp16 pieces under per-launch power-of-two scales
+ *                         derived from the cores' and h_0's maxima (no overflow for any finite input), terms
+ *                         x0w0 + x0w1 + x1w0: operands carry >= 22 significand bits, per-product error <= 2^-21.4
+ *                         relative — below the rounding an fp32 sum of 256 such products accumulates anyway; 5.3x
+ *                         less matrix-pipe time.
+ *                     Measured against a float64 evaluation both flavours sit where TTRNN_MATH_EXACT sits (DESIGN.md
+ *                     section 4a; tests/test_gpu_parity.py::test_split_math_*).
  * Default: TTRNN_MATH_SPLIT where a split kernel exists for the descriptor (DESIGN.md section 5 lists them and gives
  * the measured error of both modes against a float64 evaluation); the environment variable TTRNN_FP32_MATH =
  * "exact" | "split", read at first use, overrides the default; ttrnn_set_fp32_math overrides both.

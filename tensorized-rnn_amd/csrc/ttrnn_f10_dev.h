@@ -88,4 +88,81 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __b
   }
 }
 
+// ---- the same step on two-piece fp16 operands (ttrnn_split.h): LSTM forward kernels ---------------------------------
+// Scale header at the start of the fragment workspace, written by k_f10h_scale (powers of two, exact):
+//   [0] 2^a   core 2 (S2's constant operand)      max |G2| 2^a  <= 2^6
+//   [1] 2^sH  h (S2's dynamic operand)            max |h| 2^sH  <= 2^6   (|h_t| < 1; h_0 is the caller's)
+//   [2] 2^sw  the fused core W10                  max |W10| 2^sw <= 2^12 (bound R1 max|G0| max|G1|)
+//   [3] 2^S, [4] 2^-S with S = a + sH + sw: accumulators of S10 are 2^S times the pre-activations
+// so that |T| 2^(a+sH) <= J2 2^12 = 2^15 stays inside fp16 and the second pieces stay normal over >= 9 binades below each
+// operand's maximum (smaller entries keep an ABSOLUTE error of 2^-31 of the maximum or better).
+static constexpr int F10H_HDR_BYTES = 256;
+
+template <class S, int KS>
+constexpr size_t f10h_lds_bytes() {
+  // fp32 h (two parities, for the output store) + fp16 h planes (two parities x two planes) + the two planes of the S10
+  // operand + (KS == 2) the partial accumulators handed from the second k-half's waves to the gate waves
+  return 2 * sizeof(float) * F10<S>::H + 2 * 2 * 2 * (size_t)F10<S>::H + 2 * 2 * (size_t)F10<S>::PLANE +
+         (KS == 2 ? F10<S>::MT * 64 * sizeof(f32x4) : 0);
+}
+
+// term-packed fragment of core 2 for m-tile mt: k-groups w0 | w1 | w0 | w1 against activation groups x0 | x0 | x1 | x1:
+// ONE MFMA = x0 w0 + x0 w1 + x1 w0 + x1 w1
+template <class S>
+__device__ __forceinline__ void f10h_load_w2(xh8& a1, const float* packed, int mt, int lane, float g2scale) {
+  using F = F10<S>;
+  const int r = lane & 15, q = lane >> 4;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 p0, p1;
+    split2h(e < F::J2 ? W2[e * F::M2 + 16 * mt + r] * g2scale : 0.f, p0, p1);
+    a1[e] = (q & 1) ? p1 : p0;
+  }
+}
+template <class S>
+__device__ __forceinline__ f32x4 f10h_s2_mma(const xh8& a1, const _Float16* hp, int rt, int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const xh8 b1 = *reinterpret_cast<const xh8*>(hp + (q >> 1) * F::XPL + (16 * rt + c) * 8);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
+template <class S>
+__device__ __forceinline__ void f10h_s2_store(f32x4 acc, _Float16* img, int mt, int rt, int lane) {
+  using F = F10<S>;
+  const int c = lane & 15, q = lane >> 4;
+  const int row = 16 * rt + c;
+  const int m0 = 16 * mt + 4 * q;
+  const int i = m0 / F::R2, a0 = m0 % F::R2;
+  if (row < F::ROWS2) store_split4_h(img, F::PLANE, x_off<F::K>(i, F::kperm(row, a0)), acc);   // padding rows: no store
+}
+// S10 k-blocks [u0, u0 + NU): (w1, t0) and (w0, t1) into acc_lo, the leading term into acc_hi
+template <class S, int NU>
+__device__ __forceinline__ void f10h_s10_part(const xh8 (&w10)[2][NU], const _Float16* img, int row, int q, int u0,
+                                              f32x4& acc_lo, f32x4& acc_hi) {
+  using F = F10<S>;
+  constexpr int PD = NU < 4 ? NU : 4;
+  xh8 af[NU][2];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+    const int off = x_off<F::K>(row, 32 * (u0 + u) + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) af[u][p] = *reinterpret_cast<const xh8*>(img + p * F::PLANE + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (u + PD < NU) {
+      const int off = x_off<F::K>(row, 32 * (u0 + u + PD) + 8 * q);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) af[u + PD][p] = *reinterpret_cast<const xh8*>(img + p * F::PLANE + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10[1][u], af[u][0], acc_lo, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10[0][u], af[u][1], acc_lo, 0, 0, 0);
+    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w10[0][u], af[u][0], acc_hi, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace ttrnn

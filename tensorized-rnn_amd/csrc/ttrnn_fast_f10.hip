@@ -24,15 +24,20 @@
 // Per timestep:
 //     phase A  all 8 waves   S2: two tiles (16 features x 16 chain rows) per wave, results split into three bf16 planes
 //     barrier
-//     phase B  waves 0-3     S10 on split-bf16 MFMAs (ttrnn_split.h), gates, h_t -> LDS;  wave 7 streams h_{t-1} to `out`
+//     phase B  waves 0-3     S10 on split MFMAs (ttrnn_split.h), gates, h_t -> LDS;  wave 7 streams h_{t-1} to `out`
 //     barrier
 // (Overlapping the second half of phase A with the first half of phase B on the partner waves of each SIMD was
 // measured 5 % SLOWER: the MFMA stream of the gate wave takes half of the SIMD's issue slots from the splitting
 // VALU work, and the extra barrier costs more than the overlap returns.)
-// S2 has a contraction length of only J2 = 8, so its six split terms are PACKED along the 32-wide k of one bf16 MFMA:
-//     MFMA 1:  core groups [w0|w1|w0|w1] x activation groups [x0|x0|x1|x1]  =  x0w0 + x0w1 + x1w0 + x1w1
-//     MFMA 2:  core groups [w2|w0| 0| 0] x activation groups [x0|x2| -| -]  =  x0w2 + x2w0
-// (two bf16 MFMAs = 32 matrix-pipe cycles per tile instead of two fp32 MFMAs = 64).
+// Operand precision of the two LSTM kernels (k_lstm_fwd_f10 here, k_lstm_fwd_f10_nb): every fp32 operand is carried as
+// TWO fp16 pieces under a power-of-two scale fixed per launch (k_f10h_scale; ttrnn_split.h, ttrnn_f10_dev.h) and a
+// product is x0w0 + x0w1 + x1w0 with fp32 accumulation — against three bf16 pieces and six terms this halves S10's
+// matrix-pipe time (768 -> 384 cycles per SIMD and step), the splitting VALU work (7 -> 4 instructions per pair) and the
+// LDS image (3 -> 2 planes): cfg2 0.79 -> 0.56 ms, error against float64 unchanged (= the fp32-MFMA mode's).
+// S2 has a contraction length of only J2 = 8, so ALL FOUR of its terms are PACKED along the 32-wide k of one fp16 MFMA:
+//     core groups [w0|w1|w0|w1] x activation groups [x0|x0|x1|x1]  =  x0w0 + x0w1 + x1w0 + x1w1
+// (16 matrix-pipe cycles per tile instead of two fp32 MFMAs = 64).  k_ttlinear_fwd_f10 and k_gru_fwd_f10 keep bf16 pieces
+// (three / one): the S2 packing of the former is  [w0|w1|w0|w1] x [x0|x0|x1|x1]  +  [w2|w0|0|0] x [x0|x2|-|-].
 // Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 with the hidden chain of t3nsor/ops.py:78-93.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -81,6 +86,82 @@ __global__ void __launch_bounds__(64) k_f10_prep(const float* __restrict__ packe
 template <class S>
 constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
 
+// ---- two-piece fp16 operands (LSTM forward kernels): scale header + fragments --------------------------------------
+// One workgroup: maxima of the three cores and of the caller's h_0 -> the power-of-two scales of ttrnn_f10_dev.h.
+template <class S>
+__global__ void __launch_bounds__(1024) k_f10h_scale(const float* __restrict__ packed, const float* __restrict__ h0,
+                                                     long n_h0, float* __restrict__ hdr) {
+  using F = F10<S>;
+  __shared__ float red[4][16];
+  const int tid = threadIdx.x;
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    for (int i = woff_of<S>(k) + tid; i < woff_of<S>(k + 1); i += 1024) m[k] = fmaxf(m[k], fabsf(packed[i]));
+  if (h0)
+    for (long i = tid; i < n_h0; i += 1024) m[3] = fmaxf(m[3], fabsf(h0[i]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
+    if ((tid & 63) == 0) red[k][tid >> 6] = m[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int w = 1; w < 16; ++w) red[k][0] = fmaxf(red[k][0], red[k][w]);
+    // x < 2^e (frexp: x = f 2^e, f in [0.5, 1)); zero / non-finite maxima fall back to a neutral exponent
+    auto expo = [](float x) {
+      if (!(x > 0.f)) return 0;
+      if (!(x < 3e38f)) return 40;
+      int e;
+      frexpf(x, &e);
+      return e < -40 ? -40 : (e > 40 ? 40 : e);
+    };
+    const int eg = expo(red[2][0]);
+    int eh = expo(red[3][0]);
+    if (eh < 0) eh = 0;                                              // |h_t| < 1 for every t >= 1
+    const int ew = expo((float)F::R1 * red[0][0] * red[1][0]);
+    const int a = 6 - eg, sh = 6 - eh, sw = 12 - ew;
+    hdr[0] = ldexpf(1.f, a);
+    hdr[1] = ldexpf(1.f, sh);
+    hdr[2] = ldexpf(1.f, sw);
+    hdr[3] = ldexpf(1.f, a + sh + sw);
+    hdr[4] = ldexpf(1.f, -(a + sh + sw));
+  }
+}
+
+// The fused core in fragment order (see k_f10_prep), rows pre-multiplied by -log2(e) (gates i, f, o) / 2 log2(e) (gate g)
+// and by the header's 2^sw, as two fp16 pieces:  wfrag[((t*NM + u)*2 + plane)*64 + lane].
+template <class S>
+__global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ packed, const float* __restrict__ hdr,
+                                                  xh8* __restrict__ wfrag) {
+  using F = F10<S>;
+  const int lane = threadIdx.x, u = blockIdx.x % F::NM, t = blockIdx.x / F::NM;
+  const int r = lane & 15, q = lane >> 4;
+  const int m = F::MPG * (r & 3) + 4 * t + (r >> 2);     // gate r&3, feature-within-gate 4t + (r>>2)
+  const int i0 = m / F::I1, i1 = m % F::I1;
+  const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+  const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+  const float sc = ((r & 3) == 2 ? 2.8853900817779268f : -1.4426950408889634f) * hdr[2];
+  xh8 f0, f1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int slot = 4 * u + q;                           // k = 8*slot + e in F10::kperm order
+    const int r2 = (slot / F::HR) * 4 + (e & 3), row2 = 2 * (slot % F::HR) + (e >> 2);
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+    _Float16 p0, p1;
+    split2h(v * sc, p0, p1);
+    f0[e] = p0; f1[e] = p1;
+  }
+  xh8* dst = wfrag + (size_t)((t * F::NM + u) * 2) * 64 + lane;
+  dst[0] = f0; dst[64] = f1;
+}
+
 // KS = 1: waves 0..MT-1 run the whole contraction of their tile.  KS = 2 (long contractions: the resident fragments
 // of a whole tile row would not fit the register file): waves t and t+4 — the two waves of one SIMD — take one half of
 // the k-blocks each, the second hands its partial accumulators to the first through LDS.
@@ -88,7 +169,8 @@ template <class S, int KS, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
-                                                          const xbf8* __restrict__ wfrag,
+                                                          const float* __restrict__ hdr,
+                                                          const xh8* __restrict__ wfrag,
                                                           const float* __restrict__ bias_hid, float* __restrict__ out,
                                                           float* __restrict__ hT, float* __restrict__ cT,
                                                           float* __restrict__ reserve) {
@@ -97,10 +179,11 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   constexpr int H = F::H;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* hbuf = reinterpret_cast<float*>(smem);                             // fp32 h, two parities (output store)
-  __bf16* hpl = reinterpret_cast<__bf16*>(smem + 2 * sizeof(float) * H);    // bf16 planes of h: [parity][3][H]
-  __bf16* img = hpl + 2 * 3 * H;                                            // three bf16 planes [I2][K10]
-  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 3 * F::PLANE);                // KS == 2: partial accumulators
+  float* hbuf = reinterpret_cast<float*>(smem);                                   // fp32 h, two parities (output store)
+  _Float16* hpl = reinterpret_cast<_Float16*>(smem + 2 * sizeof(float) * H);      // fp16 pieces of 2^sH h: [parity][2][H]
+  _Float16* img = hpl + 2 * 2 * H;                                                // two fp16 planes [I2][K10]
+  f32x4* xbuf = reinterpret_cast<f32x4*>(img + 2 * F::PLANE);                      // KS == 2: partial accumulators
+  const float g2s = hdr[0], hsc = hdr[1], psc = hdr[3], usc = hdr[4];             // power-of-two scales (ttrnn_f10_dev.h)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,21 +197,21 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const int u0 = KS == 2 ? (wave >> 2) * NU : 0;         // its first k-block
 
   // S2 fragments of the m-tiles {wave + 8x}
-  xbf8 s1[F::XA], s2[F::XA];
+  xh8 s1[F::XA];
 #pragma unroll
-  for (int x = 0; x < F::XA; ++x) f10_load_w2<S>(s1[x], s2[x], packed_hid, wave + FAST_NW * x, lane);
-  xbf8 w10[3][NU];
+  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, g2s);
+  xh8 w10[2][NU];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w10[p][u][e] = (__bf16)0.f;
+      for (int e = 0; e < 8; ++e) w10[p][u][e] = (_Float16)0.f;
   if (mma_wave) {
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 3 + p) * 64 + lane];
+      for (int p = 0; p < 2; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 2 + p) * 64 + lane];
   }
 
   // the hidden unit of this lane in phase B (waves 0 .. MT-1): hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o.
@@ -141,6 +224,11 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
   float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
+  // The fused core's rows are pre-multiplied (k_f10h_prep) so that an accumulator, times the header's 2^-S, IS the
+  // argument of v_exp_f32: sigmoid(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 1 - 2 / (1 + 2^(2 log2e x)).  The input
+  // projection + biases get the same factors (and 2^S) and enter the MFMA chain as its initial accumulator value, so
+  // nothing but the merge of the two chains stands between the last MFMA and the transcendental unit.
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
   XChunk<float> xq;
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -149,14 +237,15 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
     if (T > 0) {
       if (in1) {
         bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
-        vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
+        vv = (*reinterpret_cast<const f32x4*>(gin + hd * 4) - bb) * gsc;
+        bb = (bb + bh) * gsc;
       } else {
         gi = *reinterpret_cast<const f32x4*>(gin + ((b * T) * H + hd) * 4);
       }
     }
-    __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
-    split3(hst, p0, p1, p2);
-    hpl[hd] = p0; hpl[H + hd] = p1; hpl[2 * H + hd] = p2;
+    _Float16 p0, p1;                                       // parity 0 = h_{-1}
+    split2h(hst * hsc, p0, p1);
+    hpl[hd] = p0; hpl[H + hd] = p1;
     hbuf[hd] = hst;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
@@ -167,8 +256,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   for (int t = 0; t < T; ++t) {
-    const __bf16* hp = hpl + (t & 1) * 3 * H;             // planes of h_{t-1}
-    __bf16* hn = hpl + ((t + 1) & 1) * 3 * H;             // planes of h_t
+    const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
+    _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
     // ---- phase A: S2, all waves ---------------------------------------------------------------------------
     // all MFMAs first, then the splitting: the VALU work of one tile runs in the shadow of the others' MFMA latency
     // instead of behind an s_nop after every pair
@@ -176,14 +265,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       f32x4 t2[F::XA][2];
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        t2[x][0] = f10_s2_mma<S>(s1[x], s2[x], hp, 0, lane);
-        t2[x][1] = f10_s2_mma<S>(s1[x], s2[x], hp, 1, lane);
+        t2[x][0] = f10h_s2_mma<S>(s1[x], hp, 0, lane);
+        t2[x][1] = f10h_s2_mma<S>(s1[x], hp, 1, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        f10_s2_store<S>(t2[x][0], img, wave + FAST_NW * x, 0, lane);
-        f10_s2_store<S>(t2[x][1], img, wave + FAST_NW * x, 1, lane);
+        f10h_s2_store<S>(t2[x][0], img, wave + FAST_NW * x, 0, lane);
+        f10h_s2_store<S>(t2[x][1], img, wave + FAST_NW * x, 1, lane);
       }
     }
     TT_STAMP(0)
@@ -194,8 +283,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (mma_wave) {
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-      f10_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
-      acc = acc_hi + acc_lo;
+      if (gate_wave) {
+        // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
+        const f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+        acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
+      }
+      f10h_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
+      acc = acc_hi * usc + acc_lo * usc;                // 2^-S, exact
       if constexpr (DIAG) {
         asm volatile("" : "+v"(acc));
       }
@@ -207,19 +301,19 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       if (gate_wave) acc += xbuf[tile * 64 + lane];
     }
     if (gate_wave) {
-      if (in1) gi = bb + xq.at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
-      const float ig = fsigmoid(acc[0] + gi[0] + bh[0]);      // lstm.py:26
-      const float fg = fsigmoid(acc[1] + gi[2] + bh[2]);      // lstm.py:27
-      const float gg = ftanh(acc[2] + gi[1] + bh[1]);         // lstm.py:28
-      const float og = fsigmoid(acc[3] + gi[3] + bh[3]);      // lstm.py:29
+      // acc = -log2e * pre-activation (i, f, o) / 2 log2e * pre-activation (g)
+      const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));                // lstm.py:26
+      const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1]));                // lstm.py:27
+      const float gg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2]));  // lstm.py:28
+      const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3]));                // lstm.py:29
       const float cy = fg * cst + ig * gg;                    // lstm.py:31
       const float hy = og * ftanh(cy);                        // lstm.py:32
       if (ok) {
         cst = cy;
         hst = hy;
-        __bf16 p0, p1, p2;
-        split3(hy, p0, p1, p2);
-        hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
+        _Float16 p0, p1;
+        split2h(hy * hsc, p0, p1);
+        hn[hd] = p0; hn[H + hd] = p1;
         hbuf[((t + 1) & 1) * H + hd] = hy;
         if (reserve) {
           float* rv = reserve + (bt * H + hd) * 8;
@@ -609,20 +703,24 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                       hipStream_t stream) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
-  xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
-  hipLaunchKernelGGL((k_f10_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
-  constexpr size_t lds = f10_lds_bytes<S, KS>();
+  static_assert(F10H_HDR_BYTES + (size_t)F10<S>::MT * F10<S>::NM * 2 * 64 * sizeof(xh8) <= f10_wfrag_bytes<S>(), "workspace");
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(1), dim3(1024), 0, stream, packed_hid, (const float*)h0,
+                     (long)rs.B * rs.H, hdr);
+  hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
+  constexpr size_t lds = f10h_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
   const bool dg = opt(OPT_DIAG) && reserve;
   // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
   const int cus = device_cu_count();
   if (rs.B > cus && !dg && !opt(OPT_F10_NB1)) {      // OPT_F10_NB1: A/B switch, one sample per workgroup
-    return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, wfrag, bh, out, hT, cT, reserve, stream);
+    return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
   }
   auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
-                     (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
+                     (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

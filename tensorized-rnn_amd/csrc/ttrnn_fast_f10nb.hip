@@ -20,7 +20,8 @@ template <class S, int KS, int NB>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
-                                                          const xbf8* __restrict__ wfrag,
+                                                          const float* __restrict__ hdr,
+                                                          const xh8* __restrict__ wfrag,
                                                           const float* __restrict__ bias_hid, float* __restrict__ out,
                                                           float* __restrict__ hT, float* __restrict__ cT,
                                                           float* __restrict__ reserve) {
@@ -29,7 +30,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   constexpr bool DIAG = false;
   using F = F10<S>;
   constexpr int H = F::H;
-  constexpr size_t SMP = f10_lds_bytes<S, KS>();                            // LDS bytes of one sample
+  constexpr size_t SMP = f10h_lds_bytes<S, KS>();                           // LDS bytes of one sample
+  const float g2s = hdr[0], hsc = hdr[1], psc = hdr[3], usc = hdr[4];       // power-of-two scales (ttrnn_f10_dev.h)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_nb[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -43,21 +45,21 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   const int u0 = KS == 2 ? (wave >> 2) * NU : 0;         // its first k-block
 
   // S2 fragments of the m-tiles {wave + 8x}
-  xbf8 s1[F::XA], s2[F::XA];
+  xh8 s1[F::XA];
 #pragma unroll
-  for (int x = 0; x < F::XA; ++x) f10_load_w2<S>(s1[x], s2[x], packed_hid, wave + FAST_NW * x, lane);
-  xbf8 w10[3][NU];
+  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, g2s);
+  xh8 w10[2][NU];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w10[p][u][e] = (__bf16)0.f;
+      for (int e = 0; e < 8; ++e) w10[p][u][e] = (_Float16)0.f;
   if (mma_wave) {
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 3 + p) * 64 + lane];
+      for (int p = 0; p < 2; ++p) w10[p][u] = wfrag[(size_t)((tile * F::NM + u0 + u) * 2 + p) * 64 + lane];
   }
 
   // the hidden unit of this lane in phase B (waves 0 .. MT-1): hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o.
@@ -68,11 +70,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, vv = bh, bb = bh;       // slot order i,g,f,o
+  // pre-scaled accumulators, exactly as in k_lstm_fwd_f10 (same arithmetic per sample: the two kernels agree bit for bit)
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
   if (ok) {
     if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
     if (T > 0 && in1) {
       bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
-      vv = *reinterpret_cast<const f32x4*>(gin + hd * 4) - bb;
+      vv = (*reinterpret_cast<const f32x4*>(gin + hd * 4) - bb) * gsc;
+      bb = (bb + bh) * gsc;
     }
   }
   // per-sample state; a workgroup whose second sample lies past the batch carries a copy of the last one (never stored)
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   f32x4 gi[NB];
   XChunk<float> xq[NB];
   float* hbuf[NB];
-  __bf16 *hpl[NB], *img[NB];
+  _Float16 *hpl[NB], *img[NB];
   f32x4* xbuf[NB];
 #pragma unroll
   for (int sm = 0; sm < NB; ++sm) {
@@ -91,9 +96,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
     bs[sm] = live[sm] ? bb0 : (size_t)B - 1;
     unsigned char* base = smem_nb + sm * SMP;
     hbuf[sm] = reinterpret_cast<float*>(base);                                 // fp32 h, two parities (output store)
-    hpl[sm] = reinterpret_cast<__bf16*>(base + 2 * sizeof(float) * H);         // bf16 planes of h: [parity][3][H]
-    img[sm] = hpl[sm] + 2 * 3 * H;                                             // three bf16 planes [I2][K10]
-    xbuf[sm] = reinterpret_cast<f32x4*>(img[sm] + 3 * F::PLANE);                // KS == 2: partial accumulators
+    hpl[sm] = reinterpret_cast<_Float16*>(base + 2 * sizeof(float) * H);       // fp16 pieces of 2^sH h: [parity][2][H]
+    img[sm] = hpl[sm] + 2 * 2 * H;                                             // two fp16 planes [I2][K10]
+    xbuf[sm] = reinterpret_cast<f32x4*>(img[sm] + 2 * F::PLANE);                // KS == 2: partial accumulators
     hst[sm] = (ok && h0) ? h0[bs[sm] * H + hd] : 0.f;
     cst[sm] = (ok && c0) ? c0[bs[sm] * H + hd] : 0.f;
     gi[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -101,9 +106,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
     if (in1) xq[sm].init(xs, bs[sm] * T, T, lane);
     if (ok) {
       if (T > 0 && !in1) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bs[sm] * T) * H + hd) * 4);
-      __bf16 p0, p1, p2;                                     // parity 0 = h_{-1}
-      split3(hst[sm], p0, p1, p2);
-      hpl[sm][hd] = p0; hpl[sm][H + hd] = p1; hpl[sm][2 * H + hd] = p2;
+      _Float16 p0, p1;                                       // parity 0 = h_{-1}
+      split2h(hst[sm] * hsc, p0, p1);
+      hpl[sm][hd] = p0; hpl[sm][H + hd] = p1;
       hbuf[sm][hd] = hst[sm];
     }
   }
@@ -120,18 +125,18 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
     // instead of behind an s_nop after every pair
 #pragma unroll
     for (int sm = 0; sm < NB; ++sm) {
-      const __bf16* hp = hpl[sm] + (t & 1) * 3 * H;       // planes of h_{t-1}
+      const _Float16* hp = hpl[sm] + (t & 1) * 2 * H;     // pieces of h_{t-1}
       f32x4 t2[F::XA][2];
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        t2[x][0] = f10_s2_mma<S>(s1[x], s2[x], hp, 0, lane);
-        t2[x][1] = f10_s2_mma<S>(s1[x], s2[x], hp, 1, lane);
+        t2[x][0] = f10h_s2_mma<S>(s1[x], hp, 0, lane);
+        t2[x][1] = f10h_s2_mma<S>(s1[x], hp, 1, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < F::XA; ++x) {
-        f10_s2_store<S>(t2[x][0], img[sm], wave + FAST_NW * x, 0, lane);
-        f10_s2_store<S>(t2[x][1], img[sm], wave + FAST_NW * x, 1, lane);
+        f10h_s2_store<S>(t2[x][0], img[sm], wave + FAST_NW * x, 0, lane);
+        f10h_s2_store<S>(t2[x][1], img[sm], wave + FAST_NW * x, 1, lane);
       }
     }
     TT_STAMP(0)
@@ -144,8 +149,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
       acc[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (mma_wave) {
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-        f10_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
-        acc[sm] = acc_hi + acc_lo;
+        if (gate_wave) {
+          const f32x4 pre = in1 ? bb + xq[sm].at(t) * vv : (gi[sm] + bh) * gsc;
+          acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
+        }
+        f10h_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
+        acc[sm] = acc_hi * usc + acc_lo * usc;              // 2^-S, exact
         if constexpr (DIAG) {
           asm volatile("" : "+v"(acc[sm]));
         }
@@ -167,20 +176,19 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
 #pragma unroll
       for (int sm = 0; sm < NB; ++sm) {
         const size_t bt = bs[sm] * T + t;
-        __bf16* hn = hpl[sm] + ((t + 1) & 1) * 3 * H;       // planes of h_t
-        if (in1) gi[sm] = bb + xq[sm].at(t) * vv;      // W_in x_t + b_in from the two unit rows (GinSrc)
-        const float ig = fsigmoid(acc[sm][0] + gi[sm][0] + bh[0]);      // lstm.py:26
-        const float fg = fsigmoid(acc[sm][1] + gi[sm][2] + bh[2]);      // lstm.py:27
-        const float gg = ftanh(acc[sm][2] + gi[sm][1] + bh[1]);         // lstm.py:28
-        const float og = fsigmoid(acc[sm][3] + gi[sm][3] + bh[3]);      // lstm.py:29
+        _Float16* hn = hpl[sm] + ((t + 1) & 1) * 2 * H;     // pieces of h_t
+        const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sm][0]));                // lstm.py:26
+        const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sm][1]));                // lstm.py:27
+        const float gg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sm][2]));  // lstm.py:28
+        const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sm][3]));                // lstm.py:29
         const float cy = fg * cst[sm] + ig * gg;                        // lstm.py:31
         const float hy = og * ftanh(cy);                                // lstm.py:32
         if (ok) {
           cst[sm] = cy;
           hst[sm] = hy;
-          __bf16 p0, p1, p2;
-          split3(hy, p0, p1, p2);
-          hn[hd] = p0; hn[H + hd] = p1; hn[2 * H + hd] = p2;
+          _Float16 p0, p1;
+          split2h(hy * hsc, p0, p1);
+          hn[hd] = p0; hn[H + hd] = p1;
           hbuf[sm][((t + 1) & 1) * H + hd] = hy;
           if (reserve && live[sm]) {
             float* rv = reserve + (bt * H + hd) * 8;
@@ -233,21 +241,23 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
 
 template <class S, int KS>
 static int launch_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
-                      const void* wfrag, const float* bh, void* out, void* hT, void* cT, float* reserve,
+                      const void* ws, const float* bh, void* out, void* hT, void* cT, float* reserve,
                       hipStream_t stream) {
-  constexpr size_t lds = 2 * f10_lds_bytes<S, KS>();
+  const float* hdr = reinterpret_cast<const float*>(ws);
+  const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
+  constexpr size_t lds = 2 * f10h_lds_bytes<S, KS>();
   static_assert(lds <= 160 * 1024, "two samples must fit the LDS");
   {
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_f10_nb<S, KS, 2>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((k_lstm_fwd_f10_nb<S, KS, 2>), dim3((rs.B + 1) / 2), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin,
-                     (const float*)h0, (const float*)c0, packed_hid, (const xbf8*)wfrag, bh, (float*)out, (float*)hT,
+                     (const float*)h0, (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT,
                      (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-// wfrag: the fragments k_f10_prep built for this launch (ttrnn_fast_f10.hip)
+// wfrag: scale header + the fragments k_f10h_scale / k_f10h_prep built for this launch (ttrnn_fast_f10.hip)
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
                            hipStream_t stream) {

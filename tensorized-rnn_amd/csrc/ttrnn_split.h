@@ -73,6 +73,47 @@ __device__ __forceinline__ void store_split4(__bf16* img, int plane_elems, int o
   *reinterpret_cast<u32x2*>(img + 2 * plane_elems + off) = u32x2{c0, c1};
 }
 
+// ---- two-piece fp16 split (the fused-core LSTM forward kernels) ------------------------------------------------------
+// v = p0 + p1 + e with p0 = fp16(v), p1 = fp16(v - p0), |e| <= 2^-23 |v| (22+ significand bits; fp32 carries 24) as long
+// as p1 is a normal fp16 number; below that |e| <= 2^-25 in the SCALED domain the caller chooses (powers of two, exact).
+// A product x*w is taken as x0 w0 + x0 w1 + x1 w0 on fp16 MFMAs with fp32 accumulation (error-compensated product of
+// Ootomo & Yokota, "Recovering single precision accuracy from Tensor Cores ...", 2022: x1 w1 <= 2^-22 |x w| is dropped).
+// Measured against a float64 evaluation the recurrence has the same error as a genuine fp32 evaluation (tools/
+// split_precision_sim.py; tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges).
+typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 xh2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {          // v_cvt_pk_f16_f32 (round to nearest even)
+  const xh2 p = __builtin_convertvector(f32x2{a, b}, xh2);
+  return __builtin_bit_cast(unsigned, p);
+}
+// v - (one fp16 half of `pieces`), exact, ONE instruction: v_fma_mix_f32 reads the half as an fp16 source operand
+__device__ __forceinline__ float f16_residual_lo(unsigned pieces, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pieces), "v"(v));
+  return r;
+}
+__device__ __forceinline__ float f16_residual_hi(unsigned pieces, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pieces), "v"(v));
+  return r;
+}
+__device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
+  p0 = pk_f16(a, b);
+  p1 = pk_f16(f16_residual_lo(p0, a), f16_residual_hi(p0, b));
+}
+__device__ __forceinline__ void split2h(float v, _Float16& p0, _Float16& p1) {
+  p0 = (_Float16)v;
+  p1 = (_Float16)(v - (float)p0);
+}
+// four consecutive elements -> two 8-byte stores (planes 0 and 1)
+__device__ __forceinline__ void store_split4_h(_Float16* img, int plane_elems, int off, f32x4 v) {
+  unsigned a0, b0, a1, b1;
+  split_pair_h(v[0], v[1], a0, b0);
+  split_pair_h(v[2], v[3], a1, b1);
+  *reinterpret_cast<u32x2*>(img + off) = u32x2{a0, a1};
+  *reinterpret_cast<u32x2*>(img + plane_elems + off) = u32x2{b0, b1};
+}
+
 // MFMA term order of the six-term product, smallest terms first: (w2,x0) (w0,x2) (w1,x1) | (w1,x0) (w0,x1) | (w0,x0)
 static constexpr int SPLIT_TW[6] = {2, 0, 1, 1, 0, 0};
 static constexpr int SPLIT_TX[6] = {0, 2, 1, 0, 1, 0};

@@ -810,6 +810,52 @@ def test_split_math_large_magnitude_inputs_and_states(wscale, xscale, T, tol):
         assert err <= tol * max(1.0, float(c64.abs().max()))      # relative to the state's scale
 
 
+@pytest.mark.parametrize("case", ["tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes"])
+def test_split_math_operand_ranges(case):
+    """The split mode of the fused-core LSTM kernels multiplies two-piece fp16 operands under power-of-two scales chosen
+    per launch from the cores' and h_0's maxima (ttrnn_f10_dev.h): nothing may overflow fp16's range or lose the small
+    entries, whatever the magnitudes.  Both modes against the float64 oracle, error relative to the largest state."""
+    import ttrnn_hip
+    m = _cfg2_module()
+    torch.manual_seed(17)
+    T = 5
+    h0, c0 = torch.randn(3, 256) * 0.3, torch.randn(3, 256) * 0.3
+    x = torch.randn(3, T, 1)
+    with torch.no_grad():
+        cores = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+        assert len(cores) == 3
+        if case == "tiny_weights":
+            for p in cores:
+                p.mul_(1e-4)                                  # TT-matrix entries ~1e-13
+        elif case == "huge_weights":
+            for p in cores:
+                p.mul_(40.0)                                  # TT-matrix x 64 000: pre-activations in the thousands
+        elif case == "huge_h0":
+            h0 = torch.randn(3, 256) * 300.0                  # far outside (-1, 1): only a caller's h_0 can be
+        elif case == "zero_core":
+            cores[1].zero_()
+        elif case == "mixed_magnitudes":
+            # rows of very different size inside one core: entries down to 1e-9 of the maximum
+            for k, step, f in ((2, 3, 1e-6), (0, 2, 1e-5)):
+                w = cores[k].detach().clone().reshape(-1)
+                w[::step] *= f
+                cores[k].copy_(w.reshape(cores[k].shape))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, _, c64 = _oracle_forward("ttlstm", sd, 1, x.double(), (h0.double(), c0.double()))
+    scale = max(1e-30, float(c64.abs().max()), float(r64.abs().max()))
+    errs = {}
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            out, (hT, cT) = m(x.to(dev()), (h0.to(dev()), c0.to(dev())))
+        assert torch.isfinite(out).all() and torch.isfinite(cT).all(), (case, mode)
+        errs[mode] = max(_maxabs(out, r64), _maxabs(cT, c64))
+    print(case, "max abs error vs float64 (state scale %.3g):" % scale, errs)
+    # saturated gates amplify one fp32 ulp of a pre-activation in the thousands (2e-4) into the state: both modes alike
+    tol = 2e-3 if case in ("huge_weights", "huge_h0") else 2e-6
+    assert errs["split"] <= tol * max(1.0, scale)
+    assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
+
+
 def test_math_modes_full_size_properties(math_mode):
     """cfg2 at full size: batch independence, causality, bitwise repeatability — in either mode."""
     m = _cfg2_module()
