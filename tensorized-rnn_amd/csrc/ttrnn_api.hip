@@ -24,7 +24,7 @@ struct OptTable {
         "TTRNN_FP32_MATH", "TTRNN_FORCE_GENERIC", "TTRNN_NO_GEMM", "TTRNN_NO_IN1", "TTRNN_NO_F10", "TTRNN_NO_G2",
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
-        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32"};
+        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_GEMM_BF16"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
@@ -41,7 +41,7 @@ OptTable& table() {
 }
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
-    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32"};
+    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "gemm_bf16"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }
@@ -395,7 +395,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   // K-in as a dense split-bf16 GEMM (ttrnn_fast_gemm.hip): identity rows, dense W_in, its bf16 planes
   if (f.f10_lin_bytes > 0 && rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 && gemm_split_ok(rs.in, 4 * rs.H))
     f.gemm_bytes = gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) +
-                   gemm_split_plane_bytes(rs.in, 4 * rs.H);
+                   gemm_split_plane_bytes(rs.in, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
   return f;
 }
 
@@ -476,10 +476,19 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
       st = launch_fill_identity(TTRNN_F32, rs.in, gw, (hipStream_t)stream);
       if (st == TTRNN_OK)
         st = launch_ttlinear_fwd_f10(rs.in_s, rs.in, packed_in, nullptr, gw, wdense, lin10, (hipStream_t)stream);
-      if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, (hipStream_t)stream);
-      if (st == TTRNN_OK)
-        st = launch_gemm_split(TTRNN_F32, (int64_t)rs.B * rs.T, rs.in, 4 * rs.H, x, planes, bin, rs.H, gin,
-                               (hipStream_t)stream);
+      // two-piece fp16 operands (three MFMA terms); OPT_GEMM_BF16: the three-piece bf16 GEMM (A/B switch)
+      void* gscr = (char*)planes + gemm_split_plane_bytes(rs.in, 4 * rs.H);
+      if (opt(OPT_GEMM_BF16)) {
+        if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, (hipStream_t)stream);
+        if (st == TTRNN_OK)
+          st = launch_gemm_split(TTRNN_F32, (int64_t)rs.B * rs.T, rs.in, 4 * rs.H, x, planes, bin, rs.H, gin,
+                                 (hipStream_t)stream);
+      } else {
+        if (st == TTRNN_OK) st = launch_gemm_half_prep(wdense, rs.in, 4 * rs.H, planes, gscr, (hipStream_t)stream);
+        if (st == TTRNN_OK)
+          st = launch_gemm_half(TTRNN_F32, (int64_t)rs.B * rs.T, rs.in, 4 * rs.H, x, planes, gscr, bin, rs.H, gin,
+                                (hipStream_t)stream);
+      }
     } else if (fp32_math() == TTRNN_MATH_SPLIT && f.f10_lin_bytes > 0 &&
                f10_ttlinear_fwd_available(rs.in_s, desc->dtype, rs.H, ilv_mode)) {
       // K-in of a layer fed by another layer (in = H): fused-core kernel, split fp32 math

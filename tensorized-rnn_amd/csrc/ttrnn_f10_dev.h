@@ -89,14 +89,49 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __b
 }
 
 // ---- the same step on two-piece fp16 operands (ttrnn_split.h): LSTM forward kernels ---------------------------------
-// Scale header at the start of the fragment workspace, written by k_f10h_scale (powers of two, exact):
-//   [0] 2^a   core 2 (S2's constant operand)      max |G2| 2^a  <= 2^6
-//   [1] 2^sH  h (S2's dynamic operand)            max |h| 2^sH  <= 2^6   (|h_t| < 1; h_0 is the caller's)
-//   [2] 2^sw  the fused core W10                  max |W10| 2^sw <= 2^12 (bound R1 max|G0| max|G1|)
-//   [3] 2^S, [4] 2^-S with S = a + sH + sw: accumulators of S10 are 2^S times the pre-activations
+// Scales (powers of two, exact) derived from the maxima k_f10h_scale leaves at the start of the fragment workspace:
+//   2^a   core 2 (S2's constant operand)      max |G2| 2^a  <= 2^6
+//   2^sH  h (S2's dynamic operand)            max |h| 2^sH  <= 2^6   (|h_t| < 1; h_0 is the caller's)
+//   2^sw  the fused core W10                  max |W10| 2^sw <= 2^12 (bound R1 max|G0| max|G1|)
+//   2^S, 2^-S with S = a + sH + sw: accumulators of S10 are 2^S times the pre-activations
 // so that |T| 2^(a+sH) <= J2 2^12 = 2^15 stays inside fp16 and the second pieces stay normal over >= 9 binades below each
 // operand's maximum (smaller entries keep an ABSOLUTE error of 2^-31 of the maximum or better).
 static constexpr int F10H_HDR_BYTES = 256;
+// The header holds F10H_PARTS partial maxima per quantity ([part][4]: |core 0|, |core 1|, |core 2|, |h_0|), one per
+// workgroup of k_f10h_scale; every consumer (prep and recurrent workgroups) reduces them itself — 16 loads — instead of
+// waiting for one more dependent launch to do it.
+static constexpr int F10H_PARTS = 16;
+struct F10hScales { float g2, h, w, pre, un; };
+__device__ __forceinline__ int f10h_expo(float x) {
+  // x < 2^e (frexp: x = f 2^e, f in [0.5, 1)); zero / non-finite maxima fall back to a neutral exponent
+  if (!(x > 0.f)) return 0;
+  if (!(x < 3e38f)) return 40;
+  int e;
+  frexpf(x, &e);
+  return e < -40 ? -40 : (e > 40 ? 40 : e);
+}
+template <class S>
+__device__ __forceinline__ F10hScales f10h_scales(const float* __restrict__ hdr) {
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < F10H_PARTS; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(hdr + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+  }
+  const int eg = f10h_expo(m[2]);
+  int eh = f10h_expo(m[3]);
+  if (eh < 0) eh = 0;                                              // |h_t| < 1 for every t >= 1
+  const int ew = f10h_expo((float)F10<S>::R1 * m[0] * m[1]);
+  const int a = 6 - eg, sh = 6 - eh, sw = 12 - ew;
+  F10hScales r;
+  r.g2 = ldexpf(1.f, a);
+  r.h = ldexpf(1.f, sh);
+  r.w = ldexpf(1.f, sw);
+  r.pre = ldexpf(1.f, a + sh + sw);
+  r.un = ldexpf(1.f, -(a + sh + sw));
+  return r;
+}
 
 template <class S, int KS>
 constexpr size_t f10h_lds_bytes() {

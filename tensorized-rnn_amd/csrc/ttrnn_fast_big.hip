@@ -537,7 +537,8 @@ bool big_rnn_fwd_available(const RnnShape& rs, int dtype) {
 static int big_merge_level() { return opt(OPT_BIG_MERGE); }
 
 static size_t big_gemm_bytes(const RnnShape& rs) {
-  return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H);
+  return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H) +
+         gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
 }
 
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {
@@ -616,10 +617,18 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
       hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(rs.in < cus ? rs.in : cus), dim3(FAST_NT), lds_lin, stream,
                          (int64_t)rs.in, m2_in, (const TS*)ident, wdense, slab, 2);
       if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-      st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, stream);
-      if (st != TTRNN_OK) return st;
-      st = launch_gemm_split(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, rs.in, 4 * rs.H, x, planes, nullptr, rs.H,
-                             gin, stream);
+      // two-piece fp16 operands (three MFMA terms); OPT_GEMM_BF16: three bf16 pieces, six terms (A/B switch)
+      void* gscr = (char*)planes + gemm_split_plane_bytes(rs.in, 4 * rs.H);
+      const int gdt = sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16;
+      if (opt(OPT_GEMM_BF16)) {
+        st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, stream);
+        if (st != TTRNN_OK) return st;
+        st = launch_gemm_split(gdt, n_rows, rs.in, 4 * rs.H, x, planes, nullptr, rs.H, gin, stream);
+      } else {
+        st = launch_gemm_half_prep(wdense, rs.in, 4 * rs.H, planes, gscr, stream);
+        if (st != TTRNN_OK) return st;
+        st = launch_gemm_half(gdt, n_rows, rs.in, 4 * rs.H, x, planes, gscr, nullptr, rs.H, gin, stream);
+      }
       if (st != TTRNN_OK) return st;
     } else {
       hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(grid2), dim3(FAST_NT), lds_lin, stream, n_rows, m2_in,

@@ -87,19 +87,25 @@ template <class S>
 constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
 
 // ---- two-piece fp16 operands (LSTM forward kernels): scale header + fragments --------------------------------------
-// One workgroup: maxima of the three cores and of the caller's h_0 -> the power-of-two scales of ttrnn_f10_dev.h.
+// F10H_PARTS workgroups: partial maxima of the three cores and of the caller's h_0 (f10h_scales turns them into the
+// power-of-two scales of ttrnn_f10_dev.h).
 template <class S>
-__global__ void __launch_bounds__(1024) k_f10h_scale(const float* __restrict__ packed, const float* __restrict__ h0,
-                                                     long n_h0, float* __restrict__ hdr) {
-  using F = F10<S>;
-  __shared__ float red[4][16];
-  const int tid = threadIdx.x;
+__global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, const float* __restrict__ h0,
+                                                    long n_h0, float* __restrict__ hdr) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, g = blockIdx.x * 256 + tid;
+  constexpr int STRIDE = F10H_PARTS * 256;
   float m[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    for (int i = woff_of<S>(k) + tid; i < woff_of<S>(k + 1); i += 1024) m[k] = fmaxf(m[k], fabsf(packed[i]));
-  if (h0)
-    for (long i = tid; i < n_h0; i += 1024) m[3] = fmaxf(m[3], fabsf(h0[i]));
+    for (int i = woff_of<S>(k) + g; i < woff_of<S>(k + 1); i += STRIDE) m[k] = fmaxf(m[k], fabsf(packed[i]));
+  if (h0) {
+    const long n4 = n_h0 >> 2;                                       // B * H, H a multiple of 4
+    for (long i = g; i < n4; i += STRIDE) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(h0 + 4 * i);
+      m[3] = fmaxf(fmaxf(m[3], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -107,29 +113,7 @@ __global__ void __launch_bounds__(1024) k_f10h_scale(const float* __restrict__ p
     if ((tid & 63) == 0) red[k][tid >> 6] = m[k];
   }
   __syncthreads();
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      for (int w = 1; w < 16; ++w) red[k][0] = fmaxf(red[k][0], red[k][w]);
-    // x < 2^e (frexp: x = f 2^e, f in [0.5, 1)); zero / non-finite maxima fall back to a neutral exponent
-    auto expo = [](float x) {
-      if (!(x > 0.f)) return 0;
-      if (!(x < 3e38f)) return 40;
-      int e;
-      frexpf(x, &e);
-      return e < -40 ? -40 : (e > 40 ? 40 : e);
-    };
-    const int eg = expo(red[2][0]);
-    int eh = expo(red[3][0]);
-    if (eh < 0) eh = 0;                                              // |h_t| < 1 for every t >= 1
-    const int ew = expo((float)F::R1 * red[0][0] * red[1][0]);
-    const int a = 6 - eg, sh = 6 - eh, sw = 12 - ew;
-    hdr[0] = ldexpf(1.f, a);
-    hdr[1] = ldexpf(1.f, sh);
-    hdr[2] = ldexpf(1.f, sw);
-    hdr[3] = ldexpf(1.f, a + sh + sw);
-    hdr[4] = ldexpf(1.f, -(a + sh + sw));
-  }
+  if (tid < 4) hdr[4 * blockIdx.x + tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
 }
 
 // The fused core in fragment order (see k_f10_prep), rows pre-multiplied by -log2(e) (gates i, f, o) / 2 log2(e) (gate g)
@@ -144,7 +128,7 @@ __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ pack
   const int i0 = m / F::I1, i1 = m % F::I1;
   const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
   const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
-  const float sc = ((r & 3) == 2 ? 2.8853900817779268f : -1.4426950408889634f) * hdr[2];
+  const float sc = ((r & 3) == 2 ? 2.8853900817779268f : -1.4426950408889634f) * f10h_scales<S>(hdr).w;
   xh8 f0, f1;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -183,7 +167,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   _Float16* hpl = reinterpret_cast<_Float16*>(smem + 2 * sizeof(float) * H);      // fp16 pieces of 2^sH h: [parity][2][H]
   _Float16* img = hpl + 2 * 2 * H;                                                // two fp16 planes [I2][K10]
   f32x4* xbuf = reinterpret_cast<f32x4*>(img + 2 * F::PLANE);                      // KS == 2: partial accumulators
-  const float g2s = hdr[0], hsc = hdr[1], psc = hdr[3], usc = hdr[4];             // power-of-two scales (ttrnn_f10_dev.h)
+  const F10hScales fsc = f10h_scales<S>(hdr);                                       // power-of-two scales (ttrnn_f10_dev.h)
+  const float g2s = fsc.g2, hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,7 +691,8 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   static_assert(F10H_HDR_BYTES + (size_t)F10<S>::MT * F10<S>::NM * 2 * 64 * sizeof(xh8) <= f10_wfrag_bytes<S>(), "workspace");
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
-  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(1), dim3(1024), 0, stream, packed_hid, (const float*)h0,
+  static_assert(F10H_PARTS * 4 * sizeof(float) <= F10H_HDR_BYTES, "header");
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, (const float*)h0,
                      (long)rs.B * rs.H, hdr);
   hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   constexpr size_t lds = f10h_lds_bytes<S, KS>();

@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   using F = F10<S>;
   constexpr int H = F::H;
   constexpr size_t SMP = f10h_lds_bytes<S, KS>();                           // LDS bytes of one sample
-  const float g2s = hdr[0], hsc = hdr[1], psc = hdr[3], usc = hdr[4];       // power-of-two scales (ttrnn_f10_dev.h)
+  const F10hScales fsc = f10h_scales<S>(hdr);                               // power-of-two scales (ttrnn_f10_dev.h)
+  const float g2s = fsc.g2, hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_nb[];
   const int tid = threadIdx.x, lane = tid & 63;

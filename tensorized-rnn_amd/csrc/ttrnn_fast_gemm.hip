@@ -14,6 +14,7 @@
 // Replaces t3nsor/layers.py:121-127 -> ops.py:54-93 for the input_weights of a whole sequence (lstm.py:25).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
 #include "ttrnn_opts.h"
@@ -30,8 +31,50 @@ constexpr int GK = 32;                        // k per chunk = one bf16 MFMA
 constexpr int GPA = GR * GK, GPB = GF * GK;   // bf16 elements per plane tile (rows / features)
 constexpr int G_BUF = 3 * GPA + 3 * GPB;      // one buffer: three planes of each operand
 constexpr size_t G_LDS = (size_t)2 * G_BUF * sizeof(__bf16);
+constexpr int G_BUF_H = 2 * GPA + 2 * GPB;    // two-piece fp16 operands: two planes of each
+constexpr size_t G_LDS_H = (size_t)2 * G_BUF_H * sizeof(_Float16);
+constexpr int G_PARTS = 64;                   // partial maxima of |W| (scratch header)
+constexpr int G_HDR = 256;                    // bytes in front of the row scales
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Two-piece fp16 variant (HALF): every row of x is multiplied by its own power of two (max |x[n][:]| 2^e <= 2^14), W by
+// one (max |W| 2^ew <= 2^14), both exact; product = x0w0 + x0w1 + x1w0 (ttrnn_split.h), the epilogue undoes the scales.
+// An output's error is relative to (row maximum) x (matrix maximum) — what matters for a gate pre-activation — and equals
+// the bf16 variant's wherever the entries lie within 2^17 of those maxima.
+__device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral
+  if (!(x > 0.f) || !(x < 3e38f)) return 0;
+  int e;
+  frexpf(x, &e);
+  return e;
+}
+__device__ __forceinline__ float g_wscale(const float* __restrict__ parts) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < G_PARTS; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(parts + i);
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  return ldexpf(1.f, 14 - g_expo(m));
+}
 }  // namespace
+
+// partial maxima of |a[0..n)| (strided view: element i at a[(i / M) * sk + (i % M) * sm]) -> parts[G_PARTS]
+__global__ void __launch_bounds__(256) k_absmax_parts(const float* __restrict__ a, size_t n, float* __restrict__ parts) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)G_PARTS * 256) m = fmaxf(m, fabsf(a[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// rs[n] = 2^(14 - e), max_k |x[n][k]| < 2^e: one wave per row, 8 elements per lane and pass (K % 8 == 0)
+template <typename TS>
+__global__ void __launch_bounds__(256) k_row_scales(const TS* __restrict__ x, int64_t n_rows, int K,
+                                                    float* __restrict__ rs);
+
 
 template <typename TS>
 __global__ void __launch_bounds__(256) k_fill_identity(TS* __restrict__ id, int K) {
@@ -59,6 +102,26 @@ __global__ void __launch_bounds__(256) k_gemm_prep(const float* __restrict__ WG,
   *reinterpret_cast<u32x2*>(planes + 2 * pl + off) = u32x2{c0, c1};
 }
 
+__global__ void __launch_bounds__(256) k_gemm_prep_h(const float* __restrict__ WG, int K, int KCn, int M, int64_t sk,
+                                                     int64_t sm, const float* __restrict__ parts,
+                                                     _Float16* __restrict__ planes) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (k quad, m)
+  const int m = (int)(e % M);
+  const int k4 = (int)(e / M) * 4;
+  if (k4 >= 32 * KCn) return;
+  const float ws = g_wscale(parts);
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = k4 + i < K ? WG[(size_t)(k4 + i) * sk + (size_t)m * sm] * ws : 0.f;
+  unsigned a0, b0, a1, b1;
+  split_pair_h(v[0], v[1], a0, b0);
+  split_pair_h(v[2], v[3], a1, b1);
+  const size_t pl = (size_t)KCn * M * 32;
+  const size_t off = ((size_t)(k4 >> 5) * M + m) * 32 + (k4 & 31);
+  *reinterpret_cast<u32x2*>(planes + off) = u32x2{a0, a1};
+  *reinterpret_cast<u32x2*>(planes + pl + off) = u32x2{b0, b1};
+}
+
 __device__ __forceinline__ void ld8(const float* p, size_t i, f32x4& a, f32x4& b) {
   a = *reinterpret_cast<const f32x4*>(p + i);
   b = *reinterpret_cast<const f32x4*>(p + i + 4);
@@ -74,13 +137,20 @@ __device__ __forceinline__ void ld8(const bf16_t* p, size_t i, f32x4& a, f32x4& 
 // y[n][m'] (fp32, row stride M) = sum_k x[n][k] W[k][m'] (+ bias of hidden unit m'/4, slots i,g,f,o when bias != NULL)
 // Workgroup tile: 128 features x 256 rows, wave tile 64 x 64 (4 x 4 MFMA tiles: 24 fragment reads feed 96 MFMAs per
 // chunk — the 128 x 128 tile with 32 x 64 wave tiles spent as long in LDS traffic, splitting and barriers as in MFMAs).
-template <typename TS>
+template <typename TS, bool HALF>
 __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, int KCn, int M,
-                                                        const TS* __restrict__ x, const __bf16* __restrict__ planes,
+                                                        const TS* __restrict__ x, const void* __restrict__ planes_v,
                                                         const TS* __restrict__ bias, int Hb, float* __restrict__ y,
-                                                        const float* __restrict__ bias_ilv) {
+                                                        const float* __restrict__ bias_ilv,
+                                                        const float* __restrict__ scratch) {
+  // HALF: two fp16 pieces, three terms, scales in `scratch` ([0, G_HDR): partial maxima of |W|, then one scale per row)
+  using E = typename std::conditional<HALF, _Float16, __bf16>::type;
+  using X8 = typename std::conditional<HALF, xh8, xbf8>::type;
+  constexpr int NP = HALF ? 2 : 3;
+  constexpr int BUF = NP * (GPA + GPB);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* lds = reinterpret_cast<__bf16*>(smem);           // [buf][A planes 3][256][32], [B planes 3][128][32]
+  E* lds = reinterpret_cast<E*>(smem);                     // [buf][A planes NP][256][32], [B planes NP][128][32]
+  const E* planes = reinterpret_cast<const E*>(planes_v);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,45 +180,57 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   // ---- staging: thread -> (rows tid >> 2 and 128 + (tid >> 2) / feature tid >> 2, k group tid & 3) ------------------------
   const int srow = tid >> 2, skq = tid & 3;
   const TS* xrow[2];
+  float xsc[2] = {1.f, 1.f};                               // HALF: the staged rows' scales
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int64_t an = n0 + srow + 128 * e < n_rows ? n0 + srow + 128 * e : n_rows - 1;
     xrow[e] = x + (size_t)an * K;
+    if constexpr (HALF) xsc[e] = scratch[G_HDR / 4 + an];
   }
   const size_t plane_elems = (size_t)KCn * M * 32;
-  const __bf16* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
+  const E* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
   f32x4 xa[2], xb[2];
-  xbf8 wb[3];
+  X8 wb[NP];
   auto stage_load = [&](int kc) {
     const int k = kc * GK + 8 * skq;
     const int kcl = k + 8 <= K ? k : (K >= 8 ? K - 8 : 0);      // unconditional loads; out-of-range groups are zeroed below
 #pragma unroll
     for (int e = 0; e < 2; ++e) ld8(xrow[e], (size_t)kcl, xa[e], xb[e]);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      wb[p] = *reinterpret_cast<const xbf8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
+    for (int p = 0; p < NP; ++p)
+      wb[p] = *reinterpret_cast<const X8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
   };
   auto stage_store = [&](int buf, int kc) {
-    __bf16* As = lds + buf * G_BUF;
-    __bf16* Bs = As + 3 * GPA;
+    E* As = lds + buf * BUF;
+    E* Bs = As + NP * GPA;
     const int k = kc * GK + 8 * skq;
     const float keep = k + 8 <= K ? 1.0f : 0.0f;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const f32x4 va = xa[e] * keep, vb = xb[e] * keep;
-      unsigned p0[4], p1[4], p2[4];
-      split_pair(va[0], va[1], p0[0], p1[0], p2[0]);
-      split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
-      split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
-      split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
+      const f32x4 va = xa[e] * (keep * xsc[e]), vb = xb[e] * (keep * xsc[e]);
       const int off = x_off<GK>(srow + 128 * e, 8 * skq);   // 16-byte slots XOR-swizzled per row group (ttrnn_split.h)
-      *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
-      *reinterpret_cast<u32x4*>(As + GPA + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
-      *reinterpret_cast<u32x4*>(As + 2 * GPA + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      if constexpr (HALF) {
+        unsigned p0[4], p1[4];
+        split_pair_h(va[0], va[1], p0[0], p1[0]);
+        split_pair_h(va[2], va[3], p0[1], p1[1]);
+        split_pair_h(vb[0], vb[1], p0[2], p1[2]);
+        split_pair_h(vb[2], vb[3], p0[3], p1[3]);
+        *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
+        *reinterpret_cast<u32x4*>(As + GPA + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      } else {
+        unsigned p0[4], p1[4], p2[4];
+        split_pair(va[0], va[1], p0[0], p1[0], p2[0]);
+        split_pair(va[2], va[3], p0[1], p1[1], p2[1]);
+        split_pair(vb[0], vb[1], p0[2], p1[2], p2[2]);
+        split_pair(vb[2], vb[3], p0[3], p1[3], p2[3]);
+        *reinterpret_cast<u32x4*>(As + off) = u32x4{p0[0], p0[1], p0[2], p0[3]};
+        *reinterpret_cast<u32x4*>(As + GPA + off) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+        *reinterpret_cast<u32x4*>(As + 2 * GPA + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      }
     }
     const int offb = x_off<GK>(srow, 8 * skq);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<xbf8*>(Bs + p * GPB + offb) = wb[p];
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<X8*>(Bs + p * GPB + offb) = wb[p];
   };
 
   // one fp32 accumulator per tile: the six terms of a chunk are added smallest first (SPLIT_TW / SPLIT_TX order)
@@ -164,30 +246,47 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   for (int kc = 0; kc < KCn; ++kc) {
     const int buf = kc & 1;
     lds_barrier();                                         // chunk kc is in `buf`; nobody reads the other buffer any more
-    const __bf16* As = lds + buf * G_BUF;
-    const __bf16* Bs = As + 3 * GPA;
-    xbf8 wf[4][3];
+    const E* As = lds + buf * BUF;
+    const E* Bs = As + NP * GPA;
+    X8 wf[4][NP];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        wf[mi][p] = *reinterpret_cast<const xbf8*>(Bs + p * GPB + x_off<GK>(wm * 64 + 16 * mi + c, 8 * q));
+      for (int p = 0; p < NP; ++p)
+        wf[mi][p] = *reinterpret_cast<const X8*>(Bs + p * GPB + x_off<GK>(wm * 64 + 16 * mi + c, 8 * q));
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
-      xbf8 af[3];
+      X8 af[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        af[p] = *reinterpret_cast<const xbf8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
+      for (int p = 0; p < NP; ++p)
+        af[p] = *reinterpret_cast<const X8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
       // the next chunk's split + LDS stores (other buffer; its data was requested a chunk ago) ride inside the MFMA stream
       if (ri == 1) {                                        // unconditional: no branch inside the chunk
         stage_store(buf ^ 1, kc + 1);                       // past the end it fills the idle buffer with a masked chunk
         stage_load(kc + 2 < KCn ? kc + 2 : KCn - 1);
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
+        if constexpr (HALF) {
+          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][1], af[0], acc[mi][ri], 0, 0, 0);
+          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[1], acc[mi][ri], 0, 0, 0);
+          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[0], acc[mi][ri], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 6; ++s)
-          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc[mi][ri], 0, 0, 0);
+          for (int s = 0; s < 6; ++s)
+            acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc[mi][ri], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // HALF: undo the scales (powers of two: exact), one factor per output row
+  float unsc[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (HALF) {
+    const float wun = 1.0f / g_wscale(scratch);
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const int64_t n = n0 + wr * 64 + 16 * ri + c;
+      unsc[ri] = wun / scratch[G_HDR / 4 + (n < n_rows ? n : n_rows - 1)];
     }
   }
   // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 64wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
@@ -204,8 +303,27 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] + bh;
+      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] * unsc[ri] + bh;
     }
+  }
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(256) k_row_scales(const TS* __restrict__ x, int64_t n_rows, int K,
+                                                    float* __restrict__ rs) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  for (int64_t n = w; n < n_rows; n += nw) {
+    float m = 0.f;
+    for (int k = 8 * lane; k < K; k += 512) {
+      f32x4 a, b;
+      ld8(x + (size_t)n * K, (size_t)k, a, b);
+      m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
+                         fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3])))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) rs[n] = ldexpf(1.f, 14 - g_expo(m));
   }
 }
 
@@ -559,11 +677,25 @@ int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStrea
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-template <typename TS>
+// two-piece fp16 variant: scratch = G_HDR bytes (partial maxima of |W|) + one fp32 scale per row of x
+size_t gemm_half_scratch_bytes(int64_t n_rows) { return al256g((size_t)G_HDR + (size_t)(n_rows > 0 ? n_rows : 0) * sizeof(float)); }
+
+int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream, bool transposed) {
+  const int KCn = gemm_chunks(K);
+  const size_t threads = (size_t)KCn * 8 * M;
+  // the dense matrix is contiguous either way ([K][M] or [M][K]): its maximum does not care about the view
+  hipLaunchKernelGGL(k_absmax_parts, dim3(G_PARTS), dim3(256), 0, stream, WG, (size_t)K * M, (float*)scratch);
+  hipLaunchKernelGGL(k_gemm_prep_h, dim3((int)((threads + 255) / 256)), dim3(256), 0, stream, WG, K, KCn, M,
+                     (int64_t)(transposed ? 1 : M), (int64_t)(transposed ? K : 1), (const float*)scratch,
+                     (_Float16*)planes);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+template <typename TS, bool HALF = false>
 static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias, int Hb,
-                         float* y, hipStream_t stream, const float* bias_ilv) {
+                         float* y, hipStream_t stream, const float* bias_ilv, const float* scratch = nullptr) {
   {
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_split<TS>), G_LDS) != TTRNN_OK)
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_split<TS, HALF>), HALF ? G_LDS_H : G_LDS) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
   }
   const int KCn = gemm_chunks(K);
@@ -576,9 +708,22 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
   } else {
     grid = (int64_t)MT * RT;
   }
-  hipLaunchKernelGGL(k_gemm_split<TS>, dim3((unsigned)grid), dim3(FAST_NT), G_LDS, stream, n_rows, K, KCn, M,
-                     (const TS*)x, (const __bf16*)planes, (const TS*)bias, Hb, y, bias_ilv);
+  hipLaunchKernelGGL((k_gemm_split<TS, HALF>), dim3((unsigned)grid), dim3(FAST_NT), HALF ? G_LDS_H : G_LDS, stream, n_rows,
+                     K, KCn, M, (const TS*)x, planes, (const TS*)bias, Hb, y, bias_ilv, scratch);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
+                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
+  if (n_rows <= 0) return TTRNN_OK;
+  float* rs = (float*)scratch + G_HDR / 4;
+  const int grid = (int)((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
+  if (dtype == TTRNN_F32) {
+    hipLaunchKernelGGL(k_row_scales<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, n_rows, K, rs);
+    return launch_gemm_t<float, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
+  }
+  hipLaunchKernelGGL(k_row_scales<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, n_rows, K, rs);
+  return launch_gemm_t<bf16_t, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
 }
 
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,

@@ -807,7 +807,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
-    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H);
+    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
     w.xpad = inp != rs.in ? g2_al((size_t)rs.B * rs.T * inp * 4) : 0;
   }
   w.lin = g2_al(plan_ttlinear_fwd(rs.in_s, in1 ? 1 : rs.in).ws_bytes);
@@ -858,7 +858,11 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     const LinPlan lp = plan_ttlinear_fwd(rs.in_s, rs.in);
     if (st == TTRNN_OK)
       st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, rs.in, packed_in, nullptr, ident, wdense, linws, stream, H, ilv);
-    if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, inp, 4 * H, planes, stream);
+    void* gscr = (char*)planes + gemm_split_plane_bytes(inp, 4 * H);      // two-piece fp16 GEMM: scales
+    const bool ghalf = !opt(OPT_GEMM_BF16);
+    if (st == TTRNN_OK)
+      st = ghalf ? launch_gemm_half_prep(wdense, inp, 4 * H, planes, gscr, stream)
+                 : launch_gemm_split_prep(wdense, inp, 4 * H, planes, stream);
     const void* xg = x;
     if (st == TTRNN_OK && inp != rs.in) {
       const long n = (long)rows * inp;
@@ -867,7 +871,9 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
       st = check();
       xg = xpad;
     }
-    if (st == TTRNN_OK) st = launch_gemm_split(dtype, rows, inp, 4 * H, xg, planes, nullptr, 0, gin, stream, bilv);
+    if (st == TTRNN_OK)
+      st = ghalf ? launch_gemm_half(dtype, rows, inp, 4 * H, xg, planes, gscr, nullptr, 0, gin, stream, bilv)
+                 : launch_gemm_split(dtype, rows, inp, 4 * H, xg, planes, nullptr, 0, gin, stream, bilv);
   }
   if (st != TTRNN_OK) return st;
   const xbf8* fs2;

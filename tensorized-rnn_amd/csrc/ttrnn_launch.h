@@ -141,6 +141,14 @@ int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStrea
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
                       int Hb, float* y, hipStream_t stream, const float* bias_ilv = nullptr);
 
+// the same GEMM on two-piece fp16 operands (three MFMA terms instead of six; per-row scales of x and one scale of W,
+// powers of two): forward input projections.  `planes` as above (two of the three planes are used).
+size_t gemm_half_scratch_bytes(int64_t n_rows);
+int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream,
+                          bool transposed = false);
+int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
+                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv = nullptr);
+
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
