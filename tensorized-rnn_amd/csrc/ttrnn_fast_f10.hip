@@ -702,6 +702,8 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
   const int cus = device_cu_count();
   if (rs.B > cus && !dg && !opt(OPT_F10_NB1)) {      // OPT_F10_NB1: A/B switch, one sample per workgroup
+    // four-wave workgroups, two per CU (ttrnn_fast_f10q.hip); OPT_F10_NB2: two samples per eight-wave workgroup (A/B)
+    if (!opt(OPT_F10_NB2)) return launch_rnn_fwd_f10_q(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
     return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
   }
   auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;

@@ -1,0 +1,192 @@
+// ttrnn_fast_f10q.hip — the fused-core TT-LSTM forward kernel as FOUR-wave workgroups, two of them per CU (gfx950).
+//
+// With more samples than CUs the eight-wave kernel (ttrnn_fast_f10.hip: one workgroup owns a CU) runs the samples of a CU one
+// after the other, each alone with its barriers, LDS round trips and transcendental chains while the matrix pipe idles
+// three quarters of the time; the two-samples-per-workgroup variant (ttrnn_fast_f10nb.hip) shares those phases but keeps
+// the two samples in lockstep.  Here one sample is ONE workgroup of four waves — one per SIMD, every wave owns one S10
+// feature tile with the whole contraction (resident fragments of two fp16 pieces: 64 / 128 VGPRs for r = 8 / 16) and is a
+// gate wave — at no more than 256 VGPRs, so two workgroups share a CU and run out of phase: one sample's MFMA stream fills
+// the other's barrier waits, LDS latencies and gate chains.  Same arithmetic, bit for bit, as k_lstm_fwd_f10 (for r = 16 the
+// contraction is summed in the two halves that kernel's wave pairs produce).
+// Replaces the same reference code as ttrnn_fast_f10.hip: tensorized_rnn/lstm.py:23-32,123-133 + t3nsor/ops.py:78-93.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10.h"
+#include "ttrnn_f10_dev.h"
+
+namespace ttrnn {
+
+constexpr int QW = 4;                 // waves per workgroup
+
+template <class S>
+constexpr size_t f10q_lds_bytes() {
+  // fp16 pieces of 2^sH h (two parities x two planes) + the two planes of the S10 operand
+  return 2 * 2 * 2 * (size_t)F10<S>::H + 2 * 2 * (size_t)F10<S>::PLANE;
+}
+
+// KH = 1: one accumulation over all k-blocks (= k_lstm_fwd_f10<S, 1>);  KH = 2: the two halves of k_lstm_fwd_f10<S, 2>
+template <class S, int KH>
+__global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
+                                                               const float* __restrict__ c0,
+                                                               const float* __restrict__ packed_hid,
+                                                               const float* __restrict__ hdr,
+                                                               const xh8* __restrict__ wfrag,
+                                                               const float* __restrict__ bias_hid,
+                                                               float* __restrict__ out, float* __restrict__ hT,
+                                                               float* __restrict__ cT, float* __restrict__ reserve) {
+  static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
+  using F = F10<S>;
+  static_assert(F::MT == QW && F::MT2 % QW == 0 && F::NM % KH == 0, "one S10 tile per wave");
+  constexpr int H = F::H;
+  constexpr int XQ = F::MT2 / QW;                        // S2 m-tiles per wave
+  constexpr int NH = F::NM / KH;                         // k-blocks per half
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+  _Float16* hpl = reinterpret_cast<_Float16*>(smem_q);   // fp16 pieces of 2^sH h: [parity][2][H]
+  _Float16* img = hpl + 2 * 2 * H;                       // two fp16 planes [I2][K10]
+  const F10hScales fsc = f10h_scales<S>(hdr);
+  const float hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  xh8 s1[XQ];
+#pragma unroll
+  for (int x = 0; x < XQ; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + QW * x, lane, fsc.g2);
+  xh8 w10[KH][2][NH];
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int u = 0; u < NH; ++u)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w10[kh][p][u] = wfrag[(size_t)((wave * F::NM + kh * NH + u) * 2 + p) * 64 + lane];
+
+  // the hidden unit of this lane: hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o; gin slots i,g,f,o
+  const float* __restrict__ gin = gs.gin;
+  const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
+  const bool in1 = gs.in1 != 0;
+  const bool ok = c < F::I2;
+  const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
+  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
+  float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
+  f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
+  XChunk<float> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
+  if (ok) {
+    if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
+    if (T > 0) {
+      if (in1) {
+        bb = *reinterpret_cast<const f32x4*>(gin + (H + hd) * 4);
+        vv = (*reinterpret_cast<const f32x4*>(gin + hd * 4) - bb) * gsc;
+        bb = (bb + bh) * gsc;
+      } else {
+        gi = *reinterpret_cast<const f32x4*>(gin + ((b * T) * H + hd) * 4);
+      }
+    }
+    _Float16 p0, p1;                                       // parity 0 = h_{-1}
+    split2h(hst * hsc, p0, p1);
+    hpl[hd] = p0; hpl[H + hd] = p1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
+  lds_barrier();
+  // (Delaying the workgroup in the odd wave slot by half a step — so that the two workgroups of a CU start out of phase —
+  // changed nothing: measured 1.71 ms for every delay between 0 and 3 800 cycles on cfg4.)
+
+  const int row10 = c < F::I2 ? c : F::I2 - 1;
+  for (int t = 0; t < T; ++t) {
+    const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
+    _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
+    // ---- phase A: S2, two m-tiles at a time (MFMAs first, then the splitting) -------------------------------------
+#pragma unroll
+    for (int x0 = 0; x0 < XQ; x0 += 2) {
+      f32x4 t2[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        t2[x][0] = f10h_s2_mma<S>(s1[x0 + x], hp, 0, lane);
+        t2[x][1] = f10h_s2_mma<S>(s1[x0 + x], hp, 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        f10h_s2_store<S>(t2[x][0], img, wave + QW * (x0 + x), 0, lane);
+        f10h_s2_store<S>(t2[x][1], img, wave + QW * (x0 + x), 1, lane);
+      }
+    }
+    lds_barrier();
+    const size_t bt = b * T + t;
+    // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
+    f32x4 acc;
+    {
+      // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
+      const f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
+      f10h_s10_part<S, NH>(w10[0], img, row10, q, 0, acc_lo, acc_hi);
+      acc = acc_hi * usc + acc_lo * usc;                  // 2^-S, exact
+      if constexpr (KH == 2) {
+        f32x4 bl = f32x4{0.f, 0.f, 0.f, 0.f}, bhh = bl;
+        f10h_s10_part<S, NH>(w10[1], img, row10, q, NH, bl, bhh);
+        acc += bhh * usc + bl * usc;
+      }
+    }
+    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));                // lstm.py:26
+    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1]));                // lstm.py:27
+    const float gg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2]));  // lstm.py:28
+    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3]));                // lstm.py:29
+    const float cy = fg * cst + ig * gg;                    // lstm.py:31
+    const float hy = og * ftanh(cy);                        // lstm.py:32
+    if (ok) {
+      cst = cy;
+      hst = hy;
+      _Float16 p0, p1;
+      split2h(hy * hsc, p0, p1);
+      hn[hd] = p0; hn[H + hd] = p1;
+      out[bt * H + hd] = hy;                                // outputs[:, t, :] (lstm.py:133): 256 contiguous bytes per wave
+      if (reserve) {
+        float* rv = reserve + (bt * H + hd) * 8;
+        *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
+        rv[4] = cy;
+      }
+      if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
+    }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
+    lds_barrier();
+  }
+  if (ok) {
+    if (hT) hT[b * H + hd] = hst;
+    if (cT) cT[b * H + hd] = cst;
+  }
+}
+
+template <class S, int KH>
+static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid, const void* ws,
+                    const float* bh, void* out, void* hT, void* cT, float* reserve, hipStream_t stream) {
+  const float* hdr = reinterpret_cast<const float*>(ws);
+  const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
+  constexpr size_t lds = f10q_lds_bytes<S>();
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_f10q<S, KH>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL((k_lstm_fwd_f10q<S, KH>), dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
+                     (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// ws: scale header + the fragments k_f10h_scale / k_f10h_prep built for this launch (ttrnn_fast_f10.hip)
+int launch_rnn_fwd_f10_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                         const void* ws, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                         hipStream_t stream) {
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
+    return launch_q<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
+  if (shape_matches<ShpH256R16L>(rs.hid_s))
+    return launch_q<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn

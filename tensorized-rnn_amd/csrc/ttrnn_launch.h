@@ -116,6 +116,9 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
                            hipStream_t stream);
+int launch_rnn_fwd_f10_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                           const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                           hipStream_t stream);
 
 // the same fused-core recurrent kernel on the fp32 MFMA (TTRNN_MATH_EXACT; ttrnn_fast_f10x.hip); ws as above
 bool f10x_rnn_fwd_available(const RnnShape& rs, int dtype);

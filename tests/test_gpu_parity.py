@@ -856,6 +856,40 @@ def test_split_math_operand_ranges(case):
     assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_half_piece_gemm_input_ranges(storage):
+    """The batched input projection runs as a GEMM on two-piece fp16 operands with one power-of-two scale per row of x and
+    one for the matrix (ttrnn_fast_gemm.hip): rows of wildly different magnitude, zero rows and outliers inside a row
+    must come out as they do with three bf16 pieces (option gemm_bf16) and as the float64 oracle says."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(5)
+    kind = "ttlstm" if storage == "f32" else "ttgru"
+    meta = dict(kind=kind, input_size=40, hidden_size=256 if storage == "f32" else 512, num_layers=1, n_cores=3, tt_rank=16 if storage == "f32" else 4)
+    m = build_module(meta, dev())
+    B, T = 64, 16
+    x = torch.randn(B, T, 40) * (10.0 ** (torch.rand(B, T, 1) * 9 - 6))      # row scales 1e-6 .. 1e3
+    x[3, 2] = 0.0
+    x[5, 1, 7] = 2.0e4                                                         # outlier inside a small row
+    x[:, 0] *= 1e-3
+    if storage == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    ref = _oracle_forward(kind, sd, 1, x.double())[0]
+    outs = {}
+    for name, val in (("half", 0), ("bf16x3", 1)):
+        with ttrnn_hip.option("gemm_bf16", val), torch.no_grad():
+            outs[name] = m(x.to(dev()))[0].float()
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) in ("fused_core", "runtime_mfma")
+    # rows scaled by 1e3 put pre-activations in the thousands, where one fp32 ulp is 1e-4: both variants sit at 2e-5
+    tol = 1e-4 if storage == "f32" else 2e-2
+    errs = {k: _maxabs(v, ref) for k, v in outs.items()}
+    print(storage, "max abs error vs float64:", errs, "between the two:", _maxabs(outs["half"], outs["bf16x3"]))
+    assert torch.isfinite(outs["half"]).all()
+    assert errs["half"] <= tol and errs["half"] <= 2.0 * errs["bf16x3"] + (2e-7 if storage == "f32" else 4e-3)
+
+
 def test_math_modes_full_size_properties(math_mode):
     """cfg2 at full size: batch independence, causality, bitwise repeatability — in either mode."""
     m = _cfg2_module()
