@@ -76,15 +76,17 @@ EXECUTED = {
     # cfg3: bf16 storage, plain bf16 MFMAs: S2 12 tiles + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10)
     "cfg3": dict(bf16_mfma=12 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
                  note="bf16 fused core, no splitting (storage precision is bf16)"),
-    # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense split-bf16 GEMM,
-    # 6 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
-    "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=6 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
-                 pipe16="f16_mfma + bf16_mfma", terms=3,
-                 note="per layer: fused core (r = 16) on two-piece fp16 operands + K-in as one dense split-bf16 GEMM over B*T rows"),
-    # cfg5: merged two-core matrix on the fp32 MFMA (8.4 MFLOP per sample-step) + K-in as a dense split-bf16 GEMM
+    # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense GEMM on fp16 pieces,
+    # 3 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
+    "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=3 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
+                 pipe16="f16_mfma", terms=3,
+                 note="per layer: fused core (r = 16) on two-piece fp16 operands (four-wave workgroups, two per CU) + K-in as one "
+                      "dense GEMM over B*T rows on two-piece fp16 operands (three terms)"),
+    # cfg5: merged two-core matrix on the fp32 MFMA (8.4 MFLOP per sample-step) + K-in as a dense GEMM on fp16 pieces
     "cfg5": dict(bf16_mfma=0, fp32_mfma=(2 * 16 * 64 * 2048 + 2 * 64 * 512 * 64) // 2048,
-                 kin_bf16_flop=6 * 2 * 1024 * 4096, rec_simds=8,
-                 note="K-rec: merged 2-core chain on the fp32 MFMA, two workgroups per sample; K-in: dense split-bf16 GEMM"),
+                 kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, pipe16="f16_mfma", terms=3,
+                 note="K-rec: merged 2-core chain on the fp32 MFMA, two workgroups per sample; K-in: dense GEMM on two-piece "
+                      "fp16 operands (three terms)"),
 }
 
 
