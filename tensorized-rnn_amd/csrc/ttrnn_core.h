@@ -152,7 +152,22 @@ TT_HD void stage_fwd(int tid, int nthr, const float* A, int sA, float* C, int sC
     const float* Ab = A + (size_t)s * sA + (size_t)row0 * K;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (nr == RT) {
-      for (int kk = 0; kk < K; ++kk) {
+      // the core lives in global memory (L2): eight loads are issued before the first one is consumed — one load per
+      // iteration left every FMA group waiting a full L2 round trip (same sums in the same order)
+      int kk = 0;
+      for (; kk + 8 <= K; kk += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(kk + u) * M + m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc0 = fmaf(Ab[kk + u], w[u], acc0);
+          acc1 = fmaf(Ab[K + kk + u], w[u], acc1);
+          acc2 = fmaf(Ab[2 * K + kk + u], w[u], acc2);
+          acc3 = fmaf(Ab[3 * K + kk + u], w[u], acc3);
+        }
+      }
+      for (; kk < K; ++kk) {
         const float w = W[(size_t)kk * M + m];
         acc0 = fmaf(Ab[kk], w, acc0);
         acc1 = fmaf(Ab[K + kk], w, acc1);
@@ -192,7 +207,20 @@ TT_HD void stage_bwd_data(int tid, int nthr, const float* dC, int sC, float* dA,
     const float* Cs = dC + (size_t)s * sC + (size_t)row0 * R;
     for (int i = 0; i < I; ++i) {
       const float* Ci = Cs + (size_t)i * rows * R;
-      for (int a = 0; a < R; ++a) {
+      int a = 0;
+      for (; a + 8 <= R; a += 8) {          // eight transposed-core loads in flight (see stage_fwd)
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(i * R + a + u) * K + kk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc0 = fmaf(Ci[a + u], w[u], acc0);
+          if (nr > 1) acc1 = fmaf(Ci[R + a + u], w[u], acc1);
+          if (nr > 2) acc2 = fmaf(Ci[2 * R + a + u], w[u], acc2);
+          if (nr > 3) acc3 = fmaf(Ci[3 * R + a + u], w[u], acc3);
+        }
+      }
+      for (; a < R; ++a) {
         const float w = Wt[(size_t)(i * R + a) * K + kk];
         acc0 = fmaf(Ci[a], w, acc0);
         if (nr > 1) acc1 = fmaf(Ci[R + a], w, acc1);
