@@ -180,8 +180,9 @@ int ttrnn_head_backward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_r
  * LSTMCell.forward lstm.py:23-32 / GRUCell.forward gru.py:25-44 and both TTLinear chains.
  *   x[B][T][in], h0/c0[B][H] (NULL = zeros, lstm.py:88-91) -> out[B][T][H], hT/cT[B][H] (may be NULL).
  *   c0 / cT are ignored for GRU.
- *   reserve: NULL for inference; else fp32 [B][T][H][8] (LSTM, per hidden unit: i,g,f,o,c_t,-,-,-) or
- *            [B][T][H][4] (GRU: r,z,n, hidden_part_n) saved for ttrnn_rnn_backward. */
+ *   reserve: NULL for inference; else fp32, ttrnn_rnn_reserve_bytes long, saved for ttrnn_rnn_backward: LSTM
+ *            [B][T][H][4] (per hidden unit the activated gates i,g,f,o) followed by [B][T][H] (the cell states c_t);
+ *            GRU [B][T][H][4] (r,z,n, hidden_part_n). */
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc);
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc);
 int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,

@@ -433,7 +433,7 @@ size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
-  const size_t per = rs.cell == TTRNN_LSTM ? (size_t)8 * rs.H : (size_t)4 * rs.H;
+  const size_t per = rs.cell == TTRNN_LSTM ? (size_t)5 * rs.H : (size_t)4 * rs.H;   // res_gate / res_cell (ttrnn_core.h)
   return (size_t)rs.B * rs.T * per * sizeof(float);
 }
 

@@ -134,6 +134,12 @@ inline int rnn_shape_init(RnnShape* r, const ttrnn_rnn_desc* d) {
 // ------------------------------------------------------------------------------------------------
 template <typename T> TT_HD T tmin(T a, T b) { return a < b ? a : b; }
 
+// Training reserve (include/ttrnn.h).  LSTM: the activated gates [B*T][H][4] (i,g,f,o: one 16-byte record per hidden unit)
+// followed by the cell states [B*T][H] — five floats per unit and step, not a padded record of eight.  GRU: [B*T][H][4]
+// (r,z,n,hid_n).  `rows` = B*T.
+TT_HD size_t res_gate(size_t bt, int H, int j) { return (bt * (size_t)H + j) * 4; }
+TT_HD size_t res_cell(size_t rows, size_t bt, int H, int j) { return rows * (size_t)H * 4 + bt * (size_t)H + j; }
+
 // C[s][i][row][a] = sum_kk A[s][row][kk] * W[kk][i*R+a]      (thread <- (s, 4-row tile, m))
 TT_HD void stage_fwd(int tid, int nthr, const float* A, int sA, float* C, int sC, const float* W,
                      int nb, int rows, int K, int I, int R) {
@@ -435,7 +441,7 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* hbuf, float* cbuf, float* gin) {
   const int H = rs.H, G = rs.G, GH = G * H, in = rs.in, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RU = lstm ? 8 : 4;           // reserve floats per (b, t, hidden unit): LSTM i,g,f,o,c,-,-,-  GRU r,z,n,hn
+  const size_t RROWS = (size_t)rs.B * rs.T;   // reserve layout: res_gate / res_cell
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;
@@ -485,8 +491,9 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           hy = og * tanhf(cy);
           cbuf[e] = cy;
           if (reserve) {
-            float* rv = reserve + (bt * H + j) * RU;
-            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+            float* rv = reserve + res_gate(bt, H, j);
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+            reserve[res_cell(RROWS, bt, H, j)] = cy;
           }
         } else {
           float hr = gh[j], hz = gh[H + j], hn = gh[2 * H + j];
@@ -496,7 +503,7 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           const float ng = tanhf(gi[2 * H + j] + rg * hn);
           hy = (1.0f - zg) * ng + zg * hbuf[e];
           if (reserve) {
-            float* rv = reserve + (bt * H + j) * RU;
+            float* rv = reserve + res_gate(bt, H, j);
             rv[0] = rg; rv[1] = zg; rv[2] = ng; rv[3] = hn;
           }
         }
@@ -528,7 +535,7 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
                         float* bufA, float* bufB, float* dh, float* dc, float* dhd, float* dstate = nullptr) {
   const int H = rs.H, G = rs.G, GH = G * H, Tn = rs.T, bs = rs.bs;
   const bool lstm = rs.cell == TTRNN_LSTM;
-  const int RU = lstm ? 8 : 4;
+  const size_t RROWS = (size_t)rs.B * rs.T;
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * H; e += nthr) {
       const int s = e / H, j = e - s * H;
@@ -542,13 +549,13 @@ TT_HD void rnn_bwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
         const int s = e / H, j = e - s * H;
         const size_t b = (size_t)(b0 + s);
         const size_t bt = b * Tn + t;
-        const float* rv = reserve + (bt * H + j) * RU;
+        const float* rv = reserve + res_gate(bt, H, j);
         float dht = dh[e];
         if (d_out) dht += ld(d_out, bt * H + j);
         float* ga = bufA + (size_t)s * bs;
         if (lstm) {
-          const float ig = rv[0], gg = rv[1], fg = rv[2], og = rv[3], cy = rv[4];
-          const float cprev = t > 0 ? reserve[((bt - 1) * H + j) * RU + 4] : (c0 ? ld(c0, b * H + j) : 0.f);
+          const float ig = rv[0], gg = rv[1], fg = rv[2], og = rv[3], cy = reserve[res_cell(RROWS, bt, H, j)];
+          const float cprev = t > 0 ? reserve[res_cell(RROWS, bt - 1, H, j)] : (c0 ? ld(c0, b * H + j) : 0.f);
           const float tc = tanhf(cy);
           const float dct = dc[e] + dht * og * (1.0f - tc * tc);
           if (dstate) { dstate[(bt * H + j) * 2] = dht; dstate[(bt * H + j) * 2 + 1] = dct; }

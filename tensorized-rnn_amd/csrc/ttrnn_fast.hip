@@ -158,8 +158,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
           hy = og * ftanh(cy);
           cst[u] = cy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hid) * 8;
-            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+            float* rv = reserve + res_gate(bt, H, hid);
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+            reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
           }
         } else {
           const float hn = gbuf[2 * H + hid] + bh[u][2];
@@ -379,9 +380,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
           const float cy = u * cst[x][y] + ig_g;                                             // lstm.py:31
           const float hy = round_storage<TS>(v * ftanh(cy));                                 // lstm.py:32
           if (reserve && ok[x][y]) {
-            float* rv = reserve + (bt * H + hd) * 8 + 2 * pair;                              // i,g | f,o,c
+            float* rv = reserve + res_gate(bt, H, hd) + 2 * pair;                            // i,g | f,o ; c
             rv[0] = u; rv[1] = v;
-            if (pair) rv[2] = cy;
+            if (pair) reserve[res_cell((size_t)B * T, bt, H, hd)] = cy;
           }
           if (ok[x][y] && pair) {
             cst[x][y] = cy;
@@ -403,8 +404,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
           hst[x][y] = hy;
           hbuf[a_off<SL::K>(hd / SL::K, hd % SL::K)] = hy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hd) * 8;
-            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+            float* rv = reserve + res_gate(bt, H, hd);
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+            reserve[res_cell((size_t)B * T, bt, H, hd)] = cy;
           }
           if (!in1 && t + 1 < T) {
             const f32x4 nx = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);

@@ -270,8 +270,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
           hy = og * htanh(cy);                                                     // lstm.py:32
           cst[u] = cy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hid) * 8;
-            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+            float* rv = reserve + res_gate(bt, H, hid);
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+            reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
           }
         } else {
           const float hn = gbuf[2 * H + hid] + bh[u][2];

@@ -322,8 +322,9 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
           hy = og * btanh(cy);                                                     // lstm.py:32
           cst[u] = cy;
           if (reserve) {
-            float* rv = reserve + (bt * H + hid) * 8;
-            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+            float* rv = reserve + res_gate(bt, H, hid);
+            rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+            reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
           }
         } else {
           // bias_in must not be scaled by r: split the fused bias again for the n gate (gru.py:42-43)
@@ -483,8 +484,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
       float hy = og * btanh(cy);
       cst = cy;
       if (reserve) {
-        float* rv = reserve + (bt * H + hid) * 8;
-        rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og; rv[4] = cy;
+        float* rv = reserve + res_gate(bt, H, hid);
+        rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+        reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
       }
       st(out, bt * H + hid, hy);
       hy = round_like(out, hy);                    // what the next step sees: rounded once to the storage type

@@ -255,12 +255,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
     c0v[u] = c0 ? ld(c0, b * H + hid[u]) : 0.f;
     const size_t bt = b * T + (T - 1);
     const size_t bt1 = T > 1 ? bt - 1 : bt;
-    const float* rv = reserve + (bt * H + hid[u]) * 8;
-    const float* rv1 = reserve + (bt1 * H + hid[u]) * 8;
-    ra[u] = *reinterpret_cast<const f32x4*>(rv);
-    rc[u] = rv[4];
-    na[u] = *reinterpret_cast<const f32x4*>(rv1);
-    nc[u] = rv1[4];
+    ra[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid[u]));
+    rc[u] = reserve[res_cell((size_t)B * T, bt, H, hid[u])];
+    na[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt1, H, hid[u]));
+    nc[u] = reserve[res_cell((size_t)B * T, bt1, H, hid[u])];
     dcur[u] = d_out ? ld(d_out, bt * H + hid[u]) : 0.f;
     dnxt[u] = d_out ? ld(d_out, bt1 * H + hid[u]) : 0.f;
   }
@@ -297,9 +295,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       dg[0] = p0; dg[H] = p1; dg[2 * H] = p2; dg[3 * H] = p3;
       // record / d_out of step t-2, consumed two iterations from now
       const size_t b2 = t > 1 ? bt - 2 : b * T;
-      const float* rv = reserve + (b2 * H + hid[u]) * 8;
-      fa[u] = *reinterpret_cast<const f32x4*>(rv);
-      fc[u] = rv[4];
+      fa[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid[u]));
+      fc[u] = reserve[res_cell((size_t)B * T, b2, H, hid[u])];
       fd[u] = d_out ? ld(d_out, b2 * H + hid[u]) : 0.f;
     }
     __syncthreads();

@@ -246,7 +246,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
   constexpr int H = in_size_of<S>();
   constexpr int G = CELL == TTRNN_LSTM ? 4 : 3;
   constexpr int GH = G * H;
-  constexpr int RU = CELL == TTRNN_LSTM ? 8 : 4;
   constexpr int HPT = (H + FAST_NT - 1) / FAST_NT;
   constexpr int MAXC = maxc_of<S>();
 
@@ -290,9 +289,8 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_fast(int B, int T, const TS
     for (int u = 0; u < HPT; ++u) {
       const int hid = tid + u * FAST_NT;
       if (hid < H) {
-        const float* rv = reserve + (bt * H + hid) * RU;
-        f.a[u] = *reinterpret_cast<const f32x4*>(rv);
-        if constexpr (CELL == TTRNN_LSTM) f.c[u] = rv[4];
+        f.a[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid));
+        if constexpr (CELL == TTRNN_LSTM) f.c[u] = reserve[res_cell((size_t)B * T, bt, H, hid)];
         f.dout[u] = dptr[bt * H + hid];
         if constexpr (CELL == TTRNN_GRU) {
           const TS* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);

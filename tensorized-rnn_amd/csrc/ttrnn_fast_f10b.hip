@@ -188,13 +188,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
     for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
     if (T > 0) {                         // set 0 = record(T-1), set 1 = record(T-2)
       const size_t bt = b * T + (T - 1);
-      const float* rv = reserve + (bt * H + hid) * 8;
+      const float* rv = reserve + res_gate(bt, H, hid);
+      const float* rc = reserve + res_cell((size_t)Bn * T, bt, H, hid);
       ra0 = *reinterpret_cast<const f32x4*>(rv);
-      rb0 = rv[4];
+      rb0 = rc[0];
       do0 = dptr[bt * H + hid];
       if (T > 1) {
-        ra1 = *reinterpret_cast<const f32x4*>(rv - H * 8);
-        rb1 = rv[4 - H * 8];
+        ra1 = *reinterpret_cast<const f32x4*>(rv - H * 4);
+        rb1 = rc[-H];
         do1 = dptr[(bt - 1) * H + hid];
       }
     }
@@ -215,9 +216,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
         // three loads, no branch (index clamped, a null d_out reads the reserve and is scaled by zero): a conditional
         // VMEM operation makes the compiler's vmcnt bookkeeping fall back to vmcnt(0)
         const size_t b2 = t > 1 ? bt - 2 : b * T;
-        const float* rv = reserve + (b2 * H + hid) * 8;
-        fa = *reinterpret_cast<const f32x4*>(rv);
-        fb = rv[4];
+        fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+        fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
         dout_f = dptr[b2 * H + hid];                 // scaled where it is consumed
       }
       const f32x4 qa = ra;

@@ -192,9 +192,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
           hn[hd] = p0; hn[H + hd] = p1;
           hbuf[sm][((t + 1) & 1) * H + hd] = hy;
           if (reserve && live[sm]) {
-            float* rv = reserve + (bt * H + hd) * 8;
-            *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
-            rv[4] = cy;
+            *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hd)) = f32x4{ig, gg, fg, og};
+            reserve[res_cell((size_t)B * T, bt, H, hd)] = cy;
           }
           if (!in1 && t + 1 < T) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
         }

@@ -150,9 +150,8 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
       hn[hd] = p0; hn[H + hd] = p1;
       out[bt * H + hd] = hy;                                // outputs[:, t, :] (lstm.py:133): 256 contiguous bytes per wave
       if (reserve) {
-        float* rv = reserve + (bt * H + hd) * 8;
-        *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
-        rv[4] = cy;
+        *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hd)) = f32x4{ig, gg, fg, og};
+        reserve[res_cell((size_t)B * T, bt, H, hd)] = cy;
       }
       if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
     }

@@ -443,9 +443,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             hy = og * ftanh(cy);
             cst[u] = cy;
             if (reserve) {
-              float* rv = reserve + (bt * H + hid) * 8;
-              *reinterpret_cast<f32x4*>(rv) = f32x4{ig, gg, fg, og};
-              rv[4] = cy;
+              *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hid)) = f32x4{ig, gg, fg, og};
+              reserve[res_cell((size_t)P.B * T, bt, H, hid)] = cy;
             }
           } else {                                       // gin slots r,z,n, b_hid of n
             const float hn = y[2] + g4[3];                 // slot 3: b_hid of the n gate (k_g2_bias)
@@ -587,10 +586,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
           if (d_out) dht += ld(d_out, bt * H + hid);
           float p[4] = {0.f, 0.f, 0.f, 0.f}, ph2 = 0.f;
           if (LSTM) {
-            const float* rv = reserve + (bt * H + hid) * 8;
-            const f32x4 gq = *reinterpret_cast<const f32x4*>(rv);
-            const float ig = gq[0], gg = gq[1], fg = gq[2], og = gq[3], cy = rv[4];
-            const float cprev = t > 0 ? reserve[((bt - 1) * H + hid) * 8 + 4] : (c0 ? ld(c0, b * H + hid) : 0.f);
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid));
+            const float ig = gq[0], gg = gq[1], fg = gq[2], og = gq[3], cy = reserve[res_cell((size_t)P.B * T, bt, H, hid)];
+            const float cprev = t > 0 ? reserve[res_cell((size_t)P.B * T, bt - 1, H, hid)] : (c0 ? ld(c0, b * H + hid) : 0.f);
             const float tc = ftanh(cy);
             const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
             if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = dct; }

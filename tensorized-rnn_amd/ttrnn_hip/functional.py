@@ -365,7 +365,8 @@ class _TTRnnLayerFn(torch.autograd.Function):
                                         _ptr(bias_in), _ptr(packed_hid), _ptr(bias_hid), _ptr(out), _ptr(hT),
                                         _ptr(cT), _ptr(reserve), _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward")
         if stats is not None:
-            stats.forward(out, reserve.view(B, T, H, 8)[..., 4] if spec.cell == "lstm" else None)
+            # LSTM reserve: gates [B][T][H][4], then the cell states [B][T][H] (ttrnn_core.h: res_gate / res_cell)
+            stats.forward(out, reserve[4 * B * T * H:].view(B, T, H) if spec.cell == "lstm" else None)
         ctx.stats = stats
         ctx.spec = spec
         ctx.n_in = n_in

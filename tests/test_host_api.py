@@ -158,7 +158,7 @@ def test_descriptor_validation_without_gpu():
     spec = RnnLayerSpec("lstm", 1, 256, TTSpec([1, 1, 1], [8, 8, 16], [1, 8, 8, 1]),
                         TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
     d = spec.desc(64, 784, 0)
-    assert lib.ttrnn_rnn_reserve_bytes(ctypes.byref(d)) == 64 * 784 * 8 * 256 * 4
+    assert lib.ttrnn_rnn_reserve_bytes(ctypes.byref(d)) == 64 * 784 * 5 * 256 * 4      # gates [.][4] + cell states [.]
     # cfg2 runs on the shape-specialised kernel; input_size == 1 -> only two hoisted rows [2][H][4] + unit inputs
     # two unit rows of gate inputs + the unit input rows + the fused-core fragments of the f10 kernel (4 x 8 x 3 KB)
     assert lib.ttrnn_rnn_workspace(ctypes.byref(d)) == 2 * 256 * 4 * 4 + 256 + 4 * 8 * 3 * 1024

@@ -153,7 +153,7 @@ def test_hostemu_rnn(emu, name):
         out = np.zeros((B, T, H), dtype=np.float32)
         hT = np.zeros((B, H), dtype=np.float32)
         cT = np.zeros((B, H), dtype=np.float32)
-        reserve = np.zeros((B, T, (8 if lstm else 4) * H), dtype=np.float32)
+        reserve = np.zeros((B, T, (5 if lstm else 4) * H), dtype=np.float32)
         rc = emu.hostemu_rnn_forward(ctypes.byref(d), _p(seq), _p(h0), _p(c0), _p(w_in.packed), _p(w_in.bias),
                                      _p(w_hid.packed), _p(w_hid.bias), _p(out), _p(hT), _p(cT), _p(reserve), 2, 40)
         assert rc == 0
