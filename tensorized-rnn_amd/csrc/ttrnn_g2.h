@@ -49,7 +49,7 @@ struct G2Mat {
   int K1S;                          // fp32 dC1 image [16*N1T][K1S]
   // element counts of the per-launch buffers (workspace)
   long head_elems, tail_elems;      // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
-  long fs2_bytes, ft1_bytes;        // forward: head fragment stream (bf16 x 3 planes), tail fragments (fp32)
+  long fs2_bytes, ft1_bytes;        // forward: head fragment stream (fp16 x 2 planes, scaled), tail fragments (fp32, scaled)
   long bs2_bytes, bt1_bytes;        // reverse: the same for T2 / T1
 };
 
@@ -139,7 +139,7 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->K1S = m->It * m->Rp + 4;
   m->head_elems = (long)m->Ih * m->Jh * m->R;
   m->tail_elems = (long)m->It * m->Jt * m->R;
-  m->fs2_bytes = (long)nw * m->UW * m->KBP * 3 * 64 * 16;
+  m->fs2_bytes = (long)nw * m->UW * m->KBP * 2 * 64 * 16;
   m->ft1_bytes = (long)m->M1T * m->KS1 * 64 * 4;
   m->bs2_bytes = (long)nw * m->bUW * m->bKBP * 3 * 64 * 16;
   m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
@@ -171,7 +171,7 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
   const G2Mat& m = p->hid;
   p->f_hb = (int)g2_al((size_t)16 * m.N1T * m.JtS * 4);
-  p->f_img = (int)g2_al((size_t)3 * 16 * m.N2T * m.K2S * 2);
+  p->f_img = (int)g2_al((size_t)2 * 16 * m.N2T * m.K2S * 2);     // forward: two fp16 planes (ttrnn_split.h, flavour b)
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
   p->f_tab = (int)g2_al((size_t)m.T1 * 64 * 4);
   p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab;
@@ -189,8 +189,11 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
+constexpr int G2_HDR_BYTES = 256;     // partial maxima of |Gh|, |Gt|, |h_0| (forward: power-of-two scales of the fp16 pieces)
+constexpr int G2_HDR_PARTS = 16;
 inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
-  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes);
+  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes) +
+         G2_HDR_BYTES;
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);

@@ -75,12 +75,63 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
   }
 }
 
+// ---- forward operand scales (two-piece fp16 flavour of ttrnn_split.h) ---------------------------------------------------------
+// Stage 1 stays on the fp32 MFMA; its result C1 = Gt h is what gets split, so the TAIL is pre-multiplied by 2^a with
+// J_t max|Gt| max(1, |h_0|) 2^a < 2^15 (|h_t| < 1 afterwards, LSTM and GRU alike), the head by 2^b with max|Gh| 2^b < 2^14, and
+// the gate phase multiplies the stage-2 sums by 2^-(a+b).  All powers of two: exact.
+struct G2Scales { float tail, head, un; };
+__device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / non-finite: neutral
+  if (!(x > 0.f)) return 0;
+  if (!(x < 3e38f)) return 40;
+  int e;
+  frexpf(x, &e);
+  return e < -40 ? -40 : (e > 40 ? 40 : e);
+}
+__device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ hdr, int Jt) {
+  float mh = 0.f, mt = 0.f, m0 = 0.f;
+#pragma unroll
+  for (int i = 0; i < G2_HDR_PARTS; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(hdr + 4 * i);
+    mh = fmaxf(mh, v[0]); mt = fmaxf(mt, v[1]); m0 = fmaxf(m0, v[2]);
+  }
+  const int a = 15 - g2_expo((float)Jt * mt * fmaxf(1.0f, m0));
+  const int b = 14 - g2_expo(mh);
+  G2Scales r;
+  r.tail = ldexpf(1.f, a);
+  r.head = ldexpf(1.f, b);
+  r.un = ldexpf(1.f, -(a + b));
+  return r;
+}
+template <typename TS>
+__global__ void __launch_bounds__(256) k_g2_absmax(const float* __restrict__ Gh, long nh, const float* __restrict__ Gt, long nt,
+                                                   const TS* __restrict__ h0, long n0, float* __restrict__ hdr) {
+  __shared__ float red[3][4];
+  const long g = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)G2_HDR_PARTS * 256;
+  float m[3] = {0.f, 0.f, 0.f};
+  for (long i = g; i < nh; i += stride) m[0] = fmaxf(m[0], fabsf(Gh[i]));
+  for (long i = g; i < nt; i += stride) m[1] = fmaxf(m[1], fabsf(Gt[i]));
+  if (h0)
+    for (long i = g; i < n0; i += stride) m[2] = fmaxf(m[2], fabsf(ld(h0, (size_t)i)));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = m[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    hdr[4 * blockIdx.x + threadIdx.x] =
+        threadIdx.x < 3 ? fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3])) : 0.f;
+}
+
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
 // head stream (bf16 x 3 planes): block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl)*3 planes * 64 lanes
 //   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
 //   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
+// forward (REV = false): TWO fp16 planes of 2^b Gh (g2_scales), block stride 2 * 64 lanes; reverse: three bf16 planes
 template <bool REV>
-__global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs) {
+__global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs,
+                                                     const float* __restrict__ hdr) {
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
@@ -88,8 +139,14 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int kbl = blk % KBP, ui = (blk / KBP) % UW, w = blk / (KBP * UW);
   const int u = w + ui * m.nw;
   xbf8 f0, f1, f2;
+  xh8 g0, g1;
+  float hsc = 1.f;
+  if constexpr (!REV) hsc = g2_scales(hdr, m.Jt).head;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f; }
+  for (int e = 0; e < 8; ++e) {
+    f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f;
+    g0[e] = (_Float16)0.f; g1[e] = (_Float16)0.f;
+  }
   if (u < U && kbl < KPER) {
     const int tile = u / KSPLIT, part = u % KSPLIT;
     const int mt = tile / m.N2T;
@@ -113,21 +170,33 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
         else { ih = row; unpos(k, jh, a); }
         float v = 0.f;
         if (ih < m.Ih && jh < m.Jh && a < m.R) v = Gh[((size_t)ih * m.Jh + jh) * m.R + a];
-        __bf16 p0, p1, p2;
-        split3(v, p0, p1, p2);
-        f0[e] = p0; f1[e] = p1; f2[e] = p2;
+        if constexpr (REV) {
+          __bf16 p0, p1, p2;
+          split3(v, p0, p1, p2);
+          f0[e] = p0; f1[e] = p1; f2[e] = p2;
+        } else {
+          _Float16 p0, p1;
+          split2h(v * hsc, p0, p1);
+          g0[e] = p0; g1[e] = p1;
+        }
       }
     }
   }
-  xbf8* dst = fs + (size_t)blk * 3 * 64 + lane;
-  dst[0] = f0; dst[64] = f1; dst[128] = f2;
+  if constexpr (REV) {
+    xbf8* dst = fs + (size_t)blk * 3 * 64 + lane;
+    dst[0] = f0; dst[64] = f1; dst[128] = f2;
+  } else {
+    xh8* dst = reinterpret_cast<xh8*>(fs) + (size_t)blk * 2 * 64 + lane;
+    dst[0] = g0; dst[64] = g1;
+  }
 }
 
 // tail fragments (fp32, one value per lane and k-step):  lane (m = lane & 15, kq = lane >> 4)
 //   forward: A[m][k] = Gt[(i_t, a) = divmod(16 mt + m, Rp)][j_t = 4 ks + kq]         at (mt*KS1 + ks)*64 + lane
 //   reverse: A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]         at (mt*bKS1 + ks)*64 + lane
 template <bool REV>
-__global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft) {
+__global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft,
+                                                     const float* __restrict__ hdr) {
   const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
   const int KS = REV ? m.bKS1 : m.KS1;
   const int ks = blockIdx.x % KS, mt = blockIdx.x / KS;
@@ -136,6 +205,7 @@ __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __res
   else { const int row = 16 * mt + mm; it = row / m.Rp; a = row % m.Rp; jt = 4 * ks + kq; }
   float v = 0.f;
   if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
+  if constexpr (!REV) v *= g2_scales(hdr, m.Jt).tail;          // forward: C1 comes out of stage 1 already scaled
   ft[(size_t)blockIdx.x * 64 + lane] = v;
 }
 
@@ -186,16 +256,24 @@ __device__ __forceinline__ void split_block(const xbf8 (&w)[3], const xbf8 (&x)[
   acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc_a, 0, 0, 0);
 }
 
+// the three-term product of two-piece fp16 operands on two chains (lo: w1x0 + w0x1, hi: w0x0)
+__device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[2], f32x4& acc_lo, f32x4& acc_hi) {
+  acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], x[0], acc_lo, 0, 0, 0);
+  acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], x[0], acc_hi, 0, 0, 0);
+  acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], x[1], acc_lo, 0, 0, 0);
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------------------
 template <int CELL, typename TS, int UPT, bool RES, bool DIAG>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
-                                                  const TS* __restrict__ c0, const xbf8* __restrict__ fs2,
-                                                  const float* __restrict__ ft1, TS* __restrict__ out, TS* __restrict__ hT,
+                                                  const TS* __restrict__ c0, const xh8* __restrict__ fs2,
+                                                  const float* __restrict__ ft1, const float* __restrict__ hdr,
+                                                  TS* __restrict__ out, TS* __restrict__ hT,
                                                   TS* __restrict__ cT, float* __restrict__ reserve) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
   float* hb = reinterpret_cast<float*>(smem);
-  __bf16* img = reinterpret_cast<__bf16*>(smem + P.f_hb);
+  _Float16* img = reinterpret_cast<_Float16*>(smem + P.f_hb);     // stage 2's operand: two fp16 planes of 2^a C1
   float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
   float* lt1 = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // tail fragments (P.f_t1 > 0)
@@ -208,6 +286,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
+  const float unsc = g2_scales(hdr, m.Jt).un;                       // 2^-(a+b): stage-2 sums -> pre-activations
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
   for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
@@ -252,15 +331,15 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const int total = nu_w * m.KBP;
   // RES (chosen by the host for the whole launch: UW * KBP <= G2_PF): every wave's share of the head core lives in its
   // register slots for all T steps; otherwise the slots roll over a stream of fragments
-  const xbf8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 3 * 64 + lane;
-  xbf8 wbuf[G2_PF][3];
+  const xh8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 2 * 64 + lane;
+  xh8 wbuf[G2_PF][2];
 #pragma unroll
   for (int j = 0; j < G2_PF; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
-      if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (_Float16)0.f;
+      if (total > 0) wbuf[j][p] = sp[(size_t)j * 2 * 64 + p * 64];
     }
   // ---- per-wave constants of the time loop, computed ONCE (the tier is instruction-issue bound: DESIGN.md 4c) -----------------
   // first stage-1 tile pair of this wave (small and medium shapes have no other)
@@ -280,7 +359,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   int r_nlive = m.NKBt - r_kloc < m.KPER ? m.NKBt - r_kloc : m.KPER;
   r_nlive = (nu_w > 0 && r_nlive > 0) ? r_nlive : 0;
   const int r_kb0 = (m.ng > 1 ? (16 * r_mt) / m.IhG : 0) * m.NKBt + r_kloc;
-  const __bf16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
+  const _Float16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
   const int r_ybase = r_part * GH + (16 * r_mt + 4 * q) * m.It + 16 * r_nt + c;
   int r_ymask = 0;
 #pragma unroll
@@ -317,8 +396,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[e], xb[e], accb, 0, 0, 0);
           }
       }
-      if (offa >= 0) store_split4(img, plane, offa, acca);
-      if (offb >= 0) store_split4(img, plane, offb, accb);
+      if (offa >= 0) store_split4_h(img, plane, offa, acca);
+      if (offb >= 0) store_split4_h(img, plane, offb, accb);
     };
     auto stage1 = [&](auto frag) {
       if (s1_has) pair(frag, s1_fa, s1_fb, s1_bpa, s1_bpb, s1_oa, s1_ob);
@@ -348,14 +427,14 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
         const int kloc0 = part * m.KPER;                                              // inside the tile's own k range
         const int kbase = (m.ng > 1 ? (16 * mt) / m.IhG : 0) * m.NKBt;                // block-diagonal heads: the gate's range
-        const __bf16* brow = img + (16 * nt + c) * m.K2S + 8 * q + 32 * kbase;
-        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+        const _Float16* brow = img + (16 * nt + c) * m.K2S + 8 * q + 32 * kbase;
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
         // operand fragments of the NEXT block are requested before the current block's MFMAs are issued
-        xbf8 bf[2][3];
+        xh8 bf[2][2];
         {
           const int kbc = kloc0 < m.NKBt ? kloc0 : m.NKBt - 1;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kbc);
+          for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kbc);
         }
         for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
 #pragma unroll
@@ -363,19 +442,18 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             const int kb = kloc0 + kbl + j;
             if (kbl + j + 1 < m.KPER && kb + 1 < m.NKBt) {     // the next block is live (padding blocks are never read)
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
+              for (int p = 0; p < 2; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * (kb + 1));
             }
-            if (kbl + j < m.KPER && kb < m.NKBt) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            if (kbl + j < m.KPER && kb < m.NKBt) split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
             {
               int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
               nxt -= nxt >= total ? total : 0;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              for (int p = 0; p < 2; ++p) wbuf[j][p] = sp[(size_t)nxt * 2 * 64 + p * 64];
               ++seq;
             }
           }
         }
-        const f32x4 acc_lo = acc_a + acc_b;
         const f32x4 acc = acc_hi + acc_lo;
         const int itc = 16 * nt + c;
         if (itc < m.It) {
@@ -390,21 +468,21 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     if constexpr (RES) {
       // one unit, at most G2_PF blocks, every constant hoisted: fragment reads at immediate offsets, MFMAs, four stores
       if (r_nlive > 0) {
-        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
-        xbf8 bf[2][3];
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        xh8 bf[2][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(r_brow + p * plane);
+        for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane);
 #pragma unroll
         for (int j = 0; j < G2_PF; ++j) {
           if (j < r_nlive) {
             if (j + 1 < r_nlive) {
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(r_brow + p * plane + 32 * (j + 1));
+              for (int p = 0; p < 2; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane + 32 * (j + 1));
             }
-            split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+            split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
           }
         }
-        const f32x4 acc = acc_hi + (acc_a + acc_b);
+        const f32x4 acc = acc_hi + acc_lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (r_ymask & (1 << j)) ybuf[r_ybase + j * m.It] = acc[j];
@@ -431,6 +509,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
             for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ya[g] + k1 * yb[g];
           }
+#pragma unroll
+          for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] *= unsc;         // exact: a power of two
           f32x4 g4 = gi[u];
           if (in1) g4 = bb[u] + xq.at(t) * gi[u];
           float hy;
@@ -748,21 +828,30 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }
 
 // merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
+// h0 / n_h0 / hdr_out: forward only (operand maxima for the fp16 scales)
 int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
-         hipStream_t stream) {
+         hipStream_t stream, int dtype = TTRNN_F32, const void* h0 = nullptr, long n_h0 = 0, const float** hdr_out = nullptr) {
   char* p = (char*)ws;
   float* Gh = (float*)p; p += g2_al((size_t)m.head_elems * 4);
   float* Gt = (float*)p; p += g2_al((size_t)m.tail_elems * 4);
   xbf8* hs = (xbf8*)p; p += g2_al((size_t)(rev ? m.bs2_bytes : m.fs2_bytes));
-  float* tf = (float*)p;
+  float* tf = (float*)p; p += g2_al((size_t)(rev ? m.bt1_bytes : m.ft1_bytes));
+  float* hdr = (float*)p;                     // forward only (g2_fwd_ws_bytes)
   const long nm = (long)m.Ih * m.Jh + (long)m.It * m.Jt;
   hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, s, m, packed, Gh, Gt);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs);
-    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const float*)nullptr);
+    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs);
-    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf);
+    if (dtype == TTRNN_F32)
+      hipLaunchKernelGGL(k_g2_absmax<float>, dim3(G2_HDR_PARTS), dim3(256), 0, stream, Gh, m.head_elems, Gt, m.tail_elems,
+                         (const float*)h0, n_h0, hdr);
+    else
+      hipLaunchKernelGGL(k_g2_absmax<bf16_t>, dim3(G2_HDR_PARTS), dim3(256), 0, stream, Gh, m.head_elems, Gt, m.tail_elems,
+                         (const bf16_t*)h0, n_h0, hdr);
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const float*)hdr);
+    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr);
+    if (hdr_out) *hdr_out = hdr;
   }
   *fs = hs;
   *ft = tf;
@@ -876,7 +965,8 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   const xbf8* fs2;
   const float* ft1;
-  st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream);
+  const float* hdr = nullptr;
+  st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream, dtype, h0, (long)rs.B * rs.H, &hdr);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
@@ -886,8 +976,8 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
                                                                : k_g2_fwd<CELLV, TS, UPTV, true, false>)                 \
                     : k_g2_fwd<CELLV, TS, UPTV, false, false>;                                                            \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0, fs2,   \
-                       ft1, (TS*)out, (TS*)hT, (TS*)cT, reserve);                                                         \
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,       \
+                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve);                 \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
     if (P.upt == 1) TT_G2_FWD(TTRNN_LSTM, 1, 0);
