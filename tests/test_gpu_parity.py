@@ -810,8 +810,9 @@ def test_split_math_large_magnitude_inputs_and_states(wscale, xscale, T, tol):
         assert err <= tol * max(1.0, float(c64.abs().max()))      # relative to the state's scale
 
 
+@pytest.mark.parametrize("route", ["fused_core", "runtime_mfma"])
 @pytest.mark.parametrize("case", ["tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes"])
-def test_split_math_operand_ranges(case):
+def test_split_math_operand_ranges(case, route):
     """The split mode of the fused-core LSTM kernels multiplies two-piece fp16 operands under power-of-two scales chosen
     per launch from the cores' and h_0's maxima (ttrnn_f10_dev.h): nothing may overflow fp16's range or lose the small
     entries, whatever the magnitudes.  Both modes against the float64 oracle, error relative to the largest state."""
@@ -845,7 +846,12 @@ def test_split_math_operand_ranges(case):
     scale = max(1e-30, float(c64.abs().max()), float(r64.abs().max()))
     errs = {}
     for mode in ("exact", "split"):
-        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+        # the runtime-shape tier (ttrnn_g2.hip) uses the same two-piece fp16 operands in its stage 2, with its own scales
+        with ttrnn_hip.fp32_math(mode), ttrnn_hip.option("force_g2", 1 if (route == "runtime_mfma" and mode == "split") else 0), \
+                torch.no_grad():
+            if mode == "split":
+                from ttrnn_hip import functional as F
+                assert F.rnn_route(m._all_layers[0]._layer_spec(), 3, T) == route
             out, (hT, cT) = m(x.to(dev()), (h0.to(dev()), c0.to(dev())))
         assert torch.isfinite(out).all() and torch.isfinite(cT).all(), (case, mode)
         errs[mode] = max(_maxabs(out, r64), _maxabs(cT, c64))
