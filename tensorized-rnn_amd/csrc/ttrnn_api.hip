@@ -24,12 +24,13 @@ struct OptTable {
         "TTRNN_FP32_MATH", "TTRNN_FORCE_GENERIC", "TTRNN_NO_GEMM", "TTRNN_NO_IN1", "TTRNN_NO_F10", "TTRNN_NO_G2",
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
-        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_BF16"};
+        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+      else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -41,7 +42,7 @@ OptTable& table() {
 }
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
-    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_bf16"};
+    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }
@@ -56,7 +57,8 @@ int opt_set(const char* name, int value) {
   if (i < 0) return -1;
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
-  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && value != 0 && value != 1) return -1;
+  if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
+  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;
 }
@@ -476,9 +478,9 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
       st = launch_fill_identity(TTRNN_F32, rs.in, gw, (hipStream_t)stream);
       if (st == TTRNN_OK)
         st = launch_ttlinear_fwd_f10(rs.in_s, rs.in, packed_in, nullptr, gw, wdense, lin10, (hipStream_t)stream);
-      // two-piece fp16 operands (three MFMA terms); OPT_GEMM_BF16: the three-piece bf16 GEMM (A/B switch)
+      // two-piece fp16 operands (three MFMA terms) where the scale passes pay off, else three bf16 pieces (gemm_use_half)
       void* gscr = (char*)planes + gemm_split_plane_bytes(rs.in, 4 * rs.H);
-      if (opt(OPT_GEMM_BF16)) {
+      if (!gemm_use_half((int64_t)rs.B * rs.T, rs.in, 4 * rs.H)) {
         if (st == TTRNN_OK) st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, (hipStream_t)stream);
         if (st == TTRNN_OK)
           st = launch_gemm_split(TTRNN_F32, (int64_t)rs.B * rs.T, rs.in, 4 * rs.H, x, planes, bin, rs.H, gin,

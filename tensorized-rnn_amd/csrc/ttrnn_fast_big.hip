@@ -619,10 +619,10 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
       hipLaunchKernelGGL((k_ttlinear_fwd_big<S2, 4, TS>), dim3(rs.in < cus ? rs.in : cus), dim3(FAST_NT), lds_lin, stream,
                          (int64_t)rs.in, m2_in, (const TS*)ident, wdense, slab, 2);
       if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-      // two-piece fp16 operands (three MFMA terms); OPT_GEMM_BF16: three bf16 pieces, six terms (A/B switch)
+      // two-piece fp16 operands (three MFMA terms) where the scale passes pay off, else three bf16 pieces (gemm_use_half)
       void* gscr = (char*)planes + gemm_split_plane_bytes(rs.in, 4 * rs.H);
       const int gdt = sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16;
-      if (opt(OPT_GEMM_BF16)) {
+      if (!gemm_use_half(n_rows, rs.in, 4 * rs.H)) {
         st = launch_gemm_split_prep(wdense, rs.in, 4 * rs.H, planes, stream);
         if (st != TTRNN_OK) return st;
         st = launch_gemm_split(gdt, n_rows, rs.in, 4 * rs.H, x, planes, nullptr, rs.H, gin, stream);

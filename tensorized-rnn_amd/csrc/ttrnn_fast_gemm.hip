@@ -677,6 +677,13 @@ int launch_gemm_split_prep(const float* WG, int K, int M, void* planes, hipStrea
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+bool gemm_use_half(int64_t n_rows, int K, int M) {
+  const int pieces = opt(OPT_GEMM_PIECES);
+  if (pieces == 2) return true;
+  if (pieces == 3) return false;
+  return (double)n_rows * K * M >= 4294967296.0;
+}
+
 // two-piece fp16 variant: scratch = G_HDR bytes (partial maxima of |W|) + one fp32 scale per row of x
 size_t gemm_half_scratch_bytes(int64_t n_rows) { return al256g((size_t)G_HDR + (size_t)(n_rows > 0 ? n_rows : 0) * sizeof(float)); }
 

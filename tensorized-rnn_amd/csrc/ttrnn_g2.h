@@ -189,11 +189,11 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
-constexpr int G2_HDR_BYTES = 256;     // partial maxima of |Gh|, |Gt|, |h_0| (forward: power-of-two scales of the fp16 pieces)
-constexpr int G2_HDR_PARTS = 16;
+// forward: per-block maxima (|Gh|, |Gt|) of the merge kernel -> the power-of-two scales of the fp16 pieces
+inline long g2_merge_blocks(const G2Mat& m) { return ((long)m.Ih * m.Jh + (long)m.It * m.Jt + 255) / 256; }
 inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes) +
-         G2_HDR_BYTES;
+         g2_al((size_t)g2_merge_blocks(m) * 2 * sizeof(float));
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);

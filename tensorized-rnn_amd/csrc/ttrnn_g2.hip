@@ -33,11 +33,13 @@ namespace {
 
 // ---- prep 1: contract the cores on either side of the split point ------------------------------------------------------
 // packed: W_k[(j*R_{k+1} + b)*M_k + (i*R_k + a)] = G_k[a, i, j, b]  (include/ttrnn.h)
+// parts (forward only): [block][2] = the largest |Gh| / |Gt| entry this block produced (g2_scales)
 __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const float* __restrict__ packed,
-                                                  float* __restrict__ Gh, float* __restrict__ Gt) {
+                                                  float* __restrict__ Gh, float* __restrict__ Gt, float* __restrict__ parts) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nh = (long)m.Ih * m.Jh, nt = (long)m.It * m.Jt;
   float v[G2_MAX_R], w[G2_MAX_R];
+  float mxh = 0.f, mxt = 0.f;
   if (e < nh) {
     int ih = (int)(e / m.Jh), jh = (int)(e % m.Jh);
     int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
       }
       for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
     }
-    for (int a = 0; a < m.R; ++a) Gh[(size_t)e * m.R + a] = v[a];
+    for (int a = 0; a < m.R; ++a) { Gh[(size_t)e * m.R + a] = v[a]; mxh = fmaxf(mxh, fabsf(v[a])); }
   } else if (e < nh + nt) {
     const long f = e - nh;
     int it = (int)(f / m.Jt), jt = (int)(f % m.Jt);
@@ -71,14 +73,26 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
       }
       for (int a = 0; a < s.R[k]; ++a) v[a] = w[a];
     }
-    for (int a = 0; a < m.R; ++a) Gt[(size_t)f * m.R + a] = v[a];
+    for (int a = 0; a < m.R; ++a) { Gt[(size_t)f * m.R + a] = v[a]; mxt = fmaxf(mxt, fabsf(v[a])); }
+  }
+  if (parts) {                                   // uniform
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mxh = fmaxf(mxh, __shfl_xor(mxh, o)); mxt = fmaxf(mxt, __shfl_xor(mxt, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mxh; red[1][threadIdx.x >> 6] = mxt; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+      parts[2 * blockIdx.x + threadIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]),
+                                                   fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
   }
 }
 
 // ---- forward operand scales (two-piece fp16 flavour of ttrnn_split.h) ---------------------------------------------------------
 // Stage 1 stays on the fp32 MFMA; its result C1 = Gt h is what gets split, so the TAIL is pre-multiplied by 2^a with
-// J_t max|Gt| max(1, |h_0|) 2^a < 2^15 (|h_t| < 1 afterwards, LSTM and GRU alike), the head by 2^b with max|Gh| 2^b < 2^14, and
-// the gate phase multiplies the stage-2 sums by 2^-(a+b).  All powers of two: exact.
+// J_t max|Gt| 2^a < 2^15 (|h_t| < 1 for t >= 1, LSTM and GRU alike; a caller's h_0 is put into the image times a per-sample
+// power of two that the first step's sums are multiplied back by), the head by 2^b with max|Gh| 2^b < 2^14, and the gate
+// phase multiplies the stage-2 sums by 2^-(a+b).  All powers of two: exact.  The maxima come out of the merge kernel
+// (one pair per block), no launch of their own.
 struct G2Scales { float tail, head, un; };
 __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / non-finite: neutral
   if (!(x > 0.f)) return 0;
@@ -87,41 +101,22 @@ __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / no
   frexpf(x, &e);
   return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
-__device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ hdr, int Jt) {
-  float mh = 0.f, mt = 0.f, m0 = 0.f;
-#pragma unroll
-  for (int i = 0; i < G2_HDR_PARTS; ++i) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(hdr + 4 * i);
-    mh = fmaxf(mh, v[0]); mt = fmaxf(mt, v[1]); m0 = fmaxf(m0, v[2]);
+// every lane of a wave calls this; parts = the merge kernel's per-block maxima [nblk][2]
+__device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ parts, int nblk, int Jt, int lane) {
+  float mh = 0.f, mt = 0.f;
+  for (int i = lane; i < nblk; i += 64) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(parts + 2 * i);
+    mh = fmaxf(mh, v[0]); mt = fmaxf(mt, v[1]);
   }
-  const int a = 15 - g2_expo((float)Jt * mt * fmaxf(1.0f, m0));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mt = fmaxf(mt, __shfl_xor(mt, o)); }
+  const int a = 15 - g2_expo((float)Jt * mt);            // |h| <= 1 in the image (h_0: scaled per sample by the kernel)
   const int b = 14 - g2_expo(mh);
   G2Scales r;
   r.tail = ldexpf(1.f, a);
   r.head = ldexpf(1.f, b);
   r.un = ldexpf(1.f, -(a + b));
   return r;
-}
-template <typename TS>
-__global__ void __launch_bounds__(256) k_g2_absmax(const float* __restrict__ Gh, long nh, const float* __restrict__ Gt, long nt,
-                                                   const TS* __restrict__ h0, long n0, float* __restrict__ hdr) {
-  __shared__ float red[3][4];
-  const long g = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)G2_HDR_PARTS * 256;
-  float m[3] = {0.f, 0.f, 0.f};
-  for (long i = g; i < nh; i += stride) m[0] = fmaxf(m[0], fabsf(Gh[i]));
-  for (long i = g; i < nt; i += stride) m[1] = fmaxf(m[1], fabsf(Gt[i]));
-  if (h0)
-    for (long i = g; i < n0; i += stride) m[2] = fmaxf(m[2], fabsf(ld(h0, (size_t)i)));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
-    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = m[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 4)
-    hdr[4 * blockIdx.x + threadIdx.x] =
-        threadIdx.x < 3 ? fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3])) : 0.f;
 }
 
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
@@ -131,7 +126,7 @@ __global__ void __launch_bounds__(256) k_g2_absmax(const float* __restrict__ Gh,
 // forward (REV = false): TWO fp16 planes of 2^b Gh (g2_scales), block stride 2 * 64 lanes; reverse: three bf16 planes
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs,
-                                                     const float* __restrict__ hdr) {
+                                                     const float* __restrict__ hdr, int nblk) {
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
@@ -141,7 +136,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   xbf8 f0, f1, f2;
   xh8 g0, g1;
   float hsc = 1.f;
-  if constexpr (!REV) hsc = g2_scales(hdr, m.Jt).head;
+  if constexpr (!REV) hsc = g2_scales(hdr, nblk, m.Jt, lane).head;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f;
@@ -196,7 +191,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
 //   reverse: A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]         at (mt*bKS1 + ks)*64 + lane
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft,
-                                                     const float* __restrict__ hdr) {
+                                                     const float* __restrict__ hdr, int nblk) {
   const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
   const int KS = REV ? m.bKS1 : m.KS1;
   const int ks = blockIdx.x % KS, mt = blockIdx.x / KS;
@@ -205,7 +200,7 @@ __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __res
   else { const int row = 16 * mt + mm; it = row / m.Rp; a = row % m.Rp; jt = 4 * ks + kq; }
   float v = 0.f;
   if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
-  if constexpr (!REV) v *= g2_scales(hdr, m.Jt).tail;          // forward: C1 comes out of stage 1 already scaled
+  if constexpr (!REV) v *= g2_scales(hdr, nblk, m.Jt, lane).tail;   // forward: C1 comes out of stage 1 already scaled
   ft[(size_t)blockIdx.x * 64 + lane] = v;
 }
 
@@ -267,7 +262,7 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 template <int CELL, typename TS, int UPT, bool RES, bool DIAG>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
-                                                  const float* __restrict__ ft1, const float* __restrict__ hdr,
+                                                  const float* __restrict__ ft1, const float* __restrict__ hdr, int nblk,
                                                   TS* __restrict__ out, TS* __restrict__ hT,
                                                   TS* __restrict__ cT, float* __restrict__ reserve) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,7 +281,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
-  const float unsc = g2_scales(hdr, m.Jt).un;                       // 2^-(a+b): stage-2 sums -> pre-activations
+  const float unsc = g2_scales(hdr, nblk, m.Jt, lane).un;           // 2^-(a+b): stage-2 sums -> pre-activations
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
   for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
@@ -320,11 +315,31 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         hoff[u] = (hid / m.Jt) * m.JtS + hid % m.Jt;
         hst[u] = h0 ? ld(h0, b * H + hid) : 0.f;
         cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
-        hb[hoff[u]] = hst[u];
         if (in1) { gi[u] = gin4[hid]; bb[u] = bil4[hid]; }
         else if (T > 0) gi[u] = gin4[(b * T) * H + hid];
       }
     }
+  }
+  // A caller's h_0 may lie outside (-1, 1), the range the tail scale assumes: the image of step 0 holds 2^-e0 h_0 (e0 >= 0,
+  // per sample, exact) and the stage-2 sums of that step are multiplied back by 2^e0.
+  float h0un = 1.0f;
+  {
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) mx = fmaxf(mx, fabsf(hst[u]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) ybuf[wave] = mx;                        // ybuf: free until the first stage 2
+    __syncthreads();
+    mx = 0.f;
+    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, ybuf[w]);
+    int e0 = g2_expo(mx);
+    if (e0 < 0) e0 = 0;
+    const float h0sc = ldexpf(1.f, -e0);
+    h0un = ldexpf(1.f, e0);
+#pragma unroll
+    for (int u = 0; u < UPT; ++u)
+      if (u < upt && tid + u * 256 < H && tid < 256) hb[hoff[u]] = hst[u] * h0sc;
   }
   // head stream of this wave
   const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
@@ -509,8 +524,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
             for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ya[g] + k1 * yb[g];
           }
+          const float un_t = t == 0 ? unsc * h0un : unsc;
 #pragma unroll
-          for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] *= unsc;         // exact: a power of two
+          for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] *= un_t;         // exact: a power of two
           f32x4 g4 = gi[u];
           if (in1) g4 = bb[u] + xq.at(t) * gi[u];
           float hy;
@@ -828,29 +844,23 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH; }
 
 // merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
-// h0 / n_h0 / hdr_out: forward only (operand maxima for the fp16 scales)
+// hdr_out: forward only (per-block maxima of the merged cores for the fp16 scales)
 int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
-         hipStream_t stream, int dtype = TTRNN_F32, const void* h0 = nullptr, long n_h0 = 0, const float** hdr_out = nullptr) {
+         hipStream_t stream, const float** hdr_out = nullptr) {
   char* p = (char*)ws;
   float* Gh = (float*)p; p += g2_al((size_t)m.head_elems * 4);
   float* Gt = (float*)p; p += g2_al((size_t)m.tail_elems * 4);
   xbf8* hs = (xbf8*)p; p += g2_al((size_t)(rev ? m.bs2_bytes : m.fs2_bytes));
   float* tf = (float*)p; p += g2_al((size_t)(rev ? m.bt1_bytes : m.ft1_bytes));
   float* hdr = (float*)p;                     // forward only (g2_fwd_ws_bytes)
-  const long nm = (long)m.Ih * m.Jh + (long)m.It * m.Jt;
-  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, s, m, packed, Gh, Gt);
+  const int nblk = (int)g2_merge_blocks(m);
+  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt, rev ? (float*)nullptr : hdr);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const float*)nullptr);
-    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const float*)nullptr);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const float*)nullptr, 0);
   } else {
-    if (dtype == TTRNN_F32)
-      hipLaunchKernelGGL(k_g2_absmax<float>, dim3(G2_HDR_PARTS), dim3(256), 0, stream, Gh, m.head_elems, Gt, m.tail_elems,
-                         (const float*)h0, n_h0, hdr);
-    else
-      hipLaunchKernelGGL(k_g2_absmax<bf16_t>, dim3(G2_HDR_PARTS), dim3(256), 0, stream, Gh, m.head_elems, Gt, m.tail_elems,
-                         (const bf16_t*)h0, n_h0, hdr);
-    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const float*)hdr);
-    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr);
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const float*)hdr, nblk);
+    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr, nblk);
     if (hdr_out) *hdr_out = hdr;
   }
   *fs = hs;
@@ -946,7 +956,7 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     if (st == TTRNN_OK)
       st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, rs.in, packed_in, nullptr, ident, wdense, linws, stream, H, ilv);
     void* gscr = (char*)planes + gemm_split_plane_bytes(inp, 4 * H);      // two-piece fp16 GEMM: scales
-    const bool ghalf = !opt(OPT_GEMM_BF16);
+    const bool ghalf = gemm_use_half(rows, inp, 4 * H);
     if (st == TTRNN_OK)
       st = ghalf ? launch_gemm_half_prep(wdense, inp, 4 * H, planes, gscr, stream)
                  : launch_gemm_split_prep(wdense, inp, 4 * H, planes, stream);
@@ -966,7 +976,7 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   const xbf8* fs2;
   const float* ft1;
   const float* hdr = nullptr;
-  st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream, dtype, h0, (long)rs.B * rs.H, &hdr);
+  st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream, &hdr);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
@@ -977,7 +987,8 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
                     : k_g2_fwd<CELLV, TS, UPTV, false, false>;                                                            \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,       \
-                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve);                 \
+                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (int)g2_merge_blocks(P.hid), (TS*)out, (TS*)hT,       \
+                       (TS*)cT, reserve);                                                                                 \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
     if (P.upt == 1) TT_G2_FWD(TTRNN_LSTM, 1, 0);

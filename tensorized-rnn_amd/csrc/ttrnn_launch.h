@@ -147,6 +147,10 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 // the same GEMM on two-piece fp16 operands (three MFMA terms instead of six; per-row scales of x and one scale of W,
 // powers of two): forward input projections.  `planes` as above (two of the three planes are used).
 size_t gemm_half_scratch_bytes(int64_t n_rows);
+// the two scale passes (row maxima of x, maximum of W) are two more launches: below ~4 G multiply-adds the three-piece
+// bf16 GEMM (no passes) is as fast
+// bf16 GEMM (no passes) is as fast; option gemm_pieces = 2 / 3 forces either (A/B switch, tests)
+bool gemm_use_half(int64_t n_rows, int K, int M);
 int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream,
                           bool transposed = false);
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,

@@ -866,7 +866,8 @@ def test_split_math_operand_ranges(case, route):
 def test_half_piece_gemm_input_ranges(storage):
     """The batched input projection runs as a GEMM on two-piece fp16 operands with one power-of-two scale per row of x and
     one for the matrix (ttrnn_fast_gemm.hip): rows of wildly different magnitude, zero rows and outliers inside a row
-    must come out as they do with three bf16 pieces (option gemm_bf16) and as the float64 oracle says."""
+    must come out as they do with three bf16 pieces (option gemm_pieces = 3; by default the library picks by problem size)
+    and as the float64 oracle says."""
     import ttrnn_hip
     from ttrnn_hip import functional as F
     torch.manual_seed(5)
@@ -884,8 +885,8 @@ def test_half_piece_gemm_input_ranges(storage):
     sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
     ref = _oracle_forward(kind, sd, 1, x.double())[0]
     outs = {}
-    for name, val in (("half", 0), ("bf16x3", 1)):
-        with ttrnn_hip.option("gemm_bf16", val), torch.no_grad():
+    for name, val in (("half", 2), ("bf16x3", 3)):
+        with ttrnn_hip.option("gemm_pieces", val), torch.no_grad():
             outs[name] = m(x.to(dev()))[0].float()
     assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) in ("fused_core", "runtime_mfma")
     # rows scaled by 1e3 put pre-activations in the thousands, where one fp32 ulp is 1e-4: both variants sit at 2e-5
