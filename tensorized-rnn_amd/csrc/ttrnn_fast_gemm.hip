@@ -41,11 +41,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // one (max |W| 2^ew <= 2^14), both exact; product = x0w0 + x0w1 + x1w0 (ttrnn_split.h), the epilogue undoes the scales.
 // An output's error is relative to (row maximum) x (matrix maximum) — what matters for a gate pre-activation — and equals
 // the bf16 variant's wherever the entries lie within 2^17 of those maxima.
-__device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral
-  if (!(x > 0.f) || !(x < 3e38f)) return 0;
-  int e;
+__device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral; clamped so that the
+  if (!(x > 0.f) || !(x < 3e38f)) return 0;                // product of a row scale and the matrix scale (and its inverse)
+  int e;                                                   // stays a normal fp32 number
   frexpf(x, &e);
-  return e;
+  return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
 __device__ __forceinline__ float g_wscale(const float* __restrict__ parts) {
   float m = 0.f;

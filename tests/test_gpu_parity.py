@@ -877,6 +877,7 @@ def test_half_piece_gemm_input_ranges(storage):
     B, T = 64, 16
     x = torch.randn(B, T, 40) * (10.0 ** (torch.rand(B, T, 1) * 9 - 6))      # row scales 1e-6 .. 1e3
     x[3, 2] = 0.0
+    x[7, 3] = 1e-30 * torch.randn(40)                                          # a row far below every other (scale clamp)
     x[5, 1, 7] = 2.0e4                                                         # outlier inside a small row
     x[:, 0] *= 1e-3
     if storage == "bf16":
