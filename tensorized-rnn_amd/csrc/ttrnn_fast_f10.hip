@@ -698,12 +698,17 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
   const bool dg = opt(OPT_DIAG) && reserve;
-  // two samples per workgroup once there are more samples than CUs (the kernel owns a CU: see k_lstm_fwd_f10)
+  // Four-wave workgroups (ttrnn_fast_f10q.hip; bit-identical results): always for r = 8 — 1 ... 3 % faster than the
+  // eight-wave kernel even with one workgroup per CU (fewer waves per barrier, no LDS copy of h for the output store) — and
+  // for r = 16 once two workgroups can share a CU (B > #CUs / 2: 5 % at B = 192, 10 % at B = 512; below that the eight-wave
+  // k-split kernel is 1 % ahead).  OPT_F10_NB1: eight waves, one sample per workgroup, whatever B (A/B switch);
+  // OPT_F10_NB2: two samples per eight-wave workgroup for B > #CUs (round 1's variant, A/B switch).
   const int cus = device_cu_count();
-  if (rs.B > cus && !dg && !opt(OPT_F10_NB1)) {      // OPT_F10_NB1: A/B switch, one sample per workgroup
-    // four-wave workgroups, two per CU (ttrnn_fast_f10q.hip); OPT_F10_NB2: two samples per eight-wave workgroup (A/B)
-    if (!opt(OPT_F10_NB2)) return launch_rnn_fwd_f10_q(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
-    return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
+  if (!dg && !opt(OPT_F10_NB1)) {
+    if (rs.B > cus && opt(OPT_F10_NB2))
+      return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
+    if (KS == 1 || 2 * rs.B > cus)
+      return launch_rnn_fwd_f10_q(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
   }
   auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
