@@ -320,9 +320,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
       }
     }
   }
-  // A caller's h_0 may lie outside (-1, 1), the range the tail scale assumes: the image of step 0 holds 2^-e0 h_0 (e0 >= 0,
-  // per sample, exact) and the stage-2 sums of that step are multiplied back by 2^e0.
-  float h0un = 1.0f;
+  // A caller's h_0 may lie outside (-1, 1), the range the tail scale assumes: the image holds 2^-e0 h (e0 >= 0, per sample,
+  // exact) and the stage-2 sums are multiplied back by 2^e0 — at step 0 for an LSTM (h_t = o tanh(c) is inside (-1, 1) from
+  // then on), at EVERY step for a GRU (h_t = (1 - z) n + z h_{t-1} only stays below max(1, |h_0|)).
+  float h0un = 1.0f, h0sc = 1.0f;
   {
     float mx = 0.f;
 #pragma unroll
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     for (int w = 0; w < NW; ++w) mx = fmaxf(mx, ybuf[w]);
     int e0 = g2_expo(mx);
     if (e0 < 0) e0 = 0;
-    const float h0sc = ldexpf(1.f, -e0);
+    h0sc = ldexpf(1.f, -e0);
     h0un = ldexpf(1.f, e0);
 #pragma unroll
     for (int u = 0; u < UPT; ++u)
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
             for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ya[g] + k1 * yb[g];
           }
-          const float un_t = t == 0 ? unsc * h0un : unsc;
+          const float un_t = (t == 0 || !LSTM) ? unsc * h0un : unsc;
 #pragma unroll
           for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] *= un_t;         // exact: a power of two
           f32x4 g4 = gi[u];
@@ -553,7 +554,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
           hy = round_to(hy, out);                        // the stored value is what the next step and the next layer see
           st(out, bt * H + hid, hy);
           hst[u] = hy;
-          hb[hoff[u]] = hy;
+          hb[hoff[u]] = LSTM ? hy : hy * h0sc;
           // gate inputs of the NEXT step: requested after this step's last use of the registers and after its stores, used a
           // whole step later (no wait ever lands on a request just issued; the address is clamped, the load unconditional)
           if (!in1) gi[u] = gin4[(t + 1 < T ? bt + 1 : bt) * H + hid];

@@ -862,6 +862,31 @@ def test_split_math_operand_ranges(case, route):
     assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("kind", ["ttgru", "ttlstm"])
+def test_runtime_tier_initial_state_far_outside_unit_range(kind):
+    """The runtime-shape tier's fp16 stage-2 operands assume |h| <= 1; a caller's h_0 is carried with a per-sample power of
+    two — for a GRU at every step, because h_t = (1 - z) n + z h_{t-1} can stay as large as h_0 for many steps."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(23)
+    m = build_module(dict(kind=kind, input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), dev())
+    B, T = 5, 12
+    x = torch.randn(B, T, 28)
+    h0 = torch.randn(B, 192) * torch.tensor([0.1, 3.0, 40.0, 500.0, 6000.0]).view(B, 1)
+    c0 = torch.randn(B, 192)
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    init = (h0.double(), c0.double()) if kind == "ttlstm" else h0.double()
+    ref = _oracle_forward(kind, sd, 1, x.double(), init)[0]
+    with torch.no_grad():
+        res = m(x.to(dev()), (h0.to(dev()), c0.to(dev())) if kind == "ttlstm" else h0.to(dev()))
+    out = res[0].float().cpu()
+    assert torch.isfinite(out).all()
+    for b in range(B):       # error relative to each sample's own scale (the GRU keeps |h| near |h_0| for a while)
+        scale = max(1.0, float(ref[b].abs().max()))
+        assert _maxabs(out[b], ref[b]) <= 2e-5 * scale, (b, _maxabs(out[b], ref[b]), scale)
+
+
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_half_piece_gemm_input_ranges(storage):
     """The batched input projection runs as a GEMM on two-piece fp16 operands with one power-of-two scale per row of x and
