@@ -887,6 +887,42 @@ def test_runtime_tier_initial_state_far_outside_unit_range(kind):
         assert _maxabs(out[b], ref[b]) <= 2e-5 * scale, (b, _maxabs(out[b], ref[b]), scale)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_runtime_tier_random_shapes_and_magnitudes(seed):
+    """Random (cell, H, ncores, rank, input size), every core multiplied by its own random power of ten, random initial state
+    magnitude: the runtime-shape forward (fp16 stage-2 operands, scales from the merged cores' maxima) against float64."""
+    import random
+    from ttrnn_hip import functional as F
+    rnd = random.Random(1000 + seed)
+    kind = rnd.choice(["ttlstm", "ttgru"])
+    H = rnd.choice([64, 96, 128, 192, 320, 512])
+    d = rnd.choice([2, 3, 4]) if H != 96 else rnd.choice([2, 3])
+    r = rnd.choice([2, 3, 4, 6, 8])
+    inp = rnd.choice([1, 12, 28, 40])
+    torch.manual_seed(seed)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r), dev())
+    B, T = 4, 6
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "parameters" in n:
+                p.mul_(10.0 ** rnd.uniform(-2.0, 0.7))
+    if F.rnn_route(m._all_layers[0]._layer_spec(), B, T) != "runtime_mfma":
+        pytest.skip("shape has a specialised kernel")
+    x = torch.randn(B, T, inp) * 10.0 ** rnd.uniform(-2, 1)
+    h0 = torch.randn(B, H) * 10.0 ** rnd.uniform(-3, 2)
+    c0 = torch.randn(B, H)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    init = (h0.double(), c0.double()) if kind == "ttlstm" else h0.double()
+    ref = _oracle_forward(kind, sd, 1, x.double(), init)[0]
+    with torch.no_grad():
+        out = m(x.to(dev()), (h0.to(dev()), c0.to(dev())) if kind == "ttlstm" else h0.to(dev()))[0].float().cpu()
+    assert torch.isfinite(out).all()
+    scale = max(1.0, float(ref.abs().max()))
+    err = _maxabs(out, ref)
+    print(kind, "H", H, "d", d, "r", r, "in", inp, "max|ref| %.3g err %.3g" % (float(ref.abs().max()), err))
+    assert err <= 5e-5 * scale
+
+
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_half_piece_gemm_input_ranges(storage):
     """The batched input projection runs as a GEMM on two-piece fp16 operands with one power-of-two scale per row of x and
