@@ -91,14 +91,14 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __b
 // ---- the same step on two-piece fp16 operands (ttrnn_split.h): LSTM forward kernels ---------------------------------
 // Scales (powers of two, exact) derived from the maxima k_f10h_scale leaves at the start of the fragment workspace:
 //   2^a   core 2 (S2's constant operand)      max |G2| 2^a  <= 2^6
-//   2^sH  h (S2's dynamic operand)            max |h| 2^sH  <= 2^6   (|h_t| < 1; h_0 is the caller's)
+//   2^sH  h (S2's dynamic operand)            |h| 2^sH  <= 2^6       (|h_t| < 1; a caller's h_0: f10h_h0_expo, per sample)
 //   2^sw  the fused core W10                  max |W10| 2^sw <= 2^12 (bound R1 max|G0| max|G1|)
 //   2^S, 2^-S with S = a + sH + sw: accumulators of S10 are 2^S times the pre-activations
 // so that |T| 2^(a+sH) <= J2 2^12 = 2^15 stays inside fp16 and the second pieces stay normal over >= 9 binades below each
 // operand's maximum (smaller entries keep an ABSOLUTE error of 2^-31 of the maximum or better).
 static constexpr int F10H_HDR_BYTES = 256;
 // The header holds F10H_PARTS partial maxima per quantity ([part][4]: |core 0|, |core 1|, |core 2|, |h_0|), one per
-// workgroup of k_f10h_scale; every consumer (prep and recurrent workgroups) reduces them itself — 16 loads — instead of
+// workgroup of k_f10h_scale (the h_0 column is always 0 now: f10h_h0_expo); every consumer reduces them itself — 16 loads — instead of
 // waiting for one more dependent launch to do it.
 static constexpr int F10H_PARTS = 16;
 struct F10hScales { float g2, h, w, pre, un; };
@@ -139,6 +139,25 @@ constexpr size_t f10h_lds_bytes() {
   // operand + (KS == 2) the partial accumulators handed from the second k-half's waves to the gate waves
   return 2 * sizeof(float) * F10<S>::H + 2 * 2 * 2 * (size_t)F10<S>::H + 2 * 2 * (size_t)F10<S>::PLANE +
          (KS == 2 ? F10<S>::MT * 64 * sizeof(f32x4) : 0);
+}
+
+// A caller's h_0 may lie outside (-1, 1), the range the scale of h assumes (|h_t| < 1 for every t >= 1): per SAMPLE the
+// pieces of h_0 are those of 2^-e0 h_0 (e0 >= 0, max |h_0[b]| < 2^e0) and the first step's accumulators — whose initial
+// value is scaled alike — are multiplied back by 2^e0.  Per sample, so that a sample's result never depends on which other
+// samples share its batch.  Every thread of the workgroup calls this; `scratch`: NWV floats of LDS nothing else uses yet.
+template <int NWV>
+__device__ __forceinline__ int f10h_h0_expo(float hmine, float* scratch, int wave, int lane) {
+  float mx = fabsf(hmine);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) scratch[wave] = mx;
+  lds_barrier();
+  mx = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) mx = fmaxf(mx, scratch[w]);
+  lds_barrier();
+  const int e = f10h_expo(mx);
+  return e < 0 ? 0 : e;
 }
 
 // term-packed fragment of core 2 for m-tile mt: k-groups w0 | w1 | w0 | w1 against activation groups x0 | x0 | x1 | x1:

@@ -208,6 +208,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
   float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
+  const int e0 = h0 ? f10h_h0_expo<FAST_NW>(hst, reinterpret_cast<float*>(img), wave, lane) : 0;    // uniform branch
+  const float h0sc = ldexpf(1.f, -e0), h0un = ldexpf(1.f, e0);
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
   // The fused core's rows are pre-multiplied (k_f10h_prep) so that an accumulator, times the header's 2^-S, IS the
   // argument of v_exp_f32: sigmoid(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 1 - 2 / (1 + 2^(2 log2e x)).  The input
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       }
     }
     _Float16 p0, p1;                                       // parity 0 = h_{-1}
-    split2h(hst * hsc, p0, p1);
+    split2h(hst * (hsc * h0sc), p0, p1);
     hpl[hd] = p0; hpl[H + hd] = p1;
     hbuf[hd] = hst;
   }
@@ -270,11 +272,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
       if (gate_wave) {
         // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
-        const f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+        f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+        if (t == 0) pre = pre * h0sc;                     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
         acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       }
       f10h_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
-      acc = acc_hi * usc + acc_lo * usc;                // 2^-S, exact
+      const float us_t = t == 0 ? usc * h0un : usc;
+      acc = acc_hi * us_t + acc_lo * us_t;              // 2^-S (2^(e0-S) at step 0), exact
       if constexpr (DIAG) {
         asm volatile("" : "+v"(acc));
       }
@@ -691,8 +695,8 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
   static_assert(F10H_PARTS * 4 * sizeof(float) <= F10H_HDR_BYTES, "header");
-  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, (const float*)h0,
-                     (long)rs.B * rs.H, hdr);
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, (const float*)nullptr,
+                     0L, hdr);          // h_0 is scaled per sample inside the recurrent kernels (f10h_h0_expo)
   hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   constexpr size_t lds = f10h_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   // per-sample state; a workgroup whose second sample lies past the batch carries a copy of the last one (never stored)
   size_t bs[NB];
   bool live[NB];
-  float hst[NB], cst[NB];
+  float hst[NB], cst[NB], h0sc[NB], h0un[NB];       // h0sc / h0un: per-sample 2^-e0 / 2^e0 (f10h_h0_expo)
   f32x4 gi[NB];
   XChunk<float> xq[NB];
   float* hbuf[NB];
@@ -102,13 +102,17 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
     xbuf[sm] = reinterpret_cast<f32x4*>(img[sm] + 2 * F::PLANE);                // KS == 2: partial accumulators
     hst[sm] = (ok && h0) ? h0[bs[sm] * H + hd] : 0.f;
     cst[sm] = (ok && c0) ? c0[bs[sm] * H + hd] : 0.f;
+    {
+      const int e0 = h0 ? f10h_h0_expo<FAST_NW>(hst[sm], reinterpret_cast<float*>(img[sm]), wave, lane) : 0;   // uniform branch
+      h0sc[sm] = ldexpf(1.f, -e0); h0un[sm] = ldexpf(1.f, e0);
+    }
     gi[sm] = f32x4{0.f, 0.f, 0.f, 0.f};
     xq[sm].cur = 0.f; xq[sm].nxt = 0.f;
     if (in1) xq[sm].init(xs, bs[sm] * T, T, lane);
     if (ok) {
       if (T > 0 && !in1) gi[sm] = *reinterpret_cast<const f32x4*>(gin + ((bs[sm] * T) * H + hd) * 4);
       _Float16 p0, p1;                                       // parity 0 = h_{-1}
-      split2h(hst[sm] * hsc, p0, p1);
+      split2h(hst[sm] * (hsc * h0sc[sm]), p0, p1);
       hpl[sm][hd] = p0; hpl[sm][H + hd] = p1;
       hbuf[sm][hd] = hst[sm];
     }
@@ -151,11 +155,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
       if (mma_wave) {
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
         if (gate_wave) {
-          const f32x4 pre = in1 ? bb + xq[sm].at(t) * vv : (gi[sm] + bh) * gsc;
+          f32x4 pre = in1 ? bb + xq[sm].at(t) * vv : (gi[sm] + bh) * gsc;
+          if (t == 0) pre = pre * h0sc[sm];                 // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
           acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
         }
         f10h_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
-        acc[sm] = acc_hi * usc + acc_lo * usc;              // 2^-S, exact
+        const float us_t = t == 0 ? usc * h0un[sm] : usc;
+        acc[sm] = acc_hi * us_t + acc_lo * us_t;            // 2^-S (2^(e0-S) at step 0), exact
         if constexpr (DIAG) {
           asm volatile("" : "+v"(acc[sm]));
         }

@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
   float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
+  const int e0 = h0 ? f10h_h0_expo<QW>(hst, reinterpret_cast<float*>(img), wave, lane) : 0;    // uniform branch
+  const float h0sc = ldexpf(1.f, -e0), h0un = ldexpf(1.f, e0);
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
   const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
   XChunk<float> xq;
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
       }
     }
     _Float16 p0, p1;                                       // parity 0 = h_{-1}
-    split2h(hst * hsc, p0, p1);
+    split2h(hst * (hsc * h0sc), p0, p1);
     hpl[hd] = p0; hpl[H + hd] = p1;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so that no weight-register wait lands inside the loop
@@ -126,14 +128,16 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
     f32x4 acc;
     {
       // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
-      const f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+      f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
+      if (t == 0) pre = pre * h0sc;                       // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
+      const float us_t = t == 0 ? usc * h0un : usc;
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       f10h_s10_part<S, NH>(w10[0], img, row10, q, 0, acc_lo, acc_hi);
-      acc = acc_hi * usc + acc_lo * usc;                  // 2^-S, exact
+      acc = acc_hi * us_t + acc_lo * us_t;                // 2^-S (2^(e0-S) at step 0), exact
       if constexpr (KH == 2) {
         f32x4 bl = f32x4{0.f, 0.f, 0.f, 0.f}, bhh = bl;
         f10h_s10_part<S, NH>(w10[1], img, row10, q, NH, bl, bhh);
-        acc += bhh * usc + bl * usc;
+        acc += bhh * us_t + bl * us_t;
       }
     }
     const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));                // lstm.py:26

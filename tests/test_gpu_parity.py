@@ -923,6 +923,43 @@ def test_runtime_tier_random_shapes_and_magnitudes(seed):
     assert err <= 5e-5 * scale
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fused_core_stack_random_magnitudes(seed):
+    """Two stacked H = 256 TT-LSTM layers (ranks 8 / 16: one-wave and k-split fused-core kernels, the input projections as the
+    two-piece fp16 GEMM) with every core scaled by its own random power of ten, random input and state magnitudes, against
+    the float64 oracle; the outputs must also be identical bit for bit when the batch is cut in two."""
+    import random
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    rnd = random.Random(77 + seed)
+    r = rnd.choice([8, 16])
+    torch.manual_seed(seed)
+    m = build_module(dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=r), dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "parameters" in n:
+                p.mul_(10.0 ** rnd.uniform(-1.5, 0.5))
+    B, T = rnd.choice([20, 33]), rnd.choice([5, 9])
+    assert F.rnn_route(m._all_layers[1]._layer_spec(), B, T) == "fused_core"
+    x = torch.randn(B, T, 40) * 10.0 ** rnd.uniform(-2, 1.5)
+    h0 = torch.randn(B, 256) * 10.0 ** rnd.uniform(-2, 2)
+    c0 = torch.randn(B, 256) * 10.0 ** rnd.uniform(-1, 1)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    ref = _oracle_forward("ttlstm", sd, 2, x.double(), (h0.double(), c0.double()))[0]
+    xd, hd, cd = x.to(dev()), h0.to(dev()), c0.to(dev())
+    with ttrnn_hip.option("gemm_pieces", 2), torch.no_grad():
+        out = m(xd, (hd, cd))[0]
+        cut = B - 3                      # still >= 2 * in rows: the same K-in route as the whole batch
+        oa = m(xd[:cut], (hd[:cut], cd[:cut]))[0]
+    assert torch.isfinite(out).all()
+    err = _maxabs(out, ref)
+    scale = max(1.0, float(ref.abs().max()))
+    print("r", r, "B", B, "T", T, "max|ref| %.3g err %.3g" % (float(ref.abs().max()), err))
+    assert err <= 5e-5 * scale
+    # the scale of a caller's h_0 is taken per sample (f10h_h0_expo): a sample's result does not depend on its batch mates
+    assert torch.equal(out[:cut], oa)
+
+
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_half_piece_gemm_input_ranges(storage):
     """The batched input projection runs as a GEMM on two-piece fp16 operands with one power-of-two scale per row of x and
