@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ pack
 // KS = 1: waves 0..MT-1 run the whole contraction of their tile.  KS = 2 (long contractions: the resident fragments
 // of a whole tile row would not fit the register file): waves t and t+4 — the two waves of one SIMD — take one half of
 // the k-blocks each, the second hands its partial accumulators to the first through LDS.
-template <class S, int KS, bool DIAG>
+template <class S, int KS, bool DIAG, bool H0>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ c0,
                                                           const float* __restrict__ packed_hid,
@@ -206,10 +206,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const bool in1 = gs.in1 != 0;
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
-  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
+  float hst = (H0 && ok) ? h0[b * H + hd] : 0.f;       // H0: the caller passed an initial state (f10h_h0_expo)
   float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
-  const int e0 = h0 ? f10h_h0_expo<FAST_NW>(hst, reinterpret_cast<float*>(img), wave, lane) : 0;    // uniform branch
-  const float h0sc = ldexpf(1.f, -e0), h0un = ldexpf(1.f, e0);
+  float h0sc = 1.0f, h0un = 1.0f;
+  if constexpr (H0) {
+    const int e0 = f10h_h0_expo<FAST_NW>(hst, reinterpret_cast<float*>(img), wave, lane);
+    h0sc = ldexpf(1.f, -e0); h0un = ldexpf(1.f, e0);
+  }
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
   // The fused core's rows are pre-multiplied (k_f10h_prep) so that an accumulator, times the header's 2^-S, IS the
   // argument of v_exp_f32: sigmoid(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 1 - 2 / (1 + 2^(2 log2e x)).  The input
@@ -242,6 +245,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   if constexpr (DIAG) last_ = stamp();
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
+  float us_t = usc * h0un, ps_t = h0sc;     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
@@ -273,12 +277,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       if (gate_wave) {
         // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
         f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
-        if (t == 0) pre = pre * h0sc;                     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
+        if constexpr (H0) pre = pre * ps_t;
         acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       }
       f10h_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
-      const float us_t = t == 0 ? usc * h0un : usc;
-      acc = acc_hi * us_t + acc_lo * us_t;              // 2^-S (2^(e0-S) at step 0), exact
+      const float un = H0 ? us_t : usc;
+      acc = acc_hi * un + acc_lo * un;                  // 2^-S (2^(e0-S) at step 0 of a given h_0), exact
       if constexpr (DIAG) {
         asm volatile("" : "+v"(acc));
       }
@@ -319,6 +323,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       for (int h4 = lane; h4 < H / 4; h4 += 64)
         *reinterpret_cast<f32x4*>(out + (bt - 1) * H + 4 * h4) = *reinterpret_cast<const f32x4*>(hprev + 4 * h4);
     }
+    us_t = usc; ps_t = 1.0f;
     lds_barrier();
     TT_STAMP(4)
   }
@@ -714,7 +719,8 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
     if (KS == 1 || 2 * rs.B > cus)
       return launch_rnn_fwd_f10_q(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
   }
-  auto kern = dg ? k_lstm_fwd_f10<S, KS, true> : k_lstm_fwd_f10<S, KS, false>;
+  auto kern = dg ? (h0 ? k_lstm_fwd_f10<S, KS, true, true> : k_lstm_fwd_f10<S, KS, true, false>)
+                 : (h0 ? k_lstm_fwd_f10<S, KS, false, true> : k_lstm_fwd_f10<S, KS, false, false>);
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;

@@ -155,8 +155,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
       if (mma_wave) {
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
         if (gate_wave) {
-          f32x4 pre = in1 ? bb + xq[sm].at(t) * vv : (gi[sm] + bh) * gsc;
-          if (t == 0) pre = pre * h0sc[sm];                 // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
+          const f32x4 pre = (in1 ? bb + xq[sm].at(t) * vv : (gi[sm] + bh) * gsc) * (t == 0 ? h0sc[sm] : 1.0f);   // step 0: 2^-e0 h_0
           acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
         }
         f10h_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);

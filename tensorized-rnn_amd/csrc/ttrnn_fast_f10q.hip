@@ -29,7 +29,8 @@ constexpr size_t f10q_lds_bytes() {
 }
 
 // KH = 1: one accumulation over all k-blocks (= k_lstm_fwd_f10<S, 1>);  KH = 2: the two halves of k_lstm_fwd_f10<S, 2>
-template <class S, int KH>
+// H0: the caller passed an initial state (it may lie outside (-1, 1): f10h_h0_expo); without one the scales are constants
+template <class S, int KH, bool H0>
 __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                const float* __restrict__ c0,
                                                                const float* __restrict__ packed_hid,
@@ -73,10 +74,13 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   const bool in1 = gs.in1 != 0;
   const bool ok = c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
-  float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
+  float hst = (H0 && ok) ? h0[b * H + hd] : 0.f;
   float cst = (ok && c0) ? c0[b * H + hd] : 0.f;
-  const int e0 = h0 ? f10h_h0_expo<QW>(hst, reinterpret_cast<float*>(img), wave, lane) : 0;    // uniform branch
-  const float h0sc = ldexpf(1.f, -e0), h0un = ldexpf(1.f, e0);
+  float h0sc = 1.0f, h0un = 1.0f;
+  if constexpr (H0) {
+    const int e0 = f10h_h0_expo<QW>(hst, reinterpret_cast<float*>(img), wave, lane);
+    h0sc = ldexpf(1.f, -e0); h0un = ldexpf(1.f, e0);
+  }
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
   const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
   XChunk<float> xq;
@@ -103,6 +107,7 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   // changed nothing: measured 1.71 ms for every delay between 0 and 3 800 cycles on cfg4.)
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
+  float us_t = usc * h0un, ps_t = h0sc;     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
@@ -129,15 +134,15 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
     {
       // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
       f32x4 pre = in1 ? bb + xq.at(t) * vv : (gi + bh) * gsc;
-      if (t == 0) pre = pre * h0sc;                       // step 0 runs on 2^-e0 h_0 (f10h_h0_expo)
-      const float us_t = t == 0 ? usc * h0un : usc;
+      if constexpr (H0) pre = pre * ps_t;
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       f10h_s10_part<S, NH>(w10[0], img, row10, q, 0, acc_lo, acc_hi);
-      acc = acc_hi * us_t + acc_lo * us_t;                // 2^-S (2^(e0-S) at step 0), exact
+      const float un = H0 ? us_t : usc;
+      acc = acc_hi * un + acc_lo * un;                    // 2^-S (2^(e0-S) at step 0 of a given h_0), exact
       if constexpr (KH == 2) {
         f32x4 bl = f32x4{0.f, 0.f, 0.f, 0.f}, bhh = bl;
         f10h_s10_part<S, NH>(w10[1], img, row10, q, NH, bl, bhh);
-        acc += bhh * us_t + bl * us_t;
+        acc += bhh * un + bl * un;
       }
     }
     const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));                // lstm.py:26
@@ -160,6 +165,7 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
       if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
     }
     if (in1) xq.advance(xs, b * T, T, t, lane);
+    us_t = usc; ps_t = 1.0f;
     lds_barrier();
   }
   if (ok) {
@@ -175,8 +181,9 @@ static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* 
   const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
   constexpr size_t lds = f10q_lds_bytes<S>();
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_f10q<S, KH>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL((k_lstm_fwd_f10q<S, KH>), dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
+  auto kern = h0 ? k_lstm_fwd_f10q<S, KH, true> : k_lstm_fwd_f10q<S, KH, false>;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
