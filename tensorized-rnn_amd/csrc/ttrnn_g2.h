@@ -39,7 +39,11 @@ struct G2Mat {
   // forward stage 2 (bf16 MFMA 16x16x32, three-way split): tiles (m2, n2), k blocks of 32; a tile's k range is split
   // over KSPLIT waves when there are fewer tiles than waves; unit u = tile*KSPLIT + part, wave w takes u = w, w+NW, ..
   int M2T, N2T, NKB, T2, KSPLIT, KPER, KBP, U, UW;  // KPER = k-blocks per part, KBP = KPER padded to G2_PF, UW = units per wave (max)
-  int JtS;                          // fp32 h image [16*N1T][JtS]
+  int JtS;                          // (unused since the forward stage 1 left the fp32 MFMA)
+  // forward stage 1 on two-piece fp16 operands: KB1 = 32-wide k-blocks over j_t; pack8 (J_t <= 8): the four piece products
+  // packed along the 32-wide k of ONE MFMA, k-groups [w0|w1|w0|w1] x [x0|x0|x1|x1]; JS = row stride (elements) of the two fp16
+  // planes of the h image [2][16*N1T][JS]
+  int KB1, pack8, JS;
   int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
   // reverse T2 (bf16 MFMA, split): M = Jh*Rp, N = It, K = Ih
   int bM2T, bNKB, bT2, bKBP, bU, bUW;              // no k split: T1 reads the complete dC1
@@ -83,7 +87,8 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
     for (int k = sp; k < s.d; ++k) It *= s.I[k];
     for (int k = 0; k < sp; ++k) Jh *= s.J[k];
     const long rp = (s.R[sp] + 3) & ~3;
-    // MFMA work with the tile padding: stage 1 (fp32, 4x the cycles per FLOP of a split bf16 block) + stage 2
+    // MFMA work with the tile padding: stage 1 priced as on the fp32 MFMA (what the reverse kernel's T1 still runs on; the
+    // forward's fp16 stage 1 is cheaper, the split point is shared) + stage 2
     const long c1 = (long)g2_ceil((int)(It * rp), 16) * g2_ceil((int)Jh, 16) * g2_ceil(s.in_size / (int)Jh, 4) * 32;
     const long c2 = (long)g2_ceil(s.out_size / (int)It, 16) * g2_ceil((int)It, 16) * g2_ceil((int)(Jh * rp), 32) * 96;
     long cost = c1 + c2;
@@ -117,6 +122,9 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->T2 = m->M2T * m->N2T;
   g2_split(nw, m->T2, m->NKBt, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
   m->JtS = 4 * m->KS1 + 1;
+  m->pack8 = m->Jt <= 8;
+  m->KB1 = g2_ceil(m->Jt, 32);
+  m->JS = 32 * m->KB1 + 16;
   // row stride = 32 (mod 64) bytes-of-slots: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
   // (MI355X guide, LDS table); with rows 16 bf16 past a multiple of 32 every group covers all 64 banks once (enumerated)
   m->K2S = 32 * m->NKB + 16;
@@ -140,7 +148,7 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->head_elems = (long)m->Ih * m->Jh * m->R;
   m->tail_elems = (long)m->It * m->Jt * m->R;
   m->fs2_bytes = (long)nw * m->UW * m->KBP * 2 * 64 * 16;
-  m->ft1_bytes = (long)m->M1T * m->KS1 * 64 * 4;
+  m->ft1_bytes = (long)m->M1T * m->KB1 * (m->pack8 ? 1 : 2) * 64 * 16;     // fp16 fragments (xh8 per lane), 1 or 2 planes
   m->bs2_bytes = (long)nw * m->bUW * m->bKBP * 3 * 64 * 16;
   m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
   m->ok = 1;
@@ -170,7 +178,7 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->upt = g2_ceil(rs.H, 256);
   if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
   const G2Mat& m = p->hid;
-  p->f_hb = (int)g2_al((size_t)16 * m.N1T * m.JtS * 4);
+  p->f_hb = (int)g2_al((size_t)2 * 16 * m.N1T * m.JS * 2);       // two fp16 planes of the h image
   p->f_img = (int)g2_al((size_t)2 * 16 * m.N2T * m.K2S * 2);     // forward: two fp16 planes (ttrnn_split.h, flavour b)
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
   p->f_tab = (int)g2_al((size_t)m.T1 * 64 * 4);

@@ -88,12 +88,13 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
 }
 
 // ---- forward operand scales (two-piece fp16 flavour of ttrnn_split.h) ---------------------------------------------------------
-// Stage 1 stays on the fp32 MFMA; its result C1 = Gt h is what gets split, so the TAIL is pre-multiplied by 2^a with
-// J_t max|Gt| 2^a < 2^15 (|h_t| < 1 for t >= 1, LSTM and GRU alike; a caller's h_0 is put into the image times a per-sample
-// power of two that the first step's sums are multiplied back by), the head by 2^b with max|Gh| 2^b < 2^14, and the gate
-// phase multiplies the stage-2 sums by 2^-(a+b).  All powers of two: exact.  The maxima come out of the merge kernel
-// (one pair per block), no launch of their own.
-struct G2Scales { float tail, head, un; };
+// Both stages run on two-piece fp16 operands.  Stage 1: tail fragments 2^a Gt (max < 2^13) against the image of 2^9 h
+// (|h_t| <= 1 for t >= 1, LSTM and GRU alike; a caller's h_0 is put into the image times a per-sample power of two that the
+// sums are multiplied back by); its fp32 sums are multiplied by the fixed 2^r that brings them below 2^15 and split into
+// stage 2's operand; the head fragments are 2^b Gh (max < 2^14); the gate phase multiplies the stage-2 sums by the inverse
+// of all four.  All powers of two: exact.  The maxima come out of the merge kernel (one pair per block), no launch of
+// their own.
+struct G2Scales { float tail, hsc, r1, head, un; };
 __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / non-finite: neutral
   if (!(x > 0.f)) return 0;
   if (!(x < 3e38f)) return 40;
@@ -102,6 +103,9 @@ __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / no
   return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
 // every lane of a wave calls this; parts = the merge kernel's per-block maxima [nblk][2]
+//   tail: max|Gt| 2^a < 2^13        hsc: |h| 2^9 <= 2^9 (|h| <= 1 in the image; h_0: scaled per sample by the kernel)
+//   r1:   the stage-1 sums, < J_t 2^22, times r1 < 2^15 before they are split      head: max|Gh| 2^b < 2^14
+//   un = 1 / (tail hsc r1 head)
 __device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ parts, int nblk, int Jt, int lane) {
   float mh = 0.f, mt = 0.f;
   for (int i = lane; i < nblk; i += 64) {
@@ -110,13 +114,18 @@ __device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ parts, i
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mt = fmaxf(mt, __shfl_xor(mt, o)); }
-  const int a = 15 - g2_expo((float)Jt * mt);            // |h| <= 1 in the image (h_0: scaled per sample by the kernel)
+  const int a = 13 - g2_expo(mt);
   const int b = 14 - g2_expo(mh);
-  G2Scales r;
-  r.tail = ldexpf(1.f, a);
-  r.head = ldexpf(1.f, b);
-  r.un = ldexpf(1.f, -(a + b));
-  return r;
+  int ej = 0;
+  while ((1 << ej) < Jt) ++ej;                             // J_t <= 2^ej
+  const int r = 15 - 22 - ej;
+  G2Scales s;
+  s.tail = ldexpf(1.f, a);
+  s.hsc = 512.0f;
+  s.r1 = ldexpf(1.f, r);
+  s.head = ldexpf(1.f, b);
+  s.un = ldexpf(1.f, -(a + 9 + r + b));
+  return s;
 }
 
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
@@ -186,22 +195,40 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   }
 }
 
-// tail fragments (fp32, one value per lane and k-step):  lane (m = lane & 15, kq = lane >> 4)
-//   forward: A[m][k] = Gt[(i_t, a) = divmod(16 mt + m, Rp)][j_t = 4 ks + kq]         at (mt*KS1 + ks)*64 + lane
-//   reverse: A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]         at (mt*bKS1 + ks)*64 + lane
+// tail fragments
+//   forward (fp16 pieces of 2^a Gt, MFMA 16x16x32 layout): lane (m = lane & 15, q = lane >> 4), row (i_t, a) = divmod(16 mt + m, Rp)
+//     general: k = 32 kb + 8 q + e <-> j_t, two planes            at ((mt*KB1 + kb)*2 + plane)*64 + lane   (xh8 units)
+//     pack8 (J_t <= 8): k-group q holds piece (q & 1) of j_t = e   at mt*64 + lane
+//   reverse (fp32, one value per lane and k-step): A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]   at (mt*bKS1 + ks)*64 + lane
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft,
                                                      const float* __restrict__ hdr, int nblk) {
   const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
-  const int KS = REV ? m.bKS1 : m.KS1;
-  const int ks = blockIdx.x % KS, mt = blockIdx.x / KS;
-  int it, a, jt;
-  if (REV) { const int k = 4 * ks + kq; it = k / m.Rp; a = k % m.Rp; jt = 16 * mt + mm; }
-  else { const int row = 16 * mt + mm; it = row / m.Rp; a = row % m.Rp; jt = 4 * ks + kq; }
-  float v = 0.f;
-  if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
-  if constexpr (!REV) v *= g2_scales(hdr, nblk, m.Jt, lane).tail;   // forward: C1 comes out of stage 1 already scaled
-  ft[(size_t)blockIdx.x * 64 + lane] = v;
+  if constexpr (REV) {
+    const int ks = blockIdx.x % m.bKS1, mt = blockIdx.x / m.bKS1;
+    const int k = 4 * ks + kq, it = k / m.Rp, a = k % m.Rp, jt = 16 * mt + mm;
+    float v = 0.f;
+    if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
+    ft[(size_t)blockIdx.x * 64 + lane] = v;
+  } else {
+    const float tsc = g2_scales(hdr, nblk, m.Jt, lane).tail;
+    const int kb = blockIdx.x % m.KB1, mt = blockIdx.x / m.KB1;
+    const int row = 16 * mt + mm, it = row / m.Rp, a = row % m.Rp;
+    xh8 f0, f1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int jt = m.pack8 ? e : 32 * kb + 8 * kq + e;
+      float v = 0.f;
+      if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a] * tsc;
+      _Float16 p0, p1;
+      split2h(v, p0, p1);
+      f0[e] = m.pack8 ? ((kq & 1) ? p1 : p0) : p0;
+      f1[e] = p1;
+    }
+    xh8* dst = reinterpret_cast<xh8*>(ft);
+    if (m.pack8) dst[(size_t)mt * 64 + lane] = f0;
+    else { dst[(size_t)(blockIdx.x * 2) * 64 + lane] = f0; dst[(size_t)(blockIdx.x * 2 + 1) * 64 + lane] = f1; }
+  }
 }
 
 // biases of both TTLinears -> one gate-interleaved fp32 row [H][4] that the input projection adds to gin:
@@ -267,11 +294,13 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
                                                   TS* __restrict__ cT, float* __restrict__ reserve) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
-  float* hb = reinterpret_cast<float*>(smem);
+  _Float16* hb = reinterpret_cast<_Float16*>(smem);                 // stage 1's operand: two fp16 planes of 2^9 h, [2][16*N1T][JS]
+  const int HPL = 16 * m.N1T * m.JS;
   _Float16* img = reinterpret_cast<_Float16*>(smem + P.f_hb);     // stage 2's operand: two fp16 planes of 2^a C1
   float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
-  float* lt1 = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // tail fragments (P.f_t1 > 0)
+  xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);         // tail fragments (P.f_t1 > 0)
+  const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
   const int plane = 16 * m.N2T * m.K2S;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -281,7 +310,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
-  const float unsc = g2_scales(hdr, nblk, m.Jt, lane).un;           // 2^-(a+b): stage-2 sums -> pre-activations
+  const G2Scales gsc = g2_scales(hdr, nblk, m.Jt, lane);
+  const float unsc = gsc.un;                                        // stage-2 sums -> pre-activations
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
   for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
@@ -296,7 +326,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   // the tail fragments are read by every wave every step: resident in LDS when they fit (else L1 / L2)
   const bool t1_lds = P.f_t1 > 0;
   if (t1_lds)
-    for (int e = tid; e < m.M1T * m.KS1 * 64; e += NT) lt1[e] = ft1[e];
+    for (int e = tid; e < (int)(m.ft1_bytes / 16); e += NT) lt1[e] = ft1h[e];
   float hst[UPT], cst[UPT];
   int hoff[UPT];
   f32x4 gi[UPT], bb[UPT];      // input_size == 1: gi holds the unit row's projection, bb the bias row
@@ -312,7 +342,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     if (u < upt) {
       const int hid = tid + u * 256;
       if (hid < H && tid < 256) {
-        hoff[u] = (hid / m.Jt) * m.JtS + hid % m.Jt;
+        hoff[u] = (hid / m.Jt) * m.JS + hid % m.Jt;
         hst[u] = h0 ? ld(h0, b * H + hid) : 0.f;
         cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
         if (in1) { gi[u] = gin4[hid]; bb[u] = bil4[hid]; }
@@ -340,7 +370,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     h0un = ldexpf(1.f, e0);
 #pragma unroll
     for (int u = 0; u < UPT; ++u)
-      if (u < upt && tid + u * 256 < H && tid < 256) hb[hoff[u]] = hst[u] * h0sc;
+      if (u < upt && tid + u * 256 < H && tid < 256) {
+        _Float16 p0, p1;
+        split2h(hst[u] * (h0sc * gsc.hsc), p0, p1);
+        hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
+      }
   }
   // head stream of this wave
   const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
@@ -363,9 +397,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const int s1_ta = s1_has ? wave : 0, s1_tb = (s1_has && wave + NW < m.T1) ? wave + NW : s1_ta;
   const int s1_mta = s1_ta / m.N1T, s1_nta = s1_ta - s1_mta * m.N1T;
   const int s1_mtb = s1_tb / m.N1T, s1_ntb = s1_tb - s1_mtb * m.N1T;
-  const int s1_fa = s1_mta * m.KS1 * 64 + lane, s1_fb = s1_mtb * m.KS1 * 64 + lane;
-  const float* s1_bpa = hb + (16 * s1_nta + c) * m.JtS + q;
-  const float* s1_bpb = hb + (16 * s1_ntb + c) * m.JtS + q;
+  // fragment index (xh8 units) / operand row of a stage-1 tile; pack8: one fragment, operand k-group q reads plane q >> 1
+  const int s1_fmul = m.pack8 ? 64 : m.KB1 * 2 * 64;
+  const int s1_boff = m.pack8 ? (q >> 1) * HPL : 8 * q;
+  const int s1_fa = s1_mta * s1_fmul + lane, s1_fb = s1_mtb * s1_fmul + lane;
+  const _Float16* s1_bpa = hb + (16 * s1_nta + c) * m.JS + s1_boff;
+  const _Float16* s1_bpb = hb + (16 * s1_ntb + c) * m.JS + s1_boff;
   const int s1_oa = s1_has ? s1off[s1_ta * 64 + lane] : -1;
   const int s1_ob = (s1_has && s1_tb != s1_ta) ? s1off[s1_tb * 64 + lane] : -1;
   // the single stage-2 unit of this wave when its head fragments are register-resident
@@ -395,25 +432,29 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
     // (tail fragments: LDS-resident or from L1 / L2 — two explicit loops: ONE pointer that may be either makes every read a
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
-    auto pair = [&](auto frag, int fa, int fb, const float* bpa, const float* bpb, int offa, int offb) {
+    auto pair = [&](auto frag, int fa, int fb, const _Float16* bpa, const _Float16* bpb, int offa, int offb) {
       f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;   // two tiles: independent MFMA / split chains
-      for (int ks0 = 0; ks0 < m.KS1; ks0 += 4) {              // operands of four k-steps are requested before the first MFMA
-        float wa[4], wb[4], xa[4], xb[4];                       // (one read -> wait -> MFMA per step exposed the LDS latency 2 KS1 times)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ks = ks0 + e < m.KS1 ? ks0 + e : m.KS1 - 1;
-          wa[e] = frag(fa + ks * 64); wb[e] = frag(fb + ks * 64);
-          xa[e] = bpa[4 * ks]; xb[e] = bpb[4 * ks];
+      if (m.pack8) {                                          // J_t <= 8: x0w0 + x0w1 + x1w0 + x1w1 in one MFMA per tile
+        const xh8 wa = frag(fa), wb = frag(fb);
+        const xh8 xa = *reinterpret_cast<const xh8*>(bpa), xb = *reinterpret_cast<const xh8*>(bpb);
+        acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xa, acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xb, accb, 0, 0, 0);
+      } else {
+        for (int kb = 0; kb < m.KB1; ++kb) {                  // J_t <= 64 in practice: one or two blocks
+          const xh8 wa0 = frag(fa + (kb * 2) * 64), wa1 = frag(fa + (kb * 2 + 1) * 64);
+          const xh8 wb0 = frag(fb + (kb * 2) * 64), wb1 = frag(fb + (kb * 2 + 1) * 64);
+          const xh8 xa0 = *reinterpret_cast<const xh8*>(bpa + 32 * kb), xa1 = *reinterpret_cast<const xh8*>(bpa + HPL + 32 * kb);
+          const xh8 xb0 = *reinterpret_cast<const xh8*>(bpb + 32 * kb), xb1 = *reinterpret_cast<const xh8*>(bpb + HPL + 32 * kb);
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, xa0, acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1, xb0, accb, 0, 0, 0);
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, xa1, acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0, xb1, accb, 0, 0, 0);
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, xa0, acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0, xb0, accb, 0, 0, 0);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (ks0 + e < m.KS1) {
-            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xa[e], acca, 0, 0, 0);
-            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[e], xb[e], accb, 0, 0, 0);
-          }
       }
-      if (offa >= 0) store_split4_h(img, plane, offa, acca);
-      if (offb >= 0) store_split4_h(img, plane, offb, accb);
+      if (offa >= 0) store_split4_h(img, plane, offa, acca * gsc.r1);     // 2^r: below 2^15 (g2_scales)
+      if (offb >= 0) store_split4_h(img, plane, offb, accb * gsc.r1);
     };
     auto stage1 = [&](auto frag) {
       if (s1_has) pair(frag, s1_fa, s1_fb, s1_bpa, s1_bpb, s1_oa, s1_ob);
@@ -421,12 +462,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int t1b = t1 + NW < m.T1 ? t1 + NW : t1;          // (the second tile repeats the first when there is none)
         const int mta = t1 / m.N1T, nta = t1 - mta * m.N1T;
         const int mtb = t1b / m.N1T, ntb = t1b - mtb * m.N1T;
-        pair(frag, mta * m.KS1 * 64 + lane, mtb * m.KS1 * 64 + lane, hb + (16 * nta + c) * m.JtS + q,
-             hb + (16 * ntb + c) * m.JtS + q, s1off[t1 * 64 + lane], t1b != t1 ? s1off[t1b * 64 + lane] : -1);
+        pair(frag, mta * s1_fmul + lane, mtb * s1_fmul + lane, hb + (16 * nta + c) * m.JS + s1_boff,
+             hb + (16 * ntb + c) * m.JS + s1_boff, s1off[t1 * 64 + lane], t1b != t1 ? s1off[t1b * 64 + lane] : -1);
       }
     };
     if (t1_lds) stage1([&](int i) { return lt1[i]; });
-    else stage1([&](int i) { return ft1[i]; });
+    else stage1([&](int i) { return ft1h[i]; });
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
@@ -554,7 +595,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
           hy = round_to(hy, out);                        // the stored value is what the next step and the next layer see
           st(out, bt * H + hid, hy);
           hst[u] = hy;
-          hb[hoff[u]] = LSTM ? hy : hy * h0sc;
+          {
+            _Float16 p0, p1;
+            split2h(hy * (LSTM ? gsc.hsc : gsc.hsc * h0sc), p0, p1);
+            hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
+          }
           // gate inputs of the NEXT step: requested after this step's last use of the registers and after its stores, used a
           // whole step later (no wait ever lands on a request just issued; the address is clamped, the load unconditional)
           if (!in1) gi[u] = gin4[(t + 1 < T ? bt + 1 : bt) * H + hid];
@@ -861,7 +906,7 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
     hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const float*)nullptr, 0);
   } else {
     hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const float*)hdr, nblk);
-    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KS1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr, nblk);
+    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KB1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr, nblk);
     if (hdr_out) *hdr_out = hdr;
   }
   *fs = hs;

@@ -882,9 +882,15 @@ def test_runtime_tier_initial_state_far_outside_unit_range(kind):
         res = m(x.to(dev()), (h0.to(dev()), c0.to(dev())) if kind == "ttlstm" else h0.to(dev()))
     out = res[0].float().cpu()
     assert torch.isfinite(out).all()
+    # the reference's own fp32 arithmetic on the same inputs: a state of 10^4 puts pre-activations at 10^4..10^5, where one
+    # fp32 ulp (4e-3) moves a gate by 1e-3 and the GRU's z * h term by 10 — the yardstick for the largest samples
+    sd32 = {k: v.float() for k, v in sd.items()}
+    init32 = (h0, c0) if kind == "ttlstm" else h0
+    ref32 = _oracle_forward(kind, sd32, 1, x, init32)[0]
     for b in range(B):       # error relative to each sample's own scale (the GRU keeps |h| near |h_0| for a while)
         scale = max(1.0, float(ref[b].abs().max()))
-        assert _maxabs(out[b], ref[b]) <= 2e-5 * scale, (b, _maxabs(out[b], ref[b]), scale)
+        err, err32 = _maxabs(out[b], ref[b]), _maxabs(ref32[b], ref[b])
+        assert err <= max(2e-5 * scale, 8.0 * err32), (b, err, err32, scale)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
