@@ -419,14 +419,14 @@ size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
   size_t alt = 0;
   if (!force_generic()) {
     alt = plan_rnn_generic(rs, true).ws_bytes;
-    if (g2_rnn_available(rs, desc->dtype) && g2_rnn_bwd_workspace(rs) > alt) alt = g2_rnn_bwd_workspace(rs);
+    if (g2_rnn_bwd_available(rs, desc->dtype) && g2_rnn_bwd_workspace(rs) > alt) alt = g2_rnn_bwd_workspace(rs);
   }
   const size_t own = [&]() -> size_t {
-  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
+  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
     return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
   if (!force_generic() && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
-  if (!force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
+  if (!force_generic() && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
   }();
   return own > alt ? own : alt;
@@ -565,7 +565,7 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
   // d_state (the per-step state gradients ActivGradLogger records) is written by the runtime-shape and the any-shape
   // reverse kernels; a request for it takes those routes (the shape-specialised kernels stay untouched)
-  const bool g2_first = (opt(OPT_FORCE_G2) || d_state) && !force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype);
+  const bool g2_first = (opt(OPT_FORCE_G2) || d_state) && !force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
   const bool want_state = d_state != nullptr;
   if (!g2_first && !want_state && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&
@@ -582,7 +582,7 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
     return launch_rnn_bwd_big(rs, desc->dtype, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                               d_h0, d_c0, workspace, (hipStream_t)stream);
   }
-  if (!force_generic() && rs.T > 0 && g2_rnn_available(rs, desc->dtype)) {
+  if (!force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                              d_h0, d_c0, workspace, (hipStream_t)stream, d_state);

@@ -155,12 +155,12 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
 }
 
 struct G2Plan {
-  int ok;
+  int ok, okf, okb;                 // both kernels / the forward / the reverse-time kernel fit
   int cell, G, H, B, T;
   G2Mat hid;
   int upt;                          // hidden units per thread
   // LDS carve-up (bytes) of the forward and the reverse-time kernel
-  int f_hb, f_img, f_ybuf, f_tab, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][64] ints; f_t1: tail fragments (0: from L2)
+  int f_hb, f_img, f_ybuf, f_tab, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_t1: tail fragments (0: from L2)
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
 };
 
@@ -181,7 +181,7 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->f_hb = (int)g2_al((size_t)2 * 16 * m.N1T * m.JS * 2);       // two fp16 planes of the h image
   p->f_img = (int)g2_al((size_t)2 * 16 * m.N2T * m.K2S * 2);     // forward: two fp16 planes (ttrnn_split.h, flavour b)
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
-  p->f_tab = (int)g2_al((size_t)m.T1 * 64 * 4);
+  p->f_tab = (int)g2_al((size_t)m.T1 * 4 * 4);      // stage-1 store offsets: one per (tile, lane quarter)
   p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab;
   p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
   p->f_lds += p->f_t1;
@@ -192,8 +192,11 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
   p->b_t1 = (m.bt1_bytes <= 32 * 1024 && p->b_lds + (int)g2_al((size_t)m.bt1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.bt1_bytes) : 0;
   p->b_lds += p->b_t1;
-  if (p->f_lds > G2_LDS_LIMIT || p->b_lds > G2_LDS_LIMIT) return;
-  p->ok = 1;
+  // the forward and the reverse-time kernel have different LDS footprints (cfg5's shape: 155 KB / 183 KB): each route is
+  // offered on its own, the reserve format is the same for every route
+  p->okf = p->f_lds <= G2_LDS_LIMIT;
+  p->okb = p->b_lds <= G2_LDS_LIMIT;
+  p->ok = p->okf && p->okb;
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams

@@ -286,7 +286,9 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------------
-template <int CELL, typename TS, int UPT, bool RES, bool DIAG>
+// P8: stage 1 term-packed into one MFMA per tile (J_t <= 8); otherwise three MFMAs per 32-k block with the next block's
+// (or next tile pair's) operands requested before the current MFMAs — two code paths in ONE kernel spilled 347 VGPRs
+template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, const float* __restrict__ hdr, int nblk,
@@ -315,14 +317,20 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
   for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
-  for (int e = tid; e < m.T1 * 64; e += NT) {
-    const int t1 = e >> 6, l = e & 63;
-    const int mt1 = t1 / m.N1T, nt1 = t1 - mt1 * m.N1T;
-    const int m1 = 16 * mt1 + 4 * (l >> 4), jh = 16 * nt1 + (l & 15);
+  // stage-1 store offsets: lane (c, q) of tile (mt1, nt1) holds rows m1 = 16 mt1 + 4 q .. + 3 = four consecutive ranks a of ONE
+  // i_t (Rp is a multiple of 4), column j_h = 16 nt1 + c:  offset = [it * K2S + pos(a)] (table, per tile and q) + j_h * RS
+  for (int e = tid; e < m.T1 * 4; e += NT) {
+    const int t1 = e >> 2, qq = e & 3;
+    const int mt1 = t1 / m.N1T;
+    const int m1 = 16 * mt1 + 4 * qq;
     const int it = m1 / m.Rp, a = m1 - it * m.Rp;
-    const int pos = m.ng > 1 ? (a / m.Rb) * m.Kg + jh * m.Rb + a % m.Rb : jh * m.Rp + a;     // gate-major for block-diagonal heads
-    s1off[e] = (it < m.It && jh < m.Jh) ? it * m.K2S + pos : -1;
+    s1off[e] = it < m.It ? it * m.K2S + (m.ng > 1 ? (a / m.Rb) * m.Kg + a % m.Rb : a) : -1;     // gate-major for block-diagonal heads
   }
+  const int s1_rs = m.ng > 1 ? m.Rb : m.Rp;
+  auto s1o = [&](int t1, int nt1) {
+    const int base = s1off[t1 * 4 + q], jh = 16 * nt1 + c;
+    return (base >= 0 && jh < m.Jh) ? base + jh * s1_rs : -1;
+  };
   // the tail fragments are read by every wave every step: resident in LDS when they fit (else L1 / L2)
   const bool t1_lds = P.f_t1 > 0;
   if (t1_lds)
@@ -398,13 +406,13 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const int s1_mta = s1_ta / m.N1T, s1_nta = s1_ta - s1_mta * m.N1T;
   const int s1_mtb = s1_tb / m.N1T, s1_ntb = s1_tb - s1_mtb * m.N1T;
   // fragment index (xh8 units) / operand row of a stage-1 tile; pack8: one fragment, operand k-group q reads plane q >> 1
-  const int s1_fmul = m.pack8 ? 64 : m.KB1 * 2 * 64;
-  const int s1_boff = m.pack8 ? (q >> 1) * HPL : 8 * q;
+  const int s1_fmul = P8 ? 64 : m.KB1 * 2 * 64;
+  const int s1_boff = P8 ? (q >> 1) * HPL : 8 * q;
   const int s1_fa = s1_mta * s1_fmul + lane, s1_fb = s1_mtb * s1_fmul + lane;
   const _Float16* s1_bpa = hb + (16 * s1_nta + c) * m.JS + s1_boff;
   const _Float16* s1_bpb = hb + (16 * s1_ntb + c) * m.JS + s1_boff;
-  const int s1_oa = s1_has ? s1off[s1_ta * 64 + lane] : -1;
-  const int s1_ob = (s1_has && s1_tb != s1_ta) ? s1off[s1_tb * 64 + lane] : -1;
+  const int s1_oa = s1_has ? s1o(s1_ta, s1_nta) : -1;
+  const int s1_ob = (s1_has && s1_tb != s1_ta) ? s1o(s1_tb, s1_ntb) : -1;
   // the single stage-2 unit of this wave when its head fragments are register-resident
   const int r_tile = wave / m.KSPLIT, r_part = wave - r_tile * m.KSPLIT;
   const int r_mt = r_tile / m.N2T, r_nt = r_tile - r_mt * m.N2T;
@@ -434,24 +442,38 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
     auto pair = [&](auto frag, int fa, int fb, const _Float16* bpa, const _Float16* bpb, int offa, int offb) {
       f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;   // two tiles: independent MFMA / split chains
-      if (m.pack8) {                                          // J_t <= 8: x0w0 + x0w1 + x1w0 + x1w1 in one MFMA per tile
+      if constexpr (P8) {                                     // J_t <= 8: x0w0 + x0w1 + x1w0 + x1w1 in one MFMA per tile
         const xh8 wa = frag(fa), wb = frag(fb);
         const xh8 xa = *reinterpret_cast<const xh8*>(bpa), xb = *reinterpret_cast<const xh8*>(bpb);
         acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xa, acca, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xb, accb, 0, 0, 0);
       } else {
-        for (int kb = 0; kb < m.KB1; ++kb) {                  // J_t <= 64 in practice: one or two blocks
-          const xh8 wa0 = frag(fa + (kb * 2) * 64), wa1 = frag(fa + (kb * 2 + 1) * 64);
-          const xh8 wb0 = frag(fb + (kb * 2) * 64), wb1 = frag(fb + (kb * 2 + 1) * 64);
-          const xh8 xa0 = *reinterpret_cast<const xh8*>(bpa + 32 * kb), xa1 = *reinterpret_cast<const xh8*>(bpa + HPL + 32 * kb);
-          const xh8 xb0 = *reinterpret_cast<const xh8*>(bpb + 32 * kb), xb1 = *reinterpret_cast<const xh8*>(bpb + HPL + 32 * kb);
-          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, xa0, acca, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1, xb0, accb, 0, 0, 0);
-          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, xa1, acca, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0, xb1, accb, 0, 0, 0);
-          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, xa0, acca, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0, xb0, accb, 0, 0, 0);
-        }
+        // one tile after the other (each a dependent chain of 3 KB1 MFMAs); the fragments of the NEXT 32-k block are
+        // requested before the current block's MFMAs (they may come from L2).  (A flat walk over all of a wave's tiles that
+        // also prefetches across tile boundaries was slower wherever the fragments sit in LDS — d = 2, H = 256: 1.15 -> 1.50 ms
+        // — and did not help the one shape that streams them, cfg5's, either.)
+        auto one = [&](int f, const _Float16* bp, f32x4& acc) {
+          auto blk = [&](const xh8& w0, const xh8& w1, int kb) {
+            const xh8 x0 = *reinterpret_cast<const xh8*>(bp + 32 * kb), x1 = *reinterpret_cast<const xh8*>(bp + HPL + 32 * kb);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x0, acc, 0, 0, 0);
+          };
+          xh8 a0 = frag(f), a1 = frag(f + 64);               // two named register sets (a runtime-indexed array would
+          for (int kb = 0; kb < m.KB1; kb += 2) {               // live in scratch)
+            const int k1 = kb + 1 < m.KB1 ? kb + 1 : kb;
+            const xh8 b0 = frag(f + (k1 * 2) * 64), b1 = frag(f + (k1 * 2 + 1) * 64);
+            blk(a0, a1, kb);
+            if (kb + 1 < m.KB1) {
+              const int k2 = kb + 2 < m.KB1 ? kb + 2 : kb + 1;
+              a0 = frag(f + (k2 * 2) * 64); a1 = frag(f + (k2 * 2 + 1) * 64);
+              blk(b0, b1, kb + 1);
+            }
+          }
+        };
+        one(fa, bpa, acca);
+        if (fb != fa) one(fb, bpb, accb);        // wave-uniform (the second tile repeats the first when there is none): an
+                                                 // MFMA under a lane-divergent branch would read masked-off operand loads
       }
       if (offa >= 0) store_split4_h(img, plane, offa, acca * gsc.r1);     // 2^r: below 2^15 (g2_scales)
       if (offb >= 0) store_split4_h(img, plane, offb, accb * gsc.r1);
@@ -463,7 +485,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int mta = t1 / m.N1T, nta = t1 - mta * m.N1T;
         const int mtb = t1b / m.N1T, ntb = t1b - mtb * m.N1T;
         pair(frag, mta * s1_fmul + lane, mtb * s1_fmul + lane, hb + (16 * nta + c) * m.JS + s1_boff,
-             hb + (16 * ntb + c) * m.JS + s1_boff, s1off[t1 * 64 + lane], t1b != t1 ? s1off[t1b * 64 + lane] : -1);
+             hb + (16 * ntb + c) * m.JS + s1_boff, s1o(t1, nta), t1b != t1 ? s1o(t1b, ntb) : -1);
       }
     };
     if (t1_lds) stage1([&](int i) { return lt1[i]; });
@@ -923,15 +945,17 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
 // GEMM's epilogue.
 static int in_pad(int in) { return (in + 7) & ~7; }
 
-bool g2_rnn_available(const RnnShape& rs, int dtype) {
+static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
   G2Plan p;
   g2_plan(&p, rs, rs.B <= device_cu_count());
-  if (!p.ok) return false;
+  if (!(backward ? p.okb : p.okf)) return false;
   if (rs.in == 1) return true;
   return gemm_split_ok(in_pad(rs.in), 4 * rs.H);
 }
+bool g2_rnn_available(const RnnShape& rs, int dtype) { return g2_available(rs, dtype, false); }
+bool g2_rnn_bwd_available(const RnnShape& rs, int dtype) { return g2_available(rs, dtype, true); }
 
 struct G2FwdWs {
   size_t gin, bilv, rec, ident, wdense, planes, xpad, lin, total;
@@ -1028,9 +1052,12 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
 #define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
-    auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? k_g2_fwd<CELLV, TS, UPTV, true, true>                   \
-                                                               : k_g2_fwd<CELLV, TS, UPTV, true, false>)                 \
-                    : k_g2_fwd<CELLV, TS, UPTV, false, false>;                                                            \
+    const bool p8 = P.hid.pack8 != 0;                                                                                   \
+    auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, true, true>       \
+                                                                     : k_g2_fwd<CELLV, TS, UPTV, true, true, false>)     \
+                                                               : (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true>      \
+                                                                     : k_g2_fwd<CELLV, TS, UPTV, true, false, false>))   \
+                    : (p8 ? k_g2_fwd<CELLV, TS, UPTV, false, false, true> : k_g2_fwd<CELLV, TS, UPTV, false, false, false>); \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,       \
                        reinterpret_cast<const xh8*>(fs2), ft1, hdr, (int)g2_merge_blocks(P.hid), (TS*)out, (TS*)hT,       \
@@ -1054,7 +1081,7 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
                       float* reserve, void* workspace, hipStream_t stream) {
   G2Plan P;
   g2_plan(&P, rs, rs.B <= device_cu_count());
-  if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
+  if (!P.okf) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
              ? fwd_t<float>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream)
              : fwd_t<bf16_t>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream);
@@ -1095,7 +1122,7 @@ int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void
                       float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate) {
   G2Plan P;
   g2_plan(&P, rs, rs.B <= device_cu_count());
-  if (!P.ok) return TTRNN_ERR_UNSUPPORTED;
+  if (!P.okb) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
              ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate)
              : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate);

@@ -183,7 +183,8 @@ int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const f
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
 
 // runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): any TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores
-bool g2_rnn_available(const RnnShape& rs, int dtype);
+bool g2_rnn_available(const RnnShape& rs, int dtype);         // forward kernel
+bool g2_rnn_bwd_available(const RnnShape& rs, int dtype);     // reverse-time kernel (larger LDS footprint for wide shapes)
 size_t g2_rnn_fwd_workspace(const RnnShape& rs);
 size_t g2_rnn_bwd_workspace(const RnnShape& rs);
 int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* h0, const void* c0, const float* packed_in,
