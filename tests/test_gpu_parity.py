@@ -599,6 +599,10 @@ G2_GRID = [
     ("ttlstm", 40, 256, 2, 3, 16, 6, 9, None),
     ("ttlstm", 1, 128, 1, 2, 4, 7, 30, None),
     ("ttlstm", 40, 256, 3, 3, 16, 300, 8, None),        # B > #CUs: four waves per workgroup, several samples per CU
+    # ... shapes whose forward fits the tier's LDS budget and whose reverse-time kernel does not: forward here, BPTT on the
+    # any-shape kernels, both reading / writing the same reserve
+    ("ttlstm", 12, 768, 1, 2, 16, 3, 5, None),
+    ("ttgru", 12, 1024, 1, 2, 16, 2, 4, None),
 ]
 
 
