@@ -401,10 +401,19 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   return f;
 }
 
+// Forward route preference: fp32 GRUs have no fused-core kernel (k_gru_fwd_f10 is the bf16-storage one); since its stages
+// moved to fp16 pieces the runtime-shape tier beats the stage-wise fp32-MFMA kernels on their shapes (H = 256, r = 8, B = 256,
+// T = 784: 0.99 vs 1.58 ms).  The reverse-time route is chosen on its own (same reserve format).
+static bool fwd_prefers_g2(const RnnShape& rs, int dtype) {
+  if (force_generic()) return false;
+  if (opt(OPT_FORCE_G2)) return g2_rnn_available(rs, dtype);
+  return rs.cell == TTRNN_GRU && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && g2_rnn_available(rs, dtype);
+}
+
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
-  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
+  if (fwd_prefers_g2(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes;
   if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
@@ -451,7 +460,7 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
   if (rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
-  const bool g2_first = opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_available(rs, desc->dtype);
+  const bool g2_first = fwd_prefers_g2(rs, desc->dtype);
   const FastFwdPlan f = g2_first ? FastFwdPlan{} : plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
     if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes)
@@ -538,7 +547,7 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
   if (force_generic()) return TTRNN_ROUTE_VALU;
-  if (opt(OPT_FORCE_G2) && g2_rnn_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  if (fwd_prefers_g2(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
