@@ -24,7 +24,8 @@ struct OptTable {
         "TTRNN_FP32_MATH", "TTRNN_FORCE_GENERIC", "TTRNN_NO_GEMM", "TTRNN_NO_IN1", "TTRNN_NO_F10", "TTRNN_NO_G2",
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
-        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES"};
+        "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES",
+        "TTRNN_BIG_FP32_MFMA"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
@@ -42,7 +43,7 @@ OptTable& table() {
 }
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
-    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces"};
+    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces", "big_fp32_mfma"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }

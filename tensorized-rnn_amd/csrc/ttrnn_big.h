@@ -94,6 +94,10 @@ constexpr int merged_elems() {
          S3::J[2] * S3::R[3] * S3::I[2] * S3::R[2];
 }
 
+// what the next step sees of a stored h: rounded once to the storage type
+__device__ __forceinline__ float round_like(const float*, float v) { return v; }
+__device__ __forceinline__ float round_like(const bf16_t*, float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 __device__ __forceinline__ float bsigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

@@ -354,8 +354,6 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
   }
 }
 
-__device__ __forceinline__ float round_like(const float*, float v) { return v; }
-__device__ __forceinline__ float round_like(const bf16_t*, float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // ---- two workgroups per sample (two-core matrices, LSTM) ------------------------------------------------------------
 // With B = 128 samples the one-workgroup-per-sample kernel leaves half of the 256 CUs idle.  Both stages of the
@@ -553,7 +551,7 @@ size_t big_rnn_fwd_workspace(const RnnShape& rs) {
   const size_t m2 = ((size_t)merged2_elems<ShpH1024R32L_M2>() * sizeof(float) + 255) & ~(size_t)255;
   const size_t pair = (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);      // tagged h exchange words of the pair kernel
   // + h exchange rows and counters of the pair kernel + identity rows, dense W_in and its bf16 planes of the GEMM K-in
-  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair + big_gemm_bytes(rs);
+  return gin + (lin > rec ? lin : rec) + 2 * (m3 + m2) + pair + big_gemm_bytes(rs) + bigh_workspace_bytes();
 }
 
 template <typename TS>
@@ -577,7 +575,8 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
     const size_t b3 = ((size_t)merged_elems<S3>() * sizeof(float) + 255) & ~(size_t)255;
     const size_t b2 = ((size_t)merged2_elems<S2>() * sizeof(float) + 255) & ~(size_t)255;
     const size_t pair_bytes = (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);
-    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes - big_gemm_bytes(rs);
+    char* tail = (char*)workspace + big_rnn_fwd_workspace(rs) - 2 * (b3 + b2) - pair_bytes - big_gemm_bytes(rs) -
+                 bigh_workspace_bytes();
     float* m3_in = (float*)tail;
     float* m3_hid = (float*)(tail + b3);
     float* m2_in = (float*)(tail + 2 * b3);
@@ -641,6 +640,10 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
       // two workgroups per sample: tagged h exchange words [B][2][H] behind the merged cores (tag 0 = never written)
       unsigned long long* hxb = (unsigned long long*)(tail + 2 * (b3 + b2));
       if (hipMemsetAsync(hxb, 0, pair_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+      // split mode: both stages on two-piece fp16 operands (ttrnn_fast_bigh.hip); OPT_BIG_FP32_MFMA: A/B switch
+      if (opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA))
+        return launch_lstm_fwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, gin, h0, c0, m2_hid, bin, bhid, out, hT,
+                                     cT, reserve, hxb, tail + 2 * (b3 + b2) + pair_bytes + big_gemm_bytes(rs), stream);
       // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (76 KB each would fit twice, and
       // the dispatcher then packs the pairs onto half of the CUs: measured no faster than one workgroup per sample)
       constexpr size_t lds_img = (size_t)(St<S2, 0>::ROWS / 2) * St<S2, 0>::KP * sizeof(float);

@@ -1,0 +1,370 @@
+// ttrnn_fast_bigh.hip — cfg5-class K-rec (H = 1024, d = 4, r = 32; merged two-core matrix, two workgroups per sample)
+// on two-piece fp16 operands (ttrnn_split.h, flavour (b)): both stages of the chain on v_mfma_f32_16x16x32_f16, three
+// terms per product, instead of the fp32 MFMA of ttrnn_fast_big.hip:k_lstm_fwd_big2 (16.4 k of its 26 k cycles per step
+// were matrix pipe).  Same pair structure and the same tagged-word exchange of h; what changes:
+//   * stage 1 (16 rows x K = 64 x 1024 features per workgroup): the h image is two fp16 planes of 2^9 h; the core
+//     fragments (two pieces of 2^a W_1) are STREAMED from L2, 256 KB per step and workgroup, through two register slots of
+//     two m-tiles, requested one slot-round ahead of their use (the first two chunks of step t+1 travel during stage 0,
+//     the gates and the exchange of step t);
+//   * its sums are rescaled by a fixed power of two (< 2^15) and split into the two fp16 planes of the stage-0 image;
+//   * stage 0 (32 local rows x K = 512 x 64 features): the fragments of 2^b W_0 are RESIDENT in registers (64 VGPRs:
+//     wave = (feature tile p, k half), both row tiles), feature rows permuted so that a lane's four accumulator
+//     registers are the four gates of ONE hidden unit: the gates run in the lanes that hold the sums, after the two k
+//     halves have been exchanged through LDS (wave kh keeps row tile kh, hands over row tile 1 - kh);
+//   * the k order of the stage-0 operand is permuted ((a / 4, j0, a % 4) instead of (j0, a)) so that a wave's stage-1
+//     store is one contiguous 512-byte run per plane.
+// Scales as in the runtime-shape tier (ttrnn_g2.hip:g2_scales), all powers of two from the maxima of the merged cores;
+// a caller's h_0 outside (-1, 1) is scaled per sample (ttrnn_f10_dev.h:f10h_h0_expo).
+// Replaces (together with the batched input projection) the reference's per-step chain + gates for this shape:
+// tensorized_rnn/lstm.py:26-32 and 77-92 (cell and sequence loop), t3nsor/ops.py:80-92 via tt_linear.py:159-160.
+#include <hip/hip_runtime.h>
+#include "ttrnn.h"
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10_dev.h"
+#include "ttrnn_big.h"
+
+namespace ttrnn {
+
+namespace {
+
+using S2 = ShpH1024R32L_M2;
+using T1 = St<S2, 1>;
+using T0 = St<S2, 0>;
+constexpr int BH_H = 1024, BH_I1 = 64, BH_HR = 32, BH_K1 = 64, BH_K0 = 512, BH_R1 = 32;
+constexpr int BH_PL_H = 16 * BH_K1;            // halfs per plane of the h image  [16 rows j0][64 j1]
+constexpr int BH_PL_I = BH_HR * BH_K0;         // halfs per plane of the stage-0 image [32 local rows i1][512 k']
+constexpr int BH_PARTS = 32;                   // partial maxima per core
+static_assert(T1::K == BH_K1 && T1::M == BH_I1 * BH_R1 && T1::ROWS == 16 && T0::K == BH_K0 && T0::M == 64 &&
+                  T0::ROWS == BH_I1 && in_size_of<S2>() == BH_H && out_size_of<S2>() == 4 * BH_H && FAST_NT == 512,
+              "merged two-core shape of cfg5");
+
+// element (kk, m) of stage k inside the fragment-ordered fp32 buffer k_merge_cores_last writes (ttrnn_big.h:frag_decode)
+template <int k>
+__device__ __forceinline__ int frag_index(int kk, int m) {
+  using T = St<S2, k>;
+  return (((m >> 4) * T::NU + (kk >> 4)) * 64 + ((kk >> 2) & 3) * 16 + (m & 15)) * 4 + (kk & 3);
+}
+
+// k order of the stage-0 operand: (j0, a) -> (a / 4) * 64 + j0 * 4 + a % 4
+__device__ __forceinline__ int bh_kperm(int j0, int a) { return (a >> 2) * 64 + j0 * 4 + (a & 3); }
+
+struct BhScales { float tail, head, r1, un; };
+// parts: [2][BH_PARTS] partial maxima (|W_0| then |W_1|); every lane of a wave calls this
+//   tail: max|W_1| 2^a < 2^13     h: 2^9     stage-1 sums < 64 * 2^22 = 2^28, times r1 = 2^-13 -> < 2^15 before the split
+//   head: max|W_0| 2^b < 2^14     un = 2^-(a + 9 - 13 + b)
+__device__ __forceinline__ BhScales bh_scales(const float* __restrict__ parts, int lane) {
+  float mh = parts[lane & (BH_PARTS - 1)], mt = parts[BH_PARTS + (lane & (BH_PARTS - 1))];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mt = fmaxf(mt, __shfl_xor(mt, o)); }
+  const int a = 13 - f10h_expo(mt), b = 14 - f10h_expo(mh);
+  BhScales s;
+  s.tail = ldexpf(1.f, a);
+  s.head = ldexpf(1.f, b);
+  s.r1 = ldexpf(1.f, -13);
+  s.un = ldexpf(1.f, -(a + 9 - 13 + b));
+  return s;
+}
+constexpr float BH_HSC = 512.0f;
+
+__global__ void __launch_bounds__(256) k_bigh_absmax(const float* __restrict__ packed2, float* __restrict__ parts) {
+  __shared__ float red[4];
+  constexpr int N0 = T0::K * T0::M, N1 = T1::K * T1::M;
+  const int which = blockIdx.x / BH_PARTS, part = blockIdx.x % BH_PARTS;
+  const float* a = packed2 + woff_of<S2>(which);
+  const int n = which == 0 ? N0 : N1;
+  float m = 0.f;
+  for (int i = part * 256 + threadIdx.x; i < n; i += BH_PARTS * 256) m = fmaxf(m, fabsf(a[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// fragment streams (16-byte entries, one per lane):
+//   f1[half][wave][x][kb][piece][lane]   stage 1: m-tile mtl = 8 wave + x of the half, k-block kb (32 values of j1)
+//   f0[wave][kbl][piece][lane]           stage 0: wave = (p, kh): feature tile p, k-block 8 kh + kbl (32 values of k')
+// stage-0 rows: row 4 q' + j of tile p <-> feature m0 = 16 j + 4 p + q' (gate j of unit-column mq = 4 p + q')
+constexpr int BH_F1 = 2 * 8 * 8 * 2 * 2 * 64, BH_F0 = 8 * 8 * 2 * 64;
+__global__ void __launch_bounds__(256) k_bigh_prep(const float* __restrict__ packed2, const float* __restrict__ parts,
+                                                   xh8* __restrict__ f1, xh8* __restrict__ f0) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = e & 63, r = lane & 15, q = lane >> 4;
+  const BhScales sc = bh_scales(parts, threadIdx.x & 63);
+  xh8 p0, p1;
+  if (e < BH_F1 / 2) {
+    const int kb = (e >> 6) & 1, x = (e >> 7) & 7, wave = (e >> 10) & 7, half = e >> 13;
+    const int m = (half * 64 + 8 * wave + x) * 16 + r;
+    const float* W = packed2 + woff_of<S2>(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      _Float16 a, b;
+      split2h(W[frag_index<1>(32 * kb + 8 * q + i, m)] * sc.tail, a, b);
+      p0[i] = a; p1[i] = b;
+    }
+    const size_t o = ((size_t)(e >> 6) * 2) * 64 + lane;
+    f1[o] = p0;
+    f1[o + 64] = p1;
+  } else if (e < BH_F1 / 2 + BH_F0 / 2) {
+    const int g = e - BH_F1 / 2;
+    const int kbl = (g >> 6) & 7, wave = g >> 9;
+    const int p = wave & 3, kh = wave >> 2;
+    const int m0 = 16 * (r & 3) + 4 * p + (r >> 2);
+    const float* W = packed2 + woff_of<S2>(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kp = 32 * (8 * kh + kbl) + 8 * q + i;                 // permuted k' -> (j0, a)
+      const int j0 = (kp & 63) >> 2, a = (kp >> 6) * 4 + (kp & 3);
+      _Float16 u, v;
+      split2h(W[frag_index<0>(j0 * BH_R1 + a, m0)] * sc.head, u, v);
+      p0[i] = u; p1[i] = v;
+    }
+    const size_t o = ((size_t)(g >> 6) * 2) * 64 + lane;
+    f0[o] = p0;
+    f0[o + 64] = p1;
+  }
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const float* __restrict__ gin,
+                                                            const TS* __restrict__ h0, const TS* __restrict__ c0,
+                                                            const xh8* __restrict__ f1, const xh8* __restrict__ f0,
+                                                            const float* __restrict__ parts,
+                                                            const TS* __restrict__ bias_in,
+                                                            const TS* __restrict__ bias_hid, TS* __restrict__ out,
+                                                            TS* __restrict__ hT, TS* __restrict__ cT,
+                                                            float* __restrict__ reserve,
+                                                            unsigned long long* __restrict__ hx) {
+  constexpr int H = BH_H;
+  __shared__ __attribute__((aligned(16))) _Float16 hpl[2 * BH_PL_H];      // h_{t-1}: two planes of 2^9 h
+  __shared__ __attribute__((aligned(16))) f32x4 xp[4][2][64];             // stage-0 sums of the OTHER k half's row tile
+  __shared__ float scr[8];
+  extern __shared__ __attribute__((aligned(16))) float big_lds[];         // stage-0 image: two planes [32][512]
+  _Float16* img = reinterpret_cast<_Float16*>(big_lds);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int p = wave & 3, kh = wave >> 2;
+  const size_t b = blockIdx.x >> 1;
+  const int half = blockIdx.x & 1;
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+  const BhScales sc = bh_scales(parts, lane);
+
+  // gate phase: lane (c, q) of wave (p, kh) owns unit-column mq = 4 p + q, local row 16 kh + c
+  const int mq = 4 * p + q, rl = 16 * kh + c;
+  const int hid = mq * BH_I1 + half * BH_HR + rl;
+  const int hidp = mq * BH_I1 + (1 - half) * BH_HR + rl;                  // the partner's unit at the same position
+  const int ho = x_off<BH_K1>(mq, half * BH_HR + rl), hop = x_off<BH_K1>(mq, (1 - half) * BH_HR + rl);
+  float hst = h0 ? ld(h0, b * H + hid) : 0.f;
+  float cst = c0 ? ld(c0, b * H + hid) : 0.f;
+  const float hpv = h0 ? ld(h0, b * H + hidp) : 0.f;
+  float bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    bh[g] = (bias_hid ? ld(bias_hid, g * H + hid) : 0.f) + (bias_in ? ld(bias_in, g * H + hid) : 0.f);
+  // h_0 outside (-1, 1): per sample, the image holds 2^-e0 h_0 and the first step's sums are multiplied back
+  const int e0 = h0 ? f10h_h0_expo<FAST_NW>(fmaxf(fabsf(hst), fabsf(hpv)), scr, wave, lane) : 0;
+  {
+    const float s0 = ldexpf(BH_HSC, -e0);
+    _Float16 u, v;
+    split2h(hst * s0, u, v);
+    hpl[ho] = u; hpl[BH_PL_H + ho] = v;
+    split2h(hpv * s0, u, v);
+    hpl[hop] = u; hpl[BH_PL_H + hop] = v;
+  }
+  float usc = ldexpf(sc.un, e0);
+  f32x4 gi = T > 0 ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};     // slots i,g,f,o; prefetched a step ahead
+  bool dead = false;
+
+  // resident stage-0 fragments
+  xh8 w0f[8][2];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) w0f[u][pc] = f0[((size_t)(wave * 8 + u) * 2 + pc) * 64 + lane];
+
+  // stage-1 stream: chunk j = m-tiles x = 2 j, 2 j + 1 of this wave; entry ((x * 2 + kb) * 2 + piece) * 64 + lane
+  const xh8* f1w = f1 + (size_t)(half * 8 + wave) * (8 * 2 * 2 * 64);
+  xh8 sa[2][4], sb[2][4];
+  auto loadc = [&](xh8 (&s)[2][4], int j, int zz) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[y][i] = f1w[(size_t)((2 * j + y) * 4 + i) * 64 + lane + zz];
+  };
+  xh8 hb[2][2];
+  // two m-tiles (one local row of the stage-0 image: a = 0..15 and 16..31), their sums split into the image
+  int cz = c, qz = q;                      // the lane's (c, q) behind the per-step opaque id: addresses are recomputed, not hoisted
+  auto s1 = [&](const xh8 (&s)[2][4], int j) {
+    f32x4 lo[2], hi[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) { lo[y] = f32x4{0.f, 0.f, 0.f, 0.f}; hi[y] = lo[y]; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        lo[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s[y][2 * kb + 1], hb[kb][0], lo[y], 0, 0, 0);
+        lo[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s[y][2 * kb], hb[kb][1], lo[y], 0, 0, 0);
+        hi[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s[y][2 * kb], hb[kb][0], hi[y], 0, 0, 0);
+      }
+    // x_off<512>(row = 4 wave + j, k' = (4 y + q) * 64 + 4 c): the XOR touches the low four slot bits only
+    const int row = 4 * wave + j;
+    const int o0 = ((row * 64 + (q >> 1) * 16 + ((((qz & 1) << 3) + (cz >> 1)) ^ (row & 15))) << 3) + ((cz & 1) << 2);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const f32x4 v = (hi[y] + lo[y]) * sc.r1;
+      store_split4_h(img, BH_PL_I, o0 + y * 256, v);
+    }
+  };
+  loadc(sa, 0, 0);
+  loadc(sb, 1, 0);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    int z = 0;
+    asm volatile("" : "+v"(z));            // per-step opaque lane id: the fragment loads stay where they are written
+    cz = (lane + z) & 15;
+    qz = (lane + z) >> 4;
+    // ---- stage 1 ----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc)
+        hb[kb][pc] = *reinterpret_cast<const xh8*>(hpl + pc * BH_PL_H + x_off<BH_K1>(cz, 32 * kb + 8 * qz));
+    s1(sa, 0);
+    loadc(sa, 2, z);
+    s1(sb, 1);
+    loadc(sb, 3, z);
+    s1(sa, 2);
+    loadc(sa, 0, z);                       // chunks 0 and 1 of step t+1 travel during stage 0, the gates and the exchange
+    s1(sb, 3);
+    loadc(sb, 1, z);
+    __syncthreads();
+    // ---- stage 0: both row tiles against this wave's k half; reads run PD operands ahead of the MFMAs ----------------
+    f32x4 acc[2];
+    {
+      constexpr int PD = 4, NI = 16;       // iteration i: row tile i / 8, k-block 8 kh + i % 8
+      xh8 af[NI][2];
+      // x_off<512>(16 rt + c, 32 (8 kh + u) + 8 q) = c * 512 + kh * 256 + bx[u & 3] + rt * 8192 + (u >> 2) * 128 halfs with
+      // bx[v] = ((4 v + q) ^ c) * 8: four addresses, the rest are immediates
+      int bx[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bx[v] = cz * 512 + kh * 256 + (((4 * v + qz) ^ cz) << 3);
+      auto rd = [&](int i) {
+        const int off = bx[i & 3] + (i >> 3) * 8192 + ((i & 7) >> 2) * 128;
+        af[i][0] = *reinterpret_cast<const xh8*>(img + off);
+        af[i][1] = *reinterpret_cast<const xh8*>(img + BH_PL_I + off);
+      };
+      f32x4 lo[2], hi[2];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) { lo[y] = f32x4{0.f, 0.f, 0.f, 0.f}; hi[y] = lo[y]; }
+#pragma unroll
+      for (int i = 0; i < PD; ++i) rd(i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i + PD < NI) rd(i + PD);
+        __builtin_amdgcn_sched_barrier(0);
+        const int y = i >> 3, u = i & 7;
+        lo[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][1], af[i][0], lo[y], 0, 0, 0);
+        lo[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], af[i][1], lo[y], 0, 0, 0);
+        hi[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], af[i][0], hi[y], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[0] = hi[0] + lo[0];
+      acc[1] = hi[1] + lo[1];
+    }
+    xp[p][kh][lane] = kh == 0 ? acc[1] : acc[0];
+    __syncthreads();
+    // ---- gates (lstm.py:26-32): register j = gate j (i, f, g, o) of unit hid ---------------------------------------------
+    const size_t bt = b * T + t;
+    {
+      const f32x4 tot = (kh == 0 ? acc[0] : acc[1]) + xp[p][1 - kh][lane];
+      const float ig = bsigmoid(fmaf(tot[0], usc, gi[0] + bh[0]));
+      const float fg = bsigmoid(fmaf(tot[1], usc, gi[2] + bh[1]));
+      const float gg = btanh(fmaf(tot[2], usc, gi[1] + bh[2]));
+      const float og = bsigmoid(fmaf(tot[3], usc, gi[3] + bh[3]));
+      usc = sc.un;
+      const float cy = fg * cst + ig * gg;
+      float hy = og * btanh(cy);
+      cst = cy;
+      if (reserve) {
+        float* rv = reserve + res_gate(bt, H, hid);
+        rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
+        reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
+      }
+      st(out, bt * H + hid, hy);
+      hy = round_like(out, hy);                    // what the next step sees: rounded once to the storage type
+      hst = hy;
+      // swap halves of h_t with the partner workgroup (ttrnn_fast_big.hip:k_lstm_fwd_big2: self-validating 64-bit words
+      // (value, step tag), relaxed agent-scope atomics, double-buffered by step parity)
+      __hip_atomic_store(hx + (b * 2 + (t & 1)) * H + hid,
+                         ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(hy),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      _Float16 u, v;
+      split2h(hy * BH_HSC, u, v);
+      hpl[ho] = u; hpl[BH_PL_H + ho] = v;
+      if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
+    }
+    {
+      const unsigned long long* src = hx + (b * 2 + (t & 1)) * H + hidp;
+      unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // bounded wait; a time-out poisons the state with NaN (see k_lstm_fwd_big2)
+      long spin = 0;
+      while (!dead && (unsigned)(w >> 32) != (unsigned)(t + 1)) {
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spin > (1L << 21)) dead = true;
+      }
+      const float hp = dead ? __uint_as_float(0x7FC00000u) : __uint_as_float((unsigned)w);
+      _Float16 u, v;
+      split2h(hp * BH_HSC, u, v);
+      hpl[hop] = u; hpl[BH_PL_H + hop] = v;
+    }
+    __syncthreads();
+  }
+  if (dead) hst = cst = __uint_as_float(0x7FC00000u);       // T == time-out step: nothing downstream has seen the NaN yet
+  if (hT) st(hT, b * H + hid, hst);
+  if (cT) st(cT, b * H + hid, cst);
+}
+
+}  // namespace
+
+size_t bigh_workspace_bytes() { return (size_t)(BH_F1 + BH_F0) * sizeof(xh8) + 256; }
+
+template <typename TS>
+static int launch_bigh_t(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* m2_hid,
+                         const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
+                         unsigned long long* hxb, void* scratch, hipStream_t stream) {
+  float* parts = (float*)scratch;
+  xh8* f1 = (xh8*)((char*)scratch + 256);
+  xh8* f0 = f1 + BH_F1;
+  hipLaunchKernelGGL(k_bigh_absmax, dim3(2 * BH_PARTS), dim3(256), 0, stream, m2_hid, parts);
+  hipLaunchKernelGGL(k_bigh_prep, dim3((BH_F1 / 2 + BH_F0 / 2 + 255) / 256), dim3(256), 0, stream, m2_hid, parts, f1, f0);
+  if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (see launch_big_t)
+  constexpr size_t lds_pair = 100 * 1024;
+  static_assert(2 * BH_PL_I * sizeof(_Float16) <= lds_pair, "stage-0 image");
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2h<TS>), lds_pair) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
+  const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
+  hipLaunchKernelGGL((k_lstm_fwd_big2h<TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
+                     (const TS*)h0, (const TS*)c0, f1, f0, parts, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_lstm_fwd_big2h(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+                          const float* m2_hid, const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT,
+                          float* reserve, unsigned long long* hxb, void* scratch, hipStream_t stream) {
+  return dtype == TTRNN_F32
+             ? launch_bigh_t<float>(rs, gin, h0, c0, m2_hid, bias_in, bias_hid, out, hT, cT, reserve, hxb, scratch, stream)
+             : launch_bigh_t<bf16_t>(rs, gin, h0, c0, m2_hid, bias_in, bias_hid, out, hT, cT, reserve, hxb, scratch,
+                                     stream);
+}
+
+}  // namespace ttrnn

@@ -169,6 +169,12 @@ int launch_rnn_fwd_big(const RnnShape& rs, int dtype, const void* x, const void*
                        const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
                        void* out, void* hT, void* cT, float* reserve, void* workspace, hipStream_t stream);
 
+// the pair kernel of the merged two-core matrix on two-piece fp16 operands (ttrnn_fast_bigh.hip); scratch: bigh_workspace_bytes()
+size_t bigh_workspace_bytes();
+int launch_lstm_fwd_big2h(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
+                          const float* m2_hid, const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT,
+                          float* reserve, unsigned long long* hxb, void* scratch, hipStream_t stream);
+
 // BPTT of the big shape through the merged two-core matrix (ttrnn_fast_bigb.hip): reverse-time kernel (one or two
 // workgroups per sample) and the batched TTLinear backward (dx through the transposed merged chain; weight + bias
 // gradients accumulated in MFMA registers)

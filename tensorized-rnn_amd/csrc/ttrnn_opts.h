@@ -26,6 +26,7 @@ enum OptId {
   OPT_DENSE_FP32,        // TTRNN_DENSE_FP32=1      dense weight gradient on the fp32 MFMA
   OPT_F10_NB2,           // TTRNN_F10_NB2=1         B > #CUs: two samples per eight-wave workgroup instead of four-wave workgroups (A/B)
   OPT_GEMM_PIECES,       // TTRNN_GEMM_PIECES=0|2|3 forward input-projection GEMMs: 0 by size, 2 two fp16 pieces, 3 three bf16 pieces (A/B)
+  OPT_BIG_FP32_MFMA,     // TTRNN_BIG_FP32_MFMA=1   big-shape pair kernel on the fp32 MFMA even in split mode (A/B)
   OPT_COUNT
 };
 
