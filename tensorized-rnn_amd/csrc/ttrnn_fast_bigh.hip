@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
   __shared__ float scr[8];
   extern __shared__ __attribute__((aligned(16))) float big_lds[];         // stage-0 image: two planes [32][512]
   _Float16* img = reinterpret_cast<_Float16*>(big_lds);
+  xh8* w1l = reinterpret_cast<xh8*>(big_lds) + 2 * BH_PL_I / 8;           // chunk 3 of every wave's stage-1 fragments (64 KB)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,6 +224,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
   };
   loadc(sa, 0, 0);
   loadc(sb, 1, 0);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w1l[(wave * 8 + e) * 64 + lane] = f1w[(size_t)(3 * 8 + e) * 64 + lane];
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
@@ -236,14 +239,24 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc)
         hb[kb][pc] = *reinterpret_cast<const xh8*>(hpl + pc * BH_PL_H + x_off<BH_K1>(cz, 32 * kb + 8 * qz));
-    s1(sa, 0);
+    // sa holds chunk u = t & 1, sb chunk v = 1 - u (requested during the previous step); chunk 2 is requested as soon as a
+    // slot is free, chunk 3 is resident in LDS and gives chunk 2 the time to arrive; the next step's chunks 0 / 1 travel
+    // during stage 0, the gates and the exchange and land in the OTHER slot each: u and v swap every step
+    const int u = t & 1, v = u ^ 1;
+    s1(sa, u);
     loadc(sa, 2, z);
-    s1(sb, 1);
-    loadc(sb, 3, z);
+    s1(sb, v);
+    loadc(sb, u, z);
+    {
+      xh8 tl[2][4];
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tl[y][i] = w1l[(wave * 8 + y * 4 + i) * 64 + lane];
+      s1(tl, 3);
+    }
     s1(sa, 2);
-    loadc(sa, 0, z);                       // chunks 0 and 1 of step t+1 travel during stage 0, the gates and the exchange
-    s1(sb, 3);
-    loadc(sb, 1, z);
+    loadc(sa, v, z);
     __syncthreads();
     // ---- stage 0: both row tiles against this wave's k half; reads run PD operands ahead of the MFMAs ----------------
     f32x4 acc[2];
@@ -347,9 +360,8 @@ static int launch_bigh_t(const RnnShape& rs, const float* gin, const void* h0, c
   hipLaunchKernelGGL(k_bigh_absmax, dim3(2 * BH_PARTS), dim3(256), 0, stream, m2_hid, parts);
   hipLaunchKernelGGL(k_bigh_prep, dim3((BH_F1 / 2 + BH_F0 / 2 + 255) / 256), dim3(256), 0, stream, m2_hid, parts, f1, f0);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-  // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (see launch_big_t)
-  constexpr size_t lds_pair = 100 * 1024;
-  static_assert(2 * BH_PL_I * sizeof(_Float16) <= lds_pair, "stage-0 image");
+  // stage-0 image (64 KB) + the LDS-resident quarter of the stage-1 fragments (64 KB): one workgroup per CU
+  constexpr size_t lds_pair = 2 * BH_PL_I * sizeof(_Float16) + 8 * 8 * 64 * sizeof(xh8);
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2h<TS>), lds_pair) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
   const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;

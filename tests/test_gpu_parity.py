@@ -1146,6 +1146,81 @@ def test_big_shape_two_workgroups_per_sample_matches_one():
     assert _maxabs(res[0][0], res[1][0]) <= 2e-6 and _maxabs(res[0][1], res[1][1]) <= 2e-6
 
 
+@pytest.mark.parametrize("case", ["fresh_init", "tiny_weights", "large_weights", "huge_weights_one_step", "huge_h0",
+                                  "mixed_magnitudes"])
+def test_big_shape_half_piece_operand_ranges(case):
+    """cfg5-class K-rec in split mode (ttrnn_fast_bigh.hip): both chain stages on two-piece fp16 operands under
+    power-of-two scales taken from the merged cores' maxima, the stage-1 sums rescaled before they are split, a caller's
+    h_0 scaled per sample.  Against the float64 oracle, next to the fp32-MFMA pair kernel (TTRNN_FP32_MATH=exact) on the
+    same inputs: finite whatever the magnitudes, and the same error class.  (With every hidden core x 3 and beyond — the
+    TT-matrix x 81 — this recurrence is chaotic: the fp32-MFMA kernel is 1.5e-2 off float64 after six steps at x 3 and 2
+    at x 5, the split kernel alike; so the long case stays at x 2 and the x 8 case — TT-matrix x 4096, pre-activations in
+    the hundreds, there for the range of the scales — runs one step.)"""
+    import ttrnn_hip
+    torch.manual_seed(91)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 3, (1 if case == "huge_weights_one_step" else 6)
+    x = torch.randn(B, T, 1024)
+    h0, c0 = torch.randn(B, 1024) * 0.3, torch.randn(B, 1024) * 0.3
+    with torch.no_grad():
+        cores = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+        assert len(cores) == 4
+        if case == "tiny_weights":
+            for p in cores:
+                p.mul_(1e-3)                                  # TT-matrix entries x 1e-12
+        elif case == "large_weights":
+            for p in cores:
+                p.mul_(2.0)                                   # TT-matrix x 16
+        elif case == "huge_weights_one_step":
+            for p in cores:
+                p.mul_(8.0)                                   # TT-matrix x 4096: pre-activations in the hundreds
+        elif case == "huge_h0":
+            h0 = torch.randn(B, 1024) * torch.tensor([2.0, 300.0, 20000.0]).view(B, 1)
+        elif case == "mixed_magnitudes":
+            for k, step, f in ((3, 3, 1e-6), (0, 2, 1e-5), (1, 5, 1e-4)):
+                w = cores[k].detach().clone().reshape(-1)
+                w[::step] *= f
+                cores[k].copy_(w.reshape(cores[k].shape))
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    r64, _, c64 = _oracle_forward("ttlstm", sd, 1, x.double(), (h0.double(), c0.double()))
+    scale = max(1.0, float(c64.abs().max()), float(r64.abs().max()))
+    errs = {}
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            out, (hT, cT) = m(x.to(dev()), (h0.to(dev()), c0.to(dev())))
+        assert torch.isfinite(out).all() and torch.isfinite(cT).all(), (case, mode)
+        errs[mode] = max(_maxabs(out.double(), r64), _maxabs(cT.double(), c64))
+    print(case, "max abs error vs float64 (state scale %.3g):" % scale, errs)
+    tol = 2e-4 if case in ("large_weights", "huge_weights_one_step", "huge_h0") else 2e-6
+    assert errs["split"] <= tol * scale
+    assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * scale
+
+
+def test_big_shape_half_piece_kernel_batch_independent_and_repeatable():
+    """The same sample gives the same bits whatever else is in the batch and on every launch (the scales come from the
+    weights and from the sample's own h_0 only); the fp32-MFMA pair kernel stays selectable (big_fp32_mfma) and agrees."""
+    import ttrnn_hip
+    torch.manual_seed(92)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    x = torch.randn(7, 40, 1024, device=dev())
+    h0 = torch.randn(7, 1024, device=dev()) * torch.tensor([0.2, 0.5, 1.0, 3.0, 0.1, 50.0, 0.3], device=dev()).view(7, 1)
+    c0 = torch.randn(7, 1024, device=dev()) * 0.3
+    with torch.no_grad():
+        out, (hT, cT) = m(x, (h0, c0))
+        out2, (_, cT2) = m(x, (h0, c0))
+        sub = [5, 1, 6]
+        outs, (_, cTs) = m(x[sub].contiguous(), (h0[sub].contiguous(), c0[sub].contiguous()))
+        with ttrnn_hip.option("big_fp32_mfma", 1):
+            outf, (_, cTf) = m(x, (h0, c0))
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, out2) and torch.equal(cT, cT2)
+    assert torch.equal(out[sub], outs) and torch.equal(cT[sub], cTs)
+    assert not torch.equal(out, outf)                         # a different kernel did run
+    assert _maxabs(out, outf) <= 2e-5 and _maxabs(cT, cTf) <= 2e-4      # sample 5 starts from |h_0| ~ 150
+
+
 def test_big_shape_gradients_vs_oracle():
     """cfg5-class BPTT through the merged two-core matrix (reverse-time kernel with two workgroups per sample, weight
     gradients accumulated in MFMA registers, product rule back to the four cores) against the oracle's autograd: every
