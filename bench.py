@@ -36,9 +36,9 @@ import torch  # noqa: E402
 FP32_MATH_DESC = {
     None: None,
     "split": "split (default where a split kernel exists): fp32 operands as error-compensated 16-bit pieces with fp32 "
-             "accumulate - two fp16 pieces / 3 MFMA terms under per-launch power-of-two scales in the fused-core LSTM "
-             "forward kernels (cfg2, cfg4), three bf16 pieces / 6 terms elsewhere; error vs float64 equal to the fp32-MFMA "
-             "mode (tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges); "
+             "accumulate - two fp16 pieces / 3 MFMA terms under per-launch power-of-two scales in the LSTM forward "
+             "kernels (cfg2, cfg4, cfg5), three bf16 pieces / 6 terms elsewhere; error vs float64 equal to the fp32-MFMA "
+             "mode (tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges, ::test_big_shape_half_piece_operand_ranges); "
              "TTRNN_FP32_MATH=exact selects the fp32 MFMA",
     "exact": "exact: v_mfma_f32_16x16x4_f32 on fp32 operands",
 }
@@ -82,11 +82,14 @@ EXECUTED = {
                  pipe16="f16_mfma", terms=3,
                  note="per layer: fused core (r = 16) on two-piece fp16 operands (four-wave workgroups, two per CU) + K-in as one "
                       "dense GEMM over B*T rows on two-piece fp16 operands (three terms)"),
-    # cfg5: merged two-core matrix on the fp32 MFMA (8.4 MFLOP per sample-step) + K-in as a dense GEMM on fp16 pieces
-    "cfg5": dict(bf16_mfma=0, fp32_mfma=(2 * 16 * 64 * 2048 + 2 * 64 * 512 * 64) // 2048,
+    # cfg5: merged two-core matrix on two-piece fp16 operands (k_lstm_fwd_big2h): stage 1 128 m-tiles x 2 k-blocks x 3 terms,
+    # stage 0 4 feature tiles x 4 row tiles x 16 k-blocks x 3 terms, over the 8 SIMDs of a workgroup pair; K-in: dense GEMM on
+    # fp16 pieces
+    "cfg5": dict(bf16_mfma=128 * 2 * 3 + 4 * 4 * 16 * 3, fp32_mfma=0,
                  kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, pipe16="f16_mfma", terms=3,
-                 note="K-rec: merged 2-core chain on the fp32 MFMA, two workgroups per sample; K-in: dense GEMM on two-piece "
-                      "fp16 operands (three terms)"),
+                 note="K-rec: merged 2-core chain on two-piece fp16 operands (three terms per product), two workgroups per "
+                      "sample, stage-1 fragments streamed from L2 (a quarter resident in LDS), stage-0 fragments resident "
+                      "in registers; K-in: dense GEMM on two-piece fp16 operands (three terms)"),
 }
 
 

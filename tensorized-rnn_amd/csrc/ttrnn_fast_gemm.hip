@@ -467,8 +467,34 @@ struct DenseS {
   static constexpr int PLANE = KB * 128;                   // bf16 elements of one [32][128] plane
   static constexpr int BUF = 3 * PLANE * 3;                // x: 3 planes; dy: 3 planes x 2 column halves
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(__bf16);
+  static constexpr int BUF_H = 2 * PLANE * 3;              // two-piece fp16 operands: two planes each
+  static constexpr size_t LDS_BYTES_H = (size_t)2 * BUF_H * sizeof(_Float16);
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Two-piece fp16 variant (HALF) of the dense gradient: the contraction runs over the ROWS, so a scale may differ per
+// COLUMN of x and per column of dy (it factors out of every sum): colmax = [IN + OUT] column maxima as fp32 bit patterns
+// (non-negative floats order like unsigned integers: atomicMax), scale = 2^(14 - e) with max < 2^e, exact; the epilogue
+// multiplies dW[j][o] by the two inverse powers of two.  Entries within 2^17 of their column's maximum keep 22+ bits.
+__device__ __forceinline__ float col_scale(unsigned bits) { return ldexpf(1.f, 14 - g_expo(__uint_as_float(bits))); }
+__device__ __forceinline__ float col_unscale(unsigned bits) { return ldexpf(1.f, g_expo(__uint_as_float(bits)) - 14); }
+
+// colmax[c] = max over rows [r0, r1) of |a[n][c]| (bit pattern); one thread per four columns, 128 rows per workgroup
+template <typename TS>
+__global__ void __launch_bounds__(256) k_col_absmax(const TS* __restrict__ a, int64_t n_rows, int C,
+                                                    unsigned* __restrict__ colmax) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = r0 + 128 < n_rows ? r0 + 128 : n_rows;
+  f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t n = r0; n < r1; ++n) {
+    const f32x4 v = ld4(a, (size_t)n * C + c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(v[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) atomicMax(colmax + c4 + i, __float_as_uint(m[i]));
+}
 
 // byte offset of 16-byte chunk ch (0..15) of row `row` in a [rows][128 x 16-bit] plane
 __device__ __forceinline__ int tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -487,13 +513,15 @@ __device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
   return __builtin_bit_cast(xbf8, v);
 }
 
-template <typename TS>
+template <typename TS, bool HALF>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part) {
+                                                               float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
+                                                               const unsigned* __restrict__ colmax) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
+  constexpr int NP = HALF ? 2 : 3, BUFE = HALF ? DenseS::BUF_H : DenseS::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-  __bf16* ldsb = reinterpret_cast<__bf16*>(smem2);
+  __bf16* ldsb = reinterpret_cast<__bf16*>(smem2);      // (fp16 pieces in the HALF variant: same 16-bit layout)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
@@ -549,6 +577,18 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
     dr[e] = id >> 6;
     dc[e] = 4 * (id & 63);
   }
+  // HALF: the staged columns' scales (a thread always stages the same columns)
+  f32x4 scx[2], scd[4];
+  if constexpr (HALF) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) scx[e][i] = xin[e] ? col_scale(colmax[j0 + xc[e] + i]) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) scd[e][i] = col_scale(colmax[IN + o0 + dc[e] + i]);
+  }
   auto stage_load = [&](int64_t nb) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -562,28 +602,38 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
     }
   };
   auto store4 = [&](__bf16* plane0, int row, int col, const f32x4& v) {   // col: 0..127, multiple of 4
-    unsigned a0, b0, c0, a1, b1, c1;
-    split_pair(v[0], v[1], a0, b0, c0);
-    split_pair(v[2], v[3], a1, b1, c1);
     char* base = reinterpret_cast<char*>(plane0) + tr_off(row, col >> 3) + 8 * ((col >> 2) & 1);
-    *reinterpret_cast<u32x2*>(base) = u32x2{a0, a1};
-    *reinterpret_cast<u32x2*>(base + PL * 2) = u32x2{b0, b1};
-    *reinterpret_cast<u32x2*>(base + 2 * PL * 2) = u32x2{c0, c1};
+    if constexpr (HALF) {
+      unsigned a0, b0, a1, b1;
+      split_pair_h(v[0], v[1], a0, b0);
+      split_pair_h(v[2], v[3], a1, b1);
+      *reinterpret_cast<u32x2*>(base) = u32x2{a0, a1};
+      *reinterpret_cast<u32x2*>(base + PL * 2) = u32x2{b0, b1};
+    } else {
+      unsigned a0, b0, c0, a1, b1, c1;
+      split_pair(v[0], v[1], a0, b0, c0);
+      split_pair(v[2], v[3], a1, b1, c1);
+      *reinterpret_cast<u32x2*>(base) = u32x2{a0, a1};
+      *reinterpret_cast<u32x2*>(base + PL * 2) = u32x2{b0, b1};
+      *reinterpret_cast<u32x2*>(base + 2 * PL * 2) = u32x2{c0, c1};
+    }
   };
   auto stage_store = [&](int buf, int64_t nb) {
-    __bf16* xs = ldsb + buf * DenseS::BUF;                 // [3][32][128]
-    __bf16* ds0 = xs + 3 * PL;                             // columns 0..127:   [3][32][128]
-    __bf16* ds1 = ds0 + 3 * PL;                            // columns 128..255: [3][32][128]
+    __bf16* xs = ldsb + buf * BUFE;                        // [NP][32][128]
+    __bf16* ds0 = xs + NP * PL;                            // columns 0..127:   [NP][32][128]
+    __bf16* ds1 = ds0 + NP * PL;                           // columns 128..255: [NP][32][128]
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float keep = (nb + xr[e] < r1 && xin[e]) ? 1.0f : 0.0f;
-      store4(xs, xr[e], xc[e], sx[e] * keep);
+      if constexpr (HALF) store4(xs, xr[e], xc[e], sx[e] * scx[e] * keep);
+      else store4(xs, xr[e], xc[e], sx[e] * keep);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float keep = nb + dr[e] < r1 ? 1.0f : 0.0f;
       const f32x4 vd = sd[e] * keep;
-      store4(dc[e] < 128 ? ds0 : ds1, dr[e], dc[e] & 127, vd);
+      if constexpr (HALF) store4(dc[e] < 128 ? ds0 : ds1, dr[e], dc[e] & 127, vd * scd[e]);
+      else store4(dc[e] < 128 ? ds0 : ds1, dr[e], dc[e] & 127, vd);
       dbs[e] += vd;
     }
   };
@@ -595,43 +645,61 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
   for (int64_t ch = 0; ch < chunks; ++ch) {
     const int buf = (int)(ch & 1);
     lds_barrier();                                         // chunk ch is in `buf`; nobody reads the other buffer any more
-    const __bf16* xs = ldsb + buf * DenseS::BUF;
-    const __bf16* dsw = xs + 3 * PL + (wn >> 1) * 3 * PL;  // this wave's column half of dy
-    xbf8 af[4][3];
+    const __bf16* xs = ldsb + buf * BUFE;
+    const __bf16* dsw = xs + NP * PL + (wn >> 1) * NP * PL;  // this wave's column half of dy
+    xbf8 af[4][NP];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[mi][p] = tr_frag(xs + p * PL, wm * 4 + mi, lane);
+      for (int p = 0; p < NP; ++p) af[mi][p] = tr_frag(xs + p * PL, wm * 4 + mi, lane);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      xbf8 bf[3];
+      xbf8 bf[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[p] = tr_frag(dsw + p * PL, (wn & 1) * 4 + ni, lane);
+      for (int p = 0; p < NP; ++p) bf[p] = tr_frag(dsw + p * PL, (wn & 1) * 4 + ni, lane);
       if (ni == 1) {                                        // the next chunk's split + stores ride inside the MFMA stream
         stage_store(buf ^ 1, r0 + (ch + 1) * KB);           // (past the end: a fully masked chunk into the idle buffer)
         stage_load(r0 + (ch + 2 < chunks ? ch + 2 : ch + 1 < chunks ? ch + 1 : ch) * KB);
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
+        if constexpr (HALF) {
+          const xh8 a0 = __builtin_bit_cast(xh8, af[mi][0]), a1 = __builtin_bit_cast(xh8, af[mi][1]);
+          const xh8 b0 = __builtin_bit_cast(xh8, bf[0]), b1 = __builtin_bit_cast(xh8, bf[1]);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[mi][ni], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 6; ++s)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc[mi][ni], 0, 0, 0);
+          for (int s = 0; s < 6; ++s)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][SPLIT_TW[s]], bf[SPLIT_TX[s]], acc[mi][ni], 0, 0, 0);
+        }
+      }
     }
+  }
+  float uny[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (HALF) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) uny[ni] = col_unscale(colmax[IN + o0 + wn * 64 + 16 * ni + c]);
   }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int j = 0; j < 4; ++j) {
+      const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
+      if (jj < IN) {
+        float unx = 1.f;
+        if constexpr (HALF) unx = col_unscale(colmax[jj]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
-        if (jj < IN) {
+        for (int ni = 0; ni < 4; ++ni) {
           const size_t e = (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
-          if (KS == 1) dW[e] = acc[mi][ni][j];
-          else if (part) part[(size_t)ks * IN * OUT + e] = acc[mi][ni][j];      // summed by k_dense_reduce
-          else atomicAdd(dW + e, acc[mi][ni][j]);
+          const float v = HALF ? acc[mi][ni][j] * (unx * uny[ni]) : acc[mi][ni][j];
+          if (KS == 1) dW[e] = v;
+          else if (part) part[(size_t)ks * IN * OUT + e] = v;      // summed by k_dense_reduce
+          else atomicAdd(dW + e, v);
         }
       }
+    }
   if (want_bias) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -745,10 +813,36 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % De
 
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
+static size_t dense_colmax_bytes(int in, int out) { return al256g((size_t)(in + out) * sizeof(unsigned)); }
+
+// two fp16 pieces (three terms) where the column-maximum passes over x and dy pay off, else three bf16 pieces
+static bool dense_wgrad_use_half(int64_t n_rows, int in, int out) {
+  const int pieces = opt(OPT_GEMM_PIECES);
+  if (pieces == 2) return true;
+  if (pieces == 3) return false;
+  return (double)n_rows * in * out >= 68719476736.0;      // 2^36 multiply-adds
+}
+
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream, bool split, float* scratch) {
+                       float* d_bias, hipStream_t stream, bool split, float* scratch_all) {
   const int cus = device_cu_count();
   split = split && out % DenseS::TO == 0 && !opt(OPT_DENSE_FP32);      // A/B switch: dense gradient on the fp32 MFMA
+  // scratch: [column maxima of x and dy (HALF) | partial tiles of the row ranges]
+  unsigned* colmax = (unsigned*)scratch_all;
+  float* scratch = scratch_all ? (float*)((char*)scratch_all + dense_colmax_bytes(in, out)) : nullptr;
+  const bool half = split && colmax && n_rows > 0 && dense_wgrad_use_half(n_rows, in, out);
+  if (half) {
+    if (hipMemsetAsync(colmax, 0, (size_t)(in + out) * sizeof(unsigned), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    const unsigned gy = (unsigned)((n_rows + 127) / 128);
+    if (dtype == TTRNN_F32)
+      hipLaunchKernelGGL(k_col_absmax<float>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const float*)x, n_rows, in,
+                         colmax);
+    else
+      hipLaunchKernelGGL(k_col_absmax<bf16_t>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)x, n_rows,
+                         in, colmax);
+    hipLaunchKernelGGL(k_col_absmax<float>, dim3((out / 4 + 255) / 256, gy), dim3(256), 0, stream, dy, n_rows, out,
+                       colmax + in);
+  }
   const int KBc = split ? DenseS::KB : DenseG::KB;
   const int tiles = split ? ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO)
                           : ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
@@ -765,12 +859,14 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   float* part = KS > 1 ? scratch : nullptr;
   if (KS > 1 && !part && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess)
     return TTRNN_ERR_LAUNCH;
-  const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0);
+  const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0) + (half ? 2 : 0);
   const void* fn = di == 0   ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
                    : di == 1 ? reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>)
-                   : di == 2 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float>)
-                             : reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t>);
-  const size_t lds = split ? DenseS::LDS_BYTES : DenseG::LDS_BYTES;
+                   : di == 2 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float, false>)
+                   : di == 3 ? reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t, false>)
+                   : di == 4 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float, true>)
+                             : reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t, true>);
+  const size_t lds = half ? DenseS::LDS_BYTES_H : split ? DenseS::LDS_BYTES : DenseG::LDS_BYTES;
   {
     if (ensure_dynamic_lds(fn, lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
@@ -786,12 +882,20 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
                          (const bf16_t*)x, dy, dW, d_bias, part);
       break;
     case 2:
-      hipLaunchKernelGGL(k_dense_wgrad_split<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias, part);
+      hipLaunchKernelGGL((k_dense_wgrad_split<float, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const float*)x, dy, dW, d_bias, part, colmax);
+      break;
+    case 3:
+      hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, colmax);
+      break;
+    case 4:
+      hipLaunchKernelGGL((k_dense_wgrad_split<float, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const float*)x, dy, dW, d_bias, part, colmax);
       break;
     default:
-      hipLaunchKernelGGL(k_dense_wgrad_split<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part);
+      hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, colmax);
   }
   if (part) {
     const size_t n4 = (size_t)in * out / 4;
@@ -800,15 +904,16 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-// bytes of the partial-tile scratch launch_dense_wgrad wants for this shape (0: one workgroup per tile covers all rows)
+// bytes of the scratch launch_dense_wgrad wants for this shape: column maxima (two-piece fp16 variant) + the partial tiles
+// of the row ranges (none when one workgroup per tile covers all rows)
 size_t dense_wgrad_scratch_bytes(int in, int out) {
   const int cus = device_cu_count();
   const int tiles_s = ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO > 0 ? out / DenseS::TO : 1);
   const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;
-  if (tiles >= cus) return 0;
+  if (tiles >= cus) return dense_colmax_bytes(in, out);
   const int KS = ((cus / tiles + 7) / 8) * 8;
-  return (size_t)KS * in * out * sizeof(float);
+  return dense_colmax_bytes(in, out) + (size_t)KS * in * out * sizeof(float);
 }
 
 }  // namespace ttrnn

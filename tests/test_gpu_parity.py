@@ -1006,6 +1006,53 @@ def test_half_piece_gemm_input_ranges(storage):
     assert errs["half"] <= tol and errs["half"] <= 2.0 * errs["bf16x3"] + (2e-7 if storage == "f32" else 4e-3)
 
 
+@pytest.mark.parametrize("shape", ["fused_core_rank16", "merged_big"])
+def test_half_piece_dense_weight_gradient_column_ranges(shape):
+    """The dense weight gradient dW = x^T dy on two-piece fp16 operands (ttrnn_fast_gemm.hip, HALF): the contraction runs
+    over the rows, so the power-of-two scales are per COLUMN of x and of dy, taken from column maxima measured per launch.
+    Columns of wildly different magnitude, a zero column and an outlier row must give the gradients the three-bf16-piece
+    variant (option gemm_pieces = 3) and the float64 oracle give.  (By default the library picks the variant by size.)"""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(77)
+    if shape == "merged_big":
+        meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+        B, T, n_in = 4, 40, 1024
+    else:
+        meta = dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=1, n_cores=3, tt_rank=16)
+        B, T, n_in = 48, 30, 40
+    m = build_module(meta, dev())
+    x = torch.randn(B, T, n_in) * (10.0 ** (torch.rand(1, 1, n_in) * 8 - 5))     # column scales 1e-5 .. 1e3
+    x[:, :, 3] = 0.0
+    x[1, 2] *= 50.0                                                              # an outlier row
+    w = torch.randn(B, T, meta["hidden_size"])
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    ro, _ = O.lstm_forward(layers, x.double(), None)
+    (ro * w.double()).sum().backward()
+    grads = {}
+    for name, val in (("half", 2), ("bf16x3", 3)):
+        m.zero_grad()
+        with ttrnn_hip.option("gemm_pieces", val):
+            out, _ = m(x.to(dev()))
+            (out * w.to(dev())).sum().backward()
+        grads[name] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    worst = {"half": 0.0, "bf16x3": 0.0}
+    differ = False
+    for n, _ in m.named_parameters():
+        ref = leaves[n].grad
+        sc = max(float(ref.abs().max()), 1e-30)
+        for k in worst:
+            assert torch.isfinite(grads[k][n]).all(), (k, n)
+            worst[k] = max(worst[k], _maxabs(grads[k][n].double(), ref) / sc)
+        differ = differ or not torch.equal(grads["half"][n], grads["bf16x3"][n])
+    print(shape, "max gradient error relative to each tensor's maximum:", worst)
+    assert differ                                                 # the two variants did run
+    # (the input columns span eight decades: on the big shape the whole backward — reverse-time kernel, projections — sits at
+    # 8e-4 of the largest gradient entry with three bf16 pieces; the yardstick is that variant, not an absolute figure)
+    assert worst["half"] <= 2e-3 and worst["half"] <= 3.0 * worst["bf16x3"] + 1e-6
+
+
 def test_math_modes_full_size_properties(math_mode):
     """cfg2 at full size: batch independence, causality, bitwise repeatability — in either mode."""
     m = _cfg2_module()
