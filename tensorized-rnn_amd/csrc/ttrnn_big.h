@@ -85,6 +85,10 @@ __global__ void __launch_bounds__(256) k_merge_cores_last(const float* __restric
   }
 }
 
+// transposed merged matrix (4096 -> 1024) with reversed mode order: inputs (i23, i01), outputs (j23, j01), rank 32
+// (ttrnn_fast_bigb.hip:k_bigb_prep builds its fragment-ordered cores)
+using ShpH1024R32L_T = Shp<2, 64, 64, 1, 1, 64, 16, 1, 1, 32, 1, 1>;
+
 template <class S2>
 constexpr int merged2_elems() { return S2::J[0] * S2::R[1] * S2::I[0] + S2::J[1] * S2::I[1] * S2::R[1]; }
 

@@ -24,8 +24,6 @@
 
 namespace ttrnn {
 
-// transposed merged matrix (4096 -> 1024) with reversed mode order: inputs (i23, i01), outputs (j23, j01), rank 32
-using ShpH1024R32L_T = Shp<2, 64, 64, 1, 1, 64, 16, 1, 1, 32, 1, 1>;
 
 // fragment-ordered (see frag_decode) cores of the transposed matrix, built from the three-core buffer of k_merge_cores01:
 //   stage 1:  W^T_1[kk = i01][m = (j01, r)]  = A[(j01, r)][i01]
@@ -724,7 +722,8 @@ bool big_rnn_bwd_available(const RnnShape& rs, int dtype) {
 }
 
 size_t big_rnn_bwd_workspace(const RnnShape& rs) {
-  return B3 + BT + (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long);      // + tagged exchange words of the pair kernel
+  // + tagged exchange words of the pair kernel + the fp16 fragments of its split-mode version
+  return B3 + BT + al256((size_t)rs.B * 2 * rs.H * sizeof(unsigned long long)) + bigbh_workspace_bytes();
 }
 
 template <typename TS>
@@ -742,6 +741,11 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
   if (pair) {
     if (hipMemsetAsync(hxb, 0, (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long), stream) != hipSuccess)
       return TTRNN_ERR_LAUNCH;
+    // split mode: both stages on two-piece fp16 operands (ttrnn_fast_bigbh.hip); OPT_BIG_FP32_MFMA: A/B switch
+    if (opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA))
+      return launch_lstm_bwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, c0, mT, reserve, d_out, d_hT, d_cT, dg_in,
+                                   d_h0, d_c0, hxb,
+                                   (char*)hxb + al256((size_t)rs.B * 2 * rs.H * sizeof(unsigned long long)), stream);
     // 64 KB image; 100 KB requested so that a second workgroup cannot share the CU (see the forward pair kernel)
     constexpr size_t lds = bigb_lds_bytes<ST, 2>() > 100 * 1024 ? bigb_lds_bytes<ST, 2>() : 100 * 1024;
     {

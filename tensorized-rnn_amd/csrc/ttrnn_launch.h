@@ -175,6 +175,12 @@ int launch_lstm_fwd_big2h(const RnnShape& rs, int dtype, const float* gin, const
                           const float* m2_hid, const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT,
                           float* reserve, unsigned long long* hxb, void* scratch, hipStream_t stream);
 
+// ... and its reverse-time counterpart (ttrnn_fast_bigbh.hip); fragT: ttrnn_fast_bigb.hip:k_bigb_prep's buffer
+size_t bigbh_workspace_bytes();
+int launch_lstm_bwd_big2h(const RnnShape& rs, int dtype, const void* c0, const float* fragT, const float* reserve,
+                          const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
+                          unsigned long long* hxb, void* scratch, hipStream_t stream);
+
 // BPTT of the big shape through the merged two-core matrix (ttrnn_fast_bigb.hip): reverse-time kernel (one or two
 // workgroups per sample) and the batched TTLinear backward (dx through the transposed merged chain; weight + bias
 // gradients accumulated in MFMA registers)

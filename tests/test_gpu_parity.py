@@ -1296,6 +1296,65 @@ def test_big_shape_gradients_vs_oracle():
         assert _maxabs(got, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps"])
+def test_big_shape_half_piece_reverse_kernel_ranges(case):
+    """cfg5-class reverse-time kernel in split mode (ttrnn_fast_bigbh.hip): gate gradients have no bound known before the
+    launch, so every step the workgroup scales them by a power of two taken from their own maximum before they are split
+    into fp16 pieces.  Output gradients spanning ten decades across steps and samples, steps with no gradient at all, and
+    plain ones: every parameter / input / initial-state gradient against the float64 oracle's autograd, next to the fp32-MFMA
+    pair kernel (option big_fp32_mfma) on the same inputs; bitwise repeatable and independent of the rest of the batch."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(93)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 4, 7
+    x = torch.randn(B, T, 1024)
+    h0, c0 = torch.randn(B, 1024) * 0.3, torch.randn(B, 1024) * 0.3
+    w = torch.randn(B, T, 1024)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))          # 1e-6 .. 1e4 per (sample, step)
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0                                           # no output gradient on steps 1..4
+        w[2] = 0.0                                                # nor anywhere on sample 2
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t.double().clone().requires_grad_(True) for t in (x, h0, c0))
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    wsum = 0.0 if case == "sparse_steps" else 1.0                 # sparse: sample 2 gets no gradient from the states either
+    ((ro * w.double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+
+    def run(sel=None):
+        m.zero_grad()
+        xs, hs, cs, ws = (t if sel is None else t[sel] for t in (x, h0, c0, w))
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (xs, hs, cs))
+        out, (hT, cT) = m(xg, (h0g, c0g))
+        ((out * ws.to(dev())).sum() + wsum * (cT.sum() + 0.5 * hT.sum())).backward()
+        return {"x": xg.grad.clone(), "h0": h0g.grad.clone(), "c0": c0g.grad.clone(),
+                **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    got = run()
+    again = run()
+    with ttrnn_hip.option("big_fp32_mfma", 1):
+        fp32 = run()
+    sub = run([2, 0])
+    refs = {"x": xr.grad, "h0": h0r.grad, "c0": c0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"split": 0.0, "fp32_mfma": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["split"] = max(worst["split"], _maxabs(got[n].double(), ref) / sc)
+        worst["fp32_mfma"] = max(worst["fp32_mfma"], _maxabs(fp32[n].double(), ref) / sc)
+    for n in ("x", "h0", "c0"):        # the reverse-time kernel's own results: repeatable, independent of the rest of the batch
+        assert torch.equal(got[n], again[n]), n                   # (bias / core gradients are flushed with atomics)
+        assert torch.equal(got[n][[2, 0]], sub[n]), n
+    if case == "sparse_steps":
+        assert float(got["x"][2].abs().max()) == 0.0 and float(got["h0"][2].abs().max()) == 0.0
+    print(case, "max gradient error relative to each tensor's maximum:", worst)
+    assert not torch.equal(got["h0"], fp32["h0"])                 # a different kernel did run
+    assert worst["split"] <= 2e-5 and worst["split"] <= 3.0 * worst["fp32_mfma"] + 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_big_shape_backward_kernels_agree(dtype):
     """The cfg5-class backward paths on the same module and inputs: pair reverse-time kernel + weight gradients through the
