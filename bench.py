@@ -88,8 +88,7 @@ EXECUTED = {
     "cfg5": dict(bf16_mfma=128 * 2 * 3 + 4 * 4 * 16 * 3, fp32_mfma=0,
                  kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, pipe16="f16_mfma", terms=3,
                  note="K-rec: merged 2-core chain on two-piece fp16 operands (three terms per product), two workgroups per "
-                      "sample, stage-1 fragments streamed from L2 (a quarter resident in LDS), stage-0 fragments resident "
-                      "in registers; K-in: dense GEMM on two-piece fp16 operands (three terms)"),
+                      "sample, every core fragment resident (registers + a quarter of stage 1's in LDS); K-in: dense GEMM on two-piece fp16 operands (three terms)"),
 }
 
 

@@ -3,11 +3,11 @@
 // terms per product, instead of the fp32 MFMA of ttrnn_fast_big.hip:k_lstm_fwd_big2 (16.4 k of its 26 k cycles per step
 // were matrix pipe).  Same pair structure and the same tagged-word exchange of h; what changes:
 //   * stage 1 (16 rows x K = 64 x 1024 features per workgroup): the h image is two fp16 planes of 2^9 h; the core
-//     fragments (two pieces of 2^a W_1) are STREAMED from L2, 256 KB per step and workgroup, through two register slots of
-//     two m-tiles, requested one slot-round ahead of their use (the first two chunks of step t+1 travel during stage 0,
-//     the gates and the exchange of step t);
+//     fragments (two pieces of 2^a W_1, 256 KB per workgroup) are RESIDENT: three quarters in registers (96 VGPRs per
+//     wave), the last quarter in LDS (64 KB) — the first version streamed them from L2 through two register slots (8.3 ms
+//     per forward against 7.6: with all 256 CUs streaming, L2 delivered ~ 26 B/clk per CU);
 //   * its sums are rescaled by a fixed power of two (< 2^15) and split into the two fp16 planes of the stage-0 image;
-//   * stage 0 (32 local rows x K = 512 x 64 features): the fragments of 2^b W_0 are RESIDENT in registers (64 VGPRs:
+//   * stage 0 (32 local rows x K = 512 x 64 features): the fragments of 2^b W_0 are resident in registers too (64 VGPRs:
 //     wave = (feature tile p, k half), both row tiles), feature rows permuted so that a lane's four accumulator
 //     registers are the four gates of ONE hidden unit: the gates run in the lanes that hold the sums, after the two k
 //     halves have been exchanged through LDS (wave kh keeps row tile kh, hands over row tile 1 - kh);
@@ -189,15 +189,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) w0f[u][pc] = f0[((size_t)(wave * 8 + u) * 2 + pc) * 64 + lane];
 
-  // stage-1 stream: chunk j = m-tiles x = 2 j, 2 j + 1 of this wave; entry ((x * 2 + kb) * 2 + piece) * 64 + lane
+  // stage-1 fragments: chunk j = m-tiles x = 2 j, 2 j + 1 of this wave; entry ((x * 2 + kb) * 2 + piece) * 64 + lane.
+  // Chunks 0..2 are resident in registers (96 VGPRs), chunk 3 in LDS: nothing is streamed during the time loop.
   const xh8* f1w = f1 + (size_t)(half * 8 + wave) * (8 * 2 * 2 * 64);
-  xh8 sa[2][4], sb[2][4];
-  auto loadc = [&](xh8 (&s)[2][4], int j, int zz) {
+  xh8 w1r[3][2][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[y][i] = f1w[(size_t)((2 * j + y) * 4 + i) * 64 + lane + zz];
-  };
+      for (int i = 0; i < 4; ++i) w1r[j][y][i] = f1w[(size_t)((2 * j + y) * 4 + i) * 64 + lane];
   xh8 hb[2][2];
   // two m-tiles (one local row of the stage-0 image: a = 0..15 and 16..31), their sums split into the image
   int cz = c, qz = q;                      // the lane's (c, q) behind the per-step opaque id: addresses are recomputed, not hoisted
@@ -222,15 +223,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       store_split4_h(img, BH_PL_I, o0 + y * 256, v);
     }
   };
-  loadc(sa, 0, 0);
-  loadc(sb, 1, 0);
 #pragma unroll
   for (int e = 0; e < 8; ++e) w1l[(wave * 8 + e) * 64 + lane] = f1w[(size_t)(3 * 8 + e) * 64 + lane];
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     int z = 0;
-    asm volatile("" : "+v"(z));            // per-step opaque lane id: the fragment loads stay where they are written
+    asm volatile("" : "+v"(z));            // per-step opaque lane id (cz, qz below)
     cz = (lane + z) & 15;
     qz = (lane + z) >> 4;
     // ---- stage 1 ----------------------------------------------------------------------------------------------------
@@ -239,14 +238,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc)
         hb[kb][pc] = *reinterpret_cast<const xh8*>(hpl + pc * BH_PL_H + x_off<BH_K1>(cz, 32 * kb + 8 * qz));
-    // sa holds chunk u = t & 1, sb chunk v = 1 - u (requested during the previous step); chunk 2 is requested as soon as a
-    // slot is free, chunk 3 is resident in LDS and gives chunk 2 the time to arrive; the next step's chunks 0 / 1 travel
-    // during stage 0, the gates and the exchange and land in the OTHER slot each: u and v swap every step
-    const int u = t & 1, v = u ^ 1;
-    s1(sa, u);
-    loadc(sa, 2, z);
-    s1(sb, v);
-    loadc(sb, u, z);
+    s1(w1r[0], 0);
+    s1(w1r[1], 1);
     {
       xh8 tl[2][4];
 #pragma unroll
@@ -255,8 +248,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
         for (int i = 0; i < 4; ++i) tl[y][i] = w1l[(wave * 8 + y * 4 + i) * 64 + lane];
       s1(tl, 3);
     }
-    s1(sa, 2);
-    loadc(sa, v, z);
+    s1(w1r[2], 2);
     __syncthreads();
     // ---- stage 0: both row tiles against this wave's k half; reads run PD operands ahead of the MFMAs ----------------
     f32x4 acc[2];
