@@ -391,9 +391,10 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
   p.buf_global = per > LDS_LIMIT;
   size_t lds = p.buf_global ? 0 : per;
   if (!p.buf_global) {
-    // more rows per tile amortise the per-stage barriers when a sample is small
+    // more rows per tile amortise the per-stage barriers when a sample is small — as long as two tiles per CU remain (a
+    // classifier head sees B rows: 128 rows in tiles of 8 ran on 16 of the 256 CUs)
     while (p.nb < 8 && (size_t)(p.nb * 2) * per + acc <= LDS_LIMIT / 2 && (int64_t)(p.nb * 2) <= n_rows &&
-           (size_t)(p.nb * 2) * p.bs < 8192)
+           (size_t)(p.nb * 2) * p.bs < 8192 && n_rows / (p.nb * 2) >= 512)
       p.nb *= 2;
     lds = (size_t)p.nb * per;
   }
