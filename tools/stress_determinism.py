@@ -32,6 +32,7 @@ CASES = {
     "cfg4": ("ttlstm", 40, 256, 3, 3, 16, 512, 160),     # full size: two samples per workgroup
     "cfg2": ("ttlstm", 1, 256, 1, 3, 8, 64, 784),
     "cfg3": ("ttgru", 1, 256, 1, 3, 8, 256, 784),
+    "cfg5": ("ttlstm", 1024, 1024, 1, 4, 32, 128, 192),  # pair kernels (two workgroups per sample), full batch, short sequence
 }
 
 
