@@ -1006,7 +1006,7 @@ def test_half_piece_gemm_input_ranges(storage):
     assert errs["half"] <= tol and errs["half"] <= 2.0 * errs["bf16x3"] + (2e-7 if storage == "f32" else 4e-3)
 
 
-@pytest.mark.parametrize("shape", ["fused_core_rank16", "merged_big"])
+@pytest.mark.parametrize("shape", ["fused_core_rank16", "merged_big", "merged_big_bf16"])
 def test_half_piece_dense_weight_gradient_column_ranges(shape):
     """The dense weight gradient dW = x^T dy on two-piece fp16 operands (ttrnn_fast_gemm.hip, HALF): the contraction runs
     over the rows, so the power-of-two scales are per COLUMN of x and of dy, taken from column maxima measured per launch.
@@ -1015,7 +1015,8 @@ def test_half_piece_dense_weight_gradient_column_ranges(shape):
     import ttrnn_hip
     from oracle import ttrnn_oracle as O
     torch.manual_seed(77)
-    if shape == "merged_big":
+    bf16 = shape.endswith("_bf16")
+    if shape.startswith("merged_big"):
         meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
         B, T, n_in = 4, 40, 1024
     else:
@@ -1026,6 +1027,9 @@ def test_half_piece_dense_weight_gradient_column_ranges(shape):
     x[:, :, 3] = 0.0
     x[1, 2] *= 50.0                                                              # an outlier row
     w = torch.randn(B, T, meta["hidden_size"])
+    if bf16:                              # bf16 storage: parameters, x and out in bf16 (the oracle sees the rounded values)
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
     sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
     layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
     ro, _ = O.lstm_forward(layers, x.double(), None)
@@ -1035,8 +1039,8 @@ def test_half_piece_dense_weight_gradient_column_ranges(shape):
         m.zero_grad()
         with ttrnn_hip.option("gemm_pieces", val):
             out, _ = m(x.to(dev()))
-            (out * w.to(dev())).sum().backward()
-        grads[name] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+            (out.float() * w.to(dev())).sum().backward()
+        grads[name] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}
     worst = {"half": 0.0, "bf16x3": 0.0}
     differ = False
     for n, _ in m.named_parameters():
@@ -1050,7 +1054,8 @@ def test_half_piece_dense_weight_gradient_column_ranges(shape):
     assert differ                                                 # the two variants did run
     # (the input columns span eight decades: on the big shape the whole backward — reverse-time kernel, projections — sits at
     # 8e-4 of the largest gradient entry with three bf16 pieces; the yardstick is that variant, not an absolute figure)
-    assert worst["half"] <= 2e-3 and worst["half"] <= 3.0 * worst["bf16x3"] + 1e-6
+    # bf16 storage: out, h and the returned gradients are rounded to bf16 (2^-9 relative each)
+    assert worst["half"] <= (5e-2 if bf16 else 2e-3) and worst["half"] <= 3.0 * worst["bf16x3"] + 1e-6
 
 
 def test_math_modes_full_size_properties(math_mode):
