@@ -49,8 +49,8 @@ __device__ __forceinline__ int frag_index(int kk, int m) {
   return (((m >> 4) * T::NU + (kk >> 4)) * 64 + ((kk >> 2) & 3) * 16 + (m & 15)) * 4 + (kk & 3);
 }
 
-// k order of the stage-0 operand: (j0, a) -> (a / 4) * 64 + j0 * 4 + a % 4
-__device__ __forceinline__ int bh_kperm(int j0, int a) { return (a >> 2) * 64 + j0 * 4 + (a & 3); }
+// k order of the stage-0 operand: (j0, a) -> k' = (a / 4) * 64 + j0 * 4 + a % 4 (k_bigh_prep inverts it for W_0's fragments, the
+// stage-1 store of the kernel produces it)
 
 struct BhScales { float tail, head, r1, un; };
 // parts: [2][BH_PARTS] partial maxima (|W_0| then |W_1|); every lane of a wave calls this
