@@ -31,8 +31,6 @@ constexpr int GK = 32;                        // k per chunk = one bf16 MFMA
 constexpr int GPA = GR * GK, GPB = GF * GK;   // bf16 elements per plane tile (rows / features)
 constexpr int G_BUF = 3 * GPA + 3 * GPB;      // one buffer: three planes of each operand
 constexpr size_t G_LDS = (size_t)2 * G_BUF * sizeof(__bf16);
-constexpr int G_BUF_H = 2 * GPA + 2 * GPB;    // two-piece fp16 operands: two planes of each
-constexpr size_t G_LDS_H = (size_t)2 * G_BUF_H * sizeof(_Float16);
 constexpr int G_PARTS = 64;                   // partial maxima of |W| (scratch header)
 constexpr int G_HDR = 256;                    // bytes in front of the row scales
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -137,7 +135,9 @@ __device__ __forceinline__ void ld8(const bf16_t* p, size_t i, f32x4& a, f32x4& 
 // y[n][m'] (fp32, row stride M) = sum_k x[n][k] W[k][m'] (+ bias of hidden unit m'/4, slots i,g,f,o when bias != NULL)
 // Workgroup tile: 128 features x 256 rows, wave tile 64 x 64 (4 x 4 MFMA tiles: 24 fragment reads feed 96 MFMAs per
 // chunk — the 128 x 128 tile with 32 x 64 wave tiles spent as long in LDS traffic, splitting and barriers as in MFMAs).
-template <typename TS, bool HALF>
+// FW = 2 (HALF only): 256 features x 256 rows per workgroup, wave tile 128 x 64 — the row operand, whose staging carries the
+// split, is then staged once per 96 instead of 48 MFMAs of a wave, and there is one barrier per 96
+template <typename TS, bool HALF, int FW = 1>
 __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, int KCn, int M,
                                                         const TS* __restrict__ x, const void* __restrict__ planes_v,
                                                         const TS* __restrict__ bias, int Hb, float* __restrict__ y,
@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   using E = typename std::conditional<HALF, _Float16, __bf16>::type;
   using X8 = typename std::conditional<HALF, xh8, xbf8>::type;
   constexpr int NP = HALF ? 2 : 3;
-  constexpr int BUF = NP * (GPA + GPB);
+  constexpr int GPBW = FW * GPB, GFW = FW * GF, MI = 4 * FW;
+  constexpr int BUF = NP * (GPA + GPBW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   E* lds = reinterpret_cast<E*>(smem);                     // [buf][A planes NP][256][32], [B planes NP][128][32]
   const E* planes = reinterpret_cast<const E*>(planes_v);
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   // ---- tile of this workgroup (XCD-aware when the feature tiles come in groups of 8) ----------------------------------
-  const int MT = M / GF;
+  const int MT = M / GFW;
   const int64_t RT = (n_rows + GR - 1) / GR;
   int mt_tile;
   int64_t rt_tile;
@@ -173,9 +174,9 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     rt_tile = blockIdx.x / MT;
   }
   if (rt_tile >= RT) return;
-  const int m0 = mt_tile * GF;
+  const int m0 = mt_tile * GFW;
   const int64_t n0 = rt_tile * GR;
-  const int wm = wave & 1, wr = wave >> 1;                 // wave tile: features [64 wm, +64) x rows [64 wr, +64)
+  const int wm = wave & 1, wr = wave >> 1;                 // wave tile: features [64 FW wm, +64 FW) x rows [64 wr, +64)
 
   // ---- staging: thread -> (rows tid >> 2 and 128 + (tid >> 2) / feature tid >> 2, k group tid & 3) ------------------------
   const int srow = tid >> 2, skq = tid & 3;
@@ -190,15 +191,17 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   const size_t plane_elems = (size_t)KCn * M * 32;
   const E* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
   f32x4 xa[2], xb[2];
-  X8 wb[NP];
+  X8 wb[FW][NP];
   auto stage_load = [&](int kc) {
     const int k = kc * GK + 8 * skq;
     const int kcl = k + 8 <= K ? k : (K >= 8 ? K - 8 : 0);      // unconditional loads; out-of-range groups are zeroed below
 #pragma unroll
     for (int e = 0; e < 2; ++e) ld8(xrow[e], (size_t)kcl, xa[e], xb[e]);
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-      wb[p] = *reinterpret_cast<const X8*>(wrow + p * plane_elems + (size_t)kc * M * 32);
+    for (int f = 0; f < FW; ++f)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        wb[f][p] = *reinterpret_cast<const X8*>(wrow + (size_t)f * GF * 32 + p * plane_elems + (size_t)kc * M * 32);
   };
   auto stage_store = [&](int buf, int kc) {
     E* As = lds + buf * BUF;
@@ -228,15 +231,18 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
         *reinterpret_cast<u32x4*>(As + 2 * GPA + off) = u32x4{p2[0], p2[1], p2[2], p2[3]};
       }
     }
-    const int offb = x_off<GK>(srow, 8 * skq);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) *reinterpret_cast<X8*>(Bs + p * GPB + offb) = wb[p];
+    for (int f = 0; f < FW; ++f) {
+      const int offb = x_off<GK>(srow + GF * f, 8 * skq);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<X8*>(Bs + p * GPBW + offb) = wb[f][p];
+    }
   };
 
   // one fp32 accumulator per tile: the six terms of a chunk are added smallest first (SPLIT_TW / SPLIT_TX order)
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) acc[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -248,33 +254,38 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     lds_barrier();                                         // chunk kc is in `buf`; nobody reads the other buffer any more
     const E* As = lds + buf * BUF;
     const E* Bs = As + NP * GPA;
-    X8 wf[4][NP];
+    // feature tiles in groups of four (FW = 2: two passes over the row tiles, so that only 32 fragment registers are live)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int h = 0; h < FW; ++h) {
+      X8 wf[4][NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        wf[mi][p] = *reinterpret_cast<const X8*>(Bs + p * GPB + x_off<GK>(wm * 64 + 16 * mi + c, 8 * q));
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      X8 af[NP];
+        for (int p = 0; p < NP; ++p)
+          wf[mi][p] = *reinterpret_cast<const X8*>(Bs + p * GPBW + x_off<GK>(wm * 64 * FW + 64 * h + 16 * mi + c, 8 * q));
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        af[p] = *reinterpret_cast<const X8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
-      // the next chunk's split + LDS stores (other buffer; its data was requested a chunk ago) ride inside the MFMA stream
-      if (ri == 1) {                                        // unconditional: no branch inside the chunk
-        stage_store(buf ^ 1, kc + 1);                       // past the end it fills the idle buffer with a masked chunk
-        stage_load(kc + 2 < KCn ? kc + 2 : KCn - 1);
-      }
+      for (int ri = 0; ri < 4; ++ri) {
+        X8 af[NP];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        if constexpr (HALF) {
-          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][1], af[0], acc[mi][ri], 0, 0, 0);
-          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[1], acc[mi][ri], 0, 0, 0);
-          acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[0], acc[mi][ri], 0, 0, 0);
-        } else {
+        for (int p = 0; p < NP; ++p)
+          af[p] = *reinterpret_cast<const X8*>(As + p * GPA + x_off<GK>(wr * 64 + 16 * ri + c, 8 * q));
+        // the next chunk's split + LDS stores (other buffer; its data was requested a chunk ago) ride inside the MFMA stream
+        if (h == 0 && ri == 1) {                            // unconditional: no branch inside the chunk
+          stage_store(buf ^ 1, kc + 1);                     // past the end it fills the idle buffer with a masked chunk
+          stage_load(kc + 2 < KCn ? kc + 2 : KCn - 1);
+        }
 #pragma unroll
-          for (int s = 0; s < 6; ++s)
-            acc[mi][ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], acc[mi][ri], 0, 0, 0);
+        for (int mi = 0; mi < 4; ++mi) {
+          f32x4& a = acc[4 * h + mi][ri];
+          if constexpr (HALF) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][1], af[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][0], af[0], a, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mi][SPLIT_TW[s]], af[SPLIT_TX[s]], a, 0, 0, 0);
+          }
         }
       }
     }
@@ -291,8 +302,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   }
   // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 64wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int mf = m0 + wm * 64 + 16 * mi + 4 * q;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int mf = m0 + wm * 64 * FW + 16 * mi + 4 * q;
     f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias) {
       const int hd = mf >> 2;
@@ -766,15 +777,16 @@ int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scr
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-template <typename TS, bool HALF = false>
+template <typename TS, bool HALF = false, int FW = 1>
 static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias, int Hb,
                          float* y, hipStream_t stream, const float* bias_ilv, const float* scratch = nullptr) {
+  constexpr size_t lds = HALF ? (size_t)2 * 2 * (GPA + FW * GPB) * sizeof(_Float16) : G_LDS;
   {
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_split<TS, HALF>), HALF ? G_LDS_H : G_LDS) != TTRNN_OK)
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_split<TS, HALF, FW>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
   }
   const int KCn = gemm_chunks(K);
-  const int MT = M / GT;
+  const int MT = M / (GT * FW);
   const int64_t RT = (n_rows + GR - 1) / GR;
   int64_t grid;
   if (MT % 8 == 0) {
@@ -783,10 +795,13 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
   } else {
     grid = (int64_t)MT * RT;
   }
-  hipLaunchKernelGGL((k_gemm_split<TS, HALF>), dim3((unsigned)grid), dim3(FAST_NT), HALF ? G_LDS_H : G_LDS, stream, n_rows,
+  hipLaunchKernelGGL((k_gemm_split<TS, HALF, FW>), dim3((unsigned)grid), dim3(FAST_NT), lds, stream, n_rows,
                      K, KCn, M, (const TS*)x, planes, (const TS*)bias, Hb, y, bias_ilv, scratch);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
+
+// 256-feature workgroup tiles where the matrix is wide enough to keep every CU busy with them
+static bool gemm_wide_tiles(int64_t n_rows, int M) { return M % (2 * GT) == 0 && (M / (2 * GT)) * ((n_rows + GR - 1) / GR) >= 1024; }
 
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
                      const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
@@ -795,10 +810,14 @@ int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, con
   const int grid = (int)((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
   if (dtype == TTRNN_F32) {
     hipLaunchKernelGGL(k_row_scales<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, n_rows, K, rs);
-    return launch_gemm_t<float, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
+    return gemm_wide_tiles(n_rows, M)
+               ? launch_gemm_t<float, true, 2>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch)
+               : launch_gemm_t<float, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
   }
   hipLaunchKernelGGL(k_row_scales<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, n_rows, K, rs);
-  return launch_gemm_t<bf16_t, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
+  return gemm_wide_tiles(n_rows, M)
+             ? launch_gemm_t<bf16_t, true, 2>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch)
+             : launch_gemm_t<bf16_t, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
 }
 
 int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, const void* bias,
