@@ -1058,6 +1058,35 @@ def test_half_piece_dense_weight_gradient_column_ranges(shape):
     assert worst["half"] <= (5e-2 if bf16 else 2e-3) and worst["half"] <= 3.0 * worst["bf16x3"] + 1e-6
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_wide_tile_gemm_matches_three_piece_variant(storage):
+    """From 1024 workgroup tiles on, the two-piece input-projection GEMM takes 256-feature tiles (k_gemm_split<., HALF, 2>):
+    16 384 rows into the cfg5-class matrix (1024 -> 4096), both storage types, against the three-bf16-piece GEMM with its
+    128-feature tiles on the same module and inputs (the recurrent kernel is the same in both runs)."""
+    import ttrnn_hip
+    torch.manual_seed(101)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 1024, 16                       # 16 384 rows, few steps (the recurrence amplifies a GEMM difference step by step)
+    x = torch.randn(B, T, 1024, device=dev()) * (10.0 ** (torch.rand(B, T, 1, device=dev()) * 3 - 3))     # rows 1e-3 .. 1
+    if storage == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+    outs = {}
+    for name, val in (("half_wide", 2), ("bf16x3", 3)):
+        with ttrnn_hip.option("gemm_pieces", val), torch.no_grad():
+            out, (hT, cT) = m(x)
+        outs[name] = (out.float(), cT.float())
+    assert torch.isfinite(outs["half_wide"][0]).all()
+    d_out = _maxabs(outs["half_wide"][0], outs["bf16x3"][0])
+    d_c = _maxabs(outs["half_wide"][1], outs["bf16x3"][1])
+    print(storage, "wide two-piece vs three-piece GEMM: max |d out|", d_out, "max |d c_T|", d_c)
+    assert not torch.equal(outs["half_wide"][0], outs["bf16x3"][0]) or storage == "bf16"
+    # fp32: both are fp32-class; bf16: one output ulp.  (With rows up to 1e2 the pre-activations reach the hundreds, where two
+    # fp32-class GEMMs differ by a few ulps = 1e-4, and so do the outputs: 9e-5 measured.)
+    assert d_out <= (5e-6 if storage == "f32" else 8e-3) and d_c <= (2e-5 if storage == "f32" else 3e-2)
+
+
 def test_math_modes_full_size_properties(math_mode):
     """cfg2 at full size: batch independence, causality, bitwise repeatability — in either mode."""
     m = _cfg2_module()
