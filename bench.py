@@ -38,7 +38,11 @@ FP32_MATH_DESC = {
     "split": "split (default where a split kernel exists): fp32 operands as error-compensated 16-bit pieces with fp32 "
              "accumulate - two fp16 pieces / 3 MFMA terms under per-launch power-of-two scales in the LSTM forward "
              "kernels (cfg2, cfg4, cfg5), three bf16 pieces / 6 terms elsewhere; error vs float64 equal to the fp32-MFMA "
-             "mode (tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges, ::test_big_shape_half_piece_operand_ranges); "
+             "mode - 1.2e-7 abs over 784 steps in BOTH modes, set by the 1-ulp hardware exp / rcp of the gate non-linearities, "
+             "not by the matrix arithmetic (the reference's CPU fp32: 1.6e-8) "
+             "(tests/test_gpu_parity.py::test_split_math_error_vs_fp64_is_fp32_class, ::test_split_math_operand_ranges, "
+             "::test_split_math_outlier_up, ::test_big_shape_half_piece_operand_ranges); operands whose magnitude spread would "
+             "cost the fp16 pieces bits are detected on the device and run on three bf16 pieces (DESIGN.md 4a); "
              "TTRNN_FP32_MATH=exact selects the fp32 MFMA",
     "exact": "exact: v_mfma_f32_16x16x4_f32 on fp32 operands",
 }
@@ -112,9 +116,16 @@ class EventTimer(object):
             ev.record()
             self.pairs.setdefault(name, []).append((self._open.pop(name), ev))
 
+    def times_ms(self, name):
+        return [a.elapsed_time(b) for a, b in self.pairs.get(name, [])]
+
     def mean_ms(self, name):
-        p = self.pairs.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else None
+        p = self.times_ms(name)
+        return sum(p) / len(p) if p else None
+
+    def median_ms(self, name):
+        p = sorted(self.times_ms(name))
+        return p[len(p) // 2] if p else None
 
     def count(self, name):
         return len(self.pairs.get(name, []))
@@ -170,12 +181,14 @@ def cpu_baseline(w, budget_s=20.0):
 
     res = {}
     sample_T = {}
-    for n in sorted({1, phys}):
+    mid = min(8, phys)                      # BASELINE.md section 3 quotes the reference at 8 threads
+    counts = sorted({1, mid, phys})
+    for n in counts:
         torch.set_num_threads(n)
         run(2)
         per_step = min(run(4), run(4)) / 4.0
         # five runs inside this thread count's share of the budget, at least 4 and at most all T steps
-        T = int(max(4, min(w["T"], budget_s / 2.0 / 5.0 / per_step)))
+        T = int(max(4, min(w["T"], budget_s / len(counts) / 5.0 / per_step)))
         times = sorted(run(T) for _ in range(5))
         res[n] = T / times[2]
         sample_T[n] = T
@@ -186,12 +199,14 @@ def cpu_baseline(w, budget_s=20.0):
     except OSError:
         model = "unknown"
     return {"value": res[best], "unit": "timesteps/s", "cores": best, "kind": "port",
-            "threads_1": res[1], "threads_all_physical": res[phys], "physical_cores": phys, "logical_cpus": logical,
+            "threads_1": res[1], "threads_8": res[mid] if mid == 8 else None, "threads_all_physical": res[phys],
+            "by_threads": {str(n): res[n] for n in counts}, "physical_cores": phys, "logical_cpus": logical,
             "cpu_model": model,
             "sample": "oracle/ttrnn_oracle.py (torch-CPU, op-for-op restatement of the reference loop; within 10 % of the "
-                      "reference's own speed: profiles/r2/oracle_speed_validation.json), batch {} x first {} (1 thread) / {} "
-                      "({} threads) of {} timesteps, fp32, no_grad, median of 5 runs each; `value` = the faster of the "
-                      "two".format(w["B"], sample_T[1], sample_T[phys], phys, w["T"])}
+                      "reference's own speed: profiles/r2/oracle_speed_validation.json), batch {}, first {} of {} timesteps at {} "
+                      "thread(s), fp32, no_grad, median of 5 runs each; `value` = the fastest thread count (all physical "
+                      "cores oversubscribe a path of ~40 tiny ATen ops per step)".format(
+                          w["B"], "/".join(str(sample_T[n]) for n in counts), w["T"], "/".join(str(n) for n in counts))}
 
 
 def run_grid(args, device):
@@ -256,6 +271,10 @@ def main():
                          "(hidden_size, ncores, ttrank, cell) combinations of the reference's experiment flags, route and "
                          "time per shape against the any-shape VALU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the configuration's batch PER GPU (the headline metric, 'timesteps/sec/GPU (batch=64)'). "
+                         "strong: the configuration's batch is the GLOBAL batch, sharded over the ranks (SURVEY.md 8(d): "
+                         "cfg4 512 -> 64 per GPU, cfg5 128 -> 16 per GPU at 8 GPUs)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward: the headline metric (no_grad forward). train: the reference's training benchmark step "
                          "(benchmarking.py:41-70: classifier forward + nll_loss + BPTT + Adam) + flat-bucket gradient "
@@ -278,8 +297,12 @@ def main():
     torch.cuda.set_device(device)
     dist = None
     backend = None
-    if world > 1:
+    # TTRNN_BENCH_FORCE_DIST=1: take the distributed branch (process group on RCCL, barriers, MAX all-reduce of the time,
+    # the flat-bucket gradient all-reduce in train mode) with ONE rank, so that a 1-GPU box runs the code path of --gpus N
+    force_dist = os.environ.get("TTRNN_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("TTRNN_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
@@ -290,7 +313,15 @@ def main():
         if world != 1:
             raise SystemExit("--workload grid is a single-GPU sweep")
         return run_grid(args, device)
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    global_batch = w["B"] * world
+    if args.scaling == "strong":
+        from ttrnn_hip.dist import shard_bounds
+        global_batch = w["B"]
+        if global_batch < world:
+            raise SystemExit("--scaling strong: global batch {} < {} ranks".format(global_batch, world))
+        lo, hi = shard_bounds(global_batch, rank, world)
+        w["B"] = hi - lo                              # this rank's contiguous shard of the global batch
     from ttrnn_hip import functional as F
     model = build_model(w, device)
     torch.manual_seed(1111 + rank)
@@ -319,7 +350,7 @@ def main():
         model.train()
         torch.manual_seed(2222 + rank)
         target = torch.randint(0, n_cls, (w["B"],), device=device)
-        reducer = FlatGradAllReduce(model) if dist is not None else None
+        reducer = FlatGradAllReduce(model, force=force_dist) if dist is not None else None
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     def step():
@@ -344,7 +375,9 @@ def main():
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        timer.start("step")
         step()
+        timer.stop("step")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -352,6 +385,8 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     kern_ms = timer.mean_ms("ttrnn_rnn_forward")
+    kern_ms_median = timer.median_ms("ttrnn_rnn_forward")
+    step_ms_median = timer.median_ms("step")          # per-step device time (events on the launch stream)
     launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
 
     # fp32 workloads: which matrix arithmetic ran (include/ttrnn.h TTRNN_MATH_*) and, at N=1, the same steps again
@@ -420,25 +455,34 @@ def main():
                                           "top of that); PMC-measured counterpart: profiles/".format(rec_cycles, per_cu),
                         "note": ex["note"]}
         line = {
-            "metric": "timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}".format(
-                w["B"], "TT-LSTM" if w["kind"] == "ttlstm" else "TT-GRU", w["H"], w["d"], w["r"]),
-            "value": world * w["T"] / t_step,
+            "metric": ("timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}" if args.scaling == "weak" else
+                       "timesteps/sec of the GLOBAL batch {} sharded over the GPUs, {} h={} ncores={} rank={}").format(
+                w["B"] if args.scaling == "weak" else global_batch,
+                "TT-LSTM" if w["kind"] == "ttlstm" else "TT-GRU", w["H"], w["d"], w["r"]),
+            # weak: every GPU advances its own batch by T timesteps per step (whole job = N x T); strong: the job is ONE
+            # global batch advanced by T timesteps per step
+            "value": (world if args.scaling == "weak" else 1) * w["T"] / t_step,
             "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_median": step_ms_median,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": arith if arith == w["dtype"] else "{} ({} storage)".format(arith, w["dtype"]), "data": "synthetic",
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
-                       "global_batch": w["B"] * world, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
+                       "global_batch": global_batch, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
                                 "train step of the reference's benchmarking.py:41-70 (zero_grad + classifier forward + nll_loss "
                                 "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM"),
                        "fp32_math": FP32_MATH_DESC.get(math_mode)},
-            "sample_timesteps_per_s": world * w["B"] * w["T"] / t_step,
+            "sample_timesteps_per_s": global_batch * w["T"] / t_step,
+            "collectives": (None if dist is None else
+                            "{} process group, world {}{}: barrier + MAX all-reduce of the time{}".format(
+                                backend, world, " (forced one-rank group, TTRNN_BENCH_FORCE_DIST=1)" if force_dist and world == 1 else "",
+                                "; flat-bucket gradient all-reduce per step" if args.mode == "train" else "")),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": "ttrnn_rnn_forward (K-in batched input projection + K-rec persistent recurrent kernel)",
-                         "kernel_ms": kern_ms,
+                         "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median,
                          "basis": "algorithmic FLOPs of the reference's stage-by-stage chain (SURVEY.md 8(d)) over the "
                                   "MFMA peak of the arithmetic dtype; the fused-core / split-math kernels execute "
                                   "fewer FLOPs, on the bf16 MFMA (DESIGN.md 4a, 8)",

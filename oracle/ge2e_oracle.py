@@ -3,7 +3,7 @@
 Loop-for-loop restatement of experiments/speaker_verification/encoder/speaker_encoder.py:93-170 of the reference
 (per-speaker Python loop, torch CPU ops; EER from sklearn's roc_curve + scipy's brentq like the reference's snippet).
 Pinned by tests/golden/g9_ge2e_*.npz, which tests/golden/gen_golden_ge2e.py produced by running the reference itself.
-Imported by tests/ only; the product (examples/ge2e.py) never imports it."""
+Imported by tests/ only; the product (ttrnn_hip/ge2e.py) never imports it."""
 import numpy as np
 import torch
 

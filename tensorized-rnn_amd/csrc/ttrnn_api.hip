@@ -332,8 +332,10 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
                                (char*)workspace + in1_bwd_bytes(s), sm);
   }
   const GenDense gd = gen_dense(s);
+  // (TTRNN_MATH_EXACT: the dense gradient stays — on the fp32 MFMA — but dx, a GEMM on bf16 pieces, goes back to the chain)
+  const bool gd_split = fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16;
   if (!force_generic() && !no_gemm() && gd.ok && d_packed && dy_dtype == TTRNN_F32 && n_rows >= 4 * (int64_t)s.in_size &&
-      (!dx || (gd.dx_ok && dtype == TTRNN_F32)) && workspace && workspace_bytes >= gd.total) {
+      (!dx || (gd.dx_ok && dtype == TTRNN_F32 && gd_split)) && workspace && workspace_bytes >= gd.total) {
     hipStream_t sm = (hipStream_t)stream;
     char* p = (char*)workspace;
     void* lin_bwd = p; p += gd.lin_bwd;
@@ -345,7 +347,7 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
     void* lin_fwd = p;
     st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
     if (st == TTRNN_OK)
-      st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, true, scratch);
+      st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch);
     if (st == TTRNN_OK) {
       const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
       st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);

@@ -948,6 +948,9 @@ static int in_pad(int in) { return (in + 7) & ~7; }
 static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
+  // every product of this tier is a product of 16-bit pieces: fp32 descriptors under TTRNN_MATH_EXACT take the any-shape
+  // fp32 kernels instead (force_g2 is the A/B override the tests use)
+  if (dtype == TTRNN_F32 && opt(OPT_FP32_MATH) == TTRNN_MATH_EXACT && !opt(OPT_FORCE_G2)) return false;
   G2Plan p;
   g2_plan(&p, rs, rs.B <= device_cu_count());
   if (!(backward ? p.okb : p.okf)) return false;

@@ -32,9 +32,24 @@ class FusedCellMixin(object):
     """Adds `_operands()` / `_layer_spec()` to a cell that owns input_weights / hidden_weights."""
     kind = None      # 'lstm' | 'gru'
 
+    def _fusable(self):
+        """Can both weights be handed to the library as TT-matrices?  Decided from the weight TYPES alone (no tensors are
+        built): nn.Linear (one core), TTLinear, or a TTLinearSet whose joint matrix (one core more than a gate's) still
+        fits the library's core limit."""
+        from ttrnn_hip._lib import TTRNN_MAX_D
+        for w in (self.input_weights, self.hidden_weights):
+            if isinstance(w, nn.Linear) or hasattr(w, 'weight_t'):
+                continue
+            if hasattr(w, 'joint_cores') and len(w.gates[0].weight_t.tt_cores) + 1 <= TTRNN_MAX_D:
+                continue
+            return False
+        return True
+
     def _operands(self):
-        """(cores_in, bias_in, cores_hid, bias_hid) or None when the cell cannot be expressed as two
-        TT matrices (naive per-gate variant)."""
+        """(cores_in, bias_in, cores_hid, bias_hid), or None when the cell cannot be expressed as two TT matrices the
+        library takes (`_fusable`): such cells are stepped."""
+        if not self._fusable():
+            return None
         ops = []
         for w in (self.input_weights, self.hidden_weights):
             if isinstance(w, nn.Linear):
@@ -164,9 +179,9 @@ class FusedRnnBase(nn.Module):
                    for attr in ('input_weights', 'hidden_weights'))
 
     def _needs_stepping(self):
-        # log_grads=True stays on the fused path (per-step statistics come out of the sequence kernels); only the naive
-        # per-gate cells (TTLinearSet) are stepped
-        return any(cell._operands() is None for cell in self._all_layers)
+        # log_grads=True and the naive per-gate cells (TTLinearSet as one joint TT-matrix) stay on the fused path; only
+        # cells with foreign weight types, or a joint matrix with more cores than the library takes, are stepped
+        return any(not cell._fusable() for cell in self._all_layers)
 
     def _forward_fused(self, input, h0, c0):
         seq = input

@@ -35,7 +35,7 @@ class GRUCell(FusedCellMixin, nn.Module):
 
     def forward(self, input, hx):
         """One timestep: (x[B,in], h[B,H]) -> h'."""
-        if self._operands() is not None:
+        if self._fusable():
             (hy,) = self._fused_step(input, hx)
         else:
             H = self.hidden_size

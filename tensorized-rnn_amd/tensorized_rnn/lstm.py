@@ -39,7 +39,7 @@ class LSTMCell(FusedCellMixin, nn.Module):
 
     def forward(self, input, hx, cx):
         """One timestep: (x[B,in], h[B,H], c[B,H]) -> (h', c')."""
-        if self._operands() is not None:
+        if self._fusable():
             hy, cy = self._fused_step(input, hx, cx)
         else:
             # naive per-gate TT variant: TTLinear kernels + device-side gate arithmetic

@@ -41,8 +41,12 @@ def broadcast_parameters(module, src=0, group=None):
 class FlatGradAllReduce(object):
     """All-reduce (mean) of every gradient of `module` through one persistent flat fp32 bucket."""
 
-    def __init__(self, module, group=None):
+    def __init__(self, module, group=None, force=False):
+        """force=True (or TTRNN_FORCE_COLLECTIVES=1): run the bucket copies and the all-reduce even when the group has ONE
+        rank, so that a 1-GPU box drives the exact RCCL call sequence of the multi-GPU step (tests, bench.py)."""
+        import os
         self.group = group
+        self.force = bool(force) or os.environ.get("TTRNN_FORCE_COLLECTIVES") == "1"
         self.params = [p for p in module.parameters() if p.requires_grad]
         # nn.Module.parameters() de-duplicates shared tensors (e.g. TTLinearSet's gate{i} / gates.{i})
         self.sizes = [p.numel() for p in self.params]
@@ -74,7 +78,7 @@ class FlatGradAllReduce(object):
     def sync(self):
         """Call after backward(): grads become the mean over ranks.  Missing grads count as zero.  Two multi-tensor
         copies (torch._foreach_copy_: one launch each, whatever the number of parameters) around ONE all-reduce."""
-        if self.world == 1:
+        if self.world == 1 and not (self.force and dist.is_initialized()):
             return
         views, grads = self._views()
         torch._foreach_copy_(views, grads)

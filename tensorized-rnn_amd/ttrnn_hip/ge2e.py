@@ -70,15 +70,19 @@ class _GatherSpeakers(torch.autograd.Function):
         return grad[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous() * ctx.world, None
 
 
-def ge2e_loss_data_parallel(local_embeds, weight, bias, group=None, with_eer=False):
+def ge2e_loss_data_parallel(local_embeds, weight, bias, group=None, with_eer=False, force_gather=False):
     """Every rank holds [S_local, U, D] embeddings of its own speakers.  The similarity matrix needs all centroids: one
     all-gather (cfg4: 512 x 256 floats), then each rank evaluates the FULL loss (identical on every rank, returned
     unscaled) and back-propagates into its slice.  After the gradient all-reduce (MEAN) of the data-parallel step
     (ttrnn_hip.dist.FlatGradAllReduce) every parameter holds its single-device gradient: the slice gradient is scaled by
     the world size in _GatherSpeakers.backward, the replicated similarity weight / bias are left alone.
     (The reference computes the loss on one CPU, main.py:280.)"""
+    import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return ge2e_loss(local_embeds, weight, bias, None, with_eer)
+    # force_gather / TTRNN_FORCE_COLLECTIVES=1: take the all-gather even in a one-rank group (drives RCCL on a 1-GPU box)
+    if dist.get_world_size(group) == 1 and not (force_gather or os.environ.get("TTRNN_FORCE_COLLECTIVES") == "1"):
         return ge2e_loss(local_embeds, weight, bias, None, with_eer)
     full = _GatherSpeakers.apply(local_embeds, group)
     return ge2e_loss(full, weight, bias, None, with_eer)

@@ -124,3 +124,61 @@ def test_bench_two_ranks_on_one_device(mode):
     assert abs(rec["value"] - 2 * 784 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]      # whole-job aggregate
     assert rec["config"]["global_batch"] == 128 and "cpu_baseline" not in rec
     assert rec["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_one_rank_group_drives_every_collective():
+    """RCCL itself, on the one GPU of the box: a world_size-1 `nccl` process group through which the parameter broadcast,
+    the flat-bucket gradient all-reduce (forced past its one-rank early-out), the GE2E all-gather and a barrier run on
+    device tensors (tests/_rccl_one_rank.py, a fresh process).  Says nothing about scaling; it makes the first multi-GPU run
+    not be the first RCCL run."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=540, env=env, cwd=ROOT)
+    assert res.returncode == 0 and "RCCL_ONE_RANK_OK" in res.stdout, (res.stdout[-2000:], res.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["forward", "train"])
+def test_bench_distributed_branch_on_rccl_with_one_rank(mode):
+    """`bench.py --gpus 1` with TTRNN_BENCH_FORCE_DIST=1: the code path of `--gpus N` (process group on the nccl backend with
+    device_id, barriers, MAX all-reduce of the elapsed time, the flat-bucket gradient all-reduce of the train step) on RCCL
+    with one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, TTRNN_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29900 + os.getpid() % 90 + (5 if mode == "train" else 0)))
+    env.pop("TTRNN_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--mode", mode,
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=800, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["collectives"].startswith("nccl process group, world 1")
+    assert ("gradient all-reduce" in rec["collectives"]) == (mode == "train")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_two_ranks_on_one_device():
+    """`--scaling strong`: the configuration's batch is the GLOBAL batch; two ranks (gloo, sharing cuda:0)
+    take 32 of cfg2's 64 samples each, and `value` counts the global batch's timesteps once."""
+    import json
+    import subprocess
+    env = dict(os.environ, TTRNN_BENCH_SINGLE_DEVICE="1", TTRNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--scaling", "strong"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=800, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["per_gpu_batch"] == 32
+    assert abs(rec["value"] - 784 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
+    assert abs(rec["sample_timesteps_per_s"] - 64 * rec["value"]) <= 1e-6 * rec["sample_timesteps_per_s"]
