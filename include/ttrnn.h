@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 2
+#define TTRNN_ABI_VERSION 3
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {
@@ -82,6 +82,20 @@ const char* ttrnn_status_string(int status);
 /* 1 when a usable HIP device is visible to this process, else 0 (never launches). */
 int ttrnn_device_available(void);
 
+/* Device-side event counters.  No call above synchronises, so a kernel cannot hand a status back through its launch; the two
+ * events a caller must be able to see are counted on the device instead and read HERE (this call synchronises the device):
+ *   counters[TTRNN_STAT_PAIR_TIMEOUTS]  threads of the two-workgroups-per-sample kernels (H = 1024 class, 2B <= #CUs) that gave
+ *                                       up waiting for their partner workgroup (~0.1 s: the partner was not resident — CUs held
+ *                                       by another stream or process).  The affected samples' outputs are NaN by construction.
+ *   counters[TTRNN_STAT_GUARD_TRIPS]    launches that left the two-piece fp16 kernel for the fp32-MFMA one because a few large
+ *                                       entries had pushed the bulk of a weight operand into fp16's subnormal range.
+ * n = number of counters wanted (<= TTRNN_STAT_COUNT); reset != 0 zeroes them after reading.  The reference has no
+ * counterpart (its failures are Python exceptions, lstm.py / ops.py raise nothing on this path). */
+#define TTRNN_STAT_PAIR_TIMEOUTS 0
+#define TTRNN_STAT_GUARD_TRIPS 1
+#define TTRNN_STAT_COUNT 4
+int ttrnn_device_status(unsigned int* counters, int n, int reset);
+
 /* How fp32 tensors are multiplied inside the shape-specialised recurrent kernels (process-wide; the analogue of
  * torch.backends.*.matmul precision switches — the reference itself has none, its fp32 GEMMs are whatever the
  * BLAS under torch.einsum does, t3nsor/ops.py:85-91):
@@ -114,7 +128,7 @@ int ttrnn_get_fp32_math(void);
  *   "fp32_math" (TTRNN_MATH_*), "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag",
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
- *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma".
+ *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
 int ttrnn_set_option(const char* name, int value);

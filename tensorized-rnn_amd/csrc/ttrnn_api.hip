@@ -25,7 +25,7 @@ struct OptTable {
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
         "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES",
-        "TTRNN_BIG_FP32_MFMA"};
+        "TTRNN_BIG_FP32_MFMA", "TTRNN_PAIR_FAULT"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
@@ -43,7 +43,8 @@ OptTable& table() {
 }
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
-    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces", "big_fp32_mfma"};
+    "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces", "big_fp32_mfma",
+    "pair_fault"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }
@@ -72,6 +73,22 @@ int opt_get(const char* name, int* value) {
 }  // namespace ttrnn
 
 namespace ttrnn {
+// event counters of ttrnn_device_status: a zero-initialised device global per device (no allocation, no launch)
+__device__ unsigned g_ttrnn_status[TTRNN_STAT_COUNT];
+unsigned* device_status_ptr() {
+  static std::mutex mu;
+  static unsigned* cached[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cached[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ttrnn_status)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    cached[dev] = (unsigned*)p;
+  }
+  return cached[dev];
+}
+
 int ensure_dynamic_lds(const void* fn, size_t bytes) {
   // (small threshold only: a kernel's static __shared__ arrays count against the default 64 KB as well; the limit is set
   // to exactly what the launch asks for — a blanket 160 KB is refused for kernels that also have static LDS)
@@ -93,6 +110,29 @@ int ensure_dynamic_lds(const void* fn, size_t bytes) {
   if (hit) hit->bytes = bytes;
   else done.push_back(Entry{dev, fn, bytes});
   return TTRNN_OK;
+}
+bool resident_at_once(const void* fn, int block_threads, size_t dyn_lds, long blocks) {
+  struct Entry { int dev; const void* fn; size_t lds; int per_cu; };
+  static std::mutex mu;
+  static std::vector<Entry> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  int per_cu = -1;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : seen)
+      if (e.dev == dev && e.fn == fn && e.lds == dyn_lds) { per_cu = e.per_cu; break; }
+    if (per_cu < 0) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, block_threads, dyn_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+      }
+      per_cu = n;
+      seen.push_back(Entry{dev, fn, dyn_lds, per_cu});
+    }
+  }
+  return (long)per_cu * device_cu_count() >= blocks;
 }
 }  // namespace ttrnn
 
@@ -121,6 +161,17 @@ const char* ttrnn_status_string(int status) {
     case TTRNN_ERR_LAUNCH: return "HIP launch failed";
     default: return "unknown status";
   }
+}
+
+int ttrnn_device_status(unsigned int* counters, int n, int reset) {
+  if (!counters || n < 1) return TTRNN_ERR_NULL;
+  unsigned* p = device_status_ptr();
+  if (!p) return TTRNN_ERR_LAUNCH;
+  unsigned host[TTRNN_STAT_COUNT] = {0};
+  if (hipMemcpy(host, p, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return TTRNN_ERR_LAUNCH; }
+  for (int i = 0; i < n; ++i) counters[i] = i < TTRNN_STAT_COUNT ? host[i] : 0u;
+  if (reset && hipMemset(p, 0, sizeof(host)) != hipSuccess) { (void)hipGetLastError(); return TTRNN_ERR_LAUNCH; }
+  return TTRNN_OK;
 }
 
 int ttrnn_device_available(void) {
@@ -400,7 +451,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   // K-in as a dense split-bf16 GEMM (ttrnn_fast_gemm.hip): identity rows, dense W_in, its bf16 planes
   if (f.f10_lin_bytes > 0 && rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 && gemm_split_ok(rs.in, 4 * rs.H))
     f.gemm_bytes = gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) +
-                   gemm_split_plane_bytes(rs.in, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
+                   gemm_split_plane_bytes(rs.in, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
   return f;
 }
 

@@ -102,6 +102,17 @@ constexpr int merged_elems() {
 __device__ __forceinline__ float round_like(const float*, float v) { return v; }
 __device__ __forceinline__ float round_like(const bf16_t*, float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
+// Guard of the kernels that carry a whole operand matrix under ONE power-of-two scale (the cfg5-class reverse-time kernel):
+// rows[0..n) = per matrix row the summed absolute representation error of the two fp16 pieces, rows[n..2n) = the summed
+// absolute scaled entries (k_bigbh_prep).  Normal pieces carry a relative error <= 2^-22 per entry; a row whose error sum
+// exceeds 2^-20 of its magnitude sum has its bulk in fp16's subnormal range (a few entries 2^16 and more above the rest of
+// the matrix), and the launch must not run on these pieces.  Every thread of the workgroup calls this (barrier inside).
+__device__ __forceinline__ bool big_guard_tripped(const float* __restrict__ rows, int n, int tid, int nthreads) {
+  int bad = 0;
+  for (int i = tid; i < n; i += nthreads) bad |= rows[i] > 9.5367431640625e-07f * rows[n + i] ? 1 : 0;
+  return __syncthreads_or(bad) != 0;
+}
+
 __device__ __forceinline__ float bsigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

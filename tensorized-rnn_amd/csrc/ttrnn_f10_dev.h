@@ -89,19 +89,23 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __b
 }
 
 // ---- the same step on two-piece fp16 operands (ttrnn_split.h): LSTM forward kernels ---------------------------------
-// Scales (powers of two, exact) derived from the maxima k_f10h_scale leaves at the start of the fragment workspace:
-//   2^a   core 2 (S2's constant operand)      max |G2| 2^a  <= 2^6
-//   2^sH  h (S2's dynamic operand)            |h| 2^sH  <= 2^6       (|h_t| < 1; a caller's h_0: f10h_h0_expo, per sample)
-//   2^sw  the fused core W10                  max |W10| 2^sw <= 2^12 (bound R1 max|G0| max|G1|)
-//   2^S, 2^-S with S = a + sH + sw: accumulators of S10 are 2^S times the pre-activations
-// so that |T| 2^(a+sH) <= J2 2^12 = 2^15 stays inside fp16 and the second pieces stay normal over >= 9 binades below each
-// operand's maximum (smaller entries keep an ABSOLUTE error of 2^-31 of the maximum or better).
-static constexpr int F10H_HDR_BYTES = 256;
-// The header holds F10H_PARTS partial maxima per quantity ([part][4]: |core 0|, |core 1|, |core 2|, |h_0|), one per
-// workgroup of k_f10h_scale (the h_0 column is always 0 now: f10h_h0_expo); every consumer reduces them itself — 16 loads — instead of
-// waiting for one more dependent launch to do it.
-static constexpr int F10H_PARTS = 16;
-struct F10hScales { float g2, h, w, pre, un; };
+// Scales: powers of two (exact), TWO-SIDED DIAGONAL — one exponent per output mode index i2 and per rank index r2 of core 2,
+// one per row of the fused core — so that a single large entry of a core moves only the scale of its own row / column and
+// every other entry keeps its 22 bits (round 2 had one scale per operand: one entry x 1e5 cost all the others 5-12 bits):
+//   core 2 (S2's constant operand)   G2'[r2,i2,j2] = G2 2^(6 + eu[i2] + ev[r2])      max over each i2 and each r2 slice < 2^6
+//   h (S2's dynamic operand)         h' = 2^6 h                                        (|h_t| < 1; a caller's h_0: f10h_h0_expo)
+//   S2's result = the S10 operand    X'[(j0,j1,r2)][i2] < J2 2^12 = 2^15: inside fp16
+//   the fused core                   W10'[m][(j0,j1,r2)] = W10 2^(ep[m] - ev[r2]) x gate factor   max over each row < 2^13.6
+//   accumulators of S10              acc[m][i2] = 2^(ep[m] + eu[i2] + 12) x gate factor x pre-activation
+// eu, ev, ep are computed once per launch by k_f10h_scale from the cores themselves (eu from the maxima of core 2 over
+// (r2, j2), ev from the maxima of 2^eu G2 over (i2, j2), ep from the row maxima of 2^-ev W10) and sit as int32 at the start of
+// the fragment workspace: [eu: 16][ev: 16][ep: 64].  Second pieces stay normal over >= 9 binades below each row's / slice's
+// maximum; smaller entries keep an ABSOLUTE error of 2^-31 of THAT maximum or better.
+static constexpr int F10H_HDR_BYTES = 512;
+static constexpr int F10H_PARTS = 16;          // workgroups of k_f10h_scale (4 rows of the fused core each)
+static constexpr int F10H_EU = 0, F10H_EV = 16, F10H_EP = 32;
+static constexpr float F10H_HSC = 64.0f;       // 2^6: the scale of h
+struct F10hScales { f32x4 pre, un; };          // per lane: 2^(ep[m_j] + eu[c] + 12) for the lane's four rows m_j, and the inverse
 __device__ __forceinline__ int f10h_expo(float x) {
   // x < 2^e (frexp: x = f 2^e, f in [0.5, 1)); zero / non-finite maxima fall back to a neutral exponent
   if (!(x > 0.f)) return 0;
@@ -110,27 +114,32 @@ __device__ __forceinline__ int f10h_expo(float x) {
   frexpf(x, &e);
   return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
+// lane (c, q) of S10 feature tile `tile`: accumulator register j is row m_j = MPG j + 4 tile + q (gate j), column i2 = c
 template <class S>
-__device__ __forceinline__ F10hScales f10h_scales(const float* __restrict__ hdr) {
-  float m[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < F10H_PARTS; ++i) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(hdr + 4 * i);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
-  }
-  const int eg = f10h_expo(m[2]);
-  int eh = f10h_expo(m[3]);
-  if (eh < 0) eh = 0;                                              // |h_t| < 1 for every t >= 1
-  const int ew = f10h_expo((float)F10<S>::R1 * m[0] * m[1]);
-  const int a = 6 - eg, sh = 6 - eh, sw = 12 - ew;
+__device__ __forceinline__ F10hScales f10h_scales(const float* __restrict__ hdr, int tile, int lane) {
+  using F = F10<S>;
+  const int* e = reinterpret_cast<const int*>(hdr);
+  const int c = lane & 15, q = lane >> 4;
+  const int eu = e[F10H_EU + (c < F::I2 ? c : F::I2 - 1)];
   F10hScales r;
-  r.g2 = ldexpf(1.f, a);
-  r.h = ldexpf(1.f, sh);
-  r.w = ldexpf(1.f, sw);
-  r.pre = ldexpf(1.f, a + sh + sw);
-  r.un = ldexpf(1.f, -(a + sh + sw));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = e[F10H_EP + F::MPG * j + 4 * tile + q] + eu + 12;
+    r.pre[j] = ldexpf(1.f, s);
+    r.un[j] = ldexpf(1.f, -s);
+  }
   return r;
+}
+// scale of row m2 = i2 R2 + r2 of core 2 / of entry (m, r2) of the fused core
+template <class S>
+__device__ __forceinline__ float f10h_g2_scale(const float* __restrict__ hdr, int m2) {
+  const int* e = reinterpret_cast<const int*>(hdr);
+  return ldexpf(1.f, 6 + e[F10H_EU + m2 / F10<S>::R2] + e[F10H_EV + m2 % F10<S>::R2]);
+}
+template <class S>
+__device__ __forceinline__ float f10h_w_scale(const float* __restrict__ hdr, int m, int r2) {
+  const int* e = reinterpret_cast<const int*>(hdr);
+  return ldexpf(1.f, e[F10H_EP + m] - e[F10H_EV + r2]);
 }
 
 template <class S, int KS>
@@ -163,10 +172,11 @@ __device__ __forceinline__ int f10h_h0_expo(float hmine, float* scratch, int wav
 // term-packed fragment of core 2 for m-tile mt: k-groups w0 | w1 | w0 | w1 against activation groups x0 | x0 | x1 | x1:
 // ONE MFMA = x0 w0 + x0 w1 + x1 w0 + x1 w1
 template <class S>
-__device__ __forceinline__ void f10h_load_w2(xh8& a1, const float* packed, int mt, int lane, float g2scale) {
+__device__ __forceinline__ void f10h_load_w2(xh8& a1, const float* packed, int mt, int lane, const float* __restrict__ hdr) {
   using F = F10<S>;
   const int r = lane & 15, q = lane >> 4;
   const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
+  const float g2scale = f10h_g2_scale<S>(hdr, 16 * mt + r);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     _Float16 p0, p1;

@@ -372,7 +372,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
                                                            const TS* __restrict__ bias_hid, TS* __restrict__ out,
                                                            TS* __restrict__ hT, TS* __restrict__ cT,
                                                            float* __restrict__ reserve,
-                                                           unsigned long long* __restrict__ hx) {
+                                                           unsigned long long* __restrict__ hx,
+                                                           unsigned* __restrict__ status) {
   static_assert(S::D == 2 && big_frag_order<S>(), "two-core matrices in fragment order");
   using T1 = St<S, 1>;
   using T0 = St<S, 0>;
@@ -508,12 +509,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
       // one time-out (~0.1 s) stop waiting for the rest of the launch.  The launch cannot report that through its status
       // (no synchronisation inside the API), so the time-out POISONS the state instead: the missing half of h becomes
       // NaN, which reaches every gate of this sample at the next step and from there `out`, hT and cT — a timed-out
-      // launch can never look like a result.
+      // launch can never look like a result — and it is COUNTED on the device (TTRNN_STAT_PAIR_TIMEOUTS, read by
+      // ttrnn_device_status).
       long spin = 0;
       while (!dead && (unsigned)(v >> 32) != (unsigned)(t + 1)) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spin > (1L << 21)) dead = true;
+        if (++spin > (1L << 21)) { dead = true; if (status) atomicAdd(status + TTRNN_STAT_PAIR_TIMEOUTS, 1u); }
       }
       hbuf[a_off<T1::KP>(hidp / T1::K, hidp % T1::K)] = dead ? __uint_as_float(0x7FC00000u) : __uint_as_float((unsigned)v);
     }
@@ -538,7 +540,7 @@ static int big_merge_level() { return opt(OPT_BIG_MERGE); }
 
 static size_t big_gemm_bytes(const RnnShape& rs) {
   return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H) +
-         gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
+         gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
 }
 
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {
@@ -636,12 +638,22 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
                          (const TS*)x, gin, slab, 2);
       if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
     }
-    if (2 * rs.B <= cus && !opt(OPT_BIG_NO_PAIR)) {      // OPT_BIG_NO_PAIR: A/B switch, one workgroup per sample
+    // two workgroups per sample need all 2B workgroups resident at once: CU count AND the occupancy the runtime reports for
+    // the kernel that would run (one 512-thread workgroup with > 100 KB of LDS per CU); OPT_BIG_NO_PAIR: A/B switch
+    const bool halfk = opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA);
+    constexpr size_t lds_img2 = (size_t)(St<S2, 0>::ROWS / 2) * St<S2, 0>::KP * sizeof(float);
+    constexpr size_t lds_pair2 = lds_img2 > 100 * 1024 ? lds_img2 : 100 * 1024;
+    const bool pair_fits =
+        2 * rs.B <= cus && !opt(OPT_BIG_NO_PAIR) &&
+        (halfk ? bigh_pair_resident(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, rs.B)
+               : (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>), lds_pair2) == TTRNN_OK &&
+                  resident_at_once(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>), FAST_NT, lds_pair2, 2L * rs.B)));
+    if (pair_fits) {
       // two workgroups per sample: tagged h exchange words [B][2][H] behind the merged cores (tag 0 = never written)
       unsigned long long* hxb = (unsigned long long*)(tail + 2 * (b3 + b2));
       if (hipMemsetAsync(hxb, 0, pair_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
       // split mode: both stages on two-piece fp16 operands (ttrnn_fast_bigh.hip); OPT_BIG_FP32_MFMA: A/B switch
-      if (opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA))
+      if (halfk)
         return launch_lstm_fwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, gin, h0, c0, m2_hid, bin, bhid, out, hT,
                                      cT, reserve, hxb, tail + 2 * (b3 + b2) + pair_bytes + big_gemm_bytes(rs), stream);
       // the image needs 64 KB; asking for 100 KB keeps a second workgroup off the CU (76 KB each would fit twice, and
@@ -652,8 +664,11 @@ static int launch_big_t(const RnnShape& rs, const void* x, const void* h0, const
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2<S2, TS>), lds_pair) != TTRNN_OK)
           return TTRNN_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL((k_lstm_fwd_big2<S2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
-                         (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb);
+      // (OPT_PAIR_FAULT, tests only: the last workgroup is not launched — its partner must time out, poison its sample
+      // with NaN and count the event)
+      hipLaunchKernelGGL((k_lstm_fwd_big2<S2, TS>), dim3(2 * rs.B - (opt(OPT_PAIR_FAULT) ? 1 : 0)), dim3(FAST_NT), lds_pair,
+                         stream, rs.B, rs.T, gin, (const TS*)h0, (const TS*)c0, m2_hid, bin, bhid, (TS*)out, (TS*)hT,
+                         (TS*)cT, reserve, hxb, device_status_ptr());
       return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((k_rnn_fwd_big<S2, TTRNN_LSTM, TS>), dim3(rs.B), dim3(FAST_NT), lds_rec, stream, rs.B, rs.T,

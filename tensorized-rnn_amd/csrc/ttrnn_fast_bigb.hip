@@ -215,10 +215,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
                                                           const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                           const TS* __restrict__ d_cT, float* __restrict__ dg_in,
                                                           TS* __restrict__ d_h0, TS* __restrict__ d_c0,
-                                                          unsigned long long* __restrict__ hx) {
+                                                          unsigned long long* __restrict__ hx,
+                                                          const float* __restrict__ guard, int guard_rows,
+                                                          unsigned* __restrict__ status) {
   using T1 = St<ST, 1>;
   using T0 = St<ST, 0>;
   constexpr int H = out_size_of<ST>(), GH = in_size_of<ST>();
+  // queued behind the two-piece fp16 kernel as its fallback (guard != NULL): runs only when that kernel stepped aside
+  if (guard && !big_guard_tripped(guard, guard_rows, threadIdx.x, FAST_NT)) return;
   constexpr int I23 = T1::ROWS;               // 64
   constexpr int RL = I23 / NH;                // i23 values (rows of T0) of this workgroup
   constexpr int NUT = 2 / NH;                 // hidden units per thread
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       while (!dead && (unsigned)(v >> 32) != (unsigned)(n + 1)) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spin > (1L << 21)) dead = true;
+        if (++spin > (1L << 21)) { dead = true; if (status) atomicAdd(status + TTRNN_STAT_PAIR_TIMEOUTS, 1u); }
       }
       dhrec[0] = dead ? __uint_as_float(0x7FC00000u) : own + __uint_as_float((unsigned)v);
     }
@@ -737,15 +741,29 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
                      packed_hid, m3);
   hipLaunchKernelGGL((k_bigb_prep<S3, ST>), dim3((int)(BT / sizeof(float) + 255) / 256), dim3(256), 0, stream, m3, mT);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-  const bool pair = 2 * rs.B <= device_cus() && !opt(OPT_BIG_NO_PAIR);      // A/B switch: one workgroup per sample
+  // two workgroups per sample: CU count and the runtime's occupancy for both kernels that may run (the fp16 one and its
+  // fp32-MFMA fallback); OPT_BIG_NO_PAIR: A/B switch, one workgroup per sample
+  const bool halfk = opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA);
+  constexpr size_t lds_p32 = bigb_lds_bytes<ST, 2>() > 100 * 1024 ? bigb_lds_bytes<ST, 2>() : 100 * 1024;
+  const bool pair = 2 * rs.B <= device_cus() && !opt(OPT_BIG_NO_PAIR) &&
+                    (!halfk || bigbh_pair_resident(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, rs.B)) &&
+                    ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 2, TS>), lds_p32) == TTRNN_OK &&
+                    resident_at_once(reinterpret_cast<const void*>(k_lstm_bwd_big<ST, 2, TS>), FAST_NT, lds_p32, 2L * rs.B);
   if (pair) {
     if (hipMemsetAsync(hxb, 0, (size_t)rs.B * 2 * rs.H * sizeof(unsigned long long), stream) != hipSuccess)
       return TTRNN_ERR_LAUNCH;
     // split mode: both stages on two-piece fp16 operands (ttrnn_fast_bigbh.hip); OPT_BIG_FP32_MFMA: A/B switch
-    if (opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_BIG_FP32_MFMA))
-      return launch_lstm_bwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, c0, mT, reserve, d_out, d_hT, d_cT, dg_in,
-                                   d_h0, d_c0, hxb,
-                                   (char*)hxb + al256((size_t)rs.B * 2 * rs.H * sizeof(unsigned long long)), stream);
+    const float* guard = nullptr;
+    int guard_rows = 0;
+    if (halfk) {
+      void* scr = (char*)hxb + al256((size_t)rs.B * 2 * rs.H * sizeof(unsigned long long));
+      const int sh = launch_lstm_bwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, c0, mT, reserve, d_out, d_hT, d_cT,
+                                           dg_in, d_h0, d_c0, hxb, scr, stream);
+      if (sh != TTRNN_OK) return sh;
+      // ... followed by the fp32-MFMA pair kernel as its fallback: exactly one of the two runs (big_guard_tripped, decided on
+      // the device from the representation error of the fp16 pieces; the other returns at once, a few microseconds)
+      guard = bigbh_guard_rows(scr, &guard_rows);
+    }
     // 64 KB image; 100 KB requested so that a second workgroup cannot share the CU (see the forward pair kernel)
     constexpr size_t lds = bigb_lds_bytes<ST, 2>() > 100 * 1024 ? bigb_lds_bytes<ST, 2>() : 100 * 1024;
     {
@@ -754,7 +772,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T,
                        (const TS*)c0, mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in,
-                       (TS*)d_h0, (TS*)d_c0, hxb);
+                       (TS*)d_h0, (TS*)d_c0, hxb, guard, guard_rows, device_status_ptr());
   } else {
     constexpr size_t lds = bigb_lds_bytes<ST, 1>();
     {
@@ -763,7 +781,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 1, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0,
                        mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0,
-                       hxb);
+                       hxb, (const float*)nullptr, 0, device_status_ptr());
   }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }

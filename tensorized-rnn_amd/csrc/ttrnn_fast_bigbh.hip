@@ -33,6 +33,10 @@ using T0 = St<ST, 0>;      // T1 of the chain: rows j01 (16), K = (i23, r) (2048
 constexpr int BB_H = 1024, BB_I23 = 64, BB_RL = 32, BB_K0L = 1024, BB_R = 32;
 constexpr int BB_PL = 16 * BB_K0L;             // halfs per plane of T1's image [16 rows j01][1024 k']
 constexpr int BB_PARTS = 32;
+// scratch header: [2][BB_PARTS] partial maxima, then per ROW of the two operand matrices (512 rows of A^T, 64 of Bm) the sum
+// of the pieces' absolute representation errors and the sum of the absolute scaled entries (big_guard_tripped)
+constexpr int BB_ROWS = 512 + 64, BB_HDR_BYTES = 8192, BB_GUARD_OFF = 2 * BB_PARTS;
+static_assert((BB_GUARD_OFF + 2 * BB_ROWS) * sizeof(float) <= BB_HDR_BYTES, "header");
 constexpr int BB_FA = 8 * 4 * 2 * 2 * 64;      // fa[wave][x][kb][piece][lane]
 constexpr int BB_FB = 2 * 8 * 16 * 2 * 64;     // fb[half][wave][kbl][piece][lane]
 constexpr int BB_RES = 12;                     // k-blocks of a wave's Bm slice resident in registers (the other 4: LDS)
@@ -62,6 +66,10 @@ __device__ __forceinline__ BbScales bb_scales(const float* __restrict__ parts, i
 
 __global__ void __launch_bounds__(256) k_bigbh_absmax(const float* __restrict__ fragT, float* __restrict__ parts) {
   __shared__ float red[4];
+  {                                              // zero the guard's row sums (k_bigbh_prep accumulates into them)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * BB_ROWS) parts[BB_GUARD_OFF + i] = 0.f;
+  }
   constexpr int N0 = T0::K * T0::M, N1 = T1::K * T1::M;
   const int which = blockIdx.x / BB_PARTS, part = blockIdx.x % BB_PARTS;
   const float* a = fragT + woff_of<ST>(which);
@@ -78,11 +86,13 @@ __global__ void __launch_bounds__(256) k_bigbh_absmax(const float* __restrict__ 
 // fa: m-tile mt = wave + 8 x of A^T, row r <-> m = (j01, r') = 16 mt + r, k = i01 = 32 kb + 8 q + i
 // fb: wave = (mt = wave & 3, kh = wave >> 2): row r <-> j23 = 16 mt + r, k' = 32 (16 kh + kbl) + 8 q + i of the workgroup's
 //     half, k' = (r' / 4) * 128 + i23l * 4 + r' % 4  <->  kk = (half * 32 + i23l) * 32 + r'
-__global__ void __launch_bounds__(256) k_bigbh_prep(const float* __restrict__ fragT, const float* __restrict__ parts,
+__global__ void __launch_bounds__(256) k_bigbh_prep(const float* __restrict__ fragT, float* __restrict__ parts,
                                                     xh8* __restrict__ fa, xh8* __restrict__ fb) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int lane = e & 63, r = lane & 15, q = lane >> 4;
   const BbScales sc = bb_scales(parts, threadIdx.x & 63);
+  float* gerr = parts + BB_GUARD_OFF;            // [BB_ROWS] error sums, then [BB_ROWS] magnitude sums
+  float esum = 0.f, asum = 0.f;
   xh8 p0, p1;
   if (e < BB_FA / 2) {
     const int kb = (e >> 6) & 1, x = (e >> 7) & 3, wave = e >> 9;
@@ -91,9 +101,14 @@ __global__ void __launch_bounds__(256) k_bigbh_prep(const float* __restrict__ fr
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       _Float16 u, v;
-      split2h(W[fragT_index<1>(32 * kb + 8 * q + i, m)] * sc.a, u, v);
+      const float w = W[fragT_index<1>(32 * kb + 8 * q + i, m)] * sc.a;
+      split2h(w, u, v);
       p0[i] = u; p1[i] = v;
+      esum += fabsf((w - (float)u) - (float)v);
+      asum += fabsf(w);
     }
+    atomicAdd(gerr + m, esum);
+    atomicAdd(gerr + BB_ROWS + m, asum);
     const size_t o = (size_t)(e >> 6) * 2 * 64 + lane;
     fa[o] = p0;
     fa[o + 64] = p1;
@@ -107,9 +122,14 @@ __global__ void __launch_bounds__(256) k_bigbh_prep(const float* __restrict__ fr
       const int kp = 32 * (16 * kh + kbl) + 8 * q + i;
       const int i23l = (kp & 127) >> 2, rr = (kp >> 7) * 4 + (kp & 3);
       _Float16 u, v;
-      split2h(W[fragT_index<0>((half * BB_RL + i23l) * BB_R + rr, 16 * mt + r)] * sc.b, u, v);
+      const float w = W[fragT_index<0>((half * BB_RL + i23l) * BB_R + rr, 16 * mt + r)] * sc.b;
+      split2h(w, u, v);
       p0[i] = u; p1[i] = v;
+      esum += fabsf((w - (float)u) - (float)v);
+      asum += fabsf(w);
     }
+    atomicAdd(gerr + 512 + 16 * mt + r, esum);
+    atomicAdd(gerr + BB_ROWS + 512 + 16 * mt + r, asum);
     const size_t o = (size_t)(g >> 6) * 2 * 64 + lane;
     fb[o] = p0;
     fb[o + 64] = p1;
@@ -124,7 +144,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
                                                             const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                             const TS* __restrict__ d_cT, float* __restrict__ dg_in,
                                                             TS* __restrict__ d_h0, TS* __restrict__ d_c0,
-                                                            unsigned long long* __restrict__ hx) {
+                                                            unsigned long long* __restrict__ hx,
+                                                            unsigned* __restrict__ status) {
   constexpr int H = BB_H, GH = 4 * BB_H, I23 = BB_I23, RL = BB_RL;
   __shared__ __attribute__((aligned(16))) float dyimg[RL * T1::K];      // gate gradients [i23 local][i01], fp32
   __shared__ __attribute__((aligned(16))) float dhp[2 * T0::M * 16];    // partial dh [k half][j23][j01]
@@ -140,6 +161,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
   const size_t b = blockIdx.x >> 1;
   const int half = blockIdx.x & 1;
   const BbScales sc = bb_scales(parts, lane);
+  // One scale per operand matrix (taken from its maximum): if a row's fp16 pieces lost more than fp32-class accuracy — a few
+  // large entries pushed the rest of the matrix into fp16's subnormal range — this launch is left to the fp32-MFMA pair
+  // kernel queued right behind it (ttrnn_fast_bigb.hip), which takes the opposite decision from the same sums
+  if (big_guard_tripped(parts + BB_GUARD_OFF, BB_ROWS, tid, FAST_NT)) {
+    if (tid == 0 && blockIdx.x == 0 && status) atomicAdd(status + TTRNN_STAT_GUARD_TRIPS, 1u);
+    return;
+  }
 
   // this thread's unit: hid = mq*64 + i23, i23 = half*RL + rl  (gate g of it is row i01 = 16g + mq of dg)
   const int rl = tid & 31, mq = tid >> 5;
@@ -317,7 +345,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
       while (!dead && (unsigned)(v >> 32) != (unsigned)(n + 1)) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spin > (1L << 21)) dead = true;
+        if (++spin > (1L << 21)) { dead = true; if (status) atomicAdd(status + TTRNN_STAT_PAIR_TIMEOUTS, 1u); }
       }
       dhrec = dead ? __uint_as_float(0x7FC00000u) : own + __uint_as_float((unsigned)v);
     }
@@ -330,23 +358,34 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
 
 }  // namespace
 
-size_t bigbh_workspace_bytes() { return (size_t)(BB_FA + BB_FB) * sizeof(xh8) + 256; }
+static constexpr size_t BB_LDS_PAIR = 2 * BB_PL * sizeof(_Float16) + (size_t)8 * (16 - BB_RES) * 2 * 64 * sizeof(xh8);
+bool bigbh_pair_resident(int dtype, int B) {
+  const void* fn = dtype == TTRNN_F32 ? reinterpret_cast<const void*>(k_lstm_bwd_big2h<float>)
+                                      : reinterpret_cast<const void*>(k_lstm_bwd_big2h<bf16_t>);
+  return ensure_dynamic_lds(fn, BB_LDS_PAIR) == TTRNN_OK && resident_at_once(fn, FAST_NT, BB_LDS_PAIR, 2L * B);
+}
+size_t bigbh_workspace_bytes() { return (size_t)(BB_FA + BB_FB) * sizeof(xh8) + BB_HDR_BYTES; }
+const float* bigbh_guard_rows(const void* scratch, int* n_rows) {
+  *n_rows = BB_ROWS;
+  return (const float*)scratch + BB_GUARD_OFF;
+}
 
 template <typename TS>
 static int launch_bigbh_t(const RnnShape& rs, const void* c0, const float* fragT, const float* reserve, const void* d_out,
                           const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
                           unsigned long long* hxb, void* scratch, hipStream_t stream) {
   float* parts = (float*)scratch;
-  xh8* fa = (xh8*)((char*)scratch + 256);
+  xh8* fa = (xh8*)((char*)scratch + BB_HDR_BYTES);
   xh8* fb = fa + BB_FA;
   hipLaunchKernelGGL(k_bigbh_absmax, dim3(2 * BB_PARTS), dim3(256), 0, stream, fragT, parts);
   hipLaunchKernelGGL(k_bigbh_prep, dim3((BB_FA / 2 + BB_FB / 2 + 255) / 256), dim3(256), 0, stream, fragT, parts, fa, fb);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   // T1's image (64 KB) + the LDS-resident quarter of Bm's fragments (64 KB): one workgroup per CU
-  constexpr size_t lds = 2 * BB_PL * sizeof(_Float16) + (size_t)8 * (16 - BB_RES) * 2 * 64 * sizeof(xh8);
+  constexpr size_t lds = BB_LDS_PAIR;
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_big2h<TS>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL((k_lstm_bwd_big2h<TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0, fa, fb,
-                     parts, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0, hxb);
+                     parts, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0, hxb,
+                     device_status_ptr());
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

@@ -37,7 +37,6 @@ using T0 = St<S2, 0>;
 constexpr int BH_H = 1024, BH_I1 = 64, BH_HR = 32, BH_K1 = 64, BH_K0 = 512, BH_R1 = 32;
 constexpr int BH_PL_H = 16 * BH_K1;            // halfs per plane of the h image  [16 rows j0][64 j1]
 constexpr int BH_PL_I = BH_HR * BH_K0;         // halfs per plane of the stage-0 image [32 local rows i1][512 k']
-constexpr int BH_PARTS = 32;                   // partial maxima per core
 static_assert(T1::K == BH_K1 && T1::M == BH_I1 * BH_R1 && T1::ROWS == 16 && T0::K == BH_K0 && T0::M == 64 &&
                   T0::ROWS == BH_I1 && in_size_of<S2>() == BH_H && out_size_of<S2>() == 4 * BH_H && FAST_NT == 512,
               "merged two-core shape of cfg5");
@@ -52,37 +51,49 @@ __device__ __forceinline__ int frag_index(int kk, int m) {
 // k order of the stage-0 operand: (j0, a) -> k' = (a / 4) * 64 + j0 * 4 + a % 4 (k_bigh_prep inverts it for W_0's fragments, the
 // stage-1 store of the kernel produces it)
 
-struct BhScales { float tail, head, r1, un; };
-// parts: [2][BH_PARTS] partial maxima (|W_0| then |W_1|); every lane of a wave calls this
-//   tail: max|W_1| 2^a < 2^13     h: 2^9     stage-1 sums < 64 * 2^22 = 2^28, times r1 = 2^-13 -> < 2^15 before the split
-//   head: max|W_0| 2^b < 2^14     un = 2^-(a + 9 - 13 + b)
-__device__ __forceinline__ BhScales bh_scales(const float* __restrict__ parts, int lane) {
-  float mh = parts[lane & (BH_PARTS - 1)], mt = parts[BH_PARTS + (lane & (BH_PARTS - 1))];
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mt = fmaxf(mt, __shfl_xor(mt, o)); }
-  const int a = 13 - f10h_expo(mt), b = 14 - f10h_expo(mh);
-  BhScales s;
-  s.tail = ldexpf(1.f, a);
-  s.head = ldexpf(1.f, b);
-  s.r1 = ldexpf(1.f, -13);
-  s.un = ldexpf(1.f, -(a + 9 - 13 + b));
-  return s;
-}
-constexpr float BH_HSC = 512.0f;
+// Diagonal power-of-two scales (as ttrnn_f10_dev.h / ttrnn_g2.hip:k_g2_diag), int32 exponents in the scratch header:
+//   tail   W_1'[j_t][(i_t, a)] = W_1 2^(13 + eu[i_t] + ev[a])      each i_t block and each rank slice a: max < 2^13
+//   h      2^9 h;  stage-1 sums < 64 * 2^22 = 2^28, times 2^-13 -> < 2^15 before the split
+//   head   W_0'[(j_0, a)][i_h] = W_0 2^(ep[i_h] - ev[a])           each output row i_h: max < 2^14
+//   sums   2^(13 + 9 - 13 + ep[i_h] + eu[i_t]) x the pre-activation of (i_h, i_t)
+// so one large core entry moves only the scale of its own row / slice (round 2: one scale per merged core).
+constexpr int BH_EU = 0, BH_EV = 64, BH_EP = 96, BH_HDR_BYTES = 1024;
+constexpr float BH_HSC = 512.0f, BH_R1SC = 1.0f / 8192.0f;
 
-__global__ void __launch_bounds__(256) k_bigh_absmax(const float* __restrict__ packed2, float* __restrict__ parts) {
-  __shared__ float red[4];
-  constexpr int N0 = T0::K * T0::M, N1 = T1::K * T1::M;
-  const int which = blockIdx.x / BH_PARTS, part = blockIdx.x % BH_PARTS;
-  const float* a = packed2 + woff_of<S2>(which);
-  const int n = which == 0 ? N0 : N1;
-  float m = 0.f;
-  for (int i = part * 256 + threadIdx.x; i < n; i += BH_PARTS * 256) m = fmaxf(m, fabsf(a[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+// one workgroup over the two merged cores (fragment-ordered fp32, L2-resident)
+__global__ void __launch_bounds__(1024) k_bigh_diag(const float* __restrict__ packed2, int* __restrict__ hdr) {
+  __shared__ unsigned mu[BH_I1], mv[BH_R1], mp[64];
+  __shared__ int eu[BH_I1], ev[BH_R1];
+  const int tid = threadIdx.x;
+  if (tid < BH_I1) { mu[tid] = 0u; mp[tid] = 0u; }
+  if (tid < BH_R1) mv[tid] = 0u;
   __syncthreads();
-  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float* W1 = packed2 + woff_of<S2>(1);
+  const float* W0 = packed2 + woff_of<S2>(0);
+  constexpr int N1 = T1::K * T1::M, N0 = T0::K * T0::M;
+  // element e of stage k: (kk, m) = (e / M, e % M) through frag_index (any enumeration covers every element once)
+  for (int e = tid; e < N1; e += 1024) {
+    const int kk = e / T1::M, m = e % T1::M;
+    atomicMax(&mu[m / BH_R1], __float_as_uint(fabsf(W1[frag_index<1>(kk, m)])));
+  }
+  __syncthreads();
+  if (tid < BH_I1) eu[tid] = -f10h_expo(__uint_as_float(mu[tid]));
+  __syncthreads();
+  for (int e = tid; e < N1; e += 1024) {
+    const int kk = e / T1::M, m = e % T1::M;
+    atomicMax(&mv[m % BH_R1], __float_as_uint(fabsf(W1[frag_index<1>(kk, m)]) * ldexpf(1.f, eu[m / BH_R1])));
+  }
+  __syncthreads();
+  if (tid < BH_R1) ev[tid] = -f10h_expo(__uint_as_float(mv[tid]));
+  __syncthreads();
+  for (int e = tid; e < N0; e += 1024) {
+    const int kk = e / T0::M, m = e % T0::M;                // kk = j0 * R1 + a
+    atomicMax(&mp[m], __float_as_uint(fabsf(W0[frag_index<0>(kk, m)]) * ldexpf(1.f, -ev[kk % BH_R1])));
+  }
+  __syncthreads();
+  if (tid < BH_I1) hdr[BH_EU + tid] = eu[tid];
+  if (tid < BH_R1) hdr[BH_EV + tid] = ev[tid];
+  if (tid < 64) hdr[BH_EP + tid] = 14 - f10h_expo(__uint_as_float(mp[tid]));
 }
 
 // fragment streams (16-byte entries, one per lane):
@@ -90,20 +101,20 @@ __global__ void __launch_bounds__(256) k_bigh_absmax(const float* __restrict__ p
 //   f0[wave][kbl][piece][lane]           stage 0: wave = (p, kh): feature tile p, k-block 8 kh + kbl (32 values of k')
 // stage-0 rows: row 4 q' + j of tile p <-> feature m0 = 16 j + 4 p + q' (gate j of unit-column mq = 4 p + q')
 constexpr int BH_F1 = 2 * 8 * 8 * 2 * 2 * 64, BH_F0 = 8 * 8 * 2 * 64;
-__global__ void __launch_bounds__(256) k_bigh_prep(const float* __restrict__ packed2, const float* __restrict__ parts,
+__global__ void __launch_bounds__(256) k_bigh_prep(const float* __restrict__ packed2, const int* __restrict__ hdr,
                                                    xh8* __restrict__ f1, xh8* __restrict__ f0) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int lane = e & 63, r = lane & 15, q = lane >> 4;
-  const BhScales sc = bh_scales(parts, threadIdx.x & 63);
   xh8 p0, p1;
   if (e < BH_F1 / 2) {
     const int kb = (e >> 6) & 1, x = (e >> 7) & 7, wave = (e >> 10) & 7, half = e >> 13;
     const int m = (half * 64 + 8 * wave + x) * 16 + r;
     const float* W = packed2 + woff_of<S2>(1);
+    const float tsc = ldexpf(1.f, 13 + hdr[BH_EU + m / BH_R1] + hdr[BH_EV + m % BH_R1]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       _Float16 a, b;
-      split2h(W[frag_index<1>(32 * kb + 8 * q + i, m)] * sc.tail, a, b);
+      split2h(W[frag_index<1>(32 * kb + 8 * q + i, m)] * tsc, a, b);
       p0[i] = a; p1[i] = b;
     }
     const size_t o = ((size_t)(e >> 6) * 2) * 64 + lane;
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(256) k_bigh_prep(const float* __restrict__ pac
       const int kp = 32 * (8 * kh + kbl) + 8 * q + i;                 // permuted k' -> (j0, a)
       const int j0 = (kp & 63) >> 2, a = (kp >> 6) * 4 + (kp & 3);
       _Float16 u, v;
-      split2h(W[frag_index<0>(j0 * BH_R1 + a, m0)] * sc.head, u, v);
+      split2h(W[frag_index<0>(j0 * BH_R1 + a, m0)] * ldexpf(1.f, hdr[BH_EP + m0] - hdr[BH_EV + a]), u, v);
       p0[i] = u; p1[i] = v;
     }
     const size_t o = ((size_t)(g >> 6) * 2) * 64 + lane;
@@ -133,12 +144,13 @@ template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const float* __restrict__ gin,
                                                             const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                             const xh8* __restrict__ f1, const xh8* __restrict__ f0,
-                                                            const float* __restrict__ parts,
+                                                            const int* __restrict__ hdr,
                                                             const TS* __restrict__ bias_in,
                                                             const TS* __restrict__ bias_hid, TS* __restrict__ out,
                                                             TS* __restrict__ hT, TS* __restrict__ cT,
                                                             float* __restrict__ reserve,
-                                                            unsigned long long* __restrict__ hx) {
+                                                            unsigned long long* __restrict__ hx,
+                                                            unsigned* __restrict__ status) {
   constexpr int H = BH_H;
   __shared__ __attribute__((aligned(16))) _Float16 hpl[2 * BH_PL_H];      // h_{t-1}: two planes of 2^9 h
   __shared__ __attribute__((aligned(16))) f32x4 xp[4][2][64];             // stage-0 sums of the OTHER k half's row tile
@@ -154,10 +166,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
   const size_t b = blockIdx.x >> 1;
   const int half = blockIdx.x & 1;
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
-  const BhScales sc = bh_scales(parts, lane);
 
   // gate phase: lane (c, q) of wave (p, kh) owns unit-column mq = 4 p + q, local row 16 kh + c
   const int mq = 4 * p + q, rl = 16 * kh + c;
+  // inverse scales of the stage-0 sums of this lane's unit: gate j is output row i_h = 16 j + mq, column i_t = 32 half + rl
+  f32x4 un4;
+  {
+    const int eut = hdr[BH_EU + half * BH_HR + rl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) un4[j] = ldexpf(1.f, -(13 + 9 - 13 + hdr[BH_EP + 16 * j + mq] + eut));
+  }
   const int hid = mq * BH_I1 + half * BH_HR + rl;
   const int hidp = mq * BH_I1 + (1 - half) * BH_HR + rl;                  // the partner's unit at the same position
   const int ho = x_off<BH_K1>(mq, half * BH_HR + rl), hop = x_off<BH_K1>(mq, (1 - half) * BH_HR + rl);
@@ -178,7 +196,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
     split2h(hpv * s0, u, v);
     hpl[hop] = u; hpl[BH_PL_H + hop] = v;
   }
-  float usc = ldexpf(sc.un, e0);
+  float e0f = ldexpf(1.f, e0);                        // step 0 runs on 2^-e0 h_0: its sums are multiplied back
   f32x4 gi = T > 0 ? gin4[(b * T) * H + hid] : f32x4{0.f, 0.f, 0.f, 0.f};     // slots i,g,f,o; prefetched a step ahead
   bool dead = false;
 
@@ -219,7 +237,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
     const int o0 = ((row * 64 + (q >> 1) * 16 + ((((qz & 1) << 3) + (cz >> 1)) ^ (row & 15))) << 3) + ((cz & 1) << 2);
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
-      const f32x4 v = (hi[y] + lo[y]) * sc.r1;
+      const f32x4 v = (hi[y] + lo[y]) * BH_R1SC;
       store_split4_h(img, BH_PL_I, o0 + y * 256, v);
     }
   };
@@ -290,11 +308,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
     const size_t bt = b * T + t;
     {
       const f32x4 tot = (kh == 0 ? acc[0] : acc[1]) + xp[p][1 - kh][lane];
-      const float ig = bsigmoid(fmaf(tot[0], usc, gi[0] + bh[0]));
-      const float fg = bsigmoid(fmaf(tot[1], usc, gi[2] + bh[1]));
-      const float gg = btanh(fmaf(tot[2], usc, gi[1] + bh[2]));
-      const float og = bsigmoid(fmaf(tot[3], usc, gi[3] + bh[3]));
-      usc = sc.un;
+      const f32x4 usc = un4 * e0f;
+      const float ig = bsigmoid(fmaf(tot[0], usc[0], gi[0] + bh[0]));
+      const float fg = bsigmoid(fmaf(tot[1], usc[1], gi[2] + bh[1]));
+      const float gg = btanh(fmaf(tot[2], usc[2], gi[1] + bh[2]));
+      const float og = bsigmoid(fmaf(tot[3], usc[3], gi[3] + bh[3]));
+      e0f = 1.0f;
       const float cy = fg * cst + ig * gg;
       float hy = og * btanh(cy);
       cst = cy;
@@ -324,7 +343,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       while (!dead && (unsigned)(w >> 32) != (unsigned)(t + 1)) {
         __builtin_amdgcn_s_sleep(1);
         w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spin > (1L << 21)) dead = true;
+        if (++spin > (1L << 21)) { dead = true; if (status) atomicAdd(status + TTRNN_STAT_PAIR_TIMEOUTS, 1u); }
       }
       const float hp = dead ? __uint_as_float(0x7FC00000u) : __uint_as_float((unsigned)w);
       _Float16 u, v;
@@ -340,25 +359,35 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
 
 }  // namespace
 
-size_t bigh_workspace_bytes() { return (size_t)(BH_F1 + BH_F0) * sizeof(xh8) + 256; }
+static constexpr size_t BH_LDS_PAIR = 2 * BH_PL_I * sizeof(_Float16) + 8 * 8 * 64 * sizeof(xh8);
+bool bigh_pair_resident(int dtype, int B) {
+  const void* fn = dtype == TTRNN_F32 ? reinterpret_cast<const void*>(k_lstm_fwd_big2h<float>)
+                                      : reinterpret_cast<const void*>(k_lstm_fwd_big2h<bf16_t>);
+  return ensure_dynamic_lds(fn, BH_LDS_PAIR) == TTRNN_OK && resident_at_once(fn, FAST_NT, BH_LDS_PAIR, 2L * B);
+}
+size_t bigh_workspace_bytes() { return (size_t)(BH_F1 + BH_F0) * sizeof(xh8) + BH_HDR_BYTES; }
 
 template <typename TS>
 static int launch_bigh_t(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* m2_hid,
                          const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT, float* reserve,
                          unsigned long long* hxb, void* scratch, hipStream_t stream) {
-  float* parts = (float*)scratch;
-  xh8* f1 = (xh8*)((char*)scratch + 256);
+  int* hdr = (int*)scratch;
+  xh8* f1 = (xh8*)((char*)scratch + BH_HDR_BYTES);
   xh8* f0 = f1 + BH_F1;
-  hipLaunchKernelGGL(k_bigh_absmax, dim3(2 * BH_PARTS), dim3(256), 0, stream, m2_hid, parts);
-  hipLaunchKernelGGL(k_bigh_prep, dim3((BH_F1 / 2 + BH_F0 / 2 + 255) / 256), dim3(256), 0, stream, m2_hid, parts, f1, f0);
+  static_assert((BH_EP + 64) * sizeof(int) <= BH_HDR_BYTES, "header");
+  hipLaunchKernelGGL(k_bigh_diag, dim3(1), dim3(1024), 0, stream, m2_hid, hdr);
+  hipLaunchKernelGGL(k_bigh_prep, dim3((BH_F1 / 2 + BH_F0 / 2 + 255) / 256), dim3(256), 0, stream, m2_hid, (const int*)hdr, f1, f0);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   // stage-0 image (64 KB) + the LDS-resident quarter of the stage-1 fragments (64 KB): one workgroup per CU
-  constexpr size_t lds_pair = 2 * BH_PL_I * sizeof(_Float16) + 8 * 8 * 64 * sizeof(xh8);
+  constexpr size_t lds_pair = BH_LDS_PAIR;
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2h<TS>), lds_pair) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
   const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
-  hipLaunchKernelGGL((k_lstm_fwd_big2h<TS>), dim3(2 * rs.B), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
-                     (const TS*)h0, (const TS*)c0, f1, f0, parts, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb);
+  // (OPT_PAIR_FAULT, tests only: the last workgroup is not launched — its partner must time out, poison its sample with NaN
+  // and count the event)
+  hipLaunchKernelGGL((k_lstm_fwd_big2h<TS>), dim3(2 * rs.B - (opt(OPT_PAIR_FAULT) ? 1 : 0)), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
+                     (const TS*)h0, (const TS*)c0, f1, f0, (const int*)hdr, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb,
+                     device_status_ptr());
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

@@ -87,37 +87,56 @@ template <class S>
 constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
 
 // ---- two-piece fp16 operands (LSTM forward kernels): scale header + fragments --------------------------------------
-// F10H_PARTS workgroups: partial maxima of the three cores and of the caller's h_0 (f10h_scales turns them into the
-// power-of-two scales of ttrnn_f10_dev.h).
+// The diagonal power-of-two scales of ttrnn_f10_dev.h, from the cores themselves.  F10H_PARTS workgroups; every one derives
+// eu / ev from core 2 (a thousand entries) and then takes M / F10H_PARTS rows of the fused core, one wave per row:
+//   eu[i2] = -expo(max_{r2,j2} |G2|),  ev[r2] = -expo(max_{i2,j2} 2^eu |G2|),  ep[m] = 12 - expo(max_k 2^-ev |W10[m][k]|)
 template <class S>
-__global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, const float* __restrict__ h0,
-                                                    long n_h0, float* __restrict__ hdr) {
-  __shared__ float red[4][4];
-  const int tid = threadIdx.x, g = blockIdx.x * 256 + tid;
-  constexpr int STRIDE = F10H_PARTS * 256;
-  float m[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    for (int i = woff_of<S>(k) + g; i < woff_of<S>(k + 1); i += STRIDE) m[k] = fmaxf(m[k], fabsf(packed[i]));
-  if (h0) {
-    const long n4 = n_h0 >> 2;                                       // B * H, H a multiple of 4
-    for (long i = g; i < n4; i += STRIDE) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(h0 + 4 * i);
-      m[3] = fmaxf(fmaxf(m[3], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], o));
-    if ((tid & 63) == 0) red[k][tid >> 6] = m[k];
+__global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, int* __restrict__ hdr) {
+  using F = F10<S>;
+  static_assert(F::M == 4 * F10H_PARTS && F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one wave per row of the fused core");
+  __shared__ unsigned mx[32];
+  __shared__ int eu[16], ev[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2], m2 = i2 R2 + r2
+  if (tid < 32) mx[tid] = 0u;
+  __syncthreads();
+  for (int i = tid; i < F::J2 * F::M2; i += 256)          // non-negative floats order like their bit patterns
+    atomicMax(&mx[(i % F::M2) / F::R2], __float_as_uint(fabsf(W2[i])));
+  __syncthreads();
+  if (tid < 16) eu[tid] = tid < F::I2 ? -f10h_expo(__uint_as_float(mx[tid])) : 0;
+  __syncthreads();
+  for (int i = tid; i < F::J2 * F::M2; i += 256) {
+    const int m2 = i % F::M2;
+    atomicMax(&mx[16 + m2 % F::R2], __float_as_uint(fabsf(W2[i]) * ldexpf(1.f, eu[m2 / F::R2])));
   }
   __syncthreads();
-  if (tid < 4) hdr[4 * blockIdx.x + tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
+  if (tid < 16) ev[tid] = tid < F::R2 ? -f10h_expo(__uint_as_float(mx[16 + tid])) : 0;
+  __syncthreads();
+  // row m of the fused core (the same fmaf chain as k_f10h_prep): lanes over k = (row2, r2)
+  const int m = 4 * blockIdx.x + wave;
+  const int i0 = m / F::I1, i1 = m % F::I1;
+  const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+  const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+  float best = 0.f;
+  for (int k = lane; k < F::K; k += 64) {
+    const int r2 = k % F::R2, row2 = k / F::R2;
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+    best = fmaxf(best, fabsf(v) * ldexpf(1.f, -ev[r2]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+  if (lane == 0) hdr[F10H_EP + m] = 12 - f10h_expo(best);
+  if (blockIdx.x == 0 && tid < 16) {
+    hdr[F10H_EU + tid] = eu[tid];
+    hdr[F10H_EV + tid] = ev[tid];
+  }
 }
 
 // The fused core in fragment order (see k_f10_prep), rows pre-multiplied by -log2(e) (gates i, f, o) / 2 log2(e) (gate g)
-// and by the header's 2^sw, as two fp16 pieces:  wfrag[((t*NM + u)*2 + plane)*64 + lane].
+// and by the header's 2^(ep[m] - ev[r2]), as two fp16 pieces:  wfrag[((t*NM + u)*2 + plane)*64 + lane].
 template <class S>
 __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ packed, const float* __restrict__ hdr,
                                                   xh8* __restrict__ wfrag) {
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ pack
   const int i0 = m / F::I1, i1 = m % F::I1;
   const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
   const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
-  const float sc = ((r & 3) == 2 ? 2.8853900817779268f : -1.4426950408889634f) * f10h_scales<S>(hdr).w;
+  const float gf = (r & 3) == 2 ? 2.8853900817779268f : -1.4426950408889634f;
   xh8 f0, f1;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -139,7 +158,7 @@ __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ pack
     float v = 0.f;
     for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
     _Float16 p0, p1;
-    split2h(v * sc, p0, p1);
+    split2h(v * (gf * f10h_w_scale<S>(hdr, m, r2)), p0, p1);
     f0[e] = p0; f1[e] = p1;
   }
   xh8* dst = wfrag + (size_t)((t * F::NM + u) * 2) * 64 + lane;
@@ -167,8 +186,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   _Float16* hpl = reinterpret_cast<_Float16*>(smem + 2 * sizeof(float) * H);      // fp16 pieces of 2^sH h: [parity][2][H]
   _Float16* img = hpl + 2 * 2 * H;                                                // two fp16 planes [I2][K10]
   f32x4* xbuf = reinterpret_cast<f32x4*>(img + 2 * F::PLANE);                      // KS == 2: partial accumulators
-  const F10hScales fsc = f10h_scales<S>(hdr);                                       // power-of-two scales (ttrnn_f10_dev.h)
-  const float g2s = fsc.g2, hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,11 +197,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   const bool mma_wave = KS == 2 || gate_wave;
   const int tile = KS == 2 ? (wave & 3) : wave;          // S10 feature tile of this wave
   const int u0 = KS == 2 ? (wave >> 2) * NU : 0;         // its first k-block
+  const F10hScales fsc = f10h_scales<S>(hdr, tile & (F::MT - 1), lane);     // diagonal power-of-two scales (ttrnn_f10_dev.h)
+  const float hsc = F10H_HSC;
+  const f32x4 psc = fsc.pre, usc = fsc.un;
 
   // S2 fragments of the m-tiles {wave + 8x}
   xh8 s1[F::XA];
 #pragma unroll
-  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, g2s);
+  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, hdr);
   xh8 w10[2][NU];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -218,7 +238,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   // argument of v_exp_f32: sigmoid(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 1 - 2 / (1 + 2^(2 log2e x)).  The input
   // projection + biases get the same factors (and 2^S) and enter the MFMA chain as its initial accumulator value, so
   // nothing but the merge of the two chains stands between the last MFMA and the transcendental unit.
-  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} *
+                    f32x4{psc[0], psc[2], psc[1], psc[3]};      // slots i,g,f,o <- accumulator rows i,f,g,o
   XChunk<float> xq;
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -245,7 +266,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
   if constexpr (DIAG) last_ = stamp();
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
-  float us_t = usc * h0un, ps_t = h0sc;     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
+  f32x4 us_t = usc * h0un;                  // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
+  float ps_t = h0sc;
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
@@ -281,8 +303,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
         acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       }
       f10h_s10_part<S, NU>(w10, img, row10, q, u0, acc_lo, acc_hi);
-      const float un = H0 ? us_t : usc;
-      acc = acc_hi * un + acc_lo * un;                  // 2^-S (2^(e0-S) at step 0 of a given h_0), exact
+      const f32x4 un = H0 ? us_t : usc;
+      acc = acc_hi * un + acc_lo * un;                  // 2^-S per row and column (2^(e0-S) at step 0 of a given h_0), exact
       if constexpr (DIAG) {
         asm volatile("" : "+v"(acc));
       }
@@ -699,9 +721,9 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   static_assert(F10H_HDR_BYTES + (size_t)F10<S>::MT * F10<S>::NM * 2 * 64 * sizeof(xh8) <= f10_wfrag_bytes<S>(), "workspace");
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
-  static_assert(F10H_PARTS * 4 * sizeof(float) <= F10H_HDR_BYTES, "header");
-  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, (const float*)nullptr,
-                     0L, hdr);          // h_0 is scaled per sample inside the recurrent kernels (f10h_h0_expo)
+  static_assert((F10H_EP + F10<S>::M) * sizeof(int) <= F10H_HDR_BYTES, "header");
+  // (h_0 is scaled per sample inside the recurrent kernels: f10h_h0_expo)
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
   hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   constexpr size_t lds = f10h_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");

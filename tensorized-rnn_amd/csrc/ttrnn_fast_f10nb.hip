@@ -31,8 +31,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   using F = F10<S>;
   constexpr int H = F::H;
   constexpr size_t SMP = f10h_lds_bytes<S, KS>();                           // LDS bytes of one sample
-  const F10hScales fsc = f10h_scales<S>(hdr);                               // power-of-two scales (ttrnn_f10_dev.h)
-  const float g2s = fsc.g2, hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_nb[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -44,11 +42,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   const bool mma_wave = KS == 2 || gate_wave;
   const int tile = KS == 2 ? (wave & 3) : wave;          // S10 feature tile of this wave
   const int u0 = KS == 2 ? (wave >> 2) * NU : 0;         // its first k-block
+  const F10hScales fsc = f10h_scales<S>(hdr, tile & (F::MT - 1), lane);     // diagonal power-of-two scales (ttrnn_f10_dev.h)
+  const float hsc = F10H_HSC;
+  const f32x4 psc = fsc.pre, usc = fsc.un;
 
   // S2 fragments of the m-tiles {wave + 8x}
   xh8 s1[F::XA];
 #pragma unroll
-  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, g2s);
+  for (int x = 0; x < F::XA; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + FAST_NW * x, lane, hdr);
   xh8 w10[2][NU];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, vv = bh, bb = bh;       // slot order i,g,f,o
   // pre-scaled accumulators, exactly as in k_lstm_fwd_f10 (same arithmetic per sample: the two kernels agree bit for bit)
-  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} *
+                    f32x4{psc[0], psc[2], psc[1], psc[3]};      // slots i,g,f,o <- accumulator rows i,f,g,o
   if (ok) {
     if (bias_hid) bh = f32x4{bias_hid[hd], bias_hid[2 * H + hd], bias_hid[H + hd], bias_hid[3 * H + hd]};
     if (T > 0 && in1) {
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
           acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
         }
         f10h_s10_part<S, NU>(w10, img[sm], row10, q, u0, acc_lo, acc_hi);
-        const float us_t = t == 0 ? usc * h0un[sm] : usc;
+        const f32x4 us_t = t == 0 ? usc * h0un[sm] : usc;
         acc[sm] = acc_hi * us_t + acc_lo * us_t;            // 2^-S (2^(e0-S) at step 0), exact
         if constexpr (DIAG) {
           asm volatile("" : "+v"(acc[sm]));

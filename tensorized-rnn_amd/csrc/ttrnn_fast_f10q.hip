@@ -49,17 +49,18 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
   _Float16* hpl = reinterpret_cast<_Float16*>(smem_q);   // fp16 pieces of 2^sH h: [parity][2][H]
   _Float16* img = hpl + 2 * 2 * H;                       // two fp16 planes [I2][K10]
-  const F10hScales fsc = f10h_scales<S>(hdr);
-  const float hsc = fsc.h, psc = fsc.pre, usc = fsc.un;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const F10hScales fsc = f10h_scales<S>(hdr, wave, lane);      // diagonal power-of-two scales (ttrnn_f10_dev.h)
+  const float hsc = F10H_HSC;
+  const f32x4 psc = fsc.pre, usc = fsc.un;
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
 
   xh8 s1[XQ];
 #pragma unroll
-  for (int x = 0; x < XQ; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + QW * x, lane, fsc.g2);
+  for (int x = 0; x < XQ; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + QW * x, lane, hdr);
   xh8 w10[KH][2][NH];
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh)
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
     h0sc = ldexpf(1.f, -e0); h0un = ldexpf(1.f, e0);
   }
   f32x4 bh = f32x4{0.f, 0.f, 0.f, 0.f}, gi = bh, vv = bh, bb = bh;       // slot order i,g,f,o
-  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} * psc;
+  const f32x4 gsc = f32x4{-1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f, -1.4426950408889634f} *
+                    f32x4{psc[0], psc[2], psc[1], psc[3]};      // slots i,g,f,o <- accumulator rows i,f,g,o
   XChunk<float> xq;
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -107,7 +109,8 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   // changed nothing: measured 1.71 ms for every delay between 0 and 3 800 cycles on cfg4.)
 
   const int row10 = c < F::I2 ? c : F::I2 - 1;
-  float us_t = usc * h0un, ps_t = h0sc;     // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
+  f32x4 us_t = usc * h0un;                  // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
+  float ps_t = h0sc;
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
@@ -137,8 +140,8 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
       if constexpr (H0) pre = pre * ps_t;
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = f32x4{pre[0], pre[2], pre[1], pre[3]};
       f10h_s10_part<S, NH>(w10[0], img, row10, q, 0, acc_lo, acc_hi);
-      const float un = H0 ? us_t : usc;
-      acc = acc_hi * un + acc_lo * un;                    // 2^-S (2^(e0-S) at step 0 of a given h_0), exact
+      const f32x4 un = H0 ? us_t : usc;
+      acc = acc_hi * un + acc_lo * un;                    // 2^-S per row and column (2^(e0-S) at step 0 of a given h_0), exact
       if constexpr (KH == 2) {
         f32x4 bl = f32x4{0.f, 0.f, 0.f, 0.f}, bhh = bl;
         f10h_s10_part<S, NH>(w10[1], img, row10, q, NH, bl, bhh);

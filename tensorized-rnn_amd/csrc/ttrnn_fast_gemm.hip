@@ -31,41 +31,52 @@ constexpr int GK = 32;                        // k per chunk = one bf16 MFMA
 constexpr int GPA = GR * GK, GPB = GF * GK;   // bf16 elements per plane tile (rows / features)
 constexpr int G_BUF = 3 * GPA + 3 * GPB;      // one buffer: three planes of each operand
 constexpr size_t G_LDS = (size_t)2 * G_BUF * sizeof(__bf16);
-constexpr int G_PARTS = 64;                   // partial maxima of |W| (scratch header)
-constexpr int G_HDR = 256;                    // bytes in front of the row scales
+// HALF scratch: [one fp32 scale per COLUMN of W (output feature): M floats, padded to 256 bytes | one per row of x]
+__host__ __device__ constexpr size_t g_rs_off(int M) { return (((size_t)M * sizeof(float) + 255) & ~(size_t)255) / sizeof(float); }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Two-piece fp16 variant (HALF): every row of x is multiplied by its own power of two (max |x[n][:]| 2^e <= 2^14), W by
-// one (max |W| 2^ew <= 2^14), both exact; product = x0w0 + x0w1 + x1w0 (ttrnn_split.h), the epilogue undoes the scales.
-// An output's error is relative to (row maximum) x (matrix maximum) — what matters for a gate pre-activation — and equals
-// the bf16 variant's wherever the entries lie within 2^17 of those maxima.
+// Two-piece fp16 variant (HALF): every row of x is multiplied by its own power of two (max |x[n][:]| 2^e <= 2^14), every
+// COLUMN of W (output feature) by its own (max_k |W[k][m]| 2^ew <= 2^14), both exact; product = x0w0 + x0w1 + x1w0
+// (ttrnn_split.h), the epilogue undoes the two scales of its (row, feature).  An output's error is relative to (row
+// maximum) x (its own column's maximum) — what matters for a gate pre-activation — and equals the bf16 variant's wherever
+// the entries lie within 2^17 of those maxima; a large entry of W costs only its own output feature bits (round 2: one
+// scale for the whole matrix).
 __device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral; clamped so that the
   if (!(x > 0.f) || !(x < 3e38f)) return 0;                // product of a row scale and the matrix scale (and its inverse)
   int e;                                                   // stays a normal fp32 number
   frexpf(x, &e);
   return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
-__device__ __forceinline__ float g_wscale(const float* __restrict__ parts) {
-  float m = 0.f;
-#pragma unroll
-  for (int i = 0; i < G_PARTS; i += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(parts + i);
-    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-  }
-  return ldexpf(1.f, 14 - g_expo(m));
-}
 }  // namespace
 
-// partial maxima of |a[0..n)| (strided view: element i at a[(i / M) * sk + (i % M) * sm]) -> parts[G_PARTS]
-__global__ void __launch_bounds__(256) k_absmax_parts(const float* __restrict__ a, size_t n, float* __restrict__ parts) {
-  __shared__ float red[4];
-  float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)G_PARTS * 256) m = fmaxf(m, fabsf(a[i]));
+// wsc[m] = 2^(14 - e), max_k |W(k, m)| < 2^e with W(k, m) = WG[k*sk + m*sm]: a workgroup takes 32 columns, its 8 thread
+// groups stride over k with 8 independent loads in flight each (one thread per column walking all of k was a chain of
+// 1 024 dependent-latency loads on 16 workgroups: 0.3 ms at cfg5's size)
+__global__ void __launch_bounds__(256) k_gemm_col_scales(const float* __restrict__ WG, int K, int M, int64_t sk, int64_t sm,
+                                                         float* __restrict__ wsc) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + col;
+  float mx = 0.f;
+  if (m < M) {
+    const float* base = WG + (size_t)m * sm;
+    int k = kg;
+    for (; k + 56 < K; k += 64) {
+      float v[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+      for (int i = 0; i < 8; ++i) v[i] = fabsf(base[(size_t)(k + 8 * i) * sk]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, v[i]);
+    }
+    for (; k < K; k += 8) mx = fmaxf(mx, fabsf(base[(size_t)k * sk]));
+  }
+  red[kg][col] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (kg == 0 && m < M) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, red[i][col]);
+    wsc[m] = ldexpf(1.f, 14 - g_expo(mx));
+  }
 }
 
 // rs[n] = 2^(14 - e), max_k |x[n][k]| < 2^e: one wave per row, 8 elements per lane and pass (K % 8 == 0)
@@ -101,13 +112,13 @@ __global__ void __launch_bounds__(256) k_gemm_prep(const float* __restrict__ WG,
 }
 
 __global__ void __launch_bounds__(256) k_gemm_prep_h(const float* __restrict__ WG, int K, int KCn, int M, int64_t sk,
-                                                     int64_t sm, const float* __restrict__ parts,
+                                                     int64_t sm, const float* __restrict__ wsc,
                                                      _Float16* __restrict__ planes) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (k quad, m)
   const int m = (int)(e % M);
   const int k4 = (int)(e / M) * 4;
   if (k4 >= 32 * KCn) return;
-  const float ws = g_wscale(parts);
+  const float ws = wsc[m];
   float v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = k4 + i < K ? WG[(size_t)(k4 + i) * sk + (size_t)m * sm] * ws : 0.f;
@@ -143,7 +154,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
                                                         const TS* __restrict__ bias, int Hb, float* __restrict__ y,
                                                         const float* __restrict__ bias_ilv,
                                                         const float* __restrict__ scratch) {
-  // HALF: two fp16 pieces, three terms, scales in `scratch` ([0, G_HDR): partial maxima of |W|, then one scale per row)
+  // HALF: two fp16 pieces, three terms, scales in `scratch` (one per column of W, then one per row of x: g_rs_off)
+  const float* rowsc = scratch + g_rs_off(M);
   using E = typename std::conditional<HALF, _Float16, __bf16>::type;
   using X8 = typename std::conditional<HALF, xh8, xbf8>::type;
   constexpr int NP = HALF ? 2 : 3;
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
   for (int e = 0; e < 2; ++e) {
     const int64_t an = n0 + srow + 128 * e < n_rows ? n0 + srow + 128 * e : n_rows - 1;
     xrow[e] = x + (size_t)an * K;
-    if constexpr (HALF) xsc[e] = scratch[G_HDR / 4 + an];
+    if constexpr (HALF) xsc[e] = rowsc[an];
   }
   const size_t plane_elems = (size_t)KCn * M * 32;
   const E* wrow = planes + (size_t)(m0 + srow) * 32 + 8 * skq;
@@ -290,14 +302,13 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
       }
     }
   }
-  // HALF: undo the scales (powers of two: exact), one factor per output row
+  // HALF: undo the scales (powers of two: exact), one factor per output row and one per output feature
   float unsc[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (HALF) {
-    const float wun = 1.0f / g_wscale(scratch);
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      unsc[ri] = wun / scratch[G_HDR / 4 + (n < n_rows ? n : n_rows - 1)];
+      unsc[ri] = 1.0f / rowsc[n < n_rows ? n : n_rows - 1];
     }
   }
   // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 64wm + 16mi + 4q .. +3 of row n0 + 64wr + 16ri + c ------
@@ -311,10 +322,15 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
     } else if (bias_ilv) {
       bh = *reinterpret_cast<const f32x4*>(bias_ilv + mf);          // fp32 row already in column order (ttrnn_g2.hip)
     }
+    f32x4 unf = f32x4{1.f, 1.f, 1.f, 1.f};
+    if constexpr (HALF) {
+      const f32x4 ws4 = *reinterpret_cast<const f32x4*>(scratch + mf);
+      unf = f32x4{1.0f / ws4[0], 1.0f / ws4[1], 1.0f / ws4[2], 1.0f / ws4[3]};
+    }
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] * unsc[ri] + bh;
+      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] * (unf * unsc[ri]) + bh;
     }
   }
 }
@@ -763,14 +779,16 @@ bool gemm_use_half(int64_t n_rows, int K, int M) {
   return (double)n_rows * K * M >= 4294967296.0;
 }
 
-// two-piece fp16 variant: scratch = G_HDR bytes (partial maxima of |W|) + one fp32 scale per row of x
-size_t gemm_half_scratch_bytes(int64_t n_rows) { return al256g((size_t)G_HDR + (size_t)(n_rows > 0 ? n_rows : 0) * sizeof(float)); }
+// two-piece fp16 variant: scratch = one fp32 scale per column of W (M, padded) + one per row of x
+size_t gemm_half_scratch_bytes(int64_t n_rows, int M) {
+  return al256g(g_rs_off(M) * sizeof(float) + (size_t)(n_rows > 0 ? n_rows : 0) * sizeof(float));
+}
 
 int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream, bool transposed) {
   const int KCn = gemm_chunks(K);
   const size_t threads = (size_t)KCn * 8 * M;
-  // the dense matrix is contiguous either way ([K][M] or [M][K]): its maximum does not care about the view
-  hipLaunchKernelGGL(k_absmax_parts, dim3(G_PARTS), dim3(256), 0, stream, WG, (size_t)K * M, (float*)scratch);
+  hipLaunchKernelGGL(k_gemm_col_scales, dim3((M + 31) / 32), dim3(256), 0, stream, WG, K, M,
+                     (int64_t)(transposed ? 1 : M), (int64_t)(transposed ? K : 1), (float*)scratch);
   hipLaunchKernelGGL(k_gemm_prep_h, dim3((int)((threads + 255) / 256)), dim3(256), 0, stream, WG, K, KCn, M,
                      (int64_t)(transposed ? 1 : M), (int64_t)(transposed ? K : 1), (const float*)scratch,
                      (_Float16*)planes);
@@ -806,7 +824,7 @@ static bool gemm_wide_tiles(int64_t n_rows, int M) { return M % (2 * GT) == 0 &&
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
                      const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
   if (n_rows <= 0) return TTRNN_OK;
-  float* rs = (float*)scratch + G_HDR / 4;
+  float* rs = (float*)scratch + g_rs_off(M);
   const int grid = (int)((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
   if (dtype == TTRNN_F32) {
     hipLaunchKernelGGL(k_row_scales<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, n_rows, K, rs);

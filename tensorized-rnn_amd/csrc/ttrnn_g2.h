@@ -160,7 +160,8 @@ struct G2Plan {
   G2Mat hid;
   int upt;                          // hidden units per thread
   // LDS carve-up (bytes) of the forward and the reverse-time kernel
-  int f_hb, f_img, f_ybuf, f_tab, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_t1: tail fragments (0: from L2)
+  int f_hb, f_img, f_ybuf, f_tab, f_sc, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_sc: the inverse output scales
+                                                     // [I_h | I_t] floats; f_t1: tail fragments (0: from L2)
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
 };
 
@@ -182,7 +183,8 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->f_img = (int)g2_al((size_t)2 * 16 * m.N2T * m.K2S * 2);     // forward: two fp16 planes (ttrnn_split.h, flavour b)
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
   p->f_tab = (int)g2_al((size_t)m.T1 * 4 * 4);      // stage-1 store offsets: one per (tile, lane quarter)
-  p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab;
+  p->f_sc = (int)g2_al((size_t)(m.Ih + m.It) * 4);
+  p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab + p->f_sc;
   p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
   p->f_lds += p->f_t1;
   p->b_dy = (int)g2_al((size_t)3 * 16 * m.N2T * m.IhS * 2);
@@ -200,11 +202,12 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
-// forward: per-block maxima (|Gh|, |Gt|) of the merge kernel -> the power-of-two scales of the fp16 pieces
+// forward: + the int32 exponents of the diagonal scales (k_g2_diag): [I_t | 64 | I_h]
 inline long g2_merge_blocks(const G2Mat& m) { return ((long)m.Ih * m.Jh + (long)m.It * m.Jt + 255) / 256; }
+inline size_t g2_diag_ints(const G2Mat& m) { return (size_t)m.It + 64 + (size_t)m.Ih; }
 inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes) +
-         g2_al((size_t)g2_merge_blocks(m) * 2 * sizeof(float));
+         g2_al(g2_diag_ints(m) * sizeof(int));
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);

@@ -33,13 +33,11 @@ namespace {
 
 // ---- prep 1: contract the cores on either side of the split point ------------------------------------------------------
 // packed: W_k[(j*R_{k+1} + b)*M_k + (i*R_k + a)] = G_k[a, i, j, b]  (include/ttrnn.h)
-// parts (forward only): [block][2] = the largest |Gh| / |Gt| entry this block produced (g2_scales)
 __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const float* __restrict__ packed,
-                                                  float* __restrict__ Gh, float* __restrict__ Gt, float* __restrict__ parts) {
+                                                  float* __restrict__ Gh, float* __restrict__ Gt) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nh = (long)m.Ih * m.Jh, nt = (long)m.It * m.Jt;
   float v[G2_MAX_R], w[G2_MAX_R];
-  float mxh = 0.f, mxt = 0.f;
   if (e < nh) {
     int ih = (int)(e / m.Jh), jh = (int)(e % m.Jh);
     int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
@@ -55,7 +53,7 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
       }
       for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
     }
-    for (int a = 0; a < m.R; ++a) { Gh[(size_t)e * m.R + a] = v[a]; mxh = fmaxf(mxh, fabsf(v[a])); }
+    for (int a = 0; a < m.R; ++a) Gh[(size_t)e * m.R + a] = v[a];
   } else if (e < nh + nt) {
     const long f = e - nh;
     int it = (int)(f / m.Jt), jt = (int)(f % m.Jt);
@@ -73,28 +71,20 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
       }
       for (int a = 0; a < s.R[k]; ++a) v[a] = w[a];
     }
-    for (int a = 0; a < m.R; ++a) { Gt[(size_t)f * m.R + a] = v[a]; mxt = fmaxf(mxt, fabsf(v[a])); }
-  }
-  if (parts) {                                   // uniform
-    __shared__ float red[2][4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mxh = fmaxf(mxh, __shfl_xor(mxh, o)); mxt = fmaxf(mxt, __shfl_xor(mxt, o)); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mxh; red[1][threadIdx.x >> 6] = mxt; }
-    __syncthreads();
-    if (threadIdx.x < 2)
-      parts[2 * blockIdx.x + threadIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]),
-                                                   fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+    for (int a = 0; a < m.R; ++a) Gt[(size_t)f * m.R + a] = v[a];
   }
 }
 
 // ---- forward operand scales (two-piece fp16 flavour of ttrnn_split.h) ---------------------------------------------------------
-// Both stages run on two-piece fp16 operands.  Stage 1: tail fragments 2^a Gt (max < 2^13) against the image of 2^9 h
-// (|h_t| <= 1 for t >= 1, LSTM and GRU alike; a caller's h_0 is put into the image times a per-sample power of two that the
-// sums are multiplied back by); its fp32 sums are multiplied by the fixed 2^r that brings them below 2^15 and split into
-// stage 2's operand; the head fragments are 2^b Gh (max < 2^14); the gate phase multiplies the stage-2 sums by the inverse
-// of all four.  All powers of two: exact.  The maxima come out of the merge kernel (one pair per block), no launch of
-// their own.
-struct G2Scales { float tail, hsc, r1, head, un; };
+// Both stages run on two-piece fp16 operands under TWO-SIDED DIAGONAL power-of-two scales (as ttrnn_f10_dev.h), so that one
+// large entry of a core moves only the scale of its own row / rank slice and every other entry keeps its 22 bits:
+//   tail fragments   Gt'[(i_t, a)][j_t] = Gt 2^(13 + eu[i_t] + ev[a])     each i_t row block and each rank slice a: max < 2^13
+//   h image          2^9 h   (|h_t| <= 1 for t >= 1, LSTM and GRU alike; a caller's h_0 enters times a per-sample power of two
+//                             that the sums are multiplied back by)
+//   stage-1 sums     < J_t 2^22, times the fixed r1 = 2^(15 - 22 - ceil(log2 J_t)) < 2^15 before they are split
+//   head fragments   Gh'[i_h][(j_h, a)] = Gh 2^(ep[i_h] - ev[a])           each row: max < 2^14
+//   stage-2 sums     y'[i_h][i_t] = 2^(13 + 9 + r + ep[i_h] + eu[i_t]) y: undone (exactly) where the sums are stored
+// eu, ev, ep: int32 exponents computed once per launch by k_g2_diag from the merged cores, hdr = [eu: I_t | ev: 64 | ep: I_h].
 __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / non-finite: neutral
   if (!(x > 0.f)) return 0;
   if (!(x < 3e38f)) return 40;
@@ -102,40 +92,51 @@ __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / no
   frexpf(x, &e);
   return e < -40 ? -40 : (e > 40 ? 40 : e);
 }
-// every lane of a wave calls this; parts = the merge kernel's per-block maxima [nblk][2]
-//   tail: max|Gt| 2^a < 2^13        hsc: |h| 2^9 <= 2^9 (|h| <= 1 in the image; h_0: scaled per sample by the kernel)
-//   r1:   the stage-1 sums, < J_t 2^22, times r1 < 2^15 before they are split      head: max|Gh| 2^b < 2^14
-//   un = 1 / (tail hsc r1 head)
-__device__ __forceinline__ G2Scales g2_scales(const float* __restrict__ parts, int nblk, int Jt, int lane) {
-  float mh = 0.f, mt = 0.f;
-  for (int i = lane; i < nblk; i += 64) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(parts + 2 * i);
-    mh = fmaxf(mh, v[0]); mt = fmaxf(mt, v[1]);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { mh = fmaxf(mh, __shfl_xor(mh, o)); mt = fmaxf(mt, __shfl_xor(mt, o)); }
-  const int a = 13 - g2_expo(mt);
-  const int b = 14 - g2_expo(mh);
+constexpr float G2_HSC = 512.0f;
+__device__ __forceinline__ int g2_r1_expo(int Jt) {
   int ej = 0;
   while ((1 << ej) < Jt) ++ej;                             // J_t <= 2^ej
-  const int r = 15 - 22 - ej;
-  G2Scales s;
-  s.tail = ldexpf(1.f, a);
-  s.hsc = 512.0f;
-  s.r1 = ldexpf(1.f, r);
-  s.head = ldexpf(1.f, b);
-  s.un = ldexpf(1.f, -(a + 9 + r + b));
-  return s;
+  return 15 - 22 - ej;
+}
+// one workgroup of 1024 threads over the merged cores (L2-resident, <= a few hundred KB):
+//   eu[i_t] = -expo(max_{a, j_t} |Gt|),  ev[a] = -expo(max_{i_t, j_t} 2^eu |Gt|),  ep[i_h] = 14 - expo(max_{j_h, a} 2^-ev |Gh|)
+__global__ void __launch_bounds__(1024) k_g2_diag(G2Mat m, const float* __restrict__ Gh, const float* __restrict__ Gt,
+                                                  int* __restrict__ hdr) {
+  extern __shared__ unsigned g2d_mx[];                     // [I_t | 64 | I_h]
+  unsigned* mu = g2d_mx;
+  unsigned* mv = g2d_mx + m.It;
+  unsigned* mp = mv + 64;
+  int* eu = hdr;
+  int* ev = hdr + m.It;
+  int* ep = ev + 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < m.It + 64 + m.Ih; i += 1024) g2d_mx[i] = 0u;
+  __syncthreads();
+  const long nt = (long)m.It * m.Jt * m.R, nh = (long)m.Ih * m.Jh * m.R;
+  const long rowt = (long)m.Jt * m.R, rowh = (long)m.Jh * m.R;
+  for (long i = tid; i < nt; i += 1024) atomicMax(&mu[i / rowt], __float_as_uint(fabsf(Gt[i])));   // |x| orders like its bits
+  __syncthreads();
+  for (int i = tid; i < m.It; i += 1024) { const int e = -g2_expo(__uint_as_float(mu[i])); eu[i] = e; mu[i] = (unsigned)e; }
+  __syncthreads();
+  for (long i = tid; i < nt; i += 1024)
+    atomicMax(&mv[i % m.R], __float_as_uint(fabsf(Gt[i]) * ldexpf(1.f, (int)mu[i / rowt])));
+  __syncthreads();
+  if (tid < 64) { const int e = tid < m.R ? -g2_expo(__uint_as_float(mv[tid])) : 0; ev[tid] = e; mv[tid] = (unsigned)e; }
+  __syncthreads();
+  for (long i = tid; i < nh; i += 1024)
+    atomicMax(&mp[i / rowh], __float_as_uint(fabsf(Gh[i]) * ldexpf(1.f, -(int)mv[i % m.R])));
+  __syncthreads();
+  for (int i = tid; i < m.Ih; i += 1024) ep[i] = 14 - g2_expo(__uint_as_float(mp[i]));
 }
 
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
 // head stream (bf16 x 3 planes): block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl)*3 planes * 64 lanes
 //   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
 //   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
-// forward (REV = false): TWO fp16 planes of 2^b Gh (g2_scales), block stride 2 * 64 lanes; reverse: three bf16 planes
+// forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag), block stride 2 * 64 lanes; reverse: three bf16 planes
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs,
-                                                     const float* __restrict__ hdr, int nblk) {
+                                                     const int* __restrict__ hdr) {
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
@@ -144,8 +145,6 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int u = w + ui * m.nw;
   xbf8 f0, f1, f2;
   xh8 g0, g1;
-  float hsc = 1.f;
-  if constexpr (!REV) hsc = g2_scales(hdr, nblk, m.Jt, lane).head;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f;
@@ -179,8 +178,9 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
           split3(v, p0, p1, p2);
           f0[e] = p0; f1[e] = p1; f2[e] = p2;
         } else {
-          _Float16 p0, p1;
-          split2h(v * hsc, p0, p1);
+          _Float16 p0, p1;                        // 2^(ep[i_h] - ev[a]) Gh (k_g2_diag)
+          if (ih < m.Ih && jh < m.Jh && a < m.R) v *= ldexpf(1.f, hdr[m.It + 64 + ih] - hdr[m.It + a]);
+          split2h(v, p0, p1);
           g0[e] = p0; g1[e] = p1;
         }
       }
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
 //   reverse (fp32, one value per lane and k-step): A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]   at (mt*bKS1 + ks)*64 + lane
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft,
-                                                     const float* __restrict__ hdr, int nblk) {
+                                                     const int* __restrict__ hdr) {
   const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
   if constexpr (REV) {
     const int ks = blockIdx.x % m.bKS1, mt = blockIdx.x / m.bKS1;
@@ -211,9 +211,9 @@ __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __res
     if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
     ft[(size_t)blockIdx.x * 64 + lane] = v;
   } else {
-    const float tsc = g2_scales(hdr, nblk, m.Jt, lane).tail;
     const int kb = blockIdx.x % m.KB1, mt = blockIdx.x / m.KB1;
     const int row = 16 * mt + mm, it = row / m.Rp, a = row % m.Rp;
+    const float tsc = (it < m.It && a < m.R) ? ldexpf(1.f, 13 + hdr[it] + hdr[m.It + a]) : 0.f;      // k_g2_diag
     xh8 f0, f1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -291,7 +291,7 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
-                                                  const float* __restrict__ ft1, const float* __restrict__ hdr, int nblk,
+                                                  const float* __restrict__ ft1, const int* __restrict__ hdr,
                                                   TS* __restrict__ out, TS* __restrict__ hT,
                                                   TS* __restrict__ cT, float* __restrict__ reserve) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   _Float16* img = reinterpret_cast<_Float16*>(smem + P.f_hb);     // stage 2's operand: two fp16 planes of 2^a C1
   float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
-  xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);         // tail fragments (P.f_t1 > 0)
+  float* unf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // [I_h]: 2^-(ep + 13 + 9 + r), then
+  float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag)
+  xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab + P.f_sc); // tail fragments (P.f_t1 > 0)
   const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
   const int plane = 16 * m.N2T * m.K2S;
 
@@ -312,8 +314,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const size_t b = blockIdx.x;
   const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
-  const G2Scales gsc = g2_scales(hdr, nblk, m.Jt, lane);
-  const float unsc = gsc.un;                                        // stage-2 sums -> pre-activations
+  const float r1sc = ldexpf(1.f, g2_r1_expo(m.Jt));                 // stage-1 sums -> below 2^15 before they are split
 
   // ---- one-time set-up: zero the padded images, stage-1 store offsets, state --------------------------------------------------
   for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
@@ -326,6 +327,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     const int it = m1 / m.Rp, a = m1 - it * m.Rp;
     s1off[e] = it < m.It ? it * m.K2S + (m.ng > 1 ? (a / m.Rb) * m.Kg + a % m.Rb : a) : -1;     // gate-major for block-diagonal heads
   }
+  // inverse scales of the stage-2 sums, per output row i_h and column i_t (exact powers of two)
+  for (int e = tid; e < m.Ih; e += NT) unf[e] = ldexpf(1.f, -(hdr[m.It + 64 + e] + 13 + 9 + g2_r1_expo(m.Jt)));
+  for (int e = tid; e < m.It; e += NT) ung[e] = ldexpf(1.f, -hdr[e]);
   const int s1_rs = m.ng > 1 ? m.Rb : m.Rp;
   auto s1o = [&](int t1, int nt1) {
     const int base = s1off[t1 * 4 + q], jh = 16 * nt1 + c;
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     for (int u = 0; u < UPT; ++u)
       if (u < upt && tid + u * 256 < H && tid < 256) {
         _Float16 p0, p1;
-        split2h(hst[u] * (h0sc * gsc.hsc), p0, p1);
+        split2h(hst[u] * (h0sc * G2_HSC), p0, p1);
         hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
       }
   }
@@ -423,8 +427,14 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const _Float16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
   const int r_ybase = r_part * GH + (16 * r_mt + 4 * q) * m.It + 16 * r_nt + c;
   int r_ymask = 0;
+  f32x4 r_un = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                   // unf / ung are complete
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r_ymask |= (16 * r_nt + c < m.It && 16 * r_mt + 4 * q + j < m.Ih) ? (1 << j) : 0;
+  for (int j = 0; j < 4; ++j) {
+    const bool live = 16 * r_nt + c < m.It && 16 * r_mt + 4 * q + j < m.Ih;
+    r_ymask |= live ? (1 << j) : 0;
+    if (live) r_un[j] = unf[16 * r_mt + 4 * q + j] * ung[16 * r_nt + c];
+  }
   XChunk<TS> xq;                    // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -475,8 +485,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         if (fb != fa) one(fb, bpb, accb);        // wave-uniform (the second tile repeats the first when there is none): an
                                                  // MFMA under a lane-divergent branch would read masked-off operand loads
       }
-      if (offa >= 0) store_split4_h(img, plane, offa, acca * gsc.r1);     // 2^r: below 2^15 (g2_scales)
-      if (offb >= 0) store_split4_h(img, plane, offb, accb * gsc.r1);
+      if (offa >= 0) store_split4_h(img, plane, offa, acca * r1sc);     // 2^r: below 2^15
+      if (offb >= 0) store_split4_h(img, plane, offb, accb * r1sc);
     };
     auto stage1 = [&](auto frag) {
       if (s1_has) pair(frag, s1_fa, s1_fb, s1_bpa, s1_bpb, s1_oa, s1_ob);
@@ -536,10 +546,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const f32x4 acc = acc_hi + acc_lo;
         const int itc = 16 * nt + c;
         if (itc < m.It) {
+          const float ug = ung[itc];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int ih = 16 * mt + 4 * q + j;
-            if (ih < m.Ih) ybuf[part * GH + ih * m.It + itc] = acc[j];
+            if (ih < m.Ih) ybuf[part * GH + ih * m.It + itc] = acc[j] * (unf[ih] * ug);
           }
         }
       }
@@ -561,7 +572,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
           }
         }
-        const f32x4 acc = acc_hi + acc_lo;
+        const f32x4 acc = (acc_hi + acc_lo) * r_un;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (r_ymask & (1 << j)) ybuf[r_ybase + j * m.It] = acc[j];
@@ -588,7 +599,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
             for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] += ya[g] + k1 * yb[g];
           }
-          const float un_t = (t == 0 || !LSTM) ? unsc * h0un : unsc;
+          const float un_t = (t == 0 || !LSTM) ? h0un : 1.0f;  // (the diagonal scales were undone where the sums were stored)
 #pragma unroll
           for (int g = 0; g < (LSTM ? 4 : 3); ++g) y[g] *= un_t;         // exact: a power of two
           f32x4 g4 = gi[u];
@@ -619,7 +630,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
           hst[u] = hy;
           {
             _Float16 p0, p1;
-            split2h(hy * (LSTM ? gsc.hsc : gsc.hsc * h0sc), p0, p1);
+            split2h(hy * (LSTM ? G2_HSC : G2_HSC * h0sc), p0, p1);
             hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
           }
           // gate inputs of the NEXT step: requested after this step's last use of the registers and after its stores, used a
@@ -914,21 +925,23 @@ int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUN
 // merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
 // hdr_out: forward only (per-block maxima of the merged cores for the fp16 scales)
 int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
-         hipStream_t stream, const float** hdr_out = nullptr) {
+         hipStream_t stream, const int** hdr_out = nullptr) {
   char* p = (char*)ws;
   float* Gh = (float*)p; p += g2_al((size_t)m.head_elems * 4);
   float* Gt = (float*)p; p += g2_al((size_t)m.tail_elems * 4);
   xbf8* hs = (xbf8*)p; p += g2_al((size_t)(rev ? m.bs2_bytes : m.fs2_bytes));
   float* tf = (float*)p; p += g2_al((size_t)(rev ? m.bt1_bytes : m.ft1_bytes));
-  float* hdr = (float*)p;                     // forward only (g2_fwd_ws_bytes)
+  int* hdr = (int*)p;                         // forward only (g2_fwd_ws_bytes): exponents of the diagonal scales
   const int nblk = (int)g2_merge_blocks(m);
-  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt, rev ? (float*)nullptr : hdr);
+  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const float*)nullptr, 0);
-    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
+    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr);
   } else {
-    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const float*)hdr, nblk);
-    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KB1), dim3(64), 0, stream, m, Gt, tf, (const float*)hdr, nblk);
+    hipLaunchKernelGGL(k_g2_diag, dim3(1), dim3(1024), g2_diag_ints(m) * sizeof(unsigned), stream, m, (const float*)Gh,
+                       (const float*)Gt, hdr);
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const int*)hdr);
+    hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KB1), dim3(64), 0, stream, m, Gt, tf, (const int*)hdr);
     if (hdr_out) *hdr_out = hdr;
   }
   *fs = hs;
@@ -977,7 +990,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
-    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T);
+    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
     w.xpad = inp != rs.in ? g2_al((size_t)rs.B * rs.T * inp * 4) : 0;
   }
   w.lin = g2_al(plan_ttlinear_fwd(rs.in_s, in1 ? 1 : rs.in).ws_bytes);
@@ -1048,7 +1061,7 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   const xbf8* fs2;
   const float* ft1;
-  const float* hdr = nullptr;
+  const int* hdr = nullptr;
   st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream, &hdr);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
@@ -1063,7 +1076,7 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
                     : (p8 ? k_g2_fwd<CELLV, TS, UPTV, false, false, true> : k_g2_fwd<CELLV, TS, UPTV, false, false, false>); \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,       \
-                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (int)g2_merge_blocks(P.hid), (TS*)out, (TS*)hT,       \
+                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT,                                   \
                        (TS*)cT, reserve);                                                                                 \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {

@@ -5,6 +5,13 @@
 
 namespace ttrnn {
 
+// Device-side event counters (one small array per device, zeroed when first used): kernels cannot return a status through an
+// API that never synchronises, so the rare events a caller must be able to see are counted on the device and read —
+// with a synchronisation — only by ttrnn_device_status (include/ttrnn.h).
+// (TTRNN_STAT_* indices: include/ttrnn.h)
+unsigned* device_status_ptr();        // device pointer to TTRNN_STAT_COUNT counters of the current device (nullptr on failure)
+
+
 // number of CUs of the current device, queried once per device and process (a hipDeviceGetAttribute per launch showed up
 // in the 0.83 ms cfg2 step)
 inline int device_cu_count() {
@@ -27,6 +34,10 @@ inline int device_cu_count() {
 // CURRENT device's copy of the function, so the memo is keyed by the device id as well — a process that drives several GPUs
 // (or switches device between calls) gets the limit raised on each of them.  Thread-safe.
 int ensure_dynamic_lds(const void* fn, size_t bytes);
+// Can all `blocks` workgroups of one launch of `fn` be resident at the same time on an otherwise idle device (occupancy per
+// CU x CUs, cached per kernel)?  The two-workgroups-per-sample kernels poll each other and need it; what the query cannot see
+// — CUs held by another stream or process at run time — is caught by their bounded wait (NaN + TTRNN_STAT_PAIR_TIMEOUTS).
+bool resident_at_once(const void* fn, int block_threads, size_t dyn_lds, long blocks);
 
 // Where the recurrent kernels get the hoisted input projection from.
 //   in1 == 0: gin = fp32 [B][T][H][4], one gate-interleaved row per (b, t)
@@ -146,7 +157,7 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 
 // the same GEMM on two-piece fp16 operands (three MFMA terms instead of six; per-row scales of x and one scale of W,
 // powers of two): forward input projections.  `planes` as above (two of the three planes are used).
-size_t gemm_half_scratch_bytes(int64_t n_rows);
+size_t gemm_half_scratch_bytes(int64_t n_rows, int M);
 // the two scale passes (row maxima of x, maximum of W) are two more launches: below ~4 G multiply-adds the three-piece
 // bf16 GEMM (no passes) is as fast
 // bf16 GEMM (no passes) is as fast; option gemm_pieces = 2 / 3 forces either (A/B switch, tests)
@@ -171,12 +182,15 @@ int launch_rnn_fwd_big(const RnnShape& rs, int dtype, const void* x, const void*
 
 // the pair kernel of the merged two-core matrix on two-piece fp16 operands (ttrnn_fast_bigh.hip); scratch: bigh_workspace_bytes()
 size_t bigh_workspace_bytes();
+bool bigh_pair_resident(int dtype, int B);       // occupancy query: all 2B workgroups of the pair kernel resident at once?
 int launch_lstm_fwd_big2h(const RnnShape& rs, int dtype, const float* gin, const void* h0, const void* c0,
                           const float* m2_hid, const void* bias_in, const void* bias_hid, void* out, void* hT, void* cT,
                           float* reserve, unsigned long long* hxb, void* scratch, hipStream_t stream);
 
 // ... and its reverse-time counterpart (ttrnn_fast_bigbh.hip); fragT: ttrnn_fast_bigb.hip:k_bigb_prep's buffer
 size_t bigbh_workspace_bytes();
+bool bigbh_pair_resident(int dtype, int B);
+const float* bigbh_guard_rows(const void* scratch, int* n_rows);      // the row sums big_guard_tripped reads (ttrnn_big.h)
 int launch_lstm_bwd_big2h(const RnnShape& rs, int dtype, const void* c0, const float* fragT, const float* reserve,
                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
                           unsigned long long* hxb, void* scratch, hipStream_t stream);

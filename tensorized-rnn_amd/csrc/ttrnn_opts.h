@@ -27,6 +27,8 @@ enum OptId {
   OPT_F10_NB2,           // TTRNN_F10_NB2=1         B > #CUs: two samples per eight-wave workgroup instead of four-wave workgroups (A/B)
   OPT_GEMM_PIECES,       // TTRNN_GEMM_PIECES=0|2|3 forward input-projection GEMMs: 0 by size, 2 two fp16 pieces, 3 three bf16 pieces (A/B)
   OPT_BIG_FP32_MFMA,     // TTRNN_BIG_FP32_MFMA=1   big-shape pair kernel on the fp32 MFMA even in split mode (A/B)
+  OPT_PAIR_FAULT,        // TTRNN_PAIR_FAULT=1      tests only: the forward pair kernels are launched one workgroup short, so that
+                         //                         the time-out path (NaN poison + device status counter) can be exercised
   OPT_COUNT
 };
 

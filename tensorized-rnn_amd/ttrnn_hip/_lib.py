@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: libttrnn resolves libamdhip
 TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TTRNN_LIB_PATH: developer override (A/B-ing two builds of the library in one session); default = the in-tree build
@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ttrnn_abi_version": (ctypes.c_int, []),
     "ttrnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "ttrnn_device_available": (ctypes.c_int, []),
+    "ttrnn_device_status": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int]),
     "ttrnn_set_fp32_math": (ctypes.c_int, [ctypes.c_int]),
     "ttrnn_get_fp32_math": (ctypes.c_int, []),
     "ttrnn_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
@@ -154,6 +155,14 @@ def option(name, value):
         yield
     finally:
         set_option(name, prev)
+
+
+def device_status(reset=False):
+    """Device-side event counters (include/ttrnn.h: ttrnn_device_status; synchronises the current device):
+    {"pair_timeouts": ..., "guard_trips": ...}."""
+    buf = (ctypes.c_uint * 4)()
+    check(load().ttrnn_device_status(buf, 4, 1 if reset else 0), "ttrnn_device_status")
+    return {"pair_timeouts": int(buf[0]), "guard_trips": int(buf[1])}
 
 
 EPILOGUES = {None: 0, "log_softmax": 1, "relu_l2norm": 2}     # TTRNN_EPI_*

@@ -866,6 +866,97 @@ def test_split_math_operand_ranges(case, route):
     assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
 
 
+OUTLIER_SHAPES = {
+    # name: (module meta, B, T, route the forward must take in split mode, options for the split run)
+    "fused_core_r8": (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 3, 5, "fused_core", {}),
+    "fused_core_r16": (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=1, n_cores=3, tt_rank=16), 90, 4, "fused_core",
+                       {"gemm_pieces": 2}),
+    "runtime_mfma": (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 5, 5, "runtime_mfma", {}),
+    "runtime_mfma_d3": (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 3, 5, "runtime_mfma",
+                        {"force_g2": 1}),
+    "runtime_mfma_gru": (dict(kind="ttgru", input_size=40, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4), 20, 5, "runtime_mfma", {}),
+    "merged_big": (dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32), 2, 3, "merged_big", {}),
+}
+
+
+@pytest.mark.parametrize("case", ["hid_core0_1e3", "hid_core1_1e5", "hid_corelast_1e7", "hid_corelast_1e5", "h0_unit_1e4",
+                                  "in_core_1e6", "x_elem_1e6"])
+@pytest.mark.parametrize("shape", sorted(OUTLIER_SHAPES))
+def test_split_math_outlier_up(shape, case):
+    """ONE large value inside an otherwise ordinary operand: a single core entry x 1e3 / 1e5 / 1e7, one unit of
+    h_0 x 1e4 inside an N(0, 0.1) state, one entry of an input-matrix core x 1e6 (a column band of the dense W_in), one element
+    of x x 1e6.  Power-of-two scales taken from an operand's MAXIMUM would push every other entry 10-23 binades down and
+    cost the two-piece fp16 operands 5-12 of their 22 bits — silently, on the bulk of the operand.  The scales are diagonal
+    (per row / column / rank slice of the cores, per row of x: ttrnn_f10_dev.h, ttrnn_g2.hip, ttrnn_fast_bigh.hip,
+    ttrnn_fast_gemm.hip), so the split mode must stay where the fp32-MFMA / fp32-FMA mode is against float64."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    meta, B, T, route, opts = OUTLIER_SHAPES[shape]
+    torch.manual_seed(41)
+    m = build_module(meta, dev())
+    H, inp = meta["hidden_size"], meta["input_size"]
+    lstm = meta["kind"] == "ttlstm"
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, T, inp, generator=g)
+    h0 = torch.randn(B, H, generator=g) * 0.1
+    c0 = torch.randn(B, H, generator=g) * 0.3
+    hid = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+    inw = [p for n, p in m.named_parameters() if "input_weights.parameters" in n]
+
+    def bump(core, factor, pos=(7, 13)):
+        with torch.no_grad():
+            flat = core.detach().clone().contiguous().view(-1)
+            flat[(pos[0] * flat.numel()) // pos[1]] *= factor
+            core.copy_(flat.view(core.shape))
+
+    if case == "hid_core0_1e3":
+        bump(hid[0], 1e3)
+    elif case == "hid_core1_1e5":
+        bump(hid[min(1, len(hid) - 1)], 1e5)
+    elif case == "hid_corelast_1e7":
+        bump(hid[-1], 1e7)
+    elif case == "hid_corelast_1e5":
+        bump(hid[-1], 1e5, (5, 11))
+    elif case == "h0_unit_1e4":
+        h0[:, 77 % H] *= 1e4
+    elif case == "in_core_1e6":
+        bump(inw[-1], 1e6)
+    elif case == "x_elem_1e6":
+        x[1, 2, 3 % inp] *= 1e6
+        x[B - 1, 0, inp - 1] *= 1e6
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    init = (h0.double(), c0.double()) if lstm else h0.double()
+    ref = _oracle_forward(meta["kind"], sd, 1, x.double(), init)
+    r64 = ref[0]
+    scale = max(1.0, float(r64.abs().max()), float(ref[2].abs().max()) if lstm else 0.0)
+    errs = {}
+    for mode in ("exact", "split"):
+        with contextlib.ExitStack() as stack:
+            stack.enter_context(ttrnn_hip.fp32_math(mode))
+            if mode == "split":
+                for k, v in opts.items():
+                    stack.enter_context(ttrnn_hip.option(k, v))
+                assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == route
+            with torch.no_grad():
+                res = m(x.to(dev()), (h0.to(dev()), c0.to(dev())) if lstm else h0.to(dev()))
+        out = res[0]
+        assert torch.isfinite(out).all(), (shape, case, mode)
+        errs[mode] = _maxabs(out, r64)
+        if lstm:
+            errs[mode] = max(errs[mode], _maxabs(res[1][1], ref[2]))
+    print(shape, case, "max abs error vs float64 (state scale %.3g):" % scale, errs)
+    # the yardstick is the library's own fp32 arithmetic on the same input (saturated gates and pre-activations in the
+    # millions amplify one fp32 ulp whatever the mode); the floor is a few ulps of the state's scale.
+    # Factor 3 wherever the large value sits in a WEIGHT or in x.  Two cases show the format itself instead — two fp16 pieces
+    # carry 22 significand bits against fp32's 24, i.e. up to 8x the relative error of ONE product: (a) a GRU computes
+    # n = tanh(in_n + r * hid_n) (gru.py:42-43) — with |hid_n| ~ 1e4 behind a large core entry the product r * hid_n feeds a
+    # non-saturated tanh, so the relative precision of that single sum is what the state sees (an LSTM's gates just
+    # saturate); (b) one unit of h_0 x 1e4: the scale of h_0 is per SAMPLE (it is the dynamic operand), so for one step the
+    # other units of that sample keep 17-19 bits; both modes then sit at 1e-6 ... 1e-5 of a pre-activation in the hundreds.
+    factor = 8.0 if (meta["kind"] == "ttgru" or case == "h0_unit_1e4") else 3.0
+    assert errs["split"] <= factor * errs["exact"] + 4e-7 * scale
+
+
 @pytest.mark.parametrize("kind", ["ttgru", "ttlstm"])
 def test_runtime_tier_initial_state_far_outside_unit_range(kind):
     """The runtime-shape tier's fp16 stage-2 operands assume |h| <= 1; a caller's h_0 is carried with a per-sample power of
@@ -1328,6 +1419,89 @@ def test_big_shape_gradients_vs_oracle():
         assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
     for got, ref in ((xg.grad, xr.grad), (h0g.grad, h0r.grad), (c0g.grad, c0r.grad)):
         assert _maxabs(got, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6)
+
+
+def test_big_shape_reverse_kernel_guard_falls_back_on_outlier_weights():
+    """The cfg5-class reverse-time kernel carries each transposed merged core under ONE power-of-two scale.  One core entry
+    x 1e6 would push the rest of the matrix into fp16's subnormal range; the prep kernel measures the pieces' representation
+    error per row, the fp16 kernel steps aside (device counter guard_trips) and the fp32-MFMA pair kernel queued behind it
+    runs instead: gradients must be as good as with the fp32-MFMA kernel selected by hand, and an ordinary model must NOT
+    trip the guard."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(95)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 3, 4
+    x = torch.randn(B, T, 1024)
+    h0, c0 = torch.randn(B, 1024) * 0.3, torch.randn(B, 1024) * 0.3
+    w = torch.randn(B, T, 1024)
+
+    def grads(opts):
+        m.zero_grad()
+        with contextlib.ExitStack() as stack:
+            for k, v in opts.items():
+                stack.enter_context(ttrnn_hip.option(k, v))
+            xg = x.to(dev()).requires_grad_(True)
+            out, (hT, cT) = m(xg, (h0.to(dev()), c0.to(dev())))
+            ((out * w.to(dev())).sum() + cT.sum()).backward()
+        return {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters()}, xg.grad.double().cpu()
+
+    ttrnn_hip.device_status(reset=True)
+    grads({})
+    assert ttrnn_hip.device_status()["guard_trips"] == 0            # fresh init: the fp16 kernel runs
+    with torch.no_grad():
+        core = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n][1]
+        flat = core.detach().clone().contiguous().view(-1)
+        flat[(5 * flat.numel()) // 11] *= 1e6
+        core.copy_(flat.view(core.shape))
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0.double(), c0.double()))
+    ((ro * w.double()).sum() + rc.sum()).backward()
+    got, gx = grads({})
+    assert ttrnn_hip.device_status()["guard_trips"] >= 1            # ... and stepped aside here
+    ref32, gx32 = grads({"big_fp32_mfma": 1})
+    worst = {"guarded": 0.0, "fp32_mfma": 0.0}
+    for n, _ in m.named_parameters():
+        ref = leaves[n].grad
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["guarded"] = max(worst["guarded"], _maxabs(got[n], ref) / sc)
+        worst["fp32_mfma"] = max(worst["fp32_mfma"], _maxabs(ref32[n], ref) / sc)
+    sx = max(float(xr.grad.abs().max()), 1e-30)
+    worst["guarded"] = max(worst["guarded"], _maxabs(gx, xr.grad) / sx)
+    worst["fp32_mfma"] = max(worst["fp32_mfma"], _maxabs(gx32, xr.grad) / sx)
+    print("max gradient error relative to each tensor's maximum:", worst)
+    assert worst["guarded"] <= 3.0 * worst["fp32_mfma"] + 1e-6
+
+
+def test_pair_kernel_timeout_poisons_and_is_counted():
+    """The two-workgroups-per-sample kernels wait for their partner with a bounded spin.  Option pair_fault launches the
+    forward pair kernel one workgroup short (the last sample's partner never runs): that sample must come out as NaN —
+    never as a plausible result — the other samples must be untouched, and the event must be visible through
+    ttrnn_device_status (counter pair_timeouts), in both math modes (fp16-piece and fp32-MFMA pair kernels)."""
+    import ttrnn_hip
+    torch.manual_seed(96)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    B, T = 3, 3
+    x = torch.randn(B, T, 1024, device=dev())
+    for mode in ("split", "exact"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            good, (gh, gc) = m(x)
+            ttrnn_hip.device_status(reset=True)
+            with ttrnn_hip.option("pair_fault", 1):
+                out, (hT, cT) = m(x)
+            torch.cuda.synchronize()
+        st = ttrnn_hip.device_status(reset=True)
+        assert st["pair_timeouts"] > 0, (mode, st)
+        assert torch.isnan(hT[B - 1]).any() and torch.isnan(cT[B - 1]).any(), mode
+        assert torch.equal(out[:B - 1], good[:B - 1]) and torch.equal(hT[:B - 1], gh[:B - 1]), mode
+    with torch.no_grad():
+        again, _ = m(x)                                   # the next ordinary launch is unaffected
+    assert torch.isfinite(again).all() and ttrnn_hip.device_status()["pair_timeouts"] == 0
 
 
 @pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps"])

@@ -138,7 +138,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.ttrnn_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ttrnn_abi_version() == _lib.ABI_VERSION == 3
     assert lib.ttrnn_status_string(0) == b"ok"
     assert b"workspace" in lib.ttrnn_status_string(-4)
 
@@ -166,10 +166,10 @@ def test_descriptor_validation_without_gpu():
                         TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True).desc(64, 784, 0)
     # gate inputs fp32 [B][T][H][4] + the fused-core fragments of the hidden AND of the (hidden-shaped) input matrix
     # + the dense-GEMM K-in: identity rows [in][in], dense W_in [in][4H] (fp32), its 16-bit planes (room for three) and
-    # the two-piece fp16 GEMM's scales (256-byte header + one fp32 per row of x)
+    # the two-piece fp16 GEMM's scales (one fp32 per column of W_in + one per row of x)
     assert lib.ttrnn_rnn_workspace(ctypes.byref(wide)) == (64 * 784 * 256 * 4 * 4 + 2 * 4 * 8 * 3 * 1024 +
                                                            256 * 256 * 4 + 256 * 1024 * 4 + 3 * 256 * 1024 * 2 +
-                                                           256 + 64 * 784 * 4)
+                                                           1024 * 4 + 64 * 784 * 4)
     tiny = RnnLayerSpec("gru", 28, 64, TTSpec([4, 7], [12, 16], [1, 3, 1]), TTSpec([8, 8], [12, 16], [1, 3, 1]),
                         True, True).desc(3, 6, 0)
     # no shape-specialised kernel: the runtime-shape MFMA route (ttrnn_g2.hip), whose workspace holds the hoisted input
