@@ -128,7 +128,8 @@ int ttrnn_get_fp32_math(void);
  *   "fp32_math" (TTRNN_MATH_*), "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag",
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
- *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path).
+ *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path),
+ *   "no_gemm3", "dev" (0..255: developer bit mask of the harnesses under tools/).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
 int ttrnn_set_option(const char* name, int value);

@@ -25,13 +25,14 @@ struct OptTable {
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
         "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES",
-        "TTRNN_BIG_FP32_MFMA", "TTRNN_PAIR_FAULT"};
+        "TTRNN_BIG_FP32_MFMA", "TTRNN_PAIR_FAULT", "TTRNN_NO_GEMM3", "TTRNN_DEV"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
       else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
+      else if (i == OPT_DEV) val = e ? (atoi(e) & 255) : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -44,7 +45,7 @@ OptTable& table() {
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
     "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces", "big_fp32_mfma",
-    "pair_fault"};
+    "pair_fault", "no_gemm3", "dev"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }
@@ -60,7 +61,8 @@ int opt_set(const char* name, int value) {
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
   if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
-  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && value != 0 && value != 1) return -1;
+  if (i == OPT_DEV && (value < 0 || value > 255)) return -1;
+  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;
 }
@@ -451,7 +453,7 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   // K-in as a dense split-bf16 GEMM (ttrnn_fast_gemm.hip): identity rows, dense W_in, its bf16 planes
   if (f.f10_lin_bytes > 0 && rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 && gemm_split_ok(rs.in, 4 * rs.H))
     f.gemm_bytes = gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) +
-                   gemm_split_plane_bytes(rs.in, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
+                   gemm_split_plane_bytes(rs.in, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, rs.in, 4 * rs.H);
   return f;
 }
 

@@ -540,7 +540,7 @@ static int big_merge_level() { return opt(OPT_BIG_MERGE); }
 
 static size_t big_gemm_bytes(const RnnShape& rs) {
   return gemm_split_identity_bytes(rs.in) + gemm_split_dense_bytes(rs.in, 4 * rs.H) + gemm_split_plane_bytes(rs.in, 4 * rs.H) +
-         gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
+         gemm_half_scratch_bytes((int64_t)rs.B * rs.T, rs.in, 4 * rs.H);
 }
 
 size_t big_rnn_fwd_workspace(const RnnShape& rs) {

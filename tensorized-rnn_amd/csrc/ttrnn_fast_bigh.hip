@@ -57,43 +57,74 @@ __device__ __forceinline__ int frag_index(int kk, int m) {
 //   head   W_0'[(j_0, a)][i_h] = W_0 2^(ep[i_h] - ev[a])           each output row i_h: max < 2^14
 //   sums   2^(13 + 9 - 13 + ep[i_h] + eu[i_t]) x the pre-activation of (i_h, i_t)
 // so one large core entry moves only the scale of its own row / slice (round 2: one scale per merged core).
-constexpr int BH_EU = 0, BH_EV = 64, BH_EP = 96, BH_HDR_BYTES = 1024;
+constexpr int BH_EU = 0, BH_EV = 64, BH_EP = 96, BH_PART = 160, BH_HDR_BYTES = 16384;      // BH_PART: [I_t][R_1] partial maxima (floats)
 constexpr float BH_HSC = 512.0f, BH_R1SC = 1.0f / 8192.0f;
 
-// one workgroup over the two merged cores (fragment-ordered fp32, L2-resident)
-__global__ void __launch_bounds__(1024) k_bigh_diag(const float* __restrict__ packed2, int* __restrict__ hdr) {
-  __shared__ unsigned mu[BH_I1], mv[BH_R1], mp[64];
-  __shared__ int eu[BH_I1], ev[BH_R1];
-  const int tid = threadIdx.x;
-  if (tid < BH_I1) { mu[tid] = 0u; mp[tid] = 0u; }
-  if (tid < BH_R1) mv[tid] = 0u;
-  __syncthreads();
+// two launches over the merged cores (fragment-ordered fp32, L2-resident), as ttrnn_g2.hip:k_g2_diag_a / _b:
+//   k_bigh_diag_a  one workgroup per i_t: eu[i_t], part[i_t][a] = max_{j_t} 2^eu |W_1|
+//   k_bigh_diag_b  one workgroup per i_h: ev (reduced by every workgroup, stored by the first), ep[i_h]
+__global__ void __launch_bounds__(256) k_bigh_diag_a(const float* __restrict__ packed2, int* __restrict__ hdr) {
+  __shared__ float red[4];
+  __shared__ unsigned mv[BH_R1];
+  __shared__ int eus;
+  const int tid = threadIdx.x, it = blockIdx.x;
   const float* W1 = packed2 + woff_of<S2>(1);
+  float* part = reinterpret_cast<float*>(hdr) + BH_PART;
+  if (tid < BH_R1) mv[tid] = 0u;
+  float v[8];                                    // 64 (j_t) x 32 (a) entries of this i_t: 8 per thread, a = tid % 32
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = fabsf(W1[frag_index<1>((tid >> 5) + 8 * i, it * BH_R1 + (tid & 31))]);
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mx = fmaxf(mx, v[i]);
+  float ma = mx;                                 // this thread's maximum for its a
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    eus = -f10h_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    hdr[BH_EU + it] = eus;
+  }
+  __syncthreads();
+  atomicMax(&mv[tid & 31], __float_as_uint(ma * ldexpf(1.f, eus)));
+  __syncthreads();
+  if (tid < BH_R1) part[it * BH_R1 + tid] = __uint_as_float(mv[tid]);
+}
+__global__ void __launch_bounds__(256) k_bigh_diag_b(const float* __restrict__ packed2, int* __restrict__ hdr) {
+  __shared__ float red[4];
+  __shared__ float pv[8][BH_R1];
+  __shared__ int ev[BH_R1];
+  const int tid = threadIdx.x, ih = blockIdx.x;
   const float* W0 = packed2 + woff_of<S2>(0);
-  constexpr int N1 = T1::K * T1::M, N0 = T0::K * T0::M;
-  // element e of stage k: (kk, m) = (e / M, e % M) through frag_index (any enumeration covers every element once)
-  for (int e = tid; e < N1; e += 1024) {
-    const int kk = e / T1::M, m = e % T1::M;
-    atomicMax(&mu[m / BH_R1], __float_as_uint(fabsf(W1[frag_index<1>(kk, m)])));
+  const float* part = reinterpret_cast<const float*>(hdr) + BH_PART;
+  {
+    const int a = tid & 31, g = tid >> 5;
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < BH_I1 / 8; ++i) mx = fmaxf(mx, part[(g + 8 * i) * BH_R1 + a]);
+    pv[g][a] = mx;
   }
   __syncthreads();
-  if (tid < BH_I1) eu[tid] = -f10h_expo(__uint_as_float(mu[tid]));
-  __syncthreads();
-  for (int e = tid; e < N1; e += 1024) {
-    const int kk = e / T1::M, m = e % T1::M;
-    atomicMax(&mv[m % BH_R1], __float_as_uint(fabsf(W1[frag_index<1>(kk, m)]) * ldexpf(1.f, eu[m / BH_R1])));
+  if (tid < BH_R1) {
+    float mx = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mx = fmaxf(mx, pv[g][tid]);
+    ev[tid] = -f10h_expo(mx);
+    if (ih == 0) hdr[BH_EV + tid] = ev[tid];
   }
   __syncthreads();
-  if (tid < BH_R1) ev[tid] = -f10h_expo(__uint_as_float(mv[tid]));
-  __syncthreads();
-  for (int e = tid; e < N0; e += 1024) {
-    const int kk = e / T0::M, m = e % T0::M;                // kk = j0 * R1 + a
-    atomicMax(&mp[m], __float_as_uint(fabsf(W0[frag_index<0>(kk, m)]) * ldexpf(1.f, -ev[kk % BH_R1])));
+  float mx = 0.f;                                // row i_h of W_0: 512 entries kk = j0 * R1 + a, two per thread
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kk = tid + 256 * i;
+    mx = fmaxf(mx, fabsf(W0[frag_index<0>(kk, ih)]) * ldexpf(1.f, -ev[kk % BH_R1]));
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  if (tid < BH_I1) hdr[BH_EU + tid] = eu[tid];
-  if (tid < BH_R1) hdr[BH_EV + tid] = ev[tid];
-  if (tid < 64) hdr[BH_EP + tid] = 14 - f10h_expo(__uint_as_float(mp[tid]));
+  if (tid == 0) hdr[BH_EP + ih] = 14 - f10h_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 // fragment streams (16-byte entries, one per lane):
@@ -374,8 +405,9 @@ static int launch_bigh_t(const RnnShape& rs, const float* gin, const void* h0, c
   int* hdr = (int*)scratch;
   xh8* f1 = (xh8*)((char*)scratch + BH_HDR_BYTES);
   xh8* f0 = f1 + BH_F1;
-  static_assert((BH_EP + 64) * sizeof(int) <= BH_HDR_BYTES, "header");
-  hipLaunchKernelGGL(k_bigh_diag, dim3(1), dim3(1024), 0, stream, m2_hid, hdr);
+  static_assert((BH_PART + BH_I1 * BH_R1) * sizeof(int) <= BH_HDR_BYTES && T1::K == 64 && T0::K == 512 && T0::M == 64, "header");
+  hipLaunchKernelGGL(k_bigh_diag_a, dim3(BH_I1), dim3(256), 0, stream, m2_hid, hdr);
+  hipLaunchKernelGGL(k_bigh_diag_b, dim3(64), dim3(256), 0, stream, m2_hid, hdr);
   hipLaunchKernelGGL(k_bigh_prep, dim3((BH_F1 / 2 + BH_F0 / 2 + 255) / 256), dim3(256), 0, stream, m2_hid, (const int*)hdr, f1, f0);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   // stage-0 image (64 KB) + the LDS-resident quarter of the stage-1 fragments (64 KB): one workgroup per CU

@@ -779,9 +779,13 @@ bool gemm_use_half(int64_t n_rows, int K, int M) {
   return (double)n_rows * K * M >= 4294967296.0;
 }
 
-// two-piece fp16 variant: scratch = one fp32 scale per column of W (M, padded) + one per row of x
-size_t gemm_half_scratch_bytes(int64_t n_rows, int M) {
+// two-piece fp16 variant: scratch = one fp32 scale per column of W (M, padded) + one per row of x (+ the pre-split pieces of
+// x where the pre-split GEMM of ttrnn_fast_gemm3.hip takes the launch)
+static size_t half_scales_bytes(int64_t n_rows, int M) {
   return al256g(g_rs_off(M) * sizeof(float) + (size_t)(n_rows > 0 ? n_rows : 0) * sizeof(float));
+}
+size_t gemm_half_scratch_bytes(int64_t n_rows, int K, int M) {
+  return half_scales_bytes(n_rows, M) + (gemm3_ok(n_rows, K, M) ? gemm3_xplane_bytes(n_rows, K) : 0);
 }
 
 int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream, bool transposed) {
@@ -824,6 +828,9 @@ static bool gemm_wide_tiles(int64_t n_rows, int M) { return M % (2 * GT) == 0 &&
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
                      const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
   if (n_rows <= 0) return TTRNN_OK;
+  if (gemm3_ok(n_rows, K, M))       // x split once into fp16 planes, both operands by LDS-DMA (ttrnn_fast_gemm3.hip)
+    return launch_gemm3h(dtype, n_rows, K, M, x, planes, scratch, (char*)scratch + half_scales_bytes(n_rows, M), bias, Hb, y,
+                         stream, bias_ilv);
   float* rs = (float*)scratch + g_rs_off(M);
   const int grid = (int)((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
   if (dtype == TTRNN_F32) {

@@ -202,12 +202,12 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
-// forward: + the int32 exponents of the diagonal scales (k_g2_diag): [I_t | 64 | I_h]
+// forward: + the int32 exponents of the diagonal scales (k_g2_diag_a / _b): [I_t | 64 | I_h], then [I_t][64] partial maxima
 inline long g2_merge_blocks(const G2Mat& m) { return ((long)m.Ih * m.Jh + (long)m.It * m.Jt + 255) / 256; }
 inline size_t g2_diag_ints(const G2Mat& m) { return (size_t)m.It + 64 + (size_t)m.Ih; }
 inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes) +
-         g2_al(g2_diag_ints(m) * sizeof(int));
+         g2_al(g2_diag_ints(m) * sizeof(int) + (size_t)m.It * 64 * sizeof(float));
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);

@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
 //   stage-1 sums     < J_t 2^22, times the fixed r1 = 2^(15 - 22 - ceil(log2 J_t)) < 2^15 before they are split
 //   head fragments   Gh'[i_h][(j_h, a)] = Gh 2^(ep[i_h] - ev[a])           each row: max < 2^14
 //   stage-2 sums     y'[i_h][i_t] = 2^(13 + 9 + r + ep[i_h] + eu[i_t]) y: undone (exactly) where the sums are stored
-// eu, ev, ep: int32 exponents computed once per launch by k_g2_diag from the merged cores, hdr = [eu: I_t | ev: 64 | ep: I_h].
+// eu, ev, ep: int32 exponents computed once per launch by k_g2_diag_a / _b from the merged cores, hdr = [eu: I_t | ev: 64 | ep: I_h]
+// (followed by the [I_t][64] partial maxima the two kernels hand over).
 __device__ __forceinline__ int g2_expo(float x) {          // x < 2^e; zero / non-finite: neutral
   if (!(x > 0.f)) return 0;
   if (!(x < 3e38f)) return 40;
@@ -98,42 +99,71 @@ __device__ __forceinline__ int g2_r1_expo(int Jt) {
   while ((1 << ej) < Jt) ++ej;                             // J_t <= 2^ej
   return 15 - 22 - ej;
 }
-// one workgroup of 1024 threads over the merged cores (L2-resident, <= a few hundred KB):
-//   eu[i_t] = -expo(max_{a, j_t} |Gt|),  ev[a] = -expo(max_{i_t, j_t} 2^eu |Gt|),  ep[i_h] = 14 - expo(max_{j_h, a} 2^-ev |Gh|)
-__global__ void __launch_bounds__(1024) k_g2_diag(G2Mat m, const float* __restrict__ Gh, const float* __restrict__ Gt,
-                                                  int* __restrict__ hdr) {
-  extern __shared__ unsigned g2d_mx[];                     // [I_t | 64 | I_h]
-  unsigned* mu = g2d_mx;
-  unsigned* mv = g2d_mx + m.It;
-  unsigned* mp = mv + 64;
-  int* eu = hdr;
-  int* ev = hdr + m.It;
-  int* ep = ev + 64;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < m.It + 64 + m.Ih; i += 1024) g2d_mx[i] = 0u;
+// Two launches over the merged cores (L2-resident), every load independent of the others:
+//   k_g2_diag_a  one workgroup per i_t:  eu[i_t] = -expo(max_{a, j_t} |Gt|), and part[i_t][a] = max_{j_t} 2^eu |Gt|
+//   k_g2_diag_b  one workgroup per i_h:  ev[a] = -expo(max_{i_t} part[i_t][a])  (every workgroup reduces it for itself; the
+//                first one stores it),   ep[i_h] = 14 - expo(max_{j_h, a} 2^-ev |Gh|)
+// (one 1024-thread workgroup walking both cores with LDS atomics was a chain of dependent L2 latencies: > 100 us.)
+__global__ void __launch_bounds__(256) k_g2_diag_a(G2Mat m, const float* __restrict__ Gt, int* __restrict__ hdr,
+                                                   float* __restrict__ part) {
+  __shared__ float red[4];
+  __shared__ unsigned mv[64];
+  __shared__ int eus;
+  const int tid = threadIdx.x, it = blockIdx.x;
+  const float* row = Gt + (size_t)it * m.Jt * m.R;
+  const int n = m.Jt * m.R;
+  if (tid < 64) mv[tid] = 0u;
+  float mx = 0.f;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, fabsf(row[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  const long nt = (long)m.It * m.Jt * m.R, nh = (long)m.Ih * m.Jh * m.R;
-  const long rowt = (long)m.Jt * m.R, rowh = (long)m.Jh * m.R;
-  for (long i = tid; i < nt; i += 1024) atomicMax(&mu[i / rowt], __float_as_uint(fabsf(Gt[i])));   // |x| orders like its bits
+  if (tid == 0) {
+    eus = -g2_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    hdr[it] = eus;
+  }
   __syncthreads();
-  for (int i = tid; i < m.It; i += 1024) { const int e = -g2_expo(__uint_as_float(mu[i])); eu[i] = e; mu[i] = (unsigned)e; }
+  const float sc = ldexpf(1.f, eus);
+  for (int i = tid; i < n; i += 256) atomicMax(&mv[i % m.R], __float_as_uint(fabsf(row[i]) * sc));   // |x| orders like its bits
   __syncthreads();
-  for (long i = tid; i < nt; i += 1024)
-    atomicMax(&mv[i % m.R], __float_as_uint(fabsf(Gt[i]) * ldexpf(1.f, (int)mu[i / rowt])));
+  if (tid < 64) part[(size_t)it * 64 + tid] = __uint_as_float(mv[tid]);
+}
+__global__ void __launch_bounds__(256) k_g2_diag_b(G2Mat m, const float* __restrict__ Gh, int* __restrict__ hdr,
+                                                   const float* __restrict__ part) {
+  __shared__ float red[4];
+  __shared__ float pv[4][64];
+  __shared__ int ev[64];
+  const int tid = threadIdx.x, ih = blockIdx.x;
+  {
+    const int a = tid & 63, g = tid >> 6;
+    float mx = 0.f;
+    for (int it = g; it < m.It; it += 4) mx = fmaxf(mx, part[(size_t)it * 64 + a]);
+    pv[g][a] = mx;
+  }
   __syncthreads();
-  if (tid < 64) { const int e = tid < m.R ? -g2_expo(__uint_as_float(mv[tid])) : 0; ev[tid] = e; mv[tid] = (unsigned)e; }
+  if (tid < 64) {
+    const int e = tid < m.R ? -g2_expo(fmaxf(fmaxf(pv[0][tid], pv[1][tid]), fmaxf(pv[2][tid], pv[3][tid]))) : 0;
+    ev[tid] = e;
+    if (ih == 0) hdr[m.It + tid] = e;
+  }
   __syncthreads();
-  for (long i = tid; i < nh; i += 1024)
-    atomicMax(&mp[i / rowh], __float_as_uint(fabsf(Gh[i]) * ldexpf(1.f, -(int)mv[i % m.R])));
+  const float* row = Gh + (size_t)ih * m.Jh * m.R;
+  const int n = m.Jh * m.R;
+  float mx = 0.f;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, fabsf(row[i]) * ldexpf(1.f, -ev[i % m.R]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  for (int i = tid; i < m.Ih; i += 1024) ep[i] = 14 - g2_expo(__uint_as_float(mp[i]));
+  if (tid == 0) hdr[m.It + 64 + ih] = 14 - g2_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
 // head stream (bf16 x 3 planes): block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl)*3 planes * 64 lanes
 //   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
 //   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
-// forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag), block stride 2 * 64 lanes; reverse: three bf16 planes
+// forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag_a / _b), block stride 2 * 64 lanes; reverse: three bf16 planes
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs,
                                                      const int* __restrict__ hdr) {
@@ -178,7 +208,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
           split3(v, p0, p1, p2);
           f0[e] = p0; f1[e] = p1; f2[e] = p2;
         } else {
-          _Float16 p0, p1;                        // 2^(ep[i_h] - ev[a]) Gh (k_g2_diag)
+          _Float16 p0, p1;                        // 2^(ep[i_h] - ev[a]) Gh (k_g2_diag_a / _b)
           if (ih < m.Ih && jh < m.Jh && a < m.R) v *= ldexpf(1.f, hdr[m.It + 64 + ih] - hdr[m.It + a]);
           split2h(v, p0, p1);
           g0[e] = p0; g1[e] = p1;
@@ -302,7 +332,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);
   float* unf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // [I_h]: 2^-(ep + 13 + 9 + r), then
-  float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag)
+  float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag_a / _b)
   xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab + P.f_sc); // tail fragments (P.f_t1 > 0)
   const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
   const int plane = 16 * m.N2T * m.K2S;
@@ -938,8 +968,9 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
     hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
     hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr);
   } else {
-    hipLaunchKernelGGL(k_g2_diag, dim3(1), dim3(1024), g2_diag_ints(m) * sizeof(unsigned), stream, m, (const float*)Gh,
-                       (const float*)Gt, hdr);
+    float* dpart = (float*)(hdr + g2_diag_ints(m));
+    hipLaunchKernelGGL(k_g2_diag_a, dim3(m.It), dim3(256), 0, stream, m, (const float*)Gt, hdr, dpart);
+    hipLaunchKernelGGL(k_g2_diag_b, dim3(m.Ih), dim3(256), 0, stream, m, (const float*)Gh, hdr, (const float*)dpart);
     hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const int*)hdr);
     hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KB1), dim3(64), 0, stream, m, Gt, tf, (const int*)hdr);
     if (hdr_out) *hdr_out = hdr;
@@ -990,7 +1021,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
-    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, 4 * rs.H);
+    w.planes = gemm_split_plane_bytes(inp, 4 * rs.H) + gemm_half_scratch_bytes((int64_t)rs.B * rs.T, inp, 4 * rs.H);
     w.xpad = inp != rs.in ? g2_al((size_t)rs.B * rs.T * inp * 4) : 0;
   }
   w.lin = g2_al(plan_ttlinear_fwd(rs.in_s, in1 ? 1 : rs.in).ws_bytes);

@@ -192,10 +192,15 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_fwd(TtShape s, int64_t n_ro
   }
 }
 
-template <typename T, typename TDY, bool BUF_GLOBAL, bool ACC_LDS>
+// ACC: 0 = atomics from every row straight into d_packed / d_bias; 1 = accumulators in LDS, one atomic flush per workgroup;
+// 2 = accumulators too large for LDS (a classifier head 1024 -> 256 with rank 32: 200 KB): a private global slab per
+// workgroup, plain adds (L2-resident), summed into d_packed / d_bias by k_slab_reduce — 33 k atomics per row from 128
+// workgroups into ONE buffer cost 1.85 ms of cfg5's training step
+template <typename T, typename TDY, bool BUF_GLOBAL, int ACC>
 __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_rows, int nb, int bs, int ss,
                                                          const float* packed, const T* x, const TDY* dy, T* dx,
-                                                         float* d_packed, float* d_bias, float* ws) {
+                                                         float* d_packed, float* d_bias, float* ws, float* slabs) {
+  constexpr bool ACC_LDS = ACC == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DevExec ex;
   float* p = smem;
@@ -213,13 +218,20 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_ro
     if (d_bias) { dbacc = p; p += s.out_size; for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) dbacc[e] = 0.f; }
     __syncthreads();
   }
+  if (ACC == 2) {
+    float* slab = slabs + (size_t)blockIdx.x * ((size_t)s.wtotal + s.out_size);
+    if (d_packed) { dWacc = slab; for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) dWacc[e] = 0.f; }
+    if (d_bias) { dbacc = slab + s.wtotal; for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) dbacc[e] = 0.f; }
+    __threadfence_block();
+    __syncthreads();
+  }
   const float* W = packed;
   const float* Wt = packed + s.wtotal;
   const int64_t ntiles = (n_rows + nb - 1) / nb;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * nb;
     const int n = (int)tmin<int64_t>(nb, n_rows - n0);
-    if (ACC_LDS)
+    if (ACC_LDS || ACC == 2)
       ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddPlain());
     else
       ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddAtomic());
@@ -229,6 +241,19 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_ro
     if (d_packed) for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) { const float v = dWacc[e]; if (v != 0.f) atomicAdd(d_packed + e, v); }
     if (d_bias) for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) { const float v = dbacc[e]; if (v != 0.f) atomicAdd(d_bias + e, v); }
   }
+}
+
+// dst[e] += sum over the `grid` slabs (each [wtotal | out] floats) of slab[e]  (k_ttlinear_bwd, ACC = 2)
+__global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ slabs, int grid, int wtotal, int out,
+                                                     float* __restrict__ d_packed, float* __restrict__ d_bias) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = wtotal + out;
+  if (e >= per) return;
+  float* dst = e < wtotal ? (d_packed ? d_packed + e : nullptr) : (d_bias ? d_bias + (e - wtotal) : nullptr);
+  if (!dst) return;
+  float v = 0.f;
+  for (int g = 0; g < grid; ++g) v += slabs[(size_t)g * per + e];
+  *dst += v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,6 +430,20 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
   const int64_t ntiles = (n_rows + p.nb - 1) / p.nb;
   p.grid = (int)(ntiles < 1 ? 1 : (ntiles > 1024 ? 1024 : ntiles));
   p.ws_bytes = p.buf_global ? (size_t)p.grid * p.nb * per : 0;
+  // accumulators that do not fit LDS: one global slab per workgroup (at most 256 workgroups then, each walking several
+  // tiles) as long as the slabs stay within 256 MB; otherwise atomics
+  p.acc_slab = false;
+  p.slab_off = 0;
+  if (!p.acc_lds) {
+    const int g = p.grid > 256 ? 256 : p.grid;
+    if ((size_t)g * acc <= ((size_t)256 << 20)) {
+      p.acc_slab = true;
+      p.grid = g;
+      p.ws_bytes = p.buf_global ? (size_t)p.grid * p.nb * per : 0;
+      p.slab_off = (p.ws_bytes + 255) & ~(size_t)255;
+      p.ws_bytes = p.slab_off + (size_t)g * acc;
+    }
+  }
   return p;
 }
 
@@ -437,18 +476,27 @@ int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n
 template <typename T, typename TDY>
 static int launch_lin_bwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+  float* slabs = p.acc_slab ? (float*)((char*)ws + p.slab_off) : nullptr;
 #define TT_LAUNCH(BG, AL)                                                                                          \
   do {                                                                                                             \
     auto kern = k_ttlinear_bwd<T, TDY, BG, AL>;                                                                         \
     if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_LIN), p.lds_bytes, stream, s, n_rows, p.nb, p.bs, p.ss, packed, \
-                       (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws);                         \
+                       (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws, slabs);                  \
   } while (0)
-  if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, true);
-  else if (!p.buf_global && !p.acc_lds) TT_LAUNCH(false, false);
-  else if (p.buf_global && p.acc_lds) TT_LAUNCH(true, true);
-  else TT_LAUNCH(true, false);
+  const bool slab = p.acc_slab && (d_packed || d_bias) && ws;
+  if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, 1);
+  else if (!p.buf_global && slab) TT_LAUNCH(false, 2);
+  else if (!p.buf_global) TT_LAUNCH(false, 0);
+  else if (p.acc_lds) TT_LAUNCH(true, 1);
+  else if (slab) TT_LAUNCH(true, 2);
+  else TT_LAUNCH(true, 0);
 #undef TT_LAUNCH
+  if (slab && !p.acc_lds) {
+    const int per = s.wtotal + s.out_size;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((per + 255) / 256), dim3(256), 0, stream, (const float*)slabs, p.grid, s.wtotal,
+                       s.out_size, d_packed, d_bias);
+  }
   return check_launch();
 }
 

@@ -58,6 +58,9 @@ struct LinPlan {
   bool w_lds;        // packed cores staged in LDS
   bool buf_global;   // chain intermediates in the global workspace (sample too large for LDS)
   bool acc_lds;      // backward: weight/bias gradient accumulators in LDS
+  bool acc_slab;     // backward, accumulators too large for LDS: one private global slab per workgroup (summed by a second
+                     // kernel) instead of atomics from every row into the one gradient buffer
+  size_t slab_off;   // byte offset of the slabs inside the workspace
   size_t lds_bytes, ws_bytes;
 };
 
@@ -157,7 +160,13 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 
 // the same GEMM on two-piece fp16 operands (three MFMA terms instead of six; per-row scales of x and one scale of W,
 // powers of two): forward input projections.  `planes` as above (two of the three planes are used).
-size_t gemm_half_scratch_bytes(int64_t n_rows, int M);
+size_t gemm_half_scratch_bytes(int64_t n_rows, int K, int M);
+// ... and on PRE-SPLIT pieces of x with both operands by LDS-DMA (ttrnn_fast_gemm3.hip): taken by launch_gemm_half itself where
+// 256 x 256 tiles fill the chip; xplanes: gemm3_xplane_bytes, part of gemm_half_scratch_bytes
+bool gemm3_ok(int64_t n_rows, int K, int M);
+size_t gemm3_xplane_bytes(int64_t n_rows, int K);
+int launch_gemm3h(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch, void* xplanes,
+                  const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv);
 // the two scale passes (row maxima of x, maximum of W) are two more launches: below ~4 G multiply-adds the three-piece
 // bf16 GEMM (no passes) is as fast
 // bf16 GEMM (no passes) is as fast; option gemm_pieces = 2 / 3 forces either (A/B switch, tests)

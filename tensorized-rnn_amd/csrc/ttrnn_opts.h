@@ -29,6 +29,10 @@ enum OptId {
   OPT_BIG_FP32_MFMA,     // TTRNN_BIG_FP32_MFMA=1   big-shape pair kernel on the fp32 MFMA even in split mode (A/B)
   OPT_PAIR_FAULT,        // TTRNN_PAIR_FAULT=1      tests only: the forward pair kernels are launched one workgroup short, so that
                          //                         the time-out path (NaN poison + device status counter) can be exercised
+  OPT_NO_GEMM3,          // TTRNN_NO_GEMM3=1        two-piece fp16 K-in GEMM with x split on the fly (round 2's kernel) instead of the
+                         //                         pre-split LDS-DMA GEMM (A/B)
+  OPT_DEV,               // TTRNN_DEV=0..255        developer bit mask for A/B experiments on kernels under construction (harnesses under
+                         //                         tools/ only; no effect on results unless a bit is documented at its use)
   OPT_COUNT
 };
 

@@ -1,0 +1,95 @@
+// tools/gemm3_bench.hip — development harness (not part of the library): times the two-piece fp16 K-in GEMM of libttrnn on
+// synthetic operands, round 2's kernel (x split on the fly, option no_gemm3 = 1) against the pre-split LDS-DMA GEMM of
+// ttrnn_fast_gemm3.hip, interleaved in one process, and checks both against a float64 evaluation of sampled outputs.
+//   make -C tensorized-rnn_amd/csrc bench_gemm3 && tools/bin/gemm3_bench [rows K M reps]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "ttrnn.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
+
+using namespace ttrnn;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+__global__ void k_fill(float* p, size_t n, unsigned seed, float scale, int K, int rowscale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  float u = (h & 0xFFFFFF) / 8388608.0f - 1.0f;
+  float s = scale;
+  if (rowscale) { unsigned r = (unsigned)(i / K) * 40503u; s *= exp2f((float)(r % 13) - 6.0f); }
+  p[i] = u * s;
+}
+
+int main(int argc, char** argv) {
+  long rows = argc > 1 ? atol(argv[1]) : 131072;
+  int K = argc > 2 ? atoi(argv[2]) : 1024, M = argc > 3 ? atoi(argv[3]) : 4096, reps = argc > 4 ? atoi(argv[4]) : 5;
+  printf("rows %ld K %d M %d\n", rows, K, M);
+  float *x, *W, *y0, *y1;
+  CK(hipMalloc(&x, (size_t)rows * K * 4)); CK(hipMalloc(&W, (size_t)K * M * 4));
+  CK(hipMalloc(&y0, (size_t)rows * M * 4)); CK(hipMalloc(&y1, (size_t)rows * M * 4));
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)rows * K + 255) / 256)), dim3(256), 0, 0, x, (size_t)rows * K, 1234u, 1.0f, K, 1);
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)K * M + 255) / 256)), dim3(256), 0, 0, W, (size_t)K * M, 99u, 0.05f, M, 0);
+  void *planes, *scr;
+  opt_set("gemm_pieces", 2);
+  opt_set("no_gemm3", 0);
+  const size_t sb = gemm_half_scratch_bytes(rows, K, M);
+  CK(hipMalloc(&planes, gemm_split_plane_bytes(K, M))); CK(hipMalloc(&scr, sb));
+  printf("gemm3_ok %d scratch %.1f MB\n", (int)gemm3_ok(rows, K, M), sb / 1e6);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (launch_gemm_half_prep(W, K, M, planes, scr, 0) != 0) { printf("prep failed\n"); return 1; }
+  float best[5] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
+  const char* names[5] = {"on-the-fly", "pingpong  ", "lockstep  ", "pp nostore", "ls nostore"};
+  const int NV = 5;
+  for (int r = 0; r < reps + 1; ++r)
+    for (int v = 0; v < NV; ++v) {
+      opt_set("no_gemm3", v == 0 ? 1 : 0);
+      opt_set("dev", v == 2 ? 1 : v == 3 ? 2 : v == 4 ? 3 : 0);
+      CK(hipEventRecord(e0, 0));
+      int st = launch_gemm_half(TTRNN_F32, rows, K, M, x, planes, scr, nullptr, M / 4, v == 0 ? y0 : y1, 0, nullptr);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      if (st != 0) { printf("launch failed %d\n", st); return 1; }
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms < best[v]) best[v] = ms;
+      if (r > 0) printf("  rep %d %s %.3f ms\n", r, names[v], ms);
+    }
+  opt_set("dev", 0);
+  // (the last timed variants dropped their stores: recompute y1 with the shipping variant for the checks below)
+  opt_set("no_gemm3", 0);
+  if (launch_gemm_half(TTRNN_F32, rows, K, M, x, planes, scr, nullptr, M / 4, y1, 0, nullptr) != 0) return 1;
+  CK(hipDeviceSynchronize());
+  const double flop = 2.0 * rows * K * M * 3;
+  for (int v = 0; v < NV; ++v)
+    printf("%s best %.3f ms = %.0f TFLOP/s executed (3 terms) = %.1f %% of 2500\n", names[v], best[v],
+           flop / best[v] / 1e9, flop / best[v] / 1e9 / 25.0);
+  // checks: sampled outputs against float64, and the two kernels against each other on a row band
+  std::vector<float> hW((size_t)K * M);
+  CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+  double worst[2] = {0, 0}, ymax = 0;
+  std::vector<float> hx(K), hy0(M), hy1(M);
+  for (int s = 0; s < 24; ++s) {
+    long n = (long)((s * 2654435761ull) % (unsigned long long)rows);
+    if (s == 0) n = rows - 1;
+    CK(hipMemcpy(hx.data(), x + (size_t)n * K, (size_t)K * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hy0.data(), y0 + (size_t)n * M, (size_t)M * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hy1.data(), y1 + (size_t)n * M, (size_t)M * 4, hipMemcpyDeviceToHost));
+    double rowmax = 0;
+    for (int k = 0; k < K; ++k) rowmax = fmax(rowmax, fabs((double)hx[k]));
+    for (int m = 0; m < M; m += 7) {
+      double ref = 0;
+      for (int k = 0; k < K; ++k) ref += (double)hx[k] * (double)hW[(size_t)k * M + m];
+      worst[0] = fmax(worst[0], fabs(hy0[m] - ref) / fmax(rowmax, 1e-30));
+      worst[1] = fmax(worst[1], fabs(hy1[m] - ref) / fmax(rowmax, 1e-30));
+      ymax = fmax(ymax, fabs(ref) / fmax(rowmax, 1e-30));
+    }
+  }
+  printf("max |y - fp64| / row max of x: on-the-fly %.3g, pre-split %.3g (max |y| / row max %.3g)\n", worst[0], worst[1], ymax);
+  return (worst[1] <= 2.0 * worst[0] + 1e-7) ? 0 : 2;
+}
