@@ -271,6 +271,9 @@ def main():
                          "(hidden_size, ncores, ttrank, cell) combinations of the reference's experiment flags, route and "
                          "time per shape against the any-shape VALU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prepared", action="store_true",
+                    help="forward mode: do not call prepare_for_inference() (by default the module keeps its weight-only "
+                         "work across the no_grad forwards of the timed loop, as the reference's eval loop keeps its weights)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the configuration's batch PER GPU (the headline metric, 'timesteps/sec/GPU (batch=64)'). "
                          "strong: the configuration's batch is the GLOBAL batch, sharded over the ranks (SURVEY.md 8(d): "
@@ -331,6 +334,9 @@ def main():
 
     timer = EventTimer()
     F.KERNEL_TIMER = timer
+    prepared = args.mode == "forward" and not args.no_prepared
+    if prepared:
+        model.prepare_for_inference()       # include/ttrnn.h: ttrnn_rnn_forward_phase (opt-in; weights are fixed in this loop)
 
     reducer = None
     if args.mode == "train":
@@ -407,6 +413,21 @@ def main():
             alt_ms = (time.perf_counter() - ta) * 1e3 / max(args.steps, 1)
         other = {"fp32_math": alt, "ms_per_step": alt_ms, "value": w["T"] / (alt_ms * 1e-3), "unit": "timesteps/s"}
 
+    # the same steps without the prepared weight-only state (every forward packs the cores and rebuilds scales / fragments)
+    unprepared = None
+    if prepared and world == 1:
+        model.release_prepared()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        un_ms = (time.perf_counter() - tu) * 1e3 / max(args.steps, 1)
+        unprepared = {"ms_per_step": un_ms, "value": w["T"] / (un_ms * 1e-3), "unit": "timesteps/s"}
+        model.prepare_for_inference()
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -473,7 +494,13 @@ def main():
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
                                 "train step of the reference's benchmarking.py:41-70 (zero_grad + classifier forward + nll_loss "
                                 "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM"),
-                       "fp32_math": FP32_MATH_DESC.get(math_mode)},
+                       "fp32_math": FP32_MATH_DESC.get(math_mode),
+                       "prepared_weights": (
+                           "prepare_for_inference(): packed cores, scale header, fused-core fragments and (input_size == 1) the "
+                           "unit-row input projection are built once and kept across the forwards of the timed loop "
+                           "(ttrnn_rnn_forward_phase; the reference's eval loop likewise runs on fixed weights, "
+                           "benchmarking.py:16-38); `unprepared` = the same steps with every forward rebuilding them"
+                           if prepared else None)},
             "sample_timesteps_per_s": global_batch * w["T"] / t_step,
             "collectives": (None if dist is None else
                             "{} process group, world {}{}: barrier + MAX all-reduce of the time{}".format(
@@ -497,6 +524,8 @@ def main():
         }
         if other is not None:
             line["other_fp32_math"] = other
+        if unprepared is not None:
+            line["unprepared"] = unprepared
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -206,6 +206,27 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
                       void* out, void* hT, void* cT, float* reserve,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inference with unchanged weights (the reference's eval loop, experiments/digit_classification/benchmarking.py:16-38, calls
+ * the model again and again on fixed parameters): part of what ttrnn_rnn_forward launches depends on the WEIGHTS only — the
+ * fused core's scale header and fragments, and for input_size == 1 the input projection of the two unit rows — and lands in
+ * `workspace`.  A caller that keeps packed cores, biases and workspace alive may split the call:
+ *   TTRNN_PHASE_ALL      = ttrnn_rnn_forward;
+ *   TTRNN_PHASE_PREPARE  only the weight-dependent launches (x, h0, c0, out, hT, cT, reserve are ignored and may be NULL);
+ *   TTRNN_PHASE_RUN      skips them: `workspace` must still hold what a PREPARE (or ALL) call with the SAME descriptor, options,
+ *                        packed cores and biases left there — the caller's responsibility; stale contents are a silent wrong
+ *                        answer, which is why this is an explicit entry point and not a cache inside the library.
+ * ttrnn_rnn_prepare_supported: 1 when the descriptor's route splits this way under the current options (input_size == 1 on the
+ * fused-core kernels: 1 launch per forward instead of 4); otherwise PREPARE is a no-op and RUN does everything. */
+#define TTRNN_PHASE_ALL 0
+#define TTRNN_PHASE_PREPARE 1
+#define TTRNN_PHASE_RUN 2
+int ttrnn_rnn_prepare_supported(const ttrnn_rnn_desc* desc);
+int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x, const void* h0, const void* c0,
+                            const float* packed_in, const void* bias_in,
+                            const float* packed_hid, const void* bias_hid,
+                            void* out, void* hT, void* cT, float* reserve,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Which family of kernels ttrnn_rnn_forward would run for this descriptor under the current options (pure host logic, no
  * launch): the benchmark sweep and the tests report / assert it, so that "an MFMA kernel ran" is a checked statement. */
 #define TTRNN_ROUTE_VALU 0            /* any-shape VALU kernels (ttrnn_generic.hip)                                   */

@@ -504,16 +504,43 @@ size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
   return (size_t)rs.B * rs.T * per * sizeof(float);
 }
 
+// does the forward route of this descriptor separate its weight-only launches (TTRNN_PHASE_*)?
+static bool phase_split_ok(const RnnShape& rs, int dtype) {
+  if (fwd_prefers_g2(rs, dtype)) return false;
+  const FastFwdPlan f = plan_fast_fwd(rs, dtype);
+  return f.use && f.in1 && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, dtype);
+}
+
+int ttrnn_rnn_prepare_supported(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return !force_generic() && rs.B > 0 && rs.T > 0 && phase_split_ok(rs, desc->dtype) ? 1 : 0;
+}
+
 int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,
                       const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
                       void* out, void* hT, void* cT, float* reserve, void* workspace, size_t workspace_bytes,
                       void* stream) {
+  return ttrnn_rnn_forward_phase(desc, TTRNN_PHASE_ALL, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve,
+                                 workspace, workspace_bytes, stream);
+}
+
+int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x, const void* h0, const void* c0,
+                            const float* packed_in, const void* bias_in, const float* packed_hid, const void* bias_hid,
+                            void* out, void* hT, void* cT, float* reserve, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   RnnShape rs;
   int st = rnn_shape_init(&rs, desc);
   if (st != TTRNN_OK) return st;
+  if (phase != TTRNN_PHASE_ALL && phase != TTRNN_PHASE_PREPARE && phase != TTRNN_PHASE_RUN) return TTRNN_ERR_BAD_DESC;
   if (rs.B == 0) return TTRNN_OK;
   if (!packed_in || !packed_hid) return TTRNN_ERR_NULL;
-  if (rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
+  // routes that do not separate their weight-only work: PREPARE has nothing to do, RUN does everything
+  if (phase != TTRNN_PHASE_ALL && (force_generic() || rs.T == 0 || !phase_split_ok(rs, desc->dtype))) {
+    if (phase == TTRNN_PHASE_PREPARE) return TTRNN_OK;
+    phase = TTRNN_PHASE_ALL;
+  }
+  if (phase != TTRNN_PHASE_PREPARE && rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   const bool g2_first = fwd_prefers_g2(rs, desc->dtype);
@@ -527,11 +554,13 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     const void* bin = rs.has_bias_in ? bias_in : nullptr;
     GinSrc src{gin, x, f.in1 ? 1 : 0};
     if (f.in1) {
-      // K-in on the two unit rows x = [1, 0] (same chain kernel, microseconds); K-rec scales by the real x
+      // K-in on the two unit rows x = [1, 0] (same chain kernel, microseconds); K-rec scales by the real x.  Weights only:
+      // TTRNN_PHASE_RUN finds the two rows in the workspace
       const void* unit = unit_rows_ptr(desc->dtype);
       if (!unit) return TTRNN_ERR_LAUNCH;
-      st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
-                                    (hipStream_t)stream);
+      if (phase != TTRNN_PHASE_RUN)
+        st = launch_ttlinear_fwd_fast(rs.in_s, desc->dtype, true, 2, packed_in, bin, unit, gin, rs.H, ilv_mode,
+                                      (hipStream_t)stream);
     } else if (fp32_math() == TTRNN_MATH_SPLIT && f.gemm_bytes > 0 && (int64_t)rs.B * rs.T >= 2 * (int64_t)rs.in &&
                !no_gemm() && f10_ttlinear_fwd_available(rs.in_s, desc->dtype, rs.H, ilv_mode)) {
       // K-in as ONE dense GEMM: W_in (gate-interleaved columns) = the fused-core kernel on the `in` unit rows, then
@@ -573,7 +602,7 @@ int ttrnn_rnn_forward(const ttrnn_rnn_desc* desc, const void* x, const void* h0,
     // fused-core kernels: fp32 LSTM shapes under the split math mode; the bf16 GRU shape always (bf16 MFMA either way)
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
       return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
-                                (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);
+                                (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream, phase);
     if (fp32_math() == TTRNN_MATH_EXACT && f.f10_bytes > 0 && f10x_rnn_fwd_available(rs, desc->dtype))
       return launch_rnn_fwd_f10x(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                  (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);

@@ -702,10 +702,12 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
 
 template <class S>
 static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
-                       void* out, void* hT, float* reserve, void* ws, hipStream_t stream) {
+                       void* out, void* hT, float* reserve, void* ws, hipStream_t stream, int phase) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
-  hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
+  if (phase != TTRNN_PHASE_RUN)
+    hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
+  if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL((k_gru_fwd_f10<S>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0,
                      packed_hid, wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr,
                      (bf16_t*)out, (bf16_t*)hT, reserve);
@@ -716,15 +718,19 @@ static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const flo
 template <class S, int KS>
 static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                      hipStream_t stream) {
+                      hipStream_t stream, int phase) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   static_assert(F10H_HDR_BYTES + (size_t)F10<S>::MT * F10<S>::NM * 2 * 64 * sizeof(xh8) <= f10_wfrag_bytes<S>(), "workspace");
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
   static_assert((F10H_EP + F10<S>::M) * sizeof(int) <= F10H_HDR_BYTES, "header");
   // (h_0 is scaled per sample inside the recurrent kernels: f10h_h0_expo)
-  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
-  hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
+  // the scale header and the fragments depend on the weights only: TTRNN_PHASE_RUN finds them in ws (ttrnn_rnn_forward_phase)
+  if (phase != TTRNN_PHASE_RUN) {
+    hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
+    hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
+  }
+  if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   constexpr size_t lds = f10h_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
@@ -767,17 +773,17 @@ bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
 
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                       hipStream_t stream) {
+                       hipStream_t stream, int phase) {
   if (rs.cell == TTRNN_GRU) {
     if (shape_matches<ShpH256R8G>(rs.hid_s))
-      return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream);
+      return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
     return TTRNN_ERR_UNSUPPORTED;
   }
   // r = 8: one wave per tile row (measured 7 % faster than the k-split layout); r = 16: k-split (register budget)
   if (shape_matches<ShpH256R8L>(rs.hid_s))
-    return launch_f10<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+    return launch_f10<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
   if (shape_matches<ShpH256R16L>(rs.hid_s))
-    return launch_f10<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+    return launch_f10<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

@@ -124,7 +124,7 @@ bool f10_rnn_fwd_available(const RnnShape& rs, int dtype);
 size_t f10_workspace_bytes(const RnnShape& rs, int dtype);   // fused-core fragments, independent of the math mode
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                       hipStream_t stream);
+                       hipStream_t stream, int phase = 0);
 
 // two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,

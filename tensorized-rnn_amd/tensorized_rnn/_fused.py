@@ -87,7 +87,24 @@ class FusedCellMixin(object):
         stats = None
         if getattr(self, '_h_logger', None) is not None:       # log_grads=True: per-step statistics from the fused call
             stats = F.StepStats(self._h_logger, getattr(self, '_c_logger', None))
-        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats)
+        prep = getattr(self, '_prepared', None)
+        if prep is not None and not torch.is_grad_enabled():
+            if not prep.fresh():                                # parameters were updated in place since: prepare again
+                prep = self._prepare()
+        else:
+            prep = None
+        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats, prepared=prep)
+
+    def _prepare(self):
+        """(Re)build the weight-only state of this cell for no-grad forwards (ttrnn_hip.functional.PreparedLayer)."""
+        from ttrnn_hip import functional as F
+        cin, bin_, chid, bhid = self._operands()
+        prep = F.PreparedLayer(self._layer_spec(), cin, bin_, chid, bhid)
+        object.__setattr__(self, '_prepared', prep)            # plain attribute: not a buffer, not in the state_dict
+        return prep
+
+    def _release_prepared(self):
+        object.__setattr__(self, '_prepared', None)
 
 
 class TTWeightsMixin(object):
@@ -172,6 +189,32 @@ class FusedRnnBase(nn.Module):
                     cell.register_forward_hook(c_fwd)
                     cell._c_backward_hook = c_bwd
                     object.__setattr__(cell, '_c_logger', c_logger)
+
+    def prepare_for_inference(self):
+        """Opt-in for repeated no-grad forwards on unchanged weights (the reference's eval loop, experiments/
+        digit_classification/benchmarking.py:16-38): every layer keeps its packed cores and, per input shape, the
+        weight-only part of the forward call, so that a forward is one recurrent-kernel launch per layer
+        (include/ttrnn.h: ttrnn_rnn_forward_phase).  In-place parameter updates are detected and prepared again; writes
+        through `.data` are not — call this again (or release_prepared()) after them.  Moving the module (.to / .cuda /
+        dtype casts) and train() drop the prepared state.  Returns self."""
+        if not self._needs_stepping():
+            for cell in self._all_layers:
+                cell._prepare()
+        return self
+
+    def release_prepared(self):
+        for cell in getattr(self, '_all_layers', ()):
+            cell._release_prepared()
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            self.release_prepared()
+        return super(FusedRnnBase, self).train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.release_prepared()
+        return super(FusedRnnBase, self)._apply(fn, *args, **kwargs)
 
     def param_count(self):
         from .rnn_utils import param_count as pc

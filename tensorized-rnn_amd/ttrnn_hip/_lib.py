@@ -12,6 +12,7 @@ import torch  # noqa: F401  (must be imported first: libttrnn resolves libamdhip
 TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
+PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
 ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -68,6 +69,8 @@ _SIGNATURES = {
     "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_forward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_prepare_supported": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_forward_phase": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
 }
@@ -109,13 +112,19 @@ def check(status, what):
 MATH_MODES = {"exact": 0, "split": 1}     # TTRNN_MATH_EXACT / TTRNN_MATH_SPLIT (include/ttrnn.h)
 
 
+# bumped whenever a library option changes: prepared workspaces (functional.PreparedLayer) are keyed on it
+OPTIONS_EPOCH = 0
+
+
 def set_fp32_math(mode):
     """Select how the shape-specialised kernels multiply fp32 operands: "exact" (fp32 MFMA) or "split"
     (three-way bf16 split, six bf16 MFMA terms, fp32 accumulation).  Process-wide; returns the previous mode."""
     if mode not in MATH_MODES:
         raise ValueError("fp32 math mode must be one of {}".format(sorted(MATH_MODES)))
+    global OPTIONS_EPOCH
     prev = get_fp32_math()
     check(load().ttrnn_set_fp32_math(MATH_MODES[mode]), "ttrnn_set_fp32_math")
+    OPTIONS_EPOCH += 1
     return prev
 
 
@@ -142,8 +151,10 @@ def get_option(name):
 
 def set_option(name, value):
     """Set a library option; returns the previous value."""
+    global OPTIONS_EPOCH
     prev = get_option(name)
     check(load().ttrnn_set_option(name.encode(), int(value)), "ttrnn_set_option({!r}, {})".format(name, value))
+    OPTIONS_EPOCH += 1
     return prev
 
 

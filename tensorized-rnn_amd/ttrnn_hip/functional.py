@@ -174,13 +174,18 @@ class TTSpec(object):
         return grads
 
 
-def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db):
+def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroed=None):
+    """zeroed: optional (dpk, db) fp32 buffers the caller has already zero-filled (one fill for several calls)."""
     lib = _lib.load()
     n = dy2d.shape[0]
     dev = dy2d.device
     dx = _alloc((n, spec.in_features), x2d.dtype, dev) if need_dx else None
-    dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
-    db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
+    if zeroed is not None:
+        dpk = zeroed[0] if need_dw else None
+        db = zeroed[1] if need_db else None
+    else:
+        dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
+        db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
     wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
     ws = _workspace(wsb, dev)
     check(lib.ttrnn_ttlinear_backward(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
@@ -419,13 +424,18 @@ class _TTRnnLayerFn(torch.autograd.Function):
         n_in = ctx.n_in
         need_dw_in = any(need[8:8 + n_in])
         need_dw_hid = any(need[8 + n_in:])
+        # the accumulate-into buffers of both matrices (packed core gradients, bias gradients): ONE zero fill
+        sizes = [spec.in_spec.packed_elems, G * H, spec.hid_spec.packed_elems, G * H]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        z_in_w, z_in_b, z_hid_w, z_hid_b = torch.split(flat, sizes)
         dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
-                                               dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3])
+                                               dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3],
+                                               zeroed=(z_in_w, z_in_b))
         # h_{t-1} rows: [h0, out[:, :-1]]
         first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
         hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
         _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
-                                                False, need_dw_hid, has_bhid and need[4])
+                                                False, need_dw_hid, has_bhid and need[4], zeroed=(z_hid_w, z_hid_b))
         dcin = spec.in_spec.unpack_grads(dpk_in, cores_in) if need_dw_in else [None] * n_in
         dchid = spec.hid_spec.unpack_grads(dpk_hid, cores_hid) if need_dw_hid else [None] * len(cores_hid)
         if dx is not None:
@@ -435,6 +445,63 @@ class _TTRnnLayerFn(torch.autograd.Function):
         if db_hid is not None:
             db_hid = db_hid.to(x.dtype)
         return (dx, d_h0, d_c0, db_in, db_hid, None, None, None) + tuple(dcin) + tuple(dchid)
+
+
+class PreparedLayer(object):
+    """Weight-only state of one recurrent layer kept across no-grad forwards (include/ttrnn.h: ttrnn_rnn_forward_phase):
+    the packed cores, and per (batch, seq_len, dtype) a workspace a TTRNN_PHASE_PREPARE call has filled with everything
+    that depends on the weights alone — the fused core's scale header and fragments and, for input_size == 1, the input
+    projection of the unit rows.  A forward is then ONE launch (the recurrent kernel) instead of five.
+
+    Opt-in (FusedRnnBase.prepare_for_inference): a stale copy would be a silent wrong answer.  In-place updates of the
+    parameters (optimizer steps, load_state_dict, .copy_) bump their version counters and are detected — the layer is
+    prepared again; writes through `.data` are NOT tracked by torch: call prepare_for_inference() again after them."""
+
+    def __init__(self, spec, cores_in, bias_in, cores_hid, bias_hid):
+        self.spec = spec
+        self.tensors = list(cores_in) + list(cores_hid) + [b for b in (bias_in, bias_hid) if b is not None]
+        self.stamp = self._stamp()
+        with torch.no_grad(), torch.cuda.device(self.tensors[0].device):
+            self.packed_in, self.packed_hid = TTSpec.pack_pair(spec.in_spec, list(cores_in), spec.hid_spec, list(cores_hid))
+        self.workspaces = {}
+
+    def _stamp(self):
+        return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in self.tensors)
+
+    def fresh(self):
+        return self.stamp == self._stamp()
+
+
+def _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prep):
+    """No-grad forward of one layer on prepared weights: TTRNN_PHASE_PREPARE once per (B, T, dtype, options), then
+    TTRNN_PHASE_RUN per call."""
+    lib = _lib.load()
+    B, T, _ = x.shape
+    H = spec.hidden_size
+    dev = x.device
+    dt = _dtype_code(x)
+    desc = spec.desc(B, T, dt)
+    key = (B, T, dt, dev, _lib.OPTIONS_EPOCH)
+    ent = prep.workspaces.get(key)
+    if ent is None:
+        wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
+        ws = _workspace(wsb, dev)
+        null = ctypes.c_void_p(0)
+        check(lib.ttrnn_rnn_forward_phase(ctypes.byref(desc), _lib.PHASE_PREPARE, null, null, null, _ptr(prep.packed_in),
+                                          _ptr(bias_in), _ptr(prep.packed_hid), _ptr(bias_hid), null, null, null, null,
+                                          _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward_phase(PREPARE)")
+        prep.workspaces = {k: v for k, v in prep.workspaces.items() if k[4] == _lib.OPTIONS_EPOCH}     # drop stale epochs
+        ent = prep.workspaces[key] = (ws, wsb)
+    ws, wsb = ent
+    out = _alloc((B, T, H), x.dtype, dev)
+    hT = _alloc((B, H), x.dtype, dev)
+    cT = _alloc((B, H), x.dtype, dev) if spec.cell == "lstm" else None
+    with _timed("ttrnn_rnn_forward"):
+        check(lib.ttrnn_rnn_forward_phase(ctypes.byref(desc), _lib.PHASE_RUN, _ptr(x), _ptr(h0), _ptr(c0),
+                                          _ptr(prep.packed_in), _ptr(bias_in), _ptr(prep.packed_hid), _ptr(bias_hid),
+                                          _ptr(out), _ptr(hT), _ptr(cT), ctypes.c_void_p(0), _ptr(ws), wsb, _stream(x)),
+              "ttrnn_rnn_forward_phase(RUN)")
+    return (out, hT, cT) if spec.cell == "lstm" else (out, hT)
 
 
 def rnn_route(spec, batch, seq_len, dtype=torch.float32):
@@ -480,10 +547,11 @@ class StepStats(object):
                 lg.log_grad.appendleft(b)
 
 
-def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None):
+def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None, prepared=None):
     """One recurrent layer over the whole sequence on the device.
     Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU.
-    stats: optional StepStats — ActivGradLogger's per-step statistics without leaving the fused path."""
+    stats: optional StepStats — ActivGradLogger's per-step statistics without leaving the fused path.
+    prepared: optional PreparedLayer — used when autograd is not recording (inference on unchanged weights)."""
     cores_in, cores_hid = list(cores_in), list(cores_hid)
     _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
     if x.dim() != 3 or x.shape[2] != spec.input_size:
@@ -496,5 +564,8 @@ def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=
     h0 = h0.contiguous().to(x.dtype) if h0 is not None else None
     c0 = c0.contiguous().to(x.dtype) if (c0 is not None and spec.cell == "lstm") else None
     spec.recording = torch.is_grad_enabled()
+    if prepared is not None and not spec.recording and stats is None and POISON_ALLOCATIONS is False:
+        with torch.cuda.device(x.device):
+            return _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prepared)
     with torch.cuda.device(x.device):       # the library launches on the CURRENT device's context
         return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), stats, *(cores_in + cores_hid))

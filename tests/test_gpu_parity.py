@@ -731,6 +731,50 @@ def test_dtype_and_device_mismatches_are_refused():
         lin(torch.rand(4, 256, device=dev()).to(torch.bfloat16))
 
 
+def test_prepared_weights_inference_matches_and_tracks_updates():
+    """prepare_for_inference(): repeated no-grad forwards reuse the packed cores and the weight-only part of the call
+    (ttrnn_rnn_forward_phase: PREPARE once per input shape, RUN per call).  Results must be bit-identical to the ordinary
+    call — on the headline shape, whose route separates the phases (one launch per forward), and on routes that do not —
+    and an in-place parameter update must be noticed (version counters) instead of answering from stale fragments."""
+    import ctypes
+    import ttrnn_hip
+    from ttrnn_hip import _lib
+    torch.manual_seed(7)
+    for meta, B, T, split in ((dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 1),
+                              (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 0),
+                              (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16), 6, 9, 0),
+                              (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0)):
+        m = build_module(meta, dev()).eval()
+        x = torch.randn(B, T, meta["input_size"], device=dev())
+        desc = m._all_layers[0]._layer_spec().desc(B, T, 0)
+        assert _lib.load().ttrnn_rnn_prepare_supported(ctypes.byref(desc)) == split
+        with torch.no_grad():
+            ref = m(x)[0]
+            m.prepare_for_inference()
+            a = m(x)[0]
+            b = m(x)[0]                                   # second call: the cached workspace
+            assert torch.equal(a, ref) and torch.equal(b, ref)
+            assert len(m._all_layers[0]._prepared.workspaces) == 1
+            x2 = torch.randn(B + 1, T + 3, meta["input_size"], device=dev())
+            assert torch.equal(m(x2)[0], m.release_prepared()(x2)[0])
+            m.prepare_for_inference()
+            m(x)
+            for p in m.parameters():                       # an optimizer-style in-place update
+                p.mul_(1.25)
+            upd = m(x)[0]                                  # must be prepared again by itself
+            m.release_prepared()
+            assert torch.equal(upd, m(x)[0]) and not torch.equal(upd, ref)
+            m.prepare_for_inference()
+            with ttrnn_hip.fp32_math("exact"):             # an option change invalidates prepared workspaces
+                e1 = m(x)[0]
+                m.release_prepared()
+                assert torch.equal(e1, m(x)[0])
+        # autograd runs never use the prepared state
+        m.prepare_for_inference()
+        m.train()
+        assert m._all_layers[0]._prepared is None
+
+
 # ---- (4) fp32 math modes: three-way bf16 split (default) vs fp32 MFMA ("exact") -------------------------
 # Every test above runs in the library's default mode (split where a split kernel exists: the cfg2 hidden shape);
 # the ones below pin BOTH modes explicitly on that shape.

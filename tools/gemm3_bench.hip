@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < reps + 1; ++r)
     for (int v = 0; v < NV; ++v) {
       opt_set("no_gemm3", v == 0 ? 1 : 0);
-      opt_set("dev", v == 2 ? 1 : v == 3 ? 2 : v == 4 ? 3 : 0);
+      opt_set("dev", v == 1 ? 1 : v == 3 ? 3 : v == 4 ? 2 : 0);
       CK(hipEventRecord(e0, 0));
       int st = launch_gemm_half(TTRNN_F32, rows, K, M, x, planes, scr, nullptr, M / 4, v == 0 ? y0 : y1, 0, nullptr);
       CK(hipEventRecord(e1, 0));
