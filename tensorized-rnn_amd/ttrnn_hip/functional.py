@@ -426,8 +426,9 @@ class _TTRnnLayerFn(torch.autograd.Function):
         need_dw_hid = any(need[8 + n_in:])
         # the accumulate-into buffers of both matrices (packed core gradients, bias gradients): ONE zero fill
         sizes = [spec.in_spec.packed_elems, G * H, spec.hid_spec.packed_elems, G * H]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        z_in_w, z_in_b, z_hid_w, z_hid_b = torch.split(flat, sizes)
+        padded = [(n + 63) // 64 * 64 for n in sizes]                       # every buffer starts on a 256-byte boundary
+        flat = torch.zeros(sum(padded), dtype=torch.float32, device=dev)
+        z_in_w, z_in_b, z_hid_w, z_hid_b = (t[:n] for t, n in zip(torch.split(flat, padded), sizes))
         dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
                                                dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3],
                                                zeroed=(z_in_w, z_in_b))
