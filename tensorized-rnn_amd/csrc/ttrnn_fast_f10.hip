@@ -757,7 +757,7 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
 // bytes of workspace launch_rnn_fwd_f10 needs for the fused core's fragments (0 when the shape has no f10 kernel)
 size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
-    return (size_t)4 * F10<ShpH256R8G>::NM * 64 * sizeof(xbf8);
+    return f10gq_workspace_bytes();      // >= the eight-wave kernel's 4 * NM fragments
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R8L>();
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R16L>();
@@ -775,6 +775,10 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream, int phase) {
   if (rs.cell == TTRNN_GRU) {
+    // dev bit 2 (A/B): four waves with the gates in the lanes that hold the sums (ttrnn_fast_f10gq.hip) — built for VERDICT r2
+    // item 4 and measured SLOWER than the eight-wave kernel below (0.678 against 0.570 ms on cfg3), so it is not the default
+    if ((opt(OPT_DEV) & 4) && f10gq_available(rs, TTRNN_BF16))
+      return launch_gru_fwd_f10gq(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
     if (shape_matches<ShpH256R8G>(rs.hid_s))
       return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
     return TTRNN_ERR_UNSUPPORTED;

@@ -126,6 +126,11 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream, int phase = 0);
 
+// the bf16 GRU as four-wave workgroups with in-lane gates (ttrnn_fast_f10gq.hip); ws: f10gq_workspace_bytes
+size_t f10gq_workspace_bytes();
+bool f10gq_available(const RnnShape& rs, int dtype);
+int launch_gru_fwd_f10gq(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
+                         void* out, void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
 // two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,

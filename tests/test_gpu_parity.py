@@ -731,6 +731,37 @@ def test_dtype_and_device_mismatches_are_refused():
         lin(torch.rand(4, 256, device=dev()).to(torch.bfloat16))
 
 
+def test_gru_four_wave_kernel_matches_eight_wave_kernel_and_oracle():
+    """The bf16 TT-GRU shape (cfg3) on the four-wave kernel whose lanes hold r, z, n of their own units (three rotated
+    MFMA tiles per pair of unit rows, ttrnn_fast_f10gq.hip; an A/B variant behind option dev bit 2 — it measured slower than
+    the default) against the eight-wave kernel with its LDS gate vector and the fp32 oracle: forward with an initial state, input_size 1 and 40 (the scalar shortcut and the hoisted
+    projection), and the gradients the forward's reserve feeds."""
+    import ttrnn_hip
+    torch.manual_seed(77)
+    for inp, B, T in ((1, 9, 37), (40, 70, 11)):
+        meta = dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8)
+        m = build_module(meta, dev()).to(torch.bfloat16)
+        x = torch.randn(B, T, inp).to(torch.bfloat16)
+        h0 = (torch.randn(B, 256) * 0.5).to(torch.bfloat16)
+        w = torch.randn(B, T, 256, device=dev())
+        res = {}
+        for name, devbits in (("four", 4), ("eight", 0)):
+            m.zero_grad()
+            with ttrnn_hip.option("dev", devbits):
+                xg = x.to(dev()).requires_grad_(True)
+                out, hT = m(xg, h0.to(dev()))
+                (out.float() * w).sum().backward()
+            res[name] = (out.detach().float().cpu(), hT.detach().float().cpu(), xg.grad.float().cpu(),
+                         {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()})
+        sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        ref = _oracle_forward("ttgru", sd, 1, x.float(), h0.float())[0]
+        assert _maxabs(res["four"][0], ref) <= 2e-2 and _maxabs(res["four"][0], res["eight"][0]) <= 1.6e-2   # one bf16 ulp of |h| <= 2
+        assert _maxabs(res["four"][1], res["eight"][1]) <= 1.6e-2
+        for n in res["four"][3]:
+            a, bq = res["four"][3][n], res["eight"][3][n]
+            assert torch.isfinite(a).all() and _maxabs(a, bq) <= 3e-2 * max(float(bq.abs().max()), 1e-6), n
+
+
 def test_prepared_weights_inference_matches_and_tracks_updates():
     """prepare_for_inference(): repeated no-grad forwards reuse the packed cores and the weight-only part of the call
     (ttrnn_rnn_forward_phase: PREPARE once per input shape, RUN per call).  Results must be bit-identical to the ordinary
