@@ -55,7 +55,8 @@ class SpeakerEncoder(nn.Module):
         self.similarity_bias = nn.Parameter(torch.tensor([-5.]))
 
     def forward(self, utterances):
-        res = self.rnn(utterances)
+        # only the last layer's final hidden state is consumed (speaker_encoder.py:80-86): inference skips its [B, T, H] outputs
+        res = self.rnn(utterances) if (self.use_gru or torch.is_grad_enabled()) else self.rnn(utterances, need_outputs=False)
         last_hidden = res[1] if self.use_gru else res[1][0]
         return self.linear.forward_head(last_hidden, "relu_l2norm")              # TTLinear + ReLU + L2 norm: one library call
 

@@ -511,6 +511,19 @@ static bool phase_split_ok(const RnnShape& rs, int dtype) {
   return f.use && f.in1 && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, dtype);
 }
 
+// may ttrnn_rnn_forward be called with out == NULL (the caller wants hT / cT only)?
+static bool out_optional(const RnnShape& rs, int dtype, bool training) {
+  if (force_generic() || fwd_prefers_g2(rs, dtype)) return false;
+  const FastFwdPlan f = plan_fast_fwd(rs, dtype);
+  return f.use && fp32_math() == TTRNN_MATH_SPLIT && f10_rnn_fwd_available(rs, dtype) && f10_out_optional(rs, dtype, training);
+}
+
+int ttrnn_rnn_out_optional(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return rs.B > 0 && rs.T > 0 && out_optional(rs, desc->dtype, false) ? 1 : 0;
+}
+
 int ttrnn_rnn_prepare_supported(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
@@ -540,7 +553,8 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
     if (phase == TTRNN_PHASE_PREPARE) return TTRNN_OK;
     phase = TTRNN_PHASE_ALL;
   }
-  if (phase != TTRNN_PHASE_PREPARE && rs.T > 0 && (!x || !out)) return TTRNN_ERR_NULL;
+  if (phase != TTRNN_PHASE_PREPARE && rs.T > 0 && (!x || (!out && !out_optional(rs, desc->dtype, reserve != nullptr))))
+    return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   const bool g2_first = fwd_prefers_g2(rs, desc->dtype);

@@ -764,6 +764,16 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
   return 0;
 }
 
+// does launch_rnn_fwd_f10 take the four-wave kernel (the one that can leave `out` unwritten) for this launch?  Mirrors launch_f10.
+bool f10_out_optional(const RnnShape& rs, int dtype, bool training) {
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_NO_F10) || opt(OPT_F10_NB1)) return false;
+  if (training) return false;           // the backward pass reads `out` (h_{t-1} rows of the hidden matrix's weight gradient)
+  const int cus = device_cu_count();
+  if (rs.B > cus && opt(OPT_F10_NB2)) return false;
+  if (shape_matches<ShpH256R8L>(rs.hid_s)) return true;
+  return shape_matches<ShpH256R16L>(rs.hid_s) && 2 * rs.B > cus;
+}
+
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);

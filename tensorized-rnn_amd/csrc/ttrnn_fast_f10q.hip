@@ -30,7 +30,8 @@ constexpr size_t f10q_lds_bytes() {
 
 // KH = 1: one accumulation over all k-blocks (= k_lstm_fwd_f10<S, 1>);  KH = 2: the two halves of k_lstm_fwd_f10<S, 2>
 // H0: the caller passed an initial state (it may lie outside (-1, 1): f10h_h0_expo); without one the scales are constants
-template <class S, int KH, bool H0>
+// OUT = false: the caller consumes only the final state (speaker_encoder.py:80-86 takes `hidden[-1]`): `out` is not written
+template <class S, int KH, bool H0, bool OUT>
 __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                const float* __restrict__ c0,
                                                                const float* __restrict__ packed_hid,
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
       _Float16 p0, p1;
       split2h(hy * hsc, p0, p1);
       hn[hd] = p0; hn[H + hd] = p1;
-      out[bt * H + hd] = hy;                                // outputs[:, t, :] (lstm.py:133): 256 contiguous bytes per wave
+      if constexpr (OUT) out[bt * H + hd] = hy;             // outputs[:, t, :] (lstm.py:133): 256 contiguous bytes per wave
       if (reserve) {
         *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hd)) = f32x4{ig, gg, fg, og};
         reserve[res_cell((size_t)B * T, bt, H, hd)] = cy;
@@ -184,7 +185,8 @@ static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* 
   const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
   constexpr size_t lds = f10q_lds_bytes<S>();
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  auto kern = h0 ? k_lstm_fwd_f10q<S, KH, true> : k_lstm_fwd_f10q<S, KH, false>;
+  auto kern = out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true> : k_lstm_fwd_f10q<S, KH, false, true>)
+                  : (h0 ? k_lstm_fwd_f10q<S, KH, true, false> : k_lstm_fwd_f10q<S, KH, false, false>);
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);

@@ -81,7 +81,7 @@ class FusedCellMixin(object):
         res = F.tt_rnn_layer(self._layer_spec(), x.unsqueeze(1), hx, cx, cin, bin_, chid, bhid)
         return res[1:]          # (hy, cy) or (hy,)
 
-    def _run_sequence(self, seq, h0, c0=None):
+    def _run_sequence(self, seq, h0, c0=None, need_out=True):
         from ttrnn_hip import functional as F
         cin, bin_, chid, bhid = self._operands()
         stats = None
@@ -93,7 +93,8 @@ class FusedCellMixin(object):
                 prep = self._prepare()
         else:
             prep = None
-        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats, prepared=prep)
+        return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats, prepared=prep,
+                              need_out=need_out)
 
     def _prepare(self):
         """(Re)build the weight-only state of this cell for no-grad forwards (ttrnn_hip.functional.PreparedLayer)."""
@@ -226,11 +227,13 @@ class FusedRnnBase(nn.Module):
         # cells with foreign weight types, or a joint matrix with more cores than the library takes, are stepped
         return any(not cell._fusable() for cell in self._all_layers)
 
-    def _forward_fused(self, input, h0, c0):
+    def _forward_fused(self, input, h0, c0, need_outputs=True):
         seq = input
         last = None
-        for cell in self._all_layers:
-            last = cell._run_sequence(seq, h0, c0)
+        n = len(self._all_layers)
+        for i, cell in enumerate(self._all_layers):
+            # only the LAST layer's outputs can go unused (layer l + 1 reads all of layer l's)
+            last = cell._run_sequence(seq, h0, c0, need_out=need_outputs or i + 1 < n)
             seq = last[0]
         return last
 

@@ -80,10 +80,13 @@ class LSTM(FusedRnnBase):
         c = torch.zeros(batch_size, self.hidden_size).to(self.device)
         return h, c
 
-    def forward(self, input, init_states=None):
+    def forward(self, input, init_states=None, need_outputs=True):
         """
         :param input:       (batch_size, seq_len, input_size)
         :param init_states: optional (h, c), each (batch_size, hidden_size); seeds every layer.
+        :param need_outputs: extension to the reference's signature.  False under torch.no_grad() tells the last layer that
+                 only the final state is consumed (speaker_encoder.py:80-86): `outputs` is then None where the kernel can skip
+                 the [B, T, H] store, and the usual tensor everywhere else (and always when autograd is recording).
         :return: outputs (batch_size, seq_len, hidden_size) of the last layer, and that layer's
                  final (h, c), each (batch_size, hidden_size).
         """
@@ -93,5 +96,5 @@ class LSTM(FusedRnnBase):
             outputs, hT, cT = self._forward_stepwise(input, h, c)
         else:
             h, c = (None, None) if init_states is None else init_states
-            outputs, hT, cT = self._forward_fused(input, h, c)
+            outputs, hT, cT = self._forward_fused(input, h, c, need_outputs)
         return outputs, (hT, cT)

@@ -473,7 +473,7 @@ class PreparedLayer(object):
         return self.stamp == self._stamp()
 
 
-def _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prep):
+def _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prep, need_out=True):
     """No-grad forward of one layer on prepared weights: TTRNN_PHASE_PREPARE once per (B, T, dtype, options), then
     TTRNN_PHASE_RUN per call."""
     lib = _lib.load()
@@ -494,7 +494,8 @@ def _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prep):
         prep.workspaces = {k: v for k, v in prep.workspaces.items() if k[4] == _lib.OPTIONS_EPOCH}     # drop stale epochs
         ent = prep.workspaces[key] = (ws, wsb)
     ws, wsb = ent
-    out = _alloc((B, T, H), x.dtype, dev)
+    want_out = need_out or not lib.ttrnn_rnn_out_optional(ctypes.byref(desc))
+    out = _alloc((B, T, H), x.dtype, dev) if want_out else None
     hT = _alloc((B, H), x.dtype, dev)
     cT = _alloc((B, H), x.dtype, dev) if spec.cell == "lstm" else None
     with _timed("ttrnn_rnn_forward"):
@@ -548,11 +549,34 @@ class StepStats(object):
                 lg.log_grad.appendleft(b)
 
 
-def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None, prepared=None):
+def _rnn_forward_nograd(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, need_out):
+    """No-grad forward without the autograd Function (nothing is saved): lets the last layer skip `out` where the route can."""
+    lib = _lib.load()
+    B, T, _ = x.shape
+    H = spec.hidden_size
+    dev = x.device
+    desc = spec.desc(B, T, _dtype_code(x))
+    packed_in, packed_hid = TTSpec.pack_pair(spec.in_spec, cores_in, spec.hid_spec, cores_hid)
+    want_out = need_out or not lib.ttrnn_rnn_out_optional(ctypes.byref(desc))
+    out = _alloc((B, T, H), x.dtype, dev) if want_out else None
+    hT = _alloc((B, H), x.dtype, dev)
+    cT = _alloc((B, H), x.dtype, dev) if spec.cell == "lstm" else None
+    wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
+    ws = _workspace(wsb, dev)
+    with _timed("ttrnn_rnn_forward"):
+        check(lib.ttrnn_rnn_forward(ctypes.byref(desc), _ptr(x), _ptr(h0), _ptr(c0), _ptr(packed_in), _ptr(bias_in),
+                                    _ptr(packed_hid), _ptr(bias_hid), _ptr(out), _ptr(hT), _ptr(cT), ctypes.c_void_p(0),
+                                    _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward")
+    return (out, hT, cT) if spec.cell == "lstm" else (out, hT)
+
+
+def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None, prepared=None, need_out=True):
     """One recurrent layer over the whole sequence on the device.
     Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU.
     stats: optional StepStats — ActivGradLogger's per-step statistics without leaving the fused path.
-    prepared: optional PreparedLayer — used when autograd is not recording (inference on unchanged weights)."""
+    prepared: optional PreparedLayer — used when autograd is not recording (inference on unchanged weights).
+    need_out=False (no-grad calls only): the caller consumes only the final state; `out` is returned as None where the
+    route can skip it (include/ttrnn.h: ttrnn_rnn_out_optional), computed as usual elsewhere."""
     cores_in, cores_hid = list(cores_in), list(cores_hid)
     _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
     if x.dim() != 3 or x.shape[2] != spec.input_size:
@@ -567,6 +591,9 @@ def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=
     spec.recording = torch.is_grad_enabled()
     if prepared is not None and not spec.recording and stats is None and POISON_ALLOCATIONS is False:
         with torch.cuda.device(x.device):
-            return _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prepared)
+            return _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prepared, need_out)
+    if not need_out and not spec.recording and stats is None:
+        with torch.cuda.device(x.device):
+            return _rnn_forward_nograd(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, need_out)
     with torch.cuda.device(x.device):       # the library launches on the CURRENT device's context
         return _TTRnnLayerFn.apply(x, h0, c0, bias_in, bias_hid, spec, len(cores_in), stats, *(cores_in + cores_hid))

@@ -762,6 +762,34 @@ def test_gru_four_wave_kernel_matches_eight_wave_kernel_and_oracle():
             assert torch.isfinite(a).all() and _maxabs(a, bq) <= 3e-2 * max(float(bq.abs().max()), 1e-6), n
 
 
+def test_last_layer_outputs_can_be_skipped_in_inference():
+    """need_outputs=False (speaker_encoder.py:80-86 consumes only the last hidden state): under no_grad the last layer's
+    four-wave fused-core kernel does not write `out` (ttrnn_rnn_out_optional); final states must be bit-identical to the
+    ordinary call, with and without prepared weights; routes that cannot skip the store return the outputs as usual, and
+    autograd runs ignore the flag."""
+    import ctypes
+    from ttrnn_hip import _lib
+    torch.manual_seed(8)
+    for meta, B, T, optional in ((dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16), 300, 7, 1),
+                                 (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 6, 30, 1),
+                                 (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0)):
+        m = build_module(meta, dev()).eval()
+        x = torch.randn(B, T, meta["input_size"], device=dev())
+        desc = m._all_layers[-1]._layer_spec().desc(B, T, 0)
+        assert _lib.load().ttrnn_rnn_out_optional(ctypes.byref(desc)) == optional
+        with torch.no_grad():
+            ref_out, (rh, rc) = m(x)
+            out, (h, c) = m(x, need_outputs=False)
+            assert (out is None) == bool(optional)
+            assert torch.equal(h, rh) and torch.equal(c, rc)
+            m.prepare_for_inference()
+            out2, (h2, c2) = m(x, need_outputs=False)
+            assert (out2 is None) == bool(optional) and torch.equal(h2, rh) and torch.equal(c2, rc)
+            m.release_prepared()
+        out3, _ = m(x, need_outputs=False)               # recording: the backward pass needs the outputs
+        assert out3 is not None and torch.equal(out3, ref_out)
+
+
 def test_prepared_weights_inference_matches_and_tracks_updates():
     """prepare_for_inference(): repeated no-grad forwards reuse the packed cores and the weight-only part of the call
     (ttrnn_rnn_forward_phase: PREPARE once per input shape, RUN per call).  Results must be bit-identical to the ordinary
