@@ -220,16 +220,25 @@ def run_grid(args, device):
     B, T, inp = 64, 64, 40
     rows = []
 
-    def timed(m, x, n):
-        with torch.no_grad():
-            m(x)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(n):
-                t0 = time.perf_counter()
+    train = args.mode == "train"      # forward + BPTT (loss = sum of the outputs) instead of the no_grad forward
+
+    def one(m, x):
+        if not train:
+            with torch.no_grad():
                 m(x)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
+            return
+        m.zero_grad(set_to_none=True)
+        m(x)[0].sum().backward()
+
+    def timed(m, x, n):
+        one(m, x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            one(m, x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
         return sorted(ts)[len(ts) // 2] * 1e3
 
     for cell, cls in (("lstm", TTLSTM), ("gru", TTGRU)):
@@ -241,21 +250,24 @@ def run_grid(args, device):
                         m = cls(inp, H, 1, device, n_cores=d, tt_rank=r).eval()
                     x = torch.rand(B, T, inp, device=device)
                     route = F.rnn_route(m._all_layers[0]._layer_spec(), B, T)
+                    bwd_route = F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T)
                     ms = timed(m, x, max(3, args.steps // 4))
                     with ttrnn_hip.option("force_generic", 1):
                         valu_ms = timed(m, x, 3)
-                    rows.append({"cell": cell, "H": H, "ncores": d, "ttrank": r, "route": route, "ms": round(ms, 4),
+                    rows.append({"cell": cell, "H": H, "ncores": d, "ttrank": r, "route": route, "bwd_route": bwd_route, "ms": round(ms, 4),
                                  "valu_ms": round(valu_ms, 4), "speedup": round(valu_ms / ms, 2)})
     on_valu = [r for r in rows if r["route"] == "valu"]
     geo = 1.0
     for r in rows:
         geo *= r["speedup"] ** (1.0 / len(rows))
-    line = {"metric": "forward time per shape, MFMA route vs any-shape VALU kernels (geometric-mean speed-up)", "value": geo,
+    line = {"metric": ("training step (forward + BPTT)" if train else "forward") +
+                      " time per shape, MFMA route vs any-shape VALU kernels (geometric-mean speed-up)", "value": geo,
             "unit": "x", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "grid: TT-LSTM / TT-GRU in=40, H in {64..1024}, ncores in {2,3,4}, ttrank in {2,4,8,16}, "
-                                   "batch 64, seq_len 64, forward (no_grad)"},
+                                   "batch 64, seq_len 64, " + ("forward + backward of sum(outputs)" if train else "forward (no_grad)")},
             "shapes": len(rows), "shapes_on_valu_route": len(on_valu),
+            "bwd_routes": {k: sum(1 for r in rows if r["bwd_route"] == k) for k in sorted({r["bwd_route"] for r in rows})},
             "routes": {k: sum(1 for r in rows if r["route"] == k) for k in sorted({r["route"] for r in rows})},
             "grid": rows}
     print(json.dumps(line))

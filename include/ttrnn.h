@@ -251,6 +251,9 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc);   /* TTRNN_ROUTE_* or a
  *      what the tensor hooks of ActivGradLogger see (rnn_utils.py:127-171, lstm.py:35-39).  Requesting it selects the
  *      runtime-shape / any-shape reverse kernels, which write it from the registers that already hold the values. */
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc);
+/* Kernel family of the reverse-time kernel for this descriptor under the current options (TTRNN_ROUTE_*; want_state != 0: a
+ * d_state request).  Pure host logic, as ttrnn_rnn_forward_route. */
+int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state);
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve,
                        const void* d_out, const void* d_hT, const void* d_cT,

@@ -660,6 +660,21 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   return TTRNN_ROUTE_VALU;
 }
 
+int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
+  if (force_generic()) return TTRNN_ROUTE_VALU;
+  const bool g2_first = (opt(OPT_FORCE_G2) || want_state) && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
+  if (!g2_first && !want_state && fast_rnn_bwd_available(rs, desc->dtype)) {
+    if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 && f10_rnn_bwd_available(rs, desc->dtype))
+      return TTRNN_ROUTE_FUSED_CORE;
+    return TTRNN_ROUTE_STAGEWISE_MFMA;
+  }
+  if (!g2_first && !want_state && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
+  if (rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  return TTRNN_ROUTE_VALU;
+}
+
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,

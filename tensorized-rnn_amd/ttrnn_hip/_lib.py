@@ -73,6 +73,7 @@ _SIGNATURES = {
     "ttrnn_rnn_out_optional": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward_phase": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_backward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

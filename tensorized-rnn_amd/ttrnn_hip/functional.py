@@ -515,6 +515,15 @@ def rnn_route(spec, batch, seq_len, dtype=torch.float32):
     return _lib.ROUTES[code]
 
 
+def rnn_backward_route(spec, batch, seq_len, dtype=torch.float32, want_state=False):
+    """Name of the kernel family of the reverse-time kernel (BPTT) for this layer at this size."""
+    desc = spec.desc(batch, seq_len, _DT[dtype])
+    code = _lib.load().ttrnn_rnn_backward_route(ctypes.byref(desc), 1 if want_state else 0)
+    if code < 0:
+        check(code, "ttrnn_rnn_backward_route")
+    return _lib.ROUTES[code]
+
+
 class StepStats(object):
     """Feeds the per-timestep statistics of ActivGradLogger (reference: tensorized_rnn/rnn_utils.py:127-171,217-226 —
     mean over the batch of ||v_t||^2 and of log ||v_t||^2, for v = h, c and their gradients) from ONE fused sequence call
