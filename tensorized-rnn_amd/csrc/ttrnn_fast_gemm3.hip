@@ -121,8 +121,13 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3h(int64_t n_rows, int64_t n_pa
     mt_tile = (int)(g % smc) * 8 + (within & 7);
     rt_tile = (g / smc) * 4 + (within >> 3);
   } else {
-    mt_tile = (int)(blockIdx.x % MT);
-    rt_tile = blockIdx.x / MT;
+    // few feature tiles (cfg4: 4): all feature tiles of a row tile on ONE XCD, so that its L2 serves the row tile's pieces of x
+    // to all of them (consecutive block ids go to different XCDs: every feature tile fetched the rows from HBM again, 815 MB per
+    // cfg4 layer against 420 MB of operands + output)
+    const int xcd = blockIdx.x & 7;
+    const int64_t i = blockIdx.x >> 3;
+    rt_tile = (i / MT) * 8 + xcd;
+    mt_tile = (int)(i % MT);
   }
   if (rt_tile >= RT) return;
   const int m0 = mt_tile * G3_TF;
@@ -342,7 +347,7 @@ int launch_gemm3h(int dtype, int64_t n_rows, int K, int M, const void* x, const 
     const int64_t supers = (int64_t)(MT / 8) * ((RT + 3) / 4);
     grid = ((supers + 7) / 8) * 8 * 32;
   } else {
-    grid = (int64_t)MT * RT;
+    grid = 8 * ((RT + 7) / 8) * (int64_t)MT;
   }
   // dev bit 0 (harness A/B): the ping-pong schedule.  Both schedules land within 3 % of each other (tools/gemm3_bench:
   // 2.25 / 2.31 ms without the output stores at cfg5's size = the 56-59 % of the f16 peak the chip sustains on random operands),

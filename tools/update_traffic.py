@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REC = {"cfg1": "k_g2_fwd", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10", "cfg4": "k_lstm_fwd_f10q", "cfg5": "k_lstm_fwd_big2h"}
+REC = {"cfg1": "k_lstm_fwd_fused", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10", "cfg4": "k_lstm_fwd_f10q", "cfg5": "k_lstm_fwd_big2h"}
 LAYERS = {"cfg1": 1, "cfg2": 1, "cfg3": 1, "cfg4": 3, "cfg5": 1}
 # kernels of the OTHER math mode that bench.py also times in the same process (not part of the default forward)
 SKIP = ("k_lstm_fwd_f10x", "k_f10x_prep", "k_lstm_fwd_fused", "k_ttlinear_fwd_fast[J=4x8x8", "k_ttlinear_fwd_fast[J=2x4x5", "k_lstm_fwd_big2[",
@@ -24,13 +24,14 @@ def main(src, label):
         if not os.path.exists(path):
             continue
         pm = json.load(open(path))["pmc_mean_per_dispatch"]
-        rec = [k for k in pm if k.startswith(REC[w]) and not any(k.startswith(s) for s in SKIP)]
+        skip = tuple(s for s in SKIP if REC[w] != s.rstrip("["))
+        rec = [k for k in pm if k.startswith(REC[w]) and not any(k.startswith(s) for s in skip)]
         if not rec or "hbm_bytes_per_dispatch" not in pm[rec[0]]:
             continue
         calls = pm[rec[0]]["_dispatches"] / float(LAYERS[w])          # forward calls of the model in the PMC pass
         total, parts = 0.0, {}
         for k, v in pm.items():
-            if any(k.startswith(s) for s in SKIP) or "hbm_bytes_per_dispatch" not in v:
+            if any(k.startswith(s) for s in skip) or "hbm_bytes_per_dispatch" not in v:
                 continue
             b = v["hbm_bytes_per_dispatch"] * v["_dispatches"] / calls
             total += b
