@@ -87,13 +87,14 @@ template <class S>
 constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
 
 // ---- two-piece fp16 operands (LSTM forward kernels): scale header + fragments --------------------------------------
-// The diagonal power-of-two scales of ttrnn_f10_dev.h, from the cores themselves.  F10H_PARTS workgroups; every one derives
-// eu / ev from core 2 (a thousand entries) and then takes M / F10H_PARTS rows of the fused core, one wave per row:
+// The diagonal power-of-two scales of ttrnn_f10_dev.h, from the cores themselves.  F10H_PARTS = M workgroups; every one derives
+// eu / ev from core 2 (one or two thousand entries) and then takes ONE row of the fused core (16 workgroups of four rows each
+// took 11 us for r = 16: a row is 512 dot products of 16 terms):
 //   eu[i2] = -expo(max_{r2,j2} |G2|),  ev[r2] = -expo(max_{i2,j2} 2^eu |G2|),  ep[m] = 12 - expo(max_k 2^-ev |W10[m][k]|)
 template <class S>
 __global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, int* __restrict__ hdr) {
   using F = F10<S>;
-  static_assert(F::M == 4 * F10H_PARTS && F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one wave per row of the fused core");
+  static_assert(F::M == F10H_PARTS && F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one workgroup per row of the fused core");
   __shared__ unsigned mx[32];
   __shared__ int eu[16], ev[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,13 +113,14 @@ __global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ pa
   __syncthreads();
   if (tid < 16) ev[tid] = tid < F::R2 ? -f10h_expo(__uint_as_float(mx[16 + tid])) : 0;
   __syncthreads();
-  // row m of the fused core (the same fmaf chain as k_f10h_prep): lanes over k = (row2, r2)
-  const int m = 4 * blockIdx.x + wave;
+  // row m = blockIdx.x of the fused core (the same fmaf chain as k_f10h_prep): the workgroup's threads over k = (row2, r2)
+  __shared__ float red[4];
+  const int m = blockIdx.x;
   const int i0 = m / F::I1, i1 = m % F::I1;
   const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
   const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
   float best = 0.f;
-  for (int k = lane; k < F::K; k += 64) {
+  for (int k = tid; k < F::K; k += 256) {
     const int r2 = k % F::R2, row2 = k / F::R2;
     const int j1 = row2 % F::J1, j0 = row2 / F::J1;
     const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
@@ -128,7 +130,9 @@ __global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ pa
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
-  if (lane == 0) hdr[F10H_EP + m] = 12 - f10h_expo(best);
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (tid == 0) hdr[F10H_EP + m] = 12 - f10h_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
   if (blockIdx.x == 0 && tid < 16) {
     hdr[F10H_EU + tid] = eu[tid];
     hdr[F10H_EV + tid] = ev[tid];
@@ -734,7 +738,7 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   constexpr size_t lds = f10h_lds_bytes<S, KS>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
-  const bool dg = opt(OPT_DIAG) && reserve;
+  const bool dg = opt(OPT_DIAG) && reserve && opt(OPT_F10_NB1);      // stamped eight-wave build; the four-wave kernel has its own
   // Four-wave workgroups (ttrnn_fast_f10q.hip; bit-identical results): always for r = 8 — 1 ... 3 % faster than the
   // eight-wave kernel even with one workgroup per CU (fewer waves per barrier, no LDS copy of h for the output store) — and
   // for r = 16 once two workgroups can share a CU (B > #CUs / 2: 5 % at B = 192, 10 % at B = 512; below that the eight-wave

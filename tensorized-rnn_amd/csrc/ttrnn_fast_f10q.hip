@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 #include "ttrnn_f10.h"
@@ -31,7 +32,8 @@ constexpr size_t f10q_lds_bytes() {
 // KH = 1: one accumulation over all k-blocks (= k_lstm_fwd_f10<S, 1>);  KH = 2: the two halves of k_lstm_fwd_f10<S, 2>
 // H0: the caller passed an initial state (it may lie outside (-1, 1): f10h_h0_expo); without one the scales are constants
 // OUT = false: the caller consumes only the final state (speaker_encoder.py:80-86 takes `hidden[-1]`): `out` is not written
-template <class S, int KH, bool H0, bool OUT>
+// DIAG: s_memtime stamps around the phases (option diag + a reserve buffer; tools/diag_stamps.py; shares only, never run times)
+template <class S, int KH, bool H0, bool OUT, bool DIAG = false>
 __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                const float* __restrict__ c0,
                                                                const float* __restrict__ packed_hid,
@@ -109,6 +111,9 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   // (Delaying the workgroup in the odd wave slot by half a step — so that the two workgroups of a CU start out of phase —
   // changed nothing: measured 1.71 ms for every delay between 0 and 3 800 cycles on cfg4.)
 
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   f32x4 us_t = usc * h0un;                  // step 0 runs on 2^-e0 h_0 (f10h_h0_expo); reset to usc / 1 at the end of it
   float ps_t = h0sc;
@@ -131,7 +136,9 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
         f10h_s2_store<S>(t2[x][1], img, wave + QW * (x0 + x), 1, lane);
       }
     }
+    TT_STAMP(0)
     lds_barrier();
+    TT_STAMP(1)
     const size_t bt = b * T + t;
     // ---- phase B: the fused S1*S0 stage, then gates + state (lstm.py:26-32) -----------------------------------
     f32x4 acc;
@@ -148,7 +155,9 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
         f10h_s10_part<S, NH>(w10[1], img, row10, q, NH, bl, bhh);
         acc += bhh * un + bl * un;
       }
+      if constexpr (DIAG) asm volatile("" : "+v"(acc));
     }
+    TT_STAMP(2)
     const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));                // lstm.py:26
     const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1]));                // lstm.py:27
     const float gg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2]));  // lstm.py:28
@@ -170,11 +179,20 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
     }
     if (in1) xq.advance(xs, b * T, T, t, lane);
     us_t = usc; ps_t = 1.0f;
+    TT_STAMP(3)
     lds_barrier();
+    TT_STAMP(4)
   }
   if (ok) {
     if (hT) hT[b * H + hd] = hst;
     if (cT) cT[b * H + hd] = cst;
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && reserve && b < 8) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * 8 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = seg[i];
+    }
   }
 }
 
@@ -187,6 +205,7 @@ static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* 
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   auto kern = out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true> : k_lstm_fwd_f10q<S, KH, false, true>)
                   : (h0 ? k_lstm_fwd_f10q<S, KH, true, false> : k_lstm_fwd_f10q<S, KH, false, false>);
+  if (opt(OPT_DIAG) && reserve && out && !h0) kern = k_lstm_fwd_f10q<S, KH, false, true, true>;      // stamped build (diagnostics)
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);

@@ -31,12 +31,13 @@ for _ in range(2):
 torch.cuda.synchronize()
 raw = captured["reserve"][:8 * 8 * 8 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
 import ttrnn_hip
-if ttrnn_hip.get_fp32_math() == "split":     # k_lstm_fwd_f10 (ttrnn_fast_f10.hip)
-    names = ["S2+split", "barrier1", "S10 mma", "gates", "barrier2", "-", "-", "-"]
+NW = 8 if os.environ.get("TTRNN_F10_NB1") == "1" else 4      # default: the four-wave kernel k_lstm_fwd_f10q (waves 4..7: unused slots)
+if ttrnn_hip.get_fp32_math() == "split":     # k_lstm_fwd_f10q / k_lstm_fwd_f10 (ttrnn_fast_f10q.hip, ttrnn_fast_f10.hip)
+    names = ["S2+split", "barrier1", "S10 mma", "gates+stores", "barrier2", "-", "-", "-"]
 else:                                        # k_lstm_fwd_fused (ttrnn_fast.hip)
     names = ["S2 mma+store", "barrier1", "S1 mma+store", "barrier2", "S0 mma", "gates", "barrier3", "-"]
 per_step = raw.astype(np.float64) / T
 print("cycles per step (mean over 8 blocks), per wave:")
-for w in range(8):
+for w in range(NW):
     print("wave", w, " ".join("%7.0f" % v for v in per_step[:, w, :7].mean(0)), " total %.0f" % per_step[:, w, :7].mean(0).sum())
 print("segments:", names[:7])
