@@ -38,8 +38,12 @@ class MNISTClassifier(nn.Module):
         return self.rnn.param_count() + sum(p.numel() for p in self.linear.parameters())
 
     def forward(self, inputs):
-        out = self.rnn(inputs)[0]
-        return self.linear.forward_head(out[:, -1, :], "log_softmax")       # TTLinear + log_softmax: one library call
+        # the reference classifies outputs[:, -1, :] (mnist_classifier.py:52-55), which IS the last layer's final hidden state:
+        # taking it from the state instead of slicing the [B, T, H] outputs spares autograd a zero-filled [B, T, H] gradient
+        # (51 MB per cfg2 step) that the reverse-time kernel would then read
+        res = self.rnn(inputs)
+        last = res[1] if self.gru else res[1][0]
+        return self.linear.forward_head(last, "log_softmax")                # TTLinear + log_softmax: one library call
 
 
 class SpeakerEncoder(nn.Module):
