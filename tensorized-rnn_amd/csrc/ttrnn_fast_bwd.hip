@@ -862,7 +862,8 @@ static int launch_lin_bwd(int dtype, int dy_dtype, int64_t n_rows, const float* 
   X(ShpH256R8G, 2)        \
   X(ShpH256R16L, 1)       \
   X(ShpH256R16G, 1)       \
-  X(ShpH128R4L, 8)
+  X(ShpH128R4L, 8)        \
+  X(ShpHd256R16, 2)
 
 bool fast_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype) {
   if (dtype == TTRNN_F32 && dy_dtype != TTRNN_F32) return false;

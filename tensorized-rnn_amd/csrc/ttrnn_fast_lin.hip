@@ -169,7 +169,8 @@ static int launch_lin(int dtype, bool y_f32, int64_t n_rows, const float* packed
   X(ShpH256R8G, 4)            \
   X(ShpH256R16L, 2)           \
   X(ShpH256R16G, 2)           \
-  X(ShpH128R4L, 16)
+  X(ShpH128R4L, 16)           \
+  X(ShpHd256R16, 4)
 
 bool fast_ttlinear_fwd_available(const TtShape& s, int dtype, int ilv_h) {
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;

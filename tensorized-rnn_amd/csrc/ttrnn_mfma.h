@@ -371,5 +371,9 @@ using ShpI1R8L = Shp<3, 1, 1, 1, 1, 8, 8, 16, 1, 8, 8, 1>;       // cfg2: in=1  
 using ShpI1R8G = Shp<3, 1, 1, 1, 1, 8, 8, 12, 1, 8, 8, 1>;       // cfg3: in=1  -> 3*256
 using ShpI40R16L = Shp<3, 2, 4, 5, 1, 8, 8, 16, 1, 16, 16, 1>;   // cfg4: in=40 -> 4*256
 using ShpI1R4L = Shp<2, 1, 1, 1, 1, 16, 32, 1, 1, 4, 1, 1>;      // cfg1: in=1  -> 4*128
+// TTLinear heads of the callers (speaker_encoder.py:47-48: 256 -> 256, d = 3, r = 16)
+using ShpHd256R16 = Shp<3, 4, 8, 8, 1, 4, 8, 8, 1, 16, 16, 1>;
+// (the classifier of benchmarking.py on the cfg5 model, 1024 -> 256 with d = 4, r = 32, does NOT fit this path: its chain images
+// need 266 KB of LDS per row; it stays on the any-shape kernels)
 
 }  // namespace ttrnn
