@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 3
+#define TTRNN_ABI_VERSION 4
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {
@@ -172,6 +172,23 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
                             const void* x, const void* dy, void* dx, float* d_packed,
                             float* d_bias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with hints from the producer of the operands, which save this call its own passes over the rows (all device pointers,
+ * any may be NULL, hints == NULL: exactly ttrnn_ttlinear_backward):
+ *   x_colmax  fp32[in]  UPPER BOUNDS of max_n |x[n][j]|  (rows that are LSTM hidden states: all 1.0)
+ *   dy_colmax fp32[out] UPPER BOUNDS of max_n |dy[n][o]| (ttrnn_rnn_backward_ex: stats rows 0 / 1)
+ *             With dy's bounds the dense weight gradient runs on two fp16 pieces under per-column scales
+ *             at every size; a bound BELOW the true maximum overflows the fp16 pieces (inf / NaN in d_packed).
+ *   xdy_sum   fp32[out] in_size == 1, dx == NULL, d_bias == NULL: sum_n x[n] dy[n][:] (stats row 2) — the weight gradient then
+ *             needs no pass over dy at all (the bias gradient is stats row 3). */
+typedef struct ttrnn_lin_hints {
+  const float* x_colmax;
+  const float* dy_colmax;
+  const float* xdy_sum;
+} ttrnn_lin_hints;
+int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                                   const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
+                                   const ttrnn_lin_hints* hints, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- TTLinear heads with fused row-wise epilogues ---------------------------------------------------------------
  * The step right after the path in both callers:
  *   TTRNN_EPI_LOG_SOFTMAX   y = log_softmax(TT(x) + b, dim=1)      experiments/digit_classification/mnist_classifier.py:55-57
@@ -259,6 +276,28 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
                        const void* d_out, const void* d_hT, const void* d_cT,
                        float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0, float* d_state,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same, also returning by-products of the reverse-time kernel that the weight-gradient step would otherwise compute by
+ * passes of its own over d_gates (cfg2: 66 us of a 2.0 ms training step for the input_size == 1 reduction; column-maximum
+ * passes of the two-piece fp16 dense gradient):
+ *   stats  fp32 [4][G*H] (overwritten), NULL = none wanted:
+ *          rows 0 / 1   max_n |d_gates_in[n][c]| / max_n |d_gates_hid[n][c]|                        TTRNN_BWD_STATS_COLMAX
+ *          rows 2 / 3   sum_n x[n] d_gates_in[n][c] / sum_n d_gates_in[n][c]  (input_size == 1, x != NULL; summed per sample in
+ *                       the kernel, then over the samples in a fixed order: repeatable bit for bit)  TTRNN_BWD_STATS_IN1SUMS
+ *   x      the layer's input [B][T][1] (storage dtype), needed for rows 2 / 3 only.
+ * ttrnn_rnn_backward_stats(desc): bitmask of what the route of this descriptor delivers under the current options (the
+ * fused-core reverse kernels do; 0 elsewhere).  Passing stats != NULL where it returns 0, or together with d_state, is
+ * TTRNN_ERR_UNSUPPORTED.  Hand the rows to ttrnn_ttlinear_backward_hinted. */
+#define TTRNN_BWD_STATS_COLMAX 1
+#define TTRNN_BWD_STATS_IN1SUMS 2
+#define TTRNN_BWD_STATS_ROWS 4
+int ttrnn_rnn_backward_stats(const ttrnn_rnn_desc* desc);
+int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
+                          const float* packed_hid, const float* reserve,
+                          const void* d_out, const void* d_hT, const void* d_cT,
+                          float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0, float* d_state,
+                          const void* x, float* stats,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -306,6 +306,16 @@ int ttrnn_ttlinear_forward(const ttrnn_ttm* w, int dtype, int64_t n_rows, const 
 int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  return ttrnn_ttlinear_backward_hinted(w, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, nullptr, workspace,
+                                        workspace_bytes, stream);
+}
+
+int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                                   const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
+                                   const ttrnn_lin_hints* hints, void* workspace, size_t workspace_bytes, void* stream) {
+  const unsigned* hx = hints ? reinterpret_cast<const unsigned*>(hints->x_colmax) : nullptr;
+  const unsigned* hdy = hints ? reinterpret_cast<const unsigned*>(hints->dy_colmax) : nullptr;
+  const float* hsum = hints ? hints->xdy_sum : nullptr;
   TtShape s;
   int st = tt_shape_init(&s, w);
   if (st != TTRNN_OK) return st;
@@ -323,6 +333,11 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       float* dv = (float*)workspace;
       const void* unit = unit_rows_ptr(dtype);
       if (!unit) return TTRNN_ERR_LAUNCH;
+      if (hsum && !d_bias) {
+        // the producer of dy has the row sums already (ttrnn_rnn_backward_ex, TTRNN_BWD_STATS_IN1SUMS): no pass over dy
+        return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, hsum, nullptr, d_packed, nullptr,
+                                        (hipStream_t)stream);
+      }
       if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return TTRNN_ERR_LAUNCH;
       st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (hipStream_t)stream);
@@ -347,7 +362,8 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
       st = launch_fill_identity(dtype, s.in_size, ident, sm);
       if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm,
                                                  fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16,
-                                                 (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)));
+                                                 (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)), hx,
+                                                 hdy);
       if (st == TTRNN_OK)
         st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       if (st != TTRNN_OK || !dx) return st;
@@ -377,10 +393,13 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
     float* dv = (float*)workspace;
     const void* unit = unit_rows_ptr(TTRNN_F32);
     if (!unit) return TTRNN_ERR_LAUNCH;
+    const LinPlan p1 = plan_ttlinear_bwd(s, 1);
+    if (hsum && !d_bias)
+      return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit, hsum, nullptr, d_packed, nullptr,
+                                 (char*)workspace + in1_bwd_bytes(s), sm);
     if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), sm) != hipSuccess) return TTRNN_ERR_LAUNCH;
     st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, sm);
     if (st != TTRNN_OK) return st;
-    const LinPlan p1 = plan_ttlinear_bwd(s, 1);
     return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
                                (char*)workspace + in1_bwd_bytes(s), sm);
   }
@@ -400,7 +419,8 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
     void* lin_fwd = p;
     st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
     if (st == TTRNN_OK)
-      st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch);
+      st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch, hx,
+                              hdy);
     if (st == TTRNN_OK) {
       const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
       st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
@@ -675,14 +695,42 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
   return TTRNN_ROUTE_VALU;
 }
 
+// which by-products (TTRNN_BWD_STATS_*) does the reverse-time route of this descriptor deliver?  The fused-core kernels:
+// the column maxima, and the input_size == 1 sums
+static int bwd_stats_mask(const RnnShape& rs, int dtype) {
+  if (force_generic() || opt(OPT_FORCE_G2) || rs.T < 1 || rs.B < 1) return 0;
+  if (fast_rnn_bwd_available(rs, dtype) && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) &&
+      f10_rnn_bwd_available(rs, dtype))
+    return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0);
+  return 0;
+}
+
+int ttrnn_rnn_backward_stats(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return bwd_stats_mask(rs, desc->dtype);
+}
+
 int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
                        float* d_state, void* workspace, size_t workspace_bytes, void* stream) {
+  return ttrnn_rnn_backward_ex(desc, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
+                               d_state, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,
+                          const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
+                          const void* d_cT, float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0,
+                          float* d_state, const void* x, float* stats, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   RnnShape rs;
   int st = rnn_shape_init(&rs, desc);
   if (st != TTRNN_OK) return st;
   if (rs.B == 0) return TTRNN_OK;
+  // by-products come from the fused-core reverse kernels only: a request elsewhere (or together with d_state, which
+  // selects another route) is an error, not a silent omission — ask ttrnn_rnn_backward_stats first
+  if (stats && (d_state || bwd_stats_mask(rs, desc->dtype) == 0)) return TTRNN_ERR_UNSUPPORTED;
   if (!packed_hid) return TTRNN_ERR_NULL;
   if (rs.T > 0 && (!reserve || !d_gates_in || !out)) return TTRNN_ERR_NULL;
   if (rs.cell == TTRNN_GRU && rs.T > 0 && !d_gates_hid) return TTRNN_ERR_NULL;
@@ -695,7 +743,7 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
         f10_rnn_bwd_available(rs, desc->dtype)) {
       if (!workspace || workspace_bytes < f10_rnn_bwd_workspace_bytes(rs, desc->dtype)) return TTRNN_ERR_WORKSPACE;
       return launch_rnn_bwd_f10(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
-                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream);
+                                d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream, x, stats);
     }
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
                                                           const float* __restrict__ d_cT, float* __restrict__ dg_in,
                                                           float* __restrict__ dg_hid, float* __restrict__ d_h0,
                                                           float* __restrict__ d_c0,
-                                                          unsigned long long* __restrict__ diag) {
+                                                          unsigned long long* __restrict__ diag, BwdStats bs) {
   static_assert(f10b_ok<S>(), "shape not supported by the fused-core reverse-time kernel");
   using F = F10<S>;
   using B = F10B<S>;
@@ -182,6 +182,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
   float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;                               // c of the three sets (a dwordx4 load with dead
                                                                        // lanes gets its registers reused -> WAW wait)
   float do0 = 0.f, do1 = 0.f, do2 = 0.f;
+  // by-products for the weight-gradient step (BwdStats, ttrnn_launch.h): column maxima of the gate gradients and, for
+  // input_size == 1, this sample's sums of x_t dg_t and dg_t — 12 VALU operations per step in registers the G phase owns.
+  // x_t rides in the rotating sets (a null x reads the reserve and is scaled by zero, as d_out)
+  const float* xptr = bs.x ? reinterpret_cast<const float*>(bs.x) : reserve;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  float xq0 = 0.f, xq1 = 0.f, xq2 = 0.f;
+  f32x4 cmx = f32x4{0.f, 0.f, 0.f, 0.f}, sxd = cmx, sdg = cmx;
   if (own) {
     dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
 #pragma unroll
@@ -193,10 +200,12 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       ra0 = *reinterpret_cast<const f32x4*>(rv);
       rb0 = rc[0];
       do0 = dptr[bt * H + hid];
+      xq0 = xptr[bt];
       if (T > 1) {
         ra1 = *reinterpret_cast<const f32x4*>(rv - H * 4);
         rb1 = rc[-H];
         do1 = dptr[(bt - 1) * H + hid];
+        xq1 = xptr[bt - 1];
       }
     }
   }
@@ -208,7 +217,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
 
   // one timestep; (ra, rb, dout_c) = record / d_out of step t, nb = record(t-1) (its c), (fa, fb, dout_f): in-flight set
   auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dout_c, const float& nb, f32x4& fa,
-                  float& fb, float& dout_f) {
+                  float& fb, float& dout_f, const float& x_c, float& x_f) {
     const size_t bt = b * T + t;
     // ---- G: gate gradients (lstm.py:26-32 differentiated) ---------------------------------------------------------
     if (own) {
@@ -219,6 +228,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
         fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
         fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
         dout_f = dptr[b2 * H + hid];                 // scaled where it is consumed
+        x_f = xptr[b2];
       }
       const f32x4 qa = ra;
       float dht = dout_c * dscale;
@@ -233,6 +243,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
       const float p2 = dct * ig * (1.0f - gg * gg);             //                     g
       const float p3 = dht * tc * og * (1.0f - og);             //                     o
       dcs = dct * fg;
+      {
+        const f32x4 pv = f32x4{p0, p1, p2, p3};
+        const float xv = x_c * xscale;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          cmx[g] = fmaxf(cmx[g], fabsf(pv[g]));
+          sxd[g] = fmaf(xv, pv[g], sxd[g]);
+          sdg[g] += pv[g];
+        }
+      }
       dgf[hid] = p0; dgf[H + hid] = p1; dgf[2 * H + hid] = p2; dgf[3 * H + hid] = p3;
       // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
       store_split4(img1, B::PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), f32x4{p0, p1, p2, p3});
@@ -296,9 +316,23 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10(int Bn, int T, const f
     TT_STAMP(5)
   };
   for (int t = T - 1; t >= 0; t -= 3) {
-    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2);
-    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0);
-    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1);
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2, xq0, xq2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0, xq1, xq0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1, xq2, xq1);
+  }
+  if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmx[g]));
+    }
+    if (bs.part) {
+      float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pp[g * H + hid] = sxd[g];
+        pp[GH + g * H + hid] = sdg[g];
+      }
+    }
   }
   if constexpr (DIAG) {
     if (lane == 0 && diag && b < 8) {
@@ -344,7 +378,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS
                                                          const float* __restrict__ reserve,
                                                          const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
                                                          float* __restrict__ dg_in, float* __restrict__ dg_hid,
-                                                         TS* __restrict__ d_h0) {
+                                                         TS* __restrict__ d_h0, BwdStats bs) {
   static_assert(f10b_gru_ok<S>(), "shape not supported by the fused-core GRU reverse-time kernel");
   using F = F10<S>;
   using B = F10B<S>;
@@ -385,30 +419,38 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS
   const float dscale = d_out ? 1.0f : 0.0f;
   f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
   TS do0 = TS{}, do1 = TS{}, do2 = TS{}, hp0 = TS{}, hp1 = TS{}, hp2 = TS{};
-  auto issue = [&](int t, f32x4& ra, TS& dq, TS& hq) {       // loads of set(t); clamped, unconditional
+  // by-products (BwdStats; see k_lstm_bwd_f10): column maxima of both gradient rows — they differ in the n gate — and the
+  // sample's sums of x_t dg_in_t and dg_in_t; a null x reads `out` and is scaled by zero
+  const TS* xptr = bs.x ? reinterpret_cast<const TS*>(bs.x) : out;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  TS xq0 = TS{}, xq1 = TS{}, xq2 = TS{};
+  float cmi[3] = {0.f, 0.f, 0.f}, sxd[3] = {0.f, 0.f, 0.f}, sdg[3] = {0.f, 0.f, 0.f}, cmh = 0.f;
+  auto issue = [&](int t, f32x4& ra, TS& dq, TS& hq, TS& xq) {       // loads of set(t); clamped, unconditional
     const size_t bt = b * T + (t > 0 ? t : 0);
     ra = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
     dq = dptr[bt * H + hid];
     const TS* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);
     hq = hp[hid];
+    xq = xptr[bt];
   };
   if (own) {
     dhs[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
 #pragma unroll
     for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
     if (T > 0) {
-      issue(T - 1, ra0, do0, hp0);
-      issue(T - 2, ra1, do1, hp1);
+      issue(T - 1, ra0, do0, hp0, xq0);
+      issue(T - 2, ra1, do1, hp1, xq1);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   lds_barrier();
 
-  auto step = [&](const int t, const f32x4& ra, const TS& dq, const TS& hq, f32x4& fa, TS& fd, TS& fh) {
+  auto step = [&](const int t, const f32x4& ra, const TS& dq, const TS& hq, const TS& xq, f32x4& fa, TS& fd, TS& fh,
+                  TS& fx) {
     const size_t bt = b * T + t;
     // ---- G: gate gradients (gru.py:38-44 differentiated) -----------------------------------------------------------
     if (own) {
-      issue(t - 2, fa, fd, fh);
+      issue(t - 2, fa, fd, fh, fx);
       float dht = dhd + to_f32(dq) * dscale;
 #pragma unroll
       for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
@@ -419,6 +461,17 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS
       const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
       dhd = dht * zg;
       const float pv[3] = {dr_pre, dz_pre, dn_pre * rg};
+      {
+        const float pin[3] = {dr_pre, dz_pre, dn_pre};
+        const float xv = to_f32(xq) * xscale;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          cmi[g] = fmaxf(cmi[g], fabsf(pin[g]));
+          sxd[g] = fmaf(xv, pin[g], sxd[g]);
+          sdg[g] += pin[g];
+        }
+        cmh = fmaxf(cmh, fabsf(pv[2]));
+      }
       dg_in[bt * GH + 2 * H + hid] = dn_pre;                // the only block where d_gates_in != d_gates_hid
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
@@ -484,9 +537,26 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS
     lds_barrier();
   };
   for (int t = T - 1; t >= 0; t -= 3) {
-    step(t, ra0, do0, hp0, ra2, do2, hp2);
-    if (t >= 1) step(t - 1, ra1, do1, hp1, ra0, do0, hp0);
-    if (t >= 2) step(t - 2, ra2, do2, hp2, ra1, do1, hp1);
+    step(t, ra0, do0, hp0, xq0, ra2, do2, hp2, xq2);
+    if (t >= 1) step(t - 1, ra1, do1, hp1, xq1, ra0, do0, hp0, xq0);
+    if (t >= 2) step(t - 2, ra2, do2, hp2, xq2, ra1, do1, hp1, xq1);
+  }
+  if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmi[g]));
+        atomicMax(bs.colmax + GH + g * H + hid, __float_as_uint(g < 2 ? cmi[g] : cmh));
+      }
+    }
+    if (bs.part) {
+      float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        pp[g * H + hid] = sxd[g];
+        pp[GH + g * H + hid] = sdg[g];
+      }
+    }
   }
   if (own && d_h0) {
     float v = dhd;
@@ -499,7 +569,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10(int Bn, int T, const TS
 template <class S, typename TS>
 static int launch_gru_bwd_f10(const RnnShape& rs, const void* out, const void* h0, const float* packed_hid,
                               const float* reserve, const void* d_out, const void* d_hT, float* dg_in, float* dg_hid,
-                              void* d_h0, void* ws, hipStream_t stream) {
+                              void* d_h0, void* ws, hipStream_t stream, const BwdStats& bs) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   using B = F10B<S>;
   xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
@@ -507,7 +577,7 @@ static int launch_gru_bwd_f10(const RnnShape& rs, const void* out, const void* h
   constexpr size_t lds = f10b_gru_lds_bytes<S>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   hipLaunchKernelGGL((k_gru_bwd_f10<S, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)out,
-                     (const TS*)h0, wfrag, reserve, (const TS*)d_out, (const TS*)d_hT, dg_in, dg_hid, (TS*)d_h0);
+                     (const TS*)h0, wfrag, reserve, (const TS*)d_out, (const TS*)d_hT, dg_in, dg_hid, (TS*)d_h0, bs);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -515,7 +585,7 @@ static int launch_gru_bwd_f10(const RnnShape& rs, const void* out, const void* h
 template <class S>
 static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
-                          void* d_h0, void* d_c0, void* ws, hipStream_t stream) {
+                          void* d_h0, void* d_c0, void* ws, hipStream_t stream, const BwdStats& bs) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   using B = F10B<S>;
   xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
@@ -536,7 +606,7 @@ static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packe
       dg ? reinterpret_cast<unsigned long long*>((char*)ws + f10b_wfrag_elems<S>() * sizeof(xbf8)) : nullptr;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, wfrag, reserve,
                      (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
-                     (float*)d_c0, diag);
+                     (float*)d_c0, diag, bs);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -572,7 +642,8 @@ bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
-size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // fragments + 4 KB for diagnostic stamps
+// fragments + 4 KB for diagnostic stamps (+ the per-sample sums of the by-products, input_size == 1)
+static size_t f10b_ws_head_bytes(const RnnShape& rs, int dtype) {
   if (rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
     return f10b_wfrag_elems<ShpH256R8G>() * sizeof(xbf8) + 4096;
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
@@ -580,26 +651,78 @@ size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // frag
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8) + 4096;
   return 0;
 }
+size_t bwd_stats_part_bytes(const RnnShape& rs) {
+  return rs.in == 1 ? ((size_t)rs.B * 2 * rs.G * rs.H * sizeof(float) + 255) & ~(size_t)255 : 0;
+}
+size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
+  const size_t head = f10b_ws_head_bytes(rs, dtype);
+  return head ? ((head + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs) : 0;
+}
+
+// per-sample sums -> stats rows 2, 3 (fixed order: four interleaved sample groups per column, then the four partial sums);
+// LSTM: d_gates_hid IS d_gates_in, row 1 = row 0
+__global__ void __launch_bounds__(256) k_bwd_stats_finish(int lstm, int Bn, int GH, const float* __restrict__ part,
+                                                          float* __restrict__ stats) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  if (part) {
+    float a = 0.f, d = 0.f;
+    if (c < GH)
+      for (int b = grp; b < Bn; b += 4) {
+        a += part[((size_t)b * 2) * GH + c];
+        d += part[((size_t)b * 2 + 1) * GH + c];
+      }
+    red[0][grp][cl] = a;
+    red[1][grp][cl] = d;
+    __syncthreads();
+    if (grp == 0 && c < GH) {
+      stats[2 * GH + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+      stats[3 * GH + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+  }
+  if (lstm && grp == 0 && c < GH) stats[GH + c] = stats[c];
+}
+
+int launch_bwd_stats_finish(int cell, int Bn, int GH, const float* part, float* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bwd_stats_finish, dim3((GH + 63) / 64), dim3(256), 0, stream, cell == TTRNN_LSTM ? 1 : 0, Bn, GH, part,
+                     stats);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
 
 int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
-                       hipStream_t stream) {
+                       hipStream_t stream, const void* x_in1, float* stats) {
+  // by-products (stats != NULL): the maxima land in stats rows 0 / 1 by atomicMax, the sums per sample behind the fragments
+  BwdStats bs;
+  const int GH = rs.G * rs.H;
+  if (stats) {
+    if (hipMemsetAsync(stats, 0, (size_t)2 * GH * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    bs.colmax = reinterpret_cast<unsigned*>(stats);
+    if (x_in1 && rs.in == 1) {
+      bs.x = x_in1;
+      bs.part = reinterpret_cast<float*>((char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255));
+    }
+  }
+  int st = TTRNN_ERR_UNSUPPORTED;
   if (rs.cell == TTRNN_GRU) {
     if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
     if (dtype == TTRNN_F32)
-      return launch_gru_bwd_f10<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0,
-                                                   ws, stream);
-    return launch_gru_bwd_f10<ShpH256R8G, bf16_t>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0,
-                                                  ws, stream);
+      st = launch_gru_bwd_f10<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws,
+                                                 stream, bs);
+    else
+      st = launch_gru_bwd_f10<ShpH256R8G, bf16_t>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws,
+                                                  stream, bs);
+  } else if (shape_matches<ShpH256R8L>(rs.hid_s)) {
+    st = launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream,
+                                    bs);
+  } else if (shape_matches<ShpH256R16L>(rs.hid_s)) {
+    st = launch_bwd_f10<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream,
+                                     bs);
   }
-  if (shape_matches<ShpH256R8L>(rs.hid_s))
-    return launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
-                                      stream);
-  if (shape_matches<ShpH256R16L>(rs.hid_s))
-    return launch_bwd_f10<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws,
-                                       stream);
-  return TTRNN_ERR_UNSUPPORTED;
+  if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, GH, bs.part, stats, stream);
+  return st;
 }
 
 }  // namespace ttrnn

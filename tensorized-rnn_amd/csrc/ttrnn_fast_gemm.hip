@@ -544,7 +544,8 @@ template <typename TS, bool HALF>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
-                                                               const unsigned* __restrict__ colmax) {
+                                                               const unsigned* __restrict__ colmax_x,
+                                                               const unsigned* __restrict__ colmax_dy) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
   constexpr int NP = HALF ? 2 : 3, BUFE = HALF ? DenseS::BUF_H : DenseS::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -610,11 +611,11 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) scx[e][i] = xin[e] ? col_scale(colmax[j0 + xc[e] + i]) : 0.f;
+      for (int i = 0; i < 4; ++i) scx[e][i] = xin[e] ? col_scale(colmax_x[j0 + xc[e] + i]) : 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) scd[e][i] = col_scale(colmax[IN + o0 + dc[e] + i]);
+      for (int i = 0; i < 4; ++i) scd[e][i] = col_scale(colmax_dy[o0 + dc[e] + i]);
   }
   auto stage_load = [&](int64_t nb) {
 #pragma unroll
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
   float uny[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (HALF) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) uny[ni] = col_unscale(colmax[IN + o0 + wn * 64 + 16 * ni + c]);
+    for (int ni = 0; ni < 4; ++ni) uny[ni] = col_unscale(colmax_dy[o0 + wn * 64 + 16 * ni + c]);
   }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -716,7 +717,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
       const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
       if (jj < IN) {
         float unx = 1.f;
-        if constexpr (HALF) unx = col_unscale(colmax[jj]);
+        if constexpr (HALF) unx = col_unscale(colmax_x[jj]);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const size_t e = (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
@@ -868,24 +869,39 @@ static bool dense_wgrad_use_half(int64_t n_rows, int in, int out) {
 }
 
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream, bool split, float* scratch_all) {
+                       float* d_bias, hipStream_t stream, bool split, float* scratch_all, const unsigned* x_colmax,
+                       const unsigned* dy_colmax) {
   const int cus = device_cu_count();
   split = split && out % DenseS::TO == 0 && !opt(OPT_DENSE_FP32);      // A/B switch: dense gradient on the fp32 MFMA
   // scratch: [column maxima of x and dy (HALF) | partial tiles of the row ranges]
   unsigned* colmax = (unsigned*)scratch_all;
   float* scratch = scratch_all ? (float*)((char*)scratch_all + dense_colmax_bytes(in, out)) : nullptr;
-  const bool half = split && colmax && n_rows > 0 && dense_wgrad_use_half(n_rows, in, out);
+  // the producer's bounds for dy's columns make the two-piece variant free of its 4-bytes-per-element pass over dy: taken
+  // at every size then (x's pass, where its bounds are missing, reads in / out of that)
+  const bool half = split && colmax && n_rows > 0 &&
+                    (dense_wgrad_use_half(n_rows, in, out) || (dy_colmax && opt(OPT_GEMM_PIECES) != 3));
+  const unsigned* cx = colmax;
+  const unsigned* cd = colmax ? colmax + in : nullptr;
   if (half) {
-    if (hipMemsetAsync(colmax, 0, (size_t)(in + out) * sizeof(unsigned), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
     const unsigned gy = (unsigned)((n_rows + 127) / 128);
-    if (dtype == TTRNN_F32)
-      hipLaunchKernelGGL(k_col_absmax<float>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const float*)x, n_rows, in,
-                         colmax);
-    else
-      hipLaunchKernelGGL(k_col_absmax<bf16_t>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)x, n_rows,
-                         in, colmax);
-    hipLaunchKernelGGL(k_col_absmax<float>, dim3((out / 4 + 255) / 256, gy), dim3(256), 0, stream, dy, n_rows, out,
-                       colmax + in);
+    if (x_colmax) {
+      cx = x_colmax;
+    } else {
+      if (hipMemsetAsync(colmax, 0, (size_t)in * sizeof(unsigned), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+      if (dtype == TTRNN_F32)
+        hipLaunchKernelGGL(k_col_absmax<float>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const float*)x, n_rows, in,
+                           colmax);
+      else
+        hipLaunchKernelGGL(k_col_absmax<bf16_t>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)x, n_rows,
+                           in, colmax);
+    }
+    if (dy_colmax) {
+      cd = dy_colmax;
+    } else {
+      if (hipMemsetAsync(colmax + in, 0, (size_t)out * sizeof(unsigned), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+      hipLaunchKernelGGL(k_col_absmax<float>, dim3((out / 4 + 255) / 256, gy), dim3(256), 0, stream, dy, n_rows, out,
+                         colmax + in);
+    }
   }
   const int KBc = split ? DenseS::KB : DenseG::KB;
   const int tiles = split ? ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO)
@@ -927,19 +943,19 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
       break;
     case 2:
       hipLaunchKernelGGL((k_dense_wgrad_split<float, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias, part, colmax);
+                         rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd);
       break;
     case 3:
       hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, colmax);
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, cx, cd);
       break;
     case 4:
       hipLaunchKernelGGL((k_dense_wgrad_split<float, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias, part, colmax);
+                         rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd);
       break;
     default:
       hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, colmax);
+                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, cx, cd);
   }
   if (part) {
     const size_t n4 = (size_t)in * out / 4;

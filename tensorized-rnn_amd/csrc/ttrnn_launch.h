@@ -184,8 +184,12 @@ int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, con
 
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
+// x_colmax / dy_colmax (optional, device): fp32 bit patterns of upper bounds of the columns' maxima (in / out entries) handed
+// over by the producer of the operand (ttrnn_ttlinear_backward_hinted): with dy's given the two-piece fp16 variant needs
+// no pass over dy and is taken at every size
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
-                       float* d_bias, hipStream_t stream, bool split, float* scratch);
+                       float* d_bias, hipStream_t stream, bool split, float* scratch, const unsigned* x_colmax = nullptr,
+                       const unsigned* dy_colmax = nullptr);
 size_t dense_wgrad_scratch_bytes(int in, int out);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
@@ -244,10 +248,21 @@ int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const vo
 // reverse-time TT-LSTM kernel on the fused core, split fp32 math (ttrnn_fast_f10b.hip); ws: fragments built per launch
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype);
+// By-products of a reverse-time kernel for the weight-gradient step (ttrnn_rnn_backward_ex): `stats` = fp32 [4][G*H] —
+// rows 0 / 1: column maxima of d_gates_in / d_gates_hid (bit patterns of non-negative floats: atomicMax), rows 2 / 3 (layers
+// with input_size == 1, x != NULL): sum_n x[n] d_gates_in[n][:] and sum_n d_gates_in[n][:], summed per sample in the kernel
+// (`part` [B][2][G*H] in the workspace) and over the samples in a fixed order by launch_bwd_stats_finish.
+struct BwdStats {
+  const void* x = nullptr;       // [B][T] (storage dtype) or NULL
+  float* part = nullptr;         // [B][2][G*H] or NULL
+  unsigned* colmax = nullptr;    // = stats rows 0, 1 (zeroed by the launcher) or NULL
+};
+int launch_bwd_stats_finish(int cell, int Bn, int GH, const float* part, float* stats, hipStream_t stream);
+size_t bwd_stats_part_bytes(const RnnShape& rs);
 int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
                        const float* packed_hid, const float* reserve, const void* d_out, const void* d_hT,
                        const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
-                       hipStream_t stream);
+                       hipStream_t stream, const void* x_in1 = nullptr, float* stats = nullptr);
 
 size_t f10b_fragment_bytes(const TtShape& s);     // the transposed fused-core fragments alone
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream);

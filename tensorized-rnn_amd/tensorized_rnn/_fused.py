@@ -81,7 +81,7 @@ class FusedCellMixin(object):
         res = F.tt_rnn_layer(self._layer_spec(), x.unsqueeze(1), hx, cx, cin, bin_, chid, bhid)
         return res[1:]          # (hy, cy) or (hy,)
 
-    def _run_sequence(self, seq, h0, c0=None, need_out=True):
+    def _run_sequence(self, seq, h0, c0=None, need_out=True, x_bounded=False):
         from ttrnn_hip import functional as F
         cin, bin_, chid, bhid = self._operands()
         stats = None
@@ -94,7 +94,7 @@ class FusedCellMixin(object):
         else:
             prep = None
         return F.tt_rnn_layer(self._layer_spec(), seq, h0, c0, cin, bin_, chid, bhid, stats=stats, prepared=prep,
-                              need_out=need_out)
+                              need_out=need_out, x_bounded=x_bounded)
 
     def _prepare(self):
         """(Re)build the weight-only state of this cell for no-grad forwards (ttrnn_hip.functional.PreparedLayer)."""
@@ -233,7 +233,10 @@ class FusedRnnBase(nn.Module):
         n = len(self._all_layers)
         for i, cell in enumerate(self._all_layers):
             # only the LAST layer's outputs can go unused (layer l + 1 reads all of layer l's)
-            last = cell._run_sequence(seq, h0, c0, need_out=need_outputs or i + 1 < n)
+            # a stacked layer's input is the hidden-state sequence below: |x| <= 1 (LSTM: o * tanh(c); GRU: convex combinations
+            # of tanh values and h_{t-1}, from |h_0| <= 1 on) — the weight-gradient step then skips its column-maximum pass
+            bounded = i > 0 and (self.kind == 'lstm' or h0 is None)
+            last = cell._run_sequence(seq, h0, c0, need_out=need_outputs or i + 1 < n, x_bounded=bounded)
             seq = last[0]
         return last
 

@@ -13,7 +13,8 @@ TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
 PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
+BWD_STATS_COLMAX, BWD_STATS_IN1SUMS, BWD_STATS_ROWS = 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TTRNN_LIB_PATH: developer override (A/B-ing two builds of the library in one session); default = the in-tree build
@@ -35,6 +36,11 @@ class RnnDesc(ctypes.Structure):
                 ("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
                 ("has_bias_in", ctypes.c_int32), ("has_bias_hid", ctypes.c_int32),
                 ("in_w", TtmDesc), ("hid_w", TtmDesc), ("hid_blocks", ctypes.c_int32)]
+
+
+class LinHints(ctypes.Structure):
+    """struct ttrnn_lin_hints"""
+    _fields_ = [("x_colmax", ctypes.c_void_p), ("dy_colmax", ctypes.c_void_p), ("xdy_sum", ctypes.c_void_p)]
 
 
 _P = ctypes.c_void_p
@@ -60,6 +66,8 @@ _SIGNATURES = {
                                               _P, ctypes.c_size_t, _P]),
     "ttrnn_ttlinear_backward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P,
                                                _P, _P, _P, ctypes.c_size_t, _P]),
+    "ttrnn_ttlinear_backward_hinted": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P,
+                                                      _P, _P, _P, _P, ctypes.POINTER(LinHints), _P, ctypes.c_size_t, _P]),
     "ttrnn_head_workspace": (ctypes.c_size_t, [ctypes.POINTER(TtmDesc), ctypes.c_int64]),
     "ttrnn_head_forward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P, _P,
                                           _P, ctypes.c_size_t, _P]),
@@ -75,6 +83,8 @@ _SIGNATURES = {
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_backward_stats": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_backward_ex": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 16 + [ctypes.c_size_t, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -174,8 +174,27 @@ class TTSpec(object):
         return grads
 
 
-def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroed=None):
-    """zeroed: optional (dpk, db) fp32 buffers the caller has already zero-filled (one fill for several calls)."""
+# Use the by-products of the reverse-time kernel (include/ttrnn.h: ttrnn_rnn_backward_ex) in the weight-gradient step.  A/B
+# switch for tests and measurements; the library decides per descriptor what it can deliver.
+USE_BWD_STATS = True
+# tests: a list here receives (mask, stats, d_gates_in, d_gates_hid) of every layer backward
+DEBUG_BWD_STATS = None
+
+_ONES = {}
+
+
+def _ones(dev, n):
+    """fp32 ones[n] on `dev` (column bounds of rows that are hidden states: |h| <= 1), cached."""
+    key = (dev, n)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(n, dtype=torch.float32, device=dev)
+    return t
+
+
+def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroed=None, hints=None):
+    """zeroed: optional (dpk, db) fp32 buffers the caller has already zero-filled (one fill for several calls).
+    hints: optional dict of fp32 device tensors x_colmax[in] / dy_colmax[out] / xdy_sum[out] (struct ttrnn_lin_hints)."""
     lib = _lib.load()
     n = dy2d.shape[0]
     dev = dy2d.device
@@ -188,9 +207,17 @@ def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroe
         db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
     wsb = lib.ttrnn_ttlinear_workspace(ctypes.byref(spec.desc), n)
     ws = _workspace(wsb, dev)
-    check(lib.ttrnn_ttlinear_backward(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
-                                      _ptr(x2d), _ptr(dy2d), _ptr(dx), _ptr(dpk), _ptr(db), _ptr(ws), wsb,
-                                      _stream(dy2d)), "ttrnn_ttlinear_backward")
+    hp = None
+    if hints:
+        for k, width in (("x_colmax", spec.in_features), ("dy_colmax", spec.out_features), ("xdy_sum", spec.out_features)):
+            t = hints.get(k)
+            if t is not None and (t.dtype != torch.float32 or t.numel() != width or not t.is_contiguous() or t.device != dev):
+                raise ValueError("hint {} must be a contiguous fp32 tensor of {} elements on {}".format(k, width, dev))
+        hs = _lib.LinHints(_ptr(hints.get("x_colmax")), _ptr(hints.get("dy_colmax")), _ptr(hints.get("xdy_sum")))
+        hp = ctypes.byref(hs)
+    check(lib.ttrnn_ttlinear_backward_hinted(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
+                                             _ptr(x2d), _ptr(dy2d), _ptr(dx), _ptr(dpk), _ptr(db), hp, _ptr(ws), wsb,
+                                             _stream(dy2d)), "ttrnn_ttlinear_backward")
     return dx, dpk, db
 
 
@@ -374,6 +401,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
             stats.forward(out, reserve[4 * B * T * H:].view(B, T, H) if spec.cell == "lstm" else None)
         ctx.stats = stats
         ctx.spec = spec
+        ctx.x_bounded = bool(getattr(spec, "x_bounded", False))
         ctx.n_in = n_in
         ctx.flags = (h0 is not None, c0 is not None, bias_in is not None, bias_hid is not None)
         saved = [x, out, reserve, packed_in, packed_hid]
@@ -413,13 +441,21 @@ class _TTRnnLayerFn(torch.autograd.Function):
         wsb = lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
         d_state = _alloc((B, T, H, 2), torch.float32, dev) if ctx.stats is not None else None
+        # by-products of the reverse-time kernel for the weight-gradient step below (column maxima of the gate gradients;
+        # input_size == 1: the sums over the rows that ARE that layer's input-weight and bias gradients)
+        mask = lib.ttrnn_rnn_backward_stats(ctypes.byref(desc)) if (USE_BWD_STATS and d_state is None) else 0
+        bstats = _alloc((_lib.BWD_STATS_ROWS, G * H), torch.float32, dev) if mask else None
+        in1 = bool(mask & _lib.BWD_STATS_IN1SUMS)
         with _timed("ttrnn_rnn_backward"):
-            check(lib.ttrnn_rnn_backward(ctypes.byref(desc), _ptr(out), _ptr(h0), _ptr(c0), _ptr(packed_hid),
-                                         _ptr(reserve), _ptr(d_out), _ptr(d_hT), _ptr(d_cT), _ptr(dg_in),
-                                         _ptr(dg_hid), _ptr(d_h0), _ptr(d_c0), _ptr(d_state), _ptr(ws), wsb, _stream(x)),
-                  "ttrnn_rnn_backward")
+            check(lib.ttrnn_rnn_backward_ex(ctypes.byref(desc), _ptr(out), _ptr(h0), _ptr(c0), _ptr(packed_hid),
+                                            _ptr(reserve), _ptr(d_out), _ptr(d_hT), _ptr(d_cT), _ptr(dg_in),
+                                            _ptr(dg_hid), _ptr(d_h0), _ptr(d_c0), _ptr(d_state),
+                                            _ptr(x) if in1 else ctypes.c_void_p(0), _ptr(bstats), _ptr(ws), wsb,
+                                            _stream(x)), "ttrnn_rnn_backward")
         if d_state is not None:
             ctx.stats.backward(d_state[..., 0], d_state[..., 1] if spec.cell == "lstm" else None)
+        if DEBUG_BWD_STATS is not None:
+            DEBUG_BWD_STATS.append((mask, bstats, dg_in, dg_hid))
         # weight / input gradients: two TTLinear backward passes over the B*T rows
         n_in = ctx.n_in
         need_dw_in = any(need[8:8 + n_in])
@@ -429,14 +465,27 @@ class _TTRnnLayerFn(torch.autograd.Function):
         padded = [(n + 63) // 64 * 64 for n in sizes]                       # every buffer starts on a 256-byte boundary
         flat = torch.zeros(sum(padded), dtype=torch.float32, device=dev)
         z_in_w, z_in_b, z_hid_w, z_hid_b = (t[:n] for t, n in zip(torch.split(flat, padded), sizes))
+        hints_in = hints_hid = None
+        want_db_in = has_bin and need[3]
+        if mask & _lib.BWD_STATS_COLMAX:
+            # rows that are hidden states are bounded by 1 (LSTM: o * tanh(c); GRU: convex combinations, from |h_0| <= 1 on)
+            state_bound = _ones(dev, H) if (spec.cell == "lstm" or h0 is None) else None
+            hints_in = {"dy_colmax": bstats[0], "x_colmax": _ones(dev, spec.input_size) if ctx.x_bounded else None}
+            hints_hid = {"dy_colmax": bstats[1], "x_colmax": state_bound}
+            if in1 and not need[0]:
+                hints_in["xdy_sum"] = bstats[2]
+        use_sums = bool(hints_in and hints_in.get("xdy_sum") is not None)
         dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
-                                               dg_in.reshape(B * T, -1), need[0], need_dw_in, has_bin and need[3],
-                                               zeroed=(z_in_w, z_in_b))
+                                               dg_in.reshape(B * T, -1), need[0], need_dw_in,
+                                               want_db_in and not use_sums, zeroed=(z_in_w, z_in_b), hints=hints_in)
+        if use_sums and want_db_in:
+            db_in = bstats[3]
         # h_{t-1} rows: [h0, out[:, :-1]]
         first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
         hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
         _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
-                                                False, need_dw_hid, has_bhid and need[4], zeroed=(z_hid_w, z_hid_b))
+                                                False, need_dw_hid, has_bhid and need[4], zeroed=(z_hid_w, z_hid_b),
+                                                hints=hints_hid)
         dcin = spec.in_spec.unpack_grads(dpk_in, cores_in) if need_dw_in else [None] * n_in
         dchid = spec.hid_spec.unpack_grads(dpk_hid, cores_hid) if need_dw_hid else [None] * len(cores_hid)
         if dx is not None:
@@ -579,13 +628,16 @@ def _rnn_forward_nograd(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid,
     return (out, hT, cT) if spec.cell == "lstm" else (out, hT)
 
 
-def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None, prepared=None, need_out=True):
+def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=None, prepared=None, need_out=True,
+                 x_bounded=False):
     """One recurrent layer over the whole sequence on the device.
     Returns (out[B,T,H], hT[B,H], cT[B,H]) for LSTM and (out, hT) for GRU.
     stats: optional StepStats — ActivGradLogger's per-step statistics without leaving the fused path.
     prepared: optional PreparedLayer — used when autograd is not recording (inference on unchanged weights).
     need_out=False (no-grad calls only): the caller consumes only the final state; `out` is returned as None where the
-    route can skip it (include/ttrnn.h: ttrnn_rnn_out_optional), computed as usual elsewhere."""
+    route can skip it (include/ttrnn.h: ttrnn_rnn_out_optional), computed as usual elsewhere.
+    x_bounded=True: the caller guarantees |x| <= 1 everywhere (x is the output of a recurrent layer below): the input matrix's
+    weight gradient then needs no pass over x for its column scales (ttrnn_ttlinear_backward_hinted)."""
     cores_in, cores_hid = list(cores_in), list(cores_hid)
     _require_device(x, h0, c0, bias_in, bias_hid, *(cores_in + cores_hid))
     if x.dim() != 3 or x.shape[2] != spec.input_size:
@@ -598,6 +650,7 @@ def tt_rnn_layer(spec, x, h0, c0, cores_in, bias_in, cores_hid, bias_hid, stats=
     h0 = h0.contiguous().to(x.dtype) if h0 is not None else None
     c0 = c0.contiguous().to(x.dtype) if (c0 is not None and spec.cell == "lstm") else None
     spec.recording = torch.is_grad_enabled()
+    spec.x_bounded = bool(x_bounded)
     if prepared is not None and not spec.recording and stats is None and POISON_ALLOCATIONS is False:
         with torch.cuda.device(x.device):
             return _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prepared, need_out)

@@ -1849,3 +1849,88 @@ def test_dense_gemm_error_vs_fp64_is_fp32_class():
     print("max abs error vs float64 oracle:", errs)
     assert errs["split"] <= 2e-6 and errs["exact"] <= 2e-6
     assert errs["split"] <= 2.0 * max(errs["exact"], errs["cpu_fp32"]) + 1e-7
+
+
+# ---- (12) by-products of the reverse-time kernels feeding the weight-gradient step --------------------------------------------
+@pytest.mark.parametrize("kind,inp,L,r,B,T,dtype,with_h0", [
+    ("ttlstm", 1, 1, 8, 9, 33, "f32", False),          # cfg2 class: in1 sums + column maxima
+    ("ttlstm", 1, 1, 8, 70, 20, "f32", True),          # dense hidden gradient (B*T >= 4*H)
+    ("ttgru", 1, 1, 8, 9, 33, "f32", False),
+    ("ttgru", 1, 1, 8, 70, 20, "bf16", False),         # cfg3 class
+    ("ttgru", 1, 1, 8, 70, 20, "f32", True),           # GRU with h0: no bound on the state rows, x's pass stays
+    ("ttlstm", 40, 2, 16, 48, 27, "f32", False),       # cfg4 class: maxima only, stacked layer's input bounded by 1
+])
+def test_reverse_kernel_by_products_feed_the_weight_gradients(kind, inp, L, r, B, T, dtype, with_h0):
+    """ttrnn_rnn_backward_ex (include/ttrnn.h): the fused-core reverse-time kernels return the column maxima of the gate
+    gradients and, for input_size == 1, sum_n x[n] dg[n] and sum_n dg[n].  (a) The rows are what torch computes from the
+    returned gate gradients — the maxima bit for bit; (b) every parameter gradient with the by-products in use
+    (ttrnn_ttlinear_backward_hinted: no in1 reduction pass, two-piece fp16 dense gradient under the producer's column
+    bounds) is as close to the float64 oracle as without them; (c) the two paths did differ (the switch works)."""
+    import ttrnn_hip.functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(5 + B + T)
+    H = 256
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=3, tt_rank=r)
+    m = build_module(meta, dev())
+    x = torch.randn(B, T, inp) * 0.7
+    w = torch.randn(B, T, H)
+    h0 = torch.randn(B, H) * 0.5 if with_h0 else None
+    if dtype == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+        h0 = h0.to(torch.bfloat16) if h0 is not None else None
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, L, requires_grad=True, dtype=torch.float64)
+    if kind == "ttlstm":
+        init = (h0.double(), torch.zeros(B, H, dtype=torch.float64)) if with_h0 else None
+        ro, _ = O.lstm_forward(layers, x.double(), init)
+    else:
+        ro, _ = O.gru_forward(layers, x.double(), h0.double() if with_h0 else None)
+    (ro * w.double()).sum().backward()
+    grads = {}
+    captured = []
+    for use in (True, False):
+        F.USE_BWD_STATS = use
+        F.DEBUG_BWD_STATS = captured if use else None
+        try:
+            m.zero_grad()
+            if kind == "ttlstm":
+                init = (h0.to(dev()), torch.zeros(B, H, device=dev(), dtype=x.dtype)) if with_h0 else None
+                out = m(x.to(dev()), init)[0]
+            else:
+                out = m(x.to(dev()), h0.to(dev()) if with_h0 else None)[0]
+            (out.float() * w.to(dev())).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            F.USE_BWD_STATS = True
+            F.DEBUG_BWD_STATS = None
+        grads[use] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}
+    # (a) the rows against torch reductions of the returned gate gradients (layers run last to first)
+    assert len(captured) == L
+    for li, (mask, stats, dg_in, dg_hid) in zip(reversed(range(L)), captured):
+        assert mask & 1, "the fused-core reverse kernel should deliver the column maxima for this shape"
+        GH = dg_in.shape[-1]
+        assert torch.equal(stats[0], dg_in.reshape(-1, GH).abs().amax(0))
+        assert torch.equal(stats[1], dg_hid.reshape(-1, GH).abs().amax(0))
+        if inp == 1 and li == 0:
+            assert mask & 2
+            xs = x.to(dev()).double().reshape(-1, 1)
+            ref2 = (xs * dg_in.reshape(-1, GH).double()).sum(0)
+            ref3 = dg_in.reshape(-1, GH).double().sum(0)
+            mag = float((xs.abs() * dg_in.reshape(-1, GH).double().abs()).sum(0).max())
+            assert _maxabs(stats[2].double(), ref2) <= 2e-6 * mag
+            assert _maxabs(stats[3].double(), ref3) <= 2e-6 * float(dg_in.reshape(-1, GH).double().abs().sum(0).max())
+    # (b), (c)
+    worst = {True: 0.0, False: 0.0}
+    differ = False
+    for n, _ in m.named_parameters():
+        ref = leaves[n].grad
+        sc = max(float(ref.abs().max()), 1e-30)
+        for k in worst:
+            assert torch.isfinite(grads[k][n]).all(), (k, n)
+            worst[k] = max(worst[k], _maxabs(grads[k][n].double(), ref) / sc)
+        differ = differ or not torch.equal(grads[True][n], grads[False][n])
+    print(kind, inp, dtype, "max gradient error relative to each tensor's maximum: with by-products %.3g, without %.3g"
+          % (worst[True], worst[False]))
+    assert differ
+    assert worst[True] <= (5e-2 if dtype == "bf16" else 2e-4) and worst[True] <= 3.0 * worst[False] + 1e-6
