@@ -384,7 +384,8 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
   if (!force_generic() && (d_packed || (dx && !d_bias)) && big_ttlinear_bwd_available(s, dtype, dy_dtype)) {
     // big shape: dx, weight and bias gradients through the merged two-core matrix
     if (!workspace || workspace_bytes < big_ttlinear_bwd_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
-    return launch_ttlinear_bwd_big(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream);
+    return launch_ttlinear_bwd_big(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream, hx,
+                                   hdy);
   }
   if (!force_generic() && !no_gemm() && s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= gen_in1_bytes(s) &&
       !opt(OPT_NO_IN1)) {
@@ -696,12 +697,13 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
 }
 
 // which by-products (TTRNN_BWD_STATS_*) does the reverse-time route of this descriptor deliver?  The fused-core kernels:
-// the column maxima, and the input_size == 1 sums
+// the column maxima, and the input_size == 1 sums; the merged-big kernels: the column maxima
 static int bwd_stats_mask(const RnnShape& rs, int dtype) {
   if (force_generic() || opt(OPT_FORCE_G2) || rs.T < 1 || rs.B < 1) return 0;
   if (fast_rnn_bwd_available(rs, dtype) && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) &&
       f10_rnn_bwd_available(rs, dtype))
     return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0);
+  if (!fast_rnn_bwd_available(rs, dtype) && big_rnn_bwd_available(rs, dtype)) return TTRNN_BWD_STATS_COLMAX;
   return 0;
 }
 
@@ -728,7 +730,7 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   int st = rnn_shape_init(&rs, desc);
   if (st != TTRNN_OK) return st;
   if (rs.B == 0) return TTRNN_OK;
-  // by-products come from the fused-core reverse kernels only: a request elsewhere (or together with d_state, which
+  // by-products come from the fused-core and the merged-big reverse kernels only: a request elsewhere (or together with d_state, which
   // selects another route) is an error, not a silent omission — ask ttrnn_rnn_backward_stats first
   if (stats && (d_state || bwd_stats_mask(rs, desc->dtype) == 0)) return TTRNN_ERR_UNSUPPORTED;
   if (!packed_hid) return TTRNN_ERR_NULL;
@@ -751,7 +753,7 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   if (!g2_first && !want_state && !force_generic() && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < big_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_big(rs, desc->dtype, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
-                              d_h0, d_c0, workspace, (hipStream_t)stream);
+                              d_h0, d_c0, workspace, (hipStream_t)stream, stats);
   }
   if (!force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;

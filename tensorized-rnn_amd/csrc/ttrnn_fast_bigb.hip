@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
                                                           TS* __restrict__ d_h0, TS* __restrict__ d_c0,
                                                           unsigned long long* __restrict__ hx,
                                                           const float* __restrict__ guard, int guard_rows,
-                                                          unsigned* __restrict__ status) {
+                                                          unsigned* __restrict__ status,
+                                                          unsigned* __restrict__ colmax) {
   using T1 = St<ST, 1>;
   using T0 = St<ST, 0>;
   constexpr int H = out_size_of<ST>(), GH = in_size_of<ST>();
@@ -265,6 +266,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
     dnxt[u] = d_out ? ld(d_out, bt1 * H + hid[u]) : 0.f;
   }
   bool dead = false;
+  f32x4 cmx[NUT];                             // column maxima of the units' gate gradients (BwdStats, ttrnn_launch.h)
+#pragma unroll
+  for (int u = 0; u < NUT; ++u) cmx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   // resident for the whole launch: T0's fragments (A^T, 64 registers) and the first chunk of T1's
   f32x4 wf1[4][4], r0[8];
   bigT_load1<ST>(wf1, fragT, wave, lane);
@@ -288,6 +292,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
       const float p2 = dct * ig * (1.0f - gg * gg);             //                     g
       const float p3 = dht * tc * og * (1.0f - og);             //                     o
       dcs[u] = dct * fg;
+      cmx[u][0] = fmaxf(cmx[u][0], fabsf(p0)); cmx[u][1] = fmaxf(cmx[u][1], fabsf(p1));
+      cmx[u][2] = fmaxf(cmx[u][2], fabsf(p2)); cmx[u][3] = fmaxf(cmx[u][3], fabsf(p3));
       const int row = 32 * u + rl;
       dyimg[a_off<T1::K>(row, 0 * 16 + mq)] = p0;
       dyimg[a_off<T1::K>(row, 1 * 16 + mq)] = p1;
@@ -345,6 +351,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big(int B, int T, const TS
   for (int u = 0; u < NUT; ++u) {
     if (d_h0) st(d_h0, b * H + hid[u], dhrec[u]);
     if (d_c0) st(d_c0, b * H + hid[u], dcs[u]);
+    if (colmax) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) atomicMax(colmax + g * H + hid[u], __float_as_uint(cmx[u][g]));
+    }
   }
 }
 
@@ -733,7 +743,7 @@ size_t big_rnn_bwd_workspace(const RnnShape& rs) {
 template <typename TS>
 static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
                          const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
-                         void* ws, hipStream_t stream) {
+                         void* ws, hipStream_t stream, unsigned* colmax) {
   float* m3 = (float*)ws;
   float* mT = (float*)((char*)ws + B3);
   unsigned long long* hxb = (unsigned long long*)((char*)ws + B3 + BT);
@@ -758,7 +768,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     if (halfk) {
       void* scr = (char*)hxb + al256((size_t)rs.B * 2 * rs.H * sizeof(unsigned long long));
       const int sh = launch_lstm_bwd_big2h(rs, sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, c0, mT, reserve, d_out, d_hT, d_cT,
-                                           dg_in, d_h0, d_c0, hxb, scr, stream);
+                                           dg_in, d_h0, d_c0, hxb, scr, stream, colmax);
       if (sh != TTRNN_OK) return sh;
       // ... followed by the fp32-MFMA pair kernel as its fallback: exactly one of the two runs (big_guard_tripped, decided on
       // the device from the representation error of the fp16 pieces; the other returns at once, a few microseconds)
@@ -772,7 +782,7 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 2, TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T,
                        (const TS*)c0, mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in,
-                       (TS*)d_h0, (TS*)d_c0, hxb, guard, guard_rows, device_status_ptr());
+                       (TS*)d_h0, (TS*)d_c0, hxb, guard, guard_rows, device_status_ptr(), colmax);
   } else {
     constexpr size_t lds = bigb_lds_bytes<ST, 1>();
     {
@@ -781,18 +791,23 @@ static int launch_bigb_t(const RnnShape& rs, const void* c0, const float* packed
     }
     hipLaunchKernelGGL((k_lstm_bwd_big<ST, 1, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0,
                        mT, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0,
-                       hxb, (const float*)nullptr, 0, device_status_ptr());
+                       hxb, (const float*)nullptr, 0, device_status_ptr(), colmax);
   }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
 int launch_rnn_bwd_big(const RnnShape& rs, int dtype, const void* c0, const float* packed_hid, const float* reserve,
                        const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
-                       void* d_c0, void* ws, hipStream_t stream) {
-  const int st = dtype == TTRNN_F32 ? launch_bigb_t<float>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0,
-                                                           d_c0, ws, stream)
-                                    : launch_bigb_t<bf16_t>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0,
-                                                            d_c0, ws, stream);
+                       void* d_c0, void* ws, hipStream_t stream, float* stats) {
+  // by-products (ttrnn_rnn_backward_ex): the column maxima of the gate gradients, stats rows 0 and 1 (LSTM: the same)
+  unsigned* colmax = reinterpret_cast<unsigned*>(stats);
+  const int GH = 4 * rs.H;
+  if (stats && hipMemsetAsync(stats, 0, (size_t)2 * GH * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  int st = dtype == TTRNN_F32 ? launch_bigb_t<float>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws,
+                                                     stream, colmax)
+                              : launch_bigb_t<bf16_t>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws,
+                                                      stream, colmax);
+  if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(TTRNN_LSTM, rs.B, GH, nullptr, stats, stream);
   if (st != TTRNN_OK) return st;
   if (dg_hid && dg_hid != dg_in &&
       hipMemcpyAsync(dg_hid, dg_in, (size_t)rs.B * rs.T * 4 * rs.H * sizeof(float), hipMemcpyDeviceToDevice, stream) !=
@@ -812,7 +827,7 @@ size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
 
 template <typename TS>
 static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, const void* dy, void* dx, float* d_packed,
-                         float* d_bias, void* ws, hipStream_t stream) {
+                         float* d_bias, void* ws, hipStream_t stream, const unsigned* x_colmax, const unsigned* dy_colmax) {
   const bool split_math = ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT;
   float* m3 = (float*)ws;
   float* m2 = (float*)((char*)ws + B3);
@@ -840,7 +855,7 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     float* dWf = (float*)((char*)dB + BDB);
     hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
     const int sd = launch_dense_wgrad(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, 1024, 4096, x, (const float*)dy, dWf,
-                                      d_bias, stream, split_math, (float*)((char*)dWf + BDW));
+                                      d_bias, stream, split_math, (float*)((char*)dWf + BDW), x_colmax, dy_colmax);
     if (sd != TTRNN_OK) return sd;
     hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
     hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);
@@ -870,10 +885,12 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
 
 // dx and / or (d_packed [+ d_bias]); a bias gradient alone is not offered
 int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
-                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream,
+                            const unsigned* x_colmax, const unsigned* dy_colmax) {
   (void)s;
-  return dtype == TTRNN_F32 ? launch_bigw_t<float>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream)
-                            : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream);
+  return dtype == TTRNN_F32
+             ? launch_bigw_t<float>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax, dy_colmax)
+             : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax, dy_colmax);
 }
 
 }  // namespace ttrnn

@@ -145,11 +145,15 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
                                                             const TS* __restrict__ d_cT, float* __restrict__ dg_in,
                                                             TS* __restrict__ d_h0, TS* __restrict__ d_c0,
                                                             unsigned long long* __restrict__ hx,
-                                                            unsigned* __restrict__ status) {
+                                                            unsigned* __restrict__ status,
+                                                            unsigned* __restrict__ colmax) {
   constexpr int H = BB_H, GH = 4 * BB_H, I23 = BB_I23, RL = BB_RL;
   __shared__ __attribute__((aligned(16))) float dyimg[RL * T1::K];      // gate gradients [i23 local][i01], fp32
   __shared__ __attribute__((aligned(16))) float dhp[2 * T0::M * 16];    // partial dh [k half][j23][j01]
   __shared__ float smax[2][FAST_NW];                                    // per-wave maxima of |dg|, by step parity
+  // running column maxima of this thread's four gate gradients (by-product for the weight-gradient step: BwdStats,
+  // ttrnn_launch.h) — in LDS: the kernel has no four registers to spare (256 VGPRs, 8 spilled)
+  __shared__ __attribute__((aligned(16))) float cmx_s[FAST_NT * 4];
   extern __shared__ __attribute__((aligned(16))) float big_lds[];
   _Float16* img = reinterpret_cast<_Float16*>(big_lds);                 // T1's image: two planes [16][1024]
   xh8* wl = reinterpret_cast<xh8*>(big_lds) + 2 * BB_PL / 8;            // the non-resident quarter of Bm's fragments
@@ -188,6 +192,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
     dnxt = d_out ? ld(d_out, bt1 * H + hid) : 0.f;
   }
   bool dead = false;
+  *reinterpret_cast<f32x4*>(cmx_s + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // resident fragments: A^T (four m-tiles), Bm k-blocks 0..BB_RES-1 of this wave's slice; the rest of the slice -> LDS
   xh8 wa[4][2][2], wb[BB_RES][2];
@@ -231,6 +236,11 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
       dyimg[a_off<T1::K>(rl, 2 * 16 + mq)] = p2;
       dyimg[a_off<T1::K>(rl, 3 * 16 + mq)] = p3;
       float mx = fmaxf(fmaxf(fabsf(p0), fabsf(p1)), fmaxf(fabsf(p2), fabsf(p3)));
+      if (colmax) {
+        f32x4 cm = *reinterpret_cast<const f32x4*>(cmx_s + 4 * tid);
+        cm = f32x4{fmaxf(cm[0], fabsf(p0)), fmaxf(cm[1], fabsf(p1)), fmaxf(cm[2], fabsf(p2)), fmaxf(cm[3], fabsf(p3))};
+        *reinterpret_cast<f32x4*>(cmx_s + 4 * tid) = cm;
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
       if (lane == 0) smax[par][wave] = mx;
@@ -354,6 +364,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
   }
   if (d_h0) st(d_h0, b * H + hid, dhrec);
   if (d_c0) st(d_c0, b * H + hid, dcs);
+  if (colmax) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicMax(colmax + g * H + hid, __float_as_uint(cmx_s[4 * tid + g]));
+  }
 }
 
 }  // namespace
@@ -373,7 +387,7 @@ const float* bigbh_guard_rows(const void* scratch, int* n_rows) {
 template <typename TS>
 static int launch_bigbh_t(const RnnShape& rs, const void* c0, const float* fragT, const float* reserve, const void* d_out,
                           const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
-                          unsigned long long* hxb, void* scratch, hipStream_t stream) {
+                          unsigned long long* hxb, void* scratch, hipStream_t stream, unsigned* colmax) {
   float* parts = (float*)scratch;
   xh8* fa = (xh8*)((char*)scratch + BB_HDR_BYTES);
   xh8* fb = fa + BB_FA;
@@ -385,17 +399,17 @@ static int launch_bigbh_t(const RnnShape& rs, const void* c0, const float* fragT
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_big2h<TS>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL((k_lstm_bwd_big2h<TS>), dim3(2 * rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)c0, fa, fb,
                      parts, reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, dg_in, (TS*)d_h0, (TS*)d_c0, hxb,
-                     device_status_ptr());
+                     device_status_ptr(), colmax);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
 int launch_lstm_bwd_big2h(const RnnShape& rs, int dtype, const void* c0, const float* fragT, const float* reserve,
                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
-                          unsigned long long* hxb, void* scratch, hipStream_t stream) {
+                          unsigned long long* hxb, void* scratch, hipStream_t stream, unsigned* colmax) {
   return dtype == TTRNN_F32 ? launch_bigbh_t<float>(rs, c0, fragT, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, hxb,
-                                                    scratch, stream)
+                                                    scratch, stream, colmax)
                             : launch_bigbh_t<bf16_t>(rs, c0, fragT, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, hxb,
-                                                     scratch, stream);
+                                                     scratch, stream, colmax);
 }
 
 }  // namespace ttrnn

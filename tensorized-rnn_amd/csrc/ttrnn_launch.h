@@ -212,7 +212,7 @@ bool bigbh_pair_resident(int dtype, int B);
 const float* bigbh_guard_rows(const void* scratch, int* n_rows);      // the row sums big_guard_tripped reads (ttrnn_big.h)
 int launch_lstm_bwd_big2h(const RnnShape& rs, int dtype, const void* c0, const float* fragT, const float* reserve,
                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0,
-                          unsigned long long* hxb, void* scratch, hipStream_t stream);
+                          unsigned long long* hxb, void* scratch, hipStream_t stream, unsigned* colmax = nullptr);
 
 // BPTT of the big shape through the merged two-core matrix (ttrnn_fast_bigb.hip): reverse-time kernel (one or two
 // workgroups per sample) and the batched TTLinear backward (dx through the transposed merged chain; weight + bias
@@ -221,11 +221,12 @@ bool big_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t big_rnn_bwd_workspace(const RnnShape& rs);
 int launch_rnn_bwd_big(const RnnShape& rs, int dtype, const void* c0, const float* packed_hid, const float* reserve,
                        const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
-                       void* d_c0, void* ws, hipStream_t stream);
+                       void* d_c0, void* ws, hipStream_t stream, float* stats = nullptr);
 bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
 size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s);
 int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
-                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream);
+                            const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream,
+                            const unsigned* x_colmax = nullptr, const unsigned* dy_colmax = nullptr);
 
 // runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): any TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores
 bool g2_rnn_available(const RnnShape& rs, int dtype);         // forward kernel
