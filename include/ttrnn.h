@@ -179,12 +179,23 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
  *             With dy's bounds the dense weight gradient runs on two fp16 pieces under per-column scales
  *             at every size; a bound BELOW the true maximum overflows the fp16 pieces (inf / NaN in d_packed).
  *   xdy_sum   fp32[out] in_size == 1, dx == NULL, d_bias == NULL: sum_n x[n] dy[n][:] (stats row 2) — the weight gradient then
- *             needs no pass over dy at all (the bias gradient is stats row 3). */
+ *             needs no pass over dy at all (the bias gradient is stats row 3).
+ *   x_period  > 0: `x` is the output out[n_rows / x_period][x_period][in] of a recurrent layer and the operand's row n is the
+ *             PREVIOUS step's state: row n - 1 of out, or row n / x_period of x_first (storage dtype; NULL = zeros) where
+ *             n % x_period == 0 — the h_{t-1} rows of the hidden matrix's weight gradient (lstm.py:123-133) read in place
+ *             instead of being materialised by the caller.  Only the dense-gradient routes read rows this way: ask
+ *             ttrnn_ttlinear_backward_shift_ok first; TTRNN_ERR_UNSUPPORTED elsewhere.  (x_colmax then bounds these rows.) */
 typedef struct ttrnn_lin_hints {
   const float* x_colmax;
   const float* dy_colmax;
   const float* xdy_sum;
+  int64_t x_period;
+  const void* x_first;
 } ttrnn_lin_hints;
+/* 1 if a ttrnn_ttlinear_backward_hinted call with these arguments (d_packed wanted, dx as said, a workspace of
+ * ttrnn_ttlinear_workspace bytes) takes a route that honours hints->x_period under the current options. */
+int ttrnn_ttlinear_backward_shift_ok(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, int64_t x_period,
+                                     int want_dx);
 int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
                                    const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
                                    const ttrnn_lin_hints* hints, void* workspace, size_t workspace_bytes, void* stream);

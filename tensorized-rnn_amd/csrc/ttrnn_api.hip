@@ -310,9 +310,23 @@ int ttrnn_ttlinear_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t
                                         workspace_bytes, stream);
 }
 
-int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
-                                   const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
-                                   const ttrnn_lin_hints* hints, void* workspace, size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+// probe: launch nothing, return 1 / 0 = the route this call would take reads x through hints->x_period / not
+static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed, const void* x,
+                        const void* dy, void* dx, float* d_packed, float* d_bias, const ttrnn_lin_hints* hints,
+                        void* workspace, size_t workspace_bytes, void* stream, bool probe) {
+  const int shT = hints && hints->x_period > 0 && d_packed ? (int)hints->x_period : 0;
+  const void* shF = shT > 0 ? hints->x_first : nullptr;
+  if (hints && hints->x_period > 0 && (hints->x_period >= ((int64_t)1 << 31) || n_rows % hints->x_period != 0))
+    return probe ? 0 : TTRNN_ERR_BAD_DESC;
+  if (shT > 0 && !probe && !dense_wgrad_shift_ok(n_rows, shT)) return TTRNN_ERR_UNSUPPORTED;
+// a route that reads x row by row itself: no shifted rows there
+#define TT_ROUTE_PLAIN_ROWS()                          \
+  do {                                                 \
+    if (probe) return 0;                               \
+    if (shT > 0) return TTRNN_ERR_UNSUPPORTED;         \
+  } while (0)
   const unsigned* hx = hints ? reinterpret_cast<const unsigned*>(hints->x_colmax) : nullptr;
   const unsigned* hdy = hints ? reinterpret_cast<const unsigned*>(hints->dy_colmax) : nullptr;
   const float* hsum = hints ? hints->xdy_sum : nullptr;
@@ -322,14 +336,15 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
   if (n_rows < 0) return TTRNN_ERR_BAD_DESC;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
   if (dy_dtype != TTRNN_F32 && dy_dtype != TTRNN_BF16) return TTRNN_ERR_UNSUPPORTED;
-  if (n_rows == 0) return TTRNN_OK;
-  if (!packed || !dy) return TTRNN_ERR_NULL;
-  if (d_packed && !x) return TTRNN_ERR_NULL;
-  if (!dx && !d_packed && !d_bias) return TTRNN_OK;
+  if (n_rows == 0) return probe ? 0 : TTRNN_OK;
+  if (!packed || !dy) return probe ? 0 : TTRNN_ERR_NULL;
+  if (d_packed && !x) return probe ? 0 : TTRNN_ERR_NULL;
+  if (!dx && !d_packed && !d_bias) return probe ? 0 : TTRNN_OK;
   if (!force_generic() && fast_ttlinear_bwd_available(s, dtype, dy_dtype)) {
     if (s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= in1_bwd_bytes(s) && !opt(OPT_NO_IN1)) {
       // y_n = b + x_n * chain(1): reduce dy over the rows once (dv = sum x_n dy_n, d_bias = sum dy_n), then
       // back-propagate dv through the chain on the single unit row
+      TT_ROUTE_PLAIN_ROWS();
       float* dv = (float*)workspace;
       const void* unit = unit_rows_ptr(dtype);
       if (!unit) return TTRNN_ERR_LAUNCH;
@@ -353,6 +368,7 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
       // Every row is independent, so the TT structure buys nothing here: one dense GEMM dW = x^T dy (fp32 MFMA), whose
       // image under the adjoint of "cores -> dense matrix" is what the fused-core weight-gradient kernel computes when it
       // is fed the `in` unit rows as x and dW's rows as dy; dx = dy W^T is a second dense GEMM (split-bf16).
+      if (probe) return dense_wgrad_shift_ok(n_rows, hints->x_period) ? 1 : 0;
       hipStream_t sm = (hipStream_t)stream;
       char* wsb = (char*)workspace;
       void* ident = wsb + dense_bwd_f10w(s);
@@ -363,7 +379,7 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
       if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm,
                                                  fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16,
                                                  (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)), hx,
-                                                 hdy);
+                                                 hdy, shT, shF);
       if (st == TTRNN_OK)
         st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       if (st != TTRNN_OK || !dx) return st;
@@ -375,21 +391,30 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
     }
     if ((fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && d_packed &&
         f10_ttlinear_wgrad_available(s, dtype, dy_dtype) && (!dx || f10_ttlinear_wgrad_has_dx(s)) &&
-        workspace && workspace_bytes >= f10_ttlinear_wgrad_workspace_bytes(s))
+        workspace && workspace_bytes >= f10_ttlinear_wgrad_workspace_bytes(s)) {
+      TT_ROUTE_PLAIN_ROWS();
       return launch_ttlinear_wgrad_f10(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                                        (hipStream_t)stream);
+    }
+    TT_ROUTE_PLAIN_ROWS();
     return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
                                     (hipStream_t)stream);
   }
   if (!force_generic() && (d_packed || (dx && !d_bias)) && big_ttlinear_bwd_available(s, dtype, dy_dtype)) {
     // big shape: dx, weight and bias gradients through the merged two-core matrix
-    if (!workspace || workspace_bytes < big_ttlinear_bwd_workspace_bytes(s)) return TTRNN_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < big_ttlinear_bwd_workspace_bytes(s)) return probe ? 0 : TTRNN_ERR_WORKSPACE;
+    if (opt(OPT_BIGW_SLICES) || !d_packed) TT_ROUTE_PLAIN_ROWS();      // (the per-row A/B kernel reads x itself)
+    // honoured, but not advertised: at this width the materialised copy is the faster way round — cfg5's training step 24.0
+    // ms reading `out` in place against 23.6 with the 0.28 ms copy, whose 537 MB the gradient GEMM then finds partly in the
+    // Infinity Cache (the narrow shapes gain: cfg4 6.75 -> 6.72)
+    if (probe) return 0;
     return launch_ttlinear_bwd_big(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace, (hipStream_t)stream, hx,
-                                   hdy);
+                                   hdy, shT, shF);
   }
   if (!force_generic() && !no_gemm() && s.in_size == 1 && !dx && d_packed && workspace && workspace_bytes >= gen_in1_bytes(s) &&
       !opt(OPT_NO_IN1)) {
     // y_n = b + x_n * chain(1): one reduction over the rows, then the any-shape backward on the single unit row
+    TT_ROUTE_PLAIN_ROWS();
     hipStream_t sm = (hipStream_t)stream;
     float* dv = (float*)workspace;
     const void* unit = unit_rows_ptr(TTRNN_F32);
@@ -409,6 +434,7 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
   const bool gd_split = fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16;
   if (!force_generic() && !no_gemm() && gd.ok && d_packed && dy_dtype == TTRNN_F32 && n_rows >= 4 * (int64_t)s.in_size &&
       (!dx || (gd.dx_ok && dtype == TTRNN_F32 && gd_split)) && workspace && workspace_bytes >= gd.total) {
+    if (probe) return dense_wgrad_shift_ok(n_rows, hints->x_period) ? 1 : 0;
     hipStream_t sm = (hipStream_t)stream;
     char* p = (char*)workspace;
     void* lin_bwd = p; p += gd.lin_bwd;
@@ -421,7 +447,7 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
     st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
     if (st == TTRNN_OK)
       st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch, hx,
-                              hdy);
+                              hdy, shT, shF);
     if (st == TTRNN_OK) {
       const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
       st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
@@ -433,11 +459,35 @@ int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, 
     if (st == TTRNN_OK) st = launch_gemm_split(TTRNN_F32, n_rows, s.out_size, s.in_size, dy, planes, nullptr, 0, (float*)dx, sm);
     return st;
   }
+  TT_ROUTE_PLAIN_ROWS();
   const LinPlan p = plan_ttlinear_bwd(s, n_rows);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_ttlinear_bwd(s, p, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                              (hipStream_t)stream);
+#undef TT_ROUTE_PLAIN_ROWS
 }
+
+extern "C" {
+
+int ttrnn_ttlinear_backward_hinted(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
+                                   const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
+                                   const ttrnn_lin_hints* hints, void* workspace, size_t workspace_bytes, void* stream) {
+  return lin_backward(w, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, hints, workspace, workspace_bytes,
+                      stream, false);
+}
+
+int ttrnn_ttlinear_backward_shift_ok(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_rows, int64_t x_period,
+                                     int want_dx) {
+  if (!w || x_period < 1) return 0;
+  ttrnn_lin_hints h = {nullptr, nullptr, nullptr, x_period, nullptr};
+  // same dispatch as the real call, with stand-in pointers and a workspace as large as ttrnn_ttlinear_workspace promises
+  void* one = reinterpret_cast<void*>(uintptr_t(256));
+  return lin_backward(w, dtype, dy_dtype, n_rows, reinterpret_cast<const float*>(one), one, one, want_dx ? one : nullptr,
+                      reinterpret_cast<float*>(one), nullptr, &h, one, ttrnn_ttlinear_workspace(w, n_rows), nullptr, true) == 1
+             ? 1
+             : 0;
+}
+
 
 // ---- recurrent layer ----------------------------------------------------------------------------
 // The shape-specialised path hoists the input projection: its workspace holds gin = W_in x + b_in for every

@@ -827,7 +827,8 @@ size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s) {
 
 template <typename TS>
 static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, const void* dy, void* dx, float* d_packed,
-                         float* d_bias, void* ws, hipStream_t stream, const unsigned* x_colmax, const unsigned* dy_colmax) {
+                         float* d_bias, void* ws, hipStream_t stream, const unsigned* x_colmax, const unsigned* dy_colmax,
+                         int shift_T, const void* shift_first) {
   const bool split_math = ttrnn_get_fp32_math() == TTRNN_MATH_SPLIT;
   float* m3 = (float*)ws;
   float* m2 = (float*)((char*)ws + B3);
@@ -855,7 +856,8 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
     float* dWf = (float*)((char*)dB + BDB);
     hipLaunchKernelGGL((k_bigw_natural<S3>), dim3((merged2_elems<S2>() + 255) / 256), dim3(256), 0, stream, m3, BmN, AT);
     const int sd = launch_dense_wgrad(sizeof(TS) == 4 ? TTRNN_F32 : TTRNN_BF16, n_rows, 1024, 4096, x, (const float*)dy, dWf,
-                                      d_bias, stream, split_math, (float*)((char*)dWf + BDW), x_colmax, dy_colmax);
+                                      d_bias, stream, split_math, (float*)((char*)dWf + BDW), x_colmax, dy_colmax, shift_T,
+                                      shift_first);
     if (sd != TTRNN_OK) return sd;
     hipLaunchKernelGGL(k_bigw_proj_a, dim3(16 * 64), dim3(256), 0, stream, dWf, BmN, dA);
     hipLaunchKernelGGL(k_bigw_proj_b, dim3(64 * 64), dim3(256), 0, stream, dWf, AT, dB);
@@ -886,11 +888,13 @@ static int launch_bigw_t(int64_t n_rows, const float* packed, const void* x, con
 // dx and / or (d_packed [+ d_bias]); a bias gradient alone is not offered
 int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream,
-                            const unsigned* x_colmax, const unsigned* dy_colmax) {
+                            const unsigned* x_colmax, const unsigned* dy_colmax, int shift_T, const void* shift_first) {
   (void)s;
-  return dtype == TTRNN_F32
-             ? launch_bigw_t<float>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax, dy_colmax)
-             : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax, dy_colmax);
+  if (shift_T > 0 && opt(OPT_BIGW_SLICES)) return TTRNN_ERR_UNSUPPORTED;
+  return dtype == TTRNN_F32 ? launch_bigw_t<float>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax,
+                                                   dy_colmax, shift_T, shift_first)
+                            : launch_bigw_t<bf16_t>(n_rows, packed, x, dy, dx, d_packed, d_bias, ws, stream, x_colmax,
+                                                    dy_colmax, shift_T, shift_first);
 }
 
 }  // namespace ttrnn

@@ -373,10 +373,29 @@ __device__ __forceinline__ f32x4 ld4(const bf16_t* p, size_t i) {
                __uint_as_float(v.y & 0xFFFF0000u)};
 }
 
+// Operand rows that are the PREVIOUS step's hidden states (the h_{t-1} rows of a hidden matrix's weight gradient) read in
+// place: x = out[B][T][IN] of the layer, row n of the operand = out row n - 1, or row n / T of `first` (h_0; zeros if
+// NULL) where n % T == 0.  T == 0: plain rows.  (Row counts below 2^31: a 32-bit division per staged quad.)
+struct RowShift {
+  int T = 0;
+  const void* first = nullptr;
+};
+template <typename TS>
+__device__ __forceinline__ f32x4 ld4_rows(const TS* __restrict__ x, const RowShift& rs, int64_t n, int IN, int col) {
+  if (rs.T <= 0) return ld4(x, (size_t)n * IN + col);
+  const unsigned b = (unsigned)n / (unsigned)rs.T;
+  const bool head = (unsigned)n == b * (unsigned)rs.T;
+  const TS* fp = reinterpret_cast<const TS*>(rs.first);
+  const TS* src = head ? (fp ? fp + (size_t)b * IN : x) : x + (size_t)(n - 1) * IN;
+  const f32x4 v = ld4(src, (size_t)col);
+  return (head && !fp) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+}
+
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                          const TS* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part) {
+                                                         float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
+                                                         RowShift rsh) {
   constexpr int KB = DenseG::KB, LS = DenseG::LS;
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
   float* xs = ldsf;                      // [2][KB][LS]
@@ -427,7 +446,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
     for (int e = 0; e < SR; ++e) {
       const int64_t n = nb + srow + 16 * e;
       const int64_t nc = n < r1 ? n : r1 - 1;               // unconditional loads; rows past the end are zeroed at the store
-      sx[e] = ld4(x, (size_t)nc * IN + jc);
+      sx[e] = ld4_rows(x, rsh, nc, IN, jc);
       sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
     }
   };
@@ -540,12 +559,12 @@ __device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
   return __builtin_bit_cast(xbf8, v);
 }
 
-template <typename TS, bool HALF>
+template <typename TS, bool HALF, bool SHIFT>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
                                                                const unsigned* __restrict__ colmax_x,
-                                                               const unsigned* __restrict__ colmax_dy) {
+                                                               const unsigned* __restrict__ colmax_dy, RowShift rsh) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
   constexpr int NP = HALF ? 2 : 3, BUFE = HALF ? DenseS::BUF_H : DenseS::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -617,11 +636,43 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
 #pragma unroll
       for (int i = 0; i < 4; ++i) scd[e][i] = col_scale(colmax_dy[o0 + dc[e] + i]);
   }
-  auto stage_load = [&](int64_t nb) {
+  // SHIFT (RowShift, T >= KB): the staged row's (sample, step) is carried from chunk to chunk — a division per staged quad
+  // cost cfg5's gradient 1.7 ms, and any branch in here splits the loop body the MFMA stream is scheduled in (1.3 ms): selects
+  // only.  Call k of stage_load stages rows r0 + k KB + xr[e] (the calls past the last chunk repeat it and are discarded: any
+  // valid address)
+  unsigned sh_n[2] = {0, 0}, sh_t[2] = {0, 0}, sh_b[2] = {0, 0};
+  if constexpr (SHIFT) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int64_t n = nb + xr[e] < r1 ? nb + xr[e] : r1 - 1;          // unconditional loads; masked at the store
-      sx[e] = ld4(x, (size_t)n * IN + (xin[e] ? j0 + xc[e] : 0));
+      sh_n[e] = (unsigned)(r0 + xr[e]);
+      sh_b[e] = sh_n[e] / (unsigned)rsh.T;
+      sh_t[e] = sh_n[e] - sh_b[e] * (unsigned)rsh.T;
+    }
+  }
+  auto stage_load = [&](int64_t nb) {
+    if constexpr (SHIFT) {
+      const TS* fp = reinterpret_cast<const TS*>(rsh.first);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int col = xin[e] ? j0 + xc[e] : 0;
+        const bool inr = (int64_t)sh_n[e] < r1, head = inr && sh_t[e] == 0;
+        // row n - 1 of x; a head row takes its sample's initial state, or reads row n (any valid address) and is zeroed
+        const unsigned row = !inr ? (unsigned)(r1 - 1) : head ? sh_n[e] : sh_n[e] - 1;
+        const TS* src = (head && fp) ? fp + (size_t)sh_b[e] * IN : x + (size_t)row * IN;
+        const f32x4 v = ld4(src, (size_t)col);
+        sx[e] = (head && !fp) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+        sh_n[e] += KB;
+        sh_t[e] += KB;
+        const bool wrap = sh_t[e] >= (unsigned)rsh.T;
+        sh_t[e] -= wrap ? (unsigned)rsh.T : 0u;
+        sh_b[e] += wrap ? 1u : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int64_t n = nb + xr[e] < r1 ? nb + xr[e] : r1 - 1;          // unconditional loads; masked at the store
+        sx[e] = ld4(x, (size_t)n * IN + (xin[e] ? j0 + xc[e] : 0));
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -854,6 +905,10 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 }
 
 
+// can launch_dense_wgrad read shifted rows (shift_T) for this many rows?
+bool dense_wgrad_shift_ok(int64_t n_rows, int64_t shift_T) {
+  return n_rows < ((int64_t)1 << 31) && shift_T >= DenseS::KB && shift_T < ((int64_t)1 << 31);
+}
 bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % DenseG::TN == 0; }
 
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
@@ -870,8 +925,12 @@ static bool dense_wgrad_use_half(int64_t n_rows, int in, int out) {
 
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
                        float* d_bias, hipStream_t stream, bool split, float* scratch_all, const unsigned* x_colmax,
-                       const unsigned* dy_colmax) {
+                       const unsigned* dy_colmax, int shift_T, const void* shift_first) {
   const int cus = device_cu_count();
+  if (shift_T > 0 && !dense_wgrad_shift_ok(n_rows, shift_T)) return TTRNN_ERR_UNSUPPORTED;
+  RowShift rsh;
+  rsh.T = shift_T > 0 ? shift_T : 0;
+  rsh.first = shift_T > 0 ? shift_first : nullptr;
   split = split && out % DenseS::TO == 0 && !opt(OPT_DENSE_FP32);      // A/B switch: dense gradient on the fp32 MFMA
   // scratch: [column maxima of x and dy (HALF) | partial tiles of the row ranges]
   unsigned* colmax = (unsigned*)scratch_all;
@@ -894,6 +953,16 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
       else
         hipLaunchKernelGGL(k_col_absmax<bf16_t>, dim3((in / 4 + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)x, n_rows,
                            in, colmax);
+      if (rsh.T > 0 && rsh.first) {      // shifted rows: the maxima over `out` bound rows 1.., the initial states are rows 0
+        const int64_t nb = n_rows / rsh.T;
+        const unsigned gb = (unsigned)((nb + 127) / 128);
+        if (dtype == TTRNN_F32)
+          hipLaunchKernelGGL(k_col_absmax<float>, dim3((in / 4 + 255) / 256, gb), dim3(256), 0, stream, (const float*)rsh.first,
+                             nb, in, colmax);
+        else
+          hipLaunchKernelGGL(k_col_absmax<bf16_t>, dim3((in / 4 + 255) / 256, gb), dim3(256), 0, stream,
+                             (const bf16_t*)rsh.first, nb, in, colmax);
+      }
     }
     if (dy_colmax) {
       cd = dy_colmax;
@@ -920,43 +989,34 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   if (KS > 1 && !part && hipMemsetAsync(dW, 0, (size_t)in * out * sizeof(float), stream) != hipSuccess)
     return TTRNN_ERR_LAUNCH;
   const int di = (dtype == TTRNN_F32 ? 0 : 1) + (split ? 2 : 0) + (half ? 2 : 0);
-  const void* fn = di == 0   ? reinterpret_cast<const void*>(k_dense_wgrad<float>)
-                   : di == 1 ? reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>)
-                   : di == 2 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float, false>)
-                   : di == 3 ? reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t, false>)
-                   : di == 4 ? reinterpret_cast<const void*>(k_dense_wgrad_split<float, true>)
-                             : reinterpret_cast<const void*>(k_dense_wgrad_split<bf16_t, true>);
   const size_t lds = half ? DenseS::LDS_BYTES_H : split ? DenseS::LDS_BYTES : DenseG::LDS_BYTES;
-  {
-    if (ensure_dynamic_lds(fn, lds) != TTRNN_OK)
-      return TTRNN_ERR_LAUNCH;
-  }
   const unsigned grid = (unsigned)(tiles * KS);
+#define TT_WG(TSV, HV, SV)                                                                                                    \
+  do {                                                                                                                        \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<TSV, HV, SV>), lds) != TTRNN_OK)                  \
+      return TTRNN_ERR_LAUNCH;                                                                                                \
+    hipLaunchKernelGGL((k_dense_wgrad_split<TSV, HV, SV>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,       \
+                       rows_per, (const TSV*)x, dy, dW, d_bias, part, cx, cd, rsh);                                           \
+  } while (0)
+#define TT_WG2(TSV, HV) do { if (rsh.T > 0) TT_WG(TSV, HV, true); else TT_WG(TSV, HV, false); } while (0)
   switch (di) {
     case 0:
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<float>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
       hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const float*)x, dy, dW, d_bias, part);
+                         (const float*)x, dy, dW, d_bias, part, rsh);
       break;
     case 1:
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
       hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const bf16_t*)x, dy, dW, d_bias, part);
+                         (const bf16_t*)x, dy, dW, d_bias, part, rsh);
       break;
-    case 2:
-      hipLaunchKernelGGL((k_dense_wgrad_split<float, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd);
-      break;
-    case 3:
-      hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, false>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, cx, cd);
-      break;
-    case 4:
-      hipLaunchKernelGGL((k_dense_wgrad_split<float, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd);
-      break;
-    default:
-      hipLaunchKernelGGL((k_dense_wgrad_split<bf16_t, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,
-                         rows_per, (const bf16_t*)x, dy, dW, d_bias, part, cx, cd);
+    case 2: TT_WG2(float, false); break;
+    case 3: TT_WG2(bf16_t, false); break;
+    case 4: TT_WG2(float, true); break;
+    default: TT_WG2(bf16_t, true);
   }
+#undef TT_WG2
+#undef TT_WG
   if (part) {
     const size_t n4 = (size_t)in * out / 4;
     hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, KS, n4, dW);

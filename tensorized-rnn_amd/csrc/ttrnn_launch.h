@@ -184,12 +184,15 @@ int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, con
 
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
+bool dense_wgrad_shift_ok(int64_t n_rows, int64_t shift_T);
+// shift_T > 0: x = out[B][shift_T][in] of a recurrent layer and the operand's row n is the previous step's output (row n - 1;
+// row n / shift_T of shift_first — zeros if NULL — where n % shift_T == 0): h_{t-1} rows read in place.
 // x_colmax / dy_colmax (optional, device): fp32 bit patterns of upper bounds of the columns' maxima (in / out entries) handed
 // over by the producer of the operand (ttrnn_ttlinear_backward_hinted): with dy's given the two-piece fp16 variant needs
 // no pass over dy and is taken at every size
 int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x, const float* dy, float* dW,
                        float* d_bias, hipStream_t stream, bool split, float* scratch, const unsigned* x_colmax = nullptr,
-                       const unsigned* dy_colmax = nullptr);
+                       const unsigned* dy_colmax = nullptr, int shift_T = 0, const void* shift_first = nullptr);
 size_t dense_wgrad_scratch_bytes(int in, int out);
 
 // shapes too large for on-chip residency (ttrnn_fast_big.hip): chain images in an L2-resident workspace
@@ -226,7 +229,8 @@ bool big_ttlinear_bwd_available(const TtShape& s, int dtype, int dy_dtype);
 size_t big_ttlinear_bwd_workspace_bytes(const TtShape& s);
 int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream,
-                            const unsigned* x_colmax = nullptr, const unsigned* dy_colmax = nullptr);
+                            const unsigned* x_colmax = nullptr, const unsigned* dy_colmax = nullptr, int shift_T = 0,
+                            const void* shift_first = nullptr);
 
 // runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): any TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores
 bool g2_rnn_available(const RnnShape& rs, int dtype);         // forward kernel

@@ -40,7 +40,8 @@ class RnnDesc(ctypes.Structure):
 
 class LinHints(ctypes.Structure):
     """struct ttrnn_lin_hints"""
-    _fields_ = [("x_colmax", ctypes.c_void_p), ("dy_colmax", ctypes.c_void_p), ("xdy_sum", ctypes.c_void_p)]
+    _fields_ = [("x_colmax", ctypes.c_void_p), ("dy_colmax", ctypes.c_void_p), ("xdy_sum", ctypes.c_void_p),
+                ("x_period", ctypes.c_int64), ("x_first", ctypes.c_void_p)]
 
 
 _P = ctypes.c_void_p
@@ -68,6 +69,8 @@ _SIGNATURES = {
                                                _P, _P, _P, ctypes.c_size_t, _P]),
     "ttrnn_ttlinear_backward_hinted": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P,
                                                       _P, _P, _P, _P, ctypes.POINTER(LinHints), _P, ctypes.c_size_t, _P]),
+    "ttrnn_ttlinear_backward_shift_ok": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                        ctypes.c_int64, ctypes.c_int]),
     "ttrnn_head_workspace": (ctypes.c_size_t, [ctypes.POINTER(TtmDesc), ctypes.c_int64]),
     "ttrnn_head_forward": (ctypes.c_int, [ctypes.POINTER(TtmDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int64, _P, _P, _P, _P, _P,
                                           _P, ctypes.c_size_t, _P]),

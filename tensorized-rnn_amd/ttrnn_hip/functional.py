@@ -177,6 +177,9 @@ class TTSpec(object):
 # Use the by-products of the reverse-time kernel (include/ttrnn.h: ttrnn_rnn_backward_ex) in the weight-gradient step.  A/B
 # switch for tests and measurements; the library decides per descriptor what it can deliver.
 USE_BWD_STATS = True
+# Read the h_{t-1} rows of the hidden matrix's weight gradient in place (hints x_period / x_first) where the route can,
+# instead of materialising [h_0, out[:, :-1]]; same kind of switch
+USE_ROW_SHIFT = True
 # tests: a list here receives (mask, stats, d_gates_in, d_gates_hid) of every layer backward
 DEBUG_BWD_STATS = None
 
@@ -194,7 +197,8 @@ def _ones(dev, n):
 
 def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroed=None, hints=None):
     """zeroed: optional (dpk, db) fp32 buffers the caller has already zero-filled (one fill for several calls).
-    hints: optional dict of fp32 device tensors x_colmax[in] / dy_colmax[out] / xdy_sum[out] (struct ttrnn_lin_hints)."""
+    hints: optional dict (struct ttrnn_lin_hints): fp32 device tensors x_colmax[in] / dy_colmax[out] / xdy_sum[out];
+    x_period (int) + x_first (tensor or None): x2d holds a layer's outputs and the operand rows are the previous steps'."""
     lib = _lib.load()
     n = dy2d.shape[0]
     dev = dy2d.device
@@ -213,7 +217,11 @@ def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroe
             t = hints.get(k)
             if t is not None and (t.dtype != torch.float32 or t.numel() != width or not t.is_contiguous() or t.device != dev):
                 raise ValueError("hint {} must be a contiguous fp32 tensor of {} elements on {}".format(k, width, dev))
-        hs = _lib.LinHints(_ptr(hints.get("x_colmax")), _ptr(hints.get("dy_colmax")), _ptr(hints.get("xdy_sum")))
+        first = hints.get("x_first")
+        if first is not None and (first.dtype != x2d.dtype or not first.is_contiguous() or first.device != dev):
+            raise ValueError("hint x_first must be a contiguous {} tensor on {}".format(x2d.dtype, dev))
+        hs = _lib.LinHints(_ptr(hints.get("x_colmax")), _ptr(hints.get("dy_colmax")), _ptr(hints.get("xdy_sum")),
+                           int(hints.get("x_period") or 0), _ptr(first))
         hp = ctypes.byref(hs)
     check(lib.ttrnn_ttlinear_backward_hinted(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
                                              _ptr(x2d), _ptr(dy2d), _ptr(dx), _ptr(dpk), _ptr(db), hp, _ptr(ws), wsb,
@@ -480,9 +488,14 @@ class _TTRnnLayerFn(torch.autograd.Function):
                                                want_db_in and not use_sums, zeroed=(z_in_w, z_in_b), hints=hints_in)
         if use_sums and want_db_in:
             db_in = bstats[3]
-        # h_{t-1} rows: [h0, out[:, :-1]]
-        first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
-        hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
+        # h_{t-1} rows: [h0, out[:, :-1]] — read in place by the dense-gradient routes, materialised for the others
+        if USE_ROW_SHIFT and need_dw_hid and T > 0 and lib.ttrnn_ttlinear_backward_shift_ok(
+                ctypes.byref(spec.hid_spec.desc), _dtype_code(out), _lib.TTRNN_F32, B * T, T, 0):
+            hprev = out.reshape(B * T, H)
+            hints_hid = dict(hints_hid or {}, x_period=T, x_first=h0)
+        else:
+            first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
+            hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
         _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
                                                 False, need_dw_hid, has_bhid and need[4], zeroed=(z_hid_w, z_hid_b),
                                                 hints=hints_hid)

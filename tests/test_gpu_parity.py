@@ -1937,3 +1937,87 @@ def test_reverse_kernel_by_products_feed_the_weight_gradients(kind, inp, H, d, L
     # size the by-products switch them from three bf16 pieces to two fp16 pieces, as for the small shapes)
     assert differ or dtype == "bf16"                             # (rounding the gradients to bf16 can hide the difference)
     assert worst[True] <= (5e-2 if dtype == "bf16" else 2e-4) and worst[True] <= 3.0 * worst[False] + 1e-6
+
+
+@pytest.mark.parametrize("kind,inp,H,d,L,r,B,T,dtype,with_h0,expect_shift", [
+    ("ttlstm", 1, 256, 3, 1, 8, 40, 35, "f32", False, True),
+    ("ttlstm", 1, 256, 3, 1, 8, 40, 35, "f32", True, True),
+    ("ttgru", 1, 256, 3, 1, 8, 37, 40, "f32", True, True),        # h0 rows enter the column-maximum pass
+    ("ttgru", 1, 256, 3, 1, 8, 37, 40, "bf16", True, True),
+    ("ttlstm", 40, 256, 3, 2, 16, 30, 43, "f32", False, True),
+    ("ttlstm", 1024, 1024, 4, 1, 32, 3, 33, "f32", True, False),  # merged-big route: honoured, not advertised (slower)
+    ("ttlstm", 16, 64, 2, 1, 4, 30, 41, "f32", True, True),       # runtime-shape tier: any-shape dense gradient
+    ("ttlstm", 1, 256, 3, 1, 8, 70, 20, "f32", True, False),      # sequences shorter than a 32-row chunk: rows materialised
+    ("ttlstm", 1, 256, 3, 1, 8, 5, 37, "f32", True, False),       # few rows: the per-row kernels, rows materialised
+])
+def test_hidden_weight_gradient_reads_previous_states_in_place(kind, inp, H, d, L, r, B, T, dtype, with_h0, expect_shift):
+    """hints x_period / x_first (include/ttrnn.h: ttrnn_lin_hints): the dense-gradient routes read the h_{t-1} rows of the
+    hidden matrix's weight gradient from the layer's outputs (row n - 1; h_0 or zeros at the sequence starts) instead of a
+    materialised [h_0, out[:, :-1]].  Same kernels on the same values: every gradient agrees with the one the materialised
+    rows give to the run-to-run noise of the float atomics downstream; ttrnn_ttlinear_backward_shift_ok says which calls
+    take such a route."""
+    import ctypes
+    import ttrnn_hip.functional as F
+    from ttrnn_hip import _lib
+    torch.manual_seed(3 + B + T)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r)
+    m = build_module(meta, dev())
+    x = torch.randn(B, T, inp) * 0.7
+    w = torch.randn(B, T, H)
+    h0 = torch.randn(B, H) * 1.5 if with_h0 else None
+    if dtype == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+        h0 = h0.to(torch.bfloat16) if h0 is not None else None
+    cell = m._all_layers[-1]
+    ok = _lib.load().ttrnn_ttlinear_backward_shift_ok(ctypes.byref(cell._layer_spec().hid_spec.desc),
+                                                      _lib.TTRNN_BF16 if dtype == "bf16" else _lib.TTRNN_F32, _lib.TTRNN_F32,
+                                                      B * T, T, 0)
+    assert bool(ok) == expect_shift
+    grads = {}
+    for use in (True, False):
+        F.USE_ROW_SHIFT = use
+        try:
+            m.zero_grad()
+            if kind == "ttlstm":
+                init = (h0.to(dev()), torch.zeros(B, H, device=dev(), dtype=x.dtype)) if with_h0 else None
+                out = m(x.to(dev()), init)[0]
+            else:
+                out = m(x.to(dev()), h0.to(dev()) if with_h0 else None)[0]
+            (out.float() * w.to(dev())).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            F.USE_ROW_SHIFT = True
+        grads[use] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    for n in grads[True]:
+        assert torch.isfinite(grads[True][n].float()).all(), n
+        # (not bitwise: bias column sums and core-gradient partial sums leave their workgroups through float atomics, whose
+        # order varies from launch to launch; a wrong row anywhere would show at the 1e-2 level)
+        sc = max(float(grads[False][n].float().abs().max()), 1e-30)
+        assert _maxabs(grads[True][n].float(), grads[False][n].float()) <= (1e-2 if dtype == "bf16" else 1e-5) * sc, n
+
+
+@pytest.mark.parametrize("with_h0", [False, True])
+def test_big_shape_dense_gradient_honours_row_shift_when_asked(with_h0):
+    """The merged-big TTLinear backward reads shifted rows when the hints ask for it (ttrnn_ttlinear_backward_shift_ok does
+    not advertise it there: measured slower than the materialised copy on cfg5) — same gradients as the materialised rows."""
+    import ttrnn_hip.functional as F
+    torch.manual_seed(9)
+    meta = dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32)
+    m = build_module(meta, dev())
+    cell = m._all_layers[0]
+    spec = cell._layer_spec().hid_spec
+    cin, bin_, chid, bhid = cell._operands()
+    B, T, H = 3, 40, 1024
+    out = torch.tanh(torch.randn(B, T, H, device=dev()))
+    h0 = torch.randn(B, H, device=dev()) if with_h0 else None
+    dy = torch.randn(B * T, 4 * H, device=dev()) * 0.1
+    packed = spec.pack(list(chid))
+    first = h0 if with_h0 else torch.zeros(B, H, device=dev())
+    hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H).contiguous()
+    _, ref, _ = F._ttlinear_backward(spec, packed, hprev, dy, False, True, False)
+    _, got, _ = F._ttlinear_backward(spec, packed, out.reshape(B * T, H), dy, False, True, False,
+                                     hints={"x_period": T, "x_first": h0})
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert _maxabs(got, ref) <= 1e-5 * float(ref.abs().max())
