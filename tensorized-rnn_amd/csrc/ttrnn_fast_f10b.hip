@@ -585,9 +585,14 @@ static int launch_gru_bwd_f10(const RnnShape& rs, const void* out, const void* h
 template <class S>
 static int launch_bwd_f10(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
-                          void* d_h0, void* d_c0, void* ws, hipStream_t stream, const BwdStats& bs) {
+                          void* d_h0, void* d_c0, void* ws, hipStream_t stream, const BwdStats& bs, void* ws_half) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   using B = F10B<S>;
+  // split mode: the two-piece fp16 kernel (ttrnn_fast_f10bh.hip); option gemm_pieces = 3 keeps this file's kernel
+  if (ws_half)
+    return launch_lstm_bwd_f10h(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws_half,
+                                reinterpret_cast<unsigned long long*>((char*)ws + f10b_wfrag_elems<S>() * sizeof(xbf8)),
+                                stream, bs);
   xbf8* wfrag = reinterpret_cast<xbf8*>(ws);
   hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed_hid, wfrag);
   constexpr size_t lds = f10b_lds_bytes<S>();
@@ -654,9 +659,11 @@ static size_t f10b_ws_head_bytes(const RnnShape& rs, int dtype) {
 size_t bwd_stats_part_bytes(const RnnShape& rs) {
   return rs.in == 1 ? ((size_t)rs.B * 2 * rs.G * rs.H * sizeof(float) + 255) & ~(size_t)255 : 0;
 }
-size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
+size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // [fragments, stamps | sums | two-piece kernel's]
   const size_t head = f10b_ws_head_bytes(rs, dtype);
-  return head ? ((head + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs) : 0;
+  if (!head) return 0;
+  const size_t half = rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 ? f10bh_workspace_bytes(rs) : 0;
+  return ((head + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs) + half;
 }
 
 // per-sample sums -> stats rows 2, 3 (fixed order: four interleaved sample groups per column, then the four partial sums);
@@ -705,6 +712,9 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
       bs.part = reinterpret_cast<float*>((char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255));
     }
   }
+  void* ws_half = nullptr;
+  if (rs.cell == TTRNN_LSTM && f10bh_available(rs, dtype))
+    ws_half = (char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs);
   int st = TTRNN_ERR_UNSUPPORTED;
   if (rs.cell == TTRNN_GRU) {
     if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
@@ -716,10 +726,10 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
                                                   stream, bs);
   } else if (shape_matches<ShpH256R8L>(rs.hid_s)) {
     st = launch_bwd_f10<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream,
-                                    bs);
+                                    bs, ws_half);
   } else if (shape_matches<ShpH256R16L>(rs.hid_s)) {
     st = launch_bwd_f10<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream,
-                                     bs);
+                                     bs, ws_half);
   }
   if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, GH, bs.part, stats, stream);
   return st;

@@ -1,0 +1,500 @@
+// ttrnn_fast_f10bh.hip — reverse-time TT-LSTM kernel on the fused core with TWO fp16 pieces per operand (gfx950).
+//
+// Same two transposed stages as ttrnn_fast_f10b.hip (T01: dC2 = W10 dg, T2: dh = G2 dC2; reference: torch autograd through
+// tensorized_rnn/lstm.py:23-32,123-133 and t3nsor/ops.py:78-93), three f16 MFMA terms (hi*hi, hi*lo, lo*hi) instead of six bf16
+// ones.  fp16's narrow exponent is handled per operand:
+//   * the weights (fixed per launch): one power-of-two scale per ROW of W10 (feature (row2, r2)) and of G2 (j2), row maximum
+//     -> [2^13, 2^14); a row is an OUTPUT row of its stage, so the scale is undone on the accumulators, per register.  The
+//     pieces' representation error is then at most 2^-22 of each entry, or 2^-25 absolute (scaled) for entries more than
+//     2^17 below their row's maximum: summed over a row never more than 2^-21 of the row's L1 norm — the error bound of an
+//     fp32 dot product with that row.  No guard and no fallback are needed (with ONE scale per matrix, as in the cfg5-class
+//     kernel, a whole row can sit in fp16's subnormal range: there they are);
+//   * the gradients (new every step, magnitudes falling over many decades along a sequence): one scale per step from the
+//     EXACT maximum of |dg_t| — every gate wave reduces its values with four DPP row rotations + four readlanes (a
+//     ds_bpermute butterfly would cost the stage it saves) and the four maxima cross the barrier behind the gate phase.  The
+//     1 024 values are split ONCE, two per thread, in a phase of its own behind that barrier (splitting them in every one of
+//     the eight waves where the fragments are read made T01 VALU-issue bound: 3 416 cycles per step against 2 956 of the
+//     three-bf16-piece kernel).  T01's results are rescaled for T2 by the bound |dC2| <= max_f L1(W10 row f) max|dg_t| — known
+//     at the same moment, so they go to LDS split already — which costs T2's operand the 3 - 5 bits between the bound and the
+//     typical entry (of the 6 it has to spare before the second piece thins out) and cannot overflow.
+// Per step: G (waves 0-3; fp32 image + row for HBM + wave maximum) | barrier | split | barrier | T01 (12 MFMAs per wave at
+// r = 8) | barrier | T2 (3 MFMAs per wave) | barrier.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+#include "ttrnn_f10.h"
+
+namespace ttrnn {
+namespace {
+
+template <class S>
+struct F10BH {
+  using F = F10<S>;
+  static constexpr int H = F::H;
+  static constexpr int K1 = F::M, NM1 = K1 / 32;            // T01 contraction (64), its k-blocks
+  static constexpr int FT = F::K / 16, XF = FT / FAST_NW;   // T01 feature tiles, per wave
+  static constexpr int K2 = F::I2 * F::R2, NM2 = K2 / 32;   // T2 contraction, its k-blocks = partial-sum slices
+  static constexpr int CT2 = F::ROWS2 / 16;                 // T2 column tiles (2)
+  static constexpr int XT2 = NM2 * CT2 / FAST_NW;           // T2 (column tile, k-block) pairs per wave
+  static constexpr int HI = F::I2 / 2;
+  static constexpr int ROWS = F::K + 16;                    // rows: W10's, then G2's (padded to a tile)
+  // header (floats): [un1: F::K | un2: 16 | L1 norms of the scaled rows: ROWS], padded to 256 bytes
+  static constexpr int UN1 = 0, UN2 = F::K, L1N = F::K + 16;
+  static constexpr int HDR_FLOATS = (F::K + 16 + ROWS + 63) / 64 * 64;
+  static constexpr size_t FRAGS = (size_t)(FT * NM1 + NM2) * 2 * 64;      // xh8 fragments
+  __device__ static constexpr int m_of_k1(int k) { return (k & 3) * F::MPG + (k >> 2); }
+  __device__ static constexpr int k2_of(int i2, int r2) { return ((r2 >> 2) * HI + (i2 >> 1)) * 8 + (i2 & 1) * 4 + (r2 & 3); }
+};
+
+template <class S>
+constexpr bool f10bh_ok() {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  return f10_ok<S>() && F::I2 == 16 && B::K1 == 64 && B::FT % FAST_NW == 0 && B::K2 % 32 == 0 &&
+         (B::NM2 * B::CT2) % FAST_NW == 0 && B::CT2 == 2 && F::J2 == 8 && F::H == 256 && B::NM2 <= FAST_NW;
+}
+
+// x < 2^e, clamped so that 2^(14 - e) and its inverse stay normal floats (gradients deep in a sequence are tiny)
+__device__ __forceinline__ int expo_wide(float x) {
+  if (!(x > 0.f)) return 0;
+  if (!(x < 3e38f)) return 100;
+  int e;
+  frexpf(x, &e);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+// The step scales inside the time loop, from the bits of the maximum (frexpf / ldexpf of the device library cost the kernel
+// 300 cycles per stage): mx >= 0 has the biased exponent eb = bits >> 23, mx < 2^(eb - 126); eb clamped to [27, 227] keeps
+// 2^(14 - e) and its inverse normal (a zero maximum scales by 2^114: zeros stay zeros).  Returns 2^(14 - e), un = 2^(e - 14).
+__device__ __forceinline__ float step_scale(float mx, float& un) {
+  int eb = (int)(__float_as_uint(mx) >> 23);
+  eb = eb < 27 ? 27 : (eb > 227 ? 227 : eb);
+  un = __uint_as_float((unsigned)(eb - 13) << 23);
+  return __uint_as_float((unsigned)(267 - eb) << 23);
+}
+
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+// maximum over the 64 lanes, in every lane (max is idempotent: rotations inside the 16-lane rows, then one lane of each row)
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, row_ror<1>(v));
+  v = fmaxf(v, row_ror<2>(v));
+  v = fmaxf(v, row_ror<4>(v));
+  v = fmaxf(v, row_ror<8>(v));
+  const int i = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(i, 0)), b = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(i, 32)), d = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// eight consecutive k of an fp32 operand -> the MFMA fragments of its two fp16 pieces
+__device__ __forceinline__ void split8h(const f32x4& va, const f32x4& vb, xh8& hi8, xh8& lo8) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split_pair_h(va[0], va[1], h0, l0);
+  split_pair_h(va[2], va[3], h1, l1);
+  split_pair_h(vb[0], vb[1], h2, l2);
+  split_pair_h(vb[2], vb[3], h3, l3);
+  hi8 = __builtin_bit_cast(xh8, u32x4{h0, h1, h2, h3});
+  lo8 = __builtin_bit_cast(xh8, u32x4{l0, l1, l2, l3});
+}
+
+// Fragments + row scales + the scaled rows' L1 norms.  Block ft < FT: rows 16 ft + r of W10 (wave u = k-block u); block FT: the rows of G2.
+// Fragment order: T01 wf[((ft*NM1 + u)*2 + p)*64 + lane], lane (r, q): k = 32u + 8q + e (gate-interleaved: m_of_k1);
+//                 T2  wf[T01 part + (u*2 + p)*64 + lane], lane (r, q): row j2 = r (< J2, else 0), k2 slot 4u + q
+template <class S>
+__global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict__ packed, float* __restrict__ hdr,
+                                                        xh8* __restrict__ wfrag) {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  __shared__ float red[2][FAST_NW][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const bool g2 = blockIdx.x == B::FT;
+  const int nu = g2 ? B::NM2 : B::NM1;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (wave < nu) {
+    if (!g2) {
+      const int f = 16 * blockIdx.x + r;
+      const int row2 = f / F::R2, r2 = f % F::R2;
+      const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+      const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+      const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = B::m_of_k1(32 * wave + 8 * q + e);
+        const int i0 = m / F::I1, i1 = m % F::I1;
+        const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+        float a = 0.f;
+        for (int r1 = 0; r1 < F::R1; ++r1) a = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], a);
+        v[e] = a;
+      }
+    } else {
+      const float* W2 = packed + woff_of<S>(2);               // [J2][M2 = I2*R2]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 4 * wave + q;
+        const int i2 = 2 * (slot % B::HI) + (e >> 2), r2 = (slot / B::HI) * 4 + (e & 3);
+        v[e] = (r < F::J2 && i2 < F::I2) ? W2[r * F::M2 + i2 * F::R2 + r2] : 0.f;
+      }
+    }
+  }
+  // row maximum: the 8 values of the lane, the four q groups of the wave, the waves of the block
+  float mx = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (q == 0) red[0][wave][r] = mx;
+  __syncthreads();
+  float rm = 0.f;
+  for (int w = 0; w < nu; ++w) rm = fmaxf(rm, red[0][w][r]);
+  const int ex = expo_wide(rm);
+  const float sc = ldexpf(1.f, 14 - ex);
+  xh8 p0, p1;
+  float as = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 a, b;
+    const float w = v[e] * sc;
+    split2h(w, a, b);
+    p0[e] = a; p1[e] = b;
+    as += fabsf(w);
+  }
+  as += __shfl_xor(as, 16); as += __shfl_xor(as, 32);
+  if (q == 0) red[1][wave][r] = as;
+  if (wave < nu) {
+    xh8* dst = wfrag + (g2 ? (size_t)(B::FT * B::NM1 + wave) * 2 * 64 : (size_t)(blockIdx.x * B::NM1 + wave) * 2 * 64) + lane;
+    dst[0] = p0;
+    dst[64] = p1;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a2 = 0.f;
+    for (int w = 0; w < nu; ++w) a2 += red[1][w][tid];
+    const int row = g2 ? F::K + tid : 16 * blockIdx.x + tid;
+    hdr[row] = ldexpf(1.f, ex - 14);                      // (tid < 16: r == tid, rm / ex are this row's)
+    hdr[B::L1N + row] = a2;
+  }
+}
+
+template <class S>
+constexpr size_t f10bh_lds_bytes() {
+  using B = F10BH<S>;
+  using F = F10<S>;
+  return sizeof(float) * ((size_t)4 * B::H + (size_t)B::NM2 * B::H) +
+         sizeof(_Float16) * 2 * ((size_t)F::I2 * B::K1 + (size_t)F::ROWS2 * B::K2);
+}
+
+template <class S, bool DIAG>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const float* __restrict__ c0,
+                                                           const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
+                                                           const float* __restrict__ reserve,
+                                                           const float* __restrict__ d_out,
+                                                           const float* __restrict__ d_hT,
+                                                           const float* __restrict__ d_cT, float* __restrict__ dg_in,
+                                                           float* __restrict__ dg_hid, float* __restrict__ d_h0,
+                                                           float* __restrict__ d_c0,
+                                                           unsigned long long* __restrict__ diag, BwdStats bs) {
+  static_assert(f10bh_ok<S>(), "shape not supported by the two-piece fused-core reverse-time kernel");
+  using F = F10<S>;
+  using B = F10BH<S>;
+  constexpr int H = F::H, GH = 4 * H;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) float smax1[4];                    // per-wave maxima of |dg| (waves 0-3)
+  __shared__ float sl1[FAST_NW];                                             // (prologue) per-wave maxima of the rows' L1 norms
+  constexpr int PL1 = F::I2 * B::K1, PL2 = F::ROWS2 * B::K2;                 // elements per fp16 plane
+  static_assert(GH / 4 == FAST_NT - H, "waves 4-7 store the fp32 row: one 16-byte piece per thread");
+  float* dgf = reinterpret_cast<float*>(smem);                               // [4H] in HBM row order
+  float* dhs = dgf + GH;                                                     // [NM2][H]
+  _Float16* img1h = reinterpret_cast<_Float16*>(dhs + B::NM2 * H);           // dg's two fp16 pieces [2][I2][K1] (x_off)
+  _Float16* img2h = img1h + 2 * PL1;                                         // dC2's two fp16 pieces [2][ROWS2][K2] (x_off)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  // resident fragments (two pieces) and the inverse row scales of the accumulator registers
+  xh8 w01[B::XF][B::NM1][2], w2t[B::XT2][2];
+  f32x4 un1[B::XF], un2;
+#pragma unroll
+  for (int x = 0; x < B::XF; ++x) {
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
+    un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+  }
+  const int ct = wave & 1;
+#pragma unroll
+  for (int x = 0; x < B::XT2; ++x)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ((wave + FAST_NW * x) >> 1) * 2 + p) * 64 + lane];
+  un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * q);
+  // bound of T01's results: |dC2[f][.]| <= L1(row f of W10) max|dg|.  The largest row norm, once per launch
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int f = tid; f < F::K; f += FAST_NT) l = fmaxf(l, hdr[B::L1N + f] * hdr[B::UN1 + f]);
+    l = wave_max(l);
+    if (lane == 0) sl1[wave] = l;
+    __syncthreads();
+    maxl1 = sl1[0];
+#pragma unroll
+    for (int w = 1; w < FAST_NW; ++w) maxl1 = fmaxf(maxl1, sl1[w]);
+  }
+
+  // gate phase: thread tid < H owns hidden unit tid; three rotating register sets (see k_lstm_bwd_f10)
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float dcs = (own && d_cT) ? d_cT[b * H + hid] : 0.f;
+  const float c0v = (own && c0) ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
+  float do0 = 0.f, do1 = 0.f, do2 = 0.f;
+  const float* xptr = bs.x ? reinterpret_cast<const float*>(bs.x) : reserve;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  float xq0 = 0.f, xq1 = 0.f, xq2 = 0.f;
+  f32x4 cmx = f32x4{0.f, 0.f, 0.f, 0.f}, sxd = cmx, sdg = cmx;
+  if (own) {
+    dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
+    if (T > 0) {
+      const size_t bt = b * T + (T - 1);
+      const float* rv = reserve + res_gate(bt, H, hid);
+      const float* rc = reserve + res_cell((size_t)Bn * T, bt, H, hid);
+      ra0 = *reinterpret_cast<const f32x4*>(rv);
+      rb0 = rc[0];
+      do0 = dptr[bt * H + hid];
+      xq0 = xptr[bt];
+      if (T > 1) {
+        ra1 = *reinterpret_cast<const f32x4*>(rv - H * 4);
+        rb1 = rc[-H];
+        do1 = dptr[(bt - 1) * H + hid];
+        xq1 = xptr[bt - 1];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dout_c, const float& nb, f32x4& fa,
+                  float& fb, float& dout_f, const float& x_c, float& x_f) {
+    const size_t bt = b * T + t;
+    f32x4 pkeep = f32x4{0.f, 0.f, 0.f, 0.f};                      // the gate waves' values stay in registers for the split
+    // ---- G: gate gradients (lstm.py:26-32 differentiated) ---------------------------------------------------------
+    if (own) {
+      {
+        const size_t b2 = t > 1 ? bt - 2 : b * T;
+        fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+        fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
+        dout_f = dptr[b2 * H + hid];
+        x_f = xptr[b2];
+      }
+      const f32x4 qa = ra;
+      float dht = dout_c * dscale;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
+      const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = rb;
+      const float cprev = t > 0 ? nb : c0v;
+      const float tc = ftanh(cy);
+      const float dct = dcs + dht * og * (1.0f - tc * tc);
+      const float p0 = dct * gg * ig * (1.0f - ig);             // d pre-activation of i
+      const float p1 = dct * cprev * fg * (1.0f - fg);          //                     f
+      const float p2 = dct * ig * (1.0f - gg * gg);             //                     g
+      const float p3 = dht * tc * og * (1.0f - og);             //                     o
+      dcs = dct * fg;
+      const f32x4 pv = f32x4{p0, p1, p2, p3};
+      const float xv = x_c * xscale;
+      float mx = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float a = fabsf(pv[g]);
+        mx = fmaxf(mx, a);
+        cmx[g] = fmaxf(cmx[g], a);
+        sxd[g] = fmaf(xv, pv[g], sxd[g]);
+        sdg[g] += pv[g];
+      }
+      dgf[hid] = p0; dgf[H + hid] = p1; dgf[2 * H + hid] = p2; dgf[3 * H + hid] = p3;
+      pkeep = pv;
+      mx = wave_max(mx);
+      if (lane == 0) smax1[wave] = mx;
+    }
+    TT_STAMP(0)
+    lds_barrier();
+    TT_STAMP(1)
+    // ---- split: the step's scale from the exact maximum; the gate waves split their own four values (still in registers) ----
+    float u2;                                                     // inverse of T2's operand scale, kept for T2's epilogue
+    float t01f;                                                   // un-scale of T01's accumulators times T2's operand scale
+    {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float ug;
+      const float sg = step_scale(mxg, ug);
+      const float s2 = step_scale(mxg * maxl1, u2);              // |dC2| <= maxl1 * mxg: no overflow, whatever the signs
+      t01f = ug * s2;
+      if (own) {
+        // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
+        store_split4_h(img1h, PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), pkeep * sg);
+      } else {                                                    // waves 4-7: the fp32 row goes out to HBM meanwhile
+        const int i4 = tid - H;
+        const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
+        reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
+        if (dg_hid && dg_hid != dg_in) reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
+      }
+    }
+    TT_STAMP(2)
+    lds_barrier();
+    TT_STAMP(3)
+    // ---- T01: dC2 = W10 dg, rescaled for T2 and split into its operand image ------------------------------------------------
+    {
+      xh8 bf[B::NM1][2];
+#pragma unroll
+      for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+      for (int x = 0; x < B::XF; ++x) {
+        f32x4 au[B::NM1];                                        // one chain per k-block: three dependent MFMAs, not six
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+          au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
+        }
+        f32x4 acc = au[0];
+#pragma unroll
+        for (int u = 1; u < B::NM1; ++u) acc += au[u];
+        // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = r20 + j): four consecutive k of T2
+        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+        store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+      }
+    }
+    TT_STAMP(4)
+    lds_barrier();
+    TT_STAMP(5)
+    // ---- T2: dh_{t-1}[row2][j2], pair = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
+#pragma unroll
+    for (int x = 0; x < B::XT2; ++x) {
+      const int ub = (wave + FAST_NW * x) >> 1;
+      const int row = 16 * ct + c;
+      xh8 b2[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+      // the two small terms on one accumulator, the large one on its own: two MFMA latencies on the path instead of three
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][1], b2[0], z4, 0, 0, 0);
+      const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[0], z4, 0, 0, 0);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[1], alo, 0, 0, 0);
+      const f32x4 acc = ahi + alo;
+      // lane (c = row2 in the column tile, q), registers j: j2 = 4q + j (valid for q < 2): hidden = row2*J2 + j2
+      if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc * (un2 * u2);
+    }
+    TT_STAMP(6)
+    lds_barrier();
+    TT_STAMP(7)
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2, xq0, xq2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0, xq1, xq0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1, xq2, xq1);
+  }
+  if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmx[g]));
+    }
+    if (bs.part) {
+      float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pp[g * H + hid] = sxd[g];
+        pp[GH + g * H + hid] = sdg[g];
+      }
+    }
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && diag && b < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) diag[(b * FAST_NW + wave) * 8 + i] = seg[i];
+    }
+  }
+  if (own) {
+    if (d_h0) {
+      float v = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) v += dhs[sl * H + hid];
+      d_h0[b * H + hid] = v;
+    }
+    if (d_c0) d_c0[b * H + hid] = dcs;
+  }
+}
+
+template <class S>
+int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+             const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+             unsigned long long* diag, hipStream_t stream, const BwdStats& bs) {
+  using B = F10BH<S>;
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* wfrag = reinterpret_cast<xh8*>(hdr + B::HDR_FLOATS);
+  hipLaunchKernelGGL((k_f10bh_prep<S>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag);
+  constexpr size_t lds = f10bh_lds_bytes<S>();
+  static_assert(lds <= 150 * 1024, "LDS image set too large");
+  const bool dg = opt(OPT_DIAG) != 0;
+  auto kern = dg ? k_lstm_bwd_f10h<S, true> : k_lstm_bwd_f10h<S, false>;
+  if (lds > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
+                     (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                     (float*)d_c0, dg ? diag : nullptr, bs);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool f10bh_available(const RnnShape& rs, int dtype) {
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_GEMM_PIECES) == 3 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT)
+    return false;
+  return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
+}
+
+size_t f10bh_workspace_bytes(const RnnShape& rs) {
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
+    return F10BH<ShpH256R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R8L>::FRAGS * sizeof(xh8);
+  if (shape_matches<ShpH256R16L>(rs.hid_s))
+    return F10BH<ShpH256R16L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R16L>::FRAGS * sizeof(xh8);
+  return 0;
+}
+
+int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                         const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
+                         void* d_c0, void* ws, unsigned long long* diag, hipStream_t stream, const BwdStats& bs) {
+  if (shape_matches<ShpH256R8L>(rs.hid_s))
+    return launch_t<ShpH256R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream,
+                                bs);
+  if (shape_matches<ShpH256R16L>(rs.hid_s))
+    return launch_t<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream,
+                                 bs);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttrnn

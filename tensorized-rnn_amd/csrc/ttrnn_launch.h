@@ -269,6 +269,14 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
                        const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
                        hipStream_t stream, const void* x_in1 = nullptr, float* stats = nullptr);
 
+// the same on two fp16 pieces per operand (ttrnn_fast_f10bh.hip): the TT-LSTM shapes in split mode (option gemm_pieces = 3:
+// the three-bf16-piece kernel)
+bool f10bh_available(const RnnShape& rs, int dtype);
+size_t f10bh_workspace_bytes(const RnnShape& rs);
+int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                         const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
+                         void* d_c0, void* ws, unsigned long long* diag, hipStream_t stream, const BwdStats& bs);
+
 size_t f10b_fragment_bytes(const TtShape& s);     // the transposed fused-core fragments alone
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream);
 

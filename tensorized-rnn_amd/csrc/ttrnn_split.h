@@ -40,6 +40,7 @@ __device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& 
 // two elements at a time: v_cvt_pk_bf16_f32 rounds both (RNE); three packed dwords out.
 typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   const xbf2 p = __builtin_convertvector(f32x2{a, b}, xbf2);
   return __builtin_bit_cast(unsigned, p);

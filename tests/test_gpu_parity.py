@@ -2021,3 +2021,120 @@ def test_big_shape_dense_gradient_honours_row_shift_when_asked(with_h0):
     torch.cuda.synchronize()
     assert torch.isfinite(got).all()
     assert _maxabs(got, ref) <= 1e-5 * float(ref.abs().max())
+
+
+# ---- (13) fused-core reverse-time kernel on two fp16 pieces (ttrnn_fast_f10bh.hip) ------------------------------------------------
+@pytest.mark.parametrize("rank,inp", [(8, 1), (16, 40)])
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only"])
+def test_fused_core_half_piece_reverse_kernel_ranges(case, rank, inp):
+    """cfg2 / cfg4-class reverse-time kernel in split mode: the weights' rows carry their own power-of-two scales, every
+    step's gate gradients are scaled from their exact maximum and T01's results from a bound (no overflow possible).
+    Output gradients spanning ten decades across steps and samples, steps with no gradient at all, a loss on the last step
+    only (the gradient decays over 60 steps) and plain ones: every parameter / input / initial-state gradient against the
+    float64 oracle's autograd, next to the three-bf16-piece kernel (option gemm_pieces = 3) on the same inputs; the kernel's
+    own results bitwise repeatable and independent of the rest of the batch."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(193 + rank)
+    H = 256
+    meta = dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=rank)
+    m = build_module(meta, dev())
+    B, T = 5, (60 if case == "last_step_only" else 9)
+    x = torch.randn(B, T, inp)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))          # 1e-6 .. 1e4 per (sample, step)
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t.double().clone().requires_grad_(True) for t in (x, h0, c0))
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    ((ro * w.double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+
+    def run(sel=None):
+        m.zero_grad()
+        xs, hs, cs, ws = (t if sel is None else t[sel] for t in (x, h0, c0, w))
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (xs, hs, cs))
+        out, (hT, cT) = m(xg, (h0g, c0g))
+        ((out * ws.to(dev())).sum() + wsum * (cT.sum() + 0.5 * hT.sum())).backward()
+        return {"x": xg.grad.clone(), "h0": h0g.grad.clone(), "c0": c0g.grad.clone(),
+                **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    got = run()
+    again = run()
+    with ttrnn_hip.option("gemm_pieces", 3):
+        three = run()
+    sub = run([2, 0])
+    refs = {"x": xr.grad, "h0": h0r.grad, "c0": c0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"two_fp16": 0.0, "three_bf16": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["two_fp16"] = max(worst["two_fp16"], _maxabs(got[n].double(), ref) / sc)
+        worst["three_bf16"] = max(worst["three_bf16"], _maxabs(three[n].double(), ref) / sc)
+    for n in ("h0", "c0") + (("x",) if inp != 1 else ()):          # the reverse-time kernel's own results
+        assert torch.equal(got[n], again[n]), n
+        assert torch.equal(got[n][[2, 0]], sub[n]), n
+    if case == "sparse_steps":
+        assert float(got["h0"][2].abs().max()) == 0.0
+    if case == "last_step_only":       # sixty steps back the gradient is many decades down, and still what float64 gives
+        rel = _maxabs(got["h0"].double(), h0r.grad) / max(float(h0r.grad.abs().max()), 1e-300)
+        print("d_h0 after 60 steps: max |ref| %.3g, relative error %.3g" % (float(h0r.grad.abs().max()), rel))
+        assert rel <= 1e-4
+    print(case, rank, "max gradient error relative to each tensor's maximum:", worst)
+    assert not torch.equal(got["h0"], three["h0"])                 # a different kernel did run
+    assert worst["two_fp16"] <= 2e-5 and worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
+
+
+@pytest.mark.parametrize("rank", [8, 16])
+@pytest.mark.parametrize("which,factor", [(2, 1e7), (1, 1e5), (0, 1e6)])
+def test_fused_core_half_piece_reverse_kernel_outlier_weights(rank, which, factor):
+    """The two-piece kernel scales every ROW of W10 and of G2 by its own power of two: one huge core entry costs only the rows it
+    touches, and inside such a row the small entries keep an absolute error of 2^-25 of the row's maximum — the error bound of an
+    fp32 dot product with that row, so no guard is needed (ttrnn_fast_f10bh.hip).  One entry of each hidden core in turn x 1e5
+    ... 1e7: every gradient as close to the float64 oracle as the three-bf16-piece kernel's."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(195)
+    H = 256
+    meta = dict(kind="ttlstm", input_size=1, hidden_size=H, num_layers=1, n_cores=3, tt_rank=rank)
+    m = build_module(meta, dev())
+    B, T = 3, 6
+    x = torch.randn(B, T, 1)
+    w = torch.randn(B, T, H)
+
+    def grads(opts):
+        m.zero_grad()
+        with contextlib.ExitStack() as stack:
+            for k, v in opts.items():
+                stack.enter_context(ttrnn_hip.option(k, v))
+            out, (hT, cT) = m(x.to(dev()))
+            ((out * w.to(dev())).sum() + cT.sum()).backward()
+        return {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters()}
+
+    with torch.no_grad():
+        core = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n][which]
+        flat = core.detach().clone().contiguous().view(-1)
+        flat[(5 * flat.numel()) // 11] *= factor
+        core.copy_(flat.view(core.shape))
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    ro, (rh, rc) = O.lstm_forward(layers, x.double(), None)
+    ((ro * w.double()).sum() + rc.sum()).backward()
+    got = grads({})
+    three = grads({"gemm_pieces": 3})
+    worst = {"two_fp16": 0.0, "three_bf16": 0.0}
+    for n, _ in m.named_parameters():
+        ref = leaves[n].grad
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["two_fp16"] = max(worst["two_fp16"], _maxabs(got[n], ref) / sc)
+        worst["three_bf16"] = max(worst["three_bf16"], _maxabs(three[n], ref) / sc)
+    print("core", which, "x", factor, "rank", rank, "max gradient error relative to each tensor's maximum:", worst)
+    assert worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
