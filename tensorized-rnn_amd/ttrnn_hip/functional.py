@@ -476,8 +476,9 @@ class _TTRnnLayerFn(torch.autograd.Function):
         hints_in = hints_hid = None
         want_db_in = has_bin and need[3]
         if mask & _lib.BWD_STATS_COLMAX:
-            # rows that are hidden states are bounded by 1 (LSTM: o * tanh(c); GRU: convex combinations, from |h_0| <= 1 on)
-            state_bound = _ones(dev, H) if (spec.cell == "lstm" or h0 is None) else None
+            # rows that are hidden states: |h_t| <= 1 for t >= 1 (LSTM: o * tanh(c); GRU: convex combinations of tanh values
+            # and h_{t-1}, so max(1, |h_0|) per unit) — and the caller's h_0 is row 0 of every sample
+            state_bound = _ones(dev, H) if h0 is None else torch.maximum(h0.float().abs().amax(0), _ones(dev, H))
             hints_in = {"dy_colmax": bstats[0], "x_colmax": _ones(dev, spec.input_size) if ctx.x_bounded else None}
             hints_hid = {"dy_colmax": bstats[1], "x_colmax": state_bound}
             if in1 and not need[0]:
