@@ -36,12 +36,21 @@ __global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, i
 
 template <int CHAINS, int SHAPE>
 void run(const char* name, int threads, unsigned long long* d, float* sink) {
-  const int iters = 2000;
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<CHAINS, SHAPE>), dim3(256), dim3(threads), 0, 0, d, sink, 100);      // warm-up
+  hipEventRecord(e0, 0);
   hipLaunchKernelGGL((k<CHAINS, SHAPE>), dim3(256), dim3(threads), 0, 0, d, sink, iters);
+  hipEventRecord(e1, 0);
   hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[8];
   hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  printf("%-44s %d waves/SIMD: %.1f cycles per MFMA per wave\n", name, threads / 256, (double)h[0] / (iters * 8.0));
+  const double flops = 256.0 * (threads / 64) * iters * 8.0 * 16384.0 * (SHAPE == 16 ? 1 : 2);
+  printf("%-40s %d waves/SIMD: %.1f ticks per MFMA per wave, %.3f ms, %.0f TFLOP/s, %.2f GHz ticks\n", name, threads / 256,
+         (double)h[0] / (iters * 8.0), ms, flops / ms * 1e-9, (double)h[0] / ms * 1e-6);
 }
 
 int main() {
