@@ -547,10 +547,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        payload = json.dumps(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing on stdout: RCCL writes its version banner through C stdio, which — on a pipe —
+        # would otherwise come out at process exit, behind the line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
+        print(payload, flush=True)
 
 
 if __name__ == "__main__":
