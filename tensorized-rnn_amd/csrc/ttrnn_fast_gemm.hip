@@ -525,21 +525,47 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float col_scale(unsigned bits) { return ldexpf(1.f, 14 - g_expo(__uint_as_float(bits))); }
 __device__ __forceinline__ float col_unscale(unsigned bits) { return ldexpf(1.f, g_expo(__uint_as_float(bits)) - 14); }
 
-// colmax[c] = max over rows [r0, r1) of |a[n][c]| (bit pattern); one thread per four columns, 128 rows per workgroup
+// colmax[c] = max over the rows of |a[n][c]| (bit pattern).  A thread per four columns and row group; narrow matrices
+// (C / 4 < 256 column quads) spread their rows over the otherwise idle threads, take up to eight times the rows per workgroup
+// and reduce the row groups in LDS before ONE atomic per column and workgroup: at one thread per quad the 40-column input of
+// cfg4's first layer kept 10 of 256 threads busy and sent 26 k atomics to 40 addresses (83 us for 13 MB).
+__host__ __device__ inline int colmax_groups(int C) { return 256 / (C / 4 < 256 ? C / 4 : 256); }
+__host__ __device__ inline int colmax_rows(int C) { const int g = colmax_groups(C); return 128 * (g < 8 ? g : 8); }
 template <typename TS>
 __global__ void __launch_bounds__(256) k_col_absmax(const TS* __restrict__ a, int64_t n_rows, int C,
                                                     unsigned* __restrict__ colmax) {
-  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c4 >= C) return;
-  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = r0 + 128 < n_rows ? r0 + 128 : n_rows;
+  __shared__ f32x4 red[256];
+  const int nq = C / 4 < 256 ? C / 4 : 256;                  // column quads of this workgroup's x-slice
+  const int ng = 256 / nq;                                   // row groups
+  const int cq = threadIdx.x % nq, rg = threadIdx.x / nq;
+  const int c4 = (blockIdx.x * 256 + cq) * 4;
+  const bool live = c4 < C && rg < ng;
+  const int RB = colmax_rows(C);
+  const int64_t r0 = (int64_t)blockIdx.y * RB, r1 = r0 + RB < n_rows ? r0 + RB : n_rows;
   f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int64_t n = r0; n < r1; ++n) {
-    const f32x4 v = ld4(a, (size_t)n * C + c4);
+  if (live)
+    for (int64_t n = r0 + rg; n < r1; n += ng) {
+      const f32x4 v = ld4(a, (size_t)n * C + c4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(v[i]));
+      for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(v[i]));
+    }
+  if (ng == 1) {
+    if (live)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicMax(colmax + c4 + i, __float_as_uint(m[i]));
+    return;
   }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  if (live && rg == 0) {
+    for (int g = 1; g < ng; ++g) {
+      const f32x4 o = red[g * nq + cq];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) atomicMax(colmax + c4 + i, __float_as_uint(m[i]));
+      for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], o[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicMax(colmax + c4 + i, __float_as_uint(m[i]));
+  }
 }
 
 // byte offset of 16-byte chunk ch (0..15) of row `row` in a [rows][128 x 16-bit] plane
@@ -942,7 +968,8 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   const unsigned* cx = colmax;
   const unsigned* cd = colmax ? colmax + in : nullptr;
   if (half) {
-    const unsigned gy = (unsigned)((n_rows + 127) / 128);
+    const unsigned gy = (unsigned)((n_rows + colmax_rows(in) - 1) / colmax_rows(in));
+    const unsigned gyo = (unsigned)((n_rows + colmax_rows(out) - 1) / colmax_rows(out));
     if (x_colmax) {
       cx = x_colmax;
     } else {
@@ -955,7 +982,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
                            in, colmax);
       if (rsh.T > 0 && rsh.first) {      // shifted rows: the maxima over `out` bound rows 1.., the initial states are rows 0
         const int64_t nb = n_rows / rsh.T;
-        const unsigned gb = (unsigned)((nb + 127) / 128);
+        const unsigned gb = (unsigned)((nb + colmax_rows(in) - 1) / colmax_rows(in));
         if (dtype == TTRNN_F32)
           hipLaunchKernelGGL(k_col_absmax<float>, dim3((in / 4 + 255) / 256, gb), dim3(256), 0, stream, (const float*)rsh.first,
                              nb, in, colmax);
@@ -968,7 +995,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
       cd = dy_colmax;
     } else {
       if (hipMemsetAsync(colmax + in, 0, (size_t)out * sizeof(unsigned), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-      hipLaunchKernelGGL(k_col_absmax<float>, dim3((out / 4 + 255) / 256, gy), dim3(256), 0, stream, dy, n_rows, out,
+      hipLaunchKernelGGL(k_col_absmax<float>, dim3((out / 4 + 255) / 256, gyo), dim3(256), 0, stream, dy, n_rows, out,
                          colmax + in);
     }
   }
