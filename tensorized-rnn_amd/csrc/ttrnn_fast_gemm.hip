@@ -1004,7 +1004,10 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
                           : ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   int KS = 1;
   if (tiles < cus) {
-    KS = ((cus / tiles + 7) / 8) * 8;                               // multiple of 8: one row range per XCD at a time
+    // multiple of 8: one row range per XCD at a time — rounded DOWN where rounding up would not fit the chip in one go
+    // (cfg3: 6 tiles x 48 ranges = 288 workgroups on 256 CUs ran as two rounds, 658 us; 40 ranges: one round)
+    const int up = ((cus / tiles + 7) / 8) * 8, dn = (cus / tiles) / 8 * 8;
+    KS = (tiles * up <= cus || dn < 8) ? up : dn;
     const int64_t max_ks = (n_rows + KBc - 1) / KBc;                // at least one chunk per split
     if (KS > max_ks) KS = max_ks < 1 ? 1 : (int)max_ks;
   }
