@@ -585,12 +585,12 @@ __device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
   return __builtin_bit_cast(xbf8, v);
 }
 
-template <typename TS, bool HALF, bool SHIFT>
+template <typename TS, bool HALF, bool SHIFT, bool ABL = false>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
                                                                const unsigned* __restrict__ colmax_x,
-                                                               const unsigned* __restrict__ colmax_dy, RowShift rsh) {
+                                                               const unsigned* __restrict__ colmax_dy, RowShift rsh, int dev) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
   constexpr int NP = HALF ? 2 : 3, BUFE = HALF ? DenseS::BUF_H : DenseS::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -675,7 +675,11 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
       sh_t[e] = sh_n[e] - sh_b[e] * (unsigned)rsh.T;
     }
   }
+  // (ABL: the harness instantiation, tools/wgrad_bench — option `dev` 8 = no MFMAs, 16 = no split / LDS stores, 32 = no loads,
+  // 64 = no fragment reads; the product instantiation has none of these branches)
+  const int dv = ABL ? dev : 0;
   auto stage_load = [&](int64_t nb) {
+    if constexpr (ABL) { if (dv & 32) return; }
     if constexpr (SHIFT) {
       const TS* fp = reinterpret_cast<const TS*>(rsh.first);
 #pragma unroll
@@ -724,6 +728,16 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
     }
   };
   auto stage_store = [&](int buf, int64_t nb) {
+    if (ABL && (dv & 16)) {
+      // keep the loaded registers alive (a dependence on every one of them), skip the split and the LDS stores
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) t += sx[e][0] + sx[e][3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t += sd[e][0] + sd[e][3];
+      dbs[0][0] += t;
+      return;
+    }
     __bf16* xs = ldsb + buf * BUFE;                        // [NP][32][128]
     __bf16* ds0 = xs + NP * PL;                            // columns 0..127:   [NP][32][128]
     __bf16* ds1 = ds0 + NP * PL;                           // columns 128..255: [NP][32][128]
@@ -756,16 +770,17 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) af[mi][p] = tr_frag(xs + p * PL, wm * 4 + mi, lane);
+      for (int p = 0; p < NP; ++p) af[mi][p] = (ABL && (dv & 64)) ? xbf8{} : tr_frag(xs + p * PL, wm * 4 + mi, lane);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       xbf8 bf[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bf[p] = tr_frag(dsw + p * PL, (wn & 1) * 4 + ni, lane);
+      for (int p = 0; p < NP; ++p) bf[p] = (ABL && (dv & 64)) ? xbf8{} : tr_frag(dsw + p * PL, (wn & 1) * 4 + ni, lane);
       if (ni == 1) {                                        // the next chunk's split + stores ride inside the MFMA stream
         stage_store(buf ^ 1, r0 + (ch + 1) * KB);           // (past the end: a fully masked chunk into the idle buffer)
         stage_load(r0 + (ch + 2 < chunks ? ch + 2 : ch + 1 < chunks ? ch + 1 : ch) * KB);
       }
+      if constexpr (ABL) { if (dv & 8) continue; }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         if constexpr (HALF) {
@@ -1026,9 +1041,15 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<TSV, HV, SV>), lds) != TTRNN_OK)                  \
       return TTRNN_ERR_LAUNCH;                                                                                                \
     hipLaunchKernelGGL((k_dense_wgrad_split<TSV, HV, SV>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,       \
-                       rows_per, (const TSV*)x, dy, dW, d_bias, part, cx, cd, rsh);                                           \
+                       rows_per, (const TSV*)x, dy, dW, d_bias, part, cx, cd, rsh, 0);                                        \
   } while (0)
 #define TT_WG2(TSV, HV) do { if (rsh.T > 0) TT_WG(TSV, HV, true); else TT_WG(TSV, HV, false); } while (0)
+  if (di == 4 && rsh.T == 0 && (opt(OPT_DEV) & (8 | 16 | 32 | 64))) {      // tools/wgrad_bench: the ablation instantiation
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<float, true, false, true>), lds) != TTRNN_OK)
+      return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((k_dense_wgrad_split<float, true, false, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out,
+                       KS, rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd, rsh, opt(OPT_DEV));
+  } else
   switch (di) {
     case 0:
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<float>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
