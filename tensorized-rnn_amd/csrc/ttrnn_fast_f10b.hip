@@ -662,7 +662,7 @@ size_t bwd_stats_part_bytes(const RnnShape& rs) {
 size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // [fragments, stamps | sums | two-piece kernel's]
   const size_t head = f10b_ws_head_bytes(rs, dtype);
   if (!head) return 0;
-  const size_t half = rs.cell == TTRNN_LSTM && dtype == TTRNN_F32 ? f10bh_workspace_bytes(rs) : 0;
+  const size_t half = f10bh_workspace_bytes(rs);
   return ((head + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs) + half;
 }
 
@@ -713,12 +713,14 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
     }
   }
   void* ws_half = nullptr;
-  if (rs.cell == TTRNN_LSTM && f10bh_available(rs, dtype))
+  if (f10bh_available(rs, dtype))
     ws_half = (char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs);
   int st = TTRNN_ERR_UNSUPPORTED;
   if (rs.cell == TTRNN_GRU) {
     if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
-    if (dtype == TTRNN_F32)
+    if (ws_half)      // two fp16 pieces (ttrnn_fast_f10bh.hip); option gemm_pieces = 3 keeps this file's kernel
+      st = launch_gru_bwd_f10h(rs, dtype, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws_half, stream, bs);
+    else if (dtype == TTRNN_F32)
       st = launch_gru_bwd_f10<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws,
                                                  stream, bs);
     else

@@ -107,7 +107,7 @@ __device__ __forceinline__ void split8h(const f32x4& va, const f32x4& vb, xh8& h
 // Fragments + row scales + the scaled rows' L1 norms.  Block ft < FT: rows 16 ft + r of W10 (wave u = k-block u); block FT: the rows of G2.
 // Fragment order: T01 wf[((ft*NM1 + u)*2 + p)*64 + lane], lane (r, q): k = 32u + 8q + e (gate-interleaved: m_of_k1);
 //                 T2  wf[T01 part + (u*2 + p)*64 + lane], lane (r, q): row j2 = r (< J2, else 0), k2 slot 4u + q
-template <class S>
+template <class S, bool NATK = false>
 __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict__ packed, float* __restrict__ hdr,
                                                         xh8* __restrict__ wfrag) {
   using F = F10<S>;
@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict_
       const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int m = B::m_of_k1(32 * wave + 8 * q + e);
+        // LSTM: gate-interleaved k order (m_of_k1); GRU: natural order (its gate index does not align with the tiles)
+        const int m = NATK ? 32 * wave + 8 * q + e : B::m_of_k1(32 * wave + 8 * q + e);
         const int i0 = m / F::I1, i1 = m % F::I1;
         const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
         float a = 0.f;
@@ -450,6 +451,265 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
   }
 }
 
+// ---- GRU -----------------------------------------------------------------------------------------------------------
+// The same scheme for the TT-GRU (fp32 or bf16 storage; reserve, gate gradients and all arithmetic fp32; gru.py:38-44
+// differentiated as in k_gru_bwd_f10): three gates, I2 = 12 columns (padded to a tile), natural k order of T01's operand —
+// a unit's gates are single elements of the image (six 2-byte stores per thread), d_gates_in differs from d_gates_hid in the
+// n block (written by the gate threads directly), the direct path dh_{t-1} += dh_t z stays in the thread's register.
+template <class S>
+constexpr bool f10bh_gru_ok() {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::H == 256 &&
+         out_size_of<S>() == 3 * F::H && F::I2 % 2 == 0 && F::I2 <= 16 && B::K1 == 64 && B::FT % FAST_NW == 0 &&
+         B::K2 % 32 == 0 && B::CT2 == 2 && F::J2 == 8 && S::R[2] % 4 == 0 && B::NM2 * B::CT2 <= FAST_NW;
+}
+
+template <class S>
+constexpr size_t f10bh_gru_lds_bytes() {
+  using B = F10BH<S>;
+  using F = F10<S>;
+  return sizeof(float) * ((size_t)3 * B::H + (size_t)B::NM2 * B::H) +
+         sizeof(_Float16) * 2 * ((size_t)16 * B::K1 + (size_t)F::ROWS2 * B::K2);
+}
+
+template <class S, typename TS>
+__global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const TS* __restrict__ out,
+                                                          const TS* __restrict__ h0, const float* __restrict__ hdr,
+                                                          const xh8* __restrict__ wfrag, const float* __restrict__ reserve,
+                                                          const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
+                                                          float* __restrict__ dg_in, float* __restrict__ dg_hid,
+                                                          TS* __restrict__ d_h0, BwdStats bs) {
+  static_assert(f10bh_gru_ok<S>(), "shape not supported by the two-piece fused-core GRU reverse-time kernel");
+  using F = F10<S>;
+  using B = F10BH<S>;
+  constexpr int H = F::H, GH = 3 * H;
+  constexpr int NP = B::NM2 * B::CT2;                                         // T2 (column tile, k-block) pairs: one per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) float smax1[4];
+  __shared__ float sl1[FAST_NW];
+  constexpr int PL1 = 16 * B::K1, PL2 = F::ROWS2 * B::K2;
+  static_assert(GH / 4 <= FAST_NT - H, "waves 4-7 store the fp32 rows");
+  float* dgf = reinterpret_cast<float*>(smem);                               // [3H]: dr, dz, dn*r (hidden chain)
+  float* dhs = dgf + GH;                                                     // [NM2][H]
+  _Float16* img1h = reinterpret_cast<_Float16*>(dhs + B::NM2 * H);           // [2][16][K1], natural k
+  _Float16* img2h = img1h + 2 * PL1;                                         // [2][ROWS2][K2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  xh8 w01[B::XF][B::NM1][2], w2t[2];
+  f32x4 un1[B::XF], un2;
+#pragma unroll
+  for (int x = 0; x < B::XF; ++x) {
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
+    un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+  }
+  const int pid = wave < NP ? wave : 0, ub = pid >> 1, ct = pid & 1;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w2t[p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ub * 2 + p) * 64 + lane];
+  un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * q);
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int f = tid; f < F::K; f += FAST_NT) l = fmaxf(l, hdr[B::L1N + f] * hdr[B::UN1 + f]);
+    l = wave_max(l);
+    if (lane == 0) sl1[wave] = l;
+    __syncthreads();
+    maxl1 = sl1[0];
+#pragma unroll
+    for (int w = 1; w < FAST_NW; ++w) maxl1 = fmaxf(maxl1, sl1[w]);
+  }
+  // columns 12..15 of T01's operand are never written by the gate threads: zeros, once (their results are never stored)
+  for (int e = tid; e < 2 * PL1; e += FAST_NT) img1h[e] = (_Float16)0.f;
+
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float dhd = 0.f;
+  const TS* dptr = d_out ? d_out : out;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  TS do0 = TS{}, do1 = TS{}, do2 = TS{}, hp0 = TS{}, hp1 = TS{}, hp2 = TS{};
+  const TS* xptr = bs.x ? reinterpret_cast<const TS*>(bs.x) : out;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  TS xq0 = TS{}, xq1 = TS{}, xq2 = TS{};
+  float cmi[3] = {0.f, 0.f, 0.f}, sxd[3] = {0.f, 0.f, 0.f}, sdg[3] = {0.f, 0.f, 0.f}, cmh = 0.f;
+  auto issue = [&](int t, f32x4& ra, TS& dq, TS& hq, TS& xq) {       // loads of set(t); clamped, unconditional
+    const size_t bt = b * T + (t > 0 ? t : 0);
+    ra = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
+    dq = dptr[bt * H + hid];
+    const TS* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);
+    hq = hp[hid];
+    xq = xptr[bt];
+  };
+  if (own) {
+    dhs[hid] = d_hT ? ld(d_hT, b * H + hid) : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
+    if (T > 0) {
+      issue(T - 1, ra0, do0, hp0, xq0);
+      issue(T - 2, ra1, do1, hp1, xq1);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  lds_barrier();
+
+  auto step = [&](const int t, const f32x4& ra, const TS& dq, const TS& hq, const TS& xq, f32x4& fa, TS& fd, TS& fh,
+                  TS& fx) {
+    const size_t bt = b * T + t;
+    float pk[3] = {0.f, 0.f, 0.f};
+    // ---- G: gate gradients (gru.py:38-44 differentiated) -----------------------------------------------------------
+    if (own) {
+      issue(t - 2, fa, fd, fh, fx);
+      float dht = dhd + to_f32(dq) * dscale;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
+      const float rg = ra[0], zg = ra[1], ng = ra[2], hn = ra[3];
+      const float hprev = (t > 0 || h0) ? to_f32(hq) : 0.f;
+      const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
+      const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
+      const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+      dhd = dht * zg;
+      pk[0] = dr_pre; pk[1] = dz_pre; pk[2] = dn_pre * rg;
+      const float pin[3] = {dr_pre, dz_pre, dn_pre};
+      const float xv = to_f32(xq) * xscale;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        cmi[g] = fmaxf(cmi[g], fabsf(pin[g]));
+        sxd[g] = fmaf(xv, pin[g], sxd[g]);
+        sdg[g] += pin[g];
+        dgf[g * H + hid] = pk[g];
+      }
+      cmh = fmaxf(cmh, fabsf(pk[2]));
+      dg_in[bt * GH + 2 * H + hid] = dn_pre;                // the only block where d_gates_in != d_gates_hid
+      const float mx = wave_max(fmaxf(fmaxf(fabsf(pk[0]), fabsf(pk[1])), fabsf(pk[2])));
+      if (lane == 0) smax1[wave] = mx;
+    }
+    lds_barrier();
+    // ---- split: the step's scale; the gate waves split their own three values; waves 4-7 send the fp32 rows to HBM ------
+    float u2, t01f;
+    {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float ug;
+      const float sg = step_scale(mxg, ug);
+      const float s2 = step_scale(mxg * maxl1, u2);
+      t01f = ug * s2;
+      if (own) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const int o = g * H + hid, m = o / F::I2, i2 = o % F::I2;     // flat gate index -> (m, i2), natural k = m
+          _Float16 p0, p1;
+          split2h(pk[g] * sg, p0, p1);
+          const int off = x_off<B::K1>(i2, m);
+          img1h[off] = p0;
+          img1h[PL1 + off] = p1;
+        }
+      } else {
+        const int i4 = tid - H;
+        if (i4 < GH / 4) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
+          reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
+          if (i4 < 2 * H / 4) reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
+        }
+      }
+    }
+    lds_barrier();
+    // ---- T01 ---------------------------------------------------------------------------------------------------------
+    {
+      const int rowc = c < F::I2 ? c : F::I2;                // (rows I2..15 of the image are zeros)
+      xh8 bf[B::NM1][2];
+#pragma unroll
+      for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(rowc, 32 * u + 8 * q));
+#pragma unroll
+      for (int x = 0; x < B::XF; ++x) {
+        f32x4 au[B::NM1];
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+          au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
+        }
+        f32x4 acc = au[0];
+#pragma unroll
+        for (int u = 1; u < B::NM1; ++u) acc += au[u];
+        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+        if (c < F::I2) store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+      }
+    }
+    lds_barrier();
+    // ---- T2: pair (column tile ct, k-block ub) = wave (< NP) ---------------------------------------------------------------
+    if (wave < NP) {
+      const int row = 16 * ct + c;
+      xh8 b2[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[1], b2[0], z4, 0, 0, 0);
+      const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[0], b2[0], z4, 0, 0, 0);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[0], b2[1], alo, 0, 0, 0);
+      const f32x4 acc = ahi + alo;
+      if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc * (un2 * u2);
+    }
+    lds_barrier();
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, do0, hp0, xq0, ra2, do2, hp2, xq2);
+    if (t >= 1) step(t - 1, ra1, do1, hp1, xq1, ra0, do0, hp0, xq0);
+    if (t >= 2) step(t - 2, ra2, do2, hp2, xq2, ra1, do1, hp1, xq1);
+  }
+  if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmi[g]));
+        atomicMax(bs.colmax + GH + g * H + hid, __float_as_uint(g < 2 ? cmi[g] : cmh));
+      }
+    }
+    if (bs.part) {
+      float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        pp[g * H + hid] = sxd[g];
+        pp[GH + g * H + hid] = sdg[g];
+      }
+    }
+  }
+  if (own && d_h0) {
+    float v = dhd;
+#pragma unroll
+    for (int sl = 0; sl < B::NM2; ++sl) v += dhs[sl * H + hid];
+    st(d_h0, b * H + hid, v);
+  }
+}
+
+template <class S, typename TS>
+int launch_gru_t(const RnnShape& rs, const void* out, const void* h0, const float* packed_hid, const float* reserve,
+                 const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0, void* ws,
+                 hipStream_t stream, const BwdStats& bs) {
+  using B = F10BH<S>;
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* wfrag = reinterpret_cast<xh8*>(hdr + B::HDR_FLOATS);
+  hipLaunchKernelGGL((k_f10bh_prep<S, true>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag);
+  constexpr size_t lds = f10bh_gru_lds_bytes<S>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  hipLaunchKernelGGL((k_gru_bwd_f10h<S, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)out,
+                     (const TS*)h0, hdr, wfrag, reserve, (const TS*)d_out, (const TS*)d_hT, dg_in, dg_hid, (TS*)d_h0, bs);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 template <class S>
 int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
              const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
@@ -472,12 +732,17 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
 }  // namespace
 
 bool f10bh_available(const RnnShape& rs, int dtype) {
-  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_GEMM_PIECES) == 3 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT)
-    return false;
+  if (opt(OPT_GEMM_PIECES) == 3) return false;
+  if (rs.cell == TTRNN_GRU)      // (bf16 storage: in every math mode, as the three-piece kernel; fp32 storage: split mode)
+    return (dtype == TTRNN_BF16 || (dtype == TTRNN_F32 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT)) &&
+           shape_matches<ShpH256R8G>(rs.hid_s);
+  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
 
 size_t f10bh_workspace_bytes(const RnnShape& rs) {
+  if (shape_matches<ShpH256R8G>(rs.hid_s))
+    return F10BH<ShpH256R8G>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R8G>::FRAGS * sizeof(xh8);
   if (shape_matches<ShpH256R8L>(rs.hid_s))
     return F10BH<ShpH256R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R8L>::FRAGS * sizeof(xh8);
   if (shape_matches<ShpH256R16L>(rs.hid_s))
@@ -495,6 +760,15 @@ int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed
     return launch_t<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream,
                                  bs);
   return TTRNN_ERR_UNSUPPORTED;
+}
+
+int launch_gru_bwd_f10h(const RnnShape& rs, int dtype, const void* out, const void* h0, const float* packed_hid,
+                        const float* reserve, const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0,
+                        void* ws, hipStream_t stream, const BwdStats& bs) {
+  if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
+  if (dtype == TTRNN_F32)
+    return launch_gru_t<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);
+  return launch_gru_t<ShpH256R8G, bf16_t>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);
 }
 
 }  // namespace ttrnn

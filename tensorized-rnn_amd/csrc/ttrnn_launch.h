@@ -277,6 +277,10 @@ int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed
                          const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
                          void* d_c0, void* ws, unsigned long long* diag, hipStream_t stream, const BwdStats& bs);
 
+int launch_gru_bwd_f10h(const RnnShape& rs, int dtype, const void* out, const void* h0, const float* packed_hid,
+                        const float* reserve, const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0,
+                        void* ws, hipStream_t stream, const BwdStats& bs);
+
 size_t f10b_fragment_bytes(const TtShape& s);     // the transposed fused-core fragments alone
 int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream);
 

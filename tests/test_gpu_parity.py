@@ -2140,3 +2140,65 @@ def test_fused_core_half_piece_reverse_kernel_outlier_weights(rank, which, facto
         worst["three_bf16"] = max(worst["three_bf16"], _maxabs(three[n], ref) / sc)
     print("core", which, "x", factor, "rank", rank, "max gradient error relative to each tensor's maximum:", worst)
     assert worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only"])
+def test_fused_core_half_piece_gru_reverse_kernel_ranges(case, dtype):
+    """cfg3-class reverse-time kernel (TT-GRU, fp32 and bf16 storage) on two fp16 pieces (k_gru_bwd_f10h): same scheme and the
+    same cases as the LSTM kernel's test above, next to the three-bf16-piece kernel (option gemm_pieces = 3); h_0 given, so the
+    direct path dh_{t-1} += dh_t z and d_h0 are exercised."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(293)
+    H = 256
+    meta = dict(kind="ttgru", input_size=1, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev())
+    B, T = 5, (60 if case == "last_step_only" else 9)
+    x = torch.randn(B, T, 1)
+    h0 = torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    if dtype == "bf16":
+        m = m.to(torch.bfloat16)
+        x, h0 = x.to(torch.bfloat16), h0.to(torch.bfloat16)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r = (t.double().clone().requires_grad_(True) for t in (x, h0))
+    ro, rh = O.gru_forward(layers, xr, h0r)
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    ((ro * w.double()).sum() + wsum * 0.5 * rh.sum()).backward()
+
+    def run(sel=None):
+        m.zero_grad()
+        xs, hs, ws = (t if sel is None else t[sel] for t in (x, h0, w))
+        xg, h0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (xs, hs))
+        out, hT = m(xg, h0g)
+        ((out.float() * ws.to(dev())).sum() + wsum * 0.5 * hT.float().sum()).backward()
+        return {"h0": h0g.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    got = run()
+    again = run()
+    with ttrnn_hip.option("gemm_pieces", 3):
+        three = run()
+    sub = run([2, 0])
+    refs = {"h0": h0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"two_fp16": 0.0, "three_bf16": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n].float()).all(), n
+        worst["two_fp16"] = max(worst["two_fp16"], _maxabs(got[n].double(), ref) / sc)
+        worst["three_bf16"] = max(worst["three_bf16"], _maxabs(three[n].double(), ref) / sc)
+    assert torch.equal(got["h0"], again["h0"])                    # the reverse-time kernel's own result: repeatable,
+    assert torch.equal(got["h0"][[2, 0]], sub["h0"])              # independent of the rest of the batch
+    if case == "sparse_steps":
+        assert float(got["h0"][2].float().abs().max()) == 0.0
+    print(case, dtype, "max gradient error relative to each tensor's maximum:", worst)
+    tol = 5e-2 if dtype == "bf16" else 2e-5
+    assert worst["two_fp16"] <= tol and worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
