@@ -358,7 +358,7 @@ TT_HD int stash_floats(const TtShape& s) {
 template <class Ex, typename T, typename TDY, class Add>
 TT_HD void ttlinear_bwd_tile(Ex& ex, const TtShape& s, const float* W, const float* Wt, const T* x, const TDY* dy, T* dx,
                              float* dWacc, float* dbacc, int64_t n0, int nb,
-                             float* stash, int ss, float* bufA, float* bufB, int bs, Add add) {
+                             float* stash, int ss, float* bufA, float* bufB, int bs, Add add, bool stash_far = false) {
   const int in = s.in_size, out = s.out_size;
   // recompute the forward chain, keeping every stage input A_k in the stash
   int soff[TTRNN_MAX_D];
@@ -374,12 +374,38 @@ TT_HD void ttlinear_bwd_tile(Ex& ex, const TtShape& s, const float* W, const flo
         a0[(size_t)sidx * ss + j] = ld(x, (size_t)(n0 + sidx) * in + j);
       }
     });
-    for (int k = s.d - 1; k >= 1; --k) {
-      const float* Wk = W + s.woff[k];
-      const int rows = s.rows[k], K = s.K[k], I = s.I[k], R = s.R[k];
-      const float* a = stash + soff[k];
-      float* c = stash + soff[k - 1];
-      ex.par([&](int tid, int nthr) { stage_fwd(tid, nthr, a, ss, c, ss, Wk, nb, rows, K, I, R); });
+    if (!stash_far) {
+      for (int k = s.d - 1; k >= 1; --k) {
+        const float* Wk = W + s.woff[k];
+        const int rows = s.rows[k], K = s.K[k], I = s.I[k], R = s.R[k];
+        const float* a = stash + soff[k];
+        float* c = stash + soff[k - 1];
+        ex.par([&](int tid, int nthr) { stage_fwd(tid, nthr, a, ss, c, ss, Wk, nb, rows, K, I, R); });
+      }
+    } else {
+      // the stash lives in the global workspace, bufA / bufB on chip (LinPlan::buf_mixed): run the chain through the two
+      // on-chip buffers — every output is a K-long dot product over its stage input — and copy each stage input out
+      float* cur = bufA; float* nxt = bufB;
+      ex.par([&](int tid, int nthr) {
+        for (int e = tid; e < nb * in; e += nthr) {
+          const int sidx = e / in, j = e - sidx * in;
+          cur[(size_t)sidx * bs + j] = a0[(size_t)sidx * ss + j];
+        }
+      });
+      for (int k = s.d - 1; k >= 1; --k) {
+        const float* Wk = W + s.woff[k];
+        const int rows = s.rows[k], K = s.K[k], I = s.I[k], R = s.R[k];
+        ex.par([&](int tid, int nthr) { stage_fwd(tid, nthr, cur, bs, nxt, bs, Wk, nb, rows, K, I, R); });
+        float* c = stash + soff[k - 1];
+        const int cnt = s.rows[k - 1] * s.K[k - 1];
+        ex.par([&](int tid, int nthr) {
+          for (int e = tid; e < nb * cnt; e += nthr) {
+            const int sidx = e / cnt, j = e - sidx * cnt;
+            c[(size_t)sidx * ss + j] = nxt[(size_t)sidx * bs + j];
+          }
+        });
+        float* t = cur; cur = nxt; nxt = t;
+      }
     }
   }
   // d y -> bufA ; bias grad

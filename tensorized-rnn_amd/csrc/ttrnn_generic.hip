@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_fwd(TtShape s, int64_t n_ro
 template <typename T, typename TDY, bool BUF_GLOBAL, int ACC>
 __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_rows, int nb, int bs, int ss,
                                                          const float* packed, const T* x, const TDY* dy, T* dx,
-                                                         float* d_packed, float* d_bias, float* ws, float* slabs) {
+                                                         float* d_packed, float* d_bias, float* ws, float* slabs, int mixed) {
   constexpr bool ACC_LDS = ACC == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DevExec ex;
@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_ro
   if (BUF_GLOBAL) {
     float* base = ws + (size_t)blockIdx.x * ((size_t)2 * nb * bs + (size_t)nb * ss);
     bufA = base; bufB = bufA + (size_t)nb * bs; stash = bufB + (size_t)nb * bs;
+    if (mixed) {      // LinPlan::buf_mixed: the two ping-pong buffers fit LDS, only the stash of stage inputs stays in the workspace
+      bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs;
+    }
   } else {
     bufA = p; p += (size_t)nb * bs; bufB = p; p += (size_t)nb * bs; stash = p; p += (size_t)nb * ss;
   }
@@ -232,9 +235,11 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_ro
     const int64_t n0 = tile * nb;
     const int n = (int)tmin<int64_t>(nb, n_rows - n0);
     if (ACC_LDS || ACC == 2)
-      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddPlain());
+      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddPlain(),
+                                         BUF_GLOBAL && mixed);
     else
-      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddAtomic());
+      ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddAtomic(),
+                                         BUF_GLOBAL && mixed);
   }
   if (ACC_LDS) {
     __syncthreads();
@@ -414,7 +419,10 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
   const size_t per = ((size_t)2 * p.bs + p.ss) * 4;
   const size_t acc = ((size_t)s.wtotal + s.out_size) * 4;
   p.buf_global = per > LDS_LIMIT;
-  size_t lds = p.buf_global ? 0 : per;
+  // a sample too large for LDS as a whole (a classifier head 1024 -> 256 with rank 32: 266 KB): keep at least the two
+  // ping-pong buffers of the gradient chain on chip (128 KB) and only the stash of stage inputs in the workspace
+  p.buf_mixed = p.buf_global && (size_t)2 * p.bs * 4 <= LDS_LIMIT - 4096;
+  size_t lds = p.buf_global ? (p.buf_mixed ? (size_t)2 * p.bs * 4 : 0) : per;
   if (!p.buf_global) {
     // more rows per tile amortise the per-stage barriers when a sample is small — as long as two tiles per CU remain (a
     // classifier head sees B rows: 128 rows in tiles of 8 ran on 16 of the 256 CUs)
@@ -482,7 +490,7 @@ static int launch_lin_bwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, 
     auto kern = k_ttlinear_bwd<T, TDY, BG, AL>;                                                                         \
     if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_LIN), p.lds_bytes, stream, s, n_rows, p.nb, p.bs, p.ss, packed, \
-                       (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws, slabs);                  \
+                       (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws, slabs, p.buf_mixed ? 1 : 0); \
   } while (0)
   const bool slab = p.acc_slab && (d_packed || d_bias) && ws;
   if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, 1);

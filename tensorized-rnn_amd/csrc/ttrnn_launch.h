@@ -57,6 +57,7 @@ struct LinPlan {
   int grid;
   bool w_lds;        // packed cores staged in LDS
   bool buf_global;   // chain intermediates in the global workspace (sample too large for LDS)
+  bool buf_mixed;    // backward, buf_global: the two ping-pong buffers in LDS all the same, only the stash in the workspace
   bool acc_lds;      // backward: weight/bias gradient accumulators in LDS
   bool acc_slab;     // backward, accumulators too large for LDS: one private global slab per workgroup (summed by a second
                      // kernel) instead of atomics from every row into the one gradient buffer
