@@ -261,7 +261,30 @@ TT_HD void stage_bwd_weight(int tid, int nthr, const float* A, int sA, const flo
     for (int s = 0; s < nb; ++s) {
       const float* As = A + (size_t)s * sA + k0;
       const float* Cs = dC + (size_t)s * sC + (size_t)i * rows * R + a;
-      for (int row = 0; row < rows; ++row) {
+      int row = 0;
+      if (nk == KT) {
+        // four rows' operands are requested before the first one is consumed: with the stage inputs in the global workspace
+        // (samples too large for LDS) one row per iteration left every FMA group waiting a full L2 round trip — same sums in
+        // the same order
+        for (; row + 4 <= rows; row += 4) {
+          float av[4][KT], dv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* Ar = As + (size_t)(row + u) * K;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) av[u][j] = Ar[j];
+            dv[u] = Cs[(size_t)(row + u) * R];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0 = fmaf(av[u][0], dv[u], acc0);
+            acc1 = fmaf(av[u][1], dv[u], acc1);
+            acc2 = fmaf(av[u][2], dv[u], acc2);
+            acc3 = fmaf(av[u][3], dv[u], acc3);
+          }
+        }
+      }
+      for (; row < rows; ++row) {
         const float dc = Cs[(size_t)row * R];
         const float* Ar = As + (size_t)row * K;
         acc0 = fmaf(Ar[0], dc, acc0);
