@@ -263,20 +263,21 @@ TT_HD void stage_bwd_weight(int tid, int nthr, const float* A, int sA, const flo
       const float* Cs = dC + (size_t)s * sC + (size_t)i * rows * R + a;
       int row = 0;
       if (nk == KT) {
-        // four rows' operands are requested before the first one is consumed: with the stage inputs in the global workspace
+        // eight rows' operands are requested before the first one is consumed: with the stage inputs in the global workspace
         // (samples too large for LDS) one row per iteration left every FMA group waiting a full L2 round trip — same sums in
         // the same order
-        for (; row + 4 <= rows; row += 4) {
-          float av[4][KT], dv[4];
+        constexpr int RU = 8;
+        for (; row + RU <= rows; row += RU) {
+          float av[RU][KT], dv[RU];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < RU; ++u) {
             const float* Ar = As + (size_t)(row + u) * K;
 #pragma unroll
             for (int j = 0; j < KT; ++j) av[u][j] = Ar[j];
             dv[u] = Cs[(size_t)(row + u) * R];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < RU; ++u) {
             acc0 = fmaf(av[u][0], dv[u], acc0);
             acc1 = fmaf(av[u][1], dv[u], acc1);
             acc2 = fmaf(av[u][2], dv[u], acc2);
