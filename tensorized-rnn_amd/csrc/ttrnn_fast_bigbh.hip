@@ -257,9 +257,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
     float mxw = smax[par][lane & (FAST_NW - 1)];
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) mxw = fmaxf(mxw, __shfl_xor(mxw, o));
-    const int eg = 14 - f10h_expo(mxw);
-    const float sg = ldexpf(1.f, eg);
-    const float un = ldexpf(1.f, -(sc.ea + eg - 18 + sc.eb));
+    // (from the exponent bits: frexpf / ldexpf of the device library cost the fused-core kernel 300 cycles per stage, lesson 36;
+    // the maximum's biased exponent clamped to f10h_expo's range, a zero maximum scales zeros)
+    int ebm = (int)(__float_as_uint(mxw) >> 23);
+    ebm = ebm < 87 ? 87 : (ebm > 167 ? 167 : ebm);
+    const int eg = 140 - ebm;                              // 14 - e with mxw < 2^e, e = ebm - 126
+    const float sg = __uint_as_float((unsigned)(127 + eg) << 23);
+    const float un = __uint_as_float((unsigned)(127 - (sc.ea + eg - 18 + sc.eb)) << 23);
     // ---- T0: dimg[(j01, r)][i23 local] = A^T dg, rescaled and split into T1's image ------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
