@@ -301,13 +301,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     f32x4 pkeep = f32x4{0.f, 0.f, 0.f, 0.f};                      // the gate waves' values stay in registers for the split
     // ---- G: gate gradients (lstm.py:26-32 differentiated) ---------------------------------------------------------
     if (own) {
-      {
-        const size_t b2 = t > 1 ? bt - 2 : b * T;
-        fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
-        fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
-        dout_f = dptr[b2 * H + hid];
-        x_f = xptr[b2];
-      }
       const f32x4 qa = ra;
       float dht = dout_c * dscale;
 #pragma unroll
@@ -353,6 +346,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
       if (own) {
         // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
         store_split4_h(img1h, PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), pkeep * sg);
+        // record(t-2), d_out(t-2), x(t-2): requested HERE, behind the gate phase's chain (their address arithmetic is thirty
+        // instructions the head of the step does not have to wait for), consumed two steps from now.  Always four loads, no
+        // branch (index clamped; a null d_out / x reads the reserve and is scaled by zero)
+        const size_t b2 = t > 1 ? bt - 2 : b * T;
+        fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+        fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
+        dout_f = dptr[b2 * H + hid];
+        x_f = xptr[b2];
       } else {                                                    // waves 4-7: the fp32 row goes out to HBM meanwhile
         const int i4 = tid - H;
         const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
