@@ -211,6 +211,25 @@ TT_HD void stage_bwd_data(int tid, int nthr, const float* dC, int sC, float* dA,
     const int nr = tmin(RT, rows - row0);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     const float* Cs = dC + (size_t)s * sC + (size_t)row0 * R;
+    if (nr == RT && R % 8 == 0) {
+      // full row tile: no per-row conditions inside the product loop (they kept the compiler from pairing the loads of the
+      // four rows with the FMAs: a classifier head's data-gradient chain ran four times as long as its forward chain)
+      for (int i = 0; i < I; ++i) {
+        const float* Ci = Cs + (size_t)i * rows * R;
+        for (int a = 0; a < R; a += 8) {
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(i * R + a + u) * K + kk];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            acc0 = fmaf(Ci[a + u], w[u], acc0);
+            acc1 = fmaf(Ci[R + a + u], w[u], acc1);
+            acc2 = fmaf(Ci[2 * R + a + u], w[u], acc2);
+            acc3 = fmaf(Ci[3 * R + a + u], w[u], acc3);
+          }
+        }
+      }
+    } else
     for (int i = 0; i < I; ++i) {
       const float* Ci = Cs + (size_t)i * rows * R;
       int a = 0;
