@@ -666,33 +666,39 @@ size_t f10_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {      // [fra
   return ((head + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs) + half;
 }
 
-// per-sample sums -> stats rows 2, 3 (fixed order: four interleaved sample groups per column, then the four partial sums);
-// LSTM: d_gates_hid IS d_gates_in, row 1 = row 0
+// per-sample sums -> stats rows 2, 3 (fixed order: sixteen interleaved sample groups per column — 16 columns x 16 groups per
+// workgroup — then the sixteen partial sums pairwise); LSTM: d_gates_hid IS d_gates_in, row 1 = row 0
 __global__ void __launch_bounds__(256) k_bwd_stats_finish(int lstm, int Bn, int GH, const float* __restrict__ part,
                                                           float* __restrict__ stats) {
-  __shared__ float red[2][4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[2][16][16];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   if (part) {
     float a = 0.f, d = 0.f;
     if (c < GH)
-      for (int b = grp; b < Bn; b += 4) {
+      for (int b = grp; b < Bn; b += 16) {
         a += part[((size_t)b * 2) * GH + c];
         d += part[((size_t)b * 2 + 1) * GH + c];
       }
     red[0][grp][cl] = a;
     red[1][grp][cl] = d;
     __syncthreads();
-    if (grp == 0 && c < GH) {
-      stats[2 * GH + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-      stats[3 * GH + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (grp < 2 && c < GH) {
+      float t[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t[g] = red[grp][g][cl];
+#pragma unroll
+      for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+        for (int g = 0; g < w; ++g) t[g] = t[2 * g] + t[2 * g + 1];
+      stats[(2 + grp) * GH + c] = t[0];
     }
   }
   if (lstm && grp == 0 && c < GH) stats[GH + c] = stats[c];
 }
 
 int launch_bwd_stats_finish(int cell, int Bn, int GH, const float* part, float* stats, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bwd_stats_finish, dim3((GH + 63) / 64), dim3(256), 0, stream, cell == TTRNN_LSTM ? 1 : 0, Bn, GH, part,
+  hipLaunchKernelGGL(k_bwd_stats_finish, dim3((GH + 15) / 16), dim3(256), 0, stream, cell == TTRNN_LSTM ? 1 : 0, Bn, GH, part,
                      stats);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
