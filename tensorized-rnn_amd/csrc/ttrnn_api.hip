@@ -350,6 +350,14 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       if (!unit) return TTRNN_ERR_LAUNCH;
       if (hsum && !d_bias) {
         // the producer of dy has the row sums already (ttrnn_rnn_backward_ex, TTRNN_BWD_STATS_IN1SUMS): no pass over dy
+        // ONE row: the any-shape kernel (a workgroup, three short stages) is quicker than the batched MFMA kernel's launch
+        // built for row tiles (cfg2: 28 -> ~13 us)
+        if (workspace_bytes >= gen_in1_bytes(s)) {
+          const void* unit32 = unit_rows_ptr(TTRNN_F32);
+          const LinPlan p1 = plan_ttlinear_bwd(s, 1);
+          return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit32, hsum, nullptr, d_packed, nullptr,
+                                     (char*)workspace + in1_bwd_bytes(s), (hipStream_t)stream);
+        }
         return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, hsum, nullptr, d_packed, nullptr,
                                         (hipStream_t)stream);
       }
