@@ -710,17 +710,18 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
   // by-products (stats != NULL): the maxima land in stats rows 0 / 1 by atomicMax, the sums per sample behind the fragments
   BwdStats bs;
   const int GH = rs.G * rs.H;
+  void* ws_half = nullptr;
+  if (f10bh_available(rs, dtype))
+    ws_half = (char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs);
   if (stats) {
-    if (hipMemsetAsync(stats, 0, (size_t)2 * GH * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    // (the two-piece kernels' prep launch clears the maxima itself)
+    if (!ws_half && hipMemsetAsync(stats, 0, (size_t)2 * GH * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
     bs.colmax = reinterpret_cast<unsigned*>(stats);
     if (x_in1 && rs.in == 1) {
       bs.x = x_in1;
       bs.part = reinterpret_cast<float*>((char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255));
     }
   }
-  void* ws_half = nullptr;
-  if (f10bh_available(rs, dtype))
-    ws_half = (char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255) + bwd_stats_part_bytes(rs);
   int st = TTRNN_ERR_UNSUPPORTED;
   if (rs.cell == TTRNN_GRU) {
     if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;

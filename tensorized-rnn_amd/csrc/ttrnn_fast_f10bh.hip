@@ -109,7 +109,10 @@ __device__ __forceinline__ void split8h(const f32x4& va, const f32x4& vb, xh8& h
 //                 T2  wf[T01 part + (u*2 + p)*64 + lane], lane (r, q): row j2 = r (< J2, else 0), k2 slot 4u + q
 template <class S, bool NATK = false>
 __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict__ packed, float* __restrict__ hdr,
-                                                        xh8* __restrict__ wfrag) {
+                                                        xh8* __restrict__ wfrag, unsigned* __restrict__ zero, int zero_n) {
+  // (the by-products' column maxima start from zero: cleared here instead of by a launch of their own)
+  if (zero)
+    for (int e = blockIdx.x * FAST_NT + threadIdx.x; e < zero_n; e += gridDim.x * FAST_NT) zero[e] = 0u;
   using F = F10<S>;
   using B = F10BH<S>;
   __shared__ float red[2][FAST_NW][16];
@@ -703,7 +706,8 @@ int launch_gru_t(const RnnShape& rs, const void* out, const void* h0, const floa
   using B = F10BH<S>;
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(hdr + B::HDR_FLOATS);
-  hipLaunchKernelGGL((k_f10bh_prep<S, true>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag);
+  hipLaunchKernelGGL((k_f10bh_prep<S, true>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag, bs.colmax,
+                     bs.colmax ? 2 * 3 * B::H : 0);
   constexpr size_t lds = f10bh_gru_lds_bytes<S>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   hipLaunchKernelGGL((k_gru_bwd_f10h<S, TS>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const TS*)out,
@@ -718,7 +722,8 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
   using B = F10BH<S>;
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(hdr + B::HDR_FLOATS);
-  hipLaunchKernelGGL((k_f10bh_prep<S>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag);
+  hipLaunchKernelGGL((k_f10bh_prep<S>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag, bs.colmax,
+                     bs.colmax ? 2 * 4 * B::H : 0);
   constexpr size_t lds = f10bh_lds_bytes<S>();
   static_assert(lds <= 150 * 1024, "LDS image set too large");
   const bool dg = opt(OPT_DIAG) != 0;

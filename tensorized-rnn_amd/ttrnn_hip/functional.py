@@ -292,8 +292,11 @@ class _TTHeadFn(torch.autograd.Function):
         dev = x2d.device
         dy = dy.contiguous().to(x2d.dtype)
         dx = _alloc((n, spec.in_features), x2d.dtype, dev) if need_dx else None
-        dpk = torch.zeros(spec.packed_elems, dtype=torch.float32, device=dev) if need_dw else None
-        db = torch.zeros(spec.out_features, dtype=torch.float32, device=dev) if need_db else None
+        # the two accumulate-into buffers: ONE zero fill (each starts on a 256-byte boundary)
+        npk = (spec.packed_elems + 63) // 64 * 64 if need_dw else 0
+        flat = torch.zeros(npk + (spec.out_features if need_db else 0), dtype=torch.float32, device=dev)
+        dpk = flat[:spec.packed_elems] if need_dw else None
+        db = flat[npk:npk + spec.out_features] if need_db else None
         wsb = lib.ttrnn_head_workspace(ctypes.byref(spec.desc), n)
         ws = _workspace(wsb, dev)
         check(lib.ttrnn_head_backward(ctypes.byref(spec.desc), _dtype_code(x2d), ctx.epi, n, _ptr(packed), _ptr(x2d), _ptr(y),
