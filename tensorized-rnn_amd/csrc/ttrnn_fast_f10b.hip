@@ -72,10 +72,14 @@ constexpr size_t f10b_wfrag_elems() {      // xbf8 fragments: T01 [FT][NM1][3][6
 // fragment order: T01: wf[((ft*NM1 + u)*3 + p)*64 + lane], lane (r, q): feature 16ft + r = row2*R2 + r2, k = 32u + 8q + e
 //                 T2 : wf[T01 part + (u*3 + p)*64 + lane],  lane (r, q): feature j2 = r (< J2, else 0)
 template <class S>
-__global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ packed, xbf8* __restrict__ wfrag) {
+__global__ void __launch_bounds__(64) k_f10b_prep(const float* __restrict__ packed, xbf8* __restrict__ wfrag,
+                                                  float* __restrict__ zero = nullptr, int zero_n = 0) {
   using F = F10<S>;
   using B = F10B<S>;
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  // (a caller's accumulator — the weight-gradient kernel's dW10 — is cleared here instead of by a launch of its own)
+  if (zero)
+    for (int e = blockIdx.x * 64 + lane; e < zero_n; e += gridDim.x * 64) zero[e] = 0.f;
   xbf8 f0, f1, f2;
   if (blockIdx.x < B::FT * B::NM1) {
     const int u = blockIdx.x % B::NM1, ft = blockIdx.x / B::NM1;
@@ -625,18 +629,18 @@ size_t f10b_fragment_bytes(const TtShape& s) {
 }
 
 template <class S>
-static int launch_prep_b(const float* packed, void* wfrag, hipStream_t stream) {
+static int launch_prep_b(const float* packed, void* wfrag, hipStream_t stream, float* zero, int zero_n) {
   using B = F10B<S>;
   hipLaunchKernelGGL((k_f10b_prep<S>), dim3(B::FT * B::NM1 + B::NM2), dim3(64), 0, stream, packed,
-                     reinterpret_cast<xbf8*>(wfrag));
+                     reinterpret_cast<xbf8*>(wfrag), zero, zero_n);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream) {
-  if (shape_matches<ShpH256R8L>(s)) return launch_prep_b<ShpH256R8L>(packed, wfrag, stream);
-  if (shape_matches<ShpH256R16L>(s)) return launch_prep_b<ShpH256R16L>(packed, wfrag, stream);
-  if (shape_matches<ShpH256R8G>(s)) return launch_prep_b<ShpH256R8G>(packed, wfrag, stream);
-  if (shape_matches<ShpI40R16L>(s)) return launch_prep_b<ShpI40R16L>(packed, wfrag, stream);
+int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream, float* zero, int zero_n) {
+  if (shape_matches<ShpH256R8L>(s)) return launch_prep_b<ShpH256R8L>(packed, wfrag, stream, zero, zero_n);
+  if (shape_matches<ShpH256R16L>(s)) return launch_prep_b<ShpH256R16L>(packed, wfrag, stream, zero, zero_n);
+  if (shape_matches<ShpH256R8G>(s)) return launch_prep_b<ShpH256R8G>(packed, wfrag, stream, zero, zero_n);
+  if (shape_matches<ShpI40R16L>(s)) return launch_prep_b<ShpI40R16L>(packed, wfrag, stream, zero, zero_n);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

@@ -341,8 +341,7 @@ static int launch_wgrad_f10(const TtShape& ts, long n_rows, const float* packed,
   float* dW10 = reinterpret_cast<float*>(ws);
   const size_t dw_bytes = (size_t)F::K * F::M * sizeof(float);
   void* wfrag = (char*)ws + dw_bytes;
-  if (hipMemsetAsync(dW10, 0, dw_bytes, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  int st = launch_f10b_prep(ts, packed, wfrag, stream);
+  int st = launch_f10b_prep(ts, packed, wfrag, stream, dW10, (int)(dw_bytes / sizeof(float)));      // + dW10 = 0
   if (st != TTRNN_OK) return st;
   constexpr size_t lds = f10w_lds_bytes<S>();
   static_assert(lds <= 160 * 1024, "LDS image set too large");

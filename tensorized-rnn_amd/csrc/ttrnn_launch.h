@@ -283,7 +283,8 @@ int launch_gru_bwd_f10h(const RnnShape& rs, int dtype, const void* out, const vo
                         void* ws, hipStream_t stream, const BwdStats& bs);
 
 size_t f10b_fragment_bytes(const TtShape& s);     // the transposed fused-core fragments alone
-int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream);
+int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStream_t stream, float* zero = nullptr,
+                     int zero_n = 0);      // zero: a caller's accumulator cleared by the same launch
 
 // batched weight (+ bias) gradients of a hidden-shaped TT-matrix through the fused core, dx optional (ttrnn_fast_f10w.hip)
 bool f10_ttlinear_wgrad_available(const TtShape& s, int dtype, int dy_dtype);
