@@ -704,6 +704,141 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
   if (own && hT) st(hT, b * H + hid, hst);
 }
 
+// Four-wave variant with S2 INSIDE the gate waves (the default; option `dev` bit 5 selects the eight-wave kernel above for
+// A/B — both give the same bits): wave w owns hidden units
+// 64w .. 64w+63 = chain rows 8w .. 8w+7, so the S2 operand of those rows — eight consecutive units per row — lives in eight
+// lanes of the same wave: gathered with eight ds_bpermute (the LDS crossbar, no memory, no barrier), multiplied by G2 for all
+// six m-tiles (16-column tiles of which 8 columns are real: the matrix pipe idles 90 % of the step anyway) and written to the
+// S10 image.  One LDS hand-off and one barrier per step fewer than k_gru_fwd_f10: [S10 | barrier | gates + S2 | barrier].
+template <class S>
+__global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs, const bf16_t* __restrict__ h0,
+                                                      const float* __restrict__ packed_hid,
+                                                      const xbf8* __restrict__ wfrag,
+                                                      const bf16_t* __restrict__ bias_hid, bf16_t* __restrict__ out,
+                                                      bf16_t* __restrict__ hT, float* __restrict__ reserve) {
+  static_assert(f10g_ok<S>() && F10<S>::H == 256 && F10<S>::J2 == 8, "shape not supported by the fused-core GRU kernel");
+  using F = F10<S>;
+  constexpr int H = F::H;
+  __shared__ __attribute__((aligned(16))) __bf16 img[F::PLANE];          // S10 operand [I2][K10]
+  __shared__ __attribute__((aligned(16))) float gbuf[3 * H];             // gate pre-activations of the hidden chain
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  // S2 fragments of ALL m-tiles: lane (r = c, q): feature 16mt + r, the 8 real k values live in k-group 0
+  xbf8 a2[F::MT2];
+  {
+    const float* W2 = packed_hid + woff_of<S>(2);          // [J2][M2]
+#pragma unroll
+    for (int mt = 0; mt < F::MT2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a2[mt][e] = (__bf16)(q == 0 ? W2[e * F::M2 + 16 * mt + c] : 0.f);
+  }
+  xbf8 w10[F::NM];
+#pragma unroll
+  for (int u = 0; u < F::NM; ++u) w10[u] = wfrag[(size_t)(wave * F::NM + u) * 64 + lane];
+
+  const float* __restrict__ gin = gs.gin;
+  const bf16_t* __restrict__ xs = reinterpret_cast<const bf16_t*>(gs.x);
+  const bool in1 = gs.in1 != 0;
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
+  const int hid = tid;
+  float hst = h0 ? ld(h0, b * H + hid) : 0.f;
+  float bh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bh[g] = bias_hid ? ld(bias_hid, g * H + hid) : 0.f;
+  f32x4 gi = f32x4{0.f, 0.f, 0.f, 0.f}, vv = gi, bb = gi;
+  XChunk<bf16_t> xq;
+  xq.cur = 0.f; xq.nxt = 0.f;
+  if (in1) xq.init(xs, b * T, T, lane);
+  if (T > 0) {
+    if (in1) {
+      bb = gin4[H + hid];
+      vv = gin4[hid] - bb;
+    } else {
+      gi = gin4[(b * T) * H + hid];
+    }
+  }
+  // S2 of this wave's eight chain rows from the state in the lanes (hv: the bf16 bit pattern of this lane's unit)
+  const int gsrc = 4 * (8 * (lane & 7));                                  // byte address of lane 8 (lane & 7) for ds_bpermute
+  const bool bvalid = q == 0 && c < 8;
+  auto s2_from_lanes = [&](unsigned hv) {
+    unsigned g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (unsigned)__builtin_amdgcn_ds_bpermute(gsrc + 4 * e, (int)hv);
+    u32x4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = bvalid ? ((g[2 * e] & 0xFFFFu) | (g[2 * e + 1] << 16)) : 0u;
+    const xbf8 bfrag = __builtin_bit_cast(xbf8, pk);
+    // all six products first, ONE guarded block of stores behind them (a guard per tile put a branch — and the wait for its
+    // MFMA — between every two of them)
+    f32x4 acc[F::MT2];
+#pragma unroll
+    for (int mt = 0; mt < F::MT2; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (c < 8) {                         // column c = chain row 8 wave + c; registers j: features 16mt + 4q + j
+#pragma unroll
+      for (int mt = 0; mt < F::MT2; ++mt) {
+        const int m0 = 16 * mt + 4 * q;
+        const int i = m0 / F::R2, a0 = m0 % F::R2;
+        xbf4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[mt][j];
+        *reinterpret_cast<xbf4*>(img + x_off<F::K>(i, F::kperm(8 * wave + c, a0))) = o;
+      }
+    }
+  };
+  s2_from_lanes((unsigned)f32_to_bf16(hst).v);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
+  lds_barrier();
+
+  const int row10 = c < F::I2 ? c : F::I2 - 1;
+  for (int t = 0; t < T; ++t) {
+    // ---- B: fused S1*S0 stage, one tile per wave --------------------------------------------------------------------
+    {
+      xbf8 af[F::NM];
+#pragma unroll
+      for (int u = 0; u < F::NM; ++u) af[u] = *reinterpret_cast<const xbf8*>(img + x_off<F::K>(row10, 32 * u + 8 * q));
+      __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first MFMA (the scheduler issued them in pairs)
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int u = 0; u < F::NM; u += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[u], af[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w10[u + 1], af[u + 1], acc1, 0, 0, 0);
+      }
+      const f32x4 acc = acc0 + acc1;
+      if (c < F::I2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gbuf[(16 * wave + 4 * q + j) * F::I2 + c] = acc[j];   // o = m*I2 + i2
+      }
+    }
+    lds_barrier();
+    // ---- C + A: gates + state (gru.py:38-44), then S2 of the new state from the lanes -------------------------------
+    const size_t bt = b * T + t;
+    {
+      if (in1) gi = bb + xq.at(t) * vv;
+      const float hn = gbuf[2 * H + hid] + bh[2];
+      const float rg = fsigmoid(gi[0] + gbuf[hid] + bh[0]);              // gru.py:38-39
+      const float zg = fsigmoid(gi[1] + gbuf[H + hid] + bh[1]);          // gru.py:40-41
+      const float ng = ftanh(gi[2] + rg * hn);                           // gru.py:42-43
+      float hy = (1.0f - zg) * ng + zg * hst;                            // gru.py:44
+      if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+      const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
+      out[bt * H + hid] = hb;
+      hst = bf16_to_f32(hb);
+      s2_from_lanes((unsigned)hb.v);
+      // (behind the S2 of this step: a conditional global load makes the compiler wait for every memory operation in flight —
+      // this step's stores included — at the point where the branches join)
+      if (!in1 && t + 1 < T) gi = gin4[(bt + 1) * H + hid];
+    }
+    if (in1) xq.advance(xs, b * T, T, t, lane);
+    lds_barrier();
+  }
+  if (hT) st(hT, b * H + hid, hst);
+}
+
 template <class S>
 static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
                        void* out, void* hT, float* reserve, void* ws, hipStream_t stream, int phase) {
@@ -712,6 +847,11 @@ static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const flo
   if (phase != TTRNN_PHASE_RUN)
     hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  if (!(opt(OPT_DEV) & 32))      // default: four waves, S2 inside the gate waves (dev bit 5: the eight-wave kernel, A/B)
+    hipLaunchKernelGGL((k_gru_fwd_f10v<S>), dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0, packed_hid,
+                       wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr, (bf16_t*)out, (bf16_t*)hT,
+                       reserve);
+  else
   hipLaunchKernelGGL((k_gru_fwd_f10<S>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0,
                      packed_hid, wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr,
                      (bf16_t*)out, (bf16_t*)hT, reserve);
