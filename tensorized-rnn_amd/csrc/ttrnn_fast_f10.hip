@@ -705,9 +705,11 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
 }
 
 // Four-wave variant with S2 INSIDE the gate waves (the default; option `dev` bit 5 selects the eight-wave kernel above for
-// A/B — both give the same bits): wave w owns hidden units
+// A/B — the two agree to one bf16 ulp of the stored C2 / h: the MFMA sums the same eight products with k in other slots):
+// wave w owns hidden units
 // 64w .. 64w+63 = chain rows 8w .. 8w+7, so the S2 operand of those rows — eight consecutive units per row — lives in eight
-// lanes of the same wave: gathered with eight ds_bpermute (the LDS crossbar, no memory, no barrier), multiplied by G2 for all
+// lanes of the same wave: paired by one DPP shift and gathered with ONE ds_bpermute per lane (the LDS crossbar, no memory, no
+// barrier; S2's eight k values are spread two per k-group so that a lane needs one pair), multiplied by G2 for all
 // six m-tiles (16-column tiles of which 8 columns are real: the matrix pipe idles 90 % of the step anyway) and written to the
 // S10 image.  One LDS hand-off and one barrier per step fewer than k_gru_fwd_f10: [S10 | barrier | gates + S2 | barrier].
 template <class S>
@@ -727,14 +729,16 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
 
-  // S2 fragments of ALL m-tiles: lane (r = c, q): feature 16mt + r, the 8 real k values live in k-group 0
+  // S2 fragments of ALL m-tiles: lane (r = c, q): feature 16mt + r.  The 8 real k values (j2) are spread over the four
+  // k-groups, two each (slots 8q, 8q + 1 = j2 2q, 2q + 1; the other six slots of a group are zero): a lane of the B operand then
+  // needs ONE pair of units of its row — one gather instead of four
   xbf8 a2[F::MT2];
   {
     const float* W2 = packed_hid + woff_of<S>(2);          // [J2][M2]
 #pragma unroll
     for (int mt = 0; mt < F::MT2; ++mt)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a2[mt][e] = (__bf16)(q == 0 ? W2[e * F::M2 + 16 * mt + c] : 0.f);
+      for (int e = 0; e < 8; ++e) a2[mt][e] = (__bf16)(e < 2 ? W2[(2 * q + e) * F::M2 + 16 * mt + c] : 0.f);
   }
   xbf8 w10[F::NM];
 #pragma unroll
@@ -762,16 +766,15 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs
     }
   }
   // S2 of this wave's eight chain rows from the state in the lanes (hv: the bf16 bit pattern of this lane's unit)
-  const int gsrc = 4 * (8 * (lane & 7));                                  // byte address of lane 8 (lane & 7) for ds_bpermute
-  const bool bvalid = q == 0 && c < 8;
+  const int gsrc = 4 * (8 * (lane & 7) + 2 * q);                          // byte address of lane 8 c' + 2 q for ds_bpermute
+  const bool bvalid = c < 8;
   auto s2_from_lanes = [&](unsigned hv) {
-    unsigned g[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = (unsigned)__builtin_amdgcn_ds_bpermute(gsrc + 4 * e, (int)hv);
-    u32x4 pk;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pk[e] = bvalid ? ((g[2 * e] & 0xFFFFu) | (g[2 * e + 1] << 16)) : 0u;
-    const xbf8 bfrag = __builtin_bit_cast(xbf8, pk);
+    // every lane first pairs its unit with its right neighbour's (DPP row_shl:1 — units 2e, 2e + 1 of a row are lanes 8c + 2e,
+    // 8c + 2e + 1: the same 16-lane row); lane (c, q) of the B operand then fetches the pair (2q, 2q + 1) of chain row c
+    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hv, 0x101, 0xF, 0xF, false);      // lane i <- lane i + 1
+    const unsigned pair = (hv & 0xFFFFu) | (nb << 16);
+    const unsigned g = (unsigned)__builtin_amdgcn_ds_bpermute(gsrc, (int)pair);
+    const xbf8 bfrag = __builtin_bit_cast(xbf8, u32x4{bvalid ? g : 0u, 0u, 0u, 0u});
     // all six products first, ONE guarded block of stores behind them (a guard per tile put a branch — and the wait for its
     // MFMA — between every two of them)
     f32x4 acc[F::MT2];

@@ -2202,3 +2202,34 @@ def test_fused_core_half_piece_gru_reverse_kernel_ranges(case, dtype):
     print(case, dtype, "max gradient error relative to each tensor's maximum:", worst)
     tol = 5e-2 if dtype == "bf16" else 2e-5
     assert worst["two_fp16"] <= tol and worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
+
+
+def test_gru_forward_kernel_with_in_wave_s2_matches_eight_wave_kernel_and_oracle():
+    """cfg3's default forward kernel (k_gru_fwd_f10v: four waves, the S2 operand gathered inside the gate waves with one DPP shift
+    and one ds_bpermute per lane) against the eight-wave kernel it replaced (option dev bit 5) and the fp32 oracle: the two
+    kernels multiply the same bf16 operands and differ by at most one bf16 ulp of an intermediate; gin-fed layers (stacked,
+    input_size 40), h_0 given, training forward (reserve) included."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(31)
+    for inp, L, B, T, with_h0 in ((1, 1, 9, 50, False), (1, 1, 70, 33, True), (40, 2, 6, 21, True)):
+        meta = dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=8)
+        m = build_module(meta, dev()).to(torch.bfloat16)
+        x = torch.rand(B, T, inp).to(torch.bfloat16)
+        h0 = (torch.randn(B, 256) * 0.5).to(torch.bfloat16) if with_h0 else None
+        sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+        layers, _ = O.layers_from_state_dict(sd, L)
+        ro, rh = O.gru_forward(layers, x.float(), h0.float() if with_h0 else None)
+        outs = {}
+        for name, d in (("in_wave", 0), ("eight_wave", 32)):
+            with ttrnn_hip.option("dev", d), torch.no_grad():
+                outs[name] = m(x.to(dev()), h0.to(dev()) if with_h0 else None)
+        a, b = outs["in_wave"][0].float(), outs["eight_wave"][0].float()
+        assert torch.isfinite(a).all()
+        assert _maxabs(a, b) <= 2.0 ** -7                      # a bf16 ulp of values below 1 (mostly identical)
+        assert _maxabs(a, ro) <= 2e-2 and _maxabs(b, ro) <= 2e-2
+        assert _maxabs(outs["in_wave"][1].float(), rh) <= 2e-2
+        # training forward writes the reserve: the backward must see the same state
+        xg = x.to(dev())
+        o1 = m(xg, h0.to(dev()) if with_h0 else None)[0]
+        assert torch.equal(o1.detach(), outs["in_wave"][0])
