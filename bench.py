@@ -77,9 +77,10 @@ EXECUTED = {
     # cfg1: stage-wise fp32 kernel: stage 1 8 m-tiles x 4 k-steps, stage 0 2 row tiles x 8 k-steps
     "cfg1": dict(bf16_mfma=0, fp32_mfma=32 + 16, kin_bf16_flop=0, rec_simds=4,
                  note="stage-wise fp32 MFMA kernel (k_lstm_fwd_fused)"),
-    # cfg3: bf16 storage, plain bf16 MFMAs: S2 12 tiles + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10)
-    "cfg3": dict(bf16_mfma=12 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
-                 note="bf16 fused core, no splitting (storage precision is bf16)"),
+    # cfg3: bf16 storage, plain bf16 MFMAs: S2 4 waves x 6 m-tiles (each wave its own eight chain rows: half of a tile's
+    # columns are padding) + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10v)
+    "cfg3": dict(bf16_mfma=24 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
+                 note="bf16 fused core, no splitting (storage precision is bf16); S2 inside the gate waves"),
     # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense GEMM on fp16 pieces,
     # 3 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
     "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=3 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
