@@ -634,22 +634,28 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
 #pragma unroll
         for (int p = 0; p < 2; ++p)
           bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(rowc, 32 * u + 8 * q));
+      // all products first, ONE guarded block of stores behind them (a guard per tile puts a branch — and the wait for that
+      // tile's MFMAs — between the tiles: lesson 40)
+      f32x4 au[B::XF][B::NM1];
 #pragma unroll
-      for (int x = 0; x < B::XF; ++x) {
-        f32x4 au[B::NM1];
+      for (int x = 0; x < B::XF; ++x)
 #pragma unroll
         for (int u = 0; u < B::NM1; ++u) {
-          au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
+          au[x][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[x][u], 0, 0, 0);
+          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[x][u], 0, 0, 0);
+          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[x][u], 0, 0, 0);
         }
-        f32x4 acc = au[0];
+      if (c < F::I2) {
 #pragma unroll
-        for (int u = 1; u < B::NM1; ++u) acc += au[u];
-        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
-        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
-        if (c < F::I2) store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+        for (int x = 0; x < B::XF; ++x) {
+          f32x4 acc = au[x][0];
+#pragma unroll
+          for (int u = 1; u < B::NM1; ++u) acc += au[x][u];
+          const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+          const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+          store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+        }
       }
     }
     lds_barrier();
