@@ -398,22 +398,32 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     lds_barrier();
     TT_STAMP(5)
     // ---- T2: dh_{t-1}[row2][j2], pair = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
+    {
+      // (r = 16: two pairs per wave — both pairs' products first, ONE guarded block of stores behind them: lesson 40)
+      f32x4 acc2[B::XT2];
 #pragma unroll
-    for (int x = 0; x < B::XT2; ++x) {
-      const int ub = (wave + FAST_NW * x) >> 1;
-      const int row = 16 * ct + c;
-      xh8 b2[2];
+      for (int x = 0; x < B::XT2; ++x) {
+        const int ub = (wave + FAST_NW * x) >> 1;
+        const int row = 16 * ct + c;
+        xh8 b2[2];
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-        b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
-      // the two small terms on one accumulator, the large one on its own: two MFMA latencies on the path instead of three
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][1], b2[0], z4, 0, 0, 0);
-      const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[0], z4, 0, 0, 0);
-      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[1], alo, 0, 0, 0);
-      const f32x4 acc = ahi + alo;
+        for (int p = 0; p < 2; ++p)
+          b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+        // the two small terms on one accumulator, the large one on its own: two MFMA latencies on the path instead of three
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][1], b2[0], z4, 0, 0, 0);
+        const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[0], z4, 0, 0, 0);
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[1], alo, 0, 0, 0);
+        acc2[x] = ahi + alo;
+      }
       // lane (c = row2 in the column tile, q), registers j: j2 = 4q + j (valid for q < 2): hidden = row2*J2 + j2
-      if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc * (un2 * u2);
+      if (q < 2) {
+#pragma unroll
+        for (int x = 0; x < B::XT2; ++x) {
+          const int ub = (wave + FAST_NW * x) >> 1;
+          *reinterpret_cast<f32x4*>(dhs + ub * H + (16 * ct + c) * F::J2 + 4 * q) = acc2[x] * (un2 * u2);
+        }
+      }
     }
     TT_STAMP(6)
     lds_barrier();
