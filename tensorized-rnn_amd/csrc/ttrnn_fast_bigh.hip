@@ -337,6 +337,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
     __syncthreads();
     // ---- gates (lstm.py:26-32): register j = gate j (i, f, g, o) of unit hid ---------------------------------------------
     const size_t bt = b * T + t;
+    f32x4 rsv;                                     // the gates and the unrounded h_t: stored behind the exchange
+    float hraw;
     {
       const f32x4 tot = (kh == 0 ? acc[0] : acc[1]) + xp[p][1 - kh][lane];
       const f32x4 usc = un4 * e0f;
@@ -348,23 +350,21 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       const float cy = fg * cst + ig * gg;
       float hy = og * btanh(cy);
       cst = cy;
-      if (reserve) {
-        float* rv = reserve + res_gate(bt, H, hid);
-        rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
-        reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
-      }
-      st(out, bt * H + hid, hy);
+      rsv = f32x4{ig, gg, fg, og};
+      hraw = hy;
       hy = round_like(out, hy);                    // what the next step sees: rounded once to the storage type
       hst = hy;
       // swap halves of h_t with the partner workgroup (ttrnn_fast_big.hip:k_lstm_fwd_big2: self-validating 64-bit words
-      // (value, step tag), relaxed agent-scope atomics, double-buffered by step parity)
+      // (value, step tag), relaxed agent-scope atomics, double-buffered by step parity).  The word goes out FIRST and nothing
+      // else is put into the memory pipe before the partner's word is back: the poll's return is counted in order with every
+      // earlier store and load of the wave — with the output / reserve stores and the next step's gin load (an HBM round trip)
+      // in front of it, every step waited for them before it could see a word that was already there
       __hip_atomic_store(hx + (b * 2 + (t & 1)) * H + hid,
                          ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(hy),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       _Float16 u, v;
       split2h(hy * BH_HSC, u, v);
       hpl[ho] = u; hpl[BH_PL_H + ho] = v;
-      if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
     }
     {
       const unsigned long long* src = hx + (b * 2 + (t & 1)) * H + hidp;
@@ -381,6 +381,14 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       split2h(hp * BH_HSC, u, v);
       hpl[hop] = u; hpl[BH_PL_H + hop] = v;
     }
+    // behind the exchange: this step's stores and the next step's gate inputs (consumed a whole step from now)
+    if (reserve) {
+      float* rv = reserve + res_gate(bt, H, hid);
+      rv[0] = rsv[0]; rv[1] = rsv[1]; rv[2] = rsv[2]; rv[3] = rsv[3];
+      reserve[res_cell((size_t)B * T, bt, H, hid)] = cst;
+    }
+    st(out, bt * H + hid, hraw);
+    if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
     __syncthreads();
   }
   if (dead) hst = cst = __uint_as_float(0x7FC00000u);       // T == time-out step: nothing downstream has seen the NaN yet
