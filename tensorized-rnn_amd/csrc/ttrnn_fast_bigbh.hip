@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
       fc = reserve[res_cell((size_t)B * T, b2, H, hid)];
       fd = d_out ? ld(d_out, b2 * H + hid) : 0.f;
     }
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
     // ---- this step's scale: max |dg| of the workgroup < 2^e  ->  2^(14 - e) -------------------------------------------------
     float mxw = smax[par][lane & (FAST_NW - 1)];
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
         }
       }
     }
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
     // ---- T1 over this workgroup's K slice: wave = (m-tile, k half), reads run PD operands ahead of the MFMAs -----------------
     {
       constexpr int PD = 4, NI = 16;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_big2h(int B, int T, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) dhp[(kh * T0::M + 16 * mt1 + 4 * q + j) * 16 + c] = acc[j];
     }
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
     // ---- dh_{t-1} of the own units + the partner's share (ttrnn_fast_bigb.hip: tagged words, relaxed agent-scope atomics) ----
     {
       const int n = T - 1 - t;                              // sequence number of this step

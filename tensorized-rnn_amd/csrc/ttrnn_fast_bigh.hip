@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       s1(tl, 3);
     }
     s1(w1r[2], 2);
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
     // ---- stage 0: both row tiles against this wave's k half; reads run PD operands ahead of the MFMAs ----------------
     f32x4 acc[2];
     {
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       acc[1] = hi[1] + lo[1];
     }
     xp[p][kh][lane] = kh == 0 ? acc[1] : acc[0];
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
     // ---- gates (lstm.py:26-32): register j = gate j (i, f, g, o) of unit hid ---------------------------------------------
     const size_t bt = b * T + t;
     f32x4 rsv;                                     // the gates and the unrounded h_t: stored behind the exchange
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
     }
     st(out, bt * H + hid, hraw);
     if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
-    __syncthreads();
+    lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
   }
   if (dead) hst = cst = __uint_as_float(0x7FC00000u);       // T == time-out step: nothing downstream has seen the NaN yet
   if (hT) st(hT, b * H + hid, hst);
