@@ -82,17 +82,22 @@ const char* ttrnn_status_string(int status);
 /* 1 when a usable HIP device is visible to this process, else 0 (never launches). */
 int ttrnn_device_available(void);
 
-/* Device-side event counters.  No call above synchronises, so a kernel cannot hand a status back through its launch; the two
+/* Device-side event counters.  No call above synchronises, so a kernel cannot hand a status back through its launch; the
  * events a caller must be able to see are counted on the device instead and read HERE (this call synchronises the device):
  *   counters[TTRNN_STAT_PAIR_TIMEOUTS]  threads of the two-workgroups-per-sample kernels (H = 1024 class, 2B <= #CUs) that gave
  *                                       up waiting for their partner workgroup (~0.1 s: the partner was not resident — CUs held
  *                                       by another stream or process).  The affected samples' outputs are NaN by construction.
  *   counters[TTRNN_STAT_GUARD_TRIPS]    launches that left the two-piece fp16 kernel for the fp32-MFMA one because a few large
  *                                       entries had pushed the bulk of a weight operand into fp16's subnormal range.
+ *   counters[TTRNN_STAT_BLOCK_VIOLATIONS]  head rows of a hidden matrix passed with hid_blocks > 1 that had a non-zero entry
+ *                                       outside their gate's rank block: the hid_blocks promise was false and the
+ *                                       runtime-shape kernels ignored those entries (outputs and gradients are those of the
+ *                                       block-diagonal part).  Checked on every launch that uses the promise.
  * n = number of counters wanted (<= TTRNN_STAT_COUNT); reset != 0 zeroes them after reading.  The reference has no
  * counterpart (its failures are Python exceptions, lstm.py / ops.py raise nothing on this path). */
 #define TTRNN_STAT_PAIR_TIMEOUTS 0
 #define TTRNN_STAT_GUARD_TRIPS 1
+#define TTRNN_STAT_BLOCK_VIOLATIONS 2
 #define TTRNN_STAT_COUNT 4
 int ttrnn_device_status(unsigned int* counters, int n, int reset);
 
@@ -279,6 +284,10 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc);   /* TTRNN_ROUTE_* or a
  *      what the tensor hooks of ActivGradLogger see (rnn_utils.py:127-171, lstm.py:35-39).  Requesting it selects the
  *      runtime-shape / any-shape reverse kernels, which write it from the registers that already hold the values. */
 size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc);
+/* The same for a caller that knows whether it will pass d_state (want_state != 0): without a d_state request the
+ * shape-specialised routes need only their own (small) workspace, not the per-sample plan of the routes that write d_state;
+ * ttrnn_rnn_backward_workspace(desc) = the larger of the two answers. */
+size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_state);
 /* Kernel family of the reverse-time kernel for this descriptor under the current options (TTRNN_ROUTE_*; want_state != 0: a
  * d_state request).  Pure host logic, as ttrnn_rnn_forward_route. */
 int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state);

@@ -556,24 +556,24 @@ size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   return plan_rnn_generic(rs, false).ws_bytes;
 }
 
-size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
+size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_state) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
-  // a d_state request (ttrnn_rnn_backward) takes the runtime-shape / any-shape route whatever the shape: cover both
-  size_t alt = 0;
-  if (!force_generic()) {
-    alt = plan_rnn_generic(rs, true).ws_bytes;
-    if (g2_rnn_bwd_available(rs, desc->dtype) && g2_rnn_bwd_workspace(rs) > alt) alt = g2_rnn_bwd_workspace(rs);
-  }
-  const size_t own = [&]() -> size_t {
-  if (opt(OPT_FORCE_G2) && !force_generic() && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
-  if (!force_generic() && fast_rnn_bwd_available(rs, desc->dtype))
+  // the same decisions, in the same order, as ttrnn_rnn_backward_ex: a d_state request takes the runtime-shape / any-shape
+  // route whatever the shape, and only then is their (per-sample, much larger) plan part of the answer
+  const bool gen = force_generic();
+  const bool g2_first = (opt(OPT_FORCE_G2) || want_state) && !gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
+  if (!g2_first && !want_state && !gen && fast_rnn_bwd_available(rs, desc->dtype))
     return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
-  if (!force_generic() && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
-  if (!force_generic() && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
+  if (!g2_first && !want_state && !gen && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
+  if (!gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
-  }();
-  return own > alt ? own : alt;
+}
+
+// without knowledge of the call: enough for either (ttrnn_rnn_backward with or without d_state)
+size_t ttrnn_rnn_backward_workspace(const ttrnn_rnn_desc* desc) {
+  const size_t a = ttrnn_rnn_backward_workspace_ex(desc, 0), b = ttrnn_rnn_backward_workspace_ex(desc, 1);
+  return a > b ? a : b;
 }
 
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {

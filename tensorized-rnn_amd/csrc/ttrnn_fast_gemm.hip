@@ -41,11 +41,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // maximum) x (its own column's maximum) — what matters for a gate pre-activation — and equals the bf16 variant's wherever
 // the entries lie within 2^17 of those maxima; a large entry of W costs only its own output feature bits (round 2: one
 // scale for the whole matrix).
-__device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral; clamped so that the
-  if (!(x > 0.f) || !(x < 3e38f)) return 0;                // product of a row scale and the matrix scale (and its inverse)
-  int e;                                                   // stays a normal fp32 number
-  frexpf(x, &e);
-  return e < -40 ? -40 : (e > 40 ? 40 : e);
+__device__ __forceinline__ int g_expo(float x) {          // x < 2^e; zero / non-finite: neutral; clamped so that a scale
+  if (!(x > 0.f) || !(x <= 3.4028235e38f)) return 0;       // 2^(14 - e) and its inverse stay normal fp32 numbers: every
+  int e;                                                   // finite row / column is brought to < 2^15 (fp16 range); the
+  frexpf(x, &e);                                           // two inverses are applied one after the other, the smaller
+  return e < -100 ? -100 : e;                              // first (unscale2), never as their product
+}
+// acc / (row scale) / (column scale) without forming the product of the two inverses (2^228 apart at worst): the smaller
+// factor first, so the intermediate overflows only where the result does
+__device__ __forceinline__ float unscale2(float a, float u, float v) { return a * fminf(u, v) * fmaxf(u, v); }
+__device__ __forceinline__ f32x4 unscale2(f32x4 a, f32x4 u, float v) {
+  return f32x4{unscale2(a[0], u[0], v), unscale2(a[1], u[1], v), unscale2(a[2], u[2], v), unscale2(a[3], u[3], v)};
 }
 }  // namespace
 
@@ -330,7 +336,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm_split(int64_t n_rows, int K, i
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] * (unf * unsc[ri]) + bh;
+      if (n < n_rows) *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = (HALF ? unscale2(acc[mi][ri], unf, unsc[ri]) : acc[mi][ri]) + bh;
     }
   }
 }
@@ -813,7 +819,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const size_t e = (size_t)jj * OUT + o0 + wn * 64 + 16 * ni + c;
-          const float v = HALF ? acc[mi][ni][j] * (unx * uny[ni]) : acc[mi][ni][j];
+          const float v = HALF ? unscale2(acc[mi][ni][j], unx, uny[ni]) : acc[mi][ni][j];
           if (KS == 1) dW[e] = v;
           else if (part) part[(size_t)ks * IN * OUT + e] = v;      // summed by k_dense_reduce
           else atomicAdd(dW + e, v);

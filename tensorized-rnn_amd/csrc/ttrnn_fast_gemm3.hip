@@ -33,11 +33,12 @@ constexpr size_t G3_LDS = (size_t)2 * G3_STAGE * sizeof(_Float16);      // 128 K
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int g3_expo(float x) {        // x < 2^e; zero / non-finite: neutral (as ttrnn_fast_gemm.hip:g_expo)
-  if (!(x > 0.f) || !(x < 3e38f)) return 0;
+  if (!(x > 0.f) || !(x <= 3.4028235e38f)) return 0;
   int e;
   frexpf(x, &e);
-  return e < -40 ? -40 : (e > 40 ? 40 : e);
+  return e < -100 ? -100 : e;
 }
+__device__ __forceinline__ float g3_unscale2(float a, float u, float v) { return a * fminf(u, v) * fmaxf(u, v); }
 __device__ __forceinline__ void g3_ld8(const float* p, size_t i, f32x4& a, f32x4& b) {
   a = *reinterpret_cast<const f32x4*>(p + i);
   b = *reinterpret_cast<const f32x4*>(p + i + 4);
@@ -305,7 +306,9 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3h(int64_t n_rows, int64_t n_pa
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
       // (dev bit 1: harness experiment — only the first row tile stores, everything else is computed and dropped)
       if (n < n_rows && (!(dev & 2) || acc[mi][ri][0] == 12345.678f))
-        *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = acc[mi][ri] * (unf * unr[ri]) + bh;
+        *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) =
+            f32x4{g3_unscale2(acc[mi][ri][0], unf[0], unr[ri]), g3_unscale2(acc[mi][ri][1], unf[1], unr[ri]),
+                  g3_unscale2(acc[mi][ri][2], unf[2], unr[ri]), g3_unscale2(acc[mi][ri][3], unf[3], unr[ri])} + bh;
     }
   }
 }

@@ -33,8 +33,11 @@ namespace {
 
 // ---- prep 1: contract the cores on either side of the split point ------------------------------------------------------
 // packed: W_k[(j*R_{k+1} + b)*M_k + (i*R_k + a)] = G_k[a, i, j, b]  (include/ttrnn.h)
+// status (may be null): the hid_blocks promise of the descriptor is CHECKED here, where every head entry passes through a
+// register anyway — a non-zero entry outside its gate's rank block (which the kernels will skip) is counted in
+// TTRNN_STAT_BLOCK_VIOLATIONS (the promise used to be taken on trust)
 __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const float* __restrict__ packed,
-                                                  float* __restrict__ Gh, float* __restrict__ Gt) {
+                                                  float* __restrict__ Gh, float* __restrict__ Gt, unsigned* status) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nh = (long)m.Ih * m.Jh, nt = (long)m.It * m.Jt;
   float v[G2_MAX_R], w[G2_MAX_R];
@@ -54,6 +57,12 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
       for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
     }
     for (int a = 0; a < m.R; ++a) Gh[(size_t)e * m.R + a] = v[a];
+    if (m.ng > 1 && status) {
+      const int g = (int)(e / m.Jh) / m.IhG;
+      bool off = false;
+      for (int a = 0; a < m.R; ++a) off = off || (a / m.Rb != g && v[a] != 0.f);
+      if (off) atomicAdd(status + TTRNN_STAT_BLOCK_VIOLATIONS, 1u);
+    }
   } else if (e < nh + nt) {
     const long f = e - nh;
     int it = (int)(f / m.Jt), jt = (int)(f % m.Jt);
@@ -963,7 +972,8 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
   float* tf = (float*)p; p += g2_al((size_t)(rev ? m.bt1_bytes : m.ft1_bytes));
   int* hdr = (int*)p;                         // forward only (g2_fwd_ws_bytes): exponents of the diagonal scales
   const int nblk = (int)g2_merge_blocks(m);
-  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt);
+  hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt,
+                     m.ng > 1 ? device_status_ptr() : (unsigned*)nullptr);
   if (rev) {
     hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
     hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr);

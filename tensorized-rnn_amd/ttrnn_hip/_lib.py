@@ -84,6 +84,7 @@ _SIGNATURES = {
     "ttrnn_rnn_out_optional": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward_phase": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_backward_workspace_ex": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
     "ttrnn_rnn_backward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_stats": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
@@ -185,10 +186,10 @@ def option(name, value):
 
 def device_status(reset=False):
     """Device-side event counters (include/ttrnn.h: ttrnn_device_status; synchronises the current device):
-    {"pair_timeouts": ..., "guard_trips": ...}."""
+    {"pair_timeouts": ..., "guard_trips": ..., "block_violations": ...}."""
     buf = (ctypes.c_uint * 4)()
     check(load().ttrnn_device_status(buf, 4, 1 if reset else 0), "ttrnn_device_status")
-    return {"pair_timeouts": int(buf[0]), "guard_trips": int(buf[1])}
+    return {"pair_timeouts": int(buf[0]), "guard_trips": int(buf[1]), "block_violations": int(buf[2])}
 
 
 EPILOGUES = {None: 0, "log_softmax": 1, "relu_l2norm": 2}     # TTRNN_EPI_*

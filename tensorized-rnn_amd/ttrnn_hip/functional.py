@@ -449,7 +449,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         d_h0 = _alloc((B, H), x.dtype, dev) if (has_h0 and need[1]) else None
         d_c0 = _alloc((B, H), x.dtype, dev) if (has_c0 and need[2]) else None
-        wsb = lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc))
+        wsb = lib.ttrnn_rnn_backward_workspace_ex(ctypes.byref(desc), int(ctx.stats is not None))
         ws = _workspace(wsb, dev)
         d_state = _alloc((B, T, H, 2), torch.float32, dev) if ctx.stats is not None else None
         # by-products of the reverse-time kernel for the weight-gradient step below (column maxima of the gate gradients;

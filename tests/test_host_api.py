@@ -180,6 +180,19 @@ def test_descriptor_validation_without_gpu():
     with ttrnn_hip.option("no_g2", 1):
         assert lib.ttrnn_rnn_forward_route(ctypes.byref(tiny)) == 0
         assert lib.ttrnn_rnn_workspace(ctypes.byref(tiny)) == 0
+    # reverse-time workspace: a caller that passes no d_state pays for its own route only; the unconditional
+    # query covers both kinds of call
+    for desc in (d, wide, tiny):
+        own, with_state = (lib.ttrnn_rnn_backward_workspace_ex(ctypes.byref(desc), w) for w in (0, 1))
+        assert lib.ttrnn_rnn_backward_workspace(ctypes.byref(desc)) == max(own, with_state)
+    own, with_state = (lib.ttrnn_rnn_backward_workspace_ex(ctypes.byref(d), w) for w in (0, 1))
+    assert lib.ttrnn_rnn_backward_route(ctypes.byref(d), 0) == 2 and lib.ttrnn_rnn_backward_route(ctypes.byref(d), 1) != 2
+    assert own > 0 and with_state > 0
+    big = RnnLayerSpec("lstm", 1024, 1024, TTSpec([4, 8, 8, 4], [8, 8, 8, 8], [1, 32, 32, 32, 1]),
+                       TTSpec([4, 8, 8, 4], [8, 8, 8, 8], [1, 32, 32, 32, 1]), True, True).desc(128, 1024, 0)
+    own, with_state = (lib.ttrnn_rnn_backward_workspace_ex(ctypes.byref(big), w) for w in (0, 1))
+    print("cfg5-class reverse-time workspace: own route", own, "with d_state", with_state)
+    assert 0 < own <= lib.ttrnn_rnn_backward_workspace(ctypes.byref(big))
     with pytest.raises(ValueError):
         RnnLayerSpec("gru", 1, 256, TTSpec([1, 1, 1], [8, 8, 16], [1, 8, 8, 1]),
                      TTSpec([4, 8, 8], [8, 8, 16], [1, 8, 8, 1]), True, True)
