@@ -41,7 +41,8 @@ class MNISTClassifier(nn.Module):
         # the reference classifies outputs[:, -1, :] (mnist_classifier.py:52-55), which IS the last layer's final hidden state:
         # taking it from the state instead of slicing the [B, T, H] outputs spares autograd a zero-filled [B, T, H] gradient
         # (51 MB per cfg2 step) that the reverse-time kernel would then read
-        res = self.rnn(inputs)
+        # (inference: the [B, T, H] outputs of the last layer are not even written — need_outputs=False)
+        res = self.rnn(inputs) if torch.is_grad_enabled() else self.rnn(inputs, need_outputs=False)
         last = res[1] if self.gru else res[1][0]
         return self.linear.forward_head(last, "log_softmax")                # TTLinear + log_softmax: one library call
 
@@ -60,7 +61,7 @@ class SpeakerEncoder(nn.Module):
 
     def forward(self, utterances):
         # only the last layer's final hidden state is consumed (speaker_encoder.py:80-86): inference skips its [B, T, H] outputs
-        res = self.rnn(utterances) if (self.use_gru or torch.is_grad_enabled()) else self.rnn(utterances, need_outputs=False)
+        res = self.rnn(utterances) if torch.is_grad_enabled() else self.rnn(utterances, need_outputs=False)
         last_hidden = res[1] if self.use_gru else res[1][0]
         return self.linear.forward_head(last_hidden, "relu_l2norm")              # TTLinear + ReLU + L2 norm: one library call
 

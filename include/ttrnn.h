@@ -232,8 +232,10 @@ int ttrnn_head_backward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_r
  *            [B][T][H][4] (per hidden unit the activated gates i,g,f,o) followed by [B][T][H] (the cell states c_t);
  *            GRU [B][T][H][4] (r,z,n, hidden_part_n). */
 /* out == NULL: the caller consumes only the final state (experiments/speaker_verification/encoder/speaker_encoder.py:80-86 keeps
- * `hidden[-1]` of the last layer and drops its outputs): accepted where ttrnn_rnn_out_optional(desc) returns 1 under the current
- * options (the four-wave fused-core LSTM kernels, inference: reserve == NULL), TTRNN_ERR_NULL elsewhere. */
+ * `hidden[-1]` of the last layer and drops its outputs; experiments/digit_classification/mnist_classifier.py:52-55 classifies
+ * the last step): accepted where ttrnn_rnn_out_optional(desc) returns 1 — on every route for an inference call (reserve ==
+ * NULL; every forward kernel guards its [B][T][H] store) — and TTRNN_ERR_NULL for a training forward (reserve != NULL: the
+ * weight-gradient step reads the rows of `out` as h_{t-1}). */
 int ttrnn_rnn_out_optional(const ttrnn_rnn_desc* desc);
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc);
 size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc);

@@ -590,12 +590,10 @@ static bool phase_split_ok(const RnnShape& rs, int dtype) {
   return f.use && f.in1 && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, dtype);
 }
 
-// may ttrnn_rnn_forward be called with out == NULL (the caller wants hT / cT only)?
-static bool out_optional(const RnnShape& rs, int dtype, bool training) {
-  if (force_generic() || fwd_prefers_g2(rs, dtype)) return false;
-  const FastFwdPlan f = plan_fast_fwd(rs, dtype);
-  return f.use && fp32_math() == TTRNN_MATH_SPLIT && f10_rnn_fwd_available(rs, dtype) && f10_out_optional(rs, dtype, training);
-}
+// may ttrnn_rnn_forward be called with out == NULL (the caller wants hT / cT only)?  Every forward kernel of every route
+// guards its [B][T][H] store (round 3; before: the four-wave fused-core kernel only); only a training forward (reserve != NULL)
+// must write `out`, whose rows the weight-gradient step reads as h_{t-1}
+static bool out_optional(const RnnShape&, int, bool training) { return !training; }
 
 int ttrnn_rnn_out_optional(const ttrnn_rnn_desc* desc) {
   RnnShape rs;

@@ -48,6 +48,9 @@ TT_HD float ld(const float* p, size_t i) { return p[i]; }
 TT_HD float ld(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
 TT_HD void st(float* p, size_t i, float v) { p[i] = v; }
 TT_HD void st(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+// v after one round trip through the storage type of p (p itself is not touched: it may be NULL)
+TT_HD float round_as(const float*, float v) { return v; }
+TT_HD float round_as(const bf16_t*, float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // ------------------------------------------------------------------------------------------------
 // shapes
@@ -577,9 +580,9 @@ TT_HD void rnn_fwd_body(Ex& ex, const RnnShape& rs, int b0, int nb,
           }
         }
         // the stored output is what the next step (and the next layer) sees: round once
-        T* op = out + bt * H;
-        st(op, j, hy);
-        hbuf[e] = ld(op, j);
+        // (out == NULL: the caller consumes only the final state — include/ttrnn.h, ttrnn_rnn_out_optional)
+        if (out) st(out + bt * H, j, hy);
+        hbuf[e] = round_as(out, hy);
       }
     });
   }

@@ -171,8 +171,8 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
           if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
         }
         // the stored output is what the next step (and the next layer) sees: round once to the storage type
-        st(out, bt * H + hid, hy);
-        hy = ld(out, bt * H + hid);
+        if (out) st(out, bt * H + hid, hy);          // out == NULL: final state only (ttrnn_rnn_out_optional)
+        hy = round_as(out, hy);
         hst[u] = hy;
         hbuf[a_off<SL::K>(hid / SL::K, hid % SL::K)] = hy;
         // prefetch the hoisted input projection of the next step; consumed one iteration later
@@ -421,7 +421,8 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
     // outputs[:, t, :] = h_t (lstm.py:133): h_t now sits complete in the LDS image the next step reads; the last
     // wave streams it out as whole 16-byte pieces per lane (one coalesced store per timestep instead of eight
     // half-empty ones).  The image is not overwritten before the next gate phase, three barriers away.
-    if (wave == FAST_NW - 1) {
+    // (out == NULL: the caller consumes only the final state — ttrnn_rnn_out_optional)
+    if (wave == FAST_NW - 1 && out) {
 #pragma unroll
       for (int h4 = lane; h4 < H / 4; h4 += 64) {
         const int hd0 = 4 * h4;

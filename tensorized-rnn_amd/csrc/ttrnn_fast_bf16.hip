@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_bf16(int B, int T, GinSrc g
           if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
         }
         const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
-        out[bt * H + hid] = hb;
+        if (out) out[bt * H + hid] = hb;              // out == NULL: final state only (ttrnn_rnn_out_optional)
         hy = bf16_to_f32(hb);
         hst[u] = hy;
         hbuf[h_off<SL::KI>(hid / SL::K, hid % SL::K)] = (__bf16)hy;

@@ -336,8 +336,8 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_big(int B, int T, const flo
           hy = (1.0f - zg) * ng + zg * hst[u];
           if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
         }
-        st(out, bt * H + hid, hy);
-        hy = ld(out, bt * H + hid);
+        if (out) st(out, bt * H + hid, hy);          // out == NULL: final state only (ttrnn_rnn_out_optional)
+        hy = round_as(out, hy);
         hst[u] = hy;
         hbuf[a_off<SL::KP>(hid / SL::K, hid % SL::K)] = hy;
       }
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2(int B, int T, const f
         rv[0] = ig; rv[1] = gg; rv[2] = fg; rv[3] = og;
         reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
       }
-      st(out, bt * H + hid, hy);
+      if (out) st(out, bt * H + hid, hy);          // out == NULL: final state only (ttrnn_rnn_out_optional)
       hy = round_like(out, hy);                    // what the next step sees: rounded once to the storage type
       hst = hy;
       hbuf[a_off<T1::KP>(hid / T1::K, hid % T1::K)] = hy;

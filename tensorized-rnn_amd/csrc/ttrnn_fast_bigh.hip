@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) k_bigh_prep(const float* __restrict__ pac
   }
 }
 
-template <typename TS>
+// OUT = false: the caller consumes only the final state (mnist_classifier.py:52-55): the [B][T][H] store is skipped
+template <typename TS, bool OUT = true>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const float* __restrict__ gin,
                                                             const TS* __restrict__ h0, const TS* __restrict__ c0,
                                                             const xh8* __restrict__ f1, const xh8* __restrict__ f0,
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_big2h(int B, int T, const 
       rv[0] = rsv[0]; rv[1] = rsv[1]; rv[2] = rsv[2]; rv[3] = rsv[3];
       reserve[res_cell((size_t)B * T, bt, H, hid)] = cst;
     }
-    st(out, bt * H + hid, hraw);
+    if constexpr (OUT) st(out, bt * H + hid, hraw);
     if (t + 1 < T) gi = gin4[(bt + 1) * H + hid];
     lds_barrier();      // LDS hand-off only: global loads / stores stay in flight (a __syncthreads waits for them)
   }
@@ -420,12 +421,13 @@ static int launch_bigh_t(const RnnShape& rs, const float* gin, const void* h0, c
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   // stage-0 image (64 KB) + the LDS-resident quarter of the stage-1 fragments (64 KB): one workgroup per CU
   constexpr size_t lds_pair = BH_LDS_PAIR;
-  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_fwd_big2h<TS>), lds_pair) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  auto kern = out ? k_lstm_fwd_big2h<TS, true> : k_lstm_fwd_big2h<TS, false>;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_pair) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   const TS* bin = rs.has_bias_in ? (const TS*)bias_in : (const TS*)nullptr;
   const TS* bhid = rs.has_bias_hid ? (const TS*)bias_hid : (const TS*)nullptr;
   // (OPT_PAIR_FAULT, tests only: the last workgroup is not launched — its partner must time out, poison its sample with NaN
   // and count the event)
-  hipLaunchKernelGGL((k_lstm_fwd_big2h<TS>), dim3(2 * rs.B - (opt(OPT_PAIR_FAULT) ? 1 : 0)), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
+  hipLaunchKernelGGL(kern, dim3(2 * rs.B - (opt(OPT_PAIR_FAULT) ? 1 : 0)), dim3(FAST_NT), lds_pair, stream, rs.B, rs.T, gin,
                      (const TS*)h0, (const TS*)c0, f1, f0, (const int*)hdr, bin, bhid, (TS*)out, (TS*)hT, (TS*)cT, reserve, hxb,
                      device_status_ptr());
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;

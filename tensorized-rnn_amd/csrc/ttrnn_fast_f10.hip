@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
       }
       if (in1) xq.advance(xs, b * T, T, t, lane);
       TT_STAMP(3)
-    } else if (wave == FAST_NW - 1 && t > 0) {
+    } else if (wave == FAST_NW - 1 && t > 0 && out) {      // out == NULL: final state only
       // outputs[:, t-1, :] = h_{t-1} (lstm.py:133): an idle wave streams the complete vector out, 16 bytes per lane
       const float* hprev = hbuf + (t & 1) * H;
 #pragma unroll
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10(int B, int T, GinSrc g
     lds_barrier();
     TT_STAMP(4)
   }
-  if (T > 0 && wave == FAST_NW - 1) {
+  if (T > 0 && wave == FAST_NW - 1 && out) {
     const float* hlast = hbuf + (T & 1) * H;
 #pragma unroll
     for (int h4 = lane; h4 < H / 4; h4 += 64)
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
       float hy = (1.0f - zg) * ng + zg * hst;                            // gru.py:44
       if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
       const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
-      out[bt * H + hid] = hb;
+      if (out) out[bt * H + hid] = hb;              // (A/B kernel: a uniform branch; out == nullptr: final state only)
       hy = bf16_to_f32(hb);
       hst = hy;
       hq[hid] = (__bf16)hy;
@@ -712,7 +712,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
 // barrier; S2's eight k values are spread two per k-group so that a lane needs one pair), multiplied by G2 for all
 // six m-tiles (16-column tiles of which 8 columns are real: the matrix pipe idles 90 % of the step anyway) and written to the
 // S10 image.  One LDS hand-off and one barrier per step fewer than k_gru_fwd_f10: [S10 | barrier | gates + S2 | barrier].
-template <class S>
+// OUT = false: the caller consumes only the final state (mnist_classifier.py:52-55 classifies the last step): no out store
+template <class S, bool OUT = true>
 __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs, const bf16_t* __restrict__ h0,
                                                       const float* __restrict__ packed_hid,
                                                       const xbf8* __restrict__ wfrag,
@@ -829,7 +830,7 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs
       float hy = (1.0f - zg) * ng + zg * hst;                            // gru.py:44
       if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
       const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
-      out[bt * H + hid] = hb;
+      if constexpr (OUT) out[bt * H + hid] = hb;
       hst = bf16_to_f32(hb);
       s2_from_lanes((unsigned)hb.v);
       // (behind the S2 of this step: a conditional global load makes the compiler wait for every memory operation in flight —
@@ -850,11 +851,12 @@ static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const flo
   if (phase != TTRNN_PHASE_RUN)
     hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
-  if (!(opt(OPT_DEV) & 32))      // default: four waves, S2 inside the gate waves (dev bit 5: the eight-wave kernel, A/B)
-    hipLaunchKernelGGL((k_gru_fwd_f10v<S>), dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0, packed_hid,
+  if (!(opt(OPT_DEV) & 32)) {    // default: four waves, S2 inside the gate waves (dev bit 5: the eight-wave kernel, A/B)
+    auto kern = out ? k_gru_fwd_f10v<S, true> : k_gru_fwd_f10v<S, false>;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0, packed_hid,
                        wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr, (bf16_t*)out, (bf16_t*)hT,
                        reserve);
-  else
+  } else
   hipLaunchKernelGGL((k_gru_fwd_f10<S>), dim3(rs.B), dim3(FAST_NT), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0,
                      packed_hid, wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr,
                      (bf16_t*)out, (bf16_t*)hT, reserve);
@@ -909,16 +911,6 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R8L>();
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R16L>();
   return 0;
-}
-
-// does launch_rnn_fwd_f10 take the four-wave kernel (the one that can leave `out` unwritten) for this launch?  Mirrors launch_f10.
-bool f10_out_optional(const RnnShape& rs, int dtype, bool training) {
-  if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_NO_F10) || opt(OPT_F10_NB1)) return false;
-  if (training) return false;           // the backward pass reads `out` (h_{t-1} rows of the hidden matrix's weight gradient)
-  const int cus = device_cu_count();
-  if (rs.B > cus && opt(OPT_F10_NB2)) return false;
-  if (shape_matches<ShpH256R8L>(rs.hid_s)) return true;
-  return shape_matches<ShpH256R16L>(rs.hid_s) && 2 * rs.B > cus;
 }
 
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {

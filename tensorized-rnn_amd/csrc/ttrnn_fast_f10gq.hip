@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(GQ_W * 64) k_gru_fwd_f10gq(int B, int T, GinSr
       if (own[s]) {
         if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid[s]) * 4) = f32x4{rg, zg, ng, hn};
         const bf16_t hb = f32_to_bf16(hy);            // rounded once: stored, fed back, kept as state
-        out[bt * H + hid[s]] = hb;
+        if (out) out[bt * H + hid[s]] = hb;
         hy = bf16_to_f32(hb);
         hst[s] = hy;
         hq[hid[s]] = (__bf16)hy;

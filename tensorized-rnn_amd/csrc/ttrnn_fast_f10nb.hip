@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
         if (in1) xq[sm].advance(xs, bs[sm] * T, T, t, lane);
       }
       TT_STAMP(3)
-    } else if (wave == FAST_NW - 1 && t > 0) {
+    } else if (wave == FAST_NW - 1 && t > 0 && out) {      // out == NULL: final state only
       // outputs[:, t-1, :] = h_{t-1} (lstm.py:133): an idle wave streams the complete vector out, 16 bytes per lane
 #pragma unroll
       for (int sm = 0; sm < NB; ++sm) {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10_nb(int B, int T, GinSr
 #pragma unroll
   for (int sm = 0; sm < NB; ++sm) {
     if (!live[sm]) continue;
-    if (T > 0 && wave == FAST_NW - 1) {
+    if (T > 0 && wave == FAST_NW - 1 && out) {
       const float* hlast = hbuf[sm] + (T & 1) * H;
 #pragma unroll
       for (int h4 = lane; h4 < H / 4; h4 += 64)

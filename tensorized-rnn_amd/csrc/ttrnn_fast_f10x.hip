@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10x(int B, int T, GinSrc 
         if (!in1 && t + 1 < T) gi = *reinterpret_cast<const f32x4*>(gin + ((bt + 1) * H + hd) * 4);
       }
       if (in1) xq.advance(xs, b * T, T, t, lane);
-    } else if (wave == FAST_NW - 1 && t > 0) {
+    } else if (wave == FAST_NW - 1 && t > 0 && out) {      // out == NULL: final state only
       // outputs[:, t-1, :] = h_{t-1} (lstm.py:133)
 #pragma unroll
       for (int h4 = lane; h4 < H / 4; h4 += 64)
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10x(int B, int T, GinSrc 
     }
     lds_barrier();
   }
-  if (T > 0 && wave == FAST_NW - 1) {
+  if (T > 0 && wave == FAST_NW - 1 && out) {
     const float* hlast = hbuf + (T & 1) * H;
 #pragma unroll
     for (int h4 = lane; h4 < H / 4; h4 += 64)

@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
           }
           hy = round_to(hy, out);                        // the stored value is what the next step and the next layer see
-          st(out, bt * H + hid, hy);
+          if (out) st(out, bt * H + hid, hy);            // out == NULL: final state only (ttrnn_rnn_out_optional)
           hst[u] = hy;
           {
             _Float16 p0, p1;

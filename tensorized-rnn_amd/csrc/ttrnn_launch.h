@@ -127,7 +127,6 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream, int phase = 0);
 
-bool f10_out_optional(const RnnShape& rs, int dtype, bool training);      // may `out` be NULL for this launch?
 // the bf16 GRU as four-wave workgroups with in-lane gates (ttrnn_fast_f10gq.hip); ws: f10gq_workspace_bytes
 size_t f10gq_workspace_bytes();
 bool f10gq_available(const RnnShape& rs, int dtype);

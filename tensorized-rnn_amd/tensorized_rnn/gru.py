@@ -72,17 +72,20 @@ class GRU(FusedRnnBase):
     def init_hidden(self, batch_size):
         return torch.zeros(batch_size, self.hidden_size).to(self.device)
 
-    def forward(self, input, init_states=None):
+    def forward(self, input, init_states=None, need_outputs=True):
         """
         :param input:       (batch_size, seq_len, input_size)
         :param init_states: optional h (batch_size, hidden_size); seeds every layer.
+        :param need_outputs: extension to the reference's signature (as LSTM.forward): False under torch.no_grad() tells the
+                 last layer that only the final state is consumed (mnist_classifier.py:52-55 classifies the last step) —
+                 `outputs` is then None and the [B, T, H] store is skipped.
         :return: outputs (batch_size, seq_len, hidden_size) of the last layer and its final h.
         """
         if self._needs_stepping():
             h = self.init_hidden(input.shape[0]) if init_states is None else init_states
             outputs, hT, _ = self._forward_stepwise(input, h.to(input.dtype), None)
         else:
-            outputs, hT = self._forward_fused(input, init_states, None)
+            outputs, hT = self._forward_fused(input, init_states, None, need_outputs)
         return outputs, hT
 
 

@@ -786,32 +786,61 @@ def test_gru_four_wave_kernel_matches_eight_wave_kernel_and_oracle():
             assert torch.isfinite(a).all() and _maxabs(a, bq) <= 3e-2 * max(float(bq.abs().max()), 1e-6), n
 
 
-def test_last_layer_outputs_can_be_skipped_in_inference():
-    """need_outputs=False (speaker_encoder.py:80-86 consumes only the last hidden state): under no_grad the last layer's
-    four-wave fused-core kernel does not write `out` (ttrnn_rnn_out_optional); final states must be bit-identical to the
-    ordinary call, with and without prepared weights; routes that cannot skip the store return the outputs as usual, and
-    autograd runs ignore the flag."""
+_SKIP_OUT_CASES = {
+    "fused_core_r16_b300": (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16), 300, 7, "f32"),
+    "fused_core_r16_b6_eight_waves": (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=1, n_cores=3, tt_rank=16), 6, 9, "f32"),
+    "fused_core_r8_in1": (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 6, 30, "f32"),
+    "fused_core_gru_bf16": (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, "bf16"),
+    "stagewise_h128_r4": (dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), 5, 20, "f32"),
+    "runtime_mfma_lstm": (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, "f32"),
+    "runtime_mfma_gru_2layers": (dict(kind="ttgru", input_size=28, hidden_size=128, num_layers=2, n_cores=3, tt_rank=4), 4, 7, "f32"),
+    "merged_big_pair": (dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32), 3, 5, "f32"),
+    "merged_big_pair_bf16": (dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32), 3, 5, "bf16"),
+    "merged_big_single_b130": (dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32), 130, 2, "f32"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_SKIP_OUT_CASES))
+def test_last_layer_outputs_can_be_skipped_in_inference(case):
+    """need_outputs=False (speaker_encoder.py:80-86 consumes only the last hidden state, mnist_classifier.py:52-55 only the
+    last step): under no_grad the last layer does not write `out` (ttrnn_rnn_out_optional: every route guards the store since
+    round 3 — fused-core four- and eight-wave kernels, the bf16 GRU kernel, stage-wise, runtime-shape, merged-big pair and
+    single-workgroup kernels, any-shape VALU kernels and both math modes); the final states must be bit-identical to the
+    ordinary call, with and without prepared weights; autograd runs ignore the flag (the backward pass reads `out`)."""
     import ctypes
+    import ttrnn_hip
     from ttrnn_hip import _lib
     torch.manual_seed(8)
-    for meta, B, T, optional in ((dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16), 300, 7, 1),
-                                 (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 6, 30, 1),
-                                 (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0)):
-        m = build_module(meta, dev()).eval()
-        x = torch.randn(B, T, meta["input_size"], device=dev())
-        desc = m._all_layers[-1]._layer_spec().desc(B, T, 0)
-        assert _lib.load().ttrnn_rnn_out_optional(ctypes.byref(desc)) == optional
-        with torch.no_grad():
-            ref_out, (rh, rc) = m(x)
-            out, (h, c) = m(x, need_outputs=False)
-            assert (out is None) == bool(optional)
-            assert torch.equal(h, rh) and torch.equal(c, rc)
+    meta, B, T, storage = _SKIP_OUT_CASES[case]
+    lstm = meta["kind"] == "ttlstm"
+    m = build_module(meta, dev()).eval()
+    x = torch.randn(B, T, meta["input_size"], device=dev())
+    if storage == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+    desc = m._all_layers[-1]._layer_spec().desc(B, T, 0 if storage == "f32" else 1)
+    assert _lib.load().ttrnn_rnn_out_optional(ctypes.byref(desc)) == 1
+    states = (lambda r: r[1]) if lstm else (lambda r: (r[1],))
+    settings = [dict()] + ([dict(fp32_math="exact")] if storage == "f32" else []) + [dict(force_generic=1)]
+    for setting in settings:
+        ctx = ttrnn_hip.fp32_math(setting["fp32_math"]) if "fp32_math" in setting else \
+            (ttrnn_hip.option("force_generic", 1) if "force_generic" in setting else contextlib.nullcontext())
+        with ctx, torch.no_grad():
+            ref = m(x)
+            res = m(x, need_outputs=False)
+            assert res[0] is None and ref[0] is not None, setting
+            for a, b_ in zip(states(res), states(ref)):
+                assert torch.equal(a, b_), setting
             m.prepare_for_inference()
-            out2, (h2, c2) = m(x, need_outputs=False)
-            assert (out2 is None) == bool(optional) and torch.equal(h2, rh) and torch.equal(c2, rc)
+            res2 = m(x, need_outputs=False)
+            assert res2[0] is None
+            for a, b_ in zip(states(res2), states(ref)):
+                assert torch.equal(a, b_), setting
             m.release_prepared()
-        out3, _ = m(x, need_outputs=False)               # recording: the backward pass needs the outputs
-        assert out3 is not None and torch.equal(out3, ref_out)
+    with torch.no_grad():
+        ref = m(x)
+    out3 = m(x, need_outputs=False)[0]               # recording: the backward pass needs the outputs
+    assert out3 is not None and torch.equal(out3, ref[0])
 
 
 def test_prepared_weights_inference_matches_and_tracks_updates():
