@@ -30,6 +30,7 @@ constexpr int G3_TF = 256, G3_TR = 256, G3_BK = 32;
 constexpr int G3_PL = 256 * G3_BK;                       // fp16 elements per piece tile (16 KB)
 constexpr int G3_STAGE = 4 * G3_PL;                      // W piece 0, W piece 1, x piece 0, x piece 1
 constexpr size_t G3_LDS = (size_t)2 * G3_STAGE * sizeof(_Float16);      // 128 KB
+constexpr size_t G3_LDS_P = G3_LDS + 2 * 768 * sizeof(float);            // + the persistent kernel's epilogue constants
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int g3_expo(float x) {        // x < 2^e; zero / non-finite: neutral (as ttrnn_fast_gemm.hip:g_expo)
@@ -313,6 +314,198 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3h(int64_t n_rows, int64_t n_pa
   }
 }
 
+// ---- the same GEMM as a PERSISTENT kernel (default; option `dev` bit 6 selects k_gemm3h<., 0> for A/B) --------------------------------
+// One workgroup per CU walks over the tiles vb = blockIdx.x, + gridDim.x, ... of k_gemm3h's launch grid (same tile <-> XCD
+// mapping: the stride is a multiple of 8).  What the non-persistent kernel pays per tile — the wait for its 256 KB of output
+// stores before the workgroup may retire, the launch of the next workgroup, the latency of its first stage's DMAs with nothing
+// else running on the CU — is hidden here: the LAST stage of a tile issues the DMAs of the NEXT tile's first stage (the
+// other stage buffer is free by then), the epilogue's 32 stores per lane go out behind them, and the next tile's first stage
+// waits with `s_waitcnt vmcnt(32)`: vector-memory operations complete in issue order (MI355X guide, s_waitcnt), so at most
+// the 32 younger stores are still in flight when the wait returns — the DMAs have landed, the stores drain under the next
+// tile's first MFMAs.  (A tile with fewer than 32 stores per lane — the last row tile, the harness's no-store experiment — is
+// followed by a plain vmcnt(0).)
+template <typename TS, bool MT8>
+__global__ void __launch_bounds__(FAST_NT) k_gemm3p(int64_t n_rows, int64_t n_pad, int KCn, int M, int nblk,
+                                                    const _Float16* __restrict__ wpl, const _Float16* __restrict__ xpl,
+                                                    const float* __restrict__ wsc, const float* __restrict__ rowsc,
+                                                    const TS* __restrict__ bias, int Hb, const float* __restrict__ bias_ilv,
+                                                    float* __restrict__ y, int dev) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  _Float16* lds = reinterpret_cast<_Float16*>(smem3);
+  // behind the two stage buffers: the epilogue's per-tile constants, double-buffered by tile parity — [256] inverse column
+  // scales, [256] bias values (feature order), [256] inverse row scales.  They are fetched with ONE global load per thread
+  // during the previous tile's last stage, so that the epilogue itself issues nothing but stores to the vector-memory queue
+  // (a load between the stores would make the wave wait for every store before it)
+  float* par = reinterpret_cast<float*>(smem3 + G3_LDS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int MT = M / G3_TF;
+  const int RT = (int)(n_pad / G3_TR);
+  // tile of virtual block vb: k_gemm3h's mapping (MT8: 8 x 4 tile blocks per XCD; few feature tiles: a row tile's feature tiles
+  // on one XCD).  32-bit scalars throughout: with 64-bit tile indices the scalar registers ran out and the DMA addresses moved
+  // into vector registers, which then spilled
+  auto tile_of = [&](int vb, int& mt_tile, int& rt_tile) -> bool {
+    const int xcd = vb & 7, i = vb >> 3;
+    if constexpr (MT8) {
+      const int g = (i >> 5) * 8 + xcd, within = i & 31, smc = MT >> 3;
+      mt_tile = (g % smc) * 8 + (within & 7);
+      rt_tile = (g / smc) * 4 + (within >> 3);
+    } else {
+      rt_tile = (i / MT) * 8 + xcd;
+      mt_tile = i % MT;
+    }
+    return rt_tile < RT;
+  };
+  const int stride = (int)gridDim.x;
+  int vb = (int)blockIdx.x;
+  int mt_tile = 0, rt_tile = 0;
+  while (vb < nblk && !tile_of(vb, mt_tile, rt_tile)) vb += stride;
+  if (vb >= nblk) return;
+  const int wm = wave & 1, wr = wave >> 1;               // wave tile: features [128 wm, +128) x rows [64 wr, +64)
+  const int srow = tid >> 2;
+  const unsigned lane_src = (unsigned)(srow * 32 + 8 * ((tid & 3) ^ ((-(srow >> 2)) & 3)));      // the thread's 16 bytes inside a [256][32] piece tile
+  const unsigned lane_src1 = lane_src + 128u * 32u;              // rows 128 .. 255 of the piece tile
+  const size_t wplane = (size_t)KCn * M * 32, xplane = (size_t)KCn * n_pad * 32;
+  // (uniform tile offsets + one 32-bit lane offset: the DMAs take their base from scalar registers)
+  auto stage_dma = [&](int mt, int rt, int buf, int kc) {
+    _Float16* dst = lds + buf * G3_STAGE + wave * 512;
+    const _Float16* ws = wpl + ((size_t)kc * M + (size_t)mt * G3_TF) * 32;
+    const _Float16* xs = xpl + ((size_t)kc * n_pad + (size_t)rt * G3_TR) * 32;
+    // (opaque to the optimiser: otherwise the eight per-DMA bases are hoisted out of the stage loop — sixteen scalar registers
+    // per tile flavour; the scalar file overflowed into vector registers and those spilled)
+    asm volatile("" : "+s"(ws), "+s"(xs));
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        g3_dma16((ws + p * wplane) + (j ? lane_src1 : lane_src), dst + p * G3_PL + j * 4096);
+        g3_dma16((xs + p * xplane) + (j ? lane_src1 : lane_src), dst + (2 + p) * G3_PL + j * 4096);
+      }
+  };
+  // the tile's epilogue constants: three loads per thread under uniform control flow only (feature f's column scale and bias,
+  // row f's scale; both halves of the workgroup load the same 256 of each — divergent branches around the loads made the
+  // compiler wait for each load where the branches join, i.e. inside the stage that issued it)
+  auto par_load = [&](int mt, int rt, float& v0, float& v1, float& v2) {
+    const unsigned f = (unsigned)tid & 255u;
+    const float* wsc_t = wsc + (size_t)mt * G3_TF;
+    const float* rs_t = rowsc + (size_t)rt * G3_TR;
+    const int64_t left = n_rows - 1 - (int64_t)rt * G3_TR;                  // >= 0 for every tile that exists
+    const unsigned last = left > 255 ? 255u : (unsigned)left;
+    const unsigned mf = (unsigned)mt * G3_TF + f, hd = mf >> 2, sl = mf & 3u;       // gate-interleaved columns: slots i,g,f,o of unit hd
+    const unsigned bi = (sl == 0 ? 0u : sl == 1 ? 2u * Hb : sl == 2 ? (unsigned)Hb : 3u * Hb) + hd;
+    v0 = wsc_t[f];
+    v1 = rs_t[f < last ? f : last];
+    v2 = 0.f;
+    if (bias) v2 = ld(bias, bi);
+    else if (bias_ilv) v2 = bias_ilv[mf];
+  };
+  // (the reciprocals are taken HERE, a stage after the loads were issued)
+  auto par_store = [&](int slot, float v0, float v1, float v2) {
+    float* ps = par + slot * 768;
+    if (tid < 256) {
+      ps[tid] = 1.0f / v0;                                         // [0, 256): inverse column scales
+      ps[512 + tid] = 1.0f / v1;                                   // [512, 768): inverse row scales
+    } else {
+      ps[tid] = v2;                                                // [256, 512): bias
+    }
+  };
+  // fragment offsets: x_off<32>(row + 16 i, 8 q) = x_off<32>(row, 8 q) + 512 i (the swizzle has period 4 in row >> 2), so one
+  // register per operand and immediate offsets in the reads (the twelve separate offsets of k_gemm3h cost this kernel spills —
+  // and a spill reload is a vector-memory operation whose wait would also wait for the previous tile's stores)
+  const int aoff0 = x_off<G3_BK>(wm * 128 + c, 8 * q), boff0 = x_off<G3_BK>(wr * 64 + c, 8 * q);
+
+  // (Tried on top, no gain: starting the workgroups of a CU quadruple a quarter of a tile apart, so that the chip does not
+  // alternate between 256 CUs multiplying and 256 CUs storing — 2.89 against 2.82 ms at cfg5's size; non-temporal stores — 2.87.)
+  {
+    float v0, v1, v2;
+    par_load(mt_tile, rt_tile, v0, v1, v2);
+    par_store(0, v0, v1, v2);                                        // visible behind the first stage's barrier
+  }
+  stage_dma(mt_tile, rt_tile, 0, 0);
+  bool counted = false;                 // the previous tile of this workgroup left exactly 32 stores per lane behind its DMAs
+  int slot = 0;
+  for (;;) {
+    const int m0 = mt_tile * G3_TF;
+    const int64_t n0 = (int64_t)rt_tile * G3_TR;
+    // the next tile of this workgroup (its first stage and its constants are requested during this tile's last stage)
+    int nvb = vb + stride;
+    int nmt = 0, nrt = 0;
+    bool has_next = false;
+    while (nvb < nblk && !(has_next = tile_of(nvb, nmt, nrt))) nvb += stride;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) acc[mi][ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nv0 = 1.f, nv1 = 1.f, nv2 = 0.f;
+    for (int kc = 0; kc < KCn; ++kc) {
+      const int buf = kc & 1;
+      // stage kc has landed (this wave's DMAs: vmcnt; everybody's: the barrier), and nobody reads the other buffer any more
+      if (kc == 0 && counted) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kc + 1 < KCn) {
+        stage_dma(mt_tile, rt_tile, buf ^ 1, kc + 1);
+        if (kc + 2 == KCn && has_next) par_load(nmt, nrt, nv0, nv1, nv2);      // the next tile's constants: back by the last stage
+      } else if (has_next) {
+        stage_dma(nmt, nrt, buf ^ 1, 0);                 // KCn is even: buf ^ 1 == 0, where every tile starts; only stores follow
+      }
+      const _Float16* Ws = lds + buf * G3_STAGE;
+      const _Float16* Xs = Ws + 2 * G3_PL;
+      xh8 bf[4][2];
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[ri][p] = *reinterpret_cast<const xh8*>(Xs + p * G3_PL + boff0 + 512 * ri);
+      xh8 af[8][2];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) af[mi][p] = *reinterpret_cast<const xh8*>(Ws + p * G3_PL + aoff0 + 512 * mi);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          f32x4& a = acc[mi][ri];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][1], bf[ri][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][0], bf[ri][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][0], bf[ri][0], a, 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (has_next) par_store(slot ^ 1, nv0, nv1, nv2);          // read two barriers from now (the next tile's epilogue)
+    // ---- epilogue: lane (c, q) of tile (mi, ri) holds features m0 + 128 wm + 16 mi + 4 q .. + 3 of row n0 + 64 wr + 16 ri + c ----
+    const float* ps = par + slot * 768;
+    float unr[4];
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) unr[ri] = ps[512 + wr * 64 + 16 * ri + c];
+    const bool full = n0 + G3_TR <= n_rows && !(dev & 2);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int fl = wm * 128 + 16 * mi + 4 * q;
+      const int mf = m0 + fl;
+      const f32x4 unf = *reinterpret_cast<const f32x4*>(ps + fl);
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(ps + 256 + fl);
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) {
+        const int64_t n = n0 + wr * 64 + 16 * ri + c;
+        if (n < n_rows && (!(dev & 2) || acc[mi][ri][0] == 12345.678f)) {
+          const f32x4 v = f32x4{g3_unscale2(acc[mi][ri][0], unf[0], unr[ri]), g3_unscale2(acc[mi][ri][1], unf[1], unr[ri]),
+                                g3_unscale2(acc[mi][ri][2], unf[2], unr[ri]), g3_unscale2(acc[mi][ri][3], unf[3], unr[ri])} + bh;
+          *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = v;
+        }
+      }
+    }
+    if (!has_next) break;
+    counted = full;
+    vb = nvb; mt_tile = nmt; rt_tile = nrt;
+    slot ^= 1;
+  }
+}
+
 size_t al256g3(size_t v) { return (v + 255) & ~(size_t)255; }
 int g3_chunks(int K) { return ((K + 2 * G3_BK - 1) / (2 * G3_BK)) * 2; }          // = ttrnn_fast_gemm.hip:gemm_chunks
 int64_t g3_npad(int64_t n_rows) { return (n_rows + G3_TR - 1) / G3_TR * G3_TR; }
@@ -363,6 +556,21 @@ int launch_gemm3h(int dtype, int64_t n_rows, int K, int M, const void* x, const 
                        (const _Float16*)planes, (const _Float16*)xplanes, (const float*)wsc, (const float*)rs,            \
                        (const TSV*)bias, Hb, bias_ilv, y, opt(OPT_DEV));                                                  \
   } while (0)
+  // default: the persistent kernel (k_gemm3p), one workgroup per CU; dev bit 6: one workgroup per tile (A/B)
+  if (var1 && !(opt(OPT_DEV) & 64) && grid < (int64_t)1 << 30) {
+    const int64_t pgrid = grid < (int64_t)device_cu_count() ? grid : (int64_t)device_cu_count() / 8 * 8;
+#define G3_LAUNCH_P(TSV, MT8V)                                                                                                  \
+  do {                                                                                                                    \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm3p<TSV, MT8V>), G3_LDS_P) != TTRNN_OK) return TTRNN_ERR_LAUNCH;   \
+    hipLaunchKernelGGL((k_gemm3p<TSV, MT8V>), dim3((unsigned)pgrid), dim3(FAST_NT), G3_LDS_P, stream, n_rows, n_pad, KCn, M, (int)grid, \
+                       (const _Float16*)planes, (const _Float16*)xplanes, (const float*)wsc, (const float*)rs,            \
+                       (const TSV*)bias, Hb, bias_ilv, y, opt(OPT_DEV));                                                  \
+  } while (0)
+    if (dtype == TTRNN_F32) { if (MT % 8 == 0) G3_LAUNCH_P(float, true); else G3_LAUNCH_P(float, false); }
+    else { if (MT % 8 == 0) G3_LAUNCH_P(bf16_t, true); else G3_LAUNCH_P(bf16_t, false); }
+#undef G3_LAUNCH_P
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
   if (dtype == TTRNN_F32) { if (var1) G3_LAUNCH(float, 0); else G3_LAUNCH(float, 2); }
   else { if (var1) G3_LAUNCH(bf16_t, 0); else G3_LAUNCH(bf16_t, 2); }
 #undef G3_LAUNCH

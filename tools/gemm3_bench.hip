@@ -43,13 +43,16 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   if (launch_gemm_half_prep(W, K, M, planes, scr, 0) != 0) { printf("prep failed\n"); return 1; }
-  float best[5] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
-  const char* names[5] = {"on-the-fly", "pingpong  ", "lockstep  ", "pp nostore", "ls nostore"};
-  const int NV = 5;
-  for (int r = 0; r < reps + 1; ++r)
-    for (int v = 0; v < NV; ++v) {
+  float best[6] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
+  const char* names[6] = {"on-the-fly", "pingpong  ", "persistent", "ps nostore", "lockstep  ", "ls nostore"};
+  const int devs[6] = {0, 1, 0, 2, 64, 66};      // option `dev`: bit 0 ping-pong, bit 1 no stores, bit 6 one workgroup per tile
+  const int NV = 6;
+  // every variant runs its repetitions back to back (interleaved, a variant's time depended on what its predecessor had left
+  // in the caches: a store-free predecessor made the next one 10 % faster at cfg4's size)
+  for (int v = 0; v < NV; ++v)
+    for (int r = 0; r < reps + 1; ++r) {
       opt_set("no_gemm3", v == 0 ? 1 : 0);
-      opt_set("dev", v == 1 ? 1 : v == 3 ? 3 : v == 4 ? 2 : 0);
+      opt_set("dev", devs[v]);
       CK(hipEventRecord(e0, 0));
       int st = launch_gemm_half(TTRNN_F32, rows, K, M, x, planes, scr, nullptr, M / 4, v == 0 ? y0 : y1, 0, nullptr);
       CK(hipEventRecord(e1, 0));
