@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 4
+#define TTRNN_ABI_VERSION 5
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {

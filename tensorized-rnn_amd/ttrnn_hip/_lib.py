@@ -13,7 +13,7 @@ TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
 PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 BWD_STATS_COLMAX, BWD_STATS_IN1SUMS, BWD_STATS_ROWS = 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
