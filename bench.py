@@ -291,6 +291,10 @@ def main():
                     help="weak: the configuration's batch PER GPU (the headline metric, 'timesteps/sec/GPU (batch=64)'). "
                          "strong: the configuration's batch is the GLOBAL batch, sharded over the ranks (SURVEY.md 8(d): "
                          "cfg4 512 -> 64 per GPU, cfg5 128 -> 16 per GPU at 8 GPUs)")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N",
+                    help="diagnostic, single GPU only: time the shard ONE rank of an N-GPU `--scaling strong` job would get "
+                         "(rank 0's slice of the configuration's batch).  The line is labelled `shard_of`; it is not the "
+                         "headline metric and no scaling number")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward: the headline metric (no_grad forward). train: the reference's training benchmark step "
                          "(benchmarking.py:41-70: classifier forward + nll_loss + BPTT + Adam) + flat-bucket gradient "
@@ -338,6 +342,13 @@ def main():
             raise SystemExit("--scaling strong: global batch {} < {} ranks".format(global_batch, world))
         lo, hi = shard_bounds(global_batch, rank, world)
         w["B"] = hi - lo                              # this rank's contiguous shard of the global batch
+    if args.shard_of > 1:
+        if world != 1 or args.scaling == "strong":
+            raise SystemExit("--shard-of is a single-GPU diagnostic (use --scaling strong under torch.distributed.run for a real job)")
+        from ttrnn_hip.dist import shard_bounds
+        lo, hi = shard_bounds(w["B"], 0, args.shard_of)
+        w["B"] = hi - lo
+        global_batch = w["B"]
     from ttrnn_hip import functional as F
     model = build_model(w, device)
     torch.manual_seed(1111 + rank)
@@ -521,6 +532,9 @@ def main():
                            "benchmarking.py:16-38); `unprepared` = the same steps with every forward rebuilding them"
                            if prepared else None)},
             "sample_timesteps_per_s": global_batch * w["T"] / t_step,
+            "shard_of": (None if args.shard_of <= 1 else
+                         "ONE rank's shard of the configuration's batch under --scaling strong on {} GPUs ({} samples), "
+                         "timed alone on one GPU: a per-rank cost, not a scaling measurement".format(args.shard_of, w["B"])),
             "collectives": (None if dist is None else
                             "{} process group, world {}{}: barrier + MAX all-reduce of the time{}".format(
                                 backend, world, " (forced one-rank group, TTRNN_BENCH_FORCE_DIST=1)" if force_dist and world == 1 else "",
