@@ -182,3 +182,24 @@ def test_bench_strong_scaling_two_ranks_on_one_device():
     assert rec["config"]["global_batch"] == 64 and rec["config"]["per_gpu_batch"] == 32
     assert abs(rec["value"] - 784 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
     assert abs(rec["sample_timesteps_per_s"] - 64 * rec["value"]) <= 1e-6 * rec["sample_timesteps_per_s"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_shard_of_times_one_ranks_strong_scaling_shard():
+    """`bench.py --shard-of 4` (single-GPU diagnostic): rank 0's slice of cfg2's 64 samples under a 4-GPU strong-scaling job —
+    16 samples, labelled `shard_of`, counted as one batch advancing T timesteps per step; refused together with a real
+    multi-rank launch flag."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--shard-of", "4", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=500, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["config"]["per_gpu_batch"] == 16 and rec["config"]["global_batch"] == 16 and rec["n_gpus"] == 1
+    assert "4 GPUs" in rec["shard_of"] and "not a scaling measurement" in rec["shard_of"]
+    assert abs(rec["value"] - 784 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
+    bad = subprocess.run(cmd + ["--scaling", "strong"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                         timeout=500, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "single-GPU diagnostic" in bad.stderr
