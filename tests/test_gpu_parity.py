@@ -359,6 +359,50 @@ def test_empty_and_degenerate_inputs():
         m(torch.zeros(2, 3, 1))                          # CPU tensor: no CPU fallback
 
 
+_DEGENERATE_ROUTES = {
+    "fused_core_lstm": dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),
+    "fused_core_lstm_r16_stack": dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16),
+    "fused_core_gru": dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),
+    "stagewise": dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4),
+    "runtime_mfma_gru": dict(kind="ttgru", input_size=28, hidden_size=128, num_layers=2, n_cores=3, tt_rank=4),
+    "merged_big": dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32),
+}
+
+
+@pytest.mark.parametrize("route", sorted(_DEGENERATE_ROUTES))
+def test_degenerate_shapes_across_routes(route):
+    """The shapes a caller can hand over without thinking (the reference's loops simply run zero or one times,
+    lstm.py:123-133 / gru.py:124-134): an empty batch, a single step, a single sample — on every kernel family, forward
+    against the oracle and one backward pass (finite gradients of the right shapes; single step: against the oracle too)."""
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(17)
+    meta = _DEGENERATE_ROUTES[route]
+    lstm = meta["kind"] == "ttlstm"
+    m = build_module(meta, dev())
+    inp, H, L = meta["input_size"], meta["hidden_size"], meta["num_layers"]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        res = m(torch.zeros(0, 4, inp, device=dev()))
+        assert res[0].shape == (0, 4, H) and (res[1][0] if lstm else res[1]).shape == (0, H)
+    for B, T in ((1, 1), (3, 1), (1, 5)):
+        x = torch.randn(B, T, inp)
+        layers, leaves = O.layers_from_state_dict(sd, L, requires_grad=True)
+        xr = x.clone().requires_grad_(True)
+        ro = (O.lstm_forward(layers, xr) if lstm else O.gru_forward(layers, xr))[0]
+        w = torch.randn(B, T, H)
+        (ro * w).sum().backward()
+        m.zero_grad()
+        xg = x.to(dev()).requires_grad_(True)
+        out = m(xg)[0]
+        (out * w.to(dev())).sum().backward()
+        assert out.shape == (B, T, H) and _maxabs(out.detach(), ro.detach()) <= 1e-5, (route, B, T)
+        assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6), (route, B, T)
+        for name, p in m.named_parameters():
+            ref = leaves[name].grad
+            assert p.grad is not None and p.grad.shape == ref.shape
+            assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), (route, B, T, name)
+
+
 def test_bf16_storage_gradients_vs_fp32_oracle():
     """bf16 storage through the MFMA forward + reverse-time + batched backward kernels (fp32 gate
     gradients against bf16 activations); checked against the fp32 oracle on the bf16-rounded weights."""
