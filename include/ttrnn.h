@@ -196,6 +196,12 @@ typedef struct ttrnn_lin_hints {
   const float* xdy_sum;
   int64_t x_period;
   const void* x_first;
+  const float* dy_rowmax;   /* ABI 5.  fp32[n_rows] or NULL: an UPPER BOUND of max_c |dy[n][c]| per row — with it the input
+                             * gradient dx = dy W^T of a stacked layer runs as a GEMM on two fp16 pieces (three MFMA terms, one
+                             * power-of-two scale per row of dy and per column of W^T) instead of three bf16 pieces (six terms)
+                             * without a pass over dy for its row maxima; the reverse-time kernel knows them
+                             * (TTRNN_BWD_STATS_ROWMAX: the exact maximum of every step's gate gradients is what it scales
+                             * its own operands by). */
 } ttrnn_lin_hints;
 /* 1 if a ttrnn_ttlinear_backward_hinted call with these arguments (d_packed wanted, dx as said, a workspace of
  * ttrnn_ttlinear_workspace bytes) takes a route that honours hints->x_period under the current options. */
@@ -312,6 +318,9 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
  * TTRNN_ERR_UNSUPPORTED.  Hand the rows to ttrnn_ttlinear_backward_hinted. */
 #define TTRNN_BWD_STATS_COLMAX 1
 #define TTRNN_BWD_STATS_IN1SUMS 2
+/* ABI 5: where ttrnn_rnn_backward_stats reports this bit, `stats` must hold [4][G*H] + [B*T] floats: behind the four rows the
+ * kernel leaves max_c |d_gates_in[n][c]| of every row n = b*T + t (the step's exact maximum) — ttrnn_lin_hints::dy_rowmax. */
+#define TTRNN_BWD_STATS_ROWMAX 4
 #define TTRNN_BWD_STATS_ROWS 4
 int ttrnn_rnn_backward_stats(const ttrnn_rnn_desc* desc);
 int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const void* h0, const void* c0,

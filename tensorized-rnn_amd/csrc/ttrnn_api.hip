@@ -268,6 +268,15 @@ static size_t gen_in1_bytes(const TtShape& s) {
   return in1_bwd_bytes(s) + ((plan_ttlinear_bwd(s, 1).ws_bytes + 255) & ~(size_t)255);
 }
 
+// dx = dy W^T on two fp16 pieces (hints->dy_rowmax given): the GEMM's column scales of W^T and row scales of dy, behind the
+// dense-gradient layout of the fused-core shapes (0: that variant is not offered for this call)
+static size_t dense_dx_half_bytes(const TtShape& s, int64_t n_rows) {
+  if (dense_bwd_bytes(s) == 0 || !gemm_split_ok(s.out_size, s.in_size) || !gemm_use_half(n_rows, s.out_size, s.in_size) ||
+      gemm3_ok(n_rows, s.out_size, s.in_size))
+    return 0;
+  return gemm_half_scratch_bytes(n_rows, s.out_size, s.in_size);
+}
+
 size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   TtShape s;
   if (tt_shape_init(&s, w) != TTRNN_OK || n_rows < 0) return 0;
@@ -277,7 +286,7 @@ size_t ttrnn_ttlinear_workspace(const ttrnn_ttm* w, int64_t n_rows) {
   if (s.in_size == 1 && in1_bwd_bytes(s) > ws) ws = in1_bwd_bytes(s);
   const size_t f10w = f10_ttlinear_wgrad_workspace_bytes(s);      // fused-core weight gradients (any math mode)
   if (f10w > ws) ws = f10w;
-  const size_t dnb = dense_bwd_bytes(s);                          // dense-gradient backward of the fused-core shapes
+  const size_t dnb = dense_bwd_bytes(s) + dense_dx_half_bytes(s, n_rows);      // dense-gradient backward of the fused-core shapes
   if (dnb > ws) ws = dnb;
   const size_t bigw = big_ttlinear_bwd_workspace_bytes(s);        // merged-core backward of the big shape
   if (bigw > ws) ws = bigw;
@@ -392,6 +401,17 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
         st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       if (st != TTRNN_OK || !dx) return st;
       st = launch_ttlinear_fwd_fast(s, dtype, true, s.in_size, packed, nullptr, ident, Wd, 0, 0, sm);     // W[j][o]
+      // two fp16 pieces (three MFMA terms instead of six) where the caller hands over the row maxima of dy — the reverse-time
+      // kernel's by-product — and the workspace has room for the scales (cfg4's two stacked layers: 257 -> ~150 us each)
+      const size_t dxh = hints && hints->dy_rowmax ? dense_dx_half_bytes(s, n_rows) : 0;
+      if (dxh > 0 && workspace_bytes >= dense_bwd_bytes(s) + dxh) {
+        void* gscr = wsb + dense_bwd_bytes(s);
+        if (st == TTRNN_OK) st = launch_gemm_half_prep(Wd, s.out_size, s.in_size, planes, gscr, sm, true);
+        if (st == TTRNN_OK)
+          st = launch_gemm_half(TTRNN_F32, n_rows, s.out_size, s.in_size, dy, planes, gscr, nullptr, 0, (float*)dx, sm, nullptr,
+                                hints->dy_rowmax);
+        return st;
+      }
       if (st == TTRNN_OK) st = launch_gemm_split_prep(Wd, s.out_size, s.in_size, planes, sm, true);
       if (st == TTRNN_OK)
         st = launch_gemm_split(TTRNN_F32, n_rows, s.out_size, s.in_size, dy, planes, nullptr, 0, (float*)dx, sm);
@@ -758,7 +778,8 @@ static int bwd_stats_mask(const RnnShape& rs, int dtype) {
   if (force_generic() || opt(OPT_FORCE_G2) || rs.T < 1 || rs.B < 1) return 0;
   if (fast_rnn_bwd_available(rs, dtype) && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) &&
       f10_rnn_bwd_available(rs, dtype))
-    return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0);
+    return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0) |
+           (rs.cell == TTRNN_LSTM && f10bh_available(rs, dtype) ? TTRNN_BWD_STATS_ROWMAX : 0);
   if (!fast_rnn_bwd_available(rs, dtype) && big_rnn_bwd_available(rs, dtype)) return TTRNN_BWD_STATS_COLMAX;
   return 0;
 }

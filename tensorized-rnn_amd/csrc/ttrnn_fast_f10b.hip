@@ -721,6 +721,7 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
     // (the two-piece kernels' prep launch clears the maxima itself)
     if (!ws_half && hipMemsetAsync(stats, 0, (size_t)2 * GH * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
     bs.colmax = reinterpret_cast<unsigned*>(stats);
+    if (ws_half && rs.cell == TTRNN_LSTM) bs.rowmax = stats + (size_t)TTRNN_BWD_STATS_ROWS * GH;      // TTRNN_BWD_STATS_ROWMAX
     if (x_in1 && rs.in == 1) {
       bs.x = x_in1;
       bs.part = reinterpret_cast<float*>((char*)ws + ((f10b_ws_head_bytes(rs, dtype) + 255) & ~(size_t)255));

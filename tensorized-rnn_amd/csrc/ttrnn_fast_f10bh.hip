@@ -342,6 +342,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     {
       const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
       const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      if (bs.rowmax && tid == FAST_NT - 1) bs.rowmax[bt] = mxg;  // by-product: the row maximum of d_gates (dy_rowmax hint of dx)
       float ug;
       const float sg = step_scale(mxg, ug);
       const float s2 = step_scale(mxg * maxl1, u2);              // |dC2| <= maxl1 * mxg: no overflow, whatever the signs

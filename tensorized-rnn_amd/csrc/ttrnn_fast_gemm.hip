@@ -924,14 +924,26 @@ static int launch_gemm_t(int64_t n_rows, int K, int M, const void* x, const void
 // 256-feature workgroup tiles where the matrix is wide enough to keep every CU busy with them
 static bool gemm_wide_tiles(int64_t n_rows, int M) { return M % (2 * GT) == 0 && (M / (2 * GT)) * ((n_rows + GR - 1) / GR) >= 1024; }
 
+// rs[n] = 2^(14 - e), bound[n] < 2^e: the row scales from maxima somebody else measured (the reverse-time kernel's by-product)
+__global__ void __launch_bounds__(256) k_rowmax_scales(const float* __restrict__ bound, int64_t n_rows, float* __restrict__ rs) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < n_rows) rs[n] = ldexpf(1.f, 14 - g_expo(bound[n]));
+}
+
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
-                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv) {
+                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv, const float* rowmax) {
   if (n_rows <= 0) return TTRNN_OK;
   if (gemm3_ok(n_rows, K, M))       // x split once into fp16 planes, both operands by LDS-DMA (ttrnn_fast_gemm3.hip)
     return launch_gemm3h(dtype, n_rows, K, M, x, planes, scratch, (char*)scratch + half_scales_bytes(n_rows, M), bias, Hb, y,
                          stream, bias_ilv);
   float* rs = (float*)scratch + g_rs_off(M);
   const int grid = (int)((n_rows + 3) / 4 < 2048 ? (n_rows + 3) / 4 : 2048);
+  if (rowmax && dtype == TTRNN_F32) {
+    hipLaunchKernelGGL(k_rowmax_scales, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, rowmax, n_rows, rs);
+    return gemm_wide_tiles(n_rows, M)
+               ? launch_gemm_t<float, true, 2>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch)
+               : launch_gemm_t<float, true>(n_rows, K, M, x, planes, bias, Hb, y, stream, bias_ilv, (const float*)scratch);
+  }
   if (dtype == TTRNN_F32) {
     hipLaunchKernelGGL(k_row_scales<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, n_rows, K, rs);
     return gemm_wide_tiles(n_rows, M)

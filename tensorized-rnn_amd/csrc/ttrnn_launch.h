@@ -180,7 +180,8 @@ bool gemm_use_half(int64_t n_rows, int K, int M);
 int launch_gemm_half_prep(const float* WG, int K, int M, void* planes, void* scratch, hipStream_t stream,
                           bool transposed = false);
 int launch_gemm_half(int dtype, int64_t n_rows, int K, int M, const void* x, const void* planes, void* scratch,
-                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv = nullptr);
+                     const void* bias, int Hb, float* y, hipStream_t stream, const float* bias_ilv = nullptr,
+                     const float* rowmax = nullptr);      // rowmax: upper bounds of the rows' maxima (no pass over x for them)
 
 // dense weight gradient dW[in][out] = x^T dy on the fp32 MFMA (ttrnn_fast_gemm.hip); the TT cores' gradients are linear in it
 bool dense_wgrad_ok(int in, int out);
@@ -261,6 +262,7 @@ struct BwdStats {
   const void* x = nullptr;       // [B][T] (storage dtype) or NULL
   float* part = nullptr;         // [B][2][G*H] or NULL
   unsigned* colmax = nullptr;    // = stats rows 0, 1 (zeroed by the launcher) or NULL
+  float* rowmax = nullptr;       // [B*T]: the step's exact max |dg| (TTRNN_BWD_STATS_ROWMAX; two-piece LSTM kernel) or NULL
 };
 int launch_bwd_stats_finish(int cell, int Bn, int GH, const float* part, float* stats, hipStream_t stream);
 size_t bwd_stats_part_bytes(const RnnShape& rs);

@@ -15,6 +15,7 @@ TTRNN_LSTM, TTRNN_GRU = 0, 1
 PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
 ABI_VERSION = 5
 BWD_STATS_COLMAX, BWD_STATS_IN1SUMS, BWD_STATS_ROWS = 1, 2, 4
+BWD_STATS_ROWMAX = 4          # stats = [4][G*H] + [B*T]: the rows' maxima behind the four rows
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TTRNN_LIB_PATH: developer override (A/B-ing two builds of the library in one session); default = the in-tree build
@@ -41,7 +42,7 @@ class RnnDesc(ctypes.Structure):
 class LinHints(ctypes.Structure):
     """struct ttrnn_lin_hints"""
     _fields_ = [("x_colmax", ctypes.c_void_p), ("dy_colmax", ctypes.c_void_p), ("xdy_sum", ctypes.c_void_p),
-                ("x_period", ctypes.c_int64), ("x_first", ctypes.c_void_p)]
+                ("x_period", ctypes.c_int64), ("x_first", ctypes.c_void_p), ("dy_rowmax", ctypes.c_void_p)]
 
 
 _P = ctypes.c_void_p

@@ -220,8 +220,12 @@ def _ttlinear_backward(spec, packed, x2d, dy2d, need_dx, need_dw, need_db, zeroe
         first = hints.get("x_first")
         if first is not None and (first.dtype != x2d.dtype or not first.is_contiguous() or first.device != dev):
             raise ValueError("hint x_first must be a contiguous {} tensor on {}".format(x2d.dtype, dev))
+        rowmax = hints.get("dy_rowmax")
+        if rowmax is not None and (rowmax.dtype != torch.float32 or rowmax.numel() != n or not rowmax.is_contiguous()
+                                   or rowmax.device != dev):
+            raise ValueError("hint dy_rowmax must be a contiguous fp32 tensor of {} elements on {}".format(n, dev))
         hs = _lib.LinHints(_ptr(hints.get("x_colmax")), _ptr(hints.get("dy_colmax")), _ptr(hints.get("xdy_sum")),
-                           int(hints.get("x_period") or 0), _ptr(first))
+                           int(hints.get("x_period") or 0), _ptr(first), _ptr(rowmax))
         hp = ctypes.byref(hs)
     check(lib.ttrnn_ttlinear_backward_hinted(ctypes.byref(spec.desc), _dtype_code(x2d), _dtype_code(dy2d), n, _ptr(packed),
                                              _ptr(x2d), _ptr(dy2d), _ptr(dx), _ptr(dpk), _ptr(db), hp, _ptr(ws), wsb,
@@ -455,7 +459,14 @@ class _TTRnnLayerFn(torch.autograd.Function):
         # by-products of the reverse-time kernel for the weight-gradient step below (column maxima of the gate gradients;
         # input_size == 1: the sums over the rows that ARE that layer's input-weight and bias gradients)
         mask = lib.ttrnn_rnn_backward_stats(ctypes.byref(desc)) if (USE_BWD_STATS and d_state is None) else 0
-        bstats = _alloc((_lib.BWD_STATS_ROWS, G * H), torch.float32, dev) if mask else None
+        # (TTRNN_BWD_STATS_ROWMAX: the rows' maxima of d_gates_in behind the four rows — the dx GEMM's row scales)
+        rowmax = None
+        if mask & _lib.BWD_STATS_ROWMAX:
+            sflat = _alloc((_lib.BWD_STATS_ROWS * G * H + B * T,), torch.float32, dev)
+            bstats = sflat[:_lib.BWD_STATS_ROWS * G * H].view(_lib.BWD_STATS_ROWS, G * H)
+            rowmax = sflat[_lib.BWD_STATS_ROWS * G * H:]
+        else:
+            bstats = _alloc((_lib.BWD_STATS_ROWS, G * H), torch.float32, dev) if mask else None
         in1 = bool(mask & _lib.BWD_STATS_IN1SUMS)
         with _timed("ttrnn_rnn_backward"):
             check(lib.ttrnn_rnn_backward_ex(ctypes.byref(desc), _ptr(out), _ptr(h0), _ptr(c0), _ptr(packed_hid),
@@ -466,7 +477,7 @@ class _TTRnnLayerFn(torch.autograd.Function):
         if d_state is not None:
             ctx.stats.backward(d_state[..., 0], d_state[..., 1] if spec.cell == "lstm" else None)
         if DEBUG_BWD_STATS is not None:
-            DEBUG_BWD_STATS.append((mask, bstats, dg_in, dg_hid))
+            DEBUG_BWD_STATS.append((mask, bstats, dg_in, dg_hid, rowmax))
         # weight / input gradients: two TTLinear backward passes over the B*T rows
         n_in = ctx.n_in
         need_dw_in = any(need[8:8 + n_in])
@@ -486,6 +497,8 @@ class _TTRnnLayerFn(torch.autograd.Function):
             hints_hid = {"dy_colmax": bstats[1], "x_colmax": state_bound}
             if in1 and not need[0]:
                 hints_in["xdy_sum"] = bstats[2]
+            if rowmax is not None and need[0]:
+                hints_in["dy_rowmax"] = rowmax
         use_sums = bool(hints_in and hints_in.get("xdy_sum") is not None)
         dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
                                                dg_in.reshape(B * T, -1), need[0], need_dw_in,

@@ -2050,11 +2050,16 @@ def test_reverse_kernel_by_products_feed_the_weight_gradients(kind, inp, H, d, L
         grads[use] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}
     # (a) the rows against torch reductions of the returned gate gradients (layers run last to first)
     assert len(captured) == L
-    for li, (mask, stats, dg_in, dg_hid) in zip(reversed(range(L)), captured):
+    for li, (mask, stats, dg_in, dg_hid, rowmax) in zip(reversed(range(L)), captured):
         assert mask & 1, "the fused-core reverse kernel should deliver the column maxima for this shape"
         GH = dg_in.shape[-1]
         assert torch.equal(stats[0], dg_in.reshape(-1, GH).abs().amax(0))
         assert torch.equal(stats[1], dg_hid.reshape(-1, GH).abs().amax(0))
+        # TTRNN_BWD_STATS_ROWMAX (two-piece TT-LSTM kernel): every row's maximum, bit for bit — the dx GEMM's row scales
+        assert (rowmax is not None) == bool(mask & 4)
+        assert rowmax is not None or not (kind == "ttlstm" and H == 256 and dtype == "f32")
+        if rowmax is not None:
+            assert torch.equal(rowmax, dg_in.reshape(-1, GH).abs().amax(1))
         if inp == 1 and li == 0:
             assert mask & 2
             xs = x.to(dev()).double().reshape(-1, 1)

@@ -16,10 +16,15 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 # the step = the kernels between the last two launches of the step's first recurrent forward kernel
-marks = [i for i, n in enumerate(names) if 'fwd_f10' in n or 'lstm_fwd' in n or 'gru_fwd' in n or 'g2_fwd' in n]
-per = {}
-lo = marks[-2] if len(marks) >= 2 else 0
-hi = marks[-1]
+# training runs: a step ends with the optimizer's multi-tensor kernels; forward runs: a step = one recurrent forward kernel
+# (single-layer workloads) — the kernels between the last two boundaries
+ends = [i for i, n in enumerate(names) if 'multi_tensor_apply' in n and (i + 1 == len(names) or 'multi_tensor_apply' not in names[i + 1])]
+if len(ends) >= 2:
+    lo, hi = ends[-2] + 1, ends[-1] + 1
+else:
+    marks = [i for i, n in enumerate(names) if 'fwd_f10' in n or 'lstm_fwd' in n or 'gru_fwd' in n or 'g2_fwd' in n]
+    lo = marks[-2] if len(marks) >= 2 else 0
+    hi = marks[-1]
 with open(sys.argv[2], 'w') as out:
     t0 = int(rows[lo]['Start_Timestamp']); prev_end = t0
     for r in rows[lo:hi]:
