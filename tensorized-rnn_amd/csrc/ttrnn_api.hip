@@ -32,7 +32,7 @@ struct OptTable {
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
       else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
-      else if (i == OPT_DEV) val = e ? (atoi(e) & 255) : 0;
+      else if (i == OPT_DEV) val = e ? (atoi(e) & 0xFFFF) : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -61,7 +61,7 @@ int opt_set(const char* name, int value) {
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
   if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
-  if (i == OPT_DEV && (value < 0 || value > 255)) return -1;
+  if (i == OPT_DEV && (value < 0 || value > 0xFFFF)) return -1;
   if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;
@@ -236,7 +236,8 @@ static size_t dense_bwd_f10w(const TtShape& s) { return (f10_ttlinear_wgrad_work
 static size_t dense_bwd_bytes(const TtShape& s) {
   if (f10_ttlinear_wgrad_workspace_bytes(s) == 0 || !dense_wgrad_ok(s.in_size, s.out_size)) return 0;
   return dense_bwd_f10w(s) + gemm_split_identity_bytes(s.in_size) + 2 * gemm_split_dense_bytes(s.in_size, s.out_size) +
-         gemm_split_plane_bytes(s.out_size, s.in_size) + dense_wgrad_scratch_bytes(s.in_size, s.out_size);
+         gemm_split_plane_bytes(s.out_size, s.in_size) + dense_wgrad_scratch_bytes(s.in_size, s.out_size) +
+         proj3_workspace_bytes(s);      // (last: the pull-back of dW to the cores, ttrnn_fast_proj.hip)
 }
 
 // The same dense-gradient backward for shapes WITHOUT a specialised kernel (the callers' side of ttrnn_g2.hip): dW = x^T dy
@@ -245,7 +246,7 @@ static size_t dense_bwd_bytes(const TtShape& s) {
 // rows.  Workspace = [any-shape backward (in rows) | identity | dW | W | planes of W^T | row-range partials | any-shape forward]
 struct GenDense {
   bool ok, dx_ok;
-  size_t lin_bwd, ident, dwd, wd, planes, scratch, lin_fwd, total;
+  size_t lin_bwd, ident, dwd, wd, planes, scratch, lin_fwd, proj, total;
 };
 static GenDense gen_dense(const TtShape& s) {
   GenDense g{};
@@ -260,7 +261,8 @@ static GenDense gen_dense(const TtShape& s) {
   g.planes = g.dx_ok ? gemm_split_plane_bytes(s.out_size, s.in_size) : 0;
   g.scratch = dense_wgrad_scratch_bytes(s.in_size, s.out_size);
   g.lin_fwd = g.dx_ok ? al(plan_ttlinear_fwd(s, s.in_size).ws_bytes) : 0;
-  g.total = g.lin_bwd + g.ident + g.dwd + g.wd + g.planes + g.scratch + g.lin_fwd;
+  g.proj = proj3_workspace_bytes(s);               // d = 3: the pull-back as three small launches (ttrnn_fast_proj.hip)
+  g.total = g.lin_bwd + g.ident + g.dwd + g.wd + g.planes + g.scratch + g.lin_fwd + g.proj;
   return g;
 }
 // input_size == 1 without a specialised kernel: dv + the any-shape backward's own workspace for ONE row
@@ -397,8 +399,13 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
                                                  fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16,
                                                  (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)), hx,
                                                  hdy, shT, shF);
-      if (st == TTRNN_OK)
-        st = launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
+      // pull dW back to the cores: three small fp32 launches (ttrnn_fast_proj.hip) instead of the fused-core weight-gradient
+      // kernel on the unit rows (r = 16: 60 + 24 us -> ~15)
+      if (st == TTRNN_OK) {
+        const size_t pj = proj3_workspace_bytes(s);
+        st = pj > 0 ? launch_proj3(s, packed, dWd, d_packed, wsb + dense_bwd_bytes(s) - pj, sm)
+                    : launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
+      }
       if (st != TTRNN_OK || !dx) return st;
       st = launch_ttlinear_fwd_fast(s, dtype, true, s.in_size, packed, nullptr, ident, Wd, 0, 0, sm);     // W[j][o]
       // two fp16 pieces (three MFMA terms instead of six) where the caller hands over the row maxima of dy — the reverse-time
@@ -477,8 +484,12 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch, hx,
                               hdy, shT, shF);
     if (st == TTRNN_OK) {
-      const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
-      st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
+      if (gd.proj > 0) {
+        st = launch_proj3(s, packed, dWd, d_packed, (char*)lin_fwd + gd.lin_fwd, sm);
+      } else {
+        const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
+        st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
+      }
     }
     if (st != TTRNN_OK || !dx) return st;
     const LinPlan pf = plan_ttlinear_fwd(s, s.in_size);

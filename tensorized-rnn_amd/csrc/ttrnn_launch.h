@@ -274,6 +274,10 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
 // the same on two fp16 pieces per operand (ttrnn_fast_f10bh.hip): the TT-LSTM shapes in split mode (option gemm_pieces = 3:
 // the three-bf16-piece kernel)
 bool f10bh_available(const RnnShape& rs, int dtype);
+// ttrnn_fast_proj.hip: d_packed += the adjoint of (three cores -> dense matrix) applied to dW (fp32 [in][out]); ws:
+// proj3_workspace_bytes (0: not offered for this shape / switched off by option dev bit 10)
+size_t proj3_workspace_bytes(const TtShape& s);
+int launch_proj3(const TtShape& s, const float* packed, const float* dW, float* d_packed, void* ws, hipStream_t stream);
 size_t f10bh_workspace_bytes(const RnnShape& rs);
 int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
                          const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0,
