@@ -431,9 +431,19 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       return launch_ttlinear_wgrad_f10(s, dtype, n_rows, packed, x, dy, dx, d_packed, d_bias, workspace,
                                        (hipStream_t)stream);
     }
-    TT_ROUTE_PLAIN_ROWS();
-    return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
-                                    (hipStream_t)stream);
+    // A shape with stage-wise MFMA kernels but no fused-core weight-gradient kernel (the TT-GRU r = 16 of the speaker encoder's
+    // --gru variant, speaker_encoder.py:69-78): over many rows the dense-gradient route below — one GEMM per gradient, the
+    // pull-back by ttrnn_fast_proj.hip — beats the row-by-row stage-wise backward by an order of magnitude (6 ms -> 0.6 per matrix
+    // at 81 920 rows); until the end of round 3 such shapes never reached it
+    const GenDense gdf = gen_dense(s);
+    const bool gdf_ok = !no_gemm() && gdf.ok && gdf.proj > 0 && d_packed && dy_dtype == TTRNN_F32 && n_rows >= 4 * (int64_t)s.in_size &&
+                        (!dx || (gdf.dx_ok && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT)) && workspace &&
+                        workspace_bytes >= gdf.total;
+    if (!gdf_ok) {
+      TT_ROUTE_PLAIN_ROWS();
+      return launch_ttlinear_bwd_fast(s, dtype, dy_dtype, n_rows, packed, x, dy, dx, d_packed, d_bias,
+                                      (hipStream_t)stream);
+    }
   }
   if (!force_generic() && (d_packed || (dx && !d_bias)) && big_ttlinear_bwd_available(s, dtype, dy_dtype)) {
     // big shape: dx, weight and bias gradients through the merged two-core matrix

@@ -403,6 +403,43 @@ def test_degenerate_shapes_across_routes(route):
             assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), (route, B, T, name)
 
 
+def test_stagewise_shape_takes_the_dense_gradient_route_over_many_rows():
+    """The speaker encoder's --gru variant (speaker_encoder.py:69-78: 3-layer TT-GRU, H = 256, r = 16): a shape with stage-wise
+    MFMA kernels but no fused-core weight-gradient kernel.  Over >= 4 * in rows its TTLinear backward now runs as dense GEMMs
+    (dW = x^T dy, dx = dy W^T) with the pull-back to the cores by ttrnn_fast_proj.hip, like the shapes of the other tiers
+    (before: row by row through the stage-wise kernel, 6 ms per matrix at the experiment's size): every gradient against
+    the oracle, and the two routes (option no_gemm) against each other."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(31)
+    meta = dict(kind="ttgru", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16)
+    m = build_module(meta, dev())
+    B, T = 24, 48                                    # 1 152 rows >= 4 * 256
+    x = torch.randn(B, T, 40) * 0.5
+    w = torch.randn(B, T, 256)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 2, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    ro = O.gru_forward(layers, xr)[0]
+    (ro * w).sum().backward()
+    grads = {}
+    for name, opts in (("dense", {}), ("rows", {"no_gemm": 1})):
+        m.zero_grad()
+        xg = x.to(dev()).requires_grad_(True)
+        with contextlib.ExitStack() as st:
+            for k, v in opts.items():
+                st.enter_context(ttrnn_hip.option(k, v))
+            out = m(xg)[0]
+            (out * w.to(dev())).sum().backward()
+        grads[name] = ({n: p.grad.detach().clone() for n, p in m.named_parameters()}, xg.grad.detach().clone())
+        assert _maxabs(out.detach(), ro.detach()) <= 1e-5
+        assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6), name
+        for n, g in grads[name][0].items():
+            ref = leaves[n].grad
+            assert _maxabs(g, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), (name, n)
+    assert any(not torch.equal(grads["dense"][0][n], grads["rows"][0][n]) for n in grads["dense"][0])      # the switch works
+
+
 def test_bf16_storage_gradients_vs_fp32_oracle():
     """bf16 storage through the MFMA forward + reverse-time + batched backward kernels (fp32 gate
     gradients against bf16 activations); checked against the fp32 oracle on the bf16-rounded weights."""
