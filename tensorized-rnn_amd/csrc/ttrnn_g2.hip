@@ -762,9 +762,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   const int nu_w = wave < m.bU ? (m.bU - wave + NW - 1) / NW : 0;
   const int total = nu_w * m.bKBP;
   const xbf8* sp = bs2 + (size_t)wave * m.bUW * m.bKBP * 3 * 64 + lane;
-  // RES (host: one column tile, bNKB <= 4 and bUW * bNKB <= G2_PF): slot s holds live block (unit s / bNKB, k-block s % bNKB)
+  // RES (host: one column tile, bNKBt <= 4 and bUW * bNKBt <= G2_PF): slot s holds live block (unit s / bNKBt, k-block s % bNKBt)
   // of this wave for the whole launch; otherwise the slots roll over the wave's stream
-  const int r_nlive = RES ? nu_w * m.bNKB : 0;
+  // (block-diagonal heads, ng > 1: a unit's live k-blocks are its gate's bNKBt, not all bNKB)
+  const int r_nlive = RES ? nu_w * m.bNKBt : 0;
   xbf8 wbuf[G2_PF][3];
 #pragma unroll
   for (int j = 0; j < G2_PF; ++j)
@@ -773,7 +774,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
       if constexpr (RES) {
-        const int ui = j / m.bNKB, kb = j - ui * m.bNKB;
+        const int ui = j / m.bNKBt, kb = j - ui * m.bNKBt;
         if (j < r_nlive) wbuf[j][p] = sp[(size_t)(ui * m.bKBP + kb) * 3 * 64 + p * 64];
       } else {
         if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
@@ -876,7 +877,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     // slot is one split block; a unit's accumulators are flushed after its last k-block.  NKB is a compile-time constant
     // inside each instantiation of the body (slot -> k-block must index registers statically).
     auto stageT2res = [&](auto nkb_tag) {
-      constexpr int NKB = decltype(nkb_tag)::value;
+      constexpr int NKB = decltype(nkb_tag)::value;             // live k-blocks per unit (= bNKBt)
       const __bf16* brow = dyimg + c * m.IhS + 8 * q;
       xbf8 bfr[NKB][3];
 #pragma unroll
@@ -890,7 +891,18 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         (void)dummy;
         const int ui = sl / NKB, kb = sl % NKB;
         if (sl < r_nlive) {
-          if (kb == 0) { acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a; }
+          if (kb == 0) {
+            acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a;
+            if (m.ng > 1) {
+              // block-diagonal heads: this unit (row tile wave + ui NW of gate g) multiplies its own gate's i_h range of dy
+              const int kbase = ((16 * (wave + ui * NW)) / m.Kg) * m.bNKBt;
+#pragma unroll
+              for (int k2 = 0; k2 < NKB; ++k2)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                  bfr[k2][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kbase + k2));
+            }
+          }
           split_block(wbuf[sl], bfr[kb], acc_a, acc_b, acc_hi);
           if (kb == NKB - 1) {
             const int off = t2off[(wave + ui * NW) * 4 + q];
@@ -900,9 +912,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       }
     };
     if constexpr (RES) {
-      if (m.bNKB == 1) stageT2res(std::integral_constant<int, 1>{});
-      else if (m.bNKB == 2) stageT2res(std::integral_constant<int, 2>{});
-      else if (m.bNKB == 3) stageT2res(std::integral_constant<int, 3>{});
+      if (m.bNKBt == 1) stageT2res(std::integral_constant<int, 1>{});
+      else if (m.bNKBt == 2) stageT2res(std::integral_constant<int, 2>{});
+      else if (m.bNKBt == 3) stageT2res(std::integral_constant<int, 3>{});
       else stageT2res(std::integral_constant<int, 4>{});
     } else {
       stageT2();
@@ -1152,7 +1164,10 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
-  const bool res = P.hid.ng == 1 && P.hid.N2T == 1 && P.hid.bNKB <= 4 && P.hid.bUW * P.hid.bNKB <= G2_PF;
+  // head^T fragments register-resident: one column tile, <= 4 live k-blocks per unit (ng > 1: a unit's gate range only — the naive
+  // per-gate sets of cfg2's size have ONE live block per unit, eight units per wave: streamed, they re-read eight padded blocks
+  // per unit from L2 every step, 10.6 ms of a 14 ms training step)
+  const bool res = P.hid.N2T == 1 && P.hid.bNKBt <= 4 && P.hid.bUW * P.hid.bNKBt <= G2_PF && !(opt(OPT_DEV) & 2048 && P.hid.ng > 1);
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \
