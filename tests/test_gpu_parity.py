@@ -684,6 +684,11 @@ G2_GRID = [
     # any-shape kernels, both reading / writing the same reserve
     ("ttlstm", 12, 768, 1, 2, 16, 3, 5, None),
     ("ttgru", 12, 1024, 1, 2, 16, 2, 4, None),
+    # ... extra-core shapes of the pMNIST flag space (pmnist_test.py --extra_core last): the first one's reverse-time kernel fits
+    # LDS with NEITHER split point (dC1 image 131 / 139 KB) — forward on the tier, BPTT on the any-shape kernels
+    ("ttlstm", 1, 512, 1, 2, 16, 3, 9, "last"),
+    ("ttgru", 1, 512, 1, 2, 16, 3, 9, "last"),
+    ("ttlstm", 1, 512, 1, 3, 16, 3, 7, "last"),
 ]
 
 
