@@ -927,7 +927,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
         const int k0 = part * m.bKS1P;
         const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
-        const float* bp = dc1 + (16 * nt + c) * m.K1S + q;
+        const int jrow = 16 * nt + c;                                  // rows past J_h: any real row (their results are dropped)
+        const float* bp = dc1 + (jrow < m.Jh ? jrow : m.Jh - 1) * m.K1S + q;
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         const int fbase = mt * m.bKS1 * 64 + lane;
         for (int ks0 = k0; ks0 < k1; ks0 += 8) {               // eight k-steps' operands in flight, two accumulator chains
