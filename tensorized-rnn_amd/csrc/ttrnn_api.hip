@@ -802,6 +802,11 @@ static int bwd_stats_mask(const RnnShape& rs, int dtype) {
     return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0) |
            (rs.cell == TTRNN_LSTM && f10bh_available(rs, dtype) ? TTRNN_BWD_STATS_ROWMAX : 0);
   if (!fast_rnn_bwd_available(rs, dtype) && big_rnn_bwd_available(rs, dtype)) return TTRNN_BWD_STATS_COLMAX;
+  // the runtime-shape reverse-time kernel (the route ttrnn_rnn_backward_ex takes when neither of the above exists): the column
+  // maxima where its LDS plan has room for them
+  if (!fast_rnn_bwd_available(rs, dtype) && !big_rnn_bwd_available(rs, dtype) && g2_rnn_bwd_available(rs, dtype) &&
+      g2_rnn_bwd_colmax(rs))
+    return TTRNN_BWD_STATS_COLMAX;
   return 0;
 }
 
@@ -856,7 +861,7 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   if (!force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
-                             d_h0, d_c0, workspace, (hipStream_t)stream, d_state);
+                             d_h0, d_c0, workspace, (hipStream_t)stream, d_state, stats);
   }
   const RnnPlan p = plan_rnn_generic(rs, true);
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

@@ -163,6 +163,8 @@ struct G2Plan {
   int f_hb, f_img, f_ybuf, f_tab, f_sc, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_sc: the inverse output scales
                                                      // [I_h | I_t] floats; f_t1: tail fragments (0: from L2)
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
+  int b_cmx;                                   // running column maxima of the gate gradients [G*H (+ H: GRU's hidden-side n)] floats, behind
+                                               // everything else; 0 = no room (the by-product is then not offered for this shape)
 };
 
 inline size_t g2_al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -200,6 +202,15 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   // offered on its own, the reserve format is the same for every route
   p->okf = p->f_lds <= G2_LDS_LIMIT;
   p->okb = p->b_lds <= G2_LDS_LIMIT;
+  // by-product of the reverse-time kernel (TTRNN_BWD_STATS_COLMAX): only where it costs no route
+  p->b_cmx = (int)g2_al((size_t)(rs.G + (rs.cell == TTRNN_GRU ? 1 : 0)) * rs.H * 4);
+  if (!p->okb || p->b_lds + p->b_cmx > G2_LDS_LIMIT) p->b_cmx = 0;
+  if (p->b_cmx > 0) {
+    // ... and no occupancy: four-wave workgroups (B > #CUs) run two per CU where their LDS allows it — 12 KB more took
+    // H = 768, d = 4 from two to one and its training step from 9.9 to 11.9 ms
+    const int w0 = G2_LDS_LIMIT / p->b_lds, w1 = G2_LDS_LIMIT / (p->b_lds + p->b_cmx);
+    if (w1 < (w0 < 2 ? w0 : 2)) p->b_cmx = 0;
+  }
   p->ok = p->okf && p->okb;
 }
 

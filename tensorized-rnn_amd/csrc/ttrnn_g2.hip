@@ -712,10 +712,15 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
                                                   const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
                                                   const float* __restrict__ bt1, float* __restrict__ dg_in,
                                                   float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0,
-                                                  float* __restrict__ dstate) {
+                                                  float* __restrict__ dstate, unsigned* __restrict__ colmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
   __bf16* dyimg = reinterpret_cast<__bf16*>(smem);
+  // by-product (colmax != NULL, P.b_cmx > 0): max_n |dg[n][c]| per column, kept per (gate, unit) in LDS by the one thread that
+  // computes that column's gradient every step (no synchronisation needed), handed over with one atomicMax per column at the end:
+  // rows 0 / 1 of ttrnn_rnn_backward_ex's stats (TTRNN_BWD_STATS_COLMAX) — the dense weight gradient then runs on two fp16
+  // pieces at every size, without its passes over dg
+  float* cmx = reinterpret_cast<float*>(smem + P.b_lds);
   float* dc1 = reinterpret_cast<float*>(smem + P.b_dy);
   float* dhb = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1);
   int* dyoff = reinterpret_cast<int*>(smem + P.b_dy + P.b_dc1 + P.b_dh);
@@ -733,6 +738,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   constexpr int NG = LSTM ? 4 : 3;
 
   for (int e = tid; e < (P.b_dy + P.b_dc1 + P.b_dh) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  if (colmax)
+    for (int e = tid; e < P.b_cmx / 4; e += NT) cmx[e] = 0.f;
   for (int o = tid; o < GH; o += NT) {
     const int ih = o / m.It, it = o - ih * m.It;
     dyoff[o] = it * m.IhS + ih;
@@ -824,6 +831,11 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             p[2] = dn_pre;                                  // w.r.t. the input part of n
             ph2 = dn_pre * rg;                              // w.r.t. the hidden part of n (inside the r * (...) product)
             dhd[u] = dht * zg;
+          }
+          if (colmax) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) cmx[g * H + hid] = fmaxf(cmx[g * H + hid], fabsf(p[g]));
+            if (!LSTM) cmx[NG * H + hid] = fmaxf(cmx[NG * H + hid], fabsf(ph2));
           }
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
@@ -968,6 +980,15 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
         if (d_h0) st(d_h0, b * H + hid, dht);
         if (LSTM && d_c0) st(d_c0, b * H + hid, dcs[u]);
+        if (colmax) {
+          // row 0: d_gates_in; row 1: d_gates_hid (LSTM: the same tensor; GRU: the n gate's hidden-side gradient differs)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const float v = cmx[g * H + hid];
+            atomicMax(colmax + g * H + hid, __float_as_uint(v));
+            atomicMax(colmax + GH + g * H + hid, __float_as_uint((!LSTM && g == 2) ? cmx[NG * H + hid] : v));
+          }
+        }
       }
     }
 }
@@ -1160,11 +1181,14 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
 template <typename TS>
 static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const void* h0, const void* c0, const float* packed_hid,
                  const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
-                 void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate) {
+                 void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate, float* stats) {
   const xbf8* bs2;
   const float* bt1;
   int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
   if (st != TTRNN_OK) return st;
+  unsigned* colmax = (stats && P.b_cmx > 0) ? reinterpret_cast<unsigned*>(stats) : nullptr;
+  if (colmax && hipMemsetAsync(colmax, 0, (size_t)2 * rs.G * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  const size_t lds_b = (size_t)P.b_lds + (colmax ? P.b_cmx : 0);
   // head^T fragments register-resident: one column tile, <= 4 live k-blocks per unit (ng > 1: a unit's gate range only — the naive
   // per-gate sets of cfg2's size have ONE live block per unit, eight units per wave: streamed, they re-read eight padded blocks
   // per unit from L2 every step, 10.6 ms of a 14 ms training step)
@@ -1172,10 +1196,10 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.b_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
-    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.b_lds, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,   \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_b) != TTRNN_OK) return TTRNN_ERR_LAUNCH;          \
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), lds_b, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,     \
                        reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
-                       (TS*)d_c0, dstate);                                                                                \
+                       (TS*)d_c0, dstate, colmax);                                                                        \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
     if (P.upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
@@ -1192,13 +1216,21 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
 
 int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
-                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate) {
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate, float* stats) {
   G2Plan P;
   g2_plan(&P, rs, rs.B <= device_cu_count());
   if (!P.okb) return TTRNN_ERR_UNSUPPORTED;
+  if (stats && P.b_cmx == 0) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
-             ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate)
-             : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate);
+             ? bwd_t<float>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate, stats)
+             : bwd_t<bf16_t>(rs, P, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, dstate, stats);
+}
+
+// does the reverse-time kernel of this shape deliver the column maxima (room for them in LDS)?
+bool g2_rnn_bwd_colmax(const RnnShape& rs) {
+  G2Plan P;
+  g2_plan(&P, rs, rs.B <= device_cu_count());
+  return P.okb && P.b_cmx > 0;
 }
 
 }  // namespace ttrnn

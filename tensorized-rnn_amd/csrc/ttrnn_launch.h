@@ -243,7 +243,9 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
                       float* reserve, void* workspace, hipStream_t stream);
 int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0, const float* packed_hid,
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
-                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate = nullptr);
+                      float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate = nullptr,
+                      float* stats = nullptr);
+bool g2_rnn_bwd_colmax(const RnnShape& rs);      // TTRNN_BWD_STATS_COLMAX from the runtime-shape reverse-time kernel?
 
 // shape-specialised reverse-time kernel (ttrnn_fast_bwd.hip)
 bool fast_rnn_bwd_available(const RnnShape& rs, int dtype);

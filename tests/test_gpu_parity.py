@@ -2041,6 +2041,8 @@ def test_dense_gemm_error_vs_fp64_is_fp32_class():
     ("ttgru", 1, 256, 3, 1, 8, 70, 20, "bf16", False),         # cfg3 class
     ("ttgru", 1, 256, 3, 1, 8, 70, 20, "f32", True),           # h0 given, entries up to ~60: the state bound is max(1, |h0|)
     ("ttlstm", 40, 256, 3, 2, 16, 48, 27, "f32", False),       # cfg4 class: maxima only, stacked layer's input bounded by 1
+    ("ttlstm", 40, 512, 3, 1, 8, 32, 40, "f32", False),         # runtime-shape tier (the reference's default size): maxima kept in LDS
+    ("ttgru", 28, 128, 3, 2, 4, 40, 30, "f32", True),          # runtime-shape tier, GRU (rows 0 and 1 differ in the n gate), two layers
     ("ttlstm", 1024, 1024, 4, 1, 32, 4, 24, "f32", False),     # cfg5 class: merged-big reverse kernels (pair, fp16 pieces)
     ("ttlstm", 1024, 1024, 4, 1, 32, 3, 10, "bf16", False),
 ])
