@@ -314,7 +314,7 @@ int ttrnn_rnn_backward(const ttrnn_rnn_desc* desc, const void* out, const void* 
  *                       the kernel, then over the samples in a fixed order: repeatable bit for bit)  TTRNN_BWD_STATS_IN1SUMS
  *   x      the layer's input [B][T][1] (storage dtype), needed for rows 2 / 3 only.
  * ttrnn_rnn_backward_stats(desc): bitmask of what the route of this descriptor delivers under the current options (the
- * fused-core reverse kernels do; 0 elsewhere).  Passing stats != NULL where it returns 0, or together with d_state, is
+ * fused-core, merged-big and — where its LDS plan has room — runtime-shape reverse kernels do; 0 elsewhere).  Passing stats != NULL where it returns 0, or together with d_state, is
  * TTRNN_ERR_UNSUPPORTED.  Hand the rows to ttrnn_ttlinear_backward_hinted. */
 #define TTRNN_BWD_STATS_COLMAX 1
 #define TTRNN_BWD_STATS_IN1SUMS 2
