@@ -394,7 +394,9 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       float* dWd = (float*)((char*)ident + gemm_split_identity_bytes(s.in_size));
       float* Wd = (float*)((char*)dWd + gemm_split_dense_bytes(s.in_size, s.out_size));
       void* planes = (char*)Wd + gemm_split_dense_bytes(s.in_size, s.out_size);
-      st = launch_fill_identity(dtype, s.in_size, ident, sm);
+      // (the unit rows feed the dense W of the dx GEMM — and the pull-back only where ttrnn_fast_proj.hip does not do it)
+      const size_t pj = proj3_workspace_bytes(s);
+      if (dx || pj == 0) st = launch_fill_identity(dtype, s.in_size, ident, sm);
       if (st == TTRNN_OK) st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm,
                                                  fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16,
                                                  (float*)((char*)planes + gemm_split_plane_bytes(s.out_size, s.in_size)), hx,
@@ -402,7 +404,6 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       // pull dW back to the cores: three small fp32 launches (ttrnn_fast_proj.hip) instead of the fused-core weight-gradient
       // kernel on the unit rows (r = 16: 60 + 24 us -> ~15)
       if (st == TTRNN_OK) {
-        const size_t pj = proj3_workspace_bytes(s);
         st = pj > 0 ? launch_proj3(s, packed, dWd, d_packed, wsb + dense_bwd_bytes(s) - pj, sm)
                     : launch_ttlinear_wgrad_f10(s, dtype, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, workspace, sm);
       }
@@ -489,7 +490,7 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
     void* planes = p; p += gd.planes;
     float* scratch = (float*)p; p += gd.scratch;
     void* lin_fwd = p;
-    st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
+    if (dx || gd.proj == 0) st = launch_fill_identity(TTRNN_F32, s.in_size, ident, sm);
     if (st == TTRNN_OK)
       st = launch_dense_wgrad(dtype, n_rows, s.in_size, s.out_size, x, (const float*)dy, dWd, d_bias, sm, gd_split, scratch, hx,
                               hdy, shT, shF);
