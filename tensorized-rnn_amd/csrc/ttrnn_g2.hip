@@ -1033,6 +1033,20 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
 // GEMM's epilogue.
 static int in_pad(int in) { return (in + 7) & ~7; }
 
+// The plan of ONE direction: eight-wave workgroups where a sample has a CU to itself (B <= #CUs), four-wave ones otherwise —
+// and four-wave ones also where the eight-wave plan of that direction does not fit LDS but the four-wave plan does (the partial
+// dh vectors of T1's k split are per wave group: naive per-gate sets of H = 512, r = 16 miss the limit by 256 bytes with eight
+// waves; their BPTT ran on the VALU kernels, 320 ... 590 ms per pMNIST step).  The forward and the reverse-time kernel are
+// separate launches: each takes its own plan.
+static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
+  const bool wide = rs.B <= device_cu_count();
+  g2_plan(p, rs, wide);
+  if (!wide || !p->hid.ok || (backward ? p->okb : p->okf)) return;
+  G2Plan q;
+  g2_plan(&q, rs, false);
+  if (q.hid.ok && (backward ? q.okb : q.okf)) *p = q;
+}
+
 static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
@@ -1040,7 +1054,7 @@ static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   // fp32 kernels instead (force_g2 is the A/B override the tests use)
   if (dtype == TTRNN_F32 && opt(OPT_FP32_MATH) == TTRNN_MATH_EXACT && !opt(OPT_FORCE_G2)) return false;
   G2Plan p;
-  g2_plan(&p, rs, rs.B <= device_cu_count());
+  plan_for(&p, rs, backward);
   if (!(backward ? p.okb : p.okf)) return false;
   if (rs.in == 1) return true;
   return gemm_split_ok(in_pad(rs.in), 4 * rs.H);
@@ -1055,7 +1069,7 @@ struct G2FwdWs {
 static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   G2FwdWs w{};
   G2Plan p;
-  g2_plan(&p, rs, rs.B <= device_cu_count());
+  plan_for(&p, rs, false);
   const bool in1 = rs.in == 1;
   const int inp = in_pad(rs.in);
   const int64_t rows = in1 ? 1 : (int64_t)rs.B * rs.T;
@@ -1077,7 +1091,7 @@ size_t g2_rnn_fwd_workspace(const RnnShape& rs) { return g2_fwd_layout(rs).total
 
 size_t g2_rnn_bwd_workspace(const RnnShape& rs) {
   G2Plan p;
-  g2_plan(&p, rs, rs.B <= device_cu_count());
+  plan_for(&p, rs, true);
   return g2_bwd_ws_bytes(p.hid);
 }
 
@@ -1171,7 +1185,7 @@ int launch_rnn_fwd_g2(const RnnShape& rs, int dtype, const void* x, const void* 
                       const void* bias_in, const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT,
                       float* reserve, void* workspace, hipStream_t stream) {
   G2Plan P;
-  g2_plan(&P, rs, rs.B <= device_cu_count());
+  plan_for(&P, rs, false);
   if (!P.okf) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
              ? fwd_t<float>(rs, P, dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace, stream)
@@ -1218,7 +1232,7 @@ int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void
                       const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in,
                       float* dg_hid, void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate, float* stats) {
   G2Plan P;
-  g2_plan(&P, rs, rs.B <= device_cu_count());
+  plan_for(&P, rs, true);
   if (!P.okb) return TTRNN_ERR_UNSUPPORTED;
   if (stats && P.b_cmx == 0) return TTRNN_ERR_UNSUPPORTED;
   return dtype == TTRNN_F32
@@ -1229,7 +1243,7 @@ int launch_rnn_bwd_g2(const RnnShape& rs, int dtype, const void* out, const void
 // does the reverse-time kernel of this shape deliver the column maxima (room for them in LDS)?
 bool g2_rnn_bwd_colmax(const RnnShape& rs) {
   G2Plan P;
-  g2_plan(&P, rs, rs.B <= device_cu_count());
+  plan_for(&P, rs, true);
   return P.okb && P.b_cmx > 0;
 }
 
