@@ -51,6 +51,7 @@ struct G2Mat {
   // reverse T1 (fp32 MFMA): M = Jt (one or more m tiles), N = Jh, K = It*Rp in steps of 4, split over bKS1P parts
   int bM1T, bKS1, bT1, bK1SPLIT, bKS1P, bU1;        // bKS1P = k-steps per part
   int K1S;                          // fp32 dC1 image [16*N1T][K1S]
+  int bNP;                          // reverse-time kernel: passes over the i_t range of dC1 (1; 2 = the image holds HALF of the columns at a time)
   // element counts of the per-launch buffers (workspace)
   long head_elems, tail_elems;      // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
   long fs2_bytes, ft1_bytes;        // forward: head fragment stream (fp16 x 2 planes, scaled), tail fragments (fp32, scaled)
@@ -145,6 +146,7 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
     m->bU1 = m->bT1 * m->bK1SPLIT;
   }
   m->K1S = m->It * m->Rp + 4;
+  m->bNP = 1;
   m->head_elems = (long)m->Ih * m->Jh * m->R;
   m->tail_elems = (long)m->It * m->Jt * m->R;
   m->fs2_bytes = (long)nw * m->UW * m->KBP * 2 * 64 * 16;
@@ -202,6 +204,20 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   // offered on its own, the reserve format is the same for every route
   p->okf = p->f_lds <= G2_LDS_LIMIT;
   p->okb = p->b_lds <= G2_LDS_LIMIT;
+  if (!p->okb && p->hid.It % 32 == 0 && p->hid.N2T % 2 == 0) {
+    // the dC1 image does not fit (H = 1024, d = 2, r = 16: 131 KB of 187): T2 and T1 run in TWO passes over halves of its i_t
+    // range — T2 computes the column tiles of one half (the head stream rolls on through the others), T1 multiplies that half
+    // of its k range and adds to the partial dh.  Twice the head stream, the same products; before: BPTT on the VALU kernels
+    G2Mat& mm = p->hid;
+    mm.bNP = 2;
+    mm.K1S = (mm.It / 2) * mm.Rp + 4;
+    p->b_dc1 = (int)g2_al(((size_t)(mm.Jh < 16 * mm.N1T ? mm.Jh : 16 * mm.N1T) * mm.K1S) * 4);
+    p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
+    p->b_t1 = (mm.bt1_bytes <= 32 * 1024 && p->b_lds + (int)g2_al((size_t)mm.bt1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)mm.bt1_bytes) : 0;
+    p->b_lds += p->b_t1;
+    p->okb = p->b_lds <= G2_LDS_LIMIT;
+    if (!p->okb) { mm.bNP = 1; mm.K1S = mm.It * mm.Rp + 4; }
+  }
   // by-product of the reverse-time kernel (TTRNN_BWD_STATS_COLMAX): only where it costs no route
   p->b_cmx = (int)g2_al((size_t)(rs.G + (rs.cell == TTRNN_GRU ? 1 : 0)) * rs.H * 4);
   if (!p->okb || p->b_lds + p->b_cmx > G2_LDS_LIMIT) p->b_cmx = 0;

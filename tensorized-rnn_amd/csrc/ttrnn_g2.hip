@@ -852,11 +852,26 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     }
     lds_barrier();
     // ---- T2: dC1 = head^T dy (split bf16 MFMA; resident / streaming instantiations as in the forward kernel) -----------------------------
-    auto stageT2 = [&]() {
+    // pass: which half of dC1's i_t range (bNP == 2; else 0 and every tile is computed)
+    auto stageT2 = [&](const int pass) {
       int seq = 0;
+      const int nth = m.N2T / m.bNP, it0 = pass * (m.It / m.bNP);
       for (int ui = 0; ui < nu_w; ++ui) {
         const int tile = wave + ui * NW;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
+        if (m.bNP > 1 && nt / nth != pass) {                    // the other half's tile: only the stream rolls on
+          for (int kbl = 0; kbl < m.bKBP; kbl += G2_PF) {
+#pragma unroll
+            for (int j = 0; j < G2_PF; ++j) {
+              int nxt = seq + G2_PF;
+              nxt -= nxt >= total ? total : 0;
+#pragma unroll
+              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+              ++seq;
+            }
+          }
+          continue;
+        }
         const int kbase = (m.ng > 1 ? (16 * mt) / m.Kg : 0) * m.bNKBt;                 // block-diagonal heads: the gate's i_h range
         const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q + 32 * kbase;
         f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
@@ -882,7 +897,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const f32x4 acc_lo = acc_a + acc_b;
         const int off = t2off[mt * 4 + q];
         const int it = 16 * nt + c;
-        if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + it * m.Rp) = acc_hi + acc_lo;
+        if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + (it - it0) * m.Rp) = acc_hi + acc_lo;
       }
     };
     // resident: the dy fragments are the SAME for every row tile (one column tile): read once per step, then every live
@@ -929,16 +944,19 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       else if (m.bNKBt == 3) stageT2res(std::integral_constant<int, 3>{});
       else stageT2res(std::integral_constant<int, 4>{});
     } else {
-      stageT2();
+      stageT2(0);
     }
     lds_barrier();
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
-    auto stageT1 = [&](auto frag) {
+    auto stageT1 = [&](auto frag, const int pass) {
+      const int ksh = m.bKS1 / m.bNP, klo = pass * ksh, khi = klo + ksh;          // this pass's k-steps (= its i_t range)
       for (int u1 = wave; u1 < m.bU1; u1 += NW) {
         const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
         const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
-        const int k0 = part * m.bKS1P;
-        const int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
+        int k0 = part * m.bKS1P;
+        int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
+        k0 = k0 > klo ? k0 : klo;
+        k1 = k1 < khi ? k1 : khi;
         const int jrow = 16 * nt + c;                                  // rows past J_h: any real row (their results are dropped)
         const float* bp = dc1 + (jrow < m.Jh ? jrow : m.Jh - 1) * m.K1S + q;
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -948,7 +966,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int ks = ks0 + e < k1 ? ks0 + e : k1 - 1;
-            wv[e] = frag(fbase + ks * 64); xv[e] = bp[4 * ks];
+            wv[e] = frag(fbase + ks * 64); xv[e] = bp[4 * (ks - klo)];
           }
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
@@ -962,14 +980,23 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int jt = 16 * mt + 4 * q + j;
-            if (jt < m.Jt) dhb[part * H + jh * m.Jt + jt] = acc[j];
+            if (jt < m.Jt) dhb[part * H + jh * m.Jt + jt] = pass == 0 ? acc[j] : dhb[part * H + jh * m.Jt + jt] + acc[j];
           }
         }
       }
     };
-    if (t1_lds) stageT1([&](int i) { return lt1[i]; });
-    else stageT1([&](int i) { return bt1[i]; });
+    if (t1_lds) stageT1([&](int i) { return lt1[i]; }, 0);
+    else stageT1([&](int i) { return bt1[i]; }, 0);
     lds_barrier();
+    if constexpr (!RES) {
+      if (m.bNP > 1) {                                      // second half of dC1's i_t range (host: the image did not fit whole)
+        stageT2(1);
+        lds_barrier();
+        if (t1_lds) stageT1([&](int i) { return lt1[i]; }, 1);
+        else stageT1([&](int i) { return bt1[i]; }, 1);
+        lds_barrier();
+      }
+    }
   }
 #pragma unroll
   for (int u = 0; u < UPT; ++u)
