@@ -184,7 +184,9 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
   const G2Mat& m = p->hid;
   p->f_hb = (int)g2_al((size_t)2 * 16 * m.N1T * m.JS * 2);       // two fp16 planes of the h image
-  p->f_img = (int)g2_al((size_t)2 * 16 * m.N2T * m.K2S * 2);     // forward: two fp16 planes (ttrnn_split.h, flavour b)
+  // forward: two fp16 planes (ttrnn_split.h, flavour b) of the I_t REAL rows (stage 2 clamps its row index; the naive per-gate
+  // sets of H = 512, r = 16, d = 3 have I_t = 8: 132 KB instead of 263 — the difference between this tier and the VALU kernels)
+  p->f_img = (int)g2_al((size_t)2 * (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.K2S * 2);
   p->f_ybuf = (int)g2_al((size_t)m.KSPLIT * rs.G * rs.H * 4);
   p->f_tab = (int)g2_al((size_t)m.T1 * 4 * 4);      // stage-1 store offsets: one per (tile, lane quarter)
   p->f_sc = (int)g2_al((size_t)(m.Ih + m.It) * 4);

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag_a / _b)
   xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab + P.f_sc); // tail fragments (P.f_t1 > 0)
   const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
-  const int plane = 16 * m.N2T * m.K2S;
+  const int plane = (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.K2S;      // the image holds its I_t real rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   int r_nlive = m.NKBt - r_kloc < m.KPER ? m.NKBt - r_kloc : m.KPER;
   r_nlive = (nu_w > 0 && r_nlive > 0) ? r_nlive : 0;
   const int r_kb0 = (m.ng > 1 ? (16 * r_mt) / m.IhG : 0) * m.NKBt + r_kloc;
-  const _Float16* r_brow = img + (16 * r_nt + c) * m.K2S + 8 * q + 32 * r_kb0;
+  const _Float16* r_brow = img + (16 * r_nt + c < m.It ? 16 * r_nt + c : m.It - 1) * m.K2S + 8 * q + 32 * r_kb0;      // (rows past I_t: dropped)
   const int r_ybase = r_part * GH + (16 * r_mt + 4 * q) * m.It + 16 * r_nt + c;
   int r_ymask = 0;
   f32x4 r_un = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
         const int kloc0 = part * m.KPER;                                              // inside the tile's own k range
         const int kbase = (m.ng > 1 ? (16 * mt) / m.IhG : 0) * m.NKBt;                // block-diagonal heads: the gate's range
-        const _Float16* brow = img + (16 * nt + c) * m.K2S + 8 * q + 32 * kbase;
+        const _Float16* brow = img + (16 * nt + c < m.It ? 16 * nt + c : m.It - 1) * m.K2S + 8 * q + 32 * kbase;
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
         // operand fragments of the NEXT block are requested before the current block's MFMAs are issued
         xh8 bf[2][2];
