@@ -193,7 +193,8 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab + p->f_sc;
   p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
   p->f_lds += p->f_t1;
-  p->b_dy = (int)g2_al((size_t)3 * 16 * m.N2T * m.IhS * 2);
+  // (the I_t real rows, as the forward's operand image: T2 clamps its row index)
+  p->b_dy = (int)g2_al((size_t)3 * (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.IhS * 2);
   // dC1 rows: the J_h real ones, not the 16 N1T of T1's row tiles (T1 clamps its row index; H = 768, d = 2, r = 16: 24 rows of
   // 1 028 floats = 99 KB instead of 131 — the difference between this kernel and the VALU fallback for that shape)
   p->b_dc1 = (int)g2_al(((size_t)(m.Jh < 16 * m.N1T ? m.Jh : 16 * m.N1T) * m.K1S) * 4);

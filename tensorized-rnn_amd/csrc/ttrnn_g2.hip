@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   int* dyoff = reinterpret_cast<int*>(smem + P.b_dy + P.b_dc1 + P.b_dh);
   int* t2off = dyoff + P.G * P.H;
   float* lt1 = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1 + P.b_dh + P.b_tab);       // tail^T fragments (P.b_t1 > 0)
-  const int plane = 16 * m.N2T * m.IhS;
+  const int plane = (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.IhS;      // the dy image holds its I_t real rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
           continue;
         }
         const int kbase = (m.ng > 1 ? (16 * mt) / m.Kg : 0) * m.bNKBt;                 // block-diagonal heads: the gate's i_h range
-        const __bf16* brow = dyimg + (16 * nt + c) * m.IhS + 8 * q + 32 * kbase;
+        const __bf16* brow = dyimg + (16 * nt + c < m.It ? 16 * nt + c : m.It - 1) * m.IhS + 8 * q + 32 * kbase;
         f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
         xbf8 bf[2][3];
 #pragma unroll
@@ -905,7 +905,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     // inside each instantiation of the body (slot -> k-block must index registers statically).
     auto stageT2res = [&](auto nkb_tag) {
       constexpr int NKB = decltype(nkb_tag)::value;             // live k-blocks per unit (= bNKBt)
-      const __bf16* brow = dyimg + c * m.IhS + 8 * q;
+      const __bf16* brow = dyimg + (c < m.It ? c : m.It - 1) * m.IhS + 8 * q;
       xbf8 bfr[NKB][3];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)

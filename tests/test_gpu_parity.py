@@ -750,10 +750,7 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     m = build_module(meta, dev())
     assert not m._needs_stepping()
     assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
-    # (joint rank 64, d = 3, TT-LSTM: the reverse-time kernel's dC1 image — I_t = 8, no halves to take — still does not fit: BPTT
-    # on the any-shape kernels, the forward on the tier)
-    bwd_ok = ("runtime_mfma", "valu") if (kind, H, d, r) == ("ttlstm", 512, 3, 16) else ("runtime_mfma",)
-    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) in bwd_ok
+    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
     lstm = kind == "ttlstm"
     x = torch.randn(B, T, inp)
     w = torch.randn(B, T, H)
