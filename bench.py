@@ -155,24 +155,17 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(w, budget_s=20.0):
+def cpu_baseline(w, state_dict, x, budget_s=20.0):
     """Times the oracle (op-for-op torch-CPU restatement of the reference path; tools/validate_oracle_speed.py checks in
     the build container that it runs within 10 % of the reference itself) on the host: torch.set_num_threads(1) and
-    (all physical cores), median of 5 runs each on a bounded T-slice of the same workload."""
+    (all physical cores), median of 5 runs each on a bounded T-slice of the same workload — the SAME
+    weights (the GPU module's state_dict, as fp32) and the SAME input tensor the GPU steps were timed on."""
     from oracle import ttrnn_oracle as O
     logical = os.cpu_count() or 1
     phys = min(physical_cores(), logical)
-    g = torch.Generator().manual_seed(1111)
-    from tensorized_rnn.rnn_utils import tt_shape
-    G = 4 if w["kind"] == "ttlstm" else 3
-    layers = []
-    for l in range(w["L"]):
-        i = w["inp"] if l == 0 else w["H"]
-        s_in = tt_shape(i, w["H"], w["d"], G)
-        s_hid = tt_shape(w["H"], w["H"], w["d"], G)
-        layers.append((O.random_tt(s_in[0], s_in[1], w["r"], g), O.random_tt(s_hid[0], s_hid[1], w["r"], g)))
+    layers, _ = O.layers_from_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items()}, w["L"])
     fwd = O.lstm_forward if w["kind"] == "ttlstm" else O.gru_forward
-    x = torch.rand(w["B"], w["T"], w["inp"], generator=g)
+    x = x.detach().float().cpu()
 
     def run(T):
         t0 = time.perf_counter()
@@ -205,7 +198,8 @@ def cpu_baseline(w, budget_s=20.0):
             "cpu_model": model,
             "sample": "oracle/ttrnn_oracle.py (torch-CPU, op-for-op restatement of the reference loop; within 10 % of the "
                       "reference's own speed: profiles/r2/oracle_speed_validation.json), batch {}, first {} of {} timesteps at {} "
-                      "thread(s), fp32, no_grad, median of 5 runs each; `value` = the fastest thread count (all physical "
+                      "thread(s), fp32, no_grad, median of 5 runs each, on the weights and the input tensor of the GPU run; "
+                      "`value` = the fastest thread count (all physical "
                       "cores oversubscribe a path of ~40 tiny ATen ops per step)".format(
                           w["B"], "/".join(str(sample_T[n]) for n in counts), w["T"], "/".join(str(n) for n in counts))}
 
@@ -274,6 +268,40 @@ def run_grid(args, device):
     print(json.dumps(line))
 
 
+def _free_port():
+    import socket
+    with contextlib.closing(socket.socket(socket.AF_INET, socket.SOCK_STREAM)) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>` as a child process, pass its output
+    through, print rank 0's JSON line last and return the child's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    payload = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            payload = ln.rstrip("\n")          # held back: it must be the LAST line
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if payload is not None:
+        print(payload, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,9 +312,10 @@ def main():
                          "(hidden_size, ncores, ttrank, cell) combinations of the reference's experiment flags, route and "
                          "time per shape against the any-shape VALU kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prepared", action="store_true",
-                    help="forward mode: do not call prepare_for_inference() (by default the module keeps its weight-only "
-                         "work across the no_grad forwards of the timed loop, as the reference's eval loop keeps its weights)")
+    ap.add_argument("--prepared", action="store_true",
+                    help="forward mode: time the steps on prepare_for_inference() modules (weight-only work kept across the "
+                         "no_grad forwards).  Default: every timed forward starts from the TT cores, as the reference's eval "
+                         "loop does (benchmarking.py:16-38); the prepared figure is then reported beside it as `prepared`")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the configuration's batch PER GPU (the headline metric, 'timesteps/sec/GPU (batch=64)'). "
                          "strong: the configuration's batch is the GLOBAL batch, sharded over the ranks (SURVEY.md 8(d): "
@@ -301,13 +330,16 @@ def main():
                          "all-reduce (RCCL) for N > 1, reported in the same unit")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU (no
+        # torch.cuda call, libttrnn not loaded), and the ranks are CHILD processes — never an exec of this one.
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node {} for --gpus {}".format(
-                args.gpus, args.gpus))
+        raise SystemExit("--gpus {} but WORLD_SIZE={}: under torch.distributed.run pass --nproc-per-node {} (or run plain "
+                         "`python bench.py --gpus {}`, which starts its own ranks)".format(args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libttrnn has no CPU path)")
     # TTRNN_BENCH_SINGLE_DEVICE=1 (with TTRNN_BENCH_BACKEND=gloo) lets a 1-GPU box exercise the N>1 code path
@@ -322,7 +354,7 @@ def main():
     force_dist = os.environ.get("TTRNN_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(20000 + os.getpid() % 20000))   # one-rank forced group: no fixed port to collide on
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("TTRNN_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
@@ -358,7 +390,7 @@ def main():
 
     timer = EventTimer()
     F.KERNEL_TIMER = timer
-    prepared = args.mode == "forward" and not args.no_prepared
+    prepared = args.mode == "forward" and args.prepared
     if prepared:
         model.prepare_for_inference()       # include/ttrnn.h: ttrnn_rnn_forward_phase (opt-in; weights are fixed in this loop)
 
@@ -410,9 +442,10 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
         timer.start("step")
-        step()
+        last = step()
         timer.stop("step")
     torch.cuda.synchronize()
     if dist is not None:
@@ -420,6 +453,38 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+
+    # ---- what was timed, checked OUTSIDE the timed region ------------------------------------------------------------
+    # (1) the last step's results are finite (train: the loss and every gradient);  (2) the library's device-side event
+    # counters — a pair kernel that timed out NaN-poisons its samples, a guard trip means a slower kernel ran than the
+    # one the line names;  (3) the kernel families the library routes this descriptor to;  (4) every rank was there.
+    import ttrnn_hip
+    def _tensors(o):
+        if torch.is_tensor(o):
+            yield o
+        elif isinstance(o, (tuple, list)):
+            for v in o:
+                for t in _tensors(v):
+                    yield t
+    checked = list(_tensors(last))
+    if args.mode == "train":
+        checked += [p.grad for p in model.parameters() if p.grad is not None]
+    finite = bool(checked) and all(bool(torch.isfinite(t.float()).all().item()) for t in checked)
+    status = ttrnn_hip.device_status()
+    rnn_module = model.rnn if args.mode == "train" else model
+    spec0 = rnn_module._all_layers[0]._layer_spec()
+    tdt = torch.bfloat16 if w["dtype"] == "bf16" else torch.float32
+    routes = {"forward": F.rnn_route(spec0, w["B"], w["T"], tdt),
+              "backward": F.rnn_backward_route(spec0, w["B"], w["T"], tdt) if args.mode == "train" else None}
+    seen = torch.ones(1, dtype=torch.float64, device=device if backend != "gloo" else "cpu")
+    if dist is not None:
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ranks_seen = int(round(float(seen.item())))
+    bad = torch.tensor([0.0 if (finite and status["pair_timeouts"] == 0) else 1.0], dtype=torch.float64,
+                       device=device if backend != "gloo" else "cpu")
+    if dist is not None:
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+    ranks_bad = int(round(float(bad.item())))
     kern_ms = timer.mean_ms("ttrnn_rnn_forward")
     kern_ms_median = timer.median_ms("ttrnn_rnn_forward")
     step_ms_median = timer.median_ms("step")          # per-step device time (events on the launch stream)
@@ -427,7 +492,6 @@ def main():
 
     # fp32 workloads: which matrix arithmetic ran (include/ttrnn.h TTRNN_MATH_*) and, at N=1, the same steps again
     # in the OTHER mode, so that both figures come from one process on one device (outside the timed region above)
-    import ttrnn_hip
     math_mode = ttrnn_hip.get_fp32_math() if w["dtype"] == "f32" else None
     other = None
     if math_mode is not None and args.mode == "forward" and world == 1:
@@ -443,10 +507,10 @@ def main():
             alt_ms = (time.perf_counter() - ta) * 1e3 / max(args.steps, 1)
         other = {"fp32_math": alt, "ms_per_step": alt_ms, "value": w["T"] / (alt_ms * 1e-3), "unit": "timesteps/s"}
 
-    # the same steps without the prepared weight-only state (every forward packs the cores and rebuilds scales / fragments)
-    unprepared = None
-    if prepared and world == 1:
-        model.release_prepared()
+    # the same steps on prepared modules (weight-only work kept across forwards) — beside the headline, never the headline
+    prepared_extra = None
+    if args.mode == "forward" and not prepared and world == 1:
+        model.prepare_for_inference()
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -454,9 +518,11 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        un_ms = (time.perf_counter() - tu) * 1e3 / max(args.steps, 1)
-        unprepared = {"ms_per_step": un_ms, "value": w["T"] / (un_ms * 1e-3), "unit": "timesteps/s"}
-        model.prepare_for_inference()
+        pr_ms = (time.perf_counter() - tu) * 1e3 / max(args.steps, 1)
+        prepared_extra = {"ms_per_step": pr_ms, "value": w["T"] / (pr_ms * 1e-3), "unit": "timesteps/s",
+                          "what": "prepare_for_inference(): packed cores, scale header, fused-core fragments and (input_size == 1) "
+                                  "the unit-row input projection built once and kept across the forwards (ttrnn_rnn_forward_phase)"}
+        model.release_prepared()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend != "gloo" else "cpu")
     if dist is not None:
@@ -509,7 +575,8 @@ def main():
             "metric": ("timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}" if args.scaling == "weak" else
                        "timesteps/sec of the GLOBAL batch {} sharded over the GPUs, {} h={} ncores={} rank={}").format(
                 w["B"] if args.scaling == "weak" else global_batch,
-                "TT-LSTM" if w["kind"] == "ttlstm" else "TT-GRU", w["H"], w["d"], w["r"]),
+                "TT-LSTM" if w["kind"] == "ttlstm" else "TT-GRU", w["H"], w["d"], w["r"]) +
+                      (" (prepared weights)" if prepared else ""),
             # weak: every GPU advances its own batch by T timesteps per step (whole job = N x T); strong: the job is ONE
             # global batch advanced by T timesteps per step
             "value": (world if args.scaling == "weak" else 1) * w["T"] / t_step,
@@ -518,7 +585,8 @@ def main():
             "ms_per_step": t_step * 1e3,
             "ms_per_step_median": step_ms_median,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": arith if arith == w["dtype"] else "{} ({} storage)".format(arith, w["dtype"]), "data": "synthetic",
+            "dtype": ("f32 (2xfp16 operands, fp32 accumulate)" if (arith == "f32" and math_mode == "split") else
+                      arith if arith == w["dtype"] else "{} ({} storage)".format(arith, w["dtype"])), "data": "synthetic",
             "config": {"workload": w["desc"], "per_gpu_batch": w["B"], "seq_len": w["T"],
                        "global_batch": global_batch, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
@@ -526,11 +594,11 @@ def main():
                                 "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM; " + optimizer_impl),
                        "fp32_math": FP32_MATH_DESC.get(math_mode),
                        "prepared_weights": (
-                           "prepare_for_inference(): packed cores, scale header, fused-core fragments and (input_size == 1) the "
-                           "unit-row input projection are built once and kept across the forwards of the timed loop "
-                           "(ttrnn_rnn_forward_phase; the reference's eval loop likewise runs on fixed weights, "
-                           "benchmarking.py:16-38); `unprepared` = the same steps with every forward rebuilding them"
-                           if prepared else None)},
+                           "--prepared: prepare_for_inference() modules — packed cores, scale header, fused-core fragments and "
+                           "(input_size == 1) the unit-row input projection are built once and kept across the forwards of the "
+                           "timed loop (ttrnn_rnn_forward_phase)" if prepared else
+                           "no: every timed forward starts from the TT cores (packs them, rebuilds scales / fragments), as the "
+                           "reference's eval loop evaluates the chain from its cores on every call (benchmarking.py:16-38)")},
             "sample_timesteps_per_s": global_batch * w["T"] / t_step,
             "shard_of": (None if args.shard_of <= 1 else
                          "ONE rank's shard of the configuration's batch under --scaling strong on {} GPUs ({} samples), "
@@ -555,12 +623,18 @@ def main():
                                       "FLOPs than the reference's chain on a faster pipe; `executed` is the bounded figure",
                          "executed": executed},
         }
+        line["ranks_seen"] = ranks_seen
+        line["checked"] = {"finite": finite, "tensors": len(checked), "ranks_bad": ranks_bad,
+                           "what": ("loss + every parameter gradient of the last timed step" if args.mode == "train" else
+                                    "outputs and final state of the last timed step") + ", torch.isfinite on rank 0; "
+                                   "ranks_bad = ranks whose results were not finite or that counted a pair time-out",
+                           "device_status": status, "routes": routes}
         if other is not None:
             line["other_fp32_math"] = other
-        if unprepared is not None:
-            line["unprepared"] = unprepared
+        if prepared_extra is not None:
+            line["prepared"] = prepared_extra
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w)
+            line["cpu_baseline"] = cpu_baseline(w, rnn_module.state_dict(), x)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         payload = json.dumps(line)
     if dist is not None:
@@ -575,7 +649,15 @@ def main():
         except (OSError, AttributeError):
             pass
         print(payload, flush=True)
+    if ranks_seen != world:
+        sys.stderr.write("bench.py: {} of {} ranks took part\n".format(ranks_seen, world))
+        return 3
+    if ranks_bad:
+        sys.stderr.write("bench.py: the timed steps are not valid on {} rank(s): finite={} device_status={}\n".format(
+            ranks_bad, finite, status))
+        return 4
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

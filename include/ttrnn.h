@@ -109,11 +109,14 @@ int ttrnn_device_status(unsigned int* counters, int n, int reset);
  *                     with fp32 accumulation (error-compensated products).  Two flavours, chosen by the kernel:
  *                     (a) three bf16 pieces (x = x0+x1+x2 exactly), the six terms of weight >= 2^-18: per-product
  *                         error < 2^-24 relative, 2.67x less matrix-pipe time than TTRNN_MATH_EXACT;
- *                     (b) the fused-core LSTM forward kernels: two fp16 pieces under per-launch power-of-two scales
- *                         derived from the cores' and h_0's maxima (no overflow for any finite input), terms
+ *                     (b) the fused-core / merged-core kernels and the dense GEMMs: two fp16 pieces under DIAGONAL
+ *                         power-of-two scales — one per row and one per column of every weight operand (two-sided: an
+ *                         outlier entry costs its own row and column range, not the whole matrix), one per hidden unit /
+ *                         per GEMM row for the activations (no overflow for any finite input) — terms
  *                         x0w0 + x0w1 + x1w0: operands carry >= 22 significand bits, per-product error <= 2^-21.4
  *                         relative — below the rounding an fp32 sum of 256 such products accumulates anyway; 5.3x
- *                         less matrix-pipe time.
+ *                         less matrix-pipe time.  A weight operand whose bulk would still land in fp16's subnormal
+ *                         range leaves for the fp32-MFMA kernel on the device (TTRNN_STAT_GUARD_TRIPS counts it).
  *                     Measured against a float64 evaluation both flavours sit where TTRNN_MATH_EXACT sits (DESIGN.md
  *                     section 4a; tests/test_gpu_parity.py::test_split_math_*).
  * Default: TTRNN_MATH_SPLIT where a split kernel exists for the descriptor (DESIGN.md section 5 lists them and gives
@@ -134,7 +137,8 @@ int ttrnn_get_fp32_math(void);
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
  *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path),
- *   "no_gemm3", "dev" (0..255: developer bit mask of the harnesses under tools/).
+ *   "no_gemm3", "dev" (0..65535: developer bit mask, A/B route switches between kernels that compute the same result;
+ *   csrc/ttrnn_opts.h lists the bits).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
 int ttrnn_set_option(const char* name, int value);

@@ -1062,12 +1062,14 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
                        rows_per, (const TSV*)x, dy, dW, d_bias, part, cx, cd, rsh, 0);                                        \
   } while (0)
 #define TT_WG2(TSV, HV) do { if (rsh.T > 0) TT_WG(TSV, HV, true); else TT_WG(TSV, HV, false); } while (0)
-  if (di == 4 && rsh.T == 0 && (opt(OPT_DEV) & (8 | 16 | 32 | 64))) {      // tools/wgrad_bench: the ablation instantiation
+#ifdef TTRNN_ABLATIONS      // harness build only (`make ablation`): the no-MFMA / no-split / no-load / no-fragment-read instantiation
+  if (di == 4 && rsh.T == 0 && (opt(OPT_DEV) & (8 | 16 | 32 | 64))) {      // tools/wgrad_bench
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<float, true, false, true>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
     hipLaunchKernelGGL((k_dense_wgrad_split<float, true, false, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out,
                        KS, rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd, rsh, opt(OPT_DEV));
   } else
+#endif
   switch (di) {
     case 0:
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<float>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;

@@ -23,6 +23,14 @@
 #include "ttrnn_mfma.h"
 #include "ttrnn_split.h"
 
+// Result-destroying ablations (no output stores) exist only in the harness build of the library (`make ablation`,
+// -DTTRNN_ABLATIONS -> tools/bin/libttrnn_abl.so); the shipped library compiles them out.
+#ifdef TTRNN_ABLATIONS
+#define G3_NOSTORE(dev) ((dev) & 2)
+#else
+#define G3_NOSTORE(dev) 0
+#endif
+
 namespace ttrnn {
 
 namespace {
@@ -305,8 +313,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3h(int64_t n_rows, int64_t n_pa
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const int64_t n = n0 + wr * 64 + 16 * ri + c;
-      // (dev bit 1: harness experiment — only the first row tile stores, everything else is computed and dropped)
-      if (n < n_rows && (!(dev & 2) || acc[mi][ri][0] == 12345.678f))
+      // (TTRNN_ABLATIONS builds only, dev bit 1: nothing stores — everything is computed and dropped)
+      if (n < n_rows && (!G3_NOSTORE(dev) || acc[mi][ri][0] == 12345.678f))
         *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) =
             f32x4{g3_unscale2(acc[mi][ri][0], unf[0], unr[ri]), g3_unscale2(acc[mi][ri][1], unf[1], unr[ri]),
                   g3_unscale2(acc[mi][ri][2], unf[2], unr[ri]), g3_unscale2(acc[mi][ri][3], unf[3], unr[ri])} + bh;
@@ -482,7 +490,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3p(int64_t n_rows, int64_t n_pa
     float unr[4];
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) unr[ri] = ps[512 + wr * 64 + 16 * ri + c];
-    const bool full = n0 + G3_TR <= n_rows && !(dev & 2);
+    const bool full = n0 + G3_TR <= n_rows && !G3_NOSTORE(dev);
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int fl = wm * 128 + 16 * mi + 4 * q;
@@ -492,7 +500,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gemm3p(int64_t n_rows, int64_t n_pa
 #pragma unroll
       for (int ri = 0; ri < 4; ++ri) {
         const int64_t n = n0 + wr * 64 + 16 * ri + c;
-        if (n < n_rows && (!(dev & 2) || acc[mi][ri][0] == 12345.678f)) {
+        if (n < n_rows && (!G3_NOSTORE(dev) || acc[mi][ri][0] == 12345.678f)) {
           const f32x4 v = f32x4{g3_unscale2(acc[mi][ri][0], unf[0], unr[ri]), g3_unscale2(acc[mi][ri][1], unf[1], unr[ri]),
                                 g3_unscale2(acc[mi][ri][2], unf[2], unr[ri]), g3_unscale2(acc[mi][ri][3], unf[3], unr[ri])} + bh;
           *reinterpret_cast<f32x4*>(y + (size_t)n * M + mf) = v;

@@ -31,8 +31,12 @@ enum OptId {
                          //                         the time-out path (NaN poison + device status counter) can be exercised
   OPT_NO_GEMM3,          // TTRNN_NO_GEMM3=1        two-piece fp16 K-in GEMM with x split on the fly (round 2's kernel) instead of the
                          //                         pre-split LDS-DMA GEMM (A/B)
-  OPT_DEV,               // TTRNN_DEV=0..255        developer bit mask for A/B experiments on kernels under construction (harnesses under
-                         //                         tools/ only; no effect on results unless a bit is documented at its use)
+  OPT_DEV,               // TTRNN_DEV=0..65535      developer bit mask: A/B ROUTE switches between kernels that compute the same result
+                         //                         (1: gemm3 ping-pong schedule, 4: f10gq for bf16 GRU, 32: eight-wave GRU kernel,
+                         //                         64: gemm3 one workgroup per tile, 1024: fused-core wgrad on unit rows, 2048: g2 head
+                         //                         fragments not resident).  Bits 2 / 8 / 16 (and 32 / 64 inside the dense weight
+                         //                         gradient) are result-destroying ablations that exist ONLY in -DTTRNN_ABLATIONS
+                         //                         builds (`make ablation` -> tools/bin/libttrnn_abl.so), never in libttrnn.so
   OPT_COUNT
 };
 

@@ -100,12 +100,22 @@ class FusedCellMixin(object):
         """(Re)build the weight-only state of this cell for no-grad forwards (ttrnn_hip.functional.PreparedLayer)."""
         from ttrnn_hip import functional as F
         cin, bin_, chid, bhid = self._operands()
-        prep = F.PreparedLayer(self._layer_spec(), cin, bin_, chid, bhid)
+        # the freshness stamp watches the cell's own Parameters (a naive set's joint cores are derived copies)
+        params = list(self.input_weights.parameters()) + list(self.hidden_weights.parameters())
+        prep = F.PreparedLayer(self._layer_spec(), cin, bin_, chid, bhid, params=params)
         object.__setattr__(self, '_prepared', prep)            # plain attribute: not a buffer, not in the state_dict
         return prep
 
     def _release_prepared(self):
         object.__setattr__(self, '_prepared', None)
+
+    def __getstate__(self):
+        # pickling (torch.save(model)) and copy.deepcopy go through here: the prepared state (packed cores, device
+        # workspaces) and the descriptor cache (ctypes structures) belong to THIS module on THIS device and are rebuilt on demand
+        state = dict(self.__dict__)
+        state.pop('_prepared', None)
+        state.pop('_spec_cache', None)
+        return state
 
 
 class TTWeightsMixin(object):

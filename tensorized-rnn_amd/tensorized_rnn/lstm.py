@@ -42,7 +42,8 @@ class LSTMCell(FusedCellMixin, nn.Module):
         if self._fusable():
             hy, cy = self._fused_step(input, hx, cx)
         else:
-            # naive per-gate TT variant: TTLinear kernels + device-side gate arithmetic
+            # cells whose weights are neither nn.Linear, TTLinear nor a TTLinearSet the library takes as one joint matrix
+            # (_fused.py: _fusable): the weights' own forward + device-side gate arithmetic
             H = self.hidden_size
             pre = self.input_weights(input) + self.hidden_weights(hx)
             i, f, o = (torch.sigmoid(pre[:, k * H:(k + 1) * H]) for k in (0, 1, 3))

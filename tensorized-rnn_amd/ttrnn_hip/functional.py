@@ -5,6 +5,7 @@ Reference arithmetic replaced (file:line under the reference repo):
   tt_linear      -> t3nsor/layers.py:121-127 + t3nsor/ops.py:54-93
   tt_rnn_layer   -> tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 for one layer
 """
+import collections
 import ctypes
 
 import torch
@@ -540,13 +541,19 @@ class PreparedLayer(object):
     parameters (optimizer steps, load_state_dict, .copy_) bump their version counters and are detected — the layer is
     prepared again; writes through `.data` are NOT tracked by torch: call prepare_for_inference() again after them."""
 
-    def __init__(self, spec, cores_in, bias_in, cores_hid, bias_hid):
+    MAX_WORKSPACES = 4      # distinct (batch, seq_len, dtype) shapes kept per layer (least recently used goes first)
+
+    def __init__(self, spec, cores_in, bias_in, cores_hid, bias_hid, params=None):
+        """params: the nn.Parameters the operands derive from — what the freshness stamp watches.  For TTLinear / nn.Linear
+        weights the operands ARE (views of) the parameters; a TTLinearSet's joint cores are fresh torch.cat copies whose
+        version counters never move, so the set's own per-gate parameters must be given here."""
         self.spec = spec
-        self.tensors = list(cores_in) + list(cores_hid) + [b for b in (bias_in, bias_hid) if b is not None]
+        operands = list(cores_in) + list(cores_hid) + [b for b in (bias_in, bias_hid) if b is not None]
+        self.tensors = list(params) if params is not None else operands
         self.stamp = self._stamp()
-        with torch.no_grad(), torch.cuda.device(self.tensors[0].device):
+        with torch.no_grad(), torch.cuda.device(operands[0].device):
             self.packed_in, self.packed_hid = TTSpec.pack_pair(spec.in_spec, list(cores_in), spec.hid_spec, list(cores_hid))
-        self.workspaces = {}
+        self.workspaces = collections.OrderedDict()
 
     def _stamp(self):
         return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in self.tensors)
@@ -564,18 +571,30 @@ def _rnn_forward_prepared(spec, x, h0, c0, bias_in, bias_hid, prep, need_out=Tru
     dev = x.device
     dt = _dtype_code(x)
     desc = spec.desc(B, T, dt)
-    key = (B, T, dt, dev, _lib.OPTIONS_EPOCH)
-    ent = prep.workspaces.get(key)
-    if ent is None:
+    if lib.ttrnn_rnn_prepare_supported(ctypes.byref(desc)):
+        # the workspace holds weight-only results a PREPARE call left there: kept per shape, a few shapes at most
+        key = (B, T, dt, dev, _lib.OPTIONS_EPOCH)
+        ent = prep.workspaces.get(key)
+        if ent is None:
+            wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
+            ws = _workspace(wsb, dev)
+            null = ctypes.c_void_p(0)
+            check(lib.ttrnn_rnn_forward_phase(ctypes.byref(desc), _lib.PHASE_PREPARE, null, null, null, _ptr(prep.packed_in),
+                                              _ptr(bias_in), _ptr(prep.packed_hid), _ptr(bias_hid), null, null, null, null,
+                                              _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward_phase(PREPARE)")
+            for k in [k for k in prep.workspaces if k[4] != _lib.OPTIONS_EPOCH]:                     # drop stale epochs
+                del prep.workspaces[k]
+            while len(prep.workspaces) >= prep.MAX_WORKSPACES:
+                prep.workspaces.popitem(last=False)
+            ent = prep.workspaces[key] = (ws, wsb)
+        else:
+            prep.workspaces.move_to_end(key)
+        ws, wsb = ent
+    else:
+        # this route has no weight-only part in its workspace (PREPARE is a no-op, RUN does everything): the buffer is per-call
+        # scratch — e.g. the [B][T][H][4] projections of a stacked layer, hundreds of MB — and is NOT kept
         wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
-        null = ctypes.c_void_p(0)
-        check(lib.ttrnn_rnn_forward_phase(ctypes.byref(desc), _lib.PHASE_PREPARE, null, null, null, _ptr(prep.packed_in),
-                                          _ptr(bias_in), _ptr(prep.packed_hid), _ptr(bias_hid), null, null, null, null,
-                                          _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward_phase(PREPARE)")
-        prep.workspaces = {k: v for k, v in prep.workspaces.items() if k[4] == _lib.OPTIONS_EPOCH}     # drop stale epochs
-        ent = prep.workspaces[key] = (ws, wsb)
-    ws, wsb = ent
     want_out = need_out or not lib.ttrnn_rnn_out_optional(ctypes.byref(desc))
     out = _alloc((B, T, H), x.dtype, dev) if want_out else None
     hT = _alloc((B, H), x.dtype, dev)

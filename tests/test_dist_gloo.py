@@ -203,3 +203,88 @@ def test_bench_shard_of_times_one_ranks_strong_scaling_shard():
     bad = subprocess.run(cmd + ["--scaling", "strong"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
                          timeout=500, env=env, cwd=ROOT)
     assert bad.returncode != 0 and "single-GPU diagnostic" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode,scaling", [("forward", "weak"), ("train", "weak"), ("forward", "strong"), ("train", "strong")])
+def test_bench_plain_invocation_launches_its_own_ranks(mode, scaling):
+    """Plain `python bench.py --gpus 2` (no torchrun environment): the process becomes the launcher, starts
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a CHILD, prints rank 0's JSON line last and exits
+    with the child's code.  Two gloo ranks share cuda:0 here (TTRNN_BENCH_SINGLE_DEVICE=1); `ranks_seen` = an all-reduce of
+    ones over the group."""
+    import json
+    import subprocess
+    env = dict(os.environ, TTRNN_BENCH_SINGLE_DEVICE="1", TTRNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
+           "--scaling", scaling]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=800, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    out_lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert out_lines[-1].startswith('{"metric"'), out_lines[-3:]
+    assert sum(1 for ln in out_lines if ln.startswith('{"metric"')) == 1
+    rec = json.loads(out_lines[-1])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == scaling
+    assert rec["checked"]["finite"] is True and rec["checked"]["ranks_bad"] == 0
+    assert rec["checked"]["device_status"]["pair_timeouts"] == 0
+    assert rec["checked"]["routes"]["forward"] == "fused_core"
+    assert (rec["checked"]["routes"]["backward"] is not None) == (mode == "train")
+    assert rec["config"]["global_batch"] == (128 if scaling == "weak" else 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_reports_and_fails_on_a_pair_timeout():
+    """The bench line vouches for what it timed: with the pair kernels' time-out path planted (option pair_fault, the
+    H = 1024 class at 2B <= #CUs: `--shard-of 8` of cfg5 = 16 samples) the affected samples are NaN by construction —
+    the line says so (`checked.finite` false, `device_status.pair_timeouts` > 0) and the exit code is non-zero.  The same
+    command without the fault exits 0 with a clean line."""
+    import json
+    import subprocess
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        base.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg5", "--shard-of", "8", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline"]
+    ok = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=800, env=base, cwd=ROOT)
+    assert ok.returncode == 0, ok.stderr[-3000:]
+    rec = json.loads([ln for ln in ok.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert rec["checked"]["finite"] is True and rec["checked"]["device_status"]["pair_timeouts"] == 0
+    assert rec["checked"]["routes"]["forward"] == "merged_big"
+    assert rec["dtype"].startswith("f32 (2xfp16 operands")
+    bad = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=800,
+                         env=dict(base, TTRNN_PAIR_FAULT="1"), cwd=ROOT)
+    assert bad.returncode != 0, bad.stdout[-1500:]
+    rec = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert rec["checked"]["device_status"]["pair_timeouts"] > 0 and rec["checked"]["ranks_bad"] == 1
+    assert "not valid" in bad.stderr
+
+
+def test_bench_launcher_passes_through_and_never_touches_the_gpu(tmp_path):
+    """The launcher half of `python bench.py --gpus N` on a box without a GPU: it must start N child ranks (which then
+    refuse to run — no GPU here) and hand their exit code back, without itself calling into torch.cuda or libttrnn.  Run
+    with a poisoned `torch.cuda.is_available` in a sitecustomize that arms itself in the PARENT only (argv[0] is bench.py
+    and there is no WORLD_SIZE) — a parent that probes the GPU fails the test."""
+    import subprocess
+    site = tmp_path / "sitecustomize.py"
+    site.write_text(
+        "import os, sys\n"
+        "if 'WORLD_SIZE' not in os.environ and sys.argv and sys.argv[0].endswith('bench.py'):\n"
+        "    import torch\n"
+        "    def _boom(*a, **k):\n"
+        "        raise SystemExit('LAUNCHER_TOUCHED_THE_GPU')\n"
+        "    torch.cuda.is_available = _boom\n"
+        "    torch.cuda.set_device = _boom\n"
+        "    torch.cuda.current_device = _boom\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300, env=env, cwd=ROOT)
+    assert "LAUNCHER_TOUCHED_THE_GPU" not in res.stderr + res.stdout
+    if not __import__("torch").cuda.is_available():
+        # the ranks were started (torchrun ran them) and each refused: that message can only come from a child with WORLD_SIZE=2
+        assert res.returncode != 0
+        assert "bench.py needs a GPU" in res.stderr, res.stderr[-2000:]

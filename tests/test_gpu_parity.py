@@ -946,7 +946,11 @@ def test_prepared_weights_inference_matches_and_tracks_updates():
     for meta, B, T, split in ((dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 1),
                               (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 0),
                               (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16), 6, 9, 0),
-                              (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0)):
+                              (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0),
+                              # naive per-gate sets: the operands are torch.cat COPIES of the parameters — the
+                              # freshness stamp must watch the gates' own parameters
+                              (dict(kind="ttlstm", input_size=28, hidden_size=64, num_layers=2, n_cores=2, tt_rank=3, is_naive=True), 4, 7, 0),
+                              (dict(kind="ttgru", input_size=1, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4, is_naive=True), 4, 9, 0)):
         m = build_module(meta, dev()).eval()
         x = torch.randn(B, T, meta["input_size"], device=dev())
         desc = m._all_layers[0]._layer_spec().desc(B, T, 0)
@@ -957,7 +961,15 @@ def test_prepared_weights_inference_matches_and_tracks_updates():
             a = m(x)[0]
             b = m(x)[0]                                   # second call: the cached workspace
             assert torch.equal(a, ref) and torch.equal(b, ref)
-            assert len(m._all_layers[0]._prepared.workspaces) == 1
+            # a workspace is kept only where it holds weight-only results (a route that splits the phases); elsewhere it is
+            # per-call scratch (hundreds of MB for a stacked layer) and must not be pinned per shape
+            prep0 = m._all_layers[0]._prepared
+            assert len(prep0.workspaces) == split
+            for k in range(1, prep0.MAX_WORKSPACES + 3):      # variable-length inference: the per-shape cache is bounded
+                m(torch.randn(B, T + k, meta["input_size"], device=dev()))
+            assert len(prep0.workspaces) == (prep0.MAX_WORKSPACES if split else 0)
+            import copy
+            assert all(getattr(c, "_prepared", None) is None for c in copy.deepcopy(m)._all_layers)
             x2 = torch.randn(B + 1, T + 3, meta["input_size"], device=dev())
             assert torch.equal(m(x2)[0], m.release_prepared()(x2)[0])
             m.prepare_for_inference()

@@ -152,3 +152,32 @@ def test_c_oracle_sequences(name):
     assert _maxabs(hT, case.arr["hT"]) <= 1e-5
     if lstm:
         assert _maxabs(cT, case.arr["cT"]) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["ttlstm", "ttgru"])
+def test_segmented_bptt_helper_equals_plain_autograd(kind):
+    """tests/bptt_oracle.py (the float64 oracle gradients of the full-size backward parity tests): replaying the sequence in
+    segments with the state gradient handed from segment to segment equals one autograd graph over all steps."""
+    import contextlib
+    import io
+    from bptt_oracle import masked_loss_grads
+    from golden_io import build_module
+    torch.manual_seed(5)
+    meta = dict(kind=kind, input_size=3, hidden_size=16, num_layers=1, n_cores=2, tt_rank=3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = build_module(meta, torch.device("cpu"))
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    n, T, H = 3, 23, 16
+    x, w = torch.randn(n, T, 3), torch.randn(n, T, H)
+    vh, vc, h0, c0 = torch.randn(n, H), torch.randn(n, H), torch.randn(n, H) * 0.3, torch.randn(n, H) * 0.3
+    for with_state in (True, False):
+        kw = dict(h0=h0, c0=c0) if with_state else {}
+        a = masked_loss_grads(kind, sd, 1, x, w, vh, vc, seg=T + 1, **kw)
+        b = masked_loss_grads(kind, sd, 1, x, w, vh, vc, seg=5, **kw)
+        for k in a["params"]:
+            assert (a["params"][k] - b["params"][k]).abs().max() <= 1e-12 * max(1.0, float(a["params"][k].abs().max())), k
+        for k in ("dx", "dh0", "dc0", "out", "hT", "cT"):
+            if a[k] is None:
+                assert b[k] is None
+            else:
+                assert (a[k] - b[k]).abs().max() <= 1e-12 * max(1.0, float(a[k].abs().max())), k
