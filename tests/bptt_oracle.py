@@ -17,7 +17,18 @@ import torch
 from oracle import ttrnn_oracle as O
 
 
-def masked_loss_grads(kind, sd, num_layers, x, w, v_h, v_c=None, h0=None, c0=None, seg=64, dtype=torch.float64):
+def masked_loss_grads(*args, **kwargs):
+    """_masked_loss_grads on at most 8 torch threads: the path is ~40 tiny ATen ops per step, and a 128-core host
+    oversubscribed with one thread per core runs it 13x SLOWER than 8 threads do (BENCH_r03 cpu_baseline: 72 vs 969 steps/s)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(8, n)))
+    try:
+        return _masked_loss_grads(*args, **kwargs)
+    finally:
+        torch.set_num_threads(n)
+
+
+def _masked_loss_grads(kind, sd, num_layers, x, w, v_h, v_c=None, h0=None, c0=None, seg=64, dtype=torch.float64):
     """kind: 'ttlstm' | 'ttgru' (or 'lstm' / 'gru').  sd: reference-keyed state_dict (CPU tensors).  x [n, T, in], w [n, T, H],
     v_h / v_c [n, H] (v_c LSTM only), h0 / c0 [n, H] or None (zeros, no gradient returned).
     Returns dict(params={key: grad}, dx, dh0, dc0, out, hT, cT) — float64 CPU tensors."""

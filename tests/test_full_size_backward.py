@@ -41,6 +41,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle(key, *args, **kwargs):
+    """The float64 oracle gradients depend on the seeded inputs only, not on the library's math mode: computed once per
+    (configuration, variant) and shared by the split / exact cases."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = masked_loss_grads(*args, **kwargs)
+    return _ORACLE_CACHE[key]
+
+
 def _rel(got, ref):
     ref = ref.double()
     return float((got.detach().double().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
@@ -98,7 +109,7 @@ def test_masked_loss_gradients_at_bench_size(name, math):
     with (ttrnn_hip.fp32_math(math) if math else _null()):
         # (A) exactly the call of the training benchmark: zero initial state, the input needs no gradient
         got = _product_step(m, lstm, x.to(dev()), W, VH, VC, x_grad=False)
-        ref = masked_loss_grads(kind, sd, L, x[rows].float(), w, vh, vc if lstm else None, seg=seg)
+        ref = _oracle((name, "A"), kind, sd, L, x[rows].float(), w, vh, vc if lstm else None, seg=seg)
         assert _rel(got["out"][rows].float(), ref["out"]) <= (2e-2 if dtype == torch.bfloat16 else 1e-4)
         worst = {}
         for k, p in got["params"].items():
@@ -108,8 +119,8 @@ def test_masked_loss_gradients_at_bench_size(name, math):
         assert max(worst.values()) <= tol, worst
         # (B) everything differentiable: input, caller's h0 / c0 (shared by all layers, lstm.py:120)
         got = _product_step(m, lstm, x.to(dev()), W, VH, VC, h0.to(dev()), c0.to(dev()), x_grad=True)
-        ref = masked_loss_grads(kind, sd, L, x[rows].float(), w, vh, vc if lstm else None, h0=h0[rows].float(),
-                                c0=c0[rows].float() if lstm else None, seg=seg)
+        ref = _oracle((name, "B"), kind, sd, L, x[rows].float(), w, vh, vc if lstm else None, h0=h0[rows].float(),
+                      c0=c0[rows].float() if lstm else None, seg=seg)
         worst = {k: _rel(p.float(), ref["params"][k]) for k, p in got["params"].items()}
         worst["dx"] = _rel(got["dx"][rows].float(), ref["dx"])
         worst["dh0"] = _rel(got["dh0"][rows].float(), ref["dh0"])
@@ -142,7 +153,7 @@ def test_cfg2_unmasked_full_batch_gradients(math):
     vh, vc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
     with ttrnn_hip.fp32_math(math):
         got = _product_step(m, True, x.to(dev()), w.to(dev()), vh.to(dev()), vc.to(dev()), x_grad=False)
-        ref = masked_loss_grads(kind, sd, L, x, w, vh, vc, seg=56)
+        ref = _oracle(("cfg2", "full"), kind, sd, L, x, w, vh, vc, seg=56)
         worst = {k: _rel(p, ref["params"][k]) for k, p in got["params"].items()}
         print("cfg2 unmasked/%s (x without gradient): %.3g (%s)" % (math, max(worst.values()), max(worst, key=worst.get)))
         assert max(worst.values()) <= 1e-4, worst
