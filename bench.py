@@ -225,6 +225,19 @@ def run_grid(args, device):
         m.zero_grad(set_to_none=True)
         m(x)[0].sum().backward()
 
+    def timed_graph(m, x, n):
+        """forward + BPTT of sum(outputs), captured once (ttrnn_hip.CapturedTrainStep, no optimizer) and replayed"""
+        cap = ttrnn_hip.CapturedTrainStep(m, None, lambda mm, xx: mm(xx)[0].sum(), (x,), warmup=2)
+        cap(x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            cap(x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e3
+
     def timed(m, x, n):
         one(m, x)
         torch.cuda.synchronize()
@@ -249,7 +262,9 @@ def run_grid(args, device):
                     ms = timed(m, x, max(3, args.steps // 4))
                     with ttrnn_hip.option("force_generic", 1):
                         valu_ms = timed(m, x, 3)
+                    graph_ms = round(timed_graph(m, x, max(3, args.steps // 4)), 4) if (train and args.graph) else None
                     rows.append({"cell": cell, "H": H, "ncores": d, "ttrank": r, "route": route, "bwd_route": bwd_route, "ms": round(ms, 4),
+                                 "graph_ms": graph_ms,
                                  "valu_ms": round(valu_ms, 4), "speedup": round(valu_ms / ms, 2)})
     on_valu = [r for r in rows if r["route"] == "valu"]
     geo = 1.0
@@ -262,6 +277,12 @@ def run_grid(args, device):
             "config": {"workload": "grid: TT-LSTM / TT-GRU in=40, H in {64..1024}, ncores in {2,3,4}, ttrank in {2,4,8,16}, "
                                    "batch 64, seq_len 64, " + ("forward + backward of sum(outputs)" if train else "forward (no_grad)")},
             "shapes": len(rows), "shapes_on_valu_route": len(on_valu),
+            "eager_ms": {"min": min(r["ms"] for r in rows), "median": sorted(r["ms"] for r in rows)[len(rows) // 2]},
+            "graph_replay_ms": (None if not (train and args.graph) else
+                                {"min": min(r["graph_ms"] for r in rows),
+                                 "median": sorted(r["graph_ms"] for r in rows)[len(rows) // 2],
+                                 "what": "the same forward + BPTT recorded once into a hipGraph and replayed "
+                                         "(ttrnn_hip.CapturedTrainStep): host floor of the eager step removed"}),
             "bwd_routes": {k: sum(1 for r in rows if r["bwd_route"] == k) for k in sorted({r["bwd_route"] for r in rows})},
             "routes": {k: sum(1 for r in rows if r["route"] == k) for k in sorted({r["route"] for r in rows})},
             "grid": rows}
@@ -328,7 +349,15 @@ def main():
                     help="forward: the headline metric (no_grad forward). train: the reference's training benchmark step "
                          "(benchmarking.py:41-70: classifier forward + nll_loss + BPTT + Adam) + flat-bucket gradient "
                          "all-reduce (RCCL) for N > 1, reported in the same unit")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode / grid --mode train: record the step once into a hipGraph (ttrnn_hip.CapturedTrainStep) and "
+                         "time REPLAYS — one host call per step instead of 30 ... 110 launches through ctypes and autograd.  "
+                         "Opt-in; the line says so in config.mode.  Single process only")
     args = ap.parse_args()
+    if args.graph and args.mode != "train":
+        raise SystemExit("--graph captures a TRAINING step: use it with --mode train")
+    if args.graph and args.gpus > 1:
+        raise SystemExit("--graph is single-process (the gradient all-reduce is not captured)")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU (no
@@ -414,12 +443,17 @@ def main():
         torch.manual_seed(2222 + rank)
         target = torch.randint(0, n_cls, (w["B"],), device=device)
         reducer = FlatGradAllReduce(model, force=force_dist) if dist is not None else None
-        try:        # one fused multi-tensor kernel instead of eight foreach launches (same update rule)
-            opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-            optimizer_impl = "torch.optim.Adam(fused=True)"
-        except (RuntimeError, TypeError, ValueError):
-            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-            optimizer_impl = "torch.optim.Adam"
+        if args.graph:
+            import ttrnn_hip
+            opt = ttrnn_hip.adam_for_capture(model.parameters(), lr=1e-3)
+            optimizer_impl = "torch.optim.Adam(capturable=True, fused where available), step replayed from a hipGraph"
+        else:
+            try:        # one fused multi-tensor kernel instead of eight foreach launches (same update rule)
+                opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+                optimizer_impl = "torch.optim.Adam(fused=True)"
+            except (RuntimeError, TypeError, ValueError):
+                opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+                optimizer_impl = "torch.optim.Adam"
 
     def step():
         if args.mode == "forward":
@@ -433,6 +467,27 @@ def main():
             reducer.sync()
         opt.step()
         return loss
+
+    eager_kern_ms = None
+    if args.graph:
+        # two eager steps with the kernel timer on (the events of the recurrent launches cannot be recorded inside a replay),
+        # then the capture; from here on step() is one graph replay
+        import ttrnn_hip
+        step()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        step()
+        step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        eager_kern_ms = (timer.mean_ms("ttrnn_rnn_forward"), timer.median_ms("ttrnn_rnn_forward"),
+                         timer.count("ttrnn_rnn_forward") / 2.0)
+        timer.pairs.clear()
+        captured = ttrnn_hip.CapturedTrainStep(
+            model, opt, lambda m, xx, tt: torch.nn.functional.nll_loss(m(xx).float(), tt), (x, target), warmup=1)
+
+        def step():                                   # noqa: F811
+            return captured(x, target)
 
     for _ in range(args.warmup):
         step()
@@ -489,6 +544,8 @@ def main():
     kern_ms_median = timer.median_ms("ttrnn_rnn_forward")
     step_ms_median = timer.median_ms("step")          # per-step device time (events on the launch stream)
     launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
+    if eager_kern_ms is not None:                     # --graph: the recurrent launches' duration from the eager steps before capture
+        kern_ms, kern_ms_median, launches_per_step = eager_kern_ms
 
     # fp32 workloads: which matrix arithmetic ran (include/ttrnn.h TTRNN_MATH_*) and, at N=1, the same steps again
     # in the OTHER mode, so that both figures come from one process on one device (outside the timed region above)
@@ -591,7 +648,8 @@ def main():
                        "global_batch": global_batch, "parallelism": "batch-sharded x{} (no forward collective)".format(world),
                        "mode": ("forward (no_grad), inputs resident in HBM" if args.mode == "forward" else
                                 "train step of the reference's benchmarking.py:41-70 (zero_grad + classifier forward + nll_loss "
-                                "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM; " + optimizer_impl),
+                                "+ BPTT + Adam; gradient all-reduce for N > 1), inputs resident in HBM; " + optimizer_impl +
+                                ("; the whole step captured once and REPLAYED as a hipGraph (--graph)" if args.graph else "")),
                        "fp32_math": FP32_MATH_DESC.get(math_mode),
                        "prepared_weights": (
                            "--prepared: prepare_for_inference() modules — packed cores, scale header, fused-core fragments and "

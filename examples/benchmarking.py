@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--gru", action="store_true")
     ap.add_argument("--naive_tt", action="store_true")
     ap.add_argument("--train", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="--train only: record the step once into a hipGraph (ttrnn_hip.CapturedTrainStep) and time replays")
     args = ap.parse_args()
     device = torch.device("cuda")
     with contextlib.redirect_stdout(io.StringIO()):
@@ -39,8 +41,15 @@ def main():
     data = torch.from_numpy(np.random.rand(args.batch_size, args.seq_len, args.in_size).astype("float32")).to(device)
     target = torch.from_numpy(np.random.randint(0, args.emb_size, args.batch_size).astype("int64")).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    captured = None
+    if args.graph and args.train:
+        import ttrnn_hip
+        opt = ttrnn_hip.adam_for_capture(model.parameters(), lr=1e-3)
+        captured = ttrnn_hip.CapturedTrainStep(model, opt, lambda m, d, t: F.nll_loss(m(d), t), (data, target))
 
     def step():
+        if captured is not None:
+            return captured(data, target)
         if not args.train:
             with torch.no_grad():
                 return model(data)
