@@ -397,10 +397,53 @@ __device__ __forceinline__ f32x4 ld4_rows(const TS* __restrict__ x, const RowShi
   return (head && !fp) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
 }
 
+// ---- bias gradient = column sums of dy, WITHOUT atomics ------------------------------------------------------------------
+// Round 3 flushed every staging thread's running column sums with atomicAdd: 8 192 atomics per workgroup onto 256 addresses
+// (16 per thread), 4 096 per address and launch at KS = 128 — same-address atomics retire one after the other at L2, and on
+// small problems (B*T = 4 096 rows: one chunk per workgroup) that queue WAS the kernel: 400 us for 5 us of work
+// (profiles/r4/seq_h64_before.txt), and the sums' last bits depended on the order of arrival.  Now: the G staging groups of a
+// workgroup (threads that stage the same column quad) are summed through LDS in a fixed order, one thread per column
+// stores the workgroup's sum to bpart[ks][column], and k_dense_bias_reduce adds the row ranges in a fixed order:
+// repeatable bit for bit, no atomics.
+template <int W, int G>
+__device__ __forceinline__ void bias_partial(float* red, const f32x4& v, int group, int col4, float* __restrict__ dst, int tid) {
+  lds_barrier();                                           // every wave is done with the staging buffers `red` overlays
+  *reinterpret_cast<f32x4*>(red + group * W + col4) = v;
+  lds_barrier();
+  if (tid < W) {
+    float sum = red[tid];
+#pragma unroll
+    for (int g = 1; g < G; ++g) sum += red[g * W + tid];
+    dst[tid] = sum;
+  }
+}
+
+// d_bias[o] += sum over the KS row ranges of bpart[ks][o] (d_bias is accumulated into by contract).  One thread per column
+// walking KS = 128 ranges was a chain of 128 dependent-issue loads (30 us); 32 columns x 8 range groups per workgroup, each
+// thread its group's ranges in order, the eight group sums added in order through LDS: the same fixed order on every launch.
+__global__ void __launch_bounds__(256) k_dense_bias_reduce(const float* __restrict__ bpart, int KS, int OUT,
+                                                           float* __restrict__ d_bias) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + c;
+  const int per = (KS + 7) / 8, k0 = kg * per, k1 = k0 + per < KS ? k0 + per : KS;
+  float v = 0.f;
+  if (o < OUT)
+    for (int k = k0; k < k1; ++k) v += bpart[(size_t)k * OUT + o];
+  red[kg][c] = v;
+  __syncthreads();
+  if (kg == 0 && o < OUT) {
+    float sum = red[0][c];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) sum += red[g][c];
+    d_bias[o] += sum;
+  }
+}
+
 template <typename TS>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                          const TS* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
+                                                         float* __restrict__ dW, float* __restrict__ bpart, float* __restrict__ part,
                                                          RowShift rsh) {
   constexpr int KB = DenseG::KB, LS = DenseG::LS;
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
@@ -438,7 +481,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
   f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool want_bias = d_bias != nullptr && tj == 0;
+  const bool want_bias = bpart != nullptr && tj == 0;      // (workgroup-uniform)
 
   // staging: thread -> rows (tid / 32) + 16e of the chunk, four consecutive columns.  The loads of chunk ch+1 are issued
   // right after chunk ch went to LDS and are not touched (not even scaled) before the next iteration
@@ -501,10 +544,8 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
           else atomicAdd(dW + e, acc[mi][ni][j]);
         }
       }
-  if (want_bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(d_bias + o0 + scol + e, dbs[e]);
-  }
+  if (want_bias)      // 16 staging rows x 32 column quads: sixteen groups over the tile's 128 columns
+    bias_partial<DenseG::TN, 16>(ldsf, dbs, srow, scol, bpart + (size_t)ks * OUT + o0, tid);
 }
 
 // ---- the same dense gradient on the bf16 MFMA (split arithmetic) ---------------------------------------------------------------
@@ -594,7 +635,7 @@ __device__ __forceinline__ xbf8 tr_frag(const __bf16* plane, int cb, int lane) {
 template <typename TS, bool HALF, bool SHIFT, bool ABL = false>
 __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, int IN, int OUT, int KS, int64_t rows_per,
                                                                const TS* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dW, float* __restrict__ d_bias, float* __restrict__ part,
+                                                               float* __restrict__ dW, float* __restrict__ bpart, float* __restrict__ part,
                                                                const unsigned* __restrict__ colmax_x,
                                                                const unsigned* __restrict__ colmax_dy, RowShift rsh, int dev) {
   constexpr int KB = DenseS::KB, PL = DenseS::PLANE;
@@ -637,7 +678,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
   f32x4 dbs[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) dbs[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool want_bias = d_bias != nullptr && tj == 0;
+  const bool want_bias = bpart != nullptr && tj == 0;      // (workgroup-uniform)
 
   // staging: x quads tid + 512e (row = id >> 5, columns 4 (id & 31)); dy quads tid + 512e (row = id >> 6, columns 4 (id & 63))
   f32x4 sx[2], sd[4];
@@ -826,23 +867,32 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad_split(int64_t n_rows, i
         }
       }
     }
-  if (want_bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(d_bias + o0 + dc[e] + i, dbs[e][i]);
-  }
+  if (want_bias)      // a thread stages the same column quad in all four of its rows; eight waves = eight groups over 256 columns
+    bias_partial<DenseS::TO, 8>(reinterpret_cast<float*>(smem2), (dbs[0] + dbs[1]) + (dbs[2] + dbs[3]), wave, dc[0],
+                                bpart + (size_t)ks * OUT + o0, tid);
 }
 
-// dW[e] = sum over the KS row ranges of part[ks][e] (row ranges past the end of the rows are not summed)
+// dW[e] = sum over the KS row ranges of part[ks][e] (row ranges past the end of the rows are not summed).  32 element quads x 8
+// range groups per workgroup, the groups' sums added in a fixed order through LDS (one thread per quad walking all KS ranges
+// left a small matrix — in = 64: 16 workgroups — at 0.4 TB/s: 37 us for 16 MB)
 __global__ void __launch_bounds__(256) k_dense_reduce(const float* __restrict__ part, int KS, size_t n4,
                                                       float* __restrict__ dW) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n4) return;
+  __shared__ f32x4 red[8][32];
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const size_t e = (size_t)blockIdx.x * 32 + c;
+  const int per = (KS + 7) / 8, k0 = kg * per, k1 = k0 + per < KS ? k0 + per : KS;
   const f32x4* p = reinterpret_cast<const f32x4*>(part);
-  f32x4 v = p[e];
-  for (int k = 1; k < KS; ++k) v += p[(size_t)k * n4 + e];
-  reinterpret_cast<f32x4*>(dW)[e] = v;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e < n4)
+    for (int k = k0; k < k1; ++k) v += p[(size_t)k * n4 + e];
+  red[kg][c] = v;
+  __syncthreads();
+  if (kg == 0 && e < n4) {
+    f32x4 sum = red[0][c];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) sum += red[g][c];
+    reinterpret_cast<f32x4*>(dW)[e] = sum;
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -973,6 +1023,8 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % De
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
 static size_t dense_colmax_bytes(int in, int out) { return al256g((size_t)(in + out) * sizeof(unsigned)); }
+// partial column sums of dy per row range (at most one range per CU, rounded up to the XCD multiple)
+static size_t dense_bias_part_bytes(int out) { return al256g((size_t)((device_cu_count() + 7) / 8 * 8) * out * sizeof(float)); }
 
 // two fp16 pieces (three terms) where the column-maximum passes over x and dy pay off, else three bf16 pieces
 static bool dense_wgrad_use_half(int64_t n_rows, int in, int out) {
@@ -991,7 +1043,9 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   rsh.T = shift_T > 0 ? shift_T : 0;
   rsh.first = shift_T > 0 ? shift_first : nullptr;
   split = split && out % DenseS::TO == 0 && !opt(OPT_DENSE_FP32);      // A/B switch: dense gradient on the fp32 MFMA
-  // scratch: [column maxima of x and dy (HALF) | partial tiles of the row ranges]
+  // scratch: [column maxima of x and dy (HALF) | partial tiles of the row ranges | partial column sums (bias) of the row ranges]
+  if (d_bias && !scratch_all) return TTRNN_ERR_WORKSPACE;
+  float* bpart = d_bias ? (float*)((char*)scratch_all + dense_wgrad_scratch_bytes(in, out) - dense_bias_part_bytes(out)) : nullptr;
   unsigned* colmax = (unsigned*)scratch_all;
   float* scratch = scratch_all ? (float*)((char*)scratch_all + dense_colmax_bytes(in, out)) : nullptr;
   // the producer's bounds for dy's columns make the two-piece variant free of its 4-bytes-per-element pass over dy: taken
@@ -1059,7 +1113,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<TSV, HV, SV>), lds) != TTRNN_OK)                  \
       return TTRNN_ERR_LAUNCH;                                                                                                \
     hipLaunchKernelGGL((k_dense_wgrad_split<TSV, HV, SV>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS,       \
-                       rows_per, (const TSV*)x, dy, dW, d_bias, part, cx, cd, rsh, 0);                                        \
+                       rows_per, (const TSV*)x, dy, dW, bpart, part, cx, cd, rsh, 0);                                         \
   } while (0)
 #define TT_WG2(TSV, HV) do { if (rsh.T > 0) TT_WG(TSV, HV, true); else TT_WG(TSV, HV, false); } while (0)
 #ifdef TTRNN_ABLATIONS      // harness build only (`make ablation`): the no-MFMA / no-split / no-load / no-fragment-read instantiation
@@ -1067,19 +1121,19 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad_split<float, true, false, true>), lds) != TTRNN_OK)
       return TTRNN_ERR_LAUNCH;
     hipLaunchKernelGGL((k_dense_wgrad_split<float, true, false, true>), dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out,
-                       KS, rows_per, (const float*)x, dy, dW, d_bias, part, cx, cd, rsh, opt(OPT_DEV));
+                       KS, rows_per, (const float*)x, dy, dW, bpart, part, cx, cd, rsh, opt(OPT_DEV));
   } else
 #endif
   switch (di) {
     case 0:
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<float>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
       hipLaunchKernelGGL(k_dense_wgrad<float>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const float*)x, dy, dW, d_bias, part, rsh);
+                         (const float*)x, dy, dW, bpart, part, rsh);
       break;
     case 1:
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_dense_wgrad<bf16_t>), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
       hipLaunchKernelGGL(k_dense_wgrad<bf16_t>, dim3(grid), dim3(FAST_NT), lds, stream, n_rows, in, out, KS, rows_per,
-                         (const bf16_t*)x, dy, dW, d_bias, part, rsh);
+                         (const bf16_t*)x, dy, dW, bpart, part, rsh);
       break;
     case 2: TT_WG2(float, false); break;
     case 3: TT_WG2(bf16_t, false); break;
@@ -1090,8 +1144,10 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
 #undef TT_WG
   if (part) {
     const size_t n4 = (size_t)in * out / 4;
-    hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, KS, n4, dW);
+    hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream, part, KS, n4, dW);
   }
+  if (bpart)
+    hipLaunchKernelGGL(k_dense_bias_reduce, dim3((unsigned)((out + 31) / 32)), dim3(256), 0, stream, bpart, KS, out, d_bias);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -1102,9 +1158,9 @@ size_t dense_wgrad_scratch_bytes(int in, int out) {
   const int tiles_s = ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO > 0 ? out / DenseS::TO : 1);
   const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
   const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;
-  if (tiles >= cus) return dense_colmax_bytes(in, out);
+  if (tiles >= cus) return dense_colmax_bytes(in, out) + dense_bias_part_bytes(out);
   const int KS = ((cus / tiles + 7) / 8) * 8;
-  return dense_colmax_bytes(in, out) + (size_t)KS * in * out * sizeof(float);
+  return dense_colmax_bytes(in, out) + al256g((size_t)KS * in * out * sizeof(float)) + dense_bias_part_bytes(out);
 }
 
 }  // namespace ttrnn

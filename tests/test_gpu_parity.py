@@ -2143,7 +2143,11 @@ def test_reverse_kernel_by_products_feed_the_weight_gradients(kind, inp, H, d, L
           % (worst[True], worst[False]))
     # (the big shape's dense gradients take the two-piece variant from 2^36 multiply-adds on by themselves; at this test's
     # size the by-products switch them from three bf16 pieces to two fp16 pieces, as for the small shapes)
-    assert differ or dtype == "bf16"                             # (rounding the gradients to bf16 can hide the difference)
+    # (rounding the gradients to bf16 can hide the difference; and where G*H is no multiple of the split dense gradient's 256-column
+    # tile — the GRU of H = 128: 384 — the gradient runs on the fp32 MFMA with or without bounds: since round 4, when the bias
+    # sums stopped going through atomics, the two runs are then equal bit for bit)
+    n_gate_cols = (4 if kind == "ttlstm" else 3) * H
+    assert differ or dtype == "bf16" or n_gate_cols % 256 != 0
     assert worst[True] <= (5e-2 if dtype == "bf16" else 2e-4) and worst[True] <= 3.0 * worst[False] + 1e-6
 
 

@@ -79,7 +79,9 @@ def test_captured_step_equals_eager_step(name):
         opt_a.step()
     torch.cuda.synchronize()
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        assert float((pa - pb).abs().max()) <= 1e-5 * max(float(pa.abs().max()), 1e-3), k
+        # Adam divides by sqrt(v): where a gradient is ~0 its last-bit noise (atomic bias sums) moves the update by a visible
+        # fraction of lr — bounded by a few per cent of the three steps' total travel (3 * lr)
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-5 * max(float(pa.detach().abs().max()), 1e-3) + 3e-4 * 1e-3, k
     assert ttrnn_hip.device_status()["pair_timeouts"] == 0
 
 

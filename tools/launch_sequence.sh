@@ -8,8 +8,14 @@ TAG=$1; shift
 OUT=$REPO/gpurun_out/seqraw_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- \
-  python3 "$REPO/bench.py" --no-cpu-baseline "$@" --steps 4 --warmup 2 > "$OUT/bench.json" 2> "$OUT/err.txt"
+# SEQ_HARNESS=1: the step of examples/benchmarking.py (the reference's own harness flags: --tt --hidden_size ... --train) instead
+if [ "${SEQ_HARNESS:-0}" = "1" ]; then
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- \
+    python3 "$REPO/examples/benchmarking.py" "$@" -n 4 > "$OUT/bench.json" 2> "$OUT/err.txt"
+else
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- \
+    python3 "$REPO/bench.py" --no-cpu-baseline "$@" --steps 4 --warmup 2 > "$OUT/bench.json" 2> "$OUT/err.txt"
+fi
 python3 - "$OUT" "$REPO/gpurun_out/seq_$TAG.txt" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
