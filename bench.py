@@ -74,9 +74,10 @@ EXECUTED = {
     "cfg2": dict(bf16_mfma=16 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
                  note="fused core on two-piece fp16 operands: S2 (K=8, four terms packed into one MFMA per tile) + S10 "
                       "(64 x 16 x 256, three terms x0w0 + x0w1 + x1w0)"),
-    # cfg1: stage-wise fp32 kernel: stage 1 8 m-tiles x 4 k-steps, stage 0 2 row tiles x 8 k-steps
-    "cfg1": dict(bf16_mfma=0, fp32_mfma=32 + 16, kin_bf16_flop=0, rec_simds=4,
-                 note="stage-wise fp32 MFMA kernel (k_lstm_fwd_fused)"),
+    # cfg1 (round 4, ttrnn_fast_f2.hip): stage 1 8 m-tiles x 2 chained MFMAs (the three split terms, K = 16 packed twice along the
+    # 32-wide k) + stage 0 2 column tiles x 3 terms, on the two waves (two SIMDs) of a sample's workgroup
+    "cfg1": dict(bf16_mfma=16 + 6, fp32_mfma=0, kin_bf16_flop=0, rec_simds=2, pipe16="f16_mfma", terms=3,
+                 note="two-core kernel on two-piece fp16 operands (k_lstm_fwd_f2): one barrier per step, gates on the accumulators"),
     # cfg3: bf16 storage, plain bf16 MFMAs: S2 4 waves x 6 m-tiles (each wave its own eight chain rows: half of a tile's
     # columns are padding) + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10v)
     "cfg3": dict(bf16_mfma=24 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,

@@ -58,6 +58,10 @@ __global__ void __launch_bounds__(FAST_NT) k_rnn_fwd_fast(int B, int T, GinSrc g
   constexpr int G = CELL == TTRNN_LSTM ? 4 : 3;
   constexpr int GH = G * H;
   static_assert(out_size_of<S>() == GH, "TT output size must be n_gates * hidden");
+  if (gs.run_if) {                                       // queued as a fallback (GinSrc::run_if): workgroup-uniform
+    if (*gs.run_if == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && gs.status) atomicAdd(gs.status + TTRNN_STAT_GUARD_TRIPS, 1u);
+  }
   constexpr int HPT = (H + FAST_NT - 1) / FAST_NT;       // hidden units per thread
   constexpr int MID = maxmid_of<S>();
   using SL = St<S, D - 1>;                               // first stage executed (reads h)
@@ -247,6 +251,10 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_fused(int B, int T, GinSrc
   constexpr int H = in_size_of<S>();
   constexpr int GH = 4 * H;
   static_assert(out_size_of<S>() == GH, "TT output size must be 4 * hidden");
+  if (gs.run_if) {                                       // queued as a fallback (GinSrc::run_if): workgroup-uniform
+    if (*gs.run_if == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && gs.status) atomicAdd(gs.status + TTRNN_STAT_GUARD_TRIPS, 1u);
+  }
   constexpr int MID = maxmid_of<S>();
   using SL = St<S, D - 1>;
   using T0 = St<S, 0>;

@@ -910,14 +910,14 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R8L>();
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R16L>();
-  return 0;
+  return f2_workspace_bytes(rs, dtype);      // two-core hidden matrices (ttrnn_fast_f2.hip)
 }
 
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
-  return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
+  return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s) || f2_rnn_fwd_available(rs, dtype);
 }
 
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
@@ -932,6 +932,8 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
       return launch_f10g<ShpH256R8G>(rs, gin, h0, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
     return TTRNN_ERR_UNSUPPORTED;
   }
+  if (f2_rnn_fwd_available(rs, TTRNN_F32))      // d = 2: both stages on fp16 pieces, one barrier per step (ttrnn_fast_f2.hip)
+    return launch_rnn_fwd_f2(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
   // r = 8: one wave per tile row (measured 7 % faster than the k-split layout); r = 16: k-split (register budget)
   if (shape_matches<ShpH256R8L>(rs.hid_s))
     return launch_f10<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);

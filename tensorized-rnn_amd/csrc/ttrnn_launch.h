@@ -48,6 +48,11 @@ struct GinSrc {
   const float* gin;
   const void* x;
   int in1;
+  // a stage-wise kernel queued BEHIND a two-piece fp16 kernel as its fallback (ttrnn_fast_f2.hip): runs only when *run_if != 0 —
+  // the fp16 kernel's prep found an operand row whose second pieces would be subnormal and that kernel stepped aside — and then
+  // counts the launch in status[TTRNN_STAT_GUARD_TRIPS].  NULL (every other caller): run unconditionally.
+  const int* run_if = nullptr;
+  unsigned* status = nullptr;
 };
 
 struct LinPlan {
@@ -126,6 +131,13 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype);   // fused-core fragm
 int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                        const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                        hipStream_t stream, int phase = 0);
+
+// two-core (d = 2) hidden matrices: both chain stages on two-piece fp16 operands, gates on the accumulators, one barrier per step
+// (ttrnn_fast_f2.hip; reached through launch_rnn_fwd_f10 / f10_workspace_bytes / f10_rnn_fwd_available)
+bool f2_rnn_fwd_available(const RnnShape& rs, int dtype);
+size_t f2_workspace_bytes(const RnnShape& rs, int dtype);
+int launch_rnn_fwd_f2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
+                      const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream, int phase);
 
 // the bf16 GRU as four-wave workgroups with in-lane gates (ttrnn_fast_f10gq.hip); ws: f10gq_workspace_bytes
 size_t f10gq_workspace_bytes();

@@ -1125,6 +1125,97 @@ def test_split_math_operand_ranges(case, route):
     assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("case", ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes"])
+def test_two_core_kernel_operand_ranges(case):
+    """ttrnn_fast_f2.hip (d = 2: H = 128, ranks 4 — BASELINE configs[0], pMNIST's default --ncores 2): both chain stages on
+    two-piece fp16 operands under diagonal power-of-two scales (per i1 / rank index of core 1, per row of core 0, per sample for a
+    caller's h_0).  784 steps for the fresh model, short runs for the operand-range cases, both math modes (exact = the
+    fp32-MFMA stage-wise kernel) against the float64 oracle; batch split and repeat launches bit for bit."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(29)
+    m = build_module(dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), dev())
+    T = 784 if case == "fresh" else 6
+    B = 5
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(B, T, 1, generator=g) if case == "fresh" else torch.randn(B, T, 1, generator=g)
+    h0, c0 = torch.randn(B, 128, generator=g) * 0.3, torch.randn(B, 128, generator=g) * 0.3
+    with torch.no_grad():
+        cores = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+        assert len(cores) == 2
+        if case == "tiny_weights":
+            for p in cores:
+                p.mul_(1e-5)
+        elif case == "huge_weights":
+            for p in cores:
+                p.mul_(200.0)
+        elif case == "huge_h0":
+            h0 = torch.randn(B, 128, generator=g) * torch.tensor([0.1, 3.0, 40.0, 500.0, 6000.0]).view(B, 1)
+        elif case == "zero_core":
+            cores[0].zero_()
+        elif case == "mixed_magnitudes":
+            for k, step, f in ((1, 3, 1e-6), (0, 2, 1e-5)):
+                w = cores[k].detach().clone().reshape(-1)
+                w[::step] *= f
+                cores[k].copy_(w.reshape(cores[k].shape))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, _, c64 = _oracle_forward("ttlstm", sd, 1, x.double(), (h0.double(), c0.double()))
+    scale = max(1e-30, float(c64.abs().max()), float(r64.abs().max()))
+    errs = {}
+    xd, hd, cd = x.to(dev()), h0.to(dev()), c0.to(dev())
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if mode == "split" else "stagewise_mfma")
+            out, (hT, cT) = m(xd, (hd, cd))
+            if mode == "split":
+                again, _ = m(xd, (hd, cd))
+                assert torch.equal(out, again)                               # repeat launch
+                part, _ = m(xd[1:3], (hd[1:3], cd[1:3]))
+                assert torch.equal(out[1:3], part)                           # samples never interact
+                assert torch.equal(out[:, -1], hT)
+                if case != "huge_weights":      # (TT-matrix x 40 000: the recurrence amplifies one ulp by 4e4 per step — sign flips of
+                    nost = m(xd)[0]             # saturated units after six steps in ANY arithmetic; the run above stays comparable)
+                    r0, _, _ = _oracle_forward("ttlstm", sd, 1, x.double())      # zero initial state: the H0 = false instantiation
+                    assert _maxabs(nost, r0) <= 2e-6 * max(1.0, float(r0.abs().max()))
+        assert torch.isfinite(out).all() and torch.isfinite(cT).all(), (case, mode)
+        errs[mode] = max(_maxabs(out, r64), _maxabs(cT, c64))
+    print(case, "two-core kernel: max abs error vs float64 (state scale %.3g):" % scale, errs)
+    tol = 2e-3 if case in ("huge_weights", "huge_h0") else 2e-6
+    assert errs["split"] <= tol * max(1.0, scale)
+    assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
+
+
+def test_two_core_kernel_guard_falls_back_on_outlier_rows():
+    """k_f2_prep's guard: the scales of the two-core kernel are u[i1] + v[a] (the most general form both stages can share), so one
+    core-1 entry x 1e5 drags the other rank rows of its i1 slice 17 binades down — second fp16 pieces subnormal, 12 of 22 bits
+    left.  Such weights leave for the fp32-MFMA stage-wise kernel queued behind the launch: the result then equals the exact
+    mode's bit for bit, the trip is counted (ttrnn_device_status), and a fresh model does not trip."""
+    import ttrnn_hip
+    torch.manual_seed(37)
+    m = build_module(dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), dev())
+    x = torch.rand(4, 9, 1, device=dev())
+    ttrnn_hip.device_status(reset=True)
+    with torch.no_grad():
+        fresh = m(x)[0]
+        assert ttrnn_hip.device_status()["guard_trips"] == 0
+        with ttrnn_hip.fp32_math("exact"):
+            fresh_exact = m(x)[0]
+        assert not torch.equal(fresh, fresh_exact) and _maxabs(fresh, fresh_exact) <= 1e-6       # two different kernels ran
+        core1 = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n][1]
+        flat = core1.detach().clone().contiguous().view(-1)
+        flat[(5 * flat.numel()) // 11] *= 1e5
+        core1.copy_(flat.view(core1.shape))
+        tripped = m(x)[0]
+        st = ttrnn_hip.device_status(reset=True)
+        assert st["guard_trips"] == 1, st
+        with ttrnn_hip.fp32_math("exact"):
+            exact = m(x)[0]
+        assert torch.equal(tripped, exact)
+        m.prepare_for_inference()                         # the guard word lives in the prepared workspace too
+        assert torch.equal(m(x)[0], exact) and torch.equal(m(x)[0], exact)
+        assert ttrnn_hip.device_status(reset=True)["guard_trips"] == 2
+
+
 OUTLIER_SHAPES = {
     # name: (module meta, B, T, route the forward must take in split mode, options for the split run)
     "fused_core_r8": (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 3, 5, "fused_core", {}),
@@ -1135,6 +1226,9 @@ OUTLIER_SHAPES = {
                         {"force_g2": 1}),
     "runtime_mfma_gru": (dict(kind="ttgru", input_size=40, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4), 20, 5, "runtime_mfma", {}),
     "merged_big": (dict(kind="ttlstm", input_size=1024, hidden_size=1024, num_layers=1, n_cores=4, tt_rank=32), 2, 3, "merged_big", {}),
+    # round 4: the two-core kernel (ttrnn_fast_f2.hip: cfg1 / pMNIST --ncores 2), in = 1 (unit rows) and in = H (a stacked layer's gin)
+    "two_core_f2": (dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), 3, 6, "fused_core", {}),
+    "two_core_f2_stack": (dict(kind="ttlstm", input_size=128, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), 5, 4, "fused_core", {}),
 }
 
 
