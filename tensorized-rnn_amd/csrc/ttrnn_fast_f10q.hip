@@ -33,7 +33,9 @@ constexpr size_t f10q_lds_bytes() {
 // H0: the caller passed an initial state (it may lie outside (-1, 1): f10h_h0_expo); without one the scales are constants
 // OUT = false: the caller consumes only the final state (speaker_encoder.py:80-86 takes `hidden[-1]`): `out` is not written
 // DIAG: s_memtime stamps around the phases (option diag + a reserve buffer; tools/diag_stamps.py; shares only, never run times)
-template <class S, int KH, bool H0, bool OUT, bool DIAG = false>
+// IN1: input_size == 1 (GinSrc::in1) as a template parameter (round 4): the runtime flag put four uniform branches and both
+// code paths into every step and cut the step into basic blocks the scheduler cannot move instructions across
+template <class S, int KH, bool H0, bool OUT, bool IN1, bool DIAG = false>
 __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                const float* __restrict__ c0,
                                                                const float* __restrict__ packed_hid,
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   // the hidden unit of this lane: hid = (4*wave + q)*I2 + c, gates in acc[0..3] = i,f,g,o; gin slots i,g,f,o
   const float* __restrict__ gin = gs.gin;
   const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
-  const bool in1 = gs.in1 != 0;
+  constexpr bool in1 = IN1;
   const bool ok = c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   float hst = (H0 && ok) ? h0[b * H + hd] : 0.f;
@@ -203,9 +205,12 @@ static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* 
   const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
   constexpr size_t lds = f10q_lds_bytes<S>();
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  auto kern = out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true> : k_lstm_fwd_f10q<S, KH, false, true>)
-                  : (h0 ? k_lstm_fwd_f10q<S, KH, true, false> : k_lstm_fwd_f10q<S, KH, false, false>);
-  if (opt(OPT_DIAG) && reserve && out && !h0) kern = k_lstm_fwd_f10q<S, KH, false, true, true>;      // stamped build (diagnostics)
+  auto kern = gin.in1 ? (out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true, true> : k_lstm_fwd_f10q<S, KH, false, true, true>)
+                             : (h0 ? k_lstm_fwd_f10q<S, KH, true, false, true> : k_lstm_fwd_f10q<S, KH, false, false, true>))
+                      : (out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true, false> : k_lstm_fwd_f10q<S, KH, false, true, false>)
+                             : (h0 ? k_lstm_fwd_f10q<S, KH, true, false, false> : k_lstm_fwd_f10q<S, KH, false, false, false>));
+  if (opt(OPT_DIAG) && reserve && out && !h0)      // stamped build (diagnostics)
+    kern = gin.in1 ? k_lstm_fwd_f10q<S, KH, false, true, true, true> : k_lstm_fwd_f10q<S, KH, false, true, false, true>;
   if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(QW * 64), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, hdr, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);

@@ -83,13 +83,17 @@ __global__ void __launch_bounds__(256) k_f2_prep(const float* __restrict__ packe
     eu[tid] = f10h_expo(mx);
   }
   __syncthreads();
-  if (tid < F::R1) {                                      // v[a]: max over (i1, j1) of 2^-u[i1] |G1| < 2^v
-    float mx = 0.f;
-    for (int i1 = 0; i1 < F::I1; ++i1) {
-      const float s = ldexpf(1.f, -eu[i1]);
-      for (int j1 = 0; j1 < F::J1; ++j1) mx = fmaxf(mx, fabsf(g1[j1 * M1 + i1 * F::R1 + tid]) * s);
+  {                                                       // v[a]: max over (i1, j1) of 2^-u[i1] |G1| < 2^v — one thread per (i1, a)
+    __shared__ unsigned vmax[16];                         // row, the rows of an `a` merged by atomicMax on the bit patterns (>= 0)
+    if (tid < 16) vmax[tid] = 0u;
+    __syncthreads();
+    if (tid < M1) {
+      float mx = 0.f;
+      for (int j1 = 0; j1 < F::J1; ++j1) mx = fmaxf(mx, fabsf(g1[j1 * M1 + tid]));
+      atomicMax(&vmax[tid % F::R1], __float_as_uint(mx * ldexpf(1.f, -eu[tid / F::R1])));
     }
-    ev[tid] = f10h_expo(mx);
+    __syncthreads();
+    if (tid < F::R1) ev[tid] = f10h_expo(__uint_as_float(vmax[tid]));
   }
   __syncthreads();
   if (tid < F::I0) {                                      // p[i0]: 2^p max over (j0, a) of 2^v[a] |G0| in [2^11, 2^12)
@@ -158,8 +162,10 @@ __global__ void __launch_bounds__(256) k_f2_prep(const float* __restrict__ packe
 
 // ---- the recurrent kernel ---------------------------------------------------------------------------------------------------------
 // H0: the caller passed an initial state (may lie outside (-1, 1): per-sample exponent);  OUT = false: only the final state is wanted
-template <class S, bool H0, bool OUT>
-__global__ void __launch_bounds__(F2<S>::NWV * 64) k_lstm_fwd_f2(int B, int T, GinSrc gs, const float* __restrict__ h0,
+// IN1: input_size == 1 (the projection of the two unit rows, scaled by x_t) — a template parameter: a runtime flag put four uniform
+// branches and both code paths into every step
+template <class S, bool H0, bool OUT, bool IN1>
+__global__ void __launch_bounds__(F2<S>::NWV * 64, 4) k_lstm_fwd_f2(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                  const float* __restrict__ c0, const int* __restrict__ hdr,
                                                                  const xh8* __restrict__ frag, const float* __restrict__ bias_hid,
                                                                  float* __restrict__ out, float* __restrict__ hT,
@@ -198,7 +204,7 @@ __global__ void __launch_bounds__(F2<S>::NWV * 64) k_lstm_fwd_f2(int B, int T, G
   const float hsc = F10H_HSC;
   const float* __restrict__ gin = gs.gin;
   const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
-  const bool in1 = gs.in1 != 0;
+  constexpr bool in1 = IN1;
   float hst = H0 ? h0[b * H + hd] : 0.f;
   float cst = c0 ? c0[b * H + hd] : 0.f;
   float h0sc = 1.0f, h0un = 1.0f;
@@ -235,29 +241,33 @@ __global__ void __launch_bounds__(F2<S>::NWV * 64) k_lstm_fwd_f2(int B, int T, G
   // stage-1 operand address of this lane: chain row j0 = c & 7 (columns 8 .. 15 of the tiles repeat 0 .. 7 and are not used),
   // j1 = 8 (q & 1) .. + 7 — the same eight values for k-groups q and q + 2 (the term packing)
   const int hoff = (c & 7) * F::J1 + 8 * (q & 1);
-  const bool wr = c < F::J0;
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;
     // ---- stage 1 --------------------------------------------------------------------------------------------------------------
     const xh8 x0 = *reinterpret_cast<const xh8*>(hp + hoff);
     const xh8 x1 = *reinterpret_cast<const xh8*>(hp + H + hoff);
+    __builtin_amdgcn_sched_barrier(0);                     // both reads in flight before the first MFMA waits for one of them
+    // tiles in pairs (small term first, then the leading ones on the same accumulator): a pair's results are split while the
+    // next pair multiplies.  Lanes c >= 8 hold copies of lanes c - 8 (their operand column is chain row c & 7 again) and store
+    // the same values to the same addresses: no branch around the split, so that it can be scheduled between the MFMAs
     f32x4 t1[MT1];
 #pragma unroll
-    for (int x = 0; x < MT1; ++x) t1[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1b[x], x1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    for (int xp = 0; xp < MT1; xp += 2) {
 #pragma unroll
-    for (int x = 0; x < MT1; ++x) t1[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1a[x], x0, t1[x], 0, 0, 0);
-    // hand-off inside the wave: lane (j0 = c, q) of tile x holds C1'[j0][i1 = 16 wave + 4 x + q][a = 0 .. 3] -> row 4 x + q, k = 4 j0
-    if (wr) {
+      for (int x = xp; x < xp + 2; ++x) t1[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1b[x], x1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int x = 0; x < MT1; ++x) {
-        unsigned a0, b0, a1, b1;
-        split_pair_h(t1[x][0], t1[x][1], a0, b0);
-        split_pair_h(t1[x][2], t1[x][3], a1, b1);
-        const int off = f2_img_off(4 * x + q, c >> 1, 8 * (c & 1));
-        *reinterpret_cast<u32x2*>(img + off) = u32x2{a0, a1};
-        *reinterpret_cast<u32x2*>(img + IPL + off) = u32x2{b0, b1};
-      }
+      for (int x = xp; x < xp + 2; ++x) t1[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1a[x], x0, t1[x], 0, 0, 0);
+    }
+    // hand-off inside the wave: lane (j0 = c & 7, q) of tile x holds C1'[j0][i1 = 16 wave + 4 x + q][a = 0 .. 3] -> row 4 x + q, k = 4 j0
+#pragma unroll
+    for (int x = 0; x < MT1; ++x) {
+      unsigned a0, b0, a1, b1;
+      split_pair_h(t1[x][0], t1[x][1], a0, b0);
+      split_pair_h(t1[x][2], t1[x][3], a1, b1);
+      const int off = f2_img_off(4 * x + q, (c & 7) >> 1, 8 * (c & 1));
+      *reinterpret_cast<u32x2*>(img + off) = u32x2{a0, a1};
+      *reinterpret_cast<u32x2*>(img + IPL + off) = u32x2{b0, b1};
     }
     const size_t bt = b * T + t;
     // (W_in x_t + b_in + b_hid) * scale, slots i,g,f,o -> accumulator rows i,f,g,o
@@ -314,8 +324,10 @@ static int launch_f2(const RnnShape& rs, GinSrc gin, const void* h0, const void*
   if (phase != TTRNN_PHASE_RUN) hipLaunchKernelGGL((k_f2_prep<S>), dim3(1), dim3(256), 0, stream, packed_hid, hdr, frag);
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
-  auto kern = out ? (h0 ? k_lstm_fwd_f2<S, true, true> : k_lstm_fwd_f2<S, false, true>)
-                  : (h0 ? k_lstm_fwd_f2<S, true, false> : k_lstm_fwd_f2<S, false, false>);
+  auto kern = gin.in1 ? (out ? (h0 ? k_lstm_fwd_f2<S, true, true, true> : k_lstm_fwd_f2<S, false, true, true>)
+                             : (h0 ? k_lstm_fwd_f2<S, true, false, true> : k_lstm_fwd_f2<S, false, false, true>))
+                      : (out ? (h0 ? k_lstm_fwd_f2<S, true, true, false> : k_lstm_fwd_f2<S, false, true, false>)
+                             : (h0 ? k_lstm_fwd_f2<S, true, false, false> : k_lstm_fwd_f2<S, false, false, false>));
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(F::NWV * 64), F::LDS_BYTES, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, (const int*)hdr, (const xh8*)frag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
