@@ -713,7 +713,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_fwd_f10(int B, int T, GinSrc gs
 // six m-tiles (16-column tiles of which 8 columns are real: the matrix pipe idles 90 % of the step anyway) and written to the
 // S10 image.  One LDS hand-off and one barrier per step fewer than k_gru_fwd_f10: [S10 | barrier | gates + S2 | barrier].
 // OUT = false: the caller consumes only the final state (mnist_classifier.py:52-55 classifies the last step): no out store
-template <class S, bool OUT = true>
+// IN1: input_size == 1 as a template parameter (round 4; see k_lstm_fwd_f10q)
+template <class S, bool OUT, bool IN1>
 __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs, const bf16_t* __restrict__ h0,
                                                       const float* __restrict__ packed_hid,
                                                       const xbf8* __restrict__ wfrag,
@@ -747,7 +748,7 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10v(int B, int T, GinSrc gs
 
   const float* __restrict__ gin = gs.gin;
   const bf16_t* __restrict__ xs = reinterpret_cast<const bf16_t*>(gs.x);
-  const bool in1 = gs.in1 != 0;
+  constexpr bool in1 = IN1;
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gin);
   const int hid = tid;
   float hst = h0 ? ld(h0, b * H + hid) : 0.f;
@@ -852,7 +853,8 @@ static int launch_f10g(const RnnShape& rs, GinSrc gin, const void* h0, const flo
     hipLaunchKernelGGL((k_f10g_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, wfrag);
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   if (!(opt(OPT_DEV) & 32)) {    // default: four waves, S2 inside the gate waves (dev bit 5: the eight-wave kernel, A/B)
-    auto kern = out ? k_gru_fwd_f10v<S, true> : k_gru_fwd_f10v<S, false>;
+    auto kern = gin.in1 ? (out ? k_gru_fwd_f10v<S, true, true> : k_gru_fwd_f10v<S, false, true>)
+                        : (out ? k_gru_fwd_f10v<S, true, false> : k_gru_fwd_f10v<S, false, false>);
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, (const bf16_t*)h0, packed_hid,
                        wfrag, rs.has_bias_hid ? (const bf16_t*)bias_hid : (const bf16_t*)nullptr, (bf16_t*)out, (bf16_t*)hT,
                        reserve);

@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(64) k_f10x_prep(const float* __restrict__ pack
 template <class S>
 constexpr size_t f10x_lds_bytes() { return sizeof(float) * (2 * F10<S>::H + F10<S>::I2 * F10<S>::K); }
 
-template <class S>
+// IN1: input_size == 1 as a template parameter (round 4; see k_lstm_fwd_f10q)
+template <class S, bool IN1>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10x(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                            const float* __restrict__ c0,
                                                            const float* __restrict__ packed_hid,
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_fwd_f10x(int B, int T, GinSrc 
 
   const float* __restrict__ gin = gs.gin;
   const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
-  const bool in1 = gs.in1 != 0;
+  constexpr bool in1 = IN1;
   const bool ok = gate_wave && c < F::I2;
   const int hd = ok ? (4 * wave + q) * F::I2 + c : 0;
   float hst = (ok && h0) ? h0[b * H + hd] : 0.f;
@@ -191,7 +192,8 @@ static int launch_f10x(const RnnShape& rs, GinSrc gin, const void* h0, const voi
   constexpr size_t lds = f10x_lds_bytes<S>();
   static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
   const float* bh = rs.has_bias_hid ? (const float*)bias_hid : (const float*)nullptr;
-  hipLaunchKernelGGL((k_lstm_fwd_f10x<S>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
+  auto kern = gin.in1 ? k_lstm_fwd_f10x<S, true> : k_lstm_fwd_f10x<S, false>;
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, gin, (const float*)h0,
                      (const float*)c0, packed_hid, wfrag, bh, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
