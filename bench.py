@@ -350,6 +350,9 @@ def main():
                     help="forward: the headline metric (no_grad forward). train: the reference's training benchmark step "
                          "(benchmarking.py:41-70: classifier forward + nll_loss + BPTT + Adam) + flat-bucket gradient "
                          "all-reduce (RCCL) for N > 1, reported in the same unit")
+    ap.add_argument("--seq-len", type=int, default=0, metavar="T",
+                    help="diagnostic: override the configuration's sequence length (the workload description says so; not the "
+                         "headline metric)")
     ap.add_argument("--graph", action="store_true",
                     help="train mode / grid --mode train: record the step once into a hipGraph (ttrnn_hip.CapturedTrainStep) and "
                          "time REPLAYS — one host call per step instead of 30 ... 110 launches through ctypes and autograd.  "
@@ -396,6 +399,9 @@ def main():
             raise SystemExit("--workload grid is a single-GPU sweep")
         return run_grid(args, device)
     w = dict(WORKLOADS[args.workload])
+    if args.seq_len > 0:
+        w["T"] = args.seq_len
+        w["desc"] += " — DIAGNOSTIC: seq_len overridden to {}".format(args.seq_len)
     global_batch = w["B"] * world
     if args.scaling == "strong":
         from ttrnn_hip.dist import shard_bounds

@@ -327,7 +327,11 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 // ---- forward ----------------------------------------------------------------------------------------------------------------
 // P8: stage 1 term-packed into one MFMA per tile (J_t <= 8); otherwise three MFMAs per 32-k block with the next block's
 // (or next tile pair's) operands requested before the current MFMAs — two code paths in ONE kernel spilled 347 VGPRs
-template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8>
+// NSL: register slots of the head fragments.  G2_PF for the rolling stream and for residents of up to eight k-blocks; sixteen
+// (round 4, RES only, eight-wave workgroups, UPT <= 2: 128 fragment VGPRs of the wave's 256) make the head of the reference's
+// default benchmark shape (H = 512, r = 8: 256 KB of two-piece fragments = sixteen k-blocks per wave) RESIDENT — streamed it
+// was 384 KB per sample-step through a 64 B/clk L2 -> CU path: 8.7 us per step at B = 512 for 1.3 us of matrix-pipe time
+template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8, int NSL = G2_PF>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, const int* __restrict__ hdr,
@@ -433,9 +437,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   // RES (chosen by the host for the whole launch: UW * KBP <= G2_PF): every wave's share of the head core lives in its
   // register slots for all T steps; otherwise the slots roll over a stream of fragments
   const xh8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 2 * 64 + lane;
-  xh8 wbuf[G2_PF][2];
+  static_assert(NSL == G2_PF || (RES && !DIAG), "more than G2_PF slots: resident fragments only");
+  xh8 wbuf[NSL][2];
 #pragma unroll
-  for (int j = 0; j < G2_PF; ++j)
+  for (int j = 0; j < NSL; ++j)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -596,13 +601,36 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     };
     if constexpr (RES) {
       // one unit, at most G2_PF blocks, every constant hoisted: fragment reads at immediate offsets, MFMAs, four stores
-      if (r_nlive > 0) {
+      if (r_nlive == NSL) {
+        // every slot live (the common case of the shapes that are resident at all): no per-block conditions — sixteen pairs of
+        // scalar compare + branch per step cut the unrolled body into basic blocks the scheduler cannot move the operand reads
+        // across (the same effect as the runtime input_size == 1 flag in the fused-core kernels)
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        xh8 bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          bf[0][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane);
+          bf[1][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane + 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+          if (j + 2 < NSL) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[(j + 2) % 3][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane + 32 * (j + 2));
+          }
+          split_block_h(wbuf[j], bf[j % 3], acc_lo, acc_hi);
+        }
+        const f32x4 acc = (acc_hi + acc_lo) * r_un;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r_ymask & (1 << j)) ybuf[r_ybase + j * m.It] = acc[j];
+      } else if (r_nlive > 0) {
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
         xh8 bf[2][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(r_brow + p * plane);
 #pragma unroll
-        for (int j = 0; j < G2_PF; ++j) {
+        for (int j = 0; j < NSL; ++j) {
           if (j < r_nlive) {
             if (j + 1 < r_nlive) {
 #pragma unroll
@@ -1065,8 +1093,22 @@ static int in_pad(int in) { return (in + 7) & ~7; }
 // dh vectors of T1's k split are per wave group: naive per-gate sets of H = 512, r = 16 miss the limit by 256 bytes with eight
 // waves; their BPTT ran on the VALU kernels, 320 ... 590 ms per pMNIST step).  The forward and the reverse-time kernel are
 // separate launches: each takes its own plan.
+// forward: the head fragments of every wave fit SIXTEEN register slots (and not eight): eight-wave plan, one stage-2 unit per wave
+static bool g2_fwd_res16(const G2Plan& p) {
+  return p.hid.ok && p.okf && p.hid.nw == 8 && p.upt <= 2 && p.hid.UW == 1 && p.hid.KBP > G2_PF && p.hid.KBP <= 16 &&
+         !opt(OPT_DIAG) && !(opt(OPT_DEV) & 4096);       // (dev bit 12: A/B switch, the streamed kernel as before)
+}
+
 static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
   const bool wide = rs.B <= device_cu_count();
+  if (!wide && !backward) {
+    // more samples than CUs: four-wave workgroups share a CU and hide each other's latencies — unless the eight-wave plan keeps
+    // the head core in registers where the four-wave plan streams it from L2 every step (two rounds of one-sample-per-CU
+    // workgroups with no weight traffic beat two co-resident workgroups pulling 2 x 384 KB per step through the same L2 port)
+    G2Plan q;
+    g2_plan(&q, rs, true);
+    if (g2_fwd_res16(q)) { *p = q; return; }
+  }
   g2_plan(p, rs, wide);
   if (!wide || !p->hid.ok || (backward ? p->okb : p->okf)) return;
   G2Plan q;
@@ -1182,9 +1224,18 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
+  const bool res16 = g2_fwd_res16(P);                  // ... in sixteen slots (eight-wave workgroups, UPT <= 2)
 #define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     const bool p8 = P.hid.pack8 != 0;                                                                                   \
+    if (res16 && UPTV <= 2) {                                                                                           \
+      auto kern16 = p8 ? k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, true, 16>                              \
+                       : k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, false, 16>;                            \
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern16), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;     \
+      hipLaunchKernelGGL(kern16, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0,          \
+                         (const TS*)c0, reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve); \
+      break;                                                                                                             \
+    }                                                                                                                    \
     auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, true, true>       \
                                                                      : k_g2_fwd<CELLV, TS, UPTV, true, true, false>)     \
                                                                : (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true>      \
