@@ -227,7 +227,9 @@ int ttrnn_unpack_core_grads(const ttrnn_ttm* w, const float* packed_grad, void* 
 
 // ---- TTLinear ---------------------------------------------------------------------------------
 // input_size == 1 backward: dv (fp32[out]) + the unit input row live in the workspace
-static size_t in1_bwd_bytes(const TtShape& s) { return ((size_t)s.out_size * sizeof(float) + 255 + 256) & ~(size_t)255; }
+// input_size == 1 backward: [dv: out floats | the reduction's partial sums (launch_in1_reduce)]
+static size_t in1_dv_bytes(const TtShape& s) { return ((size_t)s.out_size * sizeof(float) + 255 + 256) & ~(size_t)255; }
+static size_t in1_bwd_bytes(const TtShape& s) { return in1_dv_bytes(s) + ((in1_reduce_part_bytes(s.out_size) + 255) & ~(size_t)255); }
 
 // Dense-gradient backward (ttrnn_fast_gemm.hip) of a shape with a fused-core weight-gradient kernel: workspace =
 // [that kernel's own | identity rows in x in | dW in x out | dense W in x out | bf16 planes of W^T (K = out, M = in) |
@@ -372,9 +374,8 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
         return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, hsum, nullptr, d_packed, nullptr,
                                         (hipStream_t)stream);
       }
-      if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), (hipStream_t)stream) != hipSuccess)
-        return TTRNN_ERR_LAUNCH;
-      st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (hipStream_t)stream);
+      st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (float*)((char*)workspace + in1_dv_bytes(s)),
+                             (hipStream_t)stream);
       if (st != TTRNN_OK) return st;
       return launch_ttlinear_bwd_fast(s, dtype, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
                                       (hipStream_t)stream);
@@ -469,8 +470,7 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
     if (hsum && !d_bias)
       return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit, hsum, nullptr, d_packed, nullptr,
                                  (char*)workspace + in1_bwd_bytes(s), sm);
-    if (hipMemsetAsync(dv, 0, (size_t)s.out_size * sizeof(float), sm) != hipSuccess) return TTRNN_ERR_LAUNCH;
-    st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, sm);
+    st = launch_in1_reduce(dtype, dy_dtype, n_rows, s.out_size, x, dy, dv, d_bias, (float*)((char*)workspace + in1_dv_bytes(s)), sm);
     if (st != TTRNN_OK) return st;
     return launch_ttlinear_bwd(s, p1, TTRNN_F32, TTRNN_F32, 1, packed, unit, dv, nullptr, d_packed, nullptr,
                                (char*)workspace + in1_bwd_bytes(s), sm);

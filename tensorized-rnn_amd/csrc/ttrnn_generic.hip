@@ -65,10 +65,11 @@ typedef float4 f32x4_t;
 // One pass over dy (HBM-bound: reads n_rows * out values once).  A workgroup owns a slab of rows; a thread owns FOUR
 // consecutive columns (one 16-byte load per row when dy is fp32) and walks the slab eight rows at a time so that eight
 // independent loads are in flight per lane; partial sums leave through one atomic per column and workgroup.
+static constexpr int IN1_PARTS = 512;      // workgroups of k_in1_reduce at most (two per CU)
+
 template <typename TX, typename TDY>
 __global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, int rows_per_wg, const TX* __restrict__ x,
-                                                    const TDY* __restrict__ dy, float* __restrict__ dv,
-                                                    float* __restrict__ db) {
+                                                    const TDY* __restrict__ dy, float* __restrict__ part, int want_db) {
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < n_rows ? r0 + rows_per_wg : n_rows;
   if (r0 >= r1) return;
@@ -107,27 +108,59 @@ __global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, int
         ab[j] += g;
       }
     }
+    // this workgroup's partial sums [2][out] (every launched workgroup has rows: the grid is cut to the rows); summed in a
+    // fixed order by k_in1_finish — round 3 flushed them with atomicAdd: the last bits depended on the order of arrival
+    float* pw = part + (size_t)blockIdx.x * 2 * out;
     for (int j = 0; j < nc; ++j) {
-      atomicAdd(dv + o + j, av[j]);
-      if (db) atomicAdd(db + o + j, ab[j]);
+      pw[o + j] = av[j];
+      if (want_db) pw[out + o + j] = ab[j];
     }
   }
 }
 
+// dv[o] = sum over the workgroups' partials (overwritten), db[o] += the same for the plain sums: 32 columns x 8 groups of
+// workgroups per block, each thread its group's partials in order, the eight group sums in order through LDS
+__global__ void __launch_bounds__(256) k_in1_finish(const float* __restrict__ part, int nparts, int out, float* __restrict__ dv,
+                                                    float* __restrict__ db) {
+  __shared__ float red[2][8][32];
+  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int o = blockIdx.x * 32 + c;
+  const int per = (nparts + 7) / 8, k0 = kg * per, k1 = k0 + per < nparts ? k0 + per : nparts;
+  float a = 0.f, b = 0.f;
+  if (o < out)
+    for (int k = k0; k < k1; ++k) {
+      a += part[(size_t)k * 2 * out + o];
+      if (db) b += part[(size_t)k * 2 * out + out + o];
+    }
+  red[0][kg][c] = a;
+  red[1][kg][c] = b;
+  __syncthreads();
+  if (kg == 0 && o < out) {
+    float sa = red[0][0][c], sb = red[1][0][c];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { sa += red[0][g][c]; sb += red[1][g][c]; }
+    dv[o] = sa;
+    if (db) db[o] += sb;
+  }
+}
+
+size_t in1_reduce_part_bytes(int out) { return (size_t)IN1_PARTS * 2 * out * sizeof(float); }
+
 int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
-                      float* db, hipStream_t stream) {
-  // ~512 workgroups (two per CU): every workgroup ends with one atomic per column, and more workgroups than that made
-  // the atomics (1 568 per address for cfg2), not the HBM stream, the limit
-  int rows_per_wg = (int)((n_rows + 511) / 512);
+                      float* db, float* part, hipStream_t stream) {
+  // at most IN1_PARTS workgroups (two per CU), each leaving one row of partial sums
+  if (!part) return TTRNN_ERR_WORKSPACE;
+  int rows_per_wg = (int)((n_rows + IN1_PARTS - 1) / IN1_PARTS);
   rows_per_wg = (rows_per_wg + 7) & ~7;
   if (rows_per_wg < 8) rows_per_wg = 8;
   const int grid = (int)((n_rows + rows_per_wg - 1) / rows_per_wg) > 0 ? (int)((n_rows + rows_per_wg - 1) / rows_per_wg) : 1;
-#define TT_L(TX, TDY) hipLaunchKernelGGL((k_in1_reduce<TX, TDY>), dim3(grid), dim3(256), 0, stream, n_rows, out, rows_per_wg, (const TX*)x, (const TDY*)dy, dv, db)
+#define TT_L(TX, TDY) hipLaunchKernelGGL((k_in1_reduce<TX, TDY>), dim3(grid), dim3(256), 0, stream, n_rows, out, rows_per_wg, (const TX*)x, (const TDY*)dy, part, db ? 1 : 0)
   if (dtype == TTRNN_F32 && dy_dtype == TTRNN_F32) TT_L(float, float);
   else if (dtype == TTRNN_F32) TT_L(float, bf16_t);
   else if (dy_dtype == TTRNN_F32) TT_L(bf16_t, float);
   else TT_L(bf16_t, bf16_t);
 #undef TT_L
+  hipLaunchKernelGGL(k_in1_finish, dim3((out + 31) / 32), dim3(256), 0, stream, (const float*)part, grid, out, dv, db);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

@@ -81,8 +81,11 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
 RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
 
 const void* unit_rows_ptr(int dtype);   // device constant {1, 0} in the storage dtype (NULL: symbol lookup failed)
+// input_size == 1: dv[o] = sum_n x[n] dy[n][o] (overwritten), db[o] += sum_n dy[n][o]; `part`: in1_reduce_part_bytes(out) bytes of
+// scratch for the workgroups' partial sums (summed in a fixed order: repeatable bit for bit, no atomics)
+size_t in1_reduce_part_bytes(int out);
 int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
-                      float* db, hipStream_t stream);
+                      float* db, float* part, hipStream_t stream);
 int launch_pack(const TtShape& s, const void* const* cores, const int64_t* strides, int dtype, float* packed,
                 hipStream_t stream);
 int launch_pack2(const TtShape& sa, const void* const* cores_a, const int64_t* strides_a, float* packed_a,

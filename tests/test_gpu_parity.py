@@ -2537,3 +2537,35 @@ def test_gru_forward_kernel_with_in_wave_s2_matches_eight_wave_kernel_and_oracle
         xg = x.to(dev())
         o1 = m(xg, h0.to(dev()) if with_h0 else None)[0]
         assert torch.equal(o1.detach(), outs["in_wave"][0])
+
+
+# ---- (13) repeatability of the gradients ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("meta", [
+    dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),          # fused core, in = 1 sums
+    dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=3, n_cores=3, tt_rank=16),         # fused core, stacked, dense gradients
+    dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),
+    dict(kind="ttlstm", input_size=256, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8),         # runtime-shape tier (reference default)
+    dict(kind="ttlstm", input_size=1, hidden_size=1024, num_layers=1, n_cores=2, tt_rank=16),         # runtime tier, in = 1: k_in1_reduce
+    dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, is_naive=True),
+    # (not in the list: shapes whose weight gradients still run row by row on the stage-wise MFMA kernel — cfg1's H = 128, d = 2 —
+    # flush their core gradients with atomics once per workgroup)
+], ids=lambda m: "{kind}-{input_size}-{hidden_size}-L{num_layers}-d{n_cores}-r{tt_rank}{n}".format(n="-naive" if m.get("is_naive") else "", **m))
+def test_gradients_are_bitwise_repeatable(meta):
+    """Three identical backward passes give bit-identical gradients for EVERY parameter.  Round 3 left two families to the order
+    of arrival of atomicAdds: the bias gradients of every dense weight gradient (column sums of the gate gradients) and, on the
+    runtime-shape tier, the input_size == 1 reduction (k_in1_reduce).  Both now leave per-workgroup partial sums that a second
+    kernel adds in a fixed order (ttrnn_fast_gemm.hip: bias_partial / k_dense_bias_reduce; ttrnn_generic.hip: k_in1_finish)."""
+    torch.manual_seed(3)
+    m = build_module(meta, dev())
+    B, T = 96, 64
+    x = torch.randn(B, T, meta["input_size"], device=dev())
+    w = torch.randn(B, T, meta["hidden_size"], device=dev())
+    runs = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        out = m(x)[0]                  # the input is data, not differentiated — as in the reference's training loops
+        (out * w).sum().backward()     # (benchmarking.py:41-70); a differentiated first-layer input takes per-row kernels whose
+        runs.append([p.grad.clone() for p in m.parameters()])          # core-gradient flush still goes through atomics
+    names = [n for n, _ in m.named_parameters()]
+    differing = [n for n, a, b, c in zip(names, *runs) if not (torch.equal(a, b) and torch.equal(a, c))]
+    assert not differing, differing
