@@ -118,29 +118,43 @@ __global__ void __launch_bounds__(256) k_in1_reduce(int64_t n_rows, int out, int
   }
 }
 
-// dv[o] = sum over the workgroups' partials (overwritten), db[o] += the same for the plain sums: 32 columns x 8 groups of
-// workgroups per block, each thread its group's partials in order, the eight group sums in order through LDS
+// dv[o] = sum over the workgroups' partials (overwritten), db[o] += the same for the plain sums: 8 columns x 32 groups of
+// workgroups per block — a thread walks its group's (<= 16) partial rows with four loads in flight, then ONE thread per column adds
+// the 32 group sums in order from LDS (a thread walking 56 rows one dependent L2 latency at a time made this a 20 us kernel)
 __global__ void __launch_bounds__(256) k_in1_finish(const float* __restrict__ part, int nparts, int out, float* __restrict__ dv,
                                                     float* __restrict__ db) {
-  __shared__ float red[2][8][32];
-  const int c = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const int o = blockIdx.x * 32 + c;
-  const int per = (nparts + 7) / 8, k0 = kg * per, k1 = k0 + per < nparts ? k0 + per : nparts;
+  __shared__ float red[2][32][8];
+  const int c = threadIdx.x & 7, kg = threadIdx.x >> 3;
+  const int o = blockIdx.x * 8 + c;
+  const int per = (nparts + 31) / 32, k0 = kg * per, k1 = k0 + per < nparts ? k0 + per : nparts;
+  const bool wb = db != nullptr;
   float a = 0.f, b = 0.f;
-  if (o < out)
-    for (int k = k0; k < k1; ++k) {
-      a += part[(size_t)k * 2 * out + o];
-      if (db) b += part[(size_t)k * 2 * out + out + o];
+  if (o < out) {
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+      float va[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = part[(size_t)(k + i) * 2 * out + o];
+        vb[i] = wb ? part[(size_t)(k + i) * 2 * out + out + o] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a += va[i]; b += vb[i]; }
     }
+    for (; k < k1; ++k) {
+      a += part[(size_t)k * 2 * out + o];
+      if (wb) b += part[(size_t)k * 2 * out + out + o];
+    }
+  }
   red[0][kg][c] = a;
   red[1][kg][c] = b;
   __syncthreads();
   if (kg == 0 && o < out) {
     float sa = red[0][0][c], sb = red[1][0][c];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) { sa += red[0][g][c]; sb += red[1][g][c]; }
+    for (int g = 1; g < 32; ++g) { sa += red[0][g][c]; sb += red[1][g][c]; }
     dv[o] = sa;
-    if (db) db[o] += sb;
+    if (wb) db[o] += sb;
   }
 }
 
@@ -160,7 +174,7 @@ int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const vo
   else if (dy_dtype == TTRNN_F32) TT_L(bf16_t, float);
   else TT_L(bf16_t, bf16_t);
 #undef TT_L
-  hipLaunchKernelGGL(k_in1_finish, dim3((out + 31) / 32), dim3(256), 0, stream, (const float*)part, grid, out, dv, db);
+  hipLaunchKernelGGL(k_in1_finish, dim3((out + 7) / 8), dim3(256), 0, stream, (const float*)part, grid, out, dv, db);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
