@@ -605,8 +605,11 @@ size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_stat
   // route whatever the shape, and only then is their (per-sample, much larger) plan part of the answer
   const bool gen = force_generic();
   const bool g2_first = (opt(OPT_FORCE_G2) || want_state) && !gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
-  if (!g2_first && !want_state && !gen && fast_rnn_bwd_available(rs, desc->dtype))
-    return f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
+  if (!g2_first && !want_state && !gen && fast_rnn_bwd_available(rs, desc->dtype)) {
+    const size_t a = f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
+    const size_t b2 = f2_rnn_bwd_workspace_bytes(rs, desc->dtype);     // two-core reverse kernel's fragments (ttrnn_fast_f2.hip)
+    return a > b2 ? a : b2;
+  }
   if (!g2_first && !want_state && !gen && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
   if (!gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
   return plan_rnn_generic(rs, true).ws_bytes;
@@ -787,6 +790,7 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
   if (!g2_first && !want_state && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 && f10_rnn_bwd_available(rs, desc->dtype))
       return TTRNN_ROUTE_FUSED_CORE;
+    if (fp32_math() == TTRNN_MATH_SPLIT && rs.T > 0 && f2_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_FUSED_CORE;
     return TTRNN_ROUTE_STAGEWISE_MFMA;
   }
   if (!g2_first && !want_state && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
@@ -851,6 +855,11 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
       return launch_rnn_bwd_f10(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                 d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream, x, stats);
     }
+    // two-core hidden matrices in split mode: both transposed stages on two fp16 pieces (ttrnn_fast_f2.hip)
+    if (fp32_math() == TTRNN_MATH_SPLIT && rs.T > 0 && f2_rnn_bwd_available(rs, desc->dtype) && workspace &&
+        workspace_bytes >= f2_rnn_bwd_workspace_bytes(rs, desc->dtype))
+      return launch_rnn_bwd_f2(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0, workspace,
+                               (hipStream_t)stream);
     return launch_rnn_bwd_fast(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                d_gates_hid, d_h0, d_c0, (hipStream_t)stream);
   }

@@ -354,4 +354,300 @@ int launch_rnn_fwd_f2(const RnnShape& rs, GinSrc gin, const void* h0, const void
   return TTRNN_ERR_UNSUPPORTED;
 }
 
+
+// =====================================================================================================================================
+// Reverse-time kernel for the same two-core shapes (round 4): BPTT through tensorized_rnn/lstm.py:23-32,123-133 + the transposed
+// chain of t3nsor/ops.py:81-90 for d = 2,
+//     T0   dC1[(j0, a)][i1] = sum_i0      G0[i0, j0, a] dy[i0][i1]          (K = I0 = 16: the three split terms as two chained MFMAs)
+//     T1   dh[j1][j0]       = sum_(i1, a) G1[a, i1, j1] dC1[(j0, a)][i1]    (K = I1 R1 = 128, split over the two waves' i1 ranges)
+// on two fp16 pieces — the stage-wise fp32-MFMA kernel it replaces (k_rnn_bwd_fast, 2 400 cycles per step) was 54 % of cfg1's
+// training step.  Same ownership as the forward kernel: wave w holds the units (q, i1 = 16 w + c), so T0 — which contracts over
+// the gate rows i0 of ONE column i1 — is wave-local: the gate gradients go to the operand image under the WAVE's own scale
+// (max |dg_t| over its 64 units: four DPP rotations + readlanes, no barrier) and come back as the B operand through LDS inside the
+// wave; T0's results, rescaled by the bound max_m L1(G0 row m) max|dg| (cannot overflow), feed T1 the same way; T1 sums over the
+// wave's own 16 values of i1 and leaves a partial dh per wave in LDS: ONE barrier per step.  Weights: one power-of-two scale per
+// output ROW of each stage (undone on the accumulators; no guard needed: a row's entries share its scale by construction).
+// =====================================================================================================================================
+template <class S>
+struct F2B {
+  using F = F2<S>;
+  static constexpr int M0 = F::J0 * F::R1;                 // T0 rows (j0, a): 32
+  static constexpr int MT0 = M0 / 16;                      // 2 tiles
+  static constexpr int K1 = F::I1 * F::R1, NKB1 = K1 / 32; // T1 contraction 128 = 4 k-blocks, two per wave
+  static constexpr int UN0 = 0, UN1 = M0, ML1 = M0 + 16, HDR_FLOATS = 64;
+  static constexpr size_t FRAG0 = (size_t)MT0 * 2 * 64, FRAG1 = (size_t)NKB1 * 2 * 64;
+  static constexpr size_t WS_BYTES = HDR_FLOATS * sizeof(float) + (FRAG0 + FRAG1) * sizeof(xh8);
+  // LDS: dh partials [parity][wave][H] fp32 | per wave: dy image [2 pieces][16][16] fp16, dC1 image [2 pieces][J0][64] fp16
+  static constexpr int DYI = 2 * 16 * 16 * 2, DCI = 2 * F::J0 * 64 * 2;
+  static constexpr size_t LDS_BYTES = 2 * F::NWV * F::H * sizeof(float) + (size_t)F::NWV * (DYI + DCI);
+};
+template <class S>
+constexpr bool f2b_ok() { return f2_ok<S>() && F2<S>::NWV == 2 && F2B<S>::M0 == 32 && F2B<S>::NKB1 == 4 && F2<S>::I0 == 16; }
+
+template <class S>
+__global__ void __launch_bounds__(256) k_f2b_prep(const float* __restrict__ packed, float* __restrict__ hdr, xh8* __restrict__ frag) {
+  using F = F2<S>;
+  using B = F2B<S>;
+  constexpr int M1 = F::I1 * F::R1;
+  __shared__ float g1[F::J1 * M1];                        // W1[j1][(i1, a)]
+  __shared__ float g0[F::K0 * F::I0];                     // W0[(j0, a)][i0]
+  __shared__ float s0[B::M0], s1[F::J1], l1[B::M0];
+  const int tid = threadIdx.x;
+  const float* W0 = packed + woff_of<S>(0);
+  const float* W1 = packed + woff_of<S>(1);
+  for (int i = tid; i < F::J1 * M1; i += 256) g1[i] = W1[i];
+  for (int i = tid; i < F::K0 * F::I0; i += 256) g0[i] = W0[i];
+  __syncthreads();
+  if (tid < B::M0) {                                      // rows of T0: one scale per (j0, a), row maximum -> [2^13, 2^14)
+    float mx = 0.f, l = 0.f;
+    for (int i0 = 0; i0 < F::I0; ++i0) { const float v = fabsf(g0[tid * F::I0 + i0]); mx = fmaxf(mx, v); l += v; }
+    s0[tid] = ldexpf(1.f, 14 - f10h_expo(mx));
+    l1[tid] = l;
+  } else if (tid >= 64 && tid < 64 + F::J1) {             // rows of T1: one scale per j1
+    const int j1 = tid - 64;
+    float mx = 0.f;
+    for (int k = 0; k < M1; ++k) mx = fmaxf(mx, fabsf(g1[j1 * M1 + k]));
+    s1[j1] = ldexpf(1.f, 14 - f10h_expo(mx));
+  }
+  __syncthreads();
+  if (tid < B::M0) hdr[B::UN0 + tid] = 1.0f / s0[tid];
+  if (tid < F::J1) hdr[B::UN1 + tid] = 1.0f / s1[tid];
+  if (tid == 0) {
+    float m = 0.f;
+    for (int i = 0; i < B::M0; ++i) m = fmaxf(m, l1[i]);
+    hdr[B::ML1] = m;                                       // |dC1[m][.]| <= L1(row m) max|dy|
+  }
+  // T0 fragments: tile mt, lane (r, q): row m = 16 mt + r; k = 8 q + e; operand order k' = 4 q_u + g <-> i0 = 4 g + q_u (the gate
+  // thread (c, q_u) writes its four gate gradients as four consecutive k').  MFMA 1: k < 16 piece 0 of k' = k, else piece 1 of
+  // k' = k - 16;  MFMA 2: k < 16 piece 0, else 0
+  for (int idx = tid; idx < B::MT0 * 64; idx += 256) {
+    const int mt = idx >> 6, lane = idx & 63, r = lane & 15, q = lane >> 4;
+    const int m = 16 * mt + r;
+    xh8 f1, f2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kp = (8 * q + e) & 15, i0 = 4 * (kp & 3) + (kp >> 2);
+      _Float16 p0, p1;
+      split2h(g0[m * F::I0 + i0] * s0[m], p0, p1);
+      f1[e] = q < 2 ? p0 : p1;
+      f2[e] = q < 2 ? p0 : (_Float16)0.f;
+    }
+    frag[(size_t)(mt * 2 + 0) * 64 + lane] = f1;
+    frag[(size_t)(mt * 2 + 1) * 64 + lane] = f2;
+  }
+  // T1 fragments: k-block u, lane (r = j1, q): k = 32 u + 8 q + e = i1 * R1 + a (natural order)
+  for (int idx = tid; idx < B::NKB1 * 64; idx += 256) {
+    const int u = idx >> 6, lane = idx & 63, r = lane & 15, q = lane >> 4;
+    xh8 a0, a1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 p0, p1;
+      split2h(g1[r * M1 + 32 * u + 8 * q + e] * s1[r], p0, p1);
+      a0[e] = p0; a1[e] = p1;
+    }
+    frag[B::FRAG0 + (size_t)(u * 2 + 0) * 64 + lane] = a0;
+    frag[B::FRAG0 + (size_t)(u * 2 + 1) * 64 + lane] = a1;
+  }
+}
+
+// x < 2^e from the exponent bits (as ttrnn_fast_f10bh.hip: step_scale): returns 2^(14 - e), un = 2^(e - 14); zero -> zeros stay zeros
+__device__ __forceinline__ float f2b_step_scale(float mx, float& un) {
+  int eb = (int)(__float_as_uint(mx) >> 23);
+  eb = eb < 27 ? 27 : (eb > 227 ? 227 : eb);
+  un = __uint_as_float((unsigned)(eb - 13) << 23);
+  return __uint_as_float((unsigned)(267 - eb) << 23);
+}
+template <int N>
+__device__ __forceinline__ float f2b_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float f2b_wave_max(float v) {
+  v = fmaxf(v, f2b_row_ror<1>(v));
+  v = fmaxf(v, f2b_row_ror<2>(v));
+  v = fmaxf(v, f2b_row_ror<4>(v));
+  v = fmaxf(v, f2b_row_ror<8>(v));
+  const int i = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(i, 0)), b = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(i, 32)), d = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+template <class S>
+__global__ void __launch_bounds__(F2<S>::NWV * 64, 4) k_lstm_bwd_f2(int Bn, int T, const float* __restrict__ c0,
+                                                                    const float* __restrict__ hdr, const xh8* __restrict__ frag,
+                                                                    const float* __restrict__ reserve,
+                                                                    const float* __restrict__ d_out, const float* __restrict__ d_hT,
+                                                                    const float* __restrict__ d_cT, float* __restrict__ dg_in,
+                                                                    float* __restrict__ dg_hid, float* __restrict__ d_h0,
+                                                                    float* __restrict__ d_c0) {
+  static_assert(f2b_ok<S>(), "shape not supported by the two-core reverse-time kernel");
+  using F = F2<S>;
+  using B = F2B<S>;
+  constexpr int H = F::H, GH = 4 * H;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b2[];
+  float* dhs = reinterpret_cast<float*>(smem_b2);                                       // [parity][wave][H]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* dyi = smem_b2 + 2 * F::NWV * H * sizeof(float) + (size_t)wave * (B::DYI + B::DCI);   // [piece][16 rows i1][16 k'] fp16
+  unsigned char* dci = dyi + B::DYI;                                                     // [piece][J0 rows][64 k] fp16
+  constexpr int DYP = 16 * 16 * 2, DCP = F::J0 * 64 * 2;                                 // bytes per piece plane
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+  const int hid = q * F::I1 + 16 * wave + c;
+
+  xh8 t0a[B::MT0], t0b[B::MT0], t1w[2][2];
+  f32x4 un0[B::MT0];
+#pragma unroll
+  for (int mt = 0; mt < B::MT0; ++mt) {
+    t0a[mt] = frag[(size_t)(mt * 2 + 0) * 64 + lane];
+    t0b[mt] = frag[(size_t)(mt * 2 + 1) * 64 + lane];
+    un0[mt] = *reinterpret_cast<const f32x4*>(hdr + B::UN0 + 16 * mt + 4 * q);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) t1w[u][p] = frag[B::FRAG0 + (size_t)((2 * wave + u) * 2 + p) * 64 + lane];
+  const f32x4 un1 = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 4 * q);
+  const float maxl1 = hdr[B::ML1];
+
+  float dcs = d_cT ? d_cT[b * H + hid] : 0.f;
+  const float c0v = c0 ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;            // a null d_out reads the reserve and is scaled by zero: no branch in the loop
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f, do0 = 0.f, do1 = 0.f, do2 = 0.f;
+  dhs[0 * H + hid] = d_hT ? d_hT[b * H + hid] : 0.f;      // parity 0: [wave 0 | wave 1] partials = (d_hT, 0)
+  dhs[1 * H + hid] = 0.f;
+  if (T > 0) {
+    const size_t bt = b * T + (T - 1);
+    const float* rv = reserve + res_gate(bt, H, hid);
+    const float* rc = reserve + res_cell((size_t)Bn * T, bt, H, hid);
+    ra0 = *reinterpret_cast<const f32x4*>(rv);
+    rb0 = rc[0];
+    do0 = dptr[bt * H + hid];
+    if (T > 1) {
+      ra1 = *reinterpret_cast<const f32x4*>(rv - H * 4);
+      rb1 = rc[-H];
+      do1 = dptr[(bt - 1) * H + hid];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): no fragment-register wait inside the loop
+  lds_barrier();
+
+  const bool dup = dg_hid && dg_hid != dg_in;
+  int par = 0;
+  // three rotating register sets for the saved records (loads requested two steps ahead, never consumed or overwritten in the
+  // phase that issued them: DESIGN_HISTORY.md lesson 9)
+  auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dout_c, const float& nb, f32x4& fa, float& fb,
+                  float& dout_f) {
+    const size_t bt = b * T + t;
+    const float* dh_in = dhs + par * F::NWV * H;
+    float* dh_out = dhs + (par ^ 1) * F::NWV * H + wave * H;
+    // ---- gate gradients (lstm.py:26-32 differentiated; reserve slots i, g, f, o) -------------------------------------------------
+    const float dht = dout_c * dscale + dh_in[hid] + dh_in[H + hid];
+    const float ig = ra[0], gg = ra[1], fg = ra[2], og = ra[3], cy = rb;
+    const float cprev = t > 0 ? nb : c0v;
+    const float tc = ftanh(cy);
+    const float dct = dcs + dht * og * (1.0f - tc * tc);
+    const float p0 = dct * gg * ig * (1.0f - ig);                 // d pre-activation of i
+    const float p1 = dct * cprev * fg * (1.0f - fg);              //                     f
+    const float p2 = dct * ig * (1.0f - gg * gg);                 //                     g
+    const float p3 = dht * tc * og * (1.0f - og);                 //                     o
+    dcs = dct * fg;
+    const float mx = f2b_wave_max(fmaxf(fmaxf(fabsf(p0), fabsf(p1)), fmaxf(fabsf(p2), fabsf(p3))));
+    float ug, u2;
+    const float sg = f2b_step_scale(mx, ug);
+    const float s2 = f2b_step_scale(mx * maxl1, u2);              // |dC1| <= maxl1 * max|dg|: no overflow, whatever the signs
+    // T0's operand: column i1 = c of this wave, k' = 4 q + gate: one 8-byte store per piece, read back by this wave only
+    {
+      unsigned a0, b0, a1, b1;
+      split_pair_h(p0 * sg, p1 * sg, a0, b0);
+      split_pair_h(p2 * sg, p3 * sg, a1, b1);
+      *reinterpret_cast<u32x2*>(dyi + c * 32 + 8 * q) = u32x2{a0, a1};
+      *reinterpret_cast<u32x2*>(dyi + DYP + c * 32 + 8 * q) = u32x2{b0, b1};
+    }
+    // d_gates rows for the weight gradients (gate-major, as the reference's pre-activation order i, f, g, o)
+    float* gr = dg_in + bt * GH + hid;
+    gr[0] = p0; gr[H] = p1; gr[2 * H] = p2; gr[3 * H] = p3;
+    if (dup) { float* g2 = dg_hid + bt * GH + hid; g2[0] = p0; g2[H] = p1; g2[2 * H] = p2; g2[3 * H] = p3; }
+    // record(t-2), d_out(t-2): always three loads, index clamped
+    {
+      const size_t b2 = t > 1 ? bt - 2 : b * T;
+      fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+      fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
+      dout_f = dptr[b2 * H + hid];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- T0 -------------------------------------------------------------------------------------------------------------------
+    const xh8 y0 = *reinterpret_cast<const xh8*>(dyi + c * 32 + 16 * (q & 1));
+    const xh8 y1 = *reinterpret_cast<const xh8*>(dyi + DYP + c * 32 + 16 * (q & 1));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 a0t[B::MT0];
+#pragma unroll
+    for (int mt = 0; mt < B::MT0; ++mt) a0t[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0b[mt], y1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < B::MT0; ++mt) a0t[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0a[mt], y0, a0t[mt], 0, 0, 0);
+    // lane (c = i1, q) of tile mt: dC1[(j0 = 4 mt + q, a = 0 .. 3)][i1] -> T1's operand row j0, k = 4 c + a (16-byte slots swizzled by row)
+    const float t01f = ug * s2;
+#pragma unroll
+    for (int mt = 0; mt < B::MT0; ++mt) {
+      const f32x4 v = a0t[mt] * (un0[mt] * t01f);
+      unsigned a0, b0, a1, b1;
+      split_pair_h(v[0], v[1], a0, b0);
+      split_pair_h(v[2], v[3], a1, b1);
+      const int row = 4 * mt + q;
+      const int off = row * 128 + (((c >> 1) ^ (row & 7)) << 4) + 8 * (c & 1);
+      *reinterpret_cast<u32x2*>(dci + off) = u32x2{a0, a1};
+      *reinterpret_cast<u32x2*>(dci + DCP + off) = u32x2{b0, b1};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- T1: this wave's 64 of the 128 k values; columns j0 = c & 7 (columns 8 .. 15 repeat them) ----------------------------------
+    const int row1 = c & 7;
+    f32x4 alo = f32x4{0.f, 0.f, 0.f, 0.f}, ahi = alo;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int off = row1 * 128 + (((4 * u + q) ^ row1) << 4);
+      const xh8 z0 = *reinterpret_cast<const xh8*>(dci + off), z1 = *reinterpret_cast<const xh8*>(dci + DCP + off);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][1], z0, alo, 0, 0, 0);
+      ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z0, ahi, 0, 0, 0);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z1, alo, 0, 0, 0);
+    }
+    // lane (c = j0, q): dh[j0 * J1 + 4 q + j], j = 0 .. 3 (this wave's share of the sum over i1)
+    *reinterpret_cast<f32x4*>(dh_out + row1 * F::J1 + 4 * q) = (ahi + alo) * (un1 * u2);
+    par ^= 1;
+    lds_barrier();
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1);
+  }
+  const float* dh_fin = dhs + par * F::NWV * H;
+  if (d_h0) d_h0[b * H + hid] = dh_fin[hid] + dh_fin[H + hid];
+  if (d_c0) d_c0[b * H + hid] = dcs;
+}
+
+bool f2_rnn_bwd_available(const RnnShape& rs, int dtype) {
+  if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1 || dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || rs.hid_blocks > 1) return false;
+  return shape_matches<ShpH128R4L>(rs.hid_s);
+}
+size_t f2_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype) {
+  return f2_rnn_bwd_available(rs, dtype) ? F2B<ShpH128R4L>::WS_BYTES : 0;
+}
+int launch_rnn_bwd_f2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                      const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                      hipStream_t stream) {
+  using S = ShpH128R4L;
+  using B = F2B<S>;
+  if (!shape_matches<S>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* frag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + B::HDR_FLOATS * sizeof(float));
+  hipLaunchKernelGGL((k_f2b_prep<S>), dim3(1), dim3(256), 0, stream, packed_hid, hdr, frag);
+  hipLaunchKernelGGL((k_lstm_bwd_f2<S>), dim3(rs.B), dim3(F2<S>::NWV * 64), B::LDS_BYTES, stream, rs.B, rs.T, (const float*)c0,
+                     (const float*)hdr, (const xh8*)frag, reserve, (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in,
+                     dg_hid, (float*)d_h0, (float*)d_c0);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 }  // namespace ttrnn

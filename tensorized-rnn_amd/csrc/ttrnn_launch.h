@@ -141,6 +141,12 @@ bool f2_rnn_fwd_available(const RnnShape& rs, int dtype);
 size_t f2_workspace_bytes(const RnnShape& rs, int dtype);
 int launch_rnn_fwd_f2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                       const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream, int phase);
+// ... and their reverse-time kernel (two fp16 pieces, per-wave step scales, one barrier per step); ws: f2_rnn_bwd_workspace_bytes
+bool f2_rnn_bwd_available(const RnnShape& rs, int dtype);
+size_t f2_rnn_bwd_workspace_bytes(const RnnShape& rs, int dtype);
+int launch_rnn_bwd_f2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                      const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                      hipStream_t stream);
 
 // the bf16 GRU as four-wave workgroups with in-lane gates (ttrnn_fast_f10gq.hip); ws: f10gq_workspace_bytes
 size_t f10gq_workspace_bytes();

@@ -2569,3 +2569,85 @@ def test_gradients_are_bitwise_repeatable(meta):
     names = [n for n, _ in m.named_parameters()]
     differing = [n for n, a, b, c in zip(names, *runs) if not (torch.equal(a, b) and torch.equal(a, c))]
     assert not differing, differing
+
+
+# ---- (14) two-core reverse-time kernel (ttrnn_fast_f2.hip: k_lstm_bwd_f2) ------------------------------------------------------------
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only", "outlier_core0", "outlier_core1", "long"])
+def test_two_core_reverse_kernel_ranges(case):
+    """cfg1's shape (H = 128, d = 2, r = 4; pMNIST's default --ncores 2) in split mode: both transposed stages on two fp16 pieces,
+    the weights' rows under their own power-of-two scales, every step's gate gradients scaled from the maximum of their WAVE's 64
+    units and T0's results from a bound.  Output gradients over ten decades, steps and samples without gradient, a loss on the last
+    step only, one core entry x 1e5 / 1e6 (row scales: no guard needed), a 784-step sequence: every parameter / input /
+    initial-state gradient against the float64 oracle next to the stage-wise fp32-MFMA kernel (exact mode) on the same inputs;
+    the kernel's own results bitwise repeatable and independent of the rest of the batch."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    from ttrnn_hip import functional as F
+    torch.manual_seed(211)
+    H, inp = 128, 1
+    meta = dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=2, tt_rank=4)
+    m = build_module(meta, dev())
+    B = 5
+    T = 60 if case == "last_step_only" else (784 if case == "long" else 9)
+    if case.startswith("outlier"):
+        core = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n][int(case[-1])]
+        with torch.no_grad():
+            flat = core.detach().clone().contiguous().view(-1)
+            flat[(5 * flat.numel()) // 11] *= (1e5 if case[-1] == "1" else 1e6)
+            core.copy_(flat.view(core.shape))
+    x = torch.rand(B, T, inp) if case == "long" else torch.randn(B, T, inp)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t.double().clone().requires_grad_(True) for t in (x, h0, c0))
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    ((ro * w.double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+
+    def run(sel=None):
+        m.zero_grad()
+        xs, hs, cs, ws = (t if sel is None else t[sel] for t in (x, h0, c0, w))
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (xs, hs, cs))
+        out, (hT, cT) = m(xg, (h0g, c0g))
+        ((out * ws.to(dev())).sum() + wsum * (cT.sum() + 0.5 * hT.sum())).backward()
+        return {"x": xg.grad.clone(), "h0": h0g.grad.clone(), "c0": c0g.grad.clone(),
+                **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+    got = run()
+    again = run()
+    sub = run([2, 0])
+    with ttrnn_hip.fp32_math("exact"):
+        assert F.rnn_backward_route(spec, B, T) == "stagewise_mfma"
+        exact = run()
+    refs = {"x": xr.grad, "h0": h0r.grad, "c0": c0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"two_fp16": 0.0, "fp32_mfma": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["two_fp16"] = max(worst["two_fp16"], _maxabs(got[n].double(), ref) / sc)
+        worst["fp32_mfma"] = max(worst["fp32_mfma"], _maxabs(exact[n].double(), ref) / sc)
+    for n in ("h0", "c0"):                                         # the reverse-time kernel's own results
+        assert torch.equal(got[n], again[n]), n
+        assert torch.equal(got[n][[2, 0]], sub[n]), n
+    if case == "sparse_steps":
+        assert float(got["h0"][2].abs().max()) == 0.0
+    if case == "last_step_only":
+        rel = _maxabs(got["h0"].double(), h0r.grad) / max(float(h0r.grad.abs().max()), 1e-300)
+        print("d_h0 after 60 steps: max |ref| %.3g, relative error %.3g" % (float(h0r.grad.abs().max()), rel))
+        assert rel <= 1e-4
+    print(case, "max gradient error relative to each tensor's maximum:", worst)
+    assert not torch.equal(got["h0"], exact["h0"])                 # a different kernel did run
+    # (outlier forward weights trip the FORWARD kernel's guard: then both runs share the fp32 forward and differ in the reverse only;
+    # a core entry x 1e5 makes the gradients themselves ill-conditioned: the fp32-MFMA kernel sits at 5e-5 there, the yardstick)
+    assert worst["two_fp16"] <= (1.5 * worst["fp32_mfma"] + 1e-6 if case.startswith("outlier") else 2e-5)
+    assert worst["two_fp16"] <= 3.0 * worst["fp32_mfma"] + 1e-6

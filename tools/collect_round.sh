@@ -3,7 +3,7 @@
 # the grid sweep, the K-in GEMM harness, and rocprofv3 kernel stats + PMC passes.  Everything lands under gpurun_out/<tag>/;
 # copy what is worth keeping into profiles/<round>/ (tools/update_traffic.py turns the PMC summaries into profiles/traffic.json).
 #   tools/collect_round.sh r3 [quick]
-TAG=${1:-r3}
+TAG=${1:-r4}
 QUICK=${2:-}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
