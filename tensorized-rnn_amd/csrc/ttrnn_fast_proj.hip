@@ -155,6 +155,48 @@ __global__ void __launch_bounds__(256) k_proj3_fin(Proj3 p, int nb0, const float
   }
 }
 
+// ---- d = 2 (round 4: cfg1's shape reaches the dense-gradient route): W[(j0,j1)][(i0,i1)] = sum_a G0[i0,j0,a] G1[a,i1,j1] ----
+//     dG0[i0,j0,a] = sum_{i1,j1} dW[(j0,j1)][(i0,i1)] G1[a,i1,j1]        dG1[a,i1,j1] = sum_{i0,j0} dW[(j0,j1)][(i0,i1)] G0[i0,j0,a]
+// ONE wave per core entry, lanes over the terms, butterfly at the end: fixed order, no atomics, accumulated INTO d_packed.
+struct Proj2 {
+  int J0, J1, I0, I1, R1, M0, M1;
+  long w0, w1, out;
+};
+__global__ void __launch_bounds__(256) k_proj2(Proj2 p, const float* __restrict__ packed, const float* __restrict__ dW,
+                                               float* __restrict__ d_packed) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long n0 = (long)p.I0 * p.J0 * p.R1, n1 = (long)p.R1 * p.I1 * p.J1;
+  if (e >= n0 + n1) return;
+  float acc = 0.f;
+  long dst;
+  if (e < n0) {                                            // dG0: e = (j0 R1 + a) M0 + i0 (the packed order of W_0)
+    const int i0 = (int)(e % p.M0), ja = (int)(e / p.M0), a = ja % p.R1, j0 = ja / p.R1;
+    for (int t = lane; t < p.I1 * p.J1; t += 64) {
+      const int i1 = t % p.I1, j1 = t / p.I1;
+      acc = fmaf(dW[(long)(j0 * p.J1 + j1) * p.out + i0 * p.I1 + i1], packed[p.w1 + (long)j1 * p.M1 + i1 * p.R1 + a], acc);
+    }
+    dst = p.w0 + e;
+  } else {                                                 // dG1: e - n0 = j1 M1 + i1 R1 + a (the packed order of W_1)
+    const long f = e - n0;
+    const int ia = (int)(f % p.M1), j1 = (int)(f / p.M1), a = ia % p.R1, i1 = ia / p.R1;
+    for (int t = lane; t < p.I0 * p.J0; t += 64) {
+      const int i0 = t % p.I0, j0 = t / p.I0;
+      acc = fmaf(dW[(long)(j0 * p.J1 + j1) * p.out + i0 * p.I1 + i1], packed[p.w0 + (long)(j0 * p.R1 + a) * p.M0 + i0], acc);
+    }
+    dst = p.w1 + f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) d_packed[dst] += acc;
+}
+static bool proj2_shape(const TtShape& s, Proj2* p) {
+  if (s.d != 2 || s.R[0] != 1 || s.R[2] != 1) return false;
+  p->J0 = s.J[0]; p->J1 = s.J[1]; p->I0 = s.I[0]; p->I1 = s.I[1]; p->R1 = s.R[1];
+  p->M0 = s.M[0]; p->M1 = s.M[1]; p->w0 = s.woff[0]; p->w1 = s.woff[1]; p->out = s.out_size;
+  return true;
+}
+
 bool proj3_shape(const TtShape& s, Proj3* p) {
   if (s.d != 3 || s.R[0] != 1 || s.R[3] != 1) return false;
   p->J0 = s.J[0]; p->J1 = s.J[1]; p->J2 = s.J[2];
@@ -173,6 +215,8 @@ bool proj3_shape(const TtShape& s, Proj3* p) {
 size_t proj3_workspace_bytes(const TtShape& s) {
   Proj3 p;
   if (opt(OPT_DEV) & 1024) return 0;             // A/B: the fused-core weight-gradient kernel on the unit rows, as before
+  Proj2 p2;
+  if (proj2_shape(s, &p2)) return 256;           // d = 2: one launch, no scratch (a non-zero answer = "offered")
   if (!proj3_shape(s, &p)) return 0;
   const size_t pe = (size_t)p.A * p.Mm * p.R2, g2 = (size_t)p.J2 * p.I2 * p.R2;
   return ((2 * pe + (size_t)PJ_NCH * g2) * sizeof(float) + 255) & ~(size_t)255;
@@ -180,6 +224,12 @@ size_t proj3_workspace_bytes(const TtShape& s) {
 
 // d_packed += adjoint of (cores -> dense)(dW), dW = fp32 [in_size][out_size]
 int launch_proj3(const TtShape& s, const float* packed, const float* dW, float* d_packed, void* ws, hipStream_t stream) {
+  Proj2 p2;
+  if (proj2_shape(s, &p2)) {
+    const long n = (long)p2.I0 * p2.J0 * p2.R1 + (long)p2.R1 * p2.I1 * p2.J1;
+    hipLaunchKernelGGL(k_proj2, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, p2, packed, dW, d_packed);
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  }
   Proj3 p;
   if (!proj3_shape(s, &p) || !ws) return TTRNN_ERR_UNSUPPORTED;
   const size_t pe = (size_t)p.A * p.Mm * p.R2;
