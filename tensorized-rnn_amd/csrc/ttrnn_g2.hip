@@ -331,7 +331,8 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 // (round 4, RES only, eight-wave workgroups, UPT <= 2: 128 fragment VGPRs of the wave's 256) make the head of the reference's
 // default benchmark shape (H = 512, r = 8: 256 KB of two-piece fragments = sixteen k-blocks per wave) RESIDENT — streamed it
 // was 384 KB per sample-step through a 64 B/clk L2 -> CU path: 8.7 us per step at B = 512 for 1.3 us of matrix-pipe time
-template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8, int NSL = G2_PF>
+// IN1: input_size == 1 as a template parameter (round 4, lesson 44: the runtime flag cost the fused-core kernels 9 - 10 %)
+template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8, int NSL = G2_PF, bool IN1 = false>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, const int* __restrict__ hdr,
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gs.gin);
   const f32x4* bil4 = reinterpret_cast<const f32x4*>(bilv);
   const TS* xs = reinterpret_cast<const TS*>(gs.x);
-  const bool in1 = gs.in1 != 0;
+  constexpr bool in1 = IN1;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
@@ -1229,18 +1230,23 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   do {                                                                                                                   \
     const bool p8 = P.hid.pack8 != 0;                                                                                   \
     if (res16 && UPTV <= 2) {                                                                                           \
-      auto kern16 = p8 ? k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, true, 16>                              \
-                       : k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, false, 16>;                            \
+      auto kern16 = in1 ? (p8 ? k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, true, 16, true>                 \
+                              : k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, false, 16, true>)               \
+                        : (p8 ? k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, true, 16>                       \
+                              : k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, false, 16>);                    \
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern16), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;     \
       hipLaunchKernelGGL(kern16, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0,          \
                          (const TS*)c0, reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve); \
       break;                                                                                                             \
     }                                                                                                                    \
-    auto kern = res ? ((opt(OPT_DIAG) && reserve && UPTV == 1) ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, true, true>       \
-                                                                     : k_g2_fwd<CELLV, TS, UPTV, true, true, false>)     \
-                                                               : (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true>      \
-                                                                     : k_g2_fwd<CELLV, TS, UPTV, true, false, false>))   \
-                    : (p8 ? k_g2_fwd<CELLV, TS, UPTV, false, false, true> : k_g2_fwd<CELLV, TS, UPTV, false, false, false>); \
+    const bool dg = opt(OPT_DIAG) && reserve && UPTV == 1 && res && !in1;                                               \
+    auto kern = dg ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, true, true> : k_g2_fwd<CELLV, TS, UPTV, true, true, false>)   \
+              : in1 ? (res ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true, G2_PF, true>                             \
+                                 : k_g2_fwd<CELLV, TS, UPTV, true, false, false, G2_PF, true>)                           \
+                           : (p8 ? k_g2_fwd<CELLV, TS, UPTV, false, false, true, G2_PF, true>                            \
+                                 : k_g2_fwd<CELLV, TS, UPTV, false, false, false, G2_PF, true>))                         \
+              : (res ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true> : k_g2_fwd<CELLV, TS, UPTV, true, false, false>) \
+                     : (p8 ? k_g2_fwd<CELLV, TS, UPTV, false, false, true> : k_g2_fwd<CELLV, TS, UPTV, false, false, false>)); \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;        \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,       \
                        reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT,                                   \
