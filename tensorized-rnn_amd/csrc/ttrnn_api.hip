@@ -778,7 +778,8 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
     return TTRNN_ROUTE_STAGEWISE_MFMA;
   }
   if (big_rnn_fwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
-  if (g2_rnn_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  if (g2_rnn_available(rs, desc->dtype))      // (H = 512, r = 8 in split mode: this tier's K-in + the fused-core recurrent kernel)
+    return f10_h512_fwd_available(rs, desc->dtype) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
   return TTRNN_ROUTE_VALU;
 }
 

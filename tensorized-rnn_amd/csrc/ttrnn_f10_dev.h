@@ -101,8 +101,8 @@ __device__ __forceinline__ void f10_s10_part(const xbf8 (&w10)[3][NU], const __b
 // (r2, j2), ev from the maxima of 2^eu G2 over (i2, j2), ep from the row maxima of 2^-ev W10) and sit as int32 at the start of
 // the fragment workspace: [eu: 16][ev: 16][ep: 64].  Second pieces stay normal over >= 9 binades below each row's / slice's
 // maximum; smaller entries keep an ABSOLUTE error of 2^-31 of THAT maximum or better.
-static constexpr int F10H_HDR_BYTES = 512;
-static constexpr int F10H_PARTS = 64;          // workgroups of k_f10h_scale (one row of the fused core each)
+static constexpr int F10H_HDR_BYTES = 1024;      // eu[16] | ev[16] | ep[M <= 224] as int32
+static constexpr int F10H_PARTS = 64;          // (historic) workgroups of k_f10h_scale for M = 64; launched with F10<S>::M, one row of the fused core each
 static constexpr int F10H_EU = 0, F10H_EV = 16, F10H_EP = 32;
 static constexpr float F10H_HSC = 64.0f;       // 2^6: the scale of h
 struct F10hScales { f32x4 pre, un; };          // per lane: 2^(ep[m_j] + eu[c] + 12) for the lane's four rows m_j, and the inverse

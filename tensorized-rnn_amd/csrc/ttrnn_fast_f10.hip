@@ -94,7 +94,7 @@ constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 
 template <class S>
 __global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, int* __restrict__ hdr) {
   using F = F10<S>;
-  static_assert(F::M == F10H_PARTS && F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one workgroup per row of the fused core");
+  static_assert(F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one workgroup (blockIdx.x) per row of the fused core: launch F::M of them");
   __shared__ unsigned mx[32];
   __shared__ int eu[16], ev[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -878,7 +878,7 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   // (h_0 is scaled per sample inside the recurrent kernels: f10h_h0_expo)
   // the scale header and the fragments depend on the weights only: TTRNN_PHASE_RUN finds them in ws (ttrnn_rnn_forward_phase)
   if (phase != TTRNN_PHASE_RUN) {
-    hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10H_PARTS), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
+    hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
     hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   }
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
@@ -942,6 +942,30 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
   if (shape_matches<ShpH256R16L>(rs.hid_s))
     return launch_f10<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
   return TTRNN_ERR_UNSUPPORTED;
+}
+
+// ---- H = 512, r = 8 (the reference's default benchmark shape, experiments/digit_classification/benchmarking.py:75-83) ----------
+// Round 4: the fused-core forward of a shape that otherwise lives on the runtime-shape tier.  K10 = J0 J1 R2 = 512, M = I0 I1 = 128:
+// eight S10 tiles = eight waves (k_lstm_fwd_f10q<S, 1, ..., QW = 8>), each with its tile's whole contraction resident (sixteen
+// k-blocks x two fp16 pieces = 128 VGPRs), one workgroup per CU.  The caller (ttrnn_g2.hip: fwd_t) supplies gin with BOTH biases
+// folded in (k_g2_bias) and this workspace; the reverse-time kernel stays the runtime-shape tier's (same reserve format).
+size_t f10_h512_workspace_bytes() { return f10_wfrag_bytes<ShpH512R8L>(); }
+bool f10_h512_fwd_available(const RnnShape& rs, int dtype) {
+  return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & 8192) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM &&
+         rs.hid_blocks <= 1 && rs.in != 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && shape_matches<ShpH512R8L>(rs.hid_s);
+}
+int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+                            void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
+  using S = ShpH512R8L;
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
+  static_assert((F10H_EP + F10<S>::M) * sizeof(int) <= F10H_HDR_BYTES, "header");
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
+  hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
+  if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  GinSrc src{gin, nullptr, 0};
+  return launch_rnn_fwd_f10_q(rs, src, h0, c0, packed_hid, ws, nullptr, out, hT, cT, reserve, stream);
 }
 
 }  // namespace ttrnn

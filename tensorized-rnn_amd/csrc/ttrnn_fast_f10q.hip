@@ -21,7 +21,9 @@
 
 namespace ttrnn {
 
-constexpr int QW = 4;                 // waves per workgroup
+// waves per workgroup = S10 feature tiles: four (H = 256: two workgroups per CU) or eight (H = 512: one workgroup per CU)
+template <class S>
+constexpr int f10q_waves() { return F10<S>::MT; }
 
 template <class S>
 constexpr size_t f10q_lds_bytes() {
@@ -36,7 +38,7 @@ constexpr size_t f10q_lds_bytes() {
 // IN1: input_size == 1 (GinSrc::in1) as a template parameter (round 4): the runtime flag put four uniform branches and both
 // code paths into every step and cut the step into basic blocks the scheduler cannot move instructions across
 template <class S, int KH, bool H0, bool OUT, bool IN1, bool DIAG = false>
-__global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
+__global__ void __launch_bounds__(f10q_waves<S>() * 64, f10q_waves<S>() == 4 ? 2 : 1) k_lstm_fwd_f10q(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                                const float* __restrict__ c0,
                                                                const float* __restrict__ packed_hid,
                                                                const float* __restrict__ hdr,
@@ -46,9 +48,11 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
                                                                float* __restrict__ cT, float* __restrict__ reserve) {
   static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
   using F = F10<S>;
-  static_assert(F::MT == QW && F::MT2 % QW == 0 && F::NM % KH == 0, "one S10 tile per wave");
+  constexpr int QW = f10q_waves<S>();
+  static_assert((QW == 4 || QW == 8) && F::MT2 % QW == 0 && F::NM % KH == 0, "one S10 tile per wave");
   constexpr int H = F::H;
   constexpr int XQ = F::MT2 / QW;                        // S2 m-tiles per wave
+  constexpr int RT2 = F::RT2;                            // chain-row tiles of S2 (H = 256: 2, H = 512: 4)
   constexpr int NH = F::NM / KH;                         // k-blocks per half
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
@@ -122,21 +126,17 @@ __global__ void __launch_bounds__(QW * 64, 2) k_lstm_fwd_f10q(int B, int T, GinS
   for (int t = 0; t < T; ++t) {
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
-    // ---- phase A: S2, two m-tiles at a time (MFMAs first, then the splitting) -------------------------------------
+    // ---- phase A: S2, four tiles at a time (MFMAs first, then the splitting) ---------------------------------------
+    constexpr int TPW = XQ * RT2;                          // (m-tile, row-tile) pairs of this wave: 4 for both supported shapes
+    static_assert(TPW % 4 == 0, "tiles in groups of four");
 #pragma unroll
-    for (int x0 = 0; x0 < XQ; x0 += 2) {
-      f32x4 t2[2][2];
+    for (int g0 = 0; g0 < TPW; g0 += 4) {
+      f32x4 t2[4];
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        t2[x][0] = f10h_s2_mma<S>(s1[x0 + x], hp, 0, lane);
-        t2[x][1] = f10h_s2_mma<S>(s1[x0 + x], hp, 1, lane);
-      }
+      for (int i = 0; i < 4; ++i) t2[i] = f10h_s2_mma<S>(s1[(g0 + i) / RT2], hp, (g0 + i) % RT2, lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        f10h_s2_store<S>(t2[x][0], img, wave + QW * (x0 + x), 0, lane);
-        f10h_s2_store<S>(t2[x][1], img, wave + QW * (x0 + x), 1, lane);
-      }
+      for (int i = 0; i < 4; ++i) f10h_s2_store<S>(t2[i], img, wave + QW * ((g0 + i) / RT2), (g0 + i) % RT2, lane);
     }
     TT_STAMP(0)
     lds_barrier();
@@ -204,7 +204,8 @@ static int launch_q(const RnnShape& rs, GinSrc gin, const void* h0, const void* 
   const float* hdr = reinterpret_cast<const float*>(ws);
   const xh8* wfrag = reinterpret_cast<const xh8*>(reinterpret_cast<const unsigned char*>(ws) + F10H_HDR_BYTES);
   constexpr size_t lds = f10q_lds_bytes<S>();
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  constexpr int QW = f10q_waves<S>();
+  static_assert((QW == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU");
   auto kern = gin.in1 ? (out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true, true> : k_lstm_fwd_f10q<S, KH, false, true, true>)
                              : (h0 ? k_lstm_fwd_f10q<S, KH, true, false, true> : k_lstm_fwd_f10q<S, KH, false, false, true>))
                       : (out ? (h0 ? k_lstm_fwd_f10q<S, KH, true, true, false> : k_lstm_fwd_f10q<S, KH, false, true, false>)
@@ -225,6 +226,8 @@ int launch_rnn_fwd_f10_q(const RnnShape& rs, GinSrc gin, const void* h0, const v
     return launch_q<ShpH256R8L, 1>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
   if (shape_matches<ShpH256R16L>(rs.hid_s))
     return launch_q<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
+  if (shape_matches<ShpH512R8L>(rs.hid_s))      // eight waves, one workgroup per CU (launch_rnn_fwd_f10_h512)
+    return launch_q<ShpH512R8L, 1>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

@@ -1218,6 +1218,10 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
                  : launch_gemm_split(dtype, rows, inp, 4 * H, xg, planes, nullptr, 0, gin, stream, bilv);
   }
   if (st != TTRNN_OK) return st;
+  // the reference's default benchmark shape (H = 512, r = 8) in split mode: the fused-core forward kernel on the gin just built
+  // (both biases are folded into it), this tier's `rec` region as its fragment workspace (ttrnn_fast_f10.hip)
+  if (f10_h512_fwd_available(rs, dtype) && L.rec >= f10_h512_workspace_bytes())
+    return launch_rnn_fwd_f10_h512(rs, gin, h0, c0, packed_hid, out, hT, cT, reserve, rec, stream);
   const xbf8* fs2;
   const float* ft1;
   const int* hdr = nullptr;

@@ -161,6 +161,12 @@ int launch_rnn_fwd_f10_q(const RnnShape& rs, GinSrc gin, const void* h0, const v
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
                            hipStream_t stream);
 
+// H = 512, r = 8 (benchmarking.py's default shape): fused-core forward as eight-wave workgroups; gin with both biases folded in
+bool f10_h512_fwd_available(const RnnShape& rs, int dtype);
+size_t f10_h512_workspace_bytes();
+int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+                            void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream);
+
 // the same fused-core recurrent kernel on the fp32 MFMA (TTRNN_MATH_EXACT; ttrnn_fast_f10x.hip); ws as above
 bool f10x_rnn_fwd_available(const RnnShape& rs, int dtype);
 int launch_rnn_fwd_f10x(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,

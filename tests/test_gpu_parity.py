@@ -2650,3 +2650,66 @@ def test_two_core_reverse_kernel_ranges(case):
     # a core entry x 1e5 makes the gradients themselves ill-conditioned: the fp32-MFMA kernel sits at 5e-5 there, the yardstick)
     assert worst["two_fp16"] <= (1.5 * worst["fp32_mfma"] + 1e-6 if case.startswith("outlier") else 2e-5)
     assert worst["two_fp16"] <= 3.0 * worst["fp32_mfma"] + 1e-6
+
+
+# ---- (15) H = 512, r = 8: the fused-core forward under the runtime tier's K-in (ttrnn_fast_f10.hip: launch_rnn_fwd_f10_h512) ------------
+@pytest.mark.parametrize("B,T,inp,with_state", [(3, 9, 256, True), (5, 33, 40, False), (300, 6, 256, True)])
+def test_h512_fused_core_forward_route(B, T, inp, with_state):
+    """The reference's default benchmark shape (benchmarking.py:75-83: TT-LSTM hidden 512, ncores 3, ttrank 8): in split mode the
+    forward recurrent kernel is the fused-core kernel as eight-wave workgroups (k_lstm_fwd_f10q<ShpH512R8L>) behind the runtime tier's
+    dense K-in; exact mode and option dev bit 13 keep the runtime-shape / any-shape kernels.  Outputs and every gradient (the reverse
+    kernel is the runtime tier's, reading this kernel's reserve) against the float64 oracle; the two forward kernels against each
+    other; B = 300 > #CUs runs in two rounds of workgroups; batch split, repeat launches and the outputs-not-wanted call bit for bit."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    from ttrnn_hip import functional as F
+    torch.manual_seed(97 + B)
+    H = 512
+    m = build_module(dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8), dev())
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_route(spec, B, T) == "fused_core"
+    with ttrnn_hip.option("dev", 8192):
+        assert F.rnn_route(spec, B, T) == "runtime_mfma"
+    x = torch.randn(B, T, inp) * 0.5
+    h0, c0 = (torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3) if with_state else (None, None)
+    nchk = min(B, 4)
+    rows = sorted({0, B // 2, B - 1, 1 % B})[:nchk]
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x[rows].double().clone().requires_grad_(True)
+    init = (h0[rows].double(), c0[rows].double()) if with_state else None
+    ro, (rh, rc) = O.lstm_forward(layers, xr, init)
+    w = torch.randn(len(rows), T, H)
+    ((ro * w.double()).sum() + rc.sum()).backward()
+
+    def run(sel=None, need_out=True):
+        xs = x if sel is None else x[sel]
+        st = None if not with_state else ((h0 if sel is None else h0[sel]).to(dev()), (c0 if sel is None else c0[sel]).to(dev()))
+        with torch.no_grad():
+            return m(xs.to(dev()), st) if need_out else m(xs.to(dev()), st, need_outputs=False)
+
+    out, (hT, cT) = run()
+    assert _maxabs(out[rows], ro.detach()) <= 2e-6 and _maxabs(cT[rows], rc.detach()) <= 2e-6
+    again = run()
+    assert torch.equal(out, again[0]) and torch.equal(cT, again[1][1])
+    part = run(rows)
+    assert torch.equal(out[rows], part[0])
+    nout = run(need_out=False)
+    assert torch.equal(nout[1][0], hT) and torch.equal(nout[1][1], cT)
+    with ttrnn_hip.option("dev", 8192):
+        g2out = run()[0]
+    assert not torch.equal(g2out, out) and _maxabs(g2out, out) <= 2e-6
+    # training step through this forward + the runtime tier's reverse kernel (masked loss on `rows`)
+    m.zero_grad()
+    xg = x.to(dev()).requires_grad_(True)
+    st = None if not with_state else (h0.to(dev()), c0.to(dev()))
+    o2, (h2, c2) = m(xg, st)
+    W = torch.zeros(B, T, H)
+    W[rows] = w
+    mask = torch.zeros(B, 1)
+    mask[rows] = 1.0
+    ((o2 * W.to(dev())).sum() + (c2 * mask.to(dev())).sum()).backward()
+    assert _maxabs(xg.grad[rows], xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-30)
+    for n, p in m.named_parameters():
+        ref = leaves[n].grad
+        assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-30), n

@@ -72,16 +72,23 @@ def test_captured_step_equals_eager_step(name):
         for v in st.values():
             if torch.is_tensor(v):
                 v.zero_()
+    losses_c, losses_a = [], []
     for _ in range(3):
-        cap(x2, t)
+        losses_c.append(float(cap(x2, t)))
         opt_a.zero_grad(set_to_none=True)
-        _loss(a, x2, t).backward()
+        la = _loss(a, x2, t)
+        la.backward()
         opt_a.step()
+        losses_a.append(float(la))
     torch.cuda.synchronize()
-    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        # Adam divides by sqrt(v): where a gradient is ~0 its last-bit noise (atomic bias sums) moves the update by a visible
-        # fraction of lr — bounded by a few per cent of the three steps' total travel (3 * lr)
-        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-5 * max(float(pa.detach().abs().max()), 1e-3) + 3e-4 * 1e-3, k
+    # the two trajectories stay together.  (Compared through the LOSS: Adam divides by sqrt(v), so a parameter whose gradient is
+    # ~0 moves by +-lr on the sign of its last-bit noise — the small classifier head's core gradients still go through atomics —
+    # and a per-parameter comparison after three steps measures that noise, not the replay.)
+    with torch.no_grad():
+        fa, fb = float(_loss(a, x2, t)), float(_loss(b, x2, t))
+    assert losses_c[0] == losses_a[0]
+    assert all(abs(u - v) <= 2e-5 * abs(v) for u, v in zip(losses_c, losses_a)), (losses_c, losses_a)
+    assert abs(fa - fb) <= 2e-5 * abs(fa), (fa, fb)
     assert ttrnn_hip.device_status()["pair_timeouts"] == 0
 
 
