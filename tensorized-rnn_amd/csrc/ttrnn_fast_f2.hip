@@ -604,13 +604,19 @@ __global__ void __launch_bounds__(F2<S>::NWV * 64, 4) k_lstm_bwd_f2(int Bn, int 
     // ---- T1: this wave's 64 of the 128 k values; columns j0 = c & 7 (columns 8 .. 15 repeat them) ----------------------------------
     const int row1 = c & 7;
     f32x4 alo = f32x4{0.f, 0.f, 0.f, 0.f}, ahi = alo;
+    xh8 z0[2], z1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                   // all four operand reads in flight before the first MFMA
+      const int off = row1 * 128 + (((4 * u + q) ^ row1) << 4);
+      z0[u] = *reinterpret_cast<const xh8*>(dci + off);
+      z1[u] = *reinterpret_cast<const xh8*>(dci + DCP + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int off = row1 * 128 + (((4 * u + q) ^ row1) << 4);
-      const xh8 z0 = *reinterpret_cast<const xh8*>(dci + off), z1 = *reinterpret_cast<const xh8*>(dci + DCP + off);
-      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][1], z0, alo, 0, 0, 0);
-      ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z0, ahi, 0, 0, 0);
-      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z1, alo, 0, 0, 0);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][1], z0[u], alo, 0, 0, 0);
+      ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z0[u], ahi, 0, 0, 0);
+      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1w[u][0], z1[u], alo, 0, 0, 0);
     }
     // lane (c = j0, q): dh[j0 * J1 + 4 q + j], j = 0 .. 3 (this wave's share of the sum over i1)
     *reinterpret_cast<f32x4*>(dh_out + row1 * F::J1 + 4 * q) = (ahi + alo) * (un1 * u2);
