@@ -611,7 +611,11 @@ size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_stat
     return a > b2 ? a : b2;
   }
   if (!g2_first && !want_state && !gen && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return big_rnn_bwd_workspace(rs);
-  if (!gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) return g2_rnn_bwd_workspace(rs);
+  if (!gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
+    const size_t a = g2_rnn_bwd_workspace(rs);
+    const size_t b2 = !g2_first && f10bh_h512_available(rs, desc->dtype) ? f10bh_h512_workspace_bytes() : 0;
+    return a > b2 ? a : b2;
+  }
   return plan_rnn_generic(rs, true).ws_bytes;
 }
 
@@ -795,7 +799,8 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
     return TTRNN_ROUTE_STAGEWISE_MFMA;
   }
   if (!g2_first && !want_state && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
-  if (rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  if (rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype))
+    return !g2_first && f10bh_h512_available(rs, desc->dtype) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
   return TTRNN_ROUTE_VALU;
 }
 
@@ -870,6 +875,10 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
                               d_h0, d_c0, workspace, (hipStream_t)stream, stats);
   }
   if (!force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
+    // the reference's default benchmark shape in split mode: the fused-core reverse-time kernel on two fp16 pieces
+    if (!g2_first && f10bh_h512_available(rs, desc->dtype) && workspace && workspace_bytes >= f10bh_h512_workspace_bytes())
+      return launch_rnn_bwd_f10_h512(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
+                                     workspace, (hipStream_t)stream, stats);
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                              d_h0, d_c0, workspace, (hipStream_t)stream, d_state, stats);

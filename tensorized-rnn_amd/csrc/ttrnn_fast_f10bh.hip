@@ -41,6 +41,7 @@ struct F10BH {
   static constexpr int CT2 = F::ROWS2 / 16;                 // T2 column tiles (2)
   static constexpr int XT2 = NM2 * CT2 / FAST_NW;           // T2 (column tile, k-block) pairs per wave
   static constexpr int HI = F::I2 / 2;
+  static constexpr int NWG = H / 64;                        // gate waves: one hidden unit per thread (H = 512: all eight)
   static constexpr int ROWS = F::K + 16;                    // rows: W10's, then G2's (padded to a tile)
   // header (floats): [un1: F::K | un2: 16 | L1 norms of the scaled rows: ROWS], padded to 256 bytes
   static constexpr int UN1 = 0, UN2 = F::K, L1N = F::K + 16;
@@ -54,8 +55,9 @@ template <class S>
 constexpr bool f10bh_ok() {
   using F = F10<S>;
   using B = F10BH<S>;
-  return f10_ok<S>() && F::I2 == 16 && B::K1 == 64 && B::FT % FAST_NW == 0 && B::K2 % 32 == 0 &&
-         (B::NM2 * B::CT2) % FAST_NW == 0 && B::CT2 == 2 && F::J2 == 8 && F::H == 256 && B::NM2 <= FAST_NW;
+  return f10_ok<S>() && F::I2 == 16 && (B::K1 == 64 || B::K1 == 128) && B::FT % FAST_NW == 0 && B::K2 % 32 == 0 &&
+         (B::NM2 * B::CT2) % FAST_NW == 0 && (B::CT2 == 2 || B::CT2 == 4) && F::J2 == 8 && (F::H == 256 || F::H == 512) &&
+         B::NM2 <= FAST_NW && B::NM1 <= FAST_NW && B::NWG <= FAST_NW;
 }
 
 // x < 2^e, clamped so that 2^(14 - e) and its inverse stay normal floats (gradients deep in a sequence are tiny)
@@ -194,7 +196,7 @@ constexpr size_t f10bh_lds_bytes() {
   using B = F10BH<S>;
   using F = F10<S>;
   return sizeof(float) * ((size_t)4 * B::H + (size_t)B::NM2 * B::H) +
-         sizeof(_Float16) * 2 * ((size_t)F::I2 * B::K1 + (size_t)F::ROWS2 * B::K2);
+         sizeof(_Float16) * 2 * ((size_t)F::I2 * B::K1 + (size_t)F::ROWS2 * B::K2) + (B::XF >= 4 ? sizeof(float) * F::K : 0);
 }
 
 template <class S, bool DIAG>
@@ -212,14 +214,18 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
   using B = F10BH<S>;
   constexpr int H = F::H, GH = 4 * H;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) float smax1[4];                    // per-wave maxima of |dg| (waves 0-3)
+  __shared__ __attribute__((aligned(16))) float smax1[B::NWG];               // per-wave maxima of |dg| (the gate waves)
   __shared__ float sl1[FAST_NW];                                             // (prologue) per-wave maxima of the rows' L1 norms
   constexpr int PL1 = F::I2 * B::K1, PL2 = F::ROWS2 * B::K2;                 // elements per fp16 plane
-  static_assert(GH / 4 == FAST_NT - H, "waves 4-7 store the fp32 row: one 16-byte piece per thread");
+  // the fp32 row goes out in 16-byte pieces: H = 256 from waves 4-7 (one each) while the gate waves split, H = 512 (every wave
+  // is a gate wave) one piece per thread behind its split
+  static_assert(GH / 4 == FAST_NT - H || GH / 4 == FAST_NT, "one 16-byte piece of the fp32 row per storing thread");
+  constexpr bool ALLG = H == FAST_NT;
   float* dgf = reinterpret_cast<float*>(smem);                               // [4H] in HBM row order
   float* dhs = dgf + GH;                                                     // [NM2][H]
   _Float16* img1h = reinterpret_cast<_Float16*>(dhs + B::NM2 * H);           // dg's two fp16 pieces [2][I2][K1] (x_off)
   _Float16* img2h = img1h + 2 * PL1;                                         // dC2's two fp16 pieces [2][ROWS2][K2] (x_off)
+  float* un1s = reinterpret_cast<float*>(img2h + 2 * PL2);                   // (XF >= 4) T01's inverse row scales [F::K]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,14 +242,17 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
 #pragma unroll
       for (int p = 0; p < 2; ++p)
         w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
-    un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+    if constexpr (B::XF < 4) un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
   }
-  const int ct = wave & 1;
+  if constexpr (B::XF >= 4)
+    for (int f = tid; f < F::K; f += FAST_NT) un1s[f] = hdr[B::UN1 + f];
+  static_assert(FAST_NW % B::CT2 == 0, "a wave's T2 pairs share the column tile");
+  const int ct = wave % B::CT2;
 #pragma unroll
   for (int x = 0; x < B::XT2; ++x)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ((wave + FAST_NW * x) >> 1) * 2 + p) * 64 + lane];
+      w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ((wave + FAST_NW * x) / B::CT2) * 2 + p) * 64 + lane];
   un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * q);
   // bound of T01's results: |dC2[f][.]| <= L1(row f of W10) max|dg|.  The largest row norm, once per launch
   float maxl1;
@@ -340,7 +349,11 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     float u2;                                                     // inverse of T2's operand scale, kept for T2's epilogue
     float t01f;                                                   // un-scale of T01's accumulators times T2's operand scale
     {
-      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      if constexpr (B::NWG == 8) {
+        const f32x4 m5 = *reinterpret_cast<const f32x4*>(smax1 + 4);
+        m4 = f32x4{fmaxf(m4[0], m5[0]), fmaxf(m4[1], m5[1]), fmaxf(m4[2], m5[2]), fmaxf(m4[3], m5[3])};
+      }
       const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       if (bs.rowmax && tid == FAST_NT - 1) bs.rowmax[bt] = mxg;  // by-product: the row maximum of d_gates (dy_rowmax hint of dx)
       float ug;
@@ -358,8 +371,9 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
         fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
         dout_f = dptr[b2 * H + hid];
         x_f = xptr[b2];
-      } else {                                                    // waves 4-7: the fp32 row goes out to HBM meanwhile
-        const int i4 = tid - H;
+      }
+      if (ALLG || !own) {                                         // (H = 256: waves 4-7) the fp32 row goes out to HBM meanwhile
+        const int i4 = ALLG ? tid : tid - H;
         const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
         reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
         if (dg_hid && dg_hid != dg_in) reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
@@ -370,29 +384,55 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     TT_STAMP(3)
     // ---- T01: dC2 = W10 dg, rescaled for T2 and split into its operand image ------------------------------------------------
     {
-      xh8 bf[B::NM1][2];
+      if constexpr (B::XF >= 4) {
+        // many feature tiles per wave (H = 512): k-block outermost — one pair of operand fragments live at a time, the tiles'
+        // accumulators are the independent chains
+        f32x4 acc[B::XF];
 #pragma unroll
-      for (int u = 0; u < B::NM1; ++u)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-          bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
-#pragma unroll
-      for (int x = 0; x < B::XF; ++x) {
-        f32x4 au[B::NM1];                                        // one chain per k-block: three dependent MFMAs, not six
+        for (int x = 0; x < B::XF; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < B::NM1; ++u) {
-          au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
-          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
-        }
-        f32x4 acc = au[0];
+          const xh8 b0 = *reinterpret_cast<const xh8*>(img1h + x_off<B::K1>(c, 32 * u + 8 * q));
+          const xh8 b1 = *reinterpret_cast<const xh8*>(img1h + PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
 #pragma unroll
-        for (int u = 1; u < B::NM1; ++u) acc += au[u];
-        // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = r20 + j): four consecutive k of T2
-        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
-        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
-        store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+          for (int x = 0; x < B::XF; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], b0, acc[x], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < B::XF; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], b1, acc[x], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < B::XF; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], b0, acc[x], 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < B::XF; ++x) {
+          const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+          const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+          const f32x4 u1 = *reinterpret_cast<const f32x4*>(un1s + f0);
+          store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc[x] * (u1 * t01f));
+        }
+      } else {
+        xh8 bf[B::NM1][2];
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+        for (int x = 0; x < B::XF; ++x) {
+          f32x4 au[B::NM1];                                        // one chain per k-block: three dependent MFMAs, not six
+#pragma unroll
+          for (int u = 0; u < B::NM1; ++u) {
+            au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
+            au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
+            au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
+          }
+          f32x4 acc = au[0];
+#pragma unroll
+          for (int u = 1; u < B::NM1; ++u) acc += au[u];
+          // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = r20 + j): four consecutive k of T2
+          const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+          const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+          store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+        }
       }
     }
     TT_STAMP(4)
@@ -404,7 +444,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
       f32x4 acc2[B::XT2];
 #pragma unroll
       for (int x = 0; x < B::XT2; ++x) {
-        const int ub = (wave + FAST_NW * x) >> 1;
+        const int ub = (wave + FAST_NW * x) / B::CT2;
         const int row = 16 * ct + c;
         xh8 b2[2];
 #pragma unroll
@@ -421,7 +461,7 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
       if (q < 2) {
 #pragma unroll
         for (int x = 0; x < B::XT2; ++x) {
-          const int ub = (wave + FAST_NW * x) >> 1;
+          const int ub = (wave + FAST_NW * x) / B::CT2;
           *reinterpret_cast<f32x4*>(dhs + ub * H + (16 * ct + c) * F::J2 + 4 * q) = acc2[x] * (un2 * u2);
         }
       }
@@ -761,6 +801,26 @@ bool f10bh_available(const RnnShape& rs, int dtype) {
            shape_matches<ShpH256R8G>(rs.hid_s);
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
+}
+
+// the reference's default benchmark shape (H = 512, r = 8): a runtime-tier shape whose reverse-time recurrence runs here in split
+// mode — eight gate waves, four feature tiles of T01 (K = 128) and two T2 pairs per wave (dev bit 16384 keeps the tier's kernel)
+bool f10bh_h512_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && opt(OPT_GEMM_PIECES) != 3 &&
+         !(opt(OPT_DEV) & 16384) && rs.T > 0 && shape_matches<ShpH512R8L>(rs.hid_s);
+}
+size_t f10bh_h512_workspace_bytes() {
+  return F10BH<ShpH512R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH512R8L>::FRAGS * sizeof(xh8) + 4096;
+}
+int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                            hipStream_t stream, float* stats) {
+  BwdStats bs;
+  if (stats) bs.colmax = reinterpret_cast<unsigned*>(stats);      // (cleared by the prep launch)
+  unsigned long long* diag = reinterpret_cast<unsigned long long*>((char*)ws + f10bh_h512_workspace_bytes() - 4096);
+  int st = launch_t<ShpH512R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream, bs);
+  if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, rs.G * rs.H, nullptr, stats, stream);
+  return st;
 }
 
 size_t f10bh_workspace_bytes(const RnnShape& rs) {

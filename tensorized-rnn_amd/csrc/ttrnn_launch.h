@@ -303,6 +303,13 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
 // the same on two fp16 pieces per operand (ttrnn_fast_f10bh.hip): the TT-LSTM shapes in split mode (option gemm_pieces = 3:
 // the three-bf16-piece kernel)
 bool f10bh_available(const RnnShape& rs, int dtype);
+// ... and for the runtime tier's H = 512, r = 8 TT-LSTM (the reference's benchmarking.py defaults): called from that tier's branch
+// of ttrnn_rnn_backward_ex when no per-step state gradients are asked for; stats: the column maxima (rows 0 / 1) or NULL
+bool f10bh_h512_available(const RnnShape& rs, int dtype);
+size_t f10bh_h512_workspace_bytes();
+int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                            hipStream_t stream, float* stats);
 // ttrnn_fast_proj.hip: d_packed += the adjoint of (three cores -> dense matrix) applied to dW (fp32 [in][out]); ws:
 // proj3_workspace_bytes (0: not offered for this shape / switched off by option dev bit 10)
 size_t proj3_workspace_bytes(const TtShape& s);

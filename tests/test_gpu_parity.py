@@ -2713,3 +2713,93 @@ def test_h512_fused_core_forward_route(B, T, inp, with_state):
     for n, p in m.named_parameters():
         ref = leaves[n].grad
         assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-30), n
+
+
+# ---- (16) H = 512, r = 8: the fused-core reverse-time kernel (ttrnn_fast_f10bh.hip: k_lstm_bwd_f10h<ShpH512R8L>) ---------------------
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only", "outlier_core0", "outlier_core2", "two_rounds"])
+def test_h512_fused_core_reverse_kernel(case):
+    """The reference's default benchmark shape (benchmarking.py:75-83) in split mode: the reverse-time recurrence is the fused-core
+    kernel on two fp16 pieces with all eight waves as gate waves (torch autograd through lstm.py:23-32,123-133 and t3nsor/ops.py:78-93
+    is what it restates); option dev bit 14 keeps the runtime tier's kernel, exact mode its own route.  Every parameter / input / initial-state
+    gradient against the float64 oracle next to the runtime tier's kernel on the same inputs — output gradients over ten decades,
+    steps and samples without gradient, a loss on the last step only, one core entry x 1e5, 300 samples (two rounds of
+    workgroups); the kernel's own results bitwise repeatable and independent of the rest of the batch; a request for the
+    per-step state gradients still takes the runtime tier."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    from ttrnn_hip import functional as F
+    torch.manual_seed(223)
+    H, inp = 512, 40
+    meta = dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev())
+    B = 300 if case == "two_rounds" else 5
+    T = 60 if case == "last_step_only" else (4 if case == "two_rounds" else 9)
+    if case.startswith("outlier"):
+        core = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n][int(case[-1])]
+        with torch.no_grad():
+            flat = core.detach().clone().contiguous().view(-1)
+            flat[(5 * flat.numel()) // 11] *= 1e5
+            core.copy_(flat.view(core.shape))
+    x = torch.randn(B, T, inp)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    rows = list(range(B)) if B <= 8 else [0, 1, B // 2, B - 1]
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t[rows].double().clone().requires_grad_(True) for t in (x, h0, c0))
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    ((ro * w[rows].double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+    mask = torch.zeros(B, 1)
+    mask[rows] = 1.0
+
+    def run(sel=None):
+        m.zero_grad()
+        xs, hs, cs, ws, ms = (t if sel is None else t[sel] for t in (x, h0, c0, w, mask))
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (xs, hs, cs))
+        out, (hT, cT) = m(xg, (h0g, c0g))
+        md = ms.to(dev())
+        ((out * (ws * ms.unsqueeze(-1)).to(dev())).sum() + wsum * ((cT * md).sum() + 0.5 * (hT * md).sum())).backward()
+        return {"x": xg.grad.clone(), "h0": h0g.grad.clone(), "c0": c0g.grad.clone(),
+                **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+    assert F.rnn_backward_route(spec, B, T, want_state=True) == "runtime_mfma"
+    with ttrnn_hip.fp32_math("exact"):
+        assert F.rnn_backward_route(spec, B, T) != "fused_core"
+    got = run()
+    again = run()
+    sub = run([rows[2], rows[0]]) if B <= 8 else None
+    with ttrnn_hip.option("dev", 16384):
+        assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
+        tier = run()
+    refs = {"x": xr.grad, "h0": h0r.grad, "c0": c0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"two_fp16": 0.0, "tier": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        g, t = (d[n][rows] if n in ("x", "h0", "c0") else d[n] for d in (got, tier))
+        worst["two_fp16"] = max(worst["two_fp16"], _maxabs(g.double(), ref) / sc)
+        worst["tier"] = max(worst["tier"], _maxabs(t.double(), ref) / sc)
+    for n in ("h0", "c0", "x"):                                    # the reverse-time kernel's own results (x: through d_gates)
+        assert torch.equal(got[n], again[n]), n
+        if sub is not None:
+            assert torch.equal(got[n][[rows[2], rows[0]]], sub[n]), n
+    if case == "sparse_steps":
+        assert float(got["h0"][2].abs().max()) == 0.0
+    if case == "last_step_only":
+        rel = _maxabs(got["h0"].double(), h0r.grad) / max(float(h0r.grad.abs().max()), 1e-300)
+        print("d_h0 after 60 steps: max |ref| %.3g, relative error %.3g" % (float(h0r.grad.abs().max()), rel))
+        assert rel <= 1e-4
+    print(case, "max gradient error relative to each tensor's maximum:", worst)
+    assert not torch.equal(got["h0"], tier["h0"])                  # a different kernel did run
+    assert worst["two_fp16"] <= (1.5 * worst["tier"] + 1e-6 if case.startswith("outlier") else 2e-5)
+    assert worst["two_fp16"] <= 3.0 * worst["tier"] + 1e-6
