@@ -506,6 +506,277 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
   }
 }
 
+// ---- LSTM, one wave per 64 hidden units (wave-local T2) ----------------------------------------------------------------------
+// The same arithmetic as k_lstm_bwd_f10h with the work laid out so that TWO of its four barriers disappear: H / 64 waves (four at
+// H = 256, eight at H = 512), every wave a gate wave for 64 CONSECUTIVE hidden units = eight rows row2 of dh.  T01's feature tiles
+// are dealt out contiguously — wave w computes dC2 for the features (row2, r2) of exactly its own eight rows — so T2 (whose
+// contraction runs over (i2, r2) of ONE row2) reads only what the same wave wrote, and its result dh is what the same wave's
+// gate phase consumes next step: both hand-offs are in-wave LDS round trips (in order per wave, one lgkmcnt wait).  T2's column
+// tile is half empty (eight rows of sixteen): 3 NM2 MFMAs per wave and step, G2's fragments read from LDS.  What still crosses
+// the waves: the step's exact maximum (the operand scale) and the dg image, T01's operand — two barriers with the split of the
+// thread's own four values between them.  The fp32 row of d_gates goes out from the gate threads directly (four coalesced dword
+// stores); the record prefetch is issued behind the second barrier, under T01's MFMAs.  Four-wave workgroups run two per CU.
+template <class S>
+struct F10BL {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  static constexpr int NWV = F::H / 64, NT = NWV * 64;
+  static constexpr int XF = B::FT / NWV;                    // feature tiles per wave (contiguous)
+  static constexpr int RW = 16 * XF / F::R2;                // rows row2 per wave
+};
+
+template <class S>
+constexpr bool f10bl_ok() {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  using L = F10BL<S>;
+  return f10_ok<S>() && F::I2 == 16 && F::J2 == 8 && F::H % 64 == 0 && (L::NWV == 4 || L::NWV == 8) && B::FT % L::NWV == 0 &&
+         L::RW == 8 && L::RW * L::NWV == F::ROWS2 && B::K1 % 32 == 0 && B::K2 % 32 == 0 && (16 * L::XF) % F::R2 == 0 && F::R2 % 4 == 0;
+}
+
+template <class S>
+constexpr size_t f10bl_lds_bytes() {
+  using B = F10BH<S>;
+  using F = F10<S>;
+  return sizeof(float) * ((size_t)B::H + F::K) + sizeof(_Float16) * 2 * ((size_t)F::I2 * B::K1 + (size_t)F::ROWS2 * B::K2) +
+         sizeof(xh8) * (size_t)B::NM2 * 2 * 64;
+}
+
+template <class S, bool DIAG>
+__global__ void __launch_bounds__(F10BL<S>::NT, F10BL<S>::NWV == 4 ? 2 : 1)
+    k_lstm_bwd_f10l(int Bn, int T, const float* __restrict__ c0, const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
+                    const float* __restrict__ reserve, const float* __restrict__ d_out, const float* __restrict__ d_hT,
+                    const float* __restrict__ d_cT, float* __restrict__ dg_in, float* __restrict__ dg_hid,
+                    float* __restrict__ d_h0, float* __restrict__ d_c0, unsigned long long* __restrict__ diag, BwdStats bs) {
+  static_assert(f10bl_ok<S>(), "shape not supported by the wave-local fused-core reverse-time kernel");
+  using F = F10<S>;
+  using B = F10BH<S>;
+  using L = F10BL<S>;
+  constexpr int H = F::H, GH = 4 * H, NWV = L::NWV, NT = L::NT, XF = L::XF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) float smax1[NWV];
+  __shared__ float sl1[NWV];
+  constexpr int PL1 = F::I2 * B::K1, PL2 = F::ROWS2 * B::K2;
+  float* dhs = reinterpret_cast<float*>(smem);                               // [H]: dh_{t-1}, written and read by the owning wave
+  float* un1s = dhs + H;                                                     // [F::K] T01's inverse row scales
+  _Float16* img1h = reinterpret_cast<_Float16*>(un1s + F::K);                // dg's two fp16 pieces [2][I2][K1] (x_off)
+  _Float16* img2h = img1h + 2 * PL1;                                         // dC2's two fp16 pieces [2][ROWS2][K2] (x_off)
+  xh8* w2s = reinterpret_cast<xh8*>(img2h + 2 * PL2);                        // G2's fragments [NM2][2][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  xh8 w01[XF][B::NM1][2];
+#pragma unroll
+  for (int x = 0; x < XF; ++x)
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((XF * wave + x) * B::NM1 + u) * 2 + p) * 64 + lane];
+  for (int e = tid; e < B::NM2 * 2 * 64; e += NT) w2s[e] = wfrag[(size_t)B::FT * B::NM1 * 2 * 64 + e];
+  for (int f = tid; f < F::K; f += NT) un1s[f] = hdr[B::UN1 + f];
+  const f32x4 un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * (q & 1));
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int f = tid; f < F::K; f += NT) l = fmaxf(l, hdr[B::L1N + f] * hdr[B::UN1 + f]);
+    l = wave_max(l);
+    if (lane == 0) sl1[wave] = l;
+    __syncthreads();
+    maxl1 = sl1[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) maxl1 = fmaxf(maxl1, sl1[w]);
+  }
+
+  // gate phase: thread tid owns hidden unit tid; three rotating register sets (see k_lstm_bwd_f10)
+  const int hid = tid;
+  float dcs = d_cT ? d_cT[b * H + hid] : 0.f;
+  const float c0v = c0 ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
+  float do0 = 0.f, do1 = 0.f, do2 = 0.f;
+  const float* xptr = bs.x ? reinterpret_cast<const float*>(bs.x) : reserve;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  float xq0 = 0.f, xq1 = 0.f, xq2 = 0.f;
+  f32x4 cmx = f32x4{0.f, 0.f, 0.f, 0.f}, sxd = cmx, sdg = cmx;
+  dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
+  if (T > 0) {
+    const size_t bt = b * T + (T - 1);
+    const float* rv = reserve + res_gate(bt, H, hid);
+    const float* rc = reserve + res_cell((size_t)Bn * T, bt, H, hid);
+    ra0 = *reinterpret_cast<const f32x4*>(rv);
+    rb0 = rc[0];
+    do0 = dptr[bt * H + hid];
+    xq0 = xptr[bt];
+    if (T > 1) {
+      ra1 = *reinterpret_cast<const f32x4*>(rv - H * 4);
+      rb1 = rc[-H];
+      do1 = dptr[(bt - 1) * H + hid];
+      xq1 = xptr[bt - 1];
+    }
+  }
+  const bool two_rows = dg_hid && dg_hid != dg_in;
+  // this thread's places: its four gate values in the dg image, its T2 operand row and result slot
+  const int off1 = x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2));
+  const int row2r = L::RW * wave + (c & 7);
+  float* dh_dst = dhs + (L::RW * wave + (c & 7)) * F::J2 + 4 * (q & 1);
+  const bool t2_store = c < 8 && q < 2;
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dout_c, const float& nb, f32x4& fa,
+                  float& fb, float& dout_f, const float& x_c, float& x_f) {
+    const size_t bt = b * T + t;
+    // ---- G: gate gradients (lstm.py:26-32 differentiated); dh_{t-1} of this unit came from this wave's own T2 --------
+    const f32x4 qa = ra;
+    const float dht = fmaf(dout_c, dscale, dhs[hid]);
+    const float ig = qa[0], gg = qa[1], fg = qa[2], og = qa[3], cy = rb;
+    const float cprev = t > 0 ? nb : c0v;
+    const float tc = ftanh(cy);
+    const float dct = dcs + dht * og * (1.0f - tc * tc);
+    const float p0 = dct * gg * ig * (1.0f - ig);             // d pre-activation of i
+    const float p1 = dct * cprev * fg * (1.0f - fg);          //                     f
+    const float p2 = dct * ig * (1.0f - gg * gg);             //                     g
+    const float p3 = dht * tc * og * (1.0f - og);             //                     o
+    dcs = dct * fg;
+    const f32x4 pv = f32x4{p0, p1, p2, p3};
+    {
+      float* row = dg_in + bt * GH + hid;
+      row[0] = p0; row[H] = p1; row[2 * H] = p2; row[3 * H] = p3;
+      if (two_rows) {
+        float* row2 = dg_hid + bt * GH + hid;
+        row2[0] = p0; row2[H] = p1; row2[2 * H] = p2; row2[3 * H] = p3;
+      }
+    }
+    const float xv = x_c * xscale;
+    float mx = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float a = fabsf(pv[g]);
+      mx = fmaxf(mx, a);
+      cmx[g] = fmaxf(cmx[g], a);
+      sxd[g] = fmaf(xv, pv[g], sxd[g]);
+      sdg[g] += pv[g];
+    }
+    mx = wave_max(mx);
+    if (lane == 0) smax1[wave] = mx;
+    TT_STAMP(0)
+    lds_barrier();
+    TT_STAMP(1)
+    // ---- split: the step's scale from the exact maximum; every thread splits its own four values -----------------------
+    float u2, t01f;
+    {
+      f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      if constexpr (NWV == 8) {
+        const f32x4 m5 = *reinterpret_cast<const f32x4*>(smax1 + 4);
+        m4 = f32x4{fmaxf(m4[0], m5[0]), fmaxf(m4[1], m5[1]), fmaxf(m4[2], m5[2]), fmaxf(m4[3], m5[3])};
+      }
+      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      if (bs.rowmax && tid == NT - 1) bs.rowmax[bt] = mxg;
+      float ug;
+      const float sg = step_scale(mxg, ug);
+      const float s2 = step_scale(mxg * maxl1, u2);              // |dC2| <= maxl1 * mxg: no overflow, whatever the signs
+      t01f = ug * s2;
+      store_split4_h(img1h, PL1, off1, pv * sg);
+    }
+    TT_STAMP(2)
+    lds_barrier();
+    TT_STAMP(3)
+    {
+      // record(t-2), d_out(t-2), x(t-2): requested here, under T01's MFMAs, consumed two steps from now.  Always four loads, no
+      // branch (index clamped; a null d_out / x reads the reserve and is scaled by zero)
+      const size_t b2 = t > 1 ? bt - 2 : b * T;
+      fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+      fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
+      dout_f = dptr[b2 * H + hid];
+      x_f = xptr[b2];
+    }
+    // ---- T01: dC2 = W10 dg for this wave's own rows, rescaled for T2 and split into its operand image ------------------------
+    // (k-block outermost inside a group of four tiles: one pair of operand fragments and four accumulators live at a time)
+    {
+      constexpr int XG = XF > 4 ? 4 : XF;
+      static_assert(XF % XG == 0, "tile groups");
+#pragma unroll
+      for (int x0 = 0; x0 < XF; x0 += XG) {
+        f32x4 acc[XG];
+#pragma unroll
+        for (int x = 0; x < XG; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+          const xh8 b0 = *reinterpret_cast<const xh8*>(img1h + x_off<B::K1>(c, 32 * u + 8 * q));
+          const xh8 b1 = *reinterpret_cast<const xh8*>(img1h + PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+          for (int x = 0; x < XG; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x0 + x][u][1], b0, acc[x], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < XG; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x0 + x][u][0], b1, acc[x], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < XG; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x0 + x][u][0], b0, acc[x], 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < XG; ++x) {
+          // lane (c = i2, q), registers j: features 16ft + 4q + j = (row2, r2 = r20 + j): four consecutive k of T2
+          const int f0 = 16 * (XF * wave + x0 + x) + 4 * q;
+          const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+          const f32x4 u1 = *reinterpret_cast<const f32x4*>(un1s + f0);
+          store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc[x] * (u1 * t01f));
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's own rows of the dC2 image; nobody else reads them
+    TT_STAMP(4)
+    // ---- T2: dh_{t-1}[row2][j2] for the wave's eight rows (columns 8-15 of the tile repeat them, unused) ----------------------
+    {
+      f32x4 alo = f32x4{0.f, 0.f, 0.f, 0.f}, ahi = alo;
+#pragma unroll
+      for (int u = 0; u < B::NM2; ++u) {
+        const xh8 b0 = *reinterpret_cast<const xh8*>(img2h + x_off<B::K2>(row2r, 32 * u + 8 * q));
+        const xh8 b1 = *reinterpret_cast<const xh8*>(img2h + PL2 + x_off<B::K2>(row2r, 32 * u + 8 * q));
+        const xh8 a0 = w2s[(u * 2 + 0) * 64 + lane], a1 = w2s[(u * 2 + 1) * 64 + lane];
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, alo, 0, 0, 0);
+        ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, ahi, 0, 0, 0);
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, alo, 0, 0, 0);
+      }
+      // lane (c = row2 of the wave, q), registers j: j2 = 4q + j (q < 2): hidden = row2*J2 + j2
+      if (t2_store) *reinterpret_cast<f32x4*>(dh_dst) = (ahi + alo) * (un2 * u2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... read back by this wave's gate threads
+    TT_STAMP(5)
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2, xq0, xq2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0, xq1, xq0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1, xq2, xq1);
+  }
+  if (bs.colmax) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmx[g]));
+  }
+  if (bs.part) {
+    float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pp[g * H + hid] = sxd[g];
+      pp[GH + g * H + hid] = sdg[g];
+    }
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && diag && b < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) diag[(b * FAST_NW + wave) * 8 + i] = seg[i];
+    }
+  }
+  if (d_h0) d_h0[b * H + hid] = dhs[hid];
+  if (d_c0) d_c0[b * H + hid] = dcs;
+}
+
 // ---- GRU -----------------------------------------------------------------------------------------------------------
 // The same scheme for the TT-GRU (fp32 or bf16 storage; reserve, gate gradients and all arithmetic fp32; gru.py:38-44
 // differentiated as in k_gru_bwd_f10): three gates, I2 = 12 columns (padded to a tile), natural k order of T01's operand —
@@ -784,6 +1055,22 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
   constexpr size_t lds = f10bh_lds_bytes<S>();
   static_assert(lds <= 150 * 1024, "LDS image set too large");
   const bool dg = opt(OPT_DIAG) != 0;
+  if constexpr (f10bl_ok<S>()) {
+    // one wave per 64 hidden units, T2 wave-local, two barriers per step: where two of its four-wave workgroups share a CU
+    // (B > #CUs; cfg4: 586 -> 526 us per layer) and at H = 512 (eight waves either way).  One sample per CU at H = 256 stays on
+    // the eight-wave kernel, whose phases are shorter than the four barriers cost (cfg2: 2 851 against 3 301 cycles per step).
+    // Option dev bit 15: the eight-wave kernel everywhere
+    const bool local = F10BL<S>::NWV == 8 || rs.B > device_cu_count();
+    if (local && !(opt(OPT_DEV) & 32768)) {
+      constexpr size_t ldsl = f10bl_lds_bytes<S>();
+      static_assert(ldsl <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+      auto kl = dg ? k_lstm_bwd_f10l<S, true> : k_lstm_bwd_f10l<S, false>;
+      hipLaunchKernelGGL(kl, dim3(rs.B), dim3(F10BL<S>::NT), ldsl, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
+                         (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0, (float*)d_c0,
+                         dg ? diag : nullptr, bs);
+      return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    }
+  }
   auto kern = dg ? k_lstm_bwd_f10h<S, true> : k_lstm_bwd_f10h<S, false>;
   if (lds > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,

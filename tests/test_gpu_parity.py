@@ -2803,3 +2803,56 @@ def test_h512_fused_core_reverse_kernel(case):
     assert not torch.equal(got["h0"], tier["h0"])                  # a different kernel did run
     assert worst["two_fp16"] <= (1.5 * worst["tier"] + 1e-6 if case.startswith("outlier") else 2e-5)
     assert worst["two_fp16"] <= 3.0 * worst["tier"] + 1e-6
+
+
+# ---- (17) fused-core reverse LSTM kernel with one wave per 64 units (ttrnn_fast_f10bh.hip: k_lstm_bwd_f10l) at H = 256 ------------
+@pytest.mark.parametrize("rank,inp", [(8, 1), (16, 40)])
+def test_wave_local_reverse_kernel_h256(rank, inp):
+    """H = 256 launches with more samples than CUs run the reverse-time recurrence as four-wave workgroups, two per CU, whose T2 and
+    dh hand-off stay inside a wave (two barriers per step); option dev bit 15 keeps the eight-wave kernel.  Same arithmetic, another
+    summation order in T2 (whole K per wave instead of k-block partial sums): the two agree to rounding, both meet the float64 oracle
+    (autograd through lstm.py:23-32,123-133) on sampled rows; the by-products (column maxima; in = 1: the bias / input sums) come out
+    of the gate threads of either kernel."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    from ttrnn_hip import functional as F
+    torch.manual_seed(229 + rank)
+    H, B, T = 256, 300, 7
+    m = build_module(dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=rank), dev())
+    x = torch.randn(B, T, inp)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H) * (10.0 ** (torch.rand(B, T, 1) * 6 - 4))
+    rows = [0, 1, 150, 299]
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t[rows].double().clone().requires_grad_(True) for t in (x, h0, c0))
+    ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+    ((ro * w[rows].double()).sum() + rc.sum() + 0.5 * rh.sum()).backward()
+    mask = torch.zeros(B, 1)
+    mask[rows] = 1.0
+
+    def run():
+        m.zero_grad()
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (x, h0, c0))
+        out, (hT, cT) = m(xg, (h0g, c0g))
+        md = mask.to(dev())
+        ((out * (w * mask.unsqueeze(-1)).to(dev())).sum() + (cT * md).sum() + 0.5 * (hT * md).sum()).backward()
+        return {"x": xg.grad.clone(), "h0": h0g.grad.clone(), "c0": c0g.grad.clone(),
+                **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+    got, again = run(), run()
+    with ttrnn_hip.option("dev", 32768):
+        wide = run()
+    refs = {"x": xr.grad, "h0": h0r.grad, "c0": c0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        g, o = (d[n][rows] if n in ("x", "h0", "c0") else d[n] for d in (got, wide))
+        assert torch.isfinite(got[n]).all(), n
+        assert _maxabs(g.double(), ref) <= 2e-5 * sc, n
+        assert _maxabs(g, o) <= 4e-6 * sc, n
+    for n in ("h0", "c0"):
+        assert torch.equal(got[n], again[n]), n
+        assert float(got[n][[2, 77, 298]].abs().max()) == 0.0, n        # samples outside the loss
+    assert not torch.equal(got["h0"], wide["h0"])                  # a different kernel did run
