@@ -46,7 +46,7 @@ struct G2Mat {
   int KB1, pack8, JS;
   int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
   // reverse T2 (bf16 MFMA, split): M = Jh*Rp, N = It, K = Ih
-  int bM2T, bNKB, bT2, bKBP, bU, bUW;              // no k split: T1 reads the complete dC1
+  int bM2T, bNKB, bT2, bKBP, bU, bUW, bSW;         // no k split: T1 reads the complete dC1; bSW = blocks of a wave's (compact) stream
   int IhS;                          // bf16 dy planes [16*N2T][IhS]
   // reverse T1 (fp32 MFMA): M = Jt (one or more m tiles), N = Jh, K = It*Rp in steps of 4, split over bKS1P parts
   int bM1T, bKS1, bT1, bK1SPLIT, bKS1P, bU1;        // bKS1P = k-steps per part
@@ -135,6 +135,7 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->bKBP = g2_ceil(m->bNKBt, G2_PF) * G2_PF;
   m->bU = m->bT2;
   m->bUW = g2_ceil(m->bU, nw);
+  m->bSW = g2_ceil(m->bUW * m->bNKBt, G2_PF) * G2_PF;
   m->IhS = 32 * m->bNKB + 16;
   m->bM1T = g2_ceil(m->Jt, 16); m->bKS1 = (m->It * m->Rp) / 4;
   m->bT1 = m->bM1T * m->N1T;
@@ -151,7 +152,7 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->tail_elems = (long)m->It * m->Jt * m->R;
   m->fs2_bytes = (long)nw * m->UW * m->KBP * 2 * 64 * 16;
   m->ft1_bytes = (long)m->M1T * m->KB1 * (m->pack8 ? 1 : 2) * 64 * 16;     // fp16 fragments (xh8 per lane), 1 or 2 planes
-  m->bs2_bytes = (long)nw * m->bUW * m->bKBP * 3 * 64 * 16;
+  m->bs2_bytes = (long)nw * m->bSW * 3 * 64 * 16;
   m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
   m->ok = 1;
 }
@@ -242,7 +243,8 @@ inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
          g2_al(g2_diag_ints(m) * sizeof(int) + (size_t)m.It * 64 * sizeof(float));
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
-  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes);
+  // (+ 4 KB: the diagnostic stamps of -DTTRNN_ABLATIONS builds)
+  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes) + 4096;
 }
 
 }  // namespace ttrnn

@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(256) k_g2_diag_b(G2Mat m, const float* __restr
 }
 
 // ---- prep 2: merged cores -> MFMA fragments in consumption order ---------------------------------------------------------
-// head stream (bf16 x 3 planes): block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl)*3 planes * 64 lanes
+// head stream: block (wave w, unit slot ui, local k-block kbl) at ((w*UW + ui)*KBP + kbl) (forward) — the reverse stream is compact:
+// (w*bSW + ui*bNKBt + kbl), its units' live blocks back to back (bSW = the longest wave's stream padded to the slot ring)
 //   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
 //   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
 // forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag_a / _b), block stride 2 * 64 lanes; reverse: three bf16 planes
@@ -179,8 +180,10 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
-  const int blk = blockIdx.x;                    // (w*UW + ui)*KBP + kbl
-  const int kbl = blk % KBP, ui = (blk / KBP) % UW, w = blk / (KBP * UW);
+  const int blk = blockIdx.x;                    // forward: (w*UW + ui)*KBP + kbl;  reverse (compact): w*bSW + ui*bNKBt + kbl
+  const int kbl = REV ? (blk % m.bSW) % m.bNKBt : blk % KBP;
+  const int ui = REV ? (blk % m.bSW) / m.bNKBt : (blk / KBP) % UW;
+  const int w = REV ? blk / m.bSW : blk / (KBP * UW);
   const int u = w + ui * m.nw;
   xbf8 f0, f1, f2;
   xh8 g0, g1;
@@ -741,7 +744,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
                                                   const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
                                                   const float* __restrict__ bt1, float* __restrict__ dg_in,
                                                   float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0,
-                                                  float* __restrict__ dstate, unsigned* __restrict__ colmax) {
+                                                  float* __restrict__ dstate, unsigned* __restrict__ colmax,
+                                                  unsigned long long* __restrict__ diag) {
+  // (diag: -DTTRNN_ABLATIONS builds only — per-phase s_memtime stamps of the first eight workgroups, tools/diag_stamps_g2bwd.py)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
   __bf16* dyimg = reinterpret_cast<__bf16*>(smem);
@@ -796,8 +801,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     }
   }
   const int nu_w = wave < m.bU ? (m.bU - wave + NW - 1) / NW : 0;
-  const int total = nu_w * m.bKBP;
-  const xbf8* sp = bs2 + (size_t)wave * m.bUW * m.bKBP * 3 * 64 + lane;
+  const int total = (nu_w * m.bNKBt + G2_PF - 1) / G2_PF * G2_PF;      // this wave's stream: its live blocks, padded to the slot ring
+  const xbf8* sp = bs2 + (size_t)wave * m.bSW * 3 * 64 + lane;
   // RES (host: one column tile, bNKBt <= 4 and bUW * bNKBt <= G2_PF): slot s holds live block (unit s / bNKBt, k-block s % bNKBt)
   // of this wave for the whole launch; otherwise the slots roll over the wave's stream
   // (block-diagonal heads, ng > 1: a unit's live k-blocks are its gate's bNKBt, not all bNKB)
@@ -811,18 +816,55 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
       if constexpr (RES) {
         const int ui = j / m.bNKBt, kb = j - ui * m.bNKBt;
-        if (j < r_nlive) wbuf[j][p] = sp[(size_t)(ui * m.bKBP + kb) * 3 * 64 + p * 64];
+        if (j < r_nlive) wbuf[j][p] = sp[(size_t)(ui * m.bNKBt + kb) * 3 * 64 + p * 64];
       } else {
         if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
       }
     }
+  // the step's record (gates, cell / previous state, d_out) is requested one step ahead — right behind the gate phase of step t + 1, under
+  // its T2 / T1 — instead of at the head of the step that needs it (a dependent HBM / L2 round trip on every step's critical path)
+  // (four units per thread with resident head fragments: the 28 registers of a second record set spill — there the loads stay put)
+  constexpr bool PREF = UPT <= 2 || !RES;
+  f32x4 nq[UPT];
+  float na[UPT], np[UPT], nd[UPT];
+  auto load_unit = [&](const int tt, const int u) {
+    const size_t bq = b * T + tt;
+    nq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; na[u] = 0.f; np[u] = 0.f; nd[u] = 0.f;
+    if (u < upt) {
+      const int hid = tid + u * 256;
+      if (hid < H && tid < 256) {
+        if (LSTM) {
+          nq[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(bq, H, hid));
+          na[u] = reserve[res_cell((size_t)P.B * T, bq, H, hid)];
+          np[u] = tt > 0 ? reserve[res_cell((size_t)P.B * T, bq - 1, H, hid)] : (c0 ? ld(c0, b * H + hid) : 0.f);
+        } else {
+          nq[u] = *reinterpret_cast<const f32x4*>(reserve + (bq * H + hid) * 4);
+          np[u] = tt > 0 ? ld(out, (bq - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
+        }
+        if (d_out) nd[u] = ld(d_out, bq * H + hid);
+      }
+    }
+  };
+  auto load_rec = [&](const int tt) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) load_unit(tt, u);
+  };
+  if (PREF && T > 0) load_rec(T - 1);
   __syncthreads();
+#ifdef TTRNN_ABLATIONS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = stamp();
+#define G2B_STAMP(i) { const unsigned long long now_ = stamp(); seg[i] += now_ - last_; last_ = now_; }
+#else
+#define G2B_STAMP(i)
+#endif
 
   for (int t = T - 1; t >= 0; --t) {
     const size_t bt = b * T + t;
     // ---- gate gradients ------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
+      if constexpr (!PREF) load_unit(t, u);
       if (u < upt) {
         const int hid = tid + u * 256;
         if (hid < H && tid < 256) {
@@ -834,12 +876,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) dht += pt + e < m.bK1SPLIT ? pv[e] : 0.f;
           }
-          if (d_out) dht += ld(d_out, bt * H + hid);
+          dht += nd[u];
           float p[4] = {0.f, 0.f, 0.f, 0.f}, ph2 = 0.f;
           if (LSTM) {
-            const f32x4 gq = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid));
-            const float ig = gq[0], gg = gq[1], fg = gq[2], og = gq[3], cy = reserve[res_cell((size_t)P.B * T, bt, H, hid)];
-            const float cprev = t > 0 ? reserve[res_cell((size_t)P.B * T, bt - 1, H, hid)] : (c0 ? ld(c0, b * H + hid) : 0.f);
+            const f32x4 gq = nq[u];
+            const float ig = gq[0], gg = gq[1], fg = gq[2], og = gq[3], cy = na[u];
+            const float cprev = np[u];
             const float tc = ftanh(cy);
             const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
             if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = dct; }
@@ -850,9 +892,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             dcs[u] = dct * fg;
             dhd[u] = 0.f;
           } else {
-            const f32x4 gq = *reinterpret_cast<const f32x4*>(reserve + (bt * H + hid) * 4);
+            const f32x4 gq = nq[u];
             const float rg = gq[0], zg = gq[1], ng = gq[2], hn = gq[3];
-            const float hprev = t > 0 ? ld(out, (bt - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
+            const float hprev = np[u];
             if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = 0.f; }
             const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
             p[1] = dht * (hprev - ng) * zg * (1.0f - zg);
@@ -879,54 +921,74 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         }
       }
     }
+    if (PREF && t > 0) load_rec(t - 1);
+    G2B_STAMP(0)
     lds_barrier();
+    G2B_STAMP(1)
     // ---- T2: dC1 = head^T dy (split bf16 MFMA; resident / streaming instantiations as in the forward kernel) -----------------------------
     // pass: which half of dC1's i_t range (bNP == 2; else 0 and every tile is computed)
     auto stageT2 = [&](const int pass) {
-      int seq = 0;
+      // the wave's stream holds ONLY the live k-blocks of its units, back to back (unit ui, k-block kb at position ui bNKBt + kb; the
+      // tail of the last group of G2_PF is padding): with every unit padded to G2_PF blocks the shapes whose reverse contraction is
+      // short (K = I_h: 2 - 3 blocks) pulled 2.7 - 4 x their head through L2 every step — 28 TB/s at B = 512, the whole of T2's time.
+      // (unit, k-block) of a position are carried along (wave-uniform scalars); slot j of the register ring is static.
       const int nth = m.N2T / m.bNP, it0 = pass * (m.It / m.bNP);
-      for (int ui = 0; ui < nu_w; ++ui) {
-        const int tile = wave + ui * NW;
+      const int nlive = nu_w * m.bNKBt;
+      int ui = 0, kb = 0;
+      const __bf16* brow = dyimg;             // current unit: its dy rows, its store offset, its column, does this pass compute it
+      int off = -1, itc = 0;
+      bool act = false;
+      auto unit_setup = [&](const int u, const __bf16*& br, int& of, int& ic, bool& ac) {
+        const int tile = wave + u * NW;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
-        if (m.bNP > 1 && nt / nth != pass) {                    // the other half's tile: only the stream rolls on
-          for (int kbl = 0; kbl < m.bKBP; kbl += G2_PF) {
-#pragma unroll
-            for (int j = 0; j < G2_PF; ++j) {
-              int nxt = seq + G2_PF;
-              nxt -= nxt >= total ? total : 0;
-#pragma unroll
-              for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
-              ++seq;
-            }
-          }
-          continue;
-        }
+        ac = !(m.bNP > 1 && nt / nth != pass);                                           // the other half's tile: only the stream rolls on
         const int kbase = (m.ng > 1 ? (16 * mt) / m.Kg : 0) * m.bNKBt;                 // block-diagonal heads: the gate's i_h range
-        const __bf16* brow = dyimg + (16 * nt + c < m.It ? 16 * nt + c : m.It - 1) * m.IhS + 8 * q + 32 * kbase;
-        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
-        xbf8 bf[2][3];
+        br = dyimg + (16 * nt + c < m.It ? 16 * nt + c : m.It - 1) * m.IhS + 8 * q + 32 * kbase;
+        of = t2off[mt * 4 + q];
+        ic = 16 * nt + c;
+      };
+      f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+      xbf8 bf[2][3];
+      if (nlive > 0) {
+        unit_setup(0, brow, off, itc, act);
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane);
-        for (int kbl = 0; kbl < m.bKBP; kbl += G2_PF) {
+      }
+      for (int ch = 0; ch < total; ch += G2_PF) {
 #pragma unroll
-          for (int j = 0; j < G2_PF; ++j) {
-            const int kb = kbl + j;
-            if (kb + 1 < m.bNKBt) {
+        for (int j = 0; j < G2_PF; ++j) {
+          const int pos = ch + j;
+          if (pos < nlive) {
+            // the next position's dy fragments are requested before this block's MFMAs
+            const bool last = kb + 1 == m.bNKBt;
+            const __bf16* nbrow = brow;
+            int noff = off, nitc = itc;
+            bool nact = act;
+            if (pos + 1 < nlive) {
+              if (last) unit_setup(ui + 1, nbrow, noff, nitc, nact);
+              const int nkb = last ? 0 : kb + 1;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kb + 1));
+              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(nbrow + p * plane + 32 * nkb);
             }
-            if (kb < m.bNKBt) split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
-            int nxt = seq + G2_PF;
-            nxt -= nxt >= total ? total : 0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
-            ++seq;
+            if (act) {
+              split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+              if (last) {
+                if (off >= 0 && itc < m.It) *reinterpret_cast<f32x4*>(dc1 + off + (itc - it0) * m.Rp) = acc_hi + (acc_a + acc_b);
+              }
+            }
+            if (last) {
+              acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a;
+              kb = 0; ++ui;
+              brow = nbrow; off = noff; itc = nitc; act = nact;
+            } else {
+              ++kb;
+            }
           }
+          int nxt = pos + G2_PF;
+          nxt -= nxt >= total ? total : 0;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
         }
-        const f32x4 acc_lo = acc_a + acc_b;
-        const int off = t2off[mt * 4 + q];
-        const int it = 16 * nt + c;
-        if (off >= 0 && it < m.It) *reinterpret_cast<f32x4*>(dc1 + off + (it - it0) * m.Rp) = acc_hi + acc_lo;
       }
     };
     // resident: the dy fragments are the SAME for every row tile (one column tile): read once per step, then every live
@@ -975,7 +1037,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     } else {
       stageT2(0);
     }
+    G2B_STAMP(2)
     lds_barrier();
+    G2B_STAMP(3)
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
     auto stageT1 = [&](auto frag, const int pass) {
       const int ksh = m.bKS1 / m.bNP, klo = pass * ksh, khi = klo + ksh;          // this pass's k-steps (= its i_t range)
@@ -1016,7 +1080,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     };
     if (t1_lds) stageT1([&](int i) { return lt1[i]; }, 0);
     else stageT1([&](int i) { return bt1[i]; }, 0);
+    G2B_STAMP(4)
     lds_barrier();
+    G2B_STAMP(5)
     if constexpr (!RES) {
       if (m.bNP > 1) {                                      // second half of dC1's i_t range (host: the image did not fit whole)
         stageT2(1);
@@ -1027,6 +1093,13 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       }
     }
   }
+#ifdef TTRNN_ABLATIONS
+  if (diag && lane == 0 && b < 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) diag[(b * G2_NW_MAX + wave) * 8 + i] = seg[i];
+  }
+#endif
+#undef G2B_STAMP
 #pragma unroll
   for (int u = 0; u < UPT; ++u)
     if (u < upt) {
@@ -1065,7 +1138,7 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
   hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt,
                      m.ng > 1 ? device_status_ptr() : (unsigned*)nullptr);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bUW * m.bKBP), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bSW), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
     hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr);
   } else {
     float* dpart = (float*)(hdr + g2_diag_ints(m));
@@ -1290,6 +1363,7 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   if (st != TTRNN_OK) return st;
   unsigned* colmax = (stats && P.b_cmx > 0) ? reinterpret_cast<unsigned*>(stats) : nullptr;
   if (colmax && hipMemsetAsync(colmax, 0, (size_t)2 * rs.G * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  unsigned long long* diag = reinterpret_cast<unsigned long long*>((char*)ws + g2_bwd_ws_bytes(P.hid) - 4096);
   const size_t lds_b = (size_t)P.b_lds + (colmax ? P.b_cmx : 0);
   // head^T fragments register-resident: one column tile, <= 4 live k-blocks per unit (ng > 1: a unit's gate range only — the naive
   // per-gate sets of cfg2's size have ONE live block per unit, eight units per wave: streamed, they re-read eight padded blocks
@@ -1301,7 +1375,7 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_b) != TTRNN_OK) return TTRNN_ERR_LAUNCH;          \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), lds_b, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,     \
                        reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
-                       (TS*)d_c0, dstate, colmax);                                                                        \
+                       (TS*)d_c0, dstate, colmax, diag);                                                                  \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
     if (P.upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
