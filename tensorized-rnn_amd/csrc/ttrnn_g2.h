@@ -19,9 +19,12 @@ namespace ttrnn {
 constexpr int G2_NW_MAX = 8;        // waves per workgroup: 8 when every sample can own a CU (B <= #CUs: two waves per SIMD hide
 constexpr int G2_NT_MAX = G2_NW_MAX * 64;   // each other's LDS / MFMA latency on the per-step critical path), else 4 (several samples share a CU)
 constexpr int G2_PF = 8;            // head fragments in flight per wave (k-blocks of 32): ~770 matrix-pipe cycles of cover
+constexpr int G2_HUN_LDS = 1536;    // reverse kernel: head^T row scales kept in LDS up to this many rows (G2_BSL units x 8 waves x 16)
+constexpr int G2_BSL = 12;          // reverse kernel: register slots of RESIDENT head^T fragments (two fp16 pieces: 96 VGPRs)
 constexpr int G2_UPT = 4;           // hidden units per thread in the gate phase: H <= 1024
 constexpr int G2_MAX_R = 64;        // rank at the split point
 constexpr int G2_LDS_LIMIT = 160 * 1024;
+constexpr int G2_LDS_STATIC = 256;  // static __shared__ of the kernels (per-wave maxima), counted in the occupancy decisions
 
 struct G2Mat {
   int ok;
@@ -45,12 +48,13 @@ struct G2Mat {
   // planes of the h image [2][16*N1T][JS]
   int KB1, pack8, JS;
   int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
-  // reverse T2 (bf16 MFMA, split): M = Jh*Rp, N = It, K = Ih
+  // reverse T2 (f16 MFMA, two pieces per operand): M = Jh*Rp, N = It, K = Ih
   int bM2T, bNKB, bT2, bKBP, bU, bUW, bSW;         // no k split: T1 reads the complete dC1; bSW = blocks of a wave's (compact) stream
-  int IhS;                          // bf16 dy planes [16*N2T][IhS]
-  // reverse T1 (fp32 MFMA): M = Jt (one or more m tiles), N = Jh, K = It*Rp in steps of 4, split over bKS1P parts
-  int bM1T, bKS1, bT1, bK1SPLIT, bKS1P, bU1;        // bKS1P = k-steps per part
-  int K1S;                          // fp32 dC1 image [16*N1T][K1S]
+  int IhS;                          // fp16 dy planes [16*N2T][IhS]
+  // reverse T1 (f16 MFMA, two pieces per operand): M = Jt (one or more m tiles), N = Jh, K = It*Rp in blocks of 32, split over
+  // bK1SPLIT parts of bKB1P blocks
+  int bM1T, bKB1, bT1, bK1SPLIT, bKB1P, bU1;
+  int K1S;                          // row stride (halves) of the two fp16 planes of the dC1 image [2][J_h rows][K1S]
   int bNP;                          // reverse-time kernel: passes over the i_t range of dC1 (1; 2 = the image holds HALF of the columns at a time)
   // element counts of the per-launch buffers (workspace)
   long head_elems, tail_elems;      // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
@@ -137,23 +141,23 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->bUW = g2_ceil(m->bU, nw);
   m->bSW = g2_ceil(m->bUW * m->bNKBt, G2_PF) * G2_PF;
   m->IhS = 32 * m->bNKB + 16;
-  m->bM1T = g2_ceil(m->Jt, 16); m->bKS1 = (m->It * m->Rp) / 4;
+  m->bM1T = g2_ceil(m->Jt, 16); m->bKB1 = g2_ceil(m->It * m->Rp, 32);
   m->bT1 = m->bM1T * m->N1T;
   {
     int ks = 1;
-    if (m->bT1 < nw) { ks = nw / m->bT1; if (ks > m->bKS1) ks = m->bKS1; if (ks < 1) ks = 1; }
-    m->bKS1P = g2_ceil(m->bKS1, ks);
-    m->bK1SPLIT = g2_ceil(m->bKS1, m->bKS1P);
+    if (m->bT1 < nw) { ks = nw / m->bT1; if (ks > m->bKB1) ks = m->bKB1; if (ks < 1) ks = 1; }
+    m->bKB1P = g2_ceil(m->bKB1, ks);
+    m->bK1SPLIT = g2_ceil(m->bKB1, m->bKB1P);
     m->bU1 = m->bT1 * m->bK1SPLIT;
   }
-  m->K1S = m->It * m->Rp + 4;
+  m->K1S = 32 * m->bKB1 + 16;
   m->bNP = 1;
   m->head_elems = (long)m->Ih * m->Jh * m->R;
   m->tail_elems = (long)m->It * m->Jt * m->R;
   m->fs2_bytes = (long)nw * m->UW * m->KBP * 2 * 64 * 16;
   m->ft1_bytes = (long)m->M1T * m->KB1 * (m->pack8 ? 1 : 2) * 64 * 16;     // fp16 fragments (xh8 per lane), 1 or 2 planes
-  m->bs2_bytes = (long)nw * m->bSW * 3 * 64 * 16;
-  m->bt1_bytes = (long)m->bM1T * m->bKS1 * 64 * 4;
+  m->bs2_bytes = (long)nw * m->bSW * 2 * 64 * 16;      // two fp16 pieces per block
+  m->bt1_bytes = (long)m->bM1T * m->bKB1 * 2 * 64 * 16;      // two fp16 pieces per (m tile, k-block)
   m->ok = 1;
 }
 
@@ -161,11 +165,14 @@ struct G2Plan {
   int ok, okf, okb;                 // both kernels / the forward / the reverse-time kernel fit
   int cell, G, H, B, T;
   G2Mat hid;
-  int upt;                          // hidden units per thread
+  int upt;                          // hidden units per thread (forward: the first 256 threads own them)
+  int b_upt;                        // reverse kernel: every thread owns units tid + u * 64 nw
   // LDS carve-up (bytes) of the forward and the reverse-time kernel
   int f_hb, f_img, f_ybuf, f_tab, f_sc, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_sc: the inverse output scales
                                                      // [I_h | I_t] floats; f_t1: tail fragments (0: from L2)
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
+  int abl;                                     // -DTTRNN_ABLATIONS builds: option `dev` (result-destroying switches of the stamps tool); else 0
+  int b_hun;                                   // rows of the inverse-row-scale table kept in LDS (0: read from the workspace)
   int b_cmx;                                   // running column maxima of the gate gradients [G*H (+ H: GRU's hidden-side n)] floats, behind
                                                // everything else; 0 = no room (the by-product is then not offered for this shape)
 };
@@ -183,6 +190,8 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   if (rs.H > G2_UPT * 256) return;
   p->upt = g2_ceil(rs.H, 256);
   if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
+  p->b_upt = g2_ceil(rs.H, 64 * nw);
+  if (p->b_upt == 3) p->b_upt = 4;
   const G2Mat& m = p->hid;
   p->f_hb = (int)g2_al((size_t)2 * 16 * m.N1T * m.JS * 2);       // two fp16 planes of the h image
   // forward: two fp16 planes (ttrnn_split.h, flavour b) of the I_t REAL rows (stage 2 clamps its row index; the naive per-gate
@@ -195,13 +204,24 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
   p->f_lds += p->f_t1;
   // (the I_t real rows, as the forward's operand image: T2 clamps its row index)
-  p->b_dy = (int)g2_al((size_t)3 * (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.IhS * 2);
+  p->b_dy = (int)g2_al((size_t)2 * (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.IhS * 2);      // two fp16 planes
   // dC1 rows: the J_h real ones, not the 16 N1T of T1's row tiles (T1 clamps its row index; H = 768, d = 2, r = 16: 24 rows of
   // 1 028 floats = 99 KB instead of 131 — the difference between this kernel and the VALU fallback for that shape)
-  p->b_dc1 = (int)g2_al(((size_t)(m.Jh < 16 * m.N1T ? m.Jh : 16 * m.N1T) * m.K1S) * 4);
+  p->b_dc1 = (int)g2_al(((size_t)2 * (m.Jh < 16 * m.N1T ? m.Jh : 16 * m.N1T) * m.K1S) * 2);
   p->b_dh = (int)g2_al((size_t)m.bK1SPLIT * rs.H * 4);
-  p->b_tab = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4) * 4);
+  // (+ the inverse row scales of head^T, one float per row of T2, where they are few — every shape whose fragments can be resident;
+  // the 4 096 rows of a rank-64 naive set stay in L2 and are fetched a unit ahead)
+  p->b_hun = m.bM2T * 16 <= G2_HUN_LDS ? m.bM2T * 16 : 0;
+  // (+ the inverse row scales of tail^T: sixteen floats per row tile of T1)
+  p->b_tab = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4 + (size_t)m.bM1T * 16 + (size_t)p->b_hun) * 4);
   p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
+  if (p->b_hun > 0 && !(m.N2T == 1 && m.bNKBt <= 4 && m.bUW * m.bNKBt <= G2_BSL)) {
+    // streamed fragments (the resident kernel needs the table): not where the table costs a co-resident workgroup (H = 768, d = 4:
+    // 6 KB more took the four-wave workgroups from two per CU to one, 10.3 -> 10.9 ms per training step)
+    const int tab0 = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4 + (size_t)m.bM1T * 16) * 4);
+    const int lds0 = p->b_lds - p->b_tab + tab0;
+    if (G2_LDS_LIMIT / (lds0 + G2_LDS_STATIC) > G2_LDS_LIMIT / (p->b_lds + G2_LDS_STATIC)) { p->b_hun = 0; p->b_tab = tab0; p->b_lds = lds0; }
+  }
   p->b_t1 = (m.bt1_bytes <= 32 * 1024 && p->b_lds + (int)g2_al((size_t)m.bt1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.bt1_bytes) : 0;
   p->b_lds += p->b_t1;
   // the forward and the reverse-time kernel have different LDS footprints (cfg5's shape: 155 KB / 183 KB): each route is
@@ -214,13 +234,13 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
     // of its k range and adds to the partial dh.  Twice the head stream, the same products; before: BPTT on the VALU kernels
     G2Mat& mm = p->hid;
     mm.bNP = 2;
-    mm.K1S = (mm.It / 2) * mm.Rp + 4;
-    p->b_dc1 = (int)g2_al(((size_t)(mm.Jh < 16 * mm.N1T ? mm.Jh : 16 * mm.N1T) * mm.K1S) * 4);
+    mm.K1S = 32 * (mm.bKB1 / 2) + 16;               // (I_t % 32 == 0: each half is a whole number of k-blocks)
+    p->b_dc1 = (int)g2_al(((size_t)2 * (mm.Jh < 16 * mm.N1T ? mm.Jh : 16 * mm.N1T) * mm.K1S) * 2);
     p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
     p->b_t1 = (mm.bt1_bytes <= 32 * 1024 && p->b_lds + (int)g2_al((size_t)mm.bt1_bytes) <= G2_LDS_LIMIT) ? (int)g2_al((size_t)mm.bt1_bytes) : 0;
     p->b_lds += p->b_t1;
     p->okb = p->b_lds <= G2_LDS_LIMIT;
-    if (!p->okb) { mm.bNP = 1; mm.K1S = mm.It * mm.Rp + 4; }
+    if (!p->okb) { mm.bNP = 1; mm.K1S = 32 * mm.bKB1 + 16; }
   }
   // by-product of the reverse-time kernel (TTRNN_BWD_STATS_COLMAX): only where it costs no route
   p->b_cmx = (int)g2_al((size_t)(rs.G + (rs.cell == TTRNN_GRU ? 1 : 0)) * rs.H * 4);
@@ -228,7 +248,9 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   if (p->b_cmx > 0) {
     // ... and no occupancy: four-wave workgroups (B > #CUs) run two per CU where their LDS allows it — 12 KB more took
     // H = 768, d = 4 from two to one and its training step from 9.9 to 11.9 ms
-    const int w0 = G2_LDS_LIMIT / p->b_lds, w1 = G2_LDS_LIMIT / (p->b_lds + p->b_cmx);
+    // (+ the kernel's static shared words: 2 x 81 920 dynamic bytes fill the CU exactly, and the 32 bytes of the waves' maxima
+    // made it one workgroup per CU — H = 768, d = 4 again)
+    const int w0 = G2_LDS_LIMIT / (p->b_lds + G2_LDS_STATIC), w1 = G2_LDS_LIMIT / (p->b_lds + p->b_cmx + G2_LDS_STATIC);
     if (w1 < (w0 < 2 ? w0 : 2)) p->b_cmx = 0;
   }
   p->ok = p->okf && p->okb;
@@ -243,8 +265,10 @@ inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
          g2_al(g2_diag_ints(m) * sizeof(int) + (size_t)m.It * 64 * sizeof(float));
 }
 inline size_t g2_bwd_ws_bytes(const G2Mat& m) {
-  // (+ 4 KB: the diagnostic stamps of -DTTRNN_ABLATIONS builds)
-  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes) + 4096;
+  // (+ per row of head^T: inverse scale and L1 norm; per row of tail^T: inverse scale; + 4 KB: the diagnostic stamps of
+  // -DTTRNN_ABLATIONS builds)
+  return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.bs2_bytes) + g2_al((size_t)m.bt1_bytes) +
+         g2_al(((size_t)m.bM2T * 32 + (size_t)m.bM1T * 16) * 4) + 4096;
 }
 
 }  // namespace ttrnn

@@ -19,6 +19,8 @@
 // Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 with the hidden chain of
 // t3nsor/ops.py:78-93, and torch autograd through them.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
@@ -173,10 +175,12 @@ __global__ void __launch_bounds__(256) k_g2_diag_b(G2Mat m, const float* __restr
 // (w*bSW + ui*bNKBt + kbl), its units' live blocks back to back (bSW = the longest wave's stream padded to the slot ring)
 //   forward  (REV = false): MFMA row r <-> i_h = 16 mt + r,            k = 32 kb + 8 q + e <-> (j_h, a) = divmod(k, Rp)
 //   reverse  (REV = true):  MFMA row r <-> (j_h, a) = divmod(16 mt + r, Rp),  k <-> i_h
-// forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag_a / _b), block stride 2 * 64 lanes; reverse: three bf16 planes
+// forward (REV = false): TWO fp16 planes of the scaled Gh (k_g2_diag_a / _b), block stride 2 * 64 lanes
+// reverse: TWO fp16 planes as well, every ROW (j_h, a) of head^T under its own power-of-two scale (row maximum -> [2^13, 2^14): the rows
+// are T2's OUTPUT rows, the scale is undone on the accumulators: hun[row] = its inverse) — the reasoning of ttrnn_fast_f10bh.hip
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __restrict__ Gh, xbf8* __restrict__ fs,
-                                                     const int* __restrict__ hdr) {
+                                                     const int* __restrict__ hdr, float* __restrict__ hun = nullptr) {
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
@@ -185,16 +189,36 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int ui = REV ? (blk % m.bSW) / m.bNKBt : (blk / KBP) % UW;
   const int w = REV ? blk / m.bSW : blk / (KBP * UW);
   const int u = w + ui * m.nw;
-  xbf8 f0, f1, f2;
   xh8 g0, g1;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    f0[e] = (__bf16)0.f; f1[e] = (__bf16)0.f; f2[e] = (__bf16)0.f;
-    g0[e] = (_Float16)0.f; g1[e] = (_Float16)0.f;
-  }
+  for (int e = 0; e < 8; ++e) { g0[e] = (_Float16)0.f; g1[e] = (_Float16)0.f; }
+  float rsc = 1.f;                               // (REV) this lane's row scale
   if (u < U && kbl < KPER) {
     const int tile = u / KSPLIT, part = u % KSPLIT;
     const int mt = tile / m.N2T;
+    if constexpr (REV) {
+      // row maximum over i_h (zero outside the row's own gate block): the four k-groups of the lane's row share the walk
+      const int rw = 16 * mt + r;
+      int jh, a;
+      if (m.ng > 1) { const int g = rw / m.Kg, rem = rw - g * m.Kg; jh = rem / m.Rb; a = g * m.Rb + rem % m.Rb; }
+      else { jh = rw / m.Rp; a = rw % m.Rp; }
+      float mx = 0.f;
+      if (jh < m.Jh && a < m.R)
+        for (int ih = q; ih < m.Ih; ih += 4) mx = fmaxf(mx, fabsf(Gh[((size_t)ih * m.Jh + jh) * m.R + a]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int ex = g2_expo(mx);
+      rsc = ldexpf(1.f, 14 - ex);
+      if (kbl == 0 && (tile % m.N2T) == 0 && hun) {
+        // ... and the row's L1 norm (behind the inverse scales): max_row L1 x max |dg_t| bounds T2's results, the scale of T1's operand
+        float l1 = 0.f;
+        if (jh < m.Jh && a < m.R)
+          for (int ih = q; ih < m.Ih; ih += 4) l1 += fabsf(Gh[((size_t)ih * m.Jh + jh) * m.R + a]);
+        l1 += __shfl_xor(l1, 16);
+        l1 += __shfl_xor(l1, 32);
+        if (q == 0) { hun[rw] = ldexpf(1.f, ex - 14); hun[m.bM2T * 16 + rw] = l1; }
+      }
+    }
     // block-diagonal heads: a tile walks its own gate's k-blocks only (gate of a forward tile: its output rows; of a reverse
     // tile: its (g, j_h, a') rows)
     const int gate = m.ng > 1 ? (16 * mt) / (REV ? m.Kg : m.IhG) : 0;
@@ -216,9 +240,9 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
         float v = 0.f;
         if (ih < m.Ih && jh < m.Jh && a < m.R) v = Gh[((size_t)ih * m.Jh + jh) * m.R + a];
         if constexpr (REV) {
-          __bf16 p0, p1, p2;
-          split3(v, p0, p1, p2);
-          f0[e] = p0; f1[e] = p1; f2[e] = p2;
+          _Float16 p0, p1;
+          split2h(v * rsc, p0, p1);
+          g0[e] = p0; g1[e] = p1;
         } else {
           _Float16 p0, p1;                        // 2^(ep[i_h] - ev[a]) Gh (k_g2_diag_a / _b)
           if (ih < m.Ih && jh < m.Jh && a < m.R) v *= ldexpf(1.f, hdr[m.It + 64 + ih] - hdr[m.It + a]);
@@ -228,30 +252,49 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
       }
     }
   }
-  if constexpr (REV) {
-    xbf8* dst = fs + (size_t)blk * 3 * 64 + lane;
-    dst[0] = f0; dst[64] = f1; dst[128] = f2;
-  } else {
-    xh8* dst = reinterpret_cast<xh8*>(fs) + (size_t)blk * 2 * 64 + lane;
-    dst[0] = g0; dst[64] = g1;
-  }
+  xh8* dst = reinterpret_cast<xh8*>(fs) + (size_t)blk * 2 * 64 + lane;
+  dst[0] = g0; dst[64] = g1;
 }
 
 // tail fragments
 //   forward (fp16 pieces of 2^a Gt, MFMA 16x16x32 layout): lane (m = lane & 15, q = lane >> 4), row (i_t, a) = divmod(16 mt + m, Rp)
 //     general: k = 32 kb + 8 q + e <-> j_t, two planes            at ((mt*KB1 + kb)*2 + plane)*64 + lane   (xh8 units)
 //     pack8 (J_t <= 8): k-group q holds piece (q & 1) of j_t = e   at mt*64 + lane
-//   reverse (fp32, one value per lane and k-step): A[m][k] = Gt[(i_t, a) = divmod(4 ks + kq, Rp)][j_t = 16 mt + m]   at (mt*bKS1 + ks)*64 + lane
+//   reverse (two fp16 pieces of the row-scaled tail^T): A[m][k] = Gt[(i_t, a) = divmod(32 kb + 8 q + e, Rp)][j_t = 16 mt + m]
+//     at ((mt*bKB1 + kb)*2 + plane)*64 + lane   (xh8 units)
 template <bool REV>
 __global__ void __launch_bounds__(64) k_g2_tail_frag(G2Mat m, const float* __restrict__ Gt, float* __restrict__ ft,
-                                                     const int* __restrict__ hdr) {
+                                                     const int* __restrict__ hdr, float* __restrict__ tun = nullptr) {
   const int lane = threadIdx.x, mm = lane & 15, kq = lane >> 4;
   if constexpr (REV) {
-    const int ks = blockIdx.x % m.bKS1, mt = blockIdx.x / m.bKS1;
-    const int k = 4 * ks + kq, it = k / m.Rp, a = k % m.Rp, jt = 16 * mt + mm;
-    float v = 0.f;
-    if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a];
-    ft[(size_t)blockIdx.x * 64 + lane] = v;
+    // two fp16 pieces of tail^T, every row j_t under its own power-of-two scale (row maximum -> [2^13, 2^14); T1's output rows: the
+    // scale is undone on the accumulators, tun[j_t] = its inverse)
+    const int kb = blockIdx.x % m.bKB1, mt = blockIdx.x / m.bKB1;
+    const int jt = 16 * mt + mm, K = m.It * m.Rp;
+    float mx = 0.f;
+    if (jt < m.Jt)
+      for (int k = kq; k < K; k += 4) {
+        const int it = k / m.Rp, a = k - it * m.Rp;
+        if (a < m.R) mx = fmaxf(mx, fabsf(Gt[((size_t)it * m.Jt + jt) * m.R + a]));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const int ex = g2_expo(mx);
+    const float tsc = ldexpf(1.f, 14 - ex);
+    if (kb == 0 && kq == 0 && tun) tun[jt] = ldexpf(1.f, ex - 14);
+    xh8 f0, f1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * kb + 8 * kq + e, it = k / m.Rp, a = k - it * m.Rp;
+      float v = 0.f;
+      if (it < m.It && a < m.R && jt < m.Jt) v = Gt[((size_t)it * m.Jt + jt) * m.R + a] * tsc;
+      _Float16 p0, p1;
+      split2h(v, p0, p1);
+      f0[e] = p0; f1[e] = p1;
+    }
+    xh8* dst = reinterpret_cast<xh8*>(ft);
+    dst[(size_t)(blockIdx.x * 2) * 64 + lane] = f0;
+    dst[(size_t)(blockIdx.x * 2 + 1) * 64 + lane] = f1;
   } else {
     const int kb = blockIdx.x % m.KB1, mt = blockIdx.x / m.KB1;
     const int row = 16 * mt + mm, it = row / m.Rp, a = row % m.Rp;
@@ -733,6 +776,31 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     }
 }
 
+// maximum over the 64 lanes, in every lane: rotations inside the 16-lane rows (DPP), then one lane of each row — six ds_bpermute
+// round trips (__shfl_xor) were 600 cycles of the gate phase
+template <int N>
+__device__ __forceinline__ float g2_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float g2_wave_max(float v) {
+  v = fmaxf(v, g2_row_ror<1>(v));
+  v = fmaxf(v, g2_row_ror<2>(v));
+  v = fmaxf(v, g2_row_ror<4>(v));
+  v = fmaxf(v, g2_row_ror<8>(v));
+  const int i = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(i, 0)), b = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(i, 32)), d = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// the step's scale 2^(14 - e) for values < 2^e, from the bits of the maximum (biased exponent clamped to [27, 227]: the scale and its
+// inverse `un` stay normal floats; a zero maximum scales by 2^114 — zeros stay zeros)
+__device__ __forceinline__ float g2_step_scale(float mx, float& un) {
+  int eb = (int)(__float_as_uint(mx) >> 23);
+  eb = eb < 27 ? 27 : (eb > 227 ? 227 : eb);
+  un = __uint_as_float((unsigned)(eb - 13) << 23);
+  return __uint_as_float((unsigned)(267 - eb) << 23);
+}
+
 // ---- reverse time -----------------------------------------------------------------------------------------------------------
 // per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients) and
 // the split bf16 image of dy;  T2 (streamed head^T, split MFMA) -> fp32 dC1 image;  T1 (fp32 MFMA, k split over the
@@ -741,33 +809,38 @@ template <int CELL, typename TS, int UPT, bool RES>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const float* __restrict__ reserve,
                                                   const TS* __restrict__ d_out, const TS* __restrict__ d_hT,
-                                                  const TS* __restrict__ d_cT, const xbf8* __restrict__ bs2,
-                                                  const float* __restrict__ bt1, float* __restrict__ dg_in,
+                                                  const TS* __restrict__ d_cT, const xh8* __restrict__ bs2,
+                                                  const float* __restrict__ bt1, const float* __restrict__ hun,
+                                                  float* __restrict__ dg_in,
                                                   float* __restrict__ dg_hid, TS* __restrict__ d_h0, TS* __restrict__ d_c0,
                                                   float* __restrict__ dstate, unsigned* __restrict__ colmax,
                                                   unsigned long long* __restrict__ diag) {
   // (diag: -DTTRNN_ABLATIONS builds only — per-phase s_memtime stamps of the first eight workgroups, tools/diag_stamps_g2bwd.py)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const G2Mat& m = P.hid;
-  __bf16* dyimg = reinterpret_cast<__bf16*>(smem);
+  _Float16* dyimg = reinterpret_cast<_Float16*>(smem);      // two fp16 planes of 2^s dy_t (s: the step's scale), [2][I_t rows][IhS]
+  __shared__ float smax[G2_NW_MAX];                        // the waves' maxima of |dg_t| (every wave is a gate wave: unit tid + u NT)
   // by-product (colmax != NULL, P.b_cmx > 0): max_n |dg[n][c]| per column, kept per (gate, unit) in LDS by the one thread that
   // computes that column's gradient every step (no synchronisation needed), handed over with one atomicMax per column at the end:
   // rows 0 / 1 of ttrnn_rnn_backward_ex's stats (TTRNN_BWD_STATS_COLMAX) — the dense weight gradient then runs on two fp16
   // pieces at every size, without its passes over dg
   float* cmx = reinterpret_cast<float*>(smem + P.b_lds);
-  float* dc1 = reinterpret_cast<float*>(smem + P.b_dy);
+  _Float16* dc1 = reinterpret_cast<_Float16*>(smem + P.b_dy);      // two fp16 planes of 2^s2 dC1 (s2: from the step's bound), [2][J_h rows][K1S]
   float* dhb = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1);
   int* dyoff = reinterpret_cast<int*>(smem + P.b_dy + P.b_dc1 + P.b_dh);
   int* t2off = dyoff + P.G * P.H;
+  float* tunl = reinterpret_cast<float*>(t2off + m.bM2T * 4);                              // inverse row scales of tail^T [16 bM1T]
+  float* hunl = tunl + m.bM1T * 16;                                                        // inverse row scales of head^T [b_hun]
   float* lt1 = reinterpret_cast<float*>(smem + P.b_dy + P.b_dc1 + P.b_dh + P.b_tab);       // tail^T fragments (P.b_t1 > 0)
   const int plane = (m.It < 16 * m.N2T ? m.It : 16 * m.N2T) * m.IhS;      // the dy image holds its I_t real rows
+  const int planeC = (m.Jh < 16 * m.N1T ? m.Jh : 16 * m.N1T) * m.K1S;     // ... the dC1 image its J_h real rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   const int NW = m.nw, NT = NW * 64;
   const size_t b = blockIdx.x;
-  const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
+  const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.b_upt;
   constexpr bool LSTM = CELL == TTRNN_LSTM;
   constexpr int NG = LSTM ? 4 : 3;
 
@@ -785,16 +858,31 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     else { jh = m2 / m.Rp; a = m2 - jh * m.Rp; }
     t2off[e] = (jh < m.Jh && a < m.Rp) ? jh * m.K1S + a : -1;
   }
+  const bool hl = P.b_hun > 0;
+  for (int e = tid; e < P.b_hun; e += NT) hunl[e] = hun[e];
+  for (int e = tid; e < m.bM1T * 16; e += NT) tunl[e] = hun[m.bM2T * 32 + e];
+  if (tid < G2_NW_MAX) smax[tid] = 0.f;
   const bool t1_lds = P.b_t1 > 0;
   if (t1_lds)
-    for (int e = tid; e < m.bM1T * m.bKS1 * 64; e += NT) lt1[e] = bt1[e];
+    for (int e = tid; e < m.bM1T * m.bKB1 * 2 * 64 * 4; e += NT) lt1[e] = bt1[e];      // (xh8 fragments, copied as floats)
+  // bound of T2's results: |dC1[row][.]| <= L1(row of head^T) max|dg_t|.  The largest row norm, once per launch
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int e = tid; e < m.bM2T * 16; e += NT) l = fmaxf(l, hun[m.bM2T * 16 + e]);
+    l = g2_wave_max(l);
+    __syncthreads();
+    if (lane == 0) smax[wave] = l;
+    __syncthreads();
+    maxl1 = fmaxf(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])), fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7])));
+  }
   float dhd[UPT], dcs[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
     dhd[u] = 0.f; dcs[u] = 0.f;
     if (u < upt) {
-      const int hid = tid + u * 256;
-      if (hid < H && tid < 256) {
+      const int hid = tid + u * NT;
+      if (hid < H) {
         dhd[u] = d_hT ? ld(d_hT, b * H + hid) : 0.f;      // carried dh that does not come through the chain
         dcs[u] = (LSTM && d_cT) ? ld(d_cT, b * H + hid) : 0.f;
       }
@@ -802,23 +890,23 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   }
   const int nu_w = wave < m.bU ? (m.bU - wave + NW - 1) / NW : 0;
   const int total = (nu_w * m.bNKBt + G2_PF - 1) / G2_PF * G2_PF;      // this wave's stream: its live blocks, padded to the slot ring
-  const xbf8* sp = bs2 + (size_t)wave * m.bSW * 3 * 64 + lane;
+  const xh8* sp = bs2 + (size_t)wave * m.bSW * 2 * 64 + lane;
   // RES (host: one column tile, bNKBt <= 4 and bUW * bNKBt <= G2_PF): slot s holds live block (unit s / bNKBt, k-block s % bNKBt)
   // of this wave for the whole launch; otherwise the slots roll over the wave's stream
   // (block-diagonal heads, ng > 1: a unit's live k-blocks are its gate's bNKBt, not all bNKB)
   const int r_nlive = RES ? nu_w * m.bNKBt : 0;
-  xbf8 wbuf[G2_PF][3];
+  constexpr int NSL = RES ? G2_BSL : G2_PF;      // resident: twelve slots; the rolling stream: a ring of G2_PF
+  xh8 wbuf[NSL][2];
 #pragma unroll
-  for (int j = 0; j < G2_PF; ++j)
+  for (int j = 0; j < NSL; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (__bf16)0.f;
+      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (_Float16)0.f;
       if constexpr (RES) {
-        const int ui = j / m.bNKBt, kb = j - ui * m.bNKBt;
-        if (j < r_nlive) wbuf[j][p] = sp[(size_t)(ui * m.bNKBt + kb) * 3 * 64 + p * 64];
+        if (j < r_nlive) wbuf[j][p] = sp[(size_t)j * 2 * 64 + p * 64];
       } else {
-        if (total > 0) wbuf[j][p] = sp[(size_t)j * 3 * 64 + p * 64];
+        if (total > 0) wbuf[j][p] = sp[(size_t)j * 2 * 64 + p * 64];
       }
     }
   // the step's record (gates, cell / previous state, d_out) is requested one step ahead — right behind the gate phase of step t + 1, under
@@ -827,29 +915,40 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
   constexpr bool PREF = UPT <= 2 || !RES;
   f32x4 nq[UPT];
   float na[UPT], np[UPT], nd[UPT];
-  auto load_unit = [&](const int tt, const int u) {
-    const size_t bq = b * T + tt;
-    nq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; na[u] = 0.f; np[u] = 0.f; nd[u] = 0.f;
-    if (u < upt) {
-      const int hid = tid + u * 256;
-      if (hid < H && tid < 256) {
-        if (LSTM) {
-          nq[u] = *reinterpret_cast<const f32x4*>(reserve + res_gate(bq, H, hid));
-          na[u] = reserve[res_cell((size_t)P.B * T, bq, H, hid)];
-          np[u] = tt > 0 ? reserve[res_cell((size_t)P.B * T, bq - 1, H, hid)] : (c0 ? ld(c0, b * H + hid) : 0.f);
-        } else {
-          nq[u] = *reinterpret_cast<const f32x4*>(reserve + (bq * H + hid) * 4);
-          np[u] = tt > 0 ? ld(out, (bq - 1) * H + hid) : (h0 ? ld(h0, b * H + hid) : 0.f);
-        }
-        if (d_out) nd[u] = ld(d_out, bq * H + hid);
-      }
+#ifdef TTRNN_ABLATIONS
+  const int abl = P.abl;      // 8: no d_gates stores, 16: no record loads, 32: no column maxima, 64: no dh partial-sum reads
+#else
+  constexpr int abl = 0;
+#endif
+  // No lane-divergent branch around the loads: a load inside a divergent region is merged with the register's other value at the join,
+  // and the compiler waits for it THERE — vmcnt(0) right behind the request, 1 900 of 4 800 cycles of the GRU gate phase at H = 512.
+  // Lanes (and unit slots) without a unit read unit 0's record; a null d_out reads the reserve and is scaled by zero.
+  const float dsc = d_out ? 1.f : 0.f;
+  // (b T + t) H, carried from step to step: the 64-bit products of the row index were nineteen scalar multiplies per step
+  size_t rH = T > 0 ? (b * T + (T - 1)) * (size_t)H : 0;
+  const size_t cellb = (size_t)P.B * T * H * 4;             // the cells follow the gate records in the reserve (res_cell)
+  auto load_unit = [&](const int tt, const size_t rq, const int u) {      // rq = (b T + tt) H
+    const int hid0 = tid + u * NT;
+    const int hid = (u < upt && hid0 < H) ? hid0 : 0;
+    if (abl & 16) { nq[u] = f32x4{0.f, 0.f, 0.f, 0.f}; na[u] = 0.f; np[u] = 0.f; nd[u] = 0.f; return; }
+    if (LSTM) {
+      nq[u] = *reinterpret_cast<const f32x4*>(reserve + (rq + hid) * 4);          // res_gate
+      na[u] = reserve[cellb + rq + hid];                                           // res_cell
+      if (tt > 0) np[u] = reserve[cellb + rq - H + hid];      // (wave-uniform branches)
+      else np[u] = c0 ? ld(c0, b * H + hid) : 0.f;
+    } else {
+      nq[u] = *reinterpret_cast<const f32x4*>(reserve + (rq + hid) * 4);
+      na[u] = 0.f;
+      if (tt > 0) np[u] = ld(out, rq - H + hid);
+      else np[u] = h0 ? ld(h0, b * H + hid) : 0.f;
     }
+    nd[u] = d_out ? ld(d_out, rq + hid) * dsc : 0.f;
   };
-  auto load_rec = [&](const int tt) {
+  auto load_rec = [&](const int tt, const size_t rq) {
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) load_unit(tt, u);
+    for (int u = 0; u < UPT; ++u) load_unit(tt, rq, u);
   };
-  if (PREF && T > 0) load_rec(T - 1);
+  if (PREF && T > 0) load_rec(T - 1, rH);
   __syncthreads();
 #ifdef TTRNN_ABLATIONS
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -860,16 +959,24 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #endif
 
   for (int t = T - 1; t >= 0; --t) {
-    const size_t bt = b * T + t;
     // ---- gate gradients ------------------------------------------------------------------------------------------------------------
+    // vmcnt(0), said once and unconditionally: the record requested a step ago has long arrived, but the compiler cannot know (its
+    // consumers sit in a lane-divergent region) and would otherwise wait before the NEXT request overwrites the registers — behind
+    // this step's d_gates stores, i.e. for their completion (ISA of the GRU instantiation: s_waitcnt vmcnt(0) between stores and loads)
+    if constexpr (PREF) __builtin_amdgcn_s_waitcnt(0x0F70);
+    G2B_STAMP(6)      // (diagnostic builds: the wait for the record, if any)
+    float pk[UPT][4];                                         // the hidden-side gate gradients of this thread's units
+    float tmx = 0.f;
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
-      if constexpr (!PREF) load_unit(t, u);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pk[u][g] = 0.f;
+      if constexpr (!PREF) load_unit(t, rH, u);
       if (u < upt) {
-        const int hid = tid + u * 256;
-        if (hid < H && tid < 256) {
+        const int hid = tid + u * NT;
+        if (hid < H) {
           float dht = dhd[u];
-          for (int pt = 0; pt < m.bK1SPLIT; pt += 4) {        // up to four partial sums per trip, reads issued together
+          for (int pt = 0; pt < ((abl & 64) ? 0 : m.bK1SPLIT); pt += 4) {        // up to four partial sums per trip, reads issued together
             float pv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) pv[e] = dhb[(pt + e < m.bK1SPLIT ? pt + e : pt) * H + hid];
@@ -884,7 +991,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             const float cprev = np[u];
             const float tc = ftanh(cy);
             const float dct = dcs[u] + dht * og * (1.0f - tc * tc);
-            if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = dct; }
+            if (dstate) { dstate[(rH + hid) * 2] = dht; dstate[(rH + hid) * 2 + 1] = dct; }
             p[0] = dct * gg * ig * (1.0f - ig);
             p[1] = dct * cprev * fg * (1.0f - fg);
             p[2] = dct * ig * (1.0f - gg * gg);
@@ -895,7 +1002,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             const f32x4 gq = nq[u];
             const float rg = gq[0], zg = gq[1], ng = gq[2], hn = gq[3];
             const float hprev = np[u];
-            if (dstate) { dstate[(bt * H + hid) * 2] = dht; dstate[(bt * H + hid) * 2 + 1] = 0.f; }
+            if (dstate) { dstate[(rH + hid) * 2] = dht; dstate[(rH + hid) * 2 + 1] = 0.f; }
             const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
             p[1] = dht * (hprev - ng) * zg * (1.0f - zg);
             p[0] = dn_pre * hn * rg * (1.0f - rg);
@@ -903,25 +1010,51 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             ph2 = dn_pre * rg;                              // w.r.t. the hidden part of n (inside the r * (...) product)
             dhd[u] = dht * zg;
           }
-          if (colmax) {
+          if (colmax && !(abl & 32)) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) cmx[g * H + hid] = fmaxf(cmx[g * H + hid], fabsf(p[g]));
             if (!LSTM) cmx[NG * H + hid] = fmaxf(cmx[NG * H + hid], fabsf(ph2));
           }
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            dg_in[bt * GH + g * H + hid] = p[g];
+            if (!(abl & 8)) dg_in[rH * NG + g * H + hid] = p[g];
             const float ph = (!LSTM && g == 2) ? ph2 : p[g];
-            if (!LSTM) dg_hid[bt * GH + g * H + hid] = ph;
-            __bf16 s0, s1, s2;
-            split3(ph, s0, s1, s2);
-            const int off = dyoff[g * H + hid];
-            dyimg[off] = s0; dyimg[plane + off] = s1; dyimg[2 * plane + off] = s2;
+            if (!LSTM && !(abl & 8)) dg_hid[rH * NG + g * H + hid] = ph;
+            pk[u][g] = ph;
+            tmx = fmaxf(tmx, fabsf(ph));
           }
         }
       }
     }
-    if (PREF && t > 0) load_rec(t - 1);
+    if (PREF && t > 0) load_rec(t - 1, rH - H);
+    // the step's operand scale from the EXACT maximum of |dg_t| (the gate waves' maxima cross a barrier of their own), then every
+    // owner splits its values into the two fp16 planes: 2^s dy_t with the maximum in [2^13, 2^14) — ttrnn_fast_f10bh.hip's scheme
+    tmx = g2_wave_max(tmx);
+    if (lane == 0) smax[wave] = tmx;
+    G2B_STAMP(7)      // (diagnostic builds: gate math + stores + record request, before the maxima cross)
+    lds_barrier();
+    float ust2;          // T2's accumulators -> T1's operand: undo the step's scale, apply 2^s2 (from the bound maxl1 max|dg_t|: cannot overflow)
+    float u2;            // inverse of 2^s2, applied where T1's accumulators are stored
+    {
+      const float mxg = fmaxf(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])), fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7])));
+      float ustep;
+      const float sg = g2_step_scale(mxg, ustep);
+      ust2 = ustep * g2_step_scale(mxg * maxl1, u2);
+#pragma unroll
+      for (int u = 0; u < UPT; ++u)
+        if (u < upt) {
+          const int hid = tid + u * NT;
+          if (hid < H) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              _Float16 s0, s1;
+              split2h(pk[u][g] * sg, s0, s1);
+              const int off = dyoff[g * H + hid];
+              dyimg[off] = s0; dyimg[plane + off] = s1;
+            }
+          }
+        }
+    }
     G2B_STAMP(0)
     lds_barrier();
     G2B_STAMP(1)
@@ -935,10 +1068,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       const int nth = m.N2T / m.bNP, it0 = pass * (m.It / m.bNP);
       const int nlive = nu_w * m.bNKBt;
       int ui = 0, kb = 0;
-      const __bf16* brow = dyimg;             // current unit: its dy rows, its store offset, its column, does this pass compute it
+      const _Float16* brow = dyimg;           // current unit: its dy rows, its store offset, its column, does this pass compute it
       int off = -1, itc = 0;
       bool act = false;
-      auto unit_setup = [&](const int u, const __bf16*& br, int& of, int& ic, bool& ac) {
+      auto unit_setup = [&](const int u, const _Float16*& br, int& of, int& ic, bool& ac, int& rw) {
         const int tile = wave + u * NW;
         const int mt = tile / m.N2T, nt = tile - mt * m.N2T;
         ac = !(m.bNP > 1 && nt / nth != pass);                                           // the other half's tile: only the stream rolls on
@@ -946,13 +1079,17 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         br = dyimg + (16 * nt + c < m.It ? 16 * nt + c : m.It - 1) * m.IhS + 8 * q + 32 * kbase;
         of = t2off[mt * 4 + q];
         ic = 16 * nt + c;
+        rw = 16 * mt + 4 * q;
       };
-      f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
-      xbf8 bf[2][3];
+      int row0 = 0;                           // first of the lane's four T2 rows (their inverse scales: hunl, or fetched a unit ahead)
+      f32x4 cun = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+      xh8 bf[2][2];
       if (nlive > 0) {
-        unit_setup(0, brow, off, itc, act);
+        unit_setup(0, brow, off, itc, act, row0);
+        if (!hl) cun = *reinterpret_cast<const f32x4*>(hun + row0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[0][p] = *reinterpret_cast<const xbf8*>(brow + p * plane);
+        for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(brow + p * plane);
       }
       for (int ch = 0; ch < total; ch += G2_PF) {
 #pragma unroll
@@ -961,25 +1098,30 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
           if (pos < nlive) {
             // the next position's dy fragments are requested before this block's MFMAs
             const bool last = kb + 1 == m.bNKBt;
-            const __bf16* nbrow = brow;
-            int noff = off, nitc = itc;
+            const _Float16* nbrow = brow;
+            int noff = off, nitc = itc, nrow0 = row0;
             bool nact = act;
+            f32x4 nun = cun;
             if (pos + 1 < nlive) {
-              if (last) unit_setup(ui + 1, nbrow, noff, nitc, nact);
+              if (last) {
+                unit_setup(ui + 1, nbrow, noff, nitc, nact, nrow0);
+                if (!hl) nun = *reinterpret_cast<const f32x4*>(hun + nrow0);
+              }
               const int nkb = last ? 0 : kb + 1;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xbf8*>(nbrow + p * plane + 32 * nkb);
+              for (int p = 0; p < 2; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xh8*>(nbrow + p * plane + 32 * nkb);
             }
             if (act) {
-              split_block(wbuf[j], bf[j & 1], acc_a, acc_b, acc_hi);
+              split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
               if (last) {
-                if (off >= 0 && itc < m.It) *reinterpret_cast<f32x4*>(dc1 + off + (itc - it0) * m.Rp) = acc_hi + (acc_a + acc_b);
+                const f32x4 un = (hl ? *reinterpret_cast<const f32x4*>(hunl + row0) : cun) * ust2;
+                if (off >= 0 && itc < m.It) store_split4_h(dc1, planeC, off + (itc - it0) * m.Rp, (acc_hi + acc_lo) * un);
               }
             }
             if (last) {
-              acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a;
+              acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi = acc_lo;
               kb = 0; ++ui;
-              brow = nbrow; off = noff; itc = nitc; act = nact;
+              brow = nbrow; off = noff; itc = nitc; act = nact; row0 = nrow0; cun = nun;
             } else {
               ++kb;
             }
@@ -987,7 +1129,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
           int nxt = pos + G2_PF;
           nxt -= nxt >= total ? total : 0;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) wbuf[j][p] = sp[(size_t)nxt * 3 * 64 + p * 64];
+          for (int p = 0; p < 2; ++p) wbuf[j][p] = sp[(size_t)nxt * 2 * 64 + p * 64];
         }
       }
     };
@@ -996,35 +1138,35 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     // inside each instantiation of the body (slot -> k-block must index registers statically).
     auto stageT2res = [&](auto nkb_tag) {
       constexpr int NKB = decltype(nkb_tag)::value;             // live k-blocks per unit (= bNKBt)
-      const __bf16* brow = dyimg + (c < m.It ? c : m.It - 1) * m.IhS + 8 * q;
-      xbf8 bfr[NKB][3];
+      const _Float16* brow = dyimg + (c < m.It ? c : m.It - 1) * m.IhS + 8 * q;
+      xh8 bfr[NKB][2];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bfr[kb][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * kb);
-      f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_hi = acc_a;
+        for (int p = 0; p < 2; ++p) bfr[kb][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kb);
+      f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
 #pragma unroll
-      for (int sl = 0; sl < G2_PF; ++sl) {
-        constexpr int dummy = 0;
-        (void)dummy;
+      for (int sl = 0; sl < NSL; ++sl) {
         const int ui = sl / NKB, kb = sl % NKB;
         if (sl < r_nlive) {
           if (kb == 0) {
-            acc_a = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b = acc_a; acc_hi = acc_a;
+            acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi = acc_lo;
             if (m.ng > 1) {
               // block-diagonal heads: this unit (row tile wave + ui NW of gate g) multiplies its own gate's i_h range of dy
               const int kbase = ((16 * (wave + ui * NW)) / m.Kg) * m.bNKBt;
 #pragma unroll
               for (int k2 = 0; k2 < NKB; ++k2)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                  bfr[k2][p] = *reinterpret_cast<const xbf8*>(brow + p * plane + 32 * (kbase + k2));
+                for (int p = 0; p < 2; ++p)
+                  bfr[k2][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * (kbase + k2));
             }
           }
-          split_block(wbuf[sl], bfr[kb], acc_a, acc_b, acc_hi);
+          split_block_h(wbuf[sl], bfr[kb], acc_lo, acc_hi);
           if (kb == NKB - 1) {
-            const int off = t2off[(wave + ui * NW) * 4 + q];
-            if (off >= 0 && c < m.It) *reinterpret_cast<f32x4*>(dc1 + off + c * m.Rp) = acc_hi + (acc_a + acc_b);
+            const int mt = wave + ui * NW;
+            const int off = t2off[mt * 4 + q];
+            const f32x4 un = *reinterpret_cast<const f32x4*>(hunl + 16 * mt + 4 * q) * ust2;
+            if (off >= 0 && c < m.It) store_split4_h(dc1, planeC, off + c * m.Rp, (acc_hi + acc_lo) * un);
           }
         }
       }
@@ -1041,33 +1183,29 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     lds_barrier();
     G2B_STAMP(3)
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
-    auto stageT1 = [&](auto frag, const int pass) {
-      const int ksh = m.bKS1 / m.bNP, klo = pass * ksh, khi = klo + ksh;          // this pass's k-steps (= its i_t range)
+    auto stageT1 = [&](auto frag, const int pass) {      // frag(i): fragment i of tail^T, from LDS or from L2 (two instantiations)
+      const int kbh = m.bKB1 / m.bNP, klo = pass * kbh, khi = klo + kbh;          // this pass's k-blocks (= its i_t range)
       for (int u1 = wave; u1 < m.bU1; u1 += NW) {
         const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
         const int mt = tile / m.N1T, nt = tile - mt * m.N1T;
-        int k0 = part * m.bKS1P;
-        int k1 = k0 + m.bKS1P < m.bKS1 ? k0 + m.bKS1P : m.bKS1;
+        int k0 = part * m.bKB1P;
+        int k1 = k0 + m.bKB1P < m.bKB1 ? k0 + m.bKB1P : m.bKB1;
         k0 = k0 > klo ? k0 : klo;
         k1 = k1 < khi ? k1 : khi;
         const int jrow = 16 * nt + c;                                  // rows past J_h: any real row (their results are dropped)
-        const float* bp = dc1 + (jrow < m.Jh ? jrow : m.Jh - 1) * m.K1S + q;
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        const int fbase = mt * m.bKS1 * 64 + lane;
-        for (int ks0 = k0; ks0 < k1; ks0 += 8) {               // eight k-steps' operands in flight, two accumulator chains
-          float wv[8], xv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int ks = ks0 + e < k1 ? ks0 + e : k1 - 1;
-            wv[e] = frag(fbase + ks * 64); xv[e] = bp[4 * (ks - klo)];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            if (ks0 + e < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[e], acc0, 0, 0, 0);
-            if (ks0 + e + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e + 1], xv[e + 1], acc1, 0, 0, 0);
-          }
+        const _Float16* bp = dc1 + (jrow < m.Jh ? jrow : m.Jh - 1) * m.K1S + 8 * q - 32 * klo;
+        const int fb = mt * m.bKB1 * 2 * 64 + lane;
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        for (int kb = k0; kb < k1; kb += 2) {                    // two k-blocks' operands in flight
+          const int kc = kb + 1 < k1 ? kb + 1 : kb;
+          xh8 wa[2] = {frag(fb + kb * 2 * 64), frag(fb + kb * 2 * 64 + 64)};
+          xh8 wb[2] = {frag(fb + kc * 2 * 64), frag(fb + kc * 2 * 64 + 64)};
+          xh8 xa[2] = {*reinterpret_cast<const xh8*>(bp + 32 * kb), *reinterpret_cast<const xh8*>(bp + planeC + 32 * kb)};
+          xh8 xb[2] = {*reinterpret_cast<const xh8*>(bp + 32 * kc), *reinterpret_cast<const xh8*>(bp + planeC + 32 * kc)};
+          split_block_h(wa, xa, acc_lo, acc_hi);
+          if (kb + 1 < k1) split_block_h(wb, xb, acc_lo, acc_hi);
         }
-        const f32x4 acc = acc0 + acc1;
+        const f32x4 acc = (acc_hi + acc_lo) * (*reinterpret_cast<const f32x4*>(tunl + 16 * mt + 4 * q) * u2);
         const int jh = 16 * nt + c;
         if (jh < m.Jh) {
 #pragma unroll
@@ -1078,8 +1216,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         }
       }
     };
-    if (t1_lds) stageT1([&](int i) { return lt1[i]; }, 0);
-    else stageT1([&](int i) { return bt1[i]; }, 0);
+    if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, 0);
+    else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, 0);
     G2B_STAMP(4)
     lds_barrier();
     G2B_STAMP(5)
@@ -1087,11 +1225,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       if (m.bNP > 1) {                                      // second half of dC1's i_t range (host: the image did not fit whole)
         stageT2(1);
         lds_barrier();
-        if (t1_lds) stageT1([&](int i) { return lt1[i]; }, 1);
-        else stageT1([&](int i) { return bt1[i]; }, 1);
+        if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, 1);
+        else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, 1);
         lds_barrier();
       }
     }
+    rH -= H;
   }
 #ifdef TTRNN_ABLATIONS
   if (diag && lane == 0 && b < 8) {
@@ -1103,8 +1242,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
   for (int u = 0; u < UPT; ++u)
     if (u < upt) {
-      const int hid = tid + u * 256;
-      if (hid < H && tid < 256) {
+      const int hid = tid + u * NT;
+      if (hid < H) {
         float dht = dhd[u];
         for (int pt = 0; pt < m.bK1SPLIT; ++pt) dht += dhb[pt * H + hid];
         if (d_h0) st(d_h0, b * H + hid, dht);
@@ -1127,19 +1266,23 @@ int check() { return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUN
 // merged cores + fragments of one TT-matrix into ws: [Gh | Gt | head stream | tail fragments]
 // hdr_out: forward only (per-block maxima of the merged cores for the fp16 scales)
 int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* ws, const xbf8** fs, const float** ft,
-         hipStream_t stream, const int** hdr_out = nullptr) {
+         hipStream_t stream, const int** hdr_out = nullptr, const float** hun_out = nullptr) {
   char* p = (char*)ws;
   float* Gh = (float*)p; p += g2_al((size_t)m.head_elems * 4);
   float* Gt = (float*)p; p += g2_al((size_t)m.tail_elems * 4);
   xbf8* hs = (xbf8*)p; p += g2_al((size_t)(rev ? m.bs2_bytes : m.fs2_bytes));
   float* tf = (float*)p; p += g2_al((size_t)(rev ? m.bt1_bytes : m.ft1_bytes));
   int* hdr = (int*)p;                         // forward only (g2_fwd_ws_bytes): exponents of the diagonal scales
+  float* hun = (float*)p;                     // reverse only (g2_bwd_ws_bytes): head^T rows' inverse scales [16 bM2T], their L1 norms
+                                              // [16 bM2T], tail^T rows' inverse scales [16 bM1T]
   const int nblk = (int)g2_merge_blocks(m);
   hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)nblk), dim3(256), 0, stream, s, m, packed, Gh, Gt,
                      m.ng > 1 ? device_status_ptr() : (unsigned*)nullptr);
   if (rev) {
-    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bSW), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr);
-    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKS1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr);
+    hipLaunchKernelGGL(k_g2_head_frag<true>, dim3(m.nw * m.bSW), dim3(64), 0, stream, m, Gh, hs, (const int*)nullptr, hun);
+    if (hun_out) *hun_out = hun;
+    hipLaunchKernelGGL(k_g2_tail_frag<true>, dim3(m.bM1T * m.bKB1), dim3(64), 0, stream, m, Gt, tf, (const int*)nullptr,
+                       hun + m.bM2T * 32);
   } else {
     float* dpart = (float*)(hdr + g2_diag_ints(m));
     hipLaunchKernelGGL(k_g2_diag_a, dim3(m.It), dim3(256), 0, stream, m, (const float*)Gt, hdr, dpart);
@@ -1173,8 +1316,22 @@ static bool g2_fwd_res16(const G2Plan& p) {
          !opt(OPT_DIAG) && !(opt(OPT_DEV) & 4096);       // (dev bit 12: A/B switch, the streamed kernel as before)
 }
 
+// reverse: every wave's head^T fragments stay in registers (one column tile, at most four live k-blocks per unit, G2_BSL slots)
+static bool g2_bwd_res(const G2Plan& p) {
+  return p.hid.ok && p.okb && p.b_hun > 0 && p.hid.N2T == 1 && p.hid.bNKBt <= 4 && p.hid.bUW * p.hid.bNKBt <= G2_BSL &&
+         !(opt(OPT_DEV) & 2048 && p.hid.ng > 1);
+}
+
 static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
   const bool wide = rs.B <= device_cu_count();
+  if (!wide && backward && !(opt(OPT_DEV) & 4096)) {
+    // the same trade in the reverse kernel: eight-wave workgroups with the head^T fragments resident (two rounds) instead of two
+    // co-resident four-wave workgroups that stream them from L2 every step
+    G2Plan q4, q8;
+    g2_plan(&q4, rs, false);
+    g2_plan(&q8, rs, true);
+    if (g2_bwd_res(q8) && !g2_bwd_res(q4)) { *p = q8; return; }
+  }
   if (!wide && !backward) {
     // more samples than CUs: four-wave workgroups share a CU and hide each other's latencies — unless the eight-wave plan keeps
     // the head core in registers where the four-wave plan streams it from L2 every step (two rounds of one-sample-per-CU
@@ -1358,8 +1515,8 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
                  const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
                  void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* dstate, float* stats) {
   const xbf8* bs2;
-  const float* bt1;
-  int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream);
+  const float *bt1, *hun = nullptr;
+  int st = prep(rs.hid_s, P.hid, true, packed_hid, ws, &bs2, &bt1, stream, nullptr, &hun);
   if (st != TTRNN_OK) return st;
   unsigned* colmax = (stats && P.b_cmx > 0) ? reinterpret_cast<unsigned*>(stats) : nullptr;
   if (colmax && hipMemsetAsync(colmax, 0, (size_t)2 * rs.G * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
@@ -1368,25 +1525,39 @@ static int bwd_t(const RnnShape& rs, const G2Plan& P, const void* out, const voi
   // head^T fragments register-resident: one column tile, <= 4 live k-blocks per unit (ng > 1: a unit's gate range only — the naive
   // per-gate sets of cfg2's size have ONE live block per unit, eight units per wave: streamed, they re-read eight padded blocks
   // per unit from L2 every step, 10.6 ms of a 14 ms training step)
-  const bool res = P.hid.N2T == 1 && P.hid.bNKBt <= 4 && P.hid.bUW * P.hid.bNKBt <= G2_PF && !(opt(OPT_DEV) & 2048 && P.hid.ng > 1);
+  const bool res = g2_bwd_res(P);
+#ifdef TTRNN_ABLATIONS
+  G2Plan Pa = P;
+  Pa.abl = opt(OPT_DEV) & (8 | 16 | 32 | 64);
+  if (getenv("TTRNN_G2_PLAN"))
+    fprintf(stderr, "g2 bwd plan: nw %d s %d It %d Jt %d Ih %d Jh %d R %d ng %d | bM2T %d N2T %d bNKBt %d bUW %d bSW %d | bM1T %d N1T %d bKB1 %d bK1SPLIT %d | "
+            "lds dy %d dc1 %d dh %d tab %d (hun %d) t1 %d cmx %d = %d | upt %d res %d\n", P.hid.nw, P.hid.s, P.hid.It, P.hid.Jt, P.hid.Ih,
+            P.hid.Jh, P.hid.R, P.hid.ng, P.hid.bM2T, P.hid.N2T, P.hid.bNKBt, P.hid.bUW, P.hid.bSW, P.hid.bM1T, P.hid.N1T, P.hid.bKB1,
+            P.hid.bK1SPLIT, P.b_dy, P.b_dc1, P.b_dh, P.b_tab, P.b_hun, P.b_t1, P.b_cmx, P.b_lds, P.b_upt, (int)res);
+#define P Pa
+#endif
 #define TT_G2_BWD(CELLV, UPTV, SLOT)                                                                                      \
   do {                                                                                                                   \
     auto kern = res ? k_g2_bwd<CELLV, TS, UPTV, true> : k_g2_bwd<CELLV, TS, UPTV, false>;                                \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_b) != TTRNN_OK) return TTRNN_ERR_LAUNCH;          \
     hipLaunchKernelGGL(kern, dim3(rs.B), dim3(P.hid.nw * 64), lds_b, stream, P, (const TS*)out, (const TS*)h0, (const TS*)c0,     \
-                       reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, bs2, bt1, dg_in, dg_hid, (TS*)d_h0,   \
+                       reserve, (const TS*)d_out, (const TS*)d_hT, (const TS*)d_cT, reinterpret_cast<const xh8*>(bs2), bt1,    \
+                       hun, dg_in, dg_hid, (TS*)d_h0,                                                                        \
                        (TS*)d_c0, dstate, colmax, diag);                                                                  \
   } while (0)
   if (rs.cell == TTRNN_LSTM) {
-    if (P.upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
-    else if (P.upt == 2) TT_G2_BWD(TTRNN_LSTM, 2, 1);
+    if (P.b_upt == 1) TT_G2_BWD(TTRNN_LSTM, 1, 0);
+    else if (P.b_upt == 2) TT_G2_BWD(TTRNN_LSTM, 2, 1);
     else TT_G2_BWD(TTRNN_LSTM, 4, 2);
   } else {
-    if (P.upt == 1) TT_G2_BWD(TTRNN_GRU, 1, 0);
-    else if (P.upt == 2) TT_G2_BWD(TTRNN_GRU, 2, 1);
+    if (P.b_upt == 1) TT_G2_BWD(TTRNN_GRU, 1, 0);
+    else if (P.b_upt == 2) TT_G2_BWD(TTRNN_GRU, 2, 1);
     else TT_G2_BWD(TTRNN_GRU, 4, 2);
   }
 #undef TT_G2_BWD
+#ifdef TTRNN_ABLATIONS
+#undef P
+#endif
   return check();
 }
 

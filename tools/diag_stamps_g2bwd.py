@@ -41,7 +41,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 buf = next(t for n, t in seen if n == bws)
 raw = buf.view(torch.uint8)[bws - 4096:bws].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
-names = ["G gates", "barrier1", "T2 mma", "barrier2", "T1 mma", "barrier3"]
+names = ["max+split", "barrier1", "T2 mma", "barrier2", "T1 mma", "barrier3", "record wait", "gate math"]
 per_step = raw.astype(np.float64) / a.seq_len
 print("cycles per step (mean over 8 blocks), per wave:")
 for w in range(8):
