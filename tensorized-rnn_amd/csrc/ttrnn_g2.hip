@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     lds_barrier();
     G2B_STAMP(3)
     // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
-    auto stageT1 = [&](auto frag, const int pass) {      // frag(i): fragment i of tail^T, from LDS or from L2 (two instantiations)
+    auto stageT1 = [&](auto frag, auto depth, const int pass) {      // frag(i): fragment i of tail^T, from LDS or from L2 (two instantiations)
       const int kbh = m.bKB1 / m.bNP, klo = pass * kbh, khi = klo + kbh;          // this pass's k-blocks (= its i_t range)
       for (int u1 = wave; u1 < m.bU1; u1 += NW) {
         const int tile = u1 / m.bK1SPLIT, part = u1 - tile * m.bK1SPLIT;
@@ -1196,14 +1196,20 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const _Float16* bp = dc1 + (jrow < m.Jh ? jrow : m.Jh - 1) * m.K1S + 8 * q - 32 * klo;
         const int fb = mt * m.bKB1 * 2 * 64 + lane;
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-        for (int kb = k0; kb < k1; kb += 2) {                    // two k-blocks' operands in flight
-          const int kc = kb + 1 < k1 ? kb + 1 : kb;
-          xh8 wa[2] = {frag(fb + kb * 2 * 64), frag(fb + kb * 2 * 64 + 64)};
-          xh8 wb[2] = {frag(fb + kc * 2 * 64), frag(fb + kc * 2 * 64 + 64)};
-          xh8 xa[2] = {*reinterpret_cast<const xh8*>(bp + 32 * kb), *reinterpret_cast<const xh8*>(bp + planeC + 32 * kb)};
-          xh8 xb[2] = {*reinterpret_cast<const xh8*>(bp + 32 * kc), *reinterpret_cast<const xh8*>(bp + planeC + 32 * kc)};
-          split_block_h(wa, xa, acc_lo, acc_hi);
-          if (kb + 1 < k1) split_block_h(wb, xb, acc_lo, acc_hi);
+        // DEPTH k-blocks' operands in flight: two where the fragments sit in LDS, four where they come from L2 (H = 768, d = 4: 96 KB of
+        // tail^T, sixteen blocks per tile at two in flight = eight L2 round trips per step, 11 000 of the step's 32 000 cycles)
+        constexpr int DEPTH = decltype(depth)::value;
+        for (int kb = k0; kb < k1; kb += DEPTH) {
+          xh8 wf[DEPTH][2], xf[DEPTH][2];
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d) {
+            const int kc = kb + d < k1 ? kb + d : k1 - 1;
+            wf[d][0] = frag(fb + kc * 2 * 64); wf[d][1] = frag(fb + kc * 2 * 64 + 64);
+            xf[d][0] = *reinterpret_cast<const xh8*>(bp + 32 * kc); xf[d][1] = *reinterpret_cast<const xh8*>(bp + planeC + 32 * kc);
+          }
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d)
+            if (kb + d < k1) split_block_h(wf[d], xf[d], acc_lo, acc_hi);
         }
         const f32x4 acc = (acc_hi + acc_lo) * (*reinterpret_cast<const f32x4*>(tunl + 16 * mt + 4 * q) * u2);
         const int jh = 16 * nt + c;
@@ -1216,8 +1222,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         }
       }
     };
-    if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, 0);
-    else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, 0);
+    if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, std::integral_constant<int, 2>{}, 0);
+    else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, std::integral_constant<int, RES ? 2 : 4>{}, 0);
     G2B_STAMP(4)
     lds_barrier();
     G2B_STAMP(5)
@@ -1225,8 +1231,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
       if (m.bNP > 1) {                                      // second half of dC1's i_t range (host: the image did not fit whole)
         stageT2(1);
         lds_barrier();
-        if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, 1);
-        else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, 1);
+        if (t1_lds) stageT1([&](int i) { return reinterpret_cast<const xh8*>(lt1)[i]; }, std::integral_constant<int, 2>{}, 1);
+        else stageT1([&](int i) { return reinterpret_cast<const xh8*>(bt1)[i]; }, std::integral_constant<int, RES ? 2 : 4>{}, 1);
         lds_barrier();
       }
     }

@@ -2856,3 +2856,108 @@ def test_wave_local_reverse_kernel_h256(rank, inp):
         assert torch.equal(got[n], again[n]), n
         assert float(got[n][[2, 77, 298]].abs().max()) == 0.0, n        # samples outside the loss
     assert not torch.equal(got["h0"], wide["h0"])                  # a different kernel did run
+
+
+# ---- (18) runtime-shape reverse-time kernel on two fp16 pieces (ttrnn_g2.hip: k_g2_bwd) --------------------------------------------------
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only", "outlier_core0", "outlier_last", "many_samples"])
+@pytest.mark.parametrize("meta", [
+    dict(kind="ttgru", input_size=40, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8),        # head^T resident (twelve slots)
+    dict(kind="ttlstm", input_size=40, hidden_size=768, num_layers=1, n_cores=4, tt_rank=8),       # streamed, several units per thread
+], ids=lambda m: "{kind}-H{hidden_size}-d{n_cores}-r{tt_rank}".format(**m))
+def test_runtime_reverse_kernel_ranges(meta, case):
+    """Both transposed stages of the runtime-shape tier's reverse-time kernel multiply two fp16 pieces per operand (round 4: three bf16
+    pieces / the fp32 MFMA before): the merged cores' rows under power-of-two row scales, every step's gate gradients under the scale of
+    their exact maximum, T2's results under the bound L1(row) x max|dg_t| (the scheme of ttrnn_fast_f10bh.hip).  Output gradients over
+    ten decades, steps and samples without gradient, a loss on the last step only, one core entry x 1e3, more samples than CUs (the
+    other workgroup plan): every parameter / input / initial-state gradient against the float64 oracle (torch autograd through
+    lstm.py:23-32,123-133 / gru.py:38-44 and t3nsor/ops.py:78-93) within 2e-5 of each tensor's maximum; repeat runs bit for bit.
+    An outlier entry makes the problem itself ill-conditioned in fp32 (x 1e5: the any-shape fp32 kernels of `exact` mode miss the
+    float64 forward by 6e-4 and the gradients by 6e-3): there the yardstick is `exact` mode on the same inputs.  (Block-diagonal
+    heads — naive per-gate sets — have their gradient test in test_naive_per_gate_sets_run_on_the_fused_path.)"""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    from ttrnn_hip import functional as F
+    torch.manual_seed(241)
+    H, inp = meta["hidden_size"], meta["input_size"]
+    lstm = meta["kind"] == "ttlstm"
+    m = build_module(meta, dev())
+    B = 300 if case == "many_samples" else 5
+    T = 40 if case == "last_step_only" else (4 if case == "many_samples" else 9)
+    if case.startswith("outlier"):
+        cores = [p for n, p in m.named_parameters() if "hidden_weights" in n and p.dim() > 1]
+        core = cores[0] if case == "outlier_core0" else cores[-1]
+        with torch.no_grad():
+            flat = core.detach().clone().contiguous().view(-1)
+            flat[(5 * flat.numel()) // 11] *= 1e3
+            core.copy_(flat.view(core.shape))
+    x = torch.randn(B, T, inp)
+    h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    rows = list(range(B)) if B <= 8 else [0, 1, B // 2, B - 1]
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r, c0r = (t[rows].double().clone().requires_grad_(True) for t in (x, h0, c0))
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    if lstm:
+        ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r))
+        ((ro * w[rows].double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+    else:
+        ro, rh = O.gru_forward(layers, xr, h0r)
+        ((ro * w[rows].double()).sum() + wsum * 0.5 * rh.sum()).backward()
+    mask = torch.zeros(B, 1)
+    mask[rows] = 1.0
+
+    def run():
+        m.zero_grad()
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (x, h0, c0))
+        md = mask.to(dev())
+        if lstm:
+            out, (hT, cT) = m(xg, (h0g, c0g))
+            loss = (out * (w * mask.unsqueeze(-1)).to(dev())).sum() + wsum * ((cT * md).sum() + 0.5 * (hT * md).sum())
+        else:
+            out, hT = m(xg, h0g)
+            loss = (out * (w * mask.unsqueeze(-1)).to(dev())).sum() + wsum * 0.5 * (hT * md).sum()
+        loss.backward()
+        got = {"x": xg.grad.clone(), "h0": h0g.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+        if lstm:
+            got["c0"] = c0g.grad.clone()
+        return got
+
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
+    got, again = run(), run()
+    refs = {"x": xr.grad, "h0": h0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    if lstm:
+        refs["c0"] = c0r.grad
+    def worst_of(res):
+        wv = 0.0
+        for n, ref in refs.items():
+            sc = max(float(ref.abs().max()), 1e-30)
+            assert torch.isfinite(res[n]).all(), n
+            g = res[n][rows] if n in ("x", "h0", "c0") else res[n]
+            wv = max(wv, _maxabs(g.double(), ref) / sc)
+        return wv
+    worst = worst_of(got)
+    for n in ("h0", "x"):
+        assert torch.equal(got[n], again[n]), n
+    if case == "sparse_steps":
+        assert float(got["h0"][2].abs().max()) == 0.0
+    if case == "last_step_only":
+        rel = _maxabs(got["h0"].double(), h0r.grad) / max(float(h0r.grad.abs().max()), 1e-300)
+        print("d_h0 after 40 steps: max |ref| %.3g, relative error %.3g" % (float(h0r.grad.abs().max()), rel))
+        assert rel <= 1e-4
+    print(meta["kind"], H, case, "max gradient error relative to each tensor's maximum: %.3g" % worst)
+    if case.startswith("outlier"):
+        with ttrnn_hip.fp32_math("exact"):
+            exact = worst_of(run())
+        print("   exact mode on the same inputs: %.3g" % exact)
+        assert worst <= max(10.0 * exact, 2e-5) and worst <= 5e-3
+    else:
+        assert worst <= 2e-5
