@@ -966,6 +966,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     if constexpr (PREF) __builtin_amdgcn_s_waitcnt(0x0F70);
     G2B_STAMP(6)      // (diagnostic builds: the wait for the record, if any)
     float pk[UPT][4];                                         // the hidden-side gate gradients of this thread's units
+    // the gate phase's LDS reads (partial dh sums, running column maxima, image offsets) go out together at the head of a unit: read one
+    // by one where they are used they were sixteen dependent round trips of the phase's 3 500 cycles
+    constexpr bool OFFR = UPT == 1 || (!RES && UPT == 2);       // the image offsets stay in registers until the split (where there is room)
+    int dof[OFFR ? UPT : 1][4];
     float tmx = 0.f;
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
@@ -976,6 +980,19 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         const int hid = tid + u * NT;
         if (hid < H) {
           float dht = dhd[u];
+          float cmv[NG + 1];
+#pragma unroll
+          for (int g = 0; g <= NG; ++g) cmv[g] = 0.f;
+          const bool cm_on = colmax && !(abl & 32);
+          if (cm_on) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) cmv[g] = cmx[g * H + hid];
+            if (!LSTM) cmv[NG] = cmx[NG * H + hid];
+          }
+          if constexpr (OFFR) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) dof[u][g] = dyoff[g * H + hid];
+          }
           for (int pt = 0; pt < ((abl & 64) ? 0 : m.bK1SPLIT); pt += 4) {        // up to four partial sums per trip, reads issued together
             float pv[4];
 #pragma unroll
@@ -1010,10 +1027,10 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             ph2 = dn_pre * rg;                              // w.r.t. the hidden part of n (inside the r * (...) product)
             dhd[u] = dht * zg;
           }
-          if (colmax && !(abl & 32)) {
+          if (cm_on) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) cmx[g * H + hid] = fmaxf(cmx[g * H + hid], fabsf(p[g]));
-            if (!LSTM) cmx[NG * H + hid] = fmaxf(cmx[NG * H + hid], fabsf(ph2));
+            for (int g = 0; g < NG; ++g) cmx[g * H + hid] = fmaxf(cmv[g], fabsf(p[g]));
+            if (!LSTM) cmx[NG * H + hid] = fmaxf(cmv[NG], fabsf(ph2));
           }
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
@@ -1049,7 +1066,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
             for (int g = 0; g < NG; ++g) {
               _Float16 s0, s1;
               split2h(pk[u][g] * sg, s0, s1);
-              const int off = dyoff[g * H + hid];
+              int off;
+              if constexpr (OFFR) off = dof[u][g];
+              else off = dyoff[g * H + hid];
               dyimg[off] = s0; dyimg[plane + off] = s1;
             }
           }
