@@ -1059,8 +1059,8 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
     // one wave per 64 hidden units, T2 wave-local, two barriers per step: where two of its four-wave workgroups share a CU
     // (B > #CUs; cfg4: 586 -> 526 us per layer) and at H = 512 (eight waves either way).  One sample per CU at H = 256 stays on
     // the eight-wave kernel, whose phases are shorter than the four barriers cost (cfg2: 2 851 against 3 301 cycles per step).
-    // Option dev bit 15: the eight-wave kernel everywhere
-    const bool local = F10BL<S>::NWV == 8 || rs.B > device_cu_count();
+    // Option dev bit 15: the eight-wave kernel everywhere; bit 7: this kernel everywhere (A/B, the stamps of lesson 51)
+    const bool local = F10BL<S>::NWV == 8 || rs.B > device_cu_count() || (opt(OPT_DEV) & 128);
     if (local && !(opt(OPT_DEV) & 32768)) {
       constexpr size_t ldsl = f10bl_lds_bytes<S>();
       static_assert(ldsl <= 64 * 1024, "raise the dynamic LDS limit for this shape");

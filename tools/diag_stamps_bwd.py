@@ -42,7 +42,7 @@ raw = buf.view(torch.uint8)[off:off + 8 * 8 * 8 * 8].cpu().numpy().view(np.uint6
 # TTRNN_GEMM_PIECES=3: the three-bf16-piece kernel (6 segments); default: the two-piece fp16 kernel (8 segments)
 if os.environ.get("TTRNN_GEMM_PIECES") == "3":
     names = ["G gates", "barrier1", "T01 mma+split", "barrier2", "T2 mma", "barrier3"]
-elif int(os.environ.get("TTRNN_DEV", "0")) & 32768:
+elif raw[:, :4, 6:].sum() > 0:      # k_lstm_bwd_f10h: eight waves, four barriers (one sample per CU at H = 256; dev bit 15)
     names = ["G gates", "barrier1", "split", "barrier1b", "T01 mma", "barrier2", "T2 mma", "barrier3"]
 else:      # k_lstm_bwd_f10l: one wave per 64 units (waves 4-7 exist at H = 512 only), T2 wave-local
     names = ["G gates", "barrier1", "split", "barrier2", "T01 mma", "T2 mma"]
