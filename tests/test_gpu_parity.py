@@ -2961,3 +2961,53 @@ def test_runtime_reverse_kernel_ranges(meta, case):
         assert worst <= max(10.0 * exact, 2e-5) and worst <= 5e-3
     else:
         assert worst <= 2e-5
+
+
+# ---- (19) the round-4 reverse-time kernels at the corners -------------------------------------------------------------------------------
+@pytest.mark.parametrize("meta", [
+    dict(kind="ttlstm", input_size=40, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8),       # fused core, one wave per 64 units
+    dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),        # fused core, eight-wave kernel
+    dict(kind="ttgru", input_size=40, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8),        # runtime tier, resident fragments
+    dict(kind="ttlstm", input_size=40, hidden_size=768, num_layers=1, n_cores=4, tt_rank=8),       # runtime tier, streamed fragments
+    dict(kind="ttgru", input_size=40, hidden_size=96, num_layers=1, n_cores=2, tt_rank=3),         # runtime tier, padded rank, H < 128
+], ids=lambda m: "{kind}-H{hidden_size}-d{n_cores}-r{tt_rank}".format(**m))
+def test_reverse_kernels_edge_cases_vs_oracle(meta):
+    """B = 1, T = 1 ... 4 (the rotating record registers of the fused-core kernels, the one-step-ahead record request of the runtime
+    tier's: first and last steps are their special cases), explicit and absent initial state, a loss that uses the final states only:
+    every gradient against the float64 oracle (autograd through lstm.py:101-135 / gru.py:101-130)."""
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(307)
+    H, inp = meta["hidden_size"], meta["input_size"]
+    lstm = meta["kind"] == "ttlstm"
+    m = build_module(meta, dev())
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    for B, T, with_init, final_only in [(1, 1, False, False), (1, 2, True, False), (3, 1, True, True), (2, 3, False, False),
+                                        (2, 4, True, True), (5, 7, True, False)]:
+        x = torch.randn(B, T, inp)
+        h0, c0 = torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3
+        w = torch.zeros(B, T, H) if final_only else torch.randn(B, T, H)
+        layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+        xr, h0r, c0r = (t.double().clone().requires_grad_(True) for t in (x, h0, c0))
+        if lstm:
+            ro, (rh, rc) = O.lstm_forward(layers, xr, (h0r, c0r) if with_init else None)
+            ((ro * w.double()).sum() + rc.sum() + 0.5 * rh.sum()).backward()
+        else:
+            ro, rh = O.gru_forward(layers, xr, h0r if with_init else None)
+            ((ro * w.double()).sum() + 0.5 * rh.sum()).backward()
+        m.zero_grad()
+        xg, h0g, c0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (x, h0, c0))
+        if lstm:
+            out, (hT, cT) = m(xg, (h0g, c0g) if with_init else None)
+            ((out * w.to(dev())).sum() + cT.sum() + 0.5 * hT.sum()).backward()
+        else:
+            out, hT = m(xg, h0g if with_init else None)
+            ((out * w.to(dev())).sum() + 0.5 * hT.sum()).backward()
+        assert _maxabs(out.detach(), ro.detach()) <= 1e-5, (B, T)
+        refs = {"x": (xg.grad, xr.grad), **{n: (p.grad, leaves[n].grad) for n, p in m.named_parameters()}}
+        if with_init:
+            refs["h0"] = (h0g.grad, h0r.grad)
+            if lstm:
+                refs["c0"] = (c0g.grad, c0r.grad)
+        for n, (g, ref) in refs.items():
+            assert g is not None and torch.isfinite(g).all(), (n, B, T)
+            assert _maxabs(g.double(), ref) <= 2e-5 * max(float(ref.abs().max()), 1e-30), (n, B, T, with_init, final_only)
