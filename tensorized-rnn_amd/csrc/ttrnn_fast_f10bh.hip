@@ -363,14 +363,6 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
       if (own) {
         // o = gate*H + hid = m*I2 + i2  ->  m = MPG*gate + hid/I2, i2 = hid%I2: the 4 gates are k = 4*(hid/I2) .. +3
         store_split4_h(img1h, PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), pkeep * sg);
-        // record(t-2), d_out(t-2), x(t-2): requested HERE, behind the gate phase's chain (their address arithmetic is thirty
-        // instructions the head of the step does not have to wait for), consumed two steps from now.  Always four loads, no
-        // branch (index clamped; a null d_out / x reads the reserve and is scaled by zero)
-        const size_t b2 = t > 1 ? bt - 2 : b * T;
-        fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
-        fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
-        dout_f = dptr[b2 * H + hid];
-        x_f = xptr[b2];
       }
       if (ALLG || !own) {                                         // (H = 256: waves 4-7) the fp32 row goes out to HBM meanwhile
         const int i4 = ALLG ? tid : tid - H;
@@ -382,6 +374,16 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     TT_STAMP(2)
     lds_barrier();
     TT_STAMP(3)
+    if (own) {
+      // record(t-2), d_out(t-2), x(t-2): requested HERE, under T01's MFMAs (the gate waves reach T01's barrier 180 cycles before
+      // waves 4-7: their thirty instructions of address arithmetic cost the split phase 150 cycles and T01 nothing), consumed two
+      // steps from now.  Always four loads, no branch (index clamped; a null d_out / x reads the reserve and is scaled by zero)
+      const size_t b2 = t > 1 ? bt - 2 : b * T;
+      fa = *reinterpret_cast<const f32x4*>(reserve + res_gate(b2, H, hid));
+      fb = reserve[res_cell((size_t)Bn * T, b2, H, hid)];
+      dout_f = dptr[b2 * H + hid];
+      x_f = xptr[b2];
+    }
     // ---- T01: dC2 = W10 dg, rescaled for T2 and split into its operand image ------------------------------------------------
     {
       if constexpr (B::XF >= 4) {
