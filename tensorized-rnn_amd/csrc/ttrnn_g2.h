@@ -165,8 +165,8 @@ struct G2Plan {
   int ok, okf, okb;                 // both kernels / the forward / the reverse-time kernel fit
   int cell, G, H, B, T;
   G2Mat hid;
-  int upt;                          // hidden units per thread (forward: the first 256 threads own them)
-  int b_upt;                        // reverse kernel: every thread owns units tid + u * 64 nw
+  int upt;                          // hidden units per thread: every thread owns units tid + u * 64 nw
+  int b_upt;                        // (= upt)
   // LDS carve-up (bytes) of the forward and the reverse-time kernel
   int f_hb, f_img, f_ybuf, f_tab, f_sc, f_t1, f_lds; // f_tab: stage-1 store offsets [T1][4] ints; f_sc: the inverse output scales
                                                      // [I_h | I_t] floats; f_t1: tail fragments (0: from L2)
@@ -186,12 +186,11 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
   const int nw = wide ? G2_NW_MAX : 4;
   g2_plan_mat(&p->hid, rs.hid_s, nw, rs.hid_blocks);
   if (!p->hid.ok) return;
-  // the gate phase runs on the first 256 threads (1, 2 or 4 hidden units per thread)
+  // the gate phases run on every thread: unit tid + u * 64 nw (1, 2 or 4 hidden units per thread)
   if (rs.H > G2_UPT * 256) return;
-  p->upt = g2_ceil(rs.H, 256);
+  p->upt = g2_ceil(rs.H, 64 * nw);
   if (p->upt == 3) p->upt = 4;                 // kernels are instantiated for 1, 2, 4 units per thread
-  p->b_upt = g2_ceil(rs.H, 64 * nw);
-  if (p->b_upt == 3) p->b_upt = 4;
+  p->b_upt = p->upt;
   const G2Mat& m = p->hid;
   p->f_hb = (int)g2_al((size_t)2 * 16 * m.N1T * m.JS * 2);       // two fp16 planes of the h image
   // forward: two fp16 planes (ttrnn_split.h, flavour b) of the I_t REAL rows (stage 2 clamps its row index; the naive per-gate

@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     hst[u] = 0.f; cst[u] = 0.f; hoff[u] = 0;
     gi[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bb[u] = gi[u];
     if (u < upt) {
-      const int hid = tid + u * 256;
-      if (hid < H && tid < 256) {
+      const int hid = tid + u * NT;
+      if (hid < H) {
         hoff[u] = (hid / m.Jt) * m.JS + hid % m.Jt;
         hst[u] = h0 ? ld(h0, b * H + hid) : 0.f;
         cst[u] = (LSTM && c0) ? ld(c0, b * H + hid) : 0.f;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     h0un = ldexpf(1.f, e0);
 #pragma unroll
     for (int u = 0; u < UPT; ++u)
-      if (u < upt && tid + u * 256 < H && tid < 256) {
+      if (u < upt && tid + u * NT < H) {
         _Float16 p0, p1;
         split2h(hst[u] * (h0sc * G2_HSC), p0, p1);
         hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
@@ -701,8 +701,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
       if (u < upt) {
-        const int hid = tid + u * 256;
-        if (hid < H && tid < 256) {
+        const int hid = tid + u * NT;
+        if (hid < H) {
           float y[4] = {0.f, 0.f, 0.f, 0.f};
           for (int pt = 0; pt < m.KSPLIT; pt += 2) {           // two partial sums per trip: all reads issued before the adds
             const int p1 = pt + 1 < m.KSPLIT ? pt + 1 : pt;
@@ -747,10 +747,18 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
             split2h(hy * (LSTM ? G2_HSC : G2_HSC * h0sc), p0, p1);
             hb[hoff[u]] = p0; hb[HPL + hoff[u]] = p1;
           }
-          // gate inputs of the NEXT step: requested after this step's last use of the registers and after its stores, used a
-          // whole step later (no wait ever lands on a request just issued; the address is clamped, the load unconditional)
-          if (!in1) gi[u] = gin4[(t + 1 < T ? bt + 1 : bt) * H + hid];
         }
+      }
+    }
+    // gate inputs of the NEXT step: requested after the last unit's use of the registers and after the step's stores, used a whole step
+    // later.  No lane-divergent region and no other unit's math behind the request (lesson 53: inside `if (hid < H)`, with two
+    // units per thread, the second unit's first use of its own gin waited — vmcnt(0) — for the first unit's request just issued)
+    if (!in1) {
+      const size_t bn = (t + 1 < T ? bt + 1 : bt) * H;
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int hid0 = tid + u * NT;
+        gi[u] = gin4[bn + ((u < upt && hid0 < H) ? hid0 : 0)];
       }
     }
     if (in1) xq.advance(xs, b * T, T, t, lane);
@@ -768,8 +776,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 #pragma unroll
   for (int u = 0; u < UPT; ++u)
     if (u < upt) {
-      const int hid = tid + u * 256;
-      if (hid < H && tid < 256) {
+      const int hid = tid + u * NT;
+      if (hid < H) {
         if (hT) st(hT, b * H + hid, hst[u]);
         if (LSTM && cT) st(cT, b * H + hid, cst[u]);
       }
