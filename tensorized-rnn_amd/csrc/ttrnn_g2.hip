@@ -4,17 +4,20 @@
 // (ttrnn_generic.hip): every (hidden_size, ncores, ttrank, new_core) the reference's experiment flags can produce
 // (pmnist_test.py:47-56, params_model.py) runs its time loop on the matrix cores.
 //
-// Arithmetic: fp32-class whatever the storage type.  The big stage (stage 2 / T2) takes its fp32 operands as three bf16
-// pieces on v_mfma_f32_16x16x32_bf16 (ttrnn_split.h: six terms, fp32 accumulation); the small stage (stage 1 / T1,
-// contraction over the last mode(s) only) runs on v_mfma_f32_16x16x4_f32 straight from fp32 LDS images, so the forward
-// splits only the stage-1 result and the reverse only the gate gradients.
+// Arithmetic: fp32-class whatever the storage type: every product of both stages, in both directions, is the three-term product of
+// two fp16 pieces per operand on v_mfma_f32_16x16x32_f16 with fp32 accumulation (ttrnn_split.h), each operand under exact
+// power-of-two scales — the merged cores per row / per rank slice (prep kernels, once per launch), h under 2^9 (|h| < 1), the
+// reverse kernel's gate gradients under the scale of the step's exact maximum and its intermediate dC1 under the bound
+// L1(row) x max|dg_t| (the scheme of ttrnn_fast_f10bh.hip).  (Rounds 2 - 3: three bf16 pieces in the big stage, the fp32 MFMA in
+// the small one.)
 //
-// Data movement: one workgroup of 4 waves per sample for all T steps, h / c in registers, all intermediates in LDS.
-// The merged head core does not fit registers for runtime shapes, so each wave STREAMS its fragments from L2 every step —
-// written by the prep kernel in exactly the order the wave consumes them (coalesced 16-byte loads), G2_PF k-blocks in
-// flight through rolling register slots; the loads of step t+1 are issued while step t still multiplies, so the stream
-// never waits on the recurrence.  LDS per workgroup stays small (cfg2-like shapes: ~40 KB), several samples share a CU
-// when B > #CUs and hide each other's barriers.
+// Data movement: one workgroup of 4 or 8 waves per sample for all T steps, h / c in registers, all intermediates in LDS.
+// A wave's fragments of the merged head core stay in registers where they fit (forward: 8 or 16 slots, reverse: 12) — the
+// eight-wave plan is preferred where only it makes them fit — and are otherwise STREAMED from L2 every step, written by the prep
+// kernel in exactly the order the wave consumes them (coalesced 16-byte loads; the reverse stream holds a unit's live k-blocks
+// only), G2_PF k-blocks in flight through rolling register slots; the loads of step t+1 are issued while step t still
+// multiplies.  Every thread owns hidden units tid + u * 64 nw in the gate phases; the per-step records / gate inputs are requested
+// a step ahead, outside any lane-divergent region (DESIGN.md lesson 53).  Several samples share a CU when B > #CUs.
 //
 // Replaces, for one layer: tensorized_rnn/lstm.py:23-32,123-133 / gru.py:33-44,124-134 with the hidden chain of
 // t3nsor/ops.py:78-93, and torch autograd through them.
@@ -352,17 +355,6 @@ struct HeadStream {
 };
 
 
-// one 16x16x32 block of the six-term split product on THREE accumulator chains (a: w2x0 w0x2 w1x1, b: w1x0 w0x1, hi: w0x0),
-// issued round-robin so that no MFMA waits for the one before it (a dependent 8-pass MFMA stalls ~2x its issue time)
-__device__ __forceinline__ void split_block(const xbf8 (&w)[3], const xbf8 (&x)[3], f32x4& acc_a, f32x4& acc_b, f32x4& acc_hi) {
-  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], acc_a, 0, 0, 0);
-  acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], acc_b, 0, 0, 0);
-  acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc_hi, 0, 0, 0);
-  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], acc_a, 0, 0, 0);
-  acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], acc_b, 0, 0, 0);
-  acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc_a, 0, 0, 0);
-}
-
 // the three-term product of two-piece fp16 operands on two chains (lo: w1x0 + w0x1, hi: w0x0)
 __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[2], f32x4& acc_lo, f32x4& acc_hi) {
   acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], x[0], acc_lo, 0, 0, 0);
@@ -538,7 +530,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
   for (int t = 0; t < T; ++t) {
     const size_t bt = b * T + t;
     // gate inputs of this step: requested now, used after both stages
-    // ---- stage 1 (fp32 MFMA): C1 = Gt h, split into the three bf16 planes of stage 2's operand ------------------------------
+    // ---- stage 1 (two fp16 pieces): C1 = Gt h, split into the two fp16 planes of stage 2's operand ---------------------------
     // (tail fragments: LDS-resident or from L1 / L2 — two explicit loops: ONE pointer that may be either makes every read a
     // FLAT load, and a flat load can only be waited for with vmcnt(0): it then waits for the `out` stores of the last step)
     auto pair = [&](auto frag, int fa, int fb, const _Float16* bpa, const _Float16* bpb, int offa, int offb) {
@@ -594,7 +586,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
-    // ---- stage 2 (split bf16 MFMA) -------------------------------------------------------------------------------------------------
+    // ---- stage 2 (two fp16 pieces per operand) ---------------------------------------------------------------------------------
     // Two instantiations of the same body: RESIDENT (the wave's whole share of the head core sits in its register slots:
     // NO vector-memory instruction in the loop) and streaming (every slot is refilled unconditionally right after its use,
     // padding blocks included).  A CONDITIONAL refill makes hipcc guard every block with s_waitcnt vmcnt(0), which also
@@ -810,8 +802,9 @@ __device__ __forceinline__ float g2_step_scale(float mx, float& un) {
 }
 
 // ---- reverse time -----------------------------------------------------------------------------------------------------------
-// per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients) and
-// the split bf16 image of dy;  T2 (streamed head^T, split MFMA) -> fp32 dC1 image;  T1 (fp32 MFMA, k split over the
+// per step (t = T-1 .. 0): gate gradients (one hidden unit per thread and slot) -> dg rows (HBM, for the weight gradients), the
+// waves' maxima cross a barrier, the values are split into the two fp16 planes of dy under the step's scale;  T2 (resident or
+// streamed head^T, three-term product) -> two fp16 planes of dC1 under the bound's scale;  T1 (tail^T, k-blocks split over the
 // waves when there are few tiles) -> partial dh vectors summed by the next gate phase.
 template <int CELL, typename TS, int UPT, bool RES>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __restrict__ out, const TS* __restrict__ h0,
@@ -1085,7 +1078,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     G2B_STAMP(0)
     lds_barrier();
     G2B_STAMP(1)
-    // ---- T2: dC1 = head^T dy (split bf16 MFMA; resident / streaming instantiations as in the forward kernel) -----------------------------
+    // ---- T2: dC1 = head^T dy (two fp16 pieces per operand; resident / streaming instantiations as in the forward kernel) ---------------
     // pass: which half of dC1's i_t range (bNP == 2; else 0 and every tile is computed)
     auto stageT2 = [&](const int pass) {
       // the wave's stream holds ONLY the live k-blocks of its units, back to back (unit ui, k-block kb at position ui bNKBt + kb; the
@@ -1209,7 +1202,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
     G2B_STAMP(2)
     lds_barrier();
     G2B_STAMP(3)
-    // ---- T1: dh = tail^T dC1 (fp32 MFMA) ------------------------------------------------------------------------------------------------
+    // ---- T1: dh = tail^T dC1 (two fp16 pieces per operand) ------------------------------------------------------------------------------
     auto stageT1 = [&](auto frag, auto depth, const int pass) {      // frag(i): fragment i of tail^T, from LDS or from L2 (two instantiations)
       const int kbh = m.bKB1 / m.bNP, klo = pass * kbh, khi = klo + kbh;          // this pass's k-blocks (= its i_t range)
       for (int u1 = wave; u1 < m.bU1; u1 += NW) {
