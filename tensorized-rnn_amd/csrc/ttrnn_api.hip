@@ -256,7 +256,7 @@ static GenDense gen_dense(const TtShape& s) {
   if (!g.ok) return g;
   g.dx_ok = gemm_split_ok(s.out_size, s.in_size);
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  g.lin_bwd = al(plan_ttlinear_bwd(s, s.in_size).ws_bytes);
+  g.lin_bwd = al(plan_ttlinear_bwd(s, s.in_size, true).ws_bytes);
   g.ident = gemm_split_identity_bytes(s.in_size);
   g.dwd = gemm_split_dense_bytes(s.in_size, s.out_size);
   g.wd = g.dx_ok ? gemm_split_dense_bytes(s.in_size, s.out_size) : 0;
@@ -498,7 +498,7 @@ static int lin_backward(const ttrnn_ttm* w, int dtype, int dy_dtype, int64_t n_r
       if (gd.proj > 0) {
         st = launch_proj3(s, packed, dWd, d_packed, (char*)lin_fwd + gd.lin_fwd, sm);
       } else {
-        const LinPlan pb = plan_ttlinear_bwd(s, s.in_size);
+        const LinPlan pb = plan_ttlinear_bwd(s, s.in_size, true);      // fixed-order sums: no atomics in the pull-back
         st = launch_ttlinear_bwd(s, pb, TTRNN_F32, TTRNN_F32, s.in_size, packed, ident, dWd, nullptr, d_packed, nullptr, lin_bwd, sm);
       }
     }

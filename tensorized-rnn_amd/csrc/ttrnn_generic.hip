@@ -247,7 +247,7 @@ template <typename T, typename TDY, bool BUF_GLOBAL, int ACC>
 __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_rows, int nb, int bs, int ss,
                                                          const float* packed, const T* x, const TDY* dy, T* dx,
                                                          float* d_packed, float* d_bias, float* ws, float* slabs, int mixed) {
-  constexpr bool ACC_LDS = ACC == 1;
+  constexpr bool ACC_LDS = ACC == 1 || ACC == 3;      // 3: LDS accumulators flushed into this workgroup's slab (fixed-order sums)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DevExec ex;
   float* p = smem;
@@ -288,7 +288,12 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_bwd(TtShape s, int64_t n_ro
       ttlinear_bwd_tile<DevExec, T, TDY>(ex, s, W, Wt, x, dy, dx, dWacc, dbacc, n0, n, stash, ss, bufA, bufB, bs, AddAtomic(),
                                          BUF_GLOBAL && mixed);
   }
-  if (ACC_LDS) {
+  if (ACC == 3) {
+    __syncthreads();
+    float* slab = slabs + (size_t)blockIdx.x * ((size_t)s.wtotal + s.out_size);
+    for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) slab[e] = d_packed ? dWacc[e] : 0.f;
+    for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) slab[s.wtotal + e] = d_bias ? dbacc[e] : 0.f;
+  } else if (ACC_LDS) {
     __syncthreads();
     if (d_packed) for (int e = threadIdx.x; e < s.wtotal; e += blockDim.x) { const float v = dWacc[e]; if (v != 0.f) atomicAdd(d_packed + e, v); }
     if (d_bias) for (int e = threadIdx.x; e < s.out_size; e += blockDim.x) { const float v = dbacc[e]; if (v != 0.f) atomicAdd(d_bias + e, v); }
@@ -458,7 +463,7 @@ LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows) {
   return p;
 }
 
-LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
+LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows, bool fixed_order) {
   LinPlan p{};
   p.bs = (s.maxbuf + 3) & ~3;
   p.ss = stash_floats(s);
@@ -488,7 +493,15 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows) {
   // accumulators that do not fit LDS: one global slab per workgroup (at most 256 workgroups then, each walking several
   // tiles) as long as the slabs stay within 256 MB; otherwise atomics
   p.acc_slab = false;
+  p.acc_fixed = false;
   p.slab_off = 0;
+  if (p.acc_lds && fixed_order && p.grid > 1 && (size_t)p.grid * acc <= ((size_t)64 << 20)) {
+    // the caller wants repeatable sums (the pull-back of a dense weight gradient onto the cores: `in` rows, one workgroup each):
+    // LDS accumulators as before, flushed into a slab per workgroup instead of through atomics
+    p.acc_fixed = true;
+    p.slab_off = (p.ws_bytes + 255) & ~(size_t)255;
+    p.ws_bytes = p.slab_off + (size_t)p.grid * acc;
+  }
   if (!p.acc_lds) {
     const int g = p.grid > 256 ? 256 : p.grid;
     if ((size_t)g * acc <= ((size_t)256 << 20)) {
@@ -531,7 +544,7 @@ int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n
 template <typename T, typename TDY>
 static int launch_lin_bwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, const float* packed, const void* x,
                             const void* dy, void* dx, float* d_packed, float* d_bias, void* ws, hipStream_t stream) {
-  float* slabs = p.acc_slab ? (float*)((char*)ws + p.slab_off) : nullptr;
+  float* slabs = (p.acc_slab || p.acc_fixed) ? (float*)((char*)ws + p.slab_off) : nullptr;
 #define TT_LAUNCH(BG, AL)                                                                                          \
   do {                                                                                                             \
     auto kern = k_ttlinear_bwd<T, TDY, BG, AL>;                                                                         \
@@ -540,14 +553,17 @@ static int launch_lin_bwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, 
                        (const T*)x, (const TDY*)dy, (T*)dx, d_packed, d_bias, (float*)ws, slabs, p.buf_mixed ? 1 : 0); \
   } while (0)
   const bool slab = p.acc_slab && (d_packed || d_bias) && ws;
-  if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, 1);
+  const bool fixed = p.acc_fixed && p.acc_lds && (d_packed || d_bias) && ws;
+  if (!p.buf_global && fixed) TT_LAUNCH(false, 3);
+  else if (p.buf_global && fixed) TT_LAUNCH(true, 3);
+  else if (!p.buf_global && p.acc_lds) TT_LAUNCH(false, 1);
   else if (!p.buf_global && slab) TT_LAUNCH(false, 2);
   else if (!p.buf_global) TT_LAUNCH(false, 0);
   else if (p.acc_lds) TT_LAUNCH(true, 1);
   else if (slab) TT_LAUNCH(true, 2);
   else TT_LAUNCH(true, 0);
 #undef TT_LAUNCH
-  if (slab && !p.acc_lds) {
+  if ((slab && !p.acc_lds) || fixed) {
     const int per = s.wtotal + s.out_size;
     hipLaunchKernelGGL(k_slab_reduce, dim3((per + 255) / 256), dim3(256), 0, stream, (const float*)slabs, p.grid, s.wtotal,
                        s.out_size, d_packed, d_bias);

@@ -66,6 +66,8 @@ struct LinPlan {
   bool acc_lds;      // backward: weight/bias gradient accumulators in LDS
   bool acc_slab;     // backward, accumulators too large for LDS: one private global slab per workgroup (summed by a second
                      // kernel) instead of atomics from every row into the one gradient buffer
+  bool acc_fixed;    // backward, acc_lds with several workgroups: the LDS accumulators are flushed into per-workgroup slabs (plain
+                     // stores) and summed in a fixed order by the second kernel — no atomics, bitwise repeatable
   size_t slab_off;   // byte offset of the slabs inside the workspace
   size_t lds_bytes, ws_bytes;
 };
@@ -77,7 +79,7 @@ struct RnnPlan {
 };
 
 LinPlan plan_ttlinear_fwd(const TtShape& s, int64_t n_rows);
-LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows);
+LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows, bool fixed_order = false);
 RnnPlan plan_rnn_generic(const RnnShape& rs, bool backward);
 
 const void* unit_rows_ptr(int dtype);   // device constant {1, 0} in the storage dtype (NULL: symbol lookup failed)

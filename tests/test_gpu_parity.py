@@ -2548,6 +2548,8 @@ def test_gru_forward_kernel_with_in_wave_s2_matches_eight_wave_kernel_and_oracle
     dict(kind="ttlstm", input_size=1, hidden_size=1024, num_layers=1, n_cores=2, tt_rank=16),         # runtime tier, in = 1: k_in1_reduce
     dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, is_naive=True),
     dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4),           # cfg1: two-core kernels, dense gradient + k_proj2
+    dict(kind="ttlstm", input_size=40, hidden_size=768, num_layers=1, n_cores=4, tt_rank=8),          # d = 4: dense gradients pulled back by the any-shape kernel (fixed-order slabs)
+    dict(kind="ttgru", input_size=40, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8),           # runtime tier GRU, resident reverse fragments
 ], ids=lambda m: "{kind}-{input_size}-{hidden_size}-L{num_layers}-d{n_cores}-r{tt_rank}{n}".format(n="-naive" if m.get("is_naive") else "", **m))
 def test_gradients_are_bitwise_repeatable(meta):
     """Three identical backward passes give bit-identical gradients for EVERY parameter.  Round 3 left two families to the order
