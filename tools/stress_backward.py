@@ -27,13 +27,15 @@ ap.add_argument("--reps", type=int, default=40)
 ap.add_argument("--cases", default=",".join(CASES))
 ap.add_argument("--grid", action="store_true", help="instead of the named cases: bench.py's grid of shapes (in = 40, batch 64, --grid-steps steps)")
 ap.add_argument("--grid-steps", type=int, default=64)
+ap.add_argument("--no-poison", action="store_true", help="plain allocations: a difference that disappears here is an uninitialised read")
+ap.add_argument("--only", default="", help="--grid: substring filter on the case names")
 a = ap.parse_args()
 if a.grid:
     CASES = {"%s-H%d-d%d-r%d" % (c, H, d, r): (c, 40, H, 1, d, r, False, 64, a.grid_steps)
              for c in ("lstm", "gru") for H in (64, 128, 256, 384, 512, 768, 1024) for d in (2, 3, 4) for r in (2, 4, 8, 16)}
-    a.cases = ",".join(CASES)
+    a.cases = ",".join(k for k in CASES if a.only in k)
 dev = torch.device("cuda:0")
-F.POISON_ALLOCATIONS = True
+F.POISON_ALLOCATIONS = not a.no_poison
 bad = 0
 for name in a.cases.split(","):
     cell, inp, H, L, d, r, naive, B, T = CASES[name]
