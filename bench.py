@@ -53,6 +53,10 @@ WORKLOADS = {
                  desc="TT-LSTM in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=64/GPU fp32 (BASELINE.json configs[1])"),
     "cfg3": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=256, T=784, dtype="bf16", flop=519360, flop_in=24768,
                  desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=256/GPU bf16 storage (configs[2])"),
+    "cfg3_fp32": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=256, T=784, dtype="f32", flop=519360, flop_in=24768,
+                      desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=256/GPU fp32 (configs[2] in the reference's own dtype)"),
+    "gru64": dict(kind="ttgru", inp=1, H=256, L=1, d=3, r=8, B=64, T=784, dtype="f32", flop=519360, flop_in=24768,
+                  desc="TT-GRU in=1 H=256 ncores=3 ttrank=8 seq_len=784 batch=64/GPU fp32 (cfg2's sizes with the GRU cell)"),
     "cfg4": dict(kind="ttlstm", inp=40, H=256, L=3, d=3, r=16, B=512, T=160, dtype="f32", flop=12416768,
                  desc="3-layer TT-LSTM in=40 H=256 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (configs[3] per-GPU batch)"),
     "cfg5": dict(kind="ttlstm", inp=1024, H=1024, L=1, d=4, r=32, B=128, T=1024, dtype="f32", flop=70267904,
@@ -71,9 +75,10 @@ GPU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock; MFMA bus
 #   32 pipe cycles).  `rec_simds` = SIMDs the recurrent kernel's MFMAs of ONE sample are spread over (a workgroup owns a CU).
 EXECUTED = {
     # cfg2: S2 16 tiles x 1 term-packed fp16 MFMA + S10 4 tiles x 8 k-blocks x 3 terms (k_lstm_fwd_f10)
-    "cfg2": dict(bf16_mfma=16 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
-                 note="fused core on two-piece fp16 operands: S2 (K=8, four terms packed into one MFMA per tile) + S10 "
-                      "(64 x 16 x 256, three terms x0w0 + x0w1 + x1w0)"),
+    "cfg2": dict(bf16_mfma=32 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
+                 note="fused core on two-piece fp16 operands (k_lstm_fwd_f10s, one barrier per step): S2 inside the gate waves (K=8, "
+                      "two m-tiles per MFMA, four terms in two chained MFMAs: 8 per wave) + S10 (64 x 16 x 256, three terms "
+                      "x0w0 + x0w1 + x1w0)"),
     # cfg1 (round 4, ttrnn_fast_f2.hip): stage 1 8 m-tiles x 2 chained MFMAs (the three split terms, K = 16 packed twice along the
     # 32-wide k) + stage 0 2 column tiles x 3 terms, on the two waves (two SIMDs) of a sample's workgroup
     "cfg1": dict(bf16_mfma=16 + 6, fp32_mfma=0, kin_bf16_flop=0, rec_simds=2, pipe16="f16_mfma", terms=3,
@@ -82,6 +87,11 @@ EXECUTED = {
     # columns are padding) + S10 4 tiles x 8 k-blocks (k_gru_fwd_f10v)
     "cfg3": dict(bf16_mfma=24 + 32, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4,
                  note="bf16 fused core, no splitting (storage precision is bf16); S2 inside the gate waves"),
+    # fp32 GRU (round 5, k_gru_fwd_f10vh): S2 on tile pairs, 4 waves x 6 MFMAs, + S10 4 tiles x 8 k-blocks x 3 terms
+    "cfg3_fp32": dict(bf16_mfma=24 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
+                      note="fused core on two-piece fp16 operands, S2 (tile pairs, four terms in two MFMAs) inside the gate waves"),
+    "gru64": dict(bf16_mfma=24 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
+                  note="fused core on two-piece fp16 operands, S2 (tile pairs, four terms in two MFMAs) inside the gate waves"),
     # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense GEMM on fp16 pieces,
     # 3 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
     "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=3 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,

@@ -578,12 +578,13 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
   return f;
 }
 
-// Forward route preference: fp32 GRUs have no fused-core kernel (k_gru_fwd_f10 is the bf16-storage one); since its stages
-// moved to fp16 pieces the runtime-shape tier beats the stage-wise fp32-MFMA kernels on their shapes (H = 256, r = 8, B = 256,
-// T = 784: 0.99 vs 1.58 ms).  The reverse-time route is chosen on its own (same reserve format).
+// Forward route preference: fp32 GRUs other than the fused-core shape (H = 256, r = 8: k_gru_fwd_f10vh, round 5) run on the
+// runtime-shape tier — since its stages moved to fp16 pieces it beats the stage-wise fp32-MFMA kernels on their shapes (H = 256,
+// r = 8, B = 256, T = 784: 0.99 vs 1.58 ms).  The reverse-time route is chosen on its own (same reserve format).
 static bool fwd_prefers_g2(const RnnShape& rs, int dtype) {
   if (force_generic()) return false;
   if (opt(OPT_FORCE_G2)) return g2_rnn_available(rs, dtype);
+  if (f10gh_available(rs, dtype) && fast_rnn_fwd_available(rs, dtype)) return false;
   return rs.cell == TTRNN_GRU && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && g2_rnn_available(rs, dtype);
 }
 
@@ -740,6 +741,9 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
     }
     if (st != TTRNN_OK) return st;
     // fused-core kernels: fp32 LSTM shapes under the split math mode; the bf16 GRU shape always (bf16 MFMA either way)
+    if (desc->dtype == TTRNN_F32 && rs.cell == TTRNN_GRU && f10gh_available(rs, desc->dtype))
+      return launch_gru_fwd_f10gh(rs, src, h0, packed_hid, bias_hid, out, hT, reserve, (char*)workspace + f.gin_bytes + f.lin_ws_bytes,
+                                  (hipStream_t)stream, phase);
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
       return launch_rnn_fwd_f10(rs, src, h0, c0, packed_hid, bias_hid, out, hT, cT, reserve,
                                 (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream, phase);

@@ -229,4 +229,138 @@ __device__ __forceinline__ void f10h_s10_part(const xh8 (&w10)[2][NU], const _Fl
   }
 }
 
+// ---- S2 INSIDE the gate waves, on tile PAIRS (round 5: k_lstm_fwd_f10s, k_gru_fwd_f10vh) --------------------------------------
+// Wave w of the fused-core kernels owns hidden units 64w .. 64w+63 (lane l <-> unit 64w + l) = chain rows 8w .. 8w+7 of S2, eight
+// consecutive units (j2 = l & 7) per row (l >> 3): S2 of the NEW state needs no other wave's data.  Every lane packs its unit as
+// one dword (p0 | p1 << 16, the two fp16 pieces of 2^sH h) and the B operand is gathered through the LDS crossbar (ds_bpermute:
+// no memory, no barrier).  A wave has only EIGHT chain rows for the MFMA's sixteen columns, so two m-tiles share one MFMA:
+//     columns 0-7  = chain rows 0-7 against m-tile X = p,        live k-slots 0-15  (B is zero in 16-31)
+//     columns 8-15 = chain rows 0-7 against m-tile Y = p + NP,   live k-slots 16-31 (B is zero in 0-15)
+//     k-slot pairs (2j, 2j+1) of a half = (x0, x1) of j2 = j;   A1 = (w0, w0),  A2 = (w1, w1)  ->  two MFMAs = all four terms
+// — every lane of the result is a live (feature, chain row) pair: MT2 MFMAs and MT2 / 2 splitting passes per wave and step where
+// one m-tile per MFMA costs MT2 passes with half of the lanes masked.
+template <class S>
+struct F10P {
+  using F = F10<S>;
+  static constexpr int NP = F::MT2 / 2;                    // tile pairs
+  static_assert(F::MT2 % 2 == 0 && F::J2 == 8, "tile pairs");
+};
+// lane (r, q) of A: k = 8q .. 8q+7 <-> m-tile (q < 2 ? X : Y), j2 = 4 (q & 1) + e / 2, both slots of a pair the same piece
+template <class S>
+__device__ __forceinline__ void f10p_load_w2(xh8 (&a1)[F10P<S>::NP], xh8 (&a2)[F10P<S>::NP], const float* packed, int lane,
+                                             const float* __restrict__ hdr) {
+  using F = F10<S>;
+  constexpr int NP = F10P<S>::NP;
+  const int r = lane & 15, q = lane >> 4;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2]
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m2 = 16 * (q < 2 ? p : p + NP) + r;
+    const float sc = f10h_g2_scale<S>(hdr, m2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 p0, p1;
+      split2h(W2[(4 * (q & 1) + e) * F::M2 + m2] * sc, p0, p1);
+      a1[p][2 * e] = p0; a1[p][2 * e + 1] = p0;
+      a2[p][2 * e] = p1; a2[p][2 * e + 1] = p1;
+    }
+  }
+}
+// per-lane loop invariants: the gather address, whether the lane's B slots are live, the store offsets of the NP results
+template <class S>
+struct F10pLane {
+  int gsrc;
+  bool live;
+  int soff[F10P<S>::NP];
+  __device__ __forceinline__ void init(int wave, int lane) {
+    using F = F10<S>;
+    const int c = lane & 15, q = lane >> 4;
+    gsrc = 4 * (8 * (c & 7) + 4 * (q & 1));               // byte address of lane 8 rho + 4 (q & 1) for ds_bpermute
+    live = (c < 8) == (q < 2);
+#pragma unroll
+    for (int p = 0; p < F10P<S>::NP; ++p) {
+      const int m0 = 16 * (c < 8 ? p : p + F10P<S>::NP) + 4 * q;     // registers j: features m0 + j, chain row 8 wave + (c & 7)
+      soff[p] = x_off<F::K>(m0 / F::R2, F::kperm(8 * wave + (c & 7), m0 % F::R2));
+    }
+  }
+};
+// pk: this lane's unit as (p0 | p1 << 16); img: the two fp16 planes the NEXT S10 reads
+template <class S>
+__device__ __forceinline__ void f10p_s2(const xh8 (&a1)[F10P<S>::NP], const xh8 (&a2)[F10P<S>::NP], const F10pLane<S>& ln,
+                                        unsigned pk, _Float16* img) {
+  using F = F10<S>;
+  constexpr int NP = F10P<S>::NP;
+  unsigned d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = (unsigned)__builtin_amdgcn_ds_bpermute(ln.gsrc + 4 * e, (int)pk);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = ln.live ? d[e] : 0u;
+  const xh8 bfrag = __builtin_bit_cast(xh8, u32x4{d[0], d[1], d[2], d[3]});
+  f32x4 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[p], bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[p], bfrag, acc[p], 0, 0, 0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) store_split4_h(img, F::PLANE, ln.soff[p], acc[p]);
+}
+__device__ __forceinline__ unsigned f10p_pack(float hscaled) {
+  _Float16 p0, p1;
+  split2h(hscaled, p0, p1);
+  return (unsigned)__builtin_bit_cast(unsigned short, p0) | ((unsigned)__builtin_bit_cast(unsigned short, p1) << 16);
+}
+
+// ---- the scale header of the two-piece fp16 kernels (LSTM: ttrnn_fast_f10.hip; fp32 GRU: ttrnn_fast_f10gh.hip) ---------------
+// The diagonal power-of-two scales of ttrnn_f10_dev.h, from the cores themselves.  F10H_PARTS = M workgroups; every one derives
+// eu / ev from core 2 (one or two thousand entries) and then takes ONE row of the fused core (16 workgroups of four rows each
+// took 11 us for r = 16: a row is 512 dot products of 16 terms):
+//   eu[i2] = -expo(max_{r2,j2} |G2|),  ev[r2] = -expo(max_{i2,j2} 2^eu |G2|),  ep[m] = 12 - expo(max_k 2^-ev |W10[m][k]|)
+template <class S>
+__global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, int* __restrict__ hdr) {
+  using F = F10<S>;
+  static_assert(F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one workgroup (blockIdx.x) per row of the fused core: launch F::M of them");
+  __shared__ unsigned mx[32];
+  __shared__ int eu[16], ev[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* W2 = packed + woff_of<S>(2);               // [J2][M2], m2 = i2 R2 + r2
+  if (tid < 32) mx[tid] = 0u;
+  __syncthreads();
+  for (int i = tid; i < F::J2 * F::M2; i += 256)          // non-negative floats order like their bit patterns
+    atomicMax(&mx[(i % F::M2) / F::R2], __float_as_uint(fabsf(W2[i])));
+  __syncthreads();
+  if (tid < 16) eu[tid] = tid < F::I2 ? -f10h_expo(__uint_as_float(mx[tid])) : 0;
+  __syncthreads();
+  for (int i = tid; i < F::J2 * F::M2; i += 256) {
+    const int m2 = i % F::M2;
+    atomicMax(&mx[16 + m2 % F::R2], __float_as_uint(fabsf(W2[i]) * ldexpf(1.f, eu[m2 / F::R2])));
+  }
+  __syncthreads();
+  if (tid < 16) ev[tid] = tid < F::R2 ? -f10h_expo(__uint_as_float(mx[16 + tid])) : 0;
+  __syncthreads();
+  // row m = blockIdx.x of the fused core (the same fmaf chain as k_f10h_prep): the workgroup's threads over k = (row2, r2)
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const int i0 = m / F::I1, i1 = m % F::I1;
+  const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
+  const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
+  float best = 0.f;
+  for (int k = tid; k < F::K; k += 256) {
+    const int r2 = k % F::R2, row2 = k / F::R2;
+    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
+    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
+    float v = 0.f;
+    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
+    best = fmaxf(best, fabsf(v) * ldexpf(1.f, -ev[r2]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (tid == 0) hdr[F10H_EP + m] = 12 - f10h_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  if (blockIdx.x == 0 && tid < 16) {
+    hdr[F10H_EU + tid] = eu[tid];
+    hdr[F10H_EV + tid] = ev[tid];
+  }
+}
+
 }  // namespace ttrnn

@@ -86,59 +86,7 @@ __global__ void __launch_bounds__(64) k_f10_prep(const float* __restrict__ packe
 template <class S>
 constexpr size_t f10_wfrag_bytes() { return (size_t)F10<S>::MT * F10<S>::NM * 3 * 64 * sizeof(xbf8); }
 
-// ---- two-piece fp16 operands (LSTM forward kernels): scale header + fragments --------------------------------------
-// The diagonal power-of-two scales of ttrnn_f10_dev.h, from the cores themselves.  F10H_PARTS = M workgroups; every one derives
-// eu / ev from core 2 (one or two thousand entries) and then takes ONE row of the fused core (16 workgroups of four rows each
-// took 11 us for r = 16: a row is 512 dot products of 16 terms):
-//   eu[i2] = -expo(max_{r2,j2} |G2|),  ev[r2] = -expo(max_{i2,j2} 2^eu |G2|),  ep[m] = 12 - expo(max_k 2^-ev |W10[m][k]|)
-template <class S>
-__global__ void __launch_bounds__(256) k_f10h_scale(const float* __restrict__ packed, int* __restrict__ hdr) {
-  using F = F10<S>;
-  static_assert(F::I2 <= 16 && F::R2 <= 16 && F::K % 64 == 0, "one workgroup (blockIdx.x) per row of the fused core: launch F::M of them");
-  __shared__ unsigned mx[32];
-  __shared__ int eu[16], ev[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* W2 = packed + woff_of<S>(2);               // [J2][M2], m2 = i2 R2 + r2
-  if (tid < 32) mx[tid] = 0u;
-  __syncthreads();
-  for (int i = tid; i < F::J2 * F::M2; i += 256)          // non-negative floats order like their bit patterns
-    atomicMax(&mx[(i % F::M2) / F::R2], __float_as_uint(fabsf(W2[i])));
-  __syncthreads();
-  if (tid < 16) eu[tid] = tid < F::I2 ? -f10h_expo(__uint_as_float(mx[tid])) : 0;
-  __syncthreads();
-  for (int i = tid; i < F::J2 * F::M2; i += 256) {
-    const int m2 = i % F::M2;
-    atomicMax(&mx[16 + m2 % F::R2], __float_as_uint(fabsf(W2[i]) * ldexpf(1.f, eu[m2 / F::R2])));
-  }
-  __syncthreads();
-  if (tid < 16) ev[tid] = tid < F::R2 ? -f10h_expo(__uint_as_float(mx[16 + tid])) : 0;
-  __syncthreads();
-  // row m = blockIdx.x of the fused core (the same fmaf chain as k_f10h_prep): the workgroup's threads over k = (row2, r2)
-  __shared__ float red[4];
-  const int m = blockIdx.x;
-  const int i0 = m / F::I1, i1 = m % F::I1;
-  const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
-  const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
-  float best = 0.f;
-  for (int k = tid; k < F::K; k += 256) {
-    const int r2 = k % F::R2, row2 = k / F::R2;
-    const int j1 = row2 % F::J1, j0 = row2 / F::J1;
-    const float* w1p = W1 + (j1 * F::R2 + r2) * (F::I1 * F::R1) + i1 * F::R1;
-    float v = 0.f;
-    for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
-    best = fmaxf(best, fabsf(v) * ldexpf(1.f, -ev[r2]));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
-  if (lane == 0) red[wave] = best;
-  __syncthreads();
-  if (tid == 0) hdr[F10H_EP + m] = 12 - f10h_expo(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-  if (blockIdx.x == 0 && tid < 16) {
-    hdr[F10H_EU + tid] = eu[tid];
-    hdr[F10H_EV + tid] = ev[tid];
-  }
-}
-
+// ---- two-piece fp16 operands (LSTM forward kernels): scale header (k_f10h_scale: ttrnn_f10_dev.h) + fragments ---------
 // The fused core in fragment order (see k_f10_prep), rows pre-multiplied by -log2(e) (gates i, f, o) / 2 log2(e) (gate g)
 // and by the header's 2^(ep[m] - ev[r2]), as two fp16 pieces:  wfrag[((t*NM + u)*2 + plane)*64 + lane].
 template <class S>
@@ -895,6 +843,9 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
   if (!dg && !opt(OPT_F10_NB1)) {
     if (rs.B > cus && opt(OPT_F10_NB2))
       return launch_rnn_fwd_f10_nb2(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
+    // one barrier per step, S2 inside the gate waves (ttrnn_fast_f10s.hip, round 5): measured slower, dev bit 512 selects it (A/B)
+    if (KS == 1 && f10s_available(rs, h0 != nullptr))
+      return launch_rnn_fwd_f10_s(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
     if (KS == 1 || 2 * rs.B > cus)
       return launch_rnn_fwd_f10_q(rs, gin, h0, c0, packed_hid, ws, bh, out, hT, cT, reserve, stream);
   }
@@ -909,6 +860,7 @@ static int launch_f10(const RnnShape& rs, GinSrc gin, const void* h0, const void
 size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
     return f10gq_workspace_bytes();      // >= the eight-wave kernel's 4 * NM fragments
+  if (dtype == TTRNN_F32 && rs.cell == TTRNN_GRU) return f10gh_workspace_bytes(rs);      // two fp16 pieces (ttrnn_fast_f10gh.hip)
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R8L>();
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10_wfrag_bytes<ShpH256R16L>();
@@ -918,6 +870,7 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);
+  if (dtype == TTRNN_F32 && rs.cell == TTRNN_GRU) return f10gh_available(rs, dtype);      // (split math mode only)
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s) || f2_rnn_fwd_available(rs, dtype);
 }
@@ -965,6 +918,7 @@ int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0
   hipLaunchKernelGGL((k_f10h_prep<S>), dim3(F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   GinSrc src{gin, nullptr, 0};
+  if (f10s_available(rs, h0 != nullptr)) return launch_rnn_fwd_f10_s(rs, src, h0, c0, packed_hid, ws, nullptr, out, hT, cT, reserve, stream);
   return launch_rnn_fwd_f10_q(rs, src, h0, c0, packed_hid, ws, nullptr, out, hT, cT, reserve, stream);
 }
 

@@ -155,6 +155,15 @@ size_t f10gq_workspace_bytes();
 bool f10gq_available(const RnnShape& rs, int dtype);
 int launch_gru_fwd_f10gq(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
                          void* out, void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
+// the four-/eight-wave LSTM kernel with ONE barrier per step, S2 inside the gate waves (ttrnn_fast_f10s.hip); ws as launch_rnn_fwd_f10_q
+bool f10s_available(const RnnShape& rs, bool with_h0);
+int launch_rnn_fwd_f10_s(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid, const void* ws,
+                         const float* bias_hid, void* out, void* hT, void* cT, float* reserve, hipStream_t stream);
+// the fp32-storage GRU on two fp16 pieces (ttrnn_fast_f10gh.hip; split math mode); ws: f10gh_workspace_bytes
+size_t f10gh_workspace_bytes(const RnnShape& rs);
+bool f10gh_available(const RnnShape& rs, int dtype);
+int launch_gru_fwd_f10gh(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid, void* out,
+                         void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
 // two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,

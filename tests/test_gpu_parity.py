@@ -297,6 +297,9 @@ def test_full_size_configs_vs_oracle_and_properties(name):
     sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
     ro, rh, rc = _oracle_forward(kind, sd, L, x[rows].float())
     xd = x.to(dev())
+    if name == "cfg3_fp32":      # the reference's own GRU dtype: the two-piece fused-core kernel (k_gru_fwd_f10vh, round 5)
+        from ttrnn_hip import functional as F
+        assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "fused_core"
     with torch.no_grad():
         res = m(xd)
         out, hT = res[0], (res[1][0] if lstm else res[1])
@@ -882,6 +885,8 @@ _SKIP_OUT_CASES = {
     "fused_core_r16_b6_eight_waves": (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=1, n_cores=3, tt_rank=16), 6, 9, "f32"),
     "fused_core_r8_in1": (dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 6, 30, "f32"),
     "fused_core_gru_bf16": (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, "bf16"),
+    "fused_core_gru_fp32": (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, "f32"),
+    "fused_core_gru_fp32_in40": (dict(kind="ttgru", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=8), 70, 11, "f32"),
     "stagewise_h128_r4": (dict(kind="ttlstm", input_size=1, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), 5, 20, "f32"),
     "runtime_mfma_lstm": (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, "f32"),
     "runtime_mfma_gru_2layers": (dict(kind="ttgru", input_size=28, hidden_size=128, num_layers=2, n_cores=3, tt_rank=4), 4, 7, "f32"),
@@ -944,7 +949,9 @@ def test_prepared_weights_inference_matches_and_tracks_updates():
     from ttrnn_hip import _lib
     torch.manual_seed(7)
     for meta, B, T, split in ((dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 1),
-                              (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 0),
+                              # (fp32 GRU: fused-core route since round 5 — its scale header and fragments are weight-only work)
+                              (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 1),
+                              (dict(kind="ttgru", input_size=28, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4), 5, 40, 0),
                               (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16), 6, 9, 0),
                               (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0),
                               # naive per-gate sets: the operands are torch.cat COPIES of the parameters — the
@@ -2537,6 +2544,199 @@ def test_gru_forward_kernel_with_in_wave_s2_matches_eight_wave_kernel_and_oracle
         xg = x.to(dev())
         o1 = m(xg, h0.to(dev()) if with_h0 else None)[0]
         assert torch.equal(o1.detach(), outs["in_wave"][0])
+
+
+@pytest.mark.parametrize("H,inp,B,T,with_state", [(256, 1, 9, 60, False), (256, 1, 70, 33, True), (256, 40, 300, 12, True)])
+def test_single_barrier_forward_kernel_matches_two_barrier_kernel_and_oracle(H, inp, B, T, with_state):
+    """k_lstm_fwd_f10s (ttrnn_fast_f10s.hip, round 5: S2 of the new state inside the gate waves, ONE barrier per step; measured
+    3.5 % slower than the two-barrier kernel on cfg2 and kept behind option dev bit 9 as the A/B record of DESIGN.md lesson 56)
+    against the default kernel and the float64 oracle: same scales, same S10; S2 sums its four terms in two chained MFMAs instead
+    of one, so the two kernels agree to an ulp of an accumulator, and neither is further from float64 than the other.  Training
+    forward (reserve) + backward included; batch rows independent, repeatable."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(H + inp + B)
+    m = build_module(dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8), dev())
+    x = torch.rand(B, T, inp)
+    init = (torch.randn(B, H) * 0.5, torch.randn(B, H)) if with_state else None
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    ro, (rh, rc) = O.lstm_forward(layers, xr, None if init is None else tuple(t.double() for t in init))
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "fused_core"
+    di = None if init is None else tuple(t.to(dev()) for t in init)
+    outs = {}
+    for name, d in (("one_barrier", 512), ("two_barriers", 0)):
+        with ttrnn_hip.option("dev", d), torch.no_grad():
+            outs[name] = m(x.to(dev()), di)
+    a, b_ = outs["one_barrier"], outs["two_barriers"]
+    ea, eb = _maxabs(a[0], ro), _maxabs(b_[0], ro)
+    print("H=%d in=%d B=%d: |one - two| %.3g, vs float64: one %.3g two %.3g" % (H, inp, B, _maxabs(a[0], b_[0]), ea, eb))
+    assert _maxabs(a[0], b_[0]) <= 5e-7 and _maxabs(a[1][1], b_[1][1]) <= 1e-6
+    assert ea <= 2e-6 and ea <= 2.0 * eb + 1e-7
+    assert _maxabs(a[1][0], rh) <= 2e-6 and _maxabs(a[1][1], rc) <= 4e-6
+    w = torch.randn(B, T, H)
+    ((ro * w.double()).sum() + 0.5 * rh.sum() + 0.25 * rc.sum()).backward()
+    with ttrnn_hip.option("dev", 512):
+        with torch.no_grad():
+            again = m(x.to(dev()), di)
+            sub = m(x[[2, 0]].to(dev()), None if di is None else (di[0][[2, 0]], di[1][[2, 0]]))
+        assert torch.equal(again[0], a[0]) and torch.equal(sub[0], a[0][[2, 0]])
+        # training forward + backward through the reverse-time kernel
+        m.zero_grad()
+        xg = x.to(dev()).requires_grad_(True)
+        out, (hT, cT) = m(xg, di)
+        assert torch.equal(out.detach(), a[0])
+        ((out * w.to(dev())).sum() + 0.5 * hT.sum() + 0.25 * cT.sum()).backward()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        ref = leaves[n].grad
+        worst = max(worst, _maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-30))
+    worst = max(worst, _maxabs(xg.grad, xr.grad) / max(float(xr.grad.abs().max()), 1e-30))
+    assert worst <= 1e-4
+
+
+def _cfg3_fp32_module(inp=1, L=1):
+    torch.manual_seed(1111)
+    return build_module(dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=8), dev())
+
+
+def test_gru_fp32_fused_core_error_vs_fp64_is_fp32_class():
+    """The reference's GRU is fp32 only (tensorized_rnn/gru.py:25-50).  Its cfg3 shape on the two-piece fused-core kernel
+    (k_gru_fwd_f10vh, ttrnn_fast_f10gh.hip: the default of the split mode since round 5) over the full 784 steps against the
+    oracle evaluated in float64: as close to the exact result as ordinary fp32 arithmetic (the fp32-MFMA mode and the torch-CPU
+    fp32 oracle); the runtime-shape tier's kernel (option dev bit 8: the route fp32 GRUs took until round 4) beside it."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    m = _cfg3_fp32_module()
+    torch.manual_seed(99)
+    x = torch.rand(4, 784, 1)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, h64, _ = _oracle_forward("ttgru", sd, 1, x.double())
+    r32, h32, _ = _oracle_forward("ttgru", sd, 1, x)
+    errs = {"cpu_fp32": _maxabs(r32, r64)}
+    for mode, d in (("exact", 0), ("split", 0), ("tier", 256)):
+        with ttrnn_hip.fp32_math("exact" if mode == "exact" else "split"), ttrnn_hip.option("dev", d), torch.no_grad():
+            route = F.rnn_route(m._all_layers[0]._layer_spec(), 4, 784)
+            assert route == {"exact": "stagewise_mfma", "split": "fused_core", "tier": "runtime_mfma"}[mode], (mode, route)
+            out, hT = m(x.to(dev()))
+        assert torch.equal(out[:, -1], hT)
+        errs[mode] = _maxabs(out, r64)
+    print("TT-GRU fp32, max abs error vs float64 oracle:", errs)
+    assert errs["split"] <= 2e-6 and errs["exact"] <= 2e-6
+    assert errs["split"] <= 2.0 * max(errs["exact"], errs["cpu_fp32"]) + 1e-7
+
+
+@pytest.mark.parametrize("case", ["fresh", "tiny_weights", "huge_weights", "huge_h0", "decaying_h0", "zero_core", "mixed_magnitudes",
+                                  "outlier_entry"])
+def test_gru_fp32_fused_core_operand_ranges(case):
+    """k_gru_fwd_f10vh multiplies two-piece fp16 operands under the diagonal power-of-two scales of ttrnn_f10_dev.h (chosen per
+    launch from the cores; the state's scale per SAMPLE and — a GRU's state decays only as fast as z lets it — per STEP while a
+    caller's h_0 keeps it outside (-1, 1)): nothing may overflow fp16's range or lose the small entries, whatever the
+    magnitudes.  Both modes against the float64 oracle, error relative to the largest state; batch rows independent."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    m = _cfg3_fp32_module()
+    torch.manual_seed(17)
+    T = 40 if case == "decaying_h0" else 6
+    B = 5
+    h0 = torch.randn(B, 256) * 0.3
+    x = torch.randn(B, T, 1)
+    with torch.no_grad():
+        cores = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+        assert len(cores) == 3
+        if case == "tiny_weights":
+            for p in cores:
+                p.mul_(1e-4)
+        elif case == "huge_weights":
+            for p in cores:
+                p.mul_(40.0)
+        elif case == "huge_h0":
+            h0 = torch.randn(B, 256) * 300.0
+            h0[1] *= 1e-4                                     # one sample inside (-1, 1) next to them: scales are per sample
+        elif case == "decaying_h0":
+            h0 = torch.randn(B, 256) * 6.0                    # back inside (-1, 1) after 10 ... 20 steps (z ~ 0.5), small ever after
+            h0[3] = 0.0
+            h0[4] *= 0.25
+        elif case == "zero_core":
+            cores[1].zero_()
+        elif case == "mixed_magnitudes":
+            for k, step, f in ((2, 3, 1e-6), (0, 2, 1e-5)):
+                w = cores[k].detach().clone().reshape(-1)
+                w[::step] *= f
+                cores[k].copy_(w.reshape(cores[k].shape))
+        elif case == "outlier_entry":
+            for k in (2, 1):                                  # ONE entry x 1e4 in core 2 and in core 1: the diagonal scales keep
+                w = cores[k].detach().clone().reshape(-1)     # the other rows' / slices' bits
+                w[7] *= 1e4
+                cores[k].copy_(w.reshape(cores[k].shape))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64, h64, _ = _oracle_forward("ttgru", sd, 1, x.double(), h0.double())
+    scale = max(1e-30, float(r64.abs().max()))
+    errs, outs = {}, {}
+    for mode in ("exact", "split"):
+        with ttrnn_hip.fp32_math(mode), torch.no_grad():
+            if mode == "split":
+                assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "fused_core"
+            out, hT = m(x.to(dev()), h0.to(dev()))
+            if mode == "split":
+                sub = m(x[[3, 1]].to(dev()), h0[[3, 1]].to(dev()))[0]
+                assert torch.equal(out[[3, 1]], sub)          # a sample's result never depends on its batch
+        assert torch.isfinite(out).all(), (case, mode)
+        assert torch.equal(out[:, -1], hT)
+        errs[mode] = _maxabs(out, r64)
+        outs[mode] = out
+    # late steps on their own scale: once the state is back inside (-1, 1) its pieces must be fine again
+    late = _maxabs(outs["split"][:, -1], r64[:, -1]) / max(1e-30, float(r64[:, -1].abs().max()))
+    print(case, "max abs error vs float64 (state scale %.3g):" % scale, errs, "last step relative: %.3g" % late)
+    tol = 2e-3 if case in ("huge_weights", "huge_h0", "outlier_entry") else 2e-6
+    assert errs["split"] <= tol * max(1.0, scale)
+    assert errs["split"] <= 3.0 * errs["exact"] + 2e-7 * max(1.0, scale)
+    if case == "decaying_h0":
+        assert float(r64[:, -1].abs().max()) < 1.0 and late <= 2e-6
+
+
+def test_gru_fp32_fused_core_variants_vs_oracle_and_tier():
+    """k_gru_fwd_f10vh's template variants — input_size 1 / gin-fed (input_size 40, stacked layers), h_0 given or not, `out`
+    skipped (the classifier reads only the last step) — against the fp32 oracle and the runtime-shape tier's kernel (dev bit 8),
+    plus the training forward (reserve) feeding the reverse-time kernel k_gru_bwd_f10h: every gradient against the oracle's
+    autograd in float64."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(31)
+    for inp, L, B, T, with_h0 in ((1, 1, 9, 50, False), (1, 1, 70, 33, True), (40, 2, 6, 21, True), (40, 1, 300, 12, False)):
+        m = _cfg3_fp32_module(inp, L)
+        x = torch.rand(B, T, inp)
+        h0 = (torch.randn(B, 256) * 0.5) if with_h0 else None
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        layers, leaves = O.layers_from_state_dict({k: v.double() for k, v in sd.items()}, L, requires_grad=True, dtype=torch.float64)
+        xr = x.double().clone().requires_grad_(True)
+        ro, rh = O.gru_forward(layers, xr, h0.double() if with_h0 else None)
+        outs = {}
+        for name, d in (("fused", 0), ("tier", 256)):
+            with ttrnn_hip.option("dev", d), torch.no_grad():
+                assert F.rnn_route(m._all_layers[-1]._layer_spec(), B, T) == ("fused_core" if d == 0 else "runtime_mfma")
+                outs[name] = m(x.to(dev()), h0.to(dev()) if with_h0 else None)
+        assert _maxabs(outs["fused"][0], ro) <= 1e-5 and _maxabs(outs["fused"][1], rh) <= 1e-5
+        assert _maxabs(outs["fused"][0], outs["tier"][0]) <= 2e-6
+        # training forward + backward
+        w = torch.randn(B, T, 256)
+        ((ro * w.double()).sum() + 0.5 * rh.sum()).backward()
+        m.zero_grad()
+        xg = x.to(dev()).requires_grad_(True)
+        out, hT = m(xg, h0.to(dev()) if with_h0 else None)
+        assert torch.equal(out.detach(), outs["fused"][0])
+        ((out * w.to(dev())).sum() + 0.5 * hT.sum()).backward()
+        worst = 0.0
+        for n, p in m.named_parameters():
+            ref = leaves[n].grad
+            worst = max(worst, _maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-30))
+        worst = max(worst, _maxabs(xg.grad, xr.grad) / max(float(xr.grad.abs().max()), 1e-30))
+        print("TT-GRU fp32 in=%d L=%d B=%d T=%d h0=%s: max gradient error relative to each tensor's maximum %.3g" % (
+            inp, L, B, T, with_h0, worst))
+        assert worst <= 1e-4
 
 
 # ---- (13) repeatability of the gradients ----------------------------------------------------------------------------------------
