@@ -75,10 +75,9 @@ GPU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock; MFMA bus
 #   32 pipe cycles).  `rec_simds` = SIMDs the recurrent kernel's MFMAs of ONE sample are spread over (a workgroup owns a CU).
 EXECUTED = {
     # cfg2: S2 16 tiles x 1 term-packed fp16 MFMA + S10 4 tiles x 8 k-blocks x 3 terms (k_lstm_fwd_f10)
-    "cfg2": dict(bf16_mfma=32 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
-                 note="fused core on two-piece fp16 operands (k_lstm_fwd_f10s, one barrier per step): S2 inside the gate waves (K=8, "
-                      "two m-tiles per MFMA, four terms in two chained MFMAs: 8 per wave) + S10 (64 x 16 x 256, three terms "
-                      "x0w0 + x0w1 + x1w0)"),
+    "cfg2": dict(bf16_mfma=16 + 96, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, pipe16="f16_mfma", terms=3,
+                 note="fused core on two-piece fp16 operands: S2 (K=8, four terms packed into one MFMA per tile) + S10 "
+                      "(64 x 16 x 256, three terms x0w0 + x0w1 + x1w0)"),
     # cfg1 (round 4, ttrnn_fast_f2.hip): stage 1 8 m-tiles x 2 chained MFMAs (the three split terms, K = 16 packed twice along the
     # 32-wide k) + stage 0 2 column tiles x 3 terms, on the two waves (two SIMDs) of a sample's workgroup
     "cfg1": dict(bf16_mfma=16 + 6, fp32_mfma=0, kin_bf16_flop=0, rec_simds=2, pipe16="f16_mfma", terms=3,
@@ -94,7 +93,7 @@ EXECUTED = {
                   note="fused core on two-piece fp16 operands, S2 (tile pairs, four terms in two MFMAs) inside the gate waves"),
     # cfg4, per layer: S2 32 tiles x 1 + S10 4 tiles x 16 k-blocks x 3 terms (fp16 pieces); K-in: dense GEMM on fp16 pieces,
     # 3 terms, contraction padded to 64 (layer 0, in = 40) / 256 (layers 1, 2)
-    "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=3 * 2 * 1024 * (64 + 256 + 256), rec_simds=4,
+    "cfg4": dict(bf16_mfma=3 * (32 + 192), fp32_mfma=0, kin_bf16_flop=3 * 2 * 1024 * (64 + 256 + 256), rec_simds=4, rec_wgs_per_cu=2,
                  pipe16="f16_mfma", terms=3,
                  note="per layer: fused core (r = 16) on two-piece fp16 operands (four-wave workgroups, two per CU) + K-in as one "
                       "dense GEMM over B*T rows on two-piece fp16 operands (three terms)"),
@@ -102,7 +101,7 @@ EXECUTED = {
     # stage 0 4 feature tiles x 4 row tiles x 16 k-blocks x 3 terms, over the 8 SIMDs of a workgroup pair; K-in: dense GEMM on
     # fp16 pieces
     "cfg5": dict(bf16_mfma=128 * 2 * 3 + 4 * 4 * 16 * 3, fp32_mfma=0,
-                 kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, pipe16="f16_mfma", terms=3,
+                 kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, rec_wgs_per_sample=2, pipe16="f16_mfma", terms=3,
                  note="K-rec: merged 2-core chain on two-piece fp16 operands (three terms per product), two workgroups per "
                       "sample, every core fragment resident (registers + a quarter of stage 1's in LDS); K-in: dense GEMM on two-piece fp16 operands (three terms)"),
 }
@@ -460,6 +459,8 @@ def main():
         torch.manual_seed(2222 + rank)
         target = torch.randint(0, n_cls, (w["B"],), device=device)
         reducer = FlatGradAllReduce(model, force=force_dist) if dist is not None else None
+        if reducer is not None and backend != "gloo" and not args.graph:
+            reducer.timer = timer      # events around the bucket copies and the all-reduce (reported under "collectives_measured")
         if args.graph:
             import ttrnn_hip
             opt = ttrnn_hip.adam_for_capture(model.parameters(), lr=1e-3)
@@ -515,10 +516,13 @@ def main():
     timer.enabled = True
     t0 = time.perf_counter()
     last = None
+    # Events inside the timed region: ONE pair per library call (ttrnn_hip.functional's KERNEL_TIMER hooks around
+    # ttrnn_rnn_forward_cores / _backward) — the roofline's launch durations.  Until round 5 a second pair bracketed every step
+    # ("step" events): on this stack an event record is a barrier packet in the queue, the two extra records cost 9 us of GPU
+    # timeline per 0.5 ms step (tools/gap_report.sh: 18.8 us between one step's recurrent kernel and the next step's first
+    # launch with four records per step, back to back without), i.e. the harness was 2 % of the figure it reported.
     for _ in range(args.steps):
-        timer.start("step")
         last = step()
-        timer.stop("step")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -559,7 +563,7 @@ def main():
     ranks_bad = int(round(float(bad.item())))
     kern_ms = timer.mean_ms("ttrnn_rnn_forward")
     kern_ms_median = timer.median_ms("ttrnn_rnn_forward")
-    step_ms_median = timer.median_ms("step")          # per-step device time (events on the launch stream)
+    step_ms_median = None                             # (per-step events removed in round 5: see the timed loop)
     launches_per_step = timer.count("ttrnn_rnn_forward") / float(max(args.steps, 1))
     if eager_kern_ms is not None:                     # --graph: the recurrent launches' duration from the eager steps before capture
         kern_ms, kern_ms_median, launches_per_step = eager_kern_ms
@@ -661,6 +665,16 @@ def main():
                                           "the time the matrix pipe of an OCCUPIED CU is busy (B < 256 leaves CUs idle on "
                                           "top of that); PMC-measured counterpart: profiles/".format(rec_cycles, per_cu),
                         "note": ex["note"]}
+        frac_algo = achieved / peak
+        dense_kin = bool(ex and ex.get("kin_bf16_flop"))
+        if executed is not None and (dense_kin or frac_algo > 1.0):
+            roof_frac, roof_basis = executed["frac"], "executed MFMA instruction mix / peak of the pipe it ran on (" + executed["pipe"] + ")"
+        else:
+            roof_frac = min(frac_algo, 1.0) if executed is None else frac_algo
+            roof_basis = "algorithmic FLOPs of the reference's chain (SURVEY.md 8(d)) / " + ("fp32" if arith == "f32" else "bf16") + " MFMA peak"
+        wg_per_sample = (ex or {}).get("rec_wgs_per_sample", 1)
+        wg_per_cu = (ex or {}).get("rec_wgs_per_cu", 1)
+        chip_occ = min(1.0, w["B"] * wg_per_sample / float(wg_per_cu) / 256.0)
         line = {
             "metric": ("timesteps/sec/GPU (batch={}) {} h={} ncores={} rank={}" if args.scaling == "weak" else
                        "timesteps/sec of the GLOBAL batch {} sharded over the GPUs, {} h={} ncores={} rank={}").format(
@@ -699,7 +713,19 @@ def main():
                                 backend, world, " (forced one-rank group, TTRNN_BENCH_FORCE_DIST=1)" if force_dist and world == 1 else "",
                                 "; flat-bucket gradient all-reduce per step" if args.mode == "train" else "")),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         # `frac` is a fraction of a roof and never exceeds 1: the algorithmic figure
+                         # (SURVEY 8(d) FLOPs of the reference's chain / the arithmetic dtype's MFMA peak) where the route
+                         # evaluates that chain on the TT cores; where it runs a cheaper contraction order (K-in as a dense GEMM of
+                         # the materialised matrix: cfg4, cfg5) or the algorithmic figure exceeds 1, the EXECUTED instruction mix
+                         # over the peak of the pipe it ran on.  Both are always reported beside it.
+                         "frac": roof_frac, "frac_basis": roof_basis,
+                         "frac_algorithmic": achieved / peak,
+                         "frac_executed": (executed or {}).get("frac"),
+                         "pipe": (executed or {}).get("pipe"),
+                         "chip_occupancy": chip_occ,
+                         "chip_occupancy_note": "CUs holding a workgroup of the recurrent kernel / 256 (one sample per workgroup; "
+                                                "batch < 256 leaves CUs idle by construction)",
+                         "traffic": traffic,
                          "kernel": ("the persistent recurrent kernel alone (events around ttrnn_rnn_forward_phase(RUN) on prepared "
                                     "modules, same process)" if rec_only_ms is not None else
                                     "ttrnn_rnn_forward (K-in batched input projection + K-rec persistent recurrent kernel)"),
@@ -717,6 +743,17 @@ def main():
                                       "FLOPs than the reference's chain on a faster pipe; `executed` is the bounded figure",
                          "executed": executed},
         }
+        if reducer is not None:
+            # what the gradient exchange of a step costs on the device: events on the launch stream around
+            # the whole sync (bucket copy-in, all-reduce, scale, copy-out) and around the all-reduce call alone, rank 0
+            line["collectives_measured"] = {
+                "bucket_bytes": reducer.nbytes, "world": world,
+                "grad_sync_ms_mean": timer.mean_ms("grad_sync"), "grad_sync_ms_median": timer.median_ms("grad_sync"),
+                "all_reduce_ms_mean": timer.mean_ms("all_reduce"), "all_reduce_ms_median": timer.median_ms("all_reduce"),
+                "calls": timer.count("all_reduce"),
+                "note": "one flat fp32 bucket, one all-reduce (SUM) per step + 1/world scale; device time on rank 0 between "
+                        "events recorded on the launch stream (the RCCL kernel runs on its own stream: the pair brackets the "
+                        "wait for it); no multi-GPU scaling curve has been measured so far (no 8-GPU node in rounds 1 - 5)"}
         line["ranks_seen"] = ranks_seen
         line["checked"] = {"finite": finite, "tensors": len(checked), "ranks_bad": ranks_bad,
                            "what": ("loss + every parameter gradient of the last timed step" if args.mode == "train" else

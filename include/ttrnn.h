@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 5
+#define TTRNN_ABI_VERSION 6
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {
@@ -137,7 +137,7 @@ int ttrnn_get_fp32_math(void);
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
  *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path),
- *   "no_gemm3", "dev" (0..65535: developer bit mask, A/B route switches between kernels that compute the same result;
+ *   "no_gemm3", "dev" (0..1048575: developer bit mask, A/B route switches between kernels that compute the same result;
  *   csrc/ttrnn_opts.h lists the bits).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
@@ -274,6 +274,20 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
                             const float* packed_in, const void* bias_in,
                             const float* packed_hid, const void* bias_hid,
                             void* out, void* hT, void* cT, float* reserve,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ABI 6.  ttrnn_pack_cores2 + ttrnn_rnn_forward in ONE call, for callers whose weights may have changed since the last call (a
+ * training loop, the module API of tensorized_rnn/lstm.py:101-135 whose Parameters an optimizer updates in place): `cores_*` /
+ * `strides_*` as ttrnn_pack_cores (t3nsor/ops.py:47-51 parameter views, storage dtype = desc->dtype), `packed_in` / `packed_hid`
+ * (ttrnn_packed_elems floats each) are WRITTEN — the backward entry points read them.  Results are bit-identical to the two calls.
+ * ttrnn_rnn_forward_cores_fused: 1 when the descriptor's route does all of its weight-only work (packing, the unit-row input
+ * projection of input_size == 1, scale header, MFMA fragments) in one set-up launch under the current options — two launches per
+ * forward instead of five (BASELINE configs[1]: 0.518 -> 0.49 ms per call); 0: the call is exactly pack + forward. */
+int ttrnn_rnn_forward_cores_fused(const ttrnn_rnn_desc* desc);
+int ttrnn_rnn_forward_cores(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,
+                            const void* const* cores_in, const int64_t* strides_in, const void* bias_in,
+                            const void* const* cores_hid, const int64_t* strides_hid, const void* bias_hid,
+                            float* packed_in, float* packed_hid, void* out, void* hT, void* cT, float* reserve,
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Which family of kernels ttrnn_rnn_forward would run for this descriptor under the current options (pure host logic, no

@@ -32,7 +32,7 @@ struct OptTable {
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
       else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
-      else if (i == OPT_DEV) val = e ? (atoi(e) & 0xFFFF) : 0;
+      else if (i == OPT_DEV) val = e ? (atoi(e) & 0xFFFFF) : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -61,7 +61,7 @@ int opt_set(const char* name, int value) {
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
   if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
-  if (i == OPT_DEV && (value < 0 || value > 0xFFFF)) return -1;
+  if (i == OPT_DEV && (value < 0 || value > 0xFFFFF)) return -1;
   if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;
@@ -770,6 +770,43 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_rnn_fwd_generic(rs, p, desc->dtype, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT,
                                 reserve, workspace, (hipStream_t)stream);
+}
+
+// ttrnn_pack_cores2 + ttrnn_rnn_forward as ONE call (include/ttrnn.h).  Where the route has a fused set-up launch
+// (ttrnn_fast_setup.hip) that is: set-up kernel + recurrent kernel — two launches instead of five; elsewhere exactly the two calls.
+int ttrnn_rnn_forward_cores_fused(const ttrnn_rnn_desc* desc) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  return !force_generic() && rs.B > 0 && rs.T > 0 && phase_split_ok(rs, desc->dtype) && f10_setup_available(rs, desc->dtype) ? 1 : 0;
+}
+
+int ttrnn_rnn_forward_cores(const ttrnn_rnn_desc* desc, const void* x, const void* h0, const void* c0,
+                            const void* const* cores_in, const int64_t* strides_in, const void* bias_in,
+                            const void* const* cores_hid, const int64_t* strides_hid, const void* bias_hid,
+                            float* packed_in, float* packed_hid, void* out, void* hT, void* cT, float* reserve,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  RnnShape rs;
+  int st = rnn_shape_init(&rs, desc);
+  if (st != TTRNN_OK) return st;
+  if (!cores_in || !strides_in || !cores_hid || !strides_hid || !packed_in || !packed_hid) return TTRNN_ERR_NULL;
+  for (int k = 0; k < rs.in_s.d; ++k) if (!cores_in[k]) return TTRNN_ERR_NULL;
+  for (int k = 0; k < rs.hid_s.d; ++k) if (!cores_hid[k]) return TTRNN_ERR_NULL;
+  if (rs.B > 0 && rs.T > 0 && ttrnn_rnn_forward_cores_fused(desc)) {
+    if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
+    const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+    if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes)
+      return TTRNN_ERR_WORKSPACE;
+    st = launch_f10_setup(rs, cores_in, strides_in, bias_in, cores_hid, strides_hid, packed_in, packed_hid, (float*)workspace,
+                          (char*)workspace + f.gin_bytes + f.lin_ws_bytes, (hipStream_t)stream);
+    if (st != TTRNN_OK) return st;
+    return ttrnn_rnn_forward_phase(desc, TTRNN_PHASE_RUN, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve,
+                                   workspace, workspace_bytes, stream);
+  }
+  st = launch_pack2(rs.in_s, cores_in, strides_in, packed_in, rs.hid_s, cores_hid, strides_hid, packed_hid, desc->dtype,
+                    (hipStream_t)stream);
+  if (st != TTRNN_OK) return st;
+  return ttrnn_rnn_forward(desc, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace,
+                           workspace_bytes, stream);
 }
 
 int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {

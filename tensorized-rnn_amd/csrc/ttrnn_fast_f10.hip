@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64) k_f10h_prep(const float* __restrict__ pack
     float v = 0.f;
     for (int r1 = 0; r1 < F::R1; ++r1) v = fmaf(W0[(j0 * F::R1 + r1) * F::I0 + i0], w1p[r1], v);
     _Float16 p0, p1;
-    split2h(v * (gf * f10h_w_scale<S>(hdr, m, r2)), p0, p1);
+    split2h_scaled(v, gf * f10h_w_scale<S>(hdr, m, r2), p0, p1);      // (pinned rounding: ttrnn_split.h)
     f0[e] = p0; f1[e] = p1;
   }
   xh8* dst = wfrag + (size_t)((t * F::NM + u) * 2) * 64 + lane;

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   using F = F10<S>;
   constexpr int H = F::H;
   __shared__ __attribute__((aligned(16))) _Float16 img[2 * F::PLANE];    // S10 operand, two fp16 planes [I2][K10]
-  __shared__ __attribute__((aligned(16))) float gbuf[3 * H];             // gate pre-activations of the hidden chain
+  __shared__ __attribute__((aligned(16))) float gbuf[3 * H + 128];       // SCALED gate sums of the hidden chain (+ a dump for the padding columns)
   __shared__ float hmax[4];                                              // H0: the waves' maxima of |h_t|
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,14 +99,20 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   for (int u = 0; u < F::NM; ++u)
 #pragma unroll
     for (int p = 0; p < 2; ++p) w10[p][u] = wfrag[(size_t)((wave * F::NM + u) * 2 + p) * 64 + lane];
-  // un-scale of accumulator register j of lane (c, q): row m = 16 wave + 4q + j, column i2 = c
-  f32x4 usc;
+  // The accumulators of S10 carry 2^(ep[m] + eu[i2] + 12); they go to the gate vector as they are (one add per register) and the
+  // GATE thread multiplies its three sums back (a per-thread constant folded into an fma): o = g H + hid = m I2 + i2
+  f32x4 usc;                // gate g of this thread's unit (slot 3 unused)
   {
     const int* e = reinterpret_cast<const int*>(hdr);
-    const int eu = e[F10H_EU + (c < F::I2 ? c : F::I2 - 1)];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) usc[j] = ldexpf(1.f, -(e[F10H_EP + 16 * wave + 4 * q + j] + eu + 12));
+    for (int g = 0; g < 3; ++g) {
+      const int o = g * H + tid;
+      usc[g] = ldexpf(1.f, -(e[F10H_EP + o / F::I2] + e[F10H_EU + o % F::I2] + 12));
+    }
+    usc[3] = 0.f;
   }
+  // where lane (c, q) puts accumulator register j: row m = 16 wave + 4q + j, column i2 = c (columns >= I2: the dump)
+  const int gdst = c < F::I2 ? (16 * wave + 4 * q) * F::I2 + c : 3 * H + lane;
 
   const float* __restrict__ gin = gs.gin;
   const float* __restrict__ xs = reinterpret_cast<const float*>(gs.x);
@@ -150,12 +156,9 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
     {
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
       f10h_s10_part<S, F::NM>(w10, img, row10, q, 0, acc_lo, acc_hi);
-      const f32x4 un = H0 ? un_t : usc;
-      const f32x4 acc = acc_hi * un + acc_lo * un;          // exact powers of two
-      if (c < F::I2) {
+      const f32x4 acc = acc_hi + acc_lo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gbuf[(16 * wave + 4 * q + j) * F::I2 + c] = acc[j];   // o = m*I2 + i2
-      }
+      for (int j = 0; j < 4; ++j) gbuf[gdst + j * F::I2] = acc[j];   // o = m*I2 + i2
     }
     TT_STAMP(0)
     lds_barrier();
@@ -164,9 +167,10 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
     const size_t bt = b * T + t;
     {
       if (in1) gi = bb + xq.at(t) * vv;
-      const float hn = gbuf[2 * H + hid] + bh[2];
-      const float rg = fsigmoid(gi[0] + gbuf[hid] + bh[0]);              // gru.py:38-39
-      const float zg = fsigmoid(gi[1] + gbuf[H + hid] + bh[1]);          // gru.py:40-41
+      const f32x4 un = H0 ? un_t : usc;
+      const float hn = fmaf(gbuf[2 * H + hid], un[2], bh[2]);
+      const float rg = fsigmoid(gi[0] + fmaf(gbuf[hid], un[0], bh[0]));              // gru.py:38-39
+      const float zg = fsigmoid(gi[1] + fmaf(gbuf[H + hid], un[1], bh[1]));          // gru.py:40-41
       const float ng = ftanh(gi[2] + rg * hn);                           // gru.py:42-43
       const float hy = (1.0f - zg) * ng + zg * hst;                      // gru.py:44
       if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};

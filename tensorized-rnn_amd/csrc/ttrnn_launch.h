@@ -155,6 +155,11 @@ size_t f10gq_workspace_bytes();
 bool f10gq_available(const RnnShape& rs, int dtype);
 int launch_gru_fwd_f10gq(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid,
                          void* out, void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
+// ONE launch for pack + unit-row K-in + scale header + fragments of an input_size == 1 fused-core forward (ttrnn_fast_setup.hip)
+bool f10_setup_available(const RnnShape& rs, int dtype);
+int launch_f10_setup(const RnnShape& rs, const void* const* cores_in, const int64_t* strides_in, const void* bias_in,
+                     const void* const* cores_hid, const int64_t* strides_hid, float* packed_in, float* packed_hid, float* gin,
+                     void* ws, hipStream_t stream);
 // the four-/eight-wave LSTM kernel with ONE barrier per step, S2 inside the gate waves (ttrnn_fast_f10s.hip); ws as launch_rnn_fwd_f10_q
 bool f10s_available(const RnnShape& rs, bool with_h0);
 int launch_rnn_fwd_f10_s(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid, const void* ws,

@@ -106,6 +106,21 @@ __device__ __forceinline__ void split2h(float v, _Float16& p0, _Float16& p1) {
   p0 = (_Float16)v;
   p1 = (_Float16)(v - (float)p0);
 }
+// The pieces of a product v s whose factor s is NOT a power of two (the fused core's rows carry the gate factors -log2 e / 2 log2 e):
+// p0 = fp16(fl32(v s)), p1 = fp16(v s - p0) with the residual taken from the UNROUNDED product (one fma).  Under -ffp-contract=fast
+// hipcc is free to form that fma or not wherever split2h(v * s) is inlined — k_f10h_prep did, another instantiation of the same
+// expression (the fused set-up kernel) did not, and two of 16 384 fragment entries differed by an ulp.  Pinned here: the
+// multiplication and the fma are opaque to the optimiser (an explicit fmaf was not enough: behind it the conversion to fp16 folded
+// into v_fma_mixlo_f16 in one kernel and not in the other — one rounding against two, one entry of 16 384), so every kernel that
+// builds these fragments agrees bit for bit, and with what k_f10h_prep has produced since round 3 (tools/ab_vs_r4.py).
+__device__ __forceinline__ void split2h_scaled(float v, float s, _Float16& p0, _Float16& p1) {
+  float t, r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(s));
+  p0 = (_Float16)t;
+  const float p0f = (float)p0;
+  asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(r) : "v"(v), "v"(s), "v"(p0f));      // (opaque: an fptrunc(fma) folds into ONE v_fma_mixlo_f16,
+  p1 = (_Float16)r;                                                            // i.e. one rounding instead of two, where hipcc sees it)
+}
 // four consecutive elements -> two 8-byte stores (planes 0 and 1)
 __device__ __forceinline__ void store_split4_h(_Float16* img, int plane_elems, int off, f32x4 v) {
   unsigned a0, b0, a1, b1;

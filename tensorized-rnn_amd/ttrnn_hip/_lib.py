@@ -13,7 +13,7 @@ TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
 PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 BWD_STATS_COLMAX, BWD_STATS_IN1SUMS, BWD_STATS_ROWS = 1, 2, 4
 BWD_STATS_ROWMAX = 4          # stats = [4][G*H] + [B*T]: the rows' maxima behind the four rows
 
@@ -84,6 +84,11 @@ _SIGNATURES = {
     "ttrnn_rnn_prepare_supported": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_out_optional": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward_phase": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int] + [_P] * 12 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_forward_cores_fused": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_forward_cores": (ctypes.c_int, [ctypes.POINTER(RnnDesc), _P, _P, _P,
+                                               ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), _P,
+                                               ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), _P,
+                                               _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward_workspace_ex": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
     "ttrnn_rnn_backward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int]),

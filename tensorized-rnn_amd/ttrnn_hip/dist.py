@@ -54,6 +54,9 @@ class FlatGradAllReduce(object):
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # optional device timing of the collective (bench.py: so that the first multi-GPU run explains its own efficiency):
+        # set `timer` to an object with start(name) / stop(name) recording events on the current stream
+        self.timer = None
 
     @property
     def nbytes(self):
@@ -81,7 +84,15 @@ class FlatGradAllReduce(object):
         if self.world == 1 and not (self.force and dist.is_initialized()):
             return
         views, grads = self._views()
+        if self.timer is not None:
+            self.timer.start("grad_sync")
         torch._foreach_copy_(views, grads)
+        if self.timer is not None:
+            self.timer.start("all_reduce")
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.timer is not None:
+            self.timer.stop("all_reduce")
         self.flat.mul_(1.0 / self.world)
         torch._foreach_copy_(grads, views)
+        if self.timer is not None:
+            self.timer.stop("grad_sync")

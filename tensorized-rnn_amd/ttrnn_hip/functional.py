@@ -395,7 +395,13 @@ class _TTRnnLayerFn(torch.autograd.Function):
         H = spec.hidden_size
         dev = x.device
         desc = spec.desc(B, T, _dtype_code(x))
-        packed_in, packed_hid = TTSpec.pack_pair(spec.in_spec, cores_in, spec.hid_spec, cores_hid)
+        # packing + forward as ONE C call (ABI 6: ttrnn_rnn_forward_cores — where the route has a fused set-up launch, two
+        # launches per forward instead of five; elsewhere exactly ttrnn_pack_cores2 + ttrnn_rnn_forward)
+        _require_device(*(list(cores_in) + list(cores_hid)))
+        packed_in = _alloc((spec.in_spec.packed_elems,), torch.float32, dev)
+        packed_hid = _alloc((spec.hid_spec.packed_elems,), torch.float32, dev)
+        ptrs_in, strides_in = spec.in_spec._core_args(cores_in)
+        ptrs_hid, strides_hid = spec.hid_spec._core_args(cores_hid)
         out = _alloc((B, T, H), x.dtype, dev)
         hT = _alloc((B, H), x.dtype, dev)
         cT = _alloc((B, H), x.dtype, dev) if spec.cell == "lstm" else None
@@ -409,9 +415,10 @@ class _TTRnnLayerFn(torch.autograd.Function):
         wsb = lib.ttrnn_rnn_workspace(ctypes.byref(desc))
         ws = _workspace(wsb, dev)
         with _timed("ttrnn_rnn_forward"):
-            check(lib.ttrnn_rnn_forward(ctypes.byref(desc), _ptr(x), _ptr(h0), _ptr(c0), _ptr(packed_in),
-                                        _ptr(bias_in), _ptr(packed_hid), _ptr(bias_hid), _ptr(out), _ptr(hT),
-                                        _ptr(cT), _ptr(reserve), _ptr(ws), wsb, _stream(x)), "ttrnn_rnn_forward")
+            check(lib.ttrnn_rnn_forward_cores(ctypes.byref(desc), _ptr(x), _ptr(h0), _ptr(c0), ptrs_in, strides_in,
+                                              _ptr(bias_in), ptrs_hid, strides_hid, _ptr(bias_hid), _ptr(packed_in),
+                                              _ptr(packed_hid), _ptr(out), _ptr(hT), _ptr(cT), _ptr(reserve), _ptr(ws), wsb,
+                                              _stream(x)), "ttrnn_rnn_forward_cores")
         if stats is not None:
             # LSTM reserve: gates [B][T][H][4], then the cell states [B][T][H] (ttrnn_core.h: res_gate / res_cell)
             stats.forward(out, reserve[4 * B * T * H:].view(B, T, H) if spec.cell == "lstm" else None)

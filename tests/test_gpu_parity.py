@@ -2597,6 +2597,51 @@ def test_single_barrier_forward_kernel_matches_two_barrier_kernel_and_oracle(H, 
     assert worst <= 1e-4
 
 
+@pytest.mark.parametrize("kind", ["ttlstm", "ttgru"])
+def test_fused_setup_launch_is_bit_identical(kind):
+    """ABI 6: ttrnn_rnn_forward_cores on the input_size == 1 fused-core shapes (cfg2's TT-LSTM, the fp32 TT-GRU) does packing, the
+    unit-row input projection, the scale header and the MFMA fragments in ONE set-up launch (ttrnn_fast_setup.hip) instead of four.
+    Same expressions as the kernels it replaces: outputs, final states, the packed cores and EVERY gradient must be bit-identical
+    to the separate launches (option dev bit 16 switches the fused launch off) — strided Parameters (the reference's layout),
+    non-contiguous after an in-place update, with and without biases and initial states."""
+    import ctypes
+    import ttrnn_hip
+    from ttrnn_hip import _lib
+    torch.manual_seed(77)
+    # (B T >= 4 in rows: fewer rows take the per-row weight-gradient kernels, whose atomics are not repeatable — DESIGN 9)
+    for bias, with_state, B, T in ((True, False, 32, 40), (False, True, 70, 17), (True, True, 130, 9)):
+        meta = dict(kind=kind, input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, bias=bias)
+        m = build_module(meta, dev())
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.0 + 0.1 * torch.rand_like(p))
+        x = torch.randn(B, T, 1, device=dev())
+        h0 = torch.randn(B, 256, device=dev()) * 0.5 if with_state else None
+        init = None if h0 is None else ((h0, torch.randn(B, 256, device=dev())) if kind == "ttlstm" else h0)
+        desc = m._all_layers[0]._layer_spec().desc(B, T, 0)
+        res = {}
+        for name, d in (("fused", 0), ("separate", 65536)):
+            with ttrnn_hip.option("dev", d):
+                assert _lib.load().ttrnn_rnn_forward_cores_fused(ctypes.byref(desc)) == (1 if d == 0 else 0)
+                with torch.no_grad():
+                    r = m(x, init)
+                m.zero_grad()
+                o = m(x, init)            # (x not differentiated: a differentiated first-layer input takes the per-row
+                hT = o[1][0] if kind == "ttlstm" else o[1]      # weight-gradient kernels, whose atomics are not repeatable — DESIGN 9)
+                ((o[0] * torch.linspace(-1, 1, 256, device=dev())).sum() + hT.sum()).backward()
+                res[name] = (r, o, None, {n: p.grad.clone() for n, p in m.named_parameters()})
+        fa, se = res["fused"], res["separate"]
+        assert torch.equal(fa[0][0], se[0][0]) and torch.equal(fa[1][0], se[1][0])
+        sa = fa[0][1] if kind == "ttlstm" else (fa[0][1],)
+        sb = se[0][1] if kind == "ttlstm" else (se[0][1],)
+        for a, b_ in zip(sa, sb):
+            assert torch.equal(a, b_)
+        for n in fa[3]:
+            assert torch.equal(fa[3][n], se[3][n]), n
+    with ttrnn_hip.fp32_math("exact"):      # other math mode: no fused launch, the call is pack + forward
+        assert _lib.load().ttrnn_rnn_forward_cores_fused(ctypes.byref(desc)) == 0
+
+
 def _cfg3_fp32_module(inp=1, L=1):
     torch.manual_seed(1111)
     return build_module(dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=8), dev())
