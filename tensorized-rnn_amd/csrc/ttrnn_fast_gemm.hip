@@ -406,11 +406,12 @@ __device__ __forceinline__ f32x4 ld4_rows(const TS* __restrict__ x, const RowShi
 // stores the workgroup's sum to bpart[ks][column], and k_dense_bias_reduce adds the row ranges in a fixed order:
 // repeatable bit for bit, no atomics.
 template <int W, int G>
-__device__ __forceinline__ void bias_partial(float* red, const f32x4& v, int group, int col4, float* __restrict__ dst, int tid) {
+__device__ __forceinline__ void bias_partial(float* red, const f32x4& v, int group, int col4, float* __restrict__ dst, int tid,
+                                             int ncols = W) {      // ncols < W: a last, partly filled column tile
   lds_barrier();                                           // every wave is done with the staging buffers `red` overlays
   *reinterpret_cast<f32x4*>(red + group * W + col4) = v;
   lds_barrier();
-  if (tid < W) {
+  if (tid < ncols) {
     float sum = red[tid];
 #pragma unroll
     for (int g = 1; g < G; ++g) sum += red[g * W + tid];
@@ -452,7 +453,10 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const int TJ = (IN + DenseG::TM - 1) / DenseG::TM, TO = OUT / DenseG::TN;      // a last, partly filled j tile is masked
+  // a last, partly filled j tile is masked; so is a last column tile (round 5: gate widths that are not a multiple of 128 — a TT-GRU
+  // with H = 64 has 192 — used to leave this route for the per-row kernels and their atomics: 12 of the 16 grid shapes whose
+  // gradients were not repeatable in round 4)
+  const int TJ = (IN + DenseG::TM - 1) / DenseG::TM, TO = (OUT + DenseG::TN - 1) / DenseG::TN;
   int tj, to, ks;
   if (KS == 1 && TJ == 8 && TO == 32) {
     // one workgroup per tile: the 32 workgroups of an XCD form a 4 x 8 block of tiles
@@ -489,6 +493,8 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
   const int srow = tid >> 5, scol = (tid & 31) * 4;
   const bool jin = j0 + scol + 4 <= IN;                   // IN % 4 == 0: a column quad is in or out as a whole
   const int jc = jin ? j0 + scol : 0;
+  const bool oin = o0 + scol + 4 <= OUT;                  // OUT % 4 == 0 likewise
+  const int oc = oin ? o0 + scol : 0;
   f32x4 sx[SR], sd[SR];
   auto stage_load = [&](int64_t nb) {
 #pragma unroll
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
       const int64_t n = nb + srow + 16 * e;
       const int64_t nc = n < r1 ? n : r1 - 1;               // unconditional loads; rows past the end are zeroed at the store
       sx[e] = ld4_rows(x, rsh, nc, IN, jc);
-      sd[e] = ld4(dy, (size_t)nc * OUT + o0 + scol);
+      sd[e] = ld4(dy, (size_t)nc * OUT + oc);
     }
   };
   stage_load(r0);
@@ -508,7 +514,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
 #pragma unroll
     for (int e = 0; e < SR; ++e) {
       const float keep = r0 + ch * KB + srow + 16 * e < r1 ? 1.0f : 0.0f;
-      const f32x4 vd = sd[e] * keep;
+      const f32x4 vd = sd[e] * (oin ? keep : 0.0f);
       *reinterpret_cast<f32x4*>(xb + (srow + 16 * e) * LS + scol) = sx[e] * (jin ? keep : 0.0f);
       *reinterpret_cast<f32x4*>(db + (srow + 16 * e) * LS + scol) = vd;
       dbs += vd;
@@ -537,7 +543,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int jj = j0 + wm * 64 + 16 * mi + 4 * q + j;
-        if (jj < IN) {
+        if (jj < IN && o0 + wn * 32 + 16 * ni + c < OUT) {
           const size_t e = (size_t)jj * OUT + o0 + wn * 32 + 16 * ni + c;
           if (KS == 1) dW[e] = acc[mi][ni][j];
           else if (part) part[(size_t)ks * IN * OUT + e] = acc[mi][ni][j];      // summed by k_dense_reduce
@@ -545,7 +551,7 @@ __global__ void __launch_bounds__(FAST_NT) k_dense_wgrad(int64_t n_rows, int IN,
         }
       }
   if (want_bias)      // 16 staging rows x 32 column quads: sixteen groups over the tile's 128 columns
-    bias_partial<DenseG::TN, 16>(ldsf, dbs, srow, scol, bpart + (size_t)ks * OUT + o0, tid);
+    bias_partial<DenseG::TN, 16>(ldsf, dbs, srow, scol, bpart + (size_t)ks * OUT + o0, tid, OUT - o0 < DenseG::TN ? OUT - o0 : DenseG::TN);
 }
 
 // ---- the same dense gradient on the bf16 MFMA (split arithmetic) ---------------------------------------------------------------
@@ -1027,7 +1033,7 @@ int launch_gemm_split(int dtype, int64_t n_rows, int K, int M, const void* x, co
 bool dense_wgrad_shift_ok(int64_t n_rows, int64_t shift_T) {
   return n_rows < ((int64_t)1 << 31) && shift_T >= DenseS::KB && shift_T < ((int64_t)1 << 31);
 }
-bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out % DenseG::TN == 0; }
+bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out >= 4 && out % 4 == 0; }      // (fp32-MFMA kernel: any such width)
 
 // dW (fp32 [in][out]) = x^T dy over n_rows rows (overwritten); d_bias (may be NULL) is accumulated into.
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
@@ -1097,7 +1103,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   }
   const int KBc = split ? DenseS::KB : DenseG::KB;
   const int tiles = split ? ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO)
-                          : ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
+                          : ((in + DenseG::TM - 1) / DenseG::TM) * ((out + DenseG::TN - 1) / DenseG::TN);
   int KS = 1;
   if (tiles < cus) {
     // multiple of 8: one row range per XCD at a time — rounded DOWN where rounding up would not fit the chip in one go
@@ -1165,7 +1171,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
 size_t dense_wgrad_scratch_bytes(int in, int out) {
   const int cus = device_cu_count();
   const int tiles_s = ((in + DenseS::TJ - 1) / DenseS::TJ) * (out / DenseS::TO > 0 ? out / DenseS::TO : 1);
-  const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * (out / DenseG::TN);
+  const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * ((out + DenseG::TN - 1) / DenseG::TN);
   const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;
   if (tiles >= cus) return dense_colmax_bytes(in, out) + dense_bias_part_bytes(out);
   const int KS = ((cus / tiles + 7) / 8) * 8;

@@ -1402,6 +1402,9 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   w.gin = g2_al((size_t)rows * 4 * rs.H * sizeof(float));
   w.bilv = g2_al((size_t)4 * rs.H * sizeof(float));
   w.rec = g2_fwd_ws_bytes(p.hid);
+  // (H = 512, r = 8 in split mode: the same region is the fused-core forward kernel's fragment workspace — sized for it whatever
+  // this tier's own plan needs, so that the route report and the launch cannot disagree: ADVICE r4)
+  if (f10_h512_fwd_available(rs, TTRNN_F32) && w.rec < g2_al(f10_h512_workspace_bytes())) w.rec = g2_al(f10_h512_workspace_bytes());
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
@@ -1476,8 +1479,10 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   // the reference's default benchmark shape (H = 512, r = 8) in split mode: the fused-core forward kernel on the gin just built
   // (both biases are folded into it), this tier's `rec` region as its fragment workspace (ttrnn_fast_f10.hip)
-  if (f10_h512_fwd_available(rs, dtype) && L.rec >= f10_h512_workspace_bytes())
+  if (f10_h512_fwd_available(rs, dtype)) {
+    if (L.rec < f10_h512_workspace_bytes()) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)
     return launch_rnn_fwd_f10_h512(rs, gin, h0, c0, packed_hid, out, hT, cT, reserve, rec, stream);
+  }
   const xbf8* fs2;
   const float* ft1;
   const int* hdr = nullptr;

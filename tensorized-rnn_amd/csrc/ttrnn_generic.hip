@@ -163,6 +163,10 @@ size_t in1_reduce_part_bytes(int out) { return (size_t)IN1_PARTS * 2 * out * siz
 int launch_in1_reduce(int dtype, int dy_dtype, int64_t n_rows, int out, const void* x, const void* dy, float* dv,
                       float* db, float* part, hipStream_t stream) {
   // at most IN1_PARTS workgroups (two per CU), each leaving one row of partial sums
+  if (n_rows <= 0) {      // no rows: the sums are zero (k_in1_finish would add up a partial row nobody wrote — ADVICE r4)
+    if (hipMemsetAsync(dv, 0, (size_t)out * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+    return TTRNN_OK;
+  }
   if (!part) return TTRNN_ERR_WORKSPACE;
   int rows_per_wg = (int)((n_rows + IN1_PARTS - 1) / IN1_PARTS);
   rows_per_wg = (rows_per_wg + 7) & ~7;
@@ -495,9 +499,14 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows, bool fixed_order) {
   p.acc_slab = false;
   p.acc_fixed = false;
   p.slab_off = 0;
-  if (p.acc_lds && fixed_order && p.grid > 1 && (size_t)p.grid * acc <= ((size_t)64 << 20)) {
+  if (p.acc_lds && fixed_order && p.grid > 1) {
     // the caller wants repeatable sums (the pull-back of a dense weight gradient onto the cores: `in` rows, one workgroup each):
-    // LDS accumulators as before, flushed into a slab per workgroup instead of through atomics
+    // LDS accumulators as before, flushed into a slab per workgroup instead of through atomics.  At most 256 workgroups, each
+    // walking several tiles (the kernel strides its tiles by gridDim.x), so that the slabs stay small whatever the shape: round 4
+    // took this branch only while grid x acc fit 64 MB, and d = 4, r = 16 at H >= 768 (768 workgroups x 100 KB) fell back to
+    // atomics — four grid shapes whose hidden-core gradients differed from run to run
+    if (p.grid > 256) p.grid = 256;
+    p.ws_bytes = p.buf_global ? (size_t)p.grid * p.nb * per : 0;
     p.acc_fixed = true;
     p.slab_off = (p.ws_bytes + 255) & ~(size_t)255;
     p.ws_bytes = p.slab_off + (size_t)p.grid * acc;

@@ -3,10 +3,11 @@
 ``tt_shape`` and ``param_count`` follow the reference's ``tensorized_rnn/rnn_utils.py:20-36`` and
 ``:300-309``.  ``ActivGradLogger`` keeps the reference's public surface (``rnn_utils.py:42-226``:
 ``all_loggers``, ``create_hooks``, ``end_minibatch``, ``end_epoch``, ``get_logs``, ``del_record``)
-for ``log_grads=True`` runs; it is a diagnostic, not part of the fused hot path — modules built with
-``log_grads=True`` step their cells one timestep at a time (still on the GPU) so that per-step
-``hy`` / ``cy`` tensors exist for the hooks.  The reference's dead ``project_ttgrad`` helper is out of
-scope.
+for ``log_grads=True`` runs.  Modules built with ``log_grads=True`` stay on the fused sequence path: the
+recurrent kernels hand the logger its per-step statistics (mean ||h_t||^2, ||c_t||^2 from the forward's
+outputs / reserve records, the per-step state gradients from the reverse-time kernel's ``d_state``
+output — ``ttrnn_hip.functional.StepStats``, ``tensorized_rnn/_fused.py``), no cell is stepped one
+timestep at a time.  The reference's dead ``project_ttgrad`` helper is out of scope.
 """
 from collections import deque
 

@@ -139,8 +139,10 @@ OPTIONS_EPOCH = 0
 
 
 def set_fp32_math(mode):
-    """Select how the shape-specialised kernels multiply fp32 operands: "exact" (fp32 MFMA) or "split"
-    (three-way bf16 split, six bf16 MFMA terms, fp32 accumulation).  Process-wide; returns the previous mode."""
+    """Select how the kernels multiply fp32 operands (include/ttrnn.h: TTRNN_MATH_*): "exact" (every product an fp32 MFMA
+    product) or "split" (the default: each fp32 operand as two fp16 pieces under exact power-of-two scales, three fp16 MFMA
+    terms x0w0 + x0w1 + x1w0, fp32 accumulation — three bf16 pieces / six terms in the few kernels whose operand magnitudes
+    are unknown).  Process-wide; returns the previous mode."""
     if mode not in MATH_MODES:
         raise ValueError("fp32 math mode must be one of {}".format(sorted(MATH_MODES)))
     global OPTIONS_EPOCH

@@ -58,6 +58,10 @@ class CapturedTrainStep(object):
         with torch.cuda.graph(self.graph):
             self.static_loss = self._eager_step(zero=False)
         self.replays = 0
+        # the graph holds the kernels the library's options selected AT CAPTURE TIME: a later set_option / set_fp32_math would
+        # silently keep replaying the old route (an A/B under --graph would measure nothing) — remembered and checked per replay
+        from . import _lib
+        self._options_epoch = _lib.OPTIONS_EPOCH
 
     def _eager_step(self, zero=True):
         if zero:
@@ -85,6 +89,10 @@ class CapturedTrainStep(object):
                     raise ValueError("a captured step is bound to its input shapes: expected {} {}, got {} {}".format(
                         tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
                 dst.copy_(src, non_blocking=True)
+        from . import _lib
+        if _lib.OPTIONS_EPOCH != self._options_epoch:
+            raise _lib.TtrnnError("a library option or the fp32 math mode changed after this step was captured: the graph still "
+                                  "holds the kernels of the old setting — capture a new CapturedTrainStep")
         self.graph.replay()
         self.replays += 1
         return self.static_loss
