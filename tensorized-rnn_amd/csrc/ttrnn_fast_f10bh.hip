@@ -199,6 +199,9 @@ constexpr size_t f10bh_lds_bytes() {
          sizeof(_Float16) * 2 * ((size_t)F::I2 * B::K1 + (size_t)F::ROWS2 * B::K2) + (B::XF >= 4 ? sizeof(float) * F::K : 0);
 }
 
+template <class S>
+constexpr size_t f10bp_lds_bytes() { return f10bh_lds_bytes<S>() + (size_t)2 * 2 * F10<S>::H * sizeof(f32x4); }      // + the factor vectors
+
 template <class S, bool DIAG>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const float* __restrict__ c0,
                                                            const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
@@ -478,6 +481,277 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
     if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1, xq2, xq1);
   }
   if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmx[g]));
+    }
+    if (bs.part) {
+      float* pp = bs.part + b * 2 * GH;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pp[g * H + hid] = sxd[g];
+        pp[GH + g * H + hid] = sdg[g];
+      }
+    }
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && diag && b < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) diag[(b * FAST_NW + wave) * 8 + i] = seg[i];
+    }
+  }
+  if (own) {
+    if (d_h0) {
+      float v = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) v += dhs[sl * H + hid];
+      d_h0[b * H + hid] = v;
+    }
+    if (d_c0) d_c0[b * H + hid] = dcs;
+  }
+}
+
+// ---- LSTM, H = 256: the record-dependent half of the gate phase on the helper waves, one step AHEAD (round 5) ------------------
+// In k_lstm_bwd_f10h waves 4-7 sit 540 of the step's 2 851 stamped cycles in the barrier behind the gate phase while waves 0-3
+// walk ~75 dependent instructions per unit (profiles/r4/stamps_cfg2_f10bh.txt).  Half of that chain does not depend on the
+// recurrence at all: with the forward pass's record (i, g, f, o, c_t, c_{t-1}) the gate gradients are LINEAR in (dh_t, dc_t):
+//     dct = dcs + dht A            A  = o (1 - tanh^2 c_t)
+//     p_i = dct P0                 P0 = g i (1 - i)            p_f = dct P1      P1 = c_{t-1} f (1 - f)
+//     p_g = dct P2                 P2 = i (1 - g^2)            p_o = dht P3      P3 = tanh(c_t) o (1 - o)
+//     dcs' = dct f
+// Here waves 4-7 (thread 256 + u <-> unit u) own the records: during the gate phase of step t they turn record t-1 into
+// (A, P0, P1, P2 | P3, f, d_out) — the tanh, the derivative factors, every global load of the kernel — and leave them in LDS;
+// waves 0-3 read two 16-byte vectors and run seven multiply-adds, the wave maximum and the image stores.  The helper waves also
+// take the by-products (column maxima, input_size == 1 sums: from the fp32 image they already read for the HBM row).  T01, T2,
+// scales and barriers are k_lstm_bwd_f10h's.  Products are associated differently (dct (g i (1 - i)) instead of
+// ((dct g) i) (1 - i)): gradients agree with the other reverse kernels to an fp32 ulp of a product, not bit for bit.
+template <class S, bool DIAG>
+__global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10p(int Bn, int T, const float* __restrict__ c0,
+                                                           const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
+                                                           const float* __restrict__ reserve,
+                                                           const float* __restrict__ d_out,
+                                                           const float* __restrict__ d_hT,
+                                                           const float* __restrict__ d_cT, float* __restrict__ dg_in,
+                                                           float* __restrict__ dg_hid, float* __restrict__ d_h0,
+                                                           float* __restrict__ d_c0,
+                                                           unsigned long long* __restrict__ diag, BwdStats bs) {
+  static_assert(f10bh_ok<S>() && F10<S>::H == 256 && F10BH<S>::XF < 4, "H = 256 only: waves 4-7 are the helper waves");
+  using F = F10<S>;
+  using B = F10BH<S>;
+  constexpr int H = F::H, GH = 4 * H;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) float smax1[4];
+  __shared__ float sl1[FAST_NW];
+  constexpr int PL1 = F::I2 * B::K1, PL2 = F::ROWS2 * B::K2;
+  float* dgf = reinterpret_cast<float*>(smem);                               // [4H] in HBM row order
+  float* dhs = dgf + GH;                                                     // [NM2][H]
+  _Float16* img1h = reinterpret_cast<_Float16*>(dhs + B::NM2 * H);           // dg's two fp16 pieces [2][I2][K1] (x_off)
+  _Float16* img2h = img1h + 2 * PL1;                                         // dC2's two fp16 pieces [2][ROWS2][K2] (x_off)
+  f32x4* facA = reinterpret_cast<f32x4*>(img2h + 2 * PL2);                   // [2 parities][H]: A, P0, P1, P2
+  f32x4* facB = facA + 2 * H;                                                // [2 parities][H]: P3, f, d_out, -
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+
+  xh8 w01[B::XF][B::NM1][2], w2t[B::XT2][2];
+  f32x4 un1[B::XF], un2;
+#pragma unroll
+  for (int x = 0; x < B::XF; ++x) {
+#pragma unroll
+    for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
+    un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+  }
+  const int ct = wave % B::CT2;
+#pragma unroll
+  for (int x = 0; x < B::XT2; ++x)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      w2t[x][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ((wave + FAST_NW * x) / B::CT2) * 2 + p) * 64 + lane];
+  un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * q);
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int f = tid; f < F::K; f += FAST_NT) l = fmaxf(l, hdr[B::L1N + f] * hdr[B::UN1 + f]);
+    l = wave_max(l);
+    if (lane == 0) sl1[wave] = l;
+    __syncthreads();
+    maxl1 = sl1[0];
+#pragma unroll
+    for (int w = 1; w < FAST_NW; ++w) maxl1 = fmaxf(maxl1, sl1[w]);
+  }
+
+  const bool own = tid < H;                    // gate thread of unit tid; the others: helper thread of unit tid - H
+  const int hid = own ? tid : tid - H;
+  float dcs = (own && d_cT) ? d_cT[b * H + hid] : 0.f;
+  const float c0v = (!own && c0) ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  const float* xptr = bs.x ? reinterpret_cast<const float*>(bs.x) : reserve;
+  const float xscale = bs.x ? 1.0f : 0.0f;
+  // helper threads: three rotating record sets (gates i,g,f,o | c_t | d_out | x), loads issued two steps ahead
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f, do0 = 0.f, do1 = 0.f, do2 = 0.f, xq0 = 0.f, xq1 = 0.f, xq2 = 0.f;
+  f32x4 cmx = f32x4{0.f, 0.f, 0.f, 0.f}, sxd = cmx, sdg = cmx;      // helper thread: by-products of its unit (gates i, f, g, o)
+  auto issue = [&](int t, f32x4& ra, float& rb, float& dq, float& xq) {      // loads of record t; clamped, unconditional
+    const size_t bt = b * T + (t > 0 ? t : 0);
+    ra = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid));
+    rb = reserve[res_cell((size_t)Bn * T, bt, H, hid)];
+    dq = dptr[bt * H + hid];
+    xq = xptr[bt];
+  };
+  // record s -> the factors of step s (cn: c_{s-1}, the NEXT record's cell state), parity s & 1
+  auto factors = [&](int s, const f32x4& ra, float cy, float cn, float dq) {
+    const float ig = ra[0], gg = ra[1], fg = ra[2], og = ra[3];
+    const float cprev = s > 0 ? cn : c0v;
+    const float tc = ftanh(cy);
+    const f32x4 fa = f32x4{og * (1.0f - tc * tc), gg * ig * (1.0f - ig), cprev * fg * (1.0f - fg), ig * (1.0f - gg * gg)};
+    const f32x4 fb = f32x4{tc * og * (1.0f - og), fg, dq * dscale, 0.f};
+    facA[(s & 1) * H + hid] = fa;
+    facB[(s & 1) * H + hid] = fb;
+  };
+  if (own) {
+    dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < B::NM2; ++sl) dhs[sl * H + hid] = 0.f;
+  } else if (T > 0) {
+    issue(T - 1, ra0, rb0, do0, xq0);
+    issue(T - 2, ra1, rb1, do1, xq1);
+    issue(T - 3, ra2, rb2, do2, xq2);
+    factors(T - 1, ra0, rb0, rb1, do0);          // step T-1's factors: the loop produces step t-1's during step t
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  // step t.  Helper threads: (rn, cyn, dqn) = record t-1, cnn = c_{t-2} (record t-2's cell state), xc = x_t (record t);
+  // (fa, fb, fd, fx) = record t's own set, dead behind this step's by-products: refilled with record t-3
+  auto step = [&](const int t, const f32x4& rn, const float& cyn, const float& cnn, const float& dqn, const float& xc,
+                  f32x4& fa, float& fb, float& fd, float& fx) {
+    const size_t bt = b * T + t;
+    f32x4 pkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (own) {
+      // ---- G: seven multiply-adds per unit on the factors the helper waves left for this step -------------------------------
+      const f32x4 qa = facA[(t & 1) * H + hid], qb = facB[(t & 1) * H + hid];
+      float dht = qb[2];
+#pragma unroll
+      for (int sl = 0; sl < B::NM2; ++sl) dht += dhs[sl * H + hid];
+      const float dct = fmaf(dht, qa[0], dcs);
+      const f32x4 pv = f32x4{dct * qa[1], dct * qa[2], dct * qa[3], dht * qb[0]};
+      dcs = dct * qb[1];
+      dgf[hid] = pv[0]; dgf[H + hid] = pv[1]; dgf[2 * H + hid] = pv[2]; dgf[3 * H + hid] = pv[3];
+      pkeep = pv;
+      float mx = fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fmaxf(fabsf(pv[2]), fabsf(pv[3])));
+      mx = wave_max(mx);
+      if (lane == 0) smax1[wave] = mx;
+    } else if (t > 0) {
+      factors(t - 1, rn, cyn, cnn, dqn);
+    }
+    TT_STAMP(0)
+    lds_barrier();
+    TT_STAMP(1)
+    float u2, t01f;
+    {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      if (bs.rowmax && tid == FAST_NT - 1) bs.rowmax[bt] = mxg;
+      float ug;
+      const float sg = step_scale(mxg, ug);
+      const float s2 = step_scale(mxg * maxl1, u2);
+      t01f = ug * s2;
+      if (own) {
+        store_split4_h(img1h, PL1, x_off<B::K1>(hid % F::I2, 4 * (hid / F::I2)), pkeep * sg);
+      } else {
+        // the fp32 row goes out to HBM; the unit's by-products from the same image
+        const int i4 = tid - H;
+        const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
+        reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
+        if (dg_hid && dg_hid != dg_in) reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
+        const f32x4 pu = f32x4{dgf[hid], dgf[H + hid], dgf[2 * H + hid], dgf[3 * H + hid]};
+        const float xv = xc * xscale;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          cmx[g] = fmaxf(cmx[g], fabsf(pu[g]));
+          sxd[g] = fmaf(xv, pu[g], sxd[g]);
+          sdg[g] += pu[g];
+        }
+      }
+    }
+    TT_STAMP(2)
+    lds_barrier();
+    TT_STAMP(3)
+    if (!own) issue(t - 3, fa, fb, fd, fx);      // under T01's MFMAs, into the set record t just left; turned into factors during step t-2
+    // ---- T01 (k_lstm_bwd_f10h) --------------------------------------------------------------------------------------------------
+    {
+      xh8 bf[B::NM1][2];
+#pragma unroll
+      for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+#pragma unroll
+      for (int x = 0; x < B::XF; ++x) {
+        f32x4 au[B::NM1];
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u) {
+          au[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[u], 0, 0, 0);
+          au[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[u], 0, 0, 0);
+        }
+        f32x4 acc = au[0];
+#pragma unroll
+        for (int u = 1; u < B::NM1; ++u) acc += au[u];
+        const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+        const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+        store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
+      }
+    }
+    TT_STAMP(4)
+    lds_barrier();
+    TT_STAMP(5)
+    // ---- T2 (k_lstm_bwd_f10h) ---------------------------------------------------------------------------------------------------
+    {
+      f32x4 acc2[B::XT2];
+#pragma unroll
+      for (int x = 0; x < B::XT2; ++x) {
+        const int ub = (wave + FAST_NW * x) / B::CT2;
+        const int row = 16 * ct + c;
+        xh8 b2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][1], b2[0], z4, 0, 0, 0);
+        const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[0], z4, 0, 0, 0);
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[x][0], b2[1], alo, 0, 0, 0);
+        acc2[x] = ahi + alo;
+      }
+      if (q < 2) {
+#pragma unroll
+        for (int x = 0; x < B::XT2; ++x) {
+          const int ub = (wave + FAST_NW * x) / B::CT2;
+          *reinterpret_cast<f32x4*>(dhs + ub * H + (16 * ct + c) * F::J2 + 4 * q) = acc2[x] * (un2 * u2);
+        }
+      }
+    }
+    TT_STAMP(6)
+    lds_barrier();
+    TT_STAMP(7)
+  };
+  // three rotating record sets: record t lives in set (T - 1 - t) % 3
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra1, rb1, rb2, do1, xq0, ra0, rb0, do0, xq0);
+    if (t >= 1) step(t - 1, ra2, rb2, rb0, do2, xq1, ra1, rb1, do1, xq1);
+    if (t >= 2) step(t - 2, ra0, rb0, rb1, do0, xq2, ra2, rb2, do2, xq2);
+  }
+  if (!own) {
     if (bs.colmax) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmx[g]));
@@ -1070,6 +1344,22 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
       hipLaunchKernelGGL(kl, dim3(rs.B), dim3(F10BL<S>::NT), ldsl, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
                          (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0, (float*)d_c0,
                          dg ? diag : nullptr, bs);
+      return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    }
+  }
+  if constexpr (F10<S>::H == 256 && F10BH<S>::XF < 4) {
+    // the record-dependent half of the gate phase on the helper waves, one step ahead (k_lstm_bwd_f10p, round 5): MEASURED SLOWER
+    // (cfg2 training step 1.689 against 1.642 ms; profiles/r5/stamps_cfg2_f10p.txt: the gate waves' phase stays at 670 cycles with
+    // 45 instead of 75 instructions in it — it is made of the LDS round trips on either side of the barrier and the wave-maximum
+    // chain, not of the gate arithmetic — while the helper waves' split phase grows from 430 to 610).  Option dev bit 17 selects it.
+    if (opt(OPT_DEV) & (1 << 17)) {
+      constexpr size_t ldsp = f10bp_lds_bytes<S>();
+      static_assert(ldsp <= 150 * 1024, "LDS image set too large");
+      auto kp = dg ? k_lstm_bwd_f10p<S, true> : k_lstm_bwd_f10p<S, false>;
+      if (ldsp > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kp), ldsp) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+      hipLaunchKernelGGL(kp, dim3(rs.B), dim3(FAST_NT), ldsp, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
+                         (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                         (float*)d_c0, dg ? diag : nullptr, bs);
       return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
     }
   }

@@ -2692,6 +2692,55 @@ def test_fused_setup_launch_is_bit_identical(kind):
         assert _lib.load().ttrnn_rnn_forward_cores_fused(ctypes.byref(desc)) == 0
 
 
+@pytest.mark.parametrize("rank,inp,with_state", [(8, 1, False), (8, 40, True), (16, 40, True)])
+def test_reverse_kernel_with_precomputed_gate_factors(rank, inp, with_state):
+    """k_lstm_bwd_f10p (round 5 A/B kernel, option dev bit 17: waves 4-7 turn the forward record into the gate-gradient factors
+    one step ahead, waves 0-3 run seven multiply-adds per unit; measured 3 % slower than k_lstm_bwd_f10h and not the default —
+    DESIGN.md lesson 57) against the default reverse kernel and the float64 oracle: every gradient incl. d_h0 / d_c0 and the
+    by-products' consumers (bias gradients, input_size == 1 sums), repeatable, masked samples exactly zero."""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(rank + inp)
+    H, B, T = 256, 70, 23
+    m = build_module(dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=rank), dev())
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, H)
+    w[[2, 40]] = 0.0
+    init = (torch.randn(B, H) * 0.3, torch.randn(B, H) * 0.3) if with_state else None
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    ir = None if init is None else tuple(t.double().clone().requires_grad_(True) for t in init)
+    ro, (rh, rc) = O.lstm_forward(layers, x.double(), ir)
+    wfin = torch.ones(B, 1, dtype=torch.float64)
+    wfin[[2, 40]] = 0.0
+    ((ro * w.double()).sum() + 0.5 * (rh * wfin).sum() + 0.25 * (rc * wfin).sum()).backward()
+
+    def run(d):
+        with ttrnn_hip.option("dev", d):
+            m.zero_grad()
+            di = None if init is None else tuple(t.to(dev()).requires_grad_(True) for t in init)
+            out, (hT, cT) = m(x.to(dev()), di)
+            wf = wfin.float().to(dev())
+            ((out * w.to(dev())).sum() + 0.5 * (hT * wf).sum() + 0.25 * (cT * wf).sum()).backward()
+            g = {n: p.grad.clone() for n, p in m.named_parameters()}
+            if di is not None:
+                g["h0"], g["c0"] = di[0].grad.clone(), di[1].grad.clone()
+            return g
+
+    got, again, other = run(1 << 17), run(1 << 17), run(0)
+    refs = {n: leaves[n].grad for n, _ in m.named_parameters()}
+    if ir is not None:
+        refs["h0"], refs["c0"] = ir[0].grad, ir[1].grad
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        assert _maxabs(got[n].double(), ref) <= 2e-5 * sc, n
+        assert _maxabs(got[n], other[n]) <= 4e-6 * sc, n
+        assert torch.equal(got[n], again[n]), n
+    if init is not None:
+        assert float(got["h0"][[2, 40]].abs().max()) == 0.0 and float(got["c0"][[2, 40]].abs().max()) == 0.0
+
+
 def _cfg3_fp32_module(inp=1, L=1):
     torch.manual_seed(1111)
     return build_module(dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=8), dev())
