@@ -369,9 +369,14 @@ TT_HD size_t ilv_index(int64_t n, int o, int out, int ilv_h, int ilv_mode) {
   return ((size_t)n * ilv_h + hid) * 4 + slot;
 }
 
+// epi != 0 (TTRNN_EPI_LOG_SOFTMAX = 1 / TTRNN_EPI_RELU_L2NORM = 2, include/ttrnn.h; plain layout only): the row-wise epilogue of
+// the callers' heads (mnist_classifier.py:55-57, speaker_encoder.py:86-89) applied to the tile's rows while they are still in the
+// chain's buffer — one thread per row walks its `out` values (heads are 10 ... 256 wide) — and aux[n] keeps the row's
+// log-sum-exp / L2 norm for the backward pass: the head's forward is ONE launch (round 5; a separate k_head_epilogue before)
 template <class Ex, typename T>
 TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* bias, const T* x, T* y,
-                             int64_t n0, int nb, float* bufA, float* bufB, int bs, int ilv_h = 0, int ilv_mode = 0) {
+                             int64_t n0, int nb, float* bufA, float* bufB, int bs, int ilv_h = 0, int ilv_mode = 0,
+                             int epi = 0, float* aux = nullptr) {
   const int in = s.in_size, out = s.out_size;
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * in; e += nthr) {
@@ -380,6 +385,31 @@ TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* 
     }
   });
   float* r = chain_fwd(ex, s, W, bufA, bufB, nb, bs);
+  if (epi != 0) {
+    ex.par([&](int tid, int nthr) {
+      for (int sidx = tid; sidx < nb; sidx += nthr) {
+        float* row = r + (size_t)sidx * bs;
+        if (bias)
+          for (int o = 0; o < out; ++o) row[o] += ld(bias, o);
+        float a;
+        if (epi == 1) {
+          float m = row[0];
+          for (int o = 1; o < out; ++o) m = row[o] > m ? row[o] : m;
+          float sum = 0.f;
+          for (int o = 0; o < out; ++o) sum += expf(row[o] - m);
+          a = m + logf(sum);
+          for (int o = 0; o < out; ++o) row[o] -= a;
+        } else {
+          float sum = 0.f;
+          for (int o = 0; o < out; ++o) { const float u = row[o] > 0.f ? row[o] : 0.f; sum += u * u; }
+          a = sqrtf(sum);
+          for (int o = 0; o < out; ++o) row[o] = (row[o] > 0.f ? row[o] : 0.f) / a;      // 0 / 0 = NaN, as torch.norm + div
+        }
+        if (aux) aux[n0 + sidx] = a;
+      }
+    });
+    bias = nullptr;      // added above
+  }
   ex.par([&](int tid, int nthr) {
     for (int e = tid; e < nb * out; e += nthr) {
       const int sidx = e / out, o = e - sidx * out;

@@ -223,7 +223,7 @@ __global__ void k_unpack_core_grads(TtShape s, PackArgs a, const float* packed_g
 template <typename T, bool W_LDS, bool BUF_GLOBAL>
 __global__ void __launch_bounds__(NT_LIN) k_ttlinear_fwd(TtShape s, int64_t n_rows, int nb, int bs,
                                                          const float* packed, const T* bias, const T* x, T* y,
-                                                         float* ws, int ilv_h, int ilv_mode) {
+                                                         float* ws, int ilv_h, int ilv_mode, int epi, float* aux) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DevExec ex;
   float* p = smem;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(NT_LIN) k_ttlinear_fwd(TtShape s, int64_t n_ro
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * nb;
     const int n = (int)tmin<int64_t>(nb, n_rows - n0);
-    ttlinear_fwd_tile<DevExec, T>(ex, s, W, bias, x, y, n0, n, bufA, bufB, bs, ilv_h, ilv_mode);
+    ttlinear_fwd_tile<DevExec, T>(ex, s, W, bias, x, y, n0, n, bufA, bufB, bs, ilv_h, ilv_mode, epi, aux);
   }
 }
 
@@ -526,13 +526,13 @@ LinPlan plan_ttlinear_bwd(const TtShape& s, int64_t n_rows, bool fixed_order) {
 
 template <typename T>
 static int launch_lin_fwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, const float* packed, const void* bias,
-                            const void* x, void* y, void* ws, hipStream_t stream, int ilv_h, int ilv_mode) {
+                            const void* x, void* y, void* ws, hipStream_t stream, int ilv_h, int ilv_mode, int epi, float* aux) {
 #define TT_LAUNCH(WL, BG)                                                                                          \
   do {                                                                                                             \
     auto kern = k_ttlinear_fwd<T, WL, BG>;                                                                         \
     if (set_lds(kern, p.lds_bytes) != TTRNN_OK) return TTRNN_ERR_LAUNCH;                                           \
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NT_LIN), p.lds_bytes, stream, s, n_rows, p.nb, p.bs, packed,       \
-                       (const T*)bias, (const T*)x, (T*)y, (float*)ws, ilv_h, ilv_mode);                           \
+                       (const T*)bias, (const T*)x, (T*)y, (float*)ws, ilv_h, ilv_mode, epi, aux);                 \
   } while (0)
   if (p.w_lds && !p.buf_global) TT_LAUNCH(true, false);
   else if (!p.w_lds && !p.buf_global) TT_LAUNCH(false, false);
@@ -544,10 +544,11 @@ static int launch_lin_fwd_t(const TtShape& s, const LinPlan& p, int64_t n_rows, 
 
 int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n_rows, const float* packed,
                         const void* bias, const void* x, void* y, void* ws, hipStream_t stream, int ilv_h,
-                        int ilv_mode) {
+                        int ilv_mode, int epi, float* aux) {
   if (n_rows == 0) return TTRNN_OK;
-  return dtype == TTRNN_F32 ? launch_lin_fwd_t<float>(s, p, n_rows, packed, bias, x, y, ws, stream, ilv_h, ilv_mode)
-                            : launch_lin_fwd_t<bf16_t>(s, p, n_rows, packed, bias, x, y, ws, stream, ilv_h, ilv_mode);
+  if (epi != 0 && ilv_h != 0) return TTRNN_ERR_UNSUPPORTED;      // the in-kernel epilogue works on plain rows
+  return dtype == TTRNN_F32 ? launch_lin_fwd_t<float>(s, p, n_rows, packed, bias, x, y, ws, stream, ilv_h, ilv_mode, epi, aux)
+                            : launch_lin_fwd_t<bf16_t>(s, p, n_rows, packed, bias, x, y, ws, stream, ilv_h, ilv_mode, epi, aux);
 }
 
 template <typename T, typename TDY>

@@ -11,6 +11,7 @@
 #include "ttrnn.h"
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 
 namespace ttrnn {
 namespace {
@@ -98,10 +99,19 @@ int ttrnn_head_forward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_ro
                        const void* x, void* y, float* aux, void* workspace, size_t workspace_bytes, void* stream) {
   if (epilogue != TTRNN_EPI_NONE && epilogue != TTRNN_EPI_LOG_SOFTMAX && epilogue != TTRNN_EPI_RELU_L2NORM)
     return TTRNN_ERR_UNSUPPORTED;
-  int st = ttrnn_ttlinear_forward(w, dtype, n_rows, packed, bias, x, y, workspace, workspace_bytes, stream);
-  if (st != TTRNN_OK || epilogue == TTRNN_EPI_NONE || n_rows == 0) return st;
   TtShape s;
-  tt_shape_init(&s, w);
+  int st = tt_shape_init(&s, w);
+  if (st != TTRNN_OK) return st;
+  // shapes on the any-shape forward kernel (the classifier heads: 256 -> 10 and the like): chain + epilogue in ONE launch (round 5;
+  // option dev bit 18: the separate epilogue launch, A/B)
+  if (epilogue != TTRNN_EPI_NONE && n_rows > 0 && (dtype == TTRNN_F32 || dtype == TTRNN_BF16) && packed && x && y &&
+      !(opt(OPT_DEV) & (1 << 18)) && (opt(OPT_FORCE_GENERIC) || !fast_ttlinear_fwd_available(s, dtype, 0))) {
+    const LinPlan p = plan_ttlinear_fwd(s, n_rows);
+    if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
+    return launch_ttlinear_fwd(s, p, dtype, n_rows, packed, bias, x, y, workspace, (hipStream_t)stream, 0, 0, epilogue, aux);
+  }
+  st = ttrnn_ttlinear_forward(w, dtype, n_rows, packed, bias, x, y, workspace, workspace_bytes, stream);
+  if (st != TTRNN_OK || epilogue == TTRNN_EPI_NONE || n_rows == 0) return st;
   const unsigned grid = (unsigned)((n_rows + 3) / 4);
   if (dtype == TTRNN_F32)
     hipLaunchKernelGGL(k_head_epilogue<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, epilogue, (long)n_rows, s.out_size,

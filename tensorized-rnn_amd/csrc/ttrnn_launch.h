@@ -98,7 +98,7 @@ int launch_unpack(const TtShape& s, const float* packed_grad, void* const* grads
 // ilv_h / ilv_mode: optional gate-interleaved output layout, see ttrnn_core.h:ilv_index
 int launch_ttlinear_fwd(const TtShape& s, const LinPlan& p, int dtype, int64_t n_rows, const float* packed,
                         const void* bias, const void* x, void* y, void* ws, hipStream_t stream, int ilv_h = 0,
-                        int ilv_mode = 0);
+                        int ilv_mode = 0, int epi = 0, float* aux = nullptr);      // epi: TTRNN_EPI_* applied in-kernel (plain rows)
 int launch_ttlinear_bwd(const TtShape& s, const LinPlan& p, int dtype, int dy_dtype, int64_t n_rows, const float* packed,
                         const void* x, const void* dy, void* dx, float* d_packed, float* d_bias, void* ws,
                         hipStream_t stream);

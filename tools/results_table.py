@@ -6,12 +6,14 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r4"
-R3 = {"cfg1": (0.583, None), "cfg2": (0.552, 1.83), "cfg3": (0.513, 2.04), "cfg4": (1.62, 5.78), "cfg5": (6.80, 20.2)}
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r5"
+PREV = {"cfg1": (0.384, 1.06), "cfg2": (0.520, 1.66), "cfg3": (0.483, 1.90), "cfg3_fp32": (0.99, None), "cfg4": (1.58, 5.04), "cfg5": (6.69, 20.5)}      # round 4
 NAMES = {"cfg1": "cfg1 TT-LSTM H=128 d=2 r=4 B=32 T=784 fp32", "cfg2": "**cfg2** TT-LSTM H=256 d=3 r=8 B=64 T=784 fp32 (headline)",
          "cfg3": "cfg3 TT-GRU H=256 d=3 r=8 B=256 T=784 bf16", "cfg4": "cfg4 3-layer TT-LSTM H=256 r=16 in=40 B=512 T=160",
-         "cfg5": "cfg5 TT-LSTM H=in=1024 d=4 r=32 B=128 T=1024"}
-KERN = {"cfg1": "k_lstm_fwd_f2", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10v", "cfg4": "k_lstm_fwd_f10q", "cfg5": "k_lstm_fwd_big2h"}
+         "cfg5": "cfg5 TT-LSTM H=in=1024 d=4 r=32 B=128 T=1024",
+         "cfg3_fp32": "cfg3 in the reference's own dtype: TT-GRU H=256 d=3 r=8 B=256 T=784 fp32"}
+KERN = {"cfg1": "k_lstm_fwd_f2", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10v", "cfg3_fp32": "k_gru_fwd_f10vh", "cfg4": "k_lstm_fwd_f10q",
+        "cfg5": "k_lstm_fwd_big2h"}
 
 
 def line(path):
@@ -29,23 +31,30 @@ def kernel_avg(w):
     return None
 
 
-print("| workload (per GPU) | forward ms / step (median; prepared) | timesteps/s | `exact` mode ms | roofline frac algorithmic / executed | "
-      "dominant kernel, rocprof avg µs (calls) | HBM bytes per call (PMC) / algorithmic | train step ms (median) | round 3: fwd / train |")
+print("| workload (per GPU) | forward ms / step (prepared) | timesteps/s | `exact` mode ms | roofline frac (basis) / algorithmic / executed; chip occupancy | "
+      "dominant kernel, rocprof avg µs (calls) | HBM bytes per call (PMC) / algorithmic | train step ms | round 4: fwd / train |")
 print("|---|---|---|---|---|---|---|---|---|")
-for w in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5"):
+for w in ("cfg2", "cfg1", "cfg3", "cfg3_fp32", "cfg4", "cfg5"):
     f = line(os.path.join(src, "bench_%s.json" % w))
     tp = os.path.join(src, "bench_train_%s.json" % w)
     t = line(tp) if os.path.exists(tp) else None
     ka = kernel_avg(w)
     ex = (f.get("other_fp32_math") or {}).get("ms_per_step")
-    algo = {"cfg1": 516, "cfg2": 1028, "cfg3": 514, "cfg4": 1184, "cfg5": 8192}[w] * f["config"]["per_gpu_batch"] * f["config"]["seq_len"]
+    algo = {"cfg1": 516, "cfg2": 1028, "cfg3": 514, "cfg3_fp32": 1028, "cfg4": 1184, "cfg5": 8192}[w] * f["config"]["per_gpu_batch"] * f["config"]["seq_len"]
     exe = (f["roofline"].get("executed") or {}).get("frac")
-    print("| %s | **%.3f** (%.3f; %.3f) | %s | %s | %.3f / %s | `%s` %s | %.3g / %.3g | %s | %s / %s |" % (
-        NAMES[w], f["ms_per_step"], f["ms_per_step_median"], f["prepared"]["ms_per_step"], "{:,.0f}".format(f["value"]).replace(",", " "),
-        "%.2f" % ex if ex else "–", f["roofline"]["frac"], "%.3f" % exe if exe else "–", KERN[w],
-        "%.1f (%d)" % (ka[1], ka[0]) if ka else "–", f["roofline"]["traffic"] or float("nan"), algo,
-        "**%.2f** (%.2f)" % (t["ms_per_step"], t["ms_per_step_median"]) if t else "–",
-        R3[w][0], R3[w][1] if R3[w][1] else "–"))
+    r = f["roofline"]
+    if not r.get("traffic"):      # (a workload whose PMC summary was taken after its bench line: profiles/traffic.json has it)
+        try:
+            r["traffic"] = json.load(open(os.path.join(os.path.dirname(os.path.abspath(src)), "traffic.json")))[w]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+    basis = "executed" if (r.get("frac_basis") or "").startswith("executed") else "algorithmic"
+    print("| %s | **%.3f** (%.3f) | %s | %s | %.3f (%s) / %.3f / %s; %.2f | `%s` %s | %.3g / %.3g | %s | %s / %s |" % (
+        NAMES[w], f["ms_per_step"], f["prepared"]["ms_per_step"], "{:,.0f}".format(f["value"]).replace(",", " "),
+        "%.2f" % ex if ex else "–", r["frac"], basis, r["frac_algorithmic"], "%.3f" % exe if exe else "–", r["chip_occupancy"], KERN[w],
+        "%.1f (%d)" % (ka[1], ka[0]) if ka else "–", r["traffic"] or float("nan"), algo,
+        "**%.2f**" % t["ms_per_step"] if t else "–",
+        PREV[w][0], PREV[w][1] if PREV[w][1] else "–"))
 c = line(os.path.join(src, "bench_cfg2.json"))["cpu_baseline"]
 print()
 print("CPU baseline (oracle = op-for-op restatement of the reference's path, same weights and input, %s, %d physical cores): cfg2 %s "
