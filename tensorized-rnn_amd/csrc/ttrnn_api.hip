@@ -584,7 +584,8 @@ static FastFwdPlan plan_fast_fwd(const RnnShape& rs, int dtype) {
 static bool fwd_prefers_g2(const RnnShape& rs, int dtype) {
   if (force_generic()) return false;
   if (opt(OPT_FORCE_G2)) return g2_rnn_available(rs, dtype);
-  if (f10gh_available(rs, dtype) && fast_rnn_fwd_available(rs, dtype)) return false;
+  // (input_size == 1: this file's plan with the fused set-up launch; otherwise the tier's dense K-in in front of the same kernel)
+  if (f10gh_available(rs, dtype) && fast_rnn_fwd_available(rs, dtype) && (rs.in == 1 || !g2_rnn_available(rs, dtype))) return false;
   return rs.cell == TTRNN_GRU && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && g2_rnn_available(rs, dtype);
 }
 
@@ -813,7 +814,8 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
   if (force_generic()) return TTRNN_ROUTE_VALU;
-  if (fwd_prefers_g2(rs, desc->dtype)) return TTRNN_ROUTE_RUNTIME_MFMA;
+  if (fwd_prefers_g2(rs, desc->dtype))      // (the fp32 GRU shape with input_size != 1: the tier's K-in + the fused-core recurrent kernel)
+    return (!opt(OPT_FORCE_G2) && f10gh_available(rs, desc->dtype)) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))
@@ -824,7 +826,7 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   }
   if (big_rnn_fwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
   if (g2_rnn_available(rs, desc->dtype))      // (H = 512, r = 8 in split mode: this tier's K-in + the fused-core recurrent kernel)
-    return f10_h512_fwd_available(rs, desc->dtype) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
+    return (f10_h512_fwd_available(rs, desc->dtype) || f10gh_available(rs, desc->dtype)) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
   return TTRNN_ROUTE_VALU;
 }
 

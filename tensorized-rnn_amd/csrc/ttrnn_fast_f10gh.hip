@@ -70,8 +70,10 @@ template <class S>
 constexpr size_t f10gh_ws_bytes() { return F10H_HDR_BYTES + (size_t)4 * F10<S>::NM * 2 * 64 * sizeof(xh8); }
 
 // H0: the caller passed an initial state; OUT = false: only the final state is consumed; IN1: input_size == 1 (lesson 44: template
-// parameters, not runtime flags, inside a persistent time loop); DIAG: s_memtime stamps (tools/diag_stamps.py)
-template <class S, bool H0, bool OUT, bool IN1, bool DIAG = false>
+// parameters, not runtime flags, inside a persistent time loop); DIAG: s_memtime stamps (tools/diag_stamps.py);
+// G2GIN: gin comes from the runtime-shape tier's K-in (ttrnn_g2.hip: one dense GEMM over the B T rows) in ITS convention — slots
+// r, z carry both biases, slot n the input bias, slot 3 the hidden bias of the n gate (k_g2_bias) — and bias_hid is not read
+template <class S, bool H0, bool OUT, bool IN1, bool DIAG = false, bool G2GIN = false>
 __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc gs, const float* __restrict__ h0,
                                                           const float* __restrict__ packed_hid,
                                                           const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   float hst = H0 ? h0[b * H + hid] : 0.f;
   float bh[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) bh[g] = bias_hid ? bias_hid[g * H + hid] : 0.f;
+  for (int g = 0; g < 3; ++g) bh[g] = (!G2GIN && bias_hid) ? bias_hid[g * H + hid] : 0.f;
   f32x4 gi = f32x4{0.f, 0.f, 0.f, 0.f}, vv = gi, bb = gi;
   XChunk<float> xq;
   xq.cur = 0.f; xq.nxt = 0.f;
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
     {
       if (in1) gi = bb + xq.at(t) * vv;
       const f32x4 un = H0 ? un_t : usc;
-      const float hn = fmaf(gbuf[2 * H + hid], un[2], bh[2]);
+      const float hn = fmaf(gbuf[2 * H + hid], un[2], G2GIN ? gi[3] : bh[2]);
       const float rg = fsigmoid(gi[0] + fmaf(gbuf[hid], un[0], bh[0]));              // gru.py:38-39
       const float zg = fsigmoid(gi[1] + fmaf(gbuf[H + hid], un[1], bh[1]));          // gru.py:40-41
       const float ng = ftanh(gi[2] + rg * hn);                           // gru.py:42-43
@@ -233,6 +235,27 @@ static int launch_gh(const RnnShape& rs, GinSrc gin, const void* h0, const float
     kern = gin.in1 ? k_gru_fwd_f10vh<S, false, true, true, true> : k_gru_fwd_f10vh<S, false, true, false, true>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, (const float*)h0, packed_hid, hdr, wfrag, bh,
                      (float*)out, (float*)hT, reserve);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// The same recurrent kernel behind the runtime-shape tier's K-in (input_size != 1: the tier builds gin as ONE dense two-piece GEMM
+// over the B T rows; the chain kernel this file's own route would use there is 2 - 3 x slower at 81 920 rows: 1.07 against 0.72 ms for
+// benchmarking.py --gru --hidden_size 256).  ws: f10gh_workspace_bytes (the tier's `rec` region)
+int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+                            float* reserve, void* ws, hipStream_t stream) {
+  using S = ShpH256R8G;
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  if (!shape_matches<S>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
+  float* hdr = reinterpret_cast<float*>(ws);
+  xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
+  hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
+  hipLaunchKernelGGL((k_f10gh_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
+  if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
+  GinSrc src{gin, nullptr, 0};
+  auto kern = out ? (h0 ? k_gru_fwd_f10vh<S, true, true, false, false, true> : k_gru_fwd_f10vh<S, false, true, false, false, true>)
+                  : (h0 ? k_gru_fwd_f10vh<S, true, false, false, false, true> : k_gru_fwd_f10vh<S, false, false, false, false, true>);
+  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, src, (const float*)h0, packed_hid, hdr, wfrag,
+                     (const float*)nullptr, (float*)out, (float*)hT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

@@ -1405,6 +1405,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   // (H = 512, r = 8 in split mode: the same region is the fused-core forward kernel's fragment workspace — sized for it whatever
   // this tier's own plan needs, so that the route report and the launch cannot disagree: ADVICE r4)
   if (f10_h512_fwd_available(rs, TTRNN_F32) && w.rec < g2_al(f10_h512_workspace_bytes())) w.rec = g2_al(f10_h512_workspace_bytes());
+  if (rs.cell == TTRNN_GRU && w.rec < g2_al(f10gh_workspace_bytes(rs))) w.rec = g2_al(f10gh_workspace_bytes(rs));      // (0 for other shapes)
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
@@ -1479,6 +1480,11 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (st != TTRNN_OK) return st;
   // the reference's default benchmark shape (H = 512, r = 8) in split mode: the fused-core forward kernel on the gin just built
   // (both biases are folded into it), this tier's `rec` region as its fragment workspace (ttrnn_fast_f10.hip)
+  // the fp32 TT-GRU shape with a fused-core forward kernel (H = 256, r = 8; input_size != 1 arrives here): that kernel on this gin
+  if (!in1 && dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10gh_available(rs, dtype)) {
+    if (L.rec < f10gh_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)
+    return launch_gru_fwd_f10gh_g2(rs, gin, h0, packed_hid, out, hT, reserve, rec, stream);
+  }
   if (f10_h512_fwd_available(rs, dtype)) {
     if (L.rec < f10_h512_workspace_bytes()) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)
     return launch_rnn_fwd_f10_h512(rs, gin, h0, c0, packed_hid, out, hT, cT, reserve, rec, stream);

@@ -169,6 +169,9 @@ size_t f10gh_workspace_bytes(const RnnShape& rs);
 bool f10gh_available(const RnnShape& rs, int dtype);
 int launch_gru_fwd_f10gh(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid, void* out,
                          void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
+// ... and behind the runtime-shape tier's dense K-in (input_size != 1): gin in the tier's slot convention, ws = the tier's rec region
+int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+                            float* reserve, void* ws, hipStream_t stream);
 // two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,
