@@ -304,6 +304,37 @@ __device__ __forceinline__ void f10p_s2(const xh8 (&a1)[F10P<S>::NP], const xh8 
 #pragma unroll
   for (int p = 0; p < NP; ++p) store_split4_h(img, F::PLANE, ln.soff[p], acc[p]);
 }
+// the same with core 2's fragments in LDS (afr[(2 p + piece) * 64 + lane], written once per launch by every wave for itself or by
+// the workgroup): r = 16 shapes, whose twelve m-tiles would take 48 VGPRs next to 128 of fused-core fragments
+template <class S>
+__device__ __forceinline__ void f10p_s2_lds(const xh8* afr, int lane, const F10pLane<S>& ln, unsigned pk, _Float16* img) {
+  using F = F10<S>;
+  constexpr int NP = F10P<S>::NP;
+  unsigned d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = (unsigned)__builtin_amdgcn_ds_bpermute(ln.gsrc + 4 * e, (int)pk);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = ln.live ? d[e] : 0u;
+  const xh8 bfrag = __builtin_bit_cast(xh8, u32x4{d[0], d[1], d[2], d[3]});
+  constexpr int GP = NP < 3 ? NP : 3;      // pairs per group: three accumulators and six fragments live at a time
+  static_assert(NP % GP == 0, "pair groups");
+#pragma unroll
+  for (int p0 = 0; p0 < NP; p0 += GP) {
+    xh8 fa[GP], fb[GP];
+#pragma unroll
+    for (int p = 0; p < GP; ++p) {
+      fa[p] = afr[(2 * (p0 + p)) * 64 + lane];
+      fb[p] = afr[(2 * (p0 + p) + 1) * 64 + lane];
+    }
+    f32x4 acc[GP];
+#pragma unroll
+    for (int p = 0; p < GP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[p], bfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < GP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[p], bfrag, acc[p], 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < GP; ++p) store_split4_h(img, F::PLANE, ln.soff[p0 + p], acc[p]);
+  }
+}
 __device__ __forceinline__ unsigned f10p_pack(float hscaled) {
   _Float16 p0, p1;
   split2h(hscaled, p0, p1);

@@ -91,9 +91,25 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
 
-  // S2 fragments of ALL m-tiles, as tile pairs with the four terms packed along k (f10p_load_w2)
-  xh8 a1[F10P<S>::NP], a2[F10P<S>::NP];
-  f10p_load_w2<S>(a1, a2, packed_hid, lane, hdr);
+  // S2 fragments of ALL m-tiles, as tile pairs with the four terms packed along k (f10p_load_w2): in registers, or (r = 16: twelve
+  // m-tiles, 48 VGPRs beside 128 of fused-core fragments) in LDS — every wave needs the same set, wave 0 writes it
+  constexpr bool A2LDS = F10P<S>::NP > 3;
+  __shared__ __attribute__((aligned(16))) xh8 afr[A2LDS ? 2 * F10P<S>::NP * 64 : 1];
+  xh8 a1[A2LDS ? 1 : F10P<S>::NP], a2[A2LDS ? 1 : F10P<S>::NP];
+  if constexpr (A2LDS) {
+    if (wave == 0) {
+      xh8 t1[F10P<S>::NP], t2[F10P<S>::NP];
+      f10p_load_w2<S>(t1, t2, packed_hid, lane, hdr);
+#pragma unroll
+      for (int p = 0; p < F10P<S>::NP; ++p) {
+        afr[(2 * p) * 64 + lane] = t1[p];
+        afr[(2 * p + 1) * 64 + lane] = t2[p];
+      }
+    }
+    __syncthreads();
+  } else {
+    f10p_load_w2<S>(a1, a2, packed_hid, lane, hdr);
+  }
   F10pLane<S> ln;
   ln.init(wave, lane);
   xh8 w10[2][F::NM];
@@ -144,7 +160,10 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   f32x4 un_t = usc * ldexpf(1.f, e_cur);
 
   // S2 of this wave's eight chain rows from the state in the lanes
-  auto s2_from_lanes = [&](float hscaled) { f10p_s2<S>(a1, a2, ln, f10p_pack(hscaled), img); };
+  auto s2_from_lanes = [&](float hscaled) {
+    if constexpr (A2LDS) f10p_s2_lds<S>(afr, lane, ln, f10p_pack(hscaled), img);
+    else f10p_s2<S>(a1, a2, ln, f10p_pack(hscaled), img);
+  };
   s2_from_lanes(hst * hsc);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
   lds_barrier();
@@ -241,11 +260,10 @@ static int launch_gh(const RnnShape& rs, GinSrc gin, const void* h0, const float
 // The same recurrent kernel behind the runtime-shape tier's K-in (input_size != 1: the tier builds gin as ONE dense two-piece GEMM
 // over the B T rows; the chain kernel this file's own route would use there is 2 - 3 x slower at 81 920 rows: 1.07 against 0.72 ms for
 // benchmarking.py --gru --hidden_size 256).  ws: f10gh_workspace_bytes (the tier's `rec` region)
-int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
-                            float* reserve, void* ws, hipStream_t stream) {
-  using S = ShpH256R8G;
+template <class S>
+static int launch_gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+                        float* reserve, void* ws, hipStream_t stream) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
-  if (!shape_matches<S>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
   hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
@@ -259,13 +277,24 @@ int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+                            float* reserve, void* ws, hipStream_t stream) {
+  if (shape_matches<ShpH256R8G>(rs.hid_s)) return launch_gh_g2<ShpH256R8G>(rs, gin, h0, packed_hid, out, hT, reserve, ws, stream);
+  if (shape_matches<ShpH256R16G>(rs.hid_s)) return launch_gh_g2<ShpH256R16G>(rs, gin, h0, packed_hid, out, hT, reserve, ws, stream);
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
 // fp32-storage TT-GRU, split math mode (dev bit 256: keep the runtime-shape tier's kernel, A/B)
+// (r = 16: behind the tier's K-in only — input_size != 1; this file's own plan has no unit-row chain kernel for that input shape)
 bool f10gh_available(const RnnShape& rs, int dtype) {
   return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & 256) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 && rs.cell == TTRNN_GRU &&
-         rs.hid_blocks <= 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && shape_matches<ShpH256R8G>(rs.hid_s);
+         rs.hid_blocks <= 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT &&
+         (shape_matches<ShpH256R8G>(rs.hid_s) || (rs.in != 1 && shape_matches<ShpH256R16G>(rs.hid_s)));
 }
 size_t f10gh_workspace_bytes(const RnnShape& rs) {
-  return shape_matches<ShpH256R8G>(rs.hid_s) ? f10gh_ws_bytes<ShpH256R8G>() : 0;
+  if (shape_matches<ShpH256R8G>(rs.hid_s)) return f10gh_ws_bytes<ShpH256R8G>();
+  if (shape_matches<ShpH256R16G>(rs.hid_s)) return f10gh_ws_bytes<ShpH256R16G>();
+  return 0;
 }
 int launch_gru_fwd_f10gh(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid, void* out,
                          void* hT, float* reserve, void* ws, hipStream_t stream, int phase) {

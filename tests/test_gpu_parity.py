@@ -2741,9 +2741,9 @@ def test_reverse_kernel_with_precomputed_gate_factors(rank, inp, with_state):
         assert float(got["h0"][[2, 40]].abs().max()) == 0.0 and float(got["c0"][[2, 40]].abs().max()) == 0.0
 
 
-def _cfg3_fp32_module(inp=1, L=1):
+def _cfg3_fp32_module(inp=1, L=1, rank=8):
     torch.manual_seed(1111)
-    return build_module(dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=8), dev())
+    return build_module(dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=L, n_cores=3, tt_rank=rank), dev())
 
 
 def test_gru_fp32_fused_core_error_vs_fp64_is_fp32_class():
@@ -2850,8 +2850,11 @@ def test_gru_fp32_fused_core_variants_vs_oracle_and_tier():
     from ttrnn_hip import functional as F
     from oracle import ttrnn_oracle as O
     torch.manual_seed(31)
-    for inp, L, B, T, with_h0 in ((1, 1, 9, 50, False), (1, 1, 70, 33, True), (40, 2, 6, 21, True), (40, 1, 300, 12, False)):
-        m = _cfg3_fp32_module(inp, L)
+    # (input_size != 1: the same recurrent kernel behind the runtime tier's dense K-in; rank 16: that route only, core 2's S2
+    # fragments in LDS)
+    for inp, L, B, T, with_h0, rank in ((1, 1, 9, 50, False, 8), (1, 1, 70, 33, True, 8), (40, 2, 6, 21, True, 8), (40, 1, 300, 12, False, 8),
+                                        (40, 2, 9, 17, True, 16), (256, 1, 300, 10, False, 16)):
+        m = _cfg3_fp32_module(inp, L, rank)
         x = torch.rand(B, T, inp)
         h0 = (torch.randn(B, 256) * 0.5) if with_h0 else None
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
@@ -2878,8 +2881,8 @@ def test_gru_fp32_fused_core_variants_vs_oracle_and_tier():
             ref = leaves[n].grad
             worst = max(worst, _maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-30))
         worst = max(worst, _maxabs(xg.grad, xr.grad) / max(float(xr.grad.abs().max()), 1e-30))
-        print("TT-GRU fp32 in=%d L=%d B=%d T=%d h0=%s: max gradient error relative to each tensor's maximum %.3g" % (
-            inp, L, B, T, with_h0, worst))
+        print("TT-GRU fp32 in=%d L=%d B=%d T=%d h0=%s r=%d: max gradient error relative to each tensor's maximum %.3g" % (
+            inp, L, B, T, with_h0, rank, worst))
         assert worst <= 1e-4
 
 
