@@ -1406,6 +1406,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   // this tier's own plan needs, so that the route report and the launch cannot disagree: ADVICE r4)
   if (f10_h512_fwd_available(rs, TTRNN_F32) && w.rec < g2_al(f10_h512_workspace_bytes())) w.rec = g2_al(f10_h512_workspace_bytes());
   if (rs.cell == TTRNN_GRU && w.rec < g2_al(f10gh_workspace_bytes(rs))) w.rec = g2_al(f10gh_workspace_bytes(rs));      // (0 for other shapes)
+  if (rs.cell == TTRNN_GRU && w.rec < g2_al(f10g5_workspace_bytes(rs))) w.rec = g2_al(f10g5_workspace_bytes(rs));
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
@@ -1484,6 +1485,10 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   if (!in1 && dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10gh_available(rs, dtype)) {
     if (L.rec < f10gh_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)
     return launch_gru_fwd_f10gh_g2(rs, gin, h0, packed_hid, out, hT, reserve, rec, stream);
+  }
+  if (!in1 && dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10g5_available(rs, dtype)) {      // H = 512, r = 8: gates on the accumulators
+    if (L.rec < f10g5_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;
+    return launch_gru_fwd_f10g5(rs, gin, h0, packed_hid, out, hT, reserve, rec, stream);
   }
   if (f10_h512_fwd_available(rs, dtype)) {
     if (L.rec < f10_h512_workspace_bytes()) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)

@@ -169,6 +169,11 @@ size_t f10gh_workspace_bytes(const RnnShape& rs);
 bool f10gh_available(const RnnShape& rs, int dtype);
 int launch_gru_fwd_f10gh(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid, void* out,
                          void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
+// fp32 TT-GRU H = 512, r = 8 (benchmarking.py defaults with --gru): gates on the accumulators, behind the tier's K-in (ttrnn_fast_f10g5.hip)
+bool f10g5_available(const RnnShape& rs, int dtype);
+size_t f10g5_workspace_bytes(const RnnShape& rs);
+int launch_gru_fwd_f10g5(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+                         float* reserve, void* ws, hipStream_t stream);
 // ... and behind the runtime-shape tier's dense K-in (input_size != 1): gin in the tier's slot convention, ws = the tier's rec region
 int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
                             float* reserve, void* ws, hipStream_t stream);

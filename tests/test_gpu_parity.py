@@ -2886,6 +2886,57 @@ def test_gru_fp32_fused_core_variants_vs_oracle_and_tier():
         assert worst <= 1e-4
 
 
+@pytest.mark.parametrize("inp,B,T,h0_scale", [(256, 5, 30, None), (40, 300, 9, 0.5), (256, 70, 12, 40.0)])
+def test_gru_h512_gates_on_accumulators_kernel(inp, B, T, h0_scale):
+    """k_gru_fwd_f10g5 (ttrnn_fast_f10g5.hip, round 5): the reference's benchmark defaults with --gru (benchmarking.py:75-83:
+    TT-GRU H = 512, d = 3, rank 8 — out modes (8, 12, 16): r, z, n of a unit share a column of the fused core, 32 rows apart), gates on
+    the accumulators as in the TT-LSTM kernels, behind the runtime tier's dense K-in.  Against the float64 oracle and the tier's own
+    recurrent kernel (option dev bit 8); h_0 inside and far outside (-1, 1); final-state-only calls; training forward feeding the
+    tier's reverse kernel: every gradient against the oracle's float64 autograd."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(inp + B)
+    m = build_module(dict(kind="ttgru", input_size=inp, hidden_size=512, num_layers=1, n_cores=3, tt_rank=8), dev())
+    x = torch.rand(B, T, inp)
+    h0 = None if h0_scale is None else torch.randn(B, 512) * h0_scale
+    if h0 is not None and h0_scale > 1:
+        h0[1] *= 1e-3                                  # a sample inside (-1, 1) next to them: scales are per sample
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    ro, rh = O.gru_forward(layers, xr, None if h0 is None else h0.double())
+    scale = max(1.0, float(ro.abs().max()))
+    outs = {}
+    for name, d in (("fused", 0), ("tier", 256)):
+        with ttrnn_hip.option("dev", d), torch.no_grad():
+            assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if d == 0 else "runtime_mfma")
+            outs[name] = m(x.to(dev()), None if h0 is None else h0.to(dev()))
+    ef, et = _maxabs(outs["fused"][0], ro), _maxabs(outs["tier"][0], ro)
+    print("TT-GRU H=512 in=%d B=%d h0=%s: max abs error vs float64 fused %.3g tier %.3g (state scale %.3g)" % (inp, B, h0_scale, ef, et, scale))
+    tol = 1e-3 if (h0_scale or 0) > 1 else 2e-6
+    assert ef <= tol * scale and ef <= 3.0 * et + 2e-7 * scale
+    assert torch.equal(outs["fused"][0][:, -1], outs["fused"][1])
+    with torch.no_grad():
+        sub = m(x[[2, 0]].to(dev()), None if h0 is None else h0[[2, 0]].to(dev()))
+        fin = m(x.to(dev()), None if h0 is None else h0.to(dev()), need_outputs=False)
+    assert torch.equal(sub[0], outs["fused"][0][[2, 0]])
+    assert fin[0] is None and torch.equal(fin[1], outs["fused"][1])
+    if (h0_scale or 0) > 1:
+        return
+    w = torch.randn(B, T, 512)
+    ((ro * w.double()).sum() + 0.5 * rh.sum()).backward()
+    m.zero_grad()
+    out, hT = m(x.to(dev()), None if h0 is None else h0.to(dev()))
+    assert torch.equal(out.detach(), outs["fused"][0])
+    ((out * w.to(dev())).sum() + 0.5 * hT.sum()).backward()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        ref = leaves[n].grad
+        worst = max(worst, _maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-30))
+    assert worst <= 1e-4
+
+
 # ---- (13) repeatability of the gradients ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("meta", [
     dict(kind="ttlstm", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8),          # fused core, in = 1 sums
