@@ -54,8 +54,8 @@ constexpr bool f10_ok() {
   using F = F10<S>;
   return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::K % 32 == 0 && F::M % 16 == 0 &&
          F::I2 <= 16 && F::MPG % 4 == 0 && F::MPG * F::I2 == F::H && F::MT <= FAST_NW && F::MPG == 4 * F::MT &&
-         out_size_of<S>() == 4 * F::H && S::R[2] % 4 == 0 && F::J2 == 8 && (F::ROWS2 == 32 || F::ROWS2 == 64) && F::M2 % 128 == 0 &&
-         FAST_NW == 8;      // (ROWS2 = 64: H = 512, the four-/eight-wave kernel k_lstm_fwd_f10q only)
+         out_size_of<S>() == 4 * F::H && S::R[2] % 4 == 0 && F::J2 == 8 && (F::ROWS2 == 32 || F::ROWS2 == 48 || F::ROWS2 == 64) && F::M2 % 128 == 0 &&
+         FAST_NW == 8;      // (ROWS2 = 48 / 64: H = 384 / 512, the four-/six-/eight-wave kernel k_lstm_fwd_f10q only)
 }
 
 }  // namespace ttrnn

@@ -902,15 +902,18 @@ int launch_rnn_fwd_f10(const RnnShape& rs, GinSrc gin, const void* h0, const voi
 // eight S10 tiles = eight waves (k_lstm_fwd_f10q<S, 1, ..., QW = 8>), each with its tile's whole contraction resident (sixteen
 // k-blocks x two fp16 pieces = 128 VGPRs), one workgroup per CU.  The caller (ttrnn_g2.hip: fwd_t) supplies gin with BOTH biases
 // folded in (k_g2_bias) and this workspace; the reverse-time kernel stays the runtime-shape tier's (same reserve format).
-size_t f10_h512_workspace_bytes() { return f10_wfrag_bytes<ShpH512R8L>(); }
+// (round 5: the same route for H = 384, r = 8 — out modes (8, 12, 16), six S10 tiles = six waves: benchmarking.py --hidden_size 384)
+size_t f10_h512_workspace_bytes() {
+  return f10_wfrag_bytes<ShpH512R8L>() > f10_wfrag_bytes<ShpH384R8L>() ? f10_wfrag_bytes<ShpH512R8L>() : f10_wfrag_bytes<ShpH384R8L>();
+}
 bool f10_h512_fwd_available(const RnnShape& rs, int dtype) {
   return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & 8192) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM &&
-         rs.hid_blocks <= 1 && rs.in != 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && shape_matches<ShpH512R8L>(rs.hid_s);
+         rs.hid_blocks <= 1 && rs.in != 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT &&
+         (shape_matches<ShpH512R8L>(rs.hid_s) || shape_matches<ShpH384R8L>(rs.hid_s));
 }
-int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
-                            void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
-  using S = ShpH512R8L;
-  if (!ws) return TTRNN_ERR_WORKSPACE;
+template <class S>
+static int launch_h512_t(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid, void* out,
+                         void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(reinterpret_cast<unsigned char*>(ws) + F10H_HDR_BYTES);
   static_assert((F10H_EP + F10<S>::M) * sizeof(int) <= F10H_HDR_BYTES, "header");
@@ -920,6 +923,13 @@ int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0
   GinSrc src{gin, nullptr, 0};
   if (f10s_available(rs, h0 != nullptr)) return launch_rnn_fwd_f10_s(rs, src, h0, c0, packed_hid, ws, nullptr, out, hT, cT, reserve, stream);
   return launch_rnn_fwd_f10_q(rs, src, h0, c0, packed_hid, ws, nullptr, out, hT, cT, reserve, stream);
+}
+int launch_rnn_fwd_f10_h512(const RnnShape& rs, const float* gin, const void* h0, const void* c0, const float* packed_hid,
+                            void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
+  if (!ws) return TTRNN_ERR_WORKSPACE;
+  if (shape_matches<ShpH384R8L>(rs.hid_s))
+    return launch_h512_t<ShpH384R8L>(rs, gin, h0, c0, packed_hid, out, hT, cT, reserve, ws, stream);
+  return launch_h512_t<ShpH512R8L>(rs, gin, h0, c0, packed_hid, out, hT, cT, reserve, ws, stream);
 }
 
 }  // namespace ttrnn

@@ -49,10 +49,14 @@ __global__ void __launch_bounds__(f10q_waves<S>() * 64, f10q_waves<S>() == 4 ? 2
   static_assert(f10_ok<S>(), "shape not supported by the fused-core kernel");
   using F = F10<S>;
   constexpr int QW = f10q_waves<S>();
-  static_assert((QW == 4 || QW == 8) && F::MT2 % QW == 0 && F::NM % KH == 0, "one S10 tile per wave");
+  // EVEN = the S2 m-tiles divide over the waves (H = 256, 512): wave w takes m-tiles w + QW x over all chain-row tiles.  H = 384 (six
+  // waves, eight m-tiles x three row tiles): the 24 (m-tile, row tile) pairs are dealt out one by one, pair id = wave + QW i
+  constexpr bool EVEN = F::MT2 % QW == 0;
+  static_assert((QW == 4 || QW == 6 || QW == 8) && (F::MT2 * F::RT2) % QW == 0 && F::NM % KH == 0, "one S10 tile per wave");
   constexpr int H = F::H;
-  constexpr int XQ = F::MT2 / QW;                        // S2 m-tiles per wave
-  constexpr int RT2 = F::RT2;                            // chain-row tiles of S2 (H = 256: 2, H = 512: 4)
+  constexpr int RT2 = F::RT2;                            // chain-row tiles of S2 (H = 256: 2, H = 384: 3, H = 512: 4)
+  constexpr int TPW = F::MT2 * RT2 / QW;                 // (m-tile, row-tile) pairs of this wave: 4 for every supported shape
+  constexpr int XQ = EVEN ? F::MT2 / QW : TPW;           // S2 fragment sets of this wave
   constexpr int NH = F::NM / KH;                         // k-blocks per half
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(f10q_waves<S>() * 64, f10q_waves<S>() == 4 ? 2
 
   xh8 s1[XQ];
 #pragma unroll
-  for (int x = 0; x < XQ; ++x) f10h_load_w2<S>(s1[x], packed_hid, wave + QW * x, lane, hdr);
+  for (int x = 0; x < XQ; ++x) f10h_load_w2<S>(s1[x], packed_hid, EVEN ? wave + QW * x : (wave + QW * x) % F::MT2, lane, hdr);
   xh8 w10[KH][2][NH];
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh)
@@ -127,16 +131,24 @@ __global__ void __launch_bounds__(f10q_waves<S>() * 64, f10q_waves<S>() == 4 ? 2
     const _Float16* hp = hpl + (t & 1) * 2 * H;           // pieces of h_{t-1}
     _Float16* hn = hpl + ((t + 1) & 1) * 2 * H;           // pieces of h_t
     // ---- phase A: S2, four tiles at a time (MFMAs first, then the splitting) ---------------------------------------
-    constexpr int TPW = XQ * RT2;                          // (m-tile, row-tile) pairs of this wave: 4 for both supported shapes
     static_assert(TPW % 4 == 0, "tiles in groups of four");
 #pragma unroll
     for (int g0 = 0; g0 < TPW; g0 += 4) {
       f32x4 t2[4];
+      if constexpr (EVEN) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t2[i] = f10h_s2_mma<S>(s1[(g0 + i) / RT2], hp, (g0 + i) % RT2, lane);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 4; ++i) t2[i] = f10h_s2_mma<S>(s1[(g0 + i) / RT2], hp, (g0 + i) % RT2, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f10h_s2_store<S>(t2[i], img, wave + QW * ((g0 + i) / RT2), (g0 + i) % RT2, lane);
+        for (int i = 0; i < 4; ++i) f10h_s2_store<S>(t2[i], img, wave + QW * ((g0 + i) / RT2), (g0 + i) % RT2, lane);
+      } else {      // pair id = wave + QW (g0 + i): m-tile id % MT2 (fragment set g0 + i), row tile id / MT2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t2[i] = f10h_s2_mma<S>(s1[g0 + i], hp, (wave + QW * (g0 + i)) / F::MT2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          f10h_s2_store<S>(t2[i], img, (wave + QW * (g0 + i)) % F::MT2, (wave + QW * (g0 + i)) / F::MT2, lane);
+      }
     }
     TT_STAMP(0)
     lds_barrier();
@@ -228,6 +240,8 @@ int launch_rnn_fwd_f10_q(const RnnShape& rs, GinSrc gin, const void* h0, const v
     return launch_q<ShpH256R16L, 2>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
   if (shape_matches<ShpH512R8L>(rs.hid_s))      // eight waves, one workgroup per CU (launch_rnn_fwd_f10_h512)
     return launch_q<ShpH512R8L, 1>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
+  if (shape_matches<ShpH384R8L>(rs.hid_s))      // six waves (round 5)
+    return launch_q<ShpH384R8L, 1>(rs, gin, h0, c0, packed_hid, ws, bias_hid, out, hT, cT, reserve, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 

@@ -25,7 +25,7 @@ __device__ __forceinline__ int x_off(int row, int kk) {
   int g = 0;
   if constexpr (ns == 4) g = (-(row >> 2)) & 3;
   else if constexpr (ns == 8) g = (row >> 1) & 7;
-  else if constexpr (ns >= 16 && is_pow2(ns)) g = row & 15;
+  else if constexpr (ns >= 16 && ns % 16 == 0) g = row & 15;      // (XOR inside aligned blocks of 16 slots: K = 384 has 48)
   return ((row * ns + (slot ^ g)) << 3) + (kk & 7);
 }
 

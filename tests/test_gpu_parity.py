@@ -3055,18 +3055,20 @@ def test_two_core_reverse_kernel_ranges(case):
 
 
 # ---- (15) H = 512, r = 8: the fused-core forward under the runtime tier's K-in (ttrnn_fast_f10.hip: launch_rnn_fwd_f10_h512) ------------
-@pytest.mark.parametrize("B,T,inp,with_state", [(3, 9, 256, True), (5, 33, 40, False), (300, 6, 256, True)])
-def test_h512_fused_core_forward_route(B, T, inp, with_state):
+@pytest.mark.parametrize("B,T,inp,with_state,H", [(3, 9, 256, True, 512), (5, 33, 40, False, 512), (300, 6, 256, True, 512),
+                                                   (5, 33, 40, True, 384), (300, 6, 384, False, 384)])
+def test_h512_fused_core_forward_route(B, T, inp, with_state, H):
     """The reference's default benchmark shape (benchmarking.py:75-83: TT-LSTM hidden 512, ncores 3, ttrank 8): in split mode the
     forward recurrent kernel is the fused-core kernel as eight-wave workgroups (k_lstm_fwd_f10q<ShpH512R8L>) behind the runtime tier's
-    dense K-in; exact mode and option dev bit 13 keep the runtime-shape / any-shape kernels.  Outputs and every gradient (the reverse
+    dense K-in; exact mode and option dev bit 13 keep the runtime-shape / any-shape kernels.  Round 5: the same for --hidden_size 384
+    (out modes (8, 12, 16): six S10 tiles = six waves, the 24 S2 tiles dealt out one by one, a 48-slot image row swizzled in blocks
+    of sixteen).  Outputs and every gradient (the reverse
     kernel is the runtime tier's, reading this kernel's reserve) against the float64 oracle; the two forward kernels against each
     other; B = 300 > #CUs runs in two rounds of workgroups; batch split, repeat launches and the outputs-not-wanted call bit for bit."""
     import ttrnn_hip
     from oracle import ttrnn_oracle as O
     from ttrnn_hip import functional as F
     torch.manual_seed(97 + B)
-    H = 512
     m = build_module(dict(kind="ttlstm", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8), dev())
     spec = m._all_layers[0]._layer_spec()
     assert F.rnn_route(spec, B, T) == "fused_core"
