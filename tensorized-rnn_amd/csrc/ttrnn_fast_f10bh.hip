@@ -806,7 +806,7 @@ constexpr bool f10bl_ok() {
   using F = F10<S>;
   using B = F10BH<S>;
   using L = F10BL<S>;
-  return f10_ok<S>() && F::I2 == 16 && F::J2 == 8 && F::H % 64 == 0 && (L::NWV == 4 || L::NWV == 8) && B::FT % L::NWV == 0 &&
+  return f10_ok<S>() && F::I2 == 16 && F::J2 == 8 && F::H % 64 == 0 && (L::NWV == 4 || L::NWV == 6 || L::NWV == 8) && B::FT % L::NWV == 0 &&
          L::RW == 8 && L::RW * L::NWV == F::ROWS2 && B::K1 % 32 == 0 && B::K2 % 32 == 0 && (16 * L::XF) % F::R2 == 0 && F::R2 % 4 == 0;
 }
 
@@ -830,9 +830,10 @@ __global__ void __launch_bounds__(F10BL<S>::NT, F10BL<S>::NWV == 4 ? 2 : 1)
   using L = F10BL<S>;
   constexpr int H = F::H, GH = 4 * H, NWV = L::NWV, NT = L::NT, XF = L::XF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) float smax1[NWV];
+  __shared__ __attribute__((aligned(16))) float smax1[(NWV + 3) / 4 * 4];      // (six waves: two padding entries, zero)
   __shared__ float sl1[NWV];
   constexpr int PL1 = F::I2 * B::K1, PL2 = F::ROWS2 * B::K2;
+  if (threadIdx.x < (NWV + 3) / 4 * 4) smax1[threadIdx.x] = 0.f;
   float* dhs = reinterpret_cast<float*>(smem);                               // [H]: dh_{t-1}, written and read by the owning wave
   float* un1s = dhs + H;                                                     // [F::K] T01's inverse row scales
   _Float16* img1h = reinterpret_cast<_Float16*>(un1s + F::K);                // dg's two fp16 pieces [2][I2][K1] (x_off)
@@ -951,7 +952,7 @@ __global__ void __launch_bounds__(F10BL<S>::NT, F10BL<S>::NWV == 4 ? 2 : 1)
     float u2, t01f;
     {
       f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
-      if constexpr (NWV == 8) {
+      if constexpr (NWV > 4) {
         const f32x4 m5 = *reinterpret_cast<const f32x4*>(smax1 + 4);
         m4 = f32x4{fmaxf(m4[0], m5[0]), fmaxf(m4[1], m5[1]), fmaxf(m4[2], m5[2]), fmaxf(m4[3], m5[3])};
       }
@@ -1336,7 +1337,7 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
     // (B > #CUs; cfg4: 586 -> 526 us per layer) and at H = 512 (eight waves either way).  One sample per CU at H = 256 stays on
     // the eight-wave kernel, whose phases are shorter than the four barriers cost (cfg2: 2 851 against 3 301 cycles per step).
     // Option dev bit 15: the eight-wave kernel everywhere; bit 7: this kernel everywhere (A/B, the stamps of lesson 51)
-    const bool local = F10BL<S>::NWV == 8 || rs.B > device_cu_count() || (opt(OPT_DEV) & 128);
+    const bool local = F10BL<S>::NWV != 4 || rs.B > device_cu_count() || (opt(OPT_DEV) & 128);
     if (local && !(opt(OPT_DEV) & 32768)) {
       constexpr size_t ldsl = f10bl_lds_bytes<S>();
       static_assert(ldsl <= 64 * 1024, "raise the dynamic LDS limit for this shape");
@@ -1363,12 +1364,16 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
       return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
     }
   }
-  auto kern = dg ? k_lstm_bwd_f10h<S, true> : k_lstm_bwd_f10h<S, false>;
-  if (lds > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
-                     (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
-                     (float*)d_c0, dg ? diag : nullptr, bs);
-  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  if constexpr (f10bh_ok<S>()) {
+    auto kern = dg ? k_lstm_bwd_f10h<S, true> : k_lstm_bwd_f10h<S, false>;
+    if (lds > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
+                       (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                       (float*)d_c0, dg ? diag : nullptr, bs);
+    return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  } else {
+    return TTRNN_ERR_UNSUPPORTED;      // (H = 384: the wave-local kernel only; dev bit 15 has no eight-wave kernel to select)
+  }
 }
 
 }  // namespace
@@ -1384,12 +1389,15 @@ bool f10bh_available(const RnnShape& rs, int dtype) {
 
 // the reference's default benchmark shape (H = 512, r = 8): a runtime-tier shape whose reverse-time recurrence runs here in split
 // mode — eight gate waves, four feature tiles of T01 (K = 128) and two T2 pairs per wave (dev bit 16384 keeps the tier's kernel)
+// (round 5: H = 384, r = 8 — benchmarking.py --hidden_size 384 — on the wave-local kernel as six waves)
 bool f10bh_h512_available(const RnnShape& rs, int dtype) {
   return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && opt(OPT_GEMM_PIECES) != 3 &&
-         !(opt(OPT_DEV) & 16384) && rs.T > 0 && shape_matches<ShpH512R8L>(rs.hid_s);
+         !(opt(OPT_DEV) & 16384) && rs.T > 0 && (shape_matches<ShpH512R8L>(rs.hid_s) || shape_matches<ShpH384R8L>(rs.hid_s));
 }
 size_t f10bh_h512_workspace_bytes() {
-  return F10BH<ShpH512R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH512R8L>::FRAGS * sizeof(xh8) + 4096;
+  constexpr size_t a = F10BH<ShpH512R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH512R8L>::FRAGS * sizeof(xh8) + 4096;
+  constexpr size_t b = F10BH<ShpH384R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH384R8L>::FRAGS * sizeof(xh8) + 4096;
+  return a > b ? a : b;
 }
 int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
                             const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
@@ -1397,7 +1405,9 @@ int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* pac
   BwdStats bs;
   if (stats) bs.colmax = reinterpret_cast<unsigned*>(stats);      // (cleared by the prep launch)
   unsigned long long* diag = reinterpret_cast<unsigned long long*>((char*)ws + f10bh_h512_workspace_bytes() - 4096);
-  int st = launch_t<ShpH512R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream, bs);
+  int st = shape_matches<ShpH384R8L>(rs.hid_s)
+               ? launch_t<ShpH384R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream, bs)
+               : launch_t<ShpH512R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream, bs);
   if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, rs.G * rs.H, nullptr, stats, stream);
   return st;
 }
