@@ -137,7 +137,7 @@ int ttrnn_get_fp32_math(void);
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
  *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path),
- *   "no_gemm3", "dev" (0..1048575: developer bit mask, A/B route switches between kernels that compute the same result;
+ *   "no_gemm3", "dev" (0..4194303: developer bit mask, A/B route switches between kernels that compute the same result;
  *   csrc/ttrnn_opts.h lists the bits).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */
@@ -298,6 +298,11 @@ int ttrnn_rnn_forward_cores(const ttrnn_rnn_desc* desc, const void* x, const voi
 #define TTRNN_ROUTE_MERGED_BIG 3      /* merged two-core kernels of the H = 1024, d = 4, r = 32 shape (ttrnn_fast_big) */
 #define TTRNN_ROUTE_RUNTIME_MFMA 4    /* runtime-shape two-stage MFMA kernels, any d >= 2 (ttrnn_g2.hip)               */
 int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc);   /* TTRNN_ROUTE_* or a negative ttrnn_status */
+/* Samples one workgroup of the recurrent forward kernel carries (1, or 2: the runtime-shape tier pairs samples where the hidden
+ * matrix's merged head is streamed from L2 every step and the batch exceeds the CU count, so that each streamed block feeds two —
+ * the naive per-gate sets of tt_linearset.py:5-38 at benchmarking.py's defaults).  Pure host logic; a negative ttrnn_status on a
+ * bad descriptor. */
+int ttrnn_rnn_forward_samples_per_workgroup(const ttrnn_rnn_desc* desc);
 
 /* Reverse-time part of BPTT (reference: torch autograd through lstm.py:123-133 / gru.py:124-134).
  *   d_out[B][T][H], d_hT/d_cT[B][H] (any may be NULL = zeros)

@@ -173,6 +173,7 @@ struct G2Plan {
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
   int abl;                                     // -DTTRNN_ABLATIONS builds: option `dev` (result-destroying switches of the stamps tool); else 0
   int b_hun;                                   // rows of the inverse-row-scale table kept in LDS (0: read from the workspace)
+  int pair;                                    // forward only: k_g2_fwd_p's plan — two samples per workgroup, LDS carve-up for both (g2_plan_pair)
   int b_cmx;                                   // running column maxima of the gate gradients [G*H (+ H: GRU's hidden-side n)] floats, behind
                                                // everything else; 0 = no room (the by-product is then not offered for this shape)
 };
@@ -253,6 +254,31 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
     if (w1 < (w0 < 2 ? w0 : 2)) p->b_cmx = 0;
   }
   p->ok = p->okf && p->okb;
+}
+
+// The forward plan of k_g2_fwd_p (ttrnn_g2.hip): the eight-wave plan with the LDS images of TWO samples — the h image in its
+// eight live k-slots per row, the stage-2 operand image with rows (sample, i_t), two output vectors.  For streamed heads only
+// (the caller checks that), I_t <= 8 (both samples in ONE column tile), J_t <= 8 (term-packed stage 1), H <= 1024.
+constexpr int G2_PAIR_NS = 2;
+constexpr int G2_PAIR_JS = 8;
+inline void g2_plan_pair(G2Plan* p, const RnnShape& rs) {
+  g2_plan(p, rs, true);
+  p->okf = 0; p->ok = 0; p->okb = 0;
+  if (!p->hid.ok) return;
+  const G2Mat& m = p->hid;
+  if (m.N2T != 1 || G2_PAIR_NS * m.It > 16 || !m.pack8 || rs.H > 2 * G2_NT_MAX) return;
+  p->pair = 1;
+  p->upt = g2_ceil(rs.H, G2_NT_MAX);
+  p->b_upt = p->upt;
+  p->f_hb = (int)g2_al((size_t)2 * G2_PAIR_NS * 16 * m.N1T * G2_PAIR_JS * 2);
+  p->f_img = (int)g2_al((size_t)2 * G2_PAIR_NS * m.It * m.K2S * 2);
+  p->f_ybuf = (int)g2_al((size_t)G2_PAIR_NS * m.KSPLIT * rs.G * rs.H * 4);
+  p->f_tab = (int)g2_al((size_t)m.M1T * 4 * 4);
+  p->f_sc = (int)g2_al((size_t)(m.Ih + m.It) * 4);
+  p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab + p->f_sc;
+  p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) + G2_LDS_STATIC <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
+  p->f_lds += p->f_t1;
+  p->okf = p->f_lds + G2_LDS_STATIC <= G2_LDS_LIMIT;
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams

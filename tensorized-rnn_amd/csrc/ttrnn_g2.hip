@@ -776,6 +776,336 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     }
 }
 
+// ---- forward, TWO samples per workgroup (round 5) --------------------------------------------------------------------------------
+// Shapes whose head does not fit the register slots stream it from L2 every step — per WORKGROUP.  With I_t <= 8 a sample fills
+// half of stage 2's sixteen columns: this kernel gives the other half to a second sample, so every streamed block feeds two
+// (`--naive_tt` at H = 512: 512 KB per step and workgroup; B = 512 ran as two co-resident four-wave workgroups per CU pulling
+// 1 MB per step through one L2 port).  Eight waves, the plan of the eight-wave kernel (G2Plan::pair), J_t <= 8 (stage 1 term-packed
+// into one MFMA per tile).  Layout changes against k_g2_fwd: the h image holds its eight live k-slots per row only ([2][NS][16 N1T][8]);
+// the stage-2 operand image has rows (sample, i_t); stage 1 walks (sample, column tile, m tile) with the m tile fastest — a wave's
+// contiguous share, the column operand read once per column tile; ybuf is [NS][KSPLIT][G H].  An odd batch's last workgroup computes
+// its second sample on a copy of the first and stores nothing for it.
+constexpr int G2P_NS = G2_PAIR_NS;
+constexpr int G2P_JS = G2_PAIR_JS;
+
+template <int CELL, typename TS, int UPT, bool IN1, bool DIAG>
+__global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
+                                                    const TS* __restrict__ c0, const xh8* __restrict__ fs2,
+                                                    const float* __restrict__ ft1, const int* __restrict__ hdr,
+                                                    TS* __restrict__ out, TS* __restrict__ hT,
+                                                    TS* __restrict__ cT, float* __restrict__ reserve) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NS = G2P_NS, JS = G2P_JS, NW = G2_NW_MAX, NT = NW * 64;
+  constexpr bool LSTM = CELL == TTRNN_LSTM;
+  constexpr int NG = LSTM ? 4 : 3;
+  const G2Mat& m = P.hid;
+  _Float16* hb = reinterpret_cast<_Float16*>(smem);                 // stage 1's operand: two fp16 planes of 2^9 h, [2][NS][16*N1T][JS]
+  const int HSS = 16 * m.N1T * JS, HPL = NS * HSS;
+  _Float16* img = reinterpret_cast<_Float16*>(smem + P.f_hb);     // stage 2's operand: two fp16 planes of 2^a C1, rows (sample, i_t)
+  float* ybuf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img);
+  int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);                   // [M1T][4]
+  float* unf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // [I_h]: 2^-(ep + 13 + 9 + r), then
+  float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag_a / _b)
+  xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab + P.f_sc); // tail fragments (P.f_t1 > 0)
+  const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
+  const int rows2 = NS * m.It;
+  const int plane = rows2 * m.K2S;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int H = P.H, T = P.T, GH = P.G * P.H, upt = P.upt;
+  const float r1sc = ldexpf(1.f, g2_r1_expo(m.Jt));                 // stage-1 sums -> below 2^15 before they are split
+  size_t bsm[NS];
+  bool live[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const size_t bi = (size_t)blockIdx.x * NS + s;
+    live[s] = bi < (size_t)P.B;
+    bsm[s] = live[s] ? bi : (size_t)blockIdx.x * NS;
+  }
+
+  // ---- one-time set-up ----------------------------------------------------------------------------------------------------------
+  for (int e = tid; e < (P.f_hb + P.f_img) / 4; e += NT) reinterpret_cast<unsigned*>(smem)[e] = 0u;
+  // stage-1 store offsets: lane (c, q) of m tile mt1 holds rows m1 = 16 mt1 + 4 q .. + 3 = four consecutive ranks a of ONE i_t;
+  // the column part (j_h = 16 nt1 + c, the sample's rows) is added per column tile
+  for (int e = tid; e < m.M1T * 4; e += NT) {
+    const int m1 = 16 * (e >> 2) + 4 * (e & 3);
+    const int it = m1 / m.Rp, a = m1 - it * m.Rp;
+    s1off[e] = it < m.It ? it * m.K2S + (m.ng > 1 ? (a / m.Rb) * m.Kg + a % m.Rb : a) : -1;     // gate-major for block-diagonal heads
+  }
+  for (int e = tid; e < m.Ih; e += NT) unf[e] = ldexpf(1.f, -(hdr[m.It + 64 + e] + 13 + 9 + g2_r1_expo(m.Jt)));
+  for (int e = tid; e < m.It; e += NT) ung[e] = ldexpf(1.f, -hdr[e]);
+  const int s1_rs = m.ng > 1 ? m.Rb : m.Rp;
+  const bool t1_lds = P.f_t1 > 0;
+  if (t1_lds)
+    for (int e = tid; e < (int)(m.ft1_bytes / 16); e += NT) lt1[e] = ft1h[e];
+  float hst[NS][UPT], cst[NS][UPT];
+  int hoff[UPT];
+  f32x4 gi[NS][UPT], bb[UPT];      // input_size == 1: gi[0] holds the unit row's projection, bb the bias row
+  const f32x4* gin4 = reinterpret_cast<const f32x4*>(gs.gin);
+  const f32x4* bil4 = reinterpret_cast<const f32x4*>(bilv);
+  const TS* xs = reinterpret_cast<const TS*>(gs.x);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    hoff[u] = 0; bb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int hid = tid + u * NT;
+    const bool on = u < upt && hid < H;
+    if (on) hoff[u] = (hid / m.Jt) * JS + hid % m.Jt;
+    if (IN1 && on) bb[u] = bil4[hid];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      hst[s][u] = 0.f; cst[s][u] = 0.f; gi[s][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (on) {
+        hst[s][u] = h0 ? ld(h0, bsm[s] * H + hid) : 0.f;
+        cst[s][u] = (LSTM && c0) ? ld(c0, bsm[s] * H + hid) : 0.f;
+        if (IN1) gi[s][u] = gin4[hid];
+        else if (T > 0) gi[s][u] = gin4[(bsm[s] * T) * H + hid];
+      }
+    }
+  }
+  // a caller's h_0 outside (-1, 1): per sample, as in k_g2_fwd
+  float h0un[NS], h0sc[NS];
+  {
+    float mx[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      mx[s] = 0.f;
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) mx[s] = fmaxf(mx[s], fabsf(hst[s][u]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx[s] = fmaxf(mx[s], __shfl_xor(mx[s], o));
+      if (lane == 0) ybuf[s * NW + wave] = mx[s];                        // ybuf: free until the first stage 2
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float v = 0.f;
+      for (int w = 0; w < NW; ++w) v = fmaxf(v, ybuf[s * NW + w]);
+      int e0 = g2_expo(v);
+      if (e0 < 0) e0 = 0;
+      h0sc[s] = ldexpf(1.f, -e0);
+      h0un[s] = ldexpf(1.f, e0);
+#pragma unroll
+      for (int u = 0; u < UPT; ++u)
+        if (u < upt && tid + u * NT < H) {
+          _Float16 p0, p1;
+          split2h(hst[s][u] * (h0sc[s] * G2_HSC), p0, p1);
+          hb[s * HSS + hoff[u]] = p0; hb[HPL + s * HSS + hoff[u]] = p1;
+        }
+    }
+  }
+  // head stream of this wave: G2_PF rolling register slots
+  const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
+  const int total = nu_w * m.KBP;
+  const xh8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 2 * 64 + lane;
+  xh8 wbuf[G2_PF][2];
+#pragma unroll
+  for (int j = 0; j < G2_PF; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (_Float16)0.f;
+      if (total > 0) wbuf[j][p] = sp[(size_t)j * 2 * 64 + p * 64];
+    }
+  // stage 1: this wave's contiguous share of the (sample, column tile, m tile) walk
+  const int NC = NS * m.N1T;
+  const int tpw = (NC * m.M1T + NW - 1) / NW;
+  const int tt0 = wave * tpw, tt1 = tt0 + tpw < NC * m.M1T ? tt0 + tpw : NC * m.M1T;
+  const int cn0 = tt0 / m.M1T, mt0 = tt0 - cn0 * m.M1T;
+  const int s0 = cn0 / m.N1T, nt0 = cn0 - s0 * m.N1T;
+  // stage 2: the lane's column = (sample, i_t)
+  const bool col_on = c < rows2;
+  const int col_s = col_on ? c / m.It : 0, col_it = col_on ? c - col_s * m.It : 0;
+  const int crow = col_on ? c : rows2 - 1;
+  __syncthreads();                                   // unf / ung are complete
+  const float col_ug = ung[col_it];
+  const int col_y = col_s * m.KSPLIT * GH + col_it;
+  XChunk<TS> xq[NS];                 // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    xq[s].cur = 0.f; xq[s].nxt = 0.f;
+    if (IN1) xq[s].init(xs, bsm[s] * T, T, lane);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) here: no wait for the set-up loads inside the time loop
+  lds_barrier();
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = 0;
+  if constexpr (DIAG) last_ = stamp();
+
+  for (int t = 0; t < T; ++t) {
+    // ---- stage 1: C1 = Gt h of both samples, split into the two fp16 planes of stage 2's operand ----------------------------------
+    auto stage1 = [&](auto frag) {
+      int cs = s0, cnt = nt0, mt = mt0;
+      for (int tt = tt0; tt < tt1;) {
+        const int jh = 16 * cnt + c;
+        const xh8 xb = *reinterpret_cast<const xh8*>(hb + (q >> 1) * HPL + cs * HSS + jh * JS);
+        const int coff = jh < m.Jh ? jh * s1_rs + cs * m.It * m.K2S : -1;
+        const int mend = m.M1T - mt < tt1 - tt ? m.M1T : mt + (tt1 - tt);
+        tt += mend - mt;
+        for (; mt + 1 < mend; mt += 2) {                       // two tiles: independent MFMA / split chains
+          const xh8 wa = frag(mt * 64 + lane), wb = frag((mt + 1) * 64 + lane);
+          const int oa = s1off[mt * 4 + q], ob = s1off[(mt + 1) * 4 + q];
+          f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xb, accb, 0, 0, 0);
+          if (oa >= 0 && coff >= 0) store_split4_h(img, plane, oa + coff, acca * r1sc);
+          if (ob >= 0 && coff >= 0) store_split4_h(img, plane, ob + coff, accb * r1sc);
+        }
+        if (mt < mend) {
+          const xh8 wa = frag(mt * 64 + lane);
+          const int oa = s1off[mt * 4 + q];
+          f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f};
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acca, 0, 0, 0);
+          if (oa >= 0 && coff >= 0) store_split4_h(img, plane, oa + coff, acca * r1sc);
+          ++mt;
+        }
+        if (mt == m.M1T) { mt = 0; if (++cnt == m.N1T) { cnt = 0; ++cs; } }
+      }
+    };
+    if (t1_lds) stage1([&](int i) { return lt1[i]; });
+    else stage1([&](int i) { return ft1h[i]; });
+    TT_STAMP(0)
+    lds_barrier();
+    TT_STAMP(1)
+    // ---- stage 2: the streamed head against sixteen columns = two samples' i_t ---------------------------------------------------
+    // (every slot is refilled unconditionally right after its use, padding blocks included: see k_g2_fwd)
+    {
+      int seq = 0;
+      for (int ui = 0; ui < nu_w; ++ui) {
+        const int u = wave + ui * NW;
+        const int tile = u / m.KSPLIT, part = u - tile * m.KSPLIT;
+        const int kloc0 = part * m.KPER;                                              // inside the tile's own k range
+        const int kbase = (m.ng > 1 ? (16 * tile) / m.IhG : 0) * m.NKBt;              // block-diagonal heads: the gate's range
+        const _Float16* brow = img + crow * m.K2S + 8 * q + 32 * kbase;
+        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+        xh8 bf[2][2];
+        {
+          const int kbc = kloc0 < m.NKBt ? kloc0 : m.NKBt - 1;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kbc);
+        }
+        for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
+#pragma unroll
+          for (int j = 0; j < G2_PF; ++j) {
+            const int kb = kloc0 + kbl + j;
+            if (kbl + j + 1 < m.KPER && kb + 1 < m.NKBt) {     // the next block is live (padding blocks are never read)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * (kb + 1));
+            }
+            if (kbl + j < m.KPER && kb < m.NKBt) split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
+            {
+              int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
+              nxt -= nxt >= total ? total : 0;
+#pragma unroll
+              for (int p = 0; p < 2; ++p) wbuf[j][p] = sp[(size_t)nxt * 2 * 64 + p * 64];
+              ++seq;
+            }
+          }
+        }
+        const f32x4 acc = acc_hi + acc_lo;
+        if (col_on) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ih = 16 * tile + 4 * q + j;
+            if (ih < m.Ih) ybuf[col_y + part * GH + ih * m.It] = acc[j] * (unf[ih] * col_ug);
+          }
+        }
+      }
+    }
+    TT_STAMP(2)
+    lds_barrier();
+    TT_STAMP(3)
+    // ---- gates + state (lstm.py:26-32 / gru.py:38-44), both samples --------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const size_t bt = bsm[s] * T + t;
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int hid = tid + u * NT;
+        if (u < upt && hid < H) {
+          float y[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int pt = 0; pt < m.KSPLIT; ++pt) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) y[g] += ybuf[(s * m.KSPLIT + pt) * GH + g * H + hid];
+          }
+          const float un_t = (t == 0 || !LSTM) ? h0un[s] : 1.0f;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) y[g] *= un_t;         // exact: a power of two
+          f32x4 g4 = gi[s][u];
+          if (IN1) g4 = bb[u] + xq[s].at(t) * gi[0][u];
+          float hy;
+          if (LSTM) {                                    // gin slots i,g,f,o
+            const float ig = fsigmoid(y[0] + g4[0]);
+            const float fg = fsigmoid(y[1] + g4[2]);
+            const float gg = ftanh(y[2] + g4[1]);
+            const float og = fsigmoid(y[3] + g4[3]);
+            const float cy = fg * cst[s][u] + ig * gg;
+            hy = og * ftanh(cy);
+            cst[s][u] = cy;
+            if (reserve && live[s]) {
+              *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hid)) = f32x4{ig, gg, fg, og};
+              reserve[res_cell((size_t)P.B * T, bt, H, hid)] = cy;
+            }
+          } else {                                       // gin slots r,z,n, b_hid of n
+            const float hn = y[2] + g4[3];
+            const float rg = fsigmoid(y[0] + g4[0]);
+            const float zg = fsigmoid(y[1] + g4[1]);
+            const float ng = ftanh(g4[2] + rg * hn);
+            hy = (1.0f - zg) * ng + zg * hst[s][u];
+            if (reserve && live[s]) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+          }
+          hy = round_to(hy, out);                        // the stored value is what the next step and the next layer see
+          if (out && live[s]) st(out, bt * H + hid, hy);
+          hst[s][u] = hy;
+          {
+            _Float16 p0, p1;
+            split2h(hy * (LSTM ? G2_HSC : G2_HSC * h0sc[s]), p0, p1);
+            hb[s * HSS + hoff[u]] = p0; hb[HPL + s * HSS + hoff[u]] = p1;
+          }
+        }
+      }
+    }
+    // gate inputs of the NEXT step: requested outside any lane-divergent region (lesson 53), used a whole step later
+    if (!IN1) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const size_t bn = (bsm[s] * T + (t + 1 < T ? t + 1 : t)) * H;
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+          const int hid0 = tid + u * NT;
+          gi[s][u] = gin4[bn + ((u < upt && hid0 < H) ? hid0 : 0)];
+        }
+      }
+    }
+    if (IN1) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xq[s].advance(xs, bsm[s] * T, T, t, lane);
+    }
+    TT_STAMP(4)
+    lds_barrier();
+    TT_STAMP(5)
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && reserve && blockIdx.x < 4) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (blockIdx.x * G2_NW_MAX + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = seg[i];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int hid = tid + u * NT;
+      if (u < upt && hid < H && live[s]) {
+        if (hT) st(hT, bsm[s] * H + hid, hst[s][u]);
+        if (LSTM && cT) st(cT, bsm[s] * H + hid, cst[s][u]);
+      }
+    }
+}
+
 // maximum over the 64 lanes, in every lane: rotations inside the 16-lane rows (DPP), then one lane of each row — six ds_bpermute
 // round trips (__shfl_xor) were 600 cycles of the gate phase
 template <int N>
@@ -1348,7 +1678,7 @@ static bool g2_bwd_res(const G2Plan& p) {
          !(opt(OPT_DEV) & 2048 && p.hid.ng > 1);
 }
 
-static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
+static void plan_for_single(G2Plan* p, const RnnShape& rs, bool backward) {
   const bool wide = rs.B <= device_cu_count();
   if (!wide && backward && !(opt(OPT_DEV) & 4096)) {
     // the same trade in the reverse kernel: eight-wave workgroups with the head^T fragments resident (two rounds) instead of two
@@ -1373,6 +1703,18 @@ static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
   if (q.hid.ok && (backward ? q.okb : q.okf)) *p = q;
 }
 
+// forward, more samples than CUs, a head that no plan keeps in registers: TWO samples per workgroup share the stream (k_g2_fwd_p)
+// — where that kernel's images fit LDS (dev bit 19: A/B switch, one sample per workgroup as before)
+static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
+  plan_for_single(p, rs, backward);
+  const bool any_b = (opt(OPT_DEV) & (1 << 20)) && rs.B >= 2;      // (dev bit 20: the tests' switch — pairs whatever the batch)
+  if (backward || (rs.B <= device_cu_count() && !any_b) || (opt(OPT_DEV) & (1 << 19))) return;
+  if (p->hid.ok && p->okf && (p->hid.UW * p->hid.KBP <= G2_PF || g2_fwd_res16(*p))) return;      // resident
+  G2Plan q;
+  g2_plan_pair(&q, rs);
+  if (q.okf) *p = q;
+}
+
 static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
   if (dtype != TTRNN_F32 && dtype != TTRNN_BF16) return false;
@@ -1387,6 +1729,11 @@ static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
 }
 bool g2_rnn_available(const RnnShape& rs, int dtype) { return g2_available(rs, dtype, false); }
 bool g2_rnn_bwd_available(const RnnShape& rs, int dtype) { return g2_available(rs, dtype, true); }
+bool g2_rnn_fwd_paired(const RnnShape& rs) {
+  G2Plan p;
+  plan_for(&p, rs, false);
+  return p.okf && p.pair;
+}
 
 struct G2FwdWs {
   size_t gin, bilv, rec, ident, wdense, planes, xpad, lin, total;
@@ -1500,6 +1847,28 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   st = prep(rs.hid_s, P.hid, false, packed_hid, rec, &fs2, &ft1, stream, &hdr);
   if (st != TTRNN_OK) return st;
   GinSrc src{gin, x, in1 ? 1 : 0};
+  if (P.pair) {
+    const unsigned grid = (unsigned)((rs.B + G2_PAIR_NS - 1) / G2_PAIR_NS);
+#define TT_G2_PAIR(CELLV, UPTV, IN1V, DG)                                                                                   \
+  do {                                                                                                                     \
+    auto kern = k_g2_fwd_p<CELLV, TS, UPTV, IN1V, DG>;                                                                     \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;           \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_NT_MAX), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,     \
+                       reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve);                  \
+  } while (0)
+    const bool dg = opt(OPT_DIAG) && reserve && P.upt == 1 && !in1 && rs.cell == TTRNN_LSTM && std::is_same<TS, float>::value;
+    if (dg) {
+      if constexpr (std::is_same<TS, float>::value) TT_G2_PAIR(TTRNN_LSTM, 1, false, true);
+    } else if (rs.cell == TTRNN_LSTM) {
+      if (P.upt == 1) { if (in1) TT_G2_PAIR(TTRNN_LSTM, 1, true, false); else TT_G2_PAIR(TTRNN_LSTM, 1, false, false); }
+      else { if (in1) TT_G2_PAIR(TTRNN_LSTM, 2, true, false); else TT_G2_PAIR(TTRNN_LSTM, 2, false, false); }
+    } else {
+      if (P.upt == 1) { if (in1) TT_G2_PAIR(TTRNN_GRU, 1, true, false); else TT_G2_PAIR(TTRNN_GRU, 1, false, false); }
+      else { if (in1) TT_G2_PAIR(TTRNN_GRU, 2, true, false); else TT_G2_PAIR(TTRNN_GRU, 2, false, false); }
+    }
+#undef TT_G2_PAIR
+    return check();
+  }
   const bool res = P.hid.UW * P.hid.KBP <= G2_PF;      // head fragments register-resident for every wave
   const bool res16 = g2_fwd_res16(P);                  // ... in sixteen slots (eight-wave workgroups, UPT <= 2)
 #define TT_G2_FWD(CELLV, UPTV, SLOT)                                                                                      \

@@ -286,6 +286,7 @@ int launch_ttlinear_bwd_big(const TtShape& s, int dtype, int64_t n_rows, const f
 
 // runtime-shape two-stage MFMA kernels (ttrnn_g2.hip): any TT-LSTM / TT-GRU layer whose hidden matrix has d >= 2 cores
 bool g2_rnn_available(const RnnShape& rs, int dtype);         // forward kernel
+bool g2_rnn_fwd_paired(const RnnShape& rs);                   // ... as k_g2_fwd_p: two samples per workgroup share the head stream
 bool g2_rnn_bwd_available(const RnnShape& rs, int dtype);     // reverse-time kernel (larger LDS footprint for wide shapes)
 size_t g2_rnn_fwd_workspace(const RnnShape& rs);
 size_t g2_rnn_bwd_workspace(const RnnShape& rs);

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "ttrnn_rnn_reserve_bytes": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 12 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_forward_route": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
+    "ttrnn_rnn_forward_samples_per_workgroup": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_prepare_supported": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_out_optional": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_forward_phase": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int] + [_P] * 12 + [ctypes.c_size_t, _P]),

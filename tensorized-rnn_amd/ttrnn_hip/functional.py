@@ -623,6 +623,15 @@ def rnn_route(spec, batch, seq_len, dtype=torch.float32):
     return _lib.ROUTES[code]
 
 
+def rnn_samples_per_workgroup(spec, batch, seq_len, dtype=torch.float32):
+    """Samples a workgroup of the recurrent forward kernel carries for this layer at this size (2: the tier's paired kernel)."""
+    desc = spec.desc(batch, seq_len, _DT[dtype])
+    n = _lib.load().ttrnn_rnn_forward_samples_per_workgroup(ctypes.byref(desc))
+    if n < 0:
+        check(n, "ttrnn_rnn_forward_samples_per_workgroup")
+    return n
+
+
 def rnn_backward_route(spec, batch, seq_len, dtype=torch.float32, want_state=False):
     """Name of the kernel family of the reverse-time kernel (BPTT) for this layer at this size."""
     desc = spec.desc(batch, seq_len, _DT[dtype])

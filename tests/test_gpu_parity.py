@@ -861,6 +861,83 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     print(kind, H, d, r, "false block promise: violations counted", violations, "| promised - dense|", _maxabs(promised, as_dense))
 
 
+PAIR_CASES = [
+    # kind, in, H, d, r, naive, B, T, big_h0 — heads the tier streams from L2 every step (no plan keeps them in registers)
+    ("ttlstm", 40, 512, 3, 8, True, 5, 6, False),       # benchmarking.py --naive_tt; odd batch: the last workgroup holds one sample
+    ("ttlstm", 1, 512, 3, 8, True, 4, 9, True),
+    ("ttgru", 28, 512, 3, 8, True, 6, 5, True),
+    ("ttgru", 40, 384, 3, 16, True, 4, 6, False),       # joint rank 48
+    ("ttlstm", 1, 384, 3, 4, True, 3, 7, False),
+]
+
+
+@pytest.mark.parametrize("kind,inp,H,d,r,naive,B,T,big_h0", PAIR_CASES)
+def test_runtime_tier_two_samples_per_workgroup(kind, inp, H, d, r, naive, B, T, big_h0):
+    """k_g2_fwd_p: where the runtime tier streams the merged head from L2 every step and the batch exceeds the CU count, two samples
+    share a workgroup — and every streamed block (`--naive_tt` at H = 512: 512 KB per step).  `dev` bit 20 takes small batches there:
+    outputs, final states and the training reserve (through the gradients the reverse kernel derives from it) against the oracle,
+    and BIT-identical to the one-sample-per-workgroup kernel (same products, same order, per sample)."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(31)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r, is_naive=naive)
+    m = build_module(meta, dev())
+    lstm = kind == "ttlstm"
+    spec = m._all_layers[0]._layer_spec()
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, H)
+    h0 = torch.randn(B, H) * (5.0 if big_h0 else 0.3)
+    c0 = torch.randn(B, H)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    if lstm:
+        ro, (rh, rc) = O.lstm_forward(layers, xr, (h0, c0))
+        ((ro * w).sum() + rc.sum() + rh.sum()).backward()
+    else:
+        ro, rh = O.gru_forward(layers, xr, h0)
+        ((ro * w).sum() + rh.sum()).backward()
+    init = (h0.to(dev()), c0.to(dev())) if lstm else h0.to(dev())
+
+    def run(train):
+        xg = x.to(dev()).requires_grad_(train)
+        with torch.set_grad_enabled(train):
+            res = m(xg, init)
+            if train:
+                m.zero_grad()
+                ((res[0] * w.to(dev())).sum() + (res[1][1].sum() + res[1][0].sum() if lstm else res[1].sum())).backward()
+        return res, xg
+
+    assert F.rnn_route(spec, B, T) == "runtime_mfma"
+    assert F.rnn_samples_per_workgroup(spec, B, T) == 1
+    with ttrnn_hip.option("dev", 1 << 20):
+        assert F.rnn_samples_per_workgroup(spec, B, T) == 2
+        assert F.rnn_samples_per_workgroup(spec, 1, T) == 1
+        res, xg = run(True)
+        grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+        with ttrnn_hip.option("dev", (1 << 20) | (1 << 19)):
+            assert F.rnn_samples_per_workgroup(spec, B, T) == 1
+    out = res[0].detach()
+    assert _maxabs(out, ro.detach()) <= 1e-5 * max(1.0, float(ro.detach().abs().max()))
+    assert _maxabs((res[1][0] if lstm else res[1]).detach(), rh.detach()) <= 1e-5 * max(1.0, float(rh.detach().abs().max()))
+    if lstm:
+        assert _maxabs(res[1][1].detach(), rc.detach()) <= 1e-5 * max(1.0, float(rc.detach().abs().max()))
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6)
+    for name, g in grads.items():
+        key = name.replace(".gate", ".gates.")
+        if key in leaves:
+            ref = leaves[key].grad
+            assert _maxabs(g, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    single, _ = run(False)
+    assert torch.equal(single[0], out)
+    assert torch.equal(single[1][0] if lstm else single[1], (res[1][0] if lstm else res[1]).detach())
+    # more samples than CUs: the default route pairs them
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert F.rnn_samples_per_workgroup(spec, cus + 1, T) == 2
+    assert F.rnn_samples_per_workgroup(spec, cus, T) == 1
+
+
 def test_runtime_shape_kernels_bf16_storage_and_states():
     """bf16 storage (fp32 state / accumulation) and non-zero initial states through the runtime-shape route."""
     import ttrnn_hip
