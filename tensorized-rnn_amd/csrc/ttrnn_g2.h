@@ -48,6 +48,7 @@ struct G2Mat {
   // planes of the h image [2][16*N1T][JS]
   int KB1, pack8, JS;
   int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
+  int wrap;                         // forward head stream: blocks of cyclic copy behind every wave's live blocks (k_g2_fwd_p: G2_PF; else 0)
   // reverse T2 (f16 MFMA, two pieces per operand): M = Jh*Rp, N = It, K = Ih
   int bM2T, bNKB, bT2, bKBP, bU, bUW, bSW;         // no k split: T1 reads the complete dC1; bSW = blocks of a wave's (compact) stream
   int IhS;                          // fp16 dy planes [16*N2T][IhS]
@@ -261,13 +262,20 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 // (the caller checks that), I_t <= 8 (both samples in ONE column tile), J_t <= 8 (term-packed stage 1), H <= 1024.
 constexpr int G2_PAIR_NS = 2;
 constexpr int G2_PAIR_JS = 8;
+constexpr int G2_PAIR_MAXF = 4;      // m tiles of stage 1 a wave's share may touch (their tail fragments stay in registers)
 inline void g2_plan_pair(G2Plan* p, const RnnShape& rs) {
   g2_plan(p, rs, true);
   p->okf = 0; p->ok = 0; p->okb = 0;
   if (!p->hid.ok) return;
   const G2Mat& m = p->hid;
   if (m.N2T != 1 || G2_PAIR_NS * m.It > 16 || !m.pack8 || rs.H > 2 * G2_NT_MAX) return;
+  {
+    const int nc = G2_PAIR_NS * m.N1T, tpw = g2_ceil(nc * m.M1T, G2_NW_MAX);
+    if ((tpw + nc - 2) / nc + 1 > G2_PAIR_MAXF) return;      // m tiles a contiguous run of tpw (m tile, column) pairs can touch
+  }
   p->pair = 1;
+  p->hid.wrap = G2_PF;
+  p->hid.fs2_bytes = (long)G2_NW_MAX * (m.UW * m.KBP + G2_PF) * 2 * 64 * 16;
   p->upt = g2_ceil(rs.H, G2_NT_MAX);
   p->b_upt = p->upt;
   p->f_hb = (int)g2_al((size_t)2 * G2_PAIR_NS * 16 * m.N1T * G2_PAIR_JS * 2);
@@ -276,14 +284,13 @@ inline void g2_plan_pair(G2Plan* p, const RnnShape& rs) {
   p->f_tab = (int)g2_al((size_t)m.M1T * 4 * 4);
   p->f_sc = (int)g2_al((size_t)(m.Ih + m.It) * 4);
   p->f_lds = p->f_hb + p->f_img + p->f_ybuf + p->f_tab + p->f_sc;
-  p->f_t1 = (m.ft1_bytes <= 32 * 1024 && p->f_lds + (int)g2_al((size_t)m.ft1_bytes) + G2_LDS_STATIC <= G2_LDS_LIMIT) ? (int)g2_al((size_t)m.ft1_bytes) : 0;
-  p->f_lds += p->f_t1;
+  p->f_t1 = 0;                                 // (the tail fragments a wave needs stay in its registers)
   p->okf = p->f_lds + G2_LDS_STATIC <= G2_LDS_LIMIT;
 }
 
 // workspace of the recurrent forward / reverse kernels: merged cores (fp32) + fragment streams
 // forward: + the int32 exponents of the diagonal scales (k_g2_diag_a / _b): [I_t | 64 | I_h], then [I_t][64] partial maxima
-inline long g2_merge_blocks(const G2Mat& m) { return ((long)m.Ih * m.Jh + (long)m.It * m.Jt + 255) / 256; }
+inline long g2_merge_blocks(const G2Mat& m) { return (((long)m.Ih * m.Jh + (long)m.It * m.Jt) * m.R + 255) / 256; }
 inline size_t g2_diag_ints(const G2Mat& m) { return (size_t)m.It + 64 + (size_t)m.Ih; }
 inline size_t g2_fwd_ws_bytes(const G2Mat& m) {
   return g2_al((size_t)m.head_elems * 4) + g2_al((size_t)m.tail_elems * 4) + g2_al((size_t)m.fs2_bytes) + g2_al((size_t)m.ft1_bytes) +

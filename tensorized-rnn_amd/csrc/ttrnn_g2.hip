@@ -41,51 +41,76 @@ namespace {
 // status (may be null): the hid_blocks promise of the descriptor is CHECKED here, where every head entry passes through a
 // register anyway — a non-zero entry outside its gate's rank block (which the kernels will skip) is counted in
 // TTRNN_STAT_BLOCK_VIOLATIONS (the promise used to be taken on trust)
+// One thread per ENTRY (row, column, rank) of a merged core: the chain through the cores before the last one runs whole (it is short:
+// every rank of the previous boundary is needed), the last contraction only for the thread's own rank.  (One thread per (row, column)
+// with all R ranks of every stage took 168 us on the joint matrix of a naive per-gate set — 64 workgroups, 1 152 dependent
+// multiply-adds each through two rank-32 cores, its vectors in scratch.)
 __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const float* __restrict__ packed,
                                                   float* __restrict__ Gh, float* __restrict__ Gt, unsigned* status) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long nh = (long)m.Ih * m.Jh, nt = (long)m.It * m.Jt;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nh = (long)m.Ih * m.Jh * m.R, nt = (long)m.It * m.Jt * m.R;
   float v[G2_MAX_R], w[G2_MAX_R];
-  if (e < nh) {
+  if (t < nh) {
+    const long e = t / m.R;
+    const int own = (int)(t - e * m.R);
     int ih = (int)(e / m.Jh), jh = (int)(e % m.Jh);
     int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
     for (int k = m.s - 1; k >= 0; --k) { ii[k] = ih % s.I[k]; ih /= s.I[k]; jj[k] = jh % s.J[k]; jh /= s.J[k]; }
     const float* W0 = packed + s.woff[0];
-    for (int b = 0; b < s.R[1]; ++b) v[b] = W0[(size_t)(jj[0] * s.R[1] + b) * s.M[0] + ii[0]];
-    for (int k = 1; k < m.s; ++k) {
-      const float* Wk = packed + s.woff[k];
-      for (int b = 0; b < s.R[k + 1]; ++b) {
-        float acc = 0.f;
-        for (int a = 0; a < s.R[k]; ++a) acc = fmaf(v[a], Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], acc);
-        w[b] = acc;
+    float out;
+    if (m.s == 1) {
+      out = W0[(size_t)(jj[0] * s.R[1] + own) * s.M[0] + ii[0]];
+    } else {
+      for (int b = 0; b < s.R[1]; ++b) v[b] = W0[(size_t)(jj[0] * s.R[1] + b) * s.M[0] + ii[0]];
+      for (int k = 1; k < m.s - 1; ++k) {
+        const float* Wk = packed + s.woff[k];
+        for (int b = 0; b < s.R[k + 1]; ++b) {
+          float acc = 0.f;
+          for (int a = 0; a < s.R[k]; ++a) acc = fmaf(v[a], Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], acc);
+          w[b] = acc;
+        }
+        for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
       }
-      for (int b = 0; b < s.R[k + 1]; ++b) v[b] = w[b];
+      const int k = m.s - 1;
+      const float* Wk = packed + s.woff[k];
+      float acc = 0.f;
+      for (int a = 0; a < s.R[k]; ++a) acc = fmaf(v[a], Wk[(size_t)(jj[k] * s.R[k + 1] + own) * s.M[k] + ii[k] * s.R[k] + a], acc);
+      out = acc;
     }
-    for (int a = 0; a < m.R; ++a) Gh[(size_t)e * m.R + a] = v[a];
+    Gh[t] = out;
     if (m.ng > 1 && status) {
       const int g = (int)(e / m.Jh) / m.IhG;
-      bool off = false;
-      for (int a = 0; a < m.R; ++a) off = off || (a / m.Rb != g && v[a] != 0.f);
-      if (off) atomicAdd(status + TTRNN_STAT_BLOCK_VIOLATIONS, 1u);
+      if (own / m.Rb != g && out != 0.f) atomicAdd(status + TTRNN_STAT_BLOCK_VIOLATIONS, 1u);
     }
-  } else if (e < nh + nt) {
-    const long f = e - nh;
+  } else if (t < nh + nt) {
+    const long f = (t - nh) / m.R;
+    const int own = (int)(t - nh - f * m.R);
     int it = (int)(f / m.Jt), jt = (int)(f % m.Jt);
     int ii[TTRNN_MAX_D], jj[TTRNN_MAX_D];
     for (int k = s.d - 1; k >= m.s; --k) { ii[k] = it % s.I[k]; it /= s.I[k]; jj[k] = jt % s.J[k]; jt /= s.J[k]; }
     const int kl = s.d - 1;
     const float* Wl = packed + s.woff[kl];
-    for (int a = 0; a < s.R[kl]; ++a) v[a] = Wl[(size_t)jj[kl] * s.M[kl] + ii[kl] * s.R[kl] + a];       // R_d = 1
-    for (int k = kl - 1; k >= m.s; --k) {
-      const float* Wk = packed + s.woff[k];
-      for (int a = 0; a < s.R[k]; ++a) {
-        float acc = 0.f;
-        for (int b = 0; b < s.R[k + 1]; ++b) acc = fmaf(Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], v[b], acc);
-        w[a] = acc;
+    float out;
+    if (kl == m.s) {
+      out = Wl[(size_t)jj[kl] * s.M[kl] + ii[kl] * s.R[kl] + own];       // R_d = 1
+    } else {
+      for (int a = 0; a < s.R[kl]; ++a) v[a] = Wl[(size_t)jj[kl] * s.M[kl] + ii[kl] * s.R[kl] + a];
+      for (int k = kl - 1; k > m.s; --k) {
+        const float* Wk = packed + s.woff[k];
+        for (int a = 0; a < s.R[k]; ++a) {
+          float acc = 0.f;
+          for (int b = 0; b < s.R[k + 1]; ++b) acc = fmaf(Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + a], v[b], acc);
+          w[a] = acc;
+        }
+        for (int a = 0; a < s.R[k]; ++a) v[a] = w[a];
       }
-      for (int a = 0; a < s.R[k]; ++a) v[a] = w[a];
+      const int k = m.s;
+      const float* Wk = packed + s.woff[k];
+      float acc = 0.f;
+      for (int b = 0; b < s.R[k + 1]; ++b) acc = fmaf(Wk[(size_t)(jj[k] * s.R[k + 1] + b) * s.M[k] + ii[k] * s.R[k] + own], v[b], acc);
+      out = acc;
     }
-    for (int a = 0; a < m.R; ++a) Gt[(size_t)f * m.R + a] = v[a];
+    Gt[t - nh] = out;
   }
 }
 
@@ -187,10 +212,17 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   const int UW = REV ? m.bUW : m.UW, KBP = REV ? m.bKBP : m.KBP, U = REV ? m.bU : m.U;
   const int KSPLIT = REV ? 1 : m.KSPLIT, KPER = REV ? m.bNKBt : m.KPER, NKBt = REV ? m.bNKBt : m.NKBt;
-  const int blk = blockIdx.x;                    // forward: (w*UW + ui)*KBP + kbl;  reverse (compact): w*bSW + ui*bNKBt + kbl
-  const int kbl = REV ? (blk % m.bSW) % m.bNKBt : blk % KBP;
-  const int ui = REV ? (blk % m.bSW) / m.bNKBt : (blk / KBP) % UW;
-  const int w = REV ? blk / m.bSW : blk / (KBP * UW);
+  const int blk = blockIdx.x;                    // forward: w*(UW*KBP + wrap) + ui*KBP + kbl;  reverse (compact): w*bSW + ui*bNKBt + kbl
+  // forward, wrap > 0 (k_g2_fwd_p): the wave's live blocks [nu_w * KBP] are followed by a copy of the first `wrap` of them
+  const int FRS = UW * KBP + (REV ? 0 : m.wrap);
+  const int w = REV ? blk / m.bSW : blk / FRS;
+  int fr = REV ? 0 : blk - w * FRS;
+  if (!REV && m.wrap > 0) {
+    const int live = (w < U ? (U - w + m.nw - 1) / m.nw : 0) * KBP;
+    if (fr >= live && live > 0) fr = (fr - live) % live;
+  }
+  const int kbl = REV ? (blk % m.bSW) % m.bNKBt : fr % KBP;
+  const int ui = REV ? (blk % m.bSW) / m.bNKBt : fr / KBP;
   const int u = w + ui * m.nw;
   xh8 g0, g1;
 #pragma unroll
@@ -782,11 +814,12 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 // (`--naive_tt` at H = 512: 512 KB per step and workgroup; B = 512 ran as two co-resident four-wave workgroups per CU pulling
 // 1 MB per step through one L2 port).  Eight waves, the plan of the eight-wave kernel (G2Plan::pair), J_t <= 8 (stage 1 term-packed
 // into one MFMA per tile).  Layout changes against k_g2_fwd: the h image holds its eight live k-slots per row only ([2][NS][16 N1T][8]);
-// the stage-2 operand image has rows (sample, i_t); stage 1 walks (sample, column tile, m tile) with the m tile fastest — a wave's
-// contiguous share, the column operand read once per column tile; ybuf is [NS][KSPLIT][G H].  An odd batch's last workgroup computes
+// the stage-2 operand image has rows (sample, i_t); stage 1 walks (m tile, sample, column tile) — a wave's contiguous share, its
+// tail fragments in registers, four column tiles at a time; ybuf is [NS][KSPLIT][G H].  An odd batch's last workgroup computes
 // its second sample on a copy of the first and stores nothing for it.
 constexpr int G2P_NS = G2_PAIR_NS;
 constexpr int G2P_JS = G2_PAIR_JS;
+constexpr int G2P_MAXF = G2_PAIR_MAXF;
 
 template <int CELL, typename TS, int UPT, bool IN1, bool DIAG>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
@@ -806,7 +839,6 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
   int* s1off = reinterpret_cast<int*>(smem + P.f_hb + P.f_img + P.f_ybuf);                   // [M1T][4]
   float* unf = reinterpret_cast<float*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab);     // [I_h]: 2^-(ep + 13 + 9 + r), then
   float* ung = unf + m.Ih;                                                                   // [I_t]: 2^-eu  (k_g2_diag_a / _b)
-  xh8* lt1 = reinterpret_cast<xh8*>(smem + P.f_hb + P.f_img + P.f_ybuf + P.f_tab + P.f_sc); // tail fragments (P.f_t1 > 0)
   const xh8* ft1h = reinterpret_cast<const xh8*>(ft1);
   const int rows2 = NS * m.It;
   const int plane = rows2 * m.K2S;
@@ -837,9 +869,6 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
   for (int e = tid; e < m.Ih; e += NT) unf[e] = ldexpf(1.f, -(hdr[m.It + 64 + e] + 13 + 9 + g2_r1_expo(m.Jt)));
   for (int e = tid; e < m.It; e += NT) ung[e] = ldexpf(1.f, -hdr[e]);
   const int s1_rs = m.ng > 1 ? m.Rb : m.Rp;
-  const bool t1_lds = P.f_t1 > 0;
-  if (t1_lds)
-    for (int e = tid; e < (int)(m.ft1_bytes / 16); e += NT) lt1[e] = ft1h[e];
   float hst[NS][UPT], cst[NS][UPT];
   int hoff[UPT];
   f32x4 gi[NS][UPT], bb[UPT];      // input_size == 1: gi[0] holds the unit row's projection, bb the bias row
@@ -896,10 +925,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
         }
     }
   }
-  // head stream of this wave: G2_PF rolling register slots
+  // head stream of this wave: G2_PF rolling register slots; its region ends in a copy of its first G2_PF blocks (G2Mat::wrap)
   const int nu_w = wave < m.U ? (m.U - wave + NW - 1) / NW : 0;
-  const int total = nu_w * m.KBP;
-  const xh8* sp = fs2 + (size_t)wave * m.UW * m.KBP * 2 * 64 + lane;
+  const xh8* sp = fs2 + (size_t)wave * (m.UW * m.KBP + m.wrap) * 2 * 64;      // wave-uniform: scalar base + lane offset addressing
   xh8 wbuf[G2_PF][2];
 #pragma unroll
   for (int j = 0; j < G2_PF; ++j)
@@ -907,14 +935,25 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) wbuf[j][p][e] = (_Float16)0.f;
-      if (total > 0) wbuf[j][p] = sp[(size_t)j * 2 * 64 + p * 64];
+      if (nu_w > 0) wbuf[j][p] = sp[j * 2 * 64 + p * 64 + lane];
     }
-  // stage 1: this wave's contiguous share of the (sample, column tile, m tile) walk
+  // stage 1: this wave's contiguous share of the (m tile, sample, column tile) walk — at most G2P_MAXF m tiles (g2_plan_pair),
+  // their tail fragments and store offsets in registers for all T steps
   const int NC = NS * m.N1T;
   const int tpw = (NC * m.M1T + NW - 1) / NW;
   const int tt0 = wave * tpw, tt1 = tt0 + tpw < NC * m.M1T ? tt0 + tpw : NC * m.M1T;
-  const int cn0 = tt0 / m.M1T, mt0 = tt0 - cn0 * m.M1T;
-  const int s0 = cn0 / m.N1T, nt0 = cn0 - s0 * m.N1T;
+  const int mtA = tt0 < tt1 ? tt0 / NC : 1, mtB = tt0 < tt1 ? (tt1 - 1) / NC : 0;      // (an empty share: mtA > mtB)
+  const int cnA = tt0 - mtA * NC, cnB = tt1 - mtB * NC;                                 // first column of m tile mtA, end column of mtB
+  const int sA = cnA / m.N1T, ntA = cnA - sA * m.N1T;
+  xh8 tf[G2P_MAXF];
+  int so[G2P_MAXF];
+  const bool s1_full = m.It * m.Rp == 16 * m.M1T && m.Jh == 16 * m.N1T;
+#pragma unroll
+  for (int f = 0; f < G2P_MAXF; ++f) {
+    const int mt = mtA + f < m.M1T ? mtA + f : m.M1T - 1;
+    tf[f] = ft1h[mt * 64 + lane];
+    so[f] = s1off[mt * 4 + q];
+  }
   // stage 2: the lane's column = (sample, i_t)
   const bool col_on = c < rows2;
   const int col_s = col_on ? c / m.It : 0, col_it = col_on ? c - col_s * m.It : 0;
@@ -936,73 +975,90 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
 
   for (int t = 0; t < T; ++t) {
     // ---- stage 1: C1 = Gt h of both samples, split into the two fp16 planes of stage 2's operand ----------------------------------
-    auto stage1 = [&](auto frag) {
-      int cs = s0, cnt = nt0, mt = mt0;
-      for (int tt = tt0; tt < tt1;) {
-        const int jh = 16 * cnt + c;
-        const xh8 xb = *reinterpret_cast<const xh8*>(hb + (q >> 1) * HPL + cs * HSS + jh * JS);
-        const int coff = jh < m.Jh ? jh * s1_rs + cs * m.It * m.K2S : -1;
-        const int mend = m.M1T - mt < tt1 - tt ? m.M1T : mt + (tt1 - tt);
-        tt += mend - mt;
-        for (; mt + 1 < mend; mt += 2) {                       // two tiles: independent MFMA / split chains
-          const xh8 wa = frag(mt * 64 + lane), wb = frag((mt + 1) * 64 + lane);
-          const int oa = s1off[mt * 4 + q], ob = s1off[(mt + 1) * 4 + q];
-          f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = acca;
-          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acca, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xb, accb, 0, 0, 0);
-          if (oa >= 0 && coff >= 0) store_split4_h(img, plane, oa + coff, acca * r1sc);
-          if (ob >= 0 && coff >= 0) store_split4_h(img, plane, ob + coff, accb * r1sc);
+    // (no vector-memory instruction: a load here would wait, in issue order, for the head blocks requested behind stage 2)
+#pragma unroll
+    for (int f = 0; f < G2P_MAXF; ++f) {
+      const int mt = mtA + f;
+      if (mt <= mtB) {
+        int cn = f == 0 ? cnA : 0;
+        int cs = f == 0 ? sA : 0, cnt = f == 0 ? ntA : 0;
+        const int cend = mt == mtB ? cnB : NC;
+        const _Float16* bp = hb + (q >> 1) * HPL + c * JS;
+        auto coff_of = [&]() { const int jh = 16 * cnt + c; return jh < m.Jh ? jh * s1_rs + cs * m.It * m.K2S : -1; };
+        auto next_col = [&]() { ++cn; if (++cnt == m.N1T) { cnt = 0; ++cs; } };
+        // four tiles at a time: operand reads, MFMAs and splitting passes of independent chains (one tile after the other was a
+        // dependent LDS read -> MFMA -> fifteen VALU -> LDS write per tile: 6 500 cycles per step for sixteen tiles per wave)
+        while (cn + 4 <= cend) {
+          xh8 xv[4];
+          int co[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xv[i] = *reinterpret_cast<const xh8*>(bp + 16 * cn * JS);
+            co[i] = coff_of();
+            next_col();
+          }
+          f32x4 av[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf[f], xv[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          if (s1_full) {                                 // every lane of every tile live (wave-uniform): no exec masking
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split4_h(img, plane, so[f] + co[i], av[i] * r1sc);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (so[f] >= 0 && co[i] >= 0) store_split4_h(img, plane, so[f] + co[i], av[i] * r1sc);
+          }
         }
-        if (mt < mend) {
-          const xh8 wa = frag(mt * 64 + lane);
-          const int oa = s1off[mt * 4 + q];
+        while (cn < cend) {
+          const xh8 xa = *reinterpret_cast<const xh8*>(bp + 16 * cn * JS);
+          const int ca = coff_of();
+          next_col();
           f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f};
-          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acca, 0, 0, 0);
-          if (oa >= 0 && coff >= 0) store_split4_h(img, plane, oa + coff, acca * r1sc);
-          ++mt;
+          acca = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf[f], xa, acca, 0, 0, 0);
+          if (so[f] >= 0 && ca >= 0) store_split4_h(img, plane, so[f] + ca, acca * r1sc);
         }
-        if (mt == m.M1T) { mt = 0; if (++cnt == m.N1T) { cnt = 0; ++cs; } }
       }
-    };
-    if (t1_lds) stage1([&](int i) { return lt1[i]; });
-    else stage1([&](int i) { return ft1h[i]; });
+    }
     TT_STAMP(0)
     lds_barrier();
     TT_STAMP(1)
     // ---- stage 2: the streamed head against sixteen columns = two samples' i_t ---------------------------------------------------
-    // (every slot is refilled unconditionally right after its use, padding blocks included: see k_g2_fwd)
+    // Every slot is refilled right after its use with the block G2_PF positions ahead, unconditionally (k_g2_fwd) — by a LINEAR
+    // walk: the wave's stream ends in a copy of its first G2_PF blocks (G2Mat::wrap), so the refill needs no wrap-around arithmetic
+    // (a 64-bit select per block before); the operand ring holds the image rows of three blocks ahead.
     {
-      int seq = 0;
+      const xh8* sq = sp + (size_t)G2_PF * 2 * 64;
       for (int ui = 0; ui < nu_w; ++ui) {
         const int u = wave + ui * NW;
         const int tile = u / m.KSPLIT, part = u - tile * m.KSPLIT;
         const int kloc0 = part * m.KPER;                                              // inside the tile's own k range
         const int kbase = (m.ng > 1 ? (16 * tile) / m.IhG : 0) * m.NKBt;              // block-diagonal heads: the gate's range
-        const _Float16* brow = img + crow * m.K2S + 8 * q + 32 * kbase;
+        int nlive = m.NKBt - kloc0 < m.KPER ? m.NKBt - kloc0 : m.KPER;                // live blocks (the rest of KBP is padding)
+        nlive = nlive > 0 ? nlive : 1;                                                // (no part is empty: g2_split)
+        const _Float16* brow = img + crow * m.K2S + 8 * q + 32 * (kbase + kloc0);
         f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-        xh8 bf[2][2];
-        {
-          const int kbc = kloc0 < m.NKBt ? kloc0 : m.NKBt - 1;
+        xh8 bf[4][2];
 #pragma unroll
-          for (int p = 0; p < 2; ++p) bf[0][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kbc);
+        for (int i = 0; i < 3; ++i) {
+          const int kc = i < nlive ? i : nlive - 1;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) bf[i][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kc);
         }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[3][p] = bf[0][p];
+        // ONE path, no per-block condition: the padding blocks of the stream are zero fragments (k_g2_head_frag) and multiply
+        // the unit's last live image block (finite values: exact zeros are added)
         for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
-            const int kb = kloc0 + kbl + j;
-            if (kbl + j + 1 < m.KPER && kb + 1 < m.NKBt) {     // the next block is live (padding blocks are never read)
+            const int k3 = kbl + j + 3 < nlive ? kbl + j + 3 : nlive - 1;
 #pragma unroll
-              for (int p = 0; p < 2; ++p) bf[(j + 1) & 1][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * (kb + 1));
-            }
-            if (kbl + j < m.KPER && kb < m.NKBt) split_block_h(wbuf[j], bf[j & 1], acc_lo, acc_hi);
-            {
-              int nxt = seq + G2_PF;                     // the block G2_PF ahead (wraps into step t+1); total >= G2_PF
-              nxt -= nxt >= total ? total : 0;
+            for (int p = 0; p < 2; ++p) bf[(j + 3) & 3][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * k3);
+            split_block_h(wbuf[j], bf[j & 3], acc_lo, acc_hi);
 #pragma unroll
-              for (int p = 0; p < 2; ++p) wbuf[j][p] = sp[(size_t)nxt * 2 * 64 + p * 64];
-              ++seq;
-            }
+            for (int p = 0; p < 2; ++p) wbuf[j][p] = sq[j * 2 * 64 + p * 64 + lane];
           }
+          sq += (size_t)G2_PF * 2 * 64;
         }
         const f32x4 acc = acc_hi + acc_lo;
         if (col_on) {
@@ -1643,7 +1699,7 @@ int prep(const TtShape& s, const G2Mat& m, bool rev, const float* packed, void* 
     float* dpart = (float*)(hdr + g2_diag_ints(m));
     hipLaunchKernelGGL(k_g2_diag_a, dim3(m.It), dim3(256), 0, stream, m, (const float*)Gt, hdr, dpart);
     hipLaunchKernelGGL(k_g2_diag_b, dim3(m.Ih), dim3(256), 0, stream, m, (const float*)Gh, hdr, (const float*)dpart);
-    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * m.UW * m.KBP), dim3(64), 0, stream, m, Gh, hs, (const int*)hdr);
+    hipLaunchKernelGGL(k_g2_head_frag<false>, dim3(m.nw * (m.UW * m.KBP + m.wrap)), dim3(64), 0, stream, m, Gh, hs, (const int*)hdr);
     hipLaunchKernelGGL(k_g2_tail_frag<false>, dim3(m.M1T * m.KB1), dim3(64), 0, stream, m, Gt, tf, (const int*)hdr);
     if (hdr_out) *hdr_out = hdr;
   }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer diagnostic: per-phase cycle shares of the runtime-shape forward kernel k_g2_fwd (TTRNN_DIAG=1 instantiation: one unit per
 thread, head fragments resident in eight slots, input_size != 1; its stamps land at the head of the training reserve).  Shares only.
-   python tools/diag_stamps_g2fwd.py [--gru] [--hidden_size H] [--ncores d] [--ttrank r] [--in_size n] [--batch_size B] [--seq_len T]"""
+   python tools/diag_stamps_g2fwd.py [--gru] [--naive_tt] [--hidden_size H] [--ncores d] [--ttrank r] [--in_size n] [--batch_size B] [--seq_len T]"""
 import argparse, contextlib, io, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["TTRNN_DIAG"] = "1"
@@ -12,7 +12,7 @@ from tensorized_rnn.gru import TTGRU
 from ttrnn_hip import functional as F
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--gru", action="store_true")
+ap.add_argument("--gru", action="store_true"); ap.add_argument("--naive_tt", action="store_true")
 ap.add_argument("--in_size", type=int, default=40); ap.add_argument("--hidden_size", type=int, default=384)
 ap.add_argument("--ncores", type=int, default=3); ap.add_argument("--ttrank", type=int, default=8)
 ap.add_argument("--batch_size", type=int, default=64); ap.add_argument("--seq_len", type=int, default=160)
@@ -20,9 +20,10 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(1111)
 with contextlib.redirect_stdout(io.StringIO()):
-    m = (TTGRU if a.gru else TTLSTM)(a.in_size, a.hidden_size, 1, dev, n_cores=a.ncores, tt_rank=a.ttrank)
+    m = (TTGRU if a.gru else TTLSTM)(a.in_size, a.hidden_size, 1, dev, n_cores=a.ncores, tt_rank=a.ttrank, is_naive=a.naive_tt)
 x = torch.rand(a.batch_size, a.seq_len, a.in_size, device=dev)
-print("forward route:", F.rnn_route(m._all_layers[0]._layer_spec(), a.batch_size, a.seq_len))
+print("forward route:", F.rnn_route(m._all_layers[0]._layer_spec(), a.batch_size, a.seq_len), "| samples per workgroup:",
+      F.rnn_samples_per_workgroup(m._all_layers[0]._layer_spec(), a.batch_size, a.seq_len))
 seen = []
 orig = F._alloc
 def alloc(shape, dtype, device):
