@@ -174,7 +174,8 @@ struct G2Plan {
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
   int abl;                                     // -DTTRNN_ABLATIONS builds: option `dev` (result-destroying switches of the stamps tool); else 0
   int b_hun;                                   // rows of the inverse-row-scale table kept in LDS (0: read from the workspace)
-  int pair;                                    // forward only: k_g2_fwd_p's plan — two samples per workgroup, LDS carve-up for both (g2_plan_pair)
+  int pair;                                    // forward only: k_g2_fwd_p's plan — two samples per workgroup, LDS carve-up for both (g2_plan_pair);
+                                               // the value = column tiles of stage 2 the pair fills (1: I_t <= 8, 2: I_t <= 16)
   int b_cmx;                                   // running column maxima of the gate gradients [G*H (+ H: GRU's hidden-side n)] floats, behind
                                                // everything else; 0 = no room (the by-product is then not offered for this shape)
 };
@@ -259,7 +260,8 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
 
 // The forward plan of k_g2_fwd_p (ttrnn_g2.hip): the eight-wave plan with the LDS images of TWO samples — the h image in its
 // eight live k-slots per row, the stage-2 operand image with rows (sample, i_t), two output vectors.  For streamed heads only
-// (the caller checks that), I_t <= 8 (both samples in ONE column tile), J_t <= 8 (term-packed stage 1), H <= 1024.
+// (the caller checks that), I_t <= 16 (the pair in one or two column tiles of stage 2: each streamed block feeds both), J_t <= 8
+// (term-packed stage 1), H <= 1024.
 constexpr int G2_PAIR_NS = 2;
 constexpr int G2_PAIR_JS = 8;
 constexpr int G2_PAIR_MAXF = 4;      // m tiles of stage 1 a wave's share may touch (their tail fragments stay in registers)
@@ -268,12 +270,12 @@ inline void g2_plan_pair(G2Plan* p, const RnnShape& rs) {
   p->okf = 0; p->ok = 0; p->okb = 0;
   if (!p->hid.ok) return;
   const G2Mat& m = p->hid;
-  if (m.N2T != 1 || G2_PAIR_NS * m.It > 16 || !m.pack8 || rs.H > 2 * G2_NT_MAX) return;
+  if (m.N2T != 1 || !m.pack8 || rs.H > 2 * G2_NT_MAX) return;      // (N2T == 1: I_t <= 16, the pair in one or two column tiles)
   {
     const int nc = G2_PAIR_NS * m.N1T, tpw = g2_ceil(nc * m.M1T, G2_NW_MAX);
     if ((tpw + nc - 2) / nc + 1 > G2_PAIR_MAXF) return;      // m tiles a contiguous run of tpw (m tile, column) pairs can touch
   }
-  p->pair = 1;
+  p->pair = g2_ceil(G2_PAIR_NS * m.It, 16);      // column tiles of stage 2 (1 or 2)
   p->hid.wrap = G2_PF;
   p->hid.fs2_bytes = (long)G2_NW_MAX * (m.UW * m.KBP + G2_PF) * 2 * 64 * 16;
   p->upt = g2_ceil(rs.H, G2_NT_MAX);

@@ -810,7 +810,8 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
 
 // ---- forward, TWO samples per workgroup (round 5) --------------------------------------------------------------------------------
 // Shapes whose head does not fit the register slots stream it from L2 every step — per WORKGROUP.  With I_t <= 8 a sample fills
-// half of stage 2's sixteen columns: this kernel gives the other half to a second sample, so every streamed block feeds two
+// half of stage 2's sixteen columns: this kernel gives the other half to a second sample (NCT = 1; I_t <= 16: a second column tile,
+// NCT = 2 — two accumulator pairs per streamed block), so every streamed block feeds two
 // (`--naive_tt` at H = 512: 512 KB per step and workgroup; B = 512 ran as two co-resident four-wave workgroups per CU pulling
 // 1 MB per step through one L2 port).  Eight waves, the plan of the eight-wave kernel (G2Plan::pair), J_t <= 8 (stage 1 term-packed
 // into one MFMA per tile).  Layout changes against k_g2_fwd: the h image holds its eight live k-slots per row only ([2][NS][16 N1T][8]);
@@ -821,7 +822,7 @@ constexpr int G2P_NS = G2_PAIR_NS;
 constexpr int G2P_JS = G2_PAIR_JS;
 constexpr int G2P_MAXF = G2_PAIR_MAXF;
 
-template <int CELL, typename TS, int UPT, bool IN1, bool DIAG>
+template <int CELL, typename TS, int UPT, bool IN1, bool DIAG, int NCT = 1>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                     const TS* __restrict__ c0, const xh8* __restrict__ fs2,
                                                     const float* __restrict__ ft1, const int* __restrict__ hdr,
@@ -955,12 +956,22 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
     so[f] = s1off[mt * 4 + q];
   }
   // stage 2: the lane's column = (sample, i_t)
-  const bool col_on = c < rows2;
-  const int col_s = col_on ? c / m.It : 0, col_it = col_on ? c - col_s * m.It : 0;
-  const int crow = col_on ? c : rows2 - 1;
+  bool col_on[NCT];
+  int crow[NCT], col_y[NCT];
+  float col_ug[NCT];
+  int col_it[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int r = 16 * ct + c;
+    col_on[ct] = r < rows2;
+    const int cs_ = col_on[ct] ? r / m.It : 0;
+    col_it[ct] = col_on[ct] ? r - cs_ * m.It : 0;
+    crow[ct] = col_on[ct] ? r : rows2 - 1;
+    col_y[ct] = cs_ * m.KSPLIT * GH + col_it[ct];
+  }
   __syncthreads();                                   // unf / ung are complete
-  const float col_ug = ung[col_it];
-  const int col_y = col_s * m.KSPLIT * GH + col_it;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) col_ug[ct] = ung[col_it[ct]];
   XChunk<TS> xq[NS];                 // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -1025,7 +1036,7 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
     // ---- stage 2: the streamed head against sixteen columns = two samples' i_t ---------------------------------------------------
     // Every slot is refilled right after its use with the block G2_PF positions ahead, unconditionally (k_g2_fwd) — by a LINEAR
     // walk: the wave's stream ends in a copy of its first G2_PF blocks (G2Mat::wrap), so the refill needs no wrap-around arithmetic
-    // (a 64-bit select per block before); the operand ring holds the image rows of three blocks ahead.
+    // (a 64-bit select per block before); the operand ring holds the image rows of the next blocks.
     {
       const xh8* sq = sp + (size_t)G2_PF * 2 * 64;
       for (int ui = 0; ui < nu_w; ++ui) {
@@ -1035,37 +1046,48 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
         const int kbase = (m.ng > 1 ? (16 * tile) / m.IhG : 0) * m.NKBt;              // block-diagonal heads: the gate's range
         int nlive = m.NKBt - kloc0 < m.KPER ? m.NKBt - kloc0 : m.KPER;                // live blocks (the rest of KBP is padding)
         nlive = nlive > 0 ? nlive : 1;                                                // (no part is empty: g2_split)
-        const _Float16* brow = img + crow * m.K2S + 8 * q + 32 * (kbase + kloc0);
-        f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
-        xh8 bf[4][2];
+        const _Float16* brow[NCT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int ct = 0; ct < NCT; ++ct) brow[ct] = img + crow[ct] * m.K2S + 8 * q + 32 * (kbase + kloc0);
+        f32x4 acc_lo[NCT], acc_hi[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { acc_lo[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi[ct] = acc_lo[ct]; }
+        constexpr int RD = NCT == 1 ? 4 : 2;             // operand ring (its depth divides the group of eight)
+        xh8 bf[RD][NCT][2];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
           const int kc = i < nlive ? i : nlive - 1;
 #pragma unroll
-          for (int p = 0; p < 2; ++p) bf[i][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kc);
-        }
+          for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bf[3][p] = bf[0][p];
+            for (int p = 0; p < 2; ++p) bf[i][ct][p] = *reinterpret_cast<const xh8*>(brow[ct] + p * plane + 32 * kc);
+        }
         // ONE path, no per-block condition: the padding blocks of the stream are zero fragments (k_g2_head_frag) and multiply
         // the unit's last live image block (finite values: exact zeros are added)
         for (int kbl = 0; kbl < m.KBP; kbl += G2_PF) {
 #pragma unroll
           for (int j = 0; j < G2_PF; ++j) {
-            const int k3 = kbl + j + 3 < nlive ? kbl + j + 3 : nlive - 1;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bf[(j + 3) & 3][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * k3);
-            split_block_h(wbuf[j], bf[j & 3], acc_lo, acc_hi);
+            for (int ct = 0; ct < NCT; ++ct) split_block_h(wbuf[j], bf[j % RD][ct], acc_lo[ct], acc_hi[ct]);
+            const int k3 = kbl + j + RD < nlive ? kbl + j + RD : nlive - 1;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) bf[j % RD][ct][p] = *reinterpret_cast<const xh8*>(brow[ct] + p * plane + 32 * k3);
 #pragma unroll
             for (int p = 0; p < 2; ++p) wbuf[j][p] = sq[j * 2 * 64 + p * 64 + lane];
           }
           sq += (size_t)G2_PF * 2 * 64;
         }
-        const f32x4 acc = acc_hi + acc_lo;
-        if (col_on) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ih = 16 * tile + 4 * q + j;
-            if (ih < m.Ih) ybuf[col_y + part * GH + ih * m.It] = acc[j] * (unf[ih] * col_ug);
+        for (int ct = 0; ct < NCT; ++ct) {
+          const f32x4 acc = acc_hi[ct] + acc_lo[ct];
+          if (col_on[ct]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ih = 16 * tile + 4 * q + j;
+              if (ih < m.Ih) ybuf[col_y[ct] + part * GH + ih * m.It] = acc[j] * (unf[ih] * col_ug[ct]);
+            }
           }
         }
       }
@@ -1907,12 +1929,12 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     const unsigned grid = (unsigned)((rs.B + G2_PAIR_NS - 1) / G2_PAIR_NS);
 #define TT_G2_PAIR(CELLV, UPTV, IN1V, DG)                                                                                   \
   do {                                                                                                                     \
-    auto kern = k_g2_fwd_p<CELLV, TS, UPTV, IN1V, DG>;                                                                     \
+    auto kern = P.pair == 2 ? k_g2_fwd_p<CELLV, TS, UPTV, IN1V, false, 2> : k_g2_fwd_p<CELLV, TS, UPTV, IN1V, DG, 1>;      \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;           \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_NT_MAX), P.f_lds, stream, P, src, bilv, (const TS*)h0, (const TS*)c0,     \
                        reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve);                  \
   } while (0)
-    const bool dg = opt(OPT_DIAG) && reserve && P.upt == 1 && !in1 && rs.cell == TTRNN_LSTM && std::is_same<TS, float>::value;
+    const bool dg = opt(OPT_DIAG) && reserve && P.upt == 1 && !in1 && rs.cell == TTRNN_LSTM && std::is_same<TS, float>::value && P.pair == 1;
     if (dg) {
       if constexpr (std::is_same<TS, float>::value) TT_G2_PAIR(TTRNN_LSTM, 1, false, true);
     } else if (rs.cell == TTRNN_LSTM) {

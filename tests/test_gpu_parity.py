@@ -868,6 +868,10 @@ PAIR_CASES = [
     ("ttgru", 28, 512, 3, 8, True, 6, 5, True),
     ("ttgru", 40, 384, 3, 16, True, 4, 6, False),       # joint rank 48
     ("ttlstm", 1, 384, 3, 4, True, 3, 7, False),
+    # I_t = 16: the pair fills TWO column tiles of stage 2 (benchmarking.py --ttrank 16)
+    ("ttlstm", 40, 512, 3, 16, False, 5, 6, True),
+    ("ttgru", 1, 512, 3, 16, False, 4, 8, False),
+    ("ttgru", 40, 384, 3, 32, False, 3, 5, False),
 ]
 
 
