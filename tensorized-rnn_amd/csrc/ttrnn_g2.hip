@@ -1775,6 +1775,17 @@ static void plan_for_single(G2Plan* p, const RnnShape& rs, bool backward) {
     if (g2_fwd_res16(q)) { *p = q; return; }
   }
   g2_plan(p, rs, wide);
+  if (!wide && backward && p->hid.ok && p->okb && !(opt(OPT_DEV) & (1 << 21))) {
+    // four-wave workgroups are meant to run two per CU; where the reverse kernel's LDS leaves room for ONE, its four waves sit alone
+    // on their SIMDs with nothing to hide the T2 loop's bookkeeping behind (--naive_tt: 47 000 of a step's 57 000 cycles, 370
+    // instructions per streamed block): the eight-wave plan instead, half the blocks per wave (dev bit 21: as before)
+    const int per_cu = G2_LDS_LIMIT / (p->b_lds + p->b_cmx + G2_LDS_STATIC);
+    if (per_cu < 2) {
+      G2Plan q8;
+      g2_plan(&q8, rs, true);
+      if (q8.hid.ok && q8.okb) { *p = q8; return; }
+    }
+  }
   if (!wide || !p->hid.ok || (backward ? p->okb : p->okf)) return;
   G2Plan q;
   g2_plan(&q, rs, false);
