@@ -19,7 +19,7 @@ namespace ttrnn {
 constexpr int G2_NW_MAX = 8;        // waves per workgroup: 8 when every sample can own a CU (B <= #CUs: two waves per SIMD hide
 constexpr int G2_NT_MAX = G2_NW_MAX * 64;   // each other's LDS / MFMA latency on the per-step critical path), else 4 (several samples share a CU)
 constexpr int G2_PF = 8;            // head fragments in flight per wave (k-blocks of 32): ~770 matrix-pipe cycles of cover
-constexpr int G2_HUN_LDS = 1536;    // reverse kernel: head^T row scales kept in LDS up to this many rows (G2_BSL units x 8 waves x 16)
+constexpr int G2_HUN_LDS = 4096;    // reverse kernel: head^T row scales kept in LDS up to this many rows (G2_BSL units x 8 waves x 16)
 constexpr int G2_BSL = 12;          // reverse kernel: register slots of RESIDENT head^T fragments (two fp16 pieces: 96 VGPRs)
 constexpr int G2_UPT = 4;           // hidden units per thread in the gate phase: H <= 1024
 constexpr int G2_MAX_R = 64;        // rank at the split point
@@ -174,6 +174,7 @@ struct G2Plan {
   int b_dy, b_dc1, b_dh, b_tab, b_t1, b_lds;   // b_tab: dy plane offsets [G*H] + T2 store offsets [bM2T*4] ints
   int abl;                                     // -DTTRNN_ABLATIONS builds: option `dev` (result-destroying switches of the stamps tool); else 0
   int b_hun;                                   // rows of the inverse-row-scale table kept in LDS (0: read from the workspace)
+  int b_fast;                                  // reverse kernel: streamed T2 on the group-of-units loop where the geometry allows (set by the launcher)
   int pair;                                    // forward only: k_g2_fwd_p's plan — two samples per workgroup, LDS carve-up for both (g2_plan_pair);
                                                // the value = column tiles of stage 2 the pair fills (1: I_t <= 8, 2: I_t <= 16)
   int b_cmx;                                   // running column maxima of the gate gradients [G*H (+ H: GRU's hidden-side n)] floats, behind

@@ -1599,13 +1599,63 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
         }
       }
     };
+    // streamed, the common geometry (one column tile, one pass, 1 / 2 / 4 live k-blocks per unit, the row scales in LDS): a group of
+    // eight slots = 8 / NKB whole units, every per-position decision of stageT2 gone — that loop is 370 instructions per streamed
+    // block (unit bookkeeping with integer divisions, thirteen exec-masked regions), issued by a wave that has its SIMD to itself
+    // or shares it with one other: 47 000 of a step's 57 000 cycles at --naive_tt.  Slots past the wave's last unit hold zero
+    // fragments (k_g2_head_frag) and are multiplied, their results dropped.
+    auto stageT2fast = [&](auto nkb_tag) {
+      constexpr int NKB = decltype(nkb_tag)::value;
+      constexpr int UPG = G2_PF / NKB;
+      const int ngroups = total / G2_PF;
+      const int tpg = m.ng > 1 ? m.Kg / 16 : 1;            // row tiles per gate (block-diagonal heads)
+      int mt = wave, gate = m.ng > 1 ? wave / tpg : 0, rem = m.ng > 1 ? wave - gate * tpg : 0;
+      const _Float16* brow0 = dyimg + (c < m.It ? c : m.It - 1) * m.IhS + 8 * q;
+      for (int g = 0; g < ngroups; ++g) {
+        const xh8* nx = sp + (size_t)((g + 1 < ngroups ? g + 1 : 0) * G2_PF) * 2 * 64;      // the next group's blocks (the ring wraps here only)
+#pragma unroll
+        for (int u = 0; u < UPG; ++u) {
+          const bool on = g * UPG + u < nu_w;
+          const int mtc = on ? mt : wave;
+          const _Float16* br = brow0 + 32 * NKB * (on ? gate : 0);
+          xh8 bfr[NKB][2];
+#pragma unroll
+          for (int k = 0; k < NKB; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bfr[k][p] = *reinterpret_cast<const xh8*>(br + p * plane + 32 * k);
+          const int off = t2off[mtc * 4 + q];
+          const f32x4 hu = *reinterpret_cast<const f32x4*>(hunl + 16 * mtc + 4 * q);
+          f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+          for (int k = 0; k < NKB; ++k) {
+            split_block_h(wbuf[u * NKB + k], bfr[k], acc_lo, acc_hi);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wbuf[u * NKB + k][p] = nx[(size_t)(u * NKB + k) * 2 * 64 + p * 64];
+          }
+          if (on && off >= 0 && c < m.It) store_split4_h(dc1, planeC, off + c * m.Rp, (acc_hi + acc_lo) * (hu * ust2));
+          mt += NW;
+          if (m.ng > 1) { rem += NW; while (rem >= tpg) { rem -= tpg; ++gate; } }
+        }
+      }
+    };
     if constexpr (RES) {
       if (m.bNKBt == 1) stageT2res(std::integral_constant<int, 1>{});
       else if (m.bNKBt == 2) stageT2res(std::integral_constant<int, 2>{});
       else if (m.bNKBt == 3) stageT2res(std::integral_constant<int, 3>{});
       else stageT2res(std::integral_constant<int, 4>{});
     } else {
-      stageT2(0);
+      // (one unit per thread only: with two or four the extra operand registers spill — 15 to 54 VGPRs)
+      bool done = false;
+      if constexpr (UPT == 1) {
+        if (m.N2T == 1 && m.bNP == 1 && hl && P.b_fast) {
+          done = true;
+          if (m.bNKBt == 1) stageT2fast(std::integral_constant<int, 1>{});
+          else if (m.bNKBt == 2) stageT2fast(std::integral_constant<int, 2>{});
+          else if (m.bNKBt == 4) stageT2fast(std::integral_constant<int, 4>{});
+          else done = false;
+        }
+      }
+      if (!done) stageT2(0);
     }
     G2B_STAMP(2)
     lds_barrier();
@@ -1796,6 +1846,7 @@ static void plan_for_single(G2Plan* p, const RnnShape& rs, bool backward) {
 // — where that kernel's images fit LDS (dev bit 19: A/B switch, one sample per workgroup as before)
 static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
   plan_for_single(p, rs, backward);
+  p->b_fast = (opt(OPT_DEV) & (1 << 22)) ? 0 : 1;      // (dev bit 22: the reverse kernel's streamed T2 on its general loop everywhere)
   const bool any_b = (opt(OPT_DEV) & (1 << 20)) && rs.B >= 2;      // (dev bit 20: the tests' switch — pairs whatever the batch)
   if (backward || (rs.B <= device_cu_count() && !any_b) || (opt(OPT_DEV) & (1 << 19))) return;
   if (p->hid.ok && p->okf && (p->hid.UW * p->hid.KBP <= G2_PF || g2_fwd_res16(*p))) return;      // resident
