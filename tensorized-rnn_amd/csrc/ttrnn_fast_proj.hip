@@ -209,6 +209,104 @@ bool proj3_shape(const TtShape& s, Proj3* p) {
   return true;
 }
 
+
+// ---- d = 4 (round 5) ------------------------------------------------------------------------------------------------------------
+// W = G0 G1 (G2 G3): the last two cores contracted over r3 are ONE last core of modes (I2 I3, J2 J3),
+//     Q[r2, (i2,i3), (j2,j3)] = sum_r3 G2[r2,i2,j2,r3] G3[r3,i3,j3],
+// so the three launches above run on (G0, G1, Q) — on a scratch copy [W0 | W1 | WQ] of the packed cores and a zeroed scratch
+// gradient — and a last launch adds dW0, dW1 to d_packed and pulls dQ back:
+//     dG2[r2,i2,j2,r3] = sum_{i3,j3} dQ[r2,(i2,i3),(j2,j3)] G3[r3,i3,j3]          dG3[r3,i3,j3] = sum_{r2,i2,j2} dQ[..] G2[r2,i2,j2,r3]
+// Every d = 4 matrix of the dense-gradient route came through the any-shape chain kernel on the `in` identity rows before (the joint
+// matrix of a naive per-gate set of H = 512: 1.7 ms of its 9.6 ms training step; H = 768, d = 4: 1.0 of 8.2).
+struct Proj4 {
+  int I2, I3, J2, J3, R2, R3;
+  int M2, M3;
+  long w2, w3;                    // W2, W3 in the packed buffer
+  long n01;                       // floats of W0 | W1 (= woff[2])
+  long nq;                        // floats of WQ = J2 J3 I2 I3 R2
+};
+
+// scratch packed [W0 | W1 | WQ], scratch gradient zeroed
+__global__ void __launch_bounds__(256) k_proj4_prep(Proj4 p, const float* __restrict__ packed, float* __restrict__ sp,
+                                                    float* __restrict__ ds) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.n01 + p.nq) return;
+  ds[t] = 0.f;
+  if (t < p.n01) { sp[t] = packed[t]; return; }
+  const long u = t - p.n01;                                  // WQ index j' MQ + i' R2 + r2
+  const int MQ = p.I2 * p.I3 * p.R2;
+  const int jq = (int)(u / MQ), rem = (int)(u % MQ);
+  const int iq = rem / p.R2, r2 = rem % p.R2;
+  const int i2 = iq / p.I3, i3 = iq % p.I3, j2 = jq / p.J3, j3 = jq % p.J3;
+  float acc = 0.f;
+  for (int r3 = 0; r3 < p.R3; ++r3)
+    acc = fmaf(packed[p.w2 + (long)(j2 * p.R3 + r3) * p.M2 + i2 * p.R2 + r2], packed[p.w3 + (long)j3 * p.M3 + i3 * p.R3 + r3], acc);
+  sp[t] = acc;
+}
+
+// d_packed[W0 | W1] += scratch; dG2: one thread per entry (I3 J3 terms); dG3: one wave per entry (R2 I2 J2 terms, butterfly)
+__global__ void __launch_bounds__(256) k_proj4_fin(Proj4 p, int nb3, const float* __restrict__ packed, const float* __restrict__ ds,
+                                                   float* __restrict__ d_packed) {
+  const float* dq = ds + p.n01;                              // dQ[j' MQ + i' R2 + r2]
+  const int MQ = p.I2 * p.I3 * p.R2;
+  if ((int)blockIdx.x < nb3) {
+    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // packed index j3 M3 + i3 R3 + r3
+    const int lane = threadIdx.x & 63;
+    const long n3 = (long)p.J3 * p.M3;
+    if (v >= n3) return;
+    const int j3 = (int)(v / p.M3), rem = (int)(v % p.M3), i3 = rem / p.R3, r3 = rem % p.R3;
+    const int nt = p.R2 * p.I2 * p.J2;
+    float acc = 0.f;
+    for (int e = lane; e < nt; e += 64) {
+      const int r2 = e % p.R2, i2 = (e / p.R2) % p.I2, j2 = e / p.R2 / p.I2;
+      acc = fmaf(dq[(long)(j2 * p.J3 + j3) * MQ + (i2 * p.I3 + i3) * p.R2 + r2],
+                 packed[p.w2 + (long)(j2 * p.R3 + r3) * p.M2 + i2 * p.R2 + r2], acc);
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) acc += __shfl_xor(acc, sh);
+    if (lane == 0) d_packed[p.w3 + v] += acc;
+    return;
+  }
+  const long t = ((long)blockIdx.x - nb3) * blockDim.x + threadIdx.x;
+  const long n2 = (long)p.J2 * p.R3 * p.M2;
+  if (t < p.n01) {
+    d_packed[t] += ds[t];
+  } else if (t < p.n01 + n2) {
+    const long u = t - p.n01;                                // packed index (j2 R3 + r3) M2 + i2 R2 + r2
+    const int rem = (int)(u % p.M2), i2 = rem / p.R2, r2 = rem % p.R2;
+    const int jr = (int)(u / p.M2), r3 = jr % p.R3, j2 = jr / p.R3;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int j3 = 0; j3 < p.J3; ++j3) {
+      const float* dr = dq + (long)(j2 * p.J3 + j3) * MQ + (long)(i2 * p.I3) * p.R2 + r2;
+      const float* g3 = packed + p.w3 + (long)j3 * p.M3 + r3;
+      int i3 = 0;
+      for (; i3 + 1 < p.I3; i3 += 2) {
+        acc0 = fmaf(dr[(long)i3 * p.R2], g3[(long)i3 * p.R3], acc0);
+        acc1 = fmaf(dr[(long)(i3 + 1) * p.R2], g3[(long)(i3 + 1) * p.R3], acc1);
+      }
+      if (i3 < p.I3) acc0 = fmaf(dr[(long)i3 * p.R2], g3[(long)i3 * p.R3], acc0);
+    }
+    d_packed[p.w2 + u] += acc0 + acc1;
+  }
+}
+
+// (G0, G1, Q) as a three-core shape over the scratch buffers, and the d = 4 bookkeeping
+bool proj4_shape(const TtShape& s, Proj3* p, Proj4* q) {
+  if (s.d != 4 || s.R[0] != 1 || s.R[4] != 1) return false;
+  q->I2 = s.I[2]; q->I3 = s.I[3]; q->J2 = s.J[2]; q->J3 = s.J[3]; q->R2 = s.R[2]; q->R3 = s.R[3];
+  q->M2 = s.M[2]; q->M3 = s.M[3]; q->w2 = s.woff[2]; q->w3 = s.woff[3];
+  q->n01 = s.woff[2];
+  q->nq = (long)s.J[2] * s.J[3] * s.I[2] * s.I[3] * s.R[2];
+  p->J0 = s.J[0]; p->J1 = s.J[1]; p->J2 = s.J[2] * s.J[3];
+  p->I0 = s.I[0]; p->I1 = s.I[1]; p->I2 = s.I[2] * s.I[3];
+  p->R1 = s.R[1]; p->R2 = s.R[2];
+  p->M0 = s.M[0]; p->M1 = s.M[1]; p->M2 = p->I2 * p->R2;
+  p->w0 = s.woff[0]; p->w1 = s.woff[1]; p->w2 = s.woff[2];
+  p->A = s.J[0] * s.J[1]; p->Mm = s.I[0] * s.I[1];
+  p->out = s.out_size;
+  return true;
+}
+
 }  // namespace
 
 // workspace: P | dP ([A][Mm][R2] floats each) | the PJ_NCH partial dG2
@@ -217,9 +315,16 @@ size_t proj3_workspace_bytes(const TtShape& s) {
   if (opt(OPT_DEV) & 1024) return 0;             // A/B: the fused-core weight-gradient kernel on the unit rows, as before
   Proj2 p2;
   if (proj2_shape(s, &p2)) return 256;           // d = 2: one launch, no scratch (a non-zero answer = "offered")
-  if (!proj3_shape(s, &p)) return 0;
+  Proj4 p4;
+  size_t extra = 0;                               // d = 4: + the scratch packed cores and the scratch gradient [W0 | W1 | WQ] each
+  if (proj4_shape(s, &p, &p4)) {
+    if (opt(OPT_DEV) & (1 << 23)) return 0;       // A/B: the any-shape chain kernel on the identity rows, as before
+    extra = 2 * (size_t)(p4.n01 + p4.nq);
+  } else if (!proj3_shape(s, &p)) {
+    return 0;
+  }
   const size_t pe = (size_t)p.A * p.Mm * p.R2, g2 = (size_t)p.J2 * p.I2 * p.R2;
-  return ((2 * pe + (size_t)PJ_NCH * g2) * sizeof(float) + 255) & ~(size_t)255;
+  return ((2 * pe + (size_t)PJ_NCH * g2 + extra) * sizeof(float) + 255) & ~(size_t)255;
 }
 
 // d_packed += adjoint of (cores -> dense)(dW), dW = fp32 [in_size][out_size]
@@ -231,17 +336,36 @@ int launch_proj3(const TtShape& s, const float* packed, const float* dW, float* 
     return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   }
   Proj3 p;
-  if (!proj3_shape(s, &p) || !ws) return TTRNN_ERR_UNSUPPORTED;
+  Proj4 p4;
+  const bool four = proj4_shape(s, &p, &p4);
+  if ((!four && !proj3_shape(s, &p)) || !ws) return TTRNN_ERR_UNSUPPORTED;
   const size_t pe = (size_t)p.A * p.Mm * p.R2;
   float* P = (float*)ws;
   float* dP = P + pe;
   float* part = dP + pe;
+  float* d_real = d_packed;
+  const float* packed_real = packed;
+  if (four) {
+    // the three launches run on the scratch copy [W0 | W1 | WQ] and accumulate into the zeroed scratch gradient
+    float* sp = part + (size_t)PJ_NCH * p.J2 * p.I2 * p.R2;
+    float* ds = sp + (p4.n01 + p4.nq);
+    const long n = p4.n01 + p4.nq;
+    hipLaunchKernelGGL(k_proj4_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p4, packed, sp, ds);
+    packed = sp;
+    d_packed = ds;
+  }
   hipLaunchKernelGGL(k_proj3_p, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, stream, p, packed, dW, P, dP);
   hipLaunchKernelGGL(k_proj3_g2, dim3(p.J2, PJ_NCH), dim3(256), 0, stream, p, dW, (const float*)P, part);
   const long n0 = (long)p.I0 * p.J0 * p.R1, n12 = (long)p.R1 * p.I1 * p.J1 * p.R2 + (long)p.R2 * p.I2 * p.J2;
   const int nb0 = (int)((n0 + 3) / 4);
   hipLaunchKernelGGL(k_proj3_fin, dim3((unsigned)(nb0 + (n12 + 255) / 256)), dim3(256), 0, stream, p, nb0, packed,
                      (const float*)dP, (const float*)part, d_packed);
+  if (four) {
+    const long n3 = (long)p4.J3 * p4.M3, n2 = (long)p4.J2 * p4.R3 * p4.M2;
+    const int nb3 = (int)((n3 + 3) / 4);
+    hipLaunchKernelGGL(k_proj4_fin, dim3((unsigned)(nb3 + (p4.n01 + n2 + 255) / 256)), dim3(256), 0, stream, p4, nb3, packed_real,
+                       (const float*)d_packed, d_real);
+  }
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

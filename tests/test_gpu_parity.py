@@ -861,6 +861,49 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     print(kind, H, d, r, "false block promise: violations counted", violations, "| promised - dense|", _maxabs(promised, as_dense))
 
 
+@pytest.mark.parametrize("kind,inp,H,d,r,naive,B,T", [("ttlstm", 40, 128, 4, 4, False, 40, 16), ("ttgru", 16, 64, 3, 3, True, 32, 10),
+                                                       ("ttlstm", 12, 128, 3, 4, True, 40, 16), ("ttgru", 40, 256, 4, 8, False, 64, 20)])
+def test_dense_gradient_pull_back_of_four_core_matrices(kind, inp, H, d, r, naive, B, T):
+    """ttrnn_fast_proj.hip, d = 4 (round 5): the dense weight gradient dW = x^T dy of a four-core TT-matrix — a d = 4 layer, or the joint
+    matrix of a naive per-gate set of three-core TTLinears (tt_linearset.py:5-38) — is pulled back onto the cores as (G0, G1, G2 G3)
+    through the three-core launches + one more, instead of the any-shape chain kernel on the identity rows (`dev` bit 23: as before).
+    Every gradient against the oracle, the two routes against each other, and bitwise repeatable."""
+    import ttrnn_hip
+    torch.manual_seed(17)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r, is_naive=naive)
+    m = build_module(meta, dev())
+    lstm = kind == "ttlstm"
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, H)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+    ro = (O.lstm_forward(layers, x) if lstm else O.gru_forward(layers, x))[0]
+    (ro * w).sum().backward()
+
+    def grads():
+        m.zero_grad()
+        out = m(x.to(dev()))[0]
+        (out * w.to(dev())).sum().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    new = grads()
+    again = grads()
+    with ttrnn_hip.option("dev", 1 << 23):
+        old = grads()
+    seen = 0
+    for name, g in new.items():
+        assert torch.equal(g, again[name]), name
+        key = name.replace(".gate", ".gates.")
+        if key in leaves:
+            seen += 1
+            ref = leaves[key].grad
+            assert _maxabs(g, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+        assert _maxabs(g, old[name]) <= 2e-5 * max(float(old[name].abs().max()), 1e-6), name
+    assert seen >= 2 * d
+    assert any(not torch.equal(new[n], old[n]) for n in new)      # two different routes really ran
+
+
 PAIR_CASES = [
     # kind, in, H, d, r, naive, B, T, big_h0 — heads the tier streams from L2 every step (no plan keeps them in registers)
     ("ttlstm", 40, 512, 3, 8, True, 5, 6, False),       # benchmarking.py --naive_tt; odd batch: the last workgroup holds one sample
