@@ -12,6 +12,10 @@ DIAG_CELL=gru python tools/diag_stamps.py 2>&1 | grep -v amdgpu.ids > $O/stamps_
 DIAG_B=64 python tools/diag_stamps_bwd.py 2>&1 | tail -10 > $O/stamps_cfg2_f10bh.txt
 [ -f tools/bin/libttrnn_r4.so ] && python tools/ab_vs_r4.py 2>&1 | grep -v amdgpu.ids > $O/ab_vs_r4.txt
 tools/gap_report.sh 2>&1 | tail -10 > $O/gap_report_cfg2.txt
+python tools/diag_stamps_g2fwd.py --naive_tt --in_size 256 --hidden_size 512 --batch_size 512 2>&1 | grep -v amdgpu.ids > $O/stamps_naive_g2fwdp.txt
+python tools/diag_stamps_g2bwd.py --naive_tt 2>&1 | grep -v amdgpu.ids > $O/stamps_naive_g2bwd.txt
+python tools/diag_stamps_g2bwd.py --ttrank 16 2>&1 | grep -v amdgpu.ids > $O/stamps_r16_g2bwd.txt
+tools/pair_ab.sh eval > $O/pair_ab.txt 2>&1
 python tools/stress_backward.py --grid --reps 8 > $O/stress_backward_grid.txt 2>&1
 python tools/stress_backward.py --reps 40 > $O/stress_backward.txt 2>&1
 tools/launch_sequence.sh cfg2_train --workload cfg2 --mode train > /dev/null 2>&1; cp gpurun_out/seq_cfg2_train.txt $O/seq_cfg2_train.txt

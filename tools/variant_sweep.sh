@@ -8,6 +8,8 @@ run $mode
 run $mode --gru
 run $mode --naive_tt
 run $mode --ttrank 16
+run $mode --naive_tt --gru
+run $mode --ttrank 16 --gru
 run $mode --hidden_size 256 --gru --ttrank 16
 run $mode --in_size 1 --hidden_size 256 --seq_len 784 --batch_size 64 --gru
 run $mode --in_size 1 --hidden_size 256 --seq_len 784 --batch_size 64 --naive_tt
