@@ -114,6 +114,27 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
   }
 }
 
+// The dense matrix of a TT-matrix from its merged cores, gate-interleaved like the chain kernel's output on identity rows
+// (ttrnn_mfma.h: ytile_index): W[j][hid * 4 + slot(g)] = sum_a Gh[i_h, j_h, a] Gt[i_t, j_t, a],  j = j_h J_t + j_t, o = g H + hid = i_h I_t + i_t.
+// K-in of the tier (input_size != 1) built its dense matrix by running the any-shape chain kernel on the `in` identity rows: 83 us at the
+// reference's benchmark defaults (in = 256, 4H = 2048), 165 for a naive set's joint matrix; merge + this: ~10.
+__global__ void __launch_bounds__(256) k_g2_dense(G2Mat m, const float* __restrict__ Gh, const float* __restrict__ Gt,
+                                                  float* __restrict__ W, int ldw, int H, int ilv) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)m.in * m.out) return;
+  const int j = (int)(t / m.out), o = (int)(t - (long)j * m.out);
+  const int ih = o / m.It, it = o - ih * m.It, jh = j / m.Jt, jt = j - jh * m.Jt;
+  const float* a = Gh + ((size_t)ih * m.Jh + jh) * m.R;
+  const float* b = Gt + ((size_t)it * m.Jt + jt) * m.R;
+  float acc0 = 0.f, acc1 = 0.f;
+  int r = 0;
+  for (; r + 1 < m.R; r += 2) { acc0 = fmaf(a[r], b[r], acc0); acc1 = fmaf(a[r + 1], b[r + 1], acc1); }
+  if (r < m.R) acc0 = fmaf(a[r], b[r], acc0);
+  const int g = o / H, hid = o - g * H;
+  const int slot = ilv == 2 ? (g == 1 ? 2 : (g == 2 ? 1 : g)) : g;
+  W[(size_t)j * ldw + hid * 4 + slot] = acc0 + acc1;
+}
+
 // ---- forward operand scales (two-piece fp16 flavour of ttrnn_split.h) ---------------------------------------------------------
 // Both stages run on two-piece fp16 operands under TWO-SIDED DIAGONAL power-of-two scales (as ttrnn_f10_dev.h), so that one
 // large entry of a core moves only the scale of its own row / rank slice and every other entry keeps its 22 bits:
@@ -1901,6 +1922,13 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
     w.xpad = inp != rs.in ? g2_al((size_t)rs.B * rs.T * inp * 4) : 0;
   }
   w.lin = g2_al(plan_ttlinear_fwd(rs.in_s, in1 ? 1 : rs.in).ws_bytes);
+  if (!in1) {
+    // (the same region holds the merged input cores where K-in's dense matrix is built from them: k_g2_dense)
+    G2Mat mi;
+    g2_plan_mat(&mi, rs.in_s, 4);
+    const size_t mb = mi.ok ? g2_al((size_t)mi.head_elems * 4) + g2_al((size_t)mi.tail_elems * 4) : 0;
+    if (w.lin < mb) w.lin = mb;
+  }
   w.total = w.gin + w.bilv + w.rec + w.ident + w.wdense + w.planes + w.xpad + w.lin;
   return w;
 }
@@ -1944,10 +1972,24 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     const int inp = in_pad(rs.in);
     const int64_t rows = (int64_t)rs.B * rs.T;
     if (hipMemsetAsync(wdense, 0, (size_t)inp * 4 * H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-    st = launch_fill_identity(TTRNN_F32, rs.in, ident, stream);
-    const LinPlan lp = plan_ttlinear_fwd(rs.in_s, rs.in);
-    if (st == TTRNN_OK)
-      st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, rs.in, packed_in, nullptr, ident, wdense, linws, stream, H, ilv);
+    G2Mat mi;
+    g2_plan_mat(&mi, rs.in_s, 4);
+    if (mi.ok && !(opt(OPT_DEV) & (1 << 24))) {
+      // the dense matrix from the merged cores (dev bit 24: the chain kernel on the identity rows, as before)
+      float* Ghi = (float*)linws;
+      float* Gti = (float*)((char*)linws + g2_al((size_t)mi.head_elems * 4));
+      hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)g2_merge_blocks(mi)), dim3(256), 0, stream, rs.in_s, mi, packed_in, Ghi, Gti,
+                         (unsigned*)nullptr);
+      const long n = (long)mi.in * mi.out;
+      hipLaunchKernelGGL(k_g2_dense, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mi, (const float*)Ghi, (const float*)Gti,
+                         wdense, 4 * H, H, ilv);
+      st = check();
+    } else {
+      st = launch_fill_identity(TTRNN_F32, rs.in, ident, stream);
+      const LinPlan lp = plan_ttlinear_fwd(rs.in_s, rs.in);
+      if (st == TTRNN_OK)
+        st = launch_ttlinear_fwd(rs.in_s, lp, TTRNN_F32, rs.in, packed_in, nullptr, ident, wdense, linws, stream, H, ilv);
+    }
     void* gscr = (char*)planes + gemm_split_plane_bytes(inp, 4 * H);      // two-piece fp16 GEMM: scales
     const bool ghalf = gemm_use_half(rows, inp, 4 * H);
     if (st == TTRNN_OK)

@@ -904,6 +904,32 @@ def test_dense_gradient_pull_back_of_four_core_matrices(kind, inp, H, d, r, naiv
     assert any(not torch.equal(new[n], old[n]) for n in new)      # two different routes really ran
 
 
+@pytest.mark.parametrize("kind,inp,H,d,r,naive", [("ttlstm", 40, 512, 3, 4, False), ("ttgru", 28, 128, 2, 5, False),
+                                                   ("ttlstm", 40, 256, 3, 4, True), ("ttgru", 12, 768, 4, 6, False)])
+def test_tier_input_matrix_from_merged_cores(kind, inp, H, d, r, naive):
+    """K-in of the runtime tier (input_size != 1) is a dense GEMM whose matrix is built from the TT cores at every launch: from the
+    MERGED cores since round 5 (k_g2_merge + k_g2_dense) instead of the any-shape chain kernel on the identity rows (`dev` bit 24).
+    Same matrix up to the order of the sums: outputs within 2e-6 of each other, both within 1e-5 of the oracle."""
+    import ttrnn_hip
+    torch.manual_seed(9)
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r, is_naive=naive)
+    m = build_module(meta, dev())
+    B, T = 5, 7
+    x = torch.randn(B, T, inp)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, _ = O.layers_from_state_dict(sd, 1, requires_grad=False)
+    with torch.no_grad():
+        ro = (O.lstm_forward(layers, x) if kind == "ttlstm" else O.gru_forward(layers, x))[0]
+        with ttrnn_hip.option("force_g2", 1):
+            new = m(x.to(dev()))[0]
+            with ttrnn_hip.option("dev", 1 << 24):
+                old = m(x.to(dev()))[0]
+    assert _maxabs(new, ro) <= 1e-5 and _maxabs(old, ro) <= 1e-5
+    assert _maxabs(new, old) <= 2e-6
+    assert not torch.equal(new, old)
+
+
 PAIR_CASES = [
     # kind, in, H, d, r, naive, B, T, big_h0 — heads the tier streams from L2 every step (no plan keeps them in registers)
     ("ttlstm", 40, 512, 3, 8, True, 5, 6, False),       # benchmarking.py --naive_tt; odd batch: the last workgroup holds one sample
