@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(256) k_g2_merge(TtShape s, G2Mat m, const floa
 
 // The dense matrix of a TT-matrix from its merged cores, gate-interleaved like the chain kernel's output on identity rows
 // (ttrnn_mfma.h: ytile_index): W[j][hid * 4 + slot(g)] = sum_a Gh[i_h, j_h, a] Gt[i_t, j_t, a],  j = j_h J_t + j_t, o = g H + hid = i_h I_t + i_t.
-// K-in of the tier (input_size != 1) built its dense matrix by running the any-shape chain kernel on the `in` identity rows: 83 us at the
-// reference's benchmark defaults (in = 256, 4H = 2048), 165 for a naive set's joint matrix; merge + this: ~10.
+// K-in of the tier (input_size != 1) builds its dense matrix by running the any-shape chain kernel on the `in` identity rows: 83 us at the
+// reference's benchmark defaults (in = 256, 4H = 2048), 165 for a naive set's joint matrix; merge + this: ~10 (behind `dev` bit 24: see fwd_t).
 __global__ void __launch_bounds__(256) k_g2_dense(G2Mat m, const float* __restrict__ Gh, const float* __restrict__ Gt,
                                                   float* __restrict__ W, int ldw, int H, int ilv) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1974,8 +1974,10 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     if (hipMemsetAsync(wdense, 0, (size_t)inp * 4 * H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
     G2Mat mi;
     g2_plan_mat(&mi, rs.in_s, 4);
-    if (mi.ok && !(opt(OPT_DEV) & (1 << 24))) {
-      // the dense matrix from the merged cores (dev bit 24: the chain kernel on the identity rows, as before)
+    if (mi.ok && (opt(OPT_DEV) & (1 << 24))) {
+      // dev bit 24: the dense matrix from the merged cores (k_g2_merge + k_g2_dense, ~10 us) instead of the chain kernel on the identity rows
+      // (83 us at the benchmark defaults) — an A/B that showed no difference in the harness' eval time (1.28 / 1.26 ms, within the noise) and
+      // moved one outlier case of test_split_math_outlier_up across its bound (another order of the sums): not the default
       float* Ghi = (float*)linws;
       float* Gti = (float*)((char*)linws + g2_al((size_t)mi.head_elems * 4));
       hipLaunchKernelGGL(k_g2_merge, dim3((unsigned)g2_merge_blocks(mi)), dim3(256), 0, stream, rs.in_s, mi, packed_in, Ghi, Gti,

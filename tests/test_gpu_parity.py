@@ -907,9 +907,10 @@ def test_dense_gradient_pull_back_of_four_core_matrices(kind, inp, H, d, r, naiv
 @pytest.mark.parametrize("kind,inp,H,d,r,naive", [("ttlstm", 40, 512, 3, 4, False), ("ttgru", 28, 128, 2, 5, False),
                                                    ("ttlstm", 40, 256, 3, 4, True), ("ttgru", 12, 768, 4, 6, False)])
 def test_tier_input_matrix_from_merged_cores(kind, inp, H, d, r, naive):
-    """K-in of the runtime tier (input_size != 1) is a dense GEMM whose matrix is built from the TT cores at every launch: from the
-    MERGED cores since round 5 (k_g2_merge + k_g2_dense) instead of the any-shape chain kernel on the identity rows (`dev` bit 24).
-    Same matrix up to the order of the sums: outputs within 2e-6 of each other, both within 1e-5 of the oracle."""
+    """K-in of the runtime tier (input_size != 1) is a dense GEMM whose matrix is built from the TT cores at every launch, by the any-shape
+    chain kernel on the identity rows; `dev` bit 24 builds it from the MERGED cores instead (k_g2_merge + k_g2_dense: an A/B kept
+    in the library, no measurable difference in the harness).  Same matrix up to the order of the sums: outputs within 2e-6 of each
+    other, both within 1e-5 of the oracle."""
     import ttrnn_hip
     torch.manual_seed(9)
     meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r, is_naive=naive)
