@@ -904,6 +904,43 @@ def test_dense_gradient_pull_back_of_four_core_matrices(kind, inp, H, d, r, naiv
     assert any(not torch.equal(new[n], old[n]) for n in new)      # two different routes really ran
 
 
+@pytest.mark.parametrize("kind,r,naive", [("ttlstm", 8, True), ("ttgru", 8, True), ("ttlstm", 16, False), ("ttgru", 16, False)])
+def test_paired_kernel_at_benchmark_size_is_bit_identical_to_single(kind, r, naive):
+    """benchmarking.py's defaults with --naive_tt / --ttrank 16 (in = 256, H = 512, 160 steps) at a batch of 513 — more samples than
+    CUs, odd: the DEFAULT route pairs them (the last workgroup holds one sample) — against the one-sample-per-workgroup kernel
+    (`dev` bit 19): outputs, final states and the training reserve (compared through the gradients of a masked loss) bit for bit."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(3)
+    meta = dict(kind=kind, input_size=256, hidden_size=512, num_layers=1, n_cores=3, tt_rank=r, is_naive=naive)
+    m = build_module(meta, dev())
+    B, T = 513, 160
+    lstm = kind == "ttlstm"
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_samples_per_workgroup(spec, B, T) == 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, T, 256, generator=g).to(dev())
+    w = torch.zeros(B, T, 512)
+    w[::37, ::13] = torch.randn(B, T, 512, generator=g)[::37, ::13]
+    w[B - 1, T - 1] = 1.0
+    w = w.to(dev())
+
+    def run():
+        m.zero_grad()
+        res = m(x)
+        (res[0] * w).sum().backward()
+        return res[0].detach(), (res[1][0] if lstm else res[1]).detach(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    out2, h2, g2 = run()
+    with ttrnn_hip.option("dev", 1 << 19):
+        assert F.rnn_samples_per_workgroup(spec, B, T) == 1
+        out1, h1, g1 = run()
+    assert torch.isfinite(out2).all()
+    assert torch.equal(out1, out2) and torch.equal(h1, h2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+
+
 @pytest.mark.parametrize("kind,inp,H,d,r,naive", [("ttlstm", 40, 512, 3, 4, False), ("ttgru", 28, 128, 2, 5, False),
                                                    ("ttlstm", 40, 256, 3, 4, True), ("ttgru", 12, 768, 4, 6, False)])
 def test_tier_input_matrix_from_merged_cores(kind, inp, H, d, r, naive):
