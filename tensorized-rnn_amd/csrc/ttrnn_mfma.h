@@ -366,6 +366,7 @@ using ShpH256R8G = Shp<3, 4, 8, 8, 1, 8, 8, 12, 1, 8, 8, 1>;     // cfg3: TT-GRU
 using ShpH256R16L = Shp<3, 4, 8, 8, 1, 8, 8, 16, 1, 16, 16, 1>;  // cfg4: TT-LSTM H=256 d=3 r=16
 using ShpH256R16G = Shp<3, 4, 8, 8, 1, 8, 8, 12, 1, 16, 16, 1>;  //       TT-GRU  H=256 d=3 r=16
 using ShpH128R4L = Shp<2, 8, 16, 1, 1, 16, 32, 1, 1, 4, 1, 1>;   // cfg1: TT-LSTM H=128 d=2 r=4
+using ShpH256N = Shp<3, 4, 8, 8, 1, 4, 8, 8, 1, 8, 8, 1>;        // ONE gate of a naive per-gate TT-LSTM / TT-GRU, H=256 d=3 r=8 (tt_linearset.py:5-38)
 using ShpH384R8L = Shp<3, 6, 8, 8, 1, 8, 12, 16, 1, 8, 8, 1>;    // benchmarking.py --hidden_size 384: TT-LSTM H=384 d=3 r=8 (forward only)
 using ShpH512R8L = Shp<3, 8, 8, 8, 1, 8, 16, 16, 1, 8, 8, 1>;    // benchmarking.py defaults: TT-LSTM H=512 d=3 r=8 (forward only)
 // input-to-hidden TT matrices of the first layer

@@ -802,9 +802,10 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=L, n_cores=d, tt_rank=r, is_naive=True)
     m = build_module(meta, dev())
     assert not m._needs_stepping()
-    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
-    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
     lstm = kind == "ttlstm"
+    # (round 5: the naive TT-LSTM of H = 256, r = 8 has a fused-core forward kernel of its own, one gate per wave: ttrnn_fast_f10n.hip)
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if (lstm and H == 256 and d == 3 and r == 8) else "runtime_mfma")
+    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
     x = torch.randn(B, T, inp)
     w = torch.randn(B, T, H)
     from oracle import ttrnn_oracle as O
@@ -966,6 +967,75 @@ def test_tier_input_matrix_from_merged_cores(kind, inp, H, d, r, naive):
     assert _maxabs(new, ro) <= 1e-5 and _maxabs(old, ro) <= 1e-5
     assert _maxabs(new, old) <= 2e-6
     assert not torch.equal(new, old)
+
+
+@pytest.mark.parametrize("inp,B,T,state,need_out", [(1, 5, 40, "none", True), (1, 3, 784, "big", True), (40, 6, 9, "small", True),
+                                                     (28, 4, 12, "big", False), (1, 70, 33, "small", True)])
+def test_naive_lstm_fused_core_kernel(inp, B, T, state, need_out):
+    """k_lstm_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM (tt_linearset.py:5-38, tt_lstm.py:17-21; pmnist_test.py
+    --naive_tt) of H = 256, d = 3, r = 8 on a fused-core kernel with ONE GATE PER WAVE, behind the runtime tier's K-in, instead of the
+    tier's own recurrent kernel (`dev` bit 25).  Outputs, final states and every per-gate gradient (the tier's reverse kernel reads the
+    reserve this kernel writes) against the oracle; the two forward kernels against each other; a false block promise is counted."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(23)
+    meta = dict(kind="ttlstm", input_size=inp, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, is_naive=True)
+    m = build_module(meta, dev())
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_route(spec, B, T) == "fused_core"
+    with ttrnn_hip.option("dev", 1 << 25):
+        assert F.rnn_route(spec, B, T) == "runtime_mfma"
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, 256)
+    h0 = c0 = None
+    if state != "none":
+        h0 = torch.randn(B, 256) * (7.0 if state == "big" else 0.3)
+        c0 = torch.randn(B, 256)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    ro, (rh, rc) = O.lstm_forward(layers, xr, None if h0 is None else (h0, c0))
+    ((ro * w).sum() + rc.sum() + rh.sum()).backward()
+    init = None if h0 is None else (h0.to(dev()), c0.to(dev()))
+    xg = x.to(dev()).requires_grad_(True)
+    out, (hT, cT) = m(xg, init)
+    ((out * w.to(dev())).sum() + cT.sum() + hT.sum()).backward()
+    tol = 1e-5 * max(1.0, float(ro.detach().abs().max()))
+    assert _maxabs(out.detach(), ro.detach()) <= tol
+    assert _maxabs(hT.detach(), rh.detach()) <= tol and _maxabs(cT.detach(), rc.detach()) <= 1e-5 * max(1.0, float(rc.detach().abs().max()))
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6)
+    seen = 0
+    for name, p in m.named_parameters():
+        key = name.replace(".gate", ".gates.")
+        if key in leaves:
+            seen += 1
+            ref = leaves[key].grad
+            assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    assert seen >= 24
+    with torch.no_grad():
+        fused = m(x.to(dev()), init, need_outputs=need_out) if not need_out else m(x.to(dev()), init)
+        with ttrnn_hip.option("dev", 1 << 25):
+            tier = m(x.to(dev()), init, need_outputs=need_out) if not need_out else m(x.to(dev()), init)
+    if need_out:
+        assert torch.equal(fused[0], out.detach())                      # eval and training forwards: the same kernel, the same bits
+        assert _maxabs(fused[0], tier[0]) <= 2e-6 * max(1.0, float(ro.detach().abs().max()))
+        assert not torch.equal(fused[0], tier[0])
+    assert _maxabs(fused[1][0], tier[1][0]) <= 2e-6 * max(1.0, float(rh.detach().abs().max()))
+    assert _maxabs(fused[1][1], tier[1][1]) <= 2e-6 * max(1.0, float(rc.detach().abs().max()))
+    # a false block promise (a non-zero entry outside a gate's rank block) is counted by this route too
+    cell = m._all_layers[0]
+    cin, bin_, chid, bhid = cell._operands()
+    bad = [cc.detach().clone() for cc in chid]
+    zeros = (bad[2] == 0).nonzero()
+    bad[2][tuple(zeros[0])] = 0.25
+    ttrnn_hip.device_status(reset=True)
+    with torch.no_grad():
+        F.tt_rnn_layer(spec, x.to(dev()), None, None, cin, bin_, chid, bhid)
+    assert ttrnn_hip.device_status(reset=True)["block_violations"] == 0
+    with torch.no_grad():
+        F.tt_rnn_layer(spec, x.to(dev()), None, None, cin, bin_, bad, bhid)
+    assert ttrnn_hip.device_status(reset=True)["block_violations"] >= 1
 
 
 PAIR_CASES = [
