@@ -41,18 +41,22 @@ class TTLinearSet(nn.Module):
         per_gate = [list(member.weight_t.tt_cores) for member in self.gates]
         d = len(per_gate[0])
         ref = per_gate[0][0]
-        cores = [torch.eye(G, dtype=ref.dtype, device=ref.device).view(1, G, 1, G)]
+        # the selector's identity is a constant: built once per (device, dtype)
+        key = (ref.device, ref.dtype)
+        eyes = self.__dict__.setdefault('_eye', {})
+        eye = eyes.get(key)
+        if eye is None:
+            eye = eyes[key] = torch.eye(G, dtype=ref.dtype, device=ref.device)
+        cores = [eye.view(1, G, 1, G)]
         for k in range(d):
-            blocks = []
-            for g in range(G):
-                c = per_gate[g][k]                                  # (r_k, I_k, J_k, r_{k+1})
-                if k == d - 1:
-                    blocks.append(c)                                # last core: ranks (G r_{d-1}) -> 1, stacked along dim 0
-                    continue
-                left = c.new_zeros(c.shape[0], c.shape[1], c.shape[2], g * c.shape[3])
-                right = c.new_zeros(c.shape[0], c.shape[1], c.shape[2], (G - 1 - g) * c.shape[3])
-                blocks.append(torch.cat([left, c, right], dim=3))
-            cores.append(torch.cat(blocks, dim=0))
+            if k == d - 1:
+                cores.append(torch.cat([per_gate[g][k] for g in range(G)], dim=0))      # ranks (G r_{d-1}) -> 1: stacked along dim 0
+                continue
+            # block (g, h) of the joint core = delta_gh * gate g's core: ONE stack and ONE broadcast multiply (exact: x 1 and x 0)
+            # instead of two zero blocks and a concatenation per gate — the assembly was ~40 small launches per forward
+            c = torch.stack([per_gate[g][k] for g in range(G)], dim=0)                   # (G, r_k, I_k, J_k, r_{k+1})
+            blk = c.unsqueeze(4) * eye.view(G, 1, 1, 1, G, 1)                             # (G, r_k, I_k, J_k, G, r_{k+1})
+            cores.append(blk.reshape(G * c.shape[1], c.shape[2], c.shape[3], G * c.shape[4]))
         biases = [member.bias for member in self.gates]
         bias = None if biases[0] is None else torch.cat(biases, dim=0)
         return cores, bias
