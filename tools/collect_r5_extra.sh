@@ -9,6 +9,7 @@ timeout 900 python bench.py --workload grid --mode train --graph > $O/bench_grid
 bash tools/variant_sweep.sh > $O/variants_benchmarking.txt 2>&1
 python tools/diag_stamps.py 2>&1 | grep -v amdgpu.ids > $O/stamps_cfg2_f10q.txt
 DIAG_CELL=gru python tools/diag_stamps.py 2>&1 | grep -v amdgpu.ids > $O/stamps_gru_f10vh.txt
+DIAG_CELL=naive python tools/diag_stamps.py 2>&1 | grep -v amdgpu.ids > $O/stamps_naive_f10n.txt
 DIAG_B=64 python tools/diag_stamps_bwd.py 2>&1 | tail -10 > $O/stamps_cfg2_f10bh.txt
 [ -f tools/bin/libttrnn_r4.so ] && python tools/ab_vs_r4.py 2>&1 | grep -v amdgpu.ids > $O/ab_vs_r4.txt
 tools/gap_report.sh 2>&1 | tail -10 > $O/gap_report_cfg2.txt
