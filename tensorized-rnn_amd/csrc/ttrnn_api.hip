@@ -815,7 +815,7 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
   if (force_generic()) return TTRNN_ROUTE_VALU;
   if (fwd_prefers_g2(rs, desc->dtype))      // (the fp32 GRU shape with input_size != 1: the tier's K-in + the fused-core recurrent kernel)
-    return (!opt(OPT_FORCE_G2) && (f10gh_available(rs, desc->dtype) || f10g5_available(rs, desc->dtype))) ? TTRNN_ROUTE_FUSED_CORE
+    return (!opt(OPT_FORCE_G2) && (f10gh_available(rs, desc->dtype) || f10g5_available(rs, desc->dtype) || f10n_available(rs, desc->dtype))) ? TTRNN_ROUTE_FUSED_CORE
                                                                                                            : TTRNN_ROUTE_RUNTIME_MFMA;
   const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
   if (f.use) {

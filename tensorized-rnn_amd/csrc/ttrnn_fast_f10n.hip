@@ -1,4 +1,4 @@
-// ttrnn_fast_f10n.hip — the fused-core forward kernel for the NAIVE per-gate TT-LSTM (gfx950).
+// ttrnn_fast_f10n.hip — the fused-core forward kernel for the NAIVE per-gate TT-LSTM / TT-GRU (gfx950).
 //
 // `is_naive=True` (tensorized_rnn/tt_linearset.py:5-38, tt_lstm.py:17-21; pmnist_test.py --naive_tt) gives every gate its own
 // TTLinear; the host presents the set as ONE block-diagonal TT-matrix with a gate-selector core (ttrnn_rnn_desc::hid_blocks = 4).
@@ -13,6 +13,8 @@
 // the family: two fp16 pieces per operand under the diagonal power-of-two scales of k_f10h_scale, computed per gate.
 // Input side: the runtime tier's K-in, in its conventions (gin slots i, g, f, o with both biases folded in; input_size == 1: the
 // unit row's projection + the bias row, scaled by x_t here).  The reverse recurrence stays on the tier's kernel (same reserve).
+// The naive TT-GRU (gru.py:150-153: three gates, per-gate biases) runs the same kernel with three gate waves — the fourth does
+// gates and S2 only — and the GRU's per-step tracking of a large state's exponent (k_gru_fwd_f10vh).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "ttrnn_core.h"
@@ -27,7 +29,7 @@ namespace ttrnn {
 
 namespace {
 
-constexpr int F10N_G = 4;
+constexpr int f10n_gates(int cell) { return cell == TTRNN_LSTM ? 4 : 3; }
 
 template <class S>
 constexpr bool f10n_ok() {
@@ -42,11 +44,11 @@ constexpr int f10n_packed_elems() { return woff_of<S>(S::D); }
 // joint core k + 1 holds gate g's core k in rank block g (left rank index g for the first core: the selector's output).  The same
 // launch CHECKS the promise: a non-zero joint entry outside the blocks, or off the selector's diagonal, is counted in
 // TTRNN_STAT_BLOCK_VIOLATIONS (what k_g2_merge does for the tier).
-template <class S>
+template <class S, int G>
 __global__ void __launch_bounds__(256) k_f10n_unjoin(TtShape js, const float* __restrict__ pj, float* __restrict__ pg, unsigned* status) {
   constexpr int TOT = f10n_packed_elems<S>();
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long)F10N_G * TOT) {
+  if (t < (long)G * TOT) {
     const int g = (int)(t / TOT), e = (int)(t - (long)g * TOT);
     const int k = e < woff_of<S>(1) ? 0 : (e < woff_of<S>(2) ? 1 : 2);
     const int Rp = S::R[k], Rn = S::R[k + 1], M = S::I[k] * Rp;
@@ -65,9 +67,9 @@ __global__ void __launch_bounds__(256) k_f10n_unjoin(TtShape js, const float* __
     const int b = row % js.R[k + 1], i = col / js.R[k], a = col - i * js.R[k];
     bool inside;
     if (k == 0) inside = i == b;                                                      // selector (1, G, 1, G): the identity
-    else if (k == 1) inside = a == b / (js.R[2] / F10N_G);
+    else if (k == 1) inside = a == b / (js.R[2] / G);
     else if (k == js.d - 1) inside = true;
-    else inside = a / (js.R[k] / F10N_G) == b / (js.R[k + 1] / F10N_G);
+    else inside = a / (js.R[k] / G) == b / (js.R[k + 1] / G);
     if (!inside && pj[t] != 0.f) atomicAdd(status + TTRNN_STAT_BLOCK_VIOLATIONS, 1u);
   }
 }
@@ -108,33 +110,37 @@ __global__ void __launch_bounds__(64) k_f10n_prep(const float* __restrict__ pg, 
 template <class S>
 constexpr size_t f10n_frag_elems() { return (size_t)F10<S>::MT * F10<S>::NM * 2 * 64; }       // xh8 per gate
 template <class S>
-constexpr size_t f10n_ws_bytes() {
-  return (size_t)F10N_G * (F10H_HDR_BYTES + f10n_frag_elems<S>() * sizeof(xh8) + (size_t)f10n_packed_elems<S>() * sizeof(float));
+constexpr size_t f10n_ws_bytes(int G) {
+  return (size_t)G * (F10H_HDR_BYTES + f10n_frag_elems<S>() * sizeof(xh8) + (size_t)f10n_packed_elems<S>() * sizeof(float));
 }
 
 // H0: the caller passed an initial state; OUT = false: only the final state is consumed; IN1: input_size == 1; DIAG: stamps
-template <class S, bool H0, bool OUT, bool IN1, bool DIAG = false>
-__global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc gs, const float* __restrict__ bilv,
+template <class S, int CELL, bool H0, bool OUT, bool IN1, bool DIAG = false>
+__global__ void __launch_bounds__(256, 2) k_rnn_fwd_f10n(int B, int T, GinSrc gs, const float* __restrict__ bilv,
                                                           const float* __restrict__ h0, const float* __restrict__ c0,
                                                           const float* __restrict__ pg, const float* __restrict__ hdrs,
                                                           const xh8* __restrict__ wfrag, float* __restrict__ out,
                                                           float* __restrict__ hT, float* __restrict__ cT, float* __restrict__ reserve) {
   static_assert(f10n_ok<S>(), "shape not supported by the per-gate fused-core LSTM kernel");
   using F = F10<S>;
-  constexpr int H = F::H, G = F10N_G, NP = F10P<S>::NP;
+  constexpr bool LSTM = CELL == TTRNN_LSTM;
+  constexpr int H = F::H, G = f10n_gates(CELL), NP = F10P<S>::NP;
   __shared__ __attribute__((aligned(16))) _Float16 img[G][2 * F::PLANE];        // S10 operands, two fp16 planes [I2][K10] per gate
   __shared__ __attribute__((aligned(16))) float gbuf[G * H + 128];              // SCALED gate sums (+ a dump for the padding columns)
-  __shared__ __attribute__((aligned(16))) xh8 afr[G][2 * NP * 64];              // core-2 fragments of the four gates (tile pairs)
+  __shared__ __attribute__((aligned(16))) xh8 afr[G][2 * NP * 64];              // core-2 fragments of the gates (tile pairs)
+  __shared__ float hmax[4];                                                      // GRU, H0: the waves' maxima of |h_t|
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                     // = the gate this wave multiplies
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
-  const float* hdr_g = hdrs + wave * (F10H_HDR_BYTES / 4);
+  const bool gw = wave < G;                                                      // (a GRU's fourth wave multiplies no gate: gates + S2 only)
+  const int wg = gw ? wave : 0;
+  const float* hdr_g = hdrs + wg * (F10H_HDR_BYTES / 4);
 
-  {
+  if (gw) {
     xh8 t1[NP], t2[NP];
-    f10p_load_w2<S>(t1, t2, pg + (size_t)wave * f10n_packed_elems<S>(), lane, hdr_g);
+    f10p_load_w2<S>(t1, t2, pg + (size_t)wg * f10n_packed_elems<S>(), lane, hdr_g);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       afr[wave][(2 * p) * 64 + lane] = t1[p];
@@ -145,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
   ln.init(wave, lane);
   xh8 w10a[2][F::NM], w10b[2][F::NM];                                            // feature tiles 0 and 1 of gate `wave`
   {
-    const xh8* wf = wfrag + (size_t)wave * f10n_frag_elems<S>() + lane;
+    const xh8* wf = wfrag + (size_t)wg * f10n_frag_elems<S>() + lane;
 #pragma unroll
     for (int u = 0; u < F::NM; ++u)
 #pragma unroll
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
   }
   // the accumulators of S10 carry 2^(ep[m] + eu[i2] + 12) of their gate; the GATE thread multiplies its four sums back
   const int hid = tid;
-  f32x4 usc;
+  f32x4 usc = f32x4{0.f, 0.f, 0.f, 0.f};
   {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
     }
   }
   // where lane (c, q) puts accumulator register j of tile t2: unit (16 t2 + 4 q + j) I2 + c of gate `wave` (columns >= I2: the dump)
-  const int gdst = c < F::I2 ? wave * H + (4 * q) * F::I2 + c : G * H + lane;
+  const int gdst = c < F::I2 ? wg * H + (4 * q) * F::I2 + c : G * H + lane;
   const int gstep = c < F::I2 ? F::I2 : 0;
 
   const f32x4* gin4 = reinterpret_cast<const f32x4*>(gs.gin);
@@ -181,11 +187,13 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
     if (IN1) { gi = gin4[hid]; bb = bil4[hid]; }
     else gi = gin4[(b * T) * H + hid];
   }
-  // a caller's h_0 outside (-1, 1): the first step's operand is 2^-e0 h_0, its sums are multiplied back (|h_t| < 1 from then on)
-  int e0 = 0;
-  if constexpr (H0) e0 = __builtin_amdgcn_readfirstlane(f10h_h0_expo<4>(hst, gbuf, wave, lane));
+  // a caller's h_0 outside (-1, 1): the operand is 2^-e h, the sums are multiplied back.  LSTM: the first step only (|h_t| < 1 from
+  // then on); GRU: |h_t| <= max(1, |h_{t-1}|) only, so the exponent is re-derived every step WHILE it is positive (k_gru_fwd_f10vh)
+  int e_cur = 0;
+  if constexpr (H0) e_cur = __builtin_amdgcn_readfirstlane(f10h_h0_expo<4>(hst, gbuf, wave, lane));
   else __syncthreads();                                                          // afr is complete
-  const f32x4 un0 = usc * ldexpf(1.f, e0);
+  f32x4 un_t = usc * ldexpf(1.f, e_cur);
+  float hsc = ldexpf(F10H_HSC, -e_cur);
 
   // S2 of this wave's eight chain rows (the state in its lanes: four crossbar gathers) against every gate's core 2
   auto s2_from_lanes = [&](float hscaled) {
@@ -210,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
       for (int p = 0; p < NP; ++p) store_split4_h(img[g], F::PLANE, ln.soff[p], acc[p]);
     }
   };
-  s2_from_lanes(hst * ldexpf(F10H_HSC, -e0));
+  s2_from_lanes(hst * hsc);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): keep weight-register waits out of the time loop
   lds_barrier();
 
@@ -220,13 +228,13 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
   const int row10 = c < F::I2 ? c : F::I2 - 1;
   for (int t = 0; t < T; ++t) {
     // ---- S10 of this wave's gate: two feature tiles ------------------------------------------------------------------------------
-    {
+    if (gw) {
       // both tiles against ONE read of the operand rows (f10h_s10_part twice read them twice and ran two dependent chains one after
       // the other: 1 500 stamped cycles for the 48 MFMAs); per accumulator the same products in the same order
       f32x4 lo0 = f32x4{0.f, 0.f, 0.f, 0.f}, hi0 = lo0, lo1 = lo0, hi1 = lo0;
       {
         constexpr int NU = F::NM, PD = 4;
-        const _Float16* im = img[wave];
+        const _Float16* im = img[wg];
         xh8 af[NU][2];
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -267,22 +275,47 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
     {
       f32x4 g4 = gi;
       if (IN1) g4 = bb + xq.at(t) * gi;
-      const f32x4 un = (H0 && t == 0) ? un0 : usc;
-      const float ig = fsigmoid(fmaf(gbuf[hid], un[0], g4[0]));                  // gin slots i, g, f, o
-      const float fg = fsigmoid(fmaf(gbuf[H + hid], un[1], g4[2]));
-      const float gg = ftanh(fmaf(gbuf[2 * H + hid], un[2], g4[1]));
-      const float og = fsigmoid(fmaf(gbuf[3 * H + hid], un[3], g4[3]));
-      const float cy = fg * cst + ig * gg;
-      const float hy = og * ftanh(cy);
-      cst = cy;
-      if (reserve) {
-        *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hid)) = f32x4{ig, gg, fg, og};
-        reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
+      const f32x4 un = H0 ? un_t : usc;
+      float hy;
+      if constexpr (LSTM) {
+        const float ig = fsigmoid(fmaf(gbuf[hid], un[0], g4[0]));                  // gin slots i, g, f, o
+        const float fg = fsigmoid(fmaf(gbuf[H + hid], un[1], g4[2]));
+        const float gg = ftanh(fmaf(gbuf[2 * H + hid], un[2], g4[1]));
+        const float og = fsigmoid(fmaf(gbuf[3 * H + hid], un[3], g4[3]));
+        const float cy = fg * cst + ig * gg;
+        hy = og * ftanh(cy);
+        cst = cy;
+        if (reserve) {
+          *reinterpret_cast<f32x4*>(reserve + res_gate(bt, H, hid)) = f32x4{ig, gg, fg, og};
+          reserve[res_cell((size_t)B * T, bt, H, hid)] = cy;
+        }
+        if constexpr (H0) { un_t = usc; hsc = F10H_HSC; }                        // |h_t| < 1 from here on
+      } else {                                                                   // gin slots r, z, n, b_hid of n (the tier's convention)
+        const float hn = fmaf(gbuf[2 * H + hid], un[2], g4[3]);
+        const float rg = fsigmoid(fmaf(gbuf[hid], un[0], g4[0]));                 // gru.py:38-39
+        const float zg = fsigmoid(fmaf(gbuf[H + hid], un[1], g4[1]));             // gru.py:40-41
+        const float ng = ftanh(g4[2] + rg * hn);                                  // gru.py:42-43
+        hy = (1.0f - zg) * ng + zg * hst;                                         // gru.py:44
+        if (reserve) *reinterpret_cast<f32x4*>(reserve + (bt * H + hid) * 4) = f32x4{rg, zg, ng, hn};
+        if constexpr (H0) {
+          if (e_cur > 0) {                 // workgroup-uniform: the state was outside (-1, 1) — re-derive its exponent
+            float mx = fabsf(hy);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) hmax[wave] = mx;
+            lds_barrier();
+            mx = fmaxf(fmaxf(hmax[0], hmax[1]), fmaxf(hmax[2], hmax[3]));
+            const int e = f10h_expo(mx);
+            e_cur = __builtin_amdgcn_readfirstlane(e < 0 ? 0 : e);
+            hsc = ldexpf(F10H_HSC, -e_cur);
+            un_t = usc * ldexpf(1.f, e_cur);
+          }
+        }
       }
       if constexpr (OUT) out[bt * H + hid] = hy;
       hst = hy;
       TT_STAMP(2)
-      s2_from_lanes(hy * F10H_HSC);
+      s2_from_lanes(hy * hsc);
       if (!IN1 && t + 1 < T) gi = gin4[(bt + 1) * H + hid];
     }
     if (IN1) xq.advance(xs, b * T, T, t, lane);
@@ -291,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
     TT_STAMP(4)
   }
   if (hT) hT[b * H + hid] = hst;
-  if (cT) cT[b * H + hid] = cst;
+  if (LSTM && cT) cT[b * H + hid] = cst;
   if constexpr (DIAG) {
     if (lane == 0 && reserve && b < 8) {
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(reserve) + (b * 8 + wave) * 8;
@@ -301,44 +334,45 @@ __global__ void __launch_bounds__(256, 2) k_lstm_fwd_f10n(int B, int T, GinSrc g
   }
 }
 
-// the joint matrix of four per-gate matrices of shape S: cores (1,G,1,G), then S's cores in rank blocks
+// the joint matrix of G per-gate matrices of shape S: cores (1,G,1,G), then S's cores in rank blocks
 template <class S>
-bool f10n_joint_matches(const TtShape& s) {
-  if (s.d != S::D + 1 || s.I[0] != F10N_G || s.J[0] != 1 || s.R[0] != 1 || s.R[1] != F10N_G) return false;
+bool f10n_joint_matches(const TtShape& s, int G) {
+  if (s.d != S::D + 1 || s.I[0] != G || s.J[0] != 1 || s.R[0] != 1 || s.R[1] != G) return false;
   for (int k = 0; k < S::D; ++k) {
     if (s.I[k + 1] != S::I[k] || s.J[k + 1] != S::J[k]) return false;
-    if (s.R[k + 2] != (k == S::D - 1 ? 1 : F10N_G * S::R[k + 1])) return false;
+    if (s.R[k + 2] != (k == S::D - 1 ? 1 : G * S::R[k + 1])) return false;
   }
   return true;
 }
 
-template <class S>
+template <class S, int CELL>
 int launch_n(const RnnShape& rs, GinSrc gin, const float* bilv, const void* h0, const void* c0, const float* packed_hid, void* out,
              void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   static_assert((F10H_EP + F10<S>::M) * sizeof(int) <= F10H_HDR_BYTES, "header");
+  constexpr int G = f10n_gates(CELL);
   unsigned char* p = reinterpret_cast<unsigned char*>(ws);
-  float* hdrs = reinterpret_cast<float*>(p); p += (size_t)F10N_G * F10H_HDR_BYTES;
-  xh8* wfrag = reinterpret_cast<xh8*>(p); p += (size_t)F10N_G * f10n_frag_elems<S>() * sizeof(xh8);
+  float* hdrs = reinterpret_cast<float*>(p); p += (size_t)G * F10H_HDR_BYTES;
+  xh8* wfrag = reinterpret_cast<xh8*>(p); p += (size_t)G * f10n_frag_elems<S>() * sizeof(xh8);
   float* pg = reinterpret_cast<float*>(p);
   constexpr int TOT = f10n_packed_elems<S>();
-  const long n = (long)F10N_G * TOT > rs.hid_s.wtotal ? (long)F10N_G * TOT : rs.hid_s.wtotal;
-  hipLaunchKernelGGL((k_f10n_unjoin<S>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rs.hid_s, packed_hid, pg,
+  const long n = (long)G * TOT > rs.hid_s.wtotal ? (long)G * TOT : rs.hid_s.wtotal;
+  hipLaunchKernelGGL((k_f10n_unjoin<S, G>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rs.hid_s, packed_hid, pg,
                      device_status_ptr());
-  for (int g = 0; g < F10N_G; ++g)
+  for (int g = 0; g < G; ++g)
     hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, (const float*)(pg + (size_t)g * TOT),
                        reinterpret_cast<int*>(hdrs + g * (F10H_HDR_BYTES / 4)));
-  hipLaunchKernelGGL((k_f10n_prep<S>), dim3(F10N_G * F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, (const float*)pg,
+  hipLaunchKernelGGL((k_f10n_prep<S>), dim3(G * F10<S>::MT * F10<S>::NM), dim3(64), 0, stream, (const float*)pg,
                      (const float*)hdrs, wfrag);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
   const bool in1 = gin.in1 != 0;
   const bool hs = h0 || c0;
-  auto kern = in1 ? (out ? (hs ? k_lstm_fwd_f10n<S, true, true, true> : k_lstm_fwd_f10n<S, false, true, true>)
-                         : (hs ? k_lstm_fwd_f10n<S, true, false, true> : k_lstm_fwd_f10n<S, false, false, true>))
-                  : (out ? (hs ? k_lstm_fwd_f10n<S, true, true, false> : k_lstm_fwd_f10n<S, false, true, false>)
-                         : (hs ? k_lstm_fwd_f10n<S, true, false, false> : k_lstm_fwd_f10n<S, false, false, false>));
+  auto kern = in1 ? (out ? (hs ? k_rnn_fwd_f10n<S, CELL, true, true, true> : k_rnn_fwd_f10n<S, CELL, false, true, true>)
+                         : (hs ? k_rnn_fwd_f10n<S, CELL, true, false, true> : k_rnn_fwd_f10n<S, CELL, false, false, true>))
+                  : (out ? (hs ? k_rnn_fwd_f10n<S, CELL, true, true, false> : k_rnn_fwd_f10n<S, CELL, false, true, false>)
+                         : (hs ? k_rnn_fwd_f10n<S, CELL, true, false, false> : k_rnn_fwd_f10n<S, CELL, false, false, false>));
   if (opt(OPT_DIAG) && reserve && out && !hs)      // stamped build (diagnostics)
-    kern = in1 ? k_lstm_fwd_f10n<S, false, true, true, true> : k_lstm_fwd_f10n<S, false, true, false, true>;
+    kern = in1 ? k_rnn_fwd_f10n<S, CELL, false, true, true, true> : k_rnn_fwd_f10n<S, CELL, false, true, false, true>;
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, gin, bilv, (const float*)h0, (const float*)c0, (const float*)pg,
                      (const float*)hdrs, (const xh8*)wfrag, (float*)out, (float*)hT, (float*)cT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
@@ -346,19 +380,22 @@ int launch_n(const RnnShape& rs, GinSrc gin, const float* bilv, const void* h0, 
 
 }  // namespace
 
-// fp32-storage naive TT-LSTM of H = 256, d = 3, r = 8 per gate, split math mode (dev bit 25: the runtime-shape tier's kernel, A/B)
+// fp32-storage naive TT-LSTM / TT-GRU of H = 256, d = 3, r = 8 per gate, split math mode (dev bit 25: the runtime-shape tier's kernel, A/B)
 bool f10n_available(const RnnShape& rs, int dtype) {
-  return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & (1 << 25)) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM &&
-         rs.hid_blocks == F10N_G && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && f10n_joint_matches<ShpH256N>(rs.hid_s);
+  const int G = f10n_gates(rs.cell);
+  return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & (1 << 25)) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 &&
+         (rs.cell == TTRNN_LSTM || rs.cell == TTRNN_GRU) && rs.hid_blocks == G && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT &&
+         f10n_joint_matches<ShpH256N>(rs.hid_s, G);
 }
 size_t f10n_workspace_bytes(const RnnShape& rs) {
-  return f10n_joint_matches<ShpH256N>(rs.hid_s) && rs.hid_blocks == F10N_G ? f10n_ws_bytes<ShpH256N>() : 0;
+  const int G = f10n_gates(rs.cell);
+  return f10n_joint_matches<ShpH256N>(rs.hid_s, G) && rs.hid_blocks == G ? f10n_ws_bytes<ShpH256N>(G) : 0;
 }
 int launch_lstm_fwd_f10n(const RnnShape& rs, GinSrc gin, const float* bilv, const void* h0, const void* c0, const float* packed_hid,
                          void* out, void* hT, void* cT, float* reserve, void* ws, hipStream_t stream) {
-  if (f10n_joint_matches<ShpH256N>(rs.hid_s))
-    return launch_n<ShpH256N>(rs, gin, bilv, h0, c0, packed_hid, out, hT, cT, reserve, ws, stream);
-  return TTRNN_ERR_UNSUPPORTED;
+  if (!f10n_joint_matches<ShpH256N>(rs.hid_s, f10n_gates(rs.cell))) return TTRNN_ERR_UNSUPPORTED;
+  return rs.cell == TTRNN_LSTM ? launch_n<ShpH256N, TTRNN_LSTM>(rs, gin, bilv, h0, c0, packed_hid, out, hT, cT, reserve, ws, stream)
+                               : launch_n<ShpH256N, TTRNN_GRU>(rs, gin, bilv, h0, c0, packed_hid, out, hT, cT, reserve, ws, stream);
 }
 
 }  // namespace ttrnn

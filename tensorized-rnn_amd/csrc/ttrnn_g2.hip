@@ -1915,7 +1915,7 @@ static G2FwdWs g2_fwd_layout(const RnnShape& rs) {
   if (f10_h512_fwd_available(rs, TTRNN_F32) && w.rec < g2_al(f10_h512_workspace_bytes())) w.rec = g2_al(f10_h512_workspace_bytes());
   if (rs.cell == TTRNN_GRU && w.rec < g2_al(f10gh_workspace_bytes(rs))) w.rec = g2_al(f10gh_workspace_bytes(rs));      // (0 for other shapes)
   if (rs.cell == TTRNN_GRU && w.rec < g2_al(f10g5_workspace_bytes(rs))) w.rec = g2_al(f10g5_workspace_bytes(rs));
-  if (rs.cell == TTRNN_LSTM && w.rec < g2_al(f10n_workspace_bytes(rs))) w.rec = g2_al(f10n_workspace_bytes(rs));      // (naive H = 256)
+  if (w.rec < g2_al(f10n_workspace_bytes(rs))) w.rec = g2_al(f10n_workspace_bytes(rs));      // (naive per-gate sets, H = 256)
   if (!in1) {
     w.ident = gemm_split_identity_bytes(rs.in);
     w.wdense = gemm_split_dense_bytes(inp, 4 * rs.H);
@@ -2022,7 +2022,7 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
     if (L.rec < f10g5_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_gru_fwd_f10g5(rs, gin, h0, packed_hid, out, hT, reserve, rec, stream);
   }
-  // the naive per-gate TT-LSTM of H = 256, r = 8: one gate per wave on the fused-core scheme (ttrnn_fast_f10n.hip), either K-in
+  // the naive per-gate TT-LSTM / TT-GRU of H = 256, r = 8: one gate per wave on the fused-core scheme (ttrnn_fast_f10n.hip), either K-in
   if (dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10n_available(rs, dtype)) {
     if (L.rec < f10n_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;
     GinSrc srcn{gin, x, in1 ? 1 : 0};

@@ -170,7 +170,7 @@ bool f10gh_available(const RnnShape& rs, int dtype);
 int launch_gru_fwd_f10gh(const RnnShape& rs, GinSrc gin, const void* h0, const float* packed_hid, const void* bias_hid, void* out,
                          void* hT, float* reserve, void* ws, hipStream_t stream, int phase);
 // fp32 TT-GRU H = 512, r = 8 (benchmarking.py defaults with --gru): gates on the accumulators, behind the tier's K-in (ttrnn_fast_f10g5.hip)
-// ttrnn_fast_f10n.hip: the naive per-gate TT-LSTM (hid_blocks = 4) of H = 256, d = 3, r = 8 on a fused-core kernel, one gate per wave,
+// ttrnn_fast_f10n.hip: the naive per-gate TT-LSTM / TT-GRU (hid_blocks = 4 / 3) of H = 256, d = 3, r = 8 on a fused-core kernel, one gate per wave,
 // behind the runtime tier's K-in (gin / bilv in its conventions); ws: f10n_workspace_bytes (the tier's `rec` region)
 bool f10n_available(const RnnShape& rs, int dtype);
 size_t f10n_workspace_bytes(const RnnShape& rs);

@@ -803,8 +803,8 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     m = build_module(meta, dev())
     assert not m._needs_stepping()
     lstm = kind == "ttlstm"
-    # (round 5: the naive TT-LSTM of H = 256, r = 8 has a fused-core forward kernel of its own, one gate per wave: ttrnn_fast_f10n.hip)
-    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if (lstm and H == 256 and d == 3 and r == 8) else "runtime_mfma")
+    # (round 5: the naive sets of H = 256, r = 8 have a fused-core forward kernel of their own, one gate per wave: ttrnn_fast_f10n.hip)
+    assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if (H == 256 and d == 3 and r == 8) else "runtime_mfma")
     assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
     x = torch.randn(B, T, inp)
     w = torch.randn(B, T, H)
@@ -1036,6 +1036,53 @@ def test_naive_lstm_fused_core_kernel(inp, B, T, state, need_out):
     with torch.no_grad():
         F.tt_rnn_layer(spec, x.to(dev()), None, None, cin, bin_, bad, bhid)
     assert ttrnn_hip.device_status(reset=True)["block_violations"] >= 1
+
+
+@pytest.mark.parametrize("inp,B,T,state", [(1, 5, 40, "none"), (1, 3, 300, "big"), (40, 6, 9, "small"), (28, 70, 12, "big")])
+def test_naive_gru_fused_core_kernel(inp, B, T, state):
+    """The same kernel for the naive per-gate TT-GRU (three gate waves; gru.py:33-44,150-153: per-gate biases, the n gate's hidden bias
+    inside r * (...)), H = 256, d = 3, r = 8: outputs, final state, every per-gate gradient against the oracle; against the tier's
+    kernel (`dev` bit 25); a decaying huge h_0 (the state's exponent is re-derived every step while it is positive)."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    torch.manual_seed(29)
+    meta = dict(kind="ttgru", input_size=inp, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, is_naive=True)
+    m = build_module(meta, dev())
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_route(spec, B, T) == "fused_core"
+    with ttrnn_hip.option("dev", 1 << 25):
+        assert F.rnn_route(spec, B, T) == "runtime_mfma"
+    x = torch.randn(B, T, inp)
+    w = torch.randn(B, T, 256)
+    h0 = None if state == "none" else torch.randn(B, 256) * (9.0 if state == "big" else 0.3)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    ro, rh = O.gru_forward(layers, xr, h0)
+    ((ro * w).sum() + rh.sum()).backward()
+    init = None if h0 is None else h0.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    out, hT = m(xg, init)
+    ((out * w.to(dev())).sum() + hT.sum()).backward()
+    tol = 1e-5 * max(1.0, float(ro.detach().abs().max()))
+    assert _maxabs(out.detach(), ro.detach()) <= tol and _maxabs(hT.detach(), rh.detach()) <= tol
+    assert _maxabs(xg.grad, xr.grad) <= 1e-4 * max(float(xr.grad.abs().max()), 1e-6)
+    seen = 0
+    for name, p in m.named_parameters():
+        key = name.replace(".gate", ".gates.")
+        if key in leaves:
+            seen += 1
+            ref = leaves[key].grad
+            assert _maxabs(p.grad, ref) <= 1e-4 * max(float(ref.abs().max()), 1e-6), name
+    assert seen >= 18
+    with torch.no_grad():
+        fused = m(x.to(dev()), init)
+        with ttrnn_hip.option("dev", 1 << 25):
+            tier = m(x.to(dev()), init)
+    assert torch.equal(fused[0], out.detach())
+    assert _maxabs(fused[0], tier[0]) <= 2e-6 * max(1.0, float(ro.detach().abs().max()))
+    assert not torch.equal(fused[0], tier[0])
 
 
 PAIR_CASES = [
