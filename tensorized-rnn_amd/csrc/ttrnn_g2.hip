@@ -1117,6 +1117,24 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
     lds_barrier();
     TT_STAMP(3)
     // ---- gates + state (lstm.py:26-32 / gru.py:38-44), both samples --------------------------------------------------------------
+    // The gate inputs were requested a step ago by loads the compiler does not see (below): what is still in flight in front of
+    // the gate phase is the head stream's prefetch for the next step — the LAST 2 G2_PF vector-memory operations issued — and
+    // vector-memory operations complete in issue order, so "all but the youngest 2 G2_PF" is exactly "the gate inputs have arrived".
+    // (hipcc's own wait for the same registers was vmcnt(1): the gate phase sat out the whole prefetch burst, ~2 000 cycles of a
+    // 19 000-cycle step.)  A wave without a stream (nu_w == 0) has nothing younger than its gate inputs in flight: vmcnt(0).
+    if constexpr (!IN1) {
+      if (nu_w > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int u = 0; u < UPT; ++u) asm volatile("s_waitcnt vmcnt(16)" : "+v"(gi[s][u])::"memory");
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int u = 0; u < UPT; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gi[s][u])::"memory");
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const size_t bt = bsm[s] * T + t;
@@ -1174,7 +1192,9 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd_p(G2Plan P, GinSrc gs, con
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
           const int hid0 = tid + u * NT;
-          gi[s][u] = gin4[bn + ((u < upt && hid0 < H) ? hid0 : 0)];
+          // (opaque to hipcc's s_waitcnt insertion: the wait is the explicit one at the head of the gate phase)
+          const f32x4* gp = gin4 + bn + ((u < upt && hid0 < H) ? hid0 : 0);
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gi[s][u]) : "v"(gp) : "memory");
         }
       }
     }

@@ -17,7 +17,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     RANK, INP = int(os.environ.get("DIAG_RANK", "8")), int(os.environ.get("DIAG_IN", "1"))
     GRU = os.environ.get("DIAG_CELL", "lstm") == "gru"
     NAIVE = os.environ.get("DIAG_CELL", "lstm") == "naive"      # k_lstm_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM
-    m = (TTGRU if GRU else TTLSTM)(INP, 256, 1, dev, n_cores=3, tt_rank=RANK, is_naive=NAIVE)
+    HID = int(os.environ.get("DIAG_H", "256"))      # 512 / 384: the eight- / six-wave instantiations of k_lstm_fwd_f10q
+    m = (TTGRU if GRU else TTLSTM)(INP, HID, 1, dev, n_cores=3, tt_rank=RANK, is_naive=NAIVE)
 B, T = int(os.environ.get("DIAG_B", "64")), int(os.environ.get("DIAG_T", "784"))
 x = torch.rand(B, T, INP, device=dev, requires_grad=True)     # requires_grad -> reserve buffer exists
 captured = {}
@@ -35,7 +36,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 raw = captured["reserve"][:8 * 8 * 8 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
 import ttrnn_hip
-NW = 8 if os.environ.get("TTRNN_F10_NB1") == "1" else 4      # default: the four-wave kernel k_lstm_fwd_f10q (waves 4..7: unused slots)
+NW = 8 if (os.environ.get("TTRNN_F10_NB1") == "1" or int(os.environ.get("DIAG_H", "256")) > 256) else 4      # default: the four-wave kernel k_lstm_fwd_f10q (waves 4..7: unused slots)
 if GRU or NAIVE:                             # k_gru_fwd_f10vh (ttrnn_fast_f10gh.hip) / k_lstm_fwd_f10n (ttrnn_fast_f10n.hip)
     names = ["S10 mma+gbuf", "barrier1", "gates", "S2+split", "barrier2", "-", "-", "-"]
 elif ttrnn_hip.get_fp32_math() == "split" and (int(os.environ.get("TTRNN_DEV", "0")) & 512) and RANK == 8 \
