@@ -63,6 +63,13 @@ WORKLOADS = {
                  desc="TT-LSTM in=1024 (assumed) H=1024 ncores=4 ttrank=32 seq_len=1024 batch=128/GPU fp32 (configs[4] global batch on one GPU)"),
     "cfg1": dict(kind="ttlstm", inp=1, H=128, L=1, d=2, r=4, B=32, T=784, dtype="f32", flop=71552, flop_in=4352,
                  desc="TT-LSTM in=1 H=128 ncores=2 ttrank=4 seq_len=784 batch=32 fp32 (configs[0] shapes)"),
+    # the reference harness' defaults (benchmarking.py: in=256 H=512 batch 512, 160 steps) with --naive_tt / --ttrank 16: the runtime tier's
+    # paired forward kernel (k_g2_fwd_p).  FLOP per sample-timestep = sum over both TT-matrices (per gate for the naive set) of
+    # 2 rows_k K_k M_k over the chain's stages + 13 per hidden unit
+    "naive512": dict(kind="ttlstm", inp=256, H=512, L=1, d=3, r=8, B=512, T=160, dtype="f32", naive=True, flop=3938816,
+                     desc="naive per-gate TT-LSTM (tt_linearset.py) in=256 H=512 ncores=3 ttrank=8 seq_len=160 batch=512/GPU fp32 (benchmarking.py --naive_tt)"),
+    "r16_512": dict(kind="ttlstm", inp=256, H=512, L=1, d=3, r=16, B=512, T=160, dtype="f32", flop=13769216,
+                    desc="TT-LSTM in=256 H=512 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (benchmarking.py --ttrank 16)"),
 }
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0
@@ -104,6 +111,17 @@ EXECUTED = {
                  kin_bf16_flop=3 * 2 * 1024 * 4096, rec_simds=8, rec_wgs_per_sample=2, pipe16="f16_mfma", terms=3,
                  note="K-rec: merged 2-core chain on two-piece fp16 operands (three terms per product), two workgroups per "
                       "sample, every core fragment resident (registers + a quarter of stage 1's in LDS); K-in: dense GEMM on two-piece fp16 operands (three terms)"),
+    # runtime tier, two samples per workgroup (k_g2_fwd_p), per SAMPLE-timestep: stage 1 = 64 term-packed tiles (16 m tiles x 4 column
+    # tiles); stage 2 = the streamed head, 256 blocks x 3 terms per PAIR (naive: one column tile holds both samples) / x 6 (r = 16:
+    # two column tiles); K-in: dense GEMM on fp16 pieces
+    "naive512": dict(bf16_mfma=64 + 256 * 3 // 2, fp32_mfma=0, kin_bf16_flop=3 * 2 * 2048 * 256, rec_simds=4, rec_wgs_per_sample=0.5,
+                     pipe16="f16_mfma", terms=3,
+                     note="runtime tier, two samples per eight-wave workgroup: the block-diagonal head (512 KB of fp16 pieces) streamed from L2 "
+                          "once per step for both; bound by the L2 -> CU path (55 of 64 B/clk in stage 2), not by the matrix pipe"),
+    "r16_512": dict(bf16_mfma=64 + 256 * 6 // 2, fp32_mfma=0, kin_bf16_flop=3 * 2 * 2048 * 256, rec_simds=4, rec_wgs_per_sample=0.5,
+                    pipe16="f16_mfma", terms=3,
+                    note="runtime tier, two samples per eight-wave workgroup in two column tiles: the head (512 KB of fp16 pieces) streamed "
+                         "from L2 once per step for both; bound by the L2 -> CU path"),
 }
 
 
@@ -161,7 +179,7 @@ def build_model(w, device):
     torch.manual_seed(1111)
     cls = TTLSTM if w["kind"] == "ttlstm" else TTGRU
     with contextlib.redirect_stdout(io.StringIO()):
-        m = cls(w["inp"], w["H"], w["L"], device, n_cores=w["d"], tt_rank=w["r"])
+        m = cls(w["inp"], w["H"], w["L"], device, n_cores=w["d"], tt_rank=w["r"], is_naive=bool(w.get("naive")))
     if w["dtype"] == "bf16":
         m = m.to(torch.bfloat16)
     return m.eval()
