@@ -627,6 +627,24 @@ def test_repeat_runs_are_bitwise_identical(kind, inp, H, L, r, B, T, dtype):
         assert _maxabs(a, b) <= 2e-3 * max(float(b.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("kind,inp,H,r,naive,B,T", [("ttlstm", 40, 512, 8, True, 300, 40), ("ttgru", 40, 512, 16, False, 301, 30),
+                                                     ("ttlstm", 1, 256, 8, True, 64, 300), ("ttgru", 28, 256, 8, True, 70, 60)])
+def test_round5_forward_kernels_repeat_bitwise(kind, inp, H, r, naive, B, T):
+    """Race screen for the forward kernels of round 5 behind raw s_barrier / explicit s_waitcnt: the paired tier kernel (one and two
+    column tiles; its gate inputs arrive through loads the compiler's wait insertion does not see) and the one-gate-per-wave kernel of
+    the naive sets — twenty launches, every one bit for bit the first."""
+    torch.manual_seed(4)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=r, is_naive=naive), dev())
+    x = torch.rand(B, T, inp, device=dev())
+    with torch.no_grad():
+        ref = m(x)
+        ref_out, ref_h = ref[0].clone(), (ref[1][0] if kind == "ttlstm" else ref[1]).clone()
+        for rep in range(20):
+            got = m(x)
+            assert torch.equal(got[0], ref_out), rep
+            assert torch.equal(got[1][0] if kind == "ttlstm" else got[1], ref_h), rep
+
+
 @pytest.mark.parametrize("case,route", [("small", "default"), ("small", "nogemm"), ("mid", "nogemm"), ("mid", "default"),
                                         ("cfg4", "default"), ("cfg2", "default"), ("cfg3", "default")])
 def test_forward_200_launches_bitwise_per_kernel(case, route):
