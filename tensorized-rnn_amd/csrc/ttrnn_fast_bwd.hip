@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "ttrnn_core.h"
 #include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
 #include "ttrnn_mfma.h"
 
 namespace ttrnn {
@@ -904,7 +905,12 @@ bool fast_rnn_bwd_available(const RnnShape& rs, int dtype) {
   if (rs.cell == TTRNN_LSTM)
     return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s) ||
            shape_matches<ShpH128R4L>(rs.hid_s);
-  return shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s);
+  // TT-GRU r = 16 has no fused-core reverse kernel: this family would run its stage-wise kernel (1.50 ms at benchmarking.py
+  // --hidden_size 256 --gru --ttrank 16), the runtime tier's reverse kernel — same reserve — takes 0.95: the tier where it is on offer
+  // (split mode / bf16; dev bit 26: the stage-wise kernel, A/B)
+  if (shape_matches<ShpH256R16G>(rs.hid_s))
+    return (opt(OPT_DEV) & (1 << 26)) || opt(OPT_FORCE_GENERIC) || !g2_rnn_bwd_available(rs, dtype);
+  return shape_matches<ShpH256R8G>(rs.hid_s);
 }
 
 int launch_rnn_bwd_fast(const RnnShape& rs, int dtype, const void* out, const void* h0, const void* c0,
