@@ -585,7 +585,7 @@ static bool fwd_prefers_g2(const RnnShape& rs, int dtype) {
   if (force_generic()) return false;
   if (opt(OPT_FORCE_G2)) return g2_rnn_available(rs, dtype);
   // (input_size == 1: this file's plan with the fused set-up launch; otherwise the tier's dense K-in in front of the same kernel)
-  if (f10gh_available(rs, dtype) && fast_rnn_fwd_available(rs, dtype) && (rs.in == 1 || !g2_rnn_available(rs, dtype))) return false;
+  if (f10gh_available(rs, dtype) && f10gh_own_plan(rs) && fast_rnn_fwd_available(rs, dtype) && (rs.in == 1 || !g2_rnn_available(rs, dtype))) return false;
   return rs.cell == TTRNN_GRU && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && g2_rnn_available(rs, dtype);
 }
 
@@ -742,7 +742,7 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
     }
     if (st != TTRNN_OK) return st;
     // fused-core kernels: fp32 LSTM shapes under the split math mode; the bf16 GRU shape always (bf16 MFMA either way)
-    if (desc->dtype == TTRNN_F32 && rs.cell == TTRNN_GRU && f10gh_available(rs, desc->dtype))
+    if (desc->dtype == TTRNN_F32 && rs.cell == TTRNN_GRU && f10gh_available(rs, desc->dtype) && f10gh_own_plan(rs))
       return launch_gru_fwd_f10gh(rs, src, h0, packed_hid, bias_hid, out, hT, reserve, (char*)workspace + f.gin_bytes + f.lin_ws_bytes,
                                   (hipStream_t)stream, phase);
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, desc->dtype))

@@ -870,7 +870,7 @@ size_t f10_workspace_bytes(const RnnShape& rs, int dtype) {
 bool f10_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
   if (dtype == TTRNN_BF16 && rs.cell == TTRNN_GRU) return shape_matches<ShpH256R8G>(rs.hid_s);
-  if (dtype == TTRNN_F32 && rs.cell == TTRNN_GRU) return f10gh_available(rs, dtype);      // (split math mode only)
+  if (dtype == TTRNN_F32 && rs.cell == TTRNN_GRU) return f10gh_available(rs, dtype) && f10gh_own_plan(rs);      // (split math mode only; r = 16 runs behind the tier's K-in: ttrnn_g2.hip)
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s) || f2_rnn_fwd_available(rs, dtype);
 }

@@ -147,8 +147,13 @@ __global__ void __launch_bounds__(256, 2) k_gru_fwd_f10vh(int B, int T, GinSrc g
   if (in1) xq.init(xs, b * T, T, lane);
   if (T > 0) {
     if (in1) {
-      bb = gin4[H + hid];
-      vv = gin4[hid] - bb;
+      if constexpr (G2GIN) {                  // the tier's convention: the unit row's projection + its bias row (handed over as `bias_hid`)
+        bb = reinterpret_cast<const f32x4*>(bias_hid)[hid];
+        vv = gin4[hid];
+      } else {
+        bb = gin4[H + hid];
+        vv = gin4[hid] - bb;
+      }
     } else {
       gi = gin4[(b * T) * H + hid];
     }
@@ -261,7 +266,7 @@ static int launch_gh(const RnnShape& rs, GinSrc gin, const void* h0, const float
 // over the B T rows; the chain kernel this file's own route would use there is 2 - 3 x slower at 81 920 rows: 1.07 against 0.72 ms for
 // benchmarking.py --gru --hidden_size 256).  ws: f10gh_workspace_bytes (the tier's `rec` region)
 template <class S>
-static int launch_gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
+static int launch_gh_g2(const RnnShape& rs, GinSrc src, const float* bilv, const void* h0, const float* packed_hid, void* out, void* hT,
                         float* reserve, void* ws, hipStream_t stream) {
   if (!ws) return TTRNN_ERR_WORKSPACE;
   float* hdr = reinterpret_cast<float*>(ws);
@@ -269,27 +274,32 @@ static int launch_gh_g2(const RnnShape& rs, const float* gin, const void* h0, co
   hipLaunchKernelGGL((k_f10h_scale<S>), dim3(F10<S>::M), dim3(256), 0, stream, packed_hid, reinterpret_cast<int*>(ws));
   hipLaunchKernelGGL((k_f10gh_prep<S>), dim3(4 * F10<S>::NM), dim3(64), 0, stream, packed_hid, hdr, wfrag);
   if (hipGetLastError() != hipSuccess) return TTRNN_ERR_LAUNCH;
-  GinSrc src{gin, nullptr, 0};
-  auto kern = out ? (h0 ? k_gru_fwd_f10vh<S, true, true, false, false, true> : k_gru_fwd_f10vh<S, false, true, false, false, true>)
-                  : (h0 ? k_gru_fwd_f10vh<S, true, false, false, false, true> : k_gru_fwd_f10vh<S, false, false, false, false, true>);
+  // input_size == 1: the tier hands over the unit row's projection (gin) and its bias row (bilv, through the kernel's bias_hid slot)
+  auto kern = src.in1 ? (out ? (h0 ? k_gru_fwd_f10vh<S, true, true, true, false, true> : k_gru_fwd_f10vh<S, false, true, true, false, true>)
+                             : (h0 ? k_gru_fwd_f10vh<S, true, false, true, false, true> : k_gru_fwd_f10vh<S, false, false, true, false, true>))
+                      : (out ? (h0 ? k_gru_fwd_f10vh<S, true, true, false, false, true> : k_gru_fwd_f10vh<S, false, true, false, false, true>)
+                             : (h0 ? k_gru_fwd_f10vh<S, true, false, false, false, true> : k_gru_fwd_f10vh<S, false, false, false, false, true>));
   hipLaunchKernelGGL(kern, dim3(rs.B), dim3(256), 0, stream, rs.B, rs.T, src, (const float*)h0, packed_hid, hdr, wfrag,
-                     (const float*)nullptr, (float*)out, (float*)hT, reserve);
+                     src.in1 ? bilv : (const float*)nullptr, (float*)out, (float*)hT, reserve);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
-                            float* reserve, void* ws, hipStream_t stream) {
-  if (shape_matches<ShpH256R8G>(rs.hid_s)) return launch_gh_g2<ShpH256R8G>(rs, gin, h0, packed_hid, out, hT, reserve, ws, stream);
-  if (shape_matches<ShpH256R16G>(rs.hid_s)) return launch_gh_g2<ShpH256R16G>(rs, gin, h0, packed_hid, out, hT, reserve, ws, stream);
+int launch_gru_fwd_f10gh_g2(const RnnShape& rs, GinSrc src, const float* bilv, const void* h0, const float* packed_hid, void* out,
+                            void* hT, float* reserve, void* ws, hipStream_t stream) {
+  if (shape_matches<ShpH256R8G>(rs.hid_s)) return launch_gh_g2<ShpH256R8G>(rs, src, bilv, h0, packed_hid, out, hT, reserve, ws, stream);
+  if (shape_matches<ShpH256R16G>(rs.hid_s)) return launch_gh_g2<ShpH256R16G>(rs, src, bilv, h0, packed_hid, out, hT, reserve, ws, stream);
   return TTRNN_ERR_UNSUPPORTED;
 }
 
+// does this file's own plan (unit-row K-in + fused set-up launch, input_size == 1) exist for the shape?  (r = 8 only)
+bool f10gh_own_plan(const RnnShape& rs) { return shape_matches<ShpH256R8G>(rs.hid_s); }
+
 // fp32-storage TT-GRU, split math mode (dev bit 256: keep the runtime-shape tier's kernel, A/B)
-// (r = 16: behind the tier's K-in only — input_size != 1; this file's own plan has no unit-row chain kernel for that input shape)
+// (r = 16: behind the tier's K-in only, either input size; this file's own plan has no unit-row chain kernel for that shape)
 bool f10gh_available(const RnnShape& rs, int dtype) {
   return !opt(OPT_NO_F10) && !(opt(OPT_DEV) & 256) && rs.B >= 1 && rs.T >= 1 && dtype == TTRNN_F32 && rs.cell == TTRNN_GRU &&
          rs.hid_blocks <= 1 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT &&
-         (shape_matches<ShpH256R8G>(rs.hid_s) || (rs.in != 1 && shape_matches<ShpH256R16G>(rs.hid_s)));
+         (shape_matches<ShpH256R8G>(rs.hid_s) || shape_matches<ShpH256R16G>(rs.hid_s));
 }
 size_t f10gh_workspace_bytes(const RnnShape& rs) {
   if (shape_matches<ShpH256R8G>(rs.hid_s)) return f10gh_ws_bytes<ShpH256R8G>();

@@ -2034,9 +2034,10 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
   // the reference's default benchmark shape (H = 512, r = 8) in split mode: the fused-core forward kernel on the gin just built
   // (both biases are folded into it), this tier's `rec` region as its fragment workspace (ttrnn_fast_f10.hip)
   // the fp32 TT-GRU shape with a fused-core forward kernel (H = 256, r = 8; input_size != 1 arrives here): that kernel on this gin
-  if (!in1 && dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10gh_available(rs, dtype)) {
+  if (dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10gh_available(rs, dtype)) {      // (either input size: GinSrc says which)
     if (L.rec < f10gh_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;      // (never: g2_fwd_layout sizes it)
-    return launch_gru_fwd_f10gh_g2(rs, gin, h0, packed_hid, out, hT, reserve, rec, stream);
+    GinSrc srcg{gin, x, in1 ? 1 : 0};
+    return launch_gru_fwd_f10gh_g2(rs, srcg, bilv, h0, packed_hid, out, hT, reserve, rec, stream);
   }
   if (!in1 && dtype == TTRNN_F32 && !opt(OPT_FORCE_G2) && f10g5_available(rs, dtype)) {      // H = 512, r = 8: gates on the accumulators
     if (L.rec < f10g5_workspace_bytes(rs)) return TTRNN_ERR_WORKSPACE;

@@ -181,8 +181,9 @@ size_t f10g5_workspace_bytes(const RnnShape& rs);
 int launch_gru_fwd_f10g5(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
                          float* reserve, void* ws, hipStream_t stream);
 // ... and behind the runtime-shape tier's dense K-in (input_size != 1): gin in the tier's slot convention, ws = the tier's rec region
-int launch_gru_fwd_f10gh_g2(const RnnShape& rs, const float* gin, const void* h0, const float* packed_hid, void* out, void* hT,
-                            float* reserve, void* ws, hipStream_t stream);
+int launch_gru_fwd_f10gh_g2(const RnnShape& rs, GinSrc src, const float* bilv, const void* h0, const float* packed_hid, void* out,
+                            void* hT, float* reserve, void* ws, hipStream_t stream);
+bool f10gh_own_plan(const RnnShape& rs);      // the shape has the file's own input_size == 1 plan (r = 8)
 // two samples per workgroup (ttrnn_fast_f10nb.hip); wfrag = the fragments launch_rnn_fwd_f10 prepared
 int launch_rnn_fwd_f10_nb2(const RnnShape& rs, GinSrc gin, const void* h0, const void* c0, const float* packed_hid,
                            const void* wfrag, const float* bias_hid, void* out, void* hT, void* cT, float* reserve,

@@ -3176,7 +3176,8 @@ def test_gru_fp32_fused_core_variants_vs_oracle_and_tier():
     # (input_size != 1: the same recurrent kernel behind the runtime tier's dense K-in; rank 16: that route only, core 2's S2
     # fragments in LDS)
     for inp, L, B, T, with_h0, rank in ((1, 1, 9, 50, False, 8), (1, 1, 70, 33, True, 8), (40, 2, 6, 21, True, 8), (40, 1, 300, 12, False, 8),
-                                        (40, 2, 9, 17, True, 16), (256, 1, 300, 10, False, 16)):
+                                        (40, 2, 9, 17, True, 16), (256, 1, 300, 10, False, 16),
+                                        (1, 1, 7, 60, True, 16), (1, 1, 66, 30, False, 16)):      # r = 16, input_size 1: behind the tier's unit-row K-in
         m = _cfg3_fp32_module(inp, L, rank)
         x = torch.rand(B, T, inp)
         h0 = (torch.randn(B, 256) * 0.5) if with_h0 else None
