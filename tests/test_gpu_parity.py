@@ -990,7 +990,7 @@ def test_tier_input_matrix_from_merged_cores(kind, inp, H, d, r, naive):
 @pytest.mark.parametrize("inp,B,T,state,need_out", [(1, 5, 40, "none", True), (1, 3, 784, "big", True), (40, 6, 9, "small", True),
                                                      (28, 4, 12, "big", False), (1, 70, 33, "small", True)])
 def test_naive_lstm_fused_core_kernel(inp, B, T, state, need_out):
-    """k_lstm_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM (tt_linearset.py:5-38, tt_lstm.py:17-21; pmnist_test.py
+    """k_rnn_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM (tt_linearset.py:5-38, tt_lstm.py:17-21; pmnist_test.py
     --naive_tt) of H = 256, d = 3, r = 8 on a fused-core kernel with ONE GATE PER WAVE, behind the runtime tier's K-in, instead of the
     tier's own recurrent kernel (`dev` bit 25).  Outputs, final states and every per-gate gradient (the tier's reverse kernel reads the
     reserve this kernel writes) against the oracle; the two forward kernels against each other; a false block promise is counted."""

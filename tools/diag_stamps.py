@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer diagnostic: per-phase cycle shares of the fused-core forward kernels (TTRNN_DIAG=1 build variant with
-s_memtime stamps): the TT-LSTM kernels, with DIAG_CELL=gru the fp32 TT-GRU kernel k_gru_fwd_f10vh, with DIAG_CELL=naive k_lstm_fwd_f10n.
+s_memtime stamps): the TT-LSTM kernels, with DIAG_CELL=gru the fp32 TT-GRU kernel k_gru_fwd_f10vh, with DIAG_CELL=naive k_rnn_fwd_f10n.
 Shares only — never quote the diagnostic build's run time."""
 import contextlib, io, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ torch.manual_seed(1111)
 with contextlib.redirect_stdout(io.StringIO()):
     RANK, INP = int(os.environ.get("DIAG_RANK", "8")), int(os.environ.get("DIAG_IN", "1"))
     GRU = os.environ.get("DIAG_CELL", "lstm") == "gru"
-    NAIVE = os.environ.get("DIAG_CELL", "lstm") == "naive"      # k_lstm_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM
+    NAIVE = os.environ.get("DIAG_CELL", "lstm") == "naive"      # k_rnn_fwd_f10n (ttrnn_fast_f10n.hip): the naive per-gate TT-LSTM
     HID = int(os.environ.get("DIAG_H", "256"))      # 512 / 384: the eight- / six-wave instantiations of k_lstm_fwd_f10q
     m = (TTGRU if GRU else TTLSTM)(INP, HID, 1, dev, n_cores=3, tt_rank=RANK, is_naive=NAIVE)
 B, T = int(os.environ.get("DIAG_B", "64")), int(os.environ.get("DIAG_T", "784"))
@@ -37,7 +37,7 @@ torch.cuda.synchronize()
 raw = captured["reserve"][:8 * 8 * 8 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 8)   # [block][wave][seg]
 import ttrnn_hip
 NW = 8 if (os.environ.get("TTRNN_F10_NB1") == "1" or int(os.environ.get("DIAG_H", "256")) > 256) else 4      # default: the four-wave kernel k_lstm_fwd_f10q (waves 4..7: unused slots)
-if GRU or NAIVE:                             # k_gru_fwd_f10vh (ttrnn_fast_f10gh.hip) / k_lstm_fwd_f10n (ttrnn_fast_f10n.hip)
+if GRU or NAIVE:                             # k_gru_fwd_f10vh (ttrnn_fast_f10gh.hip) / k_rnn_fwd_f10n (ttrnn_fast_f10n.hip)
     names = ["S10 mma+gbuf", "barrier1", "gates", "S2+split", "barrier2", "-", "-", "-"]
 elif ttrnn_hip.get_fp32_math() == "split" and (int(os.environ.get("TTRNN_DEV", "0")) & 512) and RANK == 8 \
         and os.environ.get("TTRNN_F10_NB1") != "1":      # TTRNN_DEV=512: k_lstm_fwd_f10s (ttrnn_fast_f10s.hip, A/B kernel)
