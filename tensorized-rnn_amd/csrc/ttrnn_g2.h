@@ -48,6 +48,7 @@ struct G2Mat {
   // planes of the h image [2][16*N1T][JS]
   int KB1, pack8, JS;
   int K2S;                          // bf16 stage-2 operand planes [16*N2T][K2S]
+  int cin;                          // forward stage 2 with the COLUMN TILES INSIDE a unit (N2T > 1: one fragment, N2T accumulator pairs; resident plans only)
   int wrap;                         // forward head stream: blocks of cyclic copy behind every wave's live blocks (k_g2_fwd_p: G2_PF; else 0)
   // reverse T2 (f16 MFMA, two pieces per operand): M = Jh*Rp, N = It, K = Ih
   int bM2T, bNKB, bT2, bKBP, bU, bUW, bSW;         // no k split: T1 reads the complete dC1; bSW = blocks of a wave's (compact) stream
@@ -82,7 +83,7 @@ inline void g2_split(int nw, int tiles, int nkb, int* ksplit, int* kper, int* kb
   *uw = g2_ceil(*units, nw);
 }
 
-inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
+inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1, bool cin_ok = false) {
   *m = G2Mat{};
   m->nw = nw;
   if (s.d < 2) return;
@@ -127,6 +128,17 @@ inline void g2_plan_mat(G2Mat* m, const TtShape& s, int nw, int blocks = 1) {
   m->NKB = m->ng * m->NKBt;
   m->T2 = m->M2T * m->N2T;
   g2_split(nw, m->T2, m->NKBt, &m->KSPLIT, &m->KPER, &m->KBP, &m->U, &m->UW);
+  // Several column tiles (I_t > 16): a unit per (row tile, column tile) streams / holds the SAME head blocks once per column tile
+  // (H = 768, d = 2, r = 2 — the speaker encoder's own shape — 192 KB per step for 18 KB of head).  With the column tiles inside
+  // the unit a block is one fragment and N2T accumulator pairs; taken where it makes the head RESIDENT in the eight slots.
+  m->cin = 0;
+  if (cin_ok && m->N2T > 1 && m->N2T <= 4 && m->ng == 1) {
+    int ks, kper, kbp, u, uw;
+    g2_split(nw, m->M2T, m->NKBt, &ks, &kper, &kbp, &u, &uw);
+    if (uw * kbp <= G2_PF && m->UW * m->KBP > G2_PF) {
+      m->cin = 1; m->KSPLIT = ks; m->KPER = kper; m->KBP = kbp; m->U = u; m->UW = uw;
+    }
+  }
   m->JtS = 4 * m->KS1 + 1;
   m->pack8 = m->Jt <= 8;
   m->KB1 = g2_ceil(m->Jt, 32);
@@ -184,11 +196,11 @@ struct G2Plan {
 inline size_t g2_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // wide: 8 waves per workgroup (the caller passes B <= #CUs)
-inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide) {
+inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide, bool cin_ok = false) {
   *p = G2Plan{};
   p->cell = rs.cell; p->G = rs.G; p->H = rs.H; p->B = rs.B; p->T = rs.T;
   const int nw = wide ? G2_NW_MAX : 4;
-  g2_plan_mat(&p->hid, rs.hid_s, nw, rs.hid_blocks);
+  g2_plan_mat(&p->hid, rs.hid_s, nw, rs.hid_blocks, cin_ok);
   if (!p->hid.ok) return;
   // the gate phases run on every thread: unit tid + u * 64 nw (1, 2 or 4 hidden units per thread)
   if (rs.H > G2_UPT * 256) return;

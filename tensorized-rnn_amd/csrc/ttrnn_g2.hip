@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(64) k_g2_head_frag(G2Mat m, const float* __res
   float rsc = 1.f;                               // (REV) this lane's row scale
   if (u < U && kbl < KPER) {
     const int tile = u / KSPLIT, part = u % KSPLIT;
-    const int mt = tile / m.N2T;
+    const int mt = (!REV && m.cin) ? tile : tile / m.N2T;      // (cin: a forward unit is a ROW tile, its column tiles inside)
     if constexpr (REV) {
       // row maximum over i_h (zero outside the row's own gate block): the four k-groups of the lane's row share the walk
       const int rw = 16 * mt + r;
@@ -423,7 +423,8 @@ __device__ __forceinline__ void split_block_h(const xh8 (&w)[2], const xh8 (&x)[
 // default benchmark shape (H = 512, r = 8: 256 KB of two-piece fragments = sixteen k-blocks per wave) RESIDENT — streamed it
 // was 384 KB per sample-step through a 64 B/clk L2 -> CU path: 8.7 us per step at B = 512 for 1.3 us of matrix-pipe time
 // IN1: input_size == 1 as a template parameter (round 4, lesson 44: the runtime flag cost the fused-core kernels 9 - 10 %)
-template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8, int NSL = G2_PF, bool IN1 = false>
+// CIN (round 5, RES only): the unit of a wave is a ROW tile with its N2T <= 4 column tiles inside (G2Mat::cin)
+template <int CELL, typename TS, int UPT, bool RES, bool DIAG, bool P8, int NSL = G2_PF, bool IN1 = false, bool CIN = false>
 __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const float* __restrict__ bilv, const TS* __restrict__ h0,
                                                   const TS* __restrict__ c0, const xh8* __restrict__ fs2,
                                                   const float* __restrict__ ft1, const int* __restrict__ hdr,
@@ -571,6 +572,27 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
     r_ymask |= live ? (1 << j) : 0;
     if (live) r_un[j] = unf[16 * r_mt + 4 * q + j] * ung[16 * r_nt + c];
   }
+  // CIN: the same constants per column tile of the wave's row tile r_tile
+  constexpr int NCI = CIN ? 4 : 1;
+  const _Float16* c_brow[NCI];
+  int c_ybase[NCI], c_ymask[NCI];
+  f32x4 c_un[NCI];
+  if constexpr (CIN) {
+#pragma unroll
+    for (int ct = 0; ct < NCI; ++ct) {
+      const int itc = 16 * ct + c;
+      c_brow[ct] = img + (itc < m.It ? itc : m.It - 1) * m.K2S + 8 * q + 32 * r_kloc;
+      c_ybase[ct] = r_part * GH + (16 * r_tile + 4 * q) * m.It + itc;
+      c_ymask[ct] = 0;
+      c_un[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = ct < m.N2T && itc < m.It && 16 * r_tile + 4 * q + j < m.Ih && nu_w > 0;
+        c_ymask[ct] |= live ? (1 << j) : 0;
+        if (live) c_un[ct][j] = unf[16 * r_tile + 4 * q + j] * ung[itc];
+      }
+    }
+  }
   XChunk<TS> xq;                    // input_size == 1: 64 timesteps of x per register, refilled a chunk ahead
   xq.cur = 0.f; xq.nxt = 0.f;
   if (in1) xq.init(xs, b * T, T, lane);
@@ -691,7 +713,33 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_fwd(G2Plan P, GinSrc gs, const
         }
       }
     };
-    if constexpr (RES) {
+    if constexpr (RES && CIN) {
+      // one ROW tile per wave, its column tiles inside: every resident block is multiplied against the N2T column tiles' operands
+      static_assert(NSL == G2_PF, "columns inside: the eight-slot resident form");
+      f32x4 lo[NCI], hi[NCI];
+#pragma unroll
+      for (int ct = 0; ct < NCI; ++ct) { lo[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; hi[ct] = lo[ct]; }
+#pragma unroll
+      for (int j = 0; j < NSL; ++j) {
+        if (j < r_nlive) {
+#pragma unroll
+          for (int ct = 0; ct < NCI; ++ct)
+            if (ct < m.N2T) {
+              xh8 bfc[2];
+#pragma unroll
+              for (int p = 0; p < 2; ++p) bfc[p] = *reinterpret_cast<const xh8*>(c_brow[ct] + p * plane + 32 * j);
+              split_block_h(wbuf[j], bfc, lo[ct], hi[ct]);
+            }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCI; ++ct) {
+        const f32x4 acc = (hi[ct] + lo[ct]) * c_un[ct];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c_ymask[ct] & (1 << j)) ybuf[c_ybase[ct] + j * m.It] = acc[j];
+      }
+    } else if constexpr (RES) {
       // one unit, at most G2_PF blocks, every constant hoisted: fragment reads at immediate offsets, MFMAs, four stores
       if (r_nlive == NSL) {
         // every slot live (the common case of the shapes that are resident at all): no per-block conditions — sixteen pairs of
@@ -1847,8 +1895,22 @@ static bool g2_bwd_res(const G2Plan& p) {
          !(opt(OPT_DEV) & 2048 && p.hid.ng > 1);
 }
 
+static bool g2_fwd_resident(const G2Plan& p);
 static void plan_for_single(G2Plan* p, const RnnShape& rs, bool backward) {
   const bool wide = rs.B <= device_cu_count();
+  // forward: column tiles inside a stage-2 unit where that makes a streamed head resident (G2Mat::cin; dev bit 27: never) — the plan of
+  // the batch's own wave count first, the eight-wave plan where only it gets there
+  if (!backward && !(opt(OPT_DEV) & (1 << 27)) && !opt(OPT_DIAG)) {
+    G2Plan a, b8;
+    g2_plan(&a, rs, wide, true);
+    if (a.hid.ok && a.okf && a.hid.cin) { *p = a; return; }
+    if (!wide) {
+      g2_plan(&b8, rs, true, true);
+      G2Plan a0;
+      g2_plan(&a0, rs, false, false);
+      if (b8.hid.ok && b8.okf && b8.hid.cin && !(a0.hid.ok && a0.okf && g2_fwd_resident(a0))) { *p = b8; return; }
+    }
+  }
   if (!wide && backward && !(opt(OPT_DEV) & 4096)) {
     // the same trade in the reverse kernel: eight-wave workgroups with the head^T fragments resident (two rounds) instead of two
     // co-resident four-wave workgroups that stream them from L2 every step
@@ -1895,6 +1957,8 @@ static void plan_for(G2Plan* p, const RnnShape& rs, bool backward) {
   g2_plan_pair(&q, rs);
   if (q.okf) *p = q;
 }
+
+static bool g2_fwd_resident(const G2Plan& p) { return p.hid.UW * p.hid.KBP <= G2_PF || g2_fwd_res16(p); }
 
 static bool g2_available(const RnnShape& rs, int dtype, bool backward) {
   if (opt(OPT_NO_G2) || rs.B < 1 || rs.T < 1) return false;
@@ -2093,6 +2157,16 @@ static int fwd_t(const RnnShape& rs, const G2Plan& P, int dtype, const void* x, 
                               : k_g2_fwd<CELLV, TS, (UPTV <= 2 ? UPTV : 1), true, false, false, 16>);                    \
       if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern16), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;     \
       hipLaunchKernelGGL(kern16, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0,          \
+                         (const TS*)c0, reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve); \
+      break;                                                                                                             \
+    }                                                                                                                    \
+    if (P.hid.cin) {                                                                                                     \
+      auto kernc = in1 ? (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true, G2_PF, true, true>                           \
+                             : k_g2_fwd<CELLV, TS, UPTV, true, false, false, G2_PF, true, true>)                         \
+                       : (p8 ? k_g2_fwd<CELLV, TS, UPTV, true, false, true, G2_PF, false, true>                          \
+                             : k_g2_fwd<CELLV, TS, UPTV, true, false, false, G2_PF, false, true>);                       \
+      if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernc), P.f_lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;      \
+      hipLaunchKernelGGL(kernc, dim3(rs.B), dim3(P.hid.nw * 64), P.f_lds, stream, P, src, bilv, (const TS*)h0,           \
                          (const TS*)c0, reinterpret_cast<const xh8*>(fs2), ft1, hdr, (TS*)out, (TS*)hT, (TS*)cT, reserve); \
       break;                                                                                                             \
     }                                                                                                                    \

@@ -1103,6 +1103,35 @@ def test_naive_gru_fused_core_kernel(inp, B, T, state):
     assert not torch.equal(fused[0], tier[0])
 
 
+@pytest.mark.parametrize("kind,inp,H,d,r,B,T", [("ttlstm", 40, 768, 2, 2, 5, 9), ("ttgru", 1, 512, 2, 8, 4, 12), ("ttlstm", 40, 768, 4, 8, 300, 6),
+                                                 ("ttgru", 28, 1024, 2, 4, 3, 5), ("ttlstm", 1, 384, 4, 4, 70, 8)])
+def test_tier_column_tiles_inside_a_unit(kind, inp, H, d, r, B, T):
+    """G2Mat::cin (round 5): with more than one column tile in stage 2 (I_t > 16: every d = 2 / d = 4 shape from H = 384 up, the speaker
+    encoder's own H = 768, d = 2, r = 2) a forward unit is a ROW tile with its column tiles inside — one fragment, N2T accumulator pairs —
+    where that makes a streamed head resident; `dev` bit 27 = a unit per (row tile, column tile), as before.  The same products (the partial sums of a
+    unit's k range may be split over the waves differently): against each other and against the oracle."""
+    import ttrnn_hip
+    torch.manual_seed(37)
+    m = build_module(dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=d, tt_rank=r), dev())
+    lstm = kind == "ttlstm"
+    x = torch.randn(B, T, inp)
+    h0 = torch.randn(B, H) * 0.4
+    c0 = torch.randn(B, H)
+    from oracle import ttrnn_oracle as O
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    layers, _ = O.layers_from_state_dict(sd, 1, requires_grad=False)
+    with torch.no_grad():
+        ro = (O.lstm_forward(layers, x, (h0, c0)) if lstm else O.gru_forward(layers, x, h0))
+        init = (h0.to(dev()), c0.to(dev())) if lstm else h0.to(dev())
+        new = m(x.to(dev()), init)
+        with ttrnn_hip.option("dev", 1 << 27):
+            old = m(x.to(dev()), init)
+    assert _maxabs(new[0], ro[0]) <= 1e-5 and _maxabs(old[0], ro[0]) <= 1e-5
+    # (the two plans may split a unit's k range over the waves differently: same products, another order of the partial sums)
+    assert _maxabs(new[0], old[0]) <= 2e-6
+    assert _maxabs(new[1][0] if lstm else new[1], old[1][0] if lstm else old[1]) <= 2e-6
+
+
 PAIR_CASES = [
     # kind, in, H, d, r, naive, B, T, big_h0 — heads the tier streams from L2 every step (no plan keeps them in registers)
     ("ttlstm", 40, 512, 3, 8, True, 5, 6, False),       # benchmarking.py --naive_tt; odd batch: the last workgroup holds one sample
