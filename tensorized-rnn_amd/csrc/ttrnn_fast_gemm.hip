@@ -1039,6 +1039,26 @@ bool dense_wgrad_ok(int in, int out) { return in >= 4 && in % 4 == 0 && out >= 4
 // split: three-way bf16 splits on the bf16 MFMA (needs out % 256 == 0); otherwise the fp32 MFMA.
 static size_t dense_colmax_bytes(int in, int out) { return al256g((size_t)(in + out) * sizeof(unsigned)); }
 // partial column sums of dy per row range (at most one range per CU, rounded up to the XCD multiple)
+// Row ranges (split-K) of the dense weight gradient for `tiles` output tiles: a multiple of 8 (one row range per XCD at a time, its
+// tiles side by side on that XCD's L2).  Where the chip takes the tiles x ranges in ONE round, the largest such count; where it
+// does not — 72 tiles (768 x 3072: H = 768 hidden matrices) x 8 ranges = 576 workgroups ran as three rounds, the third a quarter
+// full — the count with the fewest rounds per range, a small charge per range for its partial tile and the reduction: 32 ranges
+// there (nine rounds of a quarter of the work: 2.16 -> ~1.7 ms), 24 for 18 tiles (384 x 1536).  (dev bit 28: the old rule.)
+static int dense_ks(int tiles, int cus) {
+  const int up = ((cus / tiles + 7) / 8) * 8, dn = (cus / tiles) / 8 * 8;
+  const int old_rule = (tiles * up <= cus || dn < 8) ? up : dn;
+  if (tiles * up <= cus || (opt(OPT_DEV) & (1 << 28))) return old_rule;
+  const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  int best = old_rule;
+  double bc = 1e30;
+  for (int ks = 8; ks <= 64; ks += 8) {
+    const int rounds = (tiles * (ks / 8) + per_xcd - 1) / per_xcd;
+    const double cst = (double)rounds / ks + 0.0005 * ks;
+    if (cst < bc) { bc = cst; best = ks; }
+  }
+  return best;
+}
+
 static size_t dense_bias_part_bytes(int out) { return al256g((size_t)((device_cu_count() + 7) / 8 * 8) * out * sizeof(float)); }
 
 // two fp16 pieces (three terms) where the column-maximum passes over x and dy pay off, else three bf16 pieces
@@ -1108,8 +1128,7 @@ int launch_dense_wgrad(int dtype, int64_t n_rows, int in, int out, const void* x
   if (tiles < cus) {
     // multiple of 8: one row range per XCD at a time — rounded DOWN where rounding up would not fit the chip in one go
     // (cfg3: 6 tiles x 48 ranges = 288 workgroups on 256 CUs ran as two rounds, 658 us; 40 ranges: one round)
-    const int up = ((cus / tiles + 7) / 8) * 8, dn = (cus / tiles) / 8 * 8;
-    KS = (tiles * up <= cus || dn < 8) ? up : dn;
+    KS = dense_ks(tiles, cus);
     const int64_t max_ks = (n_rows + KBc - 1) / KBc;                // at least one chunk per split
     if (KS > max_ks) KS = max_ks < 1 ? 1 : (int)max_ks;
   }
@@ -1174,7 +1193,9 @@ size_t dense_wgrad_scratch_bytes(int in, int out) {
   const int tiles_g = ((in + DenseG::TM - 1) / DenseG::TM) * ((out + DenseG::TN - 1) / DenseG::TN);
   const int tiles = tiles_s < tiles_g ? tiles_s : tiles_g;
   if (tiles >= cus) return dense_colmax_bytes(in, out) + dense_bias_part_bytes(out);
-  const int KS = ((cus / tiles + 7) / 8) * 8;
+  int KS = ((cus / tiles + 7) / 8) * 8;
+  if (tiles_s < cus && dense_ks(tiles_s, cus) > KS) KS = dense_ks(tiles_s, cus);
+  if (tiles_g < cus && dense_ks(tiles_g, cus) > KS) KS = dense_ks(tiles_g, cus);
   return dense_colmax_bytes(in, out) + al256g((size_t)KS * in * out * sizeof(float)) + dense_bias_part_bytes(out);
 }
 
