@@ -137,7 +137,7 @@ int ttrnn_get_fp32_math(void);
  *   "bf16_fp32_mfma",
  *   "big_merge" (0..2), "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2",
  *   "gemm_pieces" (0 | 2 | 3), "big_fp32_mfma", "pair_fault" (tests only: exercises the pair kernels' time-out path),
- *   "no_gemm3", "dev" (0..536870911: developer bit mask, A/B route switches between kernels that compute the same result;
+ *   "no_gemm3", "dev" (0..1073741823: developer bit mask, A/B route switches between kernels that compute the same result;
  *   csrc/ttrnn_opts.h lists the bits).
  * Workspace sizes must be queried under the same options the launch will run with.
  * Returns TTRNN_OK, or TTRNN_ERR_UNSUPPORTED for an unknown name / value out of range. */

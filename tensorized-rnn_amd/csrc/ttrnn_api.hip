@@ -32,7 +32,7 @@ struct OptTable {
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
       else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
-      else if (i == OPT_DEV) val = e ? (atoi(e) & 0x1FFFFFFF) : 0;
+      else if (i == OPT_DEV) val = e ? (atoi(e) & 0x3FFFFFFF) : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -61,7 +61,7 @@ int opt_set(const char* name, int value) {
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
   if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
-  if (i == OPT_DEV && (value < 0 || value > 0x1FFFFFFF)) return -1;
+  if (i == OPT_DEV && (value < 0 || value > 0x3FFFFFFF)) return -1;
   if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;

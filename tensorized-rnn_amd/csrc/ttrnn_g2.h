@@ -230,7 +230,7 @@ inline void g2_plan(G2Plan* p, const RnnShape& rs, bool wide, bool cin_ok = fals
   // (+ the inverse row scales of tail^T: sixteen floats per row tile of T1)
   p->b_tab = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4 + (size_t)m.bM1T * 16 + (size_t)p->b_hun) * 4);
   p->b_lds = p->b_dy + p->b_dc1 + p->b_dh + p->b_tab;
-  if (p->b_hun > 0 && !(m.N2T == 1 && m.bNKBt <= 4 && m.bUW * m.bNKBt <= G2_BSL)) {
+  if (p->b_hun > 0 && !(m.N2T <= 4 && m.bNKBt <= 4 && m.bUW * m.bNKBt <= G2_BSL)) {
     // streamed fragments (the resident kernel needs the table): not where the table costs a co-resident workgroup (H = 768, d = 4:
     // 6 KB more took the four-wave workgroups from two per CU to one, 10.3 -> 10.9 ms per training step)
     const int tab0 = (int)g2_al(((size_t)rs.G * rs.H + (size_t)m.bM2T * 4 + (size_t)m.bM1T * 16) * 4);

@@ -1662,28 +1662,39 @@ __global__ void __launch_bounds__(G2_NT_MAX) k_g2_bwd(G2Plan P, const TS* __rest
 #pragma unroll
         for (int p = 0; p < 2; ++p) bfr[kb][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * kb);
       f32x4 acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+      // several column tiles (round 5; before, such shapes never were resident: every d = 2 / d = 4 shape ran its T2 on the streamed
+      // general loop): unit ui of this wave = tile wave + ui NW = (row tile, column tile), the division by N2T <= 4 as a multiply-shift
+      const bool per_unit = m.ng > 1 || m.N2T > 1;
+      const int n2rcp = (65536 + m.N2T - 1) / m.N2T;
+      int u_mt = wave, u_itc = c;
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
         const int ui = sl / NKB, kb = sl % NKB;
         if (sl < r_nlive) {
           if (kb == 0) {
             acc_lo = f32x4{0.f, 0.f, 0.f, 0.f}; acc_hi = acc_lo;
-            if (m.ng > 1) {
-              // block-diagonal heads: this unit (row tile wave + ui NW of gate g) multiplies its own gate's i_h range of dy
-              const int kbase = ((16 * (wave + ui * NW)) / m.Kg) * m.bNKBt;
+            if (per_unit) {
+              // block-diagonal heads: this unit (row tile of gate g) multiplies its own gate's i_h range of dy; several column
+              // tiles: its own column tile's rows of dy
+              const int tile = wave + ui * NW;
+              u_mt = (tile * n2rcp) >> 16;
+              const int nt = tile - u_mt * m.N2T;
+              u_itc = 16 * nt + c;
+              const int kbase = m.ng > 1 ? ((16 * u_mt) / m.Kg) * m.bNKBt : 0;
+              const _Float16* bu = dyimg + (u_itc < m.It ? u_itc : m.It - 1) * m.IhS + 8 * q + 32 * kbase;
 #pragma unroll
               for (int k2 = 0; k2 < NKB; ++k2)
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-                  bfr[k2][p] = *reinterpret_cast<const xh8*>(brow + p * plane + 32 * (kbase + k2));
+                for (int p = 0; p < 2; ++p) bfr[k2][p] = *reinterpret_cast<const xh8*>(bu + p * plane + 32 * k2);
+            } else {
+              u_mt = wave + ui * NW;
             }
           }
           split_block_h(wbuf[sl], bfr[kb], acc_lo, acc_hi);
           if (kb == NKB - 1) {
-            const int mt = wave + ui * NW;
-            const int off = t2off[mt * 4 + q];
-            const f32x4 un = *reinterpret_cast<const f32x4*>(hunl + 16 * mt + 4 * q) * ust2;
-            if (off >= 0 && c < m.It) store_split4_h(dc1, planeC, off + c * m.Rp, (acc_hi + acc_lo) * un);
+            const int off = t2off[u_mt * 4 + q];
+            const f32x4 un = *reinterpret_cast<const f32x4*>(hunl + 16 * u_mt + 4 * q) * ust2;
+            if (off >= 0 && u_itc < m.It) store_split4_h(dc1, planeC, off + u_itc * m.Rp, (acc_hi + acc_lo) * un);
           }
         }
       }
@@ -1891,7 +1902,9 @@ static bool g2_fwd_res16(const G2Plan& p) {
 
 // reverse: every wave's head^T fragments stay in registers (one column tile, at most four live k-blocks per unit, G2_BSL slots)
 static bool g2_bwd_res(const G2Plan& p) {
-  return p.hid.ok && p.okb && p.b_hun > 0 && p.hid.N2T == 1 && p.hid.bNKBt <= 4 && p.hid.bUW * p.hid.bNKBt <= G2_BSL &&
+  // (several column tiles: resident since round 5 — dev bit 29: as before, one column tile only)
+  return p.hid.ok && p.okb && p.b_hun > 0 && (p.hid.N2T == 1 || (p.hid.N2T <= 4 && p.hid.bNP == 1 && !(opt(OPT_DEV) & (1 << 29)))) &&
+         p.hid.bNKBt <= 4 && p.hid.bUW * p.hid.bNKBt <= G2_BSL &&
          !(opt(OPT_DEV) & 2048 && p.hid.ng > 1);
 }
 

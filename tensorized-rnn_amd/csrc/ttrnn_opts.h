@@ -31,10 +31,10 @@ enum OptId {
                          //                         the time-out path (NaN poison + device status counter) can be exercised
   OPT_NO_GEMM3,          // TTRNN_NO_GEMM3=1        two-piece fp16 K-in GEMM with x split on the fly (round 2's kernel) instead of the
                          //                         pre-split LDS-DMA GEMM (A/B)
-  OPT_DEV,               // TTRNN_DEV=0..536870911     developer bit mask: A/B ROUTE switches between kernels that compute the same result
+  OPT_DEV,               // TTRNN_DEV=0..1073741823     developer bit mask: A/B ROUTE switches between kernels that compute the same result
                          //                         (1: gemm3 ping-pong schedule, 4: f10gq for bf16 GRU, 32: eight-wave GRU kernel,
                          //                         64: gemm3 one workgroup per tile, 1024: fused-core wgrad on unit rows, 4096: g2 four-wave streamed plans where the eight-wave plan would keep the head resident (forward: sixteen slots; reverse: twelve), 8192 / 16384: H = 512 r = 8 forward / reverse recurrence on the runtime tier, 32768 / 128: four-barrier / wave-local fused-core reverse LSTM kernel everywhere, 2048: g2 head
-                         //                         256: fp32 GRU H = 256 r = 8 forward on the runtime tier instead of k_gru_fwd_f10vh, 512: the single-barrier LSTM forward kernel k_lstm_fwd_f10s instead of k_lstm_fwd_f10q, 65536: no fused set-up launch (ttrnn_rnn_forward_cores = pack + forward), 262144: head forward as chain + separate epilogue launch, 268435456: the dense weight gradient's row ranges by the one-round rule everywhere, 134217728: the tier's forward plans without column tiles inside a stage-2 unit (G2Mat::cin), 67108864: TT-GRU r = 16 reverse recurrence on the stage-wise kernel instead of the runtime tier's, 33554432: naive TT-LSTM / TT-GRU H = 256 on the runtime tier instead of k_rnn_fwd_f10n, 16777216: the tier's K-in dense matrix from the merged cores (k_g2_dense) instead of the chain kernel on identity rows (measured: no difference), 8388608: d = 4 matrices' dense weight gradient pulled back onto the cores by the any-shape chain kernel instead of ttrnn_fast_proj.hip's launches, 2097152: runtime-tier reverse kernel on four-wave workgroups even where only one fits a CU, 4194304: its streamed T2 on the general per-position loop, 524288 / 1048576: the runtime tier's two-samples-per-workgroup forward kernel k_g2_fwd_p never / for every batch of two or more (default: more samples than CUs and a streamed head), 131072: H = 256 reverse LSTM kernel with the record-dependent gate factors precomputed by the helper waves (k_lstm_bwd_f10p instead of k_lstm_bwd_f10h; measured slower),
+                         //                         256: fp32 GRU H = 256 r = 8 forward on the runtime tier instead of k_gru_fwd_f10vh, 512: the single-barrier LSTM forward kernel k_lstm_fwd_f10s instead of k_lstm_fwd_f10q, 65536: no fused set-up launch (ttrnn_rnn_forward_cores = pack + forward), 262144: head forward as chain + separate epilogue launch, 536870912: the tier's reverse kernel resident for one column tile only, 268435456: the dense weight gradient's row ranges by the one-round rule everywhere, 134217728: the tier's forward plans without column tiles inside a stage-2 unit (G2Mat::cin), 67108864: TT-GRU r = 16 reverse recurrence on the stage-wise kernel instead of the runtime tier's, 33554432: naive TT-LSTM / TT-GRU H = 256 on the runtime tier instead of k_rnn_fwd_f10n, 16777216: the tier's K-in dense matrix from the merged cores (k_g2_dense) instead of the chain kernel on identity rows (measured: no difference), 8388608: d = 4 matrices' dense weight gradient pulled back onto the cores by the any-shape chain kernel instead of ttrnn_fast_proj.hip's launches, 2097152: runtime-tier reverse kernel on four-wave workgroups even where only one fits a CU, 4194304: its streamed T2 on the general per-position loop, 524288 / 1048576: the runtime tier's two-samples-per-workgroup forward kernel k_g2_fwd_p never / for every batch of two or more (default: more samples than CUs and a streamed head), 131072: H = 256 reverse LSTM kernel with the record-dependent gate factors precomputed by the helper waves (k_lstm_bwd_f10p instead of k_lstm_bwd_f10h; measured slower),
                          //                         fragments not resident).  Bits 2 / 8 / 16 (and 32 / 64 inside the dense weight
                          //                         gradient) are result-destroying ablations that exist ONLY in -DTTRNN_ABLATIONS
                          //                         builds (`make ablation` -> tools/bin/libttrnn_abl.so), never in libttrnn.so
