@@ -793,7 +793,11 @@ int ttrnn_rnn_forward_cores(const ttrnn_rnn_desc* desc, const void* x, const voi
   for (int k = 0; k < rs.in_s.d; ++k) if (!cores_in[k]) return TTRNN_ERR_NULL;
   for (int k = 0; k < rs.hid_s.d; ++k) if (!cores_hid[k]) return TTRNN_ERR_NULL;
   if (rs.B > 0 && rs.T > 0 && ttrnn_rnn_forward_cores_fused(desc)) {
+    // everything ttrnn_rnn_forward_phase(RUN) would refuse is refused HERE, before the set-up launch writes the caller's packed
+    // buffers and the workspace: a failed call leaves them untouched, as pack + forward does
     if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
+    if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
+    if (!x || (!out && !out_optional(rs, desc->dtype, reserve != nullptr))) return TTRNN_ERR_NULL;
     const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
     if (!workspace || workspace_bytes < f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes)
       return TTRNN_ERR_WORKSPACE;

@@ -371,7 +371,8 @@ TT_HD size_t ilv_index(int64_t n, int o, int out, int ilv_h, int ilv_mode) {
 
 // epi != 0 (TTRNN_EPI_LOG_SOFTMAX = 1 / TTRNN_EPI_RELU_L2NORM = 2, include/ttrnn.h; plain layout only): the row-wise epilogue of
 // the callers' heads (mnist_classifier.py:55-57, speaker_encoder.py:86-89) applied to the tile's rows while they are still in the
-// chain's buffer — one thread per row walks its `out` values (heads are 10 ... 256 wide) — and aux[n] keeps the row's
+// chain's buffer — one thread per row walks its `out` values: offered for NARROW heads only (out <= 32, the 10-class classifiers;
+// ttrnn_head_forward keeps the wave-per-row k_head_epilogue launch for wider ones such as the 256-wide speaker head) — and aux[n] keeps the row's
 // log-sum-exp / L2 norm for the backward pass: the head's forward is ONE launch (round 5; a separate k_head_epilogue before)
 template <class Ex, typename T>
 TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* bias, const T* x, T* y,
@@ -389,8 +390,9 @@ TT_HD void ttlinear_fwd_tile(Ex& ex, const TtShape& s, const float* W, const T* 
     ex.par([&](int tid, int nthr) {
       for (int sidx = tid; sidx < nb; sidx += nthr) {
         float* row = r + (size_t)sidx * bs;
-        if (bias)
-          for (int o = 0; o < out; ++o) row[o] += ld(bias, o);
+        // the linear output as the storage type holds it (bf16: rounded once, as the separate k_head_epilogue launch reads it
+        // back from y) — the fused and the two-launch path compute the same thing
+        for (int o = 0; o < out; ++o) row[o] = round_as(y, bias ? row[o] + ld(bias, o) : row[o]);
         float a;
         if (epi == 1) {
           float m = row[0];

@@ -105,6 +105,7 @@ int ttrnn_head_forward(const ttrnn_ttm* w, int dtype, int epilogue, int64_t n_ro
   // shapes on the any-shape forward kernel (the classifier heads: 256 -> 10 and the like): chain + epilogue in ONE launch (round 5;
   // option dev bit 18: the separate epilogue launch, A/B)
   if (epilogue != TTRNN_EPI_NONE && n_rows > 0 && (dtype == TTRNN_F32 || dtype == TTRNN_BF16) && packed && x && y &&
+      s.out_size <= 32 &&      // (one thread per row in there: ~4 serial passes over `out` LDS values — fine for 10, not for 256)
       !(opt(OPT_DEV) & (1 << 18)) && (opt(OPT_FORCE_GENERIC) || !fast_ttlinear_fwd_available(s, dtype, 0))) {
     const LinPlan p = plan_ttlinear_fwd(s, n_rows);
     if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;

@@ -33,6 +33,11 @@ class TTLinearSet(nn.Module):
             built.append(TTLinear(**per_gate))
             self.add_module('gate%d' % index, built[-1])
         self.gates = nn.ModuleList(built)
+        # constants of joint_cores: the gate selector's identity and the block mask — non-persistent buffers (not in the
+        # state_dict, whose keys stay the reference's), moved by .to() / .cuda() with the parameters and never allocated lazily
+        # inside a forward (a first call under hipGraph capture would put them into the graph's pool: ADVICE r5)
+        self.register_buffer('_gate_eye', torch.eye(n_gates), persistent=False)
+        self.register_buffer('_gate_mask', torch.eye(n_gates, dtype=torch.bool).view(n_gates, 1, 1, 1, n_gates, 1), persistent=False)
 
     def joint_cores(self):
         """(cores, bias) of the single TT-matrix  x -> cat_g TT_g(x):  d + 1 cores with logical shapes
@@ -41,21 +46,21 @@ class TTLinearSet(nn.Module):
         per_gate = [list(member.weight_t.tt_cores) for member in self.gates]
         d = len(per_gate[0])
         ref = per_gate[0][0]
-        # the selector's identity is a constant: built once per (device, dtype)
-        key = (ref.device, ref.dtype)
-        eyes = self.__dict__.setdefault('_eye', {})
-        eye = eyes.get(key)
-        if eye is None:
-            eye = eyes[key] = torch.eye(G, dtype=ref.dtype, device=ref.device)
+        eye = self._gate_eye
+        if eye.dtype != ref.dtype or eye.device != ref.device:      # (parameters converted behind the module's back)
+            eye = eye.to(device=ref.device, dtype=ref.dtype)
+        mask = self._gate_mask if self._gate_mask.device == ref.device else self._gate_mask.to(ref.device)
         cores = [eye.view(1, G, 1, G)]
         for k in range(d):
             if k == d - 1:
                 cores.append(torch.cat([per_gate[g][k] for g in range(G)], dim=0))      # ranks (G r_{d-1}) -> 1: stacked along dim 0
                 continue
-            # block (g, h) of the joint core = delta_gh * gate g's core: ONE stack and ONE broadcast multiply (exact: x 1 and x 0)
-            # instead of two zero blocks and a concatenation per gate — the assembly was ~40 small launches per forward
+            # block (g, h) of the joint core = gate g's core where g == h, +0.0 elsewhere: ONE stack and ONE select instead of two
+            # zero blocks and a concatenation per gate (the assembly was ~40 small launches per forward).  A select, not a
+            # multiplication by the identity: c * 0 is -0.0 for negative entries and NaN for a non-finite one, which the
+            # block-promise check of the kernels (TTRNN_STAT_BLOCK_VIOLATIONS) would report exactly when a run diverges
             c = torch.stack([per_gate[g][k] for g in range(G)], dim=0)                   # (G, r_k, I_k, J_k, r_{k+1})
-            blk = c.unsqueeze(4) * eye.view(G, 1, 1, 1, G, 1)                             # (G, r_k, I_k, J_k, G, r_{k+1})
+            blk = torch.where(mask, c.unsqueeze(4), c.new_zeros(()))                      # (G, r_k, I_k, J_k, G, r_{k+1})
             cores.append(blk.reshape(G * c.shape[1], c.shape[2], c.shape[3], G * c.shape[4]))
         biases = [member.bias for member in self.gates]
         bias = None if biases[0] is None else torch.cat(biases, dim=0)

@@ -149,7 +149,8 @@ def set_fp32_math(mode):
     global OPTIONS_EPOCH
     prev = get_fp32_math()
     check(load().ttrnn_set_fp32_math(MATH_MODES[mode]), "ttrnn_set_fp32_math")
-    OPTIONS_EPOCH += 1
+    if prev != mode:          # (a no-op set — the restore of a `with` block that changed nothing — keeps captured graphs valid)
+        OPTIONS_EPOCH += 1
     return prev
 
 
@@ -179,7 +180,8 @@ def set_option(name, value):
     global OPTIONS_EPOCH
     prev = get_option(name)
     check(load().ttrnn_set_option(name.encode(), int(value)), "ttrnn_set_option({!r}, {})".format(name, value))
-    OPTIONS_EPOCH += 1
+    if prev != int(value):
+        OPTIONS_EPOCH += 1
     return prev
 
 

@@ -279,6 +279,12 @@ def main():
     seq_case('g6_bwd_cfg4', dict(cfg4, num_layers=2), B=2, T=6, grads=True, input_dist='uniform')
     seq_case('g6_bwd_cfg4_l3', cfg4, B=2, T=6, grads=True, input_dist='uniform')        # the real cfg4: three layers
     seq_case('g6_bwd_cfg5', cfg5, B=2, T=3, grads=True)
+    # the reference's own published model family (experiments/speaker_verification/encoder/params_model.py:2-4,14-16:
+    # H = 768, one layer, n_cores = 2, rank = 2; result tables d in {2, 4}): shapes whose chain is cheaper than the dense matrix
+    spk = dict(kind='ttlstm', input_size=40, hidden_size=768, num_layers=1, n_cores=2, tt_rank=2, seed=11)
+    seq_case('g6_bwd_spk', spk, B=4, T=24, grads=True, input_dist='uniform')
+    seq_case('g6_bwd_spk_d4r4', dict(spk, n_cores=4, tt_rank=4), B=4, T=16, grads=True, input_dist='uniform')
+    seq_case('g6_bwd_spk_gru', dict(spk, kind='ttgru'), B=3, T=12, grads=True, init=True, input_dist='uniform')
 
     # ---- G7: init parity ---------------------------------------------------------------------------
     init_case('g7_init_cfg1', cfg1)

@@ -250,8 +250,10 @@ def test_bf16_storage_vs_fp32_oracle():
     with torch.no_grad():
         out, hT = m(x.to(dev()))
     assert out.dtype == torch.bfloat16
-    assert _maxabs(out.float(), ro) <= 2e-2
-    assert _maxabs(hT.float(), rh) <= 2e-2
+    # relative to the oracle's own magnitude (a default-init TT-GRU's outputs have std ~ 0.03: an absolute 2e-2 would pass a
+    # badly wrong kernel): bf16 rounding of the stored outputs is 2^-8 = 3.9e-3 of a value, everything else is fp32
+    assert _maxabs(out.float(), ro) <= 1.5e-2 * float(ro.abs().max())
+    assert _maxabs(hT.float(), rh) <= 1.5e-2 * float(rh.abs().max())
 
 
 # ---- (3) properties at full size -------------------------------------------------------------------
@@ -514,7 +516,7 @@ def test_bf16_storage_gradients_vs_fp32_oracle():
         xg = x.to(dev()).requires_grad_(True)
         res = m(xg)
         (res[0].float() * w.to(dev())).sum().backward()
-        assert _maxabs(res[0].float(), ro.detach()) <= 2e-2
+        assert _maxabs(res[0].float(), ro.detach()) <= 1.5e-2 * float(ro.detach().abs().max())      # (relative: see above)
         for name, p in m.named_parameters():
             ref = leaves[name].grad
             scale = max(float(ref.abs().max()), 1e-3)

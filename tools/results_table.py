@@ -51,7 +51,7 @@ for w in ("cfg2", "cfg1", "cfg3", "cfg3_fp32", "cfg4", "cfg5"):
     basis = "executed" if (r.get("frac_basis") or "").startswith("executed") else "algorithmic"
     print("| %s | **%.3f** (%.3f) | %s | %s | %.3f (%s) / %.3f / %s; %.2f | `%s` %s | %.3g / %.3g | %s | %s / %s |" % (
         NAMES[w], f["ms_per_step"], f["prepared"]["ms_per_step"], "{:,.0f}".format(f["value"]).replace(",", " "),
-        "%.2f" % ex if ex else "–", r["frac"], basis, r["frac_algorithmic"], "%.3f" % exe if exe else "–", r["chip_occupancy"], KERN[w],
+        "%.2f" % ex if ex else "–", r["frac"] if r.get("frac") is not None else float("nan"), basis, r["frac_algorithmic"], "%.3f" % exe if exe else "–", r["chip_occupancy"], KERN[w],
         "%.1f (%d)" % (ka[1], ka[0]) if ka else "–", r["traffic"] or float("nan"), algo,
         "**%.2f**" % t["ms_per_step"] if t else "–",
         PREV[w][0], PREV[w][1] if PREV[w][1] else "–"))
