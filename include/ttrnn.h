@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTRNN_ABI_VERSION 6
+#define TTRNN_ABI_VERSION 7
 #define TTRNN_MAX_D 6          /* n_cores (+1 for new_core='first'/'last', rnn_utils.py:29-34) */
 
 typedef enum ttrnn_status {
@@ -352,6 +352,45 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
                           float* d_gates_in, float* d_gates_hid, void* d_h0, void* d_c0, float* d_state,
                           const void* x, float* stats,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- ABI 7: the weight gradients of one recurrent layer THROUGH THE CHAIN --------------------------------------------------
+ * Replaces the autograd of a cell's two TTLinear calls over all B*T rows (reference: tensorized_rnn/lstm.py:23-26 /
+ * gru.py:33-36 -> t3nsor/layers.py:121-127 -> t3nsor/ops.py:78-93, differentiated by torch) for the shapes whose chain is the
+ * cheaper contraction — 2*in*out > 1.5 x the chain's FLOPs for the hidden matrix: low ranks on large modes, i.e. the
+ * reference's own speaker-verification encoder (experiments/speaker_verification/encoder/params_model.py:2-4,14-16: H = 768,
+ * n_cores = 2, rank = 2; the dense 768 x 3072 gradient costs 4.8 x the chain there).  Every other descriptor keeps the dense
+ * route of ttrnn_ttlinear_backward_hinted, which is cheaper for it (cfg2 / cfg4 / cfg5: 0.2 ... 0.8 x).
+ *   mats               bit 0: the input matrix's gradient is wanted, bit 1: the hidden matrix's.  With both bits on an LSTM layer
+ *                      the gate gradients are read from HBM ONCE for both matrices.
+ *   x [B][T][in], out [B][T][H], h0 [B][H] or NULL (zeros): fp32; the hidden matrix's operand rows are h_{t-1}, read in place.
+ *   d_gates_in / d_gates_hid [B][T][G*H] fp32 (ttrnn_rnn_backward_ex; the LSTM's are one buffer).
+ *   d_packed_in / d_packed_hid (accumulated into: zero-fill before; NULL where `mats` has no bit), d_bias_in / d_bias_hid
+ *                      (accumulated into; NULL = not wanted).
+ *   x_colmax [in] / h_colmax [H] / dy_colmax_in / dy_colmax_hid [G*H]: optional UPPER BOUNDS (fp32, as ttrnn_lin_hints) of the
+ *                      operands' magnitudes — what missing ones cost is a pass over the operand.
+ * ttrnn_rnn_wgrad_workspace: bytes, or 0 = this descriptor (or `mats`) is not taken by the chain kernel under the current options
+ * (fp32 storage and split fp32 math only; option dev2 bit 0 switches the route off) — call ttrnn_ttlinear_backward_hinted then.
+ * Sums over the rows are added in a fixed order: the gradients are repeatable bit for bit. */
+typedef struct ttrnn_wgrad_args {
+  const void* x;
+  const void* out;
+  const void* h0;
+  const float* d_gates_in;
+  const float* d_gates_hid;
+  const float* packed_in;
+  const float* packed_hid;
+  float* d_packed_in;
+  float* d_packed_hid;
+  float* d_bias_in;
+  float* d_bias_hid;
+  const float* x_colmax;
+  const float* h_colmax;
+  const float* dy_colmax_in;
+  const float* dy_colmax_hid;
+} ttrnn_wgrad_args;
+size_t ttrnn_rnn_wgrad_workspace(const ttrnn_rnn_desc* desc, int mats);
+int ttrnn_rnn_wgrad(const ttrnn_rnn_desc* desc, int mats, const ttrnn_wgrad_args* args, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,14 +25,14 @@ struct OptTable {
         "TTRNN_FORCE_G2",
         "TTRNN_DIAG", "TTRNN_BF16_FP32_MFMA", "TTRNN_BIG_MERGE", "TTRNN_BIG_NO_GEMM", "TTRNN_BIG_NO_PAIR",
         "TTRNN_NO_BIGB", "TTRNN_BIGW_SLICES", "TTRNN_F10_NB1", "TTRNN_DENSE_FP32", "TTRNN_F10_NB2", "TTRNN_GEMM_PIECES",
-        "TTRNN_BIG_FP32_MFMA", "TTRNN_PAIR_FAULT", "TTRNN_NO_GEMM3", "TTRNN_DEV"};
+        "TTRNN_BIG_FP32_MFMA", "TTRNN_PAIR_FAULT", "TTRNN_NO_GEMM3", "TTRNN_DEV", "TTRNN_DEV2"};
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(env[i]);
       int val = 0;
       if (i == OPT_FP32_MATH) val = (e && (e[0] == 'e' || e[0] == '0')) ? TTRNN_MATH_EXACT : TTRNN_MATH_SPLIT;
       else if (i == OPT_BIG_MERGE) val = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
       else if (i == OPT_GEMM_PIECES) val = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
-      else if (i == OPT_DEV) val = e ? (atoi(e) & 0x3FFFFFFF) : 0;
+      else if (i == OPT_DEV || i == OPT_DEV2) val = e ? (atoi(e) & 0x3FFFFFFF) : 0;
       else val = (e && e[0] == '1') ? 1 : 0;
       v[i].store(val, std::memory_order_relaxed);
     }
@@ -45,7 +45,7 @@ OptTable& table() {
 const char* const kOptNames[OPT_COUNT] = {
     "fp32_math", "force_generic", "no_gemm", "no_in1", "no_f10", "no_g2", "force_g2", "diag", "bf16_fp32_mfma", "big_merge",
     "big_no_gemm", "big_no_pair", "no_bigb", "bigw_slices", "f10_nb1", "dense_fp32", "f10_nb2", "gemm_pieces", "big_fp32_mfma",
-    "pair_fault", "no_gemm3", "dev"};
+    "pair_fault", "no_gemm3", "dev", "dev2"};
 }  // namespace
 int opt(OptId id) { return table().v[id].load(std::memory_order_relaxed); }
 const char* opt_name(OptId id) { return kOptNames[id]; }
@@ -61,8 +61,8 @@ int opt_set(const char* name, int value) {
   if (i == OPT_FP32_MATH && value != TTRNN_MATH_EXACT && value != TTRNN_MATH_SPLIT) return -1;
   if (i == OPT_BIG_MERGE && (value < 0 || value > 2)) return -1;
   if (i == OPT_GEMM_PIECES && value != 0 && value != 2 && value != 3) return -1;
-  if (i == OPT_DEV && (value < 0 || value > 0x3FFFFFFF)) return -1;
-  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && value != 0 && value != 1) return -1;
+  if ((i == OPT_DEV || i == OPT_DEV2) && (value < 0 || value > 0x3FFFFFFF)) return -1;
+  if (i != OPT_FP32_MATH && i != OPT_BIG_MERGE && i != OPT_GEMM_PIECES && i != OPT_DEV && i != OPT_DEV2 && value != 0 && value != 1) return -1;
   table().v[i].store(value, std::memory_order_relaxed);
   return 0;
 }
@@ -945,6 +945,67 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   if (p.ws_bytes > 0 && (!workspace || workspace_bytes < p.ws_bytes)) return TTRNN_ERR_WORKSPACE;
   return launch_rnn_bwd_generic(rs, p, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in,
                                 d_gates_hid, d_h0, d_c0, workspace, (hipStream_t)stream, d_state);
+}
+
+}  // extern "C"
+
+
+// ---- ABI 7: chain weight gradients of a recurrent layer (ttrnn_fast_c2w.hip) ---------------------------------------------------
+// which matrices of `mats` the chain kernel takes in ONE launch for this descriptor (0: none)
+static int wgrad_chain_mats(const RnnShape& rs, int dtype, int mats, const TtShape* shapes[2], int* hid_slot) {
+  *hid_slot = -1;
+  if (dtype != TTRNN_F32 || fp32_math() != TTRNN_MATH_SPLIT || force_generic() || no_gemm() || (opt(OPT_DEV2) & 1)) return 0;
+  if (rs.hid_blocks > 1) return 0;                 // (joint matrices of naive sets: their block structure is not exploited here)
+  if (!(mats & 2) || !c2w_prefers_chain(rs.hid_s)) return 0;      // the hidden matrix decides
+  int n = 0;
+  // the input matrix rides along where it shares the gate gradients (LSTM) and the kernel takes the pair
+  if ((mats & 1) && rs.cell == TTRNN_LSTM && rs.in >= 4 && !(opt(OPT_DEV2) & 2)) {
+    const TtShape* both[2] = {&rs.in_s, &rs.hid_s};
+    if (c2w_workspace_bytes(both, 2) > 0) { shapes[0] = &rs.in_s; shapes[1] = &rs.hid_s; *hid_slot = 1; return 3; }
+  }
+  shapes[0] = &rs.hid_s;
+  *hid_slot = 0;
+  n = c2w_workspace_bytes(shapes, 1) > 0 ? 2 : 0;
+  return n;
+}
+
+extern "C" {
+
+size_t ttrnn_rnn_wgrad_workspace(const ttrnn_rnn_desc* desc, int mats) {
+  RnnShape rs;
+  if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
+  const TtShape* shapes[2] = {nullptr, nullptr};
+  int hs;
+  const int taken = wgrad_chain_mats(rs, desc->dtype, mats, shapes, &hs);
+  if (taken != mats) return 0;                     // all or nothing: the caller keeps ONE code path per layer
+  return c2w_workspace_bytes(shapes, taken == 3 ? 2 : 1);
+}
+
+int ttrnn_rnn_wgrad(const ttrnn_rnn_desc* desc, int mats, const ttrnn_wgrad_args* a, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  RnnShape rs;
+  int st = rnn_shape_init(&rs, desc);
+  if (st != TTRNN_OK) return st;
+  if (!a) return TTRNN_ERR_NULL;
+  const TtShape* shapes[2] = {nullptr, nullptr};
+  int hs;
+  const int taken = wgrad_chain_mats(rs, desc->dtype, mats, shapes, &hs);
+  if (taken == 0 || taken != mats) return TTRNN_ERR_UNSUPPORTED;
+  if (rs.B == 0 || rs.T == 0) return TTRNN_OK;
+  if (!a->out || !a->d_gates_hid || !a->packed_hid || !a->d_packed_hid) return TTRNN_ERR_NULL;
+  if (taken == 3 && (!a->x || !a->packed_in || !a->d_packed_in || !a->d_gates_in)) return TTRNN_ERR_NULL;
+  if (taken == 3 && a->d_gates_in != a->d_gates_hid) return TTRNN_ERR_BAD_DESC;      // one pass over dy = one buffer
+  const float* packed[2]; const float* x[2]; const float* first[2]; int T[2]; const unsigned* xc[2]; int xn[2]; float* dp[2];
+  const int n = taken == 3 ? 2 : 1;
+  if (n == 2) {
+    packed[0] = a->packed_in; x[0] = (const float*)a->x; first[0] = nullptr; T[0] = 0;
+    xc[0] = reinterpret_cast<const unsigned*>(a->x_colmax); xn[0] = rs.in; dp[0] = a->d_packed_in;
+  }
+  packed[hs] = a->packed_hid; x[hs] = (const float*)a->out; first[hs] = (const float*)a->h0; T[hs] = rs.T;
+  xc[hs] = reinterpret_cast<const unsigned*>(a->h_colmax); xn[hs] = rs.H; dp[hs] = a->d_packed_hid;
+  return launch_c2w(shapes, n, (int64_t)rs.B * rs.T, packed, x, first, T, a->d_gates_hid,
+                    xc, xn, reinterpret_cast<const unsigned*>(a->dy_colmax_hid), dp, n == 2 ? a->d_bias_in : nullptr, a->d_bias_hid,
+                    workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -38,6 +38,9 @@ enum OptId {
                          //                         fragments not resident).  Bits 2 / 8 / 16 (and 32 / 64 inside the dense weight
                          //                         gradient) are result-destroying ablations that exist ONLY in -DTTRNN_ABLATIONS
                          //                         builds (`make ablation` -> tools/bin/libttrnn_abl.so), never in libttrnn.so
+  OPT_DEV2,              // TTRNN_DEV2=0..1073741823    second developer bit mask (round 6; same kind of A/B route switches as `dev`):
+                         //                         1: no chain weight gradient (ttrnn_rnn_wgrad_workspace answers 0: dense gradients everywhere),
+                         //                         2: chain weight gradient for the hidden matrix only (the input matrix keeps its dense pass over dy)
   OPT_COUNT
 };
 

@@ -13,7 +13,7 @@ TTRNN_MAX_D = 6
 TTRNN_F32, TTRNN_BF16 = 0, 1
 TTRNN_LSTM, TTRNN_GRU = 0, 1
 PHASE_ALL, PHASE_PREPARE, PHASE_RUN = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 BWD_STATS_COLMAX, BWD_STATS_IN1SUMS, BWD_STATS_ROWS = 1, 2, 4
 BWD_STATS_ROWMAX = 4          # stats = [4][G*H] + [B*T]: the rows' maxima behind the four rows
 
@@ -37,6 +37,13 @@ class RnnDesc(ctypes.Structure):
                 ("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
                 ("has_bias_in", ctypes.c_int32), ("has_bias_hid", ctypes.c_int32),
                 ("in_w", TtmDesc), ("hid_w", TtmDesc), ("hid_blocks", ctypes.c_int32)]
+
+
+class WgradArgs(ctypes.Structure):
+    """struct ttrnn_wgrad_args (include/ttrnn.h, ABI 7): operands of the chain weight gradients of one recurrent layer."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "x", "out", "h0", "d_gates_in", "d_gates_hid", "packed_in", "packed_hid", "d_packed_in", "d_packed_hid",
+        "d_bias_in", "d_bias_hid", "x_colmax", "h_colmax", "dy_colmax_in", "dy_colmax_hid")]
 
 
 class LinHints(ctypes.Structure):
@@ -96,6 +103,8 @@ _SIGNATURES = {
     "ttrnn_rnn_backward": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 14 + [ctypes.c_size_t, _P]),
     "ttrnn_rnn_backward_stats": (ctypes.c_int, [ctypes.POINTER(RnnDesc)]),
     "ttrnn_rnn_backward_ex": (ctypes.c_int, [ctypes.POINTER(RnnDesc)] + [_P] * 16 + [ctypes.c_size_t, _P]),
+    "ttrnn_rnn_wgrad_workspace": (ctypes.c_size_t, [ctypes.POINTER(RnnDesc), ctypes.c_int]),
+    "ttrnn_rnn_wgrad": (ctypes.c_int, [ctypes.POINTER(RnnDesc), ctypes.c_int, ctypes.POINTER(WgradArgs), _P, ctypes.c_size_t, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -181,6 +181,8 @@ USE_BWD_STATS = True
 # Read the h_{t-1} rows of the hidden matrix's weight gradient in place (hints x_period / x_first) where the route can,
 # instead of materialising [h_0, out[:, :-1]]; same kind of switch
 USE_ROW_SHIFT = True
+# Weight gradients through the chain kernel where the library offers it (ttrnn_rnn_wgrad, ABI 7); same kind of switch
+USE_CHAIN_WGRAD = True
 # tests: a list here receives (mask, stats, d_gates_in, d_gates_hid) of every layer backward
 DEBUG_BWD_STATS = None
 
@@ -511,22 +513,54 @@ class _TTRnnLayerFn(torch.autograd.Function):
             if rowmax is not None and need[0]:
                 hints_in["dy_rowmax"] = rowmax
         use_sums = bool(hints_in and hints_in.get("xdy_sum") is not None)
-        dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
-                                               dg_in.reshape(B * T, -1), need[0], need_dw_in,
-                                               want_db_in and not use_sums, zeroed=(z_in_w, z_in_b), hints=hints_in)
-        if use_sums and want_db_in:
-            db_in = bstats[3]
+        want_db_hid = has_bhid and need[4]
+        # ABI 7: both weight gradients through the CHAIN where it is the cheaper contraction (low ranks on large modes — the
+        # reference's speaker encoder, params_model.py:2-4,14-16): one pass over the gate gradients for both matrices of an
+        # LSTM layer.  `chain` = the matrices it took (bit 0 input, bit 1 hidden); everything else keeps the dense routes below.
+        chain = 0
+        if USE_CHAIN_WGRAD and need_dw_hid and T > 0 and x.dtype == torch.float32 and x.is_contiguous():
+            cands = ((3, 2) if (need_dw_in and not need[0] and spec.cell == "lstm") else (2,))
+            for cand in cands:
+                cwsb = lib.ttrnn_rnn_wgrad_workspace(ctypes.byref(desc), cand)
+                if cwsb > 0:
+                    chain = cand
+                    break
+        if chain:
+            cws = _workspace(cwsb, dev)
+            hb = _ones(dev, H) if h0 is None else torch.maximum(h0.float().abs().amax(0), _ones(dev, H))
+            cm = bool(mask & _lib.BWD_STATS_COLMAX)
+            wa = _lib.WgradArgs(
+                _ptr(x), _ptr(out), _ptr(h0), _ptr(dg_in), _ptr(dg_hid), _ptr(packed_in), _ptr(packed_hid),
+                _ptr(z_in_w) if chain & 1 else None, _ptr(z_hid_w),
+                _ptr(z_in_b) if (chain & 1 and want_db_in) else None, _ptr(z_hid_b) if want_db_hid else None,
+                _ptr(_ones(dev, spec.input_size)) if ctx.x_bounded else None, _ptr(hb),
+                _ptr(bstats[0]) if cm else None, _ptr(bstats[1]) if cm else None)
+            with _timed("ttrnn_rnn_wgrad"):
+                check(lib.ttrnn_rnn_wgrad(ctypes.byref(desc), chain, ctypes.byref(wa), _ptr(cws), cwsb, _stream(x)),
+                      "ttrnn_rnn_wgrad")
+        dx = dpk_in = db_in = None
+        if chain & 1:
+            dpk_in, db_in = z_in_w, (z_in_b if want_db_in else None)
+        else:
+            dx, dpk_in, db_in = _ttlinear_backward(spec.in_spec, packed_in, x.reshape(B * T, -1),
+                                                   dg_in.reshape(B * T, -1), need[0], need_dw_in,
+                                                   want_db_in and not use_sums, zeroed=(z_in_w, z_in_b), hints=hints_in)
+            if use_sums and want_db_in:
+                db_in = bstats[3]
         # h_{t-1} rows: [h0, out[:, :-1]] — read in place by the dense-gradient routes, materialised for the others
-        if USE_ROW_SHIFT and need_dw_hid and T > 0 and lib.ttrnn_ttlinear_backward_shift_ok(
+        if chain & 2:
+            dpk_hid, db_hid = z_hid_w, (z_hid_b if want_db_hid else None)
+        elif USE_ROW_SHIFT and need_dw_hid and T > 0 and lib.ttrnn_ttlinear_backward_shift_ok(
                 ctypes.byref(spec.hid_spec.desc), _dtype_code(out), _lib.TTRNN_F32, B * T, T, 0):
             hprev = out.reshape(B * T, H)
             hints_hid = dict(hints_hid or {}, x_period=T, x_first=h0)
         else:
             first = h0 if h0 is not None else torch.zeros(B, H, dtype=out.dtype, device=dev)
             hprev = torch.cat([first.unsqueeze(1), out[:, :-1]], dim=1).reshape(B * T, H)
-        _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
-                                                False, need_dw_hid, has_bhid and need[4], zeroed=(z_hid_w, z_hid_b),
-                                                hints=hints_hid)
+        if not chain & 2:
+            _, dpk_hid, db_hid = _ttlinear_backward(spec.hid_spec, packed_hid, hprev, dg_hid.reshape(B * T, -1),
+                                                    False, need_dw_hid, want_db_hid, zeroed=(z_hid_w, z_hid_b),
+                                                    hints=hints_hid)
         dcin = spec.in_spec.unpack_grads(dpk_in, cores_in) if need_dw_in else [None] * n_in
         dchid = spec.hid_spec.unpack_grads(dpk_hid, cores_hid) if need_dw_hid else [None] * len(cores_hid)
         if dx is not None:
