@@ -958,14 +958,15 @@ static int wgrad_chain_mats(const RnnShape& rs, int dtype, int mats, const TtSha
   if (rs.hid_blocks > 1) return 0;                 // (joint matrices of naive sets: their block structure is not exploited here)
   if (!(mats & 2) || !c2w_prefers_chain(rs.hid_s)) return 0;      // the hidden matrix decides
   int n = 0;
+  const bool small = !(opt(OPT_DEV2) & 8);      // (dev2 bit 3: the large kernel variant too — measured slower than the dense gradient)
   // the input matrix rides along where it shares the gate gradients (LSTM) and the kernel takes the pair
   if ((mats & 1) && rs.cell == TTRNN_LSTM && rs.in >= 4 && !(opt(OPT_DEV2) & 2)) {
     const TtShape* both[2] = {&rs.in_s, &rs.hid_s};
-    if (c2w_workspace_bytes(both, 2) > 0) { shapes[0] = &rs.in_s; shapes[1] = &rs.hid_s; *hid_slot = 1; return 3; }
+    if (c2w_workspace_bytes(both, 2, small) > 0) { shapes[0] = &rs.in_s; shapes[1] = &rs.hid_s; *hid_slot = 1; return 3; }
   }
   shapes[0] = &rs.hid_s;
   *hid_slot = 0;
-  n = c2w_workspace_bytes(shapes, 1) > 0 ? 2 : 0;
+  n = c2w_workspace_bytes(shapes, 1, small) > 0 ? 2 : 0;
   return n;
 }
 

@@ -34,8 +34,9 @@ struct C2Mat {
   int PT, QT, IhT, JtT;                  // 16-wide tiles of P, Q, I_h, JtP
   int KA, KB;                            // 32-wide k-blocks of phase A (over JtP) and phase B (over I_h)
   int NA, NB, KC, KD;                    // per block of nb rows: column tiles of A (nb*JhP) and B (nb*I_t), k-blocks of C (nb*I_t), D (nb*JhP)
-  int WA;                                // m-tiles of phase A per wave (tile pt = wave + 8*wa: its Gt fragments live in registers)
-  int nC, nD, NU, UW;                    // accumulator units: C tiles (IhT x QT) then D tiles (PT x JtT); UW = units per wave (max)
+  int WA, NAG;                           // phase A: wave w holds the Gt fragments of m-tiles pt = w % PT (+ PT*wa ... WA of them when PT > #waves)
+                                         // and walks the column tiles na = w / PT, + NAG, ... (NAG = #waves / PT groups of waves share an m-tile)
+  int nC, nD, NU, UW;                    // accumulator units: C tiles (IhT x QT) then D tiles (PT x JtT); UW = slots per wave
   int XS, CS1, CS2;                      // row strides (halves) of the x image, the C1 image [row][q][i_t], the dC1 image [row][p][j_h]
   int QR, PR;                            // rows per sample of the C1 / dC1 image (QT*16, PT*16)
   int xs_rows;                           // rows of the x image (>= nb*JhP: tile / k-block overreach lands on zero rows)
@@ -43,7 +44,8 @@ struct C2Mat {
   int EX;                                // x quads per thread and block
   long head_elems, tail_elems;           // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
   // LDS byte offsets of this matrix's own regions
-  int l_xs, l_ghf, l_tab;
+  int l_xs, l_ghf, l_tab, l_c1, l_dc1;   // (the C1 / dC1 images are per matrix: both matrices run their phases between the same two barriers)
+  int c1_plane, dc1_plane;               // plane sizes (halves) of the C1 / dC1 images
   // workspace byte offsets (from the call's workspace base)
   long w_gh, w_gt, w_dgh, w_dgt, w_gtf, w_ghf, w_hdr, w_part;
 };
@@ -52,16 +54,15 @@ struct C2Plan {
   int ok;
   int nmat;                              // matrices sharing one pass over dy (2: the LSTM's input and hidden matrix)
   int nb;                                // rows per block
-  int big;                               // kernel variant: 0 = <NACC 4, WA 1, KA 1, EQ 4>, 1 = <NACC 8, WA 2, KA 2, EQ 8>
+  int big;                               // kernel variant: 0 = <NACC 4, WA 1, KA 1, EQ 4, XQ 1>, 1 = <NACC 8, WA 2, KA 2, EQ 8, XQ 2>
   int OUT, Ih, It, DS, dy_rows, EQ;      // the dy image [row][i_h][i_t] (shared: both matrices split their output modes alike)
-  int l_dy, l_c1, l_dc1, lds;            // LDS byte offsets of the shared regions, total
-  int c1_plane, dc1_plane;               // plane sizes (halves) of the shared C1 / dC1 regions
+  int l_dy, lds;                         // LDS byte offset of the shared dy image, total
   int grid;
   long w_bpart, w_cmax, ws_bytes;
   C2Mat m[2];
 };
 
-inline int c2_ceil(int a, int b) { return (a + b - 1) / b; }
+constexpr int c2_ceil(int a, int b) { return (a + b - 1) / b; }
 
 // chain multiply-adds x 2 per row of the four GEMMs, split at sp (no tile padding)
 inline double c2_chain_flops(const TtShape& s, int sp) {
@@ -71,48 +72,114 @@ inline double c2_chain_flops(const TtShape& s, int sp) {
   const double R = s.R[sp];
   return 2.0 * (2.0 * R * It * Jh * Jt + 2.0 * R * Jh * It * Ih);
 }
-// the split point with the cheapest chain (0: d < 2)
-inline int c2_best_split(const TtShape& s) {
-  int best = 0;
-  double bc = 0;
-  for (int sp = 1; sp < s.d; ++sp) {
-    const double c = c2_chain_flops(s, sp);
-    if (best == 0 || c < bc) { best = sp; bc = c; }
-  }
-  return best;
+
+// The two-core view (d cores split at s: J_h x J_t -> I_h x I_t through rank R) of a matrix plan, everything derived from it.
+// constexpr: the shape-specialised instantiations of the kernel (the reference's speaker encoder) evaluate the SAME function at
+// compile time, so their tile counts, strides and LDS offsets are literals; 0 = this kernel does not take the matrix.
+constexpr bool c2_mat_from(C2Mat* m, int d, int sp, int Jh, int Jt, int Ih, int It, int R, int in, int out, int nb, int big) {
+  *m = C2Mat{};
+  m->d = d; m->s = sp;
+  m->Jh = Jh; m->Jt = Jt; m->Ih = Ih; m->It = It; m->R = R;
+  m->in = in; m->out = out;
+  if (R > C2_MAX_R) return false;
+  if (It % 16 != 0 || Jt % 4 != 0) return false;                 // column tiles of B inside one row; x quads inside one j_h
+  if ((nb * It) % 32 != 0) return false;
+  m->JhP = (Jh + 7) & ~7; m->JtP = (Jt + 7) & ~7;
+  m->P = R * It; m->Q = R * m->JhP;
+  m->PT = c2_ceil(m->P, 16); m->QT = c2_ceil(m->Q, 16); m->IhT = c2_ceil(Ih, 16); m->JtT = c2_ceil(m->JtP, 16);
+  m->KA = c2_ceil(m->JtP, 32); m->KB = c2_ceil(Ih, 32);
+  m->NA = c2_ceil(nb * m->JhP, 16); m->NB = nb * It / 16; m->KC = nb * It / 32; m->KD = c2_ceil(nb * m->JhP, 32);
+  m->WA = c2_ceil(m->PT, C2_NW);
+  m->NAG = m->PT < C2_NW ? C2_NW / m->PT : 1;
+  m->nC = m->IhT * m->QT; m->nD = m->PT * m->JtT; m->NU = m->nC + m->nD;
+  m->UW = c2_ceil(m->nC, C2_NW) + c2_ceil(m->nD, C2_NW);      // accumulator slots of a wave: C tiles, then D tiles
+  if (m->WA > (big ? 2 : 1) || m->KA > (big ? 2 : 1) || m->UW > (big ? 8 : 4)) return false;
+  if (m->KB > 8 || m->KC > 16 || m->KD > 16 || m->NA > 64 || m->QT > 64) return false;
+  // row strides (halves): a multiple of 8 (16-byte fragment reads); 16 lanes of a ds_read_b128 group at stride S/2 dwords hit
+  // 64 different banks when S/2 is 4 (mod 8) — JhP = 8, 24, 40 as they are, the others 8 more
+  m->XS = 32 * m->KA + 8; m->CS1 = It + 8; m->CS2 = (m->JhP % 16 == 8) ? m->JhP : m->JhP + 8;
+  m->QR = m->QT * 16; m->PR = m->PT * 16;
+  m->xs_rows = m->NA * 16 > m->KD * 32 ? m->NA * 16 : m->KD * 32;
+  m->EX = c2_ceil(nb * in / 4, C2_NT);
+  if (m->EX > (big ? 2 : 1) || in % 4 != 0) return false;
+  m->head_elems = (long)Ih * Jh * R;
+  m->tail_elems = (long)It * Jt * R;
+  m->ok = 1;
+  return true;
 }
 
 // shape-only part of a matrix plan; false = this kernel does not take the matrix
 inline bool c2_plan_mat(C2Mat* m, const TtShape& s, int sp, int nb, int big) {
   *m = C2Mat{};
   if (s.d < 2 || sp < 1 || sp >= s.d) return false;
-  m->d = s.d; m->s = sp;
-  m->It = m->Jt = m->Ih = m->Jh = 1;
-  for (int k = sp; k < s.d; ++k) { m->It *= s.I[k]; m->Jt *= s.J[k]; }
-  for (int k = 0; k < sp; ++k) { m->Ih *= s.I[k]; m->Jh *= s.J[k]; }
-  m->R = s.R[sp];
-  m->in = s.in_size; m->out = s.out_size;
-  if (m->R > C2_MAX_R) return false;
+  int It = 1, Jt = 1, Ih = 1, Jh = 1;
+  for (int k = sp; k < s.d; ++k) { It *= s.I[k]; Jt *= s.J[k]; }
+  for (int k = 0; k < sp; ++k) { Ih *= s.I[k]; Jh *= s.J[k]; }
   for (int k = 0; k <= s.d; ++k) if (s.R[k] > 64) return false;
-  if (m->It % 16 != 0 || m->Jt % 4 != 0) return false;           // column tiles of B inside one row; x quads inside one j_h
-  if ((nb * m->It) % 32 != 0) return false;
-  m->JhP = (m->Jh + 7) & ~7; m->JtP = (m->Jt + 7) & ~7;
-  m->P = m->R * m->It; m->Q = m->R * m->JhP;
-  m->PT = c2_ceil(m->P, 16); m->QT = c2_ceil(m->Q, 16); m->IhT = c2_ceil(m->Ih, 16); m->JtT = c2_ceil(m->JtP, 16);
-  m->KA = c2_ceil(m->JtP, 32); m->KB = c2_ceil(m->Ih, 32);
-  m->NA = c2_ceil(nb * m->JhP, 16); m->NB = nb * m->It / 16; m->KC = nb * m->It / 32; m->KD = c2_ceil(nb * m->JhP, 32);
-  m->WA = c2_ceil(m->PT, C2_NW);
-  m->nC = m->IhT * m->QT; m->nD = m->PT * m->JtT; m->NU = m->nC + m->nD; m->UW = c2_ceil(m->NU, C2_NW);
-  if (m->WA > (big ? 2 : 1) || m->KA > (big ? 2 : 1) || m->UW > (big ? 8 : 4)) return false;
-  if (m->KB > 8 || m->KC > 16 || m->KD > 16 || m->NA > 64 || m->QT > 64) return false;
-  m->XS = 32 * m->KA + 8; m->CS1 = m->It + 8; m->CS2 = m->JhP + 8;
-  m->QR = m->QT * 16; m->PR = m->PT * 16;
-  m->xs_rows = m->NA * 16 > m->KD * 32 ? m->NA * 16 : m->KD * 32;
-  m->EX = c2_ceil(nb * m->in / 4, C2_NT);
-  if (m->EX > 2 || m->in % 4 != 0) return false;
-  m->head_elems = (long)m->Ih * m->Jh * m->R;
-  m->tail_elems = (long)m->It * m->Jt * m->R;
-  m->ok = 1;
+  return c2_mat_from(m, s.d, sp, Jh, Jt, Ih, It, s.R[sp], s.in_size, s.out_size, nb, big);
+}
+
+// the call-level part: the shared dy image, the LDS carve-up (the matrices' plans are filled in); false = does not fit
+constexpr bool c2_layout(C2Plan* p) {
+  const int nb = p->nb, nmat = p->nmat, big = p->big;
+  if (nmat == 2 && (p->m[0].Ih != p->m[1].Ih || p->m[0].It != p->m[1].It || p->m[0].out != p->m[1].out)) return false;
+  p->OUT = p->m[0].out; p->Ih = p->m[0].Ih; p->It = p->m[0].It;
+  if (p->OUT % 4 != 0) return false;
+  p->DS = p->It + 8;
+  p->dy_rows = nb * p->Ih + 32;
+  p->EQ = c2_ceil(nb * p->OUT / 4, C2_NT);
+  if (p->EQ > (big ? 8 : 4)) return false;
+  long off = 0;
+  p->l_dy = (int)off;
+  long dyb = (long)2 * p->dy_rows * p->DS * 2;
+  if (dyb < (long)nb * p->OUT * 4) dyb = (long)nb * p->OUT * 4;      // (the bias partials pass through this region at the end)
+  off += (dyb + 15) & ~15L;
+  for (int i = 0; i < nmat; ++i) {
+    C2Mat& m = p->m[i];
+    m.c1_plane = nb * m.QR * m.CS1; m.dc1_plane = nb * m.PR * m.CS2;
+    m.l_c1 = (int)off; off += ((long)2 * m.c1_plane * 2 + 15) & ~15L;
+    m.l_dc1 = (int)off; off += ((long)2 * m.dc1_plane * 2 + 15) & ~15L;
+    m.l_xs = (int)off; off += ((long)2 * m.xs_rows * m.XS * 2 + 15) & ~15L;
+    m.l_ghf = (int)off; off += (long)m.QT * m.KB * 2 * 1024;
+    m.l_tab = (int)off;
+    off += ((long)(m.NA * 16 + m.QT * 4 + 2 * m.NB) * 4 + 15) & ~15L;
+  }
+  if (off > (long)C2_LDS_LIMIT) return false;
+  p->lds = (int)off;
+  return true;
+}
+
+// ---- compile-time plans of the shape-specialised instantiations --------------------------------------------------------------
+// SPEC 1: the reference's speaker encoder (experiments/speaker_verification/encoder/params_model.py:2-4,14-16 — 40 mel channels,
+//         H = 768, n_cores = 2, rank = 2; tt_shape: (5, 8) x (48, 64) and (24, 32) x (48, 64)), both matrices of the LSTM layer;
+// SPEC 2: its hidden matrix alone (a TT-GRU's gate gradients differ between the matrices; a layer whose input needs dx).
+template <int SPEC>
+constexpr C2Plan c2_const_plan() {
+  C2Plan p{};
+  p.nb = 2; p.big = 0;
+  if (SPEC == 1) {
+    p.nmat = 2;
+    c2_mat_from(&p.m[0], 2, 1, 5, 8, 48, 64, 2, 40, 3072, 2, 0);
+    c2_mat_from(&p.m[1], 2, 1, 24, 32, 48, 64, 2, 768, 3072, 2, 0);
+  } else {
+    p.nmat = 1;
+    c2_mat_from(&p.m[0], 2, 1, 24, 32, 48, 64, 2, 768, 3072, 2, 0);
+  }
+  p.ok = c2_layout(&p) ? 1 : 0;
+  return p;
+}
+
+// do the fields the KERNEL reads agree? (the workspace offsets and the grid are the launcher's)
+inline bool c2_same_kernel_plan(const C2Plan& a, const C2Plan& b) {
+  if (a.nmat != b.nmat || a.nb != b.nb || a.big != b.big || a.OUT != b.OUT || a.Ih != b.Ih || a.It != b.It || a.DS != b.DS ||
+      a.dy_rows != b.dy_rows || a.l_dy != b.l_dy || a.lds != b.lds)
+    return false;
+  for (int i = 0; i < a.nmat; ++i) {
+    const C2Mat &x = a.m[i], &y = b.m[i];
+    if (x.d != y.d || x.s != y.s || x.Jh != y.Jh || x.Jt != y.Jt || x.Ih != y.Ih || x.It != y.It || x.R != y.R || x.in != y.in ||
+        x.out != y.out || x.l_xs != y.l_xs || x.l_ghf != y.l_ghf || x.l_tab != y.l_tab || x.l_c1 != y.l_c1 || x.l_dc1 != y.l_dc1)
+      return false;      // (everything else of a C2Mat follows from these through c2_mat_from)
+  }
   return true;
 }
 

@@ -116,65 +116,71 @@ __device__ float c2_block_max(float v, float* red) {
   return r;
 }
 
+// Workgroup 0 of a matrix writes the header; workgroup 1 + t builds fragment tile t (tail tiles first), taking the maximum it
+// needs over the merged core itself (a single workgroup doing everything was a chain of sixteen dependent load -> split -> store
+// rounds: 28 us).  blockIdx.y = matrix.
 __global__ void __launch_bounds__(256) k_c2_prep(C2PrepArgs args) {
   __shared__ float red[256];
-  const C2Prep& a = args.p[blockIdx.x];
+  const C2Prep& a = args.p[blockIdx.y];
   const C2Mat& m = a.m;
   const int tid = threadIdx.x;
-  float mx = 0.f, md = 0.f, mgt = 0.f, mgh = 0.f, l1t = 0.f, l1h = 0.f;
-  for (int i = tid; i < a.x_n; i += 256) mx = fmaxf(mx, __uint_as_float(a.x_cmax[i]));
-  for (int i = tid; i < a.dy_n; i += 256) md = fmaxf(md, __uint_as_float(a.dy_cmax[i]));
-  for (long i = tid; i < m.tail_elems; i += 256) mgt = fmaxf(mgt, fabsf(a.Gt[i]));
-  for (long i = tid; i < m.head_elems; i += 256) mgh = fmaxf(mgh, fabsf(a.Gh[i]));
-  for (int p = tid; p < m.P; p += 256) {            // row p = (a, i_t) of Gt: sum over j_t
-    const int ra = p / m.It, it = p % m.It;
-    float s = 0.f;
-    for (int jt = 0; jt < m.Jt; ++jt) s += fabsf(a.Gt[((long)it * m.Jt + jt) * m.R + ra]);
-    l1t = fmaxf(l1t, s);
+  const int ntt = m.PT * m.KA, nth = m.QT * m.KB;
+  if ((int)blockIdx.x > ntt + nth) return;
+  if (blockIdx.x == 0) {
+    float mx = 0.f, md = 0.f, mgt = 0.f, mgh = 0.f, l1t = 0.f, l1h = 0.f;
+    for (int i = tid; i < a.x_n; i += 256) mx = fmaxf(mx, __uint_as_float(a.x_cmax[i]));
+    for (int i = tid; i < a.dy_n; i += 256) md = fmaxf(md, __uint_as_float(a.dy_cmax[i]));
+    for (long i = tid; i < m.tail_elems; i += 256) mgt = fmaxf(mgt, fabsf(a.Gt[i]));
+    for (long i = tid; i < m.head_elems; i += 256) mgh = fmaxf(mgh, fabsf(a.Gh[i]));
+    for (int p = tid; p < m.P; p += 256) {            // row p = (a, i_t) of Gt: sum over j_t
+      const int ra = p / m.It, it = p % m.It;
+      float s = 0.f;
+      for (int jt = 0; jt < m.Jt; ++jt) s += fabsf(a.Gt[((long)it * m.Jt + jt) * m.R + ra]);
+      l1t = fmaxf(l1t, s);
+    }
+    for (int q = tid; q < m.Jh * m.R; q += 256) {      // row (j_h, a) of Gh^T: sum over i_h
+      const int jh = q / m.R, ra = q % m.R;
+      float s = 0.f;
+      for (int ih = 0; ih < m.Ih; ++ih) s += fabsf(a.Gh[((long)ih * m.Jh + jh) * m.R + ra]);
+      l1h = fmaxf(l1h, s);
+    }
+    mx = c2_block_max(mx, red); md = c2_block_max(md, red);
+    mgt = c2_block_max(mgt, red); mgh = c2_block_max(mgh, red);
+    l1t = c2_block_max(l1t, red); l1h = c2_block_max(l1h, red);
+    if (tid == 0) {
+      a.hdr[0] = c2_expo(mx); a.hdr[1] = c2_expo(md); a.hdr[2] = c2_expo(mgt); a.hdr[3] = c2_expo(mgh);
+      a.hdr[4] = c2_expo(l1t * mx); a.hdr[5] = c2_expo(l1h * md);
+    }
+    return;
   }
-  for (int q = tid; q < m.Jh * m.R; q += 256) {      // row (j_h, a) of Gh^T: sum over i_h
-    const int jh = q / m.R, ra = q % m.R;
-    float s = 0.f;
-    for (int ih = 0; ih < m.Ih; ++ih) s += fabsf(a.Gh[((long)ih * m.Jh + jh) * m.R + ra]);
-    l1h = fmaxf(l1h, s);
-  }
-  mx = c2_block_max(mx, red); md = c2_block_max(md, red);
-  mgt = c2_block_max(mgt, red); mgh = c2_block_max(mgh, red);
-  l1t = c2_block_max(l1t, red); l1h = c2_block_max(l1h, red);
-  const int ex = c2_expo(mx), ed = c2_expo(md), egt = c2_expo(mgt), egh = c2_expo(mgh);
-  const int ec1 = c2_expo(l1t * mx), edc = c2_expo(l1h * md);
-  if (tid == 0) {
-    a.hdr[0] = ex; a.hdr[1] = ed; a.hdr[2] = egt; a.hdr[3] = egh; a.hdr[4] = ec1; a.hdr[5] = edc;
-  }
-  const float sgt = ldexpf(1.f, 14 - egt), sgh = ldexpf(1.f, 14 - egh);
-  const long ngt = (long)m.PT * m.KA * 64 * 8;
-  const long pl_t = ngt, pl_h = (long)m.QT * m.KB * 64 * 8;
-  for (long e = tid; e < ngt; e += 256) {
-    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
-    const long tile = e >> 9;
-    const int kb = (int)(tile % m.KA), pt = (int)(tile / m.KA);
-    const int p = 16 * pt + (lane & 15), jt = 32 * kb + 8 * (lane >> 4) + j;
+  const int tile = (int)blockIdx.x - 1;
+  const bool tail = tile < ntt;
+  float mg = 0.f;
+  if (tail) for (long i = tid; i < m.tail_elems; i += 256) mg = fmaxf(mg, fabsf(a.Gt[i]));
+  else for (long i = tid; i < m.head_elems; i += 256) mg = fmaxf(mg, fabsf(a.Gh[i]));
+  mg = c2_block_max(mg, red);
+  const float sg = ldexpf(1.f, 14 - c2_expo(mg));
+  for (int e = tid; e < 512; e += 256) {
+    const int j = e & 7, lane = e >> 3;
     float v = 0.f;
-    if (p < m.P && jt < m.Jt) v = a.Gt[((long)(p % m.It) * m.Jt + jt) * m.R + p / m.It] * sgt;
+    _Float16* dst;
+    if (tail) {
+      const int kb = tile % m.KA, pt = tile / m.KA;
+      const int p = 16 * pt + (lane & 15), jt = 32 * kb + 8 * (lane >> 4) + j;
+      if (p < m.P && jt < m.Jt) v = a.Gt[((long)(p % m.It) * m.Jt + jt) * m.R + p / m.It] * sg;
+      dst = a.gtf + (size_t)tile * 1024;                 // [(tile*2 + plane)][lane][8]
+    } else {
+      const int th = tile - ntt;
+      const int kb = th % m.KB, qt = th / m.KB;
+      const int q = 16 * qt + (lane & 15), ih = 32 * kb + 8 * (lane >> 4) + j;
+      const int ra = q / m.JhP, jh = q % m.JhP;
+      if (q < m.Q && jh < m.Jh && ih < m.Ih) v = a.Gh[((long)ih * m.Jh + jh) * m.R + ra] * sg;
+      dst = a.ghf + (size_t)th * 1024;
+    }
     _Float16 p0, p1;
     split2h(v, p0, p1);
-    // [(tile*2 + plane)][lane][8]
-    a.gtf[(tile * 2 + 0) * 512 + lane * 8 + j] = p0;
-    a.gtf[(tile * 2 + 1) * 512 + lane * 8 + j] = p1;
-  }
-  (void)pl_t;
-  for (long e = tid; e < pl_h; e += 256) {
-    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
-    const long tile = e >> 9;
-    const int kb = (int)(tile % m.KB), qt = (int)(tile / m.KB);
-    const int q = 16 * qt + (lane & 15), ih = 32 * kb + 8 * (lane >> 4) + j;
-    const int ra = q / m.JhP, jh = q % m.JhP;
-    float v = 0.f;
-    if (q < m.Q && jh < m.Jh && ih < m.Ih) v = a.Gh[((long)ih * m.Jh + jh) * m.R + ra] * sgh;
-    _Float16 p0, p1;
-    split2h(v, p0, p1);
-    a.ghf[(tile * 2 + 0) * 512 + lane * 8 + j] = p0;
-    a.ghf[(tile * 2 + 1) * 512 + lane * 8 + j] = p1;
+    dst[lane * 8 + j] = p0;
+    dst[512 + lane * 8 + j] = p1;
   }
 }
 
@@ -194,6 +200,9 @@ struct C2Args {
   const float* dy;           // [n_rows][OUT]
   float* bpart;              // [grid][OUT] or NULL
   long n_rows;
+  unsigned long long* diag;  // -DTTRNN_ABLATIONS builds only: [2 waves][8] cycle sums per segment of the block loop (workgroup 0, waves 0 and 5)
+  int abl;                   // -DTTRNN_ABLATIONS builds only (tools/c2w_bench.py): option dev2 >> 8 — 1: no phases A / B, 2: no phases C / D,
+                             // 4: no staging stores, 8: no global loads (result-destroying; 0 in libttrnn.so)
 };
 
 __device__ __forceinline__ xh8 c2_ld8(const _Float16* p) { return *reinterpret_cast<const xh8*>(p); }
@@ -223,29 +232,32 @@ __device__ __forceinline__ void c2_store4(_Float16* p0, _Float16* p1, f32x4 v) {
   *reinterpret_cast<u32x2*>(p1) = u32x2{b0, b1};
 }
 
-template <int NMAT, int NACC, int WA, int KAM, int EQ>
-__global__ void __launch_bounds__(C2_NT) k_c2w(C2Args g) {
+// Kernel variants: NW waves per workgroup; NACC accumulator units per wave and matrix; WA x KAM register slots of tail
+// fragments; EQ / XQ staged quads of dy / x per thread and block.
+// SPEC != 0: the plan is a compile-time constant (ttrnn_c2w.h: c2_const_plan — the speaker encoder's shapes): every tile count,
+// stride and LDS offset below is a literal, the loops unroll and no plan field sits in an SGPR (the run-time plan's ~150 fields
+// spilled 90 SGPRs into VGPR lanes: a v_readlane in front of every use).  SPEC == 0: any plan, at run time.
+template <int SPEC, int NMAT, int NW, int NACC, int WA, int KAM, int EQ, int XQ>
+__global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char c2_smem[];
-  const C2Plan& pl = g.pl;
+  constexpr C2Plan kpl = c2_const_plan<SPEC ? SPEC : 2>();
+  static_assert(kpl.ok == 1 && (SPEC == 0 || kpl.nmat == NMAT), "compile-time plan");
+  const C2Plan& pl = SPEC ? kpl : g.pl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < NW);
   const int c = lane & 15, gq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const int nb = pl.nb, OUT = pl.OUT, DS = pl.DS;
   const long nblk = (g.n_rows + nb - 1) / nb;
 
   // ---- LDS: zero everything once (padding rows / columns are never written afterwards: they stay finite zeros) ----
-  for (int i = tid; i < pl.lds / 16; i += C2_NT) reinterpret_cast<f32x4*>(c2_smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < pl.lds / 16; i += NT) reinterpret_cast<f32x4*>(c2_smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   _Float16* dYs = reinterpret_cast<_Float16*>(c2_smem + pl.l_dy);
   const int dpl = pl.dy_rows * DS;                              // plane size (halves)
-  _Float16* C1s = reinterpret_cast<_Float16*>(c2_smem + pl.l_c1);
-  _Float16* dC1s = reinterpret_cast<_Float16*>(c2_smem + pl.l_dc1);
 
-  // ---- tables + per-thread constants -------------------------------------------------------------------------------
-  const int* tA[NMAT]; const int* tBm[NMAT]; const int* tBd[NMAT]; const int* tBs[NMAT];
-  const int* tCa[NMAT]; const int* tCb[NMAT]; const int* tDa[NMAT];
-  _Float16* Xs[NMAT]; const _Float16* GhF[NMAT];
-  int xpl[NMAT];
+  // ---- tables (store offsets: looked up AFTER the MFMAs, off the critical loads) + per-thread constants -----------------
   xh8 gta[NMAT][WA][KAM][2];
   int moffA[NMAT][WA];
   int uA[NMAT][NACC], uB[NMAT][NACC];
@@ -257,47 +269,31 @@ __global__ void __launch_bounds__(C2_NT) k_c2w(C2Args g) {
   for (int mi = 0; mi < NMAT; ++mi) {
     const C2Mat& m = pl.m[mi];
     int* tab = reinterpret_cast<int*>(c2_smem + m.l_tab);
-    int* a_ = tab;                   // [NA*16]
-    int* bm = a_ + m.NA * 16;        // [QT*4]
-    int* bd = bm + m.QT * 4;         // [NB]   dy image offset of the column tile
-    int* bs = bd + m.NB;             // [NB]   dC1 image offset of the column tile
-    int* ca = bs + m.NB;             // [KC*4]
-    int* cb = ca + m.KC * 4;         // [KC*4]
-    int* da = cb + m.KC * 4;         // [KD*4]
-    for (int n = tid; n < m.NA * 16; n += C2_NT) a_[n] = n < nb * m.JhP ? ((n / m.JhP) * m.QR + (n % m.JhP)) * m.CS1 : -1;
-    for (int e = tid; e < m.QT * 4; e += C2_NT) {
+    int* a_ = tab;                   // [NA*16]  C1 image offset of column n of phase A (-1: past the block's rows)
+    int* bm = a_ + m.NA * 16;        // [QT*4]   dC1 image offset of the four rows m0 .. m0+3 of phase B (-1: padding)
+    int* bd = bm + m.QT * 4;         // [NB]     dy image offset of the column tile
+    int* bs = bd + m.NB;             // [NB]     dC1 image offset of the column tile
+    for (int n = tid; n < m.NA * 16; n += NT) a_[n] = n < nb * m.JhP ? ((n / m.JhP) * m.QR + (n % m.JhP)) * m.CS1 : -1;
+    for (int e = tid; e < m.QT * 4; e += NT) {
       const int m0 = 16 * (e >> 2) + 4 * (e & 3);
       bm[e] = m0 < m.Q ? (m0 / m.JhP) * m.It * m.CS2 + (m0 % m.JhP) : -1;
     }
-    for (int e = tid; e < m.NB; e += C2_NT) {
+    for (int e = tid; e < m.NB; e += NT) {
       const int n0 = 16 * e, rs = n0 / m.It, it0 = n0 % m.It;
       bd[e] = rs * pl.Ih * DS + it0;
       bs[e] = (rs * m.PR + it0) * m.CS2;
     }
-    for (int e = tid; e < m.KC * 4; e += C2_NT) {
-      const int k0 = 32 * (e >> 2) + 8 * (e & 3), rs = k0 / m.It, i0 = k0 % m.It;
-      ca[e] = rs * pl.Ih * DS + i0;
-      cb[e] = rs * m.QR * m.CS1 + i0;
-    }
-    for (int e = tid; e < m.KD * 4; e += C2_NT) {
-      const int k0 = 32 * (e >> 2) + 8 * (e & 3);
-      da[e] = k0 < nb * m.JhP ? (k0 / m.JhP) * m.PR * m.CS2 + (k0 % m.JhP) : 0;
-    }
-    tA[mi] = a_; tBm[mi] = bm; tBd[mi] = bd; tBs[mi] = bs; tCa[mi] = ca; tCb[mi] = cb; tDa[mi] = da;
-    Xs[mi] = reinterpret_cast<_Float16*>(c2_smem + m.l_xs);
-    xpl[mi] = m.xs_rows * m.XS;
     // head fragments -> LDS (fragment order: linear copy)
     {
       _Float16* dst = reinterpret_cast<_Float16*>(c2_smem + m.l_ghf);
       const int n16 = m.QT * m.KB * 2 * 64;      // 16-byte units
-      for (int i = tid; i < n16; i += C2_NT)
+      for (int i = tid; i < n16; i += NT)
         reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(g.a[mi].ghf)[i];
-      GhF[mi] = dst;
     }
-    // tail fragments -> registers (tile pt = wave + 8 wa)
+    // tail fragments -> registers (tile pt = wave % PT + PT wa; the wave groups w / PT share the column tiles)
 #pragma unroll
     for (int wa = 0; wa < WA; ++wa) {
-      const int pt = wave + C2_NW * wa;
+      const int pt = m.PT < NW ? (wave < m.PT * m.NAG ? wave % m.PT : m.PT) : wave + NW * wa;
       const int m0 = 16 * pt + 4 * gq;
       moffA[mi][wa] = (pt < m.PT && m0 < m.P) ? (m0 / m.It) * m.JhP * m.CS1 + (m0 % m.It) : -1;
 #pragma unroll
@@ -306,21 +302,24 @@ __global__ void __launch_bounds__(C2_NT) k_c2w(C2Args g) {
         for (int p = 0; p < 2; ++p) {
           xh8 v = {};
           if (pt < m.PT && kb < m.KA) v = *reinterpret_cast<const xh8*>(g.a[mi].gtf + ((size_t)((pt * m.KA + kb) * 2 + p) * 64 + lane) * 8);
-          gta[mi][wa][kb][p] = v;
+          asm volatile("" : "+v"(v));      // pinned: under register pressure the compiler re-loaded these loop invariants from
+          gta[mi][wa][kb][p] = v;          // global memory INSIDE the block loop (and every use then waited for all loads in flight)
         }
     }
-    // accumulator units u = wave + 8 i: C tiles (mt, qt) first, then D tiles (pt, jt)
+    // accumulator slots: i < SC = ceil(nC / NW): C tile u = wave + NW i (tiles (mt, qt)); then D tile v = wave + NW (i - SC) (tiles
+    // (pt, jt)) — a slot's KIND is the same in every wave (a literal under a compile-time plan), only its validity is per wave
+    const int SC = c2_ceil(m.nC, NW);
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      const int u = wave + C2_NW * i;
       acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < m.nC) {
-        uA[mi][i] = (16 * (u / m.QT) + c) * DS;                 // dy image row of i_h = 16 mt + c
-        uB[mi][i] = (16 * (u % m.QT) + c) * m.CS1;              // C1 image row of q = 16 qt + c
+      if (i < SC) {
+        const int u = wave + NW * i;
+        uA[mi][i] = u < m.nC ? (16 * (u / m.QT) + c) * DS + 8 * gq : -1;                  // dy image: row i_h = 16 mt + c, chunk gq of a k-block
+        uB[mi][i] = (16 * (u % m.QT) + c) * m.CS1 + 8 * gq;                              // C1 image: row q = 16 qt + c
       } else {
-        const int v = u - m.nC;
-        uA[mi][i] = (16 * (v / m.JtT) + c) * m.CS2;             // dC1 image row of p = 16 pt + c
-        uB[mi][i] = qq * m.XS + 16 * (v % m.JtT) + 4 * pp;      // transposed read of the x image: (row qq, columns 4 pp ..)
+        const int v = wave + NW * (i - SC);
+        uA[mi][i] = v < m.nD ? (16 * (v / m.JtT) + c) * m.CS2 : -1;                       // dC1 image: row p = 16 pt + c
+        uB[mi][i] = (8 * gq + qq) * m.XS + 16 * (v % m.JtT) + 4 * pp;                    // transposed read of the x image: (row 8 gq + qq, columns 4 pp ..)
       }
     }
     const int* h = g.a[mi].hdr;
@@ -329,184 +328,357 @@ __global__ void __launch_bounds__(C2_NT) k_c2w(C2Args g) {
     eA[mi] = h[2] + h[0] - h[4] - 14;
     eB[mi] = h[3] + h[1] - h[5] - 14;
   }
+  __syncthreads();
 
-  // ---- staging plan: dy quads id = tid + 512 e < nb*OUT/4; x quads id < nb*in/4 ---------------------------------------
+  // ---- staging plan: dy quads id = tid + NT e < nb*OUT/4; x quads id < nb*in/4 ---------------------------------------
   const int oq = OUT / 4;
-  int dyo[EQ], dyg[EQ], dyr[EQ];
+  int dyo[EQ], dyg[EQ], dyr[EQ];         // LDS offset / offset from the block's first row (-1: no such quad) / row of the block
   f32x4 sd[EQ], dbs[EQ];
 #pragma unroll
   for (int e = 0; e < EQ; ++e) {
-    const int id = tid + C2_NT * e;
+    const int id = tid + NT * e;
     const bool on = id < nb * oq;
     const int row = on ? id / oq : 0, o = on ? 4 * (id % oq) : 0;
-    dyr[e] = on ? row : -1;
-    dyg[e] = row * OUT + o;
+    dyg[e] = on ? row * OUT + o : -1;
+    dyr[e] = row;
     dyo[e] = (row * pl.Ih + o / pl.It) * DS + (o % pl.It);
     dbs[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     sd[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  int xo[NMAT][2], xcol[NMAT][2], xr[NMAT][2];
-  f32x4 sx[NMAT][2];
+  // x quads: row of the block, column; (sample, step) of the row carried from block to block (no division in the loop)
+  int xo[NMAT][XQ], xcol[NMAT][XQ], xr[NMAT][XQ];
+  unsigned xb[NMAT][XQ], xt[NMAT][XQ];
+  f32x4 sx[NMAT][XQ];
+  // a workgroup walks a CONTIGUOUS range of blocks: consecutive blocks share a page (24 KB of dy per block at the speaker
+  // encoder's size: a stride of gridDim.x blocks = 6 MB put every load of every block on a page of its own — a TLB miss per issue
+  // point, ~2 000 cycles each in the stamps)
+  const long per = (nblk + gridDim.x - 1) / gridDim.x;
+  const long blk0 = (long)blockIdx.x * per, blk1 = blk0 + per < nblk ? blk0 + per : nblk;
+  const unsigned step = (unsigned)nb;
 #pragma unroll
   for (int mi = 0; mi < NMAT; ++mi) {
     const C2Mat& m = pl.m[mi];
     const int iq = m.in / 4;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int id = tid + C2_NT * e;
-      const bool on = e < m.EX && id < nb * iq;
+    for (int e = 0; e < XQ; ++e) {
+      const int id = tid + NT * e;
+      const bool on = id < nb * iq;
       const int row = on ? id / iq : 0, col = on ? 4 * (id % iq) : 0;
       xr[mi][e] = on ? row : -1;
       xcol[mi][e] = col;
       xo[mi][e] = (row * m.JhP + col / m.Jt) * m.XS + (col % m.Jt);
       sx[mi][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned n = (unsigned)blk0 * (unsigned)nb + (unsigned)row;
+      const unsigned T = g.a[mi].T > 0 ? (unsigned)g.a[mi].T : 1u;
+      xb[mi][e] = n / T;
+      xt[mi][e] = n - xb[mi][e] * T;
     }
+  }
+  unsigned stq[NMAT], str[NMAT];          // step = stq T + str
+#pragma unroll
+  for (int mi = 0; mi < NMAT; ++mi) {
+    const unsigned T = g.a[mi].T > 0 ? (unsigned)g.a[mi].T : 1u;
+    stq[mi] = step / T;
+    str[mi] = step - stq[mi] * T;
   }
   const bool want_bias = g.bpart != nullptr;
 
-  auto load_block = [&](long blk) {
+  // loads of block `blk` (the rows' (sample, step) are in xb / xt); advances them to the block after
+  // The loads of a block are ISSUED at `NPT` points spread over the previous block's phases (point = the quads e with
+  // e % NPT == point; x rides with point 1): issued in one burst by every CU at once they fill the memory pipeline's queues and
+  // the issuing waves stall for the burst's whole transfer time (stamps: 5 000 of 17 000 cycles per block).
+  constexpr int NPT = 4;
+  // Every load is UNCONDITIONAL (clamped to a valid address; what must not count is zeroed by the `keep` factor at the store):
+  // behind an exec-masked branch or a zero-initialised select the compiler's wait-count pass put s_waitcnt vmcnt(0) in front of
+  // every load of the loop, so the five loads of a block went out one memory round trip after the other — 5 000 of a block's
+  // 17 000 cycles in the stamps.
+  float dk[EQ], xk[NMAT][XQ];
+#pragma unroll
+  for (int e = 0; e < EQ; ++e) dk[e] = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < NMAT; ++mi)
+#pragma unroll
+    for (int e = 0; e < XQ; ++e) xk[mi][e] = 0.f;
+  // (also no `if (more)` around the loop's loads and stores: two ifs on one condition are two unrelated paths to the wait-count
+  // pass — "issued but never consumed" put vmcnt(0) in front of every address computation; the iteration of a range's last block
+  // re-reads that block with keep = 0 instead)
+  auto load_block = [&](long blk, int point, bool live = true) {
     const long n0 = blk * nb;
+    const long last = live ? g.n_rows - 1 : -1;      // (not live: every row counts as past the end)
+    const long lastv = g.n_rows - 1;
 #pragma unroll
     for (int e = 0; e < EQ; ++e)
-      if (dyr[e] >= 0) {
-        const long n = n0 + dyr[e];
-        sd[e] = n < g.n_rows ? *reinterpret_cast<const f32x4*>(g.dy + (size_t)n0 * OUT + dyg[e]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (point < 0 || e % NPT == point) {
+        const int off = dyg[e] >= 0 ? dyg[e] : 0, row = dyg[e] >= 0 ? dyr[e] : 0;
+        const bool in = n0 + row <= last;
+        sd[e] = *reinterpret_cast<const f32x4*>(g.dy + (size_t)(in ? n0 : lastv) * OUT + (in ? off : off - row * OUT));
+        dk[e] = (in && dyg[e] >= 0) ? 1.f : 0.f;
       }
+    if (point >= 0 && point != 1) return;
 #pragma unroll
     for (int mi = 0; mi < NMAT; ++mi) {
       const C2Mat& m = pl.m[mi];
       const C2MatArgs& a = g.a[mi];
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        if (xr[mi][e] >= 0) {
-          const long n = n0 + xr[mi][e];
-          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (n < g.n_rows) {
-            if (a.T > 0) {
-              const long b = n / a.T;
-              const bool head = n == b * a.T;
-              if (!head) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(n - 1) * m.in + xcol[mi][e]);
-              else if (a.first) v = *reinterpret_cast<const f32x4*>(a.first + (size_t)b * m.in + xcol[mi][e]);
-            } else {
-              v = *reinterpret_cast<const f32x4*>(a.x + (size_t)n * m.in + xcol[mi][e]);
-            }
-          }
-          sx[mi][e] = v;
+      for (int e = 0; e < XQ; ++e) {
+        const int row = xr[mi][e] >= 0 ? xr[mi][e] : 0;
+        const long n = n0 + row;
+        const bool in = n <= last && xr[mi][e] >= 0;
+        const long nn = n <= lastv ? n : lastv;
+        const float* src;
+        bool zero = !in;
+        if (a.T > 0) {
+          const bool head = xt[mi][e] == 0;
+          // row n - 1 of the outputs; a head row takes its sample's initial state, or (none given) any valid row and is zeroed
+          // (the sample index is clamped: the re-read of a range's last block carries (sample, step) one block further)
+          const unsigned bmax = (unsigned)(g.n_rows / a.T) - 1u;
+          const unsigned bb = xb[mi][e] < bmax ? xb[mi][e] : bmax;
+          // (and the row never goes below 0: in that re-read the carried step no longer belongs to row n)
+          src = (head && a.first) ? a.first + (size_t)bb * m.in : a.x + (size_t)((head || nn == 0) ? nn : nn - 1) * m.in;
+          zero = zero || (head && !a.first);
+          unsigned t2 = xt[mi][e] + str[mi];
+          const bool wrap = t2 >= (unsigned)a.T;
+          xt[mi][e] = wrap ? t2 - (unsigned)a.T : t2;
+          xb[mi][e] += stq[mi] + (wrap ? 1u : 0u);
+        } else {
+          src = a.x + (size_t)nn * m.in;
         }
+        sx[mi][e] = *reinterpret_cast<const f32x4*>(src + xcol[mi][e]);
+        xk[mi][e] = zero ? 0.f : 1.f;
+      }
     }
   };
   auto store_block = [&]() {
 #pragma unroll
-    for (int e = 0; e < EQ; ++e)
-      if (dyr[e] >= 0) {
-        c2_store4(dYs + dyo[e], dYs + dpl + dyo[e], sd[e] * sdf);
-        dbs[e] += sd[e];
-      }
+    for (int e = 0; e < EQ; ++e) {
+      const f32x4 v = sd[e] * dk[e];
+      if (dyg[e] >= 0) c2_store4(dYs + dyo[e], dYs + dpl + dyo[e], v * sdf);
+      dbs[e] += v;
+    }
 #pragma unroll
-    for (int mi = 0; mi < NMAT; ++mi)
+    for (int mi = 0; mi < NMAT; ++mi) {
+      _Float16* X0 = reinterpret_cast<_Float16*>(c2_smem + pl.m[mi].l_xs);
+      const int xpl = pl.m[mi].xs_rows * pl.m[mi].XS;
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        if (xr[mi][e] >= 0) c2_store4(Xs[mi] + xo[mi][e], Xs[mi] + xpl[mi] + xo[mi][e], sx[mi][e] * sxf[mi]);
+      for (int e = 0; e < XQ; ++e)
+        if (xr[mi][e] >= 0) c2_store4(X0 + xo[mi][e], X0 + xpl + xo[mi][e], sx[mi][e] * (sxf[mi] * xk[mi][e]));
+    }
   };
 
-  if ((long)blockIdx.x < nblk) load_block(blockIdx.x);
-  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+#ifdef TTRNN_ABLATIONS
+  const int abl = g.abl;
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = stamp();
+#define C2_STAMP(i) { const unsigned long long now_ = stamp(); seg[i] += now_ - last_; last_ = now_; }
+#else
+  constexpr int abl = 0;
+#define C2_STAMP(i)
+#endif
+  // The loop body ISSUES the next block's loads at its phase points and CONSUMES them (split + LDS stores) at its own end, once
+  // the images are free: no load is pending across the back edge, so the wait counts the compiler inserts are exact (with the
+  // consuming stores at the top of the next iteration it put s_waitcnt vmcnt(0) in front of register uses all over the body).
+  if (blk0 < blk1) {
+    load_block(blk0, -1);
     store_block();
-    if (blk + gridDim.x < nblk) load_block(blk + gridDim.x);
-    __syncthreads();
+  }
+  lds_barrier();
+  for (long blk = blk0; blk < blk1; ++blk) {
+    C2_STAMP(7)
+    const bool more = blk + 1 < blk1;
+    const long nxt = more ? blk + 1 : blk;
+    if (!(abl & 8)) load_block(nxt, 0, more);
+    C2_STAMP(1)
+    // both matrices run their row-local phases A, B between the same two barriers, then their gradient phases C, D: half the
+    // barriers of matrix-after-matrix, and the small input matrix fills the waves the hidden one leaves idle
 #pragma unroll
     for (int mi = 0; mi < NMAT; ++mi) {
       const C2Mat& m = pl.m[mi];
-      const _Float16* X0 = Xs[mi];
-      const _Float16* X1 = Xs[mi] + xpl[mi];
-      const int c1p = pl.c1_plane, dcp = pl.dc1_plane;
-      // ---- phase A: C1[p][(row, j_h)] = Gt[p][j_t] x[(row, j_h)][j_t]  ->  C1 image [row][q][i_t] ----
+      const int* tab = reinterpret_cast<const int*>(c2_smem + m.l_tab);
+      const int* tA = tab; const int* tBm = tA + m.NA * 16; const int* tBd = tBm + m.QT * 4; const int* tBs = tBd + m.NB;
+      const _Float16* X0 = reinterpret_cast<const _Float16*>(c2_smem + m.l_xs);
+      const _Float16* X1 = X0 + m.xs_rows * m.XS;
+      const _Float16* GhF = reinterpret_cast<const _Float16*>(c2_smem + m.l_ghf);
+      _Float16* C1s = reinterpret_cast<_Float16*>(c2_smem + m.l_c1);
+      _Float16* dC1s = reinterpret_cast<_Float16*>(c2_smem + m.l_dc1);
+      const int c1p = m.c1_plane, dcp = m.dc1_plane;
+      if (!(abl & 1)) {
+      // ---- phase A: C1[p][(row, j_h)] = Gt[p][j_t] x[(row, j_h)][j_t]  ->  C1 image [row][q][i_t]; two column tiles at a time ----
 #pragma unroll
       for (int wa = 0; wa < WA; ++wa) {
-        const int pt = wave + C2_NW * wa;
+        const int pt = m.PT < NW ? (wave < m.PT * m.NAG ? wave % m.PT : m.PT) : wave + NW * wa;
         if (pt < m.PT) {
-          for (int na = 0; na < m.NA; ++na) {
-            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int xrow = (16 * na + c) * m.XS + 8 * gq;
+          const int na0 = m.PT < NW ? wave / m.PT : 0;
+          const int nja = c2_ceil(m.NA, 2 * m.NAG);             // (a literal under a compile-time plan: the loop unrolls)
+          for (int ja = 0; ja < nja; ++ja) {
+            const int na = na0 + 2 * m.NAG * ja;
+            if (na >= m.NA) break;
+            const int nb2 = na + m.NAG;
+            const bool has2 = nb2 < m.NA;
+            const int nc = has2 ? nb2 : na;
+            f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            const int x0 = (16 * na + c) * m.XS + 8 * gq, x1 = (16 * nc + c) * m.XS + 8 * gq;
+            xh8 b[2][KAM][2];
+#pragma unroll
+            for (int kb = 0; kb < KAM; ++kb) {
+              const int ko = kb < m.KA ? 32 * kb : 0;
+              b[0][kb][0] = c2_ld8(X0 + x0 + ko); b[0][kb][1] = c2_ld8(X1 + x0 + ko);
+              b[1][kb][0] = c2_ld8(X0 + x1 + ko); b[1][kb][1] = c2_ld8(X1 + x1 + ko);
+            }
 #pragma unroll
             for (int kb = 0; kb < KAM; ++kb)
               if (kb < m.KA) {
-                const xh8 b0 = c2_ld8(X0 + xrow + 32 * kb), b1 = c2_ld8(X1 + xrow + 32 * kb);
-                r = c2_mma3(gta[mi][wa][kb][0], gta[mi][wa][kb][1], b0, b1, r);
+                r0 = c2_mma3(gta[mi][wa][kb][0], gta[mi][wa][kb][1], b[0][kb][0], b[0][kb][1], r0);
+                r1 = c2_mma3(gta[mi][wa][kb][0], gta[mi][wa][kb][1], b[1][kb][0], b[1][kb][1], r1);
               }
-            const int off = tA[mi][16 * na + c];
-            if (off >= 0 && moffA[mi][wa] >= 0) {
-              f32x4 v;
+            // (no padding columns / rows under the compile-time plans: the guards fold away and the offsets are arithmetic)
+            const bool afull = SPEC != 0 && m.NA * 16 == nb * m.JhP && m.P == m.PT * 16 && m.PT % NW == 0;
+            const int n0a = 16 * na + c, n1a = 16 * nc + c;
+            const int off0 = afull ? ((n0a / m.JhP) * m.QR + (n0a % m.JhP)) * m.CS1 : tA[n0a];
+            const int off1 = !has2 ? -1 : afull ? ((n1a / m.JhP) * m.QR + (n1a % m.JhP)) * m.CS1 : tA[n1a];
+            if (afull || moffA[mi][wa] >= 0) {
+              if (afull || off0 >= 0) {
+                f32x4 v;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = ldexpf(r[j], eA[mi]);
-              c2_store4(C1s + off + moffA[mi][wa], C1s + c1p + off + moffA[mi][wa], v);
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(r0[j], eA[mi]);
+                c2_store4(C1s + off0 + moffA[mi][wa], C1s + c1p + off0 + moffA[mi][wa], v);
+              }
+              if (off1 >= 0) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(r1[j], eA[mi]);
+                c2_store4(C1s + off1 + moffA[mi][wa], C1s + c1p + off1 + moffA[mi][wa], v);
+              }
             }
           }
         }
       }
-      // ---- phase B: dC1[q][(row, i_t)] = Gh^T[q][i_h] dy[row][i_h][i_t]  ->  dC1 image [row][p][j_h] ----
-      for (int u = wave; u < m.QT * m.NB; u += C2_NW) {
-        const int qt = u / m.NB, nt = u % m.NB;
-        f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int dbase = tBd[mi][nt] + (8 * gq + qq) * DS + 4 * pp;
-        for (int kb = 0; kb < m.KB; ++kb) {
-          const _Float16* af = GhF[mi] + ((size_t)((qt * m.KB + kb) * 2) * 64 + lane) * 8;
-          const xh8 a0 = c2_ld8(af), a1 = c2_ld8(af + 512);
-          const xh8 b0 = c2_tr8(dYs + dbase + 32 * kb * DS, DS), b1 = c2_tr8(dYs + dpl + dbase + 32 * kb * DS, DS);
-          r = c2_mma3(a0, a1, b0, b1, r);
-        }
-        const int mo = tBm[mi][qt * 4 + gq];
-        if (mo >= 0) {
-          f32x4 v;
+      if (mi == 0 && !(abl & 8)) load_block(nxt, 1, more);
+      C2_STAMP(2)
+      // ---- phase B: dC1[q][(row, i_t)] = Gh^T[q][i_h] dy[row][i_h][i_t]  ->  dC1 image [row][p][j_h]; two k-blocks in flight ----
+      {
+        const int nub = c2_ceil(m.QT * m.NB, NW);       // units u = qt NB + nt = wave, wave + NW, ... (a literal trip count under a compile-time plan)
+        for (int ib = 0; ib < nub; ++ib) {
+          const int u = wave + NW * ib;
+          if (u >= m.QT * m.NB) break;
+          const int qt = u / m.NB, nt = u - qt * m.NB;
+          f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+          const bool bfull = SPEC != 0 && m.Q == m.QT * 16;
+          const int n0b = 16 * nt, m0b = 16 * qt + 4 * gq;
+          const int dbase = (bfull ? (n0b / m.It) * pl.Ih * DS + n0b % m.It : tBd[nt]) + (8 * gq + qq) * DS + 4 * pp;
+          const int mo = bfull ? (m0b / m.JhP) * m.It * m.CS2 + m0b % m.JhP : tBm[qt * 4 + gq];
+          const int so = (bfull ? ((n0b / m.It) * m.PR + n0b % m.It) * m.CS2 : tBs[nt]) + c * m.CS2;
+          for (int kb = 0; kb < m.KB; kb += 2) {
+            const bool has2 = kb + 1 < m.KB;
+            const int k1 = has2 ? kb + 1 : kb;
+            const _Float16* af0 = GhF + ((size_t)((qt * m.KB + kb) * 2) * 64 + lane) * 8;
+            const _Float16* af1 = GhF + ((size_t)((qt * m.KB + k1) * 2) * 64 + lane) * 8;
+            const xh8 a00 = c2_ld8(af0), a01 = c2_ld8(af0 + 512), a10 = c2_ld8(af1), a11 = c2_ld8(af1 + 512);
+            const xh8 b00 = c2_tr8(dYs + dbase + 32 * kb * DS, DS), b01 = c2_tr8(dYs + dpl + dbase + 32 * kb * DS, DS);
+            const xh8 b10 = c2_tr8(dYs + dbase + 32 * k1 * DS, DS), b11 = c2_tr8(dYs + dpl + dbase + 32 * k1 * DS, DS);
+            r = c2_mma3(a00, a01, b00, b01, r);
+            if (has2) r = c2_mma3(a10, a11, b10, b11, r);
+          }
+          if (bfull || mo >= 0) {
+            f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ldexpf(r[j], eB[mi]);
-          const int off = tBs[mi][nt] + c * m.CS2 + mo;
-          c2_store4(dC1s + off, dC1s + dcp + off, v);
+            for (int j = 0; j < 4; ++j) v[j] = ldexpf(r[j], eB[mi]);
+            c2_store4(dC1s + so + mo, dC1s + dcp + so + mo, v);
+          }
         }
       }
-      __syncthreads();
-      // ---- phases C, D: the accumulator units of this wave ----
+      }
+      C2_STAMP(3)
+    }
+    if (!(abl & 8)) load_block(nxt, 2, more);
+    lds_barrier();
+    C2_STAMP(4)
+#pragma unroll
+    for (int mi = 0; mi < NMAT; ++mi) {
+      const C2Mat& m = pl.m[mi];
+      const _Float16* X0 = reinterpret_cast<const _Float16*>(c2_smem + m.l_xs);
+      const _Float16* X1 = X0 + m.xs_rows * m.XS;
+      const _Float16* C1s = reinterpret_cast<const _Float16*>(c2_smem + m.l_c1);
+      const _Float16* dC1s = reinterpret_cast<const _Float16*>(c2_smem + m.l_dc1);
+      const int c1p = m.c1_plane, dcp = m.dc1_plane;
+      if (!(abl & 2)) {
+      // ---- phases C, D: the accumulator units of this wave; two k-blocks in flight ----
+      const int SC = c2_ceil(m.nC, NW);
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
-        const int u = wave + C2_NW * i;
-        if (u < m.nC) {
-          for (int kb = 0; kb < m.KC; ++kb) {
-            const int ka = tCa[mi][kb * 4 + gq], kbo = tCb[mi][kb * 4 + gq];
-            const xh8 a0 = c2_ld8(dYs + uA[mi][i] + ka), a1 = c2_ld8(dYs + dpl + uA[mi][i] + ka);
-            const xh8 b0 = c2_ld8(C1s + uB[mi][i] + kbo), b1 = c2_ld8(C1s + c1p + uB[mi][i] + kbo);
-            acc[mi][i] = c2_mma3(a0, a1, b0, b1, acc[mi][i]);
+        if (i < SC && (m.nC >= NW * (i + 1) || uA[mi][i] >= 0)) {
+          // k = (row, i_t): chunk k0 = 32 kb lies in row k0 / I_t (I_t a multiple of 16: a k-block's four chunks share the row
+          // only when I_t is a multiple of 32 — the row is taken per chunk below)
+          for (int kb = 0; kb < m.KC; kb += 2) {
+            const bool has2 = kb + 1 < m.KC;
+            const int k1 = has2 ? kb + 1 : kb;
+            int ra0 = 0, ra1 = 0;                 // rows of the two chunks 32 kb + 8 gq (compare chains: nb <= 4)
+            const int kk0 = 32 * kb + 8 * gq, kk1 = 32 * k1 + 8 * gq;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) { ra0 += (r < nb && kk0 >= r * m.It) ? 1 : 0; ra1 += (r < nb && kk1 >= r * m.It) ? 1 : 0; }
+            const int oa0 = ra0 * (pl.Ih * DS - m.It) + 32 * kb, oa1 = ra1 * (pl.Ih * DS - m.It) + 32 * k1;
+            const int ob0 = ra0 * (m.QR * m.CS1 - m.It) + 32 * kb, ob1 = ra1 * (m.QR * m.CS1 - m.It) + 32 * k1;
+            const xh8 a00 = c2_ld8(dYs + uA[mi][i] + oa0), a01 = c2_ld8(dYs + dpl + uA[mi][i] + oa0);
+            const xh8 b00 = c2_ld8(C1s + uB[mi][i] + ob0), b01 = c2_ld8(C1s + c1p + uB[mi][i] + ob0);
+            const xh8 a10 = c2_ld8(dYs + uA[mi][i] + oa1), a11 = c2_ld8(dYs + dpl + uA[mi][i] + oa1);
+            const xh8 b10 = c2_ld8(C1s + uB[mi][i] + ob1), b11 = c2_ld8(C1s + c1p + uB[mi][i] + ob1);
+            acc[mi][i] = c2_mma3(a00, a01, b00, b01, acc[mi][i]);
+            if (has2) acc[mi][i] = c2_mma3(a10, a11, b10, b11, acc[mi][i]);
           }
-        } else if (u < m.NU) {
-          for (int kb = 0; kb < m.KD; ++kb) {
-            const int ka = tDa[mi][kb * 4 + gq];
-            const xh8 a0 = c2_ld8(dC1s + uA[mi][i] + ka), a1 = c2_ld8(dC1s + dcp + uA[mi][i] + ka);
-            const int xb = uB[mi][i] + (32 * kb + 8 * gq) * m.XS;
-            const xh8 b0 = c2_tr8(X0 + xb, m.XS), b1 = c2_tr8(X1 + xb, m.XS);
-            acc[mi][i] = c2_mma3(a0, a1, b0, b1, acc[mi][i]);
+        } else if (i >= SC && (m.nD >= NW * (i - SC + 1) || uA[mi][i] >= 0)) {
+          for (int kb = 0; kb < m.KD; kb += 2) {
+            const bool has2 = kb + 1 < m.KD;
+            const int k1 = has2 ? kb + 1 : kb;
+            const int kk0 = 32 * kb + 8 * gq, kk1 = 32 * k1 + 8 * gq;
+            int ra0 = 0, ra1 = 0;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) { ra0 += (r < nb && kk0 >= r * m.JhP) ? 1 : 0; ra1 += (r < nb && kk1 >= r * m.JhP) ? 1 : 0; }
+            // past the block's rows (k >= nb JhP) the x image is zero: any finite dC1 address will do (row 0)
+            const int oa0 = kk0 < nb * m.JhP ? ra0 * (m.PR * m.CS2 - m.JhP) + kk0 : 0;
+            const int oa1 = kk1 < nb * m.JhP ? ra1 * (m.PR * m.CS2 - m.JhP) + kk1 : 0;
+            const xh8 a00 = c2_ld8(dC1s + uA[mi][i] + oa0), a01 = c2_ld8(dC1s + dcp + uA[mi][i] + oa0);
+            const xh8 a10 = c2_ld8(dC1s + uA[mi][i] + oa1), a11 = c2_ld8(dC1s + dcp + uA[mi][i] + oa1);
+            const int xb0 = uB[mi][i] + 32 * kb * m.XS, xb1 = uB[mi][i] + 32 * k1 * m.XS;
+            const xh8 b00 = c2_tr8(X0 + xb0, m.XS), b01 = c2_tr8(X1 + xb0, m.XS);
+            const xh8 b10 = c2_tr8(X0 + xb1, m.XS), b11 = c2_tr8(X1 + xb1, m.XS);
+            acc[mi][i] = c2_mma3(a00, a01, b00, b01, acc[mi][i]);
+            if (has2) acc[mi][i] = c2_mma3(a10, a11, b10, b11, acc[mi][i]);
           }
         }
       }
-      __syncthreads();
+      }
+      C2_STAMP(5)
     }
+    if (!(abl & 8)) load_block(nxt, 3, more);
+    lds_barrier();
+    C2_STAMP(6)
+    if (!(abl & 4)) store_block();      // (everybody is past the last reads of the dy / x images)
+    C2_STAMP(0)
+    lds_barrier();
   }
+#ifdef TTRNN_ABLATIONS
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5) && g.diag)
+    for (int i = 0; i < 8; ++i) g.diag[(wave ? 8 : 0) + i] = seg[i];
+#endif
 
   // ---- partial sums out: [workgroup][unit][lane] f32x4 (fragment order; k_c2_reduce knows the maps) ----
 #pragma unroll
   for (int mi = 0; mi < NMAT; ++mi) {
     const C2Mat& m = pl.m[mi];
+    const int SC = c2_ceil(m.nC, NW);
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      const int u = wave + C2_NW * i;
-      if (u < m.NU) reinterpret_cast<f32x4*>(g.a[mi].part)[((size_t)blockIdx.x * m.NU + u) * 64 + lane] = acc[mi][i];
+      const int u = i < SC ? wave + NW * i : m.nC + wave + NW * (i - SC);      // (unit numbering of k_c2_reduce: C tiles, then D tiles)
+      if (uA[mi][i] >= 0 && i < SC + c2_ceil(m.nD, NW))
+        reinterpret_cast<f32x4*>(g.a[mi].part)[((size_t)blockIdx.x * m.NU + u) * 64 + lane] = acc[mi][i];
     }
   }
   if (want_bias) {          // column sums of dy: the block rows of a column meet in LDS, added in row order
     float* bl = reinterpret_cast<float*>(c2_smem + pl.l_dy);
 #pragma unroll
     for (int e = 0; e < EQ; ++e)
-      if (dyr[e] >= 0) *reinterpret_cast<f32x4*>(bl + dyg[e]) = dbs[e];
+      if (dyg[e] >= 0) *reinterpret_cast<f32x4*>(bl + dyg[e]) = dbs[e];
     __syncthreads();
-    for (int o = tid; o < OUT; o += C2_NT) {
+    for (int o = tid; o < OUT; o += NT) {
       float s = bl[o];
       for (int r = 1; r < nb; ++r) s += bl[r * OUT + o];
       g.bpart[(size_t)blockIdx.x * OUT + o] = s;
@@ -515,7 +687,7 @@ __global__ void __launch_bounds__(C2_NT) k_c2w(C2Args g) {
 }
 
 // ---- fixed-order reduction of the slabs; un-scale; scatter --------------------------------------------------------------------
-// One workgroup per (matrix, unit): thread (lane, grp) sums the workgroups grp, grp + 4, ... in order, the four groups are added
+// One workgroup per (matrix, unit): thread (lane, grp) sums the workgroups grp, grp + 16, ... in order, the sixteen groups are added
 // in order through LDS.  d == 2: straight into the packed core gradients (accumulated: the caller zero-fills); d > 2: into the
 // merged-core gradients dGh / dGt, pulled back onto the cores by k_c2_pull.
 struct C2Red {
@@ -527,19 +699,21 @@ struct C2Red {
 };
 struct C2RedArgs { C2Red r[2]; int nu0; };
 
-__global__ void __launch_bounds__(256) k_c2_reduce(C2RedArgs args) {
-  __shared__ f32x4 red[4][64];
+__global__ void __launch_bounds__(1024) k_c2_reduce(C2RedArgs args) {
+  __shared__ f32x4 red[16][64];
   const int mi = (int)blockIdx.x >= args.nu0 ? 1 : 0;
   const C2Red& a = args.r[mi];
   const C2Mat& m = a.m;
   const int u = (int)blockIdx.x - (mi ? args.nu0 : 0);
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int w = grp; w < a.grid; w += 4) v += reinterpret_cast<const f32x4*>(a.part)[((size_t)w * m.NU + u) * 64 + lane];
+  for (int w = grp; w < a.grid; w += 16) v += reinterpret_cast<const f32x4*>(a.part)[((size_t)w * m.NU + u) * 64 + lane];
   red[grp][lane] = v;
   __syncthreads();
   if (grp != 0) return;
-  v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  v = red[0][lane];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][lane];
   const int c = lane & 15, gq = lane >> 4;
   const int ex = a.hdr[0], ed = a.hdr[1], ec1 = a.hdr[4], edc = a.hdr[5];
   if (u < m.nC) {
@@ -622,13 +796,22 @@ __global__ void __launch_bounds__(256) k_c2_pull(TtShape s, C2Mat m, const float
   }
 }
 
-// d_bias (+)= sum over the workgroups' partial column sums, in order; up to two destinations (the LSTM's two bias vectors)
-__global__ void __launch_bounds__(256) k_c2_bias(const float* __restrict__ bpart, int grid, int OUT, float* __restrict__ d0,
-                                                 float* __restrict__ d1) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= OUT) return;
+// d_bias (+)= sum over the workgroups' partial column sums, in a fixed order (sixteen groups of workgroups, then the groups); up to
+// two destinations (the LSTM's two bias vectors).  64 columns per workgroup.
+__global__ void __launch_bounds__(1024) k_c2_bias(const float* __restrict__ bpart, int grid, int OUT, float* __restrict__ d0,
+                                                  float* __restrict__ d1) {
+  __shared__ float red[16][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int w = 0; w < grid; ++w) s += bpart[(size_t)w * OUT + o];
+  if (o < OUT)
+    for (int w = grp; w < grid; w += 16) s += bpart[(size_t)w * OUT + o];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp != 0 || o >= OUT) return;
+  s = red[0][col];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][col];
   if (d0) d0[o] += s;
   if (d1) d1[o] += s;
 }
@@ -644,37 +827,7 @@ bool c2_plan_at(C2Plan* pl, const TtShape* const* shapes, int nmat, const int* s
       bool ok = true;
       for (int i = 0; i < nmat && ok; ++i) ok = c2_plan_mat(&p.m[i], *shapes[i], sp[i], nb, big);
       if (!ok) continue;
-      if (nmat == 2 && (p.m[0].Ih != p.m[1].Ih || p.m[0].It != p.m[1].It || p.m[0].out != p.m[1].out)) return false;
-      p.OUT = p.m[0].out; p.Ih = p.m[0].Ih; p.It = p.m[0].It;
-      if (p.OUT % 4 != 0) return false;
-      p.DS = p.It + 8;
-      p.dy_rows = nb * p.Ih + 32;
-      p.EQ = c2_ceil(nb * p.OUT / 4, C2_NT);
-      if (p.EQ > (big ? 8 : 4)) continue;
-      // LDS carve-up
-      size_t off = 0;
-      p.l_dy = (int)off;
-      size_t dyb = (size_t)2 * p.dy_rows * p.DS * 2;
-      if (dyb < (size_t)nb * p.OUT * 4) dyb = (size_t)nb * p.OUT * 4;      // (the bias partials pass through this region at the end)
-      off += (dyb + 15) & ~(size_t)15;
-      int c1h = 0, dch = 0;
-      for (int i = 0; i < nmat; ++i) {
-        const C2Mat& m = p.m[i];
-        if (nb * m.QR * m.CS1 > c1h) c1h = nb * m.QR * m.CS1;
-        if (nb * m.PR * m.CS2 > dch) dch = nb * m.PR * m.CS2;
-      }
-      p.c1_plane = c1h; p.dc1_plane = dch;
-      p.l_c1 = (int)off; off += ((size_t)2 * c1h * 2 + 15) & ~(size_t)15;
-      p.l_dc1 = (int)off; off += ((size_t)2 * dch * 2 + 15) & ~(size_t)15;
-      for (int i = 0; i < nmat; ++i) {
-        C2Mat& m = p.m[i];
-        m.l_xs = (int)off; off += ((size_t)2 * m.xs_rows * m.XS * 2 + 15) & ~(size_t)15;
-        m.l_ghf = (int)off; off += (size_t)m.QT * m.KB * 2 * 1024;
-        m.l_tab = (int)off;
-        off += ((size_t)(m.NA * 16 + m.QT * 4 + 2 * m.NB + 2 * m.KC * 4 + m.KD * 4) * 4 + 15) & ~(size_t)15;
-      }
-      if (off > (size_t)C2_LDS_LIMIT) continue;
-      p.lds = (int)off;
+      if (!c2_layout(&p)) continue;
       p.grid = cus;
       // workspace
       size_t w = 0;
@@ -724,15 +877,16 @@ bool c2_plan(C2Plan* pl, const TtShape* const* shapes, int nmat, int cus) {
 template <int NMAT>
 int c2_launch_main(const C2Args& a, hipStream_t stream) {
   const C2Plan& pl = a.pl;
-  if (pl.big) {
-    auto fn = k_c2w<NMAT, 8, 2, 2, 8>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), pl.lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(fn, dim3(pl.grid), dim3(C2_NT), pl.lds, stream, a);
-  } else {
-    auto fn = k_c2w<NMAT, 4, 1, 1, 4>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), pl.lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-    hipLaunchKernelGGL(fn, dim3(pl.grid), dim3(C2_NT), pl.lds, stream, a);
-  }
+  const void* fn;
+  void (*kf)(C2Args);
+  constexpr int SP = NMAT == 2 ? 1 : 2;
+  constexpr C2Plan spk = c2_const_plan<SP>();
+  if (pl.big) kf = k_c2w<0, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  else if (c2_same_kernel_plan(pl, spk) && !(opt(OPT_DEV2) & 4)) kf = k_c2w<SP, NMAT, C2_NW, 4, 1, 1, 4, 1>;      // (dev2 bit 2: the run-time-plan kernel, A/B)
+  else kf = k_c2w<0, NMAT, C2_NW, 4, 1, 1, 4, 1>;
+  fn = reinterpret_cast<const void*>(kf);
+  if (ensure_dynamic_lds(fn, pl.lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(kf, dim3(pl.grid), dim3(C2_NT), pl.lds, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
@@ -752,9 +906,13 @@ bool c2w_prefers_chain(const TtShape& s) {
   return bc > 0 && 2.0 * s.in_size * s.out_size > 1.5 * bc;
 }
 
-size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat) {
+// small_only: only plans of the small kernel variant count.  That is what the router offers: the large variant (P > 128 rows of
+// Gt: rank 4 at H = 768, the d = 4 shapes) spills its run-time plan and LOSES to the dense gradient (H = 768, d = 2, r = 4 at
+// the speaker encoder's size: 4.9 ms against 1.8) — it stays reachable for tests through option dev2 bit 3.
+size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only) {
   C2Plan pl;
   if (!c2_plan(&pl, shapes, nmat, device_cu_count())) return 0;
+  if (small_only && pl.big) return 0;
   return (size_t)pl.ws_bytes;
 }
 
@@ -770,6 +928,7 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
   if (!c2_plan(&pl, shapes, nmat, cus)) return TTRNN_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < (size_t)pl.ws_bytes) return TTRNN_ERR_WORKSPACE;
   if (n_rows <= 0) return TTRNN_OK;
+  if (n_rows >= ((int64_t)1 << 31)) return TTRNN_ERR_UNSUPPORTED;      // (32-bit (sample, step) arithmetic of the staged rows)
   const long nblk = (n_rows + pl.nb - 1) / pl.nb;
   if (nblk < pl.grid) pl.grid = (int)nblk;
   char* ws = (char*)workspace;
@@ -785,6 +944,10 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
   C2Args ka{};
   C2RedArgs ra{};
   ka.pl = pl; ka.dy = dy; ka.n_rows = (long)n_rows;
+#ifdef TTRNN_ABLATIONS
+  ka.abl = opt(OPT_DEV2) >> 8;
+  ka.diag = (unsigned long long*)(ws + pl.w_cmax + 64);
+#endif
   ka.bpart = (d_bias0 || d_bias1) ? (float*)(ws + pl.w_bpart) : nullptr;
   for (int i = 0; i < nmat; ++i) {
     const C2Mat& m = pl.m[i];
@@ -813,12 +976,17 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
     r.m = m; r.s = s; r.part = a.part; r.grid = pl.grid; r.hdr = p.hdr; r.d_packed = d_packed[i];
     r.dGh = (float*)(ws + m.w_dgh); r.dGt = (float*)(ws + m.w_dgt);
   }
-  hipLaunchKernelGGL(k_c2_prep, dim3(nmat), dim3(256), 0, stream, pa);
+  int ntile = 0;
+  for (int i = 0; i < nmat; ++i) {
+    const int t = 1 + pl.m[i].PT * pl.m[i].KA + pl.m[i].QT * pl.m[i].KB;
+    if (t > ntile) ntile = t;
+  }
+  hipLaunchKernelGGL(k_c2_prep, dim3(ntile, nmat), dim3(256), 0, stream, pa);
   int st = nmat == 2 ? c2_launch_main<2>(ka, stream) : c2_launch_main<1>(ka, stream);
   if (st != TTRNN_OK) return st;
   ra.nu0 = pl.m[0].NU;
   const int nu = pl.m[0].NU + (nmat == 2 ? pl.m[1].NU : 0);
-  hipLaunchKernelGGL(k_c2_reduce, dim3(nu), dim3(256), 0, stream, ra);
+  hipLaunchKernelGGL(k_c2_reduce, dim3(nu), dim3(1024), 0, stream, ra);
   for (int i = 0; i < nmat; ++i) {
     const C2Mat& m = pl.m[i];
     if (m.d > 2) {
@@ -828,7 +996,7 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
     }
   }
   if (ka.bpart)
-    hipLaunchKernelGGL(k_c2_bias, dim3((pl.OUT + 255) / 256), dim3(256), 0, stream, (const float*)ka.bpart, pl.grid, pl.OUT, d_bias0, d_bias1);
+    hipLaunchKernelGGL(k_c2_bias, dim3((pl.OUT + 63) / 64), dim3(1024), 0, stream, (const float*)ka.bpart, pl.grid, pl.OUT, d_bias0, d_bias1);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

@@ -374,7 +374,7 @@ int launch_ttlinear_bwd_fast(const TtShape& s, int dtype, int dy_dtype, int64_t 
 
 // chain weight gradients of up to two TT-matrices sharing one pass over dy (ttrnn_fast_c2w.hip, plan: ttrnn_c2w.h)
 bool c2w_prefers_chain(const TtShape& s);      // 2 in out > 1.5 x the chain's FLOPs
-size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat);      // 0: the kernel does not take these shapes
+size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only = false);      // 0: the kernel does not take these shapes
 int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const float* const* packed, const float* const* x,
                const float* const* first, const int* T, const float* dy, const unsigned* const* x_cmax, const int* x_cn,
                const unsigned* dy_cmax, float* const* d_packed, float* d_bias0, float* d_bias1, void* workspace,

@@ -40,7 +40,9 @@ enum OptId {
                          //                         builds (`make ablation` -> tools/bin/libttrnn_abl.so), never in libttrnn.so
   OPT_DEV2,              // TTRNN_DEV2=0..1073741823    second developer bit mask (round 6; same kind of A/B route switches as `dev`):
                          //                         1: no chain weight gradient (ttrnn_rnn_wgrad_workspace answers 0: dense gradients everywhere),
-                         //                         2: chain weight gradient for the hidden matrix only (the input matrix keeps its dense pass over dy)
+                         //                         2: chain weight gradient for the hidden matrix only (the input matrix keeps its dense pass over dy),
+                         //                         4: the chain kernel with the run-time plan even for the shapes that have a compile-time instantiation,
+                         //                         8: offer the chain kernel's LARGE variant too (measured slower than the dense gradient: tests only)
   OPT_COUNT
 };
 

@@ -54,7 +54,19 @@ CASES = {
 }
 
 
-def _run(case, scale_dy=1.0, seed=3, poison=False):
+# cases only the kernel's LARGE variant takes (more than 128 rows of Gt): not routed to by default — slower than the dense gradient
+BIG = {"spk_r4", "spk_d4r4"}
+
+
+def _run(case, scale_dy=1.0, seed=3, poison=False, dev2=None):
+    from ttrnn_hip import _lib
+    if dev2 is None:
+        dev2 = 8 if case in BIG else 0
+    with _lib.option("dev2", dev2):
+        return _run_inner(case, scale_dy, seed, poison)
+
+
+def _run_inner(case, scale_dy, seed, poison):
     from ttrnn_hip import _lib, functional as F
     lib = _lib.load()
     c = CASES[case]
@@ -147,6 +159,18 @@ def test_chain_wgrad_gate_gradient_ranges(scale):
             assert float((g.double() - r).abs().max()) <= 3e-6 * float(r.abs().max()), (scale, name)
 
 
+def test_run_time_plan_kernel_is_bit_identical_to_the_compile_time_instantiation():
+    """the speaker encoder's shapes run a kernel whose plan is a compile-time constant (c2_const_plan); option dev2 bit 2 selects
+    the same kernel with the plan at run time: same arithmetic, same order, same bits"""
+    for case in ("spk_lstm_h0", "spk_lstm_hid_only"):
+        _, a = _run(case, seed=11)
+        _, b = _run(case, seed=11, dev2=4)
+        for name in ("in", "hid"):
+            if name in a:
+                for x, y in zip(a[name], b[name]):
+                    assert torch.equal(x, y), (case, name)
+
+
 def test_chain_wgrad_is_bitwise_repeatable():
     """fixed-order sums: two launches on poisoned workspaces give the same bits"""
     _, a = _run("spk_lstm", seed=5, poison=True)
@@ -174,3 +198,6 @@ def test_chain_route_is_offered_only_where_the_chain_is_cheaper():
     assert not offered("lstm", ([2, 4, 5], [8, 8, 16], [1, 16, 16, 1]), ([4, 8, 8], [8, 8, 16], [1, 16, 16, 1]), 256)     # cfg4
     with _lib.option("dev2", 1):
         assert not offered("lstm", spk["inp"], spk["hid"], 768, 3)
+    # rank 4 at H = 768 needs the kernel's large variant, which loses to the dense gradient: not offered
+    r4 = CASES["spk_r4"]
+    assert not offered("lstm", r4["inp"], r4["hid"], 768, 3) and not offered("lstm", r4["inp"], r4["hid"], 768, 2)

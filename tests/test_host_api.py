@@ -138,7 +138,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.ttrnn_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ttrnn_abi_version() == _lib.ABI_VERSION == 7
     assert lib.ttrnn_status_string(0) == b"ok"
     assert b"workspace" in lib.ttrnn_status_string(-4)
 

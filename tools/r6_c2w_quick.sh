@@ -1,0 +1,9 @@
+python -m pytest tests/test_chain_wgrad.py -q -x 2>&1 | tail -2
+python tools/c2w_bench.py 2 3 10 | tail -1
+python tools/c2w_bench.py 2 2 10 | tail -1
+python tools/c2w_bench.py 4 3 10 | tail -1
+python tools/c2w_bench.py 4 2 10 | tail -1
+export TTRNN_LIB_PATH=$PWD/tools/bin/libttrnn_abl.so
+for m in 2 3; do
+  TTRNN_DEV2=0 python tools/c2w_bench.py 2 $m 10 2>&1 | tail -3
+done
