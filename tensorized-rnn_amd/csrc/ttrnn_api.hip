@@ -589,14 +589,23 @@ static bool fwd_prefers_g2(const RnnShape& rs, int dtype) {
   return rs.cell == TTRNN_GRU && dtype == TTRNN_F32 && fp32_math() == TTRNN_MATH_SPLIT && g2_rnn_available(rs, dtype);
 }
 
+static size_t rnn_workspace_other(const RnnShape& rs, int dtype);
 size_t ttrnn_rnn_workspace(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return 0;
-  if (fwd_prefers_g2(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
-  const FastFwdPlan f = plan_fast_fwd(rs, desc->dtype);
+  // (the encoder-shape kernel's fragments, or whatever the route behind it needs: an option may switch between calls)
+  const size_t w2 = w2_rnn_fwd_available(rs, desc->dtype) ? w2_rnn_fwd_workspace_bytes() : 0;
+  const size_t o = rnn_workspace_other(rs, desc->dtype);
+  return w2 > o ? w2 : o;
+}
+static size_t rnn_workspace_other(const RnnShape& rs, int dtype) {
+  const ttrnn_rnn_desc* desc = nullptr;
+  (void)desc;
+  if (fwd_prefers_g2(rs, dtype)) return g2_rnn_fwd_workspace(rs);
+  const FastFwdPlan f = plan_fast_fwd(rs, dtype);
   if (f.use) return f.gin_bytes + f.lin_ws_bytes + f.f10_bytes + f.f10_lin_bytes + f.gemm_bytes;
-  if (!force_generic() && big_rnn_fwd_available(rs, desc->dtype)) return big_rnn_fwd_workspace(rs);
-  if (!force_generic() && g2_rnn_available(rs, desc->dtype)) return g2_rnn_fwd_workspace(rs);
+  if (!force_generic() && big_rnn_fwd_available(rs, dtype)) return big_rnn_fwd_workspace(rs);
+  if (!force_generic() && g2_rnn_available(rs, dtype)) return g2_rnn_fwd_workspace(rs);
   return plan_rnn_generic(rs, false).ws_bytes;
 }
 
@@ -685,6 +694,13 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
     return TTRNN_ERR_NULL;
   if (rs.has_bias_in && !bias_in) return TTRNN_ERR_NULL;
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
+  if (rs.T > 0 && w2_rnn_fwd_available(rs, desc->dtype)) {
+    // the speaker encoder's shape: chain stages AND input projection in one persistent kernel (no K-in, no [B][T][4H] buffer)
+    if (phase == TTRNN_PHASE_PREPARE) return TTRNN_OK;
+    if (!workspace || workspace_bytes < w2_rnn_fwd_workspace_bytes()) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_fwd_w2(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace,
+                             (hipStream_t)stream);
+  }
   const bool g2_first = fwd_prefers_g2(rs, desc->dtype);
   const FastFwdPlan f = g2_first ? FastFwdPlan{} : plan_fast_fwd(rs, desc->dtype);
   if (f.use) {
@@ -818,6 +834,7 @@ int ttrnn_rnn_forward_route(const ttrnn_rnn_desc* desc) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
   if (force_generic()) return TTRNN_ROUTE_VALU;
+  if (w2_rnn_fwd_available(rs, desc->dtype)) return TTRNN_ROUTE_FUSED_CORE;
   if (fwd_prefers_g2(rs, desc->dtype))      // (the fp32 GRU shape with input_size != 1: the tier's K-in + the fused-core recurrent kernel)
     return (!opt(OPT_FORCE_G2) && (f10gh_available(rs, desc->dtype) || f10g5_available(rs, desc->dtype) || f10n_available(rs, desc->dtype))) ? TTRNN_ROUTE_FUSED_CORE
                                                                                                            : TTRNN_ROUTE_RUNTIME_MFMA;

@@ -1,0 +1,368 @@
+// ttrnn_fast_w2.hip — TT-LSTM forward for the reference's own published encoder shape: hidden 768, TWO cores, rank 2, 40 mel
+// channels in (experiments/speaker_verification/encoder/params_model.py:2-4,14-16; tt_shape: input (5, 8) x (48, 64), hidden
+// (24, 32) x (48, 64)).  Replaces tensorized_rnn/lstm.py:23-32,101-135 + t3nsor/ops.py:78-93 for that layer — INCLUDING the
+// input projection: no hoisted K-in GEMM and no [B][T][4H] buffer of pre-activations (1 GB at the encoder's batch, written and
+// read back once per forward by every other route).
+//
+// A sample is a workgroup of FOUR waves; wave w owns the output-mode slice i1 in [16 w, 16 w + 16) through BOTH chain stages
+// (the structure of ttrnn_fast_f2.hip, whose H = 128 kernel it generalises), all operands on two fp16 pieces, fp32 accumulation:
+//   stage 1   C1_a[j0][i1] = sum_j1 h[j0][j1] Gt[i1][j1][a]: the state image (LDS, [j0][j1]) is the A operand, the wave's slice of
+//             core 1 the B operand (registers); one MFMA tile per (rank index a, sixteen j0) — 12 MFMAs; the same for the five
+//             input chain rows x[j0'][j1'] against the input matrix's core 1 — 6 MFMAs;
+//   hand-off  NONE: an accumulator tile has its column i1 on the lane and four consecutive j0 in the registers — exactly what
+//             stage 2's B operand wants when its contraction index runs (j0 block, a, j0 in block): the lane converts its own
+//             eight values (2 ranks x 4 rows) to two fp16 pieces and feeds them back.  The input matrix's chain rows ride in the
+//             k-slots that the hidden matrix's 24 = 16 + 8 rows leave empty in the second k-block: the input projection costs
+//             no stage-2 MFMA at all;
+//   stage 2   y[(r, gate)][i1] = sum_k Gh[(r, gate)][k] C1[k][i1], three row tiles of core 0 (both matrices' head cores side by
+//             side along k, rows permuted so that a lane's four accumulator registers are i, f, g, o of ONE hidden unit) — 18 MFMAs;
+//   gates     on the accumulators (lstm.py:26-32); c in registers; h_t as two fp16 pieces into the other parity of the state
+//             image; ONE barrier per step.
+// Scales: powers of two per launch for the weights (k_w2_prep), 2^13 for h (|h| < 1; a caller's h_0 per sample), per STEP for
+// x_t (its own maximum, taken by the wave that stages it), per step for the hand-off (the larger of the two chains' bounds).
+#include <hip/hip_runtime.h>
+#include "ttrnn.h"
+#include "ttrnn_core.h"
+#include "ttrnn_launch.h"
+#include "ttrnn_opts.h"
+#include "ttrnn_mfma.h"
+#include "ttrnn_split.h"
+
+namespace ttrnn {
+namespace {
+
+struct W2S {      // the encoder's shape
+  static constexpr int J0 = 24, J1 = 32, I0 = 48, I1 = 64, R = 2, H = 768;
+  static constexpr int J0I = 5, J1I = 8, INP = 40;
+  static constexpr int NWV = I1 / 16;          // 4 waves (blockDim = 64 NWV)
+  static constexpr int NR = I0 / 4;            // 12 values of r (unit u = r * 64 + i1)
+  static constexpr int MT2 = 3;                // stage-2 row tiles: r in [4 t, 4 t + 4) x 4 gates
+  static constexpr int HS = 40;                // row stride (halves) of the state / input images
+  // LDS (bytes): state image [2 parity][2 pieces][32 rows][HS], input image [2][2][16][HS], step exponents of x, scratch
+  static constexpr int L_H = 0, L_X = 2 * 2 * 32 * HS * 2, L_E = L_X + 2 * 2 * 16 * HS * 2, L_RED = L_E + 16, LDS = L_RED + 64;
+  // workspace: header (ints) | fragments xh8 [tile][piece][64 lanes]: 8 tiles Gt (wave, a), 8 tiles Gt_in, 6 tiles Gh (tile, kb)
+  static constexpr int HDR_BYTES = 256, NTILES = 8 + 8 + 6;
+  static constexpr size_t WS_BYTES = HDR_BYTES + (size_t)NTILES * 2 * 64 * 16;
+};
+enum { W2_EGT = 0, W2_EC1 = 1, W2_EGTI = 2, W2_ECI = 3, W2_EGH = 4 };
+
+__device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / non-finite: neutral; clamped
+  if (!(x > 0.f) || !(x <= 3.4028235e38f)) return 0;
+  int e;
+  frexpf(x, &e);
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+// packed core k: W_k[(j*R_{k+1} + b)*M_k + i*R_k + a]
+__device__ __forceinline__ float w2_gt(const TtShape& s, const float* pk, int i1, int j1, int a) {
+  return pk[s.woff[1] + (size_t)j1 * s.M[1] + i1 * s.R[1] + a];
+}
+__device__ __forceinline__ float w2_gh(const TtShape& s, const float* pk, int i0, int j0, int a) {
+  return pk[s.woff[0] + (size_t)(j0 * s.R[1] + a) * s.M[0] + i0];
+}
+
+__device__ float w2_block_max(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- prep: one workgroup per fragment tile (each takes the maxima it needs itself); workgroup 0 also writes the header ----------
+__global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const float* __restrict__ pk_hid, const float* __restrict__ pk_in,
+                                                 int* __restrict__ hdr, _Float16* __restrict__ frag) {
+  using S = W2S;
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float mgt = 0.f, mgti = 0.f, mgh = 0.f, l1t = 0.f, l1ti = 0.f;
+  for (int e = tid; e < S::I1 * S::J1 * S::R; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
+  for (int e = tid; e < S::I1 * S::J1I * S::R; e += 256) mgti = fmaxf(mgti, fabsf(pk_in[si.woff[1] + e]));
+  for (int e = tid; e < S::I0 * S::J0 * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
+  for (int e = tid; e < S::I0 * S::J0I * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_in[si.woff[0] + e]));
+  if (blockIdx.x == 0 && tid < S::I1 * S::R) {           // rows (i1, a): L1 norms over j1 (bounds of the stage-1 results)
+    const int i1 = tid / S::R, a = tid % S::R;
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = 0; j < S::J1; ++j) s0 += fabsf(w2_gt(sh, pk_hid, i1, j, a));
+    for (int j = 0; j < S::J1I; ++j) s1 += fabsf(w2_gt(si, pk_in, i1, j, a));
+    l1t = s0; l1ti = s1;
+  }
+  mgt = w2_block_max(mgt, red); mgti = w2_block_max(mgti, red); mgh = w2_block_max(mgh, red);
+  const int egt = w2_expo(mgt), egti = w2_expo(mgti), egh = w2_expo(mgh);
+  if (blockIdx.x == 0) {
+    l1t = w2_block_max(l1t, red); l1ti = w2_block_max(l1ti, red);
+    if (tid == 0) {
+      hdr[W2_EGT] = egt; hdr[W2_EC1] = w2_expo(l1t); hdr[W2_EGTI] = egti; hdr[W2_ECI] = w2_expo(l1ti); hdr[W2_EGH] = egh;
+    }
+  }
+  const int tile = blockIdx.x;
+  if (tile >= S::NTILES) return;
+  _Float16* dst = frag + (size_t)tile * 1024;
+  for (int e = tid; e < 512; e += 256) {
+    const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
+    float v = 0.f;
+    if (tile < 8) {                     // stage-1 B operand of the hidden matrix: wave w, rank index a: B[k = j1][n = i1 - 16 w]
+      const int w = tile >> 1, a = tile & 1;
+      v = w2_gt(sh, pk_hid, 16 * w + n, 8 * g + j, a) * ldexpf(1.f, 14 - egt);
+    } else if (tile < 16) {             // the same of the input matrix: k = j1' < 8, zero beyond
+      const int w = (tile - 8) >> 1, a = tile & 1, j1 = 8 * g + j;
+      if (j1 < S::J1I) v = w2_gt(si, pk_in, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egti);
+    } else {                            // stage-2 A operand: row tile tl, k-block kb: A[row = (rr, gate)][k = (g, a, jj)]
+      const int tl = (tile - 16) >> 1, kb = tile & 1;
+      const int rr = n >> 2, gate = n & 3, i0 = gate * S::NR + 4 * tl + rr;
+      const int a = j >> 2, jj = j & 3;
+      if (kb == 0 || g < 2) {
+        v = w2_gh(sh, pk_hid, i0, 16 * kb + 4 * g + jj, a);
+      } else {
+        const int j0 = 4 * (g - 2) + jj;
+        if (j0 < S::J0I) v = w2_gh(si, pk_in, i0, j0, a);
+      }
+      v *= ldexpf(1.f, 14 - egh);
+    }
+    _Float16 p0, p1;
+    split2h(v, p0, p1);
+    dst[lane * 8 + j] = p0;
+    dst[512 + lane * 8 + j] = p1;
+  }
+}
+
+struct W2Args {
+  const float* x; const float* h0; const float* c0;
+  const float* bias_in; const float* bias_hid;
+  const int* hdr; const _Float16* frag;
+  float* out; float* hT; float* cT; float* reserve;
+  int B, T;
+};
+
+__device__ __forceinline__ xh8 w2_ld8(const _Float16* p) { return *reinterpret_cast<const xh8*>(p); }
+__device__ __forceinline__ f32x4 w2_mma3(const xh8 a0, const xh8 a1, const xh8 b0, const xh8 b1, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
+  return acc;
+}
+// eight fp32 values -> the two fp16 pieces of a k-packed operand
+__device__ __forceinline__ void w2_split8(const float (&v)[8], xh8& p0, xh8& p1) {
+  unsigned a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pair_h(v[2 * i], v[2 * i + 1], a[i], b[i]);
+  p0 = __builtin_bit_cast(xh8, u32x4{a[0], a[1], a[2], a[3]});
+  p1 = __builtin_bit_cast(xh8, u32x4{b[0], b[1], b[2], b[3]});
+}
+
+__global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
+  using S = W2S;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, T = g.T;
+  _Float16* himg = reinterpret_cast<_Float16*>(smem + S::L_H);       // [par][piece][32][HS]
+  _Float16* ximg = reinterpret_cast<_Float16*>(smem + S::L_X);       // [par][piece][16][HS]
+  int* xexp = reinterpret_cast<int*>(smem + S::L_E);
+  float* red = reinterpret_cast<float*>(smem + S::L_RED);
+  constexpr int HP = 32 * S::HS, XP = 16 * S::HS;                     // plane sizes (halves)
+  for (int i = tid; i < S::L_E / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragments (pinned in registers) ----
+  xh8 gt[2][2], gti[2][2], gh[S::MT2][2][2];
+  const xh8* fr = reinterpret_cast<const xh8*>(g.frag);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      gt[a][p] = fr[((size_t)(2 * wave + a) * 2 + p) * 64 + lane];
+      gti[a][p] = fr[((size_t)(8 + 2 * wave + a) * 2 + p) * 64 + lane];
+      asm volatile("" : "+v"(gt[a][p]), "+v"(gti[a][p]));
+    }
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        gh[tl][kb][p] = fr[((size_t)(16 + 2 * tl + kb) * 2 + p) * 64 + lane];
+        asm volatile("" : "+v"(gh[tl][kb][p]));
+      }
+  const int egt = g.hdr[W2_EGT], ec1 = g.hdr[W2_EC1], egti = g.hdr[W2_EGTI], eci = g.hdr[W2_ECI], egh = g.hdr[W2_EGH];
+
+  // ---- the lane's three hidden units (one per stage-2 row tile), their biases and state ----
+  int unit[S::MT2];
+  f32x4 bz[S::MT2];
+  float cst[S::MT2], hval[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) {
+    unit[tl] = (4 * tl + q) * 64 + 16 * wave + n;
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) {
+      float v = 0.f;
+      if (g.bias_in) v += g.bias_in[gate * S::H + unit[tl]];
+      if (g.bias_hid) v += g.bias_hid[gate * S::H + unit[tl]];
+      bz[tl][gate] = v;
+    }
+    cst[tl] = g.c0 ? g.c0[(size_t)b * S::H + unit[tl]] : 0.f;
+    hval[tl] = g.h0 ? g.h0[(size_t)b * S::H + unit[tl]] : 0.f;
+  }
+  // a caller's h_0 may exceed 1: its exponent per sample (0 when it does not)
+  int e0 = 0;
+  if (g.h0) {
+    float m = fmaxf(fmaxf(fabsf(hval[0]), fabsf(hval[1])), fabsf(hval[2]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    e0 = w2_expo(m);
+    e0 = e0 < 0 ? 0 : e0;
+  } else {
+    __syncthreads();
+  }
+  // unit u = j0 * 32 + j1 of the state image
+  int hoff[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) hoff[tl] = (unit[tl] >> 5) * S::HS + (unit[tl] & 31);
+  auto put_h = [&](int par, float scale) {
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      _Float16 p0, p1;
+      split2h(hval[tl] * scale, p0, p1);
+      himg[(par * 2 + 0) * HP + hoff[tl]] = p0;
+      himg[(par * 2 + 1) * HP + hoff[tl]] = p1;
+    }
+  };
+  // x_t: wave 0, lanes < 40 — row 8 + j0' of the input image (the k-slots the hidden rows leave free), column j1'
+  const int xo = (8 + lane / S::J1I) * S::HS + (lane % S::J1I);
+  const float* xrow = g.x + (size_t)b * T * S::INP;
+  auto put_x = [&](int par, float xv) {
+    float m = lane < S::INP ? fabsf(xv) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int ex = w2_expo(m);
+    if (lane < S::INP) {
+      _Float16 p0, p1;
+      split2h(xv * ldexpf(1.f, 13 - ex), p0, p1);
+      ximg[(par * 2 + 0) * XP + xo] = p0;
+      ximg[(par * 2 + 1) * XP + xo] = p1;
+    }
+    if (lane == 0) xexp[par] = ex;
+  };
+  put_h(0, ldexpf(1.f, 13 - e0));
+  float xnext = 0.f;
+  if (wave == 0) {
+    put_x(0, (lane < S::INP && T > 0) ? xrow[lane] : 0.f);
+    if (lane < S::INP && T > 1) xnext = xrow[S::INP + lane];
+  }
+  lds_barrier();
+
+  const size_t rrows = (size_t)g.B * T;
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const _Float16* hp = himg + par * 2 * HP;
+    const _Float16* xp = ximg + par * 2 * XP;
+    // A operands of stage 1: rows 16 mt + n of the state image, row n of the input image, eight k from 8 q
+    xh8 ah[2][2], ax[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ah[mt][p] = w2_ld8(hp + p * HP + (16 * mt + n) * S::HS + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ax[p] = w2_ld8(xp + p * XP + n * S::HS + 8 * q);
+    const int ex = xexp[par];
+    // ---- stage 1 ----
+    f32x4 d[2][2], di[2];
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) d[a][mt] = w2_mma3(ah[mt][0], ah[mt][1], gt[a][0], gt[a][1], z4);
+      di[a] = w2_mma3(ax[0], ax[1], gti[a][0], gti[a][1], z4);
+    }
+    // ---- hand-off: the lane's own (a, jj) values are its k elements of stage 2; per-step exponents ----
+    const int eh0 = t == 0 ? e0 : 0;
+    const int ech = ec1 + eh0, ecx = eci + ex;
+    const int ec = ech > ecx ? ech : ecx;
+    const int sh_ = egt - ec - 13 + eh0, si_ = egti + ex - ec - 13;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        v0[4 * a + jj] = ldexpf(d[a][0][jj], sh_);
+        const float hv = ldexpf(d[a][1][jj], sh_), iv = ldexpf(di[a][jj], si_);
+        v1[4 * a + jj] = q < 2 ? hv : iv;
+      }
+    xh8 b0[2], b1[2];
+    w2_split8(v0, b0[0], b0[1]);
+    w2_split8(v1, b1[0], b1[1]);
+    // ---- stage 2 + gates ----
+    const float zs = ldexpf(1.f, egh + ec - 28);
+    const size_t bt = (size_t)b * T + t;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      f32x4 acc = w2_mma3(gh[tl][0][0], gh[tl][0][1], b0[0], b0[1], z4);
+      acc = w2_mma3(gh[tl][1][0], gh[tl][1][1], b1[0], b1[1], acc);
+      const f32x4 z = acc * zs + bz[tl];
+      const float ig = fsigmoid(z[0]), fg = fsigmoid(z[1]), gg = ftanh(z[2]), og = fsigmoid(z[3]);
+      const float cy = fg * cst[tl] + ig * gg;
+      const float hy = og * ftanh(cy);
+      cst[tl] = cy;
+      hval[tl] = hy;
+      if (g.out) g.out[bt * S::H + unit[tl]] = hy;
+      if (g.reserve) {
+        *reinterpret_cast<f32x4*>(g.reserve + res_gate(bt, S::H, unit[tl])) = f32x4{ig, gg, fg, og};
+        g.reserve[res_cell(rrows, bt, S::H, unit[tl])] = cy;
+      }
+    }
+    put_h(par ^ 1, 8192.f);
+    if (wave == 0) {
+      put_x(par ^ 1, xnext);
+      if (lane < S::INP && t + 2 < T) xnext = xrow[(size_t)(t + 2) * S::INP + lane];
+    }
+    lds_barrier();
+  }
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) {
+    if (g.hT) g.hT[(size_t)b * S::H + unit[tl]] = hval[tl];
+    if (g.cT) g.cT[(size_t)b * S::H + unit[tl]] = cst[tl];
+  }
+}
+
+bool w2_shape(const TtShape& hid, const TtShape& in) {
+  using S = W2S;
+  return hid.d == 2 && in.d == 2 && hid.J[0] == S::J0 && hid.J[1] == S::J1 && hid.I[0] == S::I0 && hid.I[1] == S::I1 &&
+         hid.R[1] == S::R && in.J[0] == S::J0I && in.J[1] == S::J1I && in.I[0] == S::I0 && in.I[1] == S::I1 && in.R[1] == S::R;
+}
+
+}  // namespace
+
+// the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's shape
+bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
+         w2_shape(rs.hid_s, rs.in_s) && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         !(opt(OPT_DEV2) & 16);
+}
+size_t w2_rnn_fwd_workspace_bytes() { return W2S::WS_BYTES; }
+
+int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
+                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                      hipStream_t stream) {
+  using S = W2S;
+  int* hdr = (int*)ws;
+  _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
+  hipLaunchKernelGGL(k_w2_prep, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  W2Args a{};
+  a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = (const float*)c0;
+  a.bias_in = rs.has_bias_in ? (const float*)bias_in : nullptr;
+  a.bias_hid = rs.has_bias_hid ? (const float*)bias_hid : nullptr;
+  a.hdr = hdr; a.frag = frag;
+  a.out = (float*)out; a.hT = (float*)hT; a.cT = (float*)cT; a.reserve = reserve;
+  a.B = rs.B; a.T = rs.T;
+  hipLaunchKernelGGL(k_lstm_fwd_w2, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+}  // namespace ttrnn

@@ -372,6 +372,14 @@ int launch_ttlinear_bwd_fast(const TtShape& s, int dtype, int dy_dtype, int64_t 
                              const void* x, const void* dy, void* dx, float* d_packed, float* d_bias,
                              hipStream_t stream);
 
+// TT-LSTM forward of the speaker encoder's shape (H = 768, two cores, rank 2, 40 inputs): both chain stages and the input
+// projection inside one persistent kernel, no hoisted K-in (ttrnn_fast_w2.hip)
+bool w2_rnn_fwd_available(const RnnShape& rs, int dtype);
+size_t w2_rnn_fwd_workspace_bytes();
+int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
+                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                      hipStream_t stream);
+
 // chain weight gradients of up to two TT-matrices sharing one pass over dy (ttrnn_fast_c2w.hip, plan: ttrnn_c2w.h)
 bool c2w_prefers_chain(const TtShape& s);      // 2 in out > 1.5 x the chain's FLOPs
 size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only = false);      // 0: the kernel does not take these shapes

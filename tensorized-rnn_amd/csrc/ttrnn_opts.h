@@ -42,7 +42,8 @@ enum OptId {
                          //                         1: no chain weight gradient (ttrnn_rnn_wgrad_workspace answers 0: dense gradients everywhere),
                          //                         2: chain weight gradient for the hidden matrix only (the input matrix keeps its dense pass over dy),
                          //                         4: the chain kernel with the run-time plan even for the shapes that have a compile-time instantiation,
-                         //                         8: offer the chain kernel's LARGE variant too (measured slower than the dense gradient: tests only)
+                         //                         8: offer the chain kernel's LARGE variant too (measured slower than the dense gradient: tests only),
+                         //                         16: the speaker encoder's shape on the runtime tier instead of k_lstm_fwd_w2 (forward), 32: the same for the reverse-time kernel
   OPT_COUNT
 };
 
