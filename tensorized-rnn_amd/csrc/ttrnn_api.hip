@@ -615,6 +615,7 @@ size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_stat
   // the same decisions, in the same order, as ttrnn_rnn_backward_ex: a d_state request takes the runtime-shape / any-shape
   // route whatever the shape, and only then is their (per-sample, much larger) plan part of the answer
   const bool gen = force_generic();
+  if (!want_state && !gen && rs.T > 0 && w2_rnn_bwd_available(rs, desc->dtype)) return w2_rnn_bwd_workspace_bytes();
   const bool g2_first = (opt(OPT_FORCE_G2) || want_state) && !gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
   if (!g2_first && !want_state && !gen && fast_rnn_bwd_available(rs, desc->dtype)) {
     const size_t a = f10_rnn_bwd_workspace_bytes(rs, desc->dtype);     // fused-core fragments (0 for the stage-wise kernels)
@@ -866,6 +867,7 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
   RnnShape rs;
   if (rnn_shape_init(&rs, desc) != TTRNN_OK) return TTRNN_ERR_BAD_DESC;
   if (force_generic()) return TTRNN_ROUTE_VALU;
+  if (!want_state && rs.T > 0 && w2_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_FUSED_CORE;
   const bool g2_first = (opt(OPT_FORCE_G2) || want_state) && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
   if (!g2_first && !want_state && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 && f10_rnn_bwd_available(rs, desc->dtype))
@@ -883,6 +885,7 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
 // the column maxima, and the input_size == 1 sums; the merged-big kernels: the column maxima
 static int bwd_stats_mask(const RnnShape& rs, int dtype) {
   if (force_generic() || opt(OPT_FORCE_G2) || rs.T < 1 || rs.B < 1) return 0;
+  if (w2_rnn_bwd_available(rs, dtype)) return TTRNN_BWD_STATS_COLMAX;
   if (fast_rnn_bwd_available(rs, dtype) && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) &&
       f10_rnn_bwd_available(rs, dtype))
     return TTRNN_BWD_STATS_COLMAX | (rs.in == 1 ? TTRNN_BWD_STATS_IN1SUMS : 0) |
@@ -929,6 +932,12 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   // reverse kernels; a request for it takes those routes (the shape-specialised kernels stay untouched)
   const bool g2_first = (opt(OPT_FORCE_G2) || d_state) && !force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype);
   const bool want_state = d_state != nullptr;
+  if (!want_state && !force_generic() && rs.T > 0 && w2_rnn_bwd_available(rs, desc->dtype)) {
+    // the speaker encoder's shape: wave-local transposed stages, one barrier per step (ttrnn_fast_w2.hip)
+    if (!workspace || workspace_bytes < w2_rnn_bwd_workspace_bytes()) return TTRNN_ERR_WORKSPACE;
+    return launch_rnn_bwd_w2(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_h0, d_c0, workspace, (hipStream_t)stream,
+                             stats);
+  }
   if (!g2_first && !want_state && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&
         f10_rnn_bwd_available(rs, desc->dtype)) {

@@ -331,6 +331,262 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
   }
 }
 
+// ==================================================================================================================================
+// Reverse-time kernel (BPTT of lstm.py:23-32 through the hidden chain) with the same ownership: wave w owns the slice i1 in
+// [16 w, 16 w + 16) of the gate gradients — which are the gradients of ITS OWN units (unit u = r * 64 + i1), so the first transposed
+// stage is wave-local:
+//   gates     dh_t = d_out_t + (sum of the four waves' partial dh of step t + 1), dc_t in a register; the forward record gives
+//             i, g, f, o, c_t, c_{t-1}: the four pre-activation gradients of the lane's three units; written to d_gates;
+//   T2'       dC1^T[i1][(a, j0)] = sum_i0 dz[i0][i1] Gh[i0][j0][a]: the lane's own twelve values are the A operand (k runs over
+//             (row tile, gate) exactly as the lane holds them), scaled under the WAVE's maximum (no barrier) — 24 MFMAs;
+//   hand-off  none: a result tile has (a, j0) on the lane and four consecutive i1 in the registers — the B operand of a
+//             16x16x16 MFMA that sums over i1;
+//   T1        dh^T[j1][j0] (partial: this wave's sixteen i1) = sum_{a, i1} Gt[i1][j1][a] dC1[(a, j0)][i1] — 24 16x16x16 MFMAs;
+//   exchange  the partial dh of the wave as fp32 into LDS (parity buffers), ONE barrier per step; the next step's lanes add the
+//             four partials of their own units.
+// By-products: the column maxima of the gate gradients (ttrnn_rnn_backward_ex: stats rows 0 / 1) — the chain weight-gradient
+// kernel's bound on dy without a pass over the gigabyte of them.
+struct W2B {
+  static constexpr int HDR_BYTES = 256;
+  static constexpr size_t GH_BYTES = (size_t)4 * 2 * 2 * 64 * 16;           // T2' B operand: [n-tile (a, j0 block)][kb][piece][lane] xh8
+  static constexpr size_t GT_BYTES = (size_t)4 * 2 * 2 * 2 * 64 * 8;        // T1 A operand: [wave][a][j1 tile][piece][lane] xh4
+  static constexpr size_t WS_BYTES = HDR_BYTES + GH_BYTES + GT_BYTES;
+  static constexpr int PART = 1024;                                         // floats of a wave's partial dh ([32 j0][32 j1]; 24 rows live)
+  static constexpr int LDS = 2 * 4 * PART * 4 + 64;                         // [parity][wave][PART] + scratch
+};
+enum { W2B_EGH = 0, W2B_EGT = 1, W2B_EL1 = 2 };
+typedef _Float16 w2_xh4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __restrict__ pk_hid, int* __restrict__ hdr,
+                                                  _Float16* __restrict__ ghf, _Float16* __restrict__ gtf) {
+  using S = W2S;
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float mgt = 0.f, mgh = 0.f, l1 = 0.f;
+  for (int e = tid; e < S::I1 * S::J1 * S::R; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
+  for (int e = tid; e < S::I0 * S::J0 * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
+  if (blockIdx.x == 0 && tid < S::J0 * S::R) {              // rows (j0, a) of Gh^T: L1 norms over i0 (bound of dC1)
+    const int j0 = tid / S::R, a = tid % S::R;
+    float s0 = 0.f;
+    for (int i = 0; i < S::I0; ++i) s0 += fabsf(w2_gh(sh, pk_hid, i, j0, a));
+    l1 = s0;
+  }
+  mgt = w2_block_max(mgt, red); mgh = w2_block_max(mgh, red);
+  const int egt = w2_expo(mgt), egh = w2_expo(mgh);
+  if (blockIdx.x == 0) {
+    l1 = w2_block_max(l1, red);
+    if (tid == 0) { hdr[W2B_EGH] = egh; hdr[W2B_EGT] = egt; hdr[W2B_EL1] = w2_expo(l1); }
+  }
+  const int tile = blockIdx.x;
+  if (tile < 8) {            // T2' B operand, tile (nt, kb): B[k][col n]: column (a = nt >> 1, j0 = 16 (nt & 1) + n); k = (kb, g, e)
+    const int nt = tile >> 1, kb = tile & 1;
+    _Float16* dst = ghf + (size_t)tile * 1024;
+    for (int e = tid; e < 512; e += 256) {
+      const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
+      const int a = nt >> 1, j0 = 16 * (nt & 1) + n;
+      // k element j of k-group g: kb 0: row tile tl = j >> 2 (0, 1), gate = j & 3; kb 1: tl = 2, gate = j (j < 4), zero beyond
+      const int tl = kb == 0 ? (j >> 2) : 2, gate = kb == 0 ? (j & 3) : j;
+      float v = 0.f;
+      if (j0 < S::J0 && (kb == 0 || j < 4)) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
+      _Float16 p0, p1;
+      split2h(v, p0, p1);
+      dst[lane * 8 + j] = p0;
+      dst[512 + lane * 8 + j] = p1;
+    }
+  } else if (tile < 8 + 16) {   // T1 A operand (16x16x16), tile (w, a, mt): A[row j1 = 16 mt + n][k = i1 - 16 w = 4 g + j]
+    const int tt = tile - 8, w = tt >> 2, a = (tt >> 1) & 1, mt = tt & 1;
+    _Float16* dst = gtf + (size_t)tt * 512;
+    for (int e = tid; e < 256; e += 256) {
+      const int j = e & 3, lane = e >> 2, n = lane & 15, g = lane >> 4;
+      const float v = w2_gt(sh, pk_hid, 16 * w + 4 * g + j, 16 * mt + n, a) * ldexpf(1.f, 14 - egt);
+      _Float16 p0, p1;
+      split2h(v, p0, p1);
+      dst[lane * 4 + j] = p0;
+      dst[256 + lane * 4 + j] = p1;
+    }
+  }
+}
+
+struct W2BArgs {
+  const float* c0; const float* reserve;
+  const float* d_out; const float* d_hT; const float* d_cT;
+  const int* hdr; const _Float16* ghf; const _Float16* gtf;
+  float* dg; float* d_h0; float* d_c0;
+  unsigned* colmax;          // stats rows 0 and 1 ([2][4H] bit patterns, zeroed by the launcher) or NULL
+  int B, T;
+};
+
+__device__ __forceinline__ f32x4 w2_mma3_16(const w2_xh4 a0, const w2_xh4 a1, const w2_xh4 b0, const w2_xh4 b1, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc, 0, 0, 0);
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
+  using S = W2S;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W2B::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, T = g.T;
+  float* part = reinterpret_cast<float*>(smem);                 // [parity][wave][PART]
+  for (int i = tid; i < 2 * 4 * W2B::PART / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragments ----
+  xh8 gh[4][2][2];
+  w2_xh4 gta[2][2][2];
+  {
+    const xh8* f8 = reinterpret_cast<const xh8*>(g.ghf);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          gh[nt][kb][p] = f8[((size_t)(2 * nt + kb) * 2 + p) * 64 + lane];
+          asm volatile("" : "+v"(gh[nt][kb][p]));
+        }
+    const w2_xh4* f4 = reinterpret_cast<const w2_xh4*>(g.gtf);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          gta[a][mt][p] = f4[((size_t)((wave * 2 + a) * 2 + mt) * 2 + p) * 64 + lane];
+          asm volatile("" : "+v"(gta[a][mt][p]));
+        }
+  }
+  const int egh = g.hdr[W2B_EGH], egt = g.hdr[W2B_EGT], el1 = g.hdr[W2B_EL1];
+  const int shd = egh - el1 - 13;                   // T2' accumulator -> dC1 pieces (the wave's step exponent cancels)
+
+  int unit[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) unit[tl] = (4 * tl + q) * 64 + 16 * wave + n;
+  const size_t rrows = (size_t)g.B * T;
+  const size_t bt0 = (size_t)b * T;
+  // ---- records: gates two steps deep, cell states three; d_out two ----
+  f32x4 G0[S::MT2], G1[S::MT2];
+  float C0[S::MT2], C1[S::MT2], C2[S::MT2], D0[S::MT2], D1[S::MT2];
+  auto ld_gates = [&](int t, int tl) -> f32x4 {
+    return t >= 0 ? *reinterpret_cast<const f32x4*>(g.reserve + res_gate(bt0 + t, S::H, unit[tl])) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto ld_cell = [&](int t, int tl) -> float {
+    if (t >= 0) return g.reserve[res_cell(rrows, bt0 + t, S::H, unit[tl])];
+    return (t == -1 && g.c0) ? g.c0[(size_t)b * S::H + unit[tl]] : 0.f;
+  };
+  auto ld_dout = [&](int t, int tl) -> float {
+    return (t >= 0 && g.d_out) ? g.d_out[(bt0 + t) * S::H + unit[tl]] : 0.f;
+  };
+  float dc[S::MT2], cmx[S::MT2][4];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) {
+    G0[tl] = ld_gates(T - 1, tl); G1[tl] = ld_gates(T - 2, tl);
+    C0[tl] = ld_cell(T - 1, tl); C1[tl] = ld_cell(T - 2, tl); C2[tl] = ld_cell(T - 3, tl);
+    D0[tl] = ld_dout(T - 1, tl); D1[tl] = ld_dout(T - 2, tl);
+    dc[tl] = g.d_cT ? g.d_cT[(size_t)b * S::H + unit[tl]] : 0.f;
+    if (g.d_hT) D0[tl] += g.d_hT[(size_t)b * S::H + unit[tl]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cmx[tl][k] = 0.f;
+  }
+  __syncthreads();
+
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = T - 1; t >= 0; --t) {
+    const int par = t & 1;
+    // the four waves' partial dh of step t + 1 (zero in the first iteration), this lane's units
+    const float* pr = part + par * 4 * W2B::PART;
+    float dz[S::MT2][4];
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      const float dh = D0[tl] + ((pr[unit[tl]] + pr[W2B::PART + unit[tl]]) + (pr[2 * W2B::PART + unit[tl]] + pr[3 * W2B::PART + unit[tl]]));
+      const float ig = G0[tl][0], gg = G0[tl][1], fg = G0[tl][2], og = G0[tl][3];
+      const float tc = ftanh(C0[tl]);
+      const float dov = dh * tc;
+      const float dct = dc[tl] + dh * og * (1.f - tc * tc);
+      dz[tl][0] = dct * gg * ig * (1.f - ig);              // i
+      dz[tl][1] = dct * C1[tl] * fg * (1.f - fg);          // f   (C1 = c_{t-1})
+      dz[tl][2] = dct * ig * (1.f - gg * gg);              // g
+      dz[tl][3] = dov * og * (1.f - og);                   // o
+      dc[tl] = dct * fg;
+      float* dgp = g.dg + (bt0 + t) * (4 * S::H) + unit[tl];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dgp[k * S::H] = dz[tl][k];
+        cmx[tl][k] = fmaxf(cmx[tl][k], fabsf(dz[tl][k]));
+      }
+      // shift the record pipeline and issue the loads of step t - 2 (gates) / t - 3 (cell)
+      G0[tl] = G1[tl]; C0[tl] = C1[tl]; C1[tl] = C2[tl]; D0[tl] = D1[tl];
+      G1[tl] = ld_gates(t - 2, tl);
+      C2[tl] = ld_cell(t - 3, tl);
+      D1[tl] = ld_dout(t - 2, tl);
+    }
+    // ---- the wave's maximum -> exponent; A operand of T2': k-block 0 = row tiles 0, 1 x gates, k-block 1 = row tile 2 x gates ----
+    float m = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(dz[tl][k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int ed = w2_expo(m);
+    const float sd = ldexpf(1.f, 13 - ed);
+    float v0[8], v1[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v0[k] = dz[0][k] * sd; v0[4 + k] = dz[1][k] * sd; v1[k] = dz[2][k] * sd; v1[4 + k] = 0.f; }
+    xh8 a0[2], a1[2];
+    w2_split8(v0, a0[0], a0[1]);
+    w2_split8(v1, a1[0], a1[1]);
+    // ---- T2' + T1 ----
+    f32x4 zt[2][2] = {{z4, z4}, {z4, z4}};           // [j1 tile mt][j0 tile jt]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 d = w2_mma3(a0[0], a0[1], gh[nt][0][0], gh[nt][0][1], z4);
+      d = w2_mma3(a1[0], a1[1], gh[nt][1][0], gh[nt][1][1], d);
+      // lane (column (a, j0), q) holds i1 = 4 q + jj: the B operand of the 16x16x16 product over i1
+      unsigned p0a, p1a, p0b, p1b;
+      split_pair_h(ldexpf(d[0], shd), ldexpf(d[1], shd), p0a, p1a);
+      split_pair_h(ldexpf(d[2], shd), ldexpf(d[3], shd), p0b, p1b);
+      const w2_xh4 b0 = __builtin_bit_cast(w2_xh4, u32x2{p0a, p0b}), b1 = __builtin_bit_cast(w2_xh4, u32x2{p1a, p1b});
+      const int a = nt >> 1, jt = nt & 1;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) zt[mt][jt] = w2_mma3_16(gta[a][mt][0], gta[a][mt][1], b0, b1, zt[mt][jt]);
+    }
+    // ---- the wave's partial dh_{t-1}: unit u = j0 * 32 + j1, four consecutive j1 per lane and tile ----
+    const float us = ldexpf(1.f, egt + el1 + ed - 28);
+    float* pw = part + ((par ^ 1) * 4 + wave) * W2B::PART;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int j0 = 16 * jt + n;
+        if (j0 < S::J0) *reinterpret_cast<f32x4*>(pw + j0 * 32 + 16 * mt + 4 * q) = zt[mt][jt] * us;
+      }
+    lds_barrier();
+  }
+  // d_h0 / d_c0: the recurrent gradients that step 0 left (T even or odd: the parity written last is (0 & 1) ^ 1 = 1; T == 0: zeros)
+  {
+    const float* pr = part + (T > 0 ? 1 : 0) * 4 * W2B::PART;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      if (g.d_h0) {
+        float v = T > 0 ? ((pr[unit[tl]] + pr[W2B::PART + unit[tl]]) + (pr[2 * W2B::PART + unit[tl]] + pr[3 * W2B::PART + unit[tl]])) : 0.f;
+        if (T == 0 && g.d_hT) v = g.d_hT[(size_t)b * S::H + unit[tl]];
+        g.d_h0[(size_t)b * S::H + unit[tl]] = v;
+      }
+      if (g.d_c0) g.d_c0[(size_t)b * S::H + unit[tl]] = dc[tl];
+      if (g.colmax) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          atomicMax(g.colmax + k * S::H + unit[tl], __float_as_uint(cmx[tl][k]));
+          atomicMax(g.colmax + 4 * S::H + k * S::H + unit[tl], __float_as_uint(cmx[tl][k]));
+        }
+      }
+    }
+  }
+}
+
 bool w2_shape(const TtShape& hid, const TtShape& in) {
   using S = W2S;
   return hid.d == 2 && in.d == 2 && hid.J[0] == S::J0 && hid.J[1] == S::J1 && hid.I[0] == S::I0 && hid.I[1] == S::I1 &&
@@ -362,6 +618,33 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
   a.out = (float*)out; a.hT = (float*)hT; a.cT = (float*)cT; a.reserve = reserve;
   a.B = rs.B; a.T = rs.T;
   hipLaunchKernelGGL(k_lstm_fwd_w2, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// reverse-time kernel of the same shape (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)
+bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
+         w2_shape(rs.hid_s, rs.in_s) && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         !(opt(OPT_DEV2) & 32);
+}
+size_t w2_rnn_bwd_workspace_bytes() { return W2B::WS_BYTES; }
+
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
+                      float* stats) {
+  int* hdr = (int*)ws;
+  _Float16* ghf = (_Float16*)((char*)ws + W2B::HDR_BYTES);
+  _Float16* gtf = (_Float16*)((char*)ws + W2B::HDR_BYTES + W2B::GH_BYTES);
+  if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 4 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_w2b_prep, dim3(8 + 16), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  W2BArgs a{};
+  a.c0 = (const float*)c0; a.reserve = reserve;
+  a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT; a.d_cT = (const float*)d_cT;
+  a.hdr = hdr; a.ghf = ghf; a.gtf = gtf;
+  a.dg = dg_in; a.d_h0 = (float*)d_h0; a.d_c0 = (float*)d_c0;
+  a.colmax = (unsigned*)stats;
+  a.B = rs.B; a.T = rs.T;
+  hipLaunchKernelGGL(k_lstm_bwd_w2, dim3(rs.B), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 

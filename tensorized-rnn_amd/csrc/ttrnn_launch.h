@@ -380,6 +380,12 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                       hipStream_t stream);
 
+bool w2_rnn_bwd_available(const RnnShape& rs, int dtype);
+size_t w2_rnn_bwd_workspace_bytes();
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
+                      float* stats);
+
 // chain weight gradients of up to two TT-matrices sharing one pass over dy (ttrnn_fast_c2w.hip, plan: ttrnn_c2w.h)
 bool c2w_prefers_chain(const TtShape& s);      // 2 in out > 1.5 x the chain's FLOPs
 size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only = false);      // 0: the kernel does not take these shapes
