@@ -50,7 +50,7 @@ __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / n
   if (!(x > 0.f) || !(x <= 3.4028235e38f)) return 0;
   int e;
   frexpf(x, &e);
-  return e < -60 ? -60 : (e > 60 ? 60 : e);
+  return e < -100 ? -100 : e;          // (the scales 2^(13 - e), 2^(14 - e) stay normal fp32 numbers over the whole range)
 }
 // packed core k: W_k[(j*R_{k+1} + b)*M_k + i*R_k + a]
 __device__ __forceinline__ float w2_gt(const TtShape& s, const float* pk, int i1, int j1, int a) {
