@@ -153,17 +153,19 @@ constexpr bool c2_layout(C2Plan* p) {
 // SPEC 1: the reference's speaker encoder (experiments/speaker_verification/encoder/params_model.py:2-4,14-16 — 40 mel channels,
 //         H = 768, n_cores = 2, rank = 2; tt_shape: (5, 8) x (48, 64) and (24, 32) x (48, 64)), both matrices of the LSTM layer;
 // SPEC 2: its hidden matrix alone (a TT-GRU's gate gradients differ between the matrices; a layer whose input needs dx).
+// SPEC 3 / 4: the same with rank 4 (the reference's result tables go up to rank 8) — plans of the kernel's large variant.
 template <int SPEC>
 constexpr C2Plan c2_const_plan() {
   C2Plan p{};
-  p.nb = 2; p.big = 0;
-  if (SPEC == 1) {
+  constexpr int R = SPEC >= 3 ? 4 : 2;
+  p.nb = SPEC >= 3 ? 1 : 2; p.big = SPEC >= 3 ? 1 : 0;      // (rank 4: the images of two rows do not fit the LDS)
+  if (SPEC == 1 || SPEC == 3) {
     p.nmat = 2;
-    c2_mat_from(&p.m[0], 2, 1, 5, 8, 48, 64, 2, 40, 3072, 2, 0);
-    c2_mat_from(&p.m[1], 2, 1, 24, 32, 48, 64, 2, 768, 3072, 2, 0);
+    c2_mat_from(&p.m[0], 2, 1, 5, 8, 48, 64, R, 40, 3072, p.nb, p.big);
+    c2_mat_from(&p.m[1], 2, 1, 24, 32, 48, 64, R, 768, 3072, p.nb, p.big);
   } else {
     p.nmat = 1;
-    c2_mat_from(&p.m[0], 2, 1, 24, 32, 48, 64, 2, 768, 3072, 2, 0);
+    c2_mat_from(&p.m[0], 2, 1, 24, 32, 48, 64, R, 768, 3072, p.nb, p.big);
   }
   p.ok = c2_layout(&p) ? 1 : 0;
   return p;

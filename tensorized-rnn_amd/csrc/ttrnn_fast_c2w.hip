@@ -881,7 +881,10 @@ int c2_launch_main(const C2Args& a, hipStream_t stream) {
   void (*kf)(C2Args);
   constexpr int SP = NMAT == 2 ? 1 : 2;
   constexpr C2Plan spk = c2_const_plan<SP>();
-  if (pl.big) kf = k_c2w<0, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  constexpr int SP4 = NMAT == 2 ? 3 : 4;
+  constexpr C2Plan spk4 = c2_const_plan<SP4>();
+  if (pl.big && c2_same_kernel_plan(pl, spk4) && !(opt(OPT_DEV2) & 4)) kf = k_c2w<SP4, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  else if (pl.big) kf = k_c2w<0, NMAT, C2_NW, 8, 2, 2, 8, 2>;
   else if (c2_same_kernel_plan(pl, spk) && !(opt(OPT_DEV2) & 4)) kf = k_c2w<SP, NMAT, C2_NW, 4, 1, 1, 4, 1>;      // (dev2 bit 2: the run-time-plan kernel, A/B)
   else kf = k_c2w<0, NMAT, C2_NW, 4, 1, 1, 4, 1>;
   fn = reinterpret_cast<const void*>(kf);
@@ -912,7 +915,11 @@ bool c2w_prefers_chain(const TtShape& s) {
 size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only) {
   C2Plan pl;
   if (!c2_plan(&pl, shapes, nmat, device_cu_count())) return 0;
-  if (small_only && pl.big) return 0;
+  if (small_only && pl.big) {
+    // ... unless the plan has a compile-time instantiation (rank 4 at the encoder's size: no spills, and ahead of the dense gradient)
+    constexpr C2Plan s3 = c2_const_plan<3>(), s4 = c2_const_plan<4>();
+    if (!c2_same_kernel_plan(pl, pl.nmat == 2 ? s3 : s4)) return 0;
+  }
   return (size_t)pl.ws_bytes;
 }
 
