@@ -31,19 +31,27 @@
 namespace ttrnn {
 namespace {
 
-struct W2S {      // the encoder's shape
-  static constexpr int J0 = 24, J1 = 32, I0 = 48, I1 = 64, R = 2, H = 768;
+// the encoder's shape with R rank slots (2: the published model; 4: ranks 3 and 4 — a smaller real rank fills its slots with zeros)
+template <int R_>
+struct W2T {
+  static constexpr int J0 = 24, J1 = 32, I0 = 48, I1 = 64, R = R_, H = 768;
   static constexpr int J0I = 5, J1I = 8, INP = 40;
   static constexpr int NWV = I1 / 16;          // 4 waves (blockDim = 64 NWV)
   static constexpr int NR = I0 / 4;            // 12 values of r (unit u = r * 64 + i1)
   static constexpr int MT2 = 3;                // stage-2 row tiles: r in [4 t, 4 t + 4) x 4 gates
+  static constexpr int AP = R / 2;             // pairs of rank indices: a k-block of stage 2 = (16 chain rows) x (one pair)
+  static constexpr int KB2 = 2 * AP;           // k-blocks of stage 2
+  static constexpr bool GHL = R > 2;           // stage-2 A fragments in LDS (rank 4: 96 VGPRs otherwise)
   static constexpr int HS = 40;                // row stride (halves) of the state / input images
-  // LDS (bytes): state image [2 parity][2 pieces][32 rows][HS], input image [2][2][16][HS], step exponents of x, scratch
-  static constexpr int L_H = 0, L_X = 2 * 2 * 32 * HS * 2, L_E = L_X + 2 * 2 * 16 * HS * 2, L_RED = L_E + 16, LDS = L_RED + 64;
-  // workspace: header (ints) | fragments xh8 [tile][piece][64 lanes]: 8 tiles Gt (wave, a), 8 tiles Gt_in, 6 tiles Gh (tile, kb)
-  static constexpr int HDR_BYTES = 256, NTILES = 8 + 8 + 6;
+  // LDS (bytes): state image [2 parity][2 pieces][32 rows][HS], input image [2][2][16][HS], step exponents of x, scratch, (fragments)
+  static constexpr int L_H = 0, L_X = 2 * 2 * 32 * HS * 2, L_E = L_X + 2 * 2 * 16 * HS * 2, L_RED = L_E + 16, L_GH = L_RED + 64;
+  static constexpr int GH_BYTES = MT2 * KB2 * 2 * 1024;
+  static constexpr int LDS = L_GH + (GHL ? GH_BYTES : 0);
+  // workspace: header (ints) | fragments xh8 [tile][piece][64 lanes]: 4 R tiles Gt (wave, a), 4 R tiles Gt_in, MT2 KB2 tiles Gh
+  static constexpr int HDR_BYTES = 256, T_GTI = 4 * R, T_GH = 8 * R, NTILES = 8 * R + MT2 * KB2;
   static constexpr size_t WS_BYTES = HDR_BYTES + (size_t)NTILES * 2 * 64 * 16;
 };
+typedef W2T<2> W2S;
 enum { W2_EGT = 0, W2_EC1 = 1, W2_EGTI = 2, W2_ECI = 3, W2_EGH = 4 };
 
 __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / non-finite: neutral; clamped
@@ -73,21 +81,23 @@ __device__ float w2_block_max(float v, float* red) {
 }
 
 // ---- prep: one workgroup per fragment tile (each takes the maxima it needs itself); workgroup 0 also writes the header ----------
+template <int R>
 __global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const float* __restrict__ pk_hid, const float* __restrict__ pk_in,
                                                  int* __restrict__ hdr, _Float16* __restrict__ frag) {
-  using S = W2S;
+  using S = W2T<R>;
   __shared__ float red[256];
   const int tid = threadIdx.x;
+  const int rh = sh.R[1], ri = si.R[1];                  // the real ranks (<= R)
   float mgt = 0.f, mgti = 0.f, mgh = 0.f, l1t = 0.f, l1ti = 0.f;
-  for (int e = tid; e < S::I1 * S::J1 * S::R; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
-  for (int e = tid; e < S::I1 * S::J1I * S::R; e += 256) mgti = fmaxf(mgti, fabsf(pk_in[si.woff[1] + e]));
-  for (int e = tid; e < S::I0 * S::J0 * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
-  for (int e = tid; e < S::I0 * S::J0I * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_in[si.woff[0] + e]));
-  if (blockIdx.x == 0 && tid < S::I1 * S::R) {           // rows (i1, a): L1 norms over j1 (bounds of the stage-1 results)
-    const int i1 = tid / S::R, a = tid % S::R;
+  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
+  for (int e = tid; e < S::I1 * S::J1I * ri; e += 256) mgti = fmaxf(mgti, fabsf(pk_in[si.woff[1] + e]));
+  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
+  for (int e = tid; e < S::I0 * S::J0I * ri; e += 256) mgh = fmaxf(mgh, fabsf(pk_in[si.woff[0] + e]));
+  if (blockIdx.x == 0 && tid < S::I1 * R) {              // rows (i1, a): L1 norms over j1 (bounds of the stage-1 results)
+    const int i1 = tid / R, a = tid % R;
     float s0 = 0.f, s1 = 0.f;
-    for (int j = 0; j < S::J1; ++j) s0 += fabsf(w2_gt(sh, pk_hid, i1, j, a));
-    for (int j = 0; j < S::J1I; ++j) s1 += fabsf(w2_gt(si, pk_in, i1, j, a));
+    if (a < rh) for (int j = 0; j < S::J1; ++j) s0 += fabsf(w2_gt(sh, pk_hid, i1, j, a));
+    if (a < ri) for (int j = 0; j < S::J1I; ++j) s1 += fabsf(w2_gt(si, pk_in, i1, j, a));
     l1t = s0; l1ti = s1;
   }
   mgt = w2_block_max(mgt, red); mgti = w2_block_max(mgti, red); mgh = w2_block_max(mgh, red);
@@ -104,21 +114,22 @@ __global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const f
   for (int e = tid; e < 512; e += 256) {
     const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
     float v = 0.f;
-    if (tile < 8) {                     // stage-1 B operand of the hidden matrix: wave w, rank index a: B[k = j1][n = i1 - 16 w]
-      const int w = tile >> 1, a = tile & 1;
-      v = w2_gt(sh, pk_hid, 16 * w + n, 8 * g + j, a) * ldexpf(1.f, 14 - egt);
-    } else if (tile < 16) {             // the same of the input matrix: k = j1' < 8, zero beyond
-      const int w = (tile - 8) >> 1, a = tile & 1, j1 = 8 * g + j;
-      if (j1 < S::J1I) v = w2_gt(si, pk_in, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egti);
-    } else {                            // stage-2 A operand: row tile tl, k-block kb: A[row = (rr, gate)][k = (g, a, jj)]
-      const int tl = (tile - 16) >> 1, kb = tile & 1;
+    if (tile < S::T_GTI) {              // stage-1 B operand of the hidden matrix: wave w, rank index a: B[k = j1][n = i1 - 16 w]
+      const int w = tile / R, a = tile % R;
+      if (a < rh) v = w2_gt(sh, pk_hid, 16 * w + n, 8 * g + j, a) * ldexpf(1.f, 14 - egt);
+    } else if (tile < S::T_GH) {        // the same of the input matrix: k = j1' < 8, zero beyond
+      const int w = (tile - S::T_GTI) / R, a = (tile - S::T_GTI) % R, j1 = 8 * g + j;
+      if (j1 < S::J1I && a < ri) v = w2_gt(si, pk_in, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egti);
+    } else {                            // stage-2 A operand: row tile tl, k-block kb = (chain-row block mt, rank pair ap): A[row = (rr, gate)][k = (g, a, jj)]
+      const int tl = (tile - S::T_GH) / S::KB2, kb = (tile - S::T_GH) % S::KB2;
+      const int mt = kb / S::AP, ap = kb % S::AP;
       const int rr = n >> 2, gate = n & 3, i0 = gate * S::NR + 4 * tl + rr;
-      const int a = j >> 2, jj = j & 3;
-      if (kb == 0 || g < 2) {
-        v = w2_gh(sh, pk_hid, i0, 16 * kb + 4 * g + jj, a);
+      const int a = 2 * ap + (j >> 2), jj = j & 3;
+      if (mt == 0 || g < 2) {
+        if (a < rh) v = w2_gh(sh, pk_hid, i0, 16 * mt + 4 * g + jj, a);
       } else {
         const int j0 = 4 * (g - 2) + jj;
-        if (j0 < S::J0I) v = w2_gh(si, pk_in, i0, j0, a);
+        if (j0 < S::J0I && a < ri) v = w2_gh(si, pk_in, i0, j0, a);
       }
       v *= ldexpf(1.f, 14 - egh);
     }
@@ -153,8 +164,9 @@ __device__ __forceinline__ void w2_split8(const float (&v)[8], xh8& p0, xh8& p1)
   p1 = __builtin_bit_cast(xh8, u32x4{b[0], b[1], b[2], b[3]});
 }
 
+template <int R>
 __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
-  using S = W2S;
+  using S = W2T<R>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,26 +179,32 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
   constexpr int HP = 32 * S::HS, XP = 16 * S::HS;                     // plane sizes (halves)
   for (int i = tid; i < S::L_E / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragments (pinned in registers) ----
-  xh8 gt[2][2], gti[2][2], gh[S::MT2][2][2];
+  // ---- fragments: stage 1 pinned in registers; stage 2 in registers (rank 2) or in LDS in fragment order (rank 4) ----
+  xh8 gt[R][2], gti[R][2], gh[S::GHL ? 1 : S::MT2][S::GHL ? 1 : S::KB2][2];
   const xh8* fr = reinterpret_cast<const xh8*>(g.frag);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < R; ++a)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      gt[a][p] = fr[((size_t)(2 * wave + a) * 2 + p) * 64 + lane];
-      gti[a][p] = fr[((size_t)(8 + 2 * wave + a) * 2 + p) * 64 + lane];
+      gt[a][p] = fr[((size_t)(R * wave + a) * 2 + p) * 64 + lane];
+      gti[a][p] = fr[((size_t)(S::T_GTI + R * wave + a) * 2 + p) * 64 + lane];
       asm volatile("" : "+v"(gt[a][p]), "+v"(gti[a][p]));
     }
+  if constexpr (S::GHL) {
+    for (int i = tid; i < S::GH_BYTES / 16; i += 256)
+      reinterpret_cast<f32x4*>(smem + S::L_GH)[i] = reinterpret_cast<const f32x4*>(fr + (size_t)S::T_GH * 2 * 64)[i];
+  } else {
 #pragma unroll
-  for (int tl = 0; tl < S::MT2; ++tl)
+    for (int tl = 0; tl < S::MT2; ++tl)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < S::KB2; ++kb)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        gh[tl][kb][p] = fr[((size_t)(16 + 2 * tl + kb) * 2 + p) * 64 + lane];
-        asm volatile("" : "+v"(gh[tl][kb][p]));
-      }
+        for (int p = 0; p < 2; ++p) {
+          gh[tl][kb][p] = fr[((size_t)(S::T_GH + S::KB2 * tl + kb) * 2 + p) * 64 + lane];
+          asm volatile("" : "+v"(gh[tl][kb][p]));
+        }
+  }
+  const xh8* ghl = reinterpret_cast<const xh8*>(smem + S::L_GH);
   const int egt = g.hdr[W2_EGT], ec1 = g.hdr[W2_EC1], egti = g.hdr[W2_EGTI], eci = g.hdr[W2_ECI], egh = g.hdr[W2_EGH];
 
   // ---- the lane's three hidden units (one per stage-2 row tile), their biases and state ----
@@ -256,7 +274,7 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     put_x(0, (lane < S::INP && T > 0) ? xrow[lane] : 0.f);
     if (lane < S::INP && T > 1) xnext = xrow[S::INP + lane];
   }
-  lds_barrier();
+  __syncthreads();
 
   const size_t rrows = (size_t)g.B * T;
   for (int t = 0; t < T; ++t) {
@@ -273,10 +291,10 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     for (int p = 0; p < 2; ++p) ax[p] = w2_ld8(xp + p * XP + n * S::HS + 8 * q);
     const int ex = xexp[par];
     // ---- stage 1 ----
-    f32x4 d[2][2], di[2];
+    f32x4 d[R][2], di[R];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < R; ++a) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) d[a][mt] = w2_mma3(ah[mt][0], ah[mt][1], gt[a][0], gt[a][1], z4);
       di[a] = w2_mma3(ax[0], ax[1], gti[a][0], gti[a][1], z4);
@@ -286,25 +304,39 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     const int ech = ec1 + eh0, ecx = eci + ex;
     const int ec = ech > ecx ? ech : ecx;
     const int sh_ = egt - ec - 13 + eh0, si_ = egti + ex - ec - 13;
-    float v0[8], v1[8];
+    xh8 bop[S::KB2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int ap = 0; ap < S::AP; ++ap) {
+      float v0[8], v1[8];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        v0[4 * a + jj] = ldexpf(d[a][0][jj], sh_);
-        const float hv = ldexpf(d[a][1][jj], sh_), iv = ldexpf(di[a][jj], si_);
-        v1[4 * a + jj] = q < 2 ? hv : iv;
-      }
-    xh8 b0[2], b1[2];
-    w2_split8(v0, b0[0], b0[1]);
-    w2_split8(v1, b1[0], b1[1]);
+      for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int a = 2 * ap + ai;
+          v0[4 * ai + jj] = ldexpf(d[a][0][jj], sh_);
+          const float hv = ldexpf(d[a][1][jj], sh_), iv = ldexpf(di[a][jj], si_);
+          v1[4 * ai + jj] = q < 2 ? hv : iv;
+        }
+      w2_split8(v0, bop[ap][0], bop[ap][1]);
+      w2_split8(v1, bop[S::AP + ap][0], bop[S::AP + ap][1]);
+    }
     // ---- stage 2 + gates ----
     const float zs = ldexpf(1.f, egh + ec - 28);
     const size_t bt = (size_t)b * T + t;
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
-      f32x4 acc = w2_mma3(gh[tl][0][0], gh[tl][0][1], b0[0], b0[1], z4);
-      acc = w2_mma3(gh[tl][1][0], gh[tl][1][1], b1[0], b1[1], acc);
+      f32x4 acc = z4;
+#pragma unroll
+      for (int kb = 0; kb < S::KB2; ++kb) {
+        xh8 a0, a1;
+        if constexpr (S::GHL) {
+          a0 = ghl[((size_t)(S::KB2 * tl + kb) * 2 + 0) * 64 + lane];
+          a1 = ghl[((size_t)(S::KB2 * tl + kb) * 2 + 1) * 64 + lane];
+        } else {
+          a0 = gh[tl][kb][0]; a1 = gh[tl][kb][1];
+        }
+        acc = w2_mma3(a0, a1, bop[kb][0], bop[kb][1], acc);
+      }
       const f32x4 z = acc * zs + bz[tl];
       const float ig = fsigmoid(z[0]), fg = fsigmoid(z[1]), gg = ftanh(z[2]), og = fsigmoid(z[3]);
       const float cy = fg * cst[tl] + ig * gg;
@@ -346,27 +378,34 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
 //             four partials of their own units.
 // By-products: the column maxima of the gate gradients (ttrnn_rnn_backward_ex: stats rows 0 / 1) — the chain weight-gradient
 // kernel's bound on dy without a pass over the gigabyte of them.
-struct W2B {
+template <int R>
+struct W2BT {
+  static constexpr int NT2 = 2 * R;                                         // T2' column tiles: (rank index a, block of sixteen j0)
+  static constexpr bool GHL = R > 2;                                        // T2' B fragments in LDS (rank 4: 128 VGPRs otherwise)
   static constexpr int HDR_BYTES = 256;
-  static constexpr size_t GH_BYTES = (size_t)4 * 2 * 2 * 64 * 16;           // T2' B operand: [n-tile (a, j0 block)][kb][piece][lane] xh8
-  static constexpr size_t GT_BYTES = (size_t)4 * 2 * 2 * 2 * 64 * 8;        // T1 A operand: [wave][a][j1 tile][piece][lane] xh4
+  static constexpr size_t GH_BYTES = (size_t)NT2 * 2 * 2 * 64 * 16;         // T2' B operand: [n-tile][kb][piece][lane] xh8
+  static constexpr size_t GT_BYTES = (size_t)4 * R * 2 * 2 * 64 * 8;        // T1 A operand: [wave][a][j1 tile][piece][lane] xh4
   static constexpr size_t WS_BYTES = HDR_BYTES + GH_BYTES + GT_BYTES;
   static constexpr int PART = 1024;                                         // floats of a wave's partial dh ([32 j0][32 j1]; 24 rows live)
-  static constexpr int LDS = 2 * 4 * PART * 4 + 64;                         // [parity][wave][PART] + scratch
+  static constexpr int L_GH = 2 * 4 * PART * 4 + 64;                        // [parity][wave][PART] + scratch, then (rank 4) the fragments
+  static constexpr int LDS = L_GH + (GHL ? (int)GH_BYTES : 0);
 };
 enum { W2B_EGH = 0, W2B_EGT = 1, W2B_EL1 = 2 };
 typedef _Float16 w2_xh4 __attribute__((ext_vector_type(4)));
 
+template <int R>
 __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __restrict__ pk_hid, int* __restrict__ hdr,
                                                   _Float16* __restrict__ ghf, _Float16* __restrict__ gtf) {
-  using S = W2S;
+  using S = W2T<R>;
+  using Sb = W2BT<R>;
   __shared__ float red[256];
   const int tid = threadIdx.x;
+  const int rh = sh.R[1];
   float mgt = 0.f, mgh = 0.f, l1 = 0.f;
-  for (int e = tid; e < S::I1 * S::J1 * S::R; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
-  for (int e = tid; e < S::I0 * S::J0 * S::R; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
-  if (blockIdx.x == 0 && tid < S::J0 * S::R) {              // rows (j0, a) of Gh^T: L1 norms over i0 (bound of dC1)
-    const int j0 = tid / S::R, a = tid % S::R;
+  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
+  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
+  if (blockIdx.x == 0 && tid < S::J0 * rh) {               // rows (j0, a) of Gh^T: L1 norms over i0 (bound of dC1)
+    const int j0 = tid / rh, a = tid % rh;
     float s0 = 0.f;
     for (int i = 0; i < S::I0; ++i) s0 += fabsf(w2_gh(sh, pk_hid, i, j0, a));
     l1 = s0;
@@ -378,7 +417,7 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
     if (tid == 0) { hdr[W2B_EGH] = egh; hdr[W2B_EGT] = egt; hdr[W2B_EL1] = w2_expo(l1); }
   }
   const int tile = blockIdx.x;
-  if (tile < 8) {            // T2' B operand, tile (nt, kb): B[k][col n]: column (a = nt >> 1, j0 = 16 (nt & 1) + n); k = (kb, g, e)
+  if (tile < Sb::NT2 * 2) {   // T2' B operand, tile (nt, kb): B[k][col n]: column (a = nt >> 1, j0 = 16 (nt & 1) + n); k = (kb, g, e)
     const int nt = tile >> 1, kb = tile & 1;
     _Float16* dst = ghf + (size_t)tile * 1024;
     for (int e = tid; e < 512; e += 256) {
@@ -387,18 +426,18 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
       // k element j of k-group g: kb 0: row tile tl = j >> 2 (0, 1), gate = j & 3; kb 1: tl = 2, gate = j (j < 4), zero beyond
       const int tl = kb == 0 ? (j >> 2) : 2, gate = kb == 0 ? (j & 3) : j;
       float v = 0.f;
-      if (j0 < S::J0 && (kb == 0 || j < 4)) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
+      if (a < rh && j0 < S::J0 && (kb == 0 || j < 4)) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
       _Float16 p0, p1;
       split2h(v, p0, p1);
       dst[lane * 8 + j] = p0;
       dst[512 + lane * 8 + j] = p1;
     }
-  } else if (tile < 8 + 16) {   // T1 A operand (16x16x16), tile (w, a, mt): A[row j1 = 16 mt + n][k = i1 - 16 w = 4 g + j]
-    const int tt = tile - 8, w = tt >> 2, a = (tt >> 1) & 1, mt = tt & 1;
+  } else if (tile < Sb::NT2 * 2 + 4 * R * 2) {   // T1 A operand (16x16x16), tile (w, a, mt): A[row j1 = 16 mt + n][k = i1 - 16 w = 4 g + j]
+    const int tt = tile - Sb::NT2 * 2, w = tt / (2 * R), a = (tt >> 1) % R, mt = tt & 1;
     _Float16* dst = gtf + (size_t)tt * 512;
     for (int e = tid; e < 256; e += 256) {
       const int j = e & 3, lane = e >> 2, n = lane & 15, g = lane >> 4;
-      const float v = w2_gt(sh, pk_hid, 16 * w + 4 * g + j, 16 * mt + n, a) * ldexpf(1.f, 14 - egt);
+      const float v = a < rh ? w2_gt(sh, pk_hid, 16 * w + 4 * g + j, 16 * mt + n, a) * ldexpf(1.f, 14 - egt) : 0.f;
       _Float16 p0, p1;
       split2h(v, p0, p1);
       dst[lane * 4 + j] = p0;
@@ -423,41 +462,50 @@ __device__ __forceinline__ f32x4 w2_mma3_16(const w2_xh4 a0, const w2_xh4 a1, co
   return acc;
 }
 
+template <int R>
 __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
-  using S = W2S;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[W2B::LDS];
+  using S = W2T<R>;
+  using Sb = W2BT<R>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char w2b_smem[];      // Sb::LDS bytes (rank 4: 64 KB + scratch: above the static limit)
+  unsigned char* smem = w2b_smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int b = blockIdx.x, T = g.T;
   float* part = reinterpret_cast<float*>(smem);                 // [parity][wave][PART]
-  for (int i = tid; i < 2 * 4 * W2B::PART / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2 * 4 * Sb::PART / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragments ----
-  xh8 gh[4][2][2];
-  w2_xh4 gta[2][2][2];
+  xh8 gh[Sb::GHL ? 1 : Sb::NT2][2][2];
+  w2_xh4 gta[R][2][2];
   {
     const xh8* f8 = reinterpret_cast<const xh8*>(g.ghf);
+    if constexpr (Sb::GHL) {
+      for (int i = tid; i < (int)(Sb::GH_BYTES / 16); i += 256)
+        reinterpret_cast<f32x4*>(smem + Sb::L_GH)[i] = reinterpret_cast<const f32x4*>(f8)[i];
+    } else {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < Sb::NT2; ++nt)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          gh[nt][kb][p] = f8[((size_t)(2 * nt + kb) * 2 + p) * 64 + lane];
-          asm volatile("" : "+v"(gh[nt][kb][p]));
-        }
+          for (int p = 0; p < 2; ++p) {
+            gh[nt][kb][p] = f8[((size_t)(2 * nt + kb) * 2 + p) * 64 + lane];
+            asm volatile("" : "+v"(gh[nt][kb][p]));
+          }
+    }
     const w2_xh4* f4 = reinterpret_cast<const w2_xh4*>(g.gtf);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < R; ++a)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          gta[a][mt][p] = f4[((size_t)((wave * 2 + a) * 2 + mt) * 2 + p) * 64 + lane];
+          gta[a][mt][p] = f4[((size_t)((wave * R + a) * 2 + mt) * 2 + p) * 64 + lane];
           asm volatile("" : "+v"(gta[a][mt][p]));
         }
   }
+  const xh8* ghl = reinterpret_cast<const xh8*>(smem + Sb::L_GH);
   const int egh = g.hdr[W2B_EGH], egt = g.hdr[W2B_EGT], el1 = g.hdr[W2B_EL1];
   const int shd = egh - el1 - 13;                   // T2' accumulator -> dC1 pieces (the wave's step exponent cancels)
 
@@ -496,11 +544,11 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   for (int t = T - 1; t >= 0; --t) {
     const int par = t & 1;
     // the four waves' partial dh of step t + 1 (zero in the first iteration), this lane's units
-    const float* pr = part + par * 4 * W2B::PART;
+    const float* pr = part + par * 4 * Sb::PART;
     float dz[S::MT2][4];
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
-      const float dh = D0[tl] + ((pr[unit[tl]] + pr[W2B::PART + unit[tl]]) + (pr[2 * W2B::PART + unit[tl]] + pr[3 * W2B::PART + unit[tl]]));
+      const float dh = D0[tl] + ((pr[unit[tl]] + pr[Sb::PART + unit[tl]]) + (pr[2 * Sb::PART + unit[tl]] + pr[3 * Sb::PART + unit[tl]]));
       const float ig = G0[tl][0], gg = G0[tl][1], fg = G0[tl][2], og = G0[tl][3];
       const float tc = ftanh(C0[tl]);
       const float dov = dh * tc;
@@ -541,9 +589,16 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
     // ---- T2' + T1 ----
     f32x4 zt[2][2] = {{z4, z4}, {z4, z4}};           // [j1 tile mt][j0 tile jt]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 d = w2_mma3(a0[0], a0[1], gh[nt][0][0], gh[nt][0][1], z4);
-      d = w2_mma3(a1[0], a1[1], gh[nt][1][0], gh[nt][1][1], d);
+    for (int nt = 0; nt < Sb::NT2; ++nt) {
+      xh8 b00, b01, b10, b11;
+      if constexpr (Sb::GHL) {
+        b00 = ghl[((size_t)(2 * nt + 0) * 2 + 0) * 64 + lane]; b01 = ghl[((size_t)(2 * nt + 0) * 2 + 1) * 64 + lane];
+        b10 = ghl[((size_t)(2 * nt + 1) * 2 + 0) * 64 + lane]; b11 = ghl[((size_t)(2 * nt + 1) * 2 + 1) * 64 + lane];
+      } else {
+        b00 = gh[nt][0][0]; b01 = gh[nt][0][1]; b10 = gh[nt][1][0]; b11 = gh[nt][1][1];
+      }
+      f32x4 d = w2_mma3(a0[0], a0[1], b00, b01, z4);
+      d = w2_mma3(a1[0], a1[1], b10, b11, d);
       // lane (column (a, j0), q) holds i1 = 4 q + jj: the B operand of the 16x16x16 product over i1
       unsigned p0a, p1a, p0b, p1b;
       split_pair_h(ldexpf(d[0], shd), ldexpf(d[1], shd), p0a, p1a);
@@ -555,7 +610,7 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
     }
     // ---- the wave's partial dh_{t-1}: unit u = j0 * 32 + j1, four consecutive j1 per lane and tile ----
     const float us = ldexpf(1.f, egt + el1 + ed - 28);
-    float* pw = part + ((par ^ 1) * 4 + wave) * W2B::PART;
+    float* pw = part + ((par ^ 1) * 4 + wave) * Sb::PART;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -565,13 +620,13 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
       }
     lds_barrier();
   }
-  // d_h0 / d_c0: the recurrent gradients that step 0 left (T even or odd: the parity written last is (0 & 1) ^ 1 = 1; T == 0: zeros)
+  // d_h0 / d_c0: the recurrent gradients that step 0 left (the parity written last is (0 & 1) ^ 1 = 1; T == 0: nothing ran)
   {
-    const float* pr = part + (T > 0 ? 1 : 0) * 4 * W2B::PART;
+    const float* pr = part + (T > 0 ? 1 : 0) * 4 * Sb::PART;
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
       if (g.d_h0) {
-        float v = T > 0 ? ((pr[unit[tl]] + pr[W2B::PART + unit[tl]]) + (pr[2 * W2B::PART + unit[tl]] + pr[3 * W2B::PART + unit[tl]])) : 0.f;
+        float v = T > 0 ? ((pr[unit[tl]] + pr[Sb::PART + unit[tl]]) + (pr[2 * Sb::PART + unit[tl]] + pr[3 * Sb::PART + unit[tl]])) : 0.f;
         if (T == 0 && g.d_hT) v = g.d_hT[(size_t)b * S::H + unit[tl]];
         g.d_h0[(size_t)b * S::H + unit[tl]] = v;
       }
@@ -587,29 +642,33 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   }
 }
 
-bool w2_shape(const TtShape& hid, const TtShape& in) {
+// ranks 1 .. 4 of the encoder's modes: the rank-2 instantiation up to 2, the rank-4 one above (zero-padded rank slots)
+int w2_rank_slots(const TtShape& hid, const TtShape& in) {
   using S = W2S;
-  return hid.d == 2 && in.d == 2 && hid.J[0] == S::J0 && hid.J[1] == S::J1 && hid.I[0] == S::I0 && hid.I[1] == S::I1 &&
-         hid.R[1] == S::R && in.J[0] == S::J0I && in.J[1] == S::J1I && in.I[0] == S::I0 && in.I[1] == S::I1 && in.R[1] == S::R;
+  if (!(hid.d == 2 && in.d == 2 && hid.J[0] == S::J0 && hid.J[1] == S::J1 && hid.I[0] == S::I0 && hid.I[1] == S::I1 &&
+        in.J[0] == S::J0I && in.J[1] == S::J1I && in.I[0] == S::I0 && in.I[1] == S::I1))
+    return 0;
+  const int r = hid.R[1] > in.R[1] ? hid.R[1] : in.R[1];
+  return r <= 2 ? 2 : (r <= 4 ? 4 : 0);
 }
-
 }  // namespace
 
 // the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's shape
 bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
   return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
-         w2_shape(rs.hid_s, rs.in_s) && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         w2_rank_slots(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
          !(opt(OPT_DEV2) & 16);
 }
-size_t w2_rnn_fwd_workspace_bytes() { return W2S::WS_BYTES; }
+size_t w2_rnn_fwd_workspace_bytes() { return W2T<4>::WS_BYTES; }      // (the larger of the two instantiations: the query has no shape)
 
-int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
-                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                      hipStream_t stream) {
-  using S = W2S;
+template <int R>
+static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
+                           const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                           hipStream_t stream) {
+  using S = W2T<R>;
   int* hdr = (int*)ws;
   _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
-  hipLaunchKernelGGL(k_w2_prep, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  hipLaunchKernelGGL(k_w2_prep<R>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
   W2Args a{};
   a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = (const float*)c0;
   a.bias_in = rs.has_bias_in ? (const float*)bias_in : nullptr;
@@ -617,26 +676,36 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
   a.hdr = hdr; a.frag = frag;
   a.out = (float*)out; a.hT = (float*)hT; a.cT = (float*)cT; a.reserve = reserve;
   a.B = rs.B; a.T = rs.T;
-  hipLaunchKernelGGL(k_lstm_fwd_w2, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
+  hipLaunchKernelGGL(k_lstm_fwd_w2<R>, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
+                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                      hipStream_t stream) {
+  return w2_rank_slots(rs.hid_s, rs.in_s) == 2
+             ? launch_fwd_w2_t<2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream)
+             : launch_fwd_w2_t<4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
 }
 
 // reverse-time kernel of the same shape (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)
 bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
   return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
-         w2_shape(rs.hid_s, rs.in_s) && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         w2_rank_slots(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
          !(opt(OPT_DEV2) & 32);
 }
-size_t w2_rnn_bwd_workspace_bytes() { return W2B::WS_BYTES; }
+size_t w2_rnn_bwd_workspace_bytes() { return W2BT<4>::WS_BYTES; }
 
-int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
-                      float* stats) {
+template <int R>
+static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                           const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
+                           float* stats) {
+  using Sb = W2BT<R>;
   int* hdr = (int*)ws;
-  _Float16* ghf = (_Float16*)((char*)ws + W2B::HDR_BYTES);
-  _Float16* gtf = (_Float16*)((char*)ws + W2B::HDR_BYTES + W2B::GH_BYTES);
+  _Float16* ghf = (_Float16*)((char*)ws + Sb::HDR_BYTES);
+  _Float16* gtf = (_Float16*)((char*)ws + Sb::HDR_BYTES + Sb::GH_BYTES);
   if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 4 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_w2b_prep, dim3(8 + 16), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  hipLaunchKernelGGL(k_w2b_prep<R>, dim3(Sb::NT2 * 2 + 4 * R * 2), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
   W2BArgs a{};
   a.c0 = (const float*)c0; a.reserve = reserve;
   a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT; a.d_cT = (const float*)d_cT;
@@ -644,8 +713,17 @@ int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hi
   a.dg = dg_in; a.d_h0 = (float*)d_h0; a.d_c0 = (float*)d_c0;
   a.colmax = (unsigned*)stats;
   a.B = rs.B; a.T = rs.T;
-  hipLaunchKernelGGL(k_lstm_bwd_w2, dim3(rs.B), dim3(256), 0, stream, a);
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_w2<R>), Sb::LDS) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_lstm_bwd_w2<R>, dim3(rs.B), dim3(256), Sb::LDS, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
+                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
+                      float* stats) {
+  return w2_rank_slots(rs.hid_s, rs.in_s) == 2
+             ? launch_bwd_w2_t<2>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats)
+             : launch_bwd_w2_t<4>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
 }
 
 }  // namespace ttrnn
