@@ -70,6 +70,11 @@ WORKLOADS = {
                      desc="naive per-gate TT-LSTM (tt_linearset.py) in=256 H=512 ncores=3 ttrank=8 seq_len=160 batch=512/GPU fp32 (benchmarking.py --naive_tt)"),
     "r16_512": dict(kind="ttlstm", inp=256, H=512, L=1, d=3, r=16, B=512, T=160, dtype="f32", flop=13769216,
                     desc="TT-LSTM in=256 H=512 ncores=3 ttrank=16 seq_len=160 batch=512/GPU fp32 (benchmarking.py --ttrank 16)"),
+    # the reference's own published encoder layer (experiments/speaker_verification/encoder/params_model.py:2-4,14-16: 40 mel channels,
+    # hidden 768, ONE layer, n_cores 2, rank 2; 160-frame partial utterances, speaker_encoder.py:42-48) at the cfg4 batch.  FLOP per
+    # sample-timestep (SURVEY 8(d) rule): hidden 2*24*128*32 + 2*64*48*48 = 491 520, input 2*5*128*8 + 2*64*48*10 = 71 680, + 13 H
+    "spk": dict(kind="ttlstm", inp=40, H=768, L=1, d=2, r=2, B=512, T=160, dtype="f32", flop=573184, flop_in=71680,
+                desc="TT-LSTM in=40 H=768 ncores=2 ttrank=2 seq_len=160 batch=512/GPU fp32 (the reference's speaker-encoder layer, params_model.py)"),
 }
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0
@@ -118,6 +123,11 @@ EXECUTED = {
                      pipe16="f16_mfma", terms=3,
                      note="runtime tier, two samples per eight-wave workgroup: the block-diagonal head (512 KB of fp16 pieces) streamed from L2 "
                           "once per step for both; bound by the L2 -> CU path (55 of 64 B/clk in stage 2), not by the matrix pipe"),
+    # k_lstm_fwd_w2<2> (round 6): per wave stage 1 (2 ranks x 2 row blocks + 2 input tiles) x 3 terms = 18, stage 2 3 tiles x 2 k-blocks
+    # x 3 terms = 18; four waves per sample, two workgroups per CU; no K-in at all (the input chain rides in the hidden chain's padding)
+    "spk": dict(bf16_mfma=4 * 36, fp32_mfma=0, kin_bf16_flop=0, rec_simds=4, rec_wgs_per_cu=2, pipe16="f16_mfma", terms=3,
+                note="two-core kernel with wave-local stages on two-piece fp16 operands (k_lstm_fwd_w2): register-local hand-off, the "
+                     "input projection inside the recurrent kernel, one barrier per step"),
     "r16_512": dict(bf16_mfma=64 + 256 * 6 // 2, fp32_mfma=0, kin_bf16_flop=3 * 2 * 2048 * 256, rec_simds=4, rec_wgs_per_sample=0.5,
                     pipe16="f16_mfma", terms=3,
                     note="runtime tier, two samples per eight-wave workgroup in two column tiles: the head (512 KB of fp16 pieces) streamed "

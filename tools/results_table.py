@@ -6,14 +6,16 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r5"
-PREV = {"cfg1": (0.384, 1.06), "cfg2": (0.520, 1.66), "cfg3": (0.483, 1.90), "cfg3_fp32": (0.99, None), "cfg4": (1.58, 5.04), "cfg5": (6.69, 20.5)}      # round 4
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r6"
+PREV = {"cfg1": (0.369, 1.04), "cfg2": (0.493, 1.64), "cfg3": (0.473, 1.88), "cfg3_fp32": (0.652, 2.11), "cfg4": (1.555, 4.94), "cfg5": (7.039, 20.85),
+        "spk": (1.44, 5.53)}      # round 5 (spk: the harness figures of profiles/r5/variants_benchmarking.txt)
 NAMES = {"cfg1": "cfg1 TT-LSTM H=128 d=2 r=4 B=32 T=784 fp32", "cfg2": "**cfg2** TT-LSTM H=256 d=3 r=8 B=64 T=784 fp32 (headline)",
          "cfg3": "cfg3 TT-GRU H=256 d=3 r=8 B=256 T=784 bf16", "cfg4": "cfg4 3-layer TT-LSTM H=256 r=16 in=40 B=512 T=160",
          "cfg5": "cfg5 TT-LSTM H=in=1024 d=4 r=32 B=128 T=1024",
-         "cfg3_fp32": "cfg3 in the reference's own dtype: TT-GRU H=256 d=3 r=8 B=256 T=784 fp32"}
+         "cfg3_fp32": "cfg3 in the reference's own dtype: TT-GRU H=256 d=3 r=8 B=256 T=784 fp32",
+         "spk": "the reference's speaker-encoder layer: TT-LSTM in=40 H=768 d=2 r=2 B=512 T=160 fp32"}
 KERN = {"cfg1": "k_lstm_fwd_f2", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10v", "cfg3_fp32": "k_gru_fwd_f10vh", "cfg4": "k_lstm_fwd_f10q",
-        "cfg5": "k_lstm_fwd_big2h"}
+        "cfg5": "k_lstm_fwd_big2h", "spk": "k_lstm_fwd_w2"}
 
 
 def line(path):
@@ -32,15 +34,15 @@ def kernel_avg(w):
 
 
 print("| workload (per GPU) | forward ms / step (prepared) | timesteps/s | `exact` mode ms | roofline frac (basis) / algorithmic / executed; chip occupancy | "
-      "dominant kernel, rocprof avg µs (calls) | HBM bytes per call (PMC) / algorithmic | train step ms | round 4: fwd / train |")
+      "dominant kernel, rocprof avg µs (calls) | HBM bytes per call (PMC) / algorithmic | train step ms | round 5: fwd / train |")
 print("|---|---|---|---|---|---|---|---|---|")
-for w in ("cfg2", "cfg1", "cfg3", "cfg3_fp32", "cfg4", "cfg5"):
+for w in ("cfg2", "spk", "cfg1", "cfg3", "cfg3_fp32", "cfg4", "cfg5"):
     f = line(os.path.join(src, "bench_%s.json" % w))
     tp = os.path.join(src, "bench_train_%s.json" % w)
     t = line(tp) if os.path.exists(tp) else None
     ka = kernel_avg(w)
     ex = (f.get("other_fp32_math") or {}).get("ms_per_step")
-    algo = {"cfg1": 516, "cfg2": 1028, "cfg3": 514, "cfg3_fp32": 1028, "cfg4": 1184, "cfg5": 8192}[w] * f["config"]["per_gpu_batch"] * f["config"]["seq_len"]
+    algo = {"cfg1": 516, "cfg2": 1028, "cfg3": 514, "cfg3_fp32": 1028, "cfg4": 1184, "cfg5": 8192, "spk": 3232}[w] * f["config"]["per_gpu_batch"] * f["config"]["seq_len"]
     exe = (f["roofline"].get("executed") or {}).get("frac")
     r = f["roofline"]
     if not r.get("traffic"):      # (a workload whose PMC summary was taken after its bench line: profiles/traffic.json has it)

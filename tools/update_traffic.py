@@ -11,8 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REC = {"cfg1": "k_lstm_fwd_f2", "cfg2": "k_lstm_fwd_f10q", "cfg3": "k_gru_fwd_f10", "cfg3_fp32": "k_gru_fwd_f10vh", "cfg4": "k_lstm_fwd_f10q",
-       "cfg5": "k_lstm_fwd_big2h"}
-LAYERS = {"cfg1": 1, "cfg2": 1, "cfg3": 1, "cfg3_fp32": 1, "cfg4": 3, "cfg5": 1}
+       "cfg5": "k_lstm_fwd_big2h", "spk": "k_lstm_fwd_w2"}
+LAYERS = {"cfg1": 1, "cfg2": 1, "cfg3": 1, "cfg3_fp32": 1, "cfg4": 3, "cfg5": 1, "spk": 1}
 # kernels of the OTHER math mode that bench.py also times in the same process (not part of the default forward)
 SKIP = ("k_lstm_fwd_f10x", "k_f10x_prep", "k_lstm_fwd_fused", "k_ttlinear_fwd_fast[J=4x8x8", "k_ttlinear_fwd_fast[J=2x4x5", "k_lstm_fwd_big2[",
         "k_ttlinear_fwd_big", "k_rnn_fwd_fast", "k_rnn_fwd_bf16")

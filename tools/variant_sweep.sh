@@ -16,5 +16,8 @@ run $mode --in_size 1 --hidden_size 256 --seq_len 784 --batch_size 64 --naive_tt
 run $mode --in_size 1 --hidden_size 256 --seq_len 784 --batch_size 64 --naive_tt --gru
 run $mode --in_size 40 --hidden_size 768 --ncores 4
 run $mode --in_size 40 --hidden_size 768 --ncores 2 --ttrank 2
+run $mode --in_size 40 --hidden_size 768 --ncores 2 --ttrank 4
+run $mode --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4
+run $mode --in_size 40 --hidden_size 768 --ncores 2 --ttrank 2 --gru
 run $mode --n_layers 2 --hidden_size 384
 done
