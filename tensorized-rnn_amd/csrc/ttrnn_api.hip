@@ -646,6 +646,7 @@ size_t ttrnn_rnn_reserve_bytes(const ttrnn_rnn_desc* desc) {
 
 // does the forward route of this descriptor separate its weight-only launches (TTRNN_PHASE_*)?
 static bool phase_split_ok(const RnnShape& rs, int dtype) {
+  if (w2_rnn_fwd_available(rs, dtype)) return true;      // (its one weight-only launch: header + fragments)
   if (fwd_prefers_g2(rs, dtype)) return false;
   const FastFwdPlan f = plan_fast_fwd(rs, dtype);
   return f.use && f.in1 && (fp32_math() == TTRNN_MATH_SPLIT || dtype == TTRNN_BF16) && f10_rnn_fwd_available(rs, dtype);
@@ -697,10 +698,9 @@ int ttrnn_rnn_forward_phase(const ttrnn_rnn_desc* desc, int phase, const void* x
   if (rs.has_bias_hid && !bias_hid) return TTRNN_ERR_NULL;
   if (rs.T > 0 && w2_rnn_fwd_available(rs, desc->dtype)) {
     // the speaker encoder's shape: chain stages AND input projection in one persistent kernel (no K-in, no [B][T][4H] buffer)
-    if (phase == TTRNN_PHASE_PREPARE) return TTRNN_OK;
     if (!workspace || workspace_bytes < w2_rnn_fwd_workspace_bytes()) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_fwd_w2(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, workspace,
-                             (hipStream_t)stream);
+                             (hipStream_t)stream, phase);
   }
   const bool g2_first = fwd_prefers_g2(rs, desc->dtype);
   const FastFwdPlan f = g2_first ? FastFwdPlan{} : plan_fast_fwd(rs, desc->dtype);

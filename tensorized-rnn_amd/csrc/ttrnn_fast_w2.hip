@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
       float v = 0.f;
       if (g.bias_in) v += g.bias_in[gate * S::H + unit[tl]];
       if (g.bias_hid) v += g.bias_hid[gate * S::H + unit[tl]];
-      bz[tl][gate] = v;
+      // the gates' exponent factors ride on the bias and on the step's un-scale: sigmoid(z) = 1 / (1 + 2^(-log2e z)),
+      // tanh(z) = 1 - 2 / (1 + 2^(2 log2e z)) — the accumulator x factor + bias x factor IS the v_exp_f32 argument
+      bz[tl][gate] = v * (gate == 2 ? 2.8853900817779268f : -1.4426950408889634f);
     }
     cst[tl] = g.c0 ? g.c0[(size_t)b * S::H + unit[tl]] : 0.f;
     hval[tl] = g.h0 ? g.h0[(size_t)b * S::H + unit[tl]] : 0.f;
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     }
     // ---- stage 2 + gates ----
     const float zs = ldexpf(1.f, egh + ec - 28);
+    const f32x4 zsv = f32x4{-1.4426950408889634f * zs, -1.4426950408889634f * zs, 2.8853900817779268f * zs, -1.4426950408889634f * zs};
     const size_t bt = (size_t)b * T + t;
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
@@ -337,8 +340,10 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
         }
         acc = w2_mma3(a0, a1, bop[kb][0], bop[kb][1], acc);
       }
-      const f32x4 z = acc * zs + bz[tl];
-      const float ig = fsigmoid(z[0]), fg = fsigmoid(z[1]), gg = ftanh(z[2]), og = fsigmoid(z[3]);
+      const f32x4 z = acc * zsv + bz[tl];
+      const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[0])), fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[1]));
+      const float gg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[2]));
+      const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[3]));
       const float cy = fg * cst[tl] + ig * gg;
       const float hy = og * ftanh(cy);
       cst[tl] = cy;
@@ -661,14 +666,18 @@ bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
 }
 size_t w2_rnn_fwd_workspace_bytes() { return W2T<4>::WS_BYTES; }      // (the larger of the two instantiations: the query has no shape)
 
+// phase: TTRNN_PHASE_ALL / _PREPARE (the weight-only launch: header + fragments into the workspace) / _RUN (the recurrent kernel on a
+// workspace a PREPARE call has filled: prepare_for_inference() modules — ONE launch per forward)
 template <int R>
 static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                            const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                           hipStream_t stream) {
+                           hipStream_t stream, int phase) {
   using S = W2T<R>;
   int* hdr = (int*)ws;
   _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
-  hipLaunchKernelGGL(k_w2_prep<R>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  if (phase != TTRNN_PHASE_RUN)
+    hipLaunchKernelGGL(k_w2_prep<R>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   W2Args a{};
   a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = (const float*)c0;
   a.bias_in = rs.has_bias_in ? (const float*)bias_in : nullptr;
@@ -682,10 +691,10 @@ static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, co
 
 int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                      hipStream_t stream) {
+                      hipStream_t stream, int phase) {
   return w2_rank_slots(rs.hid_s, rs.in_s) == 2
-             ? launch_fwd_w2_t<2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream)
-             : launch_fwd_w2_t<4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream);
+             ? launch_fwd_w2_t<2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase)
+             : launch_fwd_w2_t<4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
 }
 
 // reverse-time kernel of the same shape (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)

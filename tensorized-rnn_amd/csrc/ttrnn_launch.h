@@ -378,7 +378,7 @@ bool w2_rnn_fwd_available(const RnnShape& rs, int dtype);
 size_t w2_rnn_fwd_workspace_bytes();
 int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                      hipStream_t stream);
+                      hipStream_t stream, int phase = 0 /* TTRNN_PHASE_ALL */);
 
 bool w2_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t w2_rnn_bwd_workspace_bytes();

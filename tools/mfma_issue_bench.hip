@@ -22,6 +22,11 @@ __global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, i
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if constexpr (SHAPE == 16) acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u % CHAINS], 0, 0, 0);
+      else if constexpr (SHAPE == 1616) {      // v_mfma_f32_16x16x16_f16 (round 6: the reverse kernel's T1 of ttrnn_fast_w2.hip)
+        typedef _Float16 xh4 __attribute__((ext_vector_type(4)));
+        const xh4 a4 = xh4{a[0], a[1], a[2], a[3]}, b4 = xh4{b[0], b[1], b[2], b[3]};
+        acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[u % CHAINS], 0, 0, 0);
+      }
       else big[u % (CHAINS > 2 ? 2 : CHAINS)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, big[u % (CHAINS > 2 ? 2 : CHAINS)], 0, 0, 0);
     }
   }
@@ -48,7 +53,7 @@ void run(const char* name, int threads, unsigned long long* d, float* sink) {
   hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[8];
   hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  const double flops = 256.0 * (threads / 64) * iters * 8.0 * 16384.0 * (SHAPE == 16 ? 1 : 2);
+  const double flops = 256.0 * (threads / 64) * iters * 8.0 * 16384.0 * (SHAPE == 16 ? 1.0 : SHAPE == 1616 ? 0.5 : 2.0);
   printf("%-40s %d waves/SIMD: %.1f ticks per MFMA per wave, %.3f ms, %.0f TFLOP/s, %.2f GHz ticks\n", name, threads / 256,
          (double)h[0] / (iters * 8.0), ms, flops / ms * 1e-9, (double)h[0] / ms * 1e-6);
 }
@@ -60,6 +65,8 @@ int main() {
     run<1, 16>("16x16x32 f16, one accumulator chain", threads, d, sink);
     run<2, 16>("16x16x32 f16, two chains", threads, d, sink);
     run<4, 16>("16x16x32 f16, four chains", threads, d, sink);
+    run<1, 1616>("16x16x16 f16, one accumulator chain", threads, d, sink);
+    run<4, 1616>("16x16x16 f16, four chains", threads, d, sink);
     run<1, 32>("32x32x16 f16, one chain", threads, d, sink);
     run<2, 32>("32x32x16 f16, two chains", threads, d, sink);
   }
