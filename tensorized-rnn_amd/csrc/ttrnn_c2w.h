@@ -41,7 +41,8 @@ struct C2Mat {
   int QR, PR;                            // rows per sample of the C1 / dC1 image (QT*16, PT*16)
   int xs_rows;                           // rows of the x image (>= nb*JhP: tile / k-block overreach lands on zero rows)
   int in, out;
-  int EX;                                // x quads per thread and block
+  int EX;                                // x quads (xelem: x elements) per thread and block
+  int xelem;                             // J_t not a multiple of 4 (the four-core input matrix, J_t = 10): x is staged element by element
   long head_elems, tail_elems;           // merged cores, fp32: Gh[Ih][Jh][R], Gt[It][Jt][R]
   // LDS byte offsets of this matrix's own regions
   int l_xs, l_ghf, l_tab, l_c1, l_dc1;   // (the C1 / dC1 images are per matrix: both matrices run their phases between the same two barriers)
@@ -82,7 +83,8 @@ constexpr bool c2_mat_from(C2Mat* m, int d, int sp, int Jh, int Jt, int Ih, int 
   m->Jh = Jh; m->Jt = Jt; m->Ih = Ih; m->It = It; m->R = R;
   m->in = in; m->out = out;
   if (R > C2_MAX_R) return false;
-  if (It % 16 != 0 || Jt % 4 != 0) return false;                 // column tiles of B inside one row; x quads inside one j_h
+  if (It % 16 != 0) return false;                                // column tiles of B inside one row
+  m->xelem = Jt % 4 != 0 ? 1 : 0;                                // x quads must lie inside one j_h row: else element by element
   if ((nb * It) % 32 != 0) return false;
   m->JhP = (Jh + 7) & ~7; m->JtP = (Jt + 7) & ~7;
   m->P = R * It; m->Q = R * m->JhP;
@@ -100,8 +102,8 @@ constexpr bool c2_mat_from(C2Mat* m, int d, int sp, int Jh, int Jt, int Ih, int 
   m->XS = 32 * m->KA + 8; m->CS1 = It + 8; m->CS2 = (m->JhP % 16 == 8) ? m->JhP : m->JhP + 8;
   m->QR = m->QT * 16; m->PR = m->PT * 16;
   m->xs_rows = m->NA * 16 > m->KD * 32 ? m->NA * 16 : m->KD * 32;
-  m->EX = c2_ceil(nb * in / 4, C2_NT);
-  if (m->EX > (big ? 2 : 1) || in % 4 != 0) return false;
+  m->EX = m->xelem ? c2_ceil(nb * in, C2_NT) : c2_ceil(nb * in / 4, C2_NT);
+  if (m->EX > (big ? 2 : 1) || (!m->xelem && in % 4 != 0)) return false;
   m->head_elems = (long)Ih * Jh * R;
   m->tail_elems = (long)It * Jt * R;
   m->ok = 1;
@@ -154,9 +156,25 @@ constexpr bool c2_layout(C2Plan* p) {
 //         H = 768, n_cores = 2, rank = 2; tt_shape: (5, 8) x (48, 64) and (24, 32) x (48, 64)), both matrices of the LSTM layer;
 // SPEC 2: its hidden matrix alone (a TT-GRU's gate gradients differ between the matrices; a layer whose input needs dx).
 // SPEC 3 / 4: the same with rank 4 (the reference's result tables go up to rank 8) — plans of the kernel's large variant.
+// SPEC 5 ... 8: the FOUR-core models of those tables at this size (tt_shape (4, 4, 6, 8) x (6, 8, 8, 8), input (2, 2, 2, 5)), split two
+//         by two: (16, 48) x (48, 64), input (4, 10) x (48, 64); 5 / 6 rank 2 pair / hidden, 7 / 8 rank 4.
 template <int SPEC>
 constexpr C2Plan c2_const_plan() {
   C2Plan p{};
+  if (SPEC >= 5) {
+    constexpr int R4 = SPEC >= 7 ? 4 : 2;
+    p.nb = SPEC == 7 ? 1 : 2; p.big = 1;               // (the planner's own choice: the largest row block whose images fit)
+    if (SPEC == 5 || SPEC == 7) {
+      p.nmat = 2;
+      c2_mat_from(&p.m[0], 4, 2, 4, 10, 48, 64, R4, 40, 3072, p.nb, p.big);
+      c2_mat_from(&p.m[1], 4, 2, 16, 48, 48, 64, R4, 768, 3072, p.nb, p.big);
+    } else {
+      p.nmat = 1;
+      c2_mat_from(&p.m[0], 4, 2, 16, 48, 48, 64, R4, 768, 3072, p.nb, p.big);
+    }
+    p.ok = c2_layout(&p) ? 1 : 0;
+    return p;
+  }
   constexpr int R = SPEC >= 3 ? 4 : 2;
   p.nb = SPEC >= 3 ? 1 : 2; p.big = SPEC >= 3 ? 1 : 0;      // (rank 4: the images of two rows do not fit the LDS)
   if (SPEC == 1 || SPEC == 3) {
@@ -178,7 +196,7 @@ inline bool c2_same_kernel_plan(const C2Plan& a, const C2Plan& b) {
     return false;
   for (int i = 0; i < a.nmat; ++i) {
     const C2Mat &x = a.m[i], &y = b.m[i];
-    if (x.d != y.d || x.s != y.s || x.Jh != y.Jh || x.Jt != y.Jt || x.Ih != y.Ih || x.It != y.It || x.R != y.R || x.in != y.in ||
+    if (x.d != y.d || x.s != y.s || x.Jh != y.Jh || x.Jt != y.Jt || x.Ih != y.Ih || x.It != y.It || x.R != y.R || x.in != y.in || x.xelem != y.xelem ||
         x.out != y.out || x.l_xs != y.l_xs || x.l_ghf != y.l_ghf || x.l_tab != y.l_tab || x.l_c1 != y.l_c1 || x.l_dc1 != y.l_dc1)
       return false;      // (everything else of a C2Mat follows from these through c2_mat_from)
   }

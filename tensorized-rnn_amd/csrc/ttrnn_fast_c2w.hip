@@ -358,12 +358,13 @@ __global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
 #pragma unroll
   for (int mi = 0; mi < NMAT; ++mi) {
     const C2Mat& m = pl.m[mi];
-    const int iq = m.in / 4;
+    const int iq = m.xelem ? m.in : m.in / 4;          // staged items of a row: quads, or single elements (xelem)
+    const int iw = m.xelem ? 1 : 4;
 #pragma unroll
     for (int e = 0; e < XQ; ++e) {
       const int id = tid + NT * e;
       const bool on = id < nb * iq;
-      const int row = on ? id / iq : 0, col = on ? 4 * (id % iq) : 0;
+      const int row = on ? id / iq : 0, col = on ? iw * (id % iq) : 0;
       xr[mi][e] = on ? row : -1;
       xcol[mi][e] = col;
       xo[mi][e] = (row * m.JhP + col / m.Jt) * m.XS + (col % m.Jt);
@@ -443,7 +444,8 @@ __global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
         } else {
           src = a.x + (size_t)nn * m.in;
         }
-        sx[mi][e] = *reinterpret_cast<const f32x4*>(src + xcol[mi][e]);
+        if (m.xelem) sx[mi][e] = f32x4{src[xcol[mi][e]], 0.f, 0.f, 0.f};
+        else sx[mi][e] = *reinterpret_cast<const f32x4*>(src + xcol[mi][e]);
         xk[mi][e] = zero ? 0.f : 1.f;
       }
     }
@@ -461,7 +463,16 @@ __global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
       const int xpl = pl.m[mi].xs_rows * pl.m[mi].XS;
 #pragma unroll
       for (int e = 0; e < XQ; ++e)
-        if (xr[mi][e] >= 0) c2_store4(X0 + xo[mi][e], X0 + xpl + xo[mi][e], sx[mi][e] * (sxf[mi] * xk[mi][e]));
+        if (xr[mi][e] >= 0) {
+          if (pl.m[mi].xelem) {
+            _Float16 p0, p1;
+            split2h(sx[mi][e][0] * (sxf[mi] * xk[mi][e]), p0, p1);
+            X0[xo[mi][e]] = p0;
+            X0[xpl + xo[mi][e]] = p1;
+          } else {
+            c2_store4(X0 + xo[mi][e], X0 + xpl + xo[mi][e], sx[mi][e] * (sxf[mi] * xk[mi][e]));
+          }
+        }
     }
   };
 
@@ -881,9 +892,12 @@ int c2_launch_main(const C2Args& a, hipStream_t stream) {
   void (*kf)(C2Args);
   constexpr int SP = NMAT == 2 ? 1 : 2;
   constexpr C2Plan spk = c2_const_plan<SP>();
-  constexpr int SP4 = NMAT == 2 ? 3 : 4;
-  constexpr C2Plan spk4 = c2_const_plan<SP4>();
-  if (pl.big && c2_same_kernel_plan(pl, spk4) && !(opt(OPT_DEV2) & 4)) kf = k_c2w<SP4, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  constexpr int SP4 = NMAT == 2 ? 3 : 4, SD2 = NMAT == 2 ? 5 : 6, SD4 = NMAT == 2 ? 7 : 8;
+  constexpr C2Plan spk4 = c2_const_plan<SP4>(), sd2 = c2_const_plan<SD2>(), sd4 = c2_const_plan<SD4>();
+  const bool ct = !(opt(OPT_DEV2) & 4);
+  if (pl.big && ct && c2_same_kernel_plan(pl, spk4)) kf = k_c2w<SP4, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  else if (pl.big && ct && c2_same_kernel_plan(pl, sd2)) kf = k_c2w<SD2, NMAT, C2_NW, 8, 2, 2, 8, 2>;
+  else if (pl.big && ct && c2_same_kernel_plan(pl, sd4)) kf = k_c2w<SD4, NMAT, C2_NW, 8, 2, 2, 8, 2>;
   else if (pl.big) kf = k_c2w<0, NMAT, C2_NW, 8, 2, 2, 8, 2>;
   else if (c2_same_kernel_plan(pl, spk) && !(opt(OPT_DEV2) & 4)) kf = k_c2w<SP, NMAT, C2_NW, 4, 1, 1, 4, 1>;      // (dev2 bit 2: the run-time-plan kernel, A/B)
   else kf = k_c2w<0, NMAT, C2_NW, 4, 1, 1, 4, 1>;
@@ -917,8 +931,10 @@ size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_on
   if (!c2_plan(&pl, shapes, nmat, device_cu_count())) return 0;
   if (small_only && pl.big) {
     // ... unless the plan has a compile-time instantiation (rank 4 at the encoder's size: no spills, and ahead of the dense gradient)
-    constexpr C2Plan s3 = c2_const_plan<3>(), s4 = c2_const_plan<4>();
-    if (!c2_same_kernel_plan(pl, pl.nmat == 2 ? s3 : s4)) return 0;
+    constexpr C2Plan s3 = c2_const_plan<3>(), s4 = c2_const_plan<4>(), s5 = c2_const_plan<5>(), s6 = c2_const_plan<6>(),
+                     s7 = c2_const_plan<7>(), s8 = c2_const_plan<8>();
+    const bool two = pl.nmat == 2;
+    if (!c2_same_kernel_plan(pl, two ? s3 : s4) && !c2_same_kernel_plan(pl, two ? s5 : s6) && !c2_same_kernel_plan(pl, two ? s7 : s8)) return 0;
   }
   return (size_t)pl.ws_bytes;
 }

@@ -45,17 +45,26 @@ CASES = {
     "spk_lstm_hid_only": dict(cell="lstm", inp=([5, 8], [48, 64], [1, 2, 1]), hid=([24, 32], [48, 64], [1, 2, 1]), H=768, B=4, T=6, h0=False, mats=2),
     "spk_gru": dict(cell="gru", inp=([5, 8], [48, 48], [1, 2, 1]), hid=([24, 32], [48, 48], [1, 2, 1]), H=768, B=4, T=5, h0=True, mats=2),
     "spk_r4": dict(cell="lstm", inp=([5, 8], [48, 64], [1, 4, 1]), hid=([24, 32], [48, 64], [1, 4, 1]), H=768, B=3, T=8, h0=False, mats=3),
-    # d = 4, r = 4 at H = 768 (the reference's result tables: d in {2, 4}): merged two by two, pulled back onto the four cores
+    # d = 4 at H = 768 (the reference's result tables: d in {2, 4}): merged two by two, pulled back onto the four cores; in = 40 as
+    # (2, 2, 2, 5): J_t = 10 is not a multiple of 4 — the input rows are staged element by element
     "spk_d4r4": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 4, 4, 4, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 4, 4, 4, 1]),
-                     H=768, B=3, T=6, h0=True, mats=2),      # (in = 40 as (2, 2, 2, 5): J_t = 10 is not a multiple of 4 — the input matrix stays dense)
+                     H=768, B=3, T=6, h0=True, mats=3),
+    "spk_d4r4_hid_only": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 4, 4, 4, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 4, 4, 4, 1]),
+                              H=768, B=5, T=4, h0=False, mats=2),
+    "spk_d4r2": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 2, 2, 2, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 2, 2, 2, 1]),
+                     H=768, B=4, T=7, h0=False, mats=3),
+    "spk_d4r2_hid_only": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 2, 2, 2, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 2, 2, 2, 1]),
+                              H=768, B=3, T=5, h0=True, mats=2),
+    "spk_d4r3": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 3, 3, 3, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 3, 3, 3, 1]),
+                     H=768, B=3, T=5, h0=True, mats=3),       # (no compile-time plan: the large variant with its plan at run time)
     # three cores, low rank: sides of one and two cores
     "h256_d3r2": dict(cell="lstm", inp=([2, 4, 5], [8, 8, 16], [1, 2, 2, 1]), hid=([4, 8, 8], [8, 8, 16], [1, 2, 2, 1]), H=256, B=4, T=10, h0=False, mats=2),
     "h256_d3r2_in64": dict(cell="lstm", inp=([2, 4, 8], [8, 8, 16], [1, 2, 2, 1]), hid=([4, 8, 8], [8, 8, 16], [1, 2, 2, 1]), H=256, B=4, T=11, h0=True, mats=3),
 }
 
 
-# cases only the kernel's LARGE variant takes (more than 128 rows of Gt): not routed to by default — slower than the dense gradient
-BIG = {"spk_d4r4"}
+# cases only the kernel's LARGE variant with a RUN-TIME plan takes: not routed to by default (spills; slower than the dense gradient)
+BIG = {"spk_d4r3"}
 
 
 def _run(case, scale_dy=1.0, seed=3, poison=False, dev2=None):
@@ -162,7 +171,7 @@ def test_chain_wgrad_gate_gradient_ranges(scale):
 def test_run_time_plan_kernel_is_bit_identical_to_the_compile_time_instantiation():
     """the speaker encoder's shapes run a kernel whose plan is a compile-time constant (c2_const_plan); option dev2 bit 2 selects
     the same kernel with the plan at run time: same arithmetic, same order, same bits"""
-    for case in ("spk_lstm_h0", "spk_lstm_hid_only"):
+    for case in ("spk_lstm_h0", "spk_lstm_hid_only", "spk_d4r2", "spk_d4r4_hid_only"):
         _, a = _run(case, seed=11)
         _, b = _run(case, seed=11, dev2=4)
         for name in ("in", "hid"):
@@ -198,9 +207,12 @@ def test_chain_route_is_offered_only_where_the_chain_is_cheaper():
     assert not offered("lstm", ([2, 4, 5], [8, 8, 16], [1, 16, 16, 1]), ([4, 8, 8], [8, 8, 16], [1, 16, 16, 1]), 256)     # cfg4
     with _lib.option("dev2", 1):
         assert not offered("lstm", spk["inp"], spk["hid"], 768, 3)
-    # rank 4 at H = 768 needs the kernel's large variant: offered because its plan has a compile-time instantiation; the d = 4
-    # shapes (run-time plan of the large variant: slower than the dense gradient) are not
+    # rank 4 at H = 768 and the four-core shapes need the kernel's large variant: offered where the plan has a compile-time
+    # instantiation (ranks 2 and 4); other ranks (run-time plan of the large variant: slower than the dense gradient) are not
     r4 = CASES["spk_r4"]
     assert offered("lstm", r4["inp"], r4["hid"], 768, 3) and offered("lstm", r4["inp"], r4["hid"], 768, 2)
-    d4 = CASES["spk_d4r4"]
-    assert not offered("lstm", d4["inp"], d4["hid"], 768, 2)
+    for name in ("spk_d4r4", "spk_d4r2"):
+        d4 = CASES[name]
+        assert offered("lstm", d4["inp"], d4["hid"], 768, 2) and offered("lstm", d4["inp"], d4["hid"], 768, 3), name
+    d3 = CASES["spk_d4r3"]
+    assert not offered("lstm", d3["inp"], d3["hid"], 768, 2)
