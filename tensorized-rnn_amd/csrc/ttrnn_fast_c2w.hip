@@ -15,6 +15,7 @@
 #include "ttrnn_launch.h"
 #include "ttrnn_opts.h"
 #include "ttrnn_split.h"
+#include <type_traits>
 
 namespace ttrnn {
 namespace {
@@ -375,12 +376,17 @@ __global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
       xt[mi][e] = n - xb[mi][e] * T;
     }
   }
-  unsigned stq[NMAT], str[NMAT];          // step = stq T + str
+  unsigned stq[NMAT], str[NMAT], bmaxs[NMAT];          // step = stq T + str; index of the last sample
 #pragma unroll
   for (int mi = 0; mi < NMAT; ++mi) {
     const unsigned T = g.a[mi].T > 0 ? (unsigned)g.a[mi].T : 1u;
     stq[mi] = step / T;
     str[mi] = step - stq[mi] * T;
+    // (computed ONCE: inside load_block this 64-bit division — a branchy ~150-instruction expansion the compiler does not hoist —
+    // ran per matrix and block, 600 cycles each in the stamps of k_c2r)
+    unsigned bm = (unsigned)(g.n_rows / (long)T) - 1u;
+    asm volatile("" : "+s"(bm));
+    bmaxs[mi] = bm;
   }
   const bool want_bias = g.bpart != nullptr;
 
@@ -432,7 +438,7 @@ __global__ void __launch_bounds__(NW * 64) k_c2w(C2Args g) {
           const bool head = xt[mi][e] == 0;
           // row n - 1 of the outputs; a head row takes its sample's initial state, or (none given) any valid row and is zeroed
           // (the sample index is clamped: the re-read of a range's last block carries (sample, step) one block further)
-          const unsigned bmax = (unsigned)(g.n_rows / a.T) - 1u;
+          const unsigned bmax = bmaxs[mi];
           const unsigned bb = xb[mi][e] < bmax ? xb[mi][e] : bmax;
           // (and the row never goes below 0: in that re-read the carried step no longer belongs to row n)
           src = (head && a.first) ? a.first + (size_t)bb * m.in : a.x + (size_t)((head || nn == 0) ? nn : nn - 1) * m.in;
@@ -907,6 +913,202 @@ int c2_launch_main(const C2Args& a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+// ---- the register hand-off kernel (ttrnn_c2r_dev.h): compile-time shapes -----------------------------------------------------
+#include "ttrnn_c2r_dev.h"
+
+// the encoder layer of the reference (params_model.py:2-4,14-16: 40 -> 768, two cores) and the four-core models of its result
+// tables split two by two; LSTM (I_t = 64) at ranks 2 and 4, the TT-GRU's hidden matrix (I_t = 48) at rank 2
+template <int R> using C2R_In2 = C2RM<5, 8, 48, 64, R, 40>;
+template <int R> using C2R_Hid2 = C2RM<24, 32, 48, 64, R, 768>;
+template <int R> using C2R_In4 = C2RM<4, 10, 48, 64, R, 40>;
+template <int R> using C2R_Hid4 = C2RM<16, 48, 48, 64, R, 768>;
+template <int R> using C2R_GruHid2 = C2RM<24, 32, 48, 48, R, 768>;
+constexpr int C2R_NBR = 2;
+
+struct C2RDims { int Jh, Jt, Ih, It, R, in; };
+template <class M> constexpr C2RDims c2r_dims() { return C2RDims{M::Jh, M::Jt, M::Ih, M::It, M::R, M::in}; }
+
+bool c2r_dims_of(const TtShape& s, C2RDims* o) {
+  if (s.d != 2 && s.d != 4) return false;
+  const int sp = s.d / 2;
+  int It = 1, Jt = 1, Ih = 1, Jh = 1;
+  for (int k = sp; k < s.d; ++k) { It *= s.I[k]; Jt *= s.J[k]; }
+  for (int k = 0; k < sp; ++k) { Ih *= s.I[k]; Jh *= s.J[k]; }
+  *o = C2RDims{Jh, Jt, Ih, It, s.R[sp], s.in_size};
+  return true;
+}
+bool c2r_same(const C2RDims& a, const C2RDims& b) {
+  return a.Jh == b.Jh && a.Jt == b.Jt && a.Ih == b.Ih && a.It == b.It && a.R == b.R && a.in == b.in;
+}
+template <class S>
+bool c2r_takes(const TtShape* const* shapes, int nmat) {
+  if (nmat != S::NMAT) return false;
+  C2RDims d0, d1;
+  if (!c2r_dims_of(*shapes[0], &d0) || !c2r_same(d0, c2r_dims<typename S::M0>())) return false;
+  if (nmat == 2 && (!c2r_dims_of(*shapes[1], &d1) || !c2r_same(d1, c2r_dims<typename S::M1>()) || shapes[1]->d != shapes[0]->d)) return false;
+  return true;
+}
+
+// the call's matrices as k_c2_merge / k_c2_prep / k_c2_pull see them: q = a * (16 JHT) + j_h (tiles of Gh^T do not straddle ranks)
+template <class M>
+bool c2r_mat(C2Mat* m, const TtShape& s) {
+  if (!c2_mat_from(m, s.d, s.d / 2, M::Jh, M::Jt, M::Ih, M::It, M::R, s.in_size, s.out_size, 1, 1)) return false;
+  m->JhP = 16 * M::JHT; m->Q = M::R * m->JhP; m->QT = m->Q / 16;
+  return m->KA == M::JTK && m->KB == M::IHK && m->PT == M::R * M::ITT;
+}
+
+struct C2RWs { long cmax, bpart, part, gh[2], gt[2], dgh[2], dgt[2], gtf[2], ghf[2], hdr[2], bytes; };
+template <class S>
+C2RWs c2r_ws(const C2Mat* m, int cus) {
+  C2RWs w{};
+  size_t o = 0;
+  w.cmax = (long)o; o += 256;
+  w.bpart = (long)o; o += c2_al((size_t)cus * S::OUT * 4);
+  w.part = (long)o; o += c2_al((size_t)cus * 8 * S::NACC * 1024);
+  for (int i = 0; i < S::NMAT; ++i) {
+    w.gh[i] = (long)o; o += c2_al((size_t)m[i].head_elems * 4);
+    w.gt[i] = (long)o; o += c2_al((size_t)m[i].tail_elems * 4);
+    w.dgh[i] = (long)o; o += c2_al((size_t)m[i].head_elems * 4);
+    w.dgt[i] = (long)o; o += c2_al((size_t)m[i].tail_elems * 4);
+    w.gtf[i] = (long)o; o += c2_al((size_t)m[i].PT * m[i].KA * 2 * 1024);
+    w.ghf[i] = (long)o; o += c2_al((size_t)m[i].QT * m[i].KB * 2 * 1024);
+    w.hdr[i] = (long)o; o += 256;
+  }
+  w.bytes = (long)o;
+  return w;
+}
+
+template <class S>
+bool c2r_mats(C2Mat* m, const TtShape* const* shapes) {
+  if (!c2r_mat<typename S::M0>(&m[0], *shapes[0])) return false;
+  if (S::NMAT == 2 && !c2r_mat<typename S::M1>(&m[1], *shapes[1])) return false;
+  return true;
+}
+
+template <class S>
+size_t c2r_workspace(const TtShape* const* shapes) {
+  C2Mat m[2];
+  if (!c2r_mats<S>(m, shapes)) return 0;
+  return (size_t)c2r_ws<S>(m, device_cu_count()).bytes;
+}
+
+template <class S>
+int c2r_launch(const TtShape* const* shapes, int64_t n_rows, const float* const* packed, const float* const* x,
+               const float* const* first, const int* T, const float* dy, const unsigned* const* x_cmax, const int* x_cn,
+               const unsigned* dy_cmax, float* const* d_packed, float* d_bias0, float* d_bias1, void* workspace,
+               size_t workspace_bytes, hipStream_t stream) {
+  constexpr int nmat = S::NMAT;
+  C2Mat m[2];
+  if (!c2r_mats<S>(m, shapes)) return TTRNN_ERR_UNSUPPORTED;
+  const int cus = device_cu_count();
+  const C2RWs w = c2r_ws<S>(m, cus);
+  if (!workspace || workspace_bytes < (size_t)w.bytes) return TTRNN_ERR_WORKSPACE;
+  if (n_rows <= 0) return TTRNN_OK;
+  if (n_rows >= ((int64_t)1 << 31)) return TTRNN_ERR_UNSUPPORTED;
+  const long nblk = (n_rows + S::NBR - 1) / S::NBR;
+  const int grid = nblk < cus ? (int)nblk : cus;
+  char* ws = (char*)workspace;
+  unsigned* cm = (unsigned*)(ws + w.cmax);
+  bool need_zero = !dy_cmax;
+  for (int i = 0; i < nmat; ++i) need_zero = need_zero || !x_cmax[i];
+  if (need_zero && hipMemsetAsync(cm, 0, 256, stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  if (!dy_cmax) {
+    const size_t n4 = (size_t)n_rows * S::OUT / 4;
+    hipLaunchKernelGGL(k_c2_absmax, dim3((unsigned)(n4 / 1024 + 1 < 2048 ? n4 / 1024 + 1 : 2048)), dim3(256), 0, stream, dy, n4, cm + 2);
+  }
+  C2PrepArgs pa{};
+  C2RArgs ka{};
+  C2RRed ra{};
+  ka.dy = dy; ka.n_rows = (long)n_rows;
+#ifdef TTRNN_ABLATIONS
+  ka.abl = opt(OPT_DEV2) >> 8;
+  ka.diag = (unsigned long long*)(ws + w.cmax + 64);
+#endif
+  ka.part = (float*)(ws + w.part);
+  ka.bpart = (d_bias0 || d_bias1) ? (float*)(ws + w.bpart) : nullptr;
+  ra.part = ka.part; ra.grid = grid;
+  int ntile = 0;
+  for (int i = 0; i < nmat; ++i) {
+    const TtShape& s = *shapes[i];
+    float* Gh = (float*)(ws + w.gh[i]);
+    float* Gt = (float*)(ws + w.gt[i]);
+    if (!x_cmax[i]) {
+      const size_t n4 = (size_t)n_rows * m[i].in / 4;
+      hipLaunchKernelGGL(k_c2_absmax, dim3((unsigned)(n4 / 1024 + 1 < 1024 ? n4 / 1024 + 1 : 1024)), dim3(256), 0, stream, x[i], n4, cm + i);
+      if (T[i] > 0 && first[i]) {
+        const size_t f4 = (size_t)(n_rows / T[i]) * m[i].in / 4;
+        hipLaunchKernelGGL(k_c2_absmax, dim3((unsigned)(f4 / 1024 + 1)), dim3(256), 0, stream, first[i], f4, cm + i);
+      }
+    }
+    const long nm = m[i].head_elems + m[i].tail_elems;
+    hipLaunchKernelGGL(k_c2_merge, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, s, m[i], packed[i], Gh, Gt);
+    C2Prep& p = pa.p[i];
+    p.m = m[i]; p.Gh = Gh; p.Gt = Gt;
+    p.x_cmax = x_cmax[i] ? x_cmax[i] : cm + i; p.x_n = x_cmax[i] ? x_cn[i] : 1;
+    p.dy_cmax = dy_cmax ? dy_cmax : cm + 2; p.dy_n = dy_cmax ? S::OUT : 1;
+    p.hdr = (int*)(ws + w.hdr[i]); p.gtf = (_Float16*)(ws + w.gtf[i]); p.ghf = (_Float16*)(ws + w.ghf[i]);
+    C2RMatArgs& a = ka.a[i];
+    a.x = x[i]; a.first = first[i]; a.T = T[i]; a.hdr = p.hdr; a.gtf = p.gtf; a.ghf = p.ghf;
+    ra.s[i] = s; ra.hdr[i] = p.hdr; ra.d_packed[i] = d_packed[i];
+    ra.dGh[i] = (float*)(ws + w.dgh[i]); ra.dGt[i] = (float*)(ws + w.dgt[i]);
+    const int t = 1 + m[i].PT * m[i].KA + m[i].QT * m[i].KB;
+    if (t > ntile) ntile = t;
+  }
+  hipLaunchKernelGGL(k_c2_prep, dim3(ntile, nmat), dim3(256), 0, stream, pa);
+  void (*kf)(C2RArgs) = k_c2r<S>;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), S::LDS) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(kf, dim3(grid), dim3(S::NT), S::LDS, stream, ka);
+  hipLaunchKernelGGL(k_c2r_reduce<S>, dim3(S::NOUT), dim3(1024), 0, stream, ra);
+  for (int i = 0; i < nmat; ++i)
+    if (m[i].d > 2) {
+      const TtShape& s = *shapes[i];
+      hipLaunchKernelGGL(k_c2_pull, dim3((unsigned)((s.wtotal + 255) / 256)), dim3(256), 0, stream, s, m[i], packed[i],
+                         (const float*)(ws + w.dgh[i]), (const float*)(ws + w.dgt[i]), d_packed[i]);
+    }
+  if (ka.bpart)
+    hipLaunchKernelGGL(k_c2_bias, dim3((S::OUT + 63) / 64), dim3(1024), 0, stream, (const float*)ka.bpart, grid, S::OUT, d_bias0, d_bias1);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
+// the instantiations: c2r_each(f) calls f.template operator()<S>() for each until one returns true.  Rank 4 only where the kernel
+// keeps its fragments in registers without spilling (the four-core hidden matrix alone: 234 VGPRs); the other rank-4 shapes —
+// 64 to 128 fragment registers per wave on top of the staging — stay on k_c2w's compile-time plans.
+template <class F>
+bool c2r_each(F&& f) {
+  return f.template operator()<C2RS<2, C2R_NBR, C2R_In2<2>, C2R_Hid2<2>>>() || f.template operator()<C2RS<1, C2R_NBR, C2R_Hid2<2>, C2R_Hid2<2>>>() ||
+         f.template operator()<C2RS<2, C2R_NBR, C2R_In4<2>, C2R_Hid4<2>>>() || f.template operator()<C2RS<1, C2R_NBR, C2R_Hid4<2>, C2R_Hid4<2>>>() ||
+         f.template operator()<C2RS<1, C2R_NBR, C2R_Hid4<4>, C2R_Hid4<4>>>() ||
+         f.template operator()<C2RS<1, C2R_NBR, C2R_GruHid2<2>, C2R_GruHid2<2>>>();
+}
+
+struct C2RWsVisit {
+  const TtShape* const* shapes; int nmat; size_t* out;
+  template <class S> bool operator()() const {
+    if (!c2r_takes<S>(shapes, nmat)) return false;
+    *out = c2r_workspace<S>(shapes);
+    return *out > 0;
+  }
+};
+struct C2RLaunchVisit {
+  const TtShape* const* shapes; int nmat; int64_t n_rows; const float* const* packed; const float* const* x;
+  const float* const* first; const int* T; const float* dy; const unsigned* const* x_cmax; const int* x_cn;
+  const unsigned* dy_cmax; float* const* d_packed; float* d_bias0; float* d_bias1; void* workspace; size_t workspace_bytes;
+  hipStream_t stream; int* status;
+  template <class S> bool operator()() const {
+    if (!c2r_takes<S>(shapes, nmat) || c2r_workspace<S>(shapes) == 0) return false;
+    *status = c2r_launch<S>(shapes, n_rows, packed, x, first, T, dy, x_cmax, x_cn, dy_cmax, d_packed, d_bias0, d_bias1, workspace,
+                            workspace_bytes, stream);
+    return true;
+  }
+};
+// bytes of the hand-off kernel's workspace; 0 = it does not take the call (option dev2 bit 6: never — the A/B against k_c2w)
+size_t c2r_workspace_bytes(const TtShape* const* shapes, int nmat) {
+  if (opt(OPT_DEV2) & 64) return 0;
+  size_t b = 0;
+  c2r_each(C2RWsVisit{shapes, nmat, &b});
+  return b;
+}
+
 }  // namespace
 
 // ---- what ttrnn_api.hip sees ------------------------------------------------------------------------------------------------------
@@ -927,6 +1129,8 @@ bool c2w_prefers_chain(const TtShape& s) {
 // Gt: rank 4 at H = 768, the d = 4 shapes) spills its run-time plan and LOSES to the dense gradient (H = 768, d = 2, r = 4 at
 // the speaker encoder's size: 4.9 ms against 1.8) — it stays reachable for tests through option dev2 bit 3.
 size_t c2w_workspace_bytes(const TtShape* const* shapes, int nmat, bool small_only) {
+  const size_t rb = c2r_workspace_bytes(shapes, nmat);
+  if (rb) return rb;
   C2Plan pl;
   if (!c2_plan(&pl, shapes, nmat, device_cu_count())) return 0;
   if (small_only && pl.big) {
@@ -946,6 +1150,12 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
                const float* const* first, const int* T, const float* dy, const unsigned* const* x_cmax, const int* x_cn,
                const unsigned* dy_cmax, float* const* d_packed, float* d_bias0, float* d_bias1, void* workspace,
                size_t workspace_bytes, hipStream_t stream) {
+  if (c2r_workspace_bytes(shapes, nmat)) {
+    int st = TTRNN_ERR_UNSUPPORTED;
+    if (c2r_each(C2RLaunchVisit{shapes, nmat, n_rows, packed, x, first, T, dy, x_cmax, x_cn, dy_cmax, d_packed, d_bias0, d_bias1,
+                                workspace, workspace_bytes, stream, &st}))
+      return st;
+  }
   C2Plan pl;
   const int cus = device_cu_count();
   if (!c2_plan(&pl, shapes, nmat, cus)) return TTRNN_ERR_UNSUPPORTED;

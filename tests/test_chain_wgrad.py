@@ -168,12 +168,25 @@ def test_chain_wgrad_gate_gradient_ranges(scale):
             assert float((g.double() - r).abs().max()) <= 3e-6 * float(r.abs().max()), (scale, name)
 
 
+@pytest.mark.parametrize("case", ["spk_lstm", "spk_lstm_h0", "spk_lstm_hid_only", "spk_gru", "spk_r4", "spk_d4r4", "spk_d4r2", "spk_d4r2_hid_only"])
+def test_image_kernel_still_takes_the_encoder_shapes(case):
+    """option dev2 bit 6 turns the register hand-off kernel (ttrnn_c2r_dev.h) off: k_c2w, the kernel with the C1 / dC1 images in
+    LDS, takes the same calls (the A/B of DESIGN.md 4c) to the same accuracy"""
+    dev2 = 64 | (8 if case in BIG else 0)
+    ref, got = _run(case, dev2=dev2)
+    for name in ("in", "hid"):
+        if name not in got:
+            continue
+        for r, g in zip(ref[name], got[name]):
+            assert float((g.double() - r).abs().max()) <= 3e-6 * float(r.abs().max()), (case, name)
+
+
 def test_run_time_plan_kernel_is_bit_identical_to_the_compile_time_instantiation():
     """the speaker encoder's shapes run a kernel whose plan is a compile-time constant (c2_const_plan); option dev2 bit 2 selects
     the same kernel with the plan at run time: same arithmetic, same order, same bits"""
     for case in ("spk_lstm_h0", "spk_lstm_hid_only", "spk_d4r2", "spk_d4r4_hid_only"):
-        _, a = _run(case, seed=11)
-        _, b = _run(case, seed=11, dev2=4)
+        _, a = _run(case, seed=11, dev2=64)
+        _, b = _run(case, seed=11, dev2=64 | 4)
         for name in ("in", "hid"):
             if name in a:
                 for x, y in zip(a[name], b[name]):

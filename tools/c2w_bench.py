@@ -66,6 +66,8 @@ if "abl" in os.environ.get("TTRNN_LIB_PATH", ""):
     st = ws[64:64 + 128].view(torch.int64).cpu().tolist()
     nblk = ((B * T + 1) // 2 + 255) // 256
     names = ["stage stores", "prefetch + barrier", "phase A", "phase B", "barrier AB", "phases C D", "barrier CD", "loop top"]
+    if not int(os.environ.get("TTRNN_DEV2", "0")) & 64:      # the register hand-off kernel (ttrnn_c2r_dev.h)
+        names = ["load issue", "step 0", "step 1", "step 2", "step 3", "stage stores", "barrier", "loop top"]
     for w, off in ((0, 0), (5, 8)):
         print("wave %d cycles per block:" % w, ", ".join("%s %d" % (n, st[off + i] // max(nblk, 1)) for i, n in enumerate(names)),
               "| total", sum(st[off:off + 8]) // max(nblk, 1))
