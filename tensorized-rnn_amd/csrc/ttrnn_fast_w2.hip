@@ -721,6 +721,45 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   }
 }
 
+// ---- d = 4: the cores contracted pairwise ONCE per launch into the packed layout of a two-core matrix (I0 I1, I2 I3) x (J0 J1,
+// J2 J3) of rank R_2, which the prep kernels then read like the d = 2 layers' packed cores (one load per entry: with the
+// contraction inside w2_gt / w2_gh every fragment tile's workgroup re-derived every merged entry for its maxima — k_w2_prep 67 us,
+// k_w2b_prep 59 us against 11 / 10 us of the two-core layers).  One thread per merged entry; mats = 1: the hidden matrix only.
+struct W2Merge { TtShape s4[2]; TtShape s2[2]; const float* pk4[2]; float* pk2[2]; int n[2]; };
+__global__ void __launch_bounds__(256) k_w2_merge(W2Merge m, int mats) {
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  for (int q = 0; q < mats; ++q) {
+    if (t >= m.n[q]) { t -= m.n[q]; continue; }
+    const TtShape& s = m.s4[q];
+    const TtShape& z = m.s2[q];
+    const int r = z.R[1];
+    const int nh = z.K[0] * z.M[0];                        // head entries: [(j0 r + b)][i0]
+    float v = 0.f;
+    if (t < nh) {
+      const int i0 = (int)(t % z.M[0]), jb = (int)(t / z.M[0]), b = jb % r, j0 = jb / r;
+      const int ia = i0 / s.I[1], ib = i0 % s.I[1], ja = j0 / s.J[1], jbb = j0 % s.J[1];
+      for (int k = 0; k < s.R[1]; ++k) v = fmaf(w2_core(s, m.pk4[q], 0, 0, ia, ja, k), w2_core(s, m.pk4[q], 1, k, ib, jbb, b), v);
+    } else {
+      const long u = t - nh;                                // tail entries: [j1][i1 r + a]
+      const int ia_ = (int)(u % z.M[1]), j1 = (int)(u / z.M[1]), a = ia_ % r, i1 = ia_ / r;
+      const int ia = i1 / s.I[3], ib = i1 % s.I[3], ja = j1 / s.J[3], jb = j1 % s.J[3];
+      for (int k = 0; k < s.R[3]; ++k) v = fmaf(w2_core(s, m.pk4[q], 2, a, ia, ja, k), w2_core(s, m.pk4[q], 3, k, ib, jb, 0), v);
+    }
+    m.pk2[q][z.woff[0] + t] = v;
+    return;
+  }
+}
+// the two-core shape of a pairwise-contracted four-core matrix
+static bool w2_shape2(const TtShape& s, TtShape* z) {
+  ttrnn_ttm w{};
+  w.d = 2;
+  w.in_modes[0] = s.J[0] * s.J[1]; w.in_modes[1] = s.J[2] * s.J[3];
+  w.out_modes[0] = s.I[0] * s.I[1]; w.out_modes[1] = s.I[2] * s.I[3];
+  w.ranks[0] = 1; w.ranks[1] = s.R[2]; w.ranks[2] = 1;
+  return tt_shape_init(z, &w) == TTRNN_OK && z->woff[0] == 0 && z->woff[1] == z->K[0] * z->M[0];
+}
+constexpr size_t W2_MERGE_BYTES = (size_t)((48 * 16 + 64 * 48 + 48 * 4 + 64 * 10) * 4 + 64) * 4;      // both matrices at rank 4, fp32
+
 // which configuration serves a layer: 0 = none; 1, 2 = A (d = 2) with 2 / 4 rank slots; 3, 4 = B (d = 4: cores contracted pairwise)
 int w2_config(const TtShape& hid, const TtShape& in) {
   int cfg = 0;
@@ -744,8 +783,21 @@ static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, co
                            hipStream_t stream, int phase) {
   int* hdr = (int*)ws;
   _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
-  if (phase != TTRNN_PHASE_RUN)
-    hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  if (phase != TTRNN_PHASE_RUN) {
+    if (rs.hid_s.d == 4) {
+      W2Merge m{};
+      m.s4[0] = rs.hid_s; m.s4[1] = rs.in_s;
+      if (!w2_shape2(rs.hid_s, &m.s2[0]) || !w2_shape2(rs.in_s, &m.s2[1])) return TTRNN_ERR_UNSUPPORTED;
+      m.pk4[0] = packed_hid; m.pk4[1] = packed_in;
+      m.n[0] = m.s2[0].wtotal; m.n[1] = m.s2[1].wtotal;
+      m.pk2[0] = (float*)((char*)ws + S::WS_BYTES); m.pk2[1] = m.pk2[0] + ((m.n[0] + 15) & ~15);
+      if ((size_t)(((m.n[0] + 15) & ~15) + m.n[1]) * 4 > W2_MERGE_BYTES) return TTRNN_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(k_w2_merge, dim3((m.n[0] + m.n[1] + 255) / 256), dim3(256), 0, stream, m, 2);
+      hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, m.s2[0], m.s2[1], (const float*)m.pk2[0], (const float*)m.pk2[1], hdr, frag);
+    } else {
+      hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+    }
+  }
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   W2Args a{};
   a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = (const float*)c0;
@@ -766,7 +818,18 @@ static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* pack
   _Float16* ghf = (_Float16*)((char*)ws + S::HDR_BYTES);
   _Float16* gtf = (_Float16*)((char*)ws + S::HDR_BYTES + S::BGH_BYTES);
   if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 4 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  if (rs.hid_s.d == 4) {
+    W2Merge m{};
+    m.s4[0] = rs.hid_s;
+    if (!w2_shape2(rs.hid_s, &m.s2[0])) return TTRNN_ERR_UNSUPPORTED;
+    m.pk4[0] = packed_hid; m.n[0] = m.s2[0].wtotal;
+    m.pk2[0] = (float*)((char*)ws + S::BWS_BYTES);
+    if ((size_t)m.n[0] * 4 > W2_MERGE_BYTES) return TTRNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_w2_merge, dim3((m.n[0] + 255) / 256), dim3(256), 0, stream, m, 1);
+    hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, m.s2[0], (const float*)m.pk2[0], hdr, ghf, gtf);
+  } else {
+    hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  }
   W2BArgs a{};
   a.c0 = (const float*)c0; a.reserve = reserve;
   a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT; a.d_cT = (const float*)d_cT;
@@ -788,7 +851,9 @@ bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
          !(opt(OPT_DEV2) & 16);
 }
 static constexpr size_t w2_max4(size_t a, size_t b, size_t c, size_t d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
-size_t w2_rnn_fwd_workspace_bytes() { return w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES, W2B4::WS_BYTES); }      // (the query has no shape)
+size_t w2_rnn_fwd_workspace_bytes() {      // (the query has no shape; the four-core configurations keep their contracted cores behind the fragments)
+  return w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES + W2_MERGE_BYTES, W2B4::WS_BYTES + W2_MERGE_BYTES);
+}
 
 int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
@@ -808,7 +873,9 @@ bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
          w2_config(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
          !(opt(OPT_DEV2) & 32);
 }
-size_t w2_rnn_bwd_workspace_bytes() { return w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES, W2B4::BWS_BYTES); }
+size_t w2_rnn_bwd_workspace_bytes() {
+  return w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES + W2_MERGE_BYTES, W2B4::BWS_BYTES + W2_MERGE_BYTES);
+}
 
 int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
                       const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws,

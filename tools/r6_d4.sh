@@ -5,17 +5,9 @@ mkdir -p gpurun_out/r6
 timeout -k 10 900 python -m pytest tests/test_chain_wgrad.py tests/test_w2.py -x -q -m gpu 2>&1 | tail -8
 run() { echo "== $*"; python examples/benchmarking.py --tt -n 5 "$@" 2>&1 | grep "mean time" | tail -1; }
 ( run --train --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4
-  TTRNN_DEV2=1 run --train --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4
   run --train --in_size 40 --hidden_size 768 --ncores 4 --ttrank 2
-  TTRNN_DEV2=1 run --train --in_size 40 --hidden_size 768 --ncores 4 --ttrank 2
   run --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4
   run --in_size 40 --hidden_size 768 --ncores 4 --ttrank 2
+  run --in_size 40 --hidden_size 768 --ncores 2 --ttrank 2
 ) > gpurun_out/r6/${TAG}_times.txt 2>&1
 cat gpurun_out/r6/${TAG}_times.txt
-REPO=$PWD
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o t -- \
-  python3 $REPO/examples/benchmarking.py --tt -n 6 --train --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4 > /dev/null 2>&1
-cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $REPO/gpurun_out/r6/${TAG}_kernel_stats.csv
-head -12 $REPO/gpurun_out/r6/${TAG}_kernel_stats.csv | cut -c1-200
