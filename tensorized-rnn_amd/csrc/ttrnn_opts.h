@@ -43,7 +43,9 @@ enum OptId {
                          //                         2: chain weight gradient for the hidden matrix only (the input matrix keeps its dense pass over dy),
                          //                         4: the chain kernel with the run-time plan even for the shapes that have a compile-time instantiation,
                          //                         8: offer the chain kernel's LARGE variant too (measured slower than the dense gradient: tests only),
-                         //                         16: the speaker encoder's shape on the runtime tier instead of k_lstm_fwd_w2 (forward), 32: the same for the reverse-time kernel
+                         //                         16: the speaker encoder's shape on the runtime tier instead of k_lstm_fwd_w2 (forward), 32: the same for the reverse-time kernel,
+                         //                         64: k_c2w (C1 / dC1 images in LDS) for the calls k_c2r (register hand-offs) would take,
+                         //                         bits 8 and up: ablation switches of the chain kernels in -DTTRNN_ABLATIONS builds (tools/c2w_bench.py)
   OPT_COUNT
 };
 
