@@ -908,8 +908,10 @@ bool fast_rnn_bwd_available(const RnnShape& rs, int dtype) {
   // TT-GRU r = 16 has no fused-core reverse kernel: this family would run its stage-wise kernel (1.50 ms at benchmarking.py
   // --hidden_size 256 --gru --ttrank 16), the runtime tier's reverse kernel — same reserve — takes 0.95: the tier where it is on offer
   // (split mode / bf16; dev bit 26: the stage-wise kernel, A/B)
+  // (round 6: the two-fp16-piece fused-core kernel takes rank 16 — k_gru_bwd_f10h<ShpH256R16G>; option dev2 bit 7 = the tier again)
   if (shape_matches<ShpH256R16G>(rs.hid_s))
-    return (opt(OPT_DEV) & (1 << 26)) || opt(OPT_FORCE_GENERIC) || !g2_rnn_bwd_available(rs, dtype);
+    return (f10bh_available(rs, dtype) && !opt(OPT_NO_F10)) || (opt(OPT_DEV) & (1 << 26)) || opt(OPT_FORCE_GENERIC) ||
+           !g2_rnn_bwd_available(rs, dtype);
   return shape_matches<ShpH256R8G>(rs.hid_s);
 }
 

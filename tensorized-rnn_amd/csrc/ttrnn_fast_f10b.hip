@@ -646,7 +646,11 @@ int launch_f10b_prep(const TtShape& s, const float* packed, void* wfrag, hipStre
 
 bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_NO_F10) || rs.B < 1 || rs.T < 1) return false;
-  if (rs.cell == TTRNN_GRU) return (dtype == TTRNN_F32 || dtype == TTRNN_BF16) && shape_matches<ShpH256R8G>(rs.hid_s);
+  if (rs.cell == TTRNN_GRU) {
+    if (shape_matches<ShpH256R8G>(rs.hid_s)) return dtype == TTRNN_F32 || dtype == TTRNN_BF16;
+    // rank 16 (round 6): only the two-fp16-piece kernel has an instantiation (twelve T2 pairs: two per wave on waves 0-3)
+    return shape_matches<ShpH256R16G>(rs.hid_s) && f10bh_available(rs, dtype);
+  }
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
@@ -655,6 +659,7 @@ bool f10_rnn_bwd_available(const RnnShape& rs, int dtype) {
 static size_t f10b_ws_head_bytes(const RnnShape& rs, int dtype) {
   if (rs.cell == TTRNN_GRU && shape_matches<ShpH256R8G>(rs.hid_s))
     return f10b_wfrag_elems<ShpH256R8G>() * sizeof(xbf8) + 4096;
+  if (rs.cell == TTRNN_GRU && shape_matches<ShpH256R16G>(rs.hid_s)) return 4096;      // (no three-piece kernel: stamps only)
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM) return 0;
   if (shape_matches<ShpH256R8L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R8L>() * sizeof(xbf8) + 4096;
   if (shape_matches<ShpH256R16L>(rs.hid_s)) return f10b_wfrag_elems<ShpH256R16L>() * sizeof(xbf8) + 4096;
@@ -729,7 +734,7 @@ int launch_rnn_bwd_f10(const RnnShape& rs, int dtype, const void* out, const voi
   }
   int st = TTRNN_ERR_UNSUPPORTED;
   if (rs.cell == TTRNN_GRU) {
-    if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
+    if (!shape_matches<ShpH256R8G>(rs.hid_s) && !(ws_half && shape_matches<ShpH256R16G>(rs.hid_s))) return TTRNN_ERR_UNSUPPORTED;
     if (ws_half)      // two fp16 pieces (ttrnn_fast_f10bh.hip); option gemm_pieces = 3 keeps this file's kernel
       st = launch_gru_bwd_f10h(rs, dtype, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws_half, stream, bs);
     else if (dtype == TTRNN_F32)

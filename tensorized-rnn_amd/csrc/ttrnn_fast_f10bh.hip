@@ -1065,7 +1065,7 @@ constexpr bool f10bh_gru_ok() {
   using B = F10BH<S>;
   return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::H == 256 &&
          out_size_of<S>() == 3 * F::H && F::I2 % 2 == 0 && F::I2 <= 16 && B::K1 == 64 && B::FT % FAST_NW == 0 &&
-         B::K2 % 32 == 0 && B::CT2 == 2 && F::J2 == 8 && S::R[2] % 4 == 0 && B::NM2 * B::CT2 <= FAST_NW;
+         B::K2 % 32 == 0 && B::CT2 == 2 && F::J2 == 8 && S::R[2] % 4 == 0 && B::NM2 * B::CT2 <= 2 * FAST_NW;
 }
 
 template <class S>
@@ -1087,7 +1087,8 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
   using F = F10<S>;
   using B = F10BH<S>;
   constexpr int H = F::H, GH = 3 * H;
-  constexpr int NP = B::NM2 * B::CT2;                                         // T2 (column tile, k-block) pairs: one per wave
+  constexpr int NP = B::NM2 * B::CT2;                                         // T2 (column tile, k-block) pairs: pair p = wave + 8 i
+  constexpr int NPW = (NP + FAST_NW - 1) / FAST_NW;                           // ... one per wave at r = 8 (six pairs), up to two at r = 16 (twelve)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) float smax1[4];
   __shared__ float sl1[FAST_NW];
@@ -1103,7 +1104,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
   const int c = lane & 15, q = lane >> 4;
   const size_t b = blockIdx.x;
 
-  xh8 w01[B::XF][B::NM1][2], w2t[2];
+  xh8 w01[B::XF][B::NM1][2], w2t[NPW][2];
   f32x4 un1[B::XF], un2;
 #pragma unroll
   for (int x = 0; x < B::XF; ++x) {
@@ -1114,9 +1115,12 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
         w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
     un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
   }
-  const int pid = wave < NP ? wave : 0, ub = pid >> 1, ct = pid & 1;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) w2t[p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ub * 2 + p) * 64 + lane];
+  for (int i = 0; i < NPW; ++i) {
+    const int pid = wave + FAST_NW * i < NP ? wave + FAST_NW * i : 0, ub = pid >> 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) w2t[i][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ub * 2 + p) * 64 + lane];
+  }
   un2 = *reinterpret_cast<const f32x4*>(hdr + B::UN2 + 4 * q);
   float maxl1;
   {
@@ -1258,19 +1262,24 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
       }
     }
     lds_barrier();
-    // ---- T2: pair (column tile ct, k-block ub) = wave (< NP) ---------------------------------------------------------------
-    if (wave < NP) {
-      const int row = 16 * ct + c;
-      xh8 b2[2];
+    // ---- T2: pairs (column tile ct, k-block ub) = wave, wave + 8 (< NP) ----------------------------------------------------
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-        b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
-      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[1], b2[0], z4, 0, 0, 0);
-      const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[0], b2[0], z4, 0, 0, 0);
-      alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[0], b2[1], alo, 0, 0, 0);
-      const f32x4 acc = ahi + alo;
-      if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc * (un2 * u2);
+    for (int i = 0; i < NPW; ++i) {
+      const int pid = wave + FAST_NW * i;
+      if (pid < NP) {
+        const int ub = pid >> 1, ct = pid & 1;
+        const int row = 16 * ct + c;
+        xh8 b2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<B::K2>(row, 32 * ub + 8 * q));
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][1], b2[0], z4, 0, 0, 0);
+        const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][0], b2[0], z4, 0, 0, 0);
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][0], b2[1], alo, 0, 0, 0);
+        const f32x4 acc = ahi + alo;
+        if (q < 2) *reinterpret_cast<f32x4*>(dhs + ub * H + row * F::J2 + 4 * q) = acc * (un2 * u2);
+      }
     }
     lds_barrier();
   };
@@ -1382,7 +1391,7 @@ bool f10bh_available(const RnnShape& rs, int dtype) {
   if (opt(OPT_GEMM_PIECES) == 3) return false;
   if (rs.cell == TTRNN_GRU)      // (bf16 storage: in every math mode, as the three-piece kernel; fp32 storage: split mode)
     return (dtype == TTRNN_BF16 || (dtype == TTRNN_F32 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT)) &&
-           shape_matches<ShpH256R8G>(rs.hid_s);
+           (shape_matches<ShpH256R8G>(rs.hid_s) || (shape_matches<ShpH256R16G>(rs.hid_s) && !(opt(OPT_DEV2) & 128)));
   if (dtype != TTRNN_F32 || rs.cell != TTRNN_LSTM || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT) return false;
   return shape_matches<ShpH256R8L>(rs.hid_s) || shape_matches<ShpH256R16L>(rs.hid_s);
 }
@@ -1415,6 +1424,8 @@ int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* pac
 size_t f10bh_workspace_bytes(const RnnShape& rs) {
   if (shape_matches<ShpH256R8G>(rs.hid_s))
     return F10BH<ShpH256R8G>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R8G>::FRAGS * sizeof(xh8);
+  if (shape_matches<ShpH256R16G>(rs.hid_s))
+    return F10BH<ShpH256R16G>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R16G>::FRAGS * sizeof(xh8);
   if (shape_matches<ShpH256R8L>(rs.hid_s))
     return F10BH<ShpH256R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH256R8L>::FRAGS * sizeof(xh8);
   if (shape_matches<ShpH256R16L>(rs.hid_s))
@@ -1437,6 +1448,11 @@ int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed
 int launch_gru_bwd_f10h(const RnnShape& rs, int dtype, const void* out, const void* h0, const float* packed_hid,
                         const float* reserve, const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0,
                         void* ws, hipStream_t stream, const BwdStats& bs) {
+  if (shape_matches<ShpH256R16G>(rs.hid_s)) {      // (round 6: `benchmarking.py --hidden_size 256 --gru --ttrank 16`)
+    if (dtype == TTRNN_F32)
+      return launch_gru_t<ShpH256R16G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);
+    return launch_gru_t<ShpH256R16G, bf16_t>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);
+  }
   if (!shape_matches<ShpH256R8G>(rs.hid_s)) return TTRNN_ERR_UNSUPPORTED;
   if (dtype == TTRNN_F32)
     return launch_gru_t<ShpH256R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);

@@ -2868,6 +2868,61 @@ def test_fused_core_half_piece_reverse_kernel_outlier_weights(rank, which, facto
     assert worst["two_fp16"] <= 3.0 * worst["three_bf16"] + 1e-6
 
 
+@pytest.mark.parametrize("inp", [1, 24])
+@pytest.mark.parametrize("case", ["plain", "decades", "last_step_only"])
+def test_fused_core_gru_reverse_kernel_rank_16(case, inp):
+    """round 6: `benchmarking.py --hidden_size 256 --gru --ttrank 16` — the TT-GRU of rank 16 on the two-piece
+    fused-core reverse-time kernel (k_gru_bwd_f10h<ShpH256R16G>: twelve T2 pairs, two per wave on waves 0-3) instead of the stage-wise
+    kernel; against the float64 oracle and against the route it replaces (option dev2 bit 7) reading the same forward records."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(311)
+    H = 256
+    meta = dict(kind="ttgru", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=16)
+    m = build_module(meta, dev())
+    B, T = 5, (50 if case == "last_step_only" else 9)
+    x = torch.randn(B, T, inp)
+    h0 = torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+    with ttrnn_hip.option("dev2", 128):
+        assert F.rnn_backward_route(spec, B, T) != "fused_core"
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr, h0r = (t.double().clone().requires_grad_(True) for t in (x, h0))
+    ro, rh = O.gru_forward(layers, xr, h0r)
+    wsum = 0.0 if case == "last_step_only" else 1.0
+    ((ro * w.double()).sum() + wsum * 0.5 * rh.sum()).backward()
+
+    def run():
+        m.zero_grad()
+        xg, h0g = (t.to(dev()).contiguous().requires_grad_(True) for t in (x, h0))
+        out, hT = m(xg, h0g)
+        ((out * w.to(dev())).sum() + wsum * 0.5 * hT.sum()).backward()
+        return {"h0": h0g.grad.clone(), "x": xg.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+
+    got = run()
+    again = run()
+    with ttrnn_hip.option("dev2", 128):
+        old = run()
+    refs = {"h0": h0r.grad, "x": xr.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    worst = {"fused": 0.0, "replaced": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["fused"] = max(worst["fused"], _maxabs(got[n].double(), ref) / sc)
+        worst["replaced"] = max(worst["replaced"], _maxabs(old[n].double(), ref) / sc)
+    assert torch.equal(got["h0"], again["h0"])
+    print(case, inp, "max gradient error relative to each tensor's maximum:", worst)
+    assert worst["fused"] <= 2e-5 and worst["fused"] <= 3.0 * worst["replaced"] + 1e-6
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only"])
 def test_fused_core_half_piece_gru_reverse_kernel_ranges(case, dtype):
