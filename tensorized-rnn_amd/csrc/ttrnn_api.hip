@@ -961,7 +961,7 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   if (!force_generic() && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
     // the reference's default benchmark shape in split mode: the fused-core reverse-time kernel on two fp16 pieces
     if (!g2_first && f10bh_h512_available(rs, desc->dtype) && workspace && workspace_bytes >= f10bh_h512_workspace_bytes())
-      return launch_rnn_bwd_f10_h512(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
+      return launch_rnn_bwd_f10_h512(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
                                      workspace, (hipStream_t)stream, stats);
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,

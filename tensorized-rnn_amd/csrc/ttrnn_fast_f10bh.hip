@@ -31,6 +31,8 @@
 namespace ttrnn {
 namespace {
 
+using ShpH512R8G = Shp<3, 8, 8, 8, 1, 8, 12, 16, 1, 8, 8, 1>;      // benchmarking.py defaults with --gru (ttrnn_fast_f10g5.hip has the forward)
+
 template <class S>
 struct F10BH {
   using F = F10<S>;
@@ -1063,9 +1065,9 @@ template <class S>
 constexpr bool f10bh_gru_ok() {
   using F = F10<S>;
   using B = F10BH<S>;
-  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && F::H == 256 &&
-         out_size_of<S>() == 3 * F::H && F::I2 % 2 == 0 && F::I2 <= 16 && B::K1 == 64 && B::FT % FAST_NW == 0 &&
-         B::K2 % 32 == 0 && B::CT2 == 2 && F::J2 == 8 && S::R[2] % 4 == 0 && B::NM2 * B::CT2 <= 2 * FAST_NW;
+  return S::D == 3 && S::R[0] == 1 && S::R[3] == 1 && shape_ok_recurrent<S>() && (F::H == 256 || F::H == 512) &&
+         out_size_of<S>() == 3 * F::H && F::I2 % 2 == 0 && F::I2 <= 16 && B::K1 % 32 == 0 && B::K1 <= 128 && B::FT % FAST_NW == 0 &&
+         B::K2 % 32 == 0 && (B::CT2 == 2 || B::CT2 == 4) && F::J2 == 8 && S::R[2] % 4 == 0 && B::NM2 * B::CT2 <= 2 * FAST_NW;
 }
 
 template <class S>
@@ -1090,10 +1092,11 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
   constexpr int NP = B::NM2 * B::CT2;                                         // T2 (column tile, k-block) pairs: pair p = wave + 8 i
   constexpr int NPW = (NP + FAST_NW - 1) / FAST_NW;                           // ... one per wave at r = 8 (six pairs), up to two at r = 16 (twelve)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) float smax1[4];
+  __shared__ __attribute__((aligned(16))) float smax1[8];
   __shared__ float sl1[FAST_NW];
   constexpr int PL1 = 16 * B::K1, PL2 = F::ROWS2 * B::K2;
-  static_assert(GH / 4 <= FAST_NT - H, "waves 4-7 store the fp32 rows");
+  constexpr bool HELPERS = GH / 4 <= FAST_NT - H;      // H = 256: waves 4-7 store the fp32 rows; H = 512: every wave is a gate wave
+  constexpr int NGW = H / 64;                           // gate waves
   float* dgf = reinterpret_cast<float*>(smem);                               // [3H]: dr, dz, dn*r (hidden chain)
   float* dhs = dgf + GH;                                                     // [NM2][H]
   _Float16* img1h = reinterpret_cast<_Float16*>(dhs + B::NM2 * H);           // [2][16][K1], natural k
@@ -1117,7 +1120,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
   }
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int pid = wave + FAST_NW * i < NP ? wave + FAST_NW * i : 0, ub = pid >> 1;
+    const int pid = wave + FAST_NW * i < NP ? wave + FAST_NW * i : 0, ub = pid / B::CT2;
 #pragma unroll
     for (int p = 0; p < 2; ++p) w2t[i][p] = wfrag[(size_t)(B::FT * B::NM1 * 2 + ub * 2 + p) * 64 + lane];
   }
@@ -1203,7 +1206,11 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
     float u2, t01f;
     {
       const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
-      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      if constexpr (NGW == 8) {
+        const f32x4 m5 = *reinterpret_cast<const f32x4*>(smax1 + 4);
+        mxg = fmaxf(mxg, fmaxf(fmaxf(m5[0], m5[1]), fmaxf(m5[2], m5[3])));
+      }
       float ug;
       const float sg = step_scale(mxg, ug);
       const float s2 = step_scale(mxg * maxl1, u2);
@@ -1218,9 +1225,11 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
           img1h[off] = p0;
           img1h[PL1 + off] = p1;
         }
-      } else {
-        const int i4 = tid - H;
-        if (i4 < GH / 4) {
+      }
+      {
+        // the fp32 rows to HBM: the helper waves (H = 256), or — every wave being a gate wave — threads 0 .. 3H/4 - 1 behind their split
+        const int i4 = HELPERS ? tid - H : tid;
+        if (i4 >= 0 && i4 < GH / 4) {
           const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
           reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
           if (i4 < 2 * H / 4) reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
@@ -1239,22 +1248,26 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
           bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(rowc, 32 * u + 8 * q));
       // all products first, ONE guarded block of stores behind them (a guard per tile puts a branch — and the wait for that
       // tile's MFMAs — between the tiles: lesson 40)
-      f32x4 au[B::XF][B::NM1];
+      // (K1 <= 64: one accumulator per k-block, added behind the MFMAs — the order the rank-8 kernel has always summed in; K1 = 96
+      // (H = 512): the k-blocks accumulate in place, four accumulators live instead of twelve)
+      constexpr int NAU = B::NM1 <= 2 ? B::NM1 : 1;
+      f32x4 au[B::XF][NAU];
 #pragma unroll
       for (int x = 0; x < B::XF; ++x)
 #pragma unroll
         for (int u = 0; u < B::NM1; ++u) {
-          au[x][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[x][u], 0, 0, 0);
-          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[x][u], 0, 0, 0);
-          au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[x][u], 0, 0, 0);
+          const int ua = NAU == 1 ? 0 : u;
+          if (NAU > 1 || u == 0) au[x][ua] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[x][ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][1], bf[u][0], au[x][ua], 0, 0, 0);
+          au[x][ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][1], au[x][ua], 0, 0, 0);
+          au[x][ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[x][u][0], bf[u][0], au[x][ua], 0, 0, 0);
         }
       if (c < F::I2) {
 #pragma unroll
         for (int x = 0; x < B::XF; ++x) {
           f32x4 acc = au[x][0];
 #pragma unroll
-          for (int u = 1; u < B::NM1; ++u) acc += au[x][u];
+          for (int u = 1; u < NAU; ++u) acc += au[x][u];
           const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
           const int row2 = f0 / F::R2, r20 = f0 % F::R2;
           store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc * (un1[x] * t01f));
@@ -1267,7 +1280,7 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
     for (int i = 0; i < NPW; ++i) {
       const int pid = wave + FAST_NW * i;
       if (pid < NP) {
-        const int ub = pid >> 1, ct = pid & 1;
+        const int ub = pid / B::CT2, ct = pid % B::CT2;
         const int row = 16 * ct + c;
         xh8 b2[2];
 #pragma unroll
@@ -1399,20 +1412,30 @@ bool f10bh_available(const RnnShape& rs, int dtype) {
 // the reference's default benchmark shape (H = 512, r = 8): a runtime-tier shape whose reverse-time recurrence runs here in split
 // mode — eight gate waves, four feature tiles of T01 (K = 128) and two T2 pairs per wave (dev bit 16384 keeps the tier's kernel)
 // (round 5: H = 384, r = 8 — benchmarking.py --hidden_size 384 — on the wave-local kernel as six waves)
+// (round 6: the TT-GRU of the same benchmark — `--gru`: (8, 8, 8) x (8, 12, 16), K1 = 96 — on k_gru_bwd_f10h as eight gate waves;
+// option dev2 bit 8 keeps the tier's kernel)
 bool f10bh_h512_available(const RnnShape& rs, int dtype) {
-  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && opt(OPT_GEMM_PIECES) != 3 &&
-         !(opt(OPT_DEV) & 16384) && rs.T > 0 && (shape_matches<ShpH512R8L>(rs.hid_s) || shape_matches<ShpH384R8L>(rs.hid_s));
+  if (dtype != TTRNN_F32 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT || opt(OPT_GEMM_PIECES) == 3 || (opt(OPT_DEV) & 16384) || rs.T <= 0)
+    return false;
+  if (rs.cell == TTRNN_GRU) return rs.hid_blocks <= 1 && shape_matches<ShpH512R8G>(rs.hid_s) && !(opt(OPT_DEV2) & 256);
+  return rs.cell == TTRNN_LSTM && (shape_matches<ShpH512R8L>(rs.hid_s) || shape_matches<ShpH384R8L>(rs.hid_s));
 }
 size_t f10bh_h512_workspace_bytes() {
   constexpr size_t a = F10BH<ShpH512R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH512R8L>::FRAGS * sizeof(xh8) + 4096;
   constexpr size_t b = F10BH<ShpH384R8L>::HDR_FLOATS * sizeof(float) + F10BH<ShpH384R8L>::FRAGS * sizeof(xh8) + 4096;
-  return a > b ? a : b;
+  constexpr size_t g = F10BH<ShpH512R8G>::HDR_FLOATS * sizeof(float) + F10BH<ShpH512R8G>::FRAGS * sizeof(xh8) + 4096;
+  return (a > b ? a : b) > g ? (a > b ? a : b) : g;
 }
-int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
-                            hipStream_t stream, float* stats) {
+int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                            const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                            void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* stats) {
   BwdStats bs;
   if (stats) bs.colmax = reinterpret_cast<unsigned*>(stats);      // (cleared by the prep launch)
+  if (rs.cell == TTRNN_GRU) {
+    int st = launch_gru_t<ShpH512R8G, float>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, bs);
+    if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, rs.G * rs.H, nullptr, stats, stream);
+    return st;
+  }
   unsigned long long* diag = reinterpret_cast<unsigned long long*>((char*)ws + f10bh_h512_workspace_bytes() - 4096);
   int st = shape_matches<ShpH384R8L>(rs.hid_s)
                ? launch_t<ShpH384R8L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream, bs)

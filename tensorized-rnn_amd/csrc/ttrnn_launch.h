@@ -339,9 +339,9 @@ bool f10bh_available(const RnnShape& rs, int dtype);
 // of ttrnn_rnn_backward_ex when no per-step state gradients are asked for; stats: the column maxima (rows 0 / 1) or NULL
 bool f10bh_h512_available(const RnnShape& rs, int dtype);
 size_t f10bh_h512_workspace_bytes();
-int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                            const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
-                            hipStream_t stream, float* stats);
+int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                            const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                            void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* stats);
 // ttrnn_fast_proj.hip: d_packed += the adjoint of (three cores -> dense matrix) applied to dW (fp32 [in][out]); ws:
 // proj3_workspace_bytes (0: not offered for this shape / switched off by option dev bit 10)
 size_t proj3_workspace_bytes(const TtShape& s);

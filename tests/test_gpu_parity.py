@@ -2923,6 +2923,67 @@ def test_fused_core_gru_reverse_kernel_rank_16(case, inp):
     assert worst["fused"] <= 2e-5 and worst["fused"] <= 3.0 * worst["replaced"] + 1e-6
 
 
+@pytest.mark.parametrize("case", ["plain", "decades", "last_step_only", "no_h0"])
+def test_fused_core_gru_reverse_kernel_h512(case):
+    """round 6: the reference's benchmark defaults with --gru (TT-GRU in = 256, H = 512, d = 3, r = 8) — the
+    reverse-time recurrence on k_gru_bwd_f10h<ShpH512R8G> (eight gate waves, K1 = 96, sixteen T2 pairs) instead of the tier's kernel;
+    against the float64 oracle and against the route it replaces (option dev2 bit 8) reading the same forward records."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(317)
+    H, inp = 512, 256
+    meta = dict(kind="ttgru", input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8)
+    m = build_module(meta, dev())
+    B, T = 4, (40 if case == "last_step_only" else 7)
+    x = torch.randn(B, T, inp)
+    h0 = None if case == "no_h0" else torch.randn(B, H) * 0.3
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+    with ttrnn_hip.option("dev2", 256):
+        assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    h0r = None if h0 is None else h0.double().clone().requires_grad_(True)
+    ro, rh = O.gru_forward(layers, xr, h0r)
+    wsum = 0.0 if case == "last_step_only" else 1.0
+    ((ro * w.double()).sum() + wsum * 0.5 * rh.sum()).backward()
+
+    def run():
+        m.zero_grad()
+        xg = x.to(dev()).contiguous().requires_grad_(True)
+        h0g = None if h0 is None else h0.to(dev()).contiguous().requires_grad_(True)
+        out, hT = m(xg, h0g)
+        ((out * w.to(dev())).sum() + wsum * 0.5 * hT.sum()).backward()
+        g = {"x": xg.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+        if h0g is not None:
+            g["h0"] = h0g.grad.clone()
+        return g
+
+    got = run()
+    again = run()
+    with ttrnn_hip.option("dev2", 256):
+        old = run()
+    refs = {"x": xr.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    if h0r is not None:
+        refs["h0"] = h0r.grad
+    worst = {"fused": 0.0, "replaced": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst["fused"] = max(worst["fused"], _maxabs(got[n].double(), ref) / sc)
+        worst["replaced"] = max(worst["replaced"], _maxabs(old[n].double(), ref) / sc)
+    assert torch.equal(got["x"], again["x"])
+    print(case, "max gradient error relative to each tensor's maximum:", worst)
+    assert worst["fused"] <= 2e-5 and worst["fused"] <= 3.0 * worst["replaced"] + 1e-6
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only"])
 def test_fused_core_half_piece_gru_reverse_kernel_ranges(case, dtype):
@@ -3756,8 +3817,13 @@ def test_runtime_reverse_kernel_ranges(meta, case):
         return got
 
     spec = m._all_layers[0]._layer_spec()
-    assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
-    got, again = run(), run()
+    # (round 6: the TT-GRU of H = 512 has a fused-core reverse-time kernel of its own; option dev2 bit 8 keeps it on the tier's kernel,
+    # which this test is about — the fused route runs the same cases further down)
+    import contextlib
+    tier = ttrnn_hip.option("dev2", 256) if not lstm else contextlib.nullcontext()
+    with tier:
+        assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
+        got, again = run(), run()
     refs = {"x": xr.grad, "h0": h0r.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
     if lstm:
         refs["c0"] = c0r.grad
@@ -3779,6 +3845,7 @@ def test_runtime_reverse_kernel_ranges(meta, case):
         print("d_h0 after 40 steps: max |ref| %.3g, relative error %.3g" % (float(h0r.grad.abs().max()), rel))
         assert rel <= 1e-4
     print(meta["kind"], H, case, "max gradient error relative to each tensor's maximum: %.3g" % worst)
+    exact = None
     if case.startswith("outlier"):
         with ttrnn_hip.fp32_math("exact"):
             exact = worst_of(run())
@@ -3786,6 +3853,16 @@ def test_runtime_reverse_kernel_ranges(meta, case):
         assert worst <= max(10.0 * exact, 2e-5) and worst <= 5e-3
     else:
         assert worst <= 2e-5
+    if not lstm:
+        assert F.rnn_backward_route(spec, B, T) == "fused_core"
+        fused, fused2 = run(), run()
+        wf = worst_of(fused)
+        print("   fused-core reverse kernel (k_gru_bwd_f10h<ShpH512R8G>): %.3g" % wf)
+        for n in ("h0", "x"):
+            assert torch.equal(fused[n], fused2[n]), n
+        if case == "sparse_steps":
+            assert float(fused["h0"][2].abs().max()) == 0.0
+        assert wf <= (max(10.0 * exact, 2e-5) if exact is not None else 2e-5)
 
 
 # ---- (19) the round-4 reverse-time kernels at the corners -------------------------------------------------------------------------------
