@@ -626,7 +626,8 @@ size_t ttrnn_rnn_backward_workspace_ex(const ttrnn_rnn_desc* desc, int want_stat
   if (!gen && rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype)) {
     const size_t a = g2_rnn_bwd_workspace(rs);
     const size_t b2 = !g2_first && f10bh_h512_available(rs, desc->dtype) ? f10bh_h512_workspace_bytes() : 0;
-    return a > b2 ? a : b2;
+    const size_t b3 = !g2_first && !want_state && f10n_bwd_available(rs, desc->dtype) ? f10n_bwd_workspace_bytes(rs) : 0;
+    return (a > b2 ? a : b2) > b3 ? (a > b2 ? a : b2) : b3;
   }
   return plan_rnn_generic(rs, true).ws_bytes;
 }
@@ -877,7 +878,9 @@ int ttrnn_rnn_backward_route(const ttrnn_rnn_desc* desc, int want_state) {
   }
   if (!g2_first && !want_state && rs.T > 0 && big_rnn_bwd_available(rs, desc->dtype)) return TTRNN_ROUTE_MERGED_BIG;
   if (rs.T > 0 && g2_rnn_bwd_available(rs, desc->dtype))
-    return !g2_first && f10bh_h512_available(rs, desc->dtype) ? TTRNN_ROUTE_FUSED_CORE : TTRNN_ROUTE_RUNTIME_MFMA;
+    return !g2_first && (f10bh_h512_available(rs, desc->dtype) || (!want_state && f10n_bwd_available(rs, desc->dtype)))
+               ? TTRNN_ROUTE_FUSED_CORE
+               : TTRNN_ROUTE_RUNTIME_MFMA;
   return TTRNN_ROUTE_VALU;
 }
 
@@ -963,6 +966,10 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
     if (!g2_first && f10bh_h512_available(rs, desc->dtype) && workspace && workspace_bytes >= f10bh_h512_workspace_bytes())
       return launch_rnn_bwd_f10_h512(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0,
                                      workspace, (hipStream_t)stream, stats);
+    // naive per-gate sets of H = 256: the per-gate fused cores (k_rnn_bwd_f10n, round 6)
+    if (!g2_first && !want_state && f10n_bwd_available(rs, desc->dtype) && workspace && workspace_bytes >= f10n_bwd_workspace_bytes(rs))
+      return launch_rnn_bwd_f10n(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0, workspace,
+                                 (hipStream_t)stream, stats);
     if (!workspace || workspace_bytes < g2_rnn_bwd_workspace(rs)) return TTRNN_ERR_WORKSPACE;
     return launch_rnn_bwd_g2(rs, desc->dtype, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid,
                              d_h0, d_c0, workspace, (hipStream_t)stream, d_state, stats);

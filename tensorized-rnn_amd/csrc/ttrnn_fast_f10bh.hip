@@ -1326,6 +1326,307 @@ __global__ void __launch_bounds__(FAST_NT) k_gru_bwd_f10h(int Bn, int T, const T
   }
 }
 
+// ---- naive per-gate sets (tt_linearset.py:5-38; `--naive_tt [--gru]`): G independent TT-matrices H -> H, one per gate ------------
+// The reverse recurrence dh_{t-1} = sum_g W_g^T dz_g on the per-gate fused cores (round 6; until then the tier's k_g2_bwd on the
+// joint matrix): S = ONE gate's shape.  T01 runs per gate — feature tile ft of gate g against that gate's sixteen-row image
+// [i2][m] (K1 = 32: one k-block) — and writes its results as k = (g, i2, r2) of chain row (j0, j1); T2 contracts over ALL gates'
+// (i2, r2) in G * NM2 k-blocks, one (column tile, k-block) pair or two per wave, each k-block un-scaled by ITS gate's row scales and
+// kept as a partial sum the gate threads add.  Per step: G | barrier | split | barrier | T01 | barrier | T2 | barrier, as the
+// single-matrix kernels.  Fragments and scale headers: k_f10bh_prep<S, true> once per gate on the un-joined cores.
+template <class S, int CELL>
+__global__ void __launch_bounds__(FAST_NT) k_rnn_bwd_f10n(int Bn, int T, const float* __restrict__ out, const float* __restrict__ h0,
+                                                          const float* __restrict__ c0, const float* __restrict__ hdrs,
+                                                          const xh8* __restrict__ wfrags, const float* __restrict__ reserve,
+                                                          const float* __restrict__ d_out, const float* __restrict__ d_hT,
+                                                          const float* __restrict__ d_cT, float* __restrict__ dg_in,
+                                                          float* __restrict__ dg_hid, float* __restrict__ d_h0,
+                                                          float* __restrict__ d_c0, BwdStats bs) {
+  using F = F10<S>;
+  using B = F10BH<S>;
+  constexpr bool LSTM = CELL == TTRNN_LSTM;
+  constexpr int G = LSTM ? 4 : 3;
+  constexpr int H = F::H, GH = G * H;
+  constexpr int K2T = G * B::K2;                                              // T2's contraction over all gates
+  constexpr int NS = G * B::NM2;                                              // its k-blocks = partial-sum slices
+  constexpr int NP = NS * B::CT2, NPW = (NP + FAST_NW - 1) / FAST_NW;        // (column tile, k-block) pairs; per wave
+  static_assert(B::NM1 == 1 && B::CT2 == 2 && B::XF == 2 && H == 256 && F::I2 == 8 && GH / 4 <= FAST_NT - H, "one gate of the naive sets of H = 256");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) float smax1[4];
+  __shared__ float sl1[FAST_NW];
+  constexpr int PG1 = 16 * B::K1;                                             // a gate's T01 image (halves per plane)
+  constexpr int PL1 = G * PG1, PL2 = F::ROWS2 * K2T;
+  float* dgf = reinterpret_cast<float*>(smem);                               // [G H]: the gate gradients of the hidden chain, HBM row order
+  float* dhs = dgf + GH;                                                     // [NS][H]
+  _Float16* img1h = reinterpret_cast<_Float16*>(dhs + NS * H);               // [2][G][16][K1]
+  _Float16* img2h = img1h + 2 * PL1;                                         // [2][ROWS2][K2T]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const size_t b = blockIdx.x;
+  constexpr int HF = B::HDR_FLOATS;
+  constexpr size_t FR = B::FRAGS;
+
+  xh8 w01[G][B::XF][2], w2t[NPW][2];
+  f32x4 un1[G][B::XF], un2[NPW];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int x = 0; x < B::XF; ++x) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w01[g][x][p] = wfrags[g * FR + (size_t)((wave + FAST_NW * x) * 2 + p) * 64 + lane];
+      un1[g][x] = *reinterpret_cast<const f32x4*>(hdrs + g * HF + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+    }
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pid = wave + FAST_NW * i < NP ? wave + FAST_NW * i : 0;
+    const int ubt = pid / B::CT2, g = ubt / B::NM2, ub = ubt % B::NM2;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) w2t[i][p] = wfrags[g * FR + (size_t)(B::FT * B::NM1 * 2 + ub * 2 + p) * 64 + lane];
+    un2[i] = *reinterpret_cast<const f32x4*>(hdrs + g * HF + B::UN2 + 4 * q);
+  }
+  float maxl1;
+  {
+    float l = 0.f;
+    for (int f = tid; f < G * F::K; f += FAST_NT) {
+      const int g = f / F::K, ff = f % F::K;
+      l = fmaxf(l, hdrs[g * HF + B::L1N + ff] * hdrs[g * HF + B::UN1 + ff]);
+    }
+    l = wave_max(l);
+    if (lane == 0) sl1[wave] = l;
+    __syncthreads();
+    maxl1 = sl1[0];
+#pragma unroll
+    for (int w = 1; w < FAST_NW; ++w) maxl1 = fmaxf(maxl1, sl1[w]);
+  }
+  // rows 8..15 of every gate's T01 image are never written by the gate threads: zeros, once
+  for (int e = tid; e < 2 * PL1; e += FAST_NT) img1h[e] = (_Float16)0.f;
+
+  const bool own = tid < H;
+  const int hid = own ? tid : 0;
+  float dhd = 0.f;                                                            // GRU: dh_t z_t; LSTM: unused
+  float dcs = (LSTM && own && d_cT) ? d_cT[b * H + hid] : 0.f;
+  const float c0v = (LSTM && own && c0) ? c0[b * H + hid] : 0.f;
+  const float* dptr = d_out ? d_out : reserve;
+  const float dscale = d_out ? 1.0f : 0.0f;
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, ra1 = ra0, ra2 = ra0;
+  float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f, do0 = 0.f, do1 = 0.f, do2 = 0.f;     // rb: LSTM c_t / GRU h_{t-1}
+  float cmi[G], cmh = 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) cmi[g] = 0.f;
+  auto issue = [&](int t, f32x4& ra, float& rb, float& dq) {                   // loads of set(t); clamped, unconditional
+    const size_t bt = b * T + (t > 0 ? t : 0);
+    ra = *reinterpret_cast<const f32x4*>(reserve + res_gate(bt, H, hid));
+    dq = dptr[bt * H + hid];
+    if (LSTM) {
+      rb = reserve[res_cell((size_t)Bn * T, bt, H, hid)];
+    } else {
+      const float* hp = t >= 1 ? out + (bt - 1) * H : (h0 ? h0 + b * H : out + bt * H);
+      rb = hp[hid];
+    }
+  };
+  if (own) {
+    dhs[hid] = d_hT ? d_hT[b * H + hid] : 0.f;
+#pragma unroll
+    for (int sl = 1; sl < NS; ++sl) dhs[sl * H + hid] = 0.f;
+    if (T > 0) {
+      issue(T - 1, ra0, rb0, do0);
+      issue(T - 2, ra1, rb1, do1);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  lds_barrier();
+
+  // nb: the record one step back (LSTM: c_{t-1} = set(t-1)'s cell value)
+  auto step = [&](const int t, const f32x4& ra, const float& rb, const float& dq, const float& nb, f32x4& fa, float& fb, float& fd) {
+    const size_t bt = b * T + t;
+    float pk[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) pk[g] = 0.f;
+    // ---- G: gate gradients (lstm.py:26-32 / gru.py:38-44 differentiated) ------------------------------------------------
+    if (own) {
+      issue(t - 2, fa, fb, fd);
+      float dht = dhd + dq * dscale;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) dht += dhs[sl * H + hid];
+      if constexpr (LSTM) {
+        const float ig = ra[0], gg = ra[1], fg = ra[2], og = ra[3], cy = rb;     // record slots i, g, f, o
+        const float cprev = t > 0 ? nb : c0v;
+        const float tc = ftanh(cy);
+        const float dct = dcs + dht * og * (1.0f - tc * tc);
+        pk[0] = dct * gg * ig * (1.0f - ig);                                     // gate order of the rows: i, f, g, o
+        pk[1] = dct * cprev * fg * (1.0f - fg);
+        pk[2] = dct * ig * (1.0f - gg * gg);
+        pk[3] = dht * tc * og * (1.0f - og);
+        dcs = dct * fg;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          cmi[g] = fmaxf(cmi[g], fabsf(pk[g]));
+          dgf[g * H + hid] = pk[g];
+        }
+      } else {
+        const float rg = ra[0], zg = ra[1], ng = ra[2], hn = ra[3];
+        const float hprev = (t > 0 || h0) ? rb : 0.f;
+        const float dn_pre = dht * (1.0f - zg) * (1.0f - ng * ng);
+        const float dz_pre = dht * (hprev - ng) * zg * (1.0f - zg);
+        const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+        dhd = dht * zg;
+        pk[0] = dr_pre; pk[1] = dz_pre; pk[2] = dn_pre * rg;
+        const float pin[3] = {dr_pre, dz_pre, dn_pre};
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          cmi[g] = fmaxf(cmi[g], fabsf(pin[g]));
+          dgf[g * H + hid] = pk[g];
+        }
+        cmh = fmaxf(cmh, fabsf(pk[2]));
+        dg_in[bt * GH + 2 * H + hid] = dn_pre;                // the only block where d_gates_in != d_gates_hid
+      }
+      float mx = fabsf(pk[0]);
+#pragma unroll
+      for (int g = 1; g < G; ++g) mx = fmaxf(mx, fabsf(pk[g]));
+      mx = wave_max(mx);
+      if (lane == 0) smax1[wave] = mx;
+    }
+    lds_barrier();
+    // ---- split: the step's scale; the gate threads split their own values; waves 4-7 send the fp32 rows to HBM ------------
+    float u2, t01f;
+    {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax1);
+      const float mxg = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float ug;
+      const float sg = step_scale(mxg, ug);
+      const float s2 = step_scale(mxg * maxl1, u2);
+      t01f = ug * s2;
+      if (own) {
+        const int m = hid / F::I2, i2 = hid % F::I2;           // the unit's place in every gate's matrix: (m, i2), natural k = m
+        const int off = x_off<B::K1>(i2, m);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          _Float16 p0, p1;
+          split2h(pk[g] * sg, p0, p1);
+          img1h[g * PG1 + off] = p0;
+          img1h[PL1 + g * PG1 + off] = p1;
+        }
+      } else {
+        const int i4 = tid - H;
+        if (i4 < GH / 4) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(dgf)[i4];
+          if (LSTM) {
+            reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;  // (an LSTM's d_gates_hid IS d_gates_in)
+          } else {
+            reinterpret_cast<f32x4*>(dg_hid + bt * GH)[i4] = v;
+            if (i4 < 2 * H / 4) reinterpret_cast<f32x4*>(dg_in + bt * GH)[i4] = v;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- T01: per gate, the wave's two feature tiles against the gate's image ------------------------------------------
+    {
+      const int rowc = c < F::I2 ? c : F::I2;                  // (rows 8..15 of a gate's image are zeros)
+      f32x4 au[G][B::XF];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        xh8 bf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + g * PG1 + x_off<B::K1>(rowc, 8 * q));
+#pragma unroll
+        for (int x = 0; x < B::XF; ++x) {
+          au[g][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+          au[g][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[g][x][1], bf[0], au[g][x], 0, 0, 0);
+          au[g][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[g][x][0], bf[1], au[g][x], 0, 0, 0);
+          au[g][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w01[g][x][0], bf[0], au[g][x], 0, 0, 0);
+        }
+      }
+      if (c < F::I2) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int x = 0; x < B::XF; ++x) {
+            const int f0 = 16 * (wave + FAST_NW * x) + 4 * q;
+            const int row2 = f0 / F::R2, r20 = f0 % F::R2;
+            store_split4_h(img2h, PL2, x_off<K2T>(row2, g * B::K2 + B::k2_of(c, r20)), au[g][x] * (un1[g][x] * t01f));
+          }
+      }
+    }
+    lds_barrier();
+    // ---- T2: pairs (column tile ct, k-block ubt of all gates) = wave, wave + 8 (< NP) -----------------------------------
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pid = wave + FAST_NW * i;
+      if (pid < NP) {
+        const int ubt = pid / B::CT2, ct = pid % B::CT2;
+        const int row = 16 * ct + c;
+        xh8 b2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          b2[p] = *reinterpret_cast<const xh8*>(img2h + p * PL2 + x_off<K2T>(row, 32 * ubt + 8 * q));
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][1], b2[0], z4, 0, 0, 0);
+        const f32x4 ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][0], b2[0], z4, 0, 0, 0);
+        alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2t[i][0], b2[1], alo, 0, 0, 0);
+        const f32x4 acc = ahi + alo;
+        if (q < 2) *reinterpret_cast<f32x4*>(dhs + ubt * H + row * F::J2 + 4 * q) = acc * (un2[i] * u2);
+      }
+    }
+    lds_barrier();
+  };
+  for (int t = T - 1; t >= 0; t -= 3) {
+    step(t, ra0, rb0, do0, rb1, ra2, rb2, do2);
+    if (t >= 1) step(t - 1, ra1, rb1, do1, rb2, ra0, rb0, do0);
+    if (t >= 2) step(t - 2, ra2, rb2, do2, rb0, ra1, rb1, do1);
+  }
+  if (own) {
+    if (bs.colmax) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        atomicMax(bs.colmax + g * H + hid, __float_as_uint(cmi[g]));
+        atomicMax(bs.colmax + GH + g * H + hid, __float_as_uint((LSTM || g < 2) ? cmi[g] : cmh));
+      }
+    }
+    if (d_h0) {
+      float v = dhd;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) v += dhs[sl * H + hid];
+      d_h0[b * H + hid] = v;
+    }
+    if (LSTM && d_c0) d_c0[b * H + hid] = dcs;
+  }
+}
+
+template <class S, int CELL>
+constexpr size_t f10n_bwd_lds_bytes() {
+  using B = F10BH<S>;
+  using F = F10<S>;
+  constexpr int G = CELL == TTRNN_LSTM ? 4 : 3;
+  return sizeof(float) * ((size_t)G * F::H + (size_t)G * B::NM2 * F::H) +
+         sizeof(_Float16) * 2 * ((size_t)G * 16 * B::K1 + (size_t)F::ROWS2 * G * B::K2);
+}
+
+template <class S, int CELL>
+int launch_n_bwd(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid, const float* reserve,
+                 const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                 hipStream_t stream, const BwdStats& bs) {
+  using B = F10BH<S>;
+  constexpr int G = CELL == TTRNN_LSTM ? 4 : 3;
+  const size_t npg = f10n_unjoined_floats(CELL);
+  float* pg = reinterpret_cast<float*>(ws);
+  float* hdrs = pg + ((npg + 63) & ~(size_t)63);
+  xh8* wfrags = reinterpret_cast<xh8*>(hdrs + (size_t)G * B::HDR_FLOATS);
+  int st = launch_f10n_unjoin(rs, packed_hid, pg, stream);
+  if (st != TTRNN_OK) return st;
+  for (int g = 0; g < G; ++g)      // (the first launch clears the by-products' column maxima)
+    hipLaunchKernelGGL((k_f10bh_prep<S, true>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, (const float*)(pg + (size_t)g * (npg / G)),
+                       hdrs + (size_t)g * B::HDR_FLOATS, wfrags + (size_t)g * B::FRAGS, g == 0 ? bs.colmax : nullptr,
+                       (g == 0 && bs.colmax) ? 2 * G * B::H : 0);
+  constexpr size_t lds = f10n_bwd_lds_bytes<S, CELL>();
+  static_assert(lds <= 64 * 1024, "raise the dynamic LDS limit for this shape");
+  hipLaunchKernelGGL((k_rnn_bwd_f10n<S, CELL>), dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)out, (const float*)h0,
+                     (const float*)c0, (const float*)hdrs, (const xh8*)wfrags, reserve, (const float*)d_out, (const float*)d_hT,
+                     (const float*)d_cT, dg_in, dg_hid, (float*)d_h0, (float*)d_c0, bs);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 template <class S, typename TS>
 int launch_gru_t(const RnnShape& rs, const void* out, const void* h0, const float* packed_hid, const float* reserve,
                  const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0, void* ws,
@@ -1466,6 +1767,29 @@ int launch_lstm_bwd_f10h(const RnnShape& rs, const void* c0, const float* packed
     return launch_t<ShpH256R16L>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, diag, stream,
                                  bs);
   return TTRNN_ERR_UNSUPPORTED;
+}
+
+// naive per-gate sets of H = 256, d = 3, r = 8 (fp32 storage, split mode; option dev2 bit 9 keeps the tier's kernel)
+bool f10n_bwd_available(const RnnShape& rs, int dtype) {
+  return dtype == TTRNN_F32 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && opt(OPT_GEMM_PIECES) != 3 && !opt(OPT_NO_F10) &&
+         !(opt(OPT_DEV2) & 512) && rs.B >= 1 && rs.T >= 1 && f10n_shape_matches(rs);
+}
+size_t f10n_bwd_workspace_bytes(const RnnShape& rs) {
+  using B = F10BH<ShpH256N>;
+  const int G = rs.cell == TTRNN_LSTM ? 4 : 3;
+  const size_t npg = (f10n_unjoined_floats(rs.cell) + 63) & ~(size_t)63;
+  return npg * sizeof(float) + (size_t)G * (B::HDR_FLOATS * sizeof(float) + B::FRAGS * sizeof(xh8)) + 256;
+}
+int launch_rnn_bwd_f10n(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                        const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                        void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* stats) {
+  BwdStats bs;
+  if (stats) bs.colmax = reinterpret_cast<unsigned*>(stats);      // (cleared by the first prep launch)
+  int st = rs.cell == TTRNN_LSTM
+               ? launch_n_bwd<ShpH256N, TTRNN_LSTM>(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, bs)
+               : launch_n_bwd<ShpH256N, TTRNN_GRU>(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, dg_hid, d_h0, d_c0, ws, stream, bs);
+  if (st == TTRNN_OK && stats) st = launch_bwd_stats_finish(rs.cell, rs.B, rs.G * rs.H, nullptr, stats, stream);
+  return st;
 }
 
 int launch_gru_bwd_f10h(const RnnShape& rs, int dtype, const void* out, const void* h0, const float* packed_hid,

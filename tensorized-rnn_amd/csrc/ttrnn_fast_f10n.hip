@@ -380,6 +380,26 @@ int launch_n(const RnnShape& rs, GinSrc gin, const float* bilv, const void* h0, 
 
 }  // namespace
 
+// the per-gate packed cores of a joint matrix, for the reverse-time kernel of the same sets (ttrnn_fast_f10bh.hip: k_rnn_bwd_f10n)
+size_t f10n_unjoined_floats(int cell) { return (size_t)f10n_gates(cell) * f10n_packed_elems<ShpH256N>(); }
+int launch_f10n_unjoin(const RnnShape& rs, const float* packed_hid, float* pg, hipStream_t stream) {
+  constexpr int TOT = f10n_packed_elems<ShpH256N>();
+  const int G = f10n_gates(rs.cell);
+  if (!f10n_joint_matches<ShpH256N>(rs.hid_s, G)) return TTRNN_ERR_UNSUPPORTED;
+  const long n = (long)G * TOT > rs.hid_s.wtotal ? (long)G * TOT : rs.hid_s.wtotal;
+  if (G == 4)
+    hipLaunchKernelGGL((k_f10n_unjoin<ShpH256N, 4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rs.hid_s, packed_hid, pg,
+                       (unsigned*)nullptr);
+  else
+    hipLaunchKernelGGL((k_f10n_unjoin<ShpH256N, 3>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rs.hid_s, packed_hid, pg,
+                       (unsigned*)nullptr);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+bool f10n_shape_matches(const RnnShape& rs) {
+  return (rs.cell == TTRNN_LSTM || rs.cell == TTRNN_GRU) && rs.hid_blocks == f10n_gates(rs.cell) &&
+         f10n_joint_matches<ShpH256N>(rs.hid_s, f10n_gates(rs.cell));
+}
+
 // fp32-storage naive TT-LSTM / TT-GRU of H = 256, d = 3, r = 8 per gate, split math mode (dev bit 25: the runtime-shape tier's kernel, A/B)
 bool f10n_available(const RnnShape& rs, int dtype) {
   const int G = f10n_gates(rs.cell);

@@ -338,6 +338,15 @@ bool f10bh_available(const RnnShape& rs, int dtype);
 // ... and for the runtime tier's H = 512, r = 8 TT-LSTM (the reference's benchmarking.py defaults): called from that tier's branch
 // of ttrnn_rnn_backward_ex when no per-step state gradients are asked for; stats: the column maxima (rows 0 / 1) or NULL
 bool f10bh_h512_available(const RnnShape& rs, int dtype);
+// naive per-gate sets of H = 256 (ttrnn_fast_f10n.hip: forward, unjoin; ttrnn_fast_f10bh.hip: the reverse-time kernel, round 6)
+size_t f10n_unjoined_floats(int cell);
+int launch_f10n_unjoin(const RnnShape& rs, const float* packed_hid, float* pg, hipStream_t stream);
+bool f10n_shape_matches(const RnnShape& rs);
+bool f10n_bwd_available(const RnnShape& rs, int dtype);
+size_t f10n_bwd_workspace_bytes(const RnnShape& rs);
+int launch_rnn_bwd_f10n(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid,
+                        const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,
+                        void* d_h0, void* d_c0, void* ws, hipStream_t stream, float* stats);
 size_t f10bh_h512_workspace_bytes();
 int launch_rnn_bwd_f10_h512(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid,
                             const float* reserve, const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid,

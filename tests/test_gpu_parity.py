@@ -825,7 +825,12 @@ def test_naive_per_gate_sets_run_on_the_fused_path(kind, inp, H, L, d, r, B, T):
     lstm = kind == "ttlstm"
     # (round 5: the naive sets of H = 256, r = 8 have a fused-core forward kernel of their own, one gate per wave: ttrnn_fast_f10n.hip)
     assert F.rnn_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if (H == 256 and d == 3 and r == 8) else "runtime_mfma")
-    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
+    # (round 6: ... and a reverse-time kernel on the per-gate fused cores, k_rnn_bwd_f10n; option dev2 bit 9 = the tier's kernel)
+    first_tier = H == 256 and d == 3 and r == 8
+    assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == ("fused_core" if first_tier else "runtime_mfma")
+    import ttrnn_hip
+    with ttrnn_hip.option("dev2", 512):
+        assert F.rnn_backward_route(m._all_layers[0]._layer_spec(), B, T) == "runtime_mfma"
     x = torch.randn(B, T, inp)
     w = torch.randn(B, T, H)
     from oracle import ttrnn_oracle as O
@@ -2921,6 +2926,110 @@ def test_fused_core_gru_reverse_kernel_rank_16(case, inp):
     assert torch.equal(got["h0"], again["h0"])
     print(case, inp, "max gradient error relative to each tensor's maximum:", worst)
     assert worst["fused"] <= 2e-5 and worst["fused"] <= 3.0 * worst["replaced"] + 1e-6
+
+
+@pytest.mark.parametrize("kind", ["ttlstm", "ttgru"])
+@pytest.mark.parametrize("case", ["plain", "decades", "sparse_steps", "last_step_only", "no_state", "outlier", "bench_size"])
+def test_naive_sets_reverse_kernel(kind, case):
+    """round 6: the naive per-gate sets of H = 256, d = 3, r = 8 (tt_linearset.py:5-38; pMNIST --naive_tt [--gru])
+    on a reverse-time kernel of their own — k_rnn_bwd_f10n: T01 per gate on the gate's fused core, T2 over all gates' k-blocks — instead
+    of the tier's kernel on the joint matrix.  Every gradient against the float64 oracle (per-gate evaluation) and against the route
+    it replaces (option dev2 bit 9) reading the same forward records; output gradients over ten decades, steps and samples without
+    gradient, a loss on the last step only, no initial state, one core entry x 1e3, and the benchmark's size (B = 64, T = 784:
+    against the tier, and twice for the bits)."""
+    import ttrnn_hip
+    from ttrnn_hip import functional as F
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(331)
+    H, inp = 256, (1 if case == "bench_size" else 24)
+    lstm = kind == "ttlstm"
+    meta = dict(kind=kind, input_size=inp, hidden_size=H, num_layers=1, n_cores=3, tt_rank=8, is_naive=True)
+    m = build_module(meta, dev())
+    if case == "outlier":
+        cores = [p for n, p in m.named_parameters() if "hidden_weights" in n and p.dim() > 1]
+        with torch.no_grad():
+            flat = cores[-1].detach().clone().contiguous().view(-1)
+            flat[(5 * flat.numel()) // 11] *= 1e3
+            cores[-1].copy_(flat.view(cores[-1].shape))
+    B, T = (64, 784) if case == "bench_size" else (5, 40 if case == "last_step_only" else 9)
+    x = torch.randn(B, T, inp)
+    state = case != "no_state"
+    h0 = torch.randn(B, H) * 0.3 if state else None
+    c0 = torch.randn(B, H) * 0.3 if (state and lstm) else None
+    w = torch.randn(B, T, H)
+    if case == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif case == "sparse_steps":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    elif case == "last_step_only":
+        w[:, :-1] = 0.0
+    wsum = 0.0 if case in ("sparse_steps", "last_step_only") else 1.0
+    spec = m._all_layers[0]._layer_spec()
+    assert F.rnn_backward_route(spec, B, T) == "fused_core"
+
+    def run():
+        m.zero_grad()
+        xg = x.to(dev()).contiguous().requires_grad_(True)
+        h0g = None if h0 is None else h0.to(dev()).contiguous().requires_grad_(True)
+        c0g = None if c0 is None else c0.to(dev()).contiguous().requires_grad_(True)
+        if lstm:
+            out, (hT, cT) = m(xg, None if h0g is None else (h0g, c0g))
+            loss = (out * w.to(dev())).sum() + wsum * (cT.sum() + 0.5 * hT.sum())
+        else:
+            out, hT = m(xg, h0g)
+            loss = (out * w.to(dev())).sum() + wsum * 0.5 * hT.sum()
+        loss.backward()
+        g = {"x": xg.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+        if h0g is not None:
+            g["h0"] = h0g.grad.clone()
+        if c0g is not None:
+            g["c0"] = c0g.grad.clone()
+        return g
+
+    got, again = run(), run()
+    with ttrnn_hip.option("dev2", 512):
+        assert F.rnn_backward_route(spec, B, T) == "runtime_mfma"
+        old = run()
+    for n in got:
+        assert torch.isfinite(got[n]).all(), n
+        assert torch.equal(got[n], again[n]) or n not in ("x", "h0", "c0"), n      # the reverse kernel's own results: bit for bit
+    if case == "sparse_steps" and state:
+        assert float(got["h0"][2].abs().max()) == 0.0
+    if case == "bench_size":
+        for n in got:
+            sc = max(float(old[n].abs().max()), 1e-30)
+            assert _maxabs(got[n], old[n]) <= 2e-4 * sc, (n, _maxabs(got[n], old[n]) / sc)
+        return
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    h0r = None if h0 is None else h0.double().clone().requires_grad_(True)
+    c0r = None if c0 is None else c0.double().clone().requires_grad_(True)
+    if lstm:
+        ro, (rh, rc) = O.lstm_forward(layers, xr, None if h0r is None else (h0r, c0r))
+        ((ro * w.double()).sum() + wsum * (rc.sum() + 0.5 * rh.sum())).backward()
+    else:
+        ro, rh = O.gru_forward(layers, xr, h0r)
+        ((ro * w.double()).sum() + wsum * 0.5 * rh.sum()).backward()
+    refs = {"x": xr.grad}
+    for n, _ in m.named_parameters():
+        key = n.replace(".gate", ".gates.")        # gate{i} (attribute) and gates.{i} (ModuleList) are the same Parameters
+        if key in leaves and leaves[key].grad is not None:
+            refs[n] = leaves[key].grad
+    assert len(refs) >= 1 + 2 * 3 * (4 if lstm else 3)
+    if h0r is not None:
+        refs["h0"] = h0r.grad
+    if c0r is not None:
+        refs["c0"] = c0r.grad
+    worst = {"fused": 0.0, "replaced": 0.0}
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        worst["fused"] = max(worst["fused"], _maxabs(got[n].double(), ref) / sc)
+        worst["replaced"] = max(worst["replaced"], _maxabs(old[n].double(), ref) / sc)
+    print(kind, case, "max gradient error relative to each tensor's maximum:", worst)
+    tol = 5e-3 if case == "outlier" else 2e-5
+    assert worst["fused"] <= tol and worst["fused"] <= 3.0 * worst["replaced"] + 1e-6
 
 
 @pytest.mark.parametrize("case", ["plain", "decades", "last_step_only", "no_h0"])
