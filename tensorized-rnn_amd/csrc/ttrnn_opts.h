@@ -45,7 +45,9 @@ enum OptId {
                          //                         8: offer the chain kernel's LARGE variant too (measured slower than the dense gradient: tests only),
                          //                         16: the speaker encoder's shape on the runtime tier instead of k_lstm_fwd_w2 (forward), 32: the same for the reverse-time kernel,
                          //                         64: k_c2w (C1 / dC1 images in LDS) for the calls k_c2r (register hand-offs) would take,
-                         //                         bits 8 and up: ablation switches of the chain kernels in -DTTRNN_ABLATIONS builds (tools/c2w_bench.py)
+                         //                         128: TT-GRU H = 256 r = 16 reverse recurrence on the tier's kernel, 256: the same for the TT-GRU of H = 512 r = 8,
+                         //                         512: naive per-gate sets of H = 256 on the tier's reverse-time kernel (instead of k_rnn_bwd_f10n),
+                         //                         (-DTTRNN_ABLATIONS builds only, tools/c2w_bench.py: bits 8 and up are the chain kernels' ablation switches instead)
   OPT_COUNT
 };
 
