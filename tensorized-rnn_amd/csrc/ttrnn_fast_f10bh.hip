@@ -32,6 +32,7 @@ namespace ttrnn {
 namespace {
 
 using ShpH512R8G = Shp<3, 8, 8, 8, 1, 8, 12, 16, 1, 8, 8, 1>;      // benchmarking.py defaults with --gru (ttrnn_fast_f10g5.hip has the forward)
+typedef _Float16 xh4 __attribute__((ext_vector_type(4)));
 
 template <class S>
 struct F10BH {
@@ -48,7 +49,8 @@ struct F10BH {
   // header (floats): [un1: F::K | un2: 16 | L1 norms of the scaled rows: ROWS], padded to 256 bytes
   static constexpr int UN1 = 0, UN2 = F::K, L1N = F::K + 16;
   static constexpr int HDR_FLOATS = (F::K + 16 + ROWS + 63) / 64 * 64;
-  static constexpr size_t FRAGS = (size_t)(FT * NM1 + NM2) * 2 * 64;      // xh8 fragments
+  static constexpr size_t FRAGS_T = (size_t)(FT * NM1 + NM2) * 2 * 64;    // xh8 fragments of T01 and T2
+  static constexpr size_t FRAGS = FRAGS_T + (size_t)F::R2 * 64;           // + (wave-local kernel) T2's B operand per r2: two planes of xh4
   __device__ static constexpr int m_of_k1(int k) { return (k & 3) * F::MPG + (k >> 2); }
   __device__ static constexpr int k2_of(int i2, int r2) { return ((r2 >> 2) * HI + (i2 >> 1)) * 8 + (i2 & 1) * 4 + (r2 & 3); }
 };
@@ -111,7 +113,10 @@ __device__ __forceinline__ void split8h(const f32x4& va, const f32x4& vb, xh8& h
 // Fragments + row scales + the scaled rows' L1 norms.  Block ft < FT: rows 16 ft + r of W10 (wave u = k-block u); block FT: the rows of G2.
 // Fragment order: T01 wf[((ft*NM1 + u)*2 + p)*64 + lane], lane (r, q): k = 32u + 8q + e (gate-interleaved: m_of_k1);
 //                 T2  wf[T01 part + (u*2 + p)*64 + lane], lane (r, q): row j2 = r (< J2, else 0), k2 slot 4u + q
-template <class S, bool NATK = false>
+// WL (round 6, k_lstm_bwd_f10h<S, DIAG, true>): feature tile t = (r2 = t / CT2, sixteen chain rows 16 (t % CT2) ..) instead of sixteen
+// consecutive (row2, r2) — a tile then shares ONE r2, which is what lets T2 take T01's accumulator tiles as its operand — and, behind
+// the fragments above, T2's B operand for v_mfma_f32_16x16x16_f16 per r2: lane (c = j2, q) holds G2[r2][j2][i2 = 4 q ..] (two planes)
+template <class S, bool NATK = false, bool WL = false>
 __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict__ packed, float* __restrict__ hdr,
                                                         xh8* __restrict__ wfrag, unsigned* __restrict__ zero, int zero_n) {
   // (the by-products' column maxima start from zero: cleared here instead of by a launch of their own)
@@ -130,7 +135,7 @@ __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict_
   if (wave < nu) {
     if (!g2) {
       const int f = 16 * blockIdx.x + r;
-      const int row2 = f / F::R2, r2 = f % F::R2;
+      const int row2 = WL ? 16 * ((int)blockIdx.x % B::CT2) + r : f / F::R2, r2 = WL ? (int)blockIdx.x / B::CT2 : f % F::R2;
       const int j1 = row2 % F::J1, j0 = row2 / F::J1;
       const float* W0 = packed + woff_of<S>(0);               // [J0*R1][I0]
       const float* W1 = packed + woff_of<S>(1);               // [J1*R2][I1*R1]
@@ -183,6 +188,23 @@ __global__ void __launch_bounds__(FAST_NT) k_f10bh_prep(const float* __restrict_
     dst[0] = p0;
     dst[64] = p1;
   }
+  if constexpr (WL) {
+    if (g2 && wave < F::R2) {                                 // wave = r2: the 16 x 16 tile B[k = i2][n = j2] of G2[r2], row j2 under its scale
+      static_assert(F::R2 <= FAST_NW && F::I2 == 16, "one wave per r2");
+      const float* W2 = packed + woff_of<S>(2);
+      xh4* d4 = reinterpret_cast<xh4*>(wfrag + B::FRAGS_T);
+      xh4 q0, q1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float w = (r < F::J2 ? W2[r * F::M2 + (4 * q + j) * F::R2 + wave] : 0.f) * sc;
+        _Float16 a, b;
+        split2h(w, a, b);
+        q0[j] = a; q1[j] = b;
+      }
+      d4[(wave * 2 + 0) * 64 + lane] = q0;
+      d4[(wave * 2 + 1) * 64 + lane] = q1;
+    }
+  }
   __syncthreads();
   if (tid < 16) {
     float a2 = 0.f;
@@ -204,7 +226,12 @@ constexpr size_t f10bh_lds_bytes() {
 template <class S>
 constexpr size_t f10bp_lds_bytes() { return f10bh_lds_bytes<S>() + (size_t)2 * 2 * F10<S>::H * sizeof(f32x4); }      // + the factor vectors
 
-template <class S, bool DIAG>
+// WL (round 6): T01 and T2 WAVE-LOCAL.  Wave w takes chain-row block rb = w % CT2 and the ranks r2 = 2 (w / CT2),
+// + 1: T01 as D[i2][row2] = dz^T[i2][m] W10[(row2, r2)][m] — the gate-gradient image is the A operand, the fused core's rows of ONE r2
+// the B operand — leaves a tile with the chain row on the lane and four consecutive i2 in the registers, which IS the A operand of
+// v_mfma_f32_16x16x16_f16 for T2's contraction over i2 (B = G2[r2][j2][i2], per r2, from registers); the wave sums its two r2 and
+// leaves one partial dh slice.  No dC2 image, no barrier between the transposed stages: three barriers per step instead of four.
+template <class S, bool DIAG, bool WL = false>
 __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const float* __restrict__ c0,
                                                            const float* __restrict__ hdr, const xh8* __restrict__ wfrag,
                                                            const float* __restrict__ reserve,
@@ -238,17 +265,29 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
   const size_t b = blockIdx.x;
 
   // resident fragments (two pieces) and the inverse row scales of the accumulator registers
+  static_assert(!WL || (B::XF == 2 && F::R2 == 8 && B::NM2 * B::CT2 == FAST_NW && F::I2 == 16), "wave-local stages: rank 8, two tiles per wave");
   xh8 w01[B::XF][B::NM1][2], w2t[B::XT2][2];
   f32x4 un1[B::XF], un2;
+  xh4 g2x[WL ? 2 : 1][2];                                  // (WL) T2's B operand of the wave's two r2
+  float un1w[2] = {0.f, 0.f}, un2w = 0.f;                   // (WL) inverse row scales: per lane column
 #pragma unroll
   for (int x = 0; x < B::XF; ++x) {
+    // (WL) tile (r2 = 2 (wave / CT2) + x, row block wave % CT2)
+    const int tile = WL ? (2 * (wave / B::CT2) + x) * B::CT2 + wave % B::CT2 : wave + FAST_NW * x;
 #pragma unroll
     for (int u = 0; u < B::NM1; ++u)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        w01[x][u][p] = wfrag[(size_t)(((wave + FAST_NW * x) * B::NM1 + u) * 2 + p) * 64 + lane];
-    if constexpr (B::XF < 4) un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * (wave + FAST_NW * x) + 4 * q);
+        w01[x][u][p] = wfrag[(size_t)((tile * B::NM1 + u) * 2 + p) * 64 + lane];
+    if constexpr (B::XF < 4) un1[x] = *reinterpret_cast<const f32x4*>(hdr + B::UN1 + 16 * tile + 4 * q);
+    if constexpr (WL) {
+      un1w[x] = hdr[B::UN1 + 16 * tile + (lane & 15)];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        g2x[x][p] = reinterpret_cast<const xh4*>(wfrag + B::FRAGS_T)[((2 * (wave / B::CT2) + x) * 2 + p) * 64 + lane];
+    }
   }
+  if constexpr (WL) un2w = hdr[B::UN2 + (lane & 15)];
   if constexpr (B::XF >= 4)
     for (int f = tid; f < F::K; f += FAST_NT) un1s[f] = hdr[B::UN1 + f];
   static_assert(FAST_NW % B::CT2 == 0, "a wave's T2 pairs share the column tile");
@@ -415,6 +454,52 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
           const f32x4 u1 = *reinterpret_cast<const f32x4*>(un1s + f0);
           store_split4_h(img2h, PL2, x_off<B::K2>(row2, B::k2_of(c, r20)), acc[x] * (u1 * t01f));
         }
+      } else if constexpr (WL) {
+        xh8 bf[B::NM1][2];
+#pragma unroll
+        for (int u = 0; u < B::NM1; ++u)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            bf[u][p] = *reinterpret_cast<const xh8*>(img1h + p * PL1 + x_off<B::K1>(c, 32 * u + 8 * q));
+        f32x4 au[2][B::NM1];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int u = 0; u < B::NM1; ++u) {                        // A = the gate-gradient image (rows i2), B = the fused core's rows of one r2
+            au[x][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][0], w01[x][u][1], au[x][u], 0, 0, 0);
+            au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][1], w01[x][u][0], au[x][u], 0, 0, 0);
+            au[x][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][0], w01[x][u][0], au[x][u], 0, 0, 0);
+          }
+        TT_STAMP(4)
+        TT_STAMP(5)
+        // lane (c = chain row in the block, q), registers j: i2 = 4 q + j — the k group of the 16x16x16 MFMA, for T2 as they are
+        // (per r2: the two small terms on one accumulator, the large one on its own, the two r2 independent: two MFMA latencies on
+        // the path instead of six)
+        f32x4 alo[2], ahi[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          f32x4 acc = au[x][0];
+#pragma unroll
+          for (int u = 1; u < B::NM1; ++u) acc += au[x][u];
+          acc = acc * (un1w[x] * t01f);
+          unsigned a0lo, a1lo, a0hi, a1hi;
+          split_pair_h(acc[0], acc[1], a0lo, a1lo);
+          split_pair_h(acc[2], acc[3], a0hi, a1hi);
+          const xh4 a0 = __builtin_bit_cast(xh4, u32x2{a0lo, a0hi}), a1 = __builtin_bit_cast(xh4, u32x2{a1lo, a1hi});
+          const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          alo[x] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, g2x[x][0], z4, 0, 0, 0);
+          ahi[x] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, g2x[x][0], z4, 0, 0, 0);
+          alo[x] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, g2x[x][1], alo[x], 0, 0, 0);
+        }
+        const f32x4 acc2 = (ahi[0] + alo[0]) + (ahi[1] + alo[1]);
+        // lane (c = j2, q), registers j: chain row 16 rb + 4 q + j -> hidden unit row * J2 + j2; slice = the wave's r2 pair
+        if (c < F::J2) {
+          float* dst = dhs + (wave / B::CT2) * H + (16 * (wave % B::CT2) + 4 * q) * F::J2 + c;
+          const float us = un2w * u2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dst[j * F::J2] = acc2[j] * us;
+        }
       } else {
         xh8 bf[B::NM1][2];
 #pragma unroll
@@ -442,11 +527,13 @@ __global__ void __launch_bounds__(FAST_NT) k_lstm_bwd_f10h(int Bn, int T, const 
         }
       }
     }
+    if constexpr (!WL) {
     TT_STAMP(4)
     lds_barrier();
     TT_STAMP(5)
+    }
     // ---- T2: dh_{t-1}[row2][j2], pair = (column tile ct, k-block ub): one partial-sum slice per k-block -------------
-    {
+    if constexpr (!WL) {
       // (r = 16: two pairs per wave — both pairs' products first, ONE guarded block of stores behind them: lesson 40)
       f32x4 acc2[B::XT2];
 #pragma unroll
@@ -1650,11 +1737,28 @@ int launch_t(const RnnShape& rs, const void* c0, const float* packed_hid, const 
   using B = F10BH<S>;
   float* hdr = reinterpret_cast<float*>(ws);
   xh8* wfrag = reinterpret_cast<xh8*>(hdr + B::HDR_FLOATS);
-  hipLaunchKernelGGL((k_f10bh_prep<S>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag, bs.colmax,
-                     bs.colmax ? 2 * 4 * B::H : 0);
   constexpr size_t lds = f10bh_lds_bytes<S>();
   static_assert(lds <= 150 * 1024, "LDS image set too large");
   const bool dg = opt(OPT_DIAG) != 0;
+  // (round 6) rank 8 at H = 256, one sample per CU: T01 and T2 wave-local, three barriers per step (option dev2 bit 10: the
+  // four-barrier kernel, A/B)
+  constexpr bool WL_OK = f10bh_ok<S>() && B::XF == 2 && F10<S>::R2 == 8 && B::NM2 * B::CT2 == FAST_NW && F10<S>::H == 256;
+  if constexpr (WL_OK) {
+    const bool other = (f10bl_ok<S>() && (rs.B > device_cu_count() || (opt(OPT_DEV) & 128)) && !(opt(OPT_DEV) & 32768)) ||
+                       (opt(OPT_DEV) & (1 << 17)) || (opt(OPT_DEV2) & 1024);
+    if (!other) {
+      hipLaunchKernelGGL((k_f10bh_prep<S, false, true>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag, bs.colmax,
+                         bs.colmax ? 2 * 4 * B::H : 0);
+      auto kern = dg ? k_lstm_bwd_f10h<S, true, true> : k_lstm_bwd_f10h<S, false, true>;
+      if (lds > 64 * 1024 && ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+      hipLaunchKernelGGL(kern, dim3(rs.B), dim3(FAST_NT), lds, stream, rs.B, rs.T, (const float*)c0, hdr, wfrag, reserve,
+                         (const float*)d_out, (const float*)d_hT, (const float*)d_cT, dg_in, dg_hid, (float*)d_h0,
+                         (float*)d_c0, dg ? diag : nullptr, bs);
+      return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((k_f10bh_prep<S>), dim3(B::FT + 1), dim3(FAST_NT), 0, stream, packed_hid, hdr, wfrag, bs.colmax,
+                     bs.colmax ? 2 * 4 * B::H : 0);
   if constexpr (f10bl_ok<S>()) {
     // one wave per 64 hidden units, T2 wave-local, two barriers per step: where two of its four-wave workgroups share a CU
     // (B > #CUs; cfg4: 586 -> 526 us per layer) and at H = 512 (eight waves either way).  One sample per CU at H = 256 stays on
