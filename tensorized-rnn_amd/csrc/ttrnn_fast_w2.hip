@@ -36,14 +36,19 @@ namespace {
 
 // Configurations: the two-core view (J0 x J1 -> 48 x 64 through R rank slots; a smaller real rank fills its slots with zeros) of
 //   A  d = 2: hidden (24, 32), input (5, 8)          B  d = 4: hidden (4*4, 6*8) = (16, 48), input (2*2, 2*5) = (4, 10)
-template <int J0_, int J1_, int J0I_, int J1I_, int R_>
+// GATES = 3: the TT-GRU of the same layer (speaker_encoder.py:33-47 `use_gru`; gru.py:33-44): output modes (48, 48), three waves, and
+// FOUR rows per unit in stage 2 all the same — r, z, the hidden part of n, the input part of n (the n gate multiplies W_hn h + b_hn by
+// r before the input part is added: the two chains must not meet in one accumulator, so row 2 carries zeros in the input chain's k-slots
+// and row 3 zeros in the hidden chain's).
+template <int J0_, int J1_, int J0I_, int J1I_, int R_, int GATES_ = 4>
 struct W2T {
-  static constexpr int J0 = J0_, J1 = J1_, I0 = 48, I1 = 64, R = R_, H = J0_ * J1_;
+  static constexpr int GATES = GATES_;
+  static constexpr int J0 = J0_, J1 = J1_, I0 = 48, I1 = GATES_ == 4 ? 64 : 48, R = R_, H = J0_ * J1_;
   static constexpr int J0I = J0I_, J1I = J1I_, INP = J0I_ * J1I_;
-  static_assert(H == 768 && INP == 40 && J1 % 16 == 0 && J1I <= 32 && J0I <= 8 && (R == 2 || R == 4), "encoder shapes");
-  static constexpr int NWV = I1 / 16;          // 4 waves (blockDim = 64 NWV)
-  static constexpr int NR = I0 / 4;            // 12 values of r (unit u = r * 64 + i1)
-  static constexpr int MT2 = 3;                // stage-2 row tiles: r in [4 t, 4 t + 4) x 4 gates
+  static_assert(H == 768 && INP == 40 && J1 % 16 == 0 && J1I <= 32 && J0I <= 8 && (R == 2 || R == 4) && I0 * I1 == GATES_ * H, "encoder shapes");
+  static constexpr int NWV = I1 / 16;          // 4 waves, GRU: 3 (blockDim = 64 NWV)
+  static constexpr int NR = I0 / GATES_;       // 12 / 16 values of r (unit u = r * I1 + i1)
+  static constexpr int MT2 = NR / 4;           // stage-2 row tiles: r in [4 t, 4 t + 4) x 4 rows per unit (LSTM: its gates)
   static constexpr int MT0 = (J0 + 15) / 16;   // blocks of sixteen chain rows j0 (stage-1 row tiles)
   static constexpr int KB1 = (J1 + 31) / 32;   // k-blocks of stage 1
   static constexpr int M1T = J1 / 16;          // reverse T1: row tiles over j1
@@ -77,6 +82,8 @@ typedef W2T<24, 32, 5, 8, 2> W2A2;
 typedef W2T<24, 32, 5, 8, 4> W2A4;
 typedef W2T<16, 48, 4, 10, 2> W2B2;
 typedef W2T<16, 48, 4, 10, 4> W2B4;
+typedef W2T<24, 32, 5, 8, 2, 3> W2GA2;      // TT-GRU, two cores, rank slots 2 / 4
+typedef W2T<24, 32, 5, 8, 4, 3> W2GA4;
 enum { W2_EGT = 0, W2_EC1 = 1, W2_EGTI = 2, W2_ECI = 3, W2_EGH = 4 };
 
 __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / non-finite: neutral; clamped
@@ -181,20 +188,22 @@ __global__ void __launch_bounds__(256) k_w2_prep(TtShape sh, TtShape si, const f
       if (j1 < S::J1I && a < ri) v = w2_gt(si, pk_in, 16 * w + n, j1, a) * ldexpf(1.f, 14 - egti);
     } else {                            // stage-2 A operand: row tile tl, k-block kb: A[row = (rr, gate)][k = (g, a, jj)]
       const int tl = (tile - S::T_GH) / S::KB2, kb = (tile - S::T_GH) % S::KB2;
-      const int rr = n >> 2, gate = n & 3, i0 = gate * S::NR + 4 * tl + rr;
+      // row (rr, slot) of the tile: LSTM slot = gate; GRU slots r, z, n (hidden chain only), n (input chain only)
+      const int rr = n >> 2, slot = n & 3, gate = S::GATES == 4 ? slot : (slot < 3 ? slot : 2), i0 = gate * S::NR + 4 * tl + rr;
+      const bool hid_row = S::GATES == 4 || slot != 3, in_row = S::GATES == 4 || slot != 2;
       const int jj = j & 3;
       if (kb < S::KB2H) {               // (chain-row block mt, rank pair ap) of the hidden matrix — and, riding, of the input matrix
         const int mt = kb / S::AP, a = 2 * (kb % S::AP) + (j >> 2);
         if (S::RIDE && mt == S::MT0 - 1 && g >= 2) {
           const int j0 = 4 * (g - 2) + jj;
-          if (j0 < S::J0I && a < ri) v = w2_gh(si, pk_in, i0, j0, a);
+          if (j0 < S::J0I && a < ri && in_row) v = w2_gh(si, pk_in, i0, j0, a);
         } else {
           const int j0 = 16 * mt + 4 * g + jj;
-          if (j0 < S::J0 && a < rh) v = w2_gh(sh, pk_hid, i0, j0, a);
+          if (j0 < S::J0 && a < rh && hid_row) v = w2_gh(sh, pk_hid, i0, j0, a);
         }
       } else {                          // the input matrix's own k-blocks (one per rank pair): chain rows 4 g + jj
         const int a = 2 * (kb - S::KB2H) + (j >> 2), j0 = 4 * g + jj;
-        if (j0 < S::J0I && a < ri) v = w2_gh(si, pk_in, i0, j0, a);
+        if (j0 < S::J0I && a < ri && in_row) v = w2_gh(si, pk_in, i0, j0, a);
       }
       v *= ldexpf(1.f, 14 - egh);
     }
@@ -445,6 +454,209 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
     if (g.hT) g.hT[(size_t)b * S::H + unit[tl]] = hval[tl];
     if (g.cT) g.cT[(size_t)b * S::H + unit[tl]] = cst[tl];
   }
+}
+
+// ---- TT-GRU forward (gru.py:33-44) on the same structure: three waves per sample, four accumulator rows per unit ---------------------
+// lane (n = i1 in the wave's slice, q), row tile tl: unit u = (4 tl + q) * 48 + 16 wave + n; accumulators: r | z | W_hn h | W_in x of
+// the n gate.  A caller's h_0 outside (-1, 1) does not decay in one step as an LSTM's does (h' = (1 - z) n + z h): the state image
+// is written under the exponent of the LAST step's exact maximum (a bound on this step's: |h'| <= max(1, |h|)), which every wave
+// leaves in LDS next to the image.
+template <class S>
+__global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
+  constexpr int R = S::R, NTH = 64 * S::NWV;
+  static_assert(S::GATES == 3 && S::GHL, "TT-GRU configuration (stage-2 fragments in LDS)");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS];
+  __shared__ float hmax[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, T = g.T;
+  _Float16* himg = reinterpret_cast<_Float16*>(smem + S::L_H);       // [par][piece][HROWS][HS]
+  _Float16* ximg = reinterpret_cast<_Float16*>(smem + S::L_X);       // [par][piece][16][XS]
+  int* xexp = reinterpret_cast<int*>(smem + S::L_E);
+  float* red = reinterpret_cast<float*>(smem + S::L_RED);
+  constexpr int HP = S::HROWS * S::HS, XP = 16 * S::XS;
+  for (int i = tid; i < S::L_E / 16; i += NTH) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  xh8 gt[R][S::KB1][2], gti[R][2];
+  const xh8* fr = reinterpret_cast<const xh8*>(g.frag);
+#pragma unroll
+  for (int a = 0; a < R; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int kb = 0; kb < S::KB1; ++kb) {
+        gt[a][kb][p] = fr[((size_t)((R * wave + a) * S::KB1 + kb) * 2 + p) * 64 + lane];
+        asm volatile("" : "+v"(gt[a][kb][p]));
+      }
+      gti[a][p] = fr[((size_t)(S::T_GTI + R * wave + a) * 2 + p) * 64 + lane];
+      asm volatile("" : "+v"(gti[a][p]));
+    }
+  for (int i = tid; i < S::GH_BYTES / 16; i += NTH)
+    reinterpret_cast<f32x4*>(smem + S::L_GH)[i] = reinterpret_cast<const f32x4*>(fr + (size_t)S::T_GH * 2 * 64)[i];
+  const xh8* ghl = reinterpret_cast<const xh8*>(smem + S::L_GH);
+  const int egt = g.hdr[W2_EGT], ec1 = g.hdr[W2_EC1], egti = g.hdr[W2_EGTI], eci = g.hdr[W2_ECI], egh = g.hdr[W2_EGH];
+
+  int unit[S::MT2];
+  f32x4 bz[S::MT2];
+  float hval[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) {
+    unit[tl] = (4 * tl + q) * S::I1 + 16 * wave + n;
+    float br = 0.f, bzz = 0.f, bhn = 0.f, bin = 0.f;
+    if (g.bias_in) { br += g.bias_in[unit[tl]]; bzz += g.bias_in[S::H + unit[tl]]; bin = g.bias_in[2 * S::H + unit[tl]]; }
+    if (g.bias_hid) { br += g.bias_hid[unit[tl]]; bzz += g.bias_hid[S::H + unit[tl]]; bhn = g.bias_hid[2 * S::H + unit[tl]]; }
+    bz[tl] = f32x4{br * -1.4426950408889634f, bzz * -1.4426950408889634f, bhn, bin};
+    hval[tl] = g.h0 ? g.h0[(size_t)b * S::H + unit[tl]] : 0.f;
+  }
+  // the exponent the state image is written under: 0 while |h| < 1
+  const bool track = g.h0 != nullptr;
+  int e_img = 0;
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) m = fmaxf(m, fabsf(hval[tl]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if (lane == 0) { red[wave] = m; hmax[0][wave] = m; }
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), red[2]);
+    e_img = track ? w2_expo(m) : 0;
+    e_img = e_img < 0 ? 0 : e_img;
+  }
+  int hoff[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) hoff[tl] = (unit[tl] / S::J1) * S::HS + (unit[tl] % S::J1);
+  auto put_h = [&](int par, float scale) {
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      _Float16 p0, p1;
+      split2h(hval[tl] * scale, p0, p1);
+      himg[(par * 2 + 0) * HP + hoff[tl]] = p0;
+      himg[(par * 2 + 1) * HP + hoff[tl]] = p1;
+    }
+  };
+  const int xo = (S::XR0 + lane / S::J1I) * S::XS + (lane % S::J1I);
+  const float* xrow = g.x + (size_t)b * T * S::INP;
+  auto put_x = [&](int par, float xv) {
+    float m = lane < S::INP ? fabsf(xv) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int ex = w2_expo(m);
+    if (lane < S::INP) {
+      _Float16 p0, p1;
+      split2h(xv * ldexpf(1.f, 13 - ex), p0, p1);
+      ximg[(par * 2 + 0) * XP + xo] = p0;
+      ximg[(par * 2 + 1) * XP + xo] = p1;
+    }
+    if (lane == 0) xexp[par] = ex;
+  };
+  put_h(0, ldexpf(1.f, 13 - e_img));
+  float xnext = 0.f;
+  if (wave == 0) {
+    put_x(0, (lane < S::INP && T > 0) ? xrow[lane] : 0.f);
+    if (lane < S::INP && T > 1) xnext = xrow[S::INP + lane];
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const _Float16* hp = himg + par * 2 * HP;
+    const _Float16* xp = ximg + par * 2 * XP;
+    xh8 ah[S::MT0][S::KB1][2], ax[2];
+#pragma unroll
+    for (int mt = 0; mt < S::MT0; ++mt)
+#pragma unroll
+      for (int kb = 0; kb < S::KB1; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ah[mt][kb][p] = w2_ld8(hp + p * HP + (16 * mt + n) * S::HS + 32 * kb + 8 * q);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ax[p] = w2_ld8(xp + p * XP + n * S::XS + 8 * q);
+    const int ex = xexp[par];
+    // the exponent of the image being read, and the one the next image is written under (the exact maximum of |h_{t-1}|)
+    const int eh0 = e_img;
+    int e_wr = 0;
+    if (track) {
+      const float m = fmaxf(fmaxf(hmax[par][0], hmax[par][1]), hmax[par][2]);
+      e_wr = w2_expo(m);
+      e_wr = e_wr < 0 ? 0 : e_wr;
+    }
+    // ---- stage 1 ----
+    f32x4 d[R][S::MT0], di[R];
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+#pragma unroll
+      for (int mt = 0; mt < S::MT0; ++mt) {
+        f32x4 acc = z4;
+#pragma unroll
+        for (int kb = 0; kb < S::KB1; ++kb) acc = w2_mma3(ah[mt][kb][0], ah[mt][kb][1], gt[a][kb][0], gt[a][kb][1], acc);
+        d[a][mt] = acc;
+      }
+      di[a] = w2_mma3(ax[0], ax[1], gti[a][0], gti[a][1], z4);
+    }
+    // ---- hand-off (k_lstm_fwd_w2's) ----
+    const int ech = ec1 + eh0, ecx = eci + ex;
+    const int ec = ech > ecx ? ech : ecx;
+    const int sh_ = egt - ec - 13 + eh0, si_ = egti + ex - ec - 13;
+    xh8 bop[S::KB2][2];
+#pragma unroll
+    for (int kb = 0; kb < S::KB2; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          if (kb < S::KB2H) {
+            const int mt = kb / S::AP, a = 2 * (kb % S::AP) + ai;
+            const float hv = ldexpf(d[a][mt][jj], sh_);
+            if (S::RIDE && mt == S::MT0 - 1) v[4 * ai + jj] = q < 2 ? hv : ldexpf(di[a][jj], si_);
+            else v[4 * ai + jj] = hv;
+          } else {
+            v[4 * ai + jj] = ldexpf(di[2 * (kb - S::KB2H) + ai][jj], si_);
+          }
+        }
+      w2_split8(v, bop[kb][0], bop[kb][1]);
+    }
+    // ---- stage 2 + gates (gru.py:38-44) ----
+    const float zs = ldexpf(1.f, egh + ec - 28);
+    const f32x4 zsv = f32x4{-1.4426950408889634f * zs, -1.4426950408889634f * zs, zs, zs};
+    const size_t bt = (size_t)b * T + t;
+    float wm = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      f32x4 acc = z4;
+#pragma unroll
+      for (int kb = 0; kb < S::KB2; ++kb)
+        acc = w2_mma3(ghl[((size_t)(S::KB2 * tl + kb) * 2 + 0) * 64 + lane], ghl[((size_t)(S::KB2 * tl + kb) * 2 + 1) * 64 + lane],
+                      bop[kb][0], bop[kb][1], acc);
+      const f32x4 z = acc * zsv + bz[tl];
+      const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[0])), zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[1]));
+      const float hn = z[2];                                     // W_hn h + b_hn
+      const float ng = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * (z[3] + rg * hn)));
+      const float hy = (1.0f - zg) * ng + zg * hval[tl];
+      hval[tl] = hy;
+      wm = fmaxf(wm, fabsf(hy));
+      if (g.out) g.out[bt * S::H + unit[tl]] = hy;
+      if (g.reserve) *reinterpret_cast<f32x4*>(g.reserve + res_gate(bt, S::H, unit[tl])) = f32x4{rg, zg, ng, hn};
+    }
+    put_h(par ^ 1, ldexpf(1.f, 13 - e_wr));
+    if (track) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+      if (lane == 0) hmax[par ^ 1][wave] = wm;
+    }
+    e_img = e_wr;
+    if (wave == 0) {
+      put_x(par ^ 1, xnext);
+      if (lane < S::INP && t + 2 < T) xnext = xrow[(size_t)(t + 2) * S::INP + lane];
+    }
+    lds_barrier();
+  }
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl)
+    if (g.hT) g.hT[(size_t)b * S::H + unit[tl]] = hval[tl];
 }
 
 // ==================================================================================================================================
@@ -777,6 +989,35 @@ int w2_config(const TtShape& hid, const TtShape& in) {
   return r <= 2 ? cfg : (r <= 4 ? cfg + 1 : 0);
 }
 
+// the TT-GRU of the encoder's layer: 0 = none; 1, 2 = two cores with 2 / 4 rank slots
+int w2_config_gru(const TtShape& hid, const TtShape& in) {
+  if (!(hid.d == 2 && in.d == 2 && hid.J[0] == 24 && hid.J[1] == 32 && hid.I[0] == 48 && hid.I[1] == 48 && in.J[0] == 5 && in.J[1] == 8 &&
+        in.I[0] == 48 && in.I[1] == 48))
+    return 0;
+  const int r = hid.R[1] > in.R[1] ? hid.R[1] : in.R[1];
+  return r <= 2 ? 1 : (r <= 4 ? 2 : 0);
+}
+
+template <class S>
+static int launch_fwd_w2g_t(const RnnShape& rs, const void* x, const void* h0, const float* packed_in, const void* bias_in,
+                            const float* packed_hid, const void* bias_hid, void* out, void* hT, float* reserve, void* ws,
+                            hipStream_t stream, int phase) {
+  int* hdr = (int*)ws;
+  _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
+  if (phase != TTRNN_PHASE_RUN)
+    hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+  W2Args a{};
+  a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = nullptr;
+  a.bias_in = rs.has_bias_in ? (const float*)bias_in : nullptr;
+  a.bias_hid = rs.has_bias_hid ? (const float*)bias_hid : nullptr;
+  a.hdr = hdr; a.frag = frag;
+  a.out = (float*)out; a.hT = (float*)hT; a.cT = nullptr; a.reserve = reserve;
+  a.B = rs.B; a.T = rs.T;
+  hipLaunchKernelGGL(k_gru_fwd_w2<S>, dim3(rs.B), dim3(64 * S::NWV), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 template <class S>
 static int launch_fwd_w2_t(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                            const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
@@ -846,18 +1087,29 @@ static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* pack
 
 // the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's size
 bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
-  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == 768 && rs.in == 40 &&
-         w2_config(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
-         !(opt(OPT_DEV2) & 16);
+  if (dtype != TTRNN_F32 || rs.hid_blocks > 1 || rs.H != 768 || rs.in != 40 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT ||
+      opt(OPT_FORCE_GENERIC) || opt(OPT_FORCE_G2) || (opt(OPT_DEV2) & 16))
+    return false;
+  if (rs.cell == TTRNN_GRU) return w2_config_gru(rs.hid_s, rs.in_s) > 0;      // (round 6: forward only; the tier's reverse kernel reads its records)
+  return rs.cell == TTRNN_LSTM && w2_config(rs.hid_s, rs.in_s) > 0;
 }
 static constexpr size_t w2_max4(size_t a, size_t b, size_t c, size_t d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
 size_t w2_rnn_fwd_workspace_bytes() {      // (the query has no shape; the four-core configurations keep their contracted cores behind the fragments)
-  return w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES + W2_MERGE_BYTES, W2B4::WS_BYTES + W2_MERGE_BYTES);
+  const size_t a = w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES + W2_MERGE_BYTES, W2B4::WS_BYTES + W2_MERGE_BYTES);
+  const size_t g = W2GA2::WS_BYTES > W2GA4::WS_BYTES ? W2GA2::WS_BYTES : W2GA4::WS_BYTES;
+  return a > g ? a : g;
 }
 
 int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const void* c0, const float* packed_in, const void* bias_in,
                       const float* packed_hid, const void* bias_hid, void* out, void* hT, void* cT, float* reserve, void* ws,
                       hipStream_t stream, int phase) {
+  if (rs.cell == TTRNN_GRU) {
+    switch (w2_config_gru(rs.hid_s, rs.in_s)) {
+      case 1: return launch_fwd_w2g_t<W2GA2>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
+      case 2: return launch_fwd_w2g_t<W2GA4>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
+    }
+    return TTRNN_ERR_UNSUPPORTED;
+  }
   switch (w2_config(rs.hid_s, rs.in_s)) {
     case 1: return launch_fwd_w2_t<W2A2>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);
     case 2: return launch_fwd_w2_t<W2A4>(rs, x, h0, c0, packed_in, bias_in, packed_hid, bias_hid, out, hT, cT, reserve, ws, stream, phase);

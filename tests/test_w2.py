@@ -38,8 +38,13 @@ def test_routes():
         assert _routes(build_module(dict(META, n_cores=4, tt_rank=r), dev()), 8, 12) == ("fused_core", "fused_core"), r
     assert _routes(build_module(dict(META, n_cores=4, tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
     assert _routes(build_module(dict(META, n_cores=3, tt_rank=2), dev()), 8, 12)[0] == "runtime_mfma"
+    # the TT-GRU of the same layer (speaker_encoder.py `use_gru`): forward on k_gru_fwd_w2 (ranks up to 4), reverse recurrence on the tier
     mg = build_module(dict(META, kind="ttgru"), dev())
-    assert _routes(mg, 8, 12)[0] == "runtime_mfma"
+    assert _routes(mg, 8, 12) == ("fused_core", "runtime_mfma")
+    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=4), dev()), 8, 12)[0] == "fused_core"
+    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=8), dev()), 8, 12)[0] == "runtime_mfma"
+    with ttrnn_hip.option("dev2", 16):
+        assert _routes(mg, 8, 12)[0] == "runtime_mfma"
 
 
 CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes", "x_ranges", "no_bias", "rank4", "rank3", "rank1",
@@ -209,3 +214,122 @@ def test_reverse_kernel_gradient_ranges(scale):
     for n, p in m.named_parameters():
         r = leaves[n].grad
         assert _maxabs(p.grad, r) <= 3e-6 * float(r.abs().max()), (scale, n)
+
+
+GRU_CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "x_ranges", "no_bias", "rank4", "rank3", "rank1"]
+
+
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_gru_forward_operand_ranges(case):
+    """k_gru_fwd_w2 (round 6): the encoder layer as a TT-GRU (speaker_encoder.py:33-47 `use_gru`; gru.py:33-44) — three waves per sample,
+    four accumulator rows per unit (r, z, the hidden and the input part of n kept apart), the state image under the exponent of the
+    previous step's exact maximum (a GRU's large h_0 decays only as fast as z lets it).  Same cases and yardsticks as the LSTM
+    kernel's test: float64 oracle, the runtime tier (dev2 bit 4) as the second opinion, repeat launches and batch splits bit for bit."""
+    import ttrnn_hip
+    torch.manual_seed(37)
+    base = dict(META, kind="ttgru")
+    meta = dict(base, bias=False) if case == "no_bias" else base
+    if case.startswith("rank"):
+        meta = dict(base, tt_rank=int(case[4:]))
+    m = build_module(meta, dev())
+    T = 160 if case in ("fresh", "rank4") else 9
+    B = 5
+    g = torch.Generator().manual_seed(41)
+    x = torch.rand(B, T, 40, generator=g) if case == "fresh" else torch.randn(B, T, 40, generator=g)
+    h0 = torch.randn(B, 768, generator=g) * 0.3
+    with torch.no_grad():
+        hid = [p for n, p in m.named_parameters() if "hidden_weights.parameters" in n]
+        inp = [p for n, p in m.named_parameters() if "input_weights.parameters" in n]
+        if case == "tiny_weights":
+            for p in hid + inp:
+                p.mul_(1e-5)
+        elif case == "huge_weights":
+            for p in hid + inp:      # (x 6 as for the LSTM makes a GRU chaotic: the tier itself then misses float64 by 0.17)
+                p.mul_(2.5)
+        elif case == "huge_h0":
+            h0 = torch.randn(B, 768, generator=g) * torch.tensor([0.1, 3.0, 40.0, 500.0, 6000.0]).view(B, 1)
+        elif case == "zero_core":
+            hid[0].zero_()
+        elif case == "x_ranges":
+            x = x * torch.tensor([1e4, 1.0, 1e-6, 0.0, 30.0, 1e-3, 1.0, 1.0, 1e2]).view(1, T, 1)
+            x[:, 4, 7] = 3e3
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r64 = _oracle_forward("ttgru", sd, 1, x.double(), h0.double())[0]
+    scale = max(1e-30, float(r64.abs().max()))
+    xd, hd = x.to(dev()), h0.to(dev())
+    tol = 2e-3 if case in ("huge_weights", "huge_h0", "x_ranges") else 2e-6
+    with torch.no_grad():
+        assert _routes(m, B, T)[0] == "fused_core"
+        out, hT = m(xd, hd)
+        again, _ = m(xd, hd)
+        assert torch.equal(out, again)
+        part, _ = m(xd[1:3], hd[1:3])
+        assert torch.equal(out[1:3], part)
+        assert torch.equal(out[:, -1], hT.reshape(B, 768))
+        nost = m(xd)[0]
+        r0 = _oracle_forward("ttgru", sd, 1, x.double())[0]
+        fin = m(xd, hd, need_outputs=False) if "need_outputs" in m.forward.__code__.co_varnames else None
+        with ttrnn_hip.option("dev2", 16):
+            assert _routes(m, B, T)[0] == "runtime_mfma"
+            tier, _ = m(xd, hd)
+            tier0 = m(xd)[0]
+        e0, e0t = _maxabs(nost, r0), _maxabs(tier0, r0)
+        print(case, "zero initial state: %.3g (tier %.3g)" % (e0, e0t))
+        assert e0 <= tol * max(1.0, float(r0.abs().max())) or e0 <= 10.0 * e0t + 1e-4
+    assert torch.isfinite(out).all(), case
+    if fin is not None:
+        assert torch.equal(fin[1].reshape(B, 768), hT.reshape(B, 768))
+    err, err_tier = _maxabs(out, r64), _maxabs(tier, r64)
+    print(case, "TT-GRU encoder-shape kernel: max abs error vs float64 (state scale %.3g): %.3g; runtime tier: %.3g" % (scale, err, err_tier))
+    assert err <= tol * max(1.0, scale)
+    if tol > 1e-5:
+        assert err <= 10.0 * err_tier + 1e-4 * max(1.0, scale)
+    else:
+        assert err <= 3.0 * err_tier + 3e-7 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("B,T,h0_scale", [(4, 12, 0.3), (3, 1, 0.3), (2, 33, 50.0), (5, 8, None)])
+def test_gru_training_step_on_the_new_forward(B, T, h0_scale):
+    """the tier's reverse-time kernel reads the records k_gru_fwd_w2 writes (r, z, n, W_hn h + b_hn): every gradient of a training step
+    against the float64 oracle's autograd, and against the step whose forward runs on the tier (dev2 bit 4)"""
+    import ttrnn_hip
+    from oracle import ttrnn_oracle as O
+    torch.manual_seed(43)
+    m = build_module(dict(META, kind="ttgru"), dev())
+    x = torch.randn(B, T, 40)
+    h0 = None if h0_scale is None else torch.randn(B, 768) * h0_scale
+    w = torch.randn(B, T, 768)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
+    xr = x.double().clone().requires_grad_(True)
+    h0r = None if h0 is None else h0.double().clone().requires_grad_(True)
+    ro, rh = O.gru_forward(layers, xr, h0r)
+    ((ro * w.double()).sum() + 0.5 * rh.sum()).backward()
+
+    def run():
+        m.zero_grad()
+        xg = x.to(dev()).requires_grad_(True)
+        h0g = None if h0 is None else h0.to(dev()).requires_grad_(True)
+        out, hT = m(xg, h0g)
+        ((out * w.to(dev())).sum() + 0.5 * hT.sum()).backward()
+        g = {"x": xg.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
+        if h0g is not None:
+            g["h0"] = h0g.grad.clone()
+        return out.detach().clone(), g
+
+    out, got = run()
+    with ttrnn_hip.option("dev2", 16):
+        out_t, old = run()
+    assert _maxabs(out, ro.detach()) <= (2e-3 if (h0_scale or 0) > 1 else 2e-6) * max(1.0, float(ro.abs().max()))
+    refs = {"x": xr.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
+    if h0r is not None:
+        refs["h0"] = h0r.grad
+    worst, worst_t = 0.0, 0.0
+    for n, ref in refs.items():
+        sc = max(float(ref.abs().max()), 1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        worst = max(worst, _maxabs(got[n].double(), ref) / sc)
+        worst_t = max(worst_t, _maxabs(old[n].double(), ref) / sc)
+    print("TT-GRU training step", B, T, h0_scale, "max gradient error relative to each tensor's maximum: %.3g (tier forward: %.3g)" % (worst, worst_t))
+    tol = 2e-3 if (h0_scale or 0) > 1 else 1e-4
+    assert worst <= tol and worst <= 3.0 * worst_t + 1e-5
