@@ -938,8 +938,8 @@ int ttrnn_rnn_backward_ex(const ttrnn_rnn_desc* desc, const void* out, const voi
   if (!want_state && !force_generic() && rs.T > 0 && w2_rnn_bwd_available(rs, desc->dtype)) {
     // the speaker encoder's shape: wave-local transposed stages, one barrier per step (ttrnn_fast_w2.hip)
     if (!workspace || workspace_bytes < w2_rnn_bwd_workspace_bytes()) return TTRNN_ERR_WORKSPACE;
-    return launch_rnn_bwd_w2(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_h0, d_c0, workspace, (hipStream_t)stream,
-                             stats);
+    return launch_rnn_bwd_w2(rs, out, h0, c0, packed_hid, reserve, d_out, d_hT, d_cT, d_gates_in, d_gates_hid, d_h0, d_c0, workspace,
+                             (hipStream_t)stream, stats);
   }
   if (!g2_first && !want_state && !force_generic() && fast_rnn_bwd_available(rs, desc->dtype)) {
     if ((fp32_math() == TTRNN_MATH_SPLIT || desc->dtype == TTRNN_BF16) && rs.T > 0 &&

@@ -712,9 +712,12 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
       const int j = e & 7, lane = e >> 3, n = lane & 15, g = lane >> 4;
       const int a = nt / S::MT0, j0 = 16 * (nt % S::MT0) + n;
       // k element j of k-group g: kb 0: row tile tl = j >> 2 (0, 1), gate = j & 3; kb 1: tl = 2, gate = j (j < 4), zero beyond
-      const int tl = kb == 0 ? (j >> 2) : 2, gate = kb == 0 ? (j & 3) : j;
+      // (TT-GRU: four row tiles x four slots fill both k-blocks; slot 3 — the input part of n — is no row of the hidden chain: zero)
+      const int tl = S::GATES == 3 ? 2 * kb + (j >> 2) : (kb == 0 ? (j >> 2) : 2);
+      const int gate = S::GATES == 3 ? (j & 3) : (kb == 0 ? (j & 3) : j);
+      const bool live = S::GATES == 3 ? gate < 3 : (kb == 0 || j < 4);
       float v = 0.f;
-      if (a < rh && j0 < S::J0 && (kb == 0 || j < 4)) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
+      if (a < rh && j0 < S::J0 && live) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
       _Float16 p0, p1;
       split2h(v, p0, p1);
       dst[lane * 8 + j] = p0;
@@ -736,9 +739,11 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
 
 struct W2BArgs {
   const float* c0; const float* reserve;
+  const float* out; const float* h0;      // TT-GRU: the layer's outputs (h_{t-1} of the gate gradients) and the initial state
   const float* d_out; const float* d_hT; const float* d_cT;
   const int* hdr; const _Float16* ghf; const _Float16* gtf;
-  float* dg; float* d_h0; float* d_c0;
+  float* dg; float* dg_hid;               // d_gates_in; TT-GRU: d_gates_hid (its n block carries r)
+  float* d_h0; float* d_c0;
   unsigned* colmax;          // stats rows 0 and 1 ([2][4H] bit patterns, zeroed by the launcher) or NULL
   int B, T;
 };
@@ -933,6 +938,185 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
   }
 }
 
+// ---- TT-GRU reverse-time kernel (BPTT of gru.py:33-44 through the hidden chain), the twin of k_lstm_bwd_w2 -----------------------------
+// Three waves per sample, wave w owns i1 in [16 w, 16 w + 16); a lane holds FOUR units (one per row tile) and, per unit, the hidden
+// chain's gate gradients (dr, dz, dn r) in slots 0 .. 2 of the forward's four rows — slot 3 (the input part of n) is no row of the
+// hidden matrix.  T2' / T1 / exchange as the LSTM kernel; the direct path dh_{t-1} += dh_t z_t stays in the lane's registers.
+// d_gates_in gets (dr, dz, dn), d_gates_hid (dr, dz, dn r); by-products: both rows of column maxima.
+template <class S>
+__global__ void __launch_bounds__(64 * S::NWV) k_gru_bwd_w2(W2BArgs g) {
+  constexpr int R = S::R, NTH = 64 * S::NWV;
+  static_assert(S::GATES == 3 && S::MT2 == 4 && S::NWV == 3, "TT-GRU configuration");
+  extern __shared__ __attribute__((aligned(16))) unsigned char w2b_smem[];
+  unsigned char* smem = w2b_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, T = g.T;
+  float* part = reinterpret_cast<float*>(smem);                 // [parity][wave][PART]
+  for (int i = tid; i < 2 * S::NWV * S::PART / 4; i += NTH) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  xh8 gh[S::GHLB ? 1 : S::NT2][2][2];
+  w2_xh4 gta[R][S::M1T][2];
+  {
+    const xh8* f8 = reinterpret_cast<const xh8*>(g.ghf);
+    if constexpr (S::GHLB) {
+      for (int i = tid; i < (int)(S::BGH_BYTES / 16); i += NTH)
+        reinterpret_cast<f32x4*>(smem + S::BL_GH)[i] = reinterpret_cast<const f32x4*>(f8)[i];
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < S::NT2; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            gh[nt][kb][p] = f8[((size_t)(2 * nt + kb) * 2 + p) * 64 + lane];
+            asm volatile("" : "+v"(gh[nt][kb][p]));
+          }
+    }
+    const w2_xh4* f4 = reinterpret_cast<const w2_xh4*>(g.gtf);
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+      for (int mt = 0; mt < S::M1T; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          gta[a][mt][p] = f4[((size_t)((wave * R + a) * S::M1T + mt) * 2 + p) * 64 + lane];
+          asm volatile("" : "+v"(gta[a][mt][p]));
+        }
+  }
+  const xh8* ghl = reinterpret_cast<const xh8*>(smem + S::BL_GH);
+  const int egh = g.hdr[W2B_EGH], egt = g.hdr[W2B_EGT], el1 = g.hdr[W2B_EL1];
+  const int shd = egh - el1 - 13;
+
+  int unit[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) unit[tl] = (4 * tl + q) * S::I1 + 16 * wave + n;
+  const size_t bt0 = (size_t)b * T;
+  constexpr int GH = 3 * S::H;
+  // ---- records two steps deep: gates (r, z, n, W_hn h + b_hn), the previous state, d_out ----
+  f32x4 G0[S::MT2], G1[S::MT2];
+  float P0[S::MT2], P1[S::MT2], D0[S::MT2], D1[S::MT2];
+  auto ld_gates = [&](int t, int tl) -> f32x4 {
+    return t >= 0 ? *reinterpret_cast<const f32x4*>(g.reserve + res_gate(bt0 + t, S::H, unit[tl])) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto ld_hprev = [&](int t, int tl) -> float {                // h_{t-1}
+    if (t >= 1) return g.out[(bt0 + t - 1) * S::H + unit[tl]];
+    return (t == 0 && g.h0) ? g.h0[(size_t)b * S::H + unit[tl]] : 0.f;
+  };
+  auto ld_dout = [&](int t, int tl) -> float {
+    return (t >= 0 && g.d_out) ? g.d_out[(bt0 + t) * S::H + unit[tl]] : 0.f;
+  };
+  float dhd[S::MT2], cmi[S::MT2][3], cmh[S::MT2];
+#pragma unroll
+  for (int tl = 0; tl < S::MT2; ++tl) {
+    G0[tl] = ld_gates(T - 1, tl); G1[tl] = ld_gates(T - 2, tl);
+    P0[tl] = ld_hprev(T - 1, tl); P1[tl] = ld_hprev(T - 2, tl);
+    D0[tl] = ld_dout(T - 1, tl); D1[tl] = ld_dout(T - 2, tl);
+    dhd[tl] = g.d_hT ? g.d_hT[(size_t)b * S::H + unit[tl]] : 0.f;
+    cmh[tl] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cmi[tl][k] = 0.f;
+  }
+  __syncthreads();
+
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = T - 1; t >= 0; --t) {
+    const int par = t & 1;
+    const float* pr = part + par * S::NWV * S::PART;
+    float dz[S::MT2][4];
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      const float dht = dhd[tl] + D0[tl] + ((pr[unit[tl]] + pr[S::PART + unit[tl]]) + pr[2 * S::PART + unit[tl]]);
+      const float rg = G0[tl][0], zg = G0[tl][1], ng = G0[tl][2], hn = G0[tl][3];
+      const float dn_pre = dht * (1.f - zg) * (1.f - ng * ng);
+      const float dz_pre = dht * (P0[tl] - ng) * zg * (1.f - zg);
+      const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+      dhd[tl] = dht * zg;
+      dz[tl][0] = dr_pre; dz[tl][1] = dz_pre; dz[tl][2] = dn_pre * rg; dz[tl][3] = 0.f;
+      float* gi = g.dg + (bt0 + t) * GH + unit[tl];
+      float* gh_ = g.dg_hid + (bt0 + t) * GH + unit[tl];
+      gi[0] = dr_pre; gi[S::H] = dz_pre; gi[2 * S::H] = dn_pre;
+      gh_[0] = dr_pre; gh_[S::H] = dz_pre; gh_[2 * S::H] = dz[tl][2];
+      cmi[tl][0] = fmaxf(cmi[tl][0], fabsf(dr_pre)); cmi[tl][1] = fmaxf(cmi[tl][1], fabsf(dz_pre));
+      cmi[tl][2] = fmaxf(cmi[tl][2], fabsf(dn_pre)); cmh[tl] = fmaxf(cmh[tl], fabsf(dz[tl][2]));
+      G0[tl] = G1[tl]; P0[tl] = P1[tl]; D0[tl] = D1[tl];
+      G1[tl] = ld_gates(t - 2, tl);
+      P1[tl] = ld_hprev(t - 2, tl);
+      D1[tl] = ld_dout(t - 2, tl);
+    }
+    // ---- the wave's maximum -> exponent; A operand of T2': k-block 0 = row tiles 0, 1, k-block 1 = row tiles 2, 3 (x four slots) ----
+    float m = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m = fmaxf(m, fabsf(dz[tl][k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const int ed = w2_expo(m);
+    const float sd = ldexpf(1.f, 13 - ed);
+    float v0[8], v1[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v0[k] = dz[0][k] * sd; v0[4 + k] = dz[1][k] * sd; v1[k] = dz[2][k] * sd; v1[4 + k] = dz[3][k] * sd; }
+    xh8 a0[2], a1[2];
+    w2_split8(v0, a0[0], a0[1]);
+    w2_split8(v1, a1[0], a1[1]);
+    // ---- T2' + T1 ----
+    f32x4 zt[S::M1T][S::MT0];
+#pragma unroll
+    for (int mt = 0; mt < S::M1T; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < S::MT0; ++jt) zt[mt][jt] = z4;
+#pragma unroll
+    for (int nt = 0; nt < S::NT2; ++nt) {
+      xh8 b00, b01, b10, b11;
+      if constexpr (S::GHLB) {
+        b00 = ghl[((size_t)(2 * nt + 0) * 2 + 0) * 64 + lane]; b01 = ghl[((size_t)(2 * nt + 0) * 2 + 1) * 64 + lane];
+        b10 = ghl[((size_t)(2 * nt + 1) * 2 + 0) * 64 + lane]; b11 = ghl[((size_t)(2 * nt + 1) * 2 + 1) * 64 + lane];
+      } else {
+        b00 = gh[nt][0][0]; b01 = gh[nt][0][1]; b10 = gh[nt][1][0]; b11 = gh[nt][1][1];
+      }
+      f32x4 d = w2_mma3(a0[0], a0[1], b00, b01, z4);
+      d = w2_mma3(a1[0], a1[1], b10, b11, d);
+      unsigned p0a, p1a, p0b, p1b;
+      split_pair_h(ldexpf(d[0], shd), ldexpf(d[1], shd), p0a, p1a);
+      split_pair_h(ldexpf(d[2], shd), ldexpf(d[3], shd), p0b, p1b);
+      const w2_xh4 b0 = __builtin_bit_cast(w2_xh4, u32x2{p0a, p0b}), b1 = __builtin_bit_cast(w2_xh4, u32x2{p1a, p1b});
+      const int a = nt / S::MT0, jt = nt % S::MT0;
+#pragma unroll
+      for (int mt = 0; mt < S::M1T; ++mt) zt[mt][jt] = w2_mma3_16(gta[a][mt][0], gta[a][mt][1], b0, b1, zt[mt][jt]);
+    }
+    const float us = ldexpf(1.f, egt + el1 + ed - 28);
+    float* pw = part + ((par ^ 1) * S::NWV + wave) * S::PART;
+#pragma unroll
+    for (int mt = 0; mt < S::M1T; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < S::MT0; ++jt) {
+        const int j0 = 16 * jt + n;
+        if (j0 < S::J0) *reinterpret_cast<f32x4*>(pw + j0 * S::J1 + 16 * mt + 4 * q) = zt[mt][jt] * us;
+      }
+    lds_barrier();
+  }
+  {
+    const float* pr = part + (T > 0 ? 1 : 0) * S::NWV * S::PART;
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl) {
+      if (g.d_h0) {
+        float v = dhd[tl];
+        if (T > 0) v += (pr[unit[tl]] + pr[S::PART + unit[tl]]) + pr[2 * S::PART + unit[tl]];
+        g.d_h0[(size_t)b * S::H + unit[tl]] = v;
+      }
+      if (g.colmax) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          atomicMax(g.colmax + k * S::H + unit[tl], __float_as_uint(cmi[tl][k]));
+          atomicMax(g.colmax + GH + k * S::H + unit[tl], __float_as_uint(k < 2 ? cmi[tl][k] : cmh[tl]));
+        }
+      }
+    }
+  }
+}
+
 // ---- d = 4: the cores contracted pairwise ONCE per launch into the packed layout of a two-core matrix (I0 I1, I2 I3) x (J0 J1,
 // J2 J3) of rank R_2, which the prep kernels then read like the d = 2 layers' packed cores (one load per entry: with the
 // contraction inside w2_gt / w2_gh every fragment tile's workgroup re-derived every merged entry for its maxima — k_w2_prep 67 us,
@@ -1083,6 +1267,27 @@ static int launch_bwd_w2_t(const RnnShape& rs, const void* c0, const float* pack
   return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
 }
 
+template <class S>
+static int launch_bwd_w2g_t(const RnnShape& rs, const void* out, const void* h0, const float* packed_hid, const float* reserve,
+                            const void* d_out, const void* d_hT, float* dg_in, float* dg_hid, void* d_h0, void* ws, hipStream_t stream,
+                            float* stats) {
+  int* hdr = (int*)ws;
+  _Float16* ghf = (_Float16*)((char*)ws + S::HDR_BYTES);
+  _Float16* gtf = (_Float16*)((char*)ws + S::HDR_BYTES + S::BGH_BYTES);
+  if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 3 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  W2BArgs a{};
+  a.reserve = reserve; a.out = (const float*)out; a.h0 = (const float*)h0;
+  a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT;
+  a.hdr = hdr; a.ghf = ghf; a.gtf = gtf;
+  a.dg = dg_in; a.dg_hid = dg_hid; a.d_h0 = (float*)d_h0;
+  a.colmax = (unsigned*)stats;
+  a.B = rs.B; a.T = rs.T;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(k_gru_bwd_w2<S>), S::BLDS) != TTRNN_OK) return TTRNN_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_gru_bwd_w2<S>, dim3(rs.B), dim3(64 * S::NWV), S::BLDS, stream, a);
+  return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
+}
+
 }  // namespace
 
 // the forward route of this file: fp32 storage, split fp32 math, a plain (not block-structured) TT-LSTM of the encoder's size
@@ -1121,17 +1326,28 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
 
 // reverse-time kernel of the same shapes (the forward's reserve format is everybody's: ttrnn_core.h res_gate / res_cell)
 bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
-  return dtype == TTRNN_F32 && rs.cell == TTRNN_LSTM && rs.hid_blocks <= 1 && rs.H == 768 && rs.in == 40 &&
-         w2_config(rs.hid_s, rs.in_s) > 0 && opt(OPT_FP32_MATH) == TTRNN_MATH_SPLIT && !opt(OPT_FORCE_GENERIC) && !opt(OPT_FORCE_G2) &&
-         !(opt(OPT_DEV2) & 32);
+  if (dtype != TTRNN_F32 || rs.hid_blocks > 1 || rs.H != 768 || rs.in != 40 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT ||
+      opt(OPT_FORCE_GENERIC) || opt(OPT_FORCE_G2) || (opt(OPT_DEV2) & 32))
+    return false;
+  if (rs.cell == TTRNN_GRU) return w2_config_gru(rs.hid_s, rs.in_s) > 0;
+  return rs.cell == TTRNN_LSTM && w2_config(rs.hid_s, rs.in_s) > 0;
 }
 size_t w2_rnn_bwd_workspace_bytes() {
-  return w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES + W2_MERGE_BYTES, W2B4::BWS_BYTES + W2_MERGE_BYTES);
+  const size_t a = w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES + W2_MERGE_BYTES, W2B4::BWS_BYTES + W2_MERGE_BYTES);
+  const size_t g = W2GA2::BWS_BYTES > W2GA4::BWS_BYTES ? W2GA2::BWS_BYTES : W2GA4::BWS_BYTES;
+  return a > g ? a : g;
 }
 
-int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve,
-                      const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws,
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid, const float* reserve,
+                      const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
                       hipStream_t stream, float* stats) {
+  if (rs.cell == TTRNN_GRU) {
+    switch (w2_config_gru(rs.hid_s, rs.in_s)) {
+      case 1: return launch_bwd_w2g_t<W2GA2>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
+      case 2: return launch_bwd_w2g_t<W2GA4>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
+    }
+    return TTRNN_ERR_UNSUPPORTED;
+  }
   switch (w2_config(rs.hid_s, rs.in_s)) {
     case 1: return launch_bwd_w2_t<W2A2>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);
     case 2: return launch_bwd_w2_t<W2A4>(rs, c0, packed_hid, reserve, d_out, d_hT, d_cT, dg_in, d_h0, d_c0, ws, stream, stats);

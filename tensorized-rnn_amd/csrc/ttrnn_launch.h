@@ -391,9 +391,9 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
 
 bool w2_rnn_bwd_available(const RnnShape& rs, int dtype);
 size_t w2_rnn_bwd_workspace_bytes();
-int launch_rnn_bwd_w2(const RnnShape& rs, const void* c0, const float* packed_hid, const float* reserve, const void* d_out,
-                      const void* d_hT, const void* d_cT, float* dg_in, void* d_h0, void* d_c0, void* ws, hipStream_t stream,
-                      float* stats);
+int launch_rnn_bwd_w2(const RnnShape& rs, const void* out, const void* h0, const void* c0, const float* packed_hid, const float* reserve,
+                      const void* d_out, const void* d_hT, const void* d_cT, float* dg_in, float* dg_hid, void* d_h0, void* d_c0, void* ws,
+                      hipStream_t stream, float* stats = nullptr);
 
 // chain weight gradients of up to two TT-matrices sharing one pass over dy (ttrnn_fast_c2w.hip, plan: ttrnn_c2w.h)
 bool c2w_prefers_chain(const TtShape& s);      // 2 in out > 1.5 x the chain's FLOPs

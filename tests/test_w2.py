@@ -38,13 +38,13 @@ def test_routes():
         assert _routes(build_module(dict(META, n_cores=4, tt_rank=r), dev()), 8, 12) == ("fused_core", "fused_core"), r
     assert _routes(build_module(dict(META, n_cores=4, tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
     assert _routes(build_module(dict(META, n_cores=3, tt_rank=2), dev()), 8, 12)[0] == "runtime_mfma"
-    # the TT-GRU of the same layer (speaker_encoder.py `use_gru`): forward on k_gru_fwd_w2 (ranks up to 4), reverse recurrence on the tier
+    # the TT-GRU of the same layer (speaker_encoder.py `use_gru`): k_gru_fwd_w2 / k_gru_bwd_w2 (ranks up to 4)
     mg = build_module(dict(META, kind="ttgru"), dev())
-    assert _routes(mg, 8, 12) == ("fused_core", "runtime_mfma")
-    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=4), dev()), 8, 12)[0] == "fused_core"
-    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=8), dev()), 8, 12)[0] == "runtime_mfma"
-    with ttrnn_hip.option("dev2", 16):
-        assert _routes(mg, 8, 12)[0] == "runtime_mfma"
+    assert _routes(mg, 8, 12) == ("fused_core", "fused_core")
+    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=4), dev()), 8, 12) == ("fused_core", "fused_core")
+    assert _routes(build_module(dict(META, kind="ttgru", tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
+    with ttrnn_hip.option("dev2", 16 | 32):
+        assert _routes(mg, 8, 12) == ("runtime_mfma", "runtime_mfma")
 
 
 CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes", "x_ranges", "no_bias", "rank4", "rank3", "rank1",
@@ -288,37 +288,54 @@ def test_gru_forward_operand_ranges(case):
         assert err <= 3.0 * err_tier + 3e-7 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("B,T,h0_scale", [(4, 12, 0.3), (3, 1, 0.3), (2, 33, 50.0), (5, 8, None)])
-def test_gru_training_step_on_the_new_forward(B, T, h0_scale):
-    """the tier's reverse-time kernel reads the records k_gru_fwd_w2 writes (r, z, n, W_hn h + b_hn): every gradient of a training step
-    against the float64 oracle's autograd, and against the step whose forward runs on the tier (dev2 bit 4)"""
+@pytest.mark.parametrize("B,T,h0_scale,dout,rank", [(4, 12, 0.3, "plain", 2), (3, 1, 0.3, "plain", 2), (2, 33, 50.0, "plain", 2), (5, 8, None, "plain", 2),
+                                                     (4, 20, 0.3, "decades", 2), (4, 24, 0.3, "last_step_only", 2), (5, 9, 0.3, "sparse", 2),
+                                                     (3, 10, 0.3, "plain", 4), (3, 7, None, "decades", 3), (300, 3, 0.3, "plain", 2)])
+def test_gru_training_step(B, T, h0_scale, dout, rank):
+    """k_gru_fwd_w2 + k_gru_bwd_w2 (wave-local transposed stages, three gates' hidden-chain gradients in the forward's four slots, the
+    direct path dh z in registers): every gradient of a training step against the float64 oracle's autograd, and against the step
+    that runs on the tier in both directions (dev2 bits 4, 5); output gradients over ten decades, a loss on the last step only,
+    steps and samples without gradient; the reverse kernel's own results bit for bit on a repeat."""
     import ttrnn_hip
     from oracle import ttrnn_oracle as O
     torch.manual_seed(43)
-    m = build_module(dict(META, kind="ttgru"), dev())
+    m = build_module(dict(META, kind="ttgru", tt_rank=rank), dev())
     x = torch.randn(B, T, 40)
     h0 = None if h0_scale is None else torch.randn(B, 768) * h0_scale
     w = torch.randn(B, T, 768)
+    if dout == "decades":
+        w = w * (10.0 ** (torch.rand(B, T, 1) * 10 - 6))
+    elif dout == "last_step_only":
+        w[:, :-1] = 0.0
+    elif dout == "sparse":
+        w[:, 1:5] = 0.0
+        w[2] = 0.0
+    assert _routes(m, B, T) == ("fused_core", "fused_core")
     sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
     layers, leaves = O.layers_from_state_dict(sd, 1, requires_grad=True, dtype=torch.float64)
     xr = x.double().clone().requires_grad_(True)
     h0r = None if h0 is None else h0.double().clone().requires_grad_(True)
     ro, rh = O.gru_forward(layers, xr, h0r)
-    ((ro * w.double()).sum() + 0.5 * rh.sum()).backward()
+    wsum = 0.0 if dout in ("sparse", "last_step_only") else 0.5
+    ((ro * w.double()).sum() + wsum * rh.sum()).backward()
 
     def run():
         m.zero_grad()
         xg = x.to(dev()).requires_grad_(True)
         h0g = None if h0 is None else h0.to(dev()).requires_grad_(True)
         out, hT = m(xg, h0g)
-        ((out * w.to(dev())).sum() + 0.5 * hT.sum()).backward()
+        ((out * w.to(dev())).sum() + wsum * hT.sum()).backward()
         g = {"x": xg.grad.clone(), **{n: p.grad.detach().clone() for n, p in m.named_parameters()}}
         if h0g is not None:
             g["h0"] = h0g.grad.clone()
         return out.detach().clone(), g
 
     out, got = run()
-    with ttrnn_hip.option("dev2", 16):
+    _, again = run()
+    for n in ("x",) + (("h0",) if h0 is not None else ()):
+        assert torch.equal(got[n], again[n]), n
+    with ttrnn_hip.option("dev2", 16 | 32):
+        assert _routes(m, B, T) == ("runtime_mfma", "runtime_mfma")
         out_t, old = run()
     assert _maxabs(out, ro.detach()) <= (2e-3 if (h0_scale or 0) > 1 else 2e-6) * max(1.0, float(ro.abs().max()))
     refs = {"x": xr.grad, **{n: leaves[n].grad for n, _ in m.named_parameters()}}
@@ -330,6 +347,8 @@ def test_gru_training_step_on_the_new_forward(B, T, h0_scale):
         assert torch.isfinite(got[n]).all(), n
         worst = max(worst, _maxabs(got[n].double(), ref) / sc)
         worst_t = max(worst_t, _maxabs(old[n].double(), ref) / sc)
-    print("TT-GRU training step", B, T, h0_scale, "max gradient error relative to each tensor's maximum: %.3g (tier forward: %.3g)" % (worst, worst_t))
+    print("TT-GRU training step", B, T, h0_scale, dout, rank, "max gradient error relative to each tensor's maximum: %.3g (tier: %.3g)" % (worst, worst_t))
     tol = 2e-3 if (h0_scale or 0) > 1 else 1e-4
     assert worst <= tol and worst <= 3.0 * worst_t + 1e-5
+    if dout == "sparse" and h0 is not None:
+        assert float(got["h0"][2].abs().max()) == 0.0
