@@ -1372,6 +1372,10 @@ def test_prepared_weights_inference_matches_and_tracks_updates():
                               # (fp32 GRU: fused-core route since round 5 — its scale header and fragments are weight-only work)
                               (dict(kind="ttgru", input_size=1, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8), 5, 40, 1),
                               (dict(kind="ttgru", input_size=28, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4), 5, 40, 0),
+                              # (round 6: the reference's encoder layer — TT-LSTM with two and four cores, TT-GRU — header + fragments are weight-only work)
+                              (dict(kind="ttlstm", input_size=40, hidden_size=768, num_layers=1, n_cores=2, tt_rank=2), 5, 12, 1),
+                              (dict(kind="ttlstm", input_size=40, hidden_size=768, num_layers=1, n_cores=4, tt_rank=4), 4, 9, 1),
+                              (dict(kind="ttgru", input_size=40, hidden_size=768, num_layers=1, n_cores=2, tt_rank=2), 5, 12, 1),
                               (dict(kind="ttlstm", input_size=40, hidden_size=256, num_layers=2, n_cores=3, tt_rank=16), 6, 9, 0),
                               (dict(kind="ttlstm", input_size=28, hidden_size=192, num_layers=1, n_cores=2, tt_rank=6), 4, 7, 0),
                               # naive per-gate sets: the operands are torch.cat COPIES of the parameters — the
