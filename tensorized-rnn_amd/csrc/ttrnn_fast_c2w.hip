@@ -923,6 +923,7 @@ template <int R> using C2R_Hid2 = C2RM<24, 32, 48, 64, R, 768>;
 template <int R> using C2R_In4 = C2RM<4, 10, 48, 64, R, 40>;
 template <int R> using C2R_Hid4 = C2RM<16, 48, 48, 64, R, 768>;
 template <int R> using C2R_GruHid2 = C2RM<24, 32, 48, 48, R, 768>;
+template <int R> using C2R_GruHid4 = C2RM<16, 48, 36, 64, R, 768>;      // the four-core TT-GRU's hidden matrix: (6, 6, 8, 8) contracted pairwise
 constexpr int C2R_NBR = 2;
 
 struct C2RDims { int Jh, Jt, Ih, It, R, in; };
@@ -1078,7 +1079,8 @@ bool c2r_each(F&& f) {
   return f.template operator()<C2RS<2, C2R_NBR, C2R_In2<2>, C2R_Hid2<2>>>() || f.template operator()<C2RS<1, C2R_NBR, C2R_Hid2<2>, C2R_Hid2<2>>>() ||
          f.template operator()<C2RS<2, C2R_NBR, C2R_In4<2>, C2R_Hid4<2>>>() || f.template operator()<C2RS<1, C2R_NBR, C2R_Hid4<2>, C2R_Hid4<2>>>() ||
          f.template operator()<C2RS<1, C2R_NBR, C2R_Hid4<4>, C2R_Hid4<4>>>() ||
-         f.template operator()<C2RS<1, C2R_NBR, C2R_GruHid2<2>, C2R_GruHid2<2>>>();
+         f.template operator()<C2RS<1, C2R_NBR, C2R_GruHid2<2>, C2R_GruHid2<2>>>() ||
+         f.template operator()<C2RS<1, C2R_NBR, C2R_GruHid4<2>, C2R_GruHid4<2>>>() || f.template operator()<C2RS<1, C2R_NBR, C2R_GruHid4<4>, C2R_GruHid4<4>>>();
 }
 
 struct C2RWsVisit {

@@ -43,7 +43,8 @@ namespace {
 template <int J0_, int J1_, int J0I_, int J1I_, int R_, int GATES_ = 4>
 struct W2T {
   static constexpr int GATES = GATES_;
-  static constexpr int J0 = J0_, J1 = J1_, I0 = 48, I1 = GATES_ == 4 ? 64 : 48, R = R_, H = J0_ * J1_;
+  // output modes: LSTM (48, 64); TT-GRU, two cores (48, 48); TT-GRU, four cores (6, 6, 8, 8) contracted pairwise: (36, 64)
+  static constexpr int J0 = J0_, J1 = J1_, I1 = (GATES_ == 3 && J0_ == 24) ? 48 : 64, I0 = GATES_ * 768 / I1, R = R_, H = J0_ * J1_;
   static constexpr int J0I = J0I_, J1I = J1I_, INP = J0I_ * J1I_;
   static_assert(H == 768 && INP == 40 && J1 % 16 == 0 && J1I <= 32 && J0I <= 8 && (R == 2 || R == 4) && I0 * I1 == GATES_ * H, "encoder shapes");
   static constexpr int NWV = I1 / 16;          // 4 waves, GRU: 3 (blockDim = 64 NWV)
@@ -84,6 +85,8 @@ typedef W2T<16, 48, 4, 10, 2> W2B2;
 typedef W2T<16, 48, 4, 10, 4> W2B4;
 typedef W2T<24, 32, 5, 8, 2, 3> W2GA2;      // TT-GRU, two cores, rank slots 2 / 4
 typedef W2T<24, 32, 5, 8, 4, 3> W2GA4;
+typedef W2T<16, 48, 4, 10, 2, 3> W2GB2;     // TT-GRU, four cores contracted pairwise: (16, 48) x (36, 64)
+typedef W2T<16, 48, 4, 10, 4, 3> W2GB4;
 enum { W2_EGT = 0, W2_EC1 = 1, W2_EGTI = 2, W2_ECI = 3, W2_EGH = 4 };
 
 __device__ __forceinline__ int w2_expo(float x) {           // x < 2^e; zero / non-finite: neutral; clamped
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(256) k_lstm_fwd_w2(W2Args g) {
 template <class S>
 __global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
   constexpr int R = S::R, NTH = 64 * S::NWV;
-  static_assert(S::GATES == 3 && S::GHL, "TT-GRU configuration (stage-2 fragments in LDS)");
+  static_assert(S::GATES == 3, "TT-GRU configuration");
   __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS];
   __shared__ float hmax[2][4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -492,8 +495,21 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
       gti[a][p] = fr[((size_t)(S::T_GTI + R * wave + a) * 2 + p) * 64 + lane];
       asm volatile("" : "+v"(gti[a][p]));
     }
-  for (int i = tid; i < S::GH_BYTES / 16; i += NTH)
-    reinterpret_cast<f32x4*>(smem + S::L_GH)[i] = reinterpret_cast<const f32x4*>(fr + (size_t)S::T_GH * 2 * 64)[i];
+  xh8 gh[S::GHL ? 1 : S::MT2][S::GHL ? 1 : S::KB2][2];
+  if constexpr (S::GHL) {
+    for (int i = tid; i < S::GH_BYTES / 16; i += NTH)
+      reinterpret_cast<f32x4*>(smem + S::L_GH)[i] = reinterpret_cast<const f32x4*>(fr + (size_t)S::T_GH * 2 * 64)[i];
+  } else {
+#pragma unroll
+    for (int tl = 0; tl < S::MT2; ++tl)
+#pragma unroll
+      for (int kb = 0; kb < S::KB2; ++kb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          gh[tl][kb][p] = fr[((size_t)(S::T_GH + S::KB2 * tl + kb) * 2 + p) * 64 + lane];
+          asm volatile("" : "+v"(gh[tl][kb][p]));
+        }
+  }
   const xh8* ghl = reinterpret_cast<const xh8*>(smem + S::L_GH);
   const int egt = g.hdr[W2_EGT], ec1 = g.hdr[W2_EC1], egti = g.hdr[W2_EGTI], eci = g.hdr[W2_ECI], egh = g.hdr[W2_EGH];
 
@@ -521,7 +537,9 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
     __syncthreads();
     if (lane == 0) { red[wave] = m; hmax[0][wave] = m; }
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), red[2]);
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < S::NWV; ++w) m = fmaxf(m, red[w]);
     e_img = track ? w2_expo(m) : 0;
     e_img = e_img < 0 ? 0 : e_img;
   }
@@ -578,7 +596,9 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
     const int eh0 = e_img;
     int e_wr = 0;
     if (track) {
-      const float m = fmaxf(fmaxf(hmax[par][0], hmax[par][1]), hmax[par][2]);
+      float m = hmax[par][0];
+#pragma unroll
+      for (int w = 1; w < S::NWV; ++w) m = fmaxf(m, hmax[par][w]);
       e_wr = w2_expo(m);
       e_wr = e_wr < 0 ? 0 : e_wr;
     }
@@ -628,9 +648,16 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_fwd_w2(W2Args g) {
     for (int tl = 0; tl < S::MT2; ++tl) {
       f32x4 acc = z4;
 #pragma unroll
-      for (int kb = 0; kb < S::KB2; ++kb)
-        acc = w2_mma3(ghl[((size_t)(S::KB2 * tl + kb) * 2 + 0) * 64 + lane], ghl[((size_t)(S::KB2 * tl + kb) * 2 + 1) * 64 + lane],
-                      bop[kb][0], bop[kb][1], acc);
+      for (int kb = 0; kb < S::KB2; ++kb) {
+        xh8 a0, a1;
+        if constexpr (S::GHL) {
+          a0 = ghl[((size_t)(S::KB2 * tl + kb) * 2 + 0) * 64 + lane];
+          a1 = ghl[((size_t)(S::KB2 * tl + kb) * 2 + 1) * 64 + lane];
+        } else {
+          a0 = gh[tl][kb][0]; a1 = gh[tl][kb][1];
+        }
+        acc = w2_mma3(a0, a1, bop[kb][0], bop[kb][1], acc);
+      }
       const f32x4 z = acc * zsv + bz[tl];
       const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[0])), zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[1]));
       const float hn = z[2];                                     // W_hn h + b_hn
@@ -713,9 +740,10 @@ __global__ void __launch_bounds__(256) k_w2b_prep(TtShape sh, const float* __res
       const int a = nt / S::MT0, j0 = 16 * (nt % S::MT0) + n;
       // k element j of k-group g: kb 0: row tile tl = j >> 2 (0, 1), gate = j & 3; kb 1: tl = 2, gate = j (j < 4), zero beyond
       // (TT-GRU: four row tiles x four slots fill both k-blocks; slot 3 — the input part of n — is no row of the hidden chain: zero)
-      const int tl = S::GATES == 3 ? 2 * kb + (j >> 2) : (kb == 0 ? (j >> 2) : 2);
-      const int gate = S::GATES == 3 ? (j & 3) : (kb == 0 ? (j & 3) : j);
-      const bool live = S::GATES == 3 ? gate < 3 : (kb == 0 || j < 4);
+      // (three row tiles: the LSTM's packing — k-block 1 = row tile 2 in its first four slots; four row tiles: both k-blocks full)
+      const int tl = S::MT2 == 4 ? 2 * kb + (j >> 2) : (kb == 0 ? (j >> 2) : 2);
+      const int gate = S::MT2 == 4 ? (j & 3) : (kb == 0 ? (j & 3) : j);
+      const bool live = (S::MT2 == 4 || kb == 0 || j < 4) && (S::GATES == 4 || gate < 3);
       float v = 0.f;
       if (a < rh && j0 < S::J0 && live) v = w2_gh(sh, pk_hid, gate * S::NR + 4 * tl + g, j0, a) * ldexpf(1.f, 14 - egh);
       _Float16 p0, p1;
@@ -946,7 +974,7 @@ __global__ void __launch_bounds__(256) k_lstm_bwd_w2(W2BArgs g) {
 template <class S>
 __global__ void __launch_bounds__(64 * S::NWV) k_gru_bwd_w2(W2BArgs g) {
   constexpr int R = S::R, NTH = 64 * S::NWV;
-  static_assert(S::GATES == 3 && S::MT2 == 4 && S::NWV == 3, "TT-GRU configuration");
+  static_assert(S::GATES == 3 && (S::MT2 == 4 || S::MT2 == 3), "TT-GRU configuration");
   extern __shared__ __attribute__((aligned(16))) unsigned char w2b_smem[];
   unsigned char* smem = w2b_smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1027,7 +1055,10 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_bwd_w2(W2BArgs g) {
     float dz[S::MT2][4];
 #pragma unroll
     for (int tl = 0; tl < S::MT2; ++tl) {
-      const float dht = dhd[tl] + D0[tl] + ((pr[unit[tl]] + pr[S::PART + unit[tl]]) + pr[2 * S::PART + unit[tl]]);
+      float psum = pr[unit[tl]];
+#pragma unroll
+      for (int w = 1; w < S::NWV; ++w) psum += pr[w * S::PART + unit[tl]];
+      const float dht = dhd[tl] + D0[tl] + psum;
       const float rg = G0[tl][0], zg = G0[tl][1], ng = G0[tl][2], hn = G0[tl][3];
       const float dn_pre = dht * (1.f - zg) * (1.f - ng * ng);
       const float dz_pre = dht * (P0[tl] - ng) * zg * (1.f - zg);
@@ -1057,7 +1088,10 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_bwd_w2(W2BArgs g) {
     const float sd = ldexpf(1.f, 13 - ed);
     float v0[8], v1[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v0[k] = dz[0][k] * sd; v0[4 + k] = dz[1][k] * sd; v1[k] = dz[2][k] * sd; v1[4 + k] = dz[3][k] * sd; }
+    for (int k = 0; k < 4; ++k) {
+      v0[k] = dz[0][k] * sd; v0[4 + k] = dz[1][k] * sd; v1[k] = dz[2][k] * sd;
+      v1[4 + k] = S::MT2 == 4 ? dz[S::MT2 - 1][k] * sd : 0.f;
+    }
     xh8 a0[2], a1[2];
     w2_split8(v0, a0[0], a0[1]);
     w2_split8(v1, a1[0], a1[1]);
@@ -1103,7 +1137,10 @@ __global__ void __launch_bounds__(64 * S::NWV) k_gru_bwd_w2(W2BArgs g) {
     for (int tl = 0; tl < S::MT2; ++tl) {
       if (g.d_h0) {
         float v = dhd[tl];
-        if (T > 0) v += (pr[unit[tl]] + pr[S::PART + unit[tl]]) + pr[2 * S::PART + unit[tl]];
+        if (T > 0) {
+#pragma unroll
+          for (int w = 0; w < S::NWV; ++w) v += pr[w * S::PART + unit[tl]];
+        }
         g.d_h0[(size_t)b * S::H + unit[tl]] = v;
       }
       if (g.colmax) {
@@ -1174,12 +1211,21 @@ int w2_config(const TtShape& hid, const TtShape& in) {
 }
 
 // the TT-GRU of the encoder's layer: 0 = none; 1, 2 = two cores with 2 / 4 rank slots
+// ... 3, 4 = four cores contracted pairwise (tt_shape (4, 4, 6, 8) x (6, 6, 8, 8), input (2, 2, 2, 5)): (16, 48) x (36, 64)
 int w2_config_gru(const TtShape& hid, const TtShape& in) {
-  if (!(hid.d == 2 && in.d == 2 && hid.J[0] == 24 && hid.J[1] == 32 && hid.I[0] == 48 && hid.I[1] == 48 && in.J[0] == 5 && in.J[1] == 8 &&
-        in.I[0] == 48 && in.I[1] == 48))
+  int cfg = 0;
+  if (hid.d == 2 && in.d == 2 && hid.J[0] == 24 && hid.J[1] == 32 && hid.I[0] == 48 && hid.I[1] == 48 && in.J[0] == 5 && in.J[1] == 8 &&
+      in.I[0] == 48 && in.I[1] == 48)
+    cfg = 1;
+  else if (hid.d == 4 && in.d == 4 && hid.J[0] * hid.J[1] == 16 && hid.J[2] * hid.J[3] == 48 && hid.I[0] * hid.I[1] == 36 &&
+           hid.I[2] * hid.I[3] == 64 && in.J[0] * in.J[1] == 4 && in.J[2] * in.J[3] == 10 && in.I[0] * in.I[1] == 36 && in.I[2] * in.I[3] == 64 &&
+           in.I[1] == hid.I[1] && in.I[3] == hid.I[3])
+    cfg = 3;
+  else
     return 0;
-  const int r = hid.R[1] > in.R[1] ? hid.R[1] : in.R[1];
-  return r <= 2 ? 1 : (r <= 4 ? 2 : 0);
+  for (int k = 0; k <= hid.d; ++k) if (hid.R[k] > 16 || in.R[k] > 16) return 0;
+  const int r = hid.R[hid.d / 2] > in.R[in.d / 2] ? hid.R[hid.d / 2] : in.R[in.d / 2];
+  return r <= 2 ? cfg : (r <= 4 ? cfg + 1 : 0);
 }
 
 template <class S>
@@ -1188,8 +1234,21 @@ static int launch_fwd_w2g_t(const RnnShape& rs, const void* x, const void* h0, c
                             hipStream_t stream, int phase) {
   int* hdr = (int*)ws;
   _Float16* frag = (_Float16*)((char*)ws + S::HDR_BYTES);
-  if (phase != TTRNN_PHASE_RUN)
-    hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+  if (phase != TTRNN_PHASE_RUN) {
+    if (rs.hid_s.d == 4) {
+      W2Merge m{};
+      m.s4[0] = rs.hid_s; m.s4[1] = rs.in_s;
+      if (!w2_shape2(rs.hid_s, &m.s2[0]) || !w2_shape2(rs.in_s, &m.s2[1])) return TTRNN_ERR_UNSUPPORTED;
+      m.pk4[0] = packed_hid; m.pk4[1] = packed_in;
+      m.n[0] = m.s2[0].wtotal; m.n[1] = m.s2[1].wtotal;
+      m.pk2[0] = (float*)((char*)ws + S::WS_BYTES); m.pk2[1] = m.pk2[0] + ((m.n[0] + 15) & ~15);
+      if ((size_t)(((m.n[0] + 15) & ~15) + m.n[1]) * 4 > W2_MERGE_BYTES) return TTRNN_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(k_w2_merge, dim3((m.n[0] + m.n[1] + 255) / 256), dim3(256), 0, stream, m, 2);
+      hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, m.s2[0], m.s2[1], (const float*)m.pk2[0], (const float*)m.pk2[1], hdr, frag);
+    } else {
+      hipLaunchKernelGGL(k_w2_prep<S>, dim3(S::NTILES), dim3(256), 0, stream, rs.hid_s, rs.in_s, packed_hid, packed_in, hdr, frag);
+    }
+  }
   if (phase == TTRNN_PHASE_PREPARE) return hipGetLastError() == hipSuccess ? TTRNN_OK : TTRNN_ERR_LAUNCH;
   W2Args a{};
   a.x = (const float*)x; a.h0 = (const float*)h0; a.c0 = nullptr;
@@ -1275,7 +1334,18 @@ static int launch_bwd_w2g_t(const RnnShape& rs, const void* out, const void* h0,
   _Float16* ghf = (_Float16*)((char*)ws + S::HDR_BYTES);
   _Float16* gtf = (_Float16*)((char*)ws + S::HDR_BYTES + S::BGH_BYTES);
   if (stats && hipMemsetAsync(stats, 0, (size_t)2 * 3 * rs.H * sizeof(float), stream) != hipSuccess) return TTRNN_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  if (rs.hid_s.d == 4) {
+    W2Merge m{};
+    m.s4[0] = rs.hid_s;
+    if (!w2_shape2(rs.hid_s, &m.s2[0])) return TTRNN_ERR_UNSUPPORTED;
+    m.pk4[0] = packed_hid; m.n[0] = m.s2[0].wtotal;
+    m.pk2[0] = (float*)((char*)ws + S::BWS_BYTES);
+    if ((size_t)m.n[0] * 4 > W2_MERGE_BYTES) return TTRNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_w2_merge, dim3((m.n[0] + 255) / 256), dim3(256), 0, stream, m, 1);
+    hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, m.s2[0], (const float*)m.pk2[0], hdr, ghf, gtf);
+  } else {
+    hipLaunchKernelGGL(k_w2b_prep<S>, dim3(S::NT2 * 2 + S::NWV * S::R * S::M1T), dim3(256), 0, stream, rs.hid_s, packed_hid, hdr, ghf, gtf);
+  }
   W2BArgs a{};
   a.reserve = reserve; a.out = (const float*)out; a.h0 = (const float*)h0;
   a.d_out = (const float*)d_out; a.d_hT = (const float*)d_hT;
@@ -1295,13 +1365,13 @@ bool w2_rnn_fwd_available(const RnnShape& rs, int dtype) {
   if (dtype != TTRNN_F32 || rs.hid_blocks > 1 || rs.H != 768 || rs.in != 40 || opt(OPT_FP32_MATH) != TTRNN_MATH_SPLIT ||
       opt(OPT_FORCE_GENERIC) || opt(OPT_FORCE_G2) || (opt(OPT_DEV2) & 16))
     return false;
-  if (rs.cell == TTRNN_GRU) return w2_config_gru(rs.hid_s, rs.in_s) > 0;      // (round 6: forward only; the tier's reverse kernel reads its records)
+  if (rs.cell == TTRNN_GRU) return w2_config_gru(rs.hid_s, rs.in_s) > 0;
   return rs.cell == TTRNN_LSTM && w2_config(rs.hid_s, rs.in_s) > 0;
 }
 static constexpr size_t w2_max4(size_t a, size_t b, size_t c, size_t d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
 size_t w2_rnn_fwd_workspace_bytes() {      // (the query has no shape; the four-core configurations keep their contracted cores behind the fragments)
   const size_t a = w2_max4(W2A2::WS_BYTES, W2A4::WS_BYTES, W2B2::WS_BYTES + W2_MERGE_BYTES, W2B4::WS_BYTES + W2_MERGE_BYTES);
-  const size_t g = W2GA2::WS_BYTES > W2GA4::WS_BYTES ? W2GA2::WS_BYTES : W2GA4::WS_BYTES;
+  const size_t g = w2_max4(W2GA2::WS_BYTES, W2GA4::WS_BYTES, W2GB2::WS_BYTES + W2_MERGE_BYTES, W2GB4::WS_BYTES + W2_MERGE_BYTES);
   return a > g ? a : g;
 }
 
@@ -1312,6 +1382,8 @@ int launch_rnn_fwd_w2(const RnnShape& rs, const void* x, const void* h0, const v
     switch (w2_config_gru(rs.hid_s, rs.in_s)) {
       case 1: return launch_fwd_w2g_t<W2GA2>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
       case 2: return launch_fwd_w2g_t<W2GA4>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
+      case 3: return launch_fwd_w2g_t<W2GB2>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
+      case 4: return launch_fwd_w2g_t<W2GB4>(rs, x, h0, packed_in, bias_in, packed_hid, bias_hid, out, hT, reserve, ws, stream, phase);
     }
     return TTRNN_ERR_UNSUPPORTED;
   }
@@ -1334,7 +1406,7 @@ bool w2_rnn_bwd_available(const RnnShape& rs, int dtype) {
 }
 size_t w2_rnn_bwd_workspace_bytes() {
   const size_t a = w2_max4(W2A2::BWS_BYTES, W2A4::BWS_BYTES, W2B2::BWS_BYTES + W2_MERGE_BYTES, W2B4::BWS_BYTES + W2_MERGE_BYTES);
-  const size_t g = W2GA2::BWS_BYTES > W2GA4::BWS_BYTES ? W2GA2::BWS_BYTES : W2GA4::BWS_BYTES;
+  const size_t g = w2_max4(W2GA2::BWS_BYTES, W2GA4::BWS_BYTES, W2GB2::BWS_BYTES + W2_MERGE_BYTES, W2GB4::BWS_BYTES + W2_MERGE_BYTES);
   return a > g ? a : g;
 }
 
@@ -1345,6 +1417,8 @@ int launch_rnn_bwd_w2(const RnnShape& rs, const void* out, const void* h0, const
     switch (w2_config_gru(rs.hid_s, rs.in_s)) {
       case 1: return launch_bwd_w2g_t<W2GA2>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
       case 2: return launch_bwd_w2g_t<W2GA4>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
+      case 3: return launch_bwd_w2g_t<W2GB2>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
+      case 4: return launch_bwd_w2g_t<W2GB4>(rs, out, h0, packed_hid, reserve, d_out, d_hT, dg_in, dg_hid, d_h0, ws, stream, stats);
     }
     return TTRNN_ERR_UNSUPPORTED;
   }

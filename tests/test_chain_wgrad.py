@@ -57,6 +57,11 @@ CASES = {
                               H=768, B=3, T=5, h0=True, mats=2),
     "spk_d4r3": dict(cell="lstm", inp=([2, 2, 2, 5], [6, 8, 8, 8], [1, 3, 3, 3, 1]), hid=([4, 4, 6, 8], [6, 8, 8, 8], [1, 3, 3, 3, 1]),
                      H=768, B=3, T=5, h0=True, mats=3),       # (no compile-time plan: the large variant with its plan at run time)
+    # the four-core TT-GRU's hidden matrix ((6, 6, 8, 8) contracted pairwise: I_h = 36)
+    "spk_gru_d4r2": dict(cell="gru", inp=([2, 2, 2, 5], [6, 6, 8, 8], [1, 2, 2, 2, 1]), hid=([4, 4, 6, 8], [6, 6, 8, 8], [1, 2, 2, 2, 1]),
+                         H=768, B=3, T=7, h0=True, mats=2),
+    "spk_gru_d4r4": dict(cell="gru", inp=([2, 2, 2, 5], [6, 6, 8, 8], [1, 4, 4, 4, 1]), hid=([4, 4, 6, 8], [6, 6, 8, 8], [1, 4, 4, 4, 1]),
+                         H=768, B=4, T=5, h0=False, mats=2),
     # edge cases of the row walk: one step per sample (every row is a head row), a single row
     "spk_T1": dict(cell="lstm", inp=([5, 8], [48, 64], [1, 2, 1]), hid=([24, 32], [48, 64], [1, 2, 1]), H=768, B=7, T=1, h0=True, mats=3),
     "spk_one_row": dict(cell="lstm", inp=([5, 8], [48, 64], [1, 2, 1]), hid=([24, 32], [48, 64], [1, 2, 1]), H=768, B=1, T=1, h0=True, mats=2),

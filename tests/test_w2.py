@@ -45,6 +45,10 @@ def test_routes():
     assert _routes(build_module(dict(META, kind="ttgru", tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
     with ttrnn_hip.option("dev2", 16 | 32):
         assert _routes(mg, 8, 12) == ("runtime_mfma", "runtime_mfma")
+    # ... and its four-core variants ((6, 6, 8, 8) contracted pairwise: (36, 64))
+    for r in (2, 3, 4):
+        assert _routes(build_module(dict(META, kind="ttgru", n_cores=4, tt_rank=r), dev()), 8, 12) == ("fused_core", "fused_core"), r
+    assert _routes(build_module(dict(META, kind="ttgru", n_cores=4, tt_rank=8), dev()), 8, 12) == ("runtime_mfma", "runtime_mfma")
 
 
 CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "mixed_magnitudes", "x_ranges", "no_bias", "rank4", "rank3", "rank1",
@@ -216,7 +220,8 @@ def test_reverse_kernel_gradient_ranges(scale):
         assert _maxabs(p.grad, r) <= 3e-6 * float(r.abs().max()), (scale, n)
 
 
-GRU_CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "x_ranges", "no_bias", "rank4", "rank3", "rank1"]
+GRU_CASES = ["fresh", "tiny_weights", "huge_weights", "huge_h0", "zero_core", "x_ranges", "no_bias", "rank4", "rank3", "rank1",
+             "d4rank2", "d4rank4", "d4rank3_x_ranges", "d4rank2_huge_h0"]
 
 
 @pytest.mark.parametrize("case", GRU_CASES)
@@ -231,8 +236,11 @@ def test_gru_forward_operand_ranges(case):
     meta = dict(base, bias=False) if case == "no_bias" else base
     if case.startswith("rank"):
         meta = dict(base, tt_rank=int(case[4:]))
+    if case.startswith("d4rank"):
+        meta = dict(base, n_cores=4, tt_rank=int(case[6]))
+        case = case[8:] or "d4"
     m = build_module(meta, dev())
-    T = 160 if case in ("fresh", "rank4") else 9
+    T = 160 if case in ("fresh", "rank4", "d4") else 9
     B = 5
     g = torch.Generator().manual_seed(41)
     x = torch.rand(B, T, 40, generator=g) if case == "fresh" else torch.randn(B, T, 40, generator=g)
@@ -288,10 +296,11 @@ def test_gru_forward_operand_ranges(case):
         assert err <= 3.0 * err_tier + 3e-7 * max(1.0, scale)
 
 
-@pytest.mark.parametrize("B,T,h0_scale,dout,rank", [(4, 12, 0.3, "plain", 2), (3, 1, 0.3, "plain", 2), (2, 33, 50.0, "plain", 2), (5, 8, None, "plain", 2),
-                                                     (4, 20, 0.3, "decades", 2), (4, 24, 0.3, "last_step_only", 2), (5, 9, 0.3, "sparse", 2),
-                                                     (3, 10, 0.3, "plain", 4), (3, 7, None, "decades", 3), (300, 3, 0.3, "plain", 2)])
-def test_gru_training_step(B, T, h0_scale, dout, rank):
+@pytest.mark.parametrize("B,T,h0_scale,dout,rank,d", [(4, 12, 0.3, "plain", 2, 2), (3, 1, 0.3, "plain", 2, 2), (2, 33, 50.0, "plain", 2, 2), (5, 8, None, "plain", 2, 2),
+                                                       (4, 20, 0.3, "decades", 2, 2), (4, 24, 0.3, "last_step_only", 2, 2), (5, 9, 0.3, "sparse", 2, 2),
+                                                       (3, 10, 0.3, "plain", 4, 2), (3, 7, None, "decades", 3, 2), (300, 3, 0.3, "plain", 2, 2),
+                                                       (4, 12, 0.3, "plain", 2, 4), (3, 9, 0.3, "decades", 4, 4), (5, 9, 0.3, "sparse", 3, 4), (2, 20, 50.0, "plain", 2, 4)])
+def test_gru_training_step(B, T, h0_scale, dout, rank, d):
     """k_gru_fwd_w2 + k_gru_bwd_w2 (wave-local transposed stages, three gates' hidden-chain gradients in the forward's four slots, the
     direct path dh z in registers): every gradient of a training step against the float64 oracle's autograd, and against the step
     that runs on the tier in both directions (dev2 bits 4, 5); output gradients over ten decades, a loss on the last step only,
@@ -299,7 +308,7 @@ def test_gru_training_step(B, T, h0_scale, dout, rank):
     import ttrnn_hip
     from oracle import ttrnn_oracle as O
     torch.manual_seed(43)
-    m = build_module(dict(META, kind="ttgru", tt_rank=rank), dev())
+    m = build_module(dict(META, kind="ttgru", tt_rank=rank, n_cores=d), dev())
     x = torch.randn(B, T, 40)
     h0 = None if h0_scale is None else torch.randn(B, 768) * h0_scale
     w = torch.randn(B, T, 768)
@@ -347,7 +356,7 @@ def test_gru_training_step(B, T, h0_scale, dout, rank):
         assert torch.isfinite(got[n]).all(), n
         worst = max(worst, _maxabs(got[n].double(), ref) / sc)
         worst_t = max(worst_t, _maxabs(old[n].double(), ref) / sc)
-    print("TT-GRU training step", B, T, h0_scale, dout, rank, "max gradient error relative to each tensor's maximum: %.3g (tier: %.3g)" % (worst, worst_t))
+    print("TT-GRU training step", B, T, h0_scale, dout, rank, d, "max gradient error relative to each tensor's maximum: %.3g (tier: %.3g)" % (worst, worst_t))
     tol = 2e-3 if (h0_scale or 0) > 1 else 1e-4
     assert worst <= tol and worst <= 3.0 * worst_t + 1e-5
     if dout == "sparse" and h0 is not None:

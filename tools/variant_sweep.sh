@@ -20,5 +20,6 @@ run $mode --in_size 40 --hidden_size 768 --ncores 2 --ttrank 4
 run $mode --in_size 40 --hidden_size 768 --ncores 4 --ttrank 4
 run $mode --in_size 40 --hidden_size 768 --ncores 4 --ttrank 2
 run $mode --in_size 40 --hidden_size 768 --ncores 2 --ttrank 2 --gru
+run $mode --in_size 40 --hidden_size 768 --ncores 4 --ttrank 2 --gru
 run $mode --n_layers 2 --hidden_size 384
 done
