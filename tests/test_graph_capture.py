@@ -27,6 +27,13 @@ CASES = {
     "runtime_tier_small": (dict(input_size=40, output_size=256, hidden_size=64, num_layers=1, n_cores=2, tt_rank=4), 64, 64),
     "runtime_tier_naive": (dict(input_size=28, output_size=10, hidden_size=128, num_layers=1, n_cores=3, tt_rank=4, naive_tt=True), 16, 20),
     "stagewise_d2": (dict(input_size=1, output_size=10, hidden_size=128, num_layers=1, n_cores=2, tt_rank=4), 32, 50),
+    # round 6: the reference's encoder layer (recurrent kernels with the input projection inside + the chain weight gradient), its
+    # TT-GRU variant, the four-core layer, the naive sets' and the rank-16 TT-GRU's reverse-time kernels
+    "encoder_lstm": (dict(input_size=40, output_size=256, hidden_size=768, num_layers=1, n_cores=2, tt_rank=2), 24, 20),
+    "encoder_gru": (dict(input_size=40, output_size=256, hidden_size=768, num_layers=1, n_cores=2, tt_rank=2, gru=True), 24, 20),
+    "encoder_lstm_d4": (dict(input_size=40, output_size=256, hidden_size=768, num_layers=1, n_cores=4, tt_rank=4), 16, 12),
+    "naive_h256": (dict(input_size=1, output_size=10, hidden_size=256, num_layers=1, n_cores=3, tt_rank=8, naive_tt=True), 16, 30),
+    "gru_r16": (dict(input_size=24, output_size=10, hidden_size=256, num_layers=1, n_cores=3, tt_rank=16, gru=True), 16, 20),
 }
 
 
