@@ -118,7 +118,7 @@ struct C2RArgs {
   float* bpart;              // [grid][OUT] or NULL
   long n_rows;
   unsigned long long* diag;  // -DTTRNN_ABLATIONS builds only: [2 waves][8] cycle sums per segment of the block loop (workgroup 0, waves 0 and 5)
-  int abl;                   // -DTTRNN_ABLATIONS builds only (tools/c2w_bench.py): option dev2 >> 8 — 1: no chain 1, 2: no chain 2, 4: no staging
+  int abl;                   // -DTTRNN_ABLATIONS builds only (tools/c2w_bench.py): option dev2 >> 16 — 1: no chain 1, 2: no chain 2, 4: no staging
                              // stores, 8: no global loads, 16: no barrier (result-destroying; 0 in libttrnn.so)
 };
 

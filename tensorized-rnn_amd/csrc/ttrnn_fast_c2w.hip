@@ -202,7 +202,7 @@ struct C2Args {
   float* bpart;              // [grid][OUT] or NULL
   long n_rows;
   unsigned long long* diag;  // -DTTRNN_ABLATIONS builds only: [2 waves][8] cycle sums per segment of the block loop (workgroup 0, waves 0 and 5)
-  int abl;                   // -DTTRNN_ABLATIONS builds only (tools/c2w_bench.py): option dev2 >> 8 — 1: no phases A / B, 2: no phases C / D,
+  int abl;                   // -DTTRNN_ABLATIONS builds only (tools/c2w_bench.py): option dev2 >> 16 — 1: no phases A / B, 2: no phases C / D,
                              // 4: no staging stores, 8: no global loads (result-destroying; 0 in libttrnn.so)
 };
 
@@ -1022,7 +1022,7 @@ int c2r_launch(const TtShape* const* shapes, int64_t n_rows, const float* const*
   C2RRed ra{};
   ka.dy = dy; ka.n_rows = (long)n_rows;
 #ifdef TTRNN_ABLATIONS
-  ka.abl = opt(OPT_DEV2) >> 8;
+  ka.abl = opt(OPT_DEV2) >> 16;
   ka.diag = (unsigned long long*)(ws + w.cmax + 64);
 #endif
   ka.part = (float*)(ws + w.part);
@@ -1180,7 +1180,7 @@ int launch_c2w(const TtShape* const* shapes, int nmat, int64_t n_rows, const flo
   C2RedArgs ra{};
   ka.pl = pl; ka.dy = dy; ka.n_rows = (long)n_rows;
 #ifdef TTRNN_ABLATIONS
-  ka.abl = opt(OPT_DEV2) >> 8;
+  ka.abl = opt(OPT_DEV2) >> 16;
   ka.diag = (unsigned long long*)(ws + pl.w_cmax + 64);
 #endif
   ka.bpart = (d_bias0 || d_bias1) ? (float*)(ws + pl.w_bpart) : nullptr;

@@ -48,7 +48,7 @@ enum OptId {
                          //                         128: TT-GRU H = 256 r = 16 reverse recurrence on the tier's kernel, 256: the same for the TT-GRU of H = 512 r = 8,
                          //                         512: naive per-gate sets of H = 256 on the tier's reverse-time kernel (instead of k_rnn_bwd_f10n),
                          //                         1024: the four-barrier fused-core LSTM reverse kernel instead of its wave-local form (k_lstm_bwd_f10h<.., WL>),
-                         //                         (-DTTRNN_ABLATIONS builds only, tools/c2w_bench.py: bits 8 and up are the chain kernels' ablation switches instead)
+                         //                         (-DTTRNN_ABLATIONS builds only, tools/c2w_bench.py: bits 16 and up are the chain kernels' ablation switches)
   OPT_COUNT
 };
 

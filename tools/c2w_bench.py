@@ -1,6 +1,6 @@
 """Times ttrnn_rnn_wgrad (the chain weight-gradient kernel, ttrnn_fast_c2w.hip) alone at the speaker-encoder size — B = 512,
 T = 160, in = 40, H = 768, d = 2 (params_model.py) — on random operands:  python tools/c2w_bench.py [rank] [mats] [reps]
-With TTRNN_LIB_PATH=tools/bin/libttrnn_abl.so and TTRNN_DEV2=<256 * bits> the ablation build leaves out phases (bits: 1 A/B,
+With TTRNN_LIB_PATH=tools/bin/libttrnn_abl.so and TTRNN_DEV2=<65536 * bits> the ablation build leaves out phases (bits: 1 A/B,
 2 C/D, 4 staging stores, 8 global loads)."""
 import ctypes
 import os

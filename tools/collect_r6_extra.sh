@@ -24,9 +24,9 @@ bash tools/variant_sweep.sh > $O/variants_benchmarking.txt 2>&1
   TTRNN_DEV2=68 python tools/c2w_bench.py 2 3 20 ) 2>&1 | grep "per call" > $O/c2w_bench.txt
 if [ -f tools/bin/libttrnn_abl.so ]; then
   ( export TTRNN_LIB_PATH=$PWD/tools/bin/libttrnn_abl.so
-    for m in 3 2; do for bits in 0 1 2 3 4 8 16; do TTRNN_DEV2=$((256*bits)) python tools/c2w_bench.py 2 $m 10 2>&1 | grep "per call\|cycles per block"; done; done ) > $O/stamps_c2r.txt 2>&1
+    for m in 3 2; do for bits in 0 1 2 3 4 8 16; do TTRNN_DEV2=$((65536*bits)) python tools/c2w_bench.py 2 $m 10 2>&1 | grep "per call\|cycles per block"; done; done ) > $O/stamps_c2r.txt 2>&1
   ( export TTRNN_LIB_PATH=$PWD/tools/bin/libttrnn_abl.so
-    for m in 3 2; do for bits in 0 1 2 3 4 8; do TTRNN_DEV2=$((256*bits+64)) python tools/c2w_bench.py 2 $m 10 2>&1 | grep "per call\|cycles per block"; done; done ) > $O/stamps_c2w.txt 2>&1
+    for m in 3 2; do for bits in 0 1 2 3 4 8; do TTRNN_DEV2=$((65536*bits+64)) python tools/c2w_bench.py 2 $m 10 2>&1 | grep "per call\|cycles per block"; done; done ) > $O/stamps_c2w.txt 2>&1
 fi
 python tools/stress_backward.py --grid --reps 8 > $O/stress_backward_grid.txt 2>&1
 python tools/stress_backward.py --reps 40 > $O/stress_backward.txt 2>&1
